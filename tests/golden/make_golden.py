@@ -1,0 +1,351 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference, which never travels to
+the GPU box).  The reference needs `gym`, `toolz` and `cv2`, none of which is
+installed, so minimal stand-ins (spaces + wrapper base classes; merge_with;
+empty cv2) are written to a temp dir first -- these stubs are this repo's own
+code and only exist to let the reference modules import.  What is stored in
+the fixtures is DATA ONLY: seeded inputs and the reference's outputs.
+
+    python tests/golden/make_golden.py            # (re)writes the .npz files
+
+Each fixture records torch / numpy versions in ``meta``.
+"""
+import json
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+STUBS = {
+    "gym/__init__.py": """
+        from . import spaces
+        class Env: pass
+        class Wrapper(Env):
+            def __init__(self, env):
+                self.env = env
+                self.action_space = getattr(env, 'action_space', None)
+                self.observation_space = getattr(env, 'observation_space', None)
+            def step(self, a): return self.env.step(a)
+            def reset(self, **kw): return self.env.reset(**kw)
+            def seed(self, s=None): return self.env.seed(s)
+            def close(self): return self.env.close()
+        class ObservationWrapper(Wrapper):
+            def reset(self, **kw): return self.observation(self.env.reset(**kw))
+            def step(self, a):
+                o, r, d, i = self.env.step(a); return self.observation(o), r, d, i
+        class RewardWrapper(Wrapper):
+            def step(self, a):
+                o, r, d, i = self.env.step(a); return o, self.reward(r), d, i
+        class ActionWrapper(Wrapper):
+            def step(self, a): return self.env.step(self.action(a))
+        def make(*a, **k): raise RuntimeError('no gym here')
+    """,
+    "gym/spaces.py": """
+        import numpy as np
+        class Box:
+            def __init__(self, low, high, shape=None, dtype=np.float32):
+                if shape is None: shape = np.shape(low)
+                self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shape)
+                self.high = np.broadcast_to(np.asarray(high, dtype=dtype), shape)
+                self.shape = tuple(shape)
+        class Discrete:
+            def __init__(self, n): self.n = n; self.shape = ()
+    """,
+    "toolz/__init__.py": "",
+    "toolz/dicttoolz.py": """
+        def merge_with(func, *dicts):
+            out = {}
+            for d in dicts:
+                for k, v in d.items(): out.setdefault(k, []).append(v)
+            return {k: func(v) for k, v in out.items()}
+    """,
+    "cv2.py": "",
+}
+
+
+def install_stubs():
+    root = tempfile.mkdtemp(prefix="trl_stubs_")
+    for rel, src in STUBS.items():
+        path = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(textwrap.dedent(src))
+    sys.path.insert(0, root)
+    sys.path.insert(0, REF)          # reference `torchrl` wins over the repo alias
+    sys.path.append(REPO)            # for `oracle` (env used as a duck-typed VecEnv)
+    np.bool = bool                   # collector/base.py:242 (numpy >= 1.24)
+
+
+META = json.dumps({"torch": torch.__version__, "numpy": np.__version__,
+                   "reference": "RchalYang/torchrl @ /root/reference"})
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, meta=np.array(META), **arrays)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+class NullLogger:
+    def __init__(self): self.infos = []
+    def add_update_info(self, d): self.infos.append(dict(d))
+    def add_epoch_info(self, *a, **k): pass
+    def log(self, *a): pass
+    def finish(self): pass
+
+
+def state_arrays(prefix, module):
+    return {prefix + k.replace(".", "__"): v.detach().cpu().numpy().copy()
+            for k, v in module.state_dict().items()}
+
+
+# ------------------------------------------------------------------ cases
+def case_gae():
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    out = {}
+
+    def run(tag, T, N, seed, p_term, p_tl, gamma, tau, stride=1):
+        rs = np.random.RandomState(seed)
+        r = rs.randn(T, N, 1).astype(np.float32)
+        v = rs.randn(T, N, 1).astype(np.float32)
+        d = (rs.rand(T, N, 1) < p_term)
+        tl = (rs.rand(T, N, 1) < p_tl) & d
+        lv = rs.randn(N, 1).astype(np.float32)
+        out[tag + "_args"] = np.array([T, N, seed, p_term, p_tl, gamma, tau, stride], dtype=np.float64)
+        if stride == 1:
+            out.update({tag + "_rewards": r, tag + "_values": v, tag + "_terminals": d,
+                        tag + "_time_limits": tl, tag + "_last_value": lv})
+        for filt in (0, 1):
+            buf = OnPolicyReplayBuffer(T * N, env_nums=N, time_limit_filter=bool(filt))
+            buf._rewards, buf._values = r.astype(np.float64), v.astype(np.float64)
+            buf._terminals, buf._time_limits = d.astype(np.float64), tl.astype(np.float64)
+            buf.generalized_advantage_estimation(lv.astype(np.float64), gamma, tau)
+            out[f"{tag}_gae{filt}_advs"] = buf._advs[:, ::stride]
+            out[f"{tag}_gae{filt}_rets"] = buf._estimate_returns[:, ::stride]
+            buf.discount_reward(lv.astype(np.float64), gamma)
+            out[f"{tag}_disc{filt}_advs"] = buf._advs[:, ::stride]
+            out[f"{tag}_disc{filt}_rets"] = buf._estimate_returns[:, ::stride]
+
+    # hand-checkable KAT of SURVEY.md section 8(a)
+    buf = OnPolicyReplayBuffer(8, env_nums=2, time_limit_filter=True)
+    buf._rewards = np.array([[1, .5], [0, 1], [2, -1], [1, 1]], dtype=np.float64)[..., None]
+    buf._values = np.array([[.5, .2], [.4, .1], [.3, 0], [.2, -.1]], dtype=np.float64)[..., None]
+    buf._terminals = np.array([[0, 0], [0, 1], [0, 0], [0, 0]], dtype=np.float64)[..., None]
+    buf._time_limits = np.array([[0, 0], [0, 0], [1, 0], [0, 0]], dtype=np.float64)[..., None]
+    lv = np.array([[.1], [.3]])
+    for k in ("rewards", "values", "terminals", "time_limits"):
+        out["kat_" + k] = getattr(buf, "_" + k)
+    out["kat_last_value"] = lv
+    for filt in (1, 0):
+        buf.time_limit_filter = bool(filt)
+        buf.generalized_advantage_estimation(lv, 0.99, 0.95)
+        out[f"kat_gae{filt}_advs"], out[f"kat_gae{filt}_rets"] = buf._advs, buf._estimate_returns
+        buf.discount_reward(lv, 0.99)
+        out[f"kat_disc{filt}_advs"], out[f"kat_disc{filt}_rets"] = buf._advs, buf._estimate_returns
+
+    run("small", 16, 8, 11, 0.1, 0.5, 0.99, 0.95)
+    run("ragged", 37, 5, 12, 0.2, 0.7, 0.9, 0.8)
+    run("one", 1, 3, 13, 0.5, 0.5, 0.99, 0.95)
+    run("cfg2", 128, 2048, 14, 0.01, 0.5, 0.99, 0.95, stride=16)   # inputs regenerated from seed
+    save("gae", **out)
+
+
+def case_index_streams():
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    out = {}
+    np.random.seed(0)
+    out["perm8_seed0"] = np.random.permutation(8)
+    np.random.seed(0)
+    out["randint100x4_seed0"] = np.random.randint(0, 100, 4)
+    # one_iteration: E passes over T rows (ppo.py:34-37) -> index stream + gathered data
+    T, N, B, E = 12, 4, 16, 3
+    rs = np.random.RandomState(5)
+    buf = OnPolicyReplayBuffer(T * N, env_nums=N)
+    for t in range(T):
+        buf.add_sample({"obs": rs.randn(N, 3).astype(np.float32), "acts": rs.randn(N, 2).astype(np.float32),
+                        "advs": rs.randn(N, 1).astype(np.float32)})
+    out["oi_obs"], out["oi_acts"], out["oi_advs"] = buf._obs, buf._acts, buf._advs
+    out["oi_args"] = np.array([T, N, B, E, 123])
+    np.random.seed(123)
+    batches = []
+    for _ in range(E):
+        for b in buf.one_iteration(B, ["obs", "acts", "advs"], True):
+            batches.append(np.concatenate([b["obs"], b["acts"], b["advs"]], -1))
+    out["oi_batches"] = np.stack(batches)
+    batches = [np.concatenate([b["obs"], b["acts"], b["advs"]], -1)
+               for b in buf.one_iteration(B, ["obs", "acts", "advs"], False)]
+    out["oi_batches_noshuffle"] = np.stack(batches)
+    # ring semantics + random_batch (base.py:19-51): 7 adds into 5 rows
+    from torchrl.replay_buffers import BaseReplayBuffer
+    N = 3
+    ring = BaseReplayBuffer(5 * N + 2, env_nums=N)       # 17 // 3 = 5 rows
+    rs = np.random.RandomState(6)
+    adds = rs.randn(7, N, 4).astype(np.float32)
+    rew = rs.randn(7, N, 1).astype(np.float32)
+    sizes, tops = [], []
+    np.random.seed(77)
+    rb = []
+    for t in range(7):
+        ring.add_sample({"obs": adds[t], "rewards": rew[t]})
+        sizes.append(ring._size); tops.append(ring._top)
+        b = ring.random_batch(2 * N, ["obs", "rewards"])
+        rb.append(np.concatenate([b["obs"], b["rewards"]], -1))
+    out.update(ring_adds=adds, ring_rew=rew, ring_sizes=np.array(sizes), ring_tops=np.array(tops),
+               ring_obs=ring._obs, ring_rewards=ring._rewards, ring_batches=np.stack(rb),
+               ring_args=np.array([17, N, 2 * N, 77]))
+    save("index_streams", **out)
+
+
+def build_nets(D, A, H, seed):
+    import torchrl.policies as policies
+    import torchrl.networks as networks
+    torch.manual_seed(seed)
+    net = dict(hidden_shapes=[H, H], append_hidden_shapes=[],
+               base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A,
+                                              tanh_action=True, **net)
+    vf = networks.Net(input_shape=(D,), output_shape=1, **net)
+    return pf, vf
+
+
+def make_ppo(pf, vf, env, buf, collector, logger, **kw):
+    from torchrl.algo import PPO
+    args = dict(plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=2, tau=0.95, shuffle=True,
+                entropy_coeff=0.005, discount=0.99, num_epochs=10, batch_size=32, gae=True,
+                env=env, replay_buffer=buf, collector=collector, logger=logger,
+                device=torch.device("cpu"), save_dir=tempfile.mkdtemp(prefix="trl_save_"))
+    args.update(kw)
+    return PPO(pf=pf, vf=vf, **args)
+
+
+class _StubCollector:
+    epoch_frames = 0
+
+
+def case_ppo_update():
+    """PPO.update on a random batch: info dict + post-step params + Adam moments."""
+    import gym
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    for tag, B, H, clipv, steps in (("small", 64, 64, False, 2), ("clipv", 96, 32, True, 1),
+                                    ("mid", 2048, 64, False, 1)):
+        D, A = 17, 6
+        pf, vf = build_nets(D, A, H, seed=3)
+        env = SynthVecEnvCPU(4)
+        env.action_space = gym.spaces.Box(-1, 1, (A,))
+        agent = make_ppo(pf, vf, env, None, _StubCollector(), NullLogger(),
+                         clipped_value_loss=clipv)
+        agent.current_epoch = 3
+        # perturb target so ratio != 1 on the first step
+        rs = np.random.RandomState(9)
+        with torch.no_grad():
+            for p in agent.target_pf.parameters():
+                p.add_(torch.as_tensor(rs.randn(*p.shape).astype(np.float32)) * 0.01)
+        batch = {"obs": rs.randn(B, D).astype(np.float32),
+                 "acts": np.tanh(rs.randn(B, A)).astype(np.float32) * 0.98,
+                 "advs": rs.randn(B, 1).astype(np.float32) * 2 + 0.5,
+                 "values": rs.randn(B, 1).astype(np.float32),
+                 "estimate_returns": rs.randn(B, 1).astype(np.float32)}
+        out.update({f"{tag}_batch_{k}": v for k, v in batch.items()})
+        out.update(state_arrays(f"{tag}_pf0_", pf))
+        out.update(state_arrays(f"{tag}_vf0_", vf))
+        out.update(state_arrays(f"{tag}_tpf0_", agent.target_pf))
+        out[f"{tag}_args"] = np.array([B, H, int(clipv), steps], dtype=np.int64)
+        for s in range(steps):
+            info = agent.update(batch)
+            out[f"{tag}_info{s}_keys"] = np.array(sorted(info.keys()))
+            out[f"{tag}_info{s}_vals"] = np.array([info[k] for k in sorted(info.keys())], dtype=np.float64)
+            out.update(state_arrays(f"{tag}_pf{s + 1}_", pf))
+            out.update(state_arrays(f"{tag}_vf{s + 1}_", vf))
+        for name, opt, mod in (("pf", agent.pf_optimizer, pf), ("vf", agent.vf_optimizer, vf)):
+            for (pn, p) in mod.named_parameters():
+                st = opt.state[p]
+                out[f"{tag}_{name}adam_m_{pn.replace('.', '__')}"] = st["exp_avg"].numpy().copy()
+                out[f"{tag}_{name}adam_v_{pn.replace('.', '__')}"] = st["exp_avg_sq"].numpy().copy()
+    save("ppo_update", **out)
+
+
+def case_collect_and_epoch():
+    """VecOnPolicyCollector.train_one_epoch on the synthetic env (with resets,
+    time-limit bootstrap), then PPO.update_per_epoch: buffers, advs, final params."""
+    import gym
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    for tag, N, T, horizon, max_frames, B, seed in (
+            ("small", 8, 16, 6, 1000, 32, 0),        # env time-limit resets every 6 steps
+            ("surpass", 8, 16, 1000, 5, 64, 1),      # collector over-length bootstrap every 5
+            ("mixed", 16, 24, 7, 5, 96, 2)):
+        D, A, H = 17, 6, 64
+        pf, vf = build_nets(D, A, H, seed=seed + 20)
+
+        def mk():
+            e = SynthVecEnvCPU(N, horizon=horizon)
+            e.action_space = gym.spaces.Box(-1, 1, (A,))
+            return e
+        env, eval_env = mk(), mk()
+        env.seed(seed)
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+        col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf,
+                                   device=torch.device("cpu"), train_render=False,
+                                   epoch_frames=N * T, max_episode_frames=max_frames,
+                                   eval_episodes=1)
+        out.update(state_arrays(f"{tag}_pf0_", pf))
+        out.update(state_arrays(f"{tag}_vf0_", vf))
+        noise_state = torch.get_rng_state()
+        res = col.train_one_epoch()
+        # the N(0,1) draws the reference consumed (Q5: == torch.randn(N, A) per step)
+        after = torch.get_rng_state()
+        torch.set_rng_state(noise_state)
+        out[f"{tag}_noise"] = torch.stack([torch.randn(N, A) for _ in range(T)]).numpy()
+        assert torch.equal(torch.get_rng_state(), after), "noise stream mismatch"
+        for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+            out[f"{tag}_buf_{k}"] = getattr(buf, "_" + k).copy()
+        out[f"{tag}_train_epoch_reward"] = np.array(res["train_epoch_reward"])
+        out[f"{tag}_train_rewards"] = np.array(res["train_rewards"], dtype=np.float64).reshape(-1)
+        out[f"{tag}_current_ob"] = np.asarray(col.current_ob).copy()
+        out[f"{tag}_args"] = np.array([N, T, horizon, max_frames, B, seed], dtype=np.int64)
+
+        logger = NullLogger()
+        agent = make_ppo(pf, vf, env, buf, col, logger, batch_size=B, opt_epochs=2)
+        agent.current_epoch = 1
+        np.random.seed(seed + 100)
+        agent.update_per_epoch()
+        out[f"{tag}_advs"] = buf._advs.copy()
+        out[f"{tag}_rets"] = buf._estimate_returns.copy()
+        keys = sorted(logger.infos[0].keys())
+        out[f"{tag}_info_keys"] = np.array(keys)
+        out[f"{tag}_infos"] = np.array([[i[k] for k in keys] for i in logger.infos], dtype=np.float64)
+        out.update(state_arrays(f"{tag}_pf1_", pf))
+        out.update(state_arrays(f"{tag}_vf1_", vf))
+    save("collect_epoch", **out)
+
+
+def case_init():
+    """networks.init: basic_init / uniform_init draws under torch.manual_seed (Q9)."""
+    out = {}
+    pf, vf = build_nets(17, 6, 64, seed=42)
+    out.update(state_arrays("pf_", pf))
+    out.update(state_arrays("vf_", vf))
+    save("net_init", **out)
+
+
+if __name__ == "__main__":
+    install_stubs()
+    case_gae()
+    case_index_streams()
+    case_init()
+    case_ppo_update()
+    case_collect_and_epoch()

@@ -1,0 +1,172 @@
+"""Pin the CPU oracle against fixtures produced by the imported reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, replay
+from oracle.collector import VecOnPolicyCollectorOracle
+from oracle.ppo import PPOOracle
+from oracle.synth_env import SynthVecEnvCPU
+
+
+def regen_gae_inputs(args):
+    T, N, seed, p_term, p_tl = int(args[0]), int(args[1]), int(args[2]), args[3], args[4]
+    rs = np.random.RandomState(seed)
+    r = rs.randn(T, N, 1).astype(np.float32)
+    v = rs.randn(T, N, 1).astype(np.float32)
+    d = rs.rand(T, N, 1) < p_term
+    tl = (rs.rand(T, N, 1) < p_tl) & d
+    lv = rs.randn(N, 1).astype(np.float32)
+    return r, v, d, tl, lv
+
+
+@pytest.mark.parametrize("tag", ["kat", "small", "ragged", "one", "cfg2"])
+def test_gae_and_discount_match_reference(golden, tag):
+    g = golden("gae")
+    if tag == "cfg2":
+        r, v, d, tl, lv = regen_gae_inputs(g["cfg2_args"])
+        gamma, tau, stride = g["cfg2_args"][5], g["cfg2_args"][6], int(g["cfg2_args"][7])
+    else:
+        r, v, d, tl, lv = (g[f"{tag}_{k}"] for k in
+                           ("rewards", "values", "terminals", "time_limits", "last_value"))
+        gamma, tau, stride = (0.99, 0.95, 1) if tag == "kat" else (g[f"{tag}_args"][5], g[f"{tag}_args"][6], 1)
+    for filt in (0, 1):
+        adv, ret = replay.gae(r, v, d, tl, lv, gamma, tau, bool(filt))
+        np.testing.assert_allclose(adv[:, ::stride], g[f"{tag}_gae{filt}_advs"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(ret[:, ::stride], g[f"{tag}_gae{filt}_rets"], rtol=0, atol=1e-12)
+        adv, ret = replay.discounted_return(r, v, d, tl, lv, gamma, bool(filt))
+        np.testing.assert_allclose(adv[:, ::stride], g[f"{tag}_disc{filt}_advs"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(ret[:, ::stride], g[f"{tag}_disc{filt}_rets"], rtol=0, atol=1e-12)
+
+
+def test_gae_kat_values_from_survey(golden):
+    g = golden("gae")
+    want = np.array([[0.799128, 1.24545], [-0.103, 0.9], [0.0, 0.214878], [0.899, 1.397]])
+    np.testing.assert_allclose(g["kat_gae1_advs"][..., 0], want, atol=1e-6)
+
+
+def test_index_streams_bit_exact(golden):
+    g = golden("index_streams")
+    np.random.seed(0)
+    assert np.array_equal(np.random.permutation(8), g["perm8_seed0"])
+    assert list(g["perm8_seed0"]) == [6, 2, 1, 7, 3, 0, 5, 4]
+    np.random.seed(0)
+    assert np.array_equal(np.random.randint(0, 100, 4), g["randint100x4_seed0"])
+    assert list(g["randint100x4_seed0"]) == [44, 47, 64, 67]
+
+
+def test_epoch_minibatches_match_reference(golden):
+    g = golden("index_streams")
+    T, N, B, E, seed = (int(x) for x in g["oi_args"])
+    ring = replay.RingOracle(T * N, env_nums=N)
+    for t in range(T):
+        ring.add({"obs": g["oi_obs"][t], "acts": g["oi_acts"][t], "advs": g["oi_advs"][t]})
+    np.random.seed(seed)
+    got = []
+    for _ in range(E):
+        for _idx, b in ring.epoch_minibatches(B, ["obs", "acts", "advs"], True):
+            got.append(np.concatenate([b["obs"], b["acts"], b["advs"]], -1))
+    assert np.array_equal(np.stack(got), g["oi_batches"])
+    got = [np.concatenate([b["obs"], b["acts"], b["advs"]], -1)
+           for _i, b in ring.epoch_minibatches(B, ["obs", "acts", "advs"], False)]
+    assert np.array_equal(np.stack(got), g["oi_batches_noshuffle"])
+
+
+def test_ring_and_uniform_sample_match_reference(golden):
+    g = golden("index_streams")
+    size, N, B, seed = (int(x) for x in g["ring_args"])
+    ring = replay.RingOracle(size, env_nums=N)
+    np.random.seed(seed)
+    for t in range(7):
+        ring.add({"obs": g["ring_adds"][t], "rewards": g["ring_rew"][t]})
+        assert ring.size == g["ring_sizes"][t] and ring.top == g["ring_tops"][t]
+        _idx, b = ring.sample_rows(B, ["obs", "rewards"])
+        assert np.array_equal(np.concatenate([b["obs"], b["rewards"]], -1), g["ring_batches"][t])
+    assert np.array_equal(ring.data["obs"], g["ring_obs"])
+    assert np.array_equal(ring.data["rewards"], g["ring_rewards"])
+    with pytest.raises(AssertionError):
+        ring.sample_rows(B + 1, ["obs"])
+
+
+def params_from(g, prefix, with_logstd):
+    names = sorted(k for k in g.files if k.startswith(prefix))
+    base = [k for k in names if "base__seq_fcs" in k]
+    head = [k for k in names if "seq_append_fcs" in k]
+    order = sorted(base, key=lambda k: (int(k.split("__")[-2]), "bias" in k)) + \
+        sorted(head, key=lambda k: "bias" in k)
+    ps = [torch.tensor(g[k]) for k in order]
+    ls = torch.tensor(g[prefix + "logstd"]) if with_logstd else None
+    return ps, ls
+
+
+def test_init_distribution_matches_reference(golden):
+    g = golden("net_init")
+    pf, ls = params_from(g, "pf_", True)
+    assert [tuple(p.shape) for p in pf] == [(64, 17), (64,), (64, 64), (64,), (6, 64), (6,)]
+    assert np.allclose(ls.numpy(), np.log(0.125))
+    mine = nets.init_mlp(17, [64, 64], 6)
+    for a, b in zip(mine, pf):
+        assert a.shape == b.shape
+    # hidden bound sqrt(1/out_features) (init.py:8), bias 0.1; head +-3e-3
+    assert pf[0].abs().max() <= 1 / 8 and pf[0].abs().max() > 0.11
+    assert torch.all(pf[1] == 0.1) and pf[4].abs().max() <= 3e-3
+    assert mine[0].abs().max() <= 1 / 8 and torch.all(mine[3] == 0.1) and mine[5].abs().max() <= 3e-3
+
+
+@pytest.mark.parametrize("tag", ["small", "clipv", "mid"])
+def test_ppo_update_matches_reference(golden, tag):
+    g = golden("ppo_update")
+    B, H, clipv, steps = (int(x) for x in g[f"{tag}_args"])
+    pf, ls = params_from(g, f"{tag}_pf0_", True)
+    vf, _ = params_from(g, f"{tag}_vf0_", False)
+    tpf, tls = params_from(g, f"{tag}_tpf0_", True)
+    o = PPOOracle(pf, ls, vf, plr=3e-4, vlr=3e-4, entropy_coeff=0.005, clip_para=0.2,
+                  clipped_value_loss=bool(clipv), num_epochs=10)
+    o.tpf, o.tlogstd = tpf, tls
+    batch = {k: g[f"{tag}_batch_{k}"] for k in ("obs", "acts", "advs", "values", "estimate_returns")}
+    for s in range(steps):
+        info = o.update(batch)
+        keys = [str(k) for k in g[f"{tag}_info{s}_keys"]]
+        assert sorted(info.keys()) == keys
+        got = np.array([info[k] for k in keys])
+        np.testing.assert_allclose(got, g[f"{tag}_info{s}_vals"], rtol=2e-5, atol=2e-6)
+        want_pf, want_ls = params_from(g, f"{tag}_pf{s + 1}_", True)
+        want_vf, _ = params_from(g, f"{tag}_vf{s + 1}_", False)
+        for a, b in zip(o.pf + [o.logstd] + o.vf, want_pf + [want_ls] + want_vf):
+            np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["small", "surpass", "mixed"])
+def test_collect_then_epoch_matches_reference(golden, tag):
+    g = golden("collect_epoch")
+    N, T, horizon, max_frames, B, seed = (int(x) for x in g[f"{tag}_args"])
+    pf, ls = params_from(g, f"{tag}_pf0_", True)
+    vf, _ = params_from(g, f"{tag}_vf0_", False)
+    env = SynthVecEnvCPU(N, horizon=horizon)
+    env.seed(seed)
+    ring = replay.RingOracle(N * T, env_nums=N, time_limit_filter=True)
+    col = VecOnPolicyCollectorOracle(env, ring, pf, ls, vf, epoch_frames=N * T,
+                                     max_episode_frames=max_frames)
+    res = col.train_one_epoch(noise=torch.tensor(g[f"{tag}_noise"]))
+    for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+        np.testing.assert_allclose(ring.data[k], g[f"{tag}_buf_{k}"], rtol=0, atol=2e-6, err_msg=k)
+    assert g[f"{tag}_buf_terminals"].sum() > 0
+    np.testing.assert_allclose(res["train_epoch_reward"], g[f"{tag}_train_epoch_reward"], atol=1e-4)
+    np.testing.assert_allclose(np.array(res["train_rewards"], dtype=np.float64).reshape(-1),
+                               g[f"{tag}_train_rewards"], atol=1e-5)
+    np.testing.assert_allclose(col.current_ob, g[f"{tag}_current_ob"], atol=2e-6)
+
+    o = PPOOracle(pf, ls, vf, plr=3e-4, vlr=3e-4, entropy_coeff=0.005, clip_para=0.2,
+                  opt_epochs=2, num_epochs=10, batch_size=B, discount=0.99, tau=0.95)
+    np.random.seed(seed + 100)
+    infos = o.epoch(ring, current_epoch=1)
+    np.testing.assert_allclose(ring.data["advs"], g[f"{tag}_advs"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ring.data["estimate_returns"], g[f"{tag}_rets"], rtol=0, atol=2e-5)
+    keys = [str(k) for k in g[f"{tag}_info_keys"]]
+    got = np.array([[i[k] for k in keys] for i in infos])
+    np.testing.assert_allclose(got, g[f"{tag}_infos"], rtol=1e-4, atol=1e-5)
+    want_pf, want_ls = params_from(g, f"{tag}_pf1_", True)
+    want_vf, _ = params_from(g, f"{tag}_vf1_", False)
+    for a, b in zip(o.pf + [o.logstd] + o.vf, want_pf + [want_ls] + want_vf):
+        np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=2e-6)
