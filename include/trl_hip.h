@@ -1,0 +1,194 @@
+/* trl_hip.h -- C ABI of libtrl_hip.so: the MI355X (gfx950) kernels behind the
+ * torchrl collector -> replay_buffer -> algo.update hot path.
+ *
+ * The reference (RchalYang/torchrl) is 100 % Python and has no FFI; the entry
+ * points below are what a maintainer would bind from the reference's own
+ * classes (ctypes stubs: INTEGRATION.md).  Each one cites the reference code
+ * (file:line under the reference root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every data pointer is a DEVICE pointer into caller-owned, contiguous
+ *    memory; nothing is allocated, freed or retained by the library.  The
+ *    trl_*_t descriptor structs themselves are HOST memory, read during the
+ *    call only;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*);
+ *  - return 0 on success, a negative TRL_E* code for a rejected argument, or a
+ *    positive hipError_t; trl_last_error() gives a thread-local message;
+ *  - rollout / replay tensors are time-major fp32: key[row][env][feat]
+ *    (reference layout, torchrl/replay_buffers/base.py:22-28, stored fp32
+ *    instead of float64); bool keys (terminals, time_limits) are 0.0f / 1.0f;
+ *  - an "MLP2" parameter block is ONE flat fp32 buffer
+ *      W1[H][D] b1[H] W2[H][H] b2[H] W3[O][H] b3[O] (logstd[O] for a policy)
+ *    i.e. nn.Linear's (out, in) layout, layer after layer -- Net/MLPBase of
+ *    torchrl/networks/nets.py:13-52, base.py:8-44 (activation after every
+ *    hidden layer, linear head).
+ */
+#ifndef TRL_HIP_H
+#define TRL_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRL_OK            0
+#define TRL_EINVAL       -1   /* bad size / null pointer / misaligned */
+#define TRL_EUNSUPPORTED -2   /* shape not instantiated in this build  */
+
+#define TRL_ACT_TANH 0
+#define TRL_ACT_RELU 1
+
+const char* trl_last_error(void);
+int trl_abi_version(void);
+
+/* --- K4: GAE / discounted-return reverse scans ---------------------------
+ * replaces OnPolicyReplayBufferBase.generalized_advantage_estimation
+ * (torchrl/replay_buffers/on_policy.py:16-44) and discount_reward (:46-70).
+ * rewards, values, terminals, time_limits, advs, rets: (T, N) fp32;
+ * last_value: (N).  time_limits may be NULL when tl_filter == 0.  If
+ * last_terminal (N) is given, last_value is masked by (1 - last_terminal) first
+ * (OnRLAlgo.process_epoch_samples, torchrl/algo/on_policy/on_rl_algo.py:27). */
+int trl_gae_f32(const float* rewards, const float* values, const float* terminals,
+                const float* time_limits, const float* last_value, const float* last_terminal,
+                float* advs, float* rets, int T, int N,
+                float gamma, float tau, int tl_filter, void* stream);
+int trl_discount_reward_f32(const float* rewards, const float* values, const float* terminals,
+                            const float* time_limits, const float* last_value, const float* last_terminal,
+                            float* advs, float* rets, int T, int N,
+                            float gamma, int tl_filter, void* stream);
+
+/* --- K5/K6: minibatch / replay gather by time-row index --------------------
+ * replaces the fancy-index copies of one_iteration (on_policy.py:72-91) and
+ * random_batch (base.py:39-51): dst[i, :] = src[row_idx[i], :], a row being
+ * N*F contiguous elements.  row_idx is produced on the host by numpy's legacy
+ * global RNG so the index stream is bit-exact with the reference. */
+int trl_gather_rows_f32(const float* src, const int64_t* row_idx, float* dst,
+                        int n_rows, int64_t row_elems, int64_t src_rows, void* stream);
+int trl_gather_rows_u8(const uint8_t* src, const int64_t* row_idx, uint8_t* dst,
+                       int n_rows, int64_t row_bytes, int64_t src_rows, void* stream);
+
+/* --- K7: per-minibatch advantage statistics --------------------------------
+ * replaces advs.mean()/std()/max()/min() of PPO.update (ppo.py:141-144) for
+ * ALL minibatches of an epoch at once.  advs: (T, N); row_idx: (n_mb, rows_mb).
+ * raw_out: (n_mb, 4) float64 = {sum, sum of squares, max, -min} -- additive /
+ * max-reducible across ranks; the consumer derives mean and the UNBIASED std
+ * (ppo.py:147) from them and the global element count. */
+int trl_adv_stats_f64(const float* advs, const int64_t* row_idx, int n_mb, int rows_mb,
+                      int N, double* raw_out, void* stream);
+
+/* --- MLP2 inference -------------------------------------------------------
+ * replaces Net.forward (nets.py:49-52) for vf(last_obs) (on_rl_algo.py:25-26)
+ * and the policy mean.  x: (M, D) -> out: (M, O). */
+int trl_mlp2_forward_f32(const float* params, const float* x, float* out,
+                         int M, int D, int H, int O, int act, void* stream);
+
+/* --- K1+K2+K3: fused vectorised rollout on the synthetic env ---------------
+ * replaces VecOnPolicyCollector.take_actions x n_steps
+ * (torchrl/collector/on_policy.py:90-155, base.py:108-122): policy mean ->
+ * tanh(mean + std*eps) (continuous_policy.py:92-132, distribution.py:60-76),
+ * vf(obs), env step, episode bookkeeping, over-length bootstrap
+ * r += gamma*vf(next_obs), terminals = done|surpass, partial reset, and the
+ * ring-buffer row write (replay_buffers/base.py:19-37).  See trl_rollout_t. */
+typedef struct trl_rollout_t {
+  /* networks (MLP2 blocks, D -> H -> H -> {A,1}) */
+  const float* pf_params;     /* incl. logstd[A] at the tail */
+  const float* vf_params;
+  int D, H, A, act;           /* act: TRL_ACT_* */
+  int tanh_action;            /* policies' tanh_action flag (continuous_policy.py:92-132) */
+  /* synthetic env: obs' = tanh(obs @ env_A + act @ env_B) */
+  const float* env_A;         /* (D, D) */
+  const float* env_B;         /* (A, D) */
+  float reward_scale;
+  int horizon;                /* env done = time_limit = (t_env >= horizon) */
+  int64_t env_seed_base;      /* env i uses seed env_seed_base + i (vecenv.py:63-65) */
+  /* persistent per-env state, all length N */
+  float*   cur_obs;           /* (N, D) */
+  int32_t* t_env;             /* steps since reset (env side) */
+  int32_t* cur_step;          /* collector side counter (base.py:180, 205) */
+  int32_t* episode_idx;
+  float*   ep_return;         /* running episode return (base.py:181, 216-219) */
+  /* noise: host-drawn eps (n_steps, N, A) for reference parity, or NULL ->
+   * device Philox keyed by (env seed, noise_step0 + t) */
+  const float* noise;
+  int64_t noise_step0;
+  int deterministic;          /* 1: eps = 0 (greedy eval_act, continuous_policy.py:78-83) */
+  /* ring buffer rows [top, top+n_steps) mod rows ; (rows, N, feat) each.
+   * All seven may be NULL together: nothing is stored (evaluation rollouts). */
+  float *obs, *next_obs, *acts, *values, *rewards, *terminals, *time_limits;
+  float *old_logp;            /* optional extra key: log pi(a|s) at collection time */
+  int rows, top;
+  int N, n_steps;
+  int max_episode_frames;
+  float discount;
+  /* outputs */
+  double*  epoch_reward;      /* += sum of raw env rewards (base.py:230) */
+  int32_t* ep_count;          /* finished-episode log: count, then entries */
+  float*   ep_log;            /* (cap, 3): step, env, return */
+  int ep_cap;
+  int step0;                  /* value written as `step` for the first step */
+} trl_rollout_t;
+int trl_rollout_synth_f32(const trl_rollout_t* args, void* stream);
+
+/* synthetic env (re)start: for every env i with mask[i] != 0 (mask NULL = all):
+ * episode_idx += 1, obs ~ N(0,1) from the Philox reset stream keyed
+ * (env_seed_base + i, episode_idx), counters and running return cleared.
+ * replaces VecEnv.reset / partial_reset (torchrl/env/vecenv.py:41-51). */
+int trl_synth_reset_f32(float* cur_obs, int32_t* t_env, int32_t* cur_step, int32_t* episode_idx,
+                        float* ep_return, const uint8_t* mask, int N, int D, int64_t env_seed_base,
+                        void* stream);
+
+/* log pi(a|s) of a diagonal Gaussian / TanhNormal given the policy mean:
+ * replaces dis.log_prob(actions).sum(-1) of GuassianContPolicyBase.update
+ * (torchrl/policies/continuous_policy.py:134-142, distribution.py:33-45).
+ * mean, acts: (B, A); logstd: (A); out: (B). */
+int trl_gauss_logp_f32(const float* mean, const float* acts, const float* logstd, float* out,
+                       int B, int A, int tanh_action, void* stream);
+
+/* --- K8+K9+K10: fused PPO minibatch gradient -------------------------------
+ * replaces, for one minibatch, PPO.update's forward/backward work
+ * (torchrl/algo/on_policy/ppo.py:41-152): advantage normalisation, vf forward,
+ * MSE / clipped value loss, pf forward, TanhNormal log-prob + entropy
+ * (distribution.py:33-45, 78-79), ratio / clip / min surrogate, and the
+ * backward pass of both MLPs on fp32 MFMA.  Writes per-workgroup partial
+ * gradients; trl_ppo_reduce_f32 folds them. */
+typedef struct trl_ppo_batch_t {
+  const float *obs, *acts, *advs, *rets, *old_values, *old_logp;  /* (rows, N, feat) */
+  const int64_t* row_idx;     /* (rows_mb) time rows of this minibatch, or NULL = rows 0.. */
+  int rows_mb, N;             /* local samples = rows_mb * N */
+  const double* adv_raw;      /* (4) {sum, sumsq, max, -min} of this minibatch (global) */
+  double n_global;            /* global sample count (all ranks) */
+  const float* pf_params; const float* vf_params;
+  int D, H, A, act;
+  float clip_para, entropy_coeff;
+  int clipped_value_loss, tanh_action;
+  float* partial;             /* (n_wg, P_STRIDE) fp32 workspace */
+  double* scal_partial;       /* (n_wg, 8) */
+  int n_wg;                   /* even; first half policy, second half value */
+} trl_ppo_batch_t;
+int trl_ppo_partial_stride(int D, int H, int A);
+int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* args, void* stream);
+/* grads: flat [pf grads (P_pf) | vf grads (P_vf)]; info: (16) doubles */
+int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg,
+                       int D, int H, int A, float* grads, double* info, void* stream);
+
+/* --- K11: global-norm clip + Adam ------------------------------------------
+ * replaces clip_grad_norm_(params, max_norm) + Adam(eps).step()
+ * (ppo.py:72-74, 117-119; a2c.py:29-39) for up to 4 parameter groups laid out
+ * back to back in params/grads/exp_avg/exp_avg_sq.  step_count is the
+ * post-increment Adam step (1 on the first call).  norms_out: (n_groups). */
+typedef struct trl_adam_t {
+  float* params; const float* grads; float* exp_avg; float* exp_avg_sq;
+  int n_groups;               /* <= 4, each clipped by its own global norm */
+  int group_sizes[4];
+  float group_lr[4];
+  float max_norm;             /* <= 0: no clipping */
+  float beta1, beta2, eps;
+  int step_count;
+  float grad_scale;           /* grads are multiplied by this first (1/world_size) */
+  float* norms_out;           /* (n_groups) pre-clip global norms */
+} trl_adam_t;
+int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRL_HIP_H */

@@ -236,7 +236,7 @@ def case_ppo_update():
     import gym
     from oracle.synth_env import SynthVecEnvCPU
     out = {}
-    for tag, B, H, clipv, steps in (("small", 64, 64, False, 2), ("clipv", 96, 32, True, 1),
+    for tag, B, H, clipv, steps in (("small", 64, 64, False, 2), ("clipv", 96, 64, True, 1),
                                     ("mid", 2048, 64, False, 1)):
         D, A = 17, 6
         pf, vf = build_nets(D, A, H, seed=3)

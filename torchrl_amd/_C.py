@@ -1,0 +1,246 @@
+"""ctypes binding of libtrl_hip.so (include/trl_hip.h).
+
+There is no CPU or pure-PyTorch fallback: every op below either runs the HIP
+kernel on the tensors' device or raises.  The library is loaded lazily so that
+host-only logic (index streams, ring bookkeeping, argument checks) imports on a
+machine without the .so; the first kernel call then fails loudly.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtrl_hip.so")
+_lib = None
+
+ACT_TANH, ACT_RELU = 0, 1
+ACT_CODES = {"tanh": ACT_TANH, "relu": ACT_RELU}
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_i64_p = C.POINTER(C.c_int64)
+c_i32_p = C.POINTER(C.c_int32)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class TrlError(RuntimeError):
+    pass
+
+
+class RolloutArgs(C.Structure):
+    _fields_ = [
+        ("pf_params", C.c_void_p), ("vf_params", C.c_void_p),
+        ("D", C.c_int), ("H", C.c_int), ("A", C.c_int), ("act", C.c_int),
+        ("tanh_action", C.c_int),
+        ("env_A", C.c_void_p), ("env_B", C.c_void_p),
+        ("reward_scale", C.c_float), ("horizon", C.c_int), ("env_seed_base", C.c_int64),
+        ("cur_obs", C.c_void_p), ("t_env", C.c_void_p), ("cur_step", C.c_void_p),
+        ("episode_idx", C.c_void_p), ("ep_return", C.c_void_p),
+        ("noise", C.c_void_p), ("noise_step0", C.c_int64), ("deterministic", C.c_int),
+        ("obs", C.c_void_p), ("next_obs", C.c_void_p), ("acts", C.c_void_p), ("values", C.c_void_p),
+        ("rewards", C.c_void_p), ("terminals", C.c_void_p), ("time_limits", C.c_void_p),
+        ("old_logp", C.c_void_p),
+        ("rows", C.c_int), ("top", C.c_int), ("N", C.c_int), ("n_steps", C.c_int),
+        ("max_episode_frames", C.c_int), ("discount", C.c_float),
+        ("epoch_reward", C.c_void_p), ("ep_count", C.c_void_p), ("ep_log", C.c_void_p),
+        ("ep_cap", C.c_int), ("step0", C.c_int),
+    ]
+
+
+class PpoBatchArgs(C.Structure):
+    _fields_ = [
+        ("obs", C.c_void_p), ("acts", C.c_void_p), ("advs", C.c_void_p), ("rets", C.c_void_p),
+        ("old_values", C.c_void_p), ("old_logp", C.c_void_p),
+        ("row_idx", C.c_void_p), ("rows_mb", C.c_int), ("N", C.c_int),
+        ("adv_raw", C.c_void_p), ("n_global", C.c_double),
+        ("pf_params", C.c_void_p), ("vf_params", C.c_void_p),
+        ("D", C.c_int), ("H", C.c_int), ("A", C.c_int), ("act", C.c_int),
+        ("clip_para", C.c_float), ("entropy_coeff", C.c_float),
+        ("clipped_value_loss", C.c_int), ("tanh_action", C.c_int),
+        ("partial", C.c_void_p), ("scal_partial", C.c_void_p), ("n_wg", C.c_int),
+    ]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+        ("n_groups", C.c_int), ("group_sizes", C.c_int * 4), ("group_lr", C.c_float * 4),
+        ("max_norm", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("step_count", C.c_int), ("grad_scale", C.c_float), ("norms_out", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); the loader checks every one of these symbols exists
+SIGNATURES = {
+    "trl_last_error": (C.c_char_p, []),
+    "trl_abi_version": (C.c_int, []),
+    "trl_gae_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "trl_discount_reward_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "trl_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "trl_gather_rows_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "trl_adv_stats_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
+    "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "trl_ppo_minibatch_grad_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p]),
+    "trl_ppo_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trl_clip_adam_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
+    "trl_synth_reset_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "trl_gauss_logp_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+
+def lib():
+    """Load (once) and type the shared library; raise if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TrlError(
+                "libtrl_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python torchrl_amd/build.py`. torchrl_amd has no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().trl_last_error().decode() or "error %d" % code
+        raise TrlError("%s failed (%d): %s" % (what, code, msg))
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dev_ptr(t, dtype=torch.float32, name="tensor", allow_none=False):
+    """Pointer to a contiguous device tensor of the given dtype (loud on anything else)."""
+    if t is None:
+        if allow_none:
+            return C.c_void_p(0)
+        raise TrlError("%s is None" % name)
+    if not isinstance(t, torch.Tensor):
+        raise TrlError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
+    if t.device.type != "cuda":
+        raise TrlError("%s lives on %s: torchrl_amd kernels need a GPU tensor (there is no CPU path)"
+                       % (name, t.device))
+    if t.dtype != dtype:
+        raise TrlError("%s has dtype %s, expected %s" % (name, t.dtype, dtype))
+    if not t.is_contiguous():
+        raise TrlError("%s must be contiguous" % name)
+    return C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------ thin op wrappers
+def gae(rewards, values, terminals, time_limits, last_value, advs, rets, gamma, tau, tl_filter,
+        last_terminal=None):
+    T, N = rewards.shape[0], rewards.shape[1]
+    check(lib().trl_gae_f32(dev_ptr(rewards, name="rewards"), dev_ptr(values, name="values"),
+                            dev_ptr(terminals, name="terminals"),
+                            dev_ptr(time_limits, name="time_limits", allow_none=not tl_filter),
+                            dev_ptr(last_value, name="last_value"),
+                            dev_ptr(last_terminal, name="last_terminal", allow_none=True),
+                            dev_ptr(advs, name="advs"),
+                            dev_ptr(rets, name="rets"), T, N, float(gamma), float(tau), int(bool(tl_filter)),
+                            stream_ptr(rewards.device)), "trl_gae_f32")
+
+
+def discount_reward(rewards, values, terminals, time_limits, last_value, advs, rets, gamma, tl_filter,
+                    last_terminal=None):
+    T, N = rewards.shape[0], rewards.shape[1]
+    check(lib().trl_discount_reward_f32(dev_ptr(rewards, name="rewards"), dev_ptr(values, name="values"),
+                                        dev_ptr(terminals, name="terminals"),
+                                        dev_ptr(time_limits, name="time_limits", allow_none=not tl_filter),
+                                        dev_ptr(last_value, name="last_value"),
+                                        dev_ptr(last_terminal, name="last_terminal", allow_none=True),
+                                        dev_ptr(advs, name="advs"),
+                                        dev_ptr(rets, name="rets"), T, N, float(gamma), int(bool(tl_filter)),
+                                        stream_ptr(rewards.device)), "trl_discount_reward_f32")
+
+
+def gather_rows(src, row_idx, out=None):
+    """out[i] = src[row_idx[i]] over the leading (time-row) dimension."""
+    n = int(row_idx.numel())
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    row_elems = 1
+    for s in src.shape[1:]:
+        row_elems *= int(s)
+    if src.dtype == torch.float32:
+        fn, name = lib().trl_gather_rows_f32, "trl_gather_rows_f32"
+    elif src.dtype == torch.uint8:
+        fn, name = lib().trl_gather_rows_u8, "trl_gather_rows_u8"
+    else:
+        raise TrlError("gather_rows: dtype %s not supported" % src.dtype)
+    check(fn(dev_ptr(src, src.dtype, "src"), dev_ptr(row_idx, torch.int64, "row_idx"),
+             dev_ptr(out, src.dtype, "out"), n, row_elems, int(src.shape[0]), stream_ptr(src.device)), name)
+    return out
+
+
+def adv_stats(advs, row_idx_2d, raw_out):
+    n_mb, rows_mb = int(row_idx_2d.shape[0]), int(row_idx_2d.shape[1])
+    check(lib().trl_adv_stats_f64(dev_ptr(advs, name="advs"), dev_ptr(row_idx_2d, torch.int64, "row_idx"),
+                                  n_mb, rows_mb, int(advs.shape[1]),
+                                  dev_ptr(raw_out, torch.float64, "raw_out"), stream_ptr(advs.device)),
+          "trl_adv_stats_f64")
+    return raw_out
+
+
+def mlp2_forward(params, x, D, H, O, act, out=None):
+    M = int(x.shape[0])
+    if out is None:
+        out = torch.empty((M, O), dtype=torch.float32, device=x.device)
+    check(lib().trl_mlp2_forward_f32(dev_ptr(params, name="params"), dev_ptr(x, name="x"),
+                                     dev_ptr(out, name="out"), M, D, H, O, act, stream_ptr(x.device)),
+          "trl_mlp2_forward_f32")
+    return out
+
+
+def rollout(args, device):
+    check(lib().trl_rollout_synth_f32(C.byref(args), stream_ptr(device)), "trl_rollout_synth_f32")
+
+
+def ppo_partial_stride(D, H, A):
+    ps = lib().trl_ppo_partial_stride(D, H, A)
+    if ps < 0:
+        check(ps, "trl_ppo_partial_stride")
+    return ps
+
+
+def ppo_minibatch_grad(args, device):
+    check(lib().trl_ppo_minibatch_grad_f32(C.byref(args), stream_ptr(device)), "trl_ppo_minibatch_grad_f32")
+
+
+def ppo_reduce(partial, scal_partial, n_wg, D, H, A, grads, info):
+    check(lib().trl_ppo_reduce_f32(dev_ptr(partial, name="partial"),
+                                   dev_ptr(scal_partial, torch.float64, "scal_partial"), n_wg, D, H, A,
+                                   dev_ptr(grads, name="grads"), dev_ptr(info, torch.float64, "info"),
+                                   stream_ptr(partial.device)), "trl_ppo_reduce_f32")
+
+
+def clip_adam(args, device):
+    check(lib().trl_clip_adam_f32(C.byref(args), stream_ptr(device)), "trl_clip_adam_f32")
+
+
+def synth_reset(cur_obs, t_env, cur_step, episode_idx, ep_return, mask, seed_base):
+    N, D = int(cur_obs.shape[0]), int(cur_obs.shape[1])
+    check(lib().trl_synth_reset_f32(dev_ptr(cur_obs, name="cur_obs"), dev_ptr(t_env, torch.int32, "t_env"),
+                                    dev_ptr(cur_step, torch.int32, "cur_step"),
+                                    dev_ptr(episode_idx, torch.int32, "episode_idx"),
+                                    dev_ptr(ep_return, name="ep_return"),
+                                    dev_ptr(mask, torch.uint8, "mask", allow_none=True), N, D, int(seed_base),
+                                    stream_ptr(cur_obs.device)), "trl_synth_reset_f32")
+
+
+def gauss_logp(mean, acts, logstd, tanh_action, out=None):
+    B, A = int(mean.shape[0]), int(mean.shape[1])
+    if out is None:
+        out = torch.empty((B,), dtype=torch.float32, device=mean.device)
+    check(lib().trl_gauss_logp_f32(dev_ptr(mean, name="mean"), dev_ptr(acts, name="acts"),
+                                   dev_ptr(logstd, name="logstd"), dev_ptr(out, name="out"), B, A,
+                                   int(bool(tanh_action)), stream_ptr(mean.device)), "trl_gauss_logp_f32")
+    return out

@@ -1,0 +1,106 @@
+// K5/K6 -- row gather (minibatch slices / uniform replay sample) and
+// K7 -- per-minibatch advantage statistics.
+//
+// A "row" is one time step of the (rows, N, feat) ring: N*feat contiguous
+// elements, so the gather is a set of large contiguous copies selected by a
+// host-generated int64 index (bit-exact with numpy's legacy RNG, see
+// torchrl/replay_buffers/base.py:44, on_policy.py:76-78).  16-byte vector
+// loads/stores when the row size allows; HBM-bound: row_bytes read + written.
+#include "trl_common.h"
+
+template <typename VecT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const VecT* __restrict__ src,
+                                                          const int64_t* __restrict__ idx,
+                                                          VecT* __restrict__ dst, int64_t row_vecs,
+                                                          int64_t src_rows) {
+  const int row = blockIdx.y;
+  const int64_t s = idx[row];
+  if (s < 0 || s >= src_rows) return;     // out-of-range index: host validates, never copy wild memory
+  const VecT* sp = src + s * row_vecs;
+  VecT* dp = dst + (int64_t)row * row_vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_vecs;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dp[i] = sp[i];
+}
+
+template <typename VecT>
+static int launch_gather(const void* src, const int64_t* idx, void* dst, int n_rows, int64_t row_vecs,
+                         int64_t src_rows, hipStream_t s) {
+  int bx = (int)((row_vecs + 255) / 256);
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
+  dim3 grid(bx, n_rows), block(256);
+  hipLaunchKernelGGL(gather_rows_kernel<VecT>, grid, block, 0, s, (const VecT*)src, idx, (VecT*)dst,
+                     row_vecs, src_rows);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+static int gather_bytes(const void* src, const int64_t* idx, void* dst, int n_rows, int64_t row_bytes,
+                        int64_t src_rows, void* stream) {
+  if (n_rows < 0 || row_bytes < 0 || src_rows < 0) { trl_set_error("gather_rows: negative size"); return TRL_EINVAL; }
+  if (n_rows == 0 || row_bytes == 0) return TRL_OK;
+  if (!src || !idx || !dst) { trl_set_error("gather_rows: null pointer"); return TRL_EINVAL; }
+  if (n_rows > 65535) { trl_set_error("gather_rows: n_rows > 65535"); return TRL_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  const uintptr_t al = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)row_bytes;
+  if ((al & 15) == 0) return launch_gather<uint4>(src, idx, dst, n_rows, row_bytes / 16, src_rows, s);
+  if ((al & 3) == 0) return launch_gather<uint32_t>(src, idx, dst, n_rows, row_bytes / 4, src_rows, s);
+  return launch_gather<uint8_t>(src, idx, dst, n_rows, row_bytes, src_rows, s);
+}
+
+extern "C" int trl_gather_rows_f32(const float* src, const int64_t* row_idx, float* dst, int n_rows,
+                                   int64_t row_elems, int64_t src_rows, void* stream) {
+  return gather_bytes(src, row_idx, dst, n_rows, row_elems * 4, src_rows, stream);
+}
+
+extern "C" int trl_gather_rows_u8(const uint8_t* src, const int64_t* row_idx, uint8_t* dst, int n_rows,
+                                  int64_t row_bytes, int64_t src_rows, void* stream) {
+  return gather_bytes(src, row_idx, dst, n_rows, row_bytes, src_rows, stream);
+}
+
+// ---------------------------------------------------------------- K7
+// One workgroup per minibatch: sum / sum-of-squares in fp64 (so the unbiased
+// variance (sumsq - sum^2/n)/(n-1) of ppo.py:142,147 has no cancellation
+// problem), max and -min.  Wave shuffles, then LDS across the 16 waves.
+#define STATS_THREADS 1024
+__global__ __launch_bounds__(STATS_THREADS) void adv_stats_kernel(const float* __restrict__ advs,
+                                                                  const int64_t* __restrict__ row_idx,
+                                                                  int rows_mb, int N,
+                                                                  double* __restrict__ raw_out) {
+  __shared__ double s_red[4][STATS_THREADS / 64];
+  const int mb = blockIdx.x;
+  double sum = 0.0, sq = 0.0;
+  float mx = -INFINITY, mn = INFINITY;
+  for (int r = 0; r < rows_mb; ++r) {
+    const float* p = advs + (size_t)row_idx[(size_t)mb * rows_mb + r] * N;
+    for (int i = threadIdx.x; i < N; i += STATS_THREADS) {
+      const float v = p[i];
+      sum += (double)v; sq += (double)v * (double)v;
+      mx = fmaxf(mx, v); mn = fminf(mn, v);
+    }
+  }
+  sum = wave_sum(sum); sq = wave_sum(sq);
+  mx = wave_max(mx); mn = -wave_max(-mn);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s_red[0][wave] = sum; s_red[1][wave] = sq; s_red[2][wave] = mx; s_red[3][wave] = -mn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0, c = -INFINITY, d = -INFINITY;
+    for (int w = 0; w < STATS_THREADS / 64; ++w) {
+      a += s_red[0][w]; b += s_red[1][w]; c = fmax(c, s_red[2][w]); d = fmax(d, s_red[3][w]);
+    }
+    raw_out[mb * 4 + 0] = a; raw_out[mb * 4 + 1] = b; raw_out[mb * 4 + 2] = c; raw_out[mb * 4 + 3] = d;
+  }
+}
+
+extern "C" int trl_adv_stats_f64(const float* advs, const int64_t* row_idx, int n_mb, int rows_mb, int N,
+                                 double* raw_out, void* stream) {
+  if (n_mb < 0 || rows_mb < 0 || N < 0) { trl_set_error("adv_stats: negative size"); return TRL_EINVAL; }
+  if (n_mb == 0) return TRL_OK;
+  if (!advs || !row_idx || !raw_out) { trl_set_error("adv_stats: null pointer"); return TRL_EINVAL; }
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(n_mb), dim3(STATS_THREADS), 0, (hipStream_t)stream, advs,
+                     row_idx, rows_mb, N, raw_out);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
