@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/s of the full PPO iteration on the synthetic
+HalfCheetah-shaped workload (BASELINE.json cfg 2).
+
+One "step" = one PPO iteration = collect T=128 steps on N=2048 envs per GPU,
+GAE, then opt_epochs=10 x 4 minibatch updates of B=65536 (per GPU) -- everything
+the reference's RLAlgo.train loop body does between evaluations
+(torchrl/algo/rl_algo.py:111-118), inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+N_PER_GPU, T, BATCH_PER_GPU, OPT_EPOCHS = 2048, 128, 65536, 10
+D, H, A = 17, 64, 6
+# algorithmic FLOPs per sample of the fused minibatch-gradient kernel (2*MACs):
+# pf fwd 11136 + vf fwd 10496 + backward 2x(fwd) for both nets; log pi_old is cached
+# by the collector, so target_pf is not re-run (76032 - 11136)
+FLOP_PER_SAMPLE = 3 * (11136 + 10496)
+MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+class NullLogger:
+    def add_update_info(self, d): pass
+    def add_epoch_info(self, *a, **k): pass
+    def log(self, *a): pass
+    def finish(self): pass
+
+
+def build_agent(dev, world, rank, seed=0):
+    import torch
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import PPO
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env import get_vec_env
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    torch.manual_seed(seed)
+    np.random.seed(seed)                         # identical index streams on every rank
+    net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase,
+               activation_func=torch.nn.Tanh)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A, tanh_action=True, **net)
+    vf = networks.Net(input_shape=(D,), output_shape=1, **net)
+    kw = dict(device=dev, index_offset=rank * N_PER_GPU, total_env_nums=world * N_PER_GPU)
+    env = get_vec_env("SynthHalfCheetah-v0", {"reward_scale": 1, "obs_norm": False}, N_PER_GPU, **kw)
+    eval_env = get_vec_env("SynthHalfCheetah-v0", {"reward_scale": 1, "obs_norm": False}, N_PER_GPU, **kw)
+    env.seed(seed)
+    buf = OnPolicyReplayBuffer(N_PER_GPU * T, env_nums=N_PER_GPU, time_limit_filter=True, device=dev)
+    col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev,
+                               epoch_frames=N_PER_GPU * T, max_episode_frames=1000, noise_mode="device")
+    agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=OPT_EPOCHS, tau=0.95, shuffle=True,
+                entropy_coeff=0.005, discount=0.99, num_epochs=100000, batch_size=BATCH_PER_GPU, gae=True,
+                env=env, replay_buffer=buf, collector=col, logger=NullLogger(), device=dev, save_dir=None)
+    return agent, col
+
+
+def iteration(agent, col, epoch):
+    """collect -> GAE -> opt_epochs x minibatches; all enqueued, one host read of the update statistics."""
+    col.rollout(col.sample_epoch_frames)
+    agent.current_epoch = epoch
+    agent.update_per_epoch()
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def cpu_baseline(budget_s=25.0):
+    """The reference-style CPU path (oracle/, a port), timed on this host on a BOUNDED sample of the
+    same workload and scaled to one full iteration: SubProcVecEnv-like stepping of per-env Python
+    objects over pickled pipes + torch-CPU policy/value forward + numpy fp64 ring (collect leg:
+    as many of the T=128 vector steps as fit in ~half the budget), then torch-CPU PPO minibatch
+    updates of the full B=65536 on synthetic rollout data (update leg: as many of the 40 as fit)."""
+    import functools
+    import torch
+    from oracle import nets, replay
+    from oracle.collector import VecOnPolicyCollectorOracle
+    from oracle.subproc_env import SubProcVecEnvCPU
+    from oracle.ppo import PPOOracle
+    from oracle.synth_env import SynthSingleEnvCPU
+    cores = os.cpu_count() or 1
+    procs = 1
+    while procs * 2 <= min(cores, 16) and N_PER_GPU % (procs * 2) == 0:
+        procs *= 2
+    threads = min(cores, 32)
+    torch.set_num_threads(threads)
+    fns = [functools.partial(SynthSingleEnvCPU, i) for i in range(N_PER_GPU)]
+    log("cpu baseline: spawning %d env workers" % procs)
+    env = SubProcVecEnvCPU(procs, N_PER_GPU, fns, SynthSingleEnvCPU(0))
+    try:
+        gen = torch.Generator().manual_seed(0)
+        pf, vf = nets.init_mlp(D, [H, H], A, generator=gen), nets.init_mlp(D, [H, H], 1, generator=gen)
+        ls = torch.full((A,), float(np.log(0.125)))
+        ring = replay.RingOracle(N_PER_GPU * T, env_nums=N_PER_GPU, time_limit_filter=True)
+        col = VecOnPolicyCollectorOracle(env, ring, pf, ls, vf, epoch_frames=N_PER_GPU * T, max_episode_frames=1000)
+        col.train_rews = []
+        for _ in range(2):
+            col.take_actions()                                   # warm the pipes
+        n_col, t0 = 0, time.perf_counter()
+        while n_col < T and (time.perf_counter() - t0) < 0.5 * budget_s:
+            col.take_actions()
+            n_col += 1
+        t_step = (time.perf_counter() - t0) / n_col
+    finally:
+        env.close()
+    log("cpu baseline: %d collect steps, %.3f s/step" % (n_col, t_step))
+    # update leg on a full synthetic rollout (values only matter for timing)
+    rs = np.random.RandomState(0)
+    ring = replay.RingOracle(N_PER_GPU * T, env_nums=N_PER_GPU, time_limit_filter=True)
+    ring.data = {"obs": rs.randn(T, N_PER_GPU, D), "next_obs": rs.randn(T, N_PER_GPU, D),
+                 "acts": np.tanh(rs.randn(T, N_PER_GPU, A)) * 0.9, "values": rs.randn(T, N_PER_GPU, 1),
+                 "rewards": rs.randn(T, N_PER_GPU, 1), "terminals": np.zeros((T, N_PER_GPU, 1)),
+                 "time_limits": np.zeros((T, N_PER_GPU, 1))}
+    ppo = PPOOracle(pf, ls, vf, entropy_coeff=0.005, opt_epochs=OPT_EPOCHS, batch_size=BATCH_PER_GPU, num_epochs=100000)
+    t0 = time.perf_counter()
+    ppo.process_epoch_samples(ring)
+    t_gae = time.perf_counter() - t0
+    keys = ["obs", "acts", "advs", "estimate_returns", "values"]
+    n_upd, t0 = 0, time.perf_counter()
+    n_mb = N_PER_GPU * T // BATCH_PER_GPU
+    while n_upd < OPT_EPOCHS * n_mb and (time.perf_counter() - t0) < 0.5 * budget_s:
+        for _idx, batch in ring.epoch_minibatches(BATCH_PER_GPU, keys, True):
+            ppo.update(batch)
+            n_upd += 1
+    t_upd = (time.perf_counter() - t0) / n_upd
+    log("cpu baseline: %d updates, %.3f s/update" % (n_upd, t_upd))
+    full = T * t_step + t_gae + OPT_EPOCHS * n_mb * t_upd
+    steps = N_PER_GPU * T
+    return {"value": steps / full, "unit": "env-steps/s", "cores": max(procs, threads), "kind": "port",
+            "sample": "collect: %d of %d vector steps of N=%d (%d env worker processes over pipes, %.0f env-steps/s); "
+                      "GAE %.3fs; update: %d of %d minibatch updates of B=%d (%d torch threads, %.3f s each); "
+                      "scaled to one full iteration = %.1f s" % (n_col, T, N_PER_GPU, procs, N_PER_GPU / t_step,
+                                                                 t_gae, n_upd, OPT_EPOCHS * n_mb, BATCH_PER_GPU,
+                                                                 threads, t_upd, full)}
+
+
+def cpu_baseline_subprocess(timeout_s=240):
+    """Run the CPU leg in its own interpreter (own torch thread pool, spawn-safe, hard time limit)."""
+    import subprocess
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], timeout=timeout_s,
+                             stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
+        for line in res.stdout.splitlines():
+            if line.startswith("CPU_BASELINE "):
+                return json.loads(line[len("CPU_BASELINE "):])
+        return {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "failed: rc=%d" % res.returncode}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "failed: exceeded %ds on this host" % timeout_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_only:                      # child mode of the cpu_baseline leg
+        print("CPU_BASELINE " + json.dumps(cpu_baseline()), flush=True)
+        return
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from torchrl_amd import dist
+    log("building agent on %s" % dev)
+    agent, col = build_agent(dev, world, rank)
+    col.env.reset()
+    eng = agent.engine()
+    torch.cuda.synchronize()
+    log("warmup x%d" % args.warmup)
+    for e in range(args.warmup):
+        iteration(agent, col, e)
+        torch.cuda.synchronize()
+        log("warmup iteration %d done" % e)
+
+    # HIP events around every launch of the dominant kernel, on the stream it is launched on
+    probes = []
+    eng.probe = probes
+    if dist.initialized():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e in range(args.steps):
+        iteration(agent, col, args.warmup + e)
+    torch.cuda.synchronize()
+    if dist.initialized():
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    log("timed %d iterations in %.3f s" % (args.steps, elapsed))
+    eng.probe = None
+    if dist.initialized():
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce_max_(tmax)
+        elapsed = float(tmax.item())
+
+    if rank != 0:
+        return
+    env_steps = world * N_PER_GPU * T * args.steps
+    grad_ms = [s.elapsed_time(e) for s, e in probes]
+    avg_s = float(np.mean(grad_ms)) * 1e-3 if grad_ms else float("nan")
+    flops = FLOP_PER_SAMPLE * BATCH_PER_GPU
+    achieved = flops / avg_s / 1e12
+    out = {
+        "metric": "env_steps_per_sec_ppo_2048env_halfcheetah_shape",
+        "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PPO cfg2: %d synthetic envs/GPU (17-d obs, 6-d act) x %d-step rollout, GAE, "
+                               "%d opt epochs x %d minibatches of %d, MLP 17-64-64-{6,1} tanh"
+                               % (N_PER_GPU, T, OPT_EPOCHS, N_PER_GPU * T // BATCH_PER_GPU, BATCH_PER_GPU),
+                   "envs_per_gpu": N_PER_GPU, "rollout_steps": T, "batch_per_gpu": BATCH_PER_GPU,
+                   "opt_epochs": OPT_EPOCHS, "exploration_noise": "device Philox4x32-10",
+                   "parallelism": "env-sharded dp%d, RCCL grad all-reduce" % world},
+        "roofline": {"bound": "mfma", "kernel": "ppo_grad_kernel<17,64,6,tanh>", "achieved": achieved,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
+                     "launches_timed": len(grad_ms)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_subprocess()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -166,9 +166,14 @@ typedef struct trl_ppo_batch_t {
 } trl_ppo_batch_t;
 int trl_ppo_partial_stride(int D, int H, int A);
 int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* args, void* stream);
-/* grads: flat [pf grads (P_pf) | vf grads (P_vf)]; info: (16) doubles */
+/* grads: flat [pf grads (P_pf) | vf grads (P_vf)].  info: (16) doubles =
+ *  0 sum_j -min(s1,s2)   1 sum logp   2 sum logp^2   3 max logp   4 -min logp
+ *  5 max ratio   6 -min ratio   7 value-loss sum (local samples; divide by the count)
+ *  8..11 mean / unbiased std / max / min of the clamped logstd (ppo.py:82-85)
+ * pf_params may be NULL (then 8..11 are left untouched). */
 int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg,
-                       int D, int H, int A, float* grads, double* info, void* stream);
+                       int D, int H, int A, const float* pf_params, float* grads, double* info,
+                       void* stream);
 
 /* --- K11: global-norm clip + Adam ------------------------------------------
  * replaces clip_grad_norm_(params, max_norm) + Adam(eps).step()

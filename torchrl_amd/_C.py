@@ -84,7 +84,7 @@ SIGNATURES = {
     "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_minibatch_grad_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p]),
-    "trl_ppo_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trl_ppo_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_clip_adam_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
     "trl_synth_reset_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "trl_gauss_logp_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -215,9 +215,10 @@ def ppo_minibatch_grad(args, device):
     check(lib().trl_ppo_minibatch_grad_f32(C.byref(args), stream_ptr(device)), "trl_ppo_minibatch_grad_f32")
 
 
-def ppo_reduce(partial, scal_partial, n_wg, D, H, A, grads, info):
+def ppo_reduce(partial, scal_partial, n_wg, D, H, A, grads, info, pf_params=None):
     check(lib().trl_ppo_reduce_f32(dev_ptr(partial, name="partial"),
                                    dev_ptr(scal_partial, torch.float64, "scal_partial"), n_wg, D, H, A,
+                                   dev_ptr(pf_params, name="pf_params", allow_none=True),
                                    dev_ptr(grads, name="grads"), dev_ptr(info, torch.float64, "info"),
                                    stream_ptr(partial.device)), "trl_ppo_reduce_f32")
 

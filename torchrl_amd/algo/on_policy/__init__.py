@@ -1,0 +1,3 @@
+from .on_rl_algo import OnRLAlgo
+from .a2c import A2C
+from .ppo import PPO

@@ -1,0 +1,231 @@
+"""PPO on the fused HIP path (reference: torchrl/algo/on_policy/ppo.py:10-160).
+
+Per epoch (`update_per_epoch`, ppo.py:27-39):
+  1. last_value + GAE scan over the rollout (kernels, on_rl_algo.py:22-33);
+  2. linear LR decay for both optimisers, `target_pf <- pf` (utils.py:23-32);
+  3. `opt_epochs` permutations of the time rows from the global numpy RNG -- the
+     reference's index stream, one permutation per pass (on_policy.py:76-78);
+  4. advantage statistics of EVERY minibatch in one launch (trl_adv_stats_f64);
+  5. per minibatch, three launches: fused gradient (critic + actor, fp32 MFMA,
+     row gather fused in), partial fold, global-norm clip + Adam for both nets.
+     Critic and actor are independent networks, so computing both gradients
+     before either step is the same arithmetic as the reference's
+     critic-then-actor order (ppo.py:149-150).
+Nothing is read back until the epoch ends; then one copy fetches the statistics
+of all minibatches and the logger receives the same info dicts, in order.
+
+`update(batch)` keeps the reference's single-minibatch entry point (ppo.py:124-152).
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ... import _C
+from ... import dist
+from ...networks import flatten_into
+from .. import utils as atu
+from .a2c import A2C
+
+_HALF_LOG_2PI_PLUS_HALF = 0.5 + 0.5 * math.log(2 * math.pi)
+
+
+class PPO(A2C):
+    def __init__(self, pf, clip_para=0.2, opt_epochs=10, clipped_value_loss=False, **kwargs):
+        self.target_pf = copy.deepcopy(pf)
+        super().__init__(pf=pf, **kwargs)
+        self.clip_para = clip_para
+        self.opt_epochs = opt_epochs
+        self.clipped_value_loss = clipped_value_loss
+        self.sample_key = ["obs", "acts", "advs", "estimate_returns", "values"]
+        self._engine = None
+
+    @property
+    def networks(self):
+        return [self.pf, self.vf, self.target_pf]
+
+    def engine(self):
+        if self._engine is None:
+            if self.optimizer_class is not optim.Adam:
+                raise _C.TrlError("the fused PPO step implements torch.optim.Adam only")
+            self._engine = _FusedPPO(self)
+        return self._engine
+
+    # ---- epoch ----
+    def _fill_old_logp(self):
+        """log pi_old of every stored (obs, act) under target_pf (ppo.py:54-56), computed once per
+        epoch; skipped when the collector kernel already wrote it with the same parameters."""
+        buf = self.replay_buffer
+        if getattr(buf, "_old_logp_fresh", False):
+            buf._old_logp_fresh = False
+            return
+        rows, n = buf._max_replay_buffer_size, buf.env_nums
+        with torch.no_grad():
+            out = self.target_pf.update(buf._obs.reshape(rows * n, -1), buf._acts.reshape(rows * n, -1))
+        buf._ensure_key("old_logp", (n, 1)).copy_(out["log_prob"].reshape(rows, n, 1))
+
+    def update_per_epoch(self):
+        self.process_epoch_samples()
+        atu.update_linear_schedule(self.pf_optimizer, self.current_epoch, self.num_epochs, self.plr)
+        atu.update_linear_schedule(self.vf_optimizer, self.current_epoch, self.num_epochs, self.vlr)
+        atu.copy_model_params_from_to(self.pf, self.target_pf)
+        self._fill_old_logp()
+        buf = self.replay_buffer
+        passes = [buf.epoch_row_indices(self.batch_size, self.shuffle) for _ in range(self.opt_epochs)]
+        row_idx = np.concatenate(passes, axis=0)                       # (E * n_mb, B // N)
+        tensors = {"obs": buf._obs, "acts": buf._acts, "advs": buf._advs, "rets": buf._estimate_returns,
+                   "old_values": buf._values, "old_logp": buf._old_logp}
+        infos = self.engine().run(tensors, row_idx, buf.env_nums)
+        self.training_update_num += len(infos)
+        for info in infos:
+            self.logger.add_update_info(info)
+
+    # ---- single minibatch (reference entry point) ----
+    def update(self, batch):
+        self.training_update_num += 1
+        dev = self.device
+        as_t = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
+            .to(device=dev, dtype=torch.float32).contiguous()
+        obs, acts = as_t(batch['obs']), as_t(batch['acts'])
+        B = obs.shape[0]
+        if "old_logp" in batch:
+            old_lp = as_t(batch["old_logp"]).reshape(B, 1)
+        else:
+            with torch.no_grad():
+                old_lp = self.target_pf.update(obs, acts)["log_prob"].reshape(B, 1).contiguous()
+        tensors = {"obs": obs.reshape(1, B, -1), "acts": acts.reshape(1, B, -1),
+                   "advs": as_t(batch['advs']).reshape(1, B, 1), "rets": as_t(batch['estimate_returns']).reshape(1, B, 1),
+                   "old_values": as_t(batch['values']).reshape(1, B, 1), "old_logp": old_lp.reshape(1, B, 1)}
+        return self.engine().run(tensors, np.zeros((1, 1), dtype=np.int64), B)[0]
+
+
+class _FusedPPO:
+    """Flat parameter / optimiser-state buffers and the per-minibatch launch sequence."""
+
+    def __init__(self, algo):
+        self.algo = algo
+        pf, vf = algo.pf, algo.vf
+        ps, vs = pf.mlp2_spec(), vf.mlp2_spec()
+        if ps is None or vs is None or not hasattr(pf, "logstd"):
+            raise _C.TrlError("fused PPO needs MLP2 nets and a GuassianContPolicyBasicBias policy")
+        if vs[0] != ps[0] or vs[1] != ps[1] or vs[2] != 1 or vs[3] != ps[3]:
+            raise _C.TrlError("policy %s and value %s must share input, width and activation" % (ps, vs))
+        self.D, self.H, self.A, self.act = ps
+        self.dev = next(pf.parameters()).device
+        if self.dev.type != "cuda":
+            raise _C.TrlError("PPO networks live on %s: the fused path needs a GPU (no CPU path exists)" % self.dev)
+        pf_list = pf._mlp2_param_list() + [pf.logstd]
+        vf_list = vf._mlp2_param_list()
+        self.P_pf = sum(p.numel() for p in pf_list)
+        self.P_vf = sum(p.numel() for p in vf_list)
+        self.flat = flatten_into(pf_list + vf_list)                   # [pf | vf], parameters become views
+        pf._flat, vf._flat = self.flat[:self.P_pf], self.flat[self.P_pf:]
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.grads = torch.zeros_like(self.flat)
+        self.step_count = 0
+        self._alias_optimizer_state(algo.pf_optimizer, pf_list, 0)
+        self._alias_optimizer_state(algo.vf_optimizer, vf_list, self.P_pf)
+        self.p_stride = _C.ppo_partial_stride(self.D, self.H, self.A)
+        self.n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        self.max_wg = 2 * max(1, self.n_cu // 2)
+        self.partial = torch.zeros(self.max_wg, self.p_stride, device=self.dev)
+        self.scal = torch.zeros(self.max_wg, 8, dtype=torch.float64, device=self.dev)
+
+    def _alias_optimizer_state(self, opt, plist, offset):
+        self._opt_steps = getattr(self, "_opt_steps", [])
+        for p in plist:
+            n = p.numel()
+            step = torch.tensor(0.0)
+            opt.state[p] = {"step": step, "exp_avg": self.m[offset:offset + n].view(p.shape),
+                            "exp_avg_sq": self.v[offset:offset + n].view(p.shape)}
+            self._opt_steps.append(step)
+            offset += n
+
+    def _n_wg(self, n_samples):
+        tiles = (n_samples + 31) // 32
+        per_net = max(1, min(self.max_wg // 2, (tiles + 3) // 4))
+        return 2 * per_net
+
+    def run(self, t, row_idx, N):
+        """t: dict of (rows, N, feat) device tensors; row_idx: (K, rows_mb) host int64.
+        Runs K minibatch updates back to back; returns K info dicts (one host sync at the end)."""
+        algo, dev = self.algo, self.dev
+        K, rows_mb = row_idx.shape
+        world = dist.world_size()
+        n_local = rows_mb * N
+        n_global = float(n_local * world)
+        idx_dev = torch.from_numpy(np.ascontiguousarray(row_idx)).to(dev)
+        rows_total = t["advs"].shape[0]
+        raw = torch.zeros(K, 4, dtype=torch.float64, device=dev)
+        _C.adv_stats(t["advs"].reshape(rows_total, N), idx_dev, raw)
+        dist.reduce_adv_raw_(raw)
+        info = torch.zeros(K, 16, dtype=torch.float64, device=dev)
+        norms = torch.zeros(K, 2, device=dev)
+        n_wg = self._n_wg(n_local)
+
+        g = _C.PpoBatchArgs()
+        for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"):
+            setattr(g, k, _C.dev_ptr(t[k], name=k).value)
+        g.rows_mb, g.N, g.n_global = rows_mb, N, n_global
+        g.pf_params, g.vf_params = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.P_pf
+        g.D, g.H, g.A, g.act = self.D, self.H, self.A, self.act
+        g.clip_para, g.entropy_coeff = float(algo.clip_para), float(algo.entropy_coeff)
+        g.clipped_value_loss, g.tanh_action = int(bool(algo.clipped_value_loss)), int(bool(algo.pf.tanh_action))
+        g.partial, g.scal_partial, g.n_wg = self.partial.data_ptr(), self.scal.data_ptr(), n_wg
+
+        a = _C.AdamArgs()
+        a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
+                                                      self.m.data_ptr(), self.v.data_ptr())
+        a.n_groups = 2
+        a.group_sizes[0], a.group_sizes[1] = self.P_pf, self.P_vf
+        a.group_lr[0] = algo.pf_optimizer.param_groups[0]['lr']
+        a.group_lr[1] = algo.vf_optimizer.param_groups[0]['lr']
+        a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = 0.5, 0.9, 0.999, 1e-5, 1.0
+
+        idx_base, raw_base, info_base, norm_base = idx_dev.data_ptr(), raw.data_ptr(), info.data_ptr(), norms.data_ptr()
+        lib, stream = _C.lib(), _C.stream_ptr(dev)
+        import ctypes as C
+        probe = getattr(self, "probe", None)                           # bench.py: HIP events around the grad kernel
+        for k in range(K):
+            g.row_idx = idx_base + 8 * rows_mb * k
+            g.adv_raw = raw_base + 32 * k
+            if probe is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "trl_ppo_minibatch_grad_f32")
+            if probe is not None:
+                ev[1].record()
+                probe.append(ev)
+            _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, self.D, self.H,
+                                            self.A, self.flat.data_ptr(), self.grads.data_ptr(),
+                                            info_base + 128 * k, stream), "trl_ppo_reduce_f32")
+            if world > 1:
+                dist.all_reduce_sum_(self.grads)                       # C1
+            self.step_count += 1
+            a.step_count = self.step_count
+            a.norms_out = norm_base + 8 * k
+            _C.check(lib.trl_clip_adam_f32(C.byref(a), stream), "trl_clip_adam_f32")
+        for s in self._opt_steps:
+            s.fill_(float(self.step_count))
+        dist.reduce_info_(info)
+        return self._infos(raw.cpu().numpy(), info.cpu().numpy(), norms.cpu().numpy(), n_global)
+
+    def _infos(self, raw, info, norms, n):
+        out = []
+        c_ent = float(self.algo.entropy_coeff)
+        for r, i, g in zip(raw, info, norms):
+            adv_var = max((r[1] - r[0] * r[0] / n) / (n - 1), 0.0)
+            lp_var = max((i[2] - i[1] * i[1] / n) / (n - 1), 0.0)
+            ent = self.A * _HALF_LOG_2PI_PLUS_HALF + self.A * i[8]
+            out.append({
+                'advs/mean': r[0] / n, 'advs/std': math.sqrt(adv_var), 'advs/max': r[2], 'advs/min': -r[3],
+                'Training/vf_loss': i[7] / n, 'grad_norm/vf': float(g[1]),
+                'Training/policy_loss': i[0] / n - c_ent * ent,
+                'logprob/mean': i[1] / n, 'logprob/std': math.sqrt(lp_var), 'logprob/max': i[3], 'logprob/min': -i[4],
+                'log_std/mean': i[8], 'log_std/std': i[9], 'log_std/max': i[10], 'log_std/min': i[11],
+                'ratio/max': i[5], 'ratio/min': -i[6], 'grad_norm/pf': float(g[0]),
+            })
+        return out

@@ -383,6 +383,7 @@ __global__ __launch_bounds__(PPO_THREADS, 1) void ppo_grad_kernel(PpoDev a) {
 __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial,
                                                          const double* __restrict__ scal, int n_wg,
                                                          int p_stride, int p_pf, int p_vf,
+                                                         const float* __restrict__ logstd, int n_act,
                                                          float* __restrict__ grads, double* __restrict__ info) {
   const int half = n_wg >> 1;
   const int net = blockIdx.y;
@@ -408,6 +409,17 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict
       double r = 0.0;
       for (int w = 0; w < half; ++w) r += scal[(size_t)(half + w) * 8 + 6];
       info[7] = r;
+      if (logstd) {                                          // log_std/{mean,std,max,min} (ppo.py:82-85)
+        double sm = 0, sq = 0, mx = -INFINITY, mn = INFINITY;
+        for (int o = 0; o < n_act; ++o) {
+          const double v = fmin(fmax((double)logstd[o], -20.0), 2.0);
+          sm += v; sq += v * v; mx = fmax(mx, v); mn = fmin(mn, v);
+        }
+        const double mean = sm / n_act;
+        info[8] = mean;
+        info[9] = n_act > 1 ? sqrt(fmax((sq - sm * mean) / (n_act - 1), 0.0)) : NAN;
+        info[10] = mx; info[11] = mn;
+      }
     }
   }
 }
@@ -534,14 +546,15 @@ extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream
 }
 
 extern "C" int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg, int D, int H,
-                                  int A, float* grads, double* info, void* stream) {
+                                  int A, const float* pf_params, float* grads, double* info, void* stream) {
   TRL_REQUIRE(partial && scal_partial && grads && info, "null pointer");
   TRL_REQUIRE(n_wg >= 2 && (n_wg % 2) == 0, "n_wg must be even and >= 2");
   const int ps = trl_ppo_partial_stride(D, H, A);
   if (ps < 0) return ps;
   const int p_pf = H * D + H + H * H + H + A * H + A + A, p_vf = H * D + H + H * H + H + H + 1;
   hipLaunchKernelGGL(ppo_reduce_kernel, dim3(trl_ceil_div(ps, 256), 2), dim3(256), 0, (hipStream_t)stream,
-                     partial, scal_partial, n_wg, ps, p_pf, p_vf, grads, info);
+                     partial, scal_partial, n_wg, ps, p_pf, p_vf,
+                     pf_params ? pf_params + (p_pf - A) : (const float*)nullptr, A, grads, info);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }

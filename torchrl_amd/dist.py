@@ -1,0 +1,78 @@
+"""Multi-GPU glue: one process per GPU, envs sharded by index, RCCL collectives
+through torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" in CPU tests).
+
+The reference has no distributed path.  What makes sharding exact here is its
+minibatch definition -- `B // N` time rows x ALL N envs
+(torchrl/replay_buffers/on_policy.py:75-88): when every rank draws the same row
+indices (same numpy seed) and owns envs [rank*N/G, (rank+1)*N/G), the union of
+the rank-local minibatches IS the single-process minibatch.  So the data path
+needs no collective; only three small reductions exist:
+  C1  flat gradient SUM (per-sample grads already carry 1/n_global),
+  C2  advantage statistics {sum, sumsq} SUM and {max, -min} MAX, once per epoch,
+  C3  logging statistics, once per epoch.
+"""
+import torch
+import torch.distributed as td
+
+
+def initialized():
+    return td.is_available() and td.is_initialized()
+
+
+def world_size():
+    return td.get_world_size() if initialized() else 1
+
+
+def rank():
+    return td.get_rank() if initialized() else 0
+
+
+def shard(total_envs, world=None, r=None):
+    """(offset, count) of the env-index block owned by rank r."""
+    world = world_size() if world is None else world
+    r = rank() if r is None else r
+    if total_envs % world != 0:
+        raise ValueError("total env count %d is not divisible by world size %d" % (total_envs, world))
+    per = total_envs // world
+    return r * per, per
+
+
+def all_reduce_sum_(t):
+    if initialized() and world_size() > 1:
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_max_(t):
+    if initialized() and world_size() > 1:
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+    return t
+
+
+def reduce_adv_raw_(raw):
+    """raw: (K, 4) float64 {sum, sumsq, max, -min} -> global statistics (C2)."""
+    if initialized() and world_size() > 1:
+        s = raw[:, :2].contiguous()
+        m = raw[:, 2:].contiguous()
+        all_reduce_sum_(s)
+        all_reduce_max_(m)
+        raw[:, :2] = s
+        raw[:, 2:] = m
+    return raw
+
+
+# columns of the per-update info rows (include/trl_hip.h, trl_ppo_reduce_f32)
+INFO_SUM_COLS = [0, 1, 2, 7]
+INFO_MAX_COLS = [3, 4, 5, 6]
+
+
+def reduce_info_(info):
+    """info: (K, 16) float64 per-update statistics -> global (C3)."""
+    if initialized() and world_size() > 1:
+        s = info[:, INFO_SUM_COLS].contiguous()
+        m = info[:, INFO_MAX_COLS].contiguous()
+        all_reduce_sum_(s)
+        all_reduce_max_(m)
+        info[:, INFO_SUM_COLS] = s
+        info[:, INFO_MAX_COLS] = m
+    return info

@@ -1,0 +1,82 @@
+"""Device-resident time-major ring buffer with the reference's interface
+(torchrl/replay_buffers/base.py:4-54).
+
+Layout: one tensor per key, ``_<key>[rows, N, feat]`` with
+``rows = max_replay_buffer_size // env_nums`` (base.py:14), fp32 on the GPU
+(the reference allocates float64 numpy, base.py:26-27; uint8 frames stay uint8).
+`_top` / `_size` are host integers exactly as in the reference.  The uniform
+sample draws its row indices with the legacy global numpy RNG
+(`np.random.randint(0, size, B // N)`, base.py:44) so the index stream is
+bit-exact, uploads the few int64s and gathers on the GPU (trl_gather_rows_*).
+"""
+import numpy as np
+import torch
+
+from .. import _C
+
+
+class BaseReplayBuffer:
+    def __init__(self, max_replay_buffer_size, env_nums=1, time_limit_filter=False, device=None):
+        self.env_nums = env_nums
+        self._max_replay_buffer_size = max_replay_buffer_size // self.env_nums
+        self._top = 0
+        self._size = 0
+        self.time_limit_filter = time_limit_filter
+        self.device = torch.device(device) if device is not None else None
+        self._keys = []
+
+    # ---- storage ----
+    def _device(self):
+        if self.device is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        return self.device
+
+    def _ensure_key(self, key, feat_shape, dtype=torch.float32):
+        """Allocate `_key[rows, *feat_shape]` on first use (reference: lazily in add_sample)."""
+        name = "_" + key
+        if not hasattr(self, name):
+            setattr(self, name, torch.zeros((self._max_replay_buffer_size,) + tuple(feat_shape),
+                                            dtype=dtype, device=self._device()))
+            self._keys.append(key)
+        return getattr(self, name)
+
+    def _as_row(self, value):
+        if isinstance(value, torch.Tensor):
+            t = value
+        else:
+            t = torch.as_tensor(np.asarray(value))
+        if t.dtype != torch.uint8:
+            t = t.to(torch.float32)
+        return t
+
+    def add_sample(self, sample_dict, **kwargs):
+        for key, value in sample_dict.items():
+            row = self._as_row(value)
+            store = self._ensure_key(key, row.shape, row.dtype)
+            store[self._top].copy_(row, non_blocking=True)
+        self._advance()
+
+    def terminate_episode(self):
+        pass
+
+    def _advance(self, steps=1):
+        self._top = (self._top + steps) % self._max_replay_buffer_size
+        self._size = min(self._size + steps, self._max_replay_buffer_size)
+
+    # ---- sampling ----
+    def _rows_per_batch(self, batch_size):
+        assert batch_size % self.env_nums == 0, "batch size should be dividable by env_nums"
+        return batch_size // self.env_nums
+
+    def _gather(self, key, idx_dev):
+        block = _C.gather_rows(getattr(self, "_" + key), idx_dev)
+        return block.reshape((block.shape[0] * self.env_nums,) + tuple(block.shape[2:]))
+
+    def random_batch(self, batch_size, sample_key):
+        nrows = self._rows_per_batch(batch_size)
+        indices = np.random.randint(0, self.num_steps_can_sample(), nrows)
+        idx_dev = torch.from_numpy(indices.astype(np.int64)).to(self._device(), non_blocking=True)
+        return {key: self._gather(key, idx_dev) for key in sample_key}
+
+    def num_steps_can_sample(self):
+        return self._size

@@ -1,0 +1,127 @@
+"""Logger with the reference's interface (torchrl/utils/logger.py:17-158):
+`add_update_info(dict)` accumulates per-update scalars, `add_epoch_info(...)`
+emits mean/std/max/min of each over the epoch plus the epoch scalars to stdout
+(tabulate if installed) and `log.csv`; tensorboardX / wandb / git are used only
+if importable (the reference hard-requires them and `params['project']`)."""
+import csv
+import json
+import logging
+import os
+import shutil
+import sys
+
+import numpy as np
+
+try:
+    from tabulate import tabulate
+except Exception:                                           # pragma: no cover
+    tabulate = None
+try:
+    import tensorboardX
+except Exception:
+    tensorboardX = None
+try:
+    import wandb
+except Exception:
+    wandb = None
+
+
+def _jsonable(obj):
+    try:
+        json.dumps(obj)
+        return obj
+    except TypeError:
+        if isinstance(obj, dict):
+            return {k: _jsonable(v) for k, v in obj.items()}
+        return repr(obj)
+
+
+class Logger:
+    def __init__(self, experiment_id, env_name, seed, params, log_dir="./log", overwrite=False):
+        self.logger = logging.getLogger("{}_{}_{}".format(experiment_id, env_name, str(seed)))
+        self.logger.handlers = []
+        self.logger.propagate = False
+        handler = logging.StreamHandler(sys.stdout)
+        handler.setFormatter(logging.Formatter("%(asctime)s %(threadName)s %(levelname)s: %(message)s"))
+        handler.setLevel(logging.INFO)
+        self.logger.addHandler(handler)
+        self.logger.setLevel(logging.INFO)
+
+        self.work_dir = os.path.join(log_dir, experiment_id, env_name, str(seed))
+        if os.path.exists(self.work_dir):
+            assert overwrite, "Experiment Exists and Did not set overwrite"
+            shutil.rmtree(self.work_dir)
+        os.makedirs(self.work_dir, exist_ok=True)
+        self.tf_writer = tensorboardX.SummaryWriter(self.work_dir) if tensorboardX is not None else None
+        self.csv_file_path = os.path.join(self.work_dir, 'log.csv')
+        self.update_count = 0
+        self.stored_infos = {}
+        with open(os.path.join(self.work_dir, 'params.json'), 'w') as f:
+            json.dump(_jsonable(params), f, indent=2)
+        self.logger.info("Experiment Name:{}".format(experiment_id))
+        params["name_combine"] = "{}_{}".format(experiment_id, env_name)
+        self.use_wb = wandb is not None and params.get('project') is not None
+        if self.use_wb:
+            wandb.init(project=params['project'], name="{}_{}_{}".format(experiment_id, env_name, str(seed)),
+                       group="{}_{}".format(experiment_id, env_name), config=_jsonable(params))
+
+    def finish(self):
+        if self.use_wb:
+            wandb.finish()
+        if self.tf_writer is not None:
+            self.tf_writer.close()
+
+    def log(self, info):
+        self.logger.info(info)
+
+    def add_update_info(self, infos):
+        for key, value in infos.items():
+            self.stored_infos.setdefault(key, []).append(value)
+        self.update_count += 1
+
+    def add_epoch_info(self, epoch_num, total_frames, total_time, infos, csv_write=True):
+        if csv_write and epoch_num == 0:
+            self._csv_titles = ["EPOCH", "Time Consumed", "Total Frames"]
+        self.logger.info("EPOCH:{}".format(epoch_num))
+        self.logger.info("Time Consumed:{}s".format(total_time))
+        self.logger.info("Total Frames:{}s".format(total_frames))
+        row = [epoch_num, total_time, total_frames]
+        table = []
+        scalars = {}
+        for key, value in infos.items():
+            scalars[key] = value
+            table.append([key, "{:.5f}".format(float(value))])
+            if csv_write:
+                if epoch_num == 0:
+                    self._csv_titles.append(key)
+                row.append(value)
+        stat_table = []
+        for key, values in self.stored_infos.items():
+            arr = np.asarray(values, dtype=np.float64)
+            stats = {"Mean": arr.mean(), "Std": arr.std(), "Max": arr.max(), "Min": arr.min()}
+            stat_table.append([key] + ["{:.5f}".format(v) for v in stats.values()])
+            for name, v in stats.items():
+                scalars["{}_{}".format(key, name)] = v
+                if csv_write:
+                    if epoch_num == 0:
+                        self._csv_titles.append("{}_{}".format(key, name))
+                    row.append(v)
+        if self.tf_writer is not None:
+            for key, v in scalars.items():
+                self.tf_writer.add_scalar(key, v, total_frames)
+        if self.use_wb:
+            wandb.log(scalars, step=total_frames)
+        if tabulate is not None:
+            self.logger.info("\n" + tabulate(table))
+            if stat_table:
+                self.logger.info("\n" + tabulate(stat_table, ["Name", "Mean", "Std", "Max", "Min"]))
+        else:
+            for line in table + stat_table:
+                self.logger.info(" ".join(str(x) for x in line))
+        if csv_write:
+            with open(self.csv_file_path, 'a') as f:
+                writer = csv.writer(f)
+                if epoch_num == 0:
+                    writer.writerow(self._csv_titles)
+                writer.writerow(row)
+        self.stored_infos = {}
