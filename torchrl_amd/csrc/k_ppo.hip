@@ -21,17 +21,25 @@
 #include "trl_common.h"
 #include "trl_mlp.h"
 
-#define PPO_THREADS 256
-#define PPO_WAVES 4
+#define PPO_THREADS 512
+#define PPO_WAVES 8
+#define PPO_PAIRS 4
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_sched_barrier(0);
 }
-// keep the scheduler from hoisting a later phase's LDS weight fetches over this point
-// (it otherwise front-loads hundreds of ds_reads and spills)
-#define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Two waves of a pair rendezvous on an LDS counter (the other pairs of the workgroup keep
+// running: a whole-workgroup s_barrier would put all 8 waves in lockstep and the MFMA phases of
+// one pair could no longer overlap the VALU/LDS phases of the pair sharing its SIMDs).
+__device__ __forceinline__ void pair_sync(int* cnt, int& expect, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  expect += 2;
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 struct PpoDev {
   const float *obs, *acts, *advs, *rets, *old_values, *old_logp;
@@ -48,53 +56,51 @@ struct PpoDev {
 };
 
 template <int D, int H, int A> struct PpoShape {
-  static constexpr int NT = H / 32;
+  static_assert(H == 64, "pair-cooperative kernel: two 32-feature tiles, one per wave of a pair");
   static constexpr int KS = ksteps_for(D);
-  static constexpr int XS = align4(32 * D);            // x tile, row-major [32][D]
-  static constexpr int DO = 32 * 8;                    // dout stage [32][8]
-  static constexpr int TS = H * TRL_TLD;               // transpose scratch
-  static constexpr int WAVE_SCR = align4(TS) + XS + DO;
+  static constexpr int TS = H * TRL_TLD;               // (64 x 33) staging tensor shared by the pair
+  static constexpr int PT = 32 * TRL_TLD;              // wave-private (32 x 33) tile
+  static constexpr int NSTAT = 7 + 2 * A;              // lp sum/sumsq/max/-min, ratio max/-min, loss, db3[A], dlogstd[A]
+  // pair scratch: H1s | DZ2s | P[2] | douts[32][8] | headp[2][8][32] | stats[NSTAT][32] | counter
+  static constexpr int O_H1 = 0, O_DZ2 = TS, O_P = 2 * TS, O_DO = O_P + 2 * PT,
+                       O_HP = O_DO + 256, O_ST = O_HP + 512, O_CNT = O_ST + align4(NSTAT * 32),
+                       PAIR_SCR = O_CNT + 4;
   static constexpr int PAR = (MlpLds<D, H, A>::SIZE > MlpLds<D, H, 1>::SIZE) ? MlpLds<D, H, A>::SIZE : MlpLds<D, H, 1>::SIZE;
   static constexpr int P_PF = MlpFlat<D, H, A>::P_PF, P_VF = MlpFlat<D, H, 1>::P_VF;
   static constexpr int P_STRIDE = ((P_PF > P_VF ? P_PF : P_VF) + 63) & ~63;
-  static constexpr int SCR_ALL = PPO_WAVES * WAVE_SCR;
+  static constexpr int SCR_ALL = PPO_PAIRS * PAIR_SCR;
   static constexpr int LDS_FLOATS = align4(PAR) + (SCR_ALL > P_STRIDE ? SCR_ALL : P_STRIDE);
 };
 
-// One network (policy if O == A and IS_PF, value if O == 1) over this workgroup's tiles.
+// One network (policy or value) over this workgroup's tiles.  A pair of waves owns a 32-sample
+// tile; wave `mo` of the pair computes the 32 hidden features [32mo, 32mo+32) of every layer,
+// its half of the weight gradients, and exchanges activations with its partner through LDS.
 template <int D, int H, int A, int ACT, bool IS_PF>
 __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
   constexpr int O = IS_PF ? A : 1;
   using S = PpoShape<D, H, A>;
   using L = MlpLds<D, H, O>;
   using F = MlpFlat<D, H, O>;
-  constexpr int NT = H / 32, KS = ksteps_for(D);
+  constexpr int KS = ksteps_for(D);
   constexpr int PARF = align4(S::PAR);
   constexpr int NQ = (O + 3) / 4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 31, j = i, hi = lane >> 5;
-  float* sp = lds;                                            // parameters
-  float* scr = lds + PARF + wave * S::WAVE_SCR;               // wave-private scratch
-  float* T = scr;
-  float* xs = scr + align4(S::TS);
-  float* douts = xs + S::XS;
+  const int pair = wave >> 1, mo0 = wave & 1;
+  const int i0 = lane & 31, hi0 = lane >> 5;
+  float* sp = lds;                                            // parameters (shared by the 4 pairs)
+  int* cnt = reinterpret_cast<int*>(lds + PARF + pair * S::PAIR_SCR + S::O_CNT);
 
   L::load(sp, IS_PF ? a.pf_params : a.vf_params, IS_PF, tid, PPO_THREADS);
-  __syncthreads();
-
-  // policy constants
-  float ls[O], inv_var[O], ls_pass[O];
-  if constexpr (IS_PF) {
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-      const float raw = sp[L::LS + o];
-      ls[o] = fminf(fmaxf(raw, -20.0f), 2.0f);               // continuous_policy.py:8-9,185
-      ls_pass[o] = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;
-      const float sd = __expf(ls[o]);
-      inv_var[o] = 1.0f / (sd * sd);
-    }
+  if (lane == 0 && mo0 == 0) *cnt = 0;
+  {
+    float* st0 = lds + PARF + pair * S::PAIR_SCR + S::O_ST;  // per-lane statistic slots, [k][32]
+    if (mo0 == 0 && hi0 == 0)
+      for (int k = 0; k < S::NSTAT; ++k) st0[k * 32 + i0] = (k >= 2 && k <= 5) ? -INFINITY : 0.0f;
   }
+  __syncthreads();
+  int expect = 0;
+
   // advantage normalisation constants (ppo.py:141-147): mean, unbiased std
   const double ng = a.n_global;
   const double adv_mean = a.adv_raw[0] / ng;
@@ -103,212 +109,242 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
   const float adv_rstd = 1.0f / ((float)sqrt(fmax(adv_var, 0.0)) + 1e-5f);
   const float inv_b = (float)(1.0 / ng);
 
-  // gradient accumulators (lane = input feature i, reg r = output feature rowmap(r,hi) of tile ma)
-  f32x16 gW2[NT][NT], gW1[NT];
-  float gW3[O][NT], gb1[NT], gb2[NT], gb3[O], gls[O];
+  // this wave's share of the gradient: rows (output features) [32mo, 32mo+32) of W2^T / W1^T
+  f32x16 gW2[2], gW1;
+  float gW3[O], gb1 = 0.f, gb2 = 0.f;
+  gW2[0] = zero_tile(); gW2[1] = zero_tile(); gW1 = zero_tile();
 #pragma unroll
-  for (int ma = 0; ma < NT; ++ma) {
-    gW1[ma] = zero_tile(); gb1[ma] = 0.f; gb2[ma] = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < NT; ++mb) gW2[ma][mb] = zero_tile();
-  }
-#pragma unroll
-  for (int o = 0; o < O; ++o) {
-    gb3[o] = 0.f; gls[o] = 0.f;
-#pragma unroll
-    for (int m = 0; m < NT; ++m) gW3[o][m] = 0.f;
-  }
-  // scalar statistics (lanes hi == 0 only)
-  double st_sum = 0.0, st_sq = 0.0, st_loss = 0.0;
-  float st_max = -INFINITY, st_nmin = -INFINITY, st_rmax = -INFINITY, st_nrmin = -INFINITY;
+  for (int o = 0; o < O; ++o) gW3[o] = 0.f;
+  // scalar statistics, db3 and dlogstd are touched once per tile by 32 lanes only: they live in
+  // per-lane LDS slots (wave mo == 0, lanes hi == 0) instead of registers
 
   const int B = a.rows_mb * a.N;
   const int n_tiles = (B + 31) / 32;
   const bool contig = (a.N % 32) == 0;
+  const bool stat_lane = (mo0 == 0 && hi0 == 0);
 
-  for (int tile = wg_in_net * PPO_WAVES + wave; tile < n_tiles; tile += n_wg_net * PPO_WAVES) {
+  for (int tile = wg_in_net * PPO_PAIRS + pair; tile < n_tiles; tile += n_wg_net * PPO_PAIRS) {
+    // Launder the lane coordinates once per tile: every LDS address below derives from them, and
+    // without this LICM hoists ~100 loop-invariant addresses out of the tile loop and spills them.
+    int i = i0, hi = hi0, mo = mo0, scr_off = PARF + pair * S::PAIR_SCR;
+    asm volatile("" : "+v"(i), "+v"(hi), "+v"(mo), "+v"(scr_off));
+    const int j = i, mx = mo ^ 1;
+    float* scr = lds + scr_off;
+    float* H1s = scr + S::O_H1;
+    float* DZ2s = scr + S::O_DZ2;
+    float* P = scr + S::O_P + mo * S::PT;                     // wave private
+    float* douts = scr + S::O_DO;
+    float* headp = scr + S::O_HP;
     const int s0 = tile * 32;
     const int s = s0 + j;
     const bool valid = s < B;
-    // flat (row, env) position of this lane's sample in the (rows, N, feat) tensors
-    int64_t pos = 0;
+    int64_t pos = 0, pos0 = 0;                                // (row, env) cell of this lane's / the tile's first sample
     if (valid) {
       const int r = s / a.N, e = s - r * a.N;
       pos = (a.row_idx ? a.row_idx[r] : (int64_t)r) * a.N + e;
     }
-    // ---- stage the x tile (row-major [32][D]) ----
     if (contig) {
       const int r0 = s0 / a.N, e0 = s0 - r0 * a.N;
-      const float* src = a.obs + ((a.row_idx ? a.row_idx[r0] : (int64_t)r0) * a.N + e0) * D;
-      for (int e = lane; e < 32 * D; e += 64) xs[e] = src[e];
-    } else {
-      for (int e = lane; e < 32 * D; e += 64) {
-        const int sj = e / D, k = e - sj * D;
-        const int64_t p = __shfl(pos, sj, 64);
-        xs[e] = (s0 + sj < B) ? a.obs[p * D + k] : 0.0f;
-      }
+      pos0 = (a.row_idx ? a.row_idx[r0] : (int64_t)r0) * a.N + e0;
     }
-    wave_lds_sync();
+    float* st = scr + S::O_ST;
+    // ---- x^T operand straight from HBM/L2: lane (sample j, hi) holds features rowmap(q, hi) ----
     float xb[KS];
 #pragma unroll
-    for (int q = 0; q < KS; ++q) { const int k = rowmap(q, hi); xb[q] = (k < D) ? xs[j * D + k] : 0.0f; }
+    for (int q = 0; q < KS; ++q) { const int k = rowmap(q, hi); xb[q] = (valid && k < D) ? a.obs[pos * D + k] : 0.0f; }
 
-    // ---- forward ----
-    f32x16 h1[NT], h2[NT];
-#pragma unroll
-    for (int mo = 0; mo < NT; ++mo)
-      h1[mo] = act_tile<ACT>(layer1_tile<D, L::LD1, KS>(bias_tile(sp + L::B1 + 32 * mo, hi), sp + L::W1, mo, xb, i, hi));
-    PHASE_FENCE();
-#pragma unroll
-    for (int mo = 0; mo < NT; ++mo) {
-      h2[mo] = act_tile<ACT>(layer_tile<NT, L::LD2>(bias_tile(sp + L::B2 + 32 * mo, hi), sp + L::W2, mo, h1, i, hi));
-      PHASE_FENCE();
+    // ---- forward layer 1, own feature tile ----
+    const f32x16 h1 = act_tile<ACT>(layer1_tile<D, L::LD1, KS>(bias_tile(sp + L::B1 + 32 * mo, hi), sp + L::W1, mo, xb, i, hi));
+    pair_sync(cnt, expect, lane);                             // partner is done with the previous tile's H1s / DZ2s
+    tile_store_T1(H1s, mo, h1, j, hi);
+    pair_sync(cnt, expect, lane);
+
+    // ---- forward layer 2: own half from registers, partner's half from LDS ----
+    f32x16 h2;
+    {
+      const f32x16 h1x = tile_load_T1(H1s, mx, j, hi);
+      f32x16 acc = bias_tile(sp + L::B2 + 32 * mo, hi);
+      acc = layer_tile_1src<L::LD2>(acc, sp + L::W2, mo, mo, h1, i, hi);
+      acc = layer_tile_1src<L::LD2>(acc, sp + L::W2, mo, mx, h1x, i, hi);
+      h2 = act_tile<ACT>(acc);
     }
-    float out[O];
-    head_fwd<NT, H, O>(sp + L::W3, sp + L::B3, h2, hi, out);
-    PHASE_FENCE();
+    // partial head over the own 32 features
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      float p = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sp + L::W3 + o * H + 32 * mo + 8 * q + 4 * hi);
+        p = fmaf(w[0], h2[4 * q + 0], p); p = fmaf(w[1], h2[4 * q + 1], p);
+        p = fmaf(w[2], h2[4 * q + 2], p); p = fmaf(w[3], h2[4 * q + 3], p);
+      }
+      p += __shfl_xor(p, 32, 64);
+      if (hi == 0) headp[(mo * 8 + o) * 32 + j] = p;
+    }
+    tile_store_T1(P, 0, h2, j, hi);                           // own H2 tile, for dW3
+    pair_sync(cnt, expect, lane);
 
-    // ---- loss and d(loss)/d(out) ----
+    // ---- loss and d(loss)/d(out) (both waves compute it; wave 0 keeps the statistics) ----
     float dout[O];
-    if constexpr (IS_PF) {
-      const float advn = valid ? (a.advs[pos] - adv_mu) * adv_rstd : 0.0f;
-      const float lp_old = valid ? a.old_logp[pos] : 0.0f;
-      float zc[O];
-      float lp = 0.0f;
+    {
+      float out[O];
 #pragma unroll
-      for (int o = 0; o < O; ++o) {
-        const float act = valid ? a.acts[pos * O + o] : 0.0f;
-        float pre = act, corr = 0.0f;
-        if (a.tanh_action) {                                   // distribution.py:40-45
-          pre = 0.5f * logf((1.0f + act) / (1.0f - act));
-          corr = logf(1.0f - act * act + 1e-6f);
+      for (int o = 0; o < O; ++o) out[o] = headp[o * 32 + j] + headp[(8 + o) * 32 + j] + sp[L::B3 + o];
+      if constexpr (IS_PF) {
+        const float advn = valid ? (a.advs[pos] - adv_mu) * adv_rstd : 0.0f;
+        const float lp_old = valid ? a.old_logp[pos] : 0.0f;
+        float zc[O], inv_var[O];
+        float lp = 0.0f;
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+          const float ls = fminf(fmaxf(sp[L::LS + o], -20.0f), 2.0f);   // continuous_policy.py:8-9,185
+          inv_var[o] = __expf(-2.0f * ls);
+          const float act = valid ? a.acts[pos * O + o] : 0.0f;
+          float pre = act, corr = 0.0f;
+          if (a.tanh_action) {                                 // distribution.py:40-45
+            pre = 0.5f * logf((1.0f + act) / (1.0f - act));
+            corr = logf(1.0f - act * act + 1e-6f);
+          }
+          zc[o] = pre - out[o];
+          lp += -(zc[o] * zc[o]) * 0.5f * inv_var[o] - ls - 0.91893853320467274f - corr;
         }
-        zc[o] = pre - out[o];
-        lp += -(zc[o] * zc[o]) * 0.5f * inv_var[o] - ls[o] - 0.91893853320467274f - corr;
-      }
-      const float ratio = __expf(lp - lp_old);
-      const float s1 = ratio * advn;
-      const float s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
-      const float g_lp = (valid && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
+        const float ratio = __expf(lp - lp_old);
+        const float s1 = ratio * advn;
+        const float s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
+        const float g_lp = (valid && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
 #pragma unroll
-      for (int o = 0; o < O; ++o) {
-        dout[o] = g_lp * zc[o] * inv_var[o];
-        if (hi == 0 && valid)
-          gls[o] += ls_pass[o] * (g_lp * (zc[o] * zc[o] * inv_var[o] - 1.0f) - a.entropy_coeff * inv_b);
+        for (int o = 0; o < O; ++o) {
+          dout[o] = g_lp * zc[o] * inv_var[o];
+          if (stat_lane && valid) {
+            const float raw = sp[L::LS + o];                    // clamp passes gradient inside [-20, 2] only
+            const float pass = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;
+            st[(7 + A + o) * 32 + j] += pass * (g_lp * (zc[o] * zc[o] * inv_var[o] - 1.0f) - a.entropy_coeff * inv_b);
+          }
+        }
+        if (stat_lane && valid) {
+          st[0 * 32 + j] += lp; st[1 * 32 + j] = fmaf(lp, lp, st[1 * 32 + j]); st[6 * 32 + j] -= fminf(s1, s2);
+          st[2 * 32 + j] = fmaxf(st[2 * 32 + j], lp); st[3 * 32 + j] = fmaxf(st[3 * 32 + j], -lp);
+          st[4 * 32 + j] = fmaxf(st[4 * 32 + j], ratio); st[5 * 32 + j] = fmaxf(st[5 * 32 + j], -ratio);
+        }
+      } else {
+        const float v = out[0];
+        const float R = valid ? a.rets[pos] : 0.0f;
+        float dv, l;
+        if (a.clipped_value_loss) {                            // ppo.py:104-111
+          const float vo = valid ? a.old_values[pos] : 0.0f;
+          const float dc = v - vo;
+          const float vc = vo + fminf(fmaxf(dc, -a.clip_para), a.clip_para);
+          const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+          const float w1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), w2 = 1.0f - w1;
+          const float pass = (dc >= -a.clip_para && dc <= a.clip_para) ? 1.0f : 0.0f;
+          l = 0.5f * fmaxf(l1, l2);
+          dv = inv_b * (w1 * (v - R) + w2 * pass * (vc - R));
+        } else {                                               // nn.MSELoss, a2c.py:43
+          l = (v - R) * (v - R);
+          dv = 2.0f * (v - R) * inv_b;
+        }
+        dout[0] = valid ? dv : 0.0f;
+        if (stat_lane && valid) st[6 * 32 + j] += l;
       }
-      if (hi == 0 && valid) {
-        st_sum += (double)lp; st_sq += (double)lp * (double)lp; st_loss += (double)(-fminf(s1, s2));
-        st_max = fmaxf(st_max, lp); st_nmin = fmaxf(st_nmin, -lp);
-        st_rmax = fmaxf(st_rmax, ratio); st_nrmin = fmaxf(st_nrmin, -ratio);
-      }
-    } else {
-      const float v = out[0];
-      const float R = valid ? a.rets[pos] : 0.0f;
-      float dv, l;
-      if (a.clipped_value_loss) {                              // ppo.py:104-111
-        const float vo = valid ? a.old_values[pos] : 0.0f;
-        const float dc = v - vo;
-        const float vc = vo + fminf(fmaxf(dc, -a.clip_para), a.clip_para);
-        const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
-        const float w1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), w2 = 1.0f - w1;
-        const float pass = (dc >= -a.clip_para && dc <= a.clip_para) ? 1.0f : 0.0f;
-        l = 0.5f * fmaxf(l1, l2);
-        dv = inv_b * (w1 * (v - R) + w2 * pass * (vc - R));
-      } else {                                                 // nn.MSELoss, a2c.py:43
-        l = (v - R) * (v - R);
-        dv = 2.0f * (v - R) * inv_b;
-      }
-      dout[0] = valid ? dv : 0.0f;
-      if (hi == 0 && valid) st_loss += (double)l;
     }
+    if (stat_lane) {
 #pragma unroll
-    for (int o = 0; o < O; ++o) if (hi == 0) gb3[o] += dout[o];
-
-    // ---- backward through the head ----
-    PHASE_FENCE();
-    f32x16 dz2[NT];
-    head_bwd<NT, H, O>(sp + L::W3, dout, hi, dz2);
-#pragma unroll
-    for (int m = 0; m < NT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dz2[m][r] *= act_grad<ACT>(h2[m][r]);
-
-    // dW3[o][f] += sum_j dout[o][j] H2[j][f]  -- needs H2 with lane = feature
-    tile_store_T<NT>(T, h2, j, hi);
-    if (hi == 0) {
+      for (int o = 0; o < O; ++o) st[(7 + o) * 32 + j] += dout[o];
 #pragma unroll
       for (int o = 0; o < 4 * NQ; ++o) douts[j * 8 + o] = (o < O) ? dout[o] : 0.0f;
     }
-    wave_lds_sync();
+
+    // ---- backward through the head, own features: dZ2 = (W3^T dout) * act'(H2) ----
+    f32x16 dz2;
 #pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      const f32x16 h2n = tile_load_N(T, m, i, hi);
+    for (int q = 0; q < 4; ++q) {
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+      for (int o = 0; o < O; ++o) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sp + L::W3 + o * H + 32 * mo + 8 * q + 4 * hi);
+        d0 = fmaf(w[0], dout[o], d0); d1 = fmaf(w[1], dout[o], d1);
+        d2 = fmaf(w[2], dout[o], d2); d3 = fmaf(w[3], dout[o], d3);
+      }
+      dz2[4 * q + 0] = d0 * act_grad<ACT>(h2[4 * q + 0]); dz2[4 * q + 1] = d1 * act_grad<ACT>(h2[4 * q + 1]);
+      dz2[4 * q + 2] = d2 * act_grad<ACT>(h2[4 * q + 2]); dz2[4 * q + 3] = d3 * act_grad<ACT>(h2[4 * q + 3]);
+    }
+    tile_store_T1(DZ2s, mo, dz2, j, hi);
+    pair_sync(cnt, expect, lane);
+
+    // ---- dW3[o][own f] += sum_s dout[o][s] H2[s][f]  (lane = feature) ----
+    {
+      const f32x16 h2n = tile_load_N(P, 0, i, hi);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const f32x4 d = *reinterpret_cast<const f32x4*>(douts + rowmap(r, hi) * 8 + 4 * q);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) if (4 * q + c < O) gW3[4 * q + c][m] = fmaf(h2n[r], d[c], gW3[4 * q + c][m]);
+          for (int c = 0; c < 4; ++c) if (4 * q + c < O) gW3[4 * q + c] = fmaf(h2n[r], d[c], gW3[4 * q + c]);
         }
       }
     }
-    wave_lds_sync();
-
-    // ---- dH1^T = W2^T dZ2^T, dZ1 = dH1 * act'(H1) ----
-    PHASE_FENCE();
-    f32x16 dz1[NT];
+    // ---- dH1^T (own rows) = W2^T dZ2^T ; dZ1 = dH1 * act'(H1) ----
+    f32x16 dz1;
+    {
+      const f32x16 dz2x = tile_load_T1(DZ2s, mx, j, hi);
+      f32x16 acc = zero_tile();
+      acc = layer_tile_wT_1src<L::LD2>(acc, sp + L::W2, mo, mo, dz2, i, hi);
+      acc = layer_tile_wT_1src<L::LD2>(acc, sp + L::W2, mo, mx, dz2x, i, hi);
 #pragma unroll
-    for (int mo = 0; mo < NT; ++mo) {
-      dz1[mo] = layer_tile_wT<NT, L::LD2>(zero_tile(), sp + L::W2, mo, dz2, i, hi);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dz1[mo][r] *= act_grad<ACT>(h1[mo][r]);
+      for (int r = 0; r < 16; ++r) dz1[r] = acc[r] * act_grad<ACT>(h1[r]);
     }
+    wave_lds_sync();                                          // P: H2 reads above precede the dZ1 writes below
+    tile_store_T1(P, 0, dz1, j, hi);
+    wave_lds_sync();
 
-    // ---- dW2^T[j_out][k_in] += sum_s dZ2[s][j_out] H1[s][k_in] ----
-    PHASE_FENCE();
-    f32x16 h1n[NT];
-    tile_store_T<NT>(T, h1, j, hi);
-    wave_lds_sync();
-#pragma unroll
-    for (int m = 0; m < NT; ++m) h1n[m] = tile_load_N(T, m, i, hi);
-    wave_lds_sync();
-    tile_store_T<NT>(T, dz2, j, hi);
-    wave_lds_sync();
-#pragma unroll
-    for (int ma = 0; ma < NT; ++ma) {
-      const f32x16 dzn = tile_load_N(T, ma, i, hi);
+    // ---- dW2^T[own j_out][k_in] += sum_s dZ2[s][j_out] H1[s][k_in] ----
+    {
+      const f32x16 dzn = tile_load_N(DZ2s, mo, i, hi);
       float bs = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) bs += dzn[r];
-      gb2[ma] += bs;
+      gb2 += bs;
 #pragma unroll
-      for (int mb = 0; mb < NT; ++mb)
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gW2[ma][mb] = mfma32(dzn[r], h1n[mb][r], gW2[ma][mb]);
+        for (int r = 0; r < 16; ++r)
+          gW2[mb] = mfma32(dzn[r], H1s[(32 * mb + i) * TRL_TLD + rowmap(r, hi)], gW2[mb]);
     }
-    wave_lds_sync();
-
-    // ---- dW1^T[j_out][k_in] += sum_s dZ1[s][j_out] X[s][k_in] ----
-    tile_store_T<NT>(T, dz1, j, hi);
-    wave_lds_sync();
-    float xn[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xn[r] = (i < D) ? xs[rowmap(r, hi) * D + i] : 0.0f;
-#pragma unroll
-    for (int ma = 0; ma < NT; ++ma) {
-      const f32x16 dzn = tile_load_N(T, ma, i, hi);
+    // ---- dW1^T[own j_out][k_in] += sum_s dZ1[s][j_out] X[s][k_in] ----
+    {
+      const f32x16 dzn = tile_load_N(P, 0, i, hi);
       float bs = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) bs += dzn[r];
-      gb1[ma] += bs;
+      gb1 += bs;
+      // X with lane = input feature, reg r = sample rowmap(r, hi): 68-byte coalesced row segments
+      float xn[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gW1[ma] = mfma32(dzn[r], xn[r], gW1[ma]);
+      for (int r = 0; r < 16; ++r) {
+        const int sj = rowmap(r, hi);
+        int64_t pr;
+        if (contig) pr = pos0 + sj;
+        else        pr = __shfl(pos, sj, 64);
+        xn[r] = (i < D && s0 + sj < B) ? a.obs[pr * D + i] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gW1 = mfma32(dzn[r], xn[r], gW1);
     }
     wave_lds_sync();
   }
 
-  // ---- fold the 4 waves in fixed order into one partial gradient (flat layout) ----
+  // ---- fold the 8 waves in fixed order into one partial gradient (flat layout) ----
+  const int i = i0, hi = hi0, mo = mo0;
+  // pull this pair's statistic slots into registers before the scratch area is recycled
+  float stv[7], db3[O], dls[O];
+  {
+    const float* st = lds + PARF + pair * S::PAIR_SCR + S::O_ST;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) stv[k] = st[k * 32 + i];
+#pragma unroll
+    for (int o = 0; o < O; ++o) { db3[o] = st[(7 + o) * 32 + i]; dls[o] = st[(7 + A + o) * 32 + i]; }
+  }
   __syncthreads();
   float* gacc = lds + PARF;                                   // reuse scratch: S::P_STRIDE floats
   for (int e = tid; e < S::P_STRIDE; e += PPO_THREADS) gacc[e] = 0.0f;
@@ -316,29 +352,28 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
   for (int w = 0; w < PPO_WAVES; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int ma = 0; ma < NT; ++ma) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int jo = 32 * ma + rowmap(r, hi);
-          if (i < D) gacc[F::W1 + jo * D + i] += gW1[ma][r];
-#pragma unroll
-          for (int mb = 0; mb < NT; ++mb) gacc[F::W2 + jo * H + 32 * mb + i] += gW2[ma][mb][r];
-        }
-        // per-feature partials live in both hi halves: fold with one shuffle
-        const float b1v = gb1[ma] + __shfl_xor(gb1[ma], 32, 64);
-        const float b2v = gb2[ma] + __shfl_xor(gb2[ma], 32, 64);
-        if (hi == 0) { gacc[F::B1 + 32 * ma + i] += b1v; gacc[F::B2 + 32 * ma + i] += b2v; }
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-          const float w3v = gW3[o][ma] + __shfl_xor(gW3[o][ma], 32, 64);
-          if (hi == 0) gacc[F::W3 + o * H + 32 * ma + i] += w3v;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int jo = 32 * mo + rowmap(r, hi);
+        if (i < D) gacc[F::W1 + jo * D + i] += gW1[r];
+        gacc[F::W2 + jo * H + i] += gW2[0][r];
+        gacc[F::W2 + jo * H + 32 + i] += gW2[1][r];
       }
+      // per-feature partials live in both lane halves: fold with one shuffle
+      const float b1v = gb1 + __shfl_xor(gb1, 32, 64);
+      const float b2v = gb2 + __shfl_xor(gb2, 32, 64);
+      if (hi == 0) { gacc[F::B1 + 32 * mo + i] += b1v; gacc[F::B2 + 32 * mo + i] += b2v; }
 #pragma unroll
       for (int o = 0; o < O; ++o) {
-        const float b3v = wave_sum(gb3[o]);                   // hi == 1 lanes hold 0
-        if (lane == 0) gacc[F::B3 + o] += b3v;
-        if (IS_PF) { const float lv = wave_sum(gls[o]); if (lane == 0) gacc[F::LS + o] += lv; }
+        const float w3v = gW3[o] + __shfl_xor(gW3[o], 32, 64);
+        if (hi == 0) gacc[F::W3 + o * H + 32 * mo + i] += w3v;
+      }
+      if (mo == 0) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+          const float b3v = wave_sum(hi == 0 ? db3[o] : 0.0f);
+          if (lane == 0) gacc[F::B3 + o] += b3v;
+          if (IS_PF) { const float lv = wave_sum(hi == 0 ? dls[o] : 0.0f); if (lane == 0) gacc[F::LS + o] += lv; }
+        }
       }
     }
     __syncthreads();
@@ -346,21 +381,24 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
   const int wg = blockIdx.x;
   for (int e = tid; e < S::P_STRIDE; e += PPO_THREADS) a.partial[(size_t)wg * a.p_stride + e] = gacc[e];
 
-  // ---- scalar statistics: wave shuffle reduce, then across waves through LDS ----
+  // ---- scalar statistics: wave shuffle reduce, then across the pairs through LDS ----
   __syncthreads();
   double* sred = reinterpret_cast<double*>(lds + PARF);
-  {
-    const double v0 = wave_sum(st_sum), v1 = wave_sum(st_sq), v6 = wave_sum(st_loss);
-    const float v2 = wave_max(st_max), v3 = wave_max(st_nmin), v4 = wave_max(st_rmax), v5 = wave_max(st_nrmin);
+  if (mo == 0) {
+    const bool own = hi == 0;
+    const double v0 = wave_sum(own ? (double)stv[0] : 0.0), v1 = wave_sum(own ? (double)stv[1] : 0.0),
+                 v6 = wave_sum(own ? (double)stv[6] : 0.0);
+    const float v2 = wave_max(own ? stv[2] : -INFINITY), v3 = wave_max(own ? stv[3] : -INFINITY),
+                v4 = wave_max(own ? stv[4] : -INFINITY), v5 = wave_max(own ? stv[5] : -INFINITY);
     if (lane == 0) {
-      double* p = sred + wave * 8;
+      double* p = sred + pair * 8;
       p[0] = v0; p[1] = v1; p[2] = v2; p[3] = v3; p[4] = v4; p[5] = v5; p[6] = v6; p[7] = 0.0;
     }
   }
   __syncthreads();
   if (tid < 8) {
     double r = sred[tid];
-    for (int w = 1; w < PPO_WAVES; ++w) {
+    for (int w = 1; w < PPO_PAIRS; ++w) {
       const double o = sred[w * 8 + tid];
       r = (tid >= 2 && tid <= 5) ? fmax(r, o) : r + o;
     }
@@ -369,7 +407,7 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
 }
 
 template <int D, int H, int A, int ACT>
-__global__ __launch_bounds__(PPO_THREADS, 1) void ppo_grad_kernel(PpoDev a) {
+__global__ __launch_bounds__(PPO_THREADS, 2) void ppo_grad_kernel(PpoDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int half = a.n_wg >> 1;
   if ((int)blockIdx.x < half) ppo_net_pass<D, H, A, ACT, true>(a, lds, blockIdx.x, half);
@@ -380,21 +418,34 @@ __global__ __launch_bounds__(PPO_THREADS, 1) void ppo_grad_kernel(PpoDev a) {
 // grads[p] = sum_w partial[w][p] in fixed order; info[] from the scalar partials:
 //  0 policy surrogate sum (-min(s1,s2))   1 sum logp   2 sum logp^2   3 max logp   4 -min logp
 //  5 max ratio   6 -min ratio   7 value-loss sum
+#define RED_CHUNK 64
 __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial,
                                                          const double* __restrict__ scal, int n_wg,
                                                          int p_stride, int p_pf, int p_vf,
                                                          const float* __restrict__ logstd, int n_act,
                                                          float* __restrict__ grads, double* __restrict__ info) {
+  // block = 64 consecutive parameters x 4 waves; wave w folds partials w, w+4, ... with 4
+  // independent accumulators (fixed order => deterministic), then the 4 waves fold through LDS.
+  __shared__ float s_acc[4][RED_CHUNK];
   const int half = n_wg >> 1;
   const int net = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * RED_CHUNK + lane;
   const int pn = net == 0 ? p_pf : p_vf;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (p < pn) {
     const float* src = partial + (size_t)(net * half) * p_stride + p;
-    float acc = 0.0f;
-    for (int w = 0; w < half; ++w) acc += src[(size_t)w * p_stride];
-    grads[(net == 0 ? 0 : p_pf) + p] = acc;
+    int w = wave;
+    for (; w + 12 < half; w += 16) {
+      a0 += src[(size_t)w * p_stride];        a1 += src[(size_t)(w + 4) * p_stride];
+      a2 += src[(size_t)(w + 8) * p_stride];  a3 += src[(size_t)(w + 12) * p_stride];
+    }
+    for (; w < half; w += 4) a0 += src[(size_t)w * p_stride];
   }
+  s_acc[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0 && p < pn)
+    grads[(net == 0 ? 0 : p_pf) + p] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) {
     const int k = threadIdx.x;
     if (k < 7) {
@@ -438,9 +489,14 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
   __shared__ float s_coef[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int g = 0; g < a.n_groups; ++g) {
-    float ss = 0.0f;
-    for (int e = a.off[g] + tid; e < a.off[g + 1]; e += 256) { const float x = a.grads[e] * a.grad_scale; ss = fmaf(x, x, ss); }
-    ss = wave_sum(ss);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int e = a.off[g] + tid;
+    for (; e + 768 < a.off[g + 1]; e += 1024) {
+      const float x0 = a.grads[e], x1 = a.grads[e + 256], x2 = a.grads[e + 512], x3 = a.grads[e + 768];
+      s0 = fmaf(x0, x0, s0); s1 = fmaf(x1, x1, s1); s2 = fmaf(x2, x2, s2); s3 = fmaf(x3, x3, s3);
+    }
+    for (; e < a.off[g + 1]; e += 256) { const float x = a.grads[e]; s0 = fmaf(x, x, s0); }
+    float ss = wave_sum((s0 + s1) + (s2 + s3)) * a.grad_scale * a.grad_scale;
     if (lane == 0) s_part[g][wave] = ss;
   }
   __syncthreads();
@@ -552,7 +608,7 @@ extern "C" int trl_ppo_reduce_f32(const float* partial, const double* scal_parti
   const int ps = trl_ppo_partial_stride(D, H, A);
   if (ps < 0) return ps;
   const int p_pf = H * D + H + H * H + H + A * H + A + A, p_vf = H * D + H + H * H + H + H + 1;
-  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(trl_ceil_div(ps, 256), 2), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(trl_ceil_div(ps, RED_CHUNK), 2), dim3(256), 0, (hipStream_t)stream,
                      partial, scal_partial, n_wg, ps, p_pf, p_vf,
                      pf_params ? pf_params + (p_pf - A) : (const float*)nullptr, A, grads, info);
   TRL_LAUNCH_CHECK();

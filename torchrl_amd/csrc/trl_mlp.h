@@ -69,8 +69,8 @@ template <int D, int H, int O> struct MlpFlat {
 template <int D, int H, int O> struct MlpLds {
   static_assert(D <= 32, "input dim > 32 not instantiated");
   static_assert(H % 32 == 0, "hidden width must be a multiple of 32");
-  static constexpr int LD1 = (D % 2 == 0) ? D + 1 : D;      // odd -> lanes i*LD1 hit distinct banks
-  static constexpr int LD2 = H + 1;
+  static constexpr int LD1 = (D % 2 == 0) ? D + 1 : D;      // odd -> lanes i*LD1 hit distinct banks (b32 reads)
+  static constexpr int LD2 = H + 4;                          // 16-B aligned rows, ds_read_b128 conflict free
   static constexpr int W1 = 0;
   static constexpr int B1 = align4(W1 + H * LD1);
   static constexpr int W2 = B1 + H;
@@ -127,25 +127,38 @@ __device__ __forceinline__ f32x16 layer1_tile(f32x16 acc, const float* w1, int m
 
 // hidden layer, output tile `mo`, all NT source tiles in registers:
 //   acc += W[32mo + i][32m + rowmap(r, hi)] * h[m][r]
+// rowmap(4q..4q+3, hi) are 4 consecutive features, so one 16-byte LDS read feeds 4 MFMAs
+template <int LD>
+__device__ __forceinline__ f32x16 layer_tile_1src(f32x16 acc, const float* w, int mo, int m, const f32x16& h, int i, int hi) {
+  static_assert(LD % 4 == 0, "rows must be 16-byte aligned");
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + (32 * mo + i) * LD + 32 * m + 8 * q + 4 * hi);
+    acc = mfma32(a[0], h[4 * q + 0], acc); acc = mfma32(a[1], h[4 * q + 1], acc);
+    acc = mfma32(a[2], h[4 * q + 2], acc); acc = mfma32(a[3], h[4 * q + 3], acc);
+  }
+  return acc;
+}
 template <int NT, int LD>
 __device__ __forceinline__ f32x16 layer_tile(f32x16 acc, const float* w, int mo, const f32x16 (&h)[NT], int i, int hi) {
 #pragma unroll
-  for (int m = 0; m < NT; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      acc = mfma32(w[(32 * mo + i) * LD + 32 * m + rowmap(r, hi)], h[m][r], acc);
+  for (int m = 0; m < NT; ++m) acc = layer_tile_1src<LD>(acc, w, mo, m, h[m], i, hi);
   return acc;
 }
 
 // same with the weight matrix read transposed (backward: dH_in^T = W^T * dZ_out^T):
 //   acc += W[32m + rowmap(r, hi)][32mo + i] * dz[m][r]
+template <int LD>
+__device__ __forceinline__ f32x16 layer_tile_wT_1src(f32x16 acc, const float* w, int mo, int m, const f32x16& dz, int i, int hi) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    acc = mfma32(w[(32 * m + rowmap(r, hi)) * LD + 32 * mo + i], dz[r], acc);
+  return acc;
+}
 template <int NT, int LD>
 __device__ __forceinline__ f32x16 layer_tile_wT(f32x16 acc, const float* w, int mo, const f32x16 (&dz)[NT], int i, int hi) {
 #pragma unroll
-  for (int m = 0; m < NT; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      acc = mfma32(w[(32 * m + rowmap(r, hi)) * LD + 32 * mo + i], dz[m][r], acc);
+  for (int m = 0; m < NT; ++m) acc = layer_tile_wT_1src<LD>(acc, w, mo, m, dz[m], i, hi);
   return acc;
 }
 
@@ -195,6 +208,18 @@ __device__ __forceinline__ void tile_store_T(float* T, const f32x16 (&h)[NT], in
   for (int m = 0; m < NT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) T[(32 * m + rowmap(r, hi)) * TRL_TLD + j] = h[m][r];
+}
+// one tile: T[(32m + feature)][sample]
+__device__ __forceinline__ void tile_store_T1(float* T, int m, const f32x16& h, int j, int hi) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) T[(32 * m + rowmap(r, hi)) * TRL_TLD + j] = h[r];
+}
+// read a tile back in the layout it was stored from (lane = sample j, reg r = feature rowmap(r, hi))
+__device__ __forceinline__ f32x16 tile_load_T1(const float* T, int m, int j, int hi) {
+  f32x16 v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = T[(32 * m + rowmap(r, hi)) * TRL_TLD + j];
+  return v;
 }
 // read back with lane = feature i of tile m, reg r = sample rowmap(r, hi)
 __device__ __forceinline__ f32x16 tile_load_N(const float* T, int m, int i, int hi) {
