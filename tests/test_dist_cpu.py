@@ -1,0 +1,109 @@
+"""Multi-GPU path on CPU: two gloo processes exercise env sharding, the collective helpers and
+the sharded-minibatch identity (union of rank-local minibatches == single-process minibatch;
+SUM of rank gradients carrying 1/n_global == full-batch gradient), using the CPU oracle for the math."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import torch.distributed as td
+    from torchrl_amd import dist
+    from oracle import nets
+    td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        assert dist.initialized() and dist.world_size() == world and dist.rank() == rank
+        N_total, T, rows_mb, D, A = 8, 6, 3, 17, 6
+        off, cnt = dist.shard(N_total)
+        assert (off, cnt) == (rank * 4, 4)
+        with pytest.raises(ValueError):
+            dist.shard(7)
+        # identical index streams on every rank (same numpy seed) -- the sharding contract
+        np.random.seed(0)
+        idx = np.random.permutation(T)[:rows_mb]
+        gathered = [None] * world
+        td.all_gather_object(gathered, idx.tolist())
+        assert gathered[0] == gathered[1]
+
+        rs = np.random.RandomState(5)
+        full = {"obs": rs.randn(T, N_total, D).astype(np.float32),
+                "acts": (np.tanh(rs.randn(T, N_total, A)) * 0.9).astype(np.float32),
+                "advs": rs.randn(T, N_total, 1).astype(np.float32)}
+        gen = torch.Generator().manual_seed(3)
+        pf = nets.init_mlp(D, [64, 64], A, generator=gen)
+        pf = [p.requires_grad_(True) for p in pf]
+        ls = torch.full((A,), -1.0, requires_grad=True)
+
+        def loss_sum(obs, acts, advn):                      # un-normalised sum; 1/n_global applied below
+            out = nets.policy_update_terms(torch.tensor(obs), torch.tensor(acts), pf, ls)
+            return -(torch.exp(out["log_prob"] - out["log_prob"].detach()) * torch.tensor(advn)).sum()
+
+        # C2: advantage statistics {sum, sumsq, max, -min} of the LOCAL shard, reduced
+        loc = {k: v[idx][:, off:off + cnt] for k, v in full.items()}
+        a = loc["advs"].astype(np.float64).reshape(-1)
+        raw = torch.tensor([[a.sum(), (a * a).sum(), a.max(), -a.min()]], dtype=torch.float64)
+        dist.reduce_adv_raw_(raw)
+        fa = full["advs"][idx].astype(np.float64).reshape(-1)
+        n = fa.size
+        np.testing.assert_allclose(raw[0].numpy(), [fa.sum(), (fa * fa).sum(), fa.max(), -fa.min()], rtol=1e-12)
+        mean, std = raw[0, 0].item() / n, np.sqrt((raw[0, 1].item() - raw[0, 0].item() ** 2 / n) / (n - 1))
+        assert abs(std - torch.tensor(fa).std().item()) < 1e-9
+
+        # C1: SUM of rank gradients (each carrying 1/n_global) == gradient of the full-batch mean loss
+        advn_loc = ((loc["advs"] - mean) / (std + 1e-5)).astype(np.float32).reshape(-1, 1)
+        g_loc = torch.autograd.grad(loss_sum(loc["obs"].reshape(-1, D), loc["acts"].reshape(-1, A), advn_loc) / n,
+                                    pf + [ls])
+        flat = torch.cat([g.reshape(-1) for g in g_loc])
+        dist.all_reduce_sum_(flat)
+        advn_full = ((full["advs"][idx] - mean) / (std + 1e-5)).astype(np.float32).reshape(-1, 1)
+        g_full = torch.autograd.grad(loss_sum(full["obs"][idx].reshape(-1, D), full["acts"][idx].reshape(-1, A),
+                                              advn_full) / n, pf + [ls])
+        want = torch.cat([g.reshape(-1) for g in g_full])
+        assert (flat - want).abs().max().item() < 1e-6 * max(1.0, want.abs().max().item())
+
+        # C3: logging statistics
+        info = torch.zeros(2, 16, dtype=torch.float64)
+        info[:, dist.INFO_SUM_COLS] = float(rank + 1)
+        info[:, dist.INFO_MAX_COLS] = float(rank)
+        info[:, 8] = 7.0                                   # log_std columns are rank-identical: untouched
+        dist.reduce_info_(info)
+        assert torch.all(info[:, dist.INFO_SUM_COLS] == 3.0) and torch.all(info[:, dist.INFO_MAX_COLS] == 1.0)
+        assert torch.all(info[:, 8] == 7.0)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce_max_(t)
+        assert t.item() == world - 1
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_and_collectives(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+
+
+def test_single_process_helpers_are_noops():
+    from torchrl_amd import dist
+    assert not dist.initialized() and dist.world_size() == 1 and dist.rank() == 0
+    assert dist.shard(2048) == (0, 2048)
+    t = torch.ones(3)
+    assert dist.all_reduce_sum_(t) is t and torch.all(t == 1)
+    raw = torch.ones(2, 4, dtype=torch.float64)
+    assert torch.all(dist.reduce_adv_raw_(raw) == 1)

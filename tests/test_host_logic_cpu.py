@@ -1,0 +1,145 @@
+"""Host-side logic of the product classes that needs no GPU: index streams, ring bookkeeping,
+argument checks, API surface / alias package, config + logger.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_alias_package_resolves_to_same_modules():
+    import torchrl
+    import torchrl_amd
+    import torchrl.algo
+    import torchrl_amd.algo
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl_amd.collector.on_policy import VecOnPolicyCollector as V2
+    assert torchrl is torchrl_amd and torchrl.algo is torchrl_amd.algo and VecOnPolicyCollector is V2
+    # the import lines of the reference's examples/ppo_continuous_vec.py:8-18
+    from torchrl.utils import get_args, get_params, Logger                  # noqa: F401
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer      # noqa: F401
+    import torchrl.policies as policies
+    import torchrl.networks as networks
+    from torchrl.algo import PPO                                           # noqa: F401
+    from torchrl.env import get_vec_env                                    # noqa: F401
+    import gym
+    assert hasattr(gym.spaces, "Box")
+    assert hasattr(policies, "GuassianContPolicyBasicBias") and hasattr(networks, "MLPBase")
+
+
+def test_epoch_row_indices_is_the_reference_permutation_stream(golden):
+    """Same numpy calls in the same order as one_iteration (on_policy.py:76-78): E permutations."""
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    g = golden("index_streams")
+    T, N, B, E, seed = (int(x) for x in g["oi_args"])
+    buf = OnPolicyReplayBuffer(T * N, env_nums=N)
+    np.random.seed(seed)
+    got = np.concatenate([buf.epoch_row_indices(B, True) for _ in range(E)])
+    np.random.seed(seed)
+    want = np.concatenate([np.random.permutation(T).reshape(-1, B // N) for _ in range(E)])
+    assert np.array_equal(got, want) and got.dtype == np.int64
+    assert np.array_equal(buf.epoch_row_indices(B, False).reshape(-1), np.arange(T))
+    # data check against the reference's gathered batches
+    cat = np.concatenate([g["oi_obs"], g["oi_acts"], g["oi_advs"]], -1)
+    for k, rows in enumerate(got):
+        assert np.array_equal(cat[rows].reshape(B, -1), g["oi_batches"][k])
+    with pytest.raises(AssertionError, match="dividable"):
+        buf.epoch_row_indices(B + 1, True)
+    with pytest.raises(ValueError, match="multiple"):
+        OnPolicyReplayBuffer(10 * N, env_nums=N).epoch_row_indices(4 * N, True)
+
+
+def test_ring_bookkeeping_matches_reference(golden):
+    from torchrl.replay_buffers import BaseReplayBuffer
+    g = golden("index_streams")
+    size, N, B, seed = (int(x) for x in g["ring_args"])
+    ring = BaseReplayBuffer(size, env_nums=N)
+    assert ring._max_replay_buffer_size == size // N
+    for t in range(7):
+        ring._advance()
+        assert ring._size == g["ring_sizes"][t] and ring._top == g["ring_tops"][t]
+    ring._advance(3)
+    assert ring._top == (g["ring_tops"][6] + 3) % (size // N) and ring.num_steps_can_sample() == size // N
+
+
+def test_net_structure_names_and_mlp2_spec():
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase,
+               activation_func=torch.nn.Tanh)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=17, output_shape=6, tanh_action=True, **net)
+    vf = networks.Net(input_shape=(17,), output_shape=1, **net)
+    assert sorted(pf.state_dict()) == ["base.seq_fcs.0.bias", "base.seq_fcs.0.weight", "base.seq_fcs.2.bias",
+                                       "base.seq_fcs.2.weight", "logstd", "seq_append_fcs.0.bias",
+                                       "seq_append_fcs.0.weight"]
+    assert pf.mlp2_spec() == (17, 64, 6, 0) and vf.mlp2_spec() == (17, 64, 1, 0)
+    assert sum(p.numel() for p in pf.parameters()) == 5708 and sum(p.numel() for p in vf.parameters()) == 5377
+    assert np.allclose(pf.logstd.detach().numpy(), np.log(0.125))
+    # reference init conventions (networks/init.py): hidden U(+-1/8), bias 0.1, head U(+-3e-3)
+    sd = vf.state_dict()
+    assert sd["base.seq_fcs.0.weight"].abs().max() <= 0.125 and torch.all(sd["base.seq_fcs.2.bias"] == 0.1)
+    assert sd["seq_append_fcs.0.weight"].abs().max() <= 3e-3
+    # flat view aliases the parameters
+    flat = vf.flat_params()
+    assert flat.numel() == 5377 and flat.data_ptr() == vf.base.seq_fcs[0].weight.data_ptr()
+    with torch.no_grad():
+        flat[:] = 0.5
+    assert float(vf.seq_append_fcs[0].bias) == 0.5
+    odd = networks.Net(input_shape=(17,), output_shape=1, hidden_shapes=[400, 300], append_hidden_shapes=[],
+                       base_type=networks.MLPBase)
+    assert odd.mlp2_spec() is None
+    # CPU / autograd forward is the plain module graph
+    out = odd(torch.zeros(3, 17))
+    assert out.shape == (3, 1) and out.requires_grad
+
+
+def test_product_path_refuses_cpu_and_unknown_envs():
+    from torchrl_amd import _C
+    from torchrl.env import get_vec_env
+    with pytest.raises(ValueError, match="unknown env id"):
+        get_vec_env("HalfCheetah-v2", {"reward_scale": 1, "obs_norm": False}, 4)
+    with pytest.raises(NotImplementedError, match="obs_norm"):
+        get_vec_env("SynthHalfCheetah-v0", {"reward_scale": 1, "obs_norm": True}, 4)
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    buf = OnPolicyReplayBuffer(8, env_nums=2, device="cpu")
+    for k in ("rewards", "values", "terminals", "time_limits"):
+        buf._ensure_key(k, (2, 1))
+    with pytest.raises(_C.TrlError, match="no CPU path"):
+        buf.generalized_advantage_estimation(torch.zeros(2, 1), 0.99, 0.95)
+
+
+def test_args_params_logger(tmp_path):
+    from torchrl.utils import get_params, Logger
+    from torchrl.utils.args import get_args
+    args = get_args(["--config", "x.json", "--vec_env_nums", "2048", "--seed", "3", "--no_cuda"])
+    assert args.vec_env_nums == 2048 and args.seed == 3 and args.cuda is False
+    params = get_params(os.path.join(REPO, "config", "ppo_synth_halfcheetah.json"))
+    assert params["replay_buffer"]["size"] == 2048 * 128 and params["general_setting"]["batch_size"] == 65536
+    log = Logger("exp", "SynthHalfCheetah-v0", 0, dict(params), str(tmp_path), overwrite=True)
+    for v in (1.0, 3.0):
+        log.add_update_info({"Training/vf_loss": v})
+    log.add_epoch_info(0, 100, 1.5, {"Train_Epoch_Reward": 2.0})
+    log.add_epoch_info(1, 200, 1.5, {"Train_Epoch_Reward": 4.0})
+    log.finish()
+    rows = open(os.path.join(log.work_dir, "log.csv")).read().strip().split("\n")
+    assert rows[0].startswith("EPOCH,Time Consumed,Total Frames,Train_Epoch_Reward,Training/vf_loss_Mean")
+    assert rows[1].split(",")[4] == "2.0" and len(rows) == 3
+    assert json.load(open(os.path.join(log.work_dir, "params.json")))["env_name"] == "SynthHalfCheetah-v0"
+    with pytest.raises(AssertionError, match="overwrite"):
+        Logger("exp", "SynthHalfCheetah-v0", 0, dict(params), str(tmp_path), overwrite=False)
+
+
+def test_linear_lr_schedule_and_param_copy():
+    from torchrl.algo import utils as atu
+    lin = torch.nn.Linear(3, 2)
+    opt = torch.optim.Adam(lin.parameters(), lr=3e-4)
+    atu.update_linear_schedule(opt, 3, 10, 3e-4)
+    assert abs(opt.param_groups[0]["lr"] - 3e-4 * 0.7) < 1e-12
+    tgt = torch.nn.Linear(3, 2)
+    atu.copy_model_params_from_to(lin, tgt)
+    assert torch.equal(tgt.weight, lin.weight)
+    atu.soft_update_from_to(torch.nn.Linear(3, 2), tgt, 0.0)
+    assert torch.equal(tgt.weight, lin.weight)

@@ -34,11 +34,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 // running: a whole-workgroup s_barrier would put all 8 waves in lockstep and the MFMA phases of
 // one pair could no longer overlap the VALU/LDS phases of the pair sharing its SIMDs).
 __device__ __forceinline__ void pair_sync(int* cnt, int& expect, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#ifdef TRL_EXP_NOSYNC
+  return;
+#endif
+  // LDS operations of one wave are performed in order, so the arrive-atomic below is ordered after
+  // every earlier ds_write of this wave without any s_waitcnt.  No fence intrinsic here on purpose:
+  // a workgroup-scope release also emits vmcnt(0) and would stall on the global loads this kernel
+  // deliberately keeps in flight across the rendezvous.
+  asm volatile("" ::: "memory");
   if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   expect += 2;
   while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");
 }
 
 struct PpoDev {
@@ -123,6 +130,14 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
   const bool contig = (a.N % 32) == 0;
   const bool stat_lane = (mo0 == 0 && hi0 == 0);
 
+  int64_t pos_next = 0;
+  {
+    const int sf = (wg_in_net * PPO_PAIRS + pair) * 32 + i0;
+    if (sf < B) {
+      const int r = sf / a.N, e = sf - r * a.N;
+      pos_next = (a.row_idx ? a.row_idx[r] : (int64_t)r) * a.N + e;
+    }
+  }
   for (int tile = wg_in_net * PPO_PAIRS + pair; tile < n_tiles; tile += n_wg_net * PPO_PAIRS) {
     // Launder the lane coordinates once per tile: every LDS address below derives from them, and
     // without this LICM hoists ~100 loop-invariant addresses out of the tile loop and spills them.
@@ -138,20 +153,35 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
     const int s0 = tile * 32;
     const int s = s0 + j;
     const bool valid = s < B;
-    int64_t pos = 0, pos0 = 0;                                // (row, env) cell of this lane's / the tile's first sample
-    if (valid) {
-      const int r = s / a.N, e = s - r * a.N;
-      pos = (a.row_idx ? a.row_idx[r] : (int64_t)r) * a.N + e;
+    const int64_t pos = pos_next;                             // (row, env) cell of this lane's sample (0 if masked)
+    {                                                         // next tile's cell: its row_idx load flies during this tile
+      const int sn = s + n_wg_net * PPO_PAIRS * 32;
+      int64_t pn = 0;
+      if (sn < B) {
+        const int r = sn / a.N, e = sn - r * a.N;
+        pn = (a.row_idx ? a.row_idx[r] : (int64_t)r) * a.N + e;
+      }
+      pos_next = pn;
     }
-    if (contig) {
-      const int r0 = s0 / a.N, e0 = s0 - r0 * a.N;
-      pos0 = (a.row_idx ? a.row_idx[r0] : (int64_t)r0) * a.N + e0;
+    // this tile's per-sample scalars, issued now and consumed after layer 2 (latency hidden by the MFMAs)
+    float in_act[IS_PF ? O : 1], in_a, in_b;
+    if constexpr (IS_PF) {
+#pragma unroll
+      for (int o = 0; o < O; ++o) in_act[o] = a.acts[pos * O + o];
+      in_a = a.advs[pos]; in_b = a.old_logp[pos];
+    } else {
+      in_act[0] = 0.0f;
+      in_a = a.rets[pos]; in_b = a.clipped_value_loss ? a.old_values[pos] : 0.0f;
     }
     float* st = scr + S::O_ST;
     // ---- x^T operand straight from HBM/L2: lane (sample j, hi) holds features rowmap(q, hi) ----
     float xb[KS];
 #pragma unroll
-    for (int q = 0; q < KS; ++q) { const int k = rowmap(q, hi); xb[q] = (valid && k < D) ? a.obs[pos * D + k] : 0.0f; }
+    for (int q = 0; q < KS; ++q) {                            // unconditional (clamped) loads + select: no exec-mask branches
+      const int k = rowmap(q, hi);
+      const float v = a.obs[pos * D + (k < D ? k : D - 1)];
+      xb[q] = (valid && k < D) ? v : 0.0f;
+    }
 
     // ---- forward layer 1, own feature tile ----
     const f32x16 h1 = act_tile<ACT>(layer1_tile<D, L::LD1, KS>(bias_tile(sp + L::B1 + 32 * mo, hi), sp + L::W1, mo, xb, i, hi));
@@ -191,22 +221,16 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
 #pragma unroll
       for (int o = 0; o < O; ++o) out[o] = headp[o * 32 + j] + headp[(8 + o) * 32 + j] + sp[L::B3 + o];
       if constexpr (IS_PF) {
-        const float advn = valid ? (a.advs[pos] - adv_mu) * adv_rstd : 0.0f;
-        const float lp_old = valid ? a.old_logp[pos] : 0.0f;
+        const float lp_old = in_b;
+        const float advn = valid ? (in_a - adv_mu) * adv_rstd : 0.0f;
         float zc[O], inv_var[O];
         float lp = 0.0f;
 #pragma unroll
         for (int o = 0; o < O; ++o) {
           const float ls = fminf(fmaxf(sp[L::LS + o], -20.0f), 2.0f);   // continuous_policy.py:8-9,185
           inv_var[o] = __expf(-2.0f * ls);
-          const float act = valid ? a.acts[pos * O + o] : 0.0f;
-          float pre = act, corr = 0.0f;
-          if (a.tanh_action) {                                 // distribution.py:40-45
-            pre = 0.5f * logf((1.0f + act) / (1.0f - act));
-            corr = logf(1.0f - act * act + 1e-6f);
-          }
-          zc[o] = pre - out[o];
-          lp += -(zc[o] * zc[o]) * 0.5f * inv_var[o] - ls - 0.91893853320467274f - corr;
+          const float act = valid ? in_act[o] : 0.0f;
+          lp += gauss_logp_term(act, out[o], inv_var[o], ls, a.tanh_action, zc[o]);
         }
         const float ratio = __expf(lp - lp_old);
         const float s1 = ratio * advn;
@@ -221,17 +245,19 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
             st[(7 + A + o) * 32 + j] += pass * (g_lp * (zc[o] * zc[o] * inv_var[o] - 1.0f) - a.entropy_coeff * inv_b);
           }
         }
+#ifndef TRL_EXP_NOSTATS
         if (stat_lane && valid) {
           st[0 * 32 + j] += lp; st[1 * 32 + j] = fmaf(lp, lp, st[1 * 32 + j]); st[6 * 32 + j] -= fminf(s1, s2);
           st[2 * 32 + j] = fmaxf(st[2 * 32 + j], lp); st[3 * 32 + j] = fmaxf(st[3 * 32 + j], -lp);
           st[4 * 32 + j] = fmaxf(st[4 * 32 + j], ratio); st[5 * 32 + j] = fmaxf(st[5 * 32 + j], -ratio);
         }
+#endif
       } else {
         const float v = out[0];
-        const float R = valid ? a.rets[pos] : 0.0f;
+        const float R = in_a;
         float dv, l;
         if (a.clipped_value_loss) {                            // ppo.py:104-111
-          const float vo = valid ? a.old_values[pos] : 0.0f;
+          const float vo = in_b;
           const float dc = v - vo;
           const float vc = vo + fminf(fmaxf(dc, -a.clip_para), a.clip_para);
           const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
@@ -271,6 +297,18 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
     tile_store_T1(DZ2s, mo, dz2, j, hi);
     pair_sync(cnt, expect, lane);
 
+    // X with lane = input feature, reg r = sample rowmap(r, hi) (68-byte coalesced row segments): issued
+    // here, consumed by the dW1 MFMAs at the end of the tile
+    float xn[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int sj = rowmap(r, hi);
+      int64_t pr;
+      if (contig) pr = pos - j + sj;                          // N % 32 == 0: the tile is one contiguous run of cells
+      else        pr = __shfl(pos, sj, 64);
+      const float v = a.obs[((s0 + sj < B) ? pr : 0) * D + (i < D ? i : 0)];
+      xn[r] = (i < D && s0 + sj < B) ? v : 0.0f;
+    }
     // ---- dW3[o][own f] += sum_s dout[o][s] H2[s][f]  (lane = feature) ----
     {
       const f32x16 h2n = tile_load_N(P, 0, i, hi);
@@ -318,16 +356,6 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
 #pragma unroll
       for (int r = 0; r < 16; ++r) bs += dzn[r];
       gb1 += bs;
-      // X with lane = input feature, reg r = sample rowmap(r, hi): 68-byte coalesced row segments
-      float xn[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int sj = rowmap(r, hi);
-        int64_t pr;
-        if (contig) pr = pos0 + sj;
-        else        pr = __shfl(pos, sj, 64);
-        xn[r] = (i < D && s0 + sj < B) ? a.obs[pr * D + i] : 0.0f;
-      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) gW1 = mfma32(dzn[r], xn[r], gW1);
     }
@@ -446,30 +474,38 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict
   __syncthreads();
   if (wave == 0 && p < pn)
     grads[(net == 0 ? 0 : p_pf) + p] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) {
-    const int k = threadIdx.x;
-    if (k < 7) {
-      double r = scal[k];
-      for (int w = 1; w < half; ++w) {
-        const double o = scal[(size_t)w * 8 + k];
-        r = (k >= 2 && k <= 5) ? fmax(r, o) : r + o;
+  // scalar statistics: one wave per network, lanes stride over the workgroup partials (independent
+  // loads, shuffle reduction) -- a serial 128-deep dependent-load chain here cost 50 us
+  if (blockIdx.x == 0 && blockIdx.y == 0 && wave < 2) {
+    const double* base = scal + (size_t)(wave * half) * 8;
+    double v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? -INFINITY : 0.0;
+    for (int w = lane; w < half; w += 64) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const double o = base[(size_t)w * 8 + k];
+        v[k] = (k >= 2 && k <= 5) ? fmax(v[k], o) : v[k] + o;
       }
-      const int slot = (k == 6) ? 0 : k + 1;               // -> layout documented above
-      info[slot] = r;
-    } else {
-      double r = 0.0;
-      for (int w = 0; w < half; ++w) r += scal[(size_t)(half + w) * 8 + 6];
-      info[7] = r;
-      if (logstd) {                                          // log_std/{mean,std,max,min} (ppo.py:82-85)
-        double sm = 0, sq = 0, mx = -INFINITY, mn = INFINITY;
-        for (int o = 0; o < n_act; ++o) {
-          const double v = fmin(fmax((double)logstd[o], -20.0), 2.0);
-          sm += v; sq += v * v; mx = fmax(mx, v); mn = fmin(mn, v);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? wave_max(v[k]) : wave_sum(v[k]);
+    if (lane == 0) {
+      if (wave == 0) {
+        info[0] = v[6]; info[1] = v[0]; info[2] = v[1]; info[3] = v[2]; info[4] = v[3]; info[5] = v[4]; info[6] = v[5];
+        if (logstd) {                                        // log_std/{mean,std,max,min} (ppo.py:82-85)
+          double sm = 0, sq = 0, mx = -INFINITY, mn = INFINITY;
+          for (int o = 0; o < n_act; ++o) {
+            const double x = fmin(fmax((double)logstd[o], -20.0), 2.0);
+            sm += x; sq += x * x; mx = fmax(mx, x); mn = fmin(mn, x);
+          }
+          const double mean = sm / n_act;
+          info[8] = mean;
+          info[9] = n_act > 1 ? sqrt(fmax((sq - sm * mean) / (n_act - 1), 0.0)) : NAN;
+          info[10] = mx; info[11] = mn;
         }
-        const double mean = sm / n_act;
-        info[8] = mean;
-        info[9] = n_act > 1 ? sqrt(fmax((sq - sm * mean) / (n_act - 1), 0.0)) : NAN;
-        info[10] = mx; info[11] = mn;
+      } else {
+        info[7] = v[6];
       }
     }
   }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   for (int o = 0; o < A; ++o) {
     lsv[o] = fminf(fmaxf(sp_pf[LP::LS + o], -20.0f), 2.0f);
     stdv[o] = __expf(lsv[o]);
-    inv_var[o] = 1.0f / (stdv[o] * stdv[o]);
+    inv_var[o] = __expf(-2.0f * lsv[o]);
   }
 
   // ---- per-env state (replicated in all 4 waves and both lane halves) ----
@@ -152,13 +152,19 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
 #pragma unroll
       for (int o = 0; o < A; ++o) eps[o] = valid ? a.noise[((size_t)t * a.N + n) * A + o] : 0.0f;
     } else {
+      // lane half hi draws Philox block hi (4 normals); the halves swap through one cross-lane
+      // exchange, so each lane pays for one block instead of ceil(A/4)
+      static_assert(A <= 8, "noise split assumes at most two Philox blocks per env-step");
       const int64_t gs = a.noise_step0 + t;
+      float z[4], zx[4];
+      philox_normals4((uint32_t)(gs & 0xFFFFFFFFll), (uint32_t)((gs >> 32) & 0xFFFFFFFFll), (uint32_t)hi,
+                      TRL_TAG_NOISE, env_seed, z);
 #pragma unroll
-      for (int b = 0; b < (A + 3) / 4; ++b) {
-        float z[4];
-        philox_normals4((uint32_t)(gs & 0xFFFFFFFFll), (uint32_t)((gs >> 32) & 0xFFFFFFFFll), b, TRL_TAG_NOISE, env_seed, z);
+      for (int c = 0; c < 4; ++c) zx[c] = __shfl_xor(z[c], 32, 64);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (4 * b + c < A) eps[4 * b + c] = z[c];
+      for (int c = 0; c < 4; ++c) {
+        if (c < A) eps[c] = hi ? zx[c] : z[c];
+        if (4 + c < A) eps[4 + c] = hi ? z[c] : zx[c];
       }
     }
 
@@ -171,13 +177,10 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
     for (int o = 0; o < A; ++o) {
       const float z = fmaf(stdv[o], eps[o], mean[o]);
       act[o] = a.tanh_action ? trl_tanh(z) : z;
-      float pre = act[o], corr = 0.0f;
-      if (a.tanh_action) {
-        pre = 0.5f * logf((1.0f + act[o]) / (1.0f - act[o]));
-        corr = logf(1.0f - act[o] * act[o] + 1e-6f);
+      if (wave == 2) {                                       // only the wave that stores old_logp needs it
+        float zc;
+        logp += gauss_logp_term(act[o], mean[o], inv_var[o], lsv[o], a.tanh_action, zc);
       }
-      const float zc = pre - mean[o];
-      logp += -(zc * zc) * 0.5f * inv_var[o] - lsv[o] - 0.91893853320467274f - corr;
       act_sq = fmaf(act[o], act[o], act_sq);
     }
 
@@ -370,12 +373,8 @@ __global__ __launch_bounds__(256) void gauss_logp_kernel(const float* __restrict
   float lp = 0.0f;
   for (int o = 0; o < A; ++o) {
     const float ls = fminf(fmaxf(logstd[o], -20.0f), 2.0f);
-    const float sd = __expf(ls);
-    const float act = acts[(size_t)b * A + o];
-    float pre = act, corr = 0.0f;
-    if (tanh_action) { pre = 0.5f * logf((1.0f + act) / (1.0f - act)); corr = logf(1.0f - act * act + 1e-6f); }
-    const float zc = pre - mean[(size_t)b * A + o];
-    lp += -(zc * zc) * 0.5f / (sd * sd) - ls - 0.91893853320467274f - corr;
+    float zc;
+    lp += gauss_logp_term(acts[(size_t)b * A + o], mean[(size_t)b * A + o], __expf(-2.0f * ls), ls, tanh_action, zc);
   }
   out[b] = lp;
 }

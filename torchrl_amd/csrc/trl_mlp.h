@@ -28,18 +28,40 @@ __host__ __device__ constexpr int ksteps_for(int d) {
 __host__ __device__ constexpr int align4(int x) { return (x + 3) & ~3; }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+#ifdef TRL_EXP_NOMFMA                     // development experiment: VALU stand-in keeps the data flow alive
+  c[0] = fmaf(a, b, c[0]);
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// tanh: 1 - 2/(exp(2|x|)+1) on v_exp_f32 / v_rcp_f32, odd polynomial for |x| < 0.1.
-// abs error < 2e-7 over the real line (checked on device against double tanh).
+// tanh(x) = 1 - 2/(exp(2x)+1) on v_exp_f32 / v_rcp_f32 (valid for both signs, saturates cleanly),
+// x - x^3/3 for |x| < 0.04 where the subtraction would cancel.  abs error < 2e-7 over the real line
+// (tests/test_kernels_gpu.py checks it on device against float64 tanh).
 __device__ __forceinline__ float trl_tanh(float x) {
-  const float ax = fabsf(x);
-  const float e = __expf(2.0f * ax);
-  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-  const float x2 = x * x;
-  const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825397f, 0.13333333333f), -0.33333333333f), 1.0f);
-  return copysignf(ax < 0.1f ? small : big, x);
+#ifdef TRL_EXP_NOTANH
+  return x * 0.5f;
+#endif
+  const float e = __expf(2.0f * x);
+  const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+  const float small = x * fmaf(x * x, -0.33333333333f, 1.0f);
+  return fabsf(x) < 0.04f ? small : big;
+}
+
+// One action dimension of log pi(a|s) for a (Tanh)Normal policy, the reference's formula
+// (torchrl/policies/distribution.py:33-45): atanh(a) = log((1+a)/(1-a))/2, Normal log-density
+// minus log(1 - a^2 + 1e-6).  Shared by the collector, the PPO loss and trl_gauss_logp_f32 so
+// that log pi and log pi_old of the same (s, a, params) are bit-identical (ratio == 1).
+// v_log_f32 / v_rcp_f32 based: rel. error ~1e-6 of each log term.  zc = atanh(a) - mean is returned.
+__device__ __forceinline__ float gauss_logp_term(float act, float mean, float inv_var, float ls, int tanh_action,
+                                                 float& zc) {
+  float pre = act, corr = 0.0f;
+  if (tanh_action) {
+    pre = 0.5f * __logf((1.0f + act) * __builtin_amdgcn_rcpf(1.0f - act));
+    corr = __logf(fmaf(-act, act, 1.0f) + 1e-6f);
+  }
+  zc = pre - mean;
+  return -(zc * zc) * 0.5f * inv_var - ls - 0.91893853320467274f - corr;
 }
 
 template <int ACT> __device__ __forceinline__ float act_fn(float z) {
