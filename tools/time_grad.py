@@ -26,14 +26,17 @@ def main():
     buf = agent.replay_buffer
     t = {"obs": buf._obs, "acts": buf._acts, "advs": buf._advs, "rets": buf._estimate_returns,
          "old_values": buf._values, "old_logp": buf._old_logp}
-    idx = np.random.permutation(128).reshape(4, 32).astype(np.int64)
-    probes = []
-    eng.probe = probes
-    for _ in range(5):
-        eng.run(t, idx, buf.env_nums)
-    torch.cuda.synchronize()
-    ms = np.array([s.elapsed_time(e) for s, e in probes][4:])
-    print("%s grad kernel: mean %.1f us  min %.1f us  (n=%d)" % (os.environ.get("TRL_LIB", "default"), ms.mean() * 1e3, ms.min() * 1e3, len(ms)))
+    eng._n_wg = lambda n: eng.max_wg                      # always the full grid, to expose the fixed cost
+    for rows in (32, 16, 8, 2, 1):
+        idx = np.random.permutation(128)[:4 * rows].reshape(4, rows).astype(np.int64)
+        probes = []
+        eng.probe = probes
+        for _ in range(5):
+            eng.run(t, idx, buf.env_nums)
+        torch.cuda.synchronize()
+        ms = np.array([s.elapsed_time(e) for s, e in probes][4:])
+        print("%s grad kernel rows_mb=%2d (B=%6d): mean %.1f us  min %.1f us  (n=%d)" % (
+            os.environ.get("TRL_LIB", "default"), rows, rows * buf.env_nums, ms.mean() * 1e3, ms.min() * 1e3, len(ms)))
 
 
 if __name__ == "__main__":

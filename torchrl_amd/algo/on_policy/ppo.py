@@ -145,7 +145,7 @@ class _FusedPPO:
             offset += n
 
     def _n_wg(self, n_samples):
-        tiles = (n_samples + 31) // 32
+        tiles = (n_samples + 15) // 16
         per_net = max(1, min(self.max_wg // 2, (tiles + 3) // 4))
         return 2 * per_net
 

@@ -21,29 +21,33 @@
 #include "trl_common.h"
 #include "trl_mlp.h"
 
-#define PPO_THREADS 512
-#define PPO_WAVES 8
-#define PPO_PAIRS 4
+// ---- geometry: a GROUP of 4 waves owns a 16-sample tile; wave `mo` owns hidden features
+// [16mo, 16mo+16) of every layer (H == 64).  3 groups per workgroup -> 12 waves, 3 per SIMD (168 VGPRs each).
+#define Q_WAVES 4
+#define G_PER_WG 3
+#define PPO_WAVES (Q_WAVES * G_PER_WG)
+#define PPO_THREADS (64 * PPO_WAVES)
+#define TL 17                                   // LDS staging row stride (16 samples + 1)
 
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-
-// Two waves of a pair rendezvous on an LDS counter (the other pairs of the workgroup keep
-// running: a whole-workgroup s_barrier would put all 8 waves in lockstep and the MFMA phases of
-// one pair could no longer overlap the VALU/LDS phases of the pair sharing its SIMDs).
-__device__ __forceinline__ void pair_sync(int* cnt, int& expect, int lane) {
+// The 4 waves of a group rendezvous on an LDS counter; the other groups of the workgroup keep
+// running (an s_barrier would put all 16 waves in lockstep and nothing would overlap the MFMA
+// chains).  LDS operations of one wave are performed in order, so the arrive-atomic is ordered
+// after this wave's earlier ds_writes without a waitcnt; no fence intrinsic on purpose -- a
+// workgroup release also emits vmcnt(0) and would stall on global loads kept in flight.
+__device__ __forceinline__ void group_sync(int* cnt, int& expect, int lane) {
 #ifdef TRL_EXP_NOSYNC
   return;
 #endif
-  // LDS operations of one wave are performed in order, so the arrive-atomic below is ordered after
-  // every earlier ds_write of this wave without any s_waitcnt.  No fence intrinsic here on purpose:
-  // a workgroup-scope release also emits vmcnt(0) and would stall on the global loads this kernel
-  // deliberately keeps in flight across the rendezvous.
   asm volatile("" ::: "memory");
   if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  expect += 2;
+  expect += Q_WAVES;
   while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
 }
@@ -63,47 +67,87 @@ struct PpoDev {
 };
 
 template <int D, int H, int A> struct PpoShape {
-  static_assert(H == 64, "pair-cooperative kernel: two 32-feature tiles, one per wave of a pair");
-  static constexpr int KS = ksteps_for(D);
-  static constexpr int TS = H * TRL_TLD;               // (64 x 33) staging tensor shared by the pair
-  static constexpr int PT = 32 * TRL_TLD;              // wave-private (32 x 33) tile
+  static_assert(H == 64 && D > 16 && D <= 32 && A <= 8, "instantiated for 16 < D <= 32, H == 64, A <= 8");
   static constexpr int NSTAT = 7 + 2 * A;              // lp sum/sumsq/max/-min, ratio max/-min, loss, db3[A], dlogstd[A]
-  // pair scratch: H1s | DZ2s | P[2] | douts[32][8] | headp[2][8][32] | stats[NSTAT][32] | counter
-  static constexpr int O_H1 = 0, O_DZ2 = TS, O_P = 2 * TS, O_DO = O_P + 2 * PT,
-                       O_HP = O_DO + 256, O_ST = O_HP + 512, O_CNT = O_ST + align4(NSTAT * 32),
-                       PAIR_SCR = O_CNT + 4;
-  static constexpr int PAR = (MlpLds<D, H, A>::SIZE > MlpLds<D, H, 1>::SIZE) ? MlpLds<D, H, A>::SIZE : MlpLds<D, H, 1>::SIZE;
+  // group scratch: H1 | DZ2 | P[4] (wave private: H2 then dZ1) | headp[4][8][16] | douts[16][TL] | stats | counter
+  static constexpr int O_H1 = 0, O_DZ2 = H * TL, O_P = 2 * H * TL, O_HP = O_P + Q_WAVES * 16 * TL,
+                       O_DO = O_HP + Q_WAVES * 8 * 16, O_ST = O_DO + 16 * TL,
+                       O_CNT = O_ST + align4(NSTAT * 16), GRP_SCR = O_CNT + 4;
+  // shared small parameters: b1 | b2 | b3[8] | logstd[8]
+  static constexpr int O_B1 = 0, O_B2 = H, O_B3 = 2 * H, O_LS = 2 * H + 8, PAR = 2 * H + 16;
   static constexpr int P_PF = MlpFlat<D, H, A>::P_PF, P_VF = MlpFlat<D, H, 1>::P_VF;
   static constexpr int P_STRIDE = ((P_PF > P_VF ? P_PF : P_VF) + 63) & ~63;
-  static constexpr int SCR_ALL = PPO_PAIRS * PAIR_SCR;
-  static constexpr int LDS_FLOATS = align4(PAR) + (SCR_ALL > P_STRIDE ? SCR_ALL : P_STRIDE);
+  static constexpr int SCR_ALL = G_PER_WG * GRP_SCR;
+  static constexpr int FOLD = G_PER_WG * P_STRIDE;      // epilogue: one gradient image per group
+  static constexpr int LDS_FLOATS = PAR + (SCR_ALL > FOLD ? SCR_ALL : FOLD);
 };
 
-// One network (policy or value) over this workgroup's tiles.  A pair of waves owns a 32-sample
-// tile; wave `mo` of the pair computes the 32 hidden features [32mo, 32mo+32) of every layer,
-// its half of the weight gradients, and exchanges activations with its partner through LDS.
+// T-layout tile (MFMA C/D): reg r of lane (j, g) <-> feature 16*slice + 4g + r, sample j.
+// Staging rows are permuted inside a slice -- feature 4g + r sits in row 4r + g -- so that the two
+// lane groups of a 32-lane half write rows one apart (17 banks apart) instead of 4 rows apart
+// (4*17 = 68 = 4 banks apart, a 2-way conflict); srow() gives the row of feature f for the
+// lane-equals-feature reads, which stay conflict free because the stride is odd.
+__device__ __forceinline__ constexpr int srow(int f) { return ((f & 3) << 2) | (f >> 2); }
+__device__ __forceinline__ void store_T(float* S, int slice, const f32x4& t, int j, int g) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[(16 * slice + 4 * r + g) * TL + j] = t[r];
+}
+__device__ __forceinline__ f32x4 load_T(const float* S, int slice, int j, int g) {
+  f32x4 t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = S[(16 * slice + 4 * r + g) * TL + j];
+  return t;
+}
+
+// One network (policy or value) over this workgroup's tiles.
 template <int D, int H, int A, int ACT, bool IS_PF>
 __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
   constexpr int O = IS_PF ? A : 1;
   using S = PpoShape<D, H, A>;
-  using L = MlpLds<D, H, O>;
   using F = MlpFlat<D, H, O>;
-  constexpr int KS = ksteps_for(D);
-  constexpr int PARF = align4(S::PAR);
-  constexpr int NQ = (O + 3) / 4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pair = wave >> 1, mo0 = wave & 1;
-  const int i0 = lane & 31, hi0 = lane >> 5;
-  float* sp = lds;                                            // parameters (shared by the 4 pairs)
-  int* cnt = reinterpret_cast<int*>(lds + PARF + pair * S::PAIR_SCR + S::O_CNT);
+  const int grp = wave >> 2, mo0 = wave & 3;
+  const int j0 = lane & 15, g0 = lane >> 4;
+  const float* gp = IS_PF ? a.pf_params : a.vf_params;
+  float* spar = lds;
+  int* cnt = reinterpret_cast<int*>(lds + S::PAR + grp * S::GRP_SCR + S::O_CNT);
 
-  L::load(sp, IS_PF ? a.pf_params : a.vf_params, IS_PF, tid, PPO_THREADS);
-  if (lane == 0 && mo0 == 0) *cnt = 0;
+  // ---- one-time setup: small shared parameters to LDS, this wave's weight slices to registers ----
+  for (int e = tid; e < H; e += PPO_THREADS) { spar[S::O_B1 + e] = gp[F::B1 + e]; spar[S::O_B2 + e] = gp[F::B2 + e]; }
+  if (tid < 8) {
+    spar[S::O_B3 + tid] = tid < O ? gp[F::B3 + tid] : 0.0f;
+    spar[S::O_LS + tid] = (IS_PF && tid < O) ? gp[F::LS + tid] : 0.0f;
+  }
   {
-    float* st0 = lds + PARF + pair * S::PAIR_SCR + S::O_ST;  // per-lane statistic slots, [k][32]
-    if (mo0 == 0 && hi0 == 0)
-      for (int k = 0; k < S::NSTAT; ++k) st0[k * 32 + i0] = (k >= 2 && k <= 5) ? -INFINITY : 0.0f;
+    float* scr0 = lds + S::PAR + grp * S::GRP_SCR;
+    if (mo0 == 0) {
+      for (int e = lane; e < 16 * TL; e += 64) scr0[S::O_DO + e] = 0.0f;          // dout rows >= O stay zero
+      for (int e = lane; e < S::NSTAT * 16; e += 64) scr0[S::O_ST + e] = (e / 16 >= 2 && e / 16 <= 5) ? -INFINITY : 0.0f;
+      if (lane == 0) *cnt = 0;
+    }
+  }
+  // A operands, lane (i, g): k index of MFMA step (slice sl, r) is feature 16 sl + 4 g + r
+  float w1r[5], w2r[4][4], w2t[4][4], w3a[4], w3b[2];
+  {
+    const int row = 16 * mo0 + j0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w1r[r] = gp[F::W1 + row * D + 4 * g0 + r];
+    w1r[4] = (16 + g0 < D) ? gp[F::W1 + row * D + 16 + (16 + g0 < D ? g0 : 0)] : 0.0f;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        w2r[sl][r] = gp[F::W2 + row * H + 16 * sl + 4 * g0 + r];                  // forward:  W2[own row][k]
+        w2t[sl][r] = gp[F::W2 + (16 * sl + 4 * g0 + r) * H + row];                // backward: W2[k][own col]
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w3a[r] = (j0 < O) ? gp[F::W3 + (j0 < O ? j0 : 0) * H + 16 * mo0 + 4 * g0 + r] : 0.0f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int o = 4 * st + g0;
+      w3b[st] = (o < O) ? gp[F::W3 + (o < O ? o : 0) * H + row] : 0.0f;
+    }
   }
   __syncthreads();
   int expect = 0;
@@ -116,317 +160,314 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
   const float adv_rstd = 1.0f / ((float)sqrt(fmax(adv_var, 0.0)) + 1e-5f);
   const float inv_b = (float)(1.0 / ng);
 
-  // this wave's share of the gradient: rows (output features) [32mo, 32mo+32) of W2^T / W1^T
-  f32x16 gW2[2], gW1;
-  float gW3[O], gb1 = 0.f, gb2 = 0.f;
-  gW2[0] = zero_tile(); gW2[1] = zero_tile(); gW1 = zero_tile();
+  // this wave's share of the gradient: rows [16mo, 16mo+16) of W2 / W1, columns 16mo.. of W3
+  f32x4 gW2[4], gW1[2], gW3;
+  float gb1 = 0.f, gb2 = 0.f;
 #pragma unroll
-  for (int o = 0; o < O; ++o) gW3[o] = 0.f;
-  // scalar statistics, db3 and dlogstd are touched once per tile by 32 lanes only: they live in
-  // per-lane LDS slots (wave mo == 0, lanes hi == 0) instead of registers
+  for (int c = 0; c < 4; ++c) gW2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gW1[0] = gW1[1] = gW3 = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int B = a.rows_mb * a.N;
-  const int n_tiles = (B + 31) / 32;
-  const bool contig = (a.N % 32) == 0;
-  const bool stat_lane = (mo0 == 0 && hi0 == 0);
+  const int n_tiles = (B + 15) / 16;
+  const bool contig = (a.N % 16) == 0;
+  const int tile_stride = n_wg_net * G_PER_WG;
 
-  int64_t pos_next = 0;
-  {
-    const int sf = (wg_in_net * PPO_PAIRS + pair) * 32 + i0;
-    if (sf < B) {
-      const int r = sf / a.N, e = sf - r * a.N;
-      pos_next = (a.row_idx ? a.row_idx[r] : (int64_t)r) * a.N + e;
+  // Per-sample inputs are fetched ONE TILE AHEAD (x operand: 5 regs; loss inputs of wave 0: 4 regs),
+  // and the cell index two tiles ahead, so no global-load latency sits on a tile's critical path.
+  auto cell_of = [&](int smp) -> int64_t {
+    if (smp >= B) return 0;
+    const int r = smp / a.N, e = smp - r * a.N;
+    return (a.row_idx ? a.row_idx[r] : (int64_t)r) * a.N + e;
+  };
+  float xq[5], lq[4];
+  auto fetch_inputs = [&](int64_t p, int g_, int mo_) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xq[r] = a.obs[p * D + 4 * g_ + r];
+    xq[4] = a.obs[p * D + (16 + g_ < D ? 16 + g_ : 0)];
+    lq[0] = lq[1] = lq[2] = lq[3] = 0.0f;
+    if (mo_ == 0) {
+      if constexpr (IS_PF) {
+        lq[0] = a.acts[p * O + (g_ < O ? g_ : 0)];
+        lq[1] = a.acts[p * O + (g_ + 4 < O ? g_ + 4 : 0)];
+        lq[2] = a.advs[p]; lq[3] = a.old_logp[p];
+      } else {
+        lq[2] = a.rets[p]; lq[3] = a.clipped_value_loss ? a.old_values[p] : 0.0f;
+      }
     }
-  }
-  for (int tile = wg_in_net * PPO_PAIRS + pair; tile < n_tiles; tile += n_wg_net * PPO_PAIRS) {
+  };
+  const int first_s = (wg_in_net * G_PER_WG + grp) * 16 + j0;
+  int64_t pos_cur = cell_of(first_s);
+  int64_t pos_next = cell_of(first_s + tile_stride * 16);
+  fetch_inputs(pos_cur, g0, mo0);
+  for (int tile = wg_in_net * G_PER_WG + grp; tile < n_tiles; tile += tile_stride) {
     // Launder the lane coordinates once per tile: every LDS address below derives from them, and
-    // without this LICM hoists ~100 loop-invariant addresses out of the tile loop and spills them.
-    int i = i0, hi = hi0, mo = mo0, scr_off = PARF + pair * S::PAIR_SCR;
-    asm volatile("" : "+v"(i), "+v"(hi), "+v"(mo), "+v"(scr_off));
-    const int j = i, mx = mo ^ 1;
+    // without this LICM hoists the loop-invariant addresses out of the tile loop and spills them.
+    int j = j0, g = g0, mo = mo0, scr_off = S::PAR + grp * S::GRP_SCR;
+    asm volatile("" : "+v"(j), "+v"(g), "+v"(mo), "+v"(scr_off));
+    const int i = j;
     float* scr = lds + scr_off;
-    float* H1s = scr + S::O_H1;
-    float* DZ2s = scr + S::O_DZ2;
-    float* P = scr + S::O_P + mo * S::PT;                     // wave private
-    float* douts = scr + S::O_DO;
+    float* S_H1 = scr + S::O_H1;
+    float* S_DZ2 = scr + S::O_DZ2;
+    float* P = scr + S::O_P + mo * 16 * TL;                   // wave private [16 features][TL]
     float* headp = scr + S::O_HP;
-    const int s0 = tile * 32;
+    float* douts = scr + S::O_DO;
+    float* st = scr + S::O_ST;
+    const int s0 = tile * 16;
     const int s = s0 + j;
     const bool valid = s < B;
-    const int64_t pos = pos_next;                             // (row, env) cell of this lane's sample (0 if masked)
-    {                                                         // next tile's cell: its row_idx load flies during this tile
-      const int sn = s + n_wg_net * PPO_PAIRS * 32;
-      int64_t pn = 0;
-      if (sn < B) {
-        const int r = sn / a.N, e = sn - r * a.N;
-        pn = (a.row_idx ? a.row_idx[r] : (int64_t)r) * a.N + e;
-      }
-      pos_next = pn;
-    }
-    // this tile's per-sample scalars, issued now and consumed after layer 2 (latency hidden by the MFMAs)
-    float in_act[IS_PF ? O : 1], in_a, in_b;
-    if constexpr (IS_PF) {
+    const int64_t pos = pos_cur;                              // (row, env) cell of this lane's sample (0 if masked)
+    // consume the prefetched inputs, then start the next tile's fetch
+    float xb[5];
 #pragma unroll
-      for (int o = 0; o < O; ++o) in_act[o] = a.acts[pos * O + o];
-      in_a = a.advs[pos]; in_b = a.old_logp[pos];
-    } else {
-      in_act[0] = 0.0f;
-      in_a = a.rets[pos]; in_b = a.clipped_value_loss ? a.old_values[pos] : 0.0f;
-    }
-    float* st = scr + S::O_ST;
-    // ---- x^T operand straight from HBM/L2: lane (sample j, hi) holds features rowmap(q, hi) ----
-    float xb[KS];
+    for (int r = 0; r < 4; ++r) xb[r] = valid ? xq[r] : 0.0f;
+    xb[4] = (valid && 16 + g < D) ? xq[4] : 0.0f;
+    const float in_act0 = lq[0], in_act1 = lq[1], in_a = lq[2], in_b = lq[3];
+    pos_cur = pos_next;
+    pos_next = cell_of(s + 2 * tile_stride * 16);
+    fetch_inputs(pos_cur, g, mo);
+
+    // ---- forward layer 1, own 16 features ----
+    f32x4 h1 = *reinterpret_cast<const f32x4*>(spar + S::O_B1 + 16 * mo + 4 * g);
 #pragma unroll
-    for (int q = 0; q < KS; ++q) {                            // unconditional (clamped) loads + select: no exec-mask branches
-      const int k = rowmap(q, hi);
-      const float v = a.obs[pos * D + (k < D ? k : D - 1)];
-      xb[q] = (valid && k < D) ? v : 0.0f;
+    for (int q = 0; q < 5; ++q) h1 = mfma16(w1r[q], xb[q], h1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1[r] = act_fn<ACT>(h1[r]);
+    group_sync(cnt, expect, lane);                            // everybody is done with the previous tile's staging
+    store_T(S_H1, mo, h1, j, g);
+    group_sync(cnt, expect, lane);
+
+    // ---- forward layer 2 ----
+    f32x4 h2 = *reinterpret_cast<const f32x4*>(spar + S::O_B2 + 16 * mo + 4 * g);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const f32x4 b = load_T(S_H1, sl, j, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h2 = mfma16(w2r[sl][r], b[r], h2);
     }
-
-    // ---- forward layer 1, own feature tile ----
-    const f32x16 h1 = act_tile<ACT>(layer1_tile<D, L::LD1, KS>(bias_tile(sp + L::B1 + 32 * mo, hi), sp + L::W1, mo, xb, i, hi));
-    pair_sync(cnt, expect, lane);                             // partner is done with the previous tile's H1s / DZ2s
-    tile_store_T1(H1s, mo, h1, j, hi);
-    pair_sync(cnt, expect, lane);
-
-    // ---- forward layer 2: own half from registers, partner's half from LDS ----
-    f32x16 h2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[r] = act_fn<ACT>(h2[r]);
+    // partial head over the own features, on the matrix pipe: D[o][sample] (rows >= O are zero)
     {
-      const f32x16 h1x = tile_load_T1(H1s, mx, j, hi);
-      f32x16 acc = bias_tile(sp + L::B2 + 32 * mo, hi);
-      acc = layer_tile_1src<L::LD2>(acc, sp + L::W2, mo, mo, h1, i, hi);
-      acc = layer_tile_1src<L::LD2>(acc, sp + L::W2, mo, mx, h1x, i, hi);
-      h2 = act_tile<ACT>(acc);
-    }
-    // partial head over the own 32 features
+      f32x4 hp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < O; ++o) {
-      float p = 0.0f;
+      for (int r = 0; r < 4; ++r) hp = mfma16(w3a[r], h2[r], hp);
+      if (g < 2) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sp + L::W3 + o * H + 32 * mo + 8 * q + 4 * hi);
-        p = fmaf(w[0], h2[4 * q + 0], p); p = fmaf(w[1], h2[4 * q + 1], p);
-        p = fmaf(w[2], h2[4 * q + 2], p); p = fmaf(w[3], h2[4 * q + 3], p);
+        for (int r = 0; r < 4; ++r) headp[(mo * 8 + 4 * g + r) * 16 + j] = hp[r];
       }
-      p += __shfl_xor(p, 32, 64);
-      if (hi == 0) headp[(mo * 8 + o) * 32 + j] = p;
     }
-    tile_store_T1(P, 0, h2, j, hi);                           // own H2 tile, for dW3
-    pair_sync(cnt, expect, lane);
+    store_T(P, 0, h2, j, g);                                  // own H2 slice, for dW3
+    group_sync(cnt, expect, lane);
 
-    // ---- loss and d(loss)/d(out) (both waves compute it; wave 0 keeps the statistics) ----
-    float dout[O];
-    {
-      float out[O];
-#pragma unroll
-      for (int o = 0; o < O; ++o) out[o] = headp[o * 32 + j] + headp[(8 + o) * 32 + j] + sp[L::B3 + o];
+    // ---- loss and d(loss)/d(out): wave 0, lane (j, g) handles outputs g and g + 4 ----
+    if (mo == 0) {
+      float dout0 = 0.f, dout1 = 0.f;
       if constexpr (IS_PF) {
-        const float lp_old = in_b;
-        const float advn = valid ? (in_a - adv_mu) * adv_rstd : 0.0f;
-        float zc[O], inv_var[O];
-        float lp = 0.0f;
+        const int o0 = g, o1 = g + 4;
+        float out0 = spar[S::O_B3 + o0], out1 = spar[S::O_B3 + (o1 < 8 ? o1 : 0)];
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
-          const float ls = fminf(fmaxf(sp[L::LS + o], -20.0f), 2.0f);   // continuous_policy.py:8-9,185
-          inv_var[o] = __expf(-2.0f * ls);
-          const float act = valid ? in_act[o] : 0.0f;
-          lp += gauss_logp_term(act, out[o], inv_var[o], ls, a.tanh_action, zc[o]);
-        }
-        const float ratio = __expf(lp - lp_old);
+        for (int w = 0; w < 4; ++w) { out0 += headp[(w * 8 + o0) * 16 + j]; out1 += headp[(w * 8 + (o1 < 8 ? o1 : 0)) * 16 + j]; }
+        const float raw0 = spar[S::O_LS + o0], raw1 = spar[S::O_LS + (o1 < 8 ? o1 : 0)];
+        const float ls0 = fminf(fmaxf(raw0, -20.0f), 2.0f), ls1 = fminf(fmaxf(raw1, -20.0f), 2.0f);   // continuous_policy.py:8-9,185
+        const float iv0 = __expf(-2.0f * ls0), iv1 = __expf(-2.0f * ls1);
+        float zc0 = 0.f, zc1 = 0.f, lp = 0.0f;
+        if (o0 < O) lp += gauss_logp_term(valid ? in_act0 : 0.0f, out0, iv0, ls0, a.tanh_action, zc0);
+        if (o1 < O) lp += gauss_logp_term(valid ? in_act1 : 0.0f, out1, iv1, ls1, a.tanh_action, zc1);
+        lp += __shfl_xor(lp, 16, 64);
+        lp += __shfl_xor(lp, 32, 64);
+        const float advn = valid ? (in_a - adv_mu) * adv_rstd : 0.0f;
+        const float ratio = __expf(lp - in_b);
         const float s1 = ratio * advn;
         const float s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
         const float g_lp = (valid && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-          dout[o] = g_lp * zc[o] * inv_var[o];
-          if (stat_lane && valid) {
-            const float raw = sp[L::LS + o];                    // clamp passes gradient inside [-20, 2] only
-            const float pass = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;
-            st[(7 + A + o) * 32 + j] += pass * (g_lp * (zc[o] * zc[o] * inv_var[o] - 1.0f) - a.entropy_coeff * inv_b);
+        dout0 = g_lp * zc0 * iv0; dout1 = g_lp * zc1 * iv1;
+        if (valid) {                                          // per-lane LDS slots: [stat][sample lane]
+          if (o0 < O) {
+            st[(7 + o0) * 16 + j] += dout0;
+            const float pass = (raw0 >= -20.0f && raw0 <= 2.0f) ? 1.0f : 0.0f;   // clamp passes gradient inside [-20, 2]
+            st[(7 + A + o0) * 16 + j] += pass * (g_lp * (zc0 * zc0 * iv0 - 1.0f) - a.entropy_coeff * inv_b);
           }
-        }
+          if (o1 < O) {
+            st[(7 + o1) * 16 + j] += dout1;
+            const float pass = (raw1 >= -20.0f && raw1 <= 2.0f) ? 1.0f : 0.0f;
+            st[(7 + A + o1) * 16 + j] += pass * (g_lp * (zc1 * zc1 * iv1 - 1.0f) - a.entropy_coeff * inv_b);
+          }
 #ifndef TRL_EXP_NOSTATS
-        if (stat_lane && valid) {
-          st[0 * 32 + j] += lp; st[1 * 32 + j] = fmaf(lp, lp, st[1 * 32 + j]); st[6 * 32 + j] -= fminf(s1, s2);
-          st[2 * 32 + j] = fmaxf(st[2 * 32 + j], lp); st[3 * 32 + j] = fmaxf(st[3 * 32 + j], -lp);
-          st[4 * 32 + j] = fmaxf(st[4 * 32 + j], ratio); st[5 * 32 + j] = fmaxf(st[5 * 32 + j], -ratio);
-        }
+          if (g == 0) {
+            st[0 * 16 + j] += lp; st[1 * 16 + j] = fmaf(lp, lp, st[1 * 16 + j]); st[6 * 16 + j] -= fminf(s1, s2);
+            st[2 * 16 + j] = fmaxf(st[2 * 16 + j], lp); st[3 * 16 + j] = fmaxf(st[3 * 16 + j], -lp);
+            st[4 * 16 + j] = fmaxf(st[4 * 16 + j], ratio); st[5 * 16 + j] = fmaxf(st[5 * 16 + j], -ratio);
+          }
 #endif
-      } else {
-        const float v = out[0];
-        const float R = in_a;
-        float dv, l;
-        if (a.clipped_value_loss) {                            // ppo.py:104-111
-          const float vo = in_b;
-          const float dc = v - vo;
-          const float vc = vo + fminf(fmaxf(dc, -a.clip_para), a.clip_para);
-          const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
-          const float w1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), w2 = 1.0f - w1;
-          const float pass = (dc >= -a.clip_para && dc <= a.clip_para) ? 1.0f : 0.0f;
-          l = 0.5f * fmaxf(l1, l2);
-          dv = inv_b * (w1 * (v - R) + w2 * pass * (vc - R));
-        } else {                                               // nn.MSELoss, a2c.py:43
-          l = (v - R) * (v - R);
-          dv = 2.0f * (v - R) * inv_b;
         }
-        dout[0] = valid ? dv : 0.0f;
-        if (stat_lane && valid) st[6 * 32 + j] += l;
+        if (o0 < O) douts[o0 * TL + j] = dout0;
+        if (o1 < O) douts[o1 * TL + j] = dout1;
+      } else {
+        if (g == 0) {
+          float v = spar[S::O_B3];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v += headp[(w * 8) * 16 + j];
+          const float R = in_a;
+          float dv, l;
+          if (a.clipped_value_loss) {                          // ppo.py:104-111
+            const float vo = in_b;
+            const float dc = v - vo;
+            const float vc = vo + fminf(fmaxf(dc, -a.clip_para), a.clip_para);
+            const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+            const float w1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), w2 = 1.0f - w1;
+            const float pass = (dc >= -a.clip_para && dc <= a.clip_para) ? 1.0f : 0.0f;
+            l = 0.5f * fmaxf(l1, l2);
+            dv = inv_b * (w1 * (v - R) + w2 * pass * (vc - R));
+          } else {                                             // nn.MSELoss, a2c.py:43
+            l = (v - R) * (v - R);
+            dv = 2.0f * (v - R) * inv_b;
+          }
+          dout0 = valid ? dv : 0.0f;
+          if (valid) { st[6 * 16 + j] += l; st[7 * 16 + j] += dout0; }
+          douts[j] = dout0;
+        }
       }
     }
-    if (stat_lane) {
-#pragma unroll
-      for (int o = 0; o < O; ++o) st[(7 + o) * 32 + j] += dout[o];
-#pragma unroll
-      for (int o = 0; o < 4 * NQ; ++o) douts[j * 8 + o] = (o < O) ? dout[o] : 0.0f;
-    }
+    group_sync(cnt, expect, lane);
 
-    // ---- backward through the head, own features: dZ2 = (W3^T dout) * act'(H2) ----
-    f32x16 dz2;
+    // ---- backward through the head on the matrix pipe: dH2^T[f][s] = sum_o W3[o][f] dout[o][s] ----
+    f32x4 dz2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dz2 = mfma16(w3b[q], douts[(4 * q + g) * TL + j], dz2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dz2[r] *= act_grad<ACT>(h2[r]);
+    store_T(S_DZ2, mo, dz2, j, g);
+    // dW3[o][own f] += sum_s dout[o][s] H2[s][f]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gW3 = mfma16(douts[i * TL + 4 * q + g], P[srow(j) * TL + 4 * q + g], gW3);
+    // X with lane = input feature, k = sample 4q + g: issued here, consumed by the dW1 MFMAs below
+    float xn0[4], xn1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll
-      for (int o = 0; o < O; ++o) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sp + L::W3 + o * H + 32 * mo + 8 * q + 4 * hi);
-        d0 = fmaf(w[0], dout[o], d0); d1 = fmaf(w[1], dout[o], d1);
-        d2 = fmaf(w[2], dout[o], d2); d3 = fmaf(w[3], dout[o], d3);
-      }
-      dz2[4 * q + 0] = d0 * act_grad<ACT>(h2[4 * q + 0]); dz2[4 * q + 1] = d1 * act_grad<ACT>(h2[4 * q + 1]);
-      dz2[4 * q + 2] = d2 * act_grad<ACT>(h2[4 * q + 2]); dz2[4 * q + 3] = d3 * act_grad<ACT>(h2[4 * q + 3]);
-    }
-    tile_store_T1(DZ2s, mo, dz2, j, hi);
-    pair_sync(cnt, expect, lane);
-
-    // X with lane = input feature, reg r = sample rowmap(r, hi) (68-byte coalesced row segments): issued
-    // here, consumed by the dW1 MFMAs at the end of the tile
-    float xn[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int sj = rowmap(r, hi);
+      const int sj = 4 * q + g;
       int64_t pr;
-      if (contig) pr = pos - j + sj;                          // N % 32 == 0: the tile is one contiguous run of cells
+      if (contig) pr = pos - j + sj;                          // N % 16 == 0: the tile is one contiguous run of cells
       else        pr = __shfl(pos, sj, 64);
-      const float v = a.obs[((s0 + sj < B) ? pr : 0) * D + (i < D ? i : 0)];
-      xn[r] = (i < D && s0 + sj < B) ? v : 0.0f;
+      const bool ok = s0 + sj < B;
+      const float v0 = a.obs[(ok ? pr : 0) * D + i];
+      const float v1 = a.obs[(ok ? pr : 0) * D + (16 + i < D ? 16 + i : 0)];
+      xn0[q] = ok ? v0 : 0.0f;
+      xn1[q] = (ok && 16 + i < D) ? v1 : 0.0f;
     }
-    // ---- dW3[o][own f] += sum_s dout[o][s] H2[s][f]  (lane = feature) ----
-    {
-      const f32x16 h2n = tile_load_N(P, 0, i, hi);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const f32x4 d = *reinterpret_cast<const f32x4*>(douts + rowmap(r, hi) * 8 + 4 * q);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) if (4 * q + c < O) gW3[4 * q + c] = fmaf(h2n[r], d[c], gW3[4 * q + c]);
-        }
-      }
-    }
+    group_sync(cnt, expect, lane);
+
     // ---- dH1^T (own rows) = W2^T dZ2^T ; dZ1 = dH1 * act'(H1) ----
-    f32x16 dz1;
-    {
-      const f32x16 dz2x = tile_load_T1(DZ2s, mx, j, hi);
-      f32x16 acc = zero_tile();
-      acc = layer_tile_wT_1src<L::LD2>(acc, sp + L::W2, mo, mo, dz2, i, hi);
-      acc = layer_tile_wT_1src<L::LD2>(acc, sp + L::W2, mo, mx, dz2x, i, hi);
+    f32x4 dz1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dz1[r] = acc[r] * act_grad<ACT>(h1[r]);
+    for (int sl = 0; sl < 4; ++sl) {
+      const f32x4 b = load_T(S_DZ2, sl, j, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz1 = mfma16(w2t[sl][r], b[r], dz1);
     }
-    wave_lds_sync();                                          // P: H2 reads above precede the dZ1 writes below
-    tile_store_T1(P, 0, dz1, j, hi);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dz1[r] *= act_grad<ACT>(h1[r]);
+    wave_lds_sync();                                          // P: the H2 reads above precede the dZ1 writes below
+    store_T(P, 0, dz1, j, g);
     wave_lds_sync();
 
-    // ---- dW2^T[own j_out][k_in] += sum_s dZ2[s][j_out] H1[s][k_in] ----
-    {
-      const f32x16 dzn = tile_load_N(DZ2s, mo, i, hi);
-      float bs = 0.0f;
+    // ---- dW2[own j_out][k_in] += sum_s dZ2[s][j_out] H1[s][k_in] ----
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bs += dzn[r];
-      gb2 += bs;
+    for (int q = 0; q < 4; ++q) {
+      const float az = S_DZ2[(16 * mo + srow(i)) * TL + 4 * q + g];
+      gb2 += az;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          gW2[mb] = mfma32(dzn[r], H1s[(32 * mb + i) * TRL_TLD + rowmap(r, hi)], gW2[mb]);
+      for (int c = 0; c < 4; ++c) gW2[c] = mfma16(az, S_H1[(16 * c + srow(j)) * TL + 4 * q + g], gW2[c]);
     }
-    // ---- dW1^T[own j_out][k_in] += sum_s dZ1[s][j_out] X[s][k_in] ----
-    {
-      const f32x16 dzn = tile_load_N(P, 0, i, hi);
-      float bs = 0.0f;
+    // ---- dW1[own j_out][k_in] += sum_s dZ1[s][j_out] X[s][k_in] ----
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bs += dzn[r];
-      gb1 += bs;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gW1 = mfma32(dzn[r], xn[r], gW1);
+    for (int q = 0; q < 4; ++q) {
+      const float az = P[srow(i) * TL + 4 * q + g];
+      gb1 += az;
+      gW1[0] = mfma16(az, xn0[q], gW1[0]);
+      gW1[1] = mfma16(az, xn1[q], gW1[1]);
     }
     wave_lds_sync();
   }
 
-  // ---- fold the 8 waves in fixed order into one partial gradient (flat layout) ----
-  const int i = i0, hi = hi0, mo = mo0;
-  // pull this pair's statistic slots into registers before the scratch area is recycled
-  float stv[7], db3[O], dls[O];
+  // ---- fold the 4 groups in fixed order into one partial gradient (flat layout) ----
+  const int j = j0, g = g0, mo = mo0;
+  // pull this group's statistic slots into registers before the scratch area is recycled
+  float stv[7], db3v = 0.f, dlsv = 0.f;
   {
-    const float* st = lds + PARF + pair * S::PAIR_SCR + S::O_ST;
+    const float* st = lds + S::PAR + grp * S::GRP_SCR + S::O_ST;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) stv[k] = st[k * 32 + i];
+    for (int k = 0; k < 7; ++k) stv[k] = st[k * 16 + j];
+    // lane (j, g) fetches db3 / dlogstd of output o = 4*(lane>>5)... simpler: o = lane >> 4 + 4*(pass)
+  }
+  float db3a[2], dlsa[2];
+  {
+    const float* st = lds + S::PAR + grp * S::GRP_SCR + S::O_ST;
 #pragma unroll
-    for (int o = 0; o < O; ++o) { db3[o] = st[(7 + o) * 32 + i]; dls[o] = st[(7 + A + o) * 32 + i]; }
+    for (int q = 0; q < 2; ++q) {
+      const int o = g + 4 * q;
+      db3a[q] = (o < O) ? st[(7 + (o < O ? o : 0)) * 16 + j] : 0.0f;
+      dlsa[q] = (IS_PF && o < O) ? st[(7 + A + (o < O ? o : 0)) * 16 + j] : 0.0f;
+    }
   }
   __syncthreads();
-  float* gacc = lds + PARF;                                   // reuse scratch: S::P_STRIDE floats
-  for (int e = tid; e < S::P_STRIDE; e += PPO_THREADS) gacc[e] = 0.0f;
+  // Every group writes its own gradient image (the 4 waves of a group own disjoint addresses), then
+  // all threads add the images in fixed order: deterministic, and two barriers instead of one per group.
+  float* gimg = lds + S::PAR + grp * S::P_STRIDE;
+  for (int e = tid; e < G_PER_WG * S::P_STRIDE; e += PPO_THREADS) lds[S::PAR + e] = 0.0f;
   __syncthreads();
-  for (int w = 0; w < PPO_WAVES; ++w) {
-    if (wave == w) {
+  gb1 += __shfl_xor(gb1, 16, 64); gb1 += __shfl_xor(gb1, 32, 64);   // bias partials over the 4 lane groups
+  gb2 += __shfl_xor(gb2, 16, 64); gb2 += __shfl_xor(gb2, 32, 64);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jo = 32 * mo + rowmap(r, hi);
-        if (i < D) gacc[F::W1 + jo * D + i] += gW1[r];
-        gacc[F::W2 + jo * H + i] += gW2[0][r];
-        gacc[F::W2 + jo * H + 32 + i] += gW2[1][r];
-      }
-      // per-feature partials live in both lane halves: fold with one shuffle
-      const float b1v = gb1 + __shfl_xor(gb1, 32, 64);
-      const float b2v = gb2 + __shfl_xor(gb2, 32, 64);
-      if (hi == 0) { gacc[F::B1 + 32 * mo + i] += b1v; gacc[F::B2 + 32 * mo + i] += b2v; }
+  for (int r = 0; r < 4; ++r) {
+    const int jo = 16 * mo + 4 * g + r;                       // output feature (row of W2 / W1)
 #pragma unroll
-      for (int o = 0; o < O; ++o) {
-        const float w3v = gW3[o] + __shfl_xor(gW3[o], 32, 64);
-        if (hi == 0) gacc[F::W3 + o * H + 32 * mo + i] += w3v;
-      }
-      if (mo == 0) {
+    for (int c = 0; c < 4; ++c) gimg[F::W2 + jo * H + 16 * c + j] = gW2[c][r];
+    gimg[F::W1 + jo * D + j] = gW1[0][r];
+    if (16 + j < D) gimg[F::W1 + jo * D + 16 + j] = gW1[1][r];
+    const int o = 4 * g + r;                                  // gW3 rows are outputs
+    if (o < O) gimg[F::W3 + o * H + 16 * mo + j] = gW3[r];
+  }
+  if (g == 0) { gimg[F::B1 + 16 * mo + j] = gb1; gimg[F::B2 + 16 * mo + j] = gb2; }
+  if (mo == 0) {
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
-          const float b3v = wave_sum(hi == 0 ? db3[o] : 0.0f);
-          if (lane == 0) gacc[F::B3 + o] += b3v;
-          if (IS_PF) { const float lv = wave_sum(hi == 0 ? dls[o] : 0.0f); if (lane == 0) gacc[F::LS + o] += lv; }
-        }
+    for (int q = 0; q < 2; ++q) {
+      const int o = g + 4 * q;
+      float b3 = db3a[q], dl = dlsa[q];                       // sum over the 16 sample lanes of this lane group
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) { b3 += __shfl_xor(b3, off, 64); dl += __shfl_xor(dl, off, 64); }
+      if (j == 0 && o < O) {
+        gimg[F::B3 + o] = b3;
+        if (IS_PF) gimg[F::LS + o] = dl;
       }
     }
-    __syncthreads();
   }
-  const int wg = blockIdx.x;
-  for (int e = tid; e < S::P_STRIDE; e += PPO_THREADS) a.partial[(size_t)wg * a.p_stride + e] = gacc[e];
-
-  // ---- scalar statistics: wave shuffle reduce, then across the pairs through LDS ----
   __syncthreads();
-  double* sred = reinterpret_cast<double*>(lds + PARF);
+  const int wg = blockIdx.x;
+  for (int e = tid; e < S::P_STRIDE; e += PPO_THREADS) {
+    float acc = lds[S::PAR + e];
+#pragma unroll
+    for (int w = 1; w < G_PER_WG; ++w) acc += lds[S::PAR + w * S::P_STRIDE + e];
+    a.partial[(size_t)wg * a.p_stride + e] = acc;
+  }
+
+  // ---- scalar statistics: wave shuffle reduce, then across the groups through LDS ----
+  __syncthreads();
+  double* sred = reinterpret_cast<double*>(lds + S::PAR);
   if (mo == 0) {
-    const bool own = hi == 0;
+    const bool own = g == 0;
     const double v0 = wave_sum(own ? (double)stv[0] : 0.0), v1 = wave_sum(own ? (double)stv[1] : 0.0),
                  v6 = wave_sum(own ? (double)stv[6] : 0.0);
     const float v2 = wave_max(own ? stv[2] : -INFINITY), v3 = wave_max(own ? stv[3] : -INFINITY),
                 v4 = wave_max(own ? stv[4] : -INFINITY), v5 = wave_max(own ? stv[5] : -INFINITY);
     if (lane == 0) {
-      double* p = sred + pair * 8;
+      double* p = sred + grp * 8;
       p[0] = v0; p[1] = v1; p[2] = v2; p[3] = v3; p[4] = v4; p[5] = v5; p[6] = v6; p[7] = 0.0;
     }
   }
   __syncthreads();
   if (tid < 8) {
     double r = sred[tid];
-    for (int w = 1; w < PPO_PAIRS; ++w) {
+    for (int w = 1; w < G_PER_WG; ++w) {
       const double o = sred[w * 8 + tid];
       r = (tid >= 2 && tid <= 5) ? fmax(r, o) : r + o;
     }
@@ -435,7 +476,7 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
 }
 
 template <int D, int H, int A, int ACT>
-__global__ __launch_bounds__(PPO_THREADS, 2) void ppo_grad_kernel(PpoDev a) {
+__global__ __launch_bounds__(PPO_THREADS, 3) void ppo_grad_kernel(PpoDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int half = a.n_wg >> 1;
   if ((int)blockIdx.x < half) ppo_net_pass<D, H, A, ACT, true>(a, lds, blockIdx.x, half);

@@ -28,7 +28,7 @@ __host__ __device__ constexpr int ksteps_for(int d) {
 __host__ __device__ constexpr int align4(int x) { return (x + 3) & ~3; }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-#ifdef TRL_EXP_NOMFMA                     // development experiment: VALU stand-in keeps the data flow alive
+#ifdef TRL_EXP_NOMFMA
   c[0] = fmaf(a, b, c[0]);
   return c;
 #endif
