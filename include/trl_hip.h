@@ -36,6 +36,7 @@ extern "C" {
 
 #define TRL_ACT_TANH 0
 #define TRL_ACT_RELU 1
+#define TRL_ACT_NONE 2
 
 const char* trl_last_error(void);
 int trl_abi_version(void);
@@ -130,7 +131,8 @@ int trl_rollout_synth_f32(const trl_rollout_t* args, void* stream);
 
 /* synthetic env (re)start: for every env i with mask[i] != 0 (mask NULL = all):
  * episode_idx += 1, obs ~ N(0,1) from the Philox reset stream keyed
- * (env_seed_base + i, episode_idx), counters and running return cleared.
+ * (env_seed_base + i, episode_idx), env step counter cleared (the collector-side counter and
+ * running return only on a full reset, mask == NULL).
  * replaces VecEnv.reset / partial_reset (torchrl/env/vecenv.py:41-51). */
 int trl_synth_reset_f32(float* cur_obs, int32_t* t_env, int32_t* cur_step, int32_t* episode_idx,
                         float* ep_return, const uint8_t* mask, int N, int D, int64_t env_seed_base,
@@ -192,6 +194,74 @@ typedef struct trl_adam_t {
   float* norms_out;           /* (n_groups) pre-clip global norms */
 } trl_adam_t;
 int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
+
+/* --- K10 (generic): dense layers of any shape on fp32 MFMA -----------------
+ * replaces nn.Linear + activation forward/backward (torchrl/networks/base.py:30-44,
+ * nets.py:34-52) for networks the fused PPO kernels are not instantiated for
+ * (256-wide SAC nets, Q nets on [obs, act], FC heads).  Row-major, nn.Linear layout:
+ *   fwd          y[M,N]  = act(x[M,K] . w[N,K]^T + bias[N])       (bias may be NULL)
+ *   bwd_input    dx[M,K] = (dy * act'(y_gate))[M,N] . w[N,K]      (y_gate NULL: no gating)
+ *   bwd_weight   dw[N,K] = (dy * act'(y_gate))^T . x ;  db[N] = column sums   (db may be NULL)
+ * act' is expressed through the layer OUTPUT y_gate.  bwd_weight needs a workspace of
+ * trl_linear_bwd_weight_workspace(M, K, N) floats (split partials, folded in fixed order). */
+int trl_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y,
+                       int M, int K, int N, int act, void* stream);
+int trl_linear_bwd_input_f32(const float* dy, const float* y_gate, int gate_act, const float* w,
+                             float* dx, int M, int K, int N, void* stream);
+int trl_linear_bwd_weight_workspace(int M, int K, int N);
+int trl_linear_bwd_weight_f32(const float* dy, const float* y_gate, int gate_act, const float* x,
+                              float* dw, float* db, float* workspace, int M, int K, int N,
+                              void* stream);
+
+/* --- K12 / K13: twin-Q SAC update pieces (torchrl/algo/off_policy/twin_sac_q.py:84-220) ---- */
+/* torch.cat([obs, act], -1) of QNet.forward (torchrl/networks/nets.py:61-68) */
+int trl_concat2_f32(const float* a, const float* b, float* out, int rows, int fa, int fb, void* stream);
+/* pf.explore(x, return_log_probs=True) after the MLP: head (B, 2A) = [mean | log_std] ->
+ * action = tanh(mean + std * eps), log_prob (B)   (continuous_policy.py:92-121, 162-170) */
+int trl_tanh_gauss_rsample_fwd_f32(const float* head, const float* eps, float* act, float* logp,
+                                   int B, int A, int tanh_action, void* stream);
+/* its backward plus the std/mean regularisers (twin_sac_q.py:157-160) -> d_head (B, 2A) */
+/* d(loss)/d(log_prob) is the same for every row: (*d_logp_ptr) * d_logp_mul (alpha is a device
+ * scalar, d_logp_mul = 1 / B); d_logp_ptr NULL means 1 */
+int trl_tanh_gauss_rsample_bwd_f32(const float* head, const float* eps, const float* act,
+                                   const float* d_act, const float* d_logp_ptr, float d_logp_mul,
+                                   float w_std, float w_mean, float* d_head, int B, int A,
+                                   int tanh_action, void* stream);
+/* alpha loss + Adam step on log_alpha + alpha = exp(log_alpha) (twin_sac_q.py:111-120).
+ * state (4): log_alpha, exp_avg, exp_avg_sq, step; out (2): alpha, alpha_loss */
+int trl_sac_alpha_step_f32(const float* logp, int B, float target_entropy, float lr, float beta1,
+                           float beta2, float eps, float* state, float* out, void* stream);
+/* TD target, twin MSE losses and all loss gradients w.r.t. the Q outputs (twin_sac_q.py:125-155).
+ * every tensor (B); alpha: device scalar; sums (4 doubles): qf1 loss sum, qf2 loss sum,
+ * sum(alpha logp - min(q1n, q2n)), sum(rewards) */
+int trl_sac_losses_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
+                       const float* logp_next, const float* rewards, const float* terminals,
+                       const float* q1n, const float* q2n, const float* logp, const float* alpha,
+                       float gamma, int B, float* dq1, float* dq2, float* dq1n, float* dq2n,
+                       double* sums, void* stream);
+/* out (rows, A) = x1[:, off:off+A] + x2[:, off:off+A]  (d policy_loss / d action through both Q nets) */
+int trl_slice_add_f32(const float* x1, const float* x2, float* out, int rows, int ld, int off, int A,
+                      void* stream);
+/* K13: target <- (1 - tau) target + tau source  (torchrl/algo/utils.py:16-20) */
+int trl_polyak_f32(float* target, const float* source, int64_t n, float tau, void* stream);
+/* logging: mean / unbiased std / max / min over columns [off, off+width) of rows of `ld` floats,
+ * each value clamped to [clamp_lo, clamp_hi] first (the logged log_std is the clamped one) */
+int trl_moments_f64(const float* x, int64_t n, int ld, int off, int width, float clamp_lo,
+                    float clamp_hi, double* out4, void* stream);
+/* N(0,1) fill from the Philox4x32-10 stream (device exploration / rsample noise) */
+int trl_philox_normal_f32(float* out, int64_t n, int64_t seed, int64_t counter, void* stream);
+/* K1 stand-alone: one VecEnv.step of the synthetic env (torchrl/env/vecenv.py:53-61); cur_obs is
+ * advanced in place and copied to next_obs; rewards / dones are (N) floats */
+int trl_synth_env_step_f32(float* cur_obs, const float* act, const float* env_A, const float* env_B,
+                           int32_t* t_env, float reward_scale, int horizon, float* next_obs,
+                           float* rewards, float* dones, int N, int D, int A, void* stream);
+
+/* off-policy collector bookkeeping after env.step (torchrl/collector/base.py:205-224): step
+ * counters, running returns (logged + cleared on done), reset_mask = done | step >= max frames */
+int trl_collector_bookkeep_f32(const float* rewards, const float* dones, int32_t* cur_step,
+                               float* ep_return, int max_episode_frames, uint8_t* reset_mask,
+                               double* epoch_reward, int32_t* ep_count, float* ep_log, int ep_cap,
+                               int step, int N, void* stream);
 
 #ifdef __cplusplus
 }

@@ -71,3 +71,53 @@ class VecOnPolicyCollectorOracle:
         for t in range(self.steps_per_epoch):
             total += self.take_actions(None if noise is None else noise[t])
         return {"train_rewards": self.train_rews, "train_epoch_reward": total}
+
+
+class VecCollectorOracle:
+    """Off-policy vector collector, restating torchrl/collector/base.py:176-230: explore (one
+    N(0,1) draw per step, no log-probs), env.step, running returns logged and cleared on done,
+    reset of envs with done | step >= max_episode_frames, one ring row per step holding the RAW
+    rewards / dones (no bootstrap on the off-policy path)."""
+
+    def __init__(self, env, ring, pf_params, epoch_frames, max_episode_frames=999, act="relu", tanh_action=True):
+        from .sac import rsample
+        self._rsample = rsample
+        self.env, self.ring, self.pf = env, ring, pf_params
+        self.act, self.tanh_action = act, tanh_action
+        self.max_episode_frames = max_episode_frames
+        n = env.env_nums
+        self.steps_per_epoch = epoch_frames // n
+        self.current_step = np.zeros((n, 1))
+        self.train_rew = np.zeros((n, 1))
+        self.env.train()
+        self.current_ob = env.reset()
+
+    @torch.no_grad()
+    def take_actions(self, noise=None):
+        ob = torch.as_tensor(np.asarray(self.current_ob), dtype=torch.float32)
+        head = nets.mlp(ob, self.pf, self.act)
+        if noise is None:
+            noise = torch.randn(ob.shape[0], head.shape[1] // 2)
+        act = self._rsample(head, torch.as_tensor(noise, dtype=torch.float32), self.tanh_action)[0].numpy()
+        next_ob, reward, done, infos = self.env.step(act)
+        self.current_step += 1
+        sample = {"obs": self.current_ob, "next_obs": next_ob, "acts": act, "rewards": reward, "terminals": done,
+                  "time_limits": infos["time_limit"][:, None] if "time_limit" in infos else [False]}
+        self.train_rew += reward
+        if np.any(done):
+            self.train_rews += list(self.train_rew[done])
+            self.train_rew[done] = 0
+        flag = (self.current_step >= self.max_episode_frames) | done
+        if np.any(flag):
+            next_ob = self.env.partial_reset(np.squeeze(flag, axis=-1))
+            self.current_step[flag] = 0
+        self.ring.add(sample)
+        self.current_ob = next_ob
+        return np.sum(reward)
+
+    def train_one_epoch(self, noise=None):
+        self.train_rews = []
+        total = 0
+        for t in range(self.steps_per_epoch):
+            total += self.take_actions(None if noise is None else noise[t])
+        return {"train_rewards": self.train_rews, "train_epoch_reward": total}

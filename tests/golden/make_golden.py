@@ -342,6 +342,56 @@ def case_init():
     save("net_init", **out)
 
 
+def case_twin_sac_q():
+    """TwinSACQ.update (torchrl/algo/off_policy/twin_sac_q.py:84-220) on random batches: info dicts,
+    the two N(0,1) draws per update, post-update pf/qf/target params and log_alpha."""
+    import gym
+    import torchrl.policies as policies
+    import torchrl.networks as networks
+    from torchrl.algo import TwinSACQ
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    for tag, B, H, w_reg, clip, steps in (("h256", 256, 256, 0.0, None, 2), ("reg", 96, 64, 1e-3, 1.0, 2)):
+        D, A = 17, 6
+        torch.manual_seed(31)
+        net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase,
+                   activation_func=torch.nn.ReLU)
+        pf = policies.GuassianContPolicy(input_shape=D, output_shape=2 * A, tanh_action=True, **net)
+        qf1 = networks.QNet(input_shape=D + A, output_shape=1, **net)
+        qf2 = networks.QNet(input_shape=D + A, output_shape=1, **net)
+        env = SynthVecEnvCPU(4)
+        env.action_space = gym.spaces.Box(-1, 1, (A,))
+        agent = TwinSACQ(pf=pf, qf1=qf1, qf2=qf2, plr=3e-4, qlr=1e-3, policy_std_reg_weight=w_reg,
+                         policy_mean_reg_weight=w_reg, reparameterization=True, automatic_entropy_tuning=True,
+                         env=env, replay_buffer=None, collector=_StubCollector(), logger=NullLogger(),
+                         grad_clip=clip, discount=0.99, num_epochs=10, batch_size=B, device=torch.device("cpu"),
+                         save_dir=tempfile.mkdtemp(prefix="trl_save_"), tau=0.005, use_soft_update=True, opt_times=1)
+        for name, mod in (("pf", pf), ("qf1", qf1), ("qf2", qf2)):
+            out.update(state_arrays(f"{tag}_{name}0_", mod))
+        out[f"{tag}_args"] = np.array([B, H, w_reg, clip if clip else 0.0, steps], dtype=np.float64)
+        rs = np.random.RandomState(17)
+        for s in range(steps):
+            batch = {"obs": rs.randn(B, D).astype(np.float32), "next_obs": rs.randn(B, D).astype(np.float32),
+                     "acts": np.tanh(rs.randn(B, A)).astype(np.float32), "rewards": rs.randn(B, 1).astype(np.float32),
+                     "terminals": (rs.rand(B, 1) < 0.1).astype(np.float32)}
+            out.update({f"{tag}_s{s}_batch_{k}": v for k, v in batch.items()})
+            torch.manual_seed(100 + s)
+            state = torch.get_rng_state()
+            info = agent.update(batch)
+            after = torch.get_rng_state()
+            torch.set_rng_state(state)
+            out[f"{tag}_s{s}_eps1"] = torch.randn(B, A).numpy()
+            out[f"{tag}_s{s}_eps2"] = torch.randn(B, A).numpy()
+            assert torch.equal(torch.get_rng_state(), after), "noise stream mismatch"
+            keys = sorted(info.keys())
+            out[f"{tag}_s{s}_info_keys"] = np.array(keys)
+            out[f"{tag}_s{s}_info_vals"] = np.array([float(info[k]) for k in keys], dtype=np.float64)
+        for name, mod in (("pf", pf), ("qf1", qf1), ("qf2", qf2), ("tqf1", agent.target_qf1), ("tqf2", agent.target_qf2)):
+            out.update(state_arrays(f"{tag}_{name}1_", mod))
+        out[f"{tag}_log_alpha"] = agent.log_alpha.detach().numpy().copy()
+    save("twin_sac_q", **out)
+
+
 if __name__ == "__main__":
     install_stubs()
     case_gae()
@@ -349,3 +399,4 @@ if __name__ == "__main__":
     case_init()
     case_ppo_update()
     case_collect_and_epoch()
+    case_twin_sac_q()

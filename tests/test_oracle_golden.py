@@ -170,3 +170,31 @@ def test_collect_then_epoch_matches_reference(golden, tag):
     want_vf, _ = params_from(g, f"{tag}_vf1_", False)
     for a, b in zip(o.pf + [o.logstd] + o.vf, want_pf + [want_ls] + want_vf):
         np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=2e-6)
+
+
+def sac_params(g, prefix):
+    names = sorted(k for k in g.files if k.startswith(prefix))
+    base = [k for k in names if "base__seq_fcs" in k]
+    head = [k for k in names if "seq_append_fcs" in k]
+    order = sorted(base, key=lambda k: (int(k.split("__")[-2]), "bias" in k)) + sorted(head, key=lambda k: "bias" in k)
+    return [torch.tensor(g[k]) for k in order]
+
+
+@pytest.mark.parametrize("tag", ["h256", "reg"])
+def test_twin_sac_q_update_matches_reference(golden, tag):
+    from oracle.sac import TwinSACQOracle
+    g = golden("twin_sac_q")
+    B, H, w_reg, clip, steps = g[f"{tag}_args"]
+    o = TwinSACQOracle(sac_params(g, f"{tag}_pf0_"), sac_params(g, f"{tag}_qf10_"), sac_params(g, f"{tag}_qf20_"),
+                       plr=3e-4, qlr=1e-3, w_std=w_reg, w_mean=w_reg, grad_clip=clip if clip > 0 else None)
+    for s in range(int(steps)):
+        batch = {k: g[f"{tag}_s{s}_batch_{k}"] for k in ("obs", "next_obs", "acts", "rewards", "terminals")}
+        info = o.update(batch, g[f"{tag}_s{s}_eps1"], g[f"{tag}_s{s}_eps2"])
+        keys = [str(k) for k in g[f"{tag}_s{s}_info_keys"]]
+        assert sorted(info.keys()) == keys
+        got = np.array([info[k] for k in keys])
+        np.testing.assert_allclose(got, g[f"{tag}_s{s}_info_vals"], rtol=5e-5, atol=5e-6)
+    for name, mine in (("pf", o.pf), ("qf1", o.q1), ("qf2", o.q2), ("tqf1", o.tq1), ("tqf2", o.tq2)):
+        for a, b in zip(mine, sac_params(g, f"{tag}_{name}1_")):
+            np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(o.log_alpha.detach().numpy(), g[f"{tag}_log_alpha"], atol=1e-7)

@@ -1,0 +1,207 @@
+"""Twin-Q SAC path on the GPU: generic MFMA dense-layer kernels vs torch, the SAC element-wise
+kernels and the whole TwinSACQ.update vs the reference's outputs (tests/golden/twin_sac_q.npz),
+the off-policy collector vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, replay
+from oracle.collector import VecCollectorOracle
+from oracle.sac import rsample
+from oracle.synth_env import SynthVecEnvCPU
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("M,K,N", [(256, 23, 256), (4096, 256, 256), (100, 17, 12), (65, 256, 1), (1, 5, 3)])
+@pytest.mark.parametrize("act", ["tanh", "relu", "none"])
+def test_linear_layer_kernels_vs_torch(M, K, N, act):
+    from torchrl_amd import _C
+    code = {"tanh": _C.ACT_TANH, "relu": _C.ACT_RELU, "none": _C.ACT_NONE}[act]
+    gen = torch.Generator().manual_seed(M + K + N)
+    x, w, b = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5, torch.randn(N, generator=gen)
+    dy = torch.randn(M, N, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    z = torch.nn.functional.linear(xr, wr, br)
+    y = {"tanh": torch.tanh, "relu": torch.relu, "none": lambda t: t}[act](z)
+    y.backward(dy)
+    yd = _C.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), code)
+    scale = lambda t: max(1.0, t.abs().max().item())
+    assert (yd.cpu() - y.detach()).abs().max().item() < 2e-5 * scale(y.detach())
+    gate = None if act == "none" else yd
+    dx = _C.linear_bwd_input(dy.to(DEV), gate, code, w.to(DEV))
+    assert (dx.cpu() - xr.grad).abs().max().item() < 5e-5 * scale(xr.grad)
+    dw, db = _C.linear_bwd_weight(dy.to(DEV), gate, code, x.to(DEV))
+    assert (dw.cpu() - wr.grad).abs().max().item() < 5e-5 * scale(wr.grad)
+    assert (db.cpu() - br.grad).abs().max().item() < 5e-5 * scale(br.grad)
+    # no bias / bias gradient not requested
+    assert (_C.linear_fwd(x.to(DEV), w.to(DEV), None, _C.ACT_NONE).cpu() - x @ w.t()).abs().max().item() < 2e-5 * scale(y.detach())
+    assert _C.linear_bwd_weight(dy.to(DEV), gate, code, x.to(DEV), need_bias=False)[1] is None
+
+
+def test_rsample_fwd_bwd_vs_autograd():
+    from torchrl_amd import _C
+    B, A = 300, 6
+    gen = torch.Generator().manual_seed(4)
+    head = torch.randn(B, 2 * A, generator=gen)
+    head[:, A:] = head[:, A:] * 0.5 - 1.5                          # moderate std: tanh rarely saturates
+    head[0, A] = 3.0; head[1, A + 1] = -25.0                      # clamp boundaries: gradient must stop there
+    eps, d_act = torch.randn(B, A, generator=gen), torch.randn(B, A, generator=gen)
+    alpha, w_std, w_mean = 0.37, 1e-3, 2e-3
+    hr = head.clone().requires_grad_(True)
+    a, lp, mean, log_std = rsample(hr, eps)
+    loss = (a * d_act).sum() + (alpha / B) * lp.sum() + w_std * (log_std ** 2).mean() + w_mean * (mean ** 2).mean()
+    loss.backward()
+    act, logp = _C.rsample_fwd(head.to(DEV), eps.to(DEV))
+    np.testing.assert_allclose(act.cpu().numpy(), a.detach().numpy(), atol=1e-6)
+    # log(1 - a^2 + 1e-6) is ill-conditioned once |a| -> 1 (the reference calls the formula "not very
+    # numerically stable", distribution.py:11): compare rows whose actions are not saturated
+    ok = (a.detach().abs().max(dim=1).values < 0.999).numpy()
+    assert ok.mean() > 0.8
+    np.testing.assert_allclose(logp.cpu().numpy()[ok], lp.detach().numpy()[ok, 0], rtol=2e-5, atol=2e-4)
+    d_head = _C.rsample_bwd(head.to(DEV), eps.to(DEV), act, d_act.to(DEV), torch.tensor([alpha], device=DEV), 1.0 / B,
+                            w_std, w_mean)
+    okr = torch.as_tensor(ok)
+    err = (d_head.cpu() - hr.grad)[okr].abs().max().item()
+    assert err < 5e-5 * max(1.0, hr.grad[okr].abs().max().item()), err
+    assert d_head[0, A].item() == 0.0 and d_head[1, A + 1].item() == 0.0
+
+
+def sac_state(g, prefix):
+    return {k[len(prefix):].replace("__", "."): torch.tensor(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+def build_sac(H, w_reg, clip, B):
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import TwinSACQ
+    from torchrl.env.synth import SynthVecEnv
+    D, A = 17, 6
+    dev = torch.device(DEV)
+    net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.GuassianContPolicy(input_shape=D, output_shape=2 * A, tanh_action=True, **net)
+    qf1 = networks.QNet(input_shape=D + A, output_shape=1, **net)
+    qf2 = networks.QNet(input_shape=D + A, output_shape=1, **net)
+    env = SynthVecEnv(4, device=dev)
+
+    class Stub:
+        epoch_frames = 0
+
+    class Log:
+        def add_update_info(self, d): pass
+        def add_epoch_info(self, *a, **k): pass
+        def log(self, *a): pass
+        def finish(self): pass
+    return pf, qf1, qf2, dict(plr=3e-4, qlr=1e-3, policy_std_reg_weight=w_reg, policy_mean_reg_weight=w_reg,
+                              reparameterization=True, automatic_entropy_tuning=True, env=env, replay_buffer=None,
+                              collector=Stub(), logger=Log(), grad_clip=clip, discount=0.99, num_epochs=10,
+                              batch_size=B, device=dev, save_dir=None, tau=0.005, use_soft_update=True, opt_times=1), TwinSACQ
+
+
+@pytest.mark.parametrize("tag", ["h256", "reg"])
+def test_twin_sac_q_update_matches_reference(golden, tag):
+    g = golden("twin_sac_q")
+    B, H, w_reg, clip, steps = g[f"{tag}_args"]
+    B, H, steps = int(B), int(H), int(steps)
+    pf, qf1, qf2, kw, TwinSACQ = build_sac(H, float(w_reg), float(clip) if clip > 0 else None, B)
+    pf.load_state_dict(sac_state(g, f"{tag}_pf0_"))
+    qf1.load_state_dict(sac_state(g, f"{tag}_qf10_"))
+    qf2.load_state_dict(sac_state(g, f"{tag}_qf20_"))
+    agent = TwinSACQ(pf=pf, qf1=qf1, qf2=qf2, **kw)
+    for s in range(steps):
+        batch = {k: g[f"{tag}_s{s}_batch_{k}"] for k in ("obs", "next_obs", "acts", "rewards", "terminals")}
+        torch.manual_seed(100 + s)                                   # the reference's two CPU draws per update
+        info = agent.update(batch)
+        keys = [str(k) for k in g[f"{tag}_s{s}_info_keys"]]
+        assert sorted(info.keys()) == keys
+        got = np.array([info[k] for k in keys])
+        np.testing.assert_allclose(got, g[f"{tag}_s{s}_info_vals"], rtol=2e-4, atol=5e-5)
+    for name, mod in (("pf", pf), ("qf1", qf1), ("qf2", qf2), ("tqf1", agent.target_qf1), ("tqf2", agent.target_qf2)):
+        for k, p in mod.state_dict().items():
+            err = np.abs(p.cpu().numpy() - g[f"{tag}_{name}1_{k.replace('.', '__')}"]).max()
+            assert err < 3e-6, (name, k, err)
+    np.testing.assert_allclose(agent.log_alpha.cpu().numpy(), g[f"{tag}_log_alpha"], atol=1e-6)
+    assert float(agent.pf_optimizer.state[pf.seq_append_fcs[0].weight]["exp_avg"].abs().sum()) > 0
+
+
+def test_env_step_and_off_policy_collector_vs_oracle():
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector import VecCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    N, T, horizon, max_frames, seed, H = 48, 20, 6, 4, 3, 64
+    dev = torch.device(DEV)
+    torch.manual_seed(9)
+    net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net)
+    pf_p = [p.detach().clone() for wb in __import__("torchrl_amd.ops", fromlist=["x"]).linear_layers(pf) for p in wb]
+    # stand-alone env step vs the oracle env
+    env0, oenv0 = SynthVecEnv(N, horizon=horizon, device=dev), SynthVecEnvCPU(N, horizon=horizon)
+    env0.seed(seed); oenv0.seed(seed)
+    np.testing.assert_allclose(env0.reset().cpu().numpy(), oenv0.reset(), atol=3e-6)
+    acts = np.tanh(np.random.RandomState(0).randn(N, 6)).astype(np.float32)
+    o, r, d, info = env0.step(acts)
+    oo, orr, od, oinfo = oenv0.step(acts)
+    np.testing.assert_allclose(o.cpu().numpy(), oo, atol=2e-6)
+    np.testing.assert_allclose(r.cpu().numpy(), orr, atol=2e-6)
+    assert np.array_equal(d.cpu().numpy(), od) and info["time_limit"].shape == (N,)
+
+    env, eval_env = SynthVecEnv(N, horizon=horizon, device=dev), SynthVecEnv(N, horizon=horizon, device=dev)
+    env.seed(seed)
+    buf = BaseReplayBuffer(N * 8, env_nums=N)                        # ring of 8 rows: 20 steps wrap around
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * T,
+                       max_episode_frames=max_frames, eval_episodes=1)
+    oenv = SynthVecEnvCPU(N, horizon=horizon)
+    oenv.seed(seed)
+    ring = replay.RingOracle(N * 8, env_nums=N)
+    ocol = VecCollectorOracle(oenv, ring, pf_p, epoch_frames=N * T, max_episode_frames=max_frames)
+    torch.manual_seed(5)
+    want = ocol.train_one_epoch()
+    torch.manual_seed(5)
+    got = col.train_one_epoch()
+    for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+        err = np.abs(getattr(buf, "_" + k).cpu().numpy() - ring.data[k]).max()
+        assert err < 2e-5, (k, err)
+    assert buf._top == ring.top and buf._size == ring.size
+    assert abs(got["train_epoch_reward"] - want["train_epoch_reward"]) < 1e-3
+    np.testing.assert_allclose(np.array(got["train_rewards"], dtype=np.float64),
+                               np.array(want["train_rewards"], dtype=np.float64).reshape(-1), atol=1e-4)
+    np.testing.assert_allclose(col.current_ob.cpu().numpy(), ocol.current_ob, atol=2e-5)
+    ev = col.eval_one_epoch()
+    assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == horizon
+
+
+def test_sac_trains_through_rlalgo_with_device_noise():
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import TwinSACQ
+    from torchrl.collector import VecCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    N, dev = 64, torch.device(DEV)
+    net = dict(hidden_shapes=[256, 256], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net)
+    qf1 = networks.QNet(input_shape=23, output_shape=1, **net)
+    qf2 = networks.QNet(input_shape=23, output_shape=1, **net)
+    env, eval_env = SynthVecEnv(N, horizon=20, device=dev), SynthVecEnv(N, horizon=20, device=dev)
+    buf = BaseReplayBuffer(N * 64, env_nums=N)
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * 8,
+                       max_episode_frames=999, eval_episodes=1, noise_mode="device")
+    infos = []
+
+    class Log:
+        def add_update_info(self, d): infos.append(d)
+        def add_epoch_info(self, *a, **k): pass
+        def log(self, *a): pass
+        def finish(self): pass
+    agent = TwinSACQ(pf=pf, qf1=qf1, qf2=qf2, plr=3e-4, qlr=3e-4, policy_std_reg_weight=0, policy_mean_reg_weight=0,
+                     reparameterization=True, automatic_entropy_tuning=True, noise_mode="device", env=env,
+                     replay_buffer=buf, collector=col, logger=Log(), discount=0.99, num_epochs=2, batch_size=4 * N,
+                     device=dev, save_dir=None, tau=0.005, use_soft_update=True, opt_times=4, pretrain_epochs=1,
+                     eval_interval=1)
+    w0 = pf.seq_append_fcs[0].weight.detach().clone()
+    agent.train()
+    assert len(infos) == 8 and all(np.isfinite(list(i.values())).all() for i in infos)
+    assert (pf.seq_append_fcs[0].weight - w0).abs().max() > 0 and infos[-1]["Alpha"] < 1.0

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtrl_hip.so")
 _lib = None
 
-ACT_TANH, ACT_RELU = 0, 1
+ACT_TANH, ACT_RELU, ACT_NONE = 0, 1, 2
 ACT_CODES = {"tanh": ACT_TANH, "relu": ACT_RELU}
 
 c_float_p = C.POINTER(C.c_float)
@@ -88,6 +88,23 @@ SIGNATURES = {
     "trl_clip_adam_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
     "trl_synth_reset_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "trl_gauss_logp_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_concat2_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_tanh_gauss_rsample_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_tanh_gauss_rsample_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float] * 3 + [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_collector_bookkeep_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_sac_alpha_step_f32": (C.c_int, [C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_void_p] * 3),
+    "trl_sac_losses_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
+    "trl_slice_add_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "trl_polyak_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "trl_moments_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "trl_philox_normal_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "trl_synth_env_step_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_linear_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_linear_bwd_weight_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "trl_linear_bwd_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 
@@ -245,3 +262,137 @@ def gauss_logp(mean, acts, logstd, tanh_action, out=None):
                                    dev_ptr(logstd, name="logstd"), dev_ptr(out, name="out"), B, A,
                                    int(bool(tanh_action)), stream_ptr(mean.device)), "trl_gauss_logp_f32")
     return out
+
+
+def linear_fwd(x, w, bias, act):
+    """y = act(x @ w.T + bias); x (M, K), w (N, K) contiguous fp32 device tensors."""
+    M, K = int(x.shape[0]), int(x.shape[1])
+    N = int(w.shape[0])
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(lib().trl_linear_fwd_f32(dev_ptr(x, name="x"), dev_ptr(w, name="w"),
+                                   dev_ptr(bias, name="bias", allow_none=True), dev_ptr(y, name="y"),
+                                   M, K, N, act, stream_ptr(x.device)), "trl_linear_fwd_f32")
+    return y
+
+
+def linear_bwd_input(dy, y_gate, gate_act, w):
+    M, N = int(dy.shape[0]), int(dy.shape[1])
+    K = int(w.shape[1])
+    dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    check(lib().trl_linear_bwd_input_f32(dev_ptr(dy, name="dy"), dev_ptr(y_gate, name="y_gate", allow_none=True),
+                                         gate_act, dev_ptr(w, name="w"), dev_ptr(dx, name="dx"), M, K, N,
+                                         stream_ptr(dy.device)), "trl_linear_bwd_input_f32")
+    return dx
+
+
+def linear_bwd_weight(dy, y_gate, gate_act, x, dw=None, db=None, need_bias=True, workspace=None):
+    """dw (N, K) and db (N) of a dense layer; `dw` / `db` may be views into a flat gradient buffer."""
+    M, N = int(dy.shape[0]), int(dy.shape[1])
+    K = int(x.shape[1])
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    if db is None and need_bias:
+        db = torch.empty((N,), dtype=torch.float32, device=dy.device)
+    need = lib().trl_linear_bwd_weight_workspace(M, K, N)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.float32, device=dy.device)
+    check(lib().trl_linear_bwd_weight_f32(dev_ptr(dy, name="dy"), dev_ptr(y_gate, name="y_gate", allow_none=True),
+                                          gate_act, dev_ptr(x, name="x"), dev_ptr(dw, name="dw"),
+                                          dev_ptr(db, name="db", allow_none=True), dev_ptr(workspace, name="workspace"),
+                                          M, K, N, stream_ptr(dy.device)), "trl_linear_bwd_weight_f32")
+    return dw, db
+
+
+def concat2(a, b):
+    rows, fa, fb = int(a.shape[0]), int(a.shape[1]), int(b.shape[1])
+    out = torch.empty((rows, fa + fb), dtype=torch.float32, device=a.device)
+    check(lib().trl_concat2_f32(dev_ptr(a, name="a"), dev_ptr(b, name="b"), dev_ptr(out, name="out"), rows, fa, fb,
+                                stream_ptr(a.device)), "trl_concat2_f32")
+    return out
+
+
+def rsample_fwd(head, eps, tanh_action=True):
+    B, A = int(eps.shape[0]), int(eps.shape[1])
+    act = torch.empty((B, A), dtype=torch.float32, device=head.device)
+    logp = torch.empty((B,), dtype=torch.float32, device=head.device)
+    check(lib().trl_tanh_gauss_rsample_fwd_f32(dev_ptr(head, name="head"), dev_ptr(eps, name="eps"),
+                                               dev_ptr(act, name="act"), dev_ptr(logp, name="logp"), B, A,
+                                               int(bool(tanh_action)), stream_ptr(head.device)),
+          "trl_tanh_gauss_rsample_fwd_f32")
+    return act, logp
+
+
+def rsample_bwd(head, eps, act, d_act, d_logp_ptr, d_logp_mul, w_std, w_mean, tanh_action=True):
+    B, A = int(eps.shape[0]), int(eps.shape[1])
+    d_head = torch.empty((B, 2 * A), dtype=torch.float32, device=head.device)
+    check(lib().trl_tanh_gauss_rsample_bwd_f32(dev_ptr(head, name="head"), dev_ptr(eps, name="eps"),
+                                               dev_ptr(act, name="act"), dev_ptr(d_act, name="d_act"),
+                                               dev_ptr(d_logp_ptr, name="d_logp_ptr", allow_none=True),
+                                               float(d_logp_mul), float(w_std), float(w_mean),
+                                               dev_ptr(d_head, name="d_head"), B, A, int(bool(tanh_action)),
+                                               stream_ptr(head.device)), "trl_tanh_gauss_rsample_bwd_f32")
+    return d_head
+
+
+def sac_alpha_step(logp, target_entropy, lr, state, out, beta1=0.9, beta2=0.999, eps=1e-8):
+    check(lib().trl_sac_alpha_step_f32(dev_ptr(logp, name="logp"), int(logp.numel()), float(target_entropy),
+                                       float(lr), beta1, beta2, eps, dev_ptr(state, name="state"),
+                                       dev_ptr(out, name="out"), stream_ptr(logp.device)), "trl_sac_alpha_step_f32")
+
+
+def sac_losses(q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp, alpha, gamma, sums):
+    B = int(q1.numel())
+    outs = [torch.empty((B, 1), dtype=torch.float32, device=q1.device) for _ in range(4)]
+    ins = [q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp, alpha]
+    check(lib().trl_sac_losses_f32(*[dev_ptr(t, name="in%d" % i) for i, t in enumerate(ins)], float(gamma), B,
+                                   *[dev_ptr(t, name="out") for t in outs], dev_ptr(sums, torch.float64, "sums"),
+                                   stream_ptr(q1.device)), "trl_sac_losses_f32")
+    return outs
+
+
+def slice_add(x1, x2, off, A):
+    rows, ld = int(x1.shape[0]), int(x1.shape[1])
+    out = torch.empty((rows, A), dtype=torch.float32, device=x1.device)
+    check(lib().trl_slice_add_f32(dev_ptr(x1, name="x1"), dev_ptr(x2, name="x2"), dev_ptr(out, name="out"), rows, ld,
+                                  off, A, stream_ptr(x1.device)), "trl_slice_add_f32")
+    return out
+
+
+def polyak(target, source, tau):
+    check(lib().trl_polyak_f32(dev_ptr(target, name="target"), dev_ptr(source, name="source"), int(target.numel()),
+                               float(tau), stream_ptr(target.device)), "trl_polyak_f32")
+
+
+def moments(x, out4, ld=None, off=0, width=None, lo=float("-inf"), hi=float("inf")):
+    ld = int(x.shape[-1]) if ld is None else ld
+    width = ld - off if width is None else width
+    check(lib().trl_moments_f64(dev_ptr(x, name="x"), int(x.numel()), ld, off, width, lo, hi,
+                                dev_ptr(out4, torch.float64, "out4"), stream_ptr(x.device)), "trl_moments_f64")
+
+
+def philox_normal(out, seed, counter):
+    check(lib().trl_philox_normal_f32(dev_ptr(out, name="out"), int(out.numel()), int(seed), int(counter),
+                                      stream_ptr(out.device)), "trl_philox_normal_f32")
+    return out
+
+
+def synth_env_step(cur_obs, act, env_A, env_B, t_env, reward_scale, horizon, next_obs, rewards, dones):
+    N, D, A = int(cur_obs.shape[0]), int(cur_obs.shape[1]), int(act.shape[1])
+    check(lib().trl_synth_env_step_f32(dev_ptr(cur_obs, name="cur_obs"), dev_ptr(act, name="act"),
+                                       dev_ptr(env_A, name="env_A"), dev_ptr(env_B, name="env_B"),
+                                       dev_ptr(t_env, torch.int32, "t_env"), float(reward_scale), int(horizon),
+                                       dev_ptr(next_obs, name="next_obs"), dev_ptr(rewards, name="rewards"),
+                                       dev_ptr(dones, name="dones"), N, D, A, stream_ptr(cur_obs.device)),
+          "trl_synth_env_step_f32")
+
+
+def collector_bookkeep(rewards, dones, cur_step, ep_return, max_frames, mask, epoch_reward, ep_count, ep_log, step):
+    N = int(rewards.numel())
+    check(lib().trl_collector_bookkeep_f32(dev_ptr(rewards, name="rewards"), dev_ptr(dones, name="dones"),
+                                           dev_ptr(cur_step, torch.int32, "cur_step"),
+                                           dev_ptr(ep_return, name="ep_return"), int(max_frames),
+                                           dev_ptr(mask, torch.uint8, "mask"),
+                                           dev_ptr(epoch_reward, torch.float64, "epoch_reward"),
+                                           dev_ptr(ep_count, torch.int32, "ep_count"), dev_ptr(ep_log, name="ep_log"),
+                                           int(ep_log.shape[0]), int(step), N, stream_ptr(rewards.device)),
+          "trl_collector_bookkeep_f32")

@@ -1,3 +1,4 @@
 from .rl_algo import RLAlgo
 from .on_policy import OnRLAlgo, A2C, PPO
+from .off_policy import OffRLAlgo, TwinSACQ
 from . import utils

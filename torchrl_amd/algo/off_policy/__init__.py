@@ -1,0 +1,2 @@
+from .off_rl_algo import OffRLAlgo
+from .twin_sac_q import TwinSACQ

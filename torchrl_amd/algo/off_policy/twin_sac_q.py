@@ -1,0 +1,236 @@
+"""Twin-Q SAC (no V net) on the HIP path (reference: torchrl/algo/off_policy/twin_sac_q.py:10-244).
+
+`update(batch)` keeps the reference's order of operations -- sample new actions, alpha step (alpha
+is re-read AFTER it), no-grad target branch, twin MSE, policy loss through min(Q1, Q2) of the new
+actions, optimiser steps pf -> qf1 -> qf2, Polyak -- but runs as a fixed launch sequence with an
+explicit chain rule instead of autograd:
+  dense layers ............ trl_linear_{fwd,bwd_input,bwd_weight}_f32   (fp32 MFMA, k_gemm.hip)
+  rsample / its backward .. trl_tanh_gauss_rsample_{fwd,bwd}_f32
+  alpha loss + its Adam ... trl_sac_alpha_step_f32 (log_alpha, its moments and alpha stay on device)
+  TD target, losses, dQ ... trl_sac_losses_f32
+  dL/da through both Qs ... bwd_input of the two Q nets + trl_slice_add_f32
+  clip + Adam x3 .......... trl_clip_adam_f32 on one flat [pf | qf1 | qf2] buffer
+  target update ........... trl_polyak_f32 on flat [qf1 | qf2] -> [tqf1 | tqf2]
+policy_loss.backward() in the reference also deposits gradients in qf1/qf2 that the following
+zero_grad() discards (its Q20); only d/d(action) is propagated here.
+The two N(0,1) draws per update come from the CPU torch generator (reference parity) or from the
+device Philox stream (`noise_mode="device"`).
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ... import _C, ops
+from ...networks import flatten_into
+from .off_rl_algo import OffRLAlgo
+
+
+class TwinSACQ(OffRLAlgo):
+    def __init__(self, pf, qf1, qf2, plr, qlr, optimizer_class=optim.Adam, policy_std_reg_weight=1e-3,
+                 policy_mean_reg_weight=1e-3, reparameterization=True, automatic_entropy_tuning=True,
+                 target_entropy=None, noise_mode="host", **kwargs):
+        super().__init__(**kwargs)
+        self.pf, self.qf1, self.qf2 = pf, qf1, qf2
+        self.target_qf1 = copy.deepcopy(qf1)
+        self.target_qf2 = copy.deepcopy(qf2)
+        self.to(self.device)
+        self.plr, self.qlr = plr, qlr
+        self.optimizer_class = optimizer_class
+        self.qf1_optimizer = optimizer_class(self.qf1.parameters(), lr=self.qlr)
+        self.qf2_optimizer = optimizer_class(self.qf2.parameters(), lr=self.qlr)
+        self.pf_optimizer = optimizer_class(self.pf.parameters(), lr=self.plr)
+        self.automatic_entropy_tuning = automatic_entropy_tuning
+        if target_entropy:
+            self.target_entropy = target_entropy
+        else:
+            self.target_entropy = -float(np.prod(self.env.action_space.shape))
+        self.policy_std_reg_weight = policy_std_reg_weight
+        self.policy_mean_reg_weight = policy_mean_reg_weight
+        if not reparameterization:
+            raise NotImplementedError
+        self.reparameterization = reparameterization
+        if noise_mode not in ("host", "device"):
+            raise ValueError("noise_mode must be 'host' or 'device'")
+        self.noise_mode = noise_mode
+        self._engine = None
+
+    @property
+    def networks(self):
+        return [self.pf, self.qf1, self.qf2, self.target_qf1, self.target_qf2]
+
+    @property
+    def snapshot_networks(self):
+        return [["pf", self.pf], ["qf1", self.qf1], ["qf2", self.qf2]]
+
+    @property
+    def target_networks(self):
+        return [(self.qf1, self.target_qf1), (self.qf2, self.target_qf2)]
+
+    @property
+    def log_alpha(self):
+        return self.engine().alpha_state[0:1]
+
+    def engine(self):
+        if self._engine is None:
+            if self.optimizer_class is not optim.Adam:
+                raise _C.TrlError("the fused SAC step implements torch.optim.Adam only")
+            self._engine = _FusedSAC(self)
+        return self._engine
+
+    def update(self, batch):
+        self.training_update_num += 1
+        return self.engine().update(batch)
+
+
+class _FusedSAC:
+    def __init__(self, algo):
+        self.algo = algo
+        nets = (algo.pf, algo.qf1, algo.qf2)
+        self.dev = next(algo.pf.parameters()).device
+        if self.dev.type != "cuda":
+            raise _C.TrlError("TwinSACQ networks live on %s: the HIP path needs a GPU (no CPU path exists)" % self.dev)
+        self.act = ops.act_code(algo.pf)
+        if any(ops.act_code(n) != self.act for n in nets[1:]):
+            raise _C.TrlError("pf / qf1 / qf2 must use the same activation")
+        self.layers = [ops.linear_layers(n) for n in nets]
+        plists = [[t for wb in ls for t in wb] for ls in self.layers]
+        self.sizes = [sum(p.numel() for p in pl) for pl in plists]
+        self.flat = flatten_into(plists[0] + plists[1] + plists[2])       # [pf | qf1 | qf2]; parameters become views
+        self.tlayers = [ops.linear_layers(n) for n in (algo.target_qf1, algo.target_qf2)]
+        self.tflat = flatten_into([t for ls in self.tlayers for wb in ls for t in wb])
+        self.grads = torch.zeros_like(self.flat)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.gviews, off = [], 0
+        for ls in self.layers:
+            views = []
+            for w, b in ls:
+                gw = self.grads[off:off + w.numel()].view(w.shape); off += w.numel()
+                gb = self.grads[off:off + b.numel()].view(b.shape); off += b.numel()
+                views.append((gw, gb))
+            self.gviews.append(views)
+        off = 0
+        for opt, pl in zip((algo.pf_optimizer, algo.qf1_optimizer, algo.qf2_optimizer), plists):
+            for p in pl:
+                n = p.numel()
+                opt.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.m[off:off + n].view(p.shape),
+                                "exp_avg_sq": self.v[off:off + n].view(p.shape)}
+                off += n
+        self.step_count = 0
+        self.alpha_state = torch.zeros(4, device=self.dev)               # log_alpha, exp_avg, exp_avg_sq, step
+        self.alpha_out = torch.ones(2, device=self.dev)                  # alpha, alpha_loss
+        self.sums = torch.zeros(4, dtype=torch.float64, device=self.dev)
+        self.mom = torch.zeros(3, 4, dtype=torch.float64, device=self.dev)
+        self.norms = torch.zeros(3, device=self.dev)
+        self.workspace = None
+        self.D = int(self.layers[0][0][0].shape[1])
+        self.A = int(self.layers[0][-1][0].shape[0]) // 2
+        self.noise_ctr = 0
+        self.noise_seed = 0x5AC
+
+    def _noise(self, B):
+        if self.algo.noise_mode == "host":                               # distribution.py:67-70: CPU generator draw
+            return torch.randn(B, self.A).to(self.dev, non_blocking=True)
+        out = torch.empty(B, self.A, device=self.dev)
+        self.noise_ctr += 1
+        return _C.philox_normal(out, self.noise_seed, self.noise_ctr)
+
+    def _ws(self, B):
+        need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
+                   for ls in self.layers for w, _ in ls)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, device=self.dev)
+        return self.workspace
+
+    def update(self, batch):
+        algo, dev, A, D = self.algo, self.dev, self.A, self.D
+        as_t = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
+            .to(device=dev, dtype=torch.float32).contiguous()
+        obs, acts, nobs = as_t(batch['obs']), as_t(batch['acts']), as_t(batch['next_obs'])
+        rew, term = as_t(batch['rewards']).reshape(-1), as_t(batch['terminals']).reshape(-1)
+        B = int(obs.shape[0])
+        ws = self._ws(B)
+        pf_l, q1_l, q2_l = self.layers
+        tanh_action = bool(algo.pf.tanh_action)
+
+        # ---- policy sample on obs, Q(s, a) of the replayed actions ----
+        eps1 = self._noise(B)
+        head, tape_pf = ops.mlp_forward(pf_l, obs, self.act)
+        new_a, logp = _C.rsample_fwd(head, eps1, tanh_action)
+        x_sa = _C.concat2(obs, acts)
+        q1p, tape_q1 = ops.mlp_forward(q1_l, x_sa, self.act)
+        q2p, tape_q2 = ops.mlp_forward(q2_l, x_sa, self.act)
+        # ---- temperature ----
+        if algo.automatic_entropy_tuning:
+            _C.sac_alpha_step(logp, algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
+        # ---- target branch (no gradient) ----
+        eps2 = self._noise(B)
+        head2, _ = ops.mlp_forward(pf_l, nobs, self.act)
+        next_a, next_logp = _C.rsample_fwd(head2, eps2, tanh_action)
+        x_next = _C.concat2(nobs, next_a)
+        tq1, _ = ops.mlp_forward(self.tlayers[0], x_next, self.act)
+        tq2, _ = ops.mlp_forward(self.tlayers[1], x_next, self.act)
+        # ---- Q of the new actions, all losses and their output gradients ----
+        x_new = _C.concat2(obs, new_a)
+        q1n, tape_q1n = ops.mlp_forward(q1_l, x_new, self.act)
+        q2n, tape_q2n = ops.mlp_forward(q2_l, x_new, self.act)
+        alpha = self.alpha_out[0:1]
+        dq1, dq2, dq1n, dq2n = _C.sac_losses(q1p, q2p, tq1, tq2, next_logp, rew, term, q1n, q2n, logp, alpha,
+                                             algo.discount, self.sums)
+        # ---- policy gradient: through both Q nets to the action, then through the sampler ----
+        dx1 = ops.mlp_backward(tape_q1n, dq1n, grads=None, need_input=True)
+        dx2 = ops.mlp_backward(tape_q2n, dq2n, grads=None, need_input=True)
+        d_act = _C.slice_add(dx1, dx2, D, A)
+        d_head = _C.rsample_bwd(head, eps1, new_a, d_act, alpha, 1.0 / B, algo.policy_std_reg_weight,
+                                algo.policy_mean_reg_weight, tanh_action)
+        ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], workspace=ws)
+        ops.mlp_backward(tape_q1, dq1, grads=self.gviews[1], workspace=ws)
+        ops.mlp_backward(tape_q2, dq2, grads=self.gviews[2], workspace=ws)
+        # ---- optimiser steps (pf, qf1, qf2) and target update ----
+        self.step_count += 1
+        a = _C.AdamArgs()
+        a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
+                                                      self.m.data_ptr(), self.v.data_ptr())
+        a.n_groups = 3
+        for k in range(3):
+            a.group_sizes[k] = self.sizes[k]
+        a.group_lr[0] = algo.pf_optimizer.param_groups[0]['lr']
+        a.group_lr[1] = algo.qf1_optimizer.param_groups[0]['lr']
+        a.group_lr[2] = algo.qf2_optimizer.param_groups[0]['lr']
+        a.max_norm = float(algo.grad_clip) if algo.grad_clip else 0.0
+        a.beta1, a.beta2, a.eps, a.grad_scale = 0.9, 0.999, 1e-8, 1.0
+        a.step_count, a.norms_out = self.step_count, self.norms.data_ptr()
+        _C.clip_adam(a, dev)
+        src = self.flat[self.sizes[0]:]
+        if algo.use_soft_update:
+            _C.polyak(self.tflat, src, algo.tau)
+        elif algo.training_update_num % algo.target_hard_update_period == 0:
+            _C.polyak(self.tflat, src, 1.0)
+        # ---- logging statistics (one read-back) ----
+        _C.moments(head, self.mom[0], ld=2 * A, off=A, width=A, lo=-20.0, hi=2.0)     # clamped log_std
+        _C.moments(logp, self.mom[1], ld=1)
+        _C.moments(head, self.mom[2], ld=2 * A, off=0, width=A)
+        sums, mom = self.sums.cpu().numpy(), self.mom.cpu().numpy()
+        aout, norms = self.alpha_out.cpu().numpy(), self.norms.cpu().numpy()
+        w_std, w_mean = algo.policy_std_reg_weight, algo.policy_mean_reg_weight
+        reg = 0.0
+        if w_std or w_mean:
+            n = B * A - 1
+            ms_ls = mom[0][1] ** 2 * n / (n + 1) + mom[0][0] ** 2                     # E[x^2] from mean / unbiased std
+            ms_mu = mom[2][1] ** 2 * n / (n + 1) + mom[2][0] ** 2
+            reg = w_std * ms_ls + w_mean * ms_mu
+        info = {'Reward_Mean': sums[3] / B}
+        if algo.automatic_entropy_tuning:
+            info["Alpha"] = float(aout[0])
+            info["Alpha_loss"] = float(aout[1])
+        info['Training/policy_loss'] = sums[2] / B + reg
+        info['Training/qf1_loss'] = sums[0] / B
+        info['Training/qf2_loss'] = sums[1] / B
+        if algo.grad_clip is not None:
+            info['Training/pf_grad_norm'], info['Training/qf1_grad_norm'], info['Training/qf2_grad_norm'] = \
+                float(norms[0]), float(norms[1]), float(norms[2])
+        for key, row in (("log_std", mom[0]), ("log_probs", mom[1]), ("mean", mom[2])):
+            info[key + '/mean'], info[key + '/std'], info[key + '/max'], info[key + '/min'] = \
+                float(row[0]), float(row[1]), float(row[2]), float(row[3])
+        return info

@@ -202,8 +202,7 @@ class _FusedPPO:
             _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, self.D, self.H,
                                             self.A, self.flat.data_ptr(), self.grads.data_ptr(),
                                             info_base + 128 * k, stream), "trl_ppo_reduce_f32")
-            if world > 1:
-                dist.all_reduce_sum_(self.grads)                       # C1
+            dist.all_reduce_sum_(self.grads)                           # C1 (no-op at world size 1)
             self.step_count += 1
             a.step_count = self.step_count
             a.norms_out = norm_base + 8 * k

@@ -76,12 +76,123 @@ class BaseCollector:
 
 
 class VecCollector(BaseCollector):
-    """Vector collector base: `epoch_frames // env_nums` vector steps per epoch
-    (torchrl/collector/base.py:176-182)."""
+    """Off-policy vector collector (torchrl/collector/base.py:176-280) on the device env.
 
-    def __init__(self, **kwargs):
+    One vector step = policy MLP on the MFMA layer kernels -> reparameterised TanhNormal sample ->
+    stand-alone env step writing next_obs / rewards / terminals straight into the replay row ->
+    bookkeeping kernel (step counters, running returns, reset mask = done | step >= max frames) ->
+    partial reset.  `epoch_frames // env_nums` vector steps per epoch (base.py:179); nothing is read
+    back until the epoch ends.  Exploration noise: CPU `torch.randn(N, A)` per step (reference
+    stream, its Q5) or the device Philox stream (`noise_mode="device"`).
+    """
+    EP_LOG_CAP = 1 << 16
+
+    def __init__(self, noise_mode="host", **kwargs):
         super().__init__(**kwargs)
         self.sample_epoch_frames //= self.env.env_nums
         if not getattr(self.env, "is_device_env", False):
             raise _C.TrlError("torchrl_amd collectors need an on-GPU env (torchrl_amd.env.get_vec_env); "
                               "host gym envs have no kernel path")
+        if noise_mode not in ("host", "device"):
+            raise ValueError("noise_mode must be 'host' or 'device'")
+        self.noise_mode = noise_mode
+        self.global_step = 0
+        dev = self.env.device
+        self._epoch_reward = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._ep_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ep_log = torch.zeros(self.EP_LOG_CAP, 3, device=dev)
+        self._mask = torch.zeros(self.env.env_nums, dtype=torch.uint8, device=dev)
+        self._noise_seed = 0xC011
+
+    # ---- pieces shared with the on-policy subclass ----
+    def _finished_episodes(self):
+        """(step, env, return) rows of episodes that ended since the log was cleared, in the
+        reference's list order (step-major, then env index)."""
+        cnt = min(int(self._ep_count.item()), self.EP_LOG_CAP)
+        log = self._ep_log[:cnt].cpu().numpy()
+        if cnt:
+            log = log[np.lexsort((log[:, 1], log[:, 0]))]
+        return log
+
+    def _policy_action(self, env, deterministic):
+        from .. import ops
+        pf = self.pf
+        if not hasattr(pf, "tanh_action") or hasattr(pf, "logstd"):
+            raise _C.TrlError("VecCollector's kernel path expects a GuassianContPolicy (mean | log_std head); "
+                              "state-independent-std policies use VecOnPolicyCollector")
+        n, a_dim = env.env_nums, env.act_dim
+        head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf))
+        if deterministic:
+            eps = torch.zeros(n, a_dim, device=env.device)
+        elif self.noise_mode == "host":
+            eps = torch.randn(n, a_dim).to(env.device, non_blocking=True)      # distribution.py:67-70
+        else:
+            eps = _C.philox_normal(torch.empty(n, a_dim, device=env.device), self._noise_seed, self.global_step)
+        act, _ = _C.rsample_fwd(head, eps, bool(pf.tanh_action))
+        return act
+
+    def _step(self, env, store, deterministic=False, max_frames=None):
+        buf = self.replay_buffer
+        n, d, a_dim = env.env_nums, env.obs_dim, env.act_dim
+        act = self._policy_action(env, deterministic)
+        if store:
+            row = buf._top
+            buf._ensure_key("obs", (n, d))[row].copy_(env.cur_obs)           # before the env advances in place
+            buf._ensure_key("acts", (n, a_dim))[row].copy_(act)
+            nxt = buf._ensure_key("next_obs", (n, d))[row]
+            rew = buf._ensure_key("rewards", (n, 1))[row]
+            done = buf._ensure_key("terminals", (n, 1))[row]
+        else:
+            nxt = torch.empty(n, d, device=env.device)
+            rew = torch.empty(n, 1, device=env.device)
+            done = torch.empty(n, 1, device=env.device)
+        _C.synth_env_step(env.cur_obs, act, env.env_A, env.env_B, env.t_env, env.effective_reward_scale,
+                          env.horizon, nxt, rew, done)
+        if store:
+            buf._ensure_key("time_limits", (n, 1))[row].copy_(done)           # synthetic env: time_limit == done
+        _C.collector_bookkeep(rew, done, env.cur_step, env.ep_return,
+                              self.max_episode_frames if max_frames is None else max_frames, self._mask,
+                              self._epoch_reward, self._ep_count, self._ep_log, self.global_step)
+        _C.synth_reset(env.cur_obs, env.t_env, env.cur_step, env.episode_idx, env.ep_return, self._mask, env.seed_base)
+        if store:
+            buf._advance()
+        self.global_step += 1
+
+    def rollout(self, n_steps):
+        """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""
+        self.env.train()
+        self._epoch_reward.zero_()
+        self._ep_count.zero_()
+        for _ in range(n_steps):
+            self._step(self.env, True)
+        self.current_ob = self.env.cur_obs
+
+    def train_one_epoch(self):
+        self.rollout(self.sample_epoch_frames)
+        log = self._finished_episodes()
+        self.train_rews = [np.float32(r) for r in log[:, 2]]
+        self.train_epoch_reward = float(self._epoch_reward.item())
+        return {'train_rewards': self.train_rews, 'train_epoch_reward': self.train_epoch_reward}
+
+    def take_actions(self):
+        self.rollout(1)
+        return float(self._epoch_reward.item())
+
+    def eval_one_epoch(self):
+        """Greedy evaluation (base.py:232-280): action = tanh(mean); first episode of every eval env."""
+        env = self.eval_env
+        env.eval()
+        rews, lens = [], []
+        for _ in range(self.eval_episodes):
+            env.reset()
+            self._epoch_reward.zero_()
+            self._ep_count.zero_()
+            step0 = self.global_step
+            for _ in range(env.horizon):
+                self._step(env, False, deterministic=True, max_frames=2 ** 31 - 1)
+            first = {}
+            for step, idx, ret in self._finished_episodes():
+                first.setdefault(int(idx), (ret, int(step) - step0 + 1))
+            rews += [np.float32(first[i][0]) for i in sorted(first)]
+            lens += [first[i][1] for i in sorted(first)]
+        return {"eval_rewards": rews, "eval_traj_length": float(np.mean(lens)) if lens else 0.0}

@@ -34,20 +34,10 @@ class OnPolicyCollectorBase(BaseCollector):
 
 
 class VecOnPolicyCollector(VecCollector):
-    EP_LOG_CAP = 1 << 16
-
     def __init__(self, vf, discount=0.99, noise_mode="host", **kwargs):
         self.vf = vf
-        super().__init__(**kwargs)
+        super().__init__(noise_mode=noise_mode, **kwargs)
         self.discount = discount
-        if noise_mode not in ("host", "device"):
-            raise ValueError("noise_mode must be 'host' or 'device'")
-        self.noise_mode = noise_mode
-        self.global_step = 0                       # Philox counter / episode-log step stamp
-        dev = self.env.device
-        self._epoch_reward = torch.zeros(1, dtype=torch.float64, device=dev)
-        self._ep_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._ep_log = torch.zeros(self.EP_LOG_CAP, 3, device=dev)
         self._check_shapes()
 
     @property
@@ -109,15 +99,6 @@ class VecOnPolicyCollector(VecCollector):
         A = self._spec[2]
         draws = [torch.randn(env.env_nums, A) for _ in range(n_steps)]    # the reference's stream, step by step
         return torch.stack(draws).to(env.device, non_blocking=True).contiguous()
-
-    def _finished_episodes(self):
-        """(step, env, return) rows of episodes that ended in the last launch, in the
-        reference's list order (step-major, then env index)."""
-        cnt = min(int(self._ep_count.item()), self.EP_LOG_CAP)
-        log = self._ep_log[:cnt].cpu().numpy()
-        if cnt:
-            log = log[np.lexsort((log[:, 1], log[:, 0]))]
-        return log
 
     def rollout(self, n_steps):
         """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""

@@ -339,7 +339,10 @@ __global__ __launch_bounds__(256) void synth_reset_kernel(float* __restrict__ cu
   float z[4];
   philox_normals4((uint32_t)ep, 0u, (uint32_t)b, TRL_TAG_RESET, seed_base + n, z);
   for (int c = 0; c < 4; ++c) if (4 * b + c < D) cur_obs[(size_t)n * D + 4 * b + c] = z[c];
-  if (b == 0) { t_env[n] = 0; cur_step[n] = 0; ep_return[n] = 0.0f; }
+  if (b == 0) {
+    t_env[n] = 0;
+    if (!mask) { cur_step[n] = 0; ep_return[n] = 0.0f; }      // collector-side state: full reset only
+  }
 }
 __global__ __launch_bounds__(256) void synth_bump_episode_kernel(int32_t* __restrict__ episode_idx,
                                                                  const uint8_t* __restrict__ mask, int N) {

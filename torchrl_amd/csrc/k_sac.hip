@@ -1,0 +1,400 @@
+// K12 / K13 and friends -- the element-wise, reduction and target-update pieces of the twin-Q SAC
+// update (torchrl/algo/off_policy/twin_sac_q.py:84-220) and of the off-policy collector
+// (torchrl/collector/base.py:184-230).  The dense layers around them run on k_gemm.hip.
+//
+// All kernels are memory-bound streaming passes over (B, <=32) fp32 rows; scalar results
+// (losses, means, Adam state of log_alpha) stay on the device.
+#include "trl_common.h"
+#include "trl_mlp.h"
+#include "trl_philox.h"
+
+#define SAC_THREADS 256
+
+// block-wide sum into thread 0 (double) -- deterministic tree
+__device__ __forceinline__ double block_sum(double v, double* smem) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int w = 0; w < SAC_THREADS / 64; ++w) r += smem[w];
+  return r;
+}
+__device__ __forceinline__ double block_max(double v, double* smem) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  double r = -INFINITY;
+  for (int w = 0; w < SAC_THREADS / 64; ++w) r = fmax(r, smem[w]);
+  return r;
+}
+
+// ---------------------------------------------------------------- concat [a | b] along features
+__global__ __launch_bounds__(SAC_THREADS) void concat2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ out, int rows, int fa, int fb) {
+  const int f = fa + fb;
+  for (int64_t e = (int64_t)blockIdx.x * SAC_THREADS + threadIdx.x; e < (int64_t)rows * f;
+       e += (int64_t)gridDim.x * SAC_THREADS) {
+    const int r = (int)(e / f), c = (int)(e - (int64_t)r * f);
+    out[e] = c < fa ? a[(size_t)r * fa + c] : b[(size_t)r * fb + (c - fa)];
+  }
+}
+extern "C" int trl_concat2_f32(const float* a, const float* b, float* out, int rows, int fa, int fb, void* stream) {
+  TRL_REQUIRE(rows >= 0 && fa > 0 && fb > 0, "bad sizes");
+  if (rows == 0) return TRL_OK;
+  TRL_REQUIRE(a && b && out, "null pointer");
+  int grid = trl_ceil_div((int64_t)rows * (fa + fb), SAC_THREADS);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(concat2_kernel, dim3(grid), dim3(SAC_THREADS), 0, (hipStream_t)stream, a, b, out, rows, fa, fb);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// ---------------------------------------------------------------- reparameterised TanhNormal sample
+// head (B, 2A) = [mean | log_std] (GuassianContPolicy.forward, continuous_policy.py:162-170: chunk,
+// clamp log_std to [-20, 2]); z = mean + std * eps; action = tanh(z);
+// log_prob = sum_a Normal(mean, std).log_prob(z) - log(1 - action^2 + 1e-6)   (distribution.py:33-45,
+// with pre_tanh_value = z as explore(return_log_probs=True) passes it, continuous_policy.py:108-114).
+__global__ __launch_bounds__(SAC_THREADS) void rsample_fwd_kernel(const float* __restrict__ head,
+                                                                  const float* __restrict__ eps,
+                                                                  float* __restrict__ act, float* __restrict__ logp,
+                                                                  int B, int A, int tanh_action) {
+  const int b = blockIdx.x * SAC_THREADS + threadIdx.x;
+  if (b >= B) return;
+  float lp = 0.0f;
+  for (int o = 0; o < A; ++o) {
+    const float mean = head[(size_t)b * 2 * A + o];
+    const float ls = fminf(fmaxf(head[(size_t)b * 2 * A + A + o], -20.0f), 2.0f);
+    const float sd = __expf(ls), e = eps[(size_t)b * A + o];
+    const float z = fmaf(sd, e, mean);
+    const float zc = z - mean;
+    float lpo = -(zc * zc) / (2.0f * sd * sd) - ls - 0.91893853320467274f;
+    float a = z;
+    if (tanh_action) { a = trl_tanh(z); lpo -= __logf(fmaf(-a, a, 1.0f) + 1e-6f); }
+    act[(size_t)b * A + o] = a;
+    lp += lpo;
+  }
+  logp[b] = lp;
+}
+extern "C" int trl_tanh_gauss_rsample_fwd_f32(const float* head, const float* eps, float* act, float* logp, int B,
+                                              int A, int tanh_action, void* stream) {
+  TRL_REQUIRE(B >= 0 && A > 0, "bad sizes");
+  if (B == 0) return TRL_OK;
+  TRL_REQUIRE(head && eps && act && logp, "null pointer");
+  hipLaunchKernelGGL(rsample_fwd_kernel, dim3(trl_ceil_div(B, SAC_THREADS)), dim3(SAC_THREADS), 0,
+                     (hipStream_t)stream, head, eps, act, logp, B, A, tanh_action);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// backward of the above + the std / mean regularisers of twin_sac_q.py:157-160:
+//   L += w_std * mean(log_std^2) + w_mean * mean(mean^2)
+// d_act (B, A) and d_logp (scalar, the same for every row: alpha / B) come from the policy loss.
+// With z = mean + std eps held through eps: d logN/d mean = 0, d logN/d log_std = -1; the tanh
+// correction contributes t = 2 a (1 - a^2) / (1 - a^2 + 1e-6) through z.
+__global__ __launch_bounds__(SAC_THREADS) void rsample_bwd_kernel(const float* __restrict__ head,
+                                                                  const float* __restrict__ eps,
+                                                                  const float* __restrict__ act,
+                                                                  const float* __restrict__ d_act,
+                                                                  const float* __restrict__ d_logp_ptr, float d_logp_mul,
+                                                                  float w_std, float w_mean,
+                                                                  float* __restrict__ d_head, int B, int A,
+                                                                  int tanh_action) {
+  const int b = blockIdx.x * SAC_THREADS + threadIdx.x;
+  if (b >= B) return;
+  const float d_logp = (d_logp_ptr ? *d_logp_ptr : 1.0f) * d_logp_mul;     // alpha / B, alpha a device scalar
+  const float reg = 2.0f / ((float)B * (float)A);
+  for (int o = 0; o < A; ++o) {
+    const float mean = head[(size_t)b * 2 * A + o];
+    const float raw = head[(size_t)b * 2 * A + A + o];
+    const float ls = fminf(fmaxf(raw, -20.0f), 2.0f);
+    const float pass = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;
+    const float se = __expf(ls) * eps[(size_t)b * A + o];
+    const float a = act[(size_t)b * A + o];
+    float da_dz = 1.0f, t = 0.0f;
+    if (tanh_action) { da_dz = fmaf(-a, a, 1.0f); t = 2.0f * a * da_dz / (da_dz + 1e-6f); }
+    const float g_z = d_act[(size_t)b * A + o] * da_dz + d_logp * t;   // through z
+    d_head[(size_t)b * 2 * A + o] = g_z + w_mean * reg * mean;
+    d_head[(size_t)b * 2 * A + A + o] = pass * (g_z * se - d_logp + w_std * reg * ls);
+  }
+}
+extern "C" int trl_tanh_gauss_rsample_bwd_f32(const float* head, const float* eps, const float* act, const float* d_act,
+                                              const float* d_logp_ptr, float d_logp_mul, float w_std, float w_mean,
+                                              float* d_head, int B, int A, int tanh_action, void* stream) {
+  TRL_REQUIRE(B >= 0 && A > 0, "bad sizes");
+  if (B == 0) return TRL_OK;
+  TRL_REQUIRE(head && eps && act && d_act && d_head, "null pointer");
+  hipLaunchKernelGGL(rsample_bwd_kernel, dim3(trl_ceil_div(B, SAC_THREADS)), dim3(SAC_THREADS), 0,
+                     (hipStream_t)stream, head, eps, act, d_act, d_logp_ptr, d_logp_mul, w_std, w_mean, d_head, B, A, tanh_action);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// ---------------------------------------------------------------- entropy temperature step
+// alpha_loss = -mean(log_alpha * (log_prob + target_entropy)); Adam step on log_alpha;
+// alpha = exp(log_alpha) AFTER the step (twin_sac_q.py:111-120, its Q19 ordering).
+// state: [log_alpha, exp_avg, exp_avg_sq, step]; out: [alpha, alpha_loss].   Single workgroup.
+__global__ __launch_bounds__(SAC_THREADS) void sac_alpha_kernel(const float* __restrict__ logp, int B,
+                                                                float target_entropy, float lr, float beta1,
+                                                                float beta2, float eps, float* __restrict__ state,
+                                                                float* __restrict__ out) {
+  __shared__ double smem[SAC_THREADS / 64];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < B; b += SAC_THREADS) s += (double)logp[b];
+  s = block_sum(s, smem);
+  if (threadIdx.x == 0) {
+    const float mean_term = (float)(s / B) + target_entropy;     // mean(log_prob + H_target)
+    const float la = state[0];
+    out[1] = -la * mean_term;                                    // alpha_loss
+    const float g = -mean_term;
+    const float t = state[3] + 1.0f;
+    const float m = beta1 * state[1] + (1.0f - beta1) * g;
+    const float v = beta2 * state[2] + (1.0f - beta2) * g * g;
+    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+    const float la_new = la - (lr / bc1) * (m / (sqrtf(v) / sqrtf(bc2) + eps));
+    state[0] = la_new; state[1] = m; state[2] = v; state[3] = t;
+    out[0] = __expf(la_new);
+  }
+}
+extern "C" int trl_sac_alpha_step_f32(const float* logp, int B, float target_entropy, float lr, float beta1,
+                                      float beta2, float eps, float* state, float* out, void* stream) {
+  TRL_REQUIRE(B > 0, "empty batch");
+  TRL_REQUIRE(logp && state && out, "null pointer");
+  hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(SAC_THREADS), 0, (hipStream_t)stream, logp, B, target_entropy,
+                     lr, beta1, beta2, eps, state, out);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// ---------------------------------------------------------------- TD target + twin MSE + policy-loss gradients
+// q_target = r + (1 - d) gamma (min(tq1, tq2) - alpha logp')          (twin_sac_q.py:125-139)
+// qf_i loss = mean((q_i - q_target)^2), dq_i = 2 (q_i - q_target) / B   (nn.MSELoss, :142-143)
+// policy_loss = mean(alpha logp - min(q1n, q2n)); torch.min ties split the gradient (:145-155)
+//   dq1n = -(q1n < q2n ? 1 : q1n == q2n ? .5 : 0) / B,  dq2n likewise.
+// alpha_ptr: device scalar written by the alpha step (or a constant 1 when tuning is off).
+// sums (double[4]): qf1 loss sum, qf2 loss sum, sum(alpha logp - min q_new), sum rewards.
+__global__ __launch_bounds__(SAC_THREADS) void sac_losses_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                                                 const float* __restrict__ tq1, const float* __restrict__ tq2,
+                                                                 const float* __restrict__ logp_next,
+                                                                 const float* __restrict__ rew, const float* __restrict__ term,
+                                                                 const float* __restrict__ q1n, const float* __restrict__ q2n,
+                                                                 const float* __restrict__ logp, const float* __restrict__ alpha_ptr,
+                                                                 float gamma, int B, float* __restrict__ dq1,
+                                                                 float* __restrict__ dq2, float* __restrict__ dq1n,
+                                                                 float* __restrict__ dq2n, double* __restrict__ sums) {
+  __shared__ double smem[SAC_THREADS / 64];
+  const float alpha = *alpha_ptr;
+  const float inv_b = 1.0f / (float)B;
+  double s1 = 0, s2 = 0, sp = 0, sr = 0;
+  for (int b = blockIdx.x * SAC_THREADS + threadIdx.x; b < B; b += gridDim.x * SAC_THREADS) {
+    const float tv = fminf(tq1[b], tq2[b]) - alpha * logp_next[b];
+    const float qt = rew[b] + (1.0f - term[b]) * gamma * tv;
+    const float e1 = q1[b] - qt, e2 = q2[b] - qt;
+    dq1[b] = 2.0f * e1 * inv_b; dq2[b] = 2.0f * e2 * inv_b;
+    const float a = q1n[b], c = q2n[b];
+    dq1n[b] = -(a < c ? 1.0f : (a == c ? 0.5f : 0.0f)) * inv_b;
+    dq2n[b] = -(c < a ? 1.0f : (a == c ? 0.5f : 0.0f)) * inv_b;
+    s1 += (double)e1 * e1; s2 += (double)e2 * e2; sp += (double)(alpha * logp[b] - fminf(a, c)); sr += (double)rew[b];
+  }
+  s1 = block_sum(s1, smem); s2 = block_sum(s2, smem); sp = block_sum(sp, smem); sr = block_sum(sr, smem);
+  if (threadIdx.x == 0) { atomicAdd(&sums[0], s1); atomicAdd(&sums[1], s2); atomicAdd(&sums[2], sp); atomicAdd(&sums[3], sr); }
+}
+extern "C" int trl_sac_losses_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
+                                  const float* logp_next, const float* rew, const float* term, const float* q1n,
+                                  const float* q2n, const float* logp, const float* alpha, float gamma, int B,
+                                  float* dq1, float* dq2, float* dq1n, float* dq2n, double* sums, void* stream) {
+  TRL_REQUIRE(B > 0, "empty batch");
+  TRL_REQUIRE(q1 && q2 && tq1 && tq2 && logp_next && rew && term && q1n && q2n && logp && alpha, "null input");
+  TRL_REQUIRE(dq1 && dq2 && dq1n && dq2n && sums, "null output");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sums, 0, 4 * sizeof(double), s);
+  if (e != hipSuccess) { trl_set_error("sac_losses: memset: %s", hipGetErrorString(e)); return (int)e; }
+  // one workgroup: B is a few thousand and the sums must be order-deterministic
+  hipLaunchKernelGGL(sac_losses_kernel, dim3(1), dim3(SAC_THREADS), 0, s, q1, q2, tq1, tq2, logp_next, rew, term, q1n,
+                     q2n, logp, alpha, gamma, B, dq1, dq2, dq1n, dq2n, sums);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// ---------------------------------------------------------------- d(policy loss)/d(action): columns [off, off+A) of dx1 + dx2
+__global__ __launch_bounds__(SAC_THREADS) void slice_add_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                                float* __restrict__ out, int rows, int ld, int off, int A) {
+  const int e = blockIdx.x * SAC_THREADS + threadIdx.x;
+  if (e >= rows * A) return;
+  const int r = e / A, c = e - r * A;
+  out[e] = x1[(size_t)r * ld + off + c] + x2[(size_t)r * ld + off + c];
+}
+extern "C" int trl_slice_add_f32(const float* x1, const float* x2, float* out, int rows, int ld, int off, int A,
+                                 void* stream) {
+  TRL_REQUIRE(rows >= 0 && A > 0 && off >= 0 && off + A <= ld, "bad sizes");
+  if (rows == 0) return TRL_OK;
+  TRL_REQUIRE(x1 && x2 && out, "null pointer");
+  hipLaunchKernelGGL(slice_add_kernel, dim3(trl_ceil_div((int64_t)rows * A, SAC_THREADS)), dim3(SAC_THREADS), 0,
+                     (hipStream_t)stream, x1, x2, out, rows, ld, off, A);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// ---------------------------------------------------------------- K13 Polyak target update
+// target <- (1 - tau) target + tau source   (atu.soft_update_from_to, torchrl/algo/utils.py:16-20)
+__global__ __launch_bounds__(SAC_THREADS) void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src,
+                                                             int64_t n, float tau) {
+  for (int64_t e = (int64_t)blockIdx.x * SAC_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * SAC_THREADS)
+    tgt[e] = tgt[e] * (1.0f - tau) + src[e] * tau;
+}
+extern "C" int trl_polyak_f32(float* target, const float* source, int64_t n, float tau, void* stream) {
+  TRL_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TRL_OK;
+  TRL_REQUIRE(target && source, "null pointer");
+  int grid = trl_ceil_div(n, SAC_THREADS);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(polyak_kernel, dim3(grid), dim3(SAC_THREADS), 0, (hipStream_t)stream, target, source, n, tau);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// ---------------------------------------------------------------- mean / unbiased std / max / min of a tensor (logging)
+__global__ __launch_bounds__(SAC_THREADS) void moments_kernel(const float* __restrict__ x, int64_t n, int ld, int off,
+                                                              int width, float lo, float hi_, double* __restrict__ out) {
+  // x viewed as rows of `ld` floats; statistics over columns [off, off+width) of every row
+  __shared__ double smem[SAC_THREADS / 64];
+  double s = 0, sq = 0, mx = -INFINITY, nmn = -INFINITY;
+  const int64_t rows = n / ld;
+  for (int64_t e = threadIdx.x; e < rows * width; e += SAC_THREADS) {
+    const int64_t r = e / width;
+    const double v = (double)fminf(fmaxf(x[r * ld + off + (e - r * width)], lo), hi_);
+    s += v; sq += v * v; mx = fmax(mx, v); nmn = fmax(nmn, -v);
+  }
+  s = block_sum(s, smem); sq = block_sum(sq, smem); mx = block_max(mx, smem); nmn = block_max(nmn, smem);
+  if (threadIdx.x == 0) {
+    const double cnt = (double)(rows * width), mean = s / cnt;
+    out[0] = mean;
+    out[1] = cnt > 1 ? sqrt(fmax((sq - s * mean) / (cnt - 1), 0.0)) : NAN;
+    out[2] = mx; out[3] = -nmn;
+  }
+}
+extern "C" int trl_moments_f64(const float* x, int64_t n, int ld, int off, int width, float clamp_lo, float clamp_hi,
+                               double* out4, void* stream) {
+  TRL_REQUIRE(n > 0 && ld > 0 && off >= 0 && width > 0 && off + width <= ld && n % ld == 0, "bad sizes");
+  TRL_REQUIRE(x && out4, "null pointer");
+  hipLaunchKernelGGL(moments_kernel, dim3(1), dim3(SAC_THREADS), 0, (hipStream_t)stream, x, n, ld, off, width, clamp_lo, clamp_hi, out4);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// ---------------------------------------------------------------- N(0,1) fill from the Philox stream
+// element e uses counter (c0 = lo32(ctr), c1 = hi32(ctr), block = e / 4, tag NOISE) under `seed`
+__global__ __launch_bounds__(SAC_THREADS) void philox_normal_kernel(float* __restrict__ out, int64_t n, int64_t seed,
+                                                                    int64_t ctr) {
+  const int64_t blk = (int64_t)blockIdx.x * SAC_THREADS + threadIdx.x;
+  if (blk * 4 >= n) return;
+  float z[4];
+  philox_normals4((uint32_t)(ctr & 0xFFFFFFFFll), (uint32_t)((ctr >> 32) & 0xFFFFFFFFll), (uint32_t)blk, TRL_TAG_NOISE,
+                  seed, z);
+  for (int c = 0; c < 4; ++c) if (blk * 4 + c < n) out[blk * 4 + c] = z[c];
+}
+extern "C" int trl_philox_normal_f32(float* out, int64_t n, int64_t seed, int64_t counter, void* stream) {
+  TRL_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TRL_OK;
+  TRL_REQUIRE(out, "null pointer");
+  hipLaunchKernelGGL(philox_normal_kernel, dim3(trl_ceil_div((n + 3) / 4, SAC_THREADS)), dim3(SAC_THREADS), 0,
+                     (hipStream_t)stream, out, n, seed, counter);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// ---------------------------------------------------------------- K1 stand-alone: one vector step of the synthetic env
+// VecEnv.step (torchrl/env/vecenv.py:53-61) for SynthVecEnv: obs' = tanh(obs A + act B),
+// reward = scale (obs'[0] - 0.1 |act|^2), done = time_limit = (t_env + 1 >= horizon).
+// Writes next_obs into cur_obs (in place) AND into next_out; rewards / dones as (N) floats.
+__global__ __launch_bounds__(SAC_THREADS) void synth_step_kernel(float* __restrict__ cur_obs, const float* __restrict__ act,
+                                                                 const float* __restrict__ envA, const float* __restrict__ envB,
+                                                                 int32_t* __restrict__ t_env, float reward_scale, int horizon,
+                                                                 float* __restrict__ next_out, float* __restrict__ rew,
+                                                                 float* __restrict__ done, int N, int D, int A) {
+  extern __shared__ float sm[];                    // envA (D*D) | envB (A*D)
+  for (int e = threadIdx.x; e < D * D; e += SAC_THREADS) sm[e] = envA[e];
+  for (int e = threadIdx.x; e < A * D; e += SAC_THREADS) sm[D * D + e] = envB[e];
+  __syncthreads();
+  const int n = blockIdx.x * SAC_THREADS + threadIdx.x;
+  if (n >= N) return;
+  float o[32], a[8];
+  for (int k = 0; k < D; ++k) o[k] = cur_obs[(size_t)n * D + k];
+  float asq = 0.0f;
+  for (int k = 0; k < A; ++k) { a[k] = act[(size_t)n * A + k]; asq = fmaf(a[k], a[k], asq); }
+  float first = 0.0f;
+  for (int f = 0; f < D; ++f) {
+    float p = 0.0f;
+    for (int k = 0; k < D; ++k) p = fmaf(o[k], sm[k * D + f], p);
+    for (int k = 0; k < A; ++k) p = fmaf(a[k], sm[D * D + k * D + f], p);
+    const float v = trl_tanh(p);
+    if (f == 0) first = v;
+    cur_obs[(size_t)n * D + f] = v;
+    next_out[(size_t)n * D + f] = v;
+  }
+  const int t = t_env[n] + 1;
+  t_env[n] = t;
+  rew[n] = reward_scale * (first - 0.1f * asq);
+  done[n] = t >= horizon ? 1.0f : 0.0f;
+}
+extern "C" int trl_synth_env_step_f32(float* cur_obs, const float* act, const float* env_A, const float* env_B,
+                                      int32_t* t_env, float reward_scale, int horizon, float* next_obs, float* rewards,
+                                      float* dones, int N, int D, int A, void* stream) {
+  TRL_REQUIRE(N >= 0 && D > 0 && D <= 32 && A > 0 && A <= 8, "bad sizes (D <= 32, A <= 8)");
+  if (N == 0) return TRL_OK;
+  TRL_REQUIRE(cur_obs && act && env_A && env_B && t_env && next_obs && rewards && dones, "null pointer");
+  hipLaunchKernelGGL(synth_step_kernel, dim3(trl_ceil_div(N, SAC_THREADS)), dim3(SAC_THREADS),
+                     (D * D + A * D) * sizeof(float), (hipStream_t)stream, cur_obs, act, env_A, env_B, t_env,
+                     reward_scale, horizon, next_obs, rewards, dones, N, D, A);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// ---------------------------------------------------------------- off-policy collector bookkeeping
+// VecCollector.take_actions after env.step (torchrl/collector/base.py:205-224): step counters,
+// running returns (logged and cleared on done only), reset mask = done | step >= max_episode_frames.
+__global__ __launch_bounds__(SAC_THREADS) void collector_bookkeep_kernel(const float* __restrict__ rew,
+                                                                         const float* __restrict__ done,
+                                                                         int32_t* __restrict__ cur_step,
+                                                                         float* __restrict__ ep_return, int max_frames,
+                                                                         uint8_t* __restrict__ mask,
+                                                                         double* __restrict__ epoch_reward,
+                                                                         int32_t* __restrict__ ep_count,
+                                                                         float* __restrict__ ep_log, int ep_cap, int step,
+                                                                         int N) {
+  __shared__ double smem[SAC_THREADS / 64];
+  const int n = blockIdx.x * SAC_THREADS + threadIdx.x;
+  double r = 0.0;
+  if (n < N) {
+    r = (double)rew[n];
+    const bool d = done[n] != 0.0f;
+    const int cs = cur_step[n] + 1;
+    float er = ep_return[n] + rew[n];
+    if (d) {
+      const int slot = atomicAdd(ep_count, 1);
+      if (slot < ep_cap) { ep_log[slot * 3 + 0] = (float)step; ep_log[slot * 3 + 1] = (float)n; ep_log[slot * 3 + 2] = er; }
+      er = 0.0f;
+    }
+    const bool flag = d || cs >= max_frames;
+    cur_step[n] = flag ? 0 : cs;
+    ep_return[n] = er;
+    mask[n] = flag ? 1 : 0;
+  }
+  r = block_sum(r, smem);
+  if (threadIdx.x == 0 && epoch_reward) atomicAdd(epoch_reward, r);
+}
+extern "C" int trl_collector_bookkeep_f32(const float* rewards, const float* dones, int32_t* cur_step, float* ep_return,
+                                          int max_episode_frames, uint8_t* reset_mask, double* epoch_reward,
+                                          int32_t* ep_count, float* ep_log, int ep_cap, int step, int N, void* stream) {
+  TRL_REQUIRE(N >= 0 && ep_cap >= 0, "bad sizes");
+  if (N == 0) return TRL_OK;
+  TRL_REQUIRE(rewards && dones && cur_step && ep_return && reset_mask && ep_count && ep_log, "null pointer");
+  hipLaunchKernelGGL(collector_bookkeep_kernel, dim3(trl_ceil_div(N, SAC_THREADS)), dim3(SAC_THREADS), 0,
+                     (hipStream_t)stream, rewards, dones, cur_step, ep_return, max_episode_frames, reset_mask,
+                     epoch_reward, ep_count, ep_log, ep_cap, step, N);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}

@@ -11,8 +11,14 @@ needs no collective; only three small reductions exist:
   C2  advantage statistics {sum, sumsq} SUM and {max, -min} MAX, once per epoch,
   C3  logging statistics, once per epoch.
 """
+import os
+
 import torch
 import torch.distributed as td
+
+# TRL_FORCE_COLLECTIVES=1 issues the collectives even at world size 1 (single-GPU smoke test of the
+# RCCL call path: dtypes, in-place views, stream ordering)
+_FORCE = os.environ.get("TRL_FORCE_COLLECTIVES", "0") == "1"
 
 
 def initialized():
@@ -37,21 +43,25 @@ def shard(total_envs, world=None, r=None):
     return r * per, per
 
 
+def _active():
+    return initialized() and (world_size() > 1 or _FORCE)
+
+
 def all_reduce_sum_(t):
-    if initialized() and world_size() > 1:
+    if _active():
         td.all_reduce(t, op=td.ReduceOp.SUM)
     return t
 
 
 def all_reduce_max_(t):
-    if initialized() and world_size() > 1:
+    if _active():
         td.all_reduce(t, op=td.ReduceOp.MAX)
     return t
 
 
 def reduce_adv_raw_(raw):
     """raw: (K, 4) float64 {sum, sumsq, max, -min} -> global statistics (C2)."""
-    if initialized() and world_size() > 1:
+    if _active():
         s = raw[:, :2].contiguous()
         m = raw[:, 2:].contiguous()
         all_reduce_sum_(s)
@@ -68,7 +78,7 @@ INFO_MAX_COLS = [3, 4, 5, 6]
 
 def reduce_info_(info):
     """info: (K, 16) float64 per-update statistics -> global (C3)."""
-    if initialized() and world_size() > 1:
+    if _active():
         s = info[:, INFO_SUM_COLS].contiguous()
         m = info[:, INFO_MAX_COLS].contiguous()
         all_reduce_sum_(s)

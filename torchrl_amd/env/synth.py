@@ -4,8 +4,9 @@
 (torchrl/env/vecenv.py:6-78: env_nums, reset, partial_reset(mask) returning the
 whole obs array, seed(s) -> env i seeded s*N+i, train/eval/close,
 observation_space / action_space, settable _reward_scale) but all state lives
-in device tensors and stepping happens inside the fused collector kernel
-(trl_rollout_synth_f32) -- there is no per-env Python object and no host copy.
+in device tensors: on-policy collection steps it inside the fused rollout kernel
+(trl_rollout_synth_f32), `step()` / the off-policy collector use the stand-alone step kernel
+(trl_synth_env_step_f32) -- there is no per-env Python object and no host copy.
 
 HalfCheetah-shaped dynamics (17-d obs, 6-d act):
     obs' = tanh(obs @ A + act @ B),  A (17x17), B (6x17) = 0.1 * RandomState(1234).randn
@@ -90,6 +91,14 @@ class SynthVecEnv:
         return self.cur_obs
 
     def step(self, actions):
-        raise NotImplementedError(
-            "SynthVecEnv is stepped inside the fused collector kernel (VecOnPolicyCollector); "
-            "a stand-alone step kernel is not part of this build")
+        """One vector step as a stand-alone kernel (torchrl/env/vecenv.py:53-61 protocol, device tensors):
+        returns (obs (N, D), rewards (N, 1), dones (N, 1) bool, {'time_limit': (N,) bool})."""
+        n = self.env_nums
+        acts = torch.as_tensor(actions).to(device=self.device, dtype=torch.float32).reshape(n, self.act_dim).contiguous()
+        nxt = torch.empty(n, self.obs_dim, device=self.device)
+        rew = torch.empty(n, 1, device=self.device)
+        done = torch.empty(n, 1, device=self.device)
+        _C.synth_env_step(self.cur_obs, acts, self.env_A, self.env_B, self.t_env, self.effective_reward_scale,
+                          self.horizon, nxt, rew, done)
+        dones = done > 0.5
+        return nxt, rew, dones, {"time_limit": dones.reshape(n)}
