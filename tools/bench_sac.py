@@ -1,0 +1,85 @@
+"""Secondary measurement: Twin-Q SAC at BASELINE cfg 3 (1024 envs, 1e6-transition replay = 976 rows,
+B = 4096, MLP 256x256 ReLU): per epoch 16 vector steps (16 384 env-steps) + 16 updates.
+Prints one JSON line; `--cpu` also times the CPU oracle on a bounded sample (2 updates)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+N, ROWS, B, H, STEPS, OPT = 1024, 976, 4096, 256, 16, 16
+
+
+class NullLog:
+    def add_update_info(self, d): pass
+    def add_epoch_info(self, *a, **k): pass
+    def log(self, *a): pass
+    def finish(self): pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=20)
+    ap.add_argument("--cpu", action="store_true")
+    args = ap.parse_args()
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import TwinSACQ
+    from torchrl.collector import VecCollector
+    from torchrl.env import get_vec_env
+    from torchrl.replay_buffers import BaseReplayBuffer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0); np.random.seed(0)
+    net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net)
+    qf1 = networks.QNet(input_shape=23, output_shape=1, **net)
+    qf2 = networks.QNet(input_shape=23, output_shape=1, **net)
+    env = get_vec_env("SynthHalfCheetah-v0", {"reward_scale": 1, "obs_norm": False}, N)
+    eval_env = get_vec_env("SynthHalfCheetah-v0", {"reward_scale": 1, "obs_norm": False}, N)
+    buf = BaseReplayBuffer(ROWS * N, env_nums=N)
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * STEPS,
+                       max_episode_frames=999, noise_mode="device")
+    agent = TwinSACQ(pf=pf, qf1=qf1, qf2=qf2, plr=3e-4, qlr=3e-4, policy_std_reg_weight=0, policy_mean_reg_weight=0,
+                     automatic_entropy_tuning=True, noise_mode="device", env=env, replay_buffer=buf, collector=col,
+                     logger=NullLog(), discount=0.99, num_epochs=1, batch_size=B, device=dev, save_dir=None, tau=0.005,
+                     opt_times=OPT)
+    for _ in range(3):
+        col.rollout(STEPS); agent.update_per_epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); tc = tu = 0.0
+    for _ in range(args.epochs):
+        a = time.perf_counter(); col.rollout(STEPS); torch.cuda.synchronize()
+        b = time.perf_counter(); agent.update_per_epoch(); torch.cuda.synchronize()
+        tc += b - a; tu += time.perf_counter() - b
+    el = time.perf_counter() - t0
+    out = {"workload": "TwinSACQ cfg3: %d envs, %d-row replay, B=%d, MLP %dx%d relu, %d steps + %d updates / epoch"
+                       % (N, ROWS, B, H, H, STEPS, OPT),
+           "env_steps_per_s": args.epochs * N * STEPS / el, "updates_per_s": args.epochs * OPT / tu,
+           "ms_per_update": 1e3 * tu / (args.epochs * OPT), "ms_per_vector_step": 1e3 * tc / (args.epochs * STEPS)}
+    if args.cpu:
+        from oracle import nets
+        from oracle.sac import TwinSACQOracle
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        gen = torch.Generator().manual_seed(0)
+        o = TwinSACQOracle(nets.init_mlp(17, [H, H], 12, generator=gen), nets.init_mlp(23, [H, H], 1, generator=gen),
+                           nets.init_mlp(23, [H, H], 1, generator=gen), w_std=0, w_mean=0)
+        rs = np.random.RandomState(0)
+        batch = {"obs": rs.randn(B, 17), "next_obs": rs.randn(B, 17), "acts": np.tanh(rs.randn(B, 6)),
+                 "rewards": rs.randn(B, 1), "terminals": np.zeros((B, 1))}
+        o.update(batch, torch.randn(B, 6), torch.randn(B, 6))
+        t0 = time.perf_counter()
+        for _ in range(2):
+            o.update(batch, torch.randn(B, 6), torch.randn(B, 6))
+        out["cpu_oracle_ms_per_update"] = 1e3 * (time.perf_counter() - t0) / 2
+        out["cpu_threads"] = torch.get_num_threads()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -15,9 +15,11 @@
 
 #define GM 64
 #define GN 64
-#define GK 16
+#define GK 32
 #define LDA_S (GK + 1)
 #define LDB_S (GN + 1)
+#define A_PER_T (GM * GK / 256)     // 16 staged A elements per thread
+#define B_PER_T (GK * GN / 256)     //  8 staged B elements per thread
 
 // act'(y) expressed through the activation OUTPUT y (tanh: 1 - y^2, relu: y > 0, none: 1)
 __device__ __forceinline__ float dact_from_out(int act, float y) {
@@ -38,12 +40,15 @@ struct GemmDev {
 };
 
 // TA: A is stored [Kred][M] (we need A^T); TB: B is stored [N][K] (we need B^T).
+// Workgroup = 4 waves, C tile 64 x 64, one 32x32 quadrant per wave (these layers are small -- a few
+// thousand rows by <= 256 columns -- so filling 256 CUs matters more than a fatter tile).  K advances
+// in steps of 32; the next step's global loads are issued into registers before the current step's
+// MFMAs (register double buffering).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   __shared__ float As[GM * LDA_S];
   __shared__ float Bs[GK * LDB_S];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
   int k_lo = 0, k_hi = g.K;
   float* C = g.C;
@@ -52,54 +57,66 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
     k_hi = min(g.K, k_lo + g.split_len);
     C += (size_t)blockIdx.z * g.M * g.ldc;
   }
-  f32x16 acc;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  float csum = 0.0f;                               // TA: thread (m = tid & 63) column-sum partial
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
+  float csum = 0.0f;                               // TA: column-sum partial of column m = tid & 63
   const int i = lane & 31, hi = lane >> 5;
+  const bool want_colsum = TA && g.colsum && blockIdx.x == 0;
 
+  float ra[A_PER_T], rb[B_PER_T];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < A_PER_T; ++t) {
+      const int e = tid + 256 * t;
+      int m, k;
+      if (!TA) { m = e / GK; k = e - m * GK; } else { k = e / GM; m = e - k * GM; }   // coalesced along the stored-contiguous dim
+      float v = 0.0f;
+      if (m0 + m < g.M && k0 + k < k_hi) {
+        const size_t idx = TA ? (size_t)(k0 + k) * g.lda + m0 + m : (size_t)(m0 + m) * g.lda + k0 + k;
+        v = g.A[idx];
+        if (g.a_gate) v *= dact_from_out(g.gate_act, g.a_gate[idx]);
+      }
+      ra[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < B_PER_T; ++t) {
+      const int e = tid + 256 * t;
+      int n, k;
+      if (!TB) { k = e / GN; n = e - k * GN; } else { n = e / GK; k = e - n * GK; }
+      float v = 0.0f;
+      if (k0 + k < k_hi && n0 + n < g.N)
+        v = TB ? g.B[(size_t)(n0 + n) * g.ldb + k0 + k] : g.B[(size_t)(k0 + k) * g.ldb + n0 + n];
+      rb[t] = v;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int t = 0; t < A_PER_T; ++t) {
+      const int e = tid + 256 * t;
+      int m, k;
+      if (!TA) { m = e / GK; k = e - m * GK; } else { k = e / GM; m = e - k * GM; }
+      As[m * LDA_S + k] = ra[t];
+      if (want_colsum) csum += ra[t];              // TA: e % GM == tid % 64 for every t -> fixed column
+    }
+#pragma unroll
+    for (int t = 0; t < B_PER_T; ++t) {
+      const int e = tid + 256 * t;
+      int n, k;
+      if (!TB) { k = e / GN; n = e - k * GN; } else { n = e / GK; k = e - n * GK; }
+      Bs[k * LDB_S + n] = rb[t];
+    }
+  };
+
+  if (k_lo < k_hi) fetch(k_lo);
   for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
-    // ---- stage A tile [GM][GK] ----
-    if (!TA) {
-      for (int e = tid; e < GM * GK; e += 256) {
-        const int m = e / GK, k = e - m * GK;
-        float v = 0.0f;
-        if (m0 + m < g.M && k0 + k < k_hi) {
-          const size_t idx = (size_t)(m0 + m) * g.lda + k0 + k;
-          v = g.A[idx];
-          if (g.a_gate) v *= dact_from_out(g.gate_act, g.a_gate[idx]);
-        }
-        As[m * LDA_S + k] = v;
-      }
-    } else {                                       // A stored [K][M]: coalesced along m
-      for (int e = tid; e < GM * GK; e += 256) {
-        const int k = e / GM, m = e - k * GM;
-        float v = 0.0f;
-        if (m0 + m < g.M && k0 + k < k_hi) {
-          const size_t idx = (size_t)(k0 + k) * g.lda + m0 + m;
-          v = g.A[idx];
-          if (g.a_gate) v *= dact_from_out(g.gate_act, g.a_gate[idx]);
-        }
-        As[m * LDA_S + k] = v;
-        if (g.colsum && blockIdx.x == 0) csum += v;            // e / GM strides by 4: thread keeps m fixed
-      }
-    }
-    // ---- stage B tile [GK][GN] ----
-    if (!TB) {
-      for (int e = tid; e < GK * GN; e += 256) {
-        const int k = e / GN, n = e - k * GN;
-        Bs[k * LDB_S + n] = (k0 + k < k_hi && n0 + n < g.N) ? g.B[(size_t)(k0 + k) * g.ldb + n0 + n] : 0.0f;
-      }
-    } else {                                       // B stored [N][K]: coalesced along k
-      for (int e = tid; e < GK * GN; e += 256) {
-        const int n = e / GK, k = e - n * GK;
-        Bs[k * LDB_S + n] = (k0 + k < k_hi && n0 + n < g.N) ? g.B[(size_t)(n0 + n) * g.ldb + k0 + k] : 0.0f;
-      }
-    }
+    stash();
     __syncthreads();
+    if (k0 + GK < k_hi) fetch(k0 + GK);            // next step's loads fly under this step's MFMAs
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 2)
-      acc = mfma32(As[(32 * wm + i) * LDA_S + kk + hi], Bs[(kk + hi) * LDB_S + 32 * wn + i], acc);
+      acc0 = mfma32(As[(32 * wm + i) * LDA_S + kk + hi], Bs[(kk + hi) * LDB_S + 32 * wn + i], acc0);
     __syncthreads();
   }
   // ---- epilogue ----
@@ -107,14 +124,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + 32 * wm + rowmap(r, hi), n = n0 + 32 * wn + i;
     if (m < g.M && n < g.N) {
-      float v = acc[r];
+      float v = acc0[r];
       if (g.bias) v += g.bias[n];
       if (g.act == TRL_ACT_TANH) v = trl_tanh(v);
       else if (g.act == TRL_ACT_RELU) v = fmaxf(v, 0.0f);
       C[(size_t)m * g.ldc + n] = v;
     }
   }
-  if (TA && g.colsum && blockIdx.x == 0) {
+  if (want_colsum) {
     // threads tid, tid+64, tid+128, tid+192 hold partials of the same column m = tid & 63
     float* s = As;                                  // reuse (all MFMA reads are behind the last barrier)
     s[tid] = csum;

@@ -565,7 +565,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
   __shared__ float s_part[4][4];
   __shared__ float s_coef[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool need_norm = a.max_norm > 0.0f;                    // no clipping requested: skip the norm pass
   for (int g = 0; g < a.n_groups; ++g) {
+    if (!need_norm) { if (lane == 0) s_part[g][wave] = 0.0f; continue; }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int e = a.off[g] + tid;
     for (; e + 768 < a.off[g + 1]; e += 1024) {
