@@ -1,0 +1,141 @@
+"""BASELINE-size (cfg 2: 2048 envs x 128 steps, B = 65 536) checks through size-independent
+properties, and the multi-GPU sharding identity emulated on one GPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+N, T, B = 2048, 128, 65536
+
+
+def make(n_env, offset=0, total=None, seed=0, noise="device"):
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import PPO
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    torch.manual_seed(11)
+    net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=17, output_shape=6, tanh_action=True, **net)
+    vf = networks.Net(input_shape=(17,), output_shape=1, **net)
+    env = SynthVecEnv(n_env, horizon=50, device=DEV, index_offset=offset, total_env_nums=total)
+    ev = SynthVecEnv(n_env, horizon=50, device=DEV, index_offset=offset, total_env_nums=total)
+    env.seed(seed)
+    buf = OnPolicyReplayBuffer(n_env * T, env_nums=n_env, time_limit_filter=True)
+    col = VecOnPolicyCollector(vf, env=env, eval_env=ev, pf=pf, replay_buffer=buf, device=DEV, epoch_frames=n_env * T,
+                               max_episode_frames=40, noise_mode=noise)
+
+    class Log:
+        infos = []
+        def add_update_info(self, d): self.infos.append(d)
+        def add_epoch_info(self, *a, **k): pass
+        def log(self, *a): pass
+        def finish(self): pass
+    agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=1, tau=0.95, shuffle=True,
+                entropy_coeff=0.005, discount=0.99, num_epochs=10, batch_size=B * n_env // N, gae=True, env=env,
+                replay_buffer=buf, collector=col, logger=Log(), device=DEV, save_dir=None)
+    return pf, vf, env, buf, col, agent
+
+
+def test_full_size_rollout_is_env_shard_invariant():
+    """Envs are independent and keyed by their GLOBAL index: a 1024-env shard at offset 1024 of a
+    2048-env logical vector env reproduces columns [1024, 2048) of the single-process rollout
+    (the multi-GPU partition of SURVEY.md section 8(e), emulated on one GPU)."""
+    _, _, _, full, col, _ = make(N)
+    col.train_one_epoch()
+    for off in (0, 1024):
+        _, _, _, part, colp, _ = make(1024, offset=off, total=N)
+        colp.train_one_epoch()
+        for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits", "old_logp"):
+            a, b = getattr(full, "_" + k)[:, off:off + 1024], getattr(part, "_" + k)
+            assert torch.equal(a, b), (k, off, (a - b).abs().max().item())
+    assert float(full._terminals.sum()) > 0
+
+
+def test_full_size_gae_properties():
+    """Linearity in the rewards and the telescoping identity ret - adv == values, at 128 x 2048."""
+    from torchrl_amd import _C
+    g = torch.Generator(device="cpu").manual_seed(0)
+    r1, r2, v = (torch.randn(T, N, generator=g).to(DEV) for _ in range(3))
+    d = (torch.rand(T, N, generator=g) < 0.02).float().to(DEV)
+    tl = ((torch.rand(T, N, generator=g) < 0.5).float().to(DEV)) * d
+    zeros, lv = torch.zeros(T, N, device=DEV), torch.randn(N, generator=g).to(DEV)
+
+    def run(r, vals, lastv):
+        adv, ret = torch.empty(T, N, device=DEV), torch.empty(T, N, device=DEV)
+        _C.gae(r, vals, d, tl, lastv, adv, ret, 0.99, 0.95, 1)
+        return adv, ret
+    a1, ret1 = run(r1, v, lv)
+    a2, _ = run(r2, zeros, torch.zeros(N, device=DEV))
+    a12, _ = run(r1 + r2, v, lv)
+    assert (a12 - (a1 + a2)).abs().max().item() < 2e-4          # A(r1 + r2, V) = A(r1, V) + A(r2, 0)
+    assert (ret1 - a1 - v).abs().max().item() < 1e-5            # estimate_returns = advs + values
+    flagged = tl > 0
+    assert float(a1[flagged].abs().max()) == 0.0                # time-limit filter zeroes the advantage there
+
+
+def test_full_size_minibatch_gradient_partition_invariance():
+    """One cfg-2 minibatch (32 rows x 2048 envs): the folded gradient must not depend on how the
+    tiles are spread over workgroups, and the two env shards' gradients (each carrying 1/n_global)
+    sum to the full gradient -- the all-reduce identity of the multi-GPU path."""
+    from torchrl_amd import _C
+    pf, vf, env, buf, col, agent = make(N)
+    col.train_one_epoch()
+    agent.current_epoch = 0
+    agent.process_epoch_samples()
+    agent._fill_old_logp()
+    eng = agent.engine()
+    np.random.seed(3)
+    rows = buf.epoch_row_indices(B, True)[0]                      # (32,) time rows
+    t = {"obs": buf._obs, "acts": buf._acts, "advs": buf._advs, "rets": buf._estimate_returns,
+         "old_values": buf._values, "old_logp": buf._old_logp}
+    idx = torch.from_numpy(rows).to(DEV)
+    raw = torch.zeros(1, 4, dtype=torch.float64, device=DEV)
+    _C.adv_stats(buf._advs.reshape(T, N), idx.reshape(1, -1), raw)
+
+    def grad(tensors, n_env, n_wg, n_global):
+        g = _C.PpoBatchArgs()
+        for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"):
+            setattr(g, k, tensors[k].data_ptr())
+        g.row_idx, g.rows_mb, g.N = idx.data_ptr(), len(rows), n_env
+        g.adv_raw, g.n_global = raw.data_ptr(), float(n_global)
+        g.pf_params, g.vf_params = eng.flat.data_ptr(), eng.flat.data_ptr() + 4 * eng.P_pf
+        g.D, g.H, g.A, g.act = 17, 64, 6, _C.ACT_TANH
+        g.clip_para, g.entropy_coeff, g.clipped_value_loss, g.tanh_action = 0.2, 0.005, 0, 1
+        partial = torch.zeros(n_wg, eng.p_stride, device=DEV)
+        scal = torch.zeros(n_wg, 8, dtype=torch.float64, device=DEV)
+        g.partial, g.scal_partial, g.n_wg = partial.data_ptr(), scal.data_ptr(), n_wg
+        _C.ppo_minibatch_grad(g, DEV)
+        out, info = torch.zeros_like(eng.grads), torch.zeros(16, dtype=torch.float64, device=DEV)
+        _C.ppo_reduce(partial, scal, n_wg, 17, 64, 6, out, info, eng.flat)
+        return out, info
+    g256, i256 = grad(t, N, 256, B)
+    g64, i64 = grad(t, N, 64, B)
+    scale = g256.abs().max().item()
+    assert (g256 - g64).abs().max().item() < 2e-6 * max(1.0, scale)
+    # surrogate SUM over 65 536 O(1) terms that cancel (normalised advantages): compare per sample
+    assert abs(i256[0].item() - i64[0].item()) / B < 1e-9
+    g_again, _ = grad(t, N, 256, B)
+    assert torch.equal(g256, g_again)                              # deterministic fold
+    halves = []
+    for off in (0, 1024):
+        th = {k: v[:, off:off + 1024].contiguous() for k, v in t.items()}
+        halves.append(grad(th, 1024, 128, B)[0])
+    assert ((halves[0] + halves[1]) - g256).abs().max().item() < 2e-6 * max(1.0, scale)
+
+
+def test_full_size_epoch_runs_and_statistics_are_consistent():
+    pf, vf, env, buf, col, agent = make(N)
+    col.train_one_epoch()
+    agent.current_epoch = 0
+    np.random.seed(0)
+    agent.update_per_epoch()
+    infos = agent.logger.infos[-4:]
+    assert len(infos) == 4 and all(np.isfinite(list(i.values())).all() for i in infos)
+    # first minibatch: same parameters as at collection time -> ratio is 1 up to the different fp32
+    # summation order of the collector (32x32x2 MFMA) and the gradient kernel (16x16x4 MFMA)
+    assert abs(infos[0]["ratio/max"] - 1.0) < 2e-5 and abs(infos[0]["ratio/min"] - 1.0) < 2e-5
+    for i in infos:
+        assert i["advs/min"] <= i["advs/mean"] <= i["advs/max"] and i["logprob/min"] <= i["logprob/mean"] <= i["logprob/max"]
