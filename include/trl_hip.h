@@ -263,6 +263,40 @@ int trl_collector_bookkeep_f32(const float* rewards, const float* dones, int32_t
                                double* epoch_reward, int32_t* ep_count, float* ep_log, int ep_cap,
                                int step, int N, void* stream);
 
+/* --- K16: conv layers of CNNBase (torchrl/networks/base.py:59-107) as im2col + the GEMM family ----
+ * activations channels-last (B, H, W, C); cols[(b,oy,ox)][c*kh*kw + i*kw + j] matches the
+ * nn.Conv2d weight viewed as (Cout, Cin*kh*kw).  No padding.  The u8 variant reads NCHW uint8
+ * frame stacks and applies x * scale + shift (ScaledFloatFrame, env/atari_wrapper.py:230-240). */
+int trl_im2col_f32(const float* in_nhwc, float* cols, int B, int C, int H, int W, int kh, int kw,
+                   int sh, int sw, void* stream);
+int trl_im2col_u8_nchw(const uint8_t* in_nchw, float* cols, int B, int C, int H, int W, int kh, int kw,
+                       int sh, int sw, float scale, float shift, void* stream);
+int trl_col2im_f32(const float* dcols, float* dx_nhwc, int B, int C, int H, int W, int kh, int kw,
+                   int sh, int sw, void* stream);
+/* out[b][c][p] = in[b][p][c]  (NCHW flatten order in front of the first FC layer, and back) */
+int trl_transpose_bpc_f32(const float* in, float* out, int B, int P, int C, void* stream);
+
+/* --- K14: DQN TD loss (torchrl/algo/off_policy/dqn.py:53-60): q, q_next (B, A); acts (B) int64;
+ * dq (B, A); sums (3 doubles): squared-error sum, q_s_a sum, reward sum */
+int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const float* q_next, const float* rewards,
+                        const float* terminals, float gamma, int B, int A, float* dq, double* sums,
+                        void* stream);
+/* --- K15: QR-DQN quantile-Huber loss + output gradient (qrdqn.py:39-60, algo/utils.py:5-13):
+ * q, q_next, dq (B, A*Q); workspace 2B doubles; sums as above (loss sum is over B*Q*Q terms) */
+int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* q_next,
+                           const float* rewards, const float* terminals, float gamma, int B, int A,
+                           int Q, float* dq, double* workspace, double* sums, void* stream);
+/* --- K17: greedy / epsilon-greedy action (torchrl/policies/discrete_policies.py:40-67, 86-89):
+ * argmax_a of Q (Q == 1) or of the mean over Q quantiles; where u[n] < epsilon -> rand_act[n] */
+int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const float* u, const int64_t* rand_act,
+                       float epsilon, int64_t* action, void* stream);
+/* synthetic Atari-shaped env: (N, C, HW) uint8 frame stacks, Philox frames (see k_dqn.hip) */
+int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base,
+                             int horizon, int A, uint8_t* next_obs, float* rewards, float* dones,
+                             int N, int C, int HW, void* stream);
+int trl_synth_frames_reset_u8(uint8_t* frames, int32_t* t_env, int64_t env_seed_base,
+                              const uint8_t* mask, int N, int C, int HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -392,6 +392,60 @@ def case_twin_sac_q():
     save("twin_sac_q", **out)
 
 
+def case_dqn():
+    """DQN.update / QRDQN.update / quantile_regression_loss on a small conv Q-net over 84x84x4 frames
+    (torchrl/algo/off_policy/dqn.py:38-74, qrdqn.py:22-74, algo/utils.py:5-13)."""
+    import gym
+    import torchrl.networks as networks
+    import torchrl.algo.utils as atu
+    from torchrl.algo.off_policy.dqn import DQN
+    from torchrl.algo.off_policy.qrdqn import QRDQN
+    out = {}
+    A = 6
+    convs = [[8, [8, 8], [4, 4], [0, 0]], [8, [4, 4], [2, 2], [0, 0]], [16, [3, 3], [1, 1], [0, 0]]]
+
+    class Env:
+        action_space = gym.spaces.Discrete(A)
+
+    class Pf:
+        epsilon = 0.25
+    for tag, cls, Q, B, steps in (("dqn", DQN, 1, 12, 2), ("qrdqn", QRDQN, 20, 10, 2)):
+        torch.manual_seed(77)
+        qf = networks.Net(output_shape=A * Q, base_type=networks.CNNBase, append_hidden_shapes=[32],
+                          activation_func=torch.nn.Tanh, input_shape=(4, 84, 84), hidden_shapes=convs)
+        kw = dict(qf=qf, pf=Pf(), qlr=2.5e-4, env=Env(), replay_buffer=None, collector=_StubCollector(),
+                  logger=NullLogger(), discount=0.99, num_epochs=10, batch_size=B, device=torch.device("cpu"),
+                  save_dir=tempfile.mkdtemp(prefix="trl_save_"), tau=0.005, use_soft_update=True, opt_times=1)
+        agent = cls(quantile_num=Q, **kw) if Q > 1 else cls(**kw)
+        out.update(state_arrays(f"{tag}_qf0_", qf))
+        out[f"{tag}_args"] = np.array([B, Q, A, steps, 23], dtype=np.int64)
+        rs = np.random.RandomState(23)
+        for s in range(steps):
+            obs_u8 = rs.randint(0, 256, size=(B, 4, 84, 84)).astype(np.uint8)
+            nobs_u8 = rs.randint(0, 256, size=(B, 4, 84, 84)).astype(np.uint8)
+            acts = rs.randint(0, A, size=(B, 1) if Q == 1 else (B,))
+            batch = {"obs": obs_u8.astype(np.float32) / 255.0 - 0.5, "next_obs": nobs_u8.astype(np.float32) / 255.0 - 0.5,
+                     "acts": acts.astype(np.float32), "rewards": rs.randn(B, 1).astype(np.float32),
+                     "terminals": (rs.rand(B, 1) < 0.2).astype(np.float32)}
+            # frames are regenerated from RandomState(23) by the tests (same call order), not stored
+            out.update({f"{tag}_s{s}_{k}": batch[k] for k in ("acts", "rewards", "terminals")})
+            info = agent.update(batch)
+            keys = sorted(info.keys())
+            out[f"{tag}_s{s}_info_keys"] = np.array(keys)
+            out[f"{tag}_s{s}_info_vals"] = np.array([float(info[k]) for k in keys], dtype=np.float64)
+        out.update(state_arrays(f"{tag}_qf1_", qf))
+        out.update(state_arrays(f"{tag}_tqf1_", agent.target_qf))
+    # quantile_regression_loss + gradient, stand-alone (Q = 200 as config/qrdqn.json)
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(7, 200, generator=g).requires_grad_(True)
+    tgt = torch.randn(7, 200, generator=g) * 2
+    coef = torch.Tensor((2 * np.arange(200) + 1) / 400.0).view(1, -1)
+    loss = atu.quantile_regression_loss(coef, src, tgt)
+    loss.backward()
+    out.update(qr_src=src.detach().numpy(), qr_tgt=tgt.numpy(), qr_loss=np.array(loss.item()), qr_grad=src.grad.numpy())
+    save("dqn", **out)
+
+
 if __name__ == "__main__":
     install_stubs()
     case_gae()
@@ -400,3 +454,4 @@ if __name__ == "__main__":
     case_ppo_update()
     case_collect_and_epoch()
     case_twin_sac_q()
+    case_dqn()

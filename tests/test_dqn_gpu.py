@@ -1,0 +1,184 @@
+"""DQN / QR-DQN path on the GPU: conv layers (im2col + MFMA GEMM) forward / backward vs torch,
+TD and quantile-Huber loss kernels and whole updates vs the reference's outputs
+(tests/golden/dqn.npz), epsilon-greedy policy and frame env vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.dqn import SynthFrameVecEnvCPU, cnn, scale_frames
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+CONVS = [[8, [8, 8], [4, 4], [0, 0]], [8, [4, 4], [2, 2], [0, 0]], [16, [3, 3], [1, 1], [0, 0]]]
+
+
+def small_qnet(A, Q=1, act=torch.nn.Tanh):
+    import torchrl.networks as networks
+    return networks.Net(output_shape=A * Q, base_type=networks.CNNBase, append_hidden_shapes=[32],
+                        activation_func=act, input_shape=(4, 84, 84), hidden_shapes=CONVS)
+
+
+@pytest.mark.parametrize("act", [torch.nn.Tanh, torch.nn.ReLU])
+def test_cnn_forward_backward_vs_torch(act):
+    from torchrl_amd import ops
+    torch.manual_seed(1)
+    net = small_qnet(6, act=act)
+    frames = torch.randint(0, 256, (5, 4, 84, 84), dtype=torch.uint8)
+    params = [p.detach().clone().requires_grad_(True) for p in ops.cnn_param_list(net)]
+    want = cnn(scale_frames(frames.numpy()), params, [4, 2, 1], "tanh" if act is torch.nn.Tanh else "relu")
+    d_out = torch.randn(5, 6)
+    want.backward(d_out)
+    net.to(DEV)
+    plist = ops.cnn_param_list(net)
+    out, tape = ops.cnn_forward(net, frames.to(DEV))
+    assert (out.cpu() - want.detach()).abs().max().item() < 2e-5
+    grads = [(torch.zeros_like(plist[k]), torch.zeros_like(plist[k + 1])) for k in range(0, len(plist), 2)]
+    ops.cnn_backward(net, tape, d_out.to(DEV), grads)
+    flat = [t for pair in grads for t in pair]
+    for g, p in zip(flat, params):
+        err = (g.cpu() - p.grad).abs().max().item()
+        assert err < 5e-5 * max(1.0, p.grad.abs().max().item()), err
+
+
+def test_im2col_col2im_transpose_vs_torch():
+    from torchrl_amd import _C
+    x = torch.randn(3, 9, 11, 5)                                             # (B, H, W, C)
+    cols, (B, Ho, Wo) = _C.im2col(x.to(DEV), 4, 3, 2, 2)
+    want = F.unfold(x.permute(0, 3, 1, 2), (4, 3), stride=(2, 2))            # (B, C*kh*kw, L)
+    assert torch.equal(cols.cpu().view(B, Ho * Wo, -1), want.transpose(1, 2).contiguous())
+    d = torch.randn_like(cols.cpu())
+    dx = _C.col2im(d.to(DEV), 3, 5, 9, 11, 4, 3, 2, 2)
+    want_dx = F.fold(d.view(B, Ho * Wo, -1).transpose(1, 2), (9, 11), (4, 3), stride=(2, 2)).permute(0, 2, 3, 1)
+    assert (dx.cpu() - want_dx).abs().max().item() < 1e-5
+    u8 = torch.randint(0, 256, (2, 4, 20, 20), dtype=torch.uint8)
+    c8, _ = _C.im2col(u8.to(DEV), 8, 8, 4, 4, scale=1 / 255.0, shift=-0.5)
+    w8 = F.unfold(u8.float() / 255.0 - 0.5, 8, stride=4).transpose(1, 2)
+    assert (c8.cpu().view(2, -1, 256) - w8).abs().max().item() < 1e-6
+    t = torch.randn(4, 7, 3)
+    assert torch.equal(_C.transpose_bpc(t.to(DEV), 4, 7, 3).cpu(), t.transpose(1, 2).contiguous())
+
+
+def test_quantile_huber_kernel_vs_reference(golden):
+    from torchrl_amd import _C
+    g = golden("dqn")
+    src, tgt = torch.tensor(g["qr_src"]), torch.tensor(g["qr_tgt"])
+    B, Q = src.shape
+    # one action, gamma 1, rewards 0, not terminal: target == next quantiles, theta == src
+    sums = torch.zeros(3, dtype=torch.float64, device=DEV)
+    dq = _C.quantile_huber(src.to(DEV).contiguous(), torch.zeros(B, dtype=torch.int64, device=DEV), tgt.to(DEV).contiguous(),
+                           torch.zeros(B, device=DEV), torch.zeros(B, device=DEV), 1.0, 1, Q, sums)
+    assert abs(sums[0].item() / (B * Q * Q) - float(g["qr_loss"])) < 1e-6
+    np.testing.assert_allclose(dq.cpu().numpy(), g["qr_grad"], atol=2e-9, rtol=1e-5)
+
+
+def dqn_batches(g, tag):
+    B, Q, A, steps, seed = (int(x) for x in g[f"{tag}_args"])
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(steps):
+        obs = rs.randint(0, 256, size=(B, 4, 84, 84)).astype(np.uint8)
+        nobs = rs.randint(0, 256, size=(B, 4, 84, 84)).astype(np.uint8)
+        acts = rs.randint(0, A, size=(B, 1) if Q == 1 else (B,))
+        out.append({"obs": torch.from_numpy(obs), "next_obs": torch.from_numpy(nobs), "acts": acts,
+                    "rewards": rs.randn(B, 1).astype(np.float32), "terminals": (rs.rand(B, 1) < 0.2).astype(np.float32)})
+    return out
+
+
+@pytest.mark.parametrize("tag", ["dqn", "qrdqn"])
+def test_dqn_updates_match_reference(golden, tag):
+    from torchrl.algo import DQN, QRDQN
+    from torchrl.env.synth import SynthFrameVecEnv
+    from torchrl.policies import EpsilonGreedyDQNDiscretePolicy
+    g = golden("dqn")
+    B, Q, A, steps, _ = (int(x) for x in g[f"{tag}_args"])
+    qf = small_qnet(A, Q)
+    qf.load_state_dict({k[len(tag) + 5:].replace("__", "."): torch.tensor(g[k]) for k in g.files if k.startswith(f"{tag}_qf0_")})
+    env = SynthFrameVecEnv(4, device=DEV)
+    pf = EpsilonGreedyDQNDiscretePolicy(qf=qf, start_epsilon=0.25, end_epsilon=0.25, decay_frames=10, action_shape=A)
+
+    class Stub:
+        epoch_frames = 0
+
+    class Log:
+        def add_update_info(self, d): pass
+        def add_epoch_info(self, *a, **k): pass
+        def log(self, *a): pass
+        def finish(self): pass
+    kw = dict(qf=qf, pf=pf, qlr=2.5e-4, env=env, replay_buffer=None, collector=Stub(), logger=Log(), discount=0.99,
+              num_epochs=10, batch_size=B, device=DEV, save_dir=None, tau=0.005, use_soft_update=True, opt_times=1)
+    agent = QRDQN(quantile_num=Q, **kw) if Q > 1 else DQN(**kw)
+    for s, batch in enumerate(dqn_batches(g, tag)):
+        info = agent.update({k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()})
+        ref = dict(zip([str(k) for k in g[f"{tag}_s{s}_info_keys"]], g[f"{tag}_s{s}_info_vals"]))
+        assert sorted(info.keys()) == sorted(ref.keys())
+        for k in ("Reward_Mean", "Training/qf_loss", "q_s_a", "epsilon"):
+            assert abs(info[k] - ref[k]) < 2e-4 * abs(ref[k]) + 2e-6, (k, info[k], ref[k])
+    for name, mod in (("qf1", qf), ("tqf1", agent.target_qf)):
+        for k, p in mod.state_dict().items():
+            err = np.abs(p.cpu().numpy() - g[f"{tag}_{name}_{k.replace('.', '__')}"]).max()
+            assert err < 3e-6, (name, k, err)
+
+
+def test_frame_env_policy_and_collector_vs_oracle():
+    from torchrl.collector import VecCollector
+    from torchrl.env import get_vec_env
+    from torchrl.policies import EpsilonGreedyDQNDiscretePolicy, EpsilonGreedyQRDQNDiscretePolicy
+    from torchrl.replay_buffers import BaseReplayBuffer
+    from torchrl_amd import ops
+    N, A, horizon, seed = 6, 6, 5, 2
+    env = get_vec_env("SynthAtari-v0", {"reward_scale": 1}, N)
+    eval_env = get_vec_env("SynthAtari-v0", {"reward_scale": 1}, N)
+    env.horizon = eval_env.horizon = horizon
+    env.seed(seed)
+    oenv = SynthFrameVecEnvCPU(N, horizon=horizon)
+    oenv.seed(seed)
+    assert np.array_equal(env.reset().cpu().numpy(), oenv.reset())
+    torch.manual_seed(3)
+    qf = small_qnet(A).to(DEV)
+    params = [p.detach().cpu() for p in ops.cnn_param_list(qf)]
+    pf = EpsilonGreedyDQNDiscretePolicy(qf=qf, start_epsilon=0.5, end_epsilon=0.1, decay_frames=100, action_shape=A)
+    buf = BaseReplayBuffer(N * 4, env_nums=N)                              # 4-row ring, 7 steps wrap
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=DEV, epoch_frames=N * 7,
+                       max_episode_frames=4, eval_episodes=1)
+    np.random.seed(11)
+    got = col.train_one_epoch()
+    # oracle replay of the same loop (reference: discrete_policies.py:43-67, collector/base.py:184-230)
+    np.random.seed(11)
+    obs = oenv.reset()
+    cur = np.zeros(N)
+    rows, total, count = [], 0.0, 0
+    for t in range(7):
+        count += 1
+        eps = 0.5 - 0.4 * count / 100
+        with torch.no_grad():
+            q = cnn(scale_frames(obs), params, [4, 2, 1], "tanh")
+        act = q.max(dim=-1)[1].numpy()
+        r = np.random.rand(N, 1)
+        ra = np.random.randint(0, A, size=(N, 1))
+        act = np.where(r[:, 0] < eps, ra[:, 0], act)
+        nobs, rew, done, _ = oenv.step(act)
+        cur += 1
+        rows.append((obs.copy(), nobs.copy(), act.copy(), rew.copy(), done.copy()))
+        total += rew.sum()
+        flag = done[:, 0] | (cur >= 4)
+        if flag.any():
+            nobs = oenv.reset(mask=flag)
+            cur[flag] = 0
+        obs = nobs
+    assert abs(got["train_epoch_reward"] - total) < 1e-6
+    for t in range(3, 7):                                                   # last 4 steps live in the ring
+        row = t % 4
+        o, no, a, rw, dn = rows[t]
+        assert np.array_equal(buf._obs[row].cpu().numpy(), o) and np.array_equal(buf._next_obs[row].cpu().numpy(), no)
+        assert np.array_equal(buf._acts[row].cpu().numpy()[:, 0], a.astype(np.float32))
+        assert np.array_equal(buf._rewards[row].cpu().numpy(), rw) and np.array_equal(buf._terminals[row].cpu().numpy(), dn.astype(np.float32))
+    assert buf._obs.dtype == torch.uint8 and np.array_equal(env.cur_obs.cpu().numpy(), obs)
+    # QR-DQN greedy action = argmax of the quantile mean, vectorised over envs
+    qfq = small_qnet(A, 8).to(DEV)
+    pq = EpsilonGreedyQRDQNDiscretePolicy(quantile_num=8, qf=qfq, start_epsilon=0.0, end_epsilon=0.0, decay_frames=1, action_shape=A)
+    qv = ops.cnn_forward(qfq, env.cur_obs)[0]
+    want = qv.view(N, A, 8).mean(-1).max(-1)[1].cpu().numpy()
+    assert np.array_equal(pq.eval_act(env.cur_obs)[:, 0], want)
+    ev = col.eval_one_epoch()
+    assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == horizon

@@ -198,3 +198,55 @@ def test_twin_sac_q_update_matches_reference(golden, tag):
         for a, b in zip(mine, sac_params(g, f"{tag}_{name}1_")):
             np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(o.log_alpha.detach().numpy(), g[f"{tag}_log_alpha"], atol=1e-7)
+
+
+def dqn_batches(g, tag):
+    """Regenerate the reference's batches: frames come from RandomState(seed) in the generator's call order."""
+    B, Q, A, steps, seed = (int(x) for x in g[f"{tag}_args"])
+    rs = np.random.RandomState(seed)
+    out = []
+    for s in range(steps):
+        obs = rs.randint(0, 256, size=(B, 4, 84, 84)).astype(np.uint8)
+        nobs = rs.randint(0, 256, size=(B, 4, 84, 84)).astype(np.uint8)
+        acts = rs.randint(0, A, size=(B, 1) if Q == 1 else (B,))
+        rew = rs.randn(B, 1).astype(np.float32)
+        term = (rs.rand(B, 1) < 0.2).astype(np.float32)
+        assert np.array_equal(acts.astype(np.float32), g[f"{tag}_s{s}_acts"]) and np.array_equal(rew, g[f"{tag}_s{s}_rewards"])
+        out.append({"obs": obs, "next_obs": nobs, "acts": acts, "rewards": rew, "terminals": term})
+    return out
+
+
+def dqn_params(g, prefix):
+    names = sorted(k for k in g.files if k.startswith(prefix))
+    conv = sorted([k for k in names if "seq_convs" in k], key=lambda k: (int(k.split("__")[-2]), "bias" in k))
+    fc = sorted([k for k in names if "seq_append_fcs" in k], key=lambda k: (int(k.split("__")[-2]), "bias" in k))
+    return [torch.tensor(g[k]) for k in conv + fc]
+
+
+@pytest.mark.parametrize("tag", ["dqn", "qrdqn"])
+def test_dqn_updates_match_reference(golden, tag):
+    from oracle.dqn import DQNOracle
+    g = golden("dqn")
+    B, Q, A, steps, _ = (int(x) for x in g[f"{tag}_args"])
+    o = DQNOracle(dqn_params(g, f"{tag}_qf0_"), strides=[4, 2, 1], quantile_num=Q, action_num=A)
+    for s, batch in enumerate(dqn_batches(g, tag)):
+        info = o.update(batch)
+        ref = dict(zip([str(k) for k in g[f"{tag}_s{s}_info_keys"]], g[f"{tag}_s{s}_info_vals"]))
+        for k, v in info.items():
+            assert abs(v - ref[k]) < 2e-5 * abs(ref[k]) + 2e-6, (k, v, ref[k])
+    for mine, name in ((o.q, "qf1"), (o.tq, "tqf1")):
+        for a, b in zip(mine, dqn_params(g, f"{tag}_{name}_")):
+            np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=2e-6)
+
+
+def test_quantile_huber_matches_reference(golden):
+    from oracle.dqn import huber
+    g = golden("dqn")
+    src = torch.tensor(g["qr_src"], requires_grad=True)
+    tgt = torch.tensor(g["qr_tgt"])
+    coef = torch.tensor((2 * np.arange(200) + 1) / 400.0, dtype=torch.float32).view(1, -1)
+    diff = tgt.unsqueeze(-1) - src.unsqueeze(1)
+    loss = (huber(diff) * (coef - (diff.detach() < 0).float()).abs()).mean()
+    loss.backward()
+    assert abs(loss.item() - float(g["qr_loss"])) < 1e-7
+    np.testing.assert_allclose(src.grad.numpy(), g["qr_grad"], atol=1e-9)

@@ -99,6 +99,15 @@ SIGNATURES = {
     "trl_moments_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "trl_philox_normal_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "trl_synth_env_step_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_im2col_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "trl_im2col_u8_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_void_p]),
+    "trl_col2im_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_dqn_td_loss_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trl_quantile_huber_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_linear_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -396,3 +405,82 @@ def collector_bookkeep(rewards, dones, cur_step, ep_return, max_frames, mask, ep
                                            dev_ptr(ep_count, torch.int32, "ep_count"), dev_ptr(ep_log, name="ep_log"),
                                            int(ep_log.shape[0]), int(step), N, stream_ptr(rewards.device)),
           "trl_collector_bookkeep_f32")
+
+
+def im2col(x, kh, kw, sh, sw, scale=None, shift=0.0):
+    """x: (B, H, W, C) fp32 channels-last, or (B, C, H, W) uint8 when `scale` is given."""
+    if x.dtype == torch.uint8:
+        B, Cc, H, W = (int(v) for v in x.shape)
+    else:
+        B, H, W, Cc = (int(v) for v in x.shape)
+    Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
+    cols = torch.empty((B * Ho * Wo, Cc * kh * kw), dtype=torch.float32, device=x.device)
+    if x.dtype == torch.uint8:
+        check(lib().trl_im2col_u8_nchw(dev_ptr(x, torch.uint8, "x"), dev_ptr(cols, name="cols"), B, Cc, H, W, kh, kw,
+                                       sh, sw, float(1.0 if scale is None else scale), float(shift),
+                                       stream_ptr(x.device)), "trl_im2col_u8_nchw")
+    else:
+        check(lib().trl_im2col_f32(dev_ptr(x, name="x"), dev_ptr(cols, name="cols"), B, Cc, H, W, kh, kw, sh, sw,
+                                   stream_ptr(x.device)), "trl_im2col_f32")
+    return cols, (B, Ho, Wo)
+
+
+def col2im(dcols, B, Cc, H, W, kh, kw, sh, sw):
+    dx = torch.empty((B, H, W, Cc), dtype=torch.float32, device=dcols.device)
+    check(lib().trl_col2im_f32(dev_ptr(dcols, name="dcols"), dev_ptr(dx, name="dx"), B, Cc, H, W, kh, kw, sh, sw,
+                               stream_ptr(dcols.device)), "trl_col2im_f32")
+    return dx
+
+
+def transpose_bpc(x, B, P, Cc):
+    out = torch.empty((B, Cc, P), dtype=torch.float32, device=x.device)
+    check(lib().trl_transpose_bpc_f32(dev_ptr(x, name="x"), dev_ptr(out, name="out"), B, P, Cc,
+                                      stream_ptr(x.device)), "trl_transpose_bpc_f32")
+    return out
+
+
+def dqn_td_loss(q, acts, q_next, rew, term, gamma, sums):
+    B, A = int(q.shape[0]), int(q.shape[1])
+    dq = torch.empty_like(q)
+    check(lib().trl_dqn_td_loss_f32(dev_ptr(q, name="q"), dev_ptr(acts, torch.int64, "acts"),
+                                    dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"), dev_ptr(term, name="term"),
+                                    float(gamma), B, A, dev_ptr(dq, name="dq"), dev_ptr(sums, torch.float64, "sums"),
+                                    stream_ptr(q.device)), "trl_dqn_td_loss_f32")
+    return dq
+
+
+def quantile_huber(q, acts, q_next, rew, term, gamma, A, Q, sums):
+    B = int(q.shape[0])
+    dq = torch.empty_like(q)
+    ws = torch.empty(2 * B, dtype=torch.float64, device=q.device)
+    check(lib().trl_quantile_huber_f32(dev_ptr(q, name="q"), dev_ptr(acts, torch.int64, "acts"),
+                                       dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"),
+                                       dev_ptr(term, name="term"), float(gamma), B, A, Q, dev_ptr(dq, name="dq"),
+                                       dev_ptr(ws, torch.float64, "ws"), dev_ptr(sums, torch.float64, "sums"),
+                                       stream_ptr(q.device)), "trl_quantile_huber_f32")
+    return dq
+
+
+def eps_greedy(q, A, Q, u, rand_act, epsilon):
+    N = int(q.shape[0])
+    action = torch.empty(N, dtype=torch.int64, device=q.device)
+    check(lib().trl_eps_greedy_i64(dev_ptr(q, name="q"), N, A, Q, dev_ptr(u, name="u", allow_none=True),
+                                   dev_ptr(rand_act, torch.int64, "rand_act", allow_none=True), float(epsilon),
+                                   dev_ptr(action, torch.int64, "action"), stream_ptr(q.device)), "trl_eps_greedy_i64")
+    return action
+
+
+def synth_frames_step(frames, acts, t_env, seed_base, horizon, A, next_obs, rewards, dones):
+    N, Cc, HW = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2]) * int(frames.shape[3])
+    check(lib().trl_synth_frames_step_u8(dev_ptr(frames, torch.uint8, "frames"), dev_ptr(acts, torch.int64, "acts"),
+                                         dev_ptr(t_env, torch.int32, "t_env"), int(seed_base), int(horizon), int(A),
+                                         dev_ptr(next_obs, torch.uint8, "next_obs", allow_none=True),
+                                         dev_ptr(rewards, name="rewards"), dev_ptr(dones, name="dones"), N, Cc, HW,
+                                         stream_ptr(frames.device)), "trl_synth_frames_step_u8")
+
+
+def synth_frames_reset(frames, t_env, seed_base, mask):
+    N, Cc, HW = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2]) * int(frames.shape[3])
+    check(lib().trl_synth_frames_reset_u8(dev_ptr(frames, torch.uint8, "frames"), dev_ptr(t_env, torch.int32, "t_env"),
+                                          int(seed_base), dev_ptr(mask, torch.uint8, "mask", allow_none=True), N, Cc, HW,
+                                          stream_ptr(frames.device)), "trl_synth_frames_reset_u8")

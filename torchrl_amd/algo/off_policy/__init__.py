@@ -1,2 +1,3 @@
 from .off_rl_algo import OffRLAlgo
 from .twin_sac_q import TwinSACQ
+from .dqn import DQN, QRDQN

@@ -1,0 +1,137 @@
+"""DQN and QR-DQN on the HIP path (torchrl/algo/off_policy/dqn.py:9-92, qrdqn.py:11-74).
+
+`update(batch)`: Q(s) and Q'(s') through the conv + dense kernels (uint8 frame stacks are read
+as stored and scaled in the first im2col), the TD / quantile-Huber loss kernel returns the loss
+sums and dL/dQ, the backward pass fills one flat gradient buffer, trl_clip_adam_f32 steps it,
+trl_polyak_f32 (soft) or a full copy every `target_hard_update_period` updates the target net.
+Actions are read as (B,) or (B, 1) and cast to int64 (the reference's two classes disagree on the
+shape, its Q16).
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ... import _C, ops
+from ...networks import flatten_into
+from .off_rl_algo import OffRLAlgo
+
+
+class DQN(OffRLAlgo):
+    quantile_num = 1
+
+    def __init__(self, qf, pf, qlr, optimizer_class=optim.Adam, optimizer_info={}, **kwargs):
+        super().__init__(**kwargs)
+        self.pf = pf
+        self.qf = qf
+        self.target_qf = copy.deepcopy(qf)
+        self.qlr = qlr
+        self.optimizer_class = optimizer_class
+        self.optimizer_info = dict(optimizer_info)
+        self.qf_optimizer = optimizer_class(self.qf.parameters(), lr=self.qlr, **optimizer_info)
+        self.to(self.device)
+        self._engine = None
+
+    @property
+    def networks(self):
+        return [self.qf, self.target_qf]
+
+    @property
+    def target_networks(self):
+        return [(self.qf, self.target_qf)]
+
+    @property
+    def snapshot_networks(self):
+        return [("pf", self.qf)]
+
+    def engine(self):
+        if self._engine is None:
+            if self.optimizer_class is not optim.Adam:
+                raise _C.TrlError("the fused DQN step implements torch.optim.Adam only")
+            self._engine = _FusedDQN(self)
+        return self._engine
+
+    def update(self, batch):
+        self.training_update_num += 1
+        return self.engine().update(batch)
+
+
+class QRDQN(DQN):
+    def __init__(self, quantile_num=100, **kwargs):
+        super().__init__(**kwargs)
+        self.quantile_num = quantile_num
+
+
+class _FusedDQN:
+    def __init__(self, algo):
+        self.algo = algo
+        self.dev = next(algo.qf.parameters()).device
+        if self.dev.type != "cuda":
+            raise _C.TrlError("DQN networks live on %s: the HIP path needs a GPU (no CPU path exists)" % self.dev)
+        plist = ops.cnn_param_list(algo.qf)
+        self.flat = flatten_into(plist)
+        self.tflat = flatten_into(ops.cnn_param_list(algo.target_qf))
+        self.grads = torch.zeros_like(self.flat)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.gviews, off = [], 0
+        for k in range(0, len(plist), 2):
+            w, b = plist[k], plist[k + 1]
+            gw = self.grads[off:off + w.numel()].view(w.shape); off += w.numel()
+            gb = self.grads[off:off + b.numel()].view(b.shape); off += b.numel()
+            self.gviews.append((gw, gb))
+        off = 0
+        for p in plist:
+            n = p.numel()
+            algo.qf_optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.m[off:off + n].view(p.shape),
+                                          "exp_avg_sq": self.v[off:off + n].view(p.shape)}
+            off += n
+        self.step_count = 0
+        self.sums = torch.zeros(3, dtype=torch.float64, device=self.dev)
+        self.A = int(algo.env.action_space.n)
+        self.workspace = None
+
+    def update(self, batch):
+        algo, dev = self.algo, self.dev
+        obs, nobs = batch['obs'], batch['next_obs']
+        if not (isinstance(obs, torch.Tensor) and obs.dtype == torch.uint8):
+            raise _C.TrlError("DQN.update expects uint8 (B, C, H, W) frame stacks from the device replay buffer")
+        obs, nobs = obs.to(dev).contiguous(), nobs.to(dev).contiguous()
+        as_f = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
+            .to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        rew, term = as_f(batch['rewards']), as_f(batch['terminals'])
+        acts = as_f(batch['acts']).to(torch.int64)
+        B, A, Q = int(obs.shape[0]), self.A, int(algo.quantile_num)
+        q, tape = ops.cnn_forward(algo.qf, obs)
+        qn, _ = ops.cnn_forward(algo.target_qf, nobs)
+        if Q == 1:
+            dq = _C.dqn_td_loss(q, acts, qn, rew, term, algo.discount, self.sums)
+            denom = float(B)
+        else:
+            dq = _C.quantile_huber(q, acts, qn, rew, term, algo.discount, A, Q, self.sums)
+            denom = float(B) * Q * Q
+        need = max(_C.lib().trl_linear_bwd_weight_workspace(int(c[0].shape[0]), int(c[0].shape[1]), int(c[2].shape[0]))
+                   for c in tape.convs)
+        need = max(need, max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
+                             for w, _ in ops.fc_layers(algo.qf)))
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, device=dev)
+        ops.cnn_backward(algo.qf, tape, dq, self.gviews, workspace=self.workspace)
+        self.step_count += 1
+        a = _C.AdamArgs()
+        a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
+                                                      self.m.data_ptr(), self.v.data_ptr())
+        a.n_groups = 1
+        a.group_sizes[0] = self.flat.numel()
+        a.group_lr[0] = algo.qf_optimizer.param_groups[0]['lr']
+        a.max_norm, a.beta1, a.beta2 = 0.0, 0.9, 0.999
+        a.eps = float(algo.optimizer_info.get("eps", 1e-8))
+        a.grad_scale, a.step_count, a.norms_out = 1.0, self.step_count, None
+        _C.clip_adam(a, dev)
+        if algo.use_soft_update:
+            _C.polyak(self.tflat, self.flat, algo.tau)
+        elif algo.training_update_num % algo.target_hard_update_period == 0:
+            _C.polyak(self.tflat, self.flat, 1.0)
+        s = self.sums.cpu().numpy()
+        return {'Reward_Mean': s[2] / B, 'Training/qf_loss': s[0] / denom, 'epsilon': algo.pf.epsilon,
+                'q_s_a': s[1] / (B * Q)}

@@ -117,6 +117,10 @@ class VecCollector(BaseCollector):
     def _policy_action(self, env, deterministic):
         from .. import ops
         pf = self.pf
+        if not self.continuous:                                             # epsilon-greedy over a Q network
+            if deterministic:
+                return torch.as_tensor(pf.eval_act(env.cur_obs)).to(env.device).reshape(-1).contiguous()
+            return pf.explore(env.cur_obs)["action"].reshape(-1).contiguous()
         if not hasattr(pf, "tanh_action") or hasattr(pf, "logstd"):
             raise _C.TrlError("VecCollector's kernel path expects a GuassianContPolicy (mean | log_std head); "
                               "state-independent-std policies use VecOnPolicyCollector")
@@ -133,6 +137,8 @@ class VecCollector(BaseCollector):
 
     def _step(self, env, store, deterministic=False, max_frames=None):
         buf = self.replay_buffer
+        if getattr(env, "kind", "vector") == "frames":
+            return self._step_frames(env, store, deterministic, max_frames)
         n, d, a_dim = env.env_nums, env.obs_dim, env.act_dim
         act = self._policy_action(env, deterministic)
         if store:
@@ -154,6 +160,34 @@ class VecCollector(BaseCollector):
                               self.max_episode_frames if max_frames is None else max_frames, self._mask,
                               self._epoch_reward, self._ep_count, self._ep_log, self.global_step)
         _C.synth_reset(env.cur_obs, env.t_env, env.cur_step, env.episode_idx, env.ep_return, self._mask, env.seed_base)
+        if store:
+            buf._advance()
+        self.global_step += 1
+
+    def _step_frames(self, env, store, deterministic, max_frames):
+        """Discrete-action step on the uint8 frame env: frames stay bytes in the replay rows; actions are
+        stored as (N, 1) so that DQN's gather works (the reference squeezes them, its Q16)."""
+        buf = self.replay_buffer
+        n, shape = env.env_nums, env.frame_shape
+        act = self._policy_action(env, deterministic)                       # (N,) int64
+        if store:
+            row = buf._top
+            buf._ensure_key("obs", (n,) + shape, dtype=torch.uint8)[row].copy_(env.cur_obs)
+            buf._ensure_key("acts", (n, 1))[row].copy_(act.unsqueeze(-1))
+            nxt = buf._ensure_key("next_obs", (n,) + shape, dtype=torch.uint8)[row]
+            rew = buf._ensure_key("rewards", (n, 1))[row]
+            done = buf._ensure_key("terminals", (n, 1))[row]
+        else:
+            nxt = None
+            rew = torch.empty(n, 1, device=env.device)
+            done = torch.empty(n, 1, device=env.device)
+        _C.synth_frames_step(env.cur_obs, act, env.t_env, env.seed_base, env.horizon, env.action_num, nxt, rew, done)
+        if store:
+            buf._ensure_key("time_limits", (n, 1))[row].copy_(done)
+        _C.collector_bookkeep(rew, done, env.cur_step, env.ep_return,
+                              self.max_episode_frames if max_frames is None else max_frames, self._mask,
+                              self._epoch_reward, self._ep_count, self._ep_log, self.global_step)
+        _C.synth_frames_reset(env.cur_obs, env.t_env, env.seed_base, self._mask)
         if store:
             buf._advance()
         self.global_step += 1

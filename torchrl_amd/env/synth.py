@@ -23,6 +23,7 @@ from gym import spaces
 from .. import _C
 
 SYNTH_IDS = {"SynthHalfCheetah-v0": dict(obs_dim=17, act_dim=6, horizon=1000)}
+SYNTH_FRAME_IDS = {"SynthAtari-v0": dict(frame_shape=(4, 84, 84), action_num=6, horizon=1000)}
 
 
 def dynamics_matrices(obs_dim, act_dim):
@@ -100,5 +101,74 @@ class SynthVecEnv:
         done = torch.empty(n, 1, device=self.device)
         _C.synth_env_step(self.cur_obs, acts, self.env_A, self.env_B, self.t_env, self.effective_reward_scale,
                           self.horizon, nxt, rew, done)
+        dones = done > 0.5
+        return nxt, rew, dones, {"time_limit": dones.reshape(n)}
+
+
+class SynthFrameVecEnv:
+    """Atari-shaped synthetic vector env (SURVEY.md section 8(d) cfg 5): uint8 frame stacks
+    (N, 4, 84, 84) resident on the GPU, Discrete(6) actions.  Each step shifts the stack and appends
+    one pseudo-random frame (Philox keyed by env seed and env time, torchrl_amd/csrc/k_dqn.hip);
+    reward = 1 when the action equals (first byte of the new frame) % A; done = time_limit =
+    (steps since reset >= horizon).  Same vector-env protocol as SynthVecEnv; frames are what the
+    reference's WarpFrame + FrameStack wrappers would deliver, kept as bytes (the /255 - 0.5 of
+    ScaledFloatFrame is applied inside the first conv layer's im2col)."""
+    is_device_env = True
+    kind = "frames"
+
+    def __init__(self, env_nums, frame_shape=(4, 84, 84), action_num=6, horizon=1000, reward_scale=1.0,
+                 device=None, index_offset=0, total_env_nums=None):
+        self.env_nums = int(env_nums)
+        self.frame_shape, self.action_num, self.horizon = tuple(frame_shape), int(action_num), int(horizon)
+        self._reward_scale = reward_scale
+        self.training = True
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.index_offset = int(index_offset)
+        self.total_env_nums = int(total_env_nums) if total_env_nums is not None else self.env_nums
+        self.observation_space = spaces.Box(0, 255, self.frame_shape, dtype=np.uint8)
+        self.action_space = spaces.Discrete(self.action_num)
+        n = self.env_nums
+        self.cur_obs = torch.zeros((n,) + self.frame_shape, dtype=torch.uint8, device=self.device)
+        self.t_env = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self.cur_step = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self.episode_idx = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self.ep_return = torch.zeros(n, device=self.device)
+        self.seed(0)
+
+    def train(self):
+        self.training = True
+
+    def eval(self):
+        self.training = False
+
+    def close(self):
+        pass
+
+    def seed(self, seed):
+        self._seed = int(seed)
+        self.seed_base = self._seed * self.total_env_nums + self.index_offset
+
+    @property
+    def effective_reward_scale(self):
+        return float(self._reward_scale) if self.training else 1.0
+
+    def reset(self, **kwargs):
+        _C.synth_frames_reset(self.cur_obs, self.t_env, self.seed_base, None)
+        self.cur_step.zero_()
+        self.ep_return.zero_()
+        return self.cur_obs
+
+    def partial_reset(self, index_mask, **kwargs):
+        mask = torch.as_tensor(index_mask).to(self.device).to(torch.uint8).contiguous()
+        _C.synth_frames_reset(self.cur_obs, self.t_env, self.seed_base, mask)
+        return self.cur_obs
+
+    def step(self, actions):
+        n = self.env_nums
+        acts = torch.as_tensor(actions).to(device=self.device).reshape(n).to(torch.int64).contiguous()
+        nxt = torch.empty_like(self.cur_obs)
+        rew = torch.empty(n, 1, device=self.device)
+        done = torch.empty(n, 1, device=self.device)
+        _C.synth_frames_step(self.cur_obs, acts, self.t_env, self.seed_base, self.horizon, self.action_num, nxt, rew, done)
         dones = done > 0.5
         return nxt, rew, dones, {"time_limit": dones.reshape(n)}

@@ -59,3 +59,86 @@ def mlp_backward(tape, d_out, grads=None, need_input=False, workspace=None):
         if k > 0 or need_input:
             d = _C.linear_bwd_input(d, gate, tape.act, w)
     return d if need_input else None
+
+
+# ---------------------------------------------------------------------------------------------
+# Conv trunks (CNNBase, torchrl/networks/base.py:59-107) + FC head, on im2col + the GEMM kernels.
+# Activations are channels-last; the first layer reads uint8 NCHW frame stacks and scales them
+# in-kernel (x / 255 - 0.5, ScaledFloatFrame).
+class ConvTape:
+    __slots__ = ("convs", "fc", "B", "act", "feat_shape")
+
+
+def conv_layers(net):
+    """[(Conv2d module), ...] of a Net whose trunk is a CNNBase without LayerNorm / padding."""
+    mods = [m for m in net.base.seq_convs if isinstance(m, nn.Conv2d)]
+    for m in mods:
+        if tuple(m.padding) != (0, 0) or tuple(m.dilation) != (1, 1) or m.groups != 1:
+            raise _C.TrlError("conv kernels support padding 0, dilation 1, groups 1 (got %s)" % m)
+    if net.base.add_ln:
+        raise _C.TrlError("conv kernels do not support LayerNorm")
+    return mods
+
+
+def fc_layers(net):
+    return [(m.weight, m.bias) for m in net.seq_append_fcs if isinstance(m, nn.Linear)]
+
+
+def cnn_act_code(net):
+    a = net.base.activation_func
+    if a not in ACT_OF or net.base.last_activation_func is not a:
+        raise _C.TrlError("conv kernels support Tanh / ReLU (got %s)" % a)
+    return ACT_OF[a]
+
+
+def cnn_param_list(net):
+    out = []
+    for m in conv_layers(net):
+        out += [m.weight, m.bias]
+    for w, b in fc_layers(net):
+        out += [w, b]
+    return out
+
+
+def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
+    """frames_u8: (B, C, H, W) uint8.  Returns (out (B, O), tape)."""
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
+        raise _C.TrlError("cnn_forward expects (B, C, H, W) uint8 frame stacks")
+    act = cnn_act_code(net)
+    t = ConvTape()
+    t.convs, t.act, t.B = [], act, int(frames_u8.shape[0])
+    x, geom_in = frames_u8.contiguous(), None
+    for k, m in enumerate(conv_layers(net)):
+        kh, kw = m.kernel_size
+        sh, sw = m.stride
+        if k == 0:
+            cols, (B, Ho, Wo) = _C.im2col(x, kh, kw, sh, sw, scale=scale, shift=shift)
+            in_shape = None
+        else:
+            in_shape = tuple(int(v) for v in x.shape)                        # (B, H, W, C)
+            cols, (B, Ho, Wo) = _C.im2col(x, kh, kw, sh, sw)
+        wmat = m.weight.view(m.weight.shape[0], -1)
+        y = _C.linear_fwd(cols, wmat, m.bias, act)                           # (B*Ho*Wo, Cout) == NHWC
+        t.convs.append((cols, y, wmat, in_shape, (kh, kw, sh, sw)))
+        x = y.view(B, Ho, Wo, int(wmat.shape[0]))
+    B, Ho, Wo, Cc = (int(v) for v in x.shape)
+    t.feat_shape = (Ho * Wo, Cc)
+    feat = _C.transpose_bpc(x, B, Ho * Wo, Cc).view(B, Cc * Ho * Wo)       # PyTorch's NCHW flatten order
+    out, t.fc = mlp_forward(fc_layers(net), feat, act)
+    return out, t
+
+
+def cnn_backward(net, tape, d_out, grads, workspace=None):
+    """grads: [(dW_view, db_view), ...] in cnn_param_list order (conv layers, then FC layers)."""
+    n_conv = len(tape.convs)
+    d_feat = mlp_backward(tape.fc, d_out, grads=grads[n_conv:], need_input=True, workspace=workspace)
+    P, Cc = tape.feat_shape
+    d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P).view(tape.B * P, Cc)   # back to (B, P, C)
+    for k in range(n_conv - 1, -1, -1):
+        cols, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]
+        gw, gb = grads[k]
+        _C.linear_bwd_weight(d, y, tape.act, cols, dw=gw.view(wmat.shape), db=gb, workspace=workspace)
+        if k > 0:
+            dcols = _C.linear_bwd_input(d, y, tape.act, wmat)
+            B, H, W, Cin = in_shape
+            d = _C.col2im(dcols, B, Cin, H, W, kh, kw, sh, sw).view(B * H * W, Cin)

@@ -1,3 +1,4 @@
 from .continuous_policy import (GuassianContPolicy, GuassianContPolicyBasicBias, GuassianContPolicyBase,
                                 FixGuassianContPolicy, UniformPolicyContinuous)
+from .discrete_policies import EpsilonGreedyDQNDiscretePolicy, EpsilonGreedyQRDQNDiscretePolicy
 from .distribution import TanhNormal

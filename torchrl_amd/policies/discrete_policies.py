@@ -1,0 +1,69 @@
+"""Epsilon-greedy wrappers over a Q network (torchrl/policies/discrete_policies.py:23-89).
+
+`explore` keeps the reference's host-side protocol -- linear epsilon decay per call, then
+`np.random.rand(*shape)` and `np.random.randint(0, A, shape)` from the global numpy stream (so
+seeded runs replay the reference's exploration decisions) -- but the Q network runs on the conv /
+dense HIP kernels and the argmax + mask is one kernel (trl_eps_greedy_i64).  Unlike the
+reference's QR-DQN policy (single env, `.item()`, its Q16) both policies are vectorised over N
+envs; actions are returned as (N, 1) int64.
+"""
+import numpy as np
+import torch
+
+from .. import _C, ops
+
+
+class EpsilonGreedyDQNDiscretePolicy:
+    quantile_num = 1
+
+    def __init__(self, qf, start_epsilon, end_epsilon, decay_frames, action_shape):
+        self.qf = qf
+        self.start_epsilon = start_epsilon
+        self.end_epsilon = end_epsilon
+        self.decay_frames = decay_frames
+        self.count = 0
+        self.action_shape = action_shape
+        self.epsilon = self.start_epsilon
+        self.continuous = False
+
+    def _q(self, x):
+        with torch.no_grad():
+            if x.dtype == torch.uint8:
+                return ops.cnn_forward(self.qf, x)[0]
+            return self.qf(x)
+
+    def q_to_a(self, q):
+        return _C.eps_greedy(q.contiguous(), self.action_shape, self.quantile_num, None, None, 0.0).unsqueeze(-1)
+
+    def explore(self, x):
+        self.count += 1
+        if x.dim() in (2, 5):
+            x = x.squeeze(0)
+        if self.count < self.decay_frames:
+            self.epsilon = self.start_epsilon - (self.start_epsilon - self.end_epsilon) * (self.count / self.decay_frames)
+        else:
+            self.epsilon = self.end_epsilon
+        output = self._q(x)
+        n = int(output.shape[0])
+        u = torch.from_numpy(np.random.rand(n, 1).astype(np.float32)).to(output.device)
+        ra = torch.from_numpy(np.random.randint(low=0, high=self.action_shape, size=(n, 1)).astype(np.int64)).to(output.device)
+        action = _C.eps_greedy(output.contiguous(), self.action_shape, self.quantile_num, u.reshape(-1).contiguous(),
+                               ra.reshape(-1).contiguous(), self.epsilon).unsqueeze(-1)
+        return {"q_value": output, "action": action}
+
+    def eval_act(self, x):
+        return self.q_to_a(self._q(x)).cpu().numpy()
+
+    def to(self, device):
+        self.qf.to(device)
+
+    def parameters(self):
+        return self.qf.parameters()
+
+
+class EpsilonGreedyQRDQNDiscretePolicy(EpsilonGreedyDQNDiscretePolicy):
+    """argmax over the mean of the quantiles (discrete_policies.py:86-89), for all N envs."""
+
+    def __init__(self, quantile_num, **kwargs):
+        super().__init__(**kwargs)
+        self.quantile_num = quantile_num
