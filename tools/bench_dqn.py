@@ -1,0 +1,80 @@
+"""Secondary measurement: DQN / QR-DQN at BASELINE cfg 5 (512 envs, 84x84x4 uint8 frames, 1e5-transition
+replay = 195 rows, conv net of config/dqn_pong.json, B = 512): per epoch 8 vector steps + 8 updates."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+N, ROWS, B, STEPS, OPT, A = 512, 195, 512, 8, 8, 6
+CONVS = [[16, [8, 8], [4, 4], [0, 0]], [32, [4, 4], [2, 2], [0, 0]], [64, [3, 3], [1, 1], [0, 0]]]
+
+
+class NullLog:
+    def add_update_info(self, d): pass
+    def add_epoch_info(self, *a, **k): pass
+    def log(self, *a): pass
+    def finish(self): pass
+
+
+def run(Q, epochs, cpu):
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import DQN, QRDQN
+    from torchrl.collector import VecCollector
+    from torchrl.env import get_vec_env
+    from torchrl.replay_buffers import BaseReplayBuffer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0); np.random.seed(0)
+    qf = networks.Net(output_shape=A * Q, base_type=networks.CNNBase, append_hidden_shapes=[512],
+                      activation_func=torch.nn.Tanh, input_shape=(4, 84, 84), hidden_shapes=CONVS)
+    env = get_vec_env("SynthAtari-v0", {"reward_scale": 1}, N)
+    eval_env = get_vec_env("SynthAtari-v0", {"reward_scale": 1}, N)
+    kwp = dict(qf=qf, start_epsilon=1, end_epsilon=0.1, decay_frames=1000000, action_shape=A)
+    pf = policies.EpsilonGreedyQRDQNDiscretePolicy(quantile_num=Q, **kwp) if Q > 1 else policies.EpsilonGreedyDQNDiscretePolicy(**kwp)
+    buf = BaseReplayBuffer(ROWS * N, env_nums=N)
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * STEPS,
+                       max_episode_frames=999)
+    kw = dict(qf=qf, pf=pf, qlr=2.5e-4, env=env, replay_buffer=buf, collector=col, logger=NullLog(), discount=0.99,
+              num_epochs=1, batch_size=B, device=dev, save_dir=None, tau=0.005, opt_times=OPT)
+    agent = QRDQN(quantile_num=Q, **kw) if Q > 1 else DQN(**kw)
+    for _ in range(2):
+        col.rollout(STEPS); agent.update_per_epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); tc = tu = 0.0
+    for _ in range(epochs):
+        a = time.perf_counter(); col.rollout(STEPS); torch.cuda.synchronize()
+        b = time.perf_counter(); agent.update_per_epoch(); torch.cuda.synchronize()
+        tc += b - a; tu += time.perf_counter() - b
+    el = time.perf_counter() - t0
+    out = {"workload": "%s cfg5: %d envs, 84x84x4 u8 frames, %d-row replay, B=%d, conv 16/32/64 + fc512%s"
+                       % ("QRDQN" if Q > 1 else "DQN", N, ROWS, B, ", Q=%d" % Q if Q > 1 else ""),
+           "env_steps_per_s": epochs * N * STEPS / el, "updates_per_s": epochs * OPT / tu,
+           "ms_per_update": 1e3 * tu / (epochs * OPT), "ms_per_vector_step": 1e3 * tc / (epochs * STEPS),
+           "update_gflop": 38e-3 * B}
+    if cpu:
+        from oracle.dqn import DQNOracle
+        from torchrl_amd import ops
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        o = DQNOracle([p.detach().cpu() for p in ops.cnn_param_list(qf)], [4, 2, 1], quantile_num=Q, action_num=A)
+        rs = np.random.RandomState(0)
+        batch = {"obs": rs.randint(0, 256, (B, 4, 84, 84)).astype(np.uint8), "next_obs": rs.randint(0, 256, (B, 4, 84, 84)).astype(np.uint8),
+                 "acts": rs.randint(0, A, (B,)), "rewards": rs.randn(B, 1), "terminals": np.zeros((B, 1))}
+        o.update(batch)
+        t0 = time.perf_counter(); o.update(batch); o.update(batch)
+        out["cpu_oracle_ms_per_update"] = 1e3 * (time.perf_counter() - t0) / 2
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--quantiles", type=int, default=1)
+    ap.add_argument("--cpu", action="store_true")
+    a = ap.parse_args()
+    run(a.quantiles, a.epochs, a.cpu)
