@@ -22,8 +22,11 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not _stale():
+def build(force=False, verbose=True, extra_flags=(), lib=None):
+    """`extra_flags` / `lib`: experimental builds for the tools/ scripts (e.g. -DTRL_EXP_CLK)."""
+    LIB = lib or globals()["LIB"]
+    FLAGS = globals()["FLAGS"] + list(extra_flags)
+    if not force and not lib and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -32,7 +35,7 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + (".exp.o" if lib else ".o"))
         cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + \
               ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -53,4 +56,9 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    # python build.py [--force] [--exp NAME -DFLAG ...]  ->  lib/libtrl_hip_NAME.so
+    if "--exp" in sys.argv:
+        k = sys.argv.index("--exp")
+        build(force=True, extra_flags=sys.argv[k + 2:], lib=os.path.join(LIB_DIR, "libtrl_hip_%s.so" % sys.argv[k + 1]))
+    else:
+        build(force="--force" in sys.argv)

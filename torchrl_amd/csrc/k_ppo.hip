@@ -27,11 +27,7 @@
 #define G_PER_WG 3
 #define PPO_WAVES (Q_WAVES * G_PER_WG)
 #define PPO_THREADS (64 * PPO_WAVES)
-#define TL 17                                   // LDS staging row stride (16 samples + 1)
 
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -82,23 +78,6 @@ template <int D, int H, int A> struct PpoShape {
   static constexpr int LDS_FLOATS = PAR + (SCR_ALL > FOLD ? SCR_ALL : FOLD);
 };
 
-// T-layout tile (MFMA C/D): reg r of lane (j, g) <-> feature 16*slice + 4g + r, sample j.
-// Staging rows are permuted inside a slice -- feature 4g + r sits in row 4r + g -- so that the two
-// lane groups of a 32-lane half write rows one apart (17 banks apart) instead of 4 rows apart
-// (4*17 = 68 = 4 banks apart, a 2-way conflict); srow() gives the row of feature f for the
-// lane-equals-feature reads, which stay conflict free because the stride is odd.
-__device__ __forceinline__ constexpr int srow(int f) { return ((f & 3) << 2) | (f >> 2); }
-__device__ __forceinline__ void store_T(float* S, int slice, const f32x4& t, int j, int g) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) S[(16 * slice + 4 * r + g) * TL + j] = t[r];
-}
-__device__ __forceinline__ f32x4 load_T(const float* S, int slice, int j, int g) {
-  f32x4 t;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) t[r] = S[(16 * slice + 4 * r + g) * TL + j];
-  return t;
-}
-
 // One network (policy or value) over this workgroup's tiles.
 template <int D, int H, int A, int ACT, bool IS_PF>
 __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
@@ -106,7 +85,7 @@ __device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_w
   using S = PpoShape<D, H, A>;
   using F = MlpFlat<D, H, O>;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (readfirstlane on `wave` measured 1.5 % slower)
   const int grp = wave >> 2, mo0 = wave & 3;
   const int j0 = lane & 15, g0 = lane >> 4;
   const float* gp = IS_PF ? a.pf_params : a.vf_params;

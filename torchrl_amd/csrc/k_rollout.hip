@@ -1,32 +1,49 @@
-// K1 + K2 + K3 -- the whole vectorised on-policy rollout as ONE persistent launch.
+// K1 + K2 + K3 -- the whole vectorised on-policy rollout as two launches: a persistent
+// policy / env kernel that walks all T steps, then one streaming value pass over the T x N cells.
 //
 // Replaces n_steps x VecOnPolicyCollector.take_actions
 // (torchrl/collector/on_policy.py:90-155; loop base.py:108-122) on the
 // synthetic env: environments are independent, the networks are shared and
-// read-only during collection, so a workgroup can carry 32 envs through all T
+// read-only during collection, so a workgroup can carry 16 envs through all T
 // steps with no inter-workgroup communication -- the 2 host<->device round
 // trips and the python env loop per step of the reference disappear, and so do
 // per-step kernel launches.
 //
-// Workgroup = 4 waves = 32 envs.  Wave (net, mo): net 0 = policy, 1 = value;
-// mo = which 32 of the 64 hidden features it computes.  Per step and wave:
-//   L1 9 MFMA -> tanh -> LDS exchange of H1 halves -> L2 32 MFMA -> tanh ->
-//   partial head on VALU -> LDS exchange -> action = tanh(mean + std*eps) ->
-//   env step as a 12-MFMA GEMM [obs, act] x [A; B] (computed by all 4 waves so
-//   everyone owns next_obs in registers) -> reward / done / over-length
-//   bootstrap (extra vf pass only when some env of the tile needs it) ->
-//   partial reset from the Philox reset stream -> ring-buffer row store.
-// The env output tile has the same register layout as the L1 input operand
-// (see trl_mlp.h), so next_obs feeds the next step without touching memory.
+// The rollout is a latency problem (T strictly sequential steps, only N/16 independent tiles), so
+// the sequential kernel carries only what the recurrence needs -- the policy and the env:
+//   * workgroup = 4 waves = 16 envs on v_mfma_f32_16x16x4_f32; wave mo computes 16 of the 64 hidden
+//     features; its slices of W1, W2, W3 and the env matrices stay in registers for the whole
+//     rollout -- the per-step critical path has no weight fetches;
+//   * per step: L1 5 MFMA -> tanh -> LDS exchange -> L2 16 MFMA -> tanh -> head partial 4 MFMA -> LDS
+//     exchange -> action = tanh(mean + std*eps) for the two action dims the lane feeds to the env GEMM ->
+//     env step as a 14-MFMA GEMM [obs, act] x [A; B] (every wave: everyone owns next_obs in the
+//     operand layout of the next L1) -> reward / done -> partial reset from the Philox reset stream ->
+//     ring-buffer row store;
+//   * exploration noise (Philox4x32-10 + Box-Muller, ~300 instructions per block) is produced 16 steps
+//     at a time, one (step, env) per lane, and parked in LDS -- 1/8 block per lane-step instead of 1.
+// The value network is not part of the recurrence: V(obs) for every stored cell, and the over-length
+// bootstrap reward + discount * V(next_obs) (on_policy.py:135-143), are computed afterwards by
+// `value_pass_kernel` at full-chip parallelism (each wave owns whole 16-sample tiles, all weights in
+// registers, layer outputs chain as the next layer's B operand -- no LDS, no barriers).
 //
 // HBM traffic per env-step: 176 B algorithmic (obs 68 + next_obs 68 + act 24 +
 // value/reward/terminal/time_limit 16; the obs read is only at launch) + 4 B
-// old_logp (+24 B if host noise is supplied).
+// old_logp (+24 B if host noise is supplied) + 76 B re-read / marker traffic of the value pass.
 #include "trl_common.h"
 #include "trl_mlp.h"
 #include "trl_philox.h"
 
 #define RO_THREADS 256
+#define RO_ENVS 16
+// development aid (tools/exp_rollout.py): per-phase cycle totals of workgroup 0 into the tail of ep_log
+#ifdef TRL_EXP_CLK
+#define CLK_DECL long long clk_prev = clock64(); float clk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CLK(ph) { const long long c_ = clock64(); clk_acc[ph] += (float)(c_ - clk_prev); clk_prev = c_; }
+#else
+#define CLK_DECL
+#define CLK(ph)
+#endif
+#define RO_NB 16                                     // steps of exploration noise generated per batch
 
 struct RolloutDev {
   const float *pf_params, *vf_params, *env_A, *env_B;
@@ -40,175 +57,190 @@ struct RolloutDev {
 };
 
 template <int D, int H, int A> struct RoShape {
-  using LP = MlpLds<D, H, A>;
-  using LV = MlpLds<D, H, 1>;
-  static constexpr int ELD = ((D + A) % 2 == 0) ? D + A + 1 : D + A;   // odd stride
-  static constexpr int OFF_PF = 0;
-  static constexpr int OFF_VF = align4(LP::SIZE);
-  static constexpr int OFF_ENV = OFF_VF + align4(LV::SIZE);
-  static constexpr int OFF_XCH = OFF_ENV + align4(32 * ELD);
-  static constexpr int OFF_HEAD = OFF_XCH + 2 * H * TRL_TLD;
-  static constexpr int LDS_FLOATS = align4(OFF_HEAD + 2 * 2 * 8 * 32);
+  static_assert(H == 64 && D > 16 && D <= 20 && A <= 8, "instantiated for 16 < D <= 20, H == 64, A <= 8");
+  // LDS: b1[H] | b2[H] | b3[8] | logstd[8] | H1 staging [H][TL] | headp [4][8][16] | eps [RO_NB][8][16]
+  static constexpr int O_B1 = 0, O_B2 = H, O_B3 = 2 * H, O_LS = O_B3 + 8, O_H1 = O_LS + 8, O_HP = O_H1 + H * TL,
+                       O_EPS = O_HP + 4 * 8 * 16, LDS_FLOATS = O_EPS + RO_NB * 8 * 16;
 };
 
 template <int D, int H, int A, int ACT>
 __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   using S = RoShape<D, H, A>;
-  using LP = typename S::LP;
-  using LV = typename S::LV;
-  constexpr int NT = H / 32, KS = ksteps_for(D), KA = (A + 1) / 2, ELD = S::ELD;
-  static_assert(NT == 2, "rollout kernel is laid out for H == 64 (2 feature tiles x 2 nets = 4 waves)");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sp_pf = lds + S::OFF_PF;
-  float* sp_vf = lds + S::OFF_VF;
-  float* senv = lds + S::OFF_ENV;
-  float* xch = lds + S::OFF_XCH;
-  float* headp = lds + S::OFF_HEAD;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int net = wave >> 1, mo = wave & 1;
-  const int i = lane & 31, j = i, hi = lane >> 5;
-  const int n = blockIdx.x * 32 + j;
+  using FP = MlpFlat<D, H, A>;
+  __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int mo = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it stay scalar
+  const int j = lane & 15, g = lane >> 4, i = j;
+  const int n = blockIdx.x * RO_ENVS + j;
   const bool valid = n < a.N;
+  const float* gp = a.pf_params;
+  const bool has_lo = g < A, has_hi = 4 + g < A;            // the lane's two action dims: g and 4 + g
+  const int o_lo = has_lo ? g : 0, o_hi = has_hi ? 4 + g : 0;
 
-  LP::load(sp_pf, a.pf_params, true, tid, RO_THREADS);
-  LV::load(sp_vf, a.vf_params, false, tid, RO_THREADS);
-  for (int e = tid; e < 32 * ELD; e += RO_THREADS) {
-    const int f = e / ELD, k = e - f * ELD;
-    float v = 0.0f;
-    if (f < D) { if (k < D) v = a.env_A[k * D + f]; else if (k < D + A) v = a.env_B[(k - D) * D + f]; }
-    senv[e] = v;
+  // ---- one-time setup: biases / logstd to LDS, this wave's weight slices to registers ----
+  for (int e = tid; e < H; e += RO_THREADS) { lds[S::O_B1 + e] = gp[FP::B1 + e]; lds[S::O_B2 + e] = gp[FP::B2 + e]; }
+  if (tid < 8) {
+    lds[S::O_B3 + tid] = tid < A ? gp[FP::B3 + tid] : 0.0f;
+    lds[S::O_LS + tid] = tid < A ? gp[FP::LS + tid] : 0.0f;
+  }
+  // A operands, lane (i, g): the k index of MFMA step (slice sl, r) is feature 16 sl + 4 g + r
+  float w1r[5], w2r[4][4], w3a[4], we0[7], w16[7];
+  {
+    const int row = 16 * mo + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w1r[r] = gp[FP::W1 + row * D + 4 * g + r];
+    w1r[4] = (16 + g < D) ? gp[FP::W1 + row * D + (16 + g < D ? 16 + g : 0)] : 0.0f;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w2r[sl][r] = gp[FP::W2 + row * H + 16 * sl + 4 * g + r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w3a[r] = (i < A) ? gp[FP::W3 + (i < A ? i : 0) * H + 16 * mo + 4 * g + r] : 0.0f;
+    // env GEMM next^T[f][j] = sum_k M[f][k] [obs; act]^T[k][j] for features f = 0..15 (we0, MFMA A operand of
+    // row f = i); feature 16 is a per-lane partial dot over the lane's own 7 inputs (w16) + a lane-group sum
+    static_assert(D == 17, "the env step keeps exactly one feature outside the 16-row MFMA tile");
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      // k of step q: obs feature 4g + q (q < 4), obs feature 16 + g (q == 4), action g (q == 5), action 4 + g (q == 6)
+      float v0 = 0.0f, v1 = 0.0f;
+      if (q < 4) { const int k = 4 * g + q; v0 = a.env_A[k * D + i]; v1 = a.env_A[k * D + 16]; }
+      else if (q == 4) { const int k = 16 + g; if (k < D) { v0 = a.env_A[k * D + i]; v1 = a.env_A[k * D + 16]; } }
+      else { const int k = (q == 5) ? g : 4 + g; if (k < A) { v0 = a.env_B[k * D + i]; v1 = a.env_B[k * D + 16]; } }
+      we0[q] = v0; w16[q] = v1;
+    }
   }
   __syncthreads();
 
-  const float* sp = net == 0 ? sp_pf : sp_vf;           // W1..B2 offsets are identical in LP and LV
-  float* my_xch = xch + net * H * TRL_TLD;
+  float* S_H1 = lds + S::O_H1;
+  float* headp = lds + S::O_HP;
+  float* S_EPS = lds + S::O_EPS;
+  const float* b1s = lds + S::O_B1 + 16 * mo + 4 * g;
+  const float* b2s = lds + S::O_B2 + 16 * mo + 4 * g;
 
-  float stdv[A], lsv[A], inv_var[A];
-#pragma unroll
-  for (int o = 0; o < A; ++o) {
-    lsv[o] = fminf(fmaxf(sp_pf[LP::LS + o], -20.0f), 2.0f);
-    stdv[o] = __expf(lsv[o]);
-    inv_var[o] = __expf(-2.0f * lsv[o]);
-  }
+  // the lane's two action dims
+  const float ls_lo = fminf(fmaxf(lds[S::O_LS + o_lo], -20.0f), 2.0f), ls_hi = fminf(fmaxf(lds[S::O_LS + o_hi], -20.0f), 2.0f);
+  const float std_lo = __expf(ls_lo), std_hi = __expf(ls_hi);
+  const float iv_lo = __expf(-2.0f * ls_lo), iv_hi = __expf(-2.0f * ls_hi);
+  const float b3_lo = lds[S::O_B3 + o_lo], b3_hi = lds[S::O_B3 + o_hi];
 
-  // ---- per-env state (replicated in all 4 waves and both lane halves) ----
-  float xb[KS];
+  // ---- per-env state (replicated in all 4 waves and all 4 lane groups) ----
+  // x operand: lane (env j, g) holds obs features 4g..4g+3 and (g == 0) feature 16
+  float xb[5];
 #pragma unroll
-  for (int q = 0; q < KS; ++q) { const int k = rowmap(q, hi); xb[q] = (valid && k < D) ? a.cur_obs[(size_t)n * D + k] : 0.0f; }
+  for (int r = 0; r < 4; ++r) xb[r] = valid ? a.cur_obs[(size_t)n * D + 4 * g + r] : 0.0f;
+  xb[4] = (valid && 16 + g < D) ? a.cur_obs[(size_t)n * D + 16 + g] : 0.0f;
   int t_env = valid ? a.t_env[n] : 0;
   int cur_step = valid ? a.cur_step[n] : 0;
   int ep_idx = valid ? a.episode_idx[n] : 0;
   float ep_ret = valid ? a.ep_return[n] : 0.0f;
   const int64_t env_seed = a.env_seed_base + n;
   double rew_sum = 0.0;
-
-  // both networks' forward; every wave returns the full policy mean and the value
-  auto forward = [&](const float (&x)[KS], float (&mean)[A], float& value) {
-    f32x16 h1 = act_tile<ACT>(layer1_tile<D, LP::LD1, KS>(bias_tile(sp + LP::B1 + 32 * mo, hi), sp + LP::W1, mo, x, i, hi));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) my_xch[(32 * mo + rowmap(r, hi)) * TRL_TLD + j] = h1[r];
-    __syncthreads();
-    f32x16 hh[NT];
-#pragma unroll
-    for (int m = 0; m < NT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hh[m][r] = my_xch[(32 * m + rowmap(r, hi)) * TRL_TLD + j];
-    f32x16 h2 = act_tile<ACT>(layer_tile<NT, LP::LD2>(bias_tile(sp + LP::B2 + 32 * mo, hi), sp + LP::W2, mo, hh, i, hi));
-    // partial head over this wave's 32 features
-    const float* w3 = net == 0 ? sp_pf + LP::W3 : sp_vf + LV::W3;
-    const int n_out = net == 0 ? A : 1;
-#pragma unroll
-    for (int o = 0; o < A; ++o) {
-      if (o < n_out) {
-        float p = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(w3 + o * H + 32 * mo + 8 * q + 4 * hi);
-          p = fmaf(w[0], h2[4 * q + 0], p); p = fmaf(w[1], h2[4 * q + 1], p);
-          p = fmaf(w[2], h2[4 * q + 2], p); p = fmaf(w[3], h2[4 * q + 3], p);
-        }
-        p += __shfl_xor(p, 32, 64);
-        if (hi == 0) headp[((net * 2 + mo) * 8 + o) * 32 + j] = p;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int o = 0; o < A; ++o)
-      mean[o] = headp[((0 * 2 + 0) * 8 + o) * 32 + j] + headp[((0 * 2 + 1) * 8 + o) * 32 + j] + sp_pf[LP::B3 + o];
-    value = headp[((1 * 2 + 0) * 8 + 0) * 32 + j] + headp[((1 * 2 + 1) * 8 + 0) * 32 + j] + sp_vf[LV::B3];
-  };
+  const bool dev_noise = !a.deterministic && !a.noise;
+  CLK_DECL
 
   for (int t = 0; t < a.n_steps; ++t) {
     const int row = (a.top + t) % a.rows;
     const size_t cell = (size_t)row * a.N + n;
 
-    // exploration noise: host stream (reference parity, distribution.py:67-70) or device Philox
-    float eps[A];
-    if (a.deterministic) {
-#pragma unroll
-      for (int o = 0; o < A; ++o) eps[o] = 0.0f;
-    } else if (a.noise) {
-#pragma unroll
-      for (int o = 0; o < A; ++o) eps[o] = valid ? a.noise[((size_t)t * a.N + n) * A + o] : 0.0f;
-    } else {
-      // lane half hi draws Philox block hi (4 normals); the halves swap through one cross-lane
-      // exchange, so each lane pays for one block instead of ceil(A/4)
-      static_assert(A <= 8, "noise split assumes at most two Philox blocks per env-step");
-      const int64_t gs = a.noise_step0 + t;
-      float z[4], zx[4];
-      philox_normals4((uint32_t)(gs & 0xFFFFFFFFll), (uint32_t)((gs >> 32) & 0xFFFFFFFFll), (uint32_t)hi,
-                      TRL_TAG_NOISE, env_seed, z);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) zx[c] = __shfl_xor(z[c], 32, 64);
+    // ---- exploration noise: host stream (reference parity, distribution.py:67-70) or device Philox ----
+    if (dev_noise && (t % RO_NB) == 0) {
+      // lane (env j, g) of wave mo draws both Philox blocks (8 normals) of step t + 4 mo + g
+      const int ts = 4 * mo + g;
+      const int64_t gs = a.noise_step0 + t + ts;
+      float z0[4], z1[4];
+      philox_normals4((uint32_t)(gs & 0xFFFFFFFFll), (uint32_t)((gs >> 32) & 0xFFFFFFFFll), 0u, TRL_TAG_NOISE, env_seed, z0);
+      if (A > 4)
+        philox_normals4((uint32_t)(gs & 0xFFFFFFFFll), (uint32_t)((gs >> 32) & 0xFFFFFFFFll), 1u, TRL_TAG_NOISE, env_seed, z1);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        if (c < A) eps[c] = hi ? zx[c] : z[c];
-        if (4 + c < A) eps[4 + c] = hi ? z[c] : zx[c];
+        S_EPS[(ts * 8 + c) * 16 + j] = z0[c];
+        if (4 + c < A) S_EPS[(ts * 8 + 4 + c) * 16 + j] = z1[c];
       }
+      __syncthreads();   // readers of the previous batch finished before the barriers of the step that ended it
+    }
+    float eps_lo = 0.0f, eps_hi = 0.0f;
+    if (dev_noise) {
+      eps_lo = S_EPS[((t % RO_NB) * 8 + o_lo) * 16 + j];
+      eps_hi = S_EPS[((t % RO_NB) * 8 + o_hi) * 16 + j];
+    } else if (a.noise) {
+      eps_lo = valid ? a.noise[((size_t)t * a.N + n) * A + o_lo] : 0.0f;
+      eps_hi = valid ? a.noise[((size_t)t * a.N + n) * A + o_hi] : 0.0f;
     }
 
-    float mean[A], value;
-    forward(xb, mean, value);
+    CLK(0)
+    // ---- policy forward ----
+    f32x4 h1 = *reinterpret_cast<const f32x4*>(b1s);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) h1 = mfma16(w1r[q], xb[q], h1);
+    // the observation part of the env step does not wait for the action: it runs in the shadow of the barriers
+    f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    float p16 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { e0 = mfma16(we0[q], xb[q], e0); p16 = fmaf(w16[q], xb[q], p16); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1[r] = act_fn<ACT>(h1[r]);
+    store_T(S_H1, mo, h1, j, g);
+    CLK(1)
+    __syncthreads();
+    CLK(2)
+    f32x4 h2 = *reinterpret_cast<const f32x4*>(b2s), h2b = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < 4; sl += 2) {                     // two interleaved accumulation chains
+      const f32x4 b0 = load_T(S_H1, sl, j, g), b1 = load_T(S_H1, sl + 1, j, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { h2 = mfma16(w2r[sl][r], b0[r], h2); h2b = mfma16(w2r[sl + 1][r], b1[r], h2b); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[r] = act_fn<ACT>(h2[r] + h2b[r]);
+    f32x4 hp = f32x4{0.f, 0.f, 0.f, 0.f};                  // partial head over the own 16 features: D[o][env]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hp = mfma16(w3a[r], h2[r], hp);
+    if (g < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) headp[(mo * 8 + 4 * g + r) * 16 + j] = hp[r];
+    }
+    CLK(3)
+    __syncthreads();
+    CLK(4)
+    float mean_lo = b3_lo, mean_hi = b3_hi;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mean_lo += headp[(w * 8 + o_lo) * 16 + j]; mean_hi += headp[(w * 8 + o_hi) * 16 + j]; }
 
     // action + log-prob under the collecting policy (continuous_policy.py:123-129, distribution.py:33-45)
-    float act[A], logp = 0.0f, act_sq = 0.0f;
-#pragma unroll
-    for (int o = 0; o < A; ++o) {
-      const float z = fmaf(stdv[o], eps[o], mean[o]);
-      act[o] = a.tanh_action ? trl_tanh(z) : z;
-      if (wave == 2) {                                       // only the wave that stores old_logp needs it
-        float zc;
-        logp += gauss_logp_term(act[o], mean[o], inv_var[o], lsv[o], a.tanh_action, zc);
-      }
-      act_sq = fmaf(act[o], act[o], act_sq);
+    const float z_lo = fmaf(std_lo, eps_lo, mean_lo), z_hi = fmaf(std_hi, eps_hi, mean_hi);
+    const float act_lo = has_lo ? (a.tanh_action ? trl_tanh(z_lo) : z_lo) : 0.0f;
+    const float act_hi = has_hi ? (a.tanh_action ? trl_tanh(z_hi) : z_hi) : 0.0f;
+    // ---- env step: next^T[f][env] = sum_k M[f][k] [obs; act]^T[k][env] (action part) ----
+    e0 = mfma16(we0[5], act_lo, e0);
+    e0 = mfma16(we0[6], act_hi, e0);
+    p16 = fmaf(w16[5], act_lo, p16);
+    p16 = fmaf(w16[6], act_hi, p16);
+    // lane-group sums (same env, g = 0..3) as ones x value MFMAs: every lane gets the total
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float e16 = mfma16(1.0f, p16, zero4)[0];
+    const float act_sq = mfma16(1.0f, fmaf(act_lo, act_lo, act_hi * act_hi), zero4)[0];   // all action dims
+    float logp = 0.0f;
+    if (mo == 3) {                                          // only the wave that stores old_logp needs it
+      float zc, lp = 0.0f;
+      if (has_lo) lp += gauss_logp_term(act_lo, mean_lo, iv_lo, ls_lo, a.tanh_action, zc);
+      if (has_hi) lp += gauss_logp_term(act_hi, mean_hi, iv_hi, ls_hi, a.tanh_action, zc);
+      logp = mfma16(1.0f, lp, zero4)[0];
     }
+    CLK(5)
+    float nx[5];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nx[r] = trl_tanh(e0[r]);     // features 4g + r
+    nx[4] = (g == 0) ? trl_tanh(e16) : 0.0f;                 // feature 16
 
-    // ---- env step: next^T[f][j] = sum_k M[f][k] [obs; act]^T[k][j] ----
-    f32x16 acc = zero_tile();
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = rowmap(s, hi);
-      acc = mfma32((k < D) ? senv[i * ELD + k] : 0.0f, xb[s], acc);
-    }
-#pragma unroll
-    for (int s = 0; s < KA; ++s) {
-      const int k = 2 * s + hi;
-      const float a_odd = (2 * s + 1 < A) ? act[(2 * s + 1 < A) ? 2 * s + 1 : 0] : 0.0f;
-      const float av = hi ? a_odd : act[2 * s];
-      acc = mfma32((k < A) ? senv[i * ELD + D + k] : 0.0f, av, acc);
-    }
-    float nx[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) nx[s] = (rowmap(s, hi) < D) ? trl_tanh(acc[s]) : 0.0f;
-
-    const float nx0 = __shfl(nx[0], j, 64);                 // feature 0 lives in the hi == 0 lane
+    CLK(6)
+    // feature 0 lives in lane group 0 (r == 0): broadcast to the other groups with a selector MFMA
+    const float nx0 = mfma16(1.0f, g == 0 ? nx[0] : 0.0f, zero4)[0];
     const float raw_rew = a.reward_scale * (nx0 - 0.1f * act_sq);
     t_env += 1; cur_step += 1;
     const bool done = t_env >= a.horizon;
     const bool surpass = cur_step >= a.max_episode_frames;
     ep_ret += raw_rew;
-    if (wave == 0 && hi == 0 && valid) {
+    if (mo == 0 && g == 0 && valid) {
       rew_sum += (double)raw_rew;
       if (done) {                                           // on_policy.py:128-130
         const int slot = atomicAdd(a.ep_count, 1);
@@ -217,77 +249,175 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
     }
     if (done) ep_ret = 0.0f;
 
-    const bool flag = valid && (done || surpass);
-    float st_rew = raw_rew, st_term = done ? 1.0f : 0.0f;
-    float xn[KS];
+    float xn[5];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xn[s] = nx[s];
-    if (__ballot(flag) != 0ull) {                           // uniform across the workgroup (state is replicated)
-      float m2[A], v2;
-      forward(nx, m2, v2);                                  // on_policy.py:135-143
-      st_rew = raw_rew + a.discount * v2 * (surpass ? 1.0f : 0.0f);
-      st_term = (done || surpass) ? 1.0f : 0.0f;
-      if (flag) {                                           // partial_reset (vecenv.py:47-51) + counters (:148)
-        ep_idx += 1; t_env = 0; cur_step = 0;
+    for (int q = 0; q < 5; ++q) xn[q] = nx[q];
+    if (done || surpass) {                                  // partial_reset (vecenv.py:47-51) + counters (:148)
+      ep_idx += 1; t_env = 0; cur_step = 0;
+      float z[4];
+      philox_normals4((uint32_t)ep_idx, 0u, (uint32_t)g, TRL_TAG_RESET, env_seed, z);     // features 4g..4g+3
 #pragma unroll
-        for (int g = 0; g < (KS + 3) / 4; ++g) {
-          float z[4];
-          philox_normals4((uint32_t)ep_idx, 0u, 2 * g + hi, TRL_TAG_RESET, env_seed, z);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) if (4 * g + c < KS) xn[4 * g + c] = (rowmap(4 * g + c, hi) < D) ? z[c] : 0.0f;
-        }
+      for (int c = 0; c < 4; ++c) xn[c] = z[c];
+      xn[4] = 0.0f;
+      if (g == 0) {
+        philox_normals4((uint32_t)ep_idx, 0u, 4u, TRL_TAG_RESET, env_seed, z);            // feature 16
+        xn[4] = z[0];
       }
     }
 
     // ---- ring-buffer row `row` (replay_buffers/base.py:19-29), one key group per wave ----
     if (valid && a.store) {
-      if (wave == 0) {
+      if (mo == 0) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { const int k = rowmap(s, hi); if (k < D) a.obs[cell * D + k] = xb[s]; }
-      } else if (wave == 1) {
+        for (int r = 0; r < 4; ++r) a.obs[cell * D + 4 * g + r] = xb[r];
+        if (g == 0) a.obs[cell * D + 16] = xb[4];
+      } else if (mo == 1) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { const int k = rowmap(s, hi); if (k < D) a.next_obs[cell * D + k] = nx[s]; }
-      } else if (wave == 2) {
-        if (hi == 0) {
-#pragma unroll
-          for (int o = 0; o < A; ++o) a.acts[cell * A + o] = act[o];
-        } else {
-          a.values[cell] = value;
-          if (a.old_logp) a.old_logp[cell] = logp;
-        }
-      } else if (hi == 0) {
-        a.rewards[cell] = st_rew; a.terminals[cell] = st_term; a.time_limits[cell] = done ? 1.0f : 0.0f;
+        for (int r = 0; r < 4; ++r) a.next_obs[cell * D + 4 * g + r] = nx[r];
+        if (g == 0) a.next_obs[cell * D + 16] = nx[4];
+      } else if (mo == 2) {
+        if (has_lo) a.acts[cell * A + g] = act_lo;
+        if (has_hi) a.acts[cell * A + 4 + g] = act_hi;
+      } else {
+        // one store instruction for the four per-cell scalars: lane group g writes key g.  values[cell]
+        // carries the over-length marker to the value pass, which overwrites it with V(obs)
+        float* dst = g == 0 ? a.values : g == 1 ? a.rewards : g == 2 ? a.terminals : a.time_limits;
+        const float val = g == 0 ? (surpass ? 1.0f : 0.0f) : g == 1 ? raw_rew
+                        : g == 2 ? ((done || surpass) ? 1.0f : 0.0f) : (done ? 1.0f : 0.0f);
+        dst[cell] = val;
+        if (g == 0 && a.old_logp) a.old_logp[cell] = logp;
       }
     }
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xb[s] = xn[s];
+    for (int q = 0; q < 5; ++q) xb[q] = xn[q];
+    CLK(7)
   }
+#ifdef TRL_EXP_CLK
+  if (blockIdx.x == 0 && lane == 0)
+    for (int ph = 0; ph < 8; ++ph) a.ep_log[(a.ep_cap - 16) * 3 + mo * 8 + ph] = clk_acc[ph];
+#endif
 
   // ---- persist env / collector state ----
-  if (wave == 0 && valid) {
+  if (mo == 0 && valid) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) { const int k = rowmap(s, hi); if (k < D) a.cur_obs[(size_t)n * D + k] = xb[s]; }
-    if (hi == 0) { a.t_env[n] = t_env; a.cur_step[n] = cur_step; a.episode_idx[n] = ep_idx; a.ep_return[n] = ep_ret; }
+    for (int r = 0; r < 4; ++r) a.cur_obs[(size_t)n * D + 4 * g + r] = xb[r];
+    if (g == 0) {
+      a.cur_obs[(size_t)n * D + 16] = xb[4];
+      a.t_env[n] = t_env; a.cur_step[n] = cur_step; a.episode_idx[n] = ep_idx; a.ep_return[n] = ep_ret;
+    }
   }
-  if (wave == 0) {
+  if (mo == 0) {
     const double tot = wave_sum(rew_sum);
     if (lane == 0 && a.epoch_reward) atomicAdd(a.epoch_reward, tot);
   }
 }
 
+// ---------------------------------------------------------------- value pass over the stored cells
+// values[cell] = V(obs[cell]); rewards[cell] += discount * V(next_obs[cell]) where the rollout left
+// the over-length marker (on_policy.py:135-143).  Sample m = t * N + n lives in ring cell
+// ((top + t) % rows) * N + n.  One wave = one 16-sample tile at a time, all of W1 / W2 in registers
+// (A operands), the D tile of layer l is the B operand of layer l + 1, the 1-wide head is 16 FMAs +
+// two cross-lane adds.  84 MFMAs per tile, no LDS traffic besides the biases.
+#define VP_THREADS 256
+
+struct ValueDev {
+  const float* vf_params; const float *obs, *next_obs; float *values, *rewards;
+  int rows, top, N, n_steps; float discount;
+};
+
+template <int D, int H, int ACT>
+__global__ __launch_bounds__(VP_THREADS, 2) void value_pass_kernel(ValueDev a) {
+  using FV = MlpFlat<D, H, 1>;
+  static_assert(H == 64 && D > 16 && D <= 20, "instantiated for 16 < D <= 20, H == 64");
+  __shared__ __attribute__((aligned(16))) float sb[2 * H];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4, i = j;
+  const float* gp = a.vf_params;
+  for (int e = tid; e < H; e += VP_THREADS) { sb[e] = gp[FV::B1 + e]; sb[H + e] = gp[FV::B2 + e]; }
+  float w1[4][5], w2[4][4][4], w3[4][4];
+#pragma unroll
+  for (int so = 0; so < 4; ++so) {
+    const int row = 16 * so + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w1[so][r] = gp[FV::W1 + row * D + 4 * g + r];
+    w1[so][4] = (16 + g < D) ? gp[FV::W1 + row * D + (16 + g < D ? 16 + g : 0)] : 0.0f;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(gp + FV::W2 + row * H + 16 * sl + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w2[so][sl][r] = w[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w3[so][r] = gp[FV::W3 + 16 * so + 4 * g + r];
+  }
+  const float b3 = gp[FV::B3];
+  __syncthreads();
+
+  auto forward = [&](const float* src, size_t cell, bool ok) -> float {
+    float xb[5];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xb[r] = ok ? src[cell * D + 4 * g + r] : 0.0f;
+    xb[4] = (ok && 16 + g < D) ? src[cell * D + (16 + g < D ? 16 + g : 0)] : 0.0f;
+    f32x4 h1[4], h2[4];
+#pragma unroll
+    for (int so = 0; so < 4; ++so) {
+      f32x4 acc = *reinterpret_cast<const f32x4*>(sb + 16 * so + 4 * g);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) acc = mfma16(w1[so][q], xb[q], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = act_fn<ACT>(acc[r]);
+      h1[so] = acc;
+    }
+#pragma unroll
+    for (int so = 0; so < 4; ++so) {
+      f32x4 acc = *reinterpret_cast<const f32x4*>(sb + H + 16 * so + 4 * g);
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(w2[so][sl][r], h1[sl][r], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = act_fn<ACT>(acc[r]);
+      h2[so] = acc;
+    }
+    float v = 0.0f;
+#pragma unroll
+    for (int so = 0; so < 4; ++so)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v = fmaf(w3[so][r], h2[so][r], v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v + b3;
+  };
+
+  const int64_t M = (int64_t)a.n_steps * a.N;
+  const int64_t n_tiles = (M + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t m = tile * 16 + j;
+    const bool ok = m < M;
+    const int t = ok ? (int)(m / a.N) : 0;
+    const int n = ok ? (int)(m - (int64_t)t * a.N) : 0;
+    const size_t cell = (size_t)((a.top + t) % a.rows) * a.N + n;
+    const float marker = ok ? a.values[cell] : 0.0f;
+    const float v = forward(a.obs, cell, ok);
+    if (ok && g == 0) a.values[cell] = v;
+    if (__ballot(marker != 0.0f) != 0ull) {
+      const float v2 = forward(a.next_obs, cell, ok);
+      if (ok && g == 0 && marker != 0.0f) a.rewards[cell] += a.discount * v2;
+    }
+  }
+}
+
 template <int D, int H, int A, int ACT>
 static int launch_rollout(const RolloutDev& d, hipStream_t s) {
-  using S = RoShape<D, H, A>;
-  const size_t lds = S::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<D, H, A, ACT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { trl_set_error("rollout: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((rollout_kernel<D, H, A, ACT>), dim3(trl_ceil_div(d.N, 32)), dim3(RO_THREADS), lds, s, d);
+  hipLaunchKernelGGL((rollout_kernel<D, H, A, ACT>), dim3(trl_ceil_div(d.N, RO_ENVS)), dim3(RO_THREADS), 0, s, d);
   TRL_LAUNCH_CHECK();
+  if (d.store) {
+    ValueDev v{d.vf_params, d.obs, d.next_obs, d.values, d.rewards, d.rows, d.top, d.N, d.n_steps, d.discount};
+    const int64_t n_tiles = ((int64_t)d.n_steps * d.N + 15) / 16;
+    const int grid = (int)(n_tiles / 4 + 1 < 512 ? n_tiles / 4 + 1 : 512);
+    hipLaunchKernelGGL((value_pass_kernel<D, H, ACT>), dim3(grid), dim3(VP_THREADS), 0, s, v);
+    TRL_LAUNCH_CHECK();
+  }
   return TRL_OK;
 }
 

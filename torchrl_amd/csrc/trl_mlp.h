@@ -250,3 +250,29 @@ __device__ __forceinline__ f32x16 tile_load_N(const float* T, int m, int i, int 
   for (int r = 0; r < 16; ++r) v[r] = T[(32 * m + i) * TRL_TLD + rowmap(r, hi)];
   return v;
 }
+
+// ------------------------------------------------------------------------------------------------
+// 16x16x4 variant (v_mfma_f32_16x16x4_f32): a wave owns 16 features x 16 samples; lane (j = lane & 15,
+// g = lane >> 4).  A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], C/D reg r <-> row 4g + r.
+#define TL 17                                   // LDS staging row stride (16 samples + 1)
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// T-layout tile (MFMA C/D): reg r of lane (j, g) <-> feature 16*slice + 4g + r, sample j.
+// Staging rows are permuted inside a slice -- feature 4g + r sits in row 4r + g -- so that the two
+// lane groups of a 32-lane half write rows one apart (17 banks apart) instead of 4 rows apart
+// (4*17 = 68 = 4 banks apart, a 2-way conflict); srow() gives the row of feature f for the
+// lane-equals-feature reads, which stay conflict free because the stride is odd.
+__device__ __forceinline__ constexpr int srow(int f) { return ((f & 3) << 2) | (f >> 2); }
+__device__ __forceinline__ void store_T(float* S, int slice, const f32x4& t, int j, int g) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[(16 * slice + 4 * r + g) * TL + j] = t[r];
+}
+__device__ __forceinline__ f32x4 load_T(const float* S, int slice, int j, int g) {
+  f32x4 t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = S[(16 * slice + 4 * r + g) * TL + j];
+  return t;
+}
+
