@@ -241,7 +241,7 @@ def main():
                    "envs_per_gpu": N_PER_GPU, "rollout_steps": T, "batch_per_gpu": BATCH_PER_GPU,
                    "opt_epochs": OPT_EPOCHS, "exploration_noise": "device Philox4x32-10",
                    "parallelism": "env-sharded dp%d, RCCL grad all-reduce" % world},
-        "roofline": {"bound": "mfma", "kernel": "ppo_grad_kernel<17,64,6,tanh>", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "ppo_grad_wave_kernel<17,64,6,tanh>", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": None, "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
                      "launches_timed": len(grad_ms)},

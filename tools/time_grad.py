@@ -37,6 +37,13 @@ def main():
         ms = np.array([s.elapsed_time(e) for s, e in probes][4:])
         print("%s grad kernel rows_mb=%2d (B=%6d): mean %.1f us  min %.1f us  (n=%d)" % (
             os.environ.get("TRL_LIB", "default"), rows, rows * buf.env_nums, ms.mean() * 1e3, ms.min() * 1e3, len(ms)))
+        if "clk" in os.environ.get("TRL_LIB", ""):
+            names = ["prologue", "L1+st", "L2+tanh", "head/loss/dW3/dH2", "dz2st+dH1+dz1st", "dW2", "dW1", "images", "fold"]
+            part = eng.partial.cpu().numpy()
+            half = part.shape[0] // 2
+            for net, sl in (("pf", slice(0, half)), ("vf", slice(half, None))):
+                c = part[sl, eng.p_stride - 16: eng.p_stride - 7].mean(axis=0)
+                print("   %s wave-0 cycles: " % net + "  ".join("%s %.0f" % (n, x) for n, x in zip(names, c)) + "  | total %.0f" % c.sum())
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@
 // log pi_old is read from the rollout (`old_logp`, written by the collector
 // kernel with the epoch-start parameters) instead of re-running target_pf on
 // every minibatch (ppo.py:54-56) -- identical values, SURVEY.md section 8(d).
+#include <cstdlib>
 #include "trl_common.h"
 #include "trl_mlp.h"
 
@@ -462,6 +463,467 @@ __global__ __launch_bounds__(PPO_THREADS, 3) void ppo_grad_kernel(PpoDev a) {
   else                        ppo_net_pass<D, H, A, ACT, false>(a, lds, blockIdx.x - half, half);
 }
 
+// ================================================================ design C: one wave = one tile
+// Every wave walks whole 16-sample tiles on its own: all four 16-feature slices of a layer are
+// independent accumulator chains in one instruction stream (the matrix pipe always has an MFMA that
+// does not wait on the previous one), layer outputs chain as the next layer's B operand in
+// registers, and the only LDS traffic is (a) the shared read-only W2 / W2^T operand copies and
+// (b) the wave-private transposes that put the sample index on the K axis for the weight-gradient
+// GEMMs.  No inter-wave synchronisation inside the tile loop.
+//   per tile (policy):  L1 20 + L2 64 + head 16 + dH2 16 + dH1 64 + dW3 16 + dW2 64 + dW1 16 = 276 MFMA
+//   per tile (value):   L1 20 + L2 64 +                      dH1 64 +          dW2 64 + dW1 16 = 228 MFMA
+// (bias gradients, the 17th input column of dW1 and the 1-wide value head are per-lane FMAs).
+#define WV_WAVES 4
+// development aid (tools/time_grad.py): per-phase cycle totals of every wave 0 into the spare tail of `partial`
+#ifdef TRL_EXP_CLK
+#define WCLK_DECL long long clk_prev = clock64(); float clk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WCLK(ph) { const long long c_ = clock64(); clk_acc[ph] += (float)(c_ - clk_prev); clk_prev = c_; }
+#else
+#define WCLK_DECL
+#define WCLK(ph)
+#endif
+#define WV_THREADS (64 * WV_WAVES)
+#define LDT 20                                   // staging row stride: 16 samples + pad, rows 16-B aligned
+#define LDW 68                                   // W2 operand copies: 64 + 4, ds_read_b128 rows
+
+template <int D, int H, int A> struct WvShape {
+  static_assert(H == 64 && D == 17 && A <= 8, "instantiated for D == 17, H == 64, A <= 8");
+  // shared: W2 (row-major) | W2^T | b1 | b2 ; per wave: H1^T | H2^T (later dZ1^T) | dZ2^T | dout^T[16]
+  static constexpr int O_W2F = 0, O_W2B = H * LDW, O_B1 = 2 * H * LDW, O_B2 = O_B1 + H, O_SCR = O_B2 + H;
+  static constexpr int O_H1 = 0, O_H2 = H * LDT, O_DZ2 = 2 * H * LDT, O_DO = 3 * H * LDT, WSCR = O_DO + 16 * LDT;
+  static constexpr int P_STRIDE = PpoShape<D, H, A>::P_STRIDE;
+  static constexpr int MAIN = O_SCR + WV_WAVES * WSCR, FOLD = WV_WAVES * P_STRIDE;
+  static constexpr int LDS_FLOATS = MAIN > FOLD ? MAIN : FOLD;
+};
+
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// sum over the 16 lanes of a DPP row (same lane group g, all sample lanes j) with row rotations on the
+// VALU (no LDS round trips); every lane ends with the total, callers read lane j == 0
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));  // row_ror:1
+  return v;
+}
+
+template <int D, int H, int A, int ACT, bool IS_PF>
+__device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
+  constexpr int O = IS_PF ? A : 1;
+  using S = WvShape<D, H, A>;
+  using F = MlpFlat<D, H, O>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4, i = j;
+  const float* gp = IS_PF ? a.pf_params : a.vf_params;
+  WCLK_DECL
+  float* W2F = lds + S::O_W2F;
+  float* W2B = lds + S::O_W2B;
+  float* scr = lds + S::O_SCR + wave * S::WSCR;
+  float* H1S = scr + S::O_H1;
+  float* H2S = scr + S::O_H2;                       // H2^T until dW3 is done, then dZ1^T
+  float* DZ2S = scr + S::O_DZ2;
+  float* DOS = scr + S::O_DO;
+
+  // ---- one-time setup ----
+  {
+    constexpr int NV = H * H / (4 * WV_THREADS);    // all loads in flight before the first LDS store
+    f32x4 wv[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) wv[t] = *reinterpret_cast<const f32x4*>(gp + F::W2 + 4 * (tid + WV_THREADS * t));
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const int e = 4 * (tid + WV_THREADS * t), r = e / H, c = e - r * H;
+      *reinterpret_cast<f32x4*>(W2F + r * LDW + c) = wv[t];      // forward A operand:  W2[own row][k]
+#pragma unroll
+      for (int x = 0; x < 4; ++x) W2B[(c + x) * LDW + r] = wv[t][x];   // backward A operand: W2[k][own column]
+    }
+  }
+  for (int e = tid; e < H; e += WV_THREADS) { lds[S::O_B1 + e] = gp[F::B1 + e]; lds[S::O_B2 + e] = gp[F::B2 + e]; }
+  for (int e = lane; e < 16 * LDT; e += 64) DOS[e] = 0.0f;       // dout rows >= O stay zero
+  // register-resident A operands, lane (i, g): k index of MFMA step (slice sl, r) is feature 16 sl + 4 g + r
+  float w1[4][5], w3h[4][4], w3t[4][4];
+#pragma unroll
+  for (int so = 0; so < 4; ++so) {
+    const int row = 16 * so + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w1[so][r] = gp[F::W1 + row * D + 4 * g + r];
+    w1[so][4] = (g == 0) ? gp[F::W1 + row * D + 16] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (IS_PF) {
+        w3h[so][r] = (i < O) ? gp[F::W3 + (i < O ? i : 0) * H + 16 * so + 4 * g + r] : 0.0f;     // head: W3[o = i][k]
+        const int o = 4 * g + r;
+        w3t[so][r] = (o < O) ? gp[F::W3 + (o < O ? o : 0) * H + row] : 0.0f;                     // dH2: W3[k = o][own f]
+      } else {
+        w3h[so][r] = gp[F::W3 + 16 * so + 4 * g + r];                                            // per-lane head weights
+        w3t[so][r] = 0.0f;
+      }
+    }
+  }
+  // per-lane constants of the lane's 4 outputs o = 4g + r (policy)
+  float lsv[4], ivv[4], b3v[4], lspass[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * g + r;
+    const float raw = (IS_PF && o < O) ? gp[F::LS + (o < O ? o : 0)] : 0.0f;
+    lsv[r] = fminf(fmaxf(raw, -20.0f), 2.0f);                   // continuous_policy.py:8-9,185
+    ivv[r] = __expf(-2.0f * lsv[r]);
+    lspass[r] = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;   // clamp passes gradient inside [-20, 2]
+    b3v[r] = (o < O) ? gp[F::B3 + (o < O ? o : 0)] : 0.0f;
+  }
+  const float vb3 = IS_PF ? 0.0f : gp[F::B3];
+  __syncthreads();
+
+  // advantage normalisation constants (ppo.py:141-147): mean, unbiased std
+  const double ng = a.n_global;
+  const double adv_mean = a.adv_raw[0] / ng;
+  const double adv_var = (a.adv_raw[1] - a.adv_raw[0] * a.adv_raw[0] / ng) / (ng - 1.0);
+  const float adv_mu = (float)adv_mean;
+  const float adv_rstd = 1.0f / ((float)sqrt(fmax(adv_var, 0.0)) + 1e-5f);
+  const float inv_b = (float)(1.0 / ng);
+
+  // ---- gradient accumulators ----
+  f32x4 gW2[4][4], gW1[4], gW3[4];                  // MFMA tiles: dW2[f2 slice][f1 slice], dW1[f1 slice][k < 16], dW3
+  float gb1[4][4], gb2[4][4], gW1c[4][4];           // per-lane (own sample) partials: db1, db2, dW1[:, 16]
+  float db3[4], dls[4], stv[7];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    gW1[x] = gW3[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db3[x] = dls[x] = 0.0f;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) { gW2[x][y] = f32x4{0.f, 0.f, 0.f, 0.f}; gb1[x][y] = gb2[x][y] = gW1c[x][y] = 0.0f; }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) stv[k] = (k >= 2 && k <= 5) ? -INFINITY : 0.0f;
+
+  const int B = a.rows_mb * a.N;
+  const int n_tiles = (B + 15) / 16;
+  const bool contig = (a.N % 16) == 0;
+  const int tile_stride = n_wg_net * WV_WAVES;
+
+  // Inputs are fetched ONE TILE AHEAD as raw values (masks are applied when they are consumed, so no wait
+  // sits next to the loads) and the minibatch row index TWO tiles ahead (the dependent load behind it is
+  // then off the critical path): x operand (5), X^T for dW1 (4), loss inputs (6 / 2).
+  auto row_of = [&](int smp, int& e) -> int { const int sm = smp < B ? smp : 0; const int r = sm / a.N; e = sm - r * a.N; return r; };
+  float xq[5], xtq[4], lq[6];
+  auto fetch_inputs = [&](int64_t p, int s0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xq[r] = a.obs[p * D + 4 * g + r];
+    xq[4] = a.obs[p * D + 16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                   // X[sample 4g + q][feature j]: B operand of the dW1 GEMM
+      const int sj = 4 * g + q;
+      int64_t pr;
+      if (contig) pr = p - j + sj;                  // N % 16 == 0: the tile is one contiguous run of cells
+      else        pr = __shfl(p, sj, 64);
+      xtq[q] = a.obs[(s0 + sj < B ? pr : 0) * D + i];
+    }
+    if constexpr (IS_PF) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lq[r] = a.acts[p * O + (4 * g + r < O ? 4 * g + r : 0)];
+      lq[4] = a.advs[p]; lq[5] = a.old_logp[p];
+    } else {
+      lq[0] = lq[1] = lq[2] = lq[3] = 0.0f;
+      lq[4] = a.rets[p]; lq[5] = a.clipped_value_loss ? a.old_values[p] : 0.0f;
+    }
+  };
+  int tile = wg_in_net * WV_WAVES + wave;
+  // pipeline registers: (row index, env) of the tile after next
+  int e_nn = 0;
+  int64_t ridx_nn = 0;
+  auto fetch_row = [&](int t) {
+    const int r = row_of(t * 16 + j, e_nn);
+    ridx_nn = a.row_idx ? a.row_idx[r] : (int64_t)r;
+  };
+  {
+    fetch_row(tile);
+    const int64_t p0 = (tile * 16 + j < B) ? ridx_nn * a.N + e_nn : 0;
+    fetch_inputs(p0, tile * 16);
+    fetch_row(tile + tile_stride);
+  }
+  WCLK(0)
+  for (; tile < n_tiles; tile += tile_stride) {
+    const int s = tile * 16 + j;
+    const bool valid = s < B;
+    float xb[5], xt[4], lin[6];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) xb[r] = valid ? xq[r] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xt[q] = (tile * 16 + 4 * g + q < B) ? xtq[q] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) lin[q] = lq[q];
+    const float x16 = xb[4];
+
+    // ---- forward layer 1: 4 independent slices ----
+    f32x4 h1[4], h2[4];
+#pragma unroll
+    for (int so = 0; so < 4; ++so) h1[so] = lds4(lds + S::O_B1 + 16 * so + 4 * g);
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+      for (int so = 0; so < 4; ++so) h1[so] = mfma16(w1[so][q], xb[q], h1[so]);
+#pragma unroll
+    for (int so = 0; so < 4; ++so)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h1[so][r] = act_fn<ACT>(h1[so][r]);
+        H1S[(16 * so + 4 * g + r) * LDT + j] = h1[so][r];        // H1^T[f][s] for dW2
+      }
+    WCLK(1)
+    // ---- forward layer 2 ----
+    // slice-major: the activation of slice so runs on the VALU under the MFMAs of slice so + 1
+#pragma unroll
+    for (int so = 0; so < 4; ++so) {
+      f32x4 acc = lds4(lds + S::O_B2 + 16 * so + 4 * g);
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        const f32x4 w = lds4(W2F + (16 * so + i) * LDW + 16 * sl + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(w[r], h1[sl][r], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h2[so][r] = act_fn<ACT>(acc[r]);
+    }
+
+    // Next tile's loads are issued HERE, mid-tile: at the top of the loop every outstanding load is then
+    // half a tile old, and no wait next to the first MFMAs can stall on a load that was just issued.
+#ifndef TRL_EXP_NOFETCH
+    {
+      const int nt = tile + tile_stride;            // loads of tile t+1 (addresses were resolved a tile ago) ...
+      const int64_t pn = (nt * 16 + j < B) ? ridx_nn * a.N + e_nn : 0;
+      fetch_inputs(pn, nt * 16);
+      fetch_row(nt + tile_stride);                  // ... and the row index of tile t+2
+    }
+#endif
+    WCLK(2)
+    // ---- head, loss, d(loss)/d(out), dZ2 ----
+    f32x4 dz2[4];
+    if constexpr (IS_PF) {
+#pragma unroll
+      for (int so = 0; so < 4; ++so)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H2S[(16 * so + 4 * g + r) * LDT + j] = h2[so][r];            // H2^T[f][s] for dW3
+      // out^T[o][s]: two interleaved accumulation chains over the 64 features
+      f32x4 oa = f32x4{b3v[0], b3v[1], b3v[2], b3v[3]}, ob = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sl = 0; sl < 4; sl += 2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { oa = mfma16(w3h[sl][r], h2[sl][r], oa); ob = mfma16(w3h[sl + 1][r], h2[sl + 1][r], ob); }
+      // lane (j, g < 2) owns outputs o = 4g + r of sample j
+      float zc[4], lp = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        zc[r] = 0.0f;
+        if (4 * g + r < O) lp += gauss_logp_term(valid ? lin[r] : 0.0f, oa[r] + ob[r], ivv[r], lsv[r], a.tanh_action, zc[r]);
+      }
+      lp += __shfl_xor(lp, 16, 64);                                // outputs 0..3 (g = 0) + 4..7 (g = 1)
+      const float advn = valid ? (lin[4] - adv_mu) * adv_rstd : 0.0f;
+      const float ratio = __expf(lp - lin[5]);
+      const float s1 = ratio * advn;
+      const float s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
+      const float g_lp = (valid && g < 2 && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
+      float dout[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool own = valid && g < 2 && 4 * g + r < O;
+        dout[r] = own ? g_lp * zc[r] * ivv[r] : 0.0f;
+        db3[r] += dout[r];
+        dls[r] += own ? lspass[r] * (g_lp * (zc[r] * zc[r] * ivv[r] - 1.0f) - a.entropy_coeff * inv_b) : 0.0f;
+        if (g < 2) DOS[(4 * g + r) * LDT + j] = dout[r];           // dout^T[o][s] for dW3
+      }
+      if (valid && g == 0) {
+        stv[0] += lp; stv[1] = fmaf(lp, lp, stv[1]); stv[6] -= fminf(s1, s2);
+        stv[2] = fmaxf(stv[2], lp); stv[3] = fmaxf(stv[3], -lp);
+        stv[4] = fmaxf(stv[4], ratio); stv[5] = fmaxf(stv[5], -ratio);
+      }
+      // dW3[o][f] += sum_s dout[s][o] H2[s][f]   (K step q is sample 4g + q)
+      {
+        const f32x4 da = lds4(DOS + i * LDT + 4 * g);
+#pragma unroll
+        for (int so = 0; so < 4; ++so) {
+          const f32x4 hb = lds4(H2S + (16 * so + j) * LDT + 4 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gW3[so] = mfma16(da[q], hb[q], gW3[so]);
+        }
+      }
+      // dH2^T[f][s] = sum_o W3[o][f] dout[o][s];  dZ2 = dH2 * act'(H2)
+#pragma unroll
+      for (int so = 0; so < 4; ++so) dz2[so] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int so = 0; so < 4; ++so) dz2[so] = mfma16(w3t[so][r], dout[r], dz2[so]);
+    } else {
+      float v = 0.0f;
+#pragma unroll
+      for (int so = 0; so < 4; ++so)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v = fmaf(w3h[so][r], h2[so][r], v);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      v += vb3;
+      const float R = lin[4];
+      float dv, l;
+      if (a.clipped_value_loss) {                                  // ppo.py:104-111
+        const float vo = lin[5];
+        const float dc = v - vo;
+        const float vc = vo + fminf(fmaxf(dc, -a.clip_para), a.clip_para);
+        const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+        const float wa = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), wb = 1.0f - wa;
+        const float pass = (dc >= -a.clip_para && dc <= a.clip_para) ? 1.0f : 0.0f;
+        l = 0.5f * fmaxf(l1, l2);
+        dv = inv_b * (wa * (v - R) + wb * pass * (vc - R));
+      } else {                                                     // nn.MSELoss, a2c.py:43
+        l = (v - R) * (v - R);
+        dv = 2.0f * (v - R) * inv_b;
+      }
+      dv = valid ? dv : 0.0f;
+      if (valid && g == 0) { stv[6] += l; db3[0] += dv; }
+#pragma unroll
+      for (int so = 0; so < 4; ++so)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dz2[so][r] = dv * w3h[so][r];
+          gW3[so][r] = fmaf(dv, h2[so][r], gW3[so][r]);             // per-lane dW3[f] partial (own sample)
+        }
+    }
+#pragma unroll
+    for (int so = 0; so < 4; ++so)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dz2[so][r] *= act_grad<ACT>(h2[so][r]);
+        gb2[so][r] += dz2[so][r];
+        DZ2S[(16 * so + 4 * g + r) * LDT + j] = dz2[so][r];        // dZ2^T[f][s] for dW2
+      }
+
+    WCLK(3)
+    // ---- dH1^T (all slices) = W2^T dZ2^T ; dZ1 = dH1 * act'(H1) ----
+    f32x4 dz1[4];
+#pragma unroll
+    for (int so = 0; so < 4; ++so) dz1[so] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      f32x4 w[4];
+#pragma unroll
+      for (int so = 0; so < 4; ++so) w[so] = lds4(W2B + (16 * so + i) * LDW + 16 * sl + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int so = 0; so < 4; ++so) dz1[so] = mfma16(w[so][r], dz2[sl][r], dz1[so]);
+    }
+#pragma unroll
+    for (int so = 0; so < 4; ++so)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dz1[so][r] *= act_grad<ACT>(h1[so][r]);
+        gb1[so][r] += dz1[so][r];
+        gW1c[so][r] = fmaf(dz1[so][r], x16, gW1c[so][r]);
+        H2S[(16 * so + 4 * g + r) * LDT + j] = dz1[so][r];         // dZ1^T[f][s] for dW1 (H2^T is consumed)
+      }
+
+    WCLK(4)
+    // ---- dW2[f2][f1] += sum_s dZ2[s][f2] H1[s][f1]  (K step q is sample 4g + q) ----
+    {
+      f32x4 hb[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) hb[c] = lds4(H1S + (16 * c + j) * LDT + 4 * g);
+#pragma unroll
+      for (int so = 0; so < 4; ++so) {
+        const f32x4 za = lds4(DZ2S + (16 * so + i) * LDT + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) gW2[so][c] = mfma16(za[q], hb[c][q], gW2[so][c]);
+      }
+    }
+    WCLK(5)
+    // ---- dW1[f1][k < 16] += sum_s dZ1[s][f1] X[s][k] ----
+#pragma unroll
+    for (int so = 0; so < 4; ++so) {
+      const f32x4 za = lds4(H2S + (16 * so + i) * LDT + 4 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gW1[so] = mfma16(za[q], xt[q], gW1[so]);
+    }
+    WCLK(6)
+  }
+
+  // ---- epilogue: every wave writes its gradient image, then all threads add the 4 images in fixed order ----
+  __syncthreads();                                                 // staging / weight copies are dead from here
+  float* gimg = lds + wave * S::P_STRIDE;            // every parameter slot below is written exactly once
+  for (int e = F::P_PF + lane; e < S::P_STRIDE; e += 64) gimg[e] = 0.0f;   // padding (and logstd slots of the value net)
+#pragma unroll
+  for (int so = 0; so < 4; ++so)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * so + 4 * g + r;                           // output feature (row of W2 / W1)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gimg[F::W2 + f * H + 16 * c + j] = gW2[so][c][r];
+      gimg[F::W1 + f * D + j] = gW1[so][r];
+      const float c16 = row_sum16(gW1c[so][r]), s1 = row_sum16(gb1[so][r]), s2 = row_sum16(gb2[so][r]);
+      if (j == 0) { gimg[F::W1 + f * D + 16] = c16; gimg[F::B1 + f] = s1; gimg[F::B2 + f] = s2; }
+      if constexpr (IS_PF) {
+        const int o = 4 * g + r;                                   // gW3 rows are outputs
+        if (o < O) gimg[F::W3 + o * H + 16 * so + j] = gW3[so][r];
+      } else {
+        const float w3s = row_sum16(gW3[so][r]);
+        if (j == 0) gimg[F::W3 + f] = w3s;
+      }
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * g + r;
+    const float b3 = row_sum16(db3[r]), dl = row_sum16(dls[r]);
+    if (j == 0 && o < O) {
+      gimg[F::B3 + o] = b3;
+      if (IS_PF) gimg[F::LS + o] = dl;
+    }
+  }
+  WCLK(7)
+  __syncthreads();
+  const int wg = blockIdx.x;
+  for (int e = tid; e < S::P_STRIDE; e += WV_THREADS) {
+    float acc = lds[e];
+#pragma unroll
+    for (int w = 1; w < WV_WAVES; ++w) acc += lds[w * S::P_STRIDE + e];
+    a.partial[(size_t)wg * a.p_stride + e] = acc;
+  }
+  WCLK(8)
+#ifdef TRL_EXP_CLK
+  if (tid == 0) for (int ph = 0; ph < 9; ++ph) a.partial[(size_t)wg * a.p_stride + S::P_STRIDE - 16 + ph] = clk_acc[ph];
+#endif
+  // ---- scalar statistics ----
+  __syncthreads();
+  double* sred = reinterpret_cast<double*>(lds);
+  {
+    const bool own = g == 0;
+    const double v0 = wave_sum(own ? (double)stv[0] : 0.0), v1 = wave_sum(own ? (double)stv[1] : 0.0),
+                 v6 = wave_sum(own ? (double)stv[6] : 0.0);
+    const float v2 = wave_max(own ? stv[2] : -INFINITY), v3 = wave_max(own ? stv[3] : -INFINITY),
+                v4 = wave_max(own ? stv[4] : -INFINITY), v5 = wave_max(own ? stv[5] : -INFINITY);
+    if (lane == 0) {
+      double* p = sred + wave * 8;
+      p[0] = v0; p[1] = v1; p[2] = v2; p[3] = v3; p[4] = v4; p[5] = v5; p[6] = v6; p[7] = 0.0;
+    }
+  }
+  __syncthreads();
+  if (tid < 8) {
+    double r = sred[tid];
+    for (int w = 1; w < WV_WAVES; ++w) {
+      const double o = sred[w * 8 + tid];
+      r = (tid >= 2 && tid <= 5) ? fmax(r, o) : r + o;
+    }
+    a.scal_partial[(size_t)wg * 8 + tid] = r;
+  }
+}
+
+template <int D, int H, int A, int ACT>
+__global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int half = a.n_wg >> 1;
+  if ((int)blockIdx.x < half) ppo_wave_pass<D, H, A, ACT, true>(a, lds, blockIdx.x, half);
+  else                        ppo_wave_pass<D, H, A, ACT, false>(a, lds, blockIdx.x - half, half);
+}
+
 // ---------------------------------------------------------------- partial reduce
 // grads[p] = sum_w partial[w][p] in fixed order; info[] from the scalar partials:
 //  0 policy surrogate sum (-min(s1,s2))   1 sum logp   2 sum logp^2   3 max logp   4 -min logp
@@ -618,8 +1080,28 @@ extern "C" int trl_ppo_partial_stride(int D, int H, int A) {
   return TRL_EUNSUPPORTED;
 }
 
+// TRL_PPO_DESIGN=a selects the older group-of-4-waves kernel (kept for A/B measurements)
+static bool ppo_use_wave_kernel() {
+  static const int v = [] { const char* e = getenv("TRL_PPO_DESIGN"); return (e && e[0] == 'a') ? 0 : 1; }();
+  return v != 0;
+}
+
 template <int D, int H, int A, int ACT>
 static int launch_ppo(const PpoDev& d, hipStream_t s) {
+  if (ppo_use_wave_kernel()) {
+    using S = WvShape<D, H, A>;
+    const size_t lds = S::LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wave_kernel<D, H, A, ACT>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { trl_set_error("ppo_grad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((ppo_grad_wave_kernel<D, H, A, ACT>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+  }
   using S = PpoShape<D, H, A>;
   const size_t lds = S::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
