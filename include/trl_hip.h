@@ -194,6 +194,16 @@ typedef struct trl_adam_t {
   float* norms_out;           /* (n_groups) pre-clip global norms */
 } trl_adam_t;
 int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
+/* Single-process fast path: trl_ppo_reduce_f32 + trl_clip_adam_f32 in one launch (the block that
+ * finishes the reduction last takes the optimiser step; fixed summation orders, deterministic).
+ * adam->grads must equal `grads`, the two groups must be [policy | value]; logstd statistics are read
+ * from adam->params.  workspace: trl_ppo_reduce_adam_workspace(D, H, A) floats, zeroed once by the
+ * caller and then owned by this entry point.  Not usable when gradients are all-reduced between
+ * the two steps (world size > 1): call the two separate entry points there. */
+int trl_ppo_reduce_adam_workspace(int D, int H, int A);
+int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg,
+                            int D, int H, int A, float* grads, double* info,
+                            const trl_adam_t* adam, float* workspace, void* stream);
 
 /* --- K10 (generic): dense layers of any shape on fp32 MFMA -----------------
  * replaces nn.Linear + activation forward/backward (torchrl/networks/base.py:30-44,

@@ -70,7 +70,7 @@ class PPO(A2C):
         self.process_epoch_samples()
         atu.update_linear_schedule(self.pf_optimizer, self.current_epoch, self.num_epochs, self.plr)
         atu.update_linear_schedule(self.vf_optimizer, self.current_epoch, self.num_epochs, self.vlr)
-        atu.copy_model_params_from_to(self.pf, self.target_pf)
+        self.engine().sync_target_pf()                                 # target_pf <- pf (utils.py:23-26), one D2D copy
         self._fill_old_logp()
         buf = self.replay_buffer
         passes = [buf.epoch_row_indices(self.batch_size, self.shuffle) for _ in range(self.opt_epochs)]
@@ -126,6 +126,11 @@ class _FusedPPO:
         self.v = torch.zeros_like(self.flat)
         self.grads = torch.zeros_like(self.flat)
         self.step_count = 0
+        # target_pf mirrors the policy block of `flat`: its parameters become views of one buffer too
+        tgt = getattr(algo, "target_pf", None)
+        self.target_flat = None
+        if tgt is not None:
+            self.target_flat = flatten_into(tgt._mlp2_param_list() + [tgt.logstd])
         self._alias_optimizer_state(algo.pf_optimizer, pf_list, 0)
         self._alias_optimizer_state(algo.vf_optimizer, vf_list, self.P_pf)
         self.p_stride = _C.ppo_partial_stride(self.D, self.H, self.A)
@@ -133,6 +138,8 @@ class _FusedPPO:
         self.max_wg = 2 * max(1, self.n_cu // 2)
         self.partial = torch.zeros(self.max_wg, self.p_stride, device=self.dev)
         self.scal = torch.zeros(self.max_wg, 8, dtype=torch.float64, device=self.dev)
+        n_ws = _C.lib().trl_ppo_reduce_adam_workspace(self.D, self.H, self.A)
+        self.red_ws = torch.zeros(n_ws, device=self.dev)              # ticket + partial norms of the fused reduce/Adam
 
     def _alias_optimizer_state(self, opt, plist, offset):
         self._opt_steps = getattr(self, "_opt_steps", [])
@@ -143,6 +150,12 @@ class _FusedPPO:
                             "exp_avg_sq": self.v[offset:offset + n].view(p.shape)}
             self._opt_steps.append(step)
             offset += n
+
+    def sync_target_pf(self):
+        if self.target_flat is not None:
+            self.target_flat.copy_(self.flat[:self.P_pf])
+        else:
+            atu.copy_model_params_from_to(self.algo.pf, self.algo.target_pf)
 
     def _n_wg(self, n_samples):
         tiles = (n_samples + 15) // 16
@@ -159,11 +172,12 @@ class _FusedPPO:
         n_global = float(n_local * world)
         idx_dev = torch.from_numpy(np.ascontiguousarray(row_idx)).to(dev)
         rows_total = t["advs"].shape[0]
-        raw = torch.zeros(K, 4, dtype=torch.float64, device=dev)
+        # one statistics buffer (one memset, one D2H at the end): raw (K,4) f64 | info (K,16) f64 | norms (K,2) f32
+        stats = torch.zeros(21 * K, dtype=torch.float64, device=dev)
+        raw, info = stats[:4 * K].view(K, 4), stats[4 * K:20 * K].view(K, 16)
+        norms = stats[20 * K:].view(torch.float32).view(K, 2)
         _C.adv_stats(t["advs"].reshape(rows_total, N), idx_dev, raw)
         dist.reduce_adv_raw_(raw)
-        info = torch.zeros(K, 16, dtype=torch.float64, device=dev)
-        norms = torch.zeros(K, 2, device=dev)
         n_wg = self._n_wg(n_local)
 
         g = _C.PpoBatchArgs()
@@ -189,6 +203,7 @@ class _FusedPPO:
         lib, stream = _C.lib(), _C.stream_ptr(dev)
         import ctypes as C
         probe = getattr(self, "probe", None)                           # bench.py: HIP events around the grad kernel
+        fused = not dist.collectives_active()
         for k in range(K):
             g.row_idx = idx_base + 8 * rows_mb * k
             g.adv_raw = raw_base + 32 * k
@@ -199,18 +214,26 @@ class _FusedPPO:
             if probe is not None:
                 ev[1].record()
                 probe.append(ev)
-            _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, self.D, self.H,
-                                            self.A, self.flat.data_ptr(), self.grads.data_ptr(),
-                                            info_base + 128 * k, stream), "trl_ppo_reduce_f32")
-            dist.all_reduce_sum_(self.grads)                           # C1 (no-op at world size 1)
             self.step_count += 1
             a.step_count = self.step_count
             a.norms_out = norm_base + 8 * k
+            if fused:                                                  # one process: reduce + clip + Adam in one launch
+                _C.check(lib.trl_ppo_reduce_adam_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, self.D,
+                                                     self.H, self.A, self.grads.data_ptr(), info_base + 128 * k,
+                                                     C.byref(a), self.red_ws.data_ptr(), stream),
+                         "trl_ppo_reduce_adam_f32")
+                continue
+            _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, self.D, self.H,
+                                            self.A, self.flat.data_ptr(), self.grads.data_ptr(),
+                                            info_base + 128 * k, stream), "trl_ppo_reduce_f32")
+            dist.all_reduce_sum_(self.grads)                           # C1: gradient SUM over ranks
             _C.check(lib.trl_clip_adam_f32(C.byref(a), stream), "trl_clip_adam_f32")
         for s in self._opt_steps:
             s.fill_(float(self.step_count))
         dist.reduce_info_(info)
-        return self._infos(raw.cpu().numpy(), info.cpu().numpy(), norms.cpu().numpy(), n_global)
+        host = stats.cpu()                                             # the only host sync of the update
+        return self._infos(host[:4 * K].view(K, 4).numpy(), host[4 * K:20 * K].view(K, 16).numpy(),
+                           host[20 * K:].view(torch.float32).view(K, 2).numpy(), n_global)
 
     def _infos(self, raw, info, norms, n):
         out = []

@@ -98,21 +98,33 @@ class VecCollector(BaseCollector):
         self.noise_mode = noise_mode
         self.global_step = 0
         dev = self.env.device
-        self._epoch_reward = torch.zeros(1, dtype=torch.float64, device=dev)
-        self._ep_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        # epoch reward (f64) and finished-episode count (i32) share one 16-byte header: one memset, one D2H
+        self._hdr = torch.zeros(2, dtype=torch.float64, device=dev)
+        self._epoch_reward = self._hdr[:1]
+        self._ep_count = self._hdr[1:].view(torch.int32)[:1]
         self._ep_log = torch.zeros(self.EP_LOG_CAP, 3, device=dev)
         self._mask = torch.zeros(self.env.env_nums, dtype=torch.uint8, device=dev)
         self._noise_seed = 0xC011
 
     # ---- pieces shared with the on-policy subclass ----
-    def _finished_episodes(self):
+    def _read_header(self):
+        """(epoch reward, finished-episode count) with a single host sync."""
+        h = self._hdr.cpu()
+        return float(h[0]), int(h[1:].view(torch.int32)[0])
+
+    def _clear_header(self):
+        self._hdr.zero_()
+
+    def _finished_episodes(self, cnt=None):
         """(step, env, return) rows of episodes that ended since the log was cleared, in the
         reference's list order (step-major, then env index)."""
-        cnt = min(int(self._ep_count.item()), self.EP_LOG_CAP)
+        if cnt is None:
+            cnt = int(self._ep_count.item())
+        cnt = min(cnt, self.EP_LOG_CAP)
+        if not cnt:
+            return np.zeros((0, 3), dtype=np.float32)
         log = self._ep_log[:cnt].cpu().numpy()
-        if cnt:
-            log = log[np.lexsort((log[:, 1], log[:, 0]))]
-        return log
+        return log[np.lexsort((log[:, 1], log[:, 0]))]
 
     def _policy_action(self, env, deterministic):
         from .. import ops
@@ -195,8 +207,7 @@ class VecCollector(BaseCollector):
     def rollout(self, n_steps):
         """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""
         self.env.train()
-        self._epoch_reward.zero_()
-        self._ep_count.zero_()
+        self._clear_header()
         for _ in range(n_steps):
             self._step(self.env, True)
         self.current_ob = self.env.cur_obs
@@ -219,8 +230,7 @@ class VecCollector(BaseCollector):
         rews, lens = [], []
         for _ in range(self.eval_episodes):
             env.reset()
-            self._epoch_reward.zero_()
-            self._ep_count.zero_()
+            self._clear_header()
             step0 = self.global_step
             for _ in range(env.horizon):
                 self._step(env, False, deterministic=True, max_frames=2 ** 31 - 1)

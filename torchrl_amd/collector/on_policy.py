@@ -87,8 +87,7 @@ class VecOnPolicyCollector(VecCollector):
         a.epoch_reward, a.ep_count, a.ep_log = (self._epoch_reward.data_ptr(), self._ep_count.data_ptr(),
                                                 self._ep_log.data_ptr())
         a.ep_cap, a.step0 = self.EP_LOG_CAP, 0
-        self._epoch_reward.zero_()
-        self._ep_count.zero_()
+        self._clear_header()
         _C.rollout(a, env.device)
         if store:
             buf._advance(n_steps)
@@ -110,9 +109,9 @@ class VecOnPolicyCollector(VecCollector):
 
     def train_one_epoch(self):
         self.rollout(self.sample_epoch_frames)
-        log = self._finished_episodes()                                    # one small D2H per epoch
+        self.train_epoch_reward, cnt = self._read_header()                # one 16-byte D2H per epoch ...
+        log = self._finished_episodes(cnt)                                 # ... plus the episode log when any ended
         self.train_rews = [np.float32(r) for r in log[:, 2]]
-        self.train_epoch_reward = float(self._epoch_reward.item())
         return {'train_rewards': self.train_rews, 'train_epoch_reward': self.train_epoch_reward}
 
     def take_actions(self):

@@ -929,11 +929,12 @@ __global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) 
 //  0 policy surrogate sum (-min(s1,s2))   1 sum logp   2 sum logp^2   3 max logp   4 -min logp
 //  5 max ratio   6 -min ratio   7 value-loss sum
 #define RED_CHUNK 64
-__global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial,
-                                                         const double* __restrict__ scal, int n_wg,
-                                                         int p_stride, int p_pf, int p_vf,
-                                                         const float* __restrict__ logstd, int n_act,
-                                                         float* __restrict__ grads, double* __restrict__ info) {
+// returns (wave 0 lanes) this block's reduced gradient value, 0 outside the parameter range
+__device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ partial,
+                                                  const double* __restrict__ scal, int n_wg,
+                                                  int p_stride, int p_pf, int p_vf,
+                                                  const float* __restrict__ logstd, int n_act,
+                                                  float* __restrict__ grads, double* __restrict__ info) {
   // block = 64 consecutive parameters x 4 waves; wave w folds partials w, w+4, ... with 4
   // independent accumulators (fixed order => deterministic), then the 4 waves fold through LDS.
   __shared__ float s_acc[4][RED_CHUNK];
@@ -942,20 +943,33 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * RED_CHUNK + lane;
   const int pn = net == 0 ? p_pf : p_vf;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  // 16 independent loads in flight per lane and round: the fold is latency-, not bandwidth-bound
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
   if (p < pn) {
     const float* src = partial + (size_t)(net * half) * p_stride + p;
     int w = wave;
-    for (; w + 12 < half; w += 16) {
-      a0 += src[(size_t)w * p_stride];        a1 += src[(size_t)(w + 4) * p_stride];
-      a2 += src[(size_t)(w + 8) * p_stride];  a3 += src[(size_t)(w + 12) * p_stride];
+    for (; w + 60 < half; w += 64) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = src[(size_t)(w + 4 * k) * p_stride];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] += v[k];
     }
-    for (; w < half; w += 4) a0 += src[(size_t)w * p_stride];
+    for (; w < half; w += 4) acc[0] += src[(size_t)w * p_stride];
   }
-  s_acc[wave][lane] = (a0 + a1) + (a2 + a3);
+#pragma unroll
+  for (int st = 8; st > 0; st >>= 1)
+#pragma unroll
+    for (int k = 0; k < st; ++k) acc[k] += acc[k + st];
+  s_acc[wave][lane] = acc[0];
   __syncthreads();
-  if (wave == 0 && p < pn)
-    grads[(net == 0 ? 0 : p_pf) + p] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+  float gval = 0.0f;
+  if (wave == 0 && p < pn) {
+    gval = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+    grads[(net == 0 ? 0 : p_pf) + p] = gval;
+  }
   // scalar statistics: one wave per network, lanes stride over the workgroup partials (independent
   // loads, shuffle reduction) -- a serial 128-deep dependent-load chain here cost 50 us
   if (blockIdx.x == 0 && blockIdx.y == 0 && wave < 2) {
@@ -991,6 +1005,15 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict
       }
     }
   }
+  return gval;
+}
+
+__global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial,
+                                                         const double* __restrict__ scal, int n_wg,
+                                                         int p_stride, int p_pf, int p_vf,
+                                                         const float* __restrict__ logstd, int n_act,
+                                                         float* __restrict__ grads, double* __restrict__ info) {
+  ppo_reduce_block(partial, scal, n_wg, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
 }
 
 // ---------------------------------------------------------------- K11 clip + Adam
@@ -1011,9 +1034,12 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
     if (!need_norm) { if (lane == 0) s_part[g][wave] = 0.0f; continue; }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int e = a.off[g] + tid;
-    for (; e + 768 < a.off[g + 1]; e += 1024) {
-      const float x0 = a.grads[e], x1 = a.grads[e + 256], x2 = a.grads[e + 512], x3 = a.grads[e + 768];
-      s0 = fmaf(x0, x0, s0); s1 = fmaf(x1, x1, s1); s2 = fmaf(x2, x2, s2); s3 = fmaf(x3, x3, s3);
+    for (; e + 7 * 256 < a.off[g + 1]; e += 8 * 256) {         // 8 loads in flight per lane and round
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = a.grads[e + 256 * k];
+      s0 = fmaf(x[0], x[0], s0); s1 = fmaf(x[1], x[1], s1); s2 = fmaf(x[2], x[2], s2); s3 = fmaf(x[3], x[3], s3);
+      s0 = fmaf(x[4], x[4], s0); s1 = fmaf(x[5], x[5], s1); s2 = fmaf(x[6], x[6], s2); s3 = fmaf(x[7], x[7], s3);
     }
     for (; e < a.off[g + 1]; e += 256) { const float x = a.grads[e]; s0 = fmaf(x, x, s0); }
     float ss = wave_sum((s0 + s1) + (s2 + s3)) * a.grad_scale * a.grad_scale;
@@ -1036,6 +1062,77 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
   a.m[e] = m; a.v[e] = v;
   const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
   a.params[e] -= (a.lr[g] / a.bc1) * (m / denom);
+}
+
+// Adam update of element e with the clip coefficient of its group
+__device__ __forceinline__ void adam_element(const AdamDev& a, int e, float gr) {
+  const float m = a.beta1 * a.m[e] + (1.0f - a.beta1) * gr;
+  const float v = a.beta2 * a.v[e] + (1.0f - a.beta2) * gr * gr;
+  a.m[e] = m; a.v[e] = v;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  int g = 0;
+  while (e >= a.off[g + 1]) ++g;
+  a.params[e] -= (a.lr[g] / a.bc1) * (m / denom);
+}
+
+// Single-GPU path: partial reduce + clip_grad_norm_ + Adam in ONE launch.  Every block folds its 64
+// parameters and publishes their sum of squares, then all blocks of the (small, always co-resident:
+// 2 x 90 blocks on 256 CUs) grid rendezvous on a ticket counter; after the rendezvous every block
+// derives the two group norms from the published partials in the same fixed order (deterministic,
+// identical in all blocks) and takes the Adam step for its own 64 parameters straight from registers.
+// ws: [0] ticket (returns to 0), [1] generation, [16..] partials.
+__global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const float* __restrict__ partial,
+                                                              const double* __restrict__ scal, int n_wg,
+                                                              int p_stride, int p_pf, int p_vf,
+                                                              const float* __restrict__ logstd, int n_act,
+                                                              float* __restrict__ grads, double* __restrict__ info,
+                                                              AdamDev a, float* __restrict__ ws) {
+  __shared__ float s_coef[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned* ticket = reinterpret_cast<unsigned*>(ws);
+  unsigned* gen = ticket + 1;
+  float* ss_part = ws + 16;                                    // [2 nets][nb]
+  const int nb = gridDim.x;
+  unsigned g0 = 0;
+  if (tid == 0) g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float gval = ppo_reduce_block(partial, scal, n_wg, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
+  if (wave == 0) {
+    const float ss = wave_sum(gval * gval);
+    if (lane == 0) {
+      // Everything exchanged here travels through agent-scope atomics (they bypass the non-coherent
+      // cache levels), so ordering only needs the store to be acknowledged before the ticket is drawn --
+      // no release/acquire fences: those write back / invalidate whole caches and cost ~10 us here.
+      __hip_atomic_store(ss_part + blockIdx.y * nb + blockIdx.x, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (unsigned)(2 * nb - 1)) {                       // last arrival opens the gate
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
+  __syncthreads();
+  // ---- group norms (pf, vf): fixed summation order, same in every block ----
+  if (wave < 2) {
+    float acc = 0.0f;
+    for (int b = lane; b < nb; b += 64)
+      acc += __hip_atomic_load(ss_part + wave * nb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc = wave_sum(acc) * a.grad_scale * a.grad_scale;
+    if (lane == 0) {
+      const float norm = sqrtf(acc);
+      s_coef[wave] = (a.max_norm > 0.0f) ? fminf(a.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+      if (a.norms_out && blockIdx.x == 0 && blockIdx.y == 0) a.norms_out[wave] = norm;
+    }
+  }
+  __syncthreads();
+  const int net = blockIdx.y;
+  const int p = blockIdx.x * RED_CHUNK + lane;
+  if (wave == 0 && p < (net == 0 ? p_pf : p_vf))
+    adam_element(a, (net == 0 ? 0 : p_pf) + p, gval * a.grad_scale * s_coef[net]);
 }
 
 // ---------------------------------------------------------------- MLP inference
@@ -1155,12 +1252,11 @@ extern "C" int trl_ppo_reduce_f32(const float* partial, const double* scal_parti
   return TRL_OK;
 }
 
-extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {
+static int fill_adam(const trl_adam_t* p, AdamDev& d) {
   if (!p) { trl_set_error("clip_adam: null descriptor"); return TRL_EINVAL; }
   TRL_REQUIRE(p->params && p->grads && p->exp_avg && p->exp_avg_sq, "null pointer");
   TRL_REQUIRE(p->n_groups >= 1 && p->n_groups <= 4, "n_groups must be 1..4");
   TRL_REQUIRE(p->step_count >= 1, "step_count starts at 1");
-  AdamDev d;
   d.params = p->params; d.grads = p->grads; d.m = p->exp_avg; d.v = p->exp_avg_sq;
   d.n_groups = p->n_groups; d.off[0] = 0;
   for (int g = 0; g < p->n_groups; ++g) {
@@ -1174,6 +1270,40 @@ extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {
   d.bc1 = (float)(1.0 - pow((double)p->beta1, (double)p->step_count));
   d.bc2_sqrt = (float)sqrt(1.0 - pow((double)p->beta2, (double)p->step_count));
   d.norms_out = p->norms_out;
+  return TRL_OK;
+}
+
+extern "C" int trl_ppo_reduce_adam_workspace(int D, int H, int A) {
+  const int ps = trl_ppo_partial_stride(D, H, A);
+  if (ps < 0) return ps;
+  return 16 + 2 * trl_ceil_div(ps, RED_CHUNK);
+}
+
+extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg, int D, int H,
+                                       int A, float* grads, double* info, const trl_adam_t* adam,
+                                       float* workspace, void* stream) {
+  TRL_REQUIRE(partial && scal_partial && grads && info && workspace, "null pointer");
+  TRL_REQUIRE(n_wg >= 2 && (n_wg % 2) == 0, "n_wg must be even and >= 2");
+  const int ps = trl_ppo_partial_stride(D, H, A);
+  if (ps < 0) return ps;
+  AdamDev d;
+  int rc = fill_adam(adam, d);
+  if (rc) return rc;
+  const int p_pf = H * D + H + H * H + H + A * H + A + A, p_vf = H * D + H + H * H + H + H + 1;
+  TRL_REQUIRE(adam->n_groups == 2 && adam->group_sizes[0] == p_pf && adam->group_sizes[1] == p_vf,
+              "optimiser groups must be [policy | value] of this shape");
+  TRL_REQUIRE(adam->grads == grads, "adam->grads must be the reduce output");
+  hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(trl_ceil_div(ps, RED_CHUNK), 2), dim3(256), 0, (hipStream_t)stream,
+                     partial, scal_partial, n_wg, ps, p_pf, p_vf, (const float*)(adam->params + (p_pf - A)), A, grads,
+                     info, d, workspace);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {
+  AdamDev d;
+  int rc = fill_adam(p, d);
+  if (rc) return rc;
   const int total = d.off[p->n_groups];
   if (total == 0) return TRL_OK;
   hipLaunchKernelGGL(clip_adam_kernel, dim3(trl_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, d);

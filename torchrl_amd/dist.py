@@ -47,6 +47,11 @@ def _active():
     return initialized() and (world_size() > 1 or _FORCE)
 
 
+def collectives_active():
+    """True when gradients / statistics are exchanged between ranks (world size > 1, or forced)."""
+    return _active()
+
+
 def all_reduce_sum_(t):
     if _active():
         td.all_reduce(t, op=td.ReduceOp.SUM)
