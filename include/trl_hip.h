@@ -164,16 +164,20 @@ typedef struct trl_ppo_batch_t {
   int clipped_value_loss, tanh_action;
   float* partial;             /* (n_wg, P_STRIDE) fp32 workspace */
   double* scal_partial;       /* (n_wg, 8) */
-  int n_wg;                   /* even; first half policy, second half value */
+  int n_wg;                   /* workgroups launched (>= 2); rows of partial / scal_partial */
+  int n_wg_pf;                /* workgroups [0, n_wg_pf) run the policy, the rest the value net;
+                                 0 = even split.  trl_ppo_wg_split() returns the balanced choice. */
 } trl_ppo_batch_t;
 int trl_ppo_partial_stride(int D, int H, int A);
+/* balanced policy / value split of n_wg workgroups for n_tiles = ceil(samples / 16) tiles */
+int trl_ppo_wg_split(int D, int H, int A, int n_tiles, int n_wg);
 int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* args, void* stream);
 /* grads: flat [pf grads (P_pf) | vf grads (P_vf)].  info: (16) doubles =
  *  0 sum_j -min(s1,s2)   1 sum logp   2 sum logp^2   3 max logp   4 -min logp
  *  5 max ratio   6 -min ratio   7 value-loss sum (local samples; divide by the count)
  *  8..11 mean / unbiased std / max / min of the clamped logstd (ppo.py:82-85)
  * pf_params may be NULL (then 8..11 are left untouched). */
-int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg,
+int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
                        int D, int H, int A, const float* pf_params, float* grads, double* info,
                        void* stream);
 
@@ -201,7 +205,7 @@ int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
  * caller and then owned by this entry point.  Not usable when gradients are all-reduced between
  * the two steps (world size > 1): call the two separate entry points there. */
 int trl_ppo_reduce_adam_workspace(int D, int H, int A);
-int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg,
+int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
                             int D, int H, int A, float* grads, double* info,
                             const trl_adam_t* adam, float* workspace, void* stream);
 

@@ -26,7 +26,7 @@ def main():
     buf = agent.replay_buffer
     t = {"obs": buf._obs, "acts": buf._acts, "advs": buf._advs, "rets": buf._estimate_returns,
          "old_values": buf._values, "old_logp": buf._old_logp}
-    eng._n_wg = lambda n: eng.max_wg                      # always the full grid, to expose the fixed cost
+    eng._n_wg = lambda n: (eng.max_wg, _C.lib().trl_ppo_wg_split(17, 64, 6, (n + 15) // 16, eng.max_wg))                      # always the full grid, to expose the fixed cost
     for rows in (32, 16, 8, 2, 1):
         idx = np.random.permutation(128)[:4 * rows].reshape(4, rows).astype(np.int64)
         probes = []

@@ -58,7 +58,7 @@ class PpoBatchArgs(C.Structure):
         ("D", C.c_int), ("H", C.c_int), ("A", C.c_int), ("act", C.c_int),
         ("clip_para", C.c_float), ("entropy_coeff", C.c_float),
         ("clipped_value_loss", C.c_int), ("tanh_action", C.c_int),
-        ("partial", C.c_void_p), ("scal_partial", C.c_void_p), ("n_wg", C.c_int),
+        ("partial", C.c_void_p), ("scal_partial", C.c_void_p), ("n_wg", C.c_int), ("n_wg_pf", C.c_int),
     ]
 
 
@@ -84,10 +84,11 @@ SIGNATURES = {
     "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_minibatch_grad_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p]),
-    "trl_ppo_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trl_ppo_wg_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "trl_ppo_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_clip_adam_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
     "trl_ppo_reduce_adam_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "trl_ppo_reduce_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+    "trl_ppo_reduce_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
     "trl_synth_reset_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "trl_gauss_logp_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -244,9 +245,9 @@ def ppo_minibatch_grad(args, device):
     check(lib().trl_ppo_minibatch_grad_f32(C.byref(args), stream_ptr(device)), "trl_ppo_minibatch_grad_f32")
 
 
-def ppo_reduce(partial, scal_partial, n_wg, D, H, A, grads, info, pf_params=None):
+def ppo_reduce(partial, scal_partial, n_wg, D, H, A, grads, info, pf_params=None, n_wg_pf=0):
     check(lib().trl_ppo_reduce_f32(dev_ptr(partial, name="partial"),
-                                   dev_ptr(scal_partial, torch.float64, "scal_partial"), n_wg, D, H, A,
+                                   dev_ptr(scal_partial, torch.float64, "scal_partial"), n_wg, n_wg_pf, D, H, A,
                                    dev_ptr(pf_params, name="pf_params", allow_none=True),
                                    dev_ptr(grads, name="grads"), dev_ptr(info, torch.float64, "info"),
                                    stream_ptr(partial.device)), "trl_ppo_reduce_f32")

@@ -158,9 +158,13 @@ class _FusedPPO:
             atu.copy_model_params_from_to(self.algo.pf, self.algo.target_pf)
 
     def _n_wg(self, n_samples):
+        """(workgroups to launch, how many of them run the policy) for one minibatch."""
         tiles = (n_samples + 15) // 16
-        per_net = max(1, min(self.max_wg // 2, (tiles + 3) // 4))
-        return 2 * per_net
+        n_wg = 2 * max(1, min(self.max_wg // 2, (tiles + 3) // 4))
+        n_pf = _C.lib().trl_ppo_wg_split(self.D, self.H, self.A, tiles, n_wg)
+        if not 0 < n_pf < n_wg:
+            raise _C.TrlError("trl_ppo_wg_split(%d tiles, %d workgroups) returned %d" % (tiles, n_wg, n_pf))
+        return n_wg, n_pf
 
     def run(self, t, row_idx, N):
         """t: dict of (rows, N, feat) device tensors; row_idx: (K, rows_mb) host int64.
@@ -178,7 +182,7 @@ class _FusedPPO:
         norms = stats[20 * K:].view(torch.float32).view(K, 2)
         _C.adv_stats(t["advs"].reshape(rows_total, N), idx_dev, raw)
         dist.reduce_adv_raw_(raw)
-        n_wg = self._n_wg(n_local)
+        n_wg, n_wg_pf = self._n_wg(n_local)
 
         g = _C.PpoBatchArgs()
         for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"):
@@ -188,7 +192,7 @@ class _FusedPPO:
         g.D, g.H, g.A, g.act = self.D, self.H, self.A, self.act
         g.clip_para, g.entropy_coeff = float(algo.clip_para), float(algo.entropy_coeff)
         g.clipped_value_loss, g.tanh_action = int(bool(algo.clipped_value_loss)), int(bool(algo.pf.tanh_action))
-        g.partial, g.scal_partial, g.n_wg = self.partial.data_ptr(), self.scal.data_ptr(), n_wg
+        g.partial, g.scal_partial, g.n_wg, g.n_wg_pf = self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf
 
         a = _C.AdamArgs()
         a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
@@ -218,12 +222,12 @@ class _FusedPPO:
             a.step_count = self.step_count
             a.norms_out = norm_base + 8 * k
             if fused:                                                  # one process: reduce + clip + Adam in one launch
-                _C.check(lib.trl_ppo_reduce_adam_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, self.D,
-                                                     self.H, self.A, self.grads.data_ptr(), info_base + 128 * k,
+                _C.check(lib.trl_ppo_reduce_adam_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf,
+                                                     self.D, self.H, self.A, self.grads.data_ptr(), info_base + 128 * k,
                                                      C.byref(a), self.red_ws.data_ptr(), stream),
                          "trl_ppo_reduce_adam_f32")
                 continue
-            _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, self.D, self.H,
+            _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf, self.D, self.H,
                                             self.A, self.flat.data_ptr(), self.grads.data_ptr(),
                                             info_base + 128 * k, stream), "trl_ppo_reduce_f32")
             dist.all_reduce_sum_(self.grads)                           # C1: gradient SUM over ranks

@@ -22,33 +22,6 @@
 #include "trl_common.h"
 #include "trl_mlp.h"
 
-// ---- geometry: a GROUP of 4 waves owns a 16-sample tile; wave `mo` owns hidden features
-// [16mo, 16mo+16) of every layer (H == 64).  3 groups per workgroup -> 12 waves, 3 per SIMD (168 VGPRs each).
-#define Q_WAVES 4
-#define G_PER_WG 3
-#define PPO_WAVES (Q_WAVES * G_PER_WG)
-#define PPO_THREADS (64 * PPO_WAVES)
-
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-// The 4 waves of a group rendezvous on an LDS counter; the other groups of the workgroup keep
-// running (an s_barrier would put all 16 waves in lockstep and nothing would overlap the MFMA
-// chains).  LDS operations of one wave are performed in order, so the arrive-atomic is ordered
-// after this wave's earlier ds_writes without a waitcnt; no fence intrinsic on purpose -- a
-// workgroup release also emits vmcnt(0) and would stall on global loads kept in flight.
-__device__ __forceinline__ void group_sync(int* cnt, int& expect, int lane) {
-#ifdef TRL_EXP_NOSYNC
-  return;
-#endif
-  asm volatile("" ::: "memory");
-  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  expect += Q_WAVES;
-  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect) __builtin_amdgcn_s_sleep(1);
-  asm volatile("" ::: "memory");
-}
-
 struct PpoDev {
   const float *obs, *acts, *advs, *rets, *old_values, *old_logp;
   const int64_t* row_idx;
@@ -60,410 +33,16 @@ struct PpoDev {
   int clipped_value_loss, tanh_action;
   float* partial;
   double* scal_partial;
-  int n_wg, p_stride;
+  int n_wg, n_pf, p_stride;                  // workgroups [0, n_pf) run the policy, [n_pf, n_wg) the value net
 };
 
 template <int D, int H, int A> struct PpoShape {
   static_assert(H == 64 && D > 16 && D <= 32 && A <= 8, "instantiated for 16 < D <= 32, H == 64, A <= 8");
-  static constexpr int NSTAT = 7 + 2 * A;              // lp sum/sumsq/max/-min, ratio max/-min, loss, db3[A], dlogstd[A]
-  // group scratch: H1 | DZ2 | P[4] (wave private: H2 then dZ1) | headp[4][8][16] | douts[16][TL] | stats | counter
-  static constexpr int O_H1 = 0, O_DZ2 = H * TL, O_P = 2 * H * TL, O_HP = O_P + Q_WAVES * 16 * TL,
-                       O_DO = O_HP + Q_WAVES * 8 * 16, O_ST = O_DO + 16 * TL,
-                       O_CNT = O_ST + align4(NSTAT * 16), GRP_SCR = O_CNT + 4;
-  // shared small parameters: b1 | b2 | b3[8] | logstd[8]
-  static constexpr int O_B1 = 0, O_B2 = H, O_B3 = 2 * H, O_LS = 2 * H + 8, PAR = 2 * H + 16;
   static constexpr int P_PF = MlpFlat<D, H, A>::P_PF, P_VF = MlpFlat<D, H, 1>::P_VF;
-  static constexpr int P_STRIDE = ((P_PF > P_VF ? P_PF : P_VF) + 63) & ~63;
-  static constexpr int SCR_ALL = G_PER_WG * GRP_SCR;
-  static constexpr int FOLD = G_PER_WG * P_STRIDE;      // epilogue: one gradient image per group
-  static constexpr int LDS_FLOATS = PAR + (SCR_ALL > FOLD ? SCR_ALL : FOLD);
+  static constexpr int P_STRIDE = ((P_PF > P_VF ? P_PF : P_VF) + 63) & ~63;   // floats per workgroup partial
 };
 
-// One network (policy or value) over this workgroup's tiles.
-template <int D, int H, int A, int ACT, bool IS_PF>
-__device__ void ppo_net_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
-  constexpr int O = IS_PF ? A : 1;
-  using S = PpoShape<D, H, A>;
-  using F = MlpFlat<D, H, O>;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (readfirstlane on `wave` measured 1.5 % slower)
-  const int grp = wave >> 2, mo0 = wave & 3;
-  const int j0 = lane & 15, g0 = lane >> 4;
-  const float* gp = IS_PF ? a.pf_params : a.vf_params;
-  float* spar = lds;
-  int* cnt = reinterpret_cast<int*>(lds + S::PAR + grp * S::GRP_SCR + S::O_CNT);
-
-  // ---- one-time setup: small shared parameters to LDS, this wave's weight slices to registers ----
-  for (int e = tid; e < H; e += PPO_THREADS) { spar[S::O_B1 + e] = gp[F::B1 + e]; spar[S::O_B2 + e] = gp[F::B2 + e]; }
-  if (tid < 8) {
-    spar[S::O_B3 + tid] = tid < O ? gp[F::B3 + tid] : 0.0f;
-    spar[S::O_LS + tid] = (IS_PF && tid < O) ? gp[F::LS + tid] : 0.0f;
-  }
-  {
-    float* scr0 = lds + S::PAR + grp * S::GRP_SCR;
-    if (mo0 == 0) {
-      for (int e = lane; e < 16 * TL; e += 64) scr0[S::O_DO + e] = 0.0f;          // dout rows >= O stay zero
-      for (int e = lane; e < S::NSTAT * 16; e += 64) scr0[S::O_ST + e] = (e / 16 >= 2 && e / 16 <= 5) ? -INFINITY : 0.0f;
-      if (lane == 0) *cnt = 0;
-    }
-  }
-  // A operands, lane (i, g): k index of MFMA step (slice sl, r) is feature 16 sl + 4 g + r
-  float w1r[5], w2r[4][4], w2t[4][4], w3a[4], w3b[2];
-  {
-    const int row = 16 * mo0 + j0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) w1r[r] = gp[F::W1 + row * D + 4 * g0 + r];
-    w1r[4] = (16 + g0 < D) ? gp[F::W1 + row * D + 16 + (16 + g0 < D ? g0 : 0)] : 0.0f;
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        w2r[sl][r] = gp[F::W2 + row * H + 16 * sl + 4 * g0 + r];                  // forward:  W2[own row][k]
-        w2t[sl][r] = gp[F::W2 + (16 * sl + 4 * g0 + r) * H + row];                // backward: W2[k][own col]
-      }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) w3a[r] = (j0 < O) ? gp[F::W3 + (j0 < O ? j0 : 0) * H + 16 * mo0 + 4 * g0 + r] : 0.0f;
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      const int o = 4 * st + g0;
-      w3b[st] = (o < O) ? gp[F::W3 + (o < O ? o : 0) * H + row] : 0.0f;
-    }
-  }
-  __syncthreads();
-  int expect = 0;
-
-  // advantage normalisation constants (ppo.py:141-147): mean, unbiased std
-  const double ng = a.n_global;
-  const double adv_mean = a.adv_raw[0] / ng;
-  const double adv_var = (a.adv_raw[1] - a.adv_raw[0] * a.adv_raw[0] / ng) / (ng - 1.0);
-  const float adv_mu = (float)adv_mean;
-  const float adv_rstd = 1.0f / ((float)sqrt(fmax(adv_var, 0.0)) + 1e-5f);
-  const float inv_b = (float)(1.0 / ng);
-
-  // this wave's share of the gradient: rows [16mo, 16mo+16) of W2 / W1, columns 16mo.. of W3
-  f32x4 gW2[4], gW1[2], gW3;
-  float gb1 = 0.f, gb2 = 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) gW2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gW1[0] = gW1[1] = gW3 = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int B = a.rows_mb * a.N;
-  const int n_tiles = (B + 15) / 16;
-  const bool contig = (a.N % 16) == 0;
-  const int tile_stride = n_wg_net * G_PER_WG;
-
-  // Per-sample inputs are fetched ONE TILE AHEAD (x operand: 5 regs; loss inputs of wave 0: 4 regs),
-  // and the cell index two tiles ahead, so no global-load latency sits on a tile's critical path.
-  auto cell_of = [&](int smp) -> int64_t {
-    if (smp >= B) return 0;
-    const int r = smp / a.N, e = smp - r * a.N;
-    return (a.row_idx ? a.row_idx[r] : (int64_t)r) * a.N + e;
-  };
-  float xq[5], lq[4];
-  auto fetch_inputs = [&](int64_t p, int g_, int mo_) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xq[r] = a.obs[p * D + 4 * g_ + r];
-    xq[4] = a.obs[p * D + (16 + g_ < D ? 16 + g_ : 0)];
-    lq[0] = lq[1] = lq[2] = lq[3] = 0.0f;
-    if (mo_ == 0) {
-      if constexpr (IS_PF) {
-        lq[0] = a.acts[p * O + (g_ < O ? g_ : 0)];
-        lq[1] = a.acts[p * O + (g_ + 4 < O ? g_ + 4 : 0)];
-        lq[2] = a.advs[p]; lq[3] = a.old_logp[p];
-      } else {
-        lq[2] = a.rets[p]; lq[3] = a.clipped_value_loss ? a.old_values[p] : 0.0f;
-      }
-    }
-  };
-  const int first_s = (wg_in_net * G_PER_WG + grp) * 16 + j0;
-  int64_t pos_cur = cell_of(first_s);
-  int64_t pos_next = cell_of(first_s + tile_stride * 16);
-  fetch_inputs(pos_cur, g0, mo0);
-  for (int tile = wg_in_net * G_PER_WG + grp; tile < n_tiles; tile += tile_stride) {
-    // Launder the lane coordinates once per tile: every LDS address below derives from them, and
-    // without this LICM hoists the loop-invariant addresses out of the tile loop and spills them.
-    int j = j0, g = g0, mo = mo0, scr_off = S::PAR + grp * S::GRP_SCR;
-    asm volatile("" : "+v"(j), "+v"(g), "+v"(mo), "+v"(scr_off));
-    const int i = j;
-    float* scr = lds + scr_off;
-    float* S_H1 = scr + S::O_H1;
-    float* S_DZ2 = scr + S::O_DZ2;
-    float* P = scr + S::O_P + mo * 16 * TL;                   // wave private [16 features][TL]
-    float* headp = scr + S::O_HP;
-    float* douts = scr + S::O_DO;
-    float* st = scr + S::O_ST;
-    const int s0 = tile * 16;
-    const int s = s0 + j;
-    const bool valid = s < B;
-    const int64_t pos = pos_cur;                              // (row, env) cell of this lane's sample (0 if masked)
-    // consume the prefetched inputs, then start the next tile's fetch
-    float xb[5];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xb[r] = valid ? xq[r] : 0.0f;
-    xb[4] = (valid && 16 + g < D) ? xq[4] : 0.0f;
-    const float in_act0 = lq[0], in_act1 = lq[1], in_a = lq[2], in_b = lq[3];
-    pos_cur = pos_next;
-    pos_next = cell_of(s + 2 * tile_stride * 16);
-    fetch_inputs(pos_cur, g, mo);
-
-    // ---- forward layer 1, own 16 features ----
-    f32x4 h1 = *reinterpret_cast<const f32x4*>(spar + S::O_B1 + 16 * mo + 4 * g);
-#pragma unroll
-    for (int q = 0; q < 5; ++q) h1 = mfma16(w1r[q], xb[q], h1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h1[r] = act_fn<ACT>(h1[r]);
-    group_sync(cnt, expect, lane);                            // everybody is done with the previous tile's staging
-    store_T(S_H1, mo, h1, j, g);
-    group_sync(cnt, expect, lane);
-
-    // ---- forward layer 2 ----
-    f32x4 h2 = *reinterpret_cast<const f32x4*>(spar + S::O_B2 + 16 * mo + 4 * g);
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      const f32x4 b = load_T(S_H1, sl, j, g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) h2 = mfma16(w2r[sl][r], b[r], h2);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h2[r] = act_fn<ACT>(h2[r]);
-    // partial head over the own features, on the matrix pipe: D[o][sample] (rows >= O are zero)
-    {
-      f32x4 hp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) hp = mfma16(w3a[r], h2[r], hp);
-      if (g < 2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) headp[(mo * 8 + 4 * g + r) * 16 + j] = hp[r];
-      }
-    }
-    store_T(P, 0, h2, j, g);                                  // own H2 slice, for dW3
-    group_sync(cnt, expect, lane);
-
-    // ---- loss and d(loss)/d(out): wave 0, lane (j, g) handles outputs g and g + 4 ----
-    if (mo == 0) {
-      float dout0 = 0.f, dout1 = 0.f;
-      if constexpr (IS_PF) {
-        const int o0 = g, o1 = g + 4;
-        float out0 = spar[S::O_B3 + o0], out1 = spar[S::O_B3 + (o1 < 8 ? o1 : 0)];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { out0 += headp[(w * 8 + o0) * 16 + j]; out1 += headp[(w * 8 + (o1 < 8 ? o1 : 0)) * 16 + j]; }
-        const float raw0 = spar[S::O_LS + o0], raw1 = spar[S::O_LS + (o1 < 8 ? o1 : 0)];
-        const float ls0 = fminf(fmaxf(raw0, -20.0f), 2.0f), ls1 = fminf(fmaxf(raw1, -20.0f), 2.0f);   // continuous_policy.py:8-9,185
-        const float iv0 = __expf(-2.0f * ls0), iv1 = __expf(-2.0f * ls1);
-        float zc0 = 0.f, zc1 = 0.f, lp = 0.0f;
-        if (o0 < O) lp += gauss_logp_term(valid ? in_act0 : 0.0f, out0, iv0, ls0, a.tanh_action, zc0);
-        if (o1 < O) lp += gauss_logp_term(valid ? in_act1 : 0.0f, out1, iv1, ls1, a.tanh_action, zc1);
-        lp += __shfl_xor(lp, 16, 64);
-        lp += __shfl_xor(lp, 32, 64);
-        const float advn = valid ? (in_a - adv_mu) * adv_rstd : 0.0f;
-        const float ratio = __expf(lp - in_b);
-        const float s1 = ratio * advn;
-        const float s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
-        const float g_lp = (valid && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
-        dout0 = g_lp * zc0 * iv0; dout1 = g_lp * zc1 * iv1;
-        if (valid) {                                          // per-lane LDS slots: [stat][sample lane]
-          if (o0 < O) {
-            st[(7 + o0) * 16 + j] += dout0;
-            const float pass = (raw0 >= -20.0f && raw0 <= 2.0f) ? 1.0f : 0.0f;   // clamp passes gradient inside [-20, 2]
-            st[(7 + A + o0) * 16 + j] += pass * (g_lp * (zc0 * zc0 * iv0 - 1.0f) - a.entropy_coeff * inv_b);
-          }
-          if (o1 < O) {
-            st[(7 + o1) * 16 + j] += dout1;
-            const float pass = (raw1 >= -20.0f && raw1 <= 2.0f) ? 1.0f : 0.0f;
-            st[(7 + A + o1) * 16 + j] += pass * (g_lp * (zc1 * zc1 * iv1 - 1.0f) - a.entropy_coeff * inv_b);
-          }
-#ifndef TRL_EXP_NOSTATS
-          if (g == 0) {
-            st[0 * 16 + j] += lp; st[1 * 16 + j] = fmaf(lp, lp, st[1 * 16 + j]); st[6 * 16 + j] -= fminf(s1, s2);
-            st[2 * 16 + j] = fmaxf(st[2 * 16 + j], lp); st[3 * 16 + j] = fmaxf(st[3 * 16 + j], -lp);
-            st[4 * 16 + j] = fmaxf(st[4 * 16 + j], ratio); st[5 * 16 + j] = fmaxf(st[5 * 16 + j], -ratio);
-          }
-#endif
-        }
-        if (o0 < O) douts[o0 * TL + j] = dout0;
-        if (o1 < O) douts[o1 * TL + j] = dout1;
-      } else {
-        if (g == 0) {
-          float v = spar[S::O_B3];
-#pragma unroll
-          for (int w = 0; w < 4; ++w) v += headp[(w * 8) * 16 + j];
-          const float R = in_a;
-          float dv, l;
-          if (a.clipped_value_loss) {                          // ppo.py:104-111
-            const float vo = in_b;
-            const float dc = v - vo;
-            const float vc = vo + fminf(fmaxf(dc, -a.clip_para), a.clip_para);
-            const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
-            const float w1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), w2 = 1.0f - w1;
-            const float pass = (dc >= -a.clip_para && dc <= a.clip_para) ? 1.0f : 0.0f;
-            l = 0.5f * fmaxf(l1, l2);
-            dv = inv_b * (w1 * (v - R) + w2 * pass * (vc - R));
-          } else {                                             // nn.MSELoss, a2c.py:43
-            l = (v - R) * (v - R);
-            dv = 2.0f * (v - R) * inv_b;
-          }
-          dout0 = valid ? dv : 0.0f;
-          if (valid) { st[6 * 16 + j] += l; st[7 * 16 + j] += dout0; }
-          douts[j] = dout0;
-        }
-      }
-    }
-    group_sync(cnt, expect, lane);
-
-    // ---- backward through the head on the matrix pipe: dH2^T[f][s] = sum_o W3[o][f] dout[o][s] ----
-    f32x4 dz2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) dz2 = mfma16(w3b[q], douts[(4 * q + g) * TL + j], dz2);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dz2[r] *= act_grad<ACT>(h2[r]);
-    store_T(S_DZ2, mo, dz2, j, g);
-    // dW3[o][own f] += sum_s dout[o][s] H2[s][f]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) gW3 = mfma16(douts[i * TL + 4 * q + g], P[srow(j) * TL + 4 * q + g], gW3);
-    // X with lane = input feature, k = sample 4q + g: issued here, consumed by the dW1 MFMAs below
-    float xn0[4], xn1[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int sj = 4 * q + g;
-      int64_t pr;
-      if (contig) pr = pos - j + sj;                          // N % 16 == 0: the tile is one contiguous run of cells
-      else        pr = __shfl(pos, sj, 64);
-      const bool ok = s0 + sj < B;
-      const float v0 = a.obs[(ok ? pr : 0) * D + i];
-      const float v1 = a.obs[(ok ? pr : 0) * D + (16 + i < D ? 16 + i : 0)];
-      xn0[q] = ok ? v0 : 0.0f;
-      xn1[q] = (ok && 16 + i < D) ? v1 : 0.0f;
-    }
-    group_sync(cnt, expect, lane);
-
-    // ---- dH1^T (own rows) = W2^T dZ2^T ; dZ1 = dH1 * act'(H1) ----
-    f32x4 dz1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      const f32x4 b = load_T(S_DZ2, sl, j, g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dz1 = mfma16(w2t[sl][r], b[r], dz1);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dz1[r] *= act_grad<ACT>(h1[r]);
-    wave_lds_sync();                                          // P: the H2 reads above precede the dZ1 writes below
-    store_T(P, 0, dz1, j, g);
-    wave_lds_sync();
-
-    // ---- dW2[own j_out][k_in] += sum_s dZ2[s][j_out] H1[s][k_in] ----
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float az = S_DZ2[(16 * mo + srow(i)) * TL + 4 * q + g];
-      gb2 += az;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) gW2[c] = mfma16(az, S_H1[(16 * c + srow(j)) * TL + 4 * q + g], gW2[c]);
-    }
-    // ---- dW1[own j_out][k_in] += sum_s dZ1[s][j_out] X[s][k_in] ----
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float az = P[srow(i) * TL + 4 * q + g];
-      gb1 += az;
-      gW1[0] = mfma16(az, xn0[q], gW1[0]);
-      gW1[1] = mfma16(az, xn1[q], gW1[1]);
-    }
-    wave_lds_sync();
-  }
-
-  // ---- fold the 4 groups in fixed order into one partial gradient (flat layout) ----
-  const int j = j0, g = g0, mo = mo0;
-  // pull this group's statistic slots into registers before the scratch area is recycled
-  float stv[7], db3v = 0.f, dlsv = 0.f;
-  {
-    const float* st = lds + S::PAR + grp * S::GRP_SCR + S::O_ST;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) stv[k] = st[k * 16 + j];
-    // lane (j, g) fetches db3 / dlogstd of output o = 4*(lane>>5)... simpler: o = lane >> 4 + 4*(pass)
-  }
-  float db3a[2], dlsa[2];
-  {
-    const float* st = lds + S::PAR + grp * S::GRP_SCR + S::O_ST;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int o = g + 4 * q;
-      db3a[q] = (o < O) ? st[(7 + (o < O ? o : 0)) * 16 + j] : 0.0f;
-      dlsa[q] = (IS_PF && o < O) ? st[(7 + A + (o < O ? o : 0)) * 16 + j] : 0.0f;
-    }
-  }
-  __syncthreads();
-  // Every group writes its own gradient image (the 4 waves of a group own disjoint addresses), then
-  // all threads add the images in fixed order: deterministic, and two barriers instead of one per group.
-  float* gimg = lds + S::PAR + grp * S::P_STRIDE;
-  for (int e = tid; e < G_PER_WG * S::P_STRIDE; e += PPO_THREADS) lds[S::PAR + e] = 0.0f;
-  __syncthreads();
-  gb1 += __shfl_xor(gb1, 16, 64); gb1 += __shfl_xor(gb1, 32, 64);   // bias partials over the 4 lane groups
-  gb2 += __shfl_xor(gb2, 16, 64); gb2 += __shfl_xor(gb2, 32, 64);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int jo = 16 * mo + 4 * g + r;                       // output feature (row of W2 / W1)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) gimg[F::W2 + jo * H + 16 * c + j] = gW2[c][r];
-    gimg[F::W1 + jo * D + j] = gW1[0][r];
-    if (16 + j < D) gimg[F::W1 + jo * D + 16 + j] = gW1[1][r];
-    const int o = 4 * g + r;                                  // gW3 rows are outputs
-    if (o < O) gimg[F::W3 + o * H + 16 * mo + j] = gW3[r];
-  }
-  if (g == 0) { gimg[F::B1 + 16 * mo + j] = gb1; gimg[F::B2 + 16 * mo + j] = gb2; }
-  if (mo == 0) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int o = g + 4 * q;
-      float b3 = db3a[q], dl = dlsa[q];                       // sum over the 16 sample lanes of this lane group
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) { b3 += __shfl_xor(b3, off, 64); dl += __shfl_xor(dl, off, 64); }
-      if (j == 0 && o < O) {
-        gimg[F::B3 + o] = b3;
-        if (IS_PF) gimg[F::LS + o] = dl;
-      }
-    }
-  }
-  __syncthreads();
-  const int wg = blockIdx.x;
-  for (int e = tid; e < S::P_STRIDE; e += PPO_THREADS) {
-    float acc = lds[S::PAR + e];
-#pragma unroll
-    for (int w = 1; w < G_PER_WG; ++w) acc += lds[S::PAR + w * S::P_STRIDE + e];
-    a.partial[(size_t)wg * a.p_stride + e] = acc;
-  }
-
-  // ---- scalar statistics: wave shuffle reduce, then across the groups through LDS ----
-  __syncthreads();
-  double* sred = reinterpret_cast<double*>(lds + S::PAR);
-  if (mo == 0) {
-    const bool own = g == 0;
-    const double v0 = wave_sum(own ? (double)stv[0] : 0.0), v1 = wave_sum(own ? (double)stv[1] : 0.0),
-                 v6 = wave_sum(own ? (double)stv[6] : 0.0);
-    const float v2 = wave_max(own ? stv[2] : -INFINITY), v3 = wave_max(own ? stv[3] : -INFINITY),
-                v4 = wave_max(own ? stv[4] : -INFINITY), v5 = wave_max(own ? stv[5] : -INFINITY);
-    if (lane == 0) {
-      double* p = sred + grp * 8;
-      p[0] = v0; p[1] = v1; p[2] = v2; p[3] = v3; p[4] = v4; p[5] = v5; p[6] = v6; p[7] = 0.0;
-    }
-  }
-  __syncthreads();
-  if (tid < 8) {
-    double r = sred[tid];
-    for (int w = 1; w < G_PER_WG; ++w) {
-      const double o = sred[w * 8 + tid];
-      r = (tid >= 2 && tid <= 5) ? fmax(r, o) : r + o;
-    }
-    a.scal_partial[(size_t)wg * 8 + tid] = r;
-  }
-}
-
-template <int D, int H, int A, int ACT>
-__global__ __launch_bounds__(PPO_THREADS, 3) void ppo_grad_kernel(PpoDev a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int half = a.n_wg >> 1;
-  if ((int)blockIdx.x < half) ppo_net_pass<D, H, A, ACT, true>(a, lds, blockIdx.x, half);
-  else                        ppo_net_pass<D, H, A, ACT, false>(a, lds, blockIdx.x - half, half);
-}
-
-// ================================================================ design C: one wave = one tile
+// ================================================================ one wave = one tile
 // Every wave walks whole 16-sample tiles on its own: all four 16-feature slices of a layer are
 // independent accumulator chains in one instruction stream (the matrix pipe always has an MFMA that
 // does not wait on the previous one), layer outputs chain as the next layer's B operand in
@@ -919,9 +498,8 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 template <int D, int H, int A, int ACT>
 __global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int half = a.n_wg >> 1;
-  if ((int)blockIdx.x < half) ppo_wave_pass<D, H, A, ACT, true>(a, lds, blockIdx.x, half);
-  else                        ppo_wave_pass<D, H, A, ACT, false>(a, lds, blockIdx.x - half, half);
+  if ((int)blockIdx.x < a.n_pf) ppo_wave_pass<D, H, A, ACT, true>(a, lds, blockIdx.x, a.n_pf);
+  else                          ppo_wave_pass<D, H, A, ACT, false>(a, lds, blockIdx.x - a.n_pf, a.n_wg - a.n_pf);
 }
 
 // ---------------------------------------------------------------- partial reduce
@@ -931,15 +509,15 @@ __global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) 
 #define RED_CHUNK 64
 // returns (wave 0 lanes) this block's reduced gradient value, 0 outside the parameter range
 __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ partial,
-                                                  const double* __restrict__ scal, int n_wg,
+                                                  const double* __restrict__ scal, int n_wg, int n_pf,
                                                   int p_stride, int p_pf, int p_vf,
                                                   const float* __restrict__ logstd, int n_act,
                                                   float* __restrict__ grads, double* __restrict__ info) {
   // block = 64 consecutive parameters x 4 waves; wave w folds partials w, w+4, ... with 4
   // independent accumulators (fixed order => deterministic), then the 4 waves fold through LDS.
   __shared__ float s_acc[4][RED_CHUNK];
-  const int half = n_wg >> 1;
   const int net = blockIdx.y;
+  const int row0 = net == 0 ? 0 : n_pf, nrow = net == 0 ? n_pf : n_wg - n_pf;   // this network's partial rows
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * RED_CHUNK + lane;
   const int pn = net == 0 ? p_pf : p_vf;
@@ -948,16 +526,16 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
   if (p < pn) {
-    const float* src = partial + (size_t)(net * half) * p_stride + p;
+    const float* src = partial + (size_t)row0 * p_stride + p;
     int w = wave;
-    for (; w + 60 < half; w += 64) {
+    for (; w + 60 < nrow; w += 64) {
       float v[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = src[(size_t)(w + 4 * k) * p_stride];
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[k] += v[k];
     }
-    for (; w < half; w += 4) acc[0] += src[(size_t)w * p_stride];
+    for (; w < nrow; w += 4) acc[0] += src[(size_t)w * p_stride];
   }
 #pragma unroll
   for (int st = 8; st > 0; st >>= 1)
@@ -973,11 +551,12 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
   // scalar statistics: one wave per network, lanes stride over the workgroup partials (independent
   // loads, shuffle reduction) -- a serial 128-deep dependent-load chain here cost 50 us
   if (blockIdx.x == 0 && blockIdx.y == 0 && wave < 2) {
-    const double* base = scal + (size_t)(wave * half) * 8;
+    const int srow0 = wave == 0 ? 0 : n_pf, snrow = wave == 0 ? n_pf : n_wg - n_pf;
+    const double* base = scal + (size_t)srow0 * 8;
     double v[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? -INFINITY : 0.0;
-    for (int w = lane; w < half; w += 64) {
+    for (int w = lane; w < snrow; w += 64) {
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const double o = base[(size_t)w * 8 + k];
@@ -1009,11 +588,11 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
 }
 
 __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial,
-                                                         const double* __restrict__ scal, int n_wg,
+                                                         const double* __restrict__ scal, int n_wg, int n_pf,
                                                          int p_stride, int p_pf, int p_vf,
                                                          const float* __restrict__ logstd, int n_act,
                                                          float* __restrict__ grads, double* __restrict__ info) {
-  ppo_reduce_block(partial, scal, n_wg, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
+  ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
 }
 
 // ---------------------------------------------------------------- K11 clip + Adam
@@ -1082,7 +661,7 @@ __device__ __forceinline__ void adam_element(const AdamDev& a, int e, float gr) 
 // identical in all blocks) and takes the Adam step for its own 64 parameters straight from registers.
 // ws: [0] ticket (returns to 0), [1] generation, [16..] partials.
 __global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const float* __restrict__ partial,
-                                                              const double* __restrict__ scal, int n_wg,
+                                                              const double* __restrict__ scal, int n_wg, int n_pf,
                                                               int p_stride, int p_pf, int p_vf,
                                                               const float* __restrict__ logstd, int n_act,
                                                               float* __restrict__ grads, double* __restrict__ info,
@@ -1095,7 +674,7 @@ __global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const float* __res
   const int nb = gridDim.x;
   unsigned g0 = 0;
   if (tid == 0) g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const float gval = ppo_reduce_block(partial, scal, n_wg, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
+  const float gval = ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
   if (wave == 0) {
     const float ss = wave_sum(gval * gval);
     if (lane == 0) {
@@ -1177,48 +756,53 @@ extern "C" int trl_ppo_partial_stride(int D, int H, int A) {
   return TRL_EUNSUPPORTED;
 }
 
-// TRL_PPO_DESIGN=a selects the older group-of-4-waves kernel (kept for A/B measurements)
-static bool ppo_use_wave_kernel() {
-  static const int v = [] { const char* e = getenv("TRL_PPO_DESIGN"); return (e && e[0] == 'a') ? 0 : 1; }();
-  return v != 0;
-}
-
+// Kernel generations that were built and measured on MI355X before this one (profiles/README.md): groups of
+// 4 waves per tile with LDS rendezvous (85 us per 65 536-sample minibatch), this wave-per-tile kernel (64 us),
+// and a PAIR of waves per tile with two waves per SIMD (75 us) -- on gfx950 the fp32 MFMA and the VALU do not
+// overlap across the two waves of a SIMD (tools/ubench/mfma_valu.hip: an MFMA-only wave and a VALU-only wave
+// on one SIMD take the SUM of their times), so a second wave only adds its duplicated loss / fetch work.
 template <int D, int H, int A, int ACT>
 static int launch_ppo(const PpoDev& d, hipStream_t s) {
-  if (ppo_use_wave_kernel()) {
-    using S = WvShape<D, H, A>;
-    const size_t lds = S::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wave_kernel<D, H, A, ACT>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { trl_set_error("ppo_grad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((ppo_grad_wave_kernel<D, H, A, ACT>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d);
-    TRL_LAUNCH_CHECK();
-    return TRL_OK;
-  }
-  using S = PpoShape<D, H, A>;
+  using S = WvShape<D, H, A>;
   const size_t lds = S::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<D, H, A, ACT>,
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wave_kernel<D, H, A, ACT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { trl_set_error("ppo_grad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_grad_kernel<D, H, A, ACT>), dim3(d.n_wg), dim3(PPO_THREADS), lds, s, d);
+  hipLaunchKernelGGL((ppo_grad_wave_kernel<D, H, A, ACT>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
+
+// Policy / value split of the grid.  A policy tile costs more than a value tile (head, log-prob loss,
+// dW3 on the matrix pipe: 16.7 k vs 12.1 k cycles measured at D=17, H=64, A=6), and every wave runs whole
+// tiles, so the split that minimises the slower side's ceil(tiles / waves) * cost is searched directly.
+extern "C" int trl_ppo_wg_split(int D, int H, int A, int n_tiles, int n_wg) {
+  if (n_wg < 2 || n_tiles <= 0) { trl_set_error("trl_ppo_wg_split: need n_wg >= 2 and n_tiles > 0"); return TRL_EINVAL; }
+  const double c_pf = 16.7, c_vf = 12.1;
+  int best = n_wg / 2;
+  double best_t = 1e300;
+  for (int x = 1; x < n_wg; ++x) {
+    const double t_pf = (double)((n_tiles + WV_WAVES * x - 1) / (WV_WAVES * x)) * c_pf;
+    const double t_vf = (double)((n_tiles + WV_WAVES * (n_wg - x) - 1) / (WV_WAVES * (n_wg - x))) * c_vf;
+    const double t = t_pf > t_vf ? t_pf : t_vf;
+    if (t < best_t - 1e-9 || (t < best_t + 1e-9 && abs(2 * x - n_wg) < abs(2 * best - n_wg))) { best_t = t; best = x; }
+  }
+  (void)D; (void)H; (void)A;
+  return best;
+}
+static int resolve_pf_wgs(int n_wg, int n_wg_pf) { return n_wg_pf > 0 ? n_wg_pf : n_wg / 2; }
 
 extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream) {
   if (!p) { trl_set_error("ppo_grad: null descriptor"); return TRL_EINVAL; }
   TRL_REQUIRE(p->obs && p->acts && p->advs && p->rets && p->old_values && p->old_logp, "null rollout tensor");
   TRL_REQUIRE(p->adv_raw && p->pf_params && p->vf_params && p->partial && p->scal_partial, "null pointer");
   TRL_REQUIRE(p->rows_mb > 0 && p->N > 0, "empty minibatch");
-  TRL_REQUIRE(p->n_wg >= 2 && (p->n_wg % 2) == 0, "n_wg must be even and >= 2");
+  TRL_REQUIRE(p->n_wg >= 2, "n_wg must be >= 2");
+  TRL_REQUIRE(p->n_wg_pf >= 0 && p->n_wg_pf < p->n_wg, "n_wg_pf must be 0 (even split) or in [1, n_wg)");
   TRL_REQUIRE(p->n_global > 1.0, "n_global must exceed 1 (unbiased std)");
   const int D = p->D, H = p->H, A = p->A;
   PpoDev d;
@@ -1228,6 +812,7 @@ extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream
   d.clip_para = p->clip_para; d.entropy_coeff = p->entropy_coeff;
   d.clipped_value_loss = p->clipped_value_loss; d.tanh_action = p->tanh_action;
   d.partial = p->partial; d.scal_partial = p->scal_partial; d.n_wg = p->n_wg;
+  d.n_pf = resolve_pf_wgs(p->n_wg, p->n_wg_pf);
   hipStream_t s = (hipStream_t)stream;
   if (SHAPE_IS(17, 64, 6)) {
     d.p_stride = PpoShape<17, 64, 6>::P_STRIDE;
@@ -1238,15 +823,15 @@ extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream
   return TRL_EUNSUPPORTED;
 }
 
-extern "C" int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg, int D, int H,
-                                  int A, const float* pf_params, float* grads, double* info, void* stream) {
+extern "C" int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf, int D,
+                                  int H, int A, const float* pf_params, float* grads, double* info, void* stream) {
   TRL_REQUIRE(partial && scal_partial && grads && info, "null pointer");
-  TRL_REQUIRE(n_wg >= 2 && (n_wg % 2) == 0, "n_wg must be even and >= 2");
+  TRL_REQUIRE(n_wg >= 2 && n_wg_pf >= 0 && n_wg_pf < n_wg, "need n_wg >= 2 and n_wg_pf in [0, n_wg)");
   const int ps = trl_ppo_partial_stride(D, H, A);
   if (ps < 0) return ps;
   const int p_pf = H * D + H + H * H + H + A * H + A + A, p_vf = H * D + H + H * H + H + H + 1;
   hipLaunchKernelGGL(ppo_reduce_kernel, dim3(trl_ceil_div(ps, RED_CHUNK), 2), dim3(256), 0, (hipStream_t)stream,
-                     partial, scal_partial, n_wg, ps, p_pf, p_vf,
+                     partial, scal_partial, n_wg, resolve_pf_wgs(n_wg, n_wg_pf), ps, p_pf, p_vf,
                      pf_params ? pf_params + (p_pf - A) : (const float*)nullptr, A, grads, info);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
@@ -1279,11 +864,11 @@ extern "C" int trl_ppo_reduce_adam_workspace(int D, int H, int A) {
   return 16 + 2 * trl_ceil_div(ps, RED_CHUNK);
 }
 
-extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg, int D, int H,
-                                       int A, float* grads, double* info, const trl_adam_t* adam,
+extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
+                                       int D, int H, int A, float* grads, double* info, const trl_adam_t* adam,
                                        float* workspace, void* stream) {
   TRL_REQUIRE(partial && scal_partial && grads && info && workspace, "null pointer");
-  TRL_REQUIRE(n_wg >= 2 && (n_wg % 2) == 0, "n_wg must be even and >= 2");
+  TRL_REQUIRE(n_wg >= 2 && n_wg_pf >= 0 && n_wg_pf < n_wg, "need n_wg >= 2 and n_wg_pf in [0, n_wg)");
   const int ps = trl_ppo_partial_stride(D, H, A);
   if (ps < 0) return ps;
   AdamDev d;
@@ -1294,8 +879,8 @@ extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_
               "optimiser groups must be [policy | value] of this shape");
   TRL_REQUIRE(adam->grads == grads, "adam->grads must be the reduce output");
   hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(trl_ceil_div(ps, RED_CHUNK), 2), dim3(256), 0, (hipStream_t)stream,
-                     partial, scal_partial, n_wg, ps, p_pf, p_vf, (const float*)(adam->params + (p_pf - A)), A, grads,
-                     info, d, workspace);
+                     partial, scal_partial, n_wg, resolve_pf_wgs(n_wg, n_wg_pf), ps, p_pf, p_vf,
+                     (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }

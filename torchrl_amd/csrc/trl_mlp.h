@@ -256,6 +256,10 @@ __device__ __forceinline__ f32x16 tile_load_N(const float* T, int m, int i, int 
 // g = lane >> 4).  A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], C/D reg r <-> row 4g + r.
 #define TL 17                                   // LDS staging row stride (16 samples + 1)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+#ifdef TRL_EXP_NOMFMA
+  c[0] = fmaf(a, b, c[0]);
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
