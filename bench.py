@@ -243,12 +243,24 @@ def main():
                    "parallelism": "env-sharded dp%d, RCCL grad all-reduce" % world},
         "roofline": {"bound": "mfma", "kernel": "ppo_grad_wave_kernel<17,64,6,tanh>", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                     "traffic": None, "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
+                     "traffic": pmc_traffic(), "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
                      "launches_timed": len(grad_ms)},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_subprocess()
     print(json.dumps(out))
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE cannot be collected from inside the timed run; profiles/grad_kernel_traffic.json records the
+    measurement, its gfx950 correction and the source CSV).  None when the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "grad_kernel_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 if __name__ == "__main__":

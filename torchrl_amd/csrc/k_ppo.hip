@@ -266,14 +266,12 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 
     // Next tile's loads are issued HERE, mid-tile: at the top of the loop every outstanding load is then
     // half a tile old, and no wait next to the first MFMAs can stall on a load that was just issued.
-#ifndef TRL_EXP_NOFETCH
     {
       const int nt = tile + tile_stride;            // loads of tile t+1 (addresses were resolved a tile ago) ...
       const int64_t pn = (nt * 16 + j < B) ? ridx_nn * a.N + e_nn : 0;
       fetch_inputs(pn, nt * 16);
       fetch_row(nt + tile_stride);                  // ... and the row index of tile t+2
     }
-#endif
     WCLK(2)
     // ---- head, loss, d(loss)/d(out), dZ2 ----
     f32x4 dz2[4];
