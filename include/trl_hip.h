@@ -311,6 +311,38 @@ int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, int32_t* t_en
 int trl_synth_frames_reset_u8(uint8_t* frames, int32_t* t_env, int64_t env_seed_base,
                               const uint8_t* mask, int N, int C, int HW, void* stream);
 
+/* --- K1..K3 stand-alone: one VecOnPolicyCollector.take_actions as separate launches
+ * (torchrl/collector/on_policy.py:90-155), for envs the persistent rollout kernel cannot carry
+ * (a running observation normaliser needs all-env statistics before every policy forward).
+ *   gauss_explore      act = [tanh](mean + exp(clamp(logstd)) * eps), logp = log pi(act) (eps / logp may be NULL)
+ *   onpolicy_bookkeep  after env.step: epoch reward, running returns (logged + cleared on done),
+ *                      rewards += discount * v_next * surpass (in place), terminals = reset_mask =
+ *                      done | surpass, step counters, *any_flag |= any(reset_mask)   (:124-148)
+ *   select_on_flag     out = *flag ? a : b -- partial_reset's whole-array return (:145-147) without a host sync */
+int trl_gauss_explore_f32(const float* mean, const float* logstd, const float* eps, float* act, float* logp,
+                          int N, int A, int tanh_action, void* stream);
+int trl_onpolicy_bookkeep_f32(float* rewards, const float* dones, const float* v_next, float discount,
+                              float* terminals, int32_t* cur_step, float* ep_return, int max_episode_frames,
+                              uint8_t* reset_mask, int32_t* any_flag, double* epoch_reward, int32_t* ep_count,
+                              float* ep_log, int ep_cap, int step, int N, void* stream);
+int trl_select_on_flag_f32(const int32_t* flag, const float* a, const float* b, float* out, int64_t n,
+                           void* stream);
+
+/* --- K18: running observation normaliser (torchrl/env/base_wrapper.py:44-121) --------------
+ * state = {mean[D], var[D], count} fp64 on the device (Normalizer._mean/_var/_count; a fresh
+ * normaliser is mean 0, var 1, count 1e-4, :64-69).  sums = {sum x [D], sum x^2 [D], n}.
+ *   update_filt   one vector step in one launch: batch moments over the N rows, Chan merge
+ *                 (update_mean_var_count, :44-60) when update != 0, then
+ *                 out = clip((x - mean) / (sqrt(var) + 1e-4), +-clip) (filt, :86-89); out may be NULL
+ *   batch_moments / merge / filt   the same three steps separately, so that env shards on several
+ *                 GPUs can all-reduce (SUM) the batch moments between the first two.  D <= 64. */
+int trl_norm_update_filt_f32(const float* x, double* state, float* out, int N, int D, float clip,
+                             int update, void* stream);
+int trl_norm_batch_moments_f64(const float* x, int N, int D, double* sums, void* stream);
+int trl_norm_merge_f64(double* state, const double* sums, int D, void* stream);
+int trl_norm_filt_f32(const float* x, const double* state, float* out, int N, int D, float clip,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

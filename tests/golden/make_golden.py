@@ -446,12 +446,72 @@ def case_dqn():
     save("dqn", **out)
 
 
+def case_obs_norm():
+    """Running observation normaliser (env/base_wrapper.py:44-121): Normalizer.update_estimate / filt on a
+    sequence of batches, and NormObs wrapped around the synthetic vector env under
+    VecOnPolicyCollector.train_one_epoch (captures the partial_reset bypass)."""
+    import gym
+    from torchrl.env.base_wrapper import Normalizer, NormObs
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    rs = np.random.RandomState(5)
+    D = 17
+    nz = Normalizer((D,))
+    batches, means, variances, counts, filts = [], [], [], [], []
+    for k, n in enumerate((8, 8, 3, 16, 1, 8)):
+        x = (rs.randn(n, D) * (1.0 + 0.5 * k) + 0.3 * k).astype(np.float32)
+        nz.update_estimate(x)
+        batches.append(x); means.append(nz._mean.copy()); variances.append(nz._var.copy()); counts.append(nz._count)
+        filts.append(nz.filt(x))
+    out["unit_sizes"] = np.array([b.shape[0] for b in batches], dtype=np.int64)
+    out["unit_x"] = np.concatenate(batches, axis=0)
+    out["unit_mean"] = np.stack(means); out["unit_var"] = np.stack(variances); out["unit_count"] = np.array(counts)
+    out["unit_filt"] = np.concatenate(filts, axis=0)
+
+    for tag, N, T, horizon, max_frames, seed in (("flow", 8, 20, 6, 1000, 3), ("flow_surpass", 8, 20, 1000, 7, 4)):
+        A, H = 6, 64
+        pf, vf = build_nets(D, A, H, seed=seed + 40)
+
+        def mk():
+            e = SynthVecEnvCPU(N, horizon=horizon)
+            e.action_space = gym.spaces.Box(-1, 1, (A,))
+            e.observation_space = gym.spaces.Box(-np.inf, np.inf, (D,))
+            return NormObs(e)
+        env, eval_env = mk(), mk()
+        env.seed(seed)
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+        col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf,
+                                   device=torch.device("cpu"), train_render=False,
+                                   epoch_frames=N * T, max_episode_frames=max_frames, eval_episodes=1)
+        out.update(state_arrays(f"{tag}_pf_", pf))
+        out.update(state_arrays(f"{tag}_vf_", vf))
+        out[f"{tag}_ob0"] = np.asarray(col.current_ob).copy()                 # normalised reset obs
+        out[f"{tag}_state0"] = np.concatenate([env._obs_normalizer._mean, env._obs_normalizer._var,
+                                               [env._obs_normalizer._count]])
+        noise_state = torch.get_rng_state()
+        res = col.train_one_epoch()
+        torch.set_rng_state(noise_state)
+        out[f"{tag}_noise"] = torch.stack([torch.randn(N, A) for _ in range(T)]).numpy()
+        for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+            out[f"{tag}_buf_{k}"] = getattr(buf, "_" + k).copy()
+        out[f"{tag}_train_epoch_reward"] = np.array(res["train_epoch_reward"])
+        out[f"{tag}_train_rewards"] = np.array(res["train_rewards"], dtype=np.float64).reshape(-1)
+        out[f"{tag}_current_ob"] = np.asarray(col.current_ob).copy()
+        out[f"{tag}_state1"] = np.concatenate([env._obs_normalizer._mean, env._obs_normalizer._var,
+                                               [env._obs_normalizer._count]])
+        out[f"{tag}_args"] = np.array([N, T, horizon, max_frames, seed], dtype=np.int64)
+    save("obs_norm", **out)
+
+
+CASES = {"gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
+         "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
+         "obs_norm": case_obs_norm}
+
 if __name__ == "__main__":
     install_stubs()
-    case_gae()
-    case_index_streams()
-    case_init()
-    case_ppo_update()
-    case_collect_and_epoch()
-    case_twin_sac_q()
-    case_dqn()
+    for name in (sys.argv[1:] or list(CASES)):               # python make_golden.py [case ...]
+        CASES[name]()

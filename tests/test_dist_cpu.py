@@ -88,6 +88,28 @@ def _worker(rank, world, port, out_dir):
         t = torch.tensor([float(rank)])
         dist.all_reduce_max_(t)
         assert t.item() == world - 1
+
+        # observation normaliser: SUM of the shards' batch moments {sum x, sum x^2, n}, then the
+        # same Chan merge on every rank == the single-process update on the full batch (what
+        # torchrl_amd.env.base_wrapper.Normalizer does between trl_norm_batch_moments_f64 and trl_norm_merge_f64)
+        from oracle.normalizer import NormalizerOracle, update_mean_var_count
+        rs2 = np.random.RandomState(7)
+        state = (np.zeros(D), np.ones(D), 1e-4)
+        ref = NormalizerOracle((D,))
+        for step in range(3):
+            xfull = rs2.randn(N_total, D) * (1 + step) + 0.2 * step
+            xloc = xfull[off:off + cnt]
+            sums = torch.tensor(np.concatenate([xloc.sum(0), (xloc * xloc).sum(0), [float(cnt)]]))
+            dist.all_reduce_sum_(sums)
+            sums = sums.numpy()
+            n_glob = sums[-1]
+            bmean = sums[:D] / n_glob
+            bvar = np.maximum(sums[D:2 * D] / n_glob - bmean * bmean, 0.0)
+            state = update_mean_var_count(*state, bmean, bvar, n_glob)
+            ref.update_estimate(xfull)
+            np.testing.assert_allclose(state[0], ref._mean, rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(state[1], ref._var, rtol=1e-11, atol=1e-13)
+            assert abs(state[2] - ref._count) < 1e-9
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         td.destroy_process_group()

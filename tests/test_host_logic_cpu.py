@@ -101,8 +101,8 @@ def test_product_path_refuses_cpu_and_unknown_envs():
     from torchrl.env import get_vec_env
     with pytest.raises(ValueError, match="unknown env id"):
         get_vec_env("HalfCheetah-v2", {"reward_scale": 1, "obs_norm": False}, 4)
-    with pytest.raises(NotImplementedError, match="obs_norm"):
-        get_vec_env("SynthHalfCheetah-v0", {"reward_scale": 1, "obs_norm": True}, 4)
+    with pytest.raises(NotImplementedError, match="rew_norm"):
+        get_vec_env("SynthHalfCheetah-v0", {"reward_scale": 1, "obs_norm": False, "rew_norm": {}}, 4)
     from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
     buf = OnPolicyReplayBuffer(8, env_nums=2, device="cpu")
     for k in ("rewards", "values", "terminals", "time_limits"):

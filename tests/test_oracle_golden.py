@@ -250,3 +250,42 @@ def test_quantile_huber_matches_reference(golden):
     loss.backward()
     assert abs(loss.item() - float(g["qr_loss"])) < 1e-7
     np.testing.assert_allclose(src.grad.numpy(), g["qr_grad"], atol=1e-9)
+
+
+# ---------------------------------------------------------------- running observation normaliser
+def test_normalizer_oracle_matches_reference_unit(golden):
+    from oracle.normalizer import NormalizerOracle
+    g = golden("obs_norm")
+    nz = NormalizerOracle((17,))
+    pos = 0
+    for k, n in enumerate(g["unit_sizes"]):
+        x = g["unit_x"][pos:pos + n]
+        nz.update_estimate(x)
+        np.testing.assert_allclose(nz._mean, g["unit_mean"][k], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(nz._var, g["unit_var"][k], rtol=1e-13, atol=0)
+        assert nz._count == g["unit_count"][k]
+        np.testing.assert_allclose(nz.filt(x), g["unit_filt"][pos:pos + n], rtol=1e-13, atol=1e-14)
+        pos += n
+
+
+@pytest.mark.parametrize("tag", ["flow", "flow_surpass"])
+def test_normobs_collect_oracle_matches_reference(golden, tag):
+    """NormObs(vec env) under the on-policy collector, including the raw-obs-after-partial_reset quirk (Q14)."""
+    from oracle.normalizer import NormObsOracle
+    g = golden("obs_norm")
+    N, T, horizon, max_frames, seed = (int(v) for v in g[tag + "_args"])
+    pf, ls = params_from(g, tag + "_pf_", True)
+    vf, _ = params_from(g, tag + "_vf_", False)
+    env = NormObsOracle(SynthVecEnvCPU(N, horizon=horizon))
+    env.seed(seed)
+    ring = replay.RingOracle(N * T, env_nums=N, time_limit_filter=True)
+    col = VecOnPolicyCollectorOracle(env, ring, pf, ls, vf, epoch_frames=N * T, max_episode_frames=max_frames)
+    np.testing.assert_allclose(col.current_ob, g[tag + "_ob0"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(env._obs_normalizer.state(), g[tag + "_state0"], rtol=1e-12, atol=1e-14)
+    res = col.train_one_epoch(noise=torch.tensor(g[tag + "_noise"]))
+    for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+        np.testing.assert_allclose(ring.data[k], g[tag + "_buf_" + k], rtol=0, atol=3e-6, err_msg=k)
+    assert g[tag + "_buf_terminals"].sum() > 0
+    np.testing.assert_allclose(env._obs_normalizer.state(), g[tag + "_state1"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(col.current_ob, g[tag + "_current_ob"], atol=3e-6)
+    np.testing.assert_allclose(res["train_epoch_reward"], g[tag + "_train_epoch_reward"], atol=1e-4)

@@ -85,6 +85,14 @@ SIGNATURES = {
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_minibatch_grad_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p]),
     "trl_ppo_wg_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "trl_gauss_explore_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_onpolicy_bookkeep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_select_on_flag_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "trl_norm_update_filt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "trl_norm_batch_moments_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_norm_merge_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "trl_norm_filt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "trl_ppo_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_clip_adam_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
     "trl_ppo_reduce_adam_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -488,3 +496,65 @@ def synth_frames_reset(frames, t_env, seed_base, mask):
     check(lib().trl_synth_frames_reset_u8(dev_ptr(frames, torch.uint8, "frames"), dev_ptr(t_env, torch.int32, "t_env"),
                                           int(seed_base), dev_ptr(mask, torch.uint8, "mask", allow_none=True), N, Cc, HW,
                                           stream_ptr(frames.device)), "trl_synth_frames_reset_u8")
+
+
+def gauss_explore(mean, logstd, eps, tanh_action, act=None, logp=None):
+    N, A = int(mean.shape[0]), int(mean.shape[1])
+    if act is None:
+        act = torch.empty((N, A), dtype=torch.float32, device=mean.device)
+    if logp is None:
+        logp = torch.empty((N,), dtype=torch.float32, device=mean.device)
+    check(lib().trl_gauss_explore_f32(dev_ptr(mean, name="mean"), dev_ptr(logstd, name="logstd"),
+                                      dev_ptr(eps, name="eps", allow_none=True), dev_ptr(act, name="act"),
+                                      dev_ptr(logp, name="logp"), N, A, int(bool(tanh_action)), stream_ptr(mean.device)),
+          "trl_gauss_explore_f32")
+    return act, logp
+
+
+def onpolicy_bookkeep(rewards, dones, v_next, discount, terminals, cur_step, ep_return, max_frames, mask, any_flag,
+                      epoch_reward, ep_count, ep_log, step):
+    N = int(rewards.numel())
+    check(lib().trl_onpolicy_bookkeep_f32(dev_ptr(rewards, name="rewards"), dev_ptr(dones, name="dones"),
+                                          dev_ptr(v_next, name="v_next"), float(discount), dev_ptr(terminals, name="terminals"),
+                                          dev_ptr(cur_step, torch.int32, "cur_step"), dev_ptr(ep_return, name="ep_return"),
+                                          int(max_frames), dev_ptr(mask, torch.uint8, "mask"),
+                                          dev_ptr(any_flag, torch.int32, "any_flag"),
+                                          dev_ptr(epoch_reward, torch.float64, "epoch_reward"),
+                                          dev_ptr(ep_count, torch.int32, "ep_count"), dev_ptr(ep_log, name="ep_log"),
+                                          int(ep_log.shape[0]), int(step), N, stream_ptr(rewards.device)),
+          "trl_onpolicy_bookkeep_f32")
+
+
+def select_on_flag(flag, a, b, out):
+    check(lib().trl_select_on_flag_f32(dev_ptr(flag, torch.int32, "flag"), dev_ptr(a, name="a"), dev_ptr(b, name="b"),
+                                       dev_ptr(out, name="out"), int(out.numel()), stream_ptr(out.device)),
+          "trl_select_on_flag_f32")
+    return out
+
+
+def norm_update_filt(x, state, out, clip, update):
+    """One vector step of the running observation normaliser: state (2D+1) fp64 = mean | var | count."""
+    N, D = int(x.shape[0]), int(x.shape[1])
+    check(lib().trl_norm_update_filt_f32(dev_ptr(x, name="x"), dev_ptr(state, torch.float64, "state"),
+                                         dev_ptr(out, name="out", allow_none=True), N, D, float(clip), int(bool(update)),
+                                         stream_ptr(x.device)), "trl_norm_update_filt_f32")
+    return out
+
+
+def norm_batch_moments(x, sums):
+    N, D = int(x.shape[0]), int(x.shape[1])
+    check(lib().trl_norm_batch_moments_f64(dev_ptr(x, name="x"), N, D, dev_ptr(sums, torch.float64, "sums"),
+                                           stream_ptr(x.device)), "trl_norm_batch_moments_f64")
+    return sums
+
+
+def norm_merge(state, sums, D):
+    check(lib().trl_norm_merge_f64(dev_ptr(state, torch.float64, "state"), dev_ptr(sums, torch.float64, "sums"), int(D),
+                                   stream_ptr(state.device)), "trl_norm_merge_f64")
+
+
+def norm_filt(x, state, out, clip):
+    N, D = int(x.shape[0]), int(x.shape[1])
+    check(lib().trl_norm_filt_f32(dev_ptr(x, name="x"), dev_ptr(state, torch.float64, "state"), dev_ptr(out, name="out"),
+                                  N, D, float(clip), stream_ptr(x.device)), "trl_norm_filt_f32")
+    return out

@@ -32,6 +32,8 @@ class BaseCollector:
         else:
             self.eval_env = copy.deepcopy(env)
         self.eval_env._reward_scale = 1
+        if hasattr(env, "_obs_normalizer"):                                 # collector/base.py:33-34
+            self.eval_env._obs_normalizer = env._obs_normalizer
         self.eval_episodes = eval_episodes
         self.eval_render = eval_render
         self.device = torch.device(device)

@@ -15,6 +15,8 @@ Exploration noise:
   * noise_mode="device": Philox4x32-10 in the kernel keyed by (env seed, global
     step) -- statistically equivalent, no host work; what bench.py uses.
 """
+import copy
+
 import numpy as np
 import torch
 
@@ -99,9 +101,78 @@ class VecOnPolicyCollector(VecCollector):
         draws = [torch.randn(env.env_nums, A) for _ in range(n_steps)]    # the reference's stream, step by step
         return torch.stack(draws).to(env.device, non_blocking=True).contiguous()
 
+    # ---- per-step launch sequence: envs with a running observation normaliser ----
+    def _step_buffers(self, env):
+        sb = getattr(self, "_sb", None)
+        if sb is None or sb["N"] != env.env_nums:
+            D, H, A, act = self._spec
+            N, dev = env.env_nums, env.device
+            f = lambda *shape: torch.empty(*shape, device=dev)
+            sb = self._sb = {"N": N, "mean": f(N, A), "eps": f(N, A), "nxt_raw": f(N, D), "v_next": f(N, 1),
+                             "done": f(N, 1), "any": torch.zeros(1, dtype=torch.int32, device=dev),
+                             # rows used when nothing is stored (evaluation)
+                             "obs": f(N, D), "next_obs": f(N, D), "acts": f(N, A), "values": f(N, 1), "rewards": f(N, 1),
+                             "terminals": f(N, 1), "time_limits": f(N, 1), "old_logp": f(N, 1)}
+        return sb
+
+    def _step_normed(self, env, ob, store, deterministic, noise_t, step, max_frames=None):
+        """One take_actions (torchrl/collector/on_policy.py:90-155) as ~12 launches; `ob` is what the policy
+        sees (normalised, or raw right after a reset -- the reference's Q14); returns the next policy input."""
+        D, H, A, act = self._spec
+        N, buf, sb, nz = env.env_nums, self.replay_buffer, self._step_buffers(env), env._obs_normalizer
+        if store:
+            row = buf._top
+            feats = (("obs", D), ("next_obs", D), ("acts", A), ("values", 1), ("rewards", 1), ("terminals", 1),
+                     ("time_limits", 1), ("old_logp", 1))
+            r = {k: buf._ensure_key(k, (N, w))[row] for k, w in feats}
+        else:
+            r = sb
+        r["obs"].copy_(ob)
+        mean = _C.mlp2_forward(self.pf.flat_params(), ob, D, H, A, act, out=sb["mean"])
+        _C.mlp2_forward(self.vf.flat_params(), ob, D, H, 1, act, out=r["values"])
+        if deterministic:
+            eps = None
+        elif noise_t is not None:
+            eps = noise_t
+        else:
+            eps = _C.philox_normal(sb["eps"], self._noise_seed, self.global_step)
+        _C.gauss_explore(mean, self.pf.logstd.detach(), eps, bool(self.pf.tanh_action), act=r["acts"],
+                         logp=r["old_logp"].view(N))
+        _C.synth_env_step(env.cur_obs, r["acts"], env.env_A, env.env_B, env.t_env, env.effective_reward_scale,
+                          env.horizon, sb["nxt_raw"], r["rewards"], sb["done"])
+        nz.update_filt(sb["nxt_raw"], update=env.training, out=r["next_obs"])          # NormObs.observation
+        _C.mlp2_forward(self.vf.flat_params(), r["next_obs"], D, H, 1, act, out=sb["v_next"])
+        r["time_limits"].copy_(sb["done"])                                            # synthetic env: time_limit == done
+        sb["any"].zero_()
+        _C.onpolicy_bookkeep(r["rewards"], sb["done"], sb["v_next"], self.discount, r["terminals"], env.cur_step,
+                             env.ep_return, self.max_episode_frames if max_frames is None else max_frames, self._mask,
+                             sb["any"], self._epoch_reward, self._ep_count, self._ep_log, step)
+        _C.synth_reset(env.cur_obs, env.t_env, env.cur_step, env.episode_idx, env.ep_return, self._mask, env.seed_base)
+        # partial_reset returns the RAW observations of all envs (base_wrapper.py:23-26, vecenv.py:47-51)
+        alt = nz.filt(env.cur_obs) if getattr(env, "normalize_partial_reset", False) else env.cur_obs
+        nxt = torch.empty(N, D, device=env.device)
+        _C.select_on_flag(sb["any"], alt, r["next_obs"], nxt)
+        if store:
+            buf._advance()
+        return nxt
+
+    def _rollout_normed(self, n_steps):
+        env = self.env
+        noise = self._host_noise(n_steps, env) if self.noise_mode == "host" else None
+        ob = torch.as_tensor(self.current_ob).to(device=env.device, dtype=torch.float32).contiguous()
+        self._clear_header()
+        for t in range(n_steps):
+            ob = self._step_normed(env, ob, True, False, None if noise is None else noise[t], t)
+            self.global_step += 1
+        self.current_ob = ob
+        buf = self.replay_buffer
+        buf._old_logp_fresh = (n_steps == buf._max_replay_buffer_size)
+
     def rollout(self, n_steps):
         """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""
         self.env.train()
+        if hasattr(self.env, "_obs_normalizer"):
+            return self._rollout_normed(n_steps)
         noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
         self._launch(self.env, n_steps, True, False, noise)
         self.global_step += n_steps
@@ -122,11 +193,18 @@ class VecOnPolicyCollector(VecCollector):
         """Greedy evaluation (torchrl/collector/base.py:232-280): every eval env plays its
         first episode with action = tanh(mean); nothing is written to the replay buffer."""
         env = self.eval_env
+        if hasattr(self.env, "_obs_normalizer"):                           # collector/base.py:236-237
+            env._obs_normalizer = copy.deepcopy(self.env._obs_normalizer)
         env.eval()
         rews, lens = [], []
         for _ in range(self.eval_episodes):
-            env.reset()
-            self._launch(env, env.horizon, False, True, None, max_frames=2 ** 31 - 1)
+            ob = env.reset()
+            if hasattr(env, "_obs_normalizer"):
+                self._clear_header()
+                for t in range(env.horizon):
+                    ob = self._step_normed(env, ob, False, True, None, t, max_frames=2 ** 31 - 1)
+            else:
+                self._launch(env, env.horizon, False, True, None, max_frames=2 ** 31 - 1)
             log = self._finished_episodes()
             first = {}
             for step, idx, ret in log:

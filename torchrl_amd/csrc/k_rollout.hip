@@ -522,3 +522,109 @@ extern "C" int trl_gauss_logp_f32(const float* mean, const float* acts, const fl
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
+
+// ---------------------------------------------------------------- per-step on-policy collection
+// The pieces of VecOnPolicyCollector.take_actions (torchrl/collector/on_policy.py:90-155) as stand-alone
+// kernels, for environments the persistent rollout kernel cannot carry: with a running observation
+// normaliser (NormObs) every step needs batch statistics over ALL envs before the next policy forward.
+
+// pf.explore + log-prob for a state-independent-std Gaussian policy (continuous_policy.py:123-129, 180-188)
+__global__ __launch_bounds__(256) void gauss_explore_kernel(const float* __restrict__ mean, const float* __restrict__ logstd,
+                                                            const float* __restrict__ eps, float* __restrict__ act,
+                                                            float* __restrict__ logp, int N, int A, int tanh_action) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float lp = 0.0f;
+  for (int o = 0; o < A; ++o) {
+    const float ls = fminf(fmaxf(logstd[o], -20.0f), 2.0f);
+    const float m = mean[(size_t)n * A + o];
+    const float z = fmaf(__expf(ls), eps ? eps[(size_t)n * A + o] : 0.0f, m);
+    const float a = tanh_action ? trl_tanh(z) : z;
+    act[(size_t)n * A + o] = a;
+    float zc;
+    lp += gauss_logp_term(a, m, __expf(-2.0f * ls), ls, tanh_action, zc);
+  }
+  if (logp) logp[n] = lp;
+}
+
+extern "C" int trl_gauss_explore_f32(const float* mean, const float* logstd, const float* eps, float* act, float* logp,
+                                     int N, int A, int tanh_action, void* stream) {
+  TRL_REQUIRE(N >= 0 && A > 0, "bad sizes");
+  if (N == 0) return TRL_OK;
+  TRL_REQUIRE(mean && logstd && act, "null pointer");
+  hipLaunchKernelGGL(gauss_explore_kernel, dim3(trl_ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, mean, logstd,
+                     eps, act, logp, N, A, tanh_action);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// bookkeeping after env.step (on_policy.py:124-148): epoch reward, running returns (logged and cleared on done),
+// over-length bootstrap r += discount * V(next_obs) * surpass, terminals = done | surpass = reset mask, and a
+// device-side "any env flagged" word for the caller's choice of the next policy input (partial_reset, :145-147)
+__global__ __launch_bounds__(256) void onpolicy_bookkeep_kernel(float* __restrict__ rew, const float* __restrict__ done,
+                                                                const float* __restrict__ v_next, float discount,
+                                                                float* __restrict__ terminals, int32_t* __restrict__ cur_step,
+                                                                float* __restrict__ ep_return, int max_frames,
+                                                                uint8_t* __restrict__ mask, int32_t* __restrict__ any_flag,
+                                                                double* __restrict__ epoch_reward, int32_t* __restrict__ ep_count,
+                                                                float* __restrict__ ep_log, int ep_cap, int step, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  double r = 0.0;
+  bool flag = false;
+  if (n < N) {
+    const float raw = rew[n];
+    r = (double)raw;
+    const bool d = done[n] != 0.0f;
+    const int cs = cur_step[n] + 1;
+    float er = ep_return[n] + raw;
+    if (d) {
+      const int slot = atomicAdd(ep_count, 1);
+      if (slot < ep_cap) { ep_log[slot * 3 + 0] = (float)step; ep_log[slot * 3 + 1] = (float)n; ep_log[slot * 3 + 2] = er; }
+      er = 0.0f;
+    }
+    const bool surpass = cs >= max_frames;
+    flag = d || surpass;
+    rew[n] = raw + discount * v_next[n] * (surpass ? 1.0f : 0.0f);
+    terminals[n] = flag ? 1.0f : 0.0f;
+    cur_step[n] = flag ? 0 : cs;
+    ep_return[n] = er;
+    mask[n] = flag ? 1 : 0;
+  }
+  const double tot = wave_sum(r);
+  if ((threadIdx.x & 63) == 0 && epoch_reward && tot != 0.0) atomicAdd(epoch_reward, tot);
+  if (__ballot(flag) != 0ull && (threadIdx.x & 63) == 0) atomicOr(any_flag, 1);
+}
+
+extern "C" int trl_onpolicy_bookkeep_f32(float* rewards, const float* dones, const float* v_next, float discount,
+                                         float* terminals, int32_t* cur_step, float* ep_return, int max_episode_frames,
+                                         uint8_t* reset_mask, int32_t* any_flag, double* epoch_reward, int32_t* ep_count,
+                                         float* ep_log, int ep_cap, int step, int N, void* stream) {
+  TRL_REQUIRE(N >= 0 && ep_cap >= 0, "bad sizes");
+  if (N == 0) return TRL_OK;
+  TRL_REQUIRE(rewards && dones && v_next && terminals && cur_step && ep_return && reset_mask && any_flag && ep_count && ep_log,
+              "null pointer");
+  hipLaunchKernelGGL(onpolicy_bookkeep_kernel, dim3(trl_ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, rewards,
+                     dones, v_next, discount, terminals, cur_step, ep_return, max_episode_frames, reset_mask, any_flag,
+                     epoch_reward, ep_count, ep_log, ep_cap, step, N);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// out = (*flag != 0) ? a : b, elementwise -- the flag stays on the device (no host round trip per step)
+__global__ __launch_bounds__(256) void select_on_flag_kernel(const int32_t* __restrict__ flag, const float* __restrict__ a,
+                                                             const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+  const bool f = *flag != 0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) out[e] = f ? a[e] : b[e];
+}
+
+extern "C" int trl_select_on_flag_f32(const int32_t* flag, const float* a, const float* b, float* out, int64_t n,
+                                      void* stream) {
+  TRL_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TRL_OK;
+  TRL_REQUIRE(flag && a && b && out, "null pointer");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(select_on_flag_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, flag, a, b, out, n);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
