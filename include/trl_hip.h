@@ -152,6 +152,8 @@ int trl_gauss_logp_f32(const float* mean, const float* acts, const float* logstd
  * (distribution.py:33-45, 78-79), ratio / clip / min surrogate, and the
  * backward pass of both MLPs on fp32 MFMA.  Writes per-workgroup partial
  * gradients; trl_ppo_reduce_f32 folds them. */
+#define TRL_LOSS_PPO_CLIP 0
+#define TRL_LOSS_A2C      1
 typedef struct trl_ppo_batch_t {
   const float *obs, *acts, *advs, *rets, *old_values, *old_logp;  /* (rows, N, feat) */
   const int64_t* row_idx;     /* (rows_mb) time rows of this minibatch, or NULL = rows 0.. */
@@ -162,6 +164,8 @@ typedef struct trl_ppo_batch_t {
   int D, H, A, act;
   float clip_para, entropy_coeff;
   int clipped_value_loss, tanh_action;
+  int loss_mode;              /* TRL_LOSS_PPO_CLIP: ratio / clip / min surrogate (ppo.py:41-91);
+                                 TRL_LOSS_A2C: -mean(log pi * adv) (a2c.py:69-70; old_logp may be NULL) */
   float* partial;             /* (n_wg, P_STRIDE) fp32 workspace */
   double* scal_partial;       /* (n_wg, 8) */
   int n_wg;                   /* workgroups launched (>= 2); rows of partial / scal_partial */
@@ -172,10 +176,13 @@ int trl_ppo_partial_stride(int D, int H, int A);
 /* balanced policy / value split of n_wg workgroups for n_tiles = ceil(samples / 16) tiles */
 int trl_ppo_wg_split(int D, int H, int A, int n_tiles, int n_wg);
 int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* args, void* stream);
-/* grads: flat [pf grads (P_pf) | vf grads (P_vf)].  info: (16) doubles =
- *  0 sum_j -min(s1,s2)   1 sum logp   2 sum logp^2   3 max logp   4 -min logp
+/* grads: flat [pf grads (P_pf) | vf grads (P_vf)].  info: (24) doubles =
+ *  0 sum_j -min(s1,s2) (A2C: sum_j -logp*adv)   1 sum logp   2 sum logp^2   3 max logp   4 -min logp
  *  5 max ratio   6 -min ratio   7 value-loss sum (local samples; divide by the count)
  *  8..11 mean / unbiased std / max / min of the clamped logstd (ppo.py:82-85)
+ *  12..15 sum / sum of squares / max / -min of the value prediction (a2c.py:89-92)
+ *  16..19 mean / unbiased std over the A dims / max / min of std = exp(clamped logstd) (a2c.py:95-100)
+ *  20..23 unused
  * pf_params may be NULL (then 8..11 are left untouched). */
 int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
                        int D, int H, int A, const float* pf_params, float* grads, double* info,

@@ -143,3 +143,39 @@ class PPOOracle:
             for _idx, batch in ring.epoch_minibatches(self.batch_size, keys, self.shuffle):
                 infos.append(self.update(batch))
         return infos
+
+
+class A2COracle(PPOOracle):
+    """A2C.update (torchrl/algo/on_policy/a2c.py:45-106) and OnRLAlgo.update_per_epoch
+    (on_rl_algo.py:35-40): L_pi = -mean(log pi * adv_normalised) - c_ent * mean(ent), policy step, then
+    L_v = MSE(V, R), value step; each with clip_grad_norm_(0.5) and Adam(eps=1e-5)."""
+
+    def update(self, batch):
+        f32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32)
+        obs, acts = f32(batch["obs"]), f32(batch["acts"])
+        advs, rets = f32(batch["advs"]), f32(batch["estimate_returns"])
+        out = nets.policy_update_terms(obs, acts, self.pf, self.logstd, self.act, self.tanh_action)
+        lp, ent, std = out["log_prob"], out["ent"], out["std"]
+        advs = (advs - advs.mean()) / (advs.std() + 1e-5)
+        pl = (-lp * advs).mean() - self.entropy_coeff * ent.mean()
+        v = nets.mlp(obs, self.vf, self.act)
+        vf_loss = ((v - rets) ** 2).mean()
+        g = torch.autograd.grad(pl, self.pf + [self.logstd])
+        g, _ = clip_global_norm(g, 0.5)
+        self.pf_opt.step(self.pf + [self.logstd], g)
+        g = torch.autograd.grad(vf_loss, self.vf)
+        g, _ = clip_global_norm(g, 0.5)
+        self.vf_opt.step(self.vf, g)
+        return {"Training/policy_loss": pl.item(), "Training/vf_loss": vf_loss.item(),
+                "v_pred/mean": v.mean().item(), "v_pred/std": v.std().item(),
+                "v_pred/max": v.max().item(), "v_pred/min": v.min().item(),
+                "std/mean": std.mean().item(), "std/std": std.std().item(),
+                "std/max": std.max().item(), "std/min": std.min().item(),
+                "ent": ent.mean().item(), "log_prob": lp.mean().item()}
+
+    def epoch(self, ring, current_epoch=0):
+        self.process_epoch_samples(ring)
+        infos = []
+        for _idx, batch in ring.epoch_minibatches(self.batch_size, ["obs", "acts", "advs", "estimate_returns"], self.shuffle):
+            infos.append(self.update(batch))
+        return infos

@@ -446,6 +446,37 @@ def case_dqn():
     save("dqn", **out)
 
 
+def case_a2c_update():
+    """A2C.update (a2c.py:45-106) on random batches: info dict + post-step params, two consecutive steps."""
+    import gym
+    from torchrl.algo import A2C
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    for tag, B in (("small", 64), ("mid", 2048)):
+        D, A, H = 17, 6, 64
+        pf, vf = build_nets(D, A, H, seed=11)
+        env = SynthVecEnvCPU(4)
+        env.action_space = gym.spaces.Box(-1, 1, (A,))
+        agent = A2C(pf=pf, vf=vf, plr=3e-4, vlr=1e-3, entropy_coeff=0.01, tau=0.95, shuffle=True, discount=0.99,
+                    num_epochs=10, batch_size=B, gae=True, env=env, replay_buffer=None, collector=_StubCollector(),
+                    logger=NullLogger(), device=torch.device("cpu"), save_dir=tempfile.mkdtemp(prefix="trl_save_"))
+        rs = np.random.RandomState(21)
+        batch = {"obs": rs.randn(B, D).astype(np.float32),
+                 "acts": np.tanh(rs.randn(B, A)).astype(np.float32) * 0.98,
+                 "advs": rs.randn(B, 1).astype(np.float32) * 2 + 0.5,
+                 "estimate_returns": rs.randn(B, 1).astype(np.float32)}
+        out.update({f"{tag}_batch_{k}": v for k, v in batch.items()})
+        out.update(state_arrays(f"{tag}_pf0_", pf))
+        out.update(state_arrays(f"{tag}_vf0_", vf))
+        for s_ in range(2):
+            info = agent.update(batch)
+            out[f"{tag}_info{s_}_keys"] = np.array(sorted(info.keys()))
+            out[f"{tag}_info{s_}_vals"] = np.array([info[k] for k in sorted(info.keys())], dtype=np.float64)
+            out.update(state_arrays(f"{tag}_pf{s_ + 1}_", pf))
+            out.update(state_arrays(f"{tag}_vf{s_ + 1}_", vf))
+    save("a2c_update", **out)
+
+
 def case_obs_norm():
     """Running observation normaliser (env/base_wrapper.py:44-121): Normalizer.update_estimate / filt on a
     sequence of batches, and NormObs wrapped around the synthetic vector env under
@@ -509,7 +540,7 @@ def case_obs_norm():
 
 CASES = {"gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
-         "obs_norm": case_obs_norm}
+         "obs_norm": case_obs_norm, "a2c_update": case_a2c_update}
 
 if __name__ == "__main__":
     install_stubs()

@@ -108,7 +108,7 @@ def test_full_size_minibatch_gradient_partition_invariance():
         scal = torch.zeros(n_wg, 8, dtype=torch.float64, device=DEV)
         g.partial, g.scal_partial, g.n_wg = partial.data_ptr(), scal.data_ptr(), n_wg
         _C.ppo_minibatch_grad(g, DEV)
-        out, info = torch.zeros_like(eng.grads), torch.zeros(16, dtype=torch.float64, device=DEV)
+        out, info = torch.zeros_like(eng.grads), torch.zeros(24, dtype=torch.float64, device=DEV)
         _C.ppo_reduce(partial, scal, n_wg, 17, 64, 6, out, info, eng.flat)
         return out, info
     g256, i256 = grad(t, N, 256, B)

@@ -350,7 +350,7 @@ class DevicePPO:
         ps = _C.ppo_partial_stride(17, 64, 6)
         self.partial = torch.zeros(n_wg, ps, device=DEV)
         self.scal = torch.zeros(n_wg, 8, dtype=torch.float64, device=DEV)
-        self.info = torch.zeros(16, dtype=torch.float64, device=DEV)
+        self.info = torch.zeros(24, dtype=torch.float64, device=DEV)
         self.norms = torch.zeros(2, device=DEV)
         self.t = 0
 

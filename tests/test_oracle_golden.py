@@ -289,3 +289,22 @@ def test_normobs_collect_oracle_matches_reference(golden, tag):
     np.testing.assert_allclose(env._obs_normalizer.state(), g[tag + "_state1"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(col.current_ob, g[tag + "_current_ob"], atol=3e-6)
     np.testing.assert_allclose(res["train_epoch_reward"], g[tag + "_train_epoch_reward"], atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["small", "mid"])
+def test_a2c_update_oracle_matches_reference(golden, tag):
+    from oracle.ppo import A2COracle
+    g = golden("a2c_update")
+    pf, ls = params_from(g, f"{tag}_pf0_", True)
+    vf, _ = params_from(g, f"{tag}_vf0_", False)
+    o = A2COracle(pf, ls, vf, plr=3e-4, vlr=1e-3, entropy_coeff=0.01)
+    batch = {k: g[f"{tag}_batch_{k}"] for k in ("obs", "acts", "advs", "estimate_returns")}
+    for s in range(2):
+        info = o.update(batch)
+        keys = [str(k) for k in g[f"{tag}_info{s}_keys"]]
+        assert sorted(info.keys()) == keys
+        np.testing.assert_allclose([info[k] for k in keys], g[f"{tag}_info{s}_vals"], rtol=2e-5, atol=2e-6)
+        want_pf, want_ls = params_from(g, f"{tag}_pf{s + 1}_", True)
+        want_vf, _ = params_from(g, f"{tag}_vf{s + 1}_", False)
+        for a, b in zip(o.pf + [o.logstd] + o.vf, want_pf + [want_ls] + want_vf):
+            np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=1e-6)

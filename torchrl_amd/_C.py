@@ -48,6 +48,9 @@ class RolloutArgs(C.Structure):
     ]
 
 
+LOSS_PPO_CLIP, LOSS_A2C = 0, 1                                   # TRL_LOSS_* of include/trl_hip.h
+
+
 class PpoBatchArgs(C.Structure):
     _fields_ = [
         ("obs", C.c_void_p), ("acts", C.c_void_p), ("advs", C.c_void_p), ("rets", C.c_void_p),
@@ -57,7 +60,7 @@ class PpoBatchArgs(C.Structure):
         ("pf_params", C.c_void_p), ("vf_params", C.c_void_p),
         ("D", C.c_int), ("H", C.c_int), ("A", C.c_int), ("act", C.c_int),
         ("clip_para", C.c_float), ("entropy_coeff", C.c_float),
-        ("clipped_value_loss", C.c_int), ("tanh_action", C.c_int),
+        ("clipped_value_loss", C.c_int), ("tanh_action", C.c_int), ("loss_mode", C.c_int),
         ("partial", C.c_void_p), ("scal_partial", C.c_void_p), ("n_wg", C.c_int), ("n_wg_pf", C.c_int),
     ]
 

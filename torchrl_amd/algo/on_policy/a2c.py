@@ -1,11 +1,19 @@
-"""A2C base: owns policy / value nets and their two Adam(eps=1e-5) optimisers
-(torchrl/algo/on_policy/a2c.py:8-43).  The optimiser objects are kept for their
-`param_groups` (the linear LR schedule writes there) and `state_dict`; the step
-itself is done by trl_clip_adam_f32 on flat buffers that the optimiser state
-aliases.  A2C's own un-clipped update is not on this repo's hot path."""
+"""A2C (torchrl/algo/on_policy/a2c.py:8-112): policy / value nets, their two Adam(eps=1e-5) optimisers and
+the un-clipped actor-critic update.  The optimiser objects are kept for their `param_groups` (the linear LR
+schedule writes there) and `state_dict`; the step itself is done by the fused engine on flat buffers that
+the optimiser state aliases.
+
+`update(batch)` = the PPO launch sequence with `loss_mode = TRL_LOSS_A2C`:
+L_pi = -mean(log pi(a|s) * adv_normalised) - c_ent * mean(ent), L_v = MSE(V(s), R)   (a2c.py:61-75),
+clip_grad_norm_(0.5) + Adam for each net.  `update_per_epoch` keeps the reference's loop
+(on_rl_algo.py:35-40: one pass of `one_iteration` minibatches) but runs it through the minibatch row
+indices on the device-resident buffer instead of materialising batches."""
+import numpy as np
+import torch
 import torch.nn as nn
 import torch.optim as optim
 
+from ... import _C
 from .on_rl_algo import OnRLAlgo
 
 
@@ -23,8 +31,36 @@ class A2C(OnRLAlgo):
         self.entropy_coeff = entropy_coeff
         self.vf_criterion = nn.MSELoss()
 
+    loss_mode = _C.LOSS_A2C
+
+    def engine(self):
+        if getattr(self, "_engine", None) is None:
+            from .ppo import _FusedPPO
+            self._engine = _FusedPPO(self)
+        return self._engine
+
+    def update_per_epoch(self):
+        self.process_epoch_samples()
+        buf = self.replay_buffer
+        row_idx = buf.epoch_row_indices(self.batch_size, self.shuffle)      # one pass (on_rl_algo.py:37-40)
+        tensors = {"obs": buf._obs, "acts": buf._acts, "advs": buf._advs, "rets": buf._estimate_returns,
+                   "old_values": None, "old_logp": None}
+        infos = self.engine().run(tensors, row_idx, buf.env_nums)
+        self.training_update_num += len(infos)
+        for info in infos:
+            self.logger.add_update_info(info)
+
     def update(self, batch):
-        raise NotImplementedError("A2C.update (a2c.py:45-106) is not on the accelerated path of this build; use PPO")
+        self.training_update_num += 1
+        dev = self.device
+        as_t = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
+            .to(device=dev, dtype=torch.float32).contiguous()
+        obs, acts = as_t(batch['obs']), as_t(batch['acts'])
+        B = obs.shape[0]
+        tensors = {"obs": obs.reshape(1, B, -1), "acts": acts.reshape(1, B, -1),
+                   "advs": as_t(batch['advs']).reshape(1, B, 1), "rets": as_t(batch['estimate_returns']).reshape(1, B, 1),
+                   "old_values": None, "old_logp": None}
+        return self.engine().run(tensors, np.zeros((1, 1), dtype=np.int64), B)[0]
 
     @property
     def snapshot_networks(self):

@@ -33,6 +33,8 @@ _HALF_LOG_2PI_PLUS_HALF = 0.5 + 0.5 * math.log(2 * math.pi)
 
 
 class PPO(A2C):
+    loss_mode = _C.LOSS_PPO_CLIP
+
     def __init__(self, pf, clip_para=0.2, opt_epochs=10, clipped_value_loss=False, **kwargs):
         self.target_pf = copy.deepcopy(pf)
         super().__init__(pf=pf, **kwargs)
@@ -176,22 +178,25 @@ class _FusedPPO:
         n_global = float(n_local * world)
         idx_dev = torch.from_numpy(np.ascontiguousarray(row_idx)).to(dev)
         rows_total = t["advs"].shape[0]
-        # one statistics buffer (one memset, one D2H at the end): raw (K,4) f64 | info (K,16) f64 | norms (K,2) f32
-        stats = torch.zeros(21 * K, dtype=torch.float64, device=dev)
-        raw, info = stats[:4 * K].view(K, 4), stats[4 * K:20 * K].view(K, 16)
-        norms = stats[20 * K:].view(torch.float32).view(K, 2)
+        # one statistics buffer (one memset, one D2H at the end): raw (K,4) f64 | info (K,24) f64 | norms (K,2) f32
+        stats = torch.zeros(29 * K, dtype=torch.float64, device=dev)
+        raw, info = stats[:4 * K].view(K, 4), stats[4 * K:28 * K].view(K, 24)
+        norms = stats[28 * K:].view(torch.float32).view(K, 2)
         _C.adv_stats(t["advs"].reshape(rows_total, N), idx_dev, raw)
         dist.reduce_adv_raw_(raw)
         n_wg, n_wg_pf = self._n_wg(n_local)
 
         g = _C.PpoBatchArgs()
+        loss_mode = int(getattr(algo, "loss_mode", _C.LOSS_PPO_CLIP))
         for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"):
-            setattr(g, k, _C.dev_ptr(t[k], name=k).value)
+            setattr(g, k, _C.dev_ptr(t[k], name=k).value if t.get(k) is not None else None)
+        g.loss_mode = loss_mode
         g.rows_mb, g.N, g.n_global = rows_mb, N, n_global
         g.pf_params, g.vf_params = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.P_pf
         g.D, g.H, g.A, g.act = self.D, self.H, self.A, self.act
-        g.clip_para, g.entropy_coeff = float(algo.clip_para), float(algo.entropy_coeff)
-        g.clipped_value_loss, g.tanh_action = int(bool(algo.clipped_value_loss)), int(bool(algo.pf.tanh_action))
+        g.clip_para, g.entropy_coeff = float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff)
+        g.clipped_value_loss = int(bool(getattr(algo, "clipped_value_loss", False)))
+        g.tanh_action = int(bool(algo.pf.tanh_action))
         g.partial, g.scal_partial, g.n_wg, g.n_wg_pf = self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf
 
         a = _C.AdamArgs()
@@ -223,21 +228,39 @@ class _FusedPPO:
             a.norms_out = norm_base + 8 * k
             if fused:                                                  # one process: reduce + clip + Adam in one launch
                 _C.check(lib.trl_ppo_reduce_adam_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf,
-                                                     self.D, self.H, self.A, self.grads.data_ptr(), info_base + 128 * k,
+                                                     self.D, self.H, self.A, self.grads.data_ptr(), info_base + 192 * k,
                                                      C.byref(a), self.red_ws.data_ptr(), stream),
                          "trl_ppo_reduce_adam_f32")
                 continue
             _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf, self.D, self.H,
                                             self.A, self.flat.data_ptr(), self.grads.data_ptr(),
-                                            info_base + 128 * k, stream), "trl_ppo_reduce_f32")
+                                            info_base + 192 * k, stream), "trl_ppo_reduce_f32")
             dist.all_reduce_sum_(self.grads)                           # C1: gradient SUM over ranks
             _C.check(lib.trl_clip_adam_f32(C.byref(a), stream), "trl_clip_adam_f32")
         for s in self._opt_steps:
             s.fill_(float(self.step_count))
         dist.reduce_info_(info)
         host = stats.cpu()                                             # the only host sync of the update
-        return self._infos(host[:4 * K].view(K, 4).numpy(), host[4 * K:20 * K].view(K, 16).numpy(),
-                           host[20 * K:].view(torch.float32).view(K, 2).numpy(), n_global)
+        make = self._infos_a2c if loss_mode == _C.LOSS_A2C else self._infos
+        return make(host[:4 * K].view(K, 4).numpy(), host[4 * K:28 * K].view(K, 24).numpy(),
+                    host[28 * K:].view(torch.float32).view(K, 2).numpy(), n_global)
+
+    def _infos_a2c(self, raw, info, norms, n):
+        """The info dict of A2C.update (a2c.py:86-105); `std` is (B, A) there, each dim repeated B times."""
+        out = []
+        c_ent = float(self.algo.entropy_coeff)
+        A = self.A
+        for r, i, g in zip(raw, info, norms):
+            v_var = max((i[13] - i[12] * i[12] / n) / (n - 1), 0.0)
+            ent = A * _HALF_LOG_2PI_PLUS_HALF + A * i[8]
+            std_ss = (i[17] ** 2) * (A - 1) if A > 1 else 0.0            # sum over dims of (std - mean)^2
+            out.append({
+                'Training/policy_loss': i[0] / n - c_ent * ent, 'Training/vf_loss': i[7] / n,
+                'v_pred/mean': i[12] / n, 'v_pred/std': math.sqrt(v_var), 'v_pred/max': i[14], 'v_pred/min': -i[15],
+                'std/mean': i[16], 'std/std': math.sqrt(n * std_ss / (n * A - 1)), 'std/max': i[18], 'std/min': i[19],
+                'ent': ent, 'log_prob': i[1] / n,
+            })
+        return out
 
     def _infos(self, raw, info, norms, n):
         out = []

@@ -31,6 +31,7 @@ struct PpoDev {
   const float *pf_params, *vf_params;
   float clip_para, entropy_coeff;
   int clipped_value_loss, tanh_action;
+  int loss_mode;                              // TRL_LOSS_PPO_CLIP (ppo.py:41-91) or TRL_LOSS_A2C (a2c.py:45-75)
   float* partial;
   double* scal_partial;
   int n_wg, n_pf, p_stride;                  // workgroups [0, n_pf) run the policy, [n_pf, n_wg) the value net
@@ -200,7 +201,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     if constexpr (IS_PF) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) lq[r] = a.acts[p * O + (4 * g + r < O ? 4 * g + r : 0)];
-      lq[4] = a.advs[p]; lq[5] = a.old_logp[p];
+      lq[4] = a.advs[p]; lq[5] = a.old_logp ? a.old_logp[p] : 0.0f;
     } else {
       lq[0] = lq[1] = lq[2] = lq[3] = 0.0f;
       lq[4] = a.rets[p]; lq[5] = a.clipped_value_loss ? a.old_values[p] : 0.0f;
@@ -295,10 +296,17 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       }
       lp += __shfl_xor(lp, 16, 64);                                // outputs 0..3 (g = 0) + 4..7 (g = 1)
       const float advn = valid ? (lin[4] - adv_mu) * adv_rstd : 0.0f;
-      const float ratio = __expf(lp - lin[5]);
-      const float s1 = ratio * advn;
-      const float s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
-      const float g_lp = (valid && g < 2 && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
+      float ratio, s1, s2, g_lp;
+      if (a.loss_mode == TRL_LOSS_A2C) {                            // L = -mean(log pi * adv) (a2c.py:69-70)
+        ratio = 1.0f;
+        s1 = s2 = lp * advn;
+        g_lp = (valid && g < 2) ? -advn * inv_b : 0.0f;
+      } else {                                                     // clipped surrogate (ppo.py:58-66)
+        ratio = __expf(lp - lin[5]);
+        s1 = ratio * advn;
+        s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
+        g_lp = (valid && g < 2 && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
+      }
       float dout[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -355,7 +363,10 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
         dv = 2.0f * (v - R) * inv_b;
       }
       dv = valid ? dv : 0.0f;
-      if (valid && g == 0) { stv[6] += l; db3[0] += dv; }
+      if (valid && g == 0) {
+        stv[6] += l; db3[0] += dv;
+        stv[0] += v; stv[1] = fmaf(v, v, stv[1]); stv[2] = fmaxf(stv[2], v); stv[3] = fmaxf(stv[3], -v);   // v_pred/*
+      }
 #pragma unroll
       for (int so = 0; so < 4; ++so)
 #pragma unroll
@@ -576,9 +587,20 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
           info[8] = mean;
           info[9] = n_act > 1 ? sqrt(fmax((sq - sm * mean) / (n_act - 1), 0.0)) : NAN;
           info[10] = mx; info[11] = mn;
+          // the same four for std = exp(clamped logstd) (a2c.py:95-100 logs std/*)
+          double es = 0, eq = 0, emx = -INFINITY, emn = INFINITY;
+          for (int o = 0; o < n_act; ++o) {
+            const double x = exp(fmin(fmax((double)logstd[o], -20.0), 2.0));
+            es += x; eq += x * x; emx = fmax(emx, x); emn = fmin(emn, x);
+          }
+          const double em = es / n_act;
+          info[16] = em;
+          info[17] = n_act > 1 ? sqrt(fmax((eq - es * em) / (n_act - 1), 0.0)) : NAN;
+          info[18] = emx; info[19] = emn;
         }
       } else {
         info[7] = v[6];
+        info[12] = v[0]; info[13] = v[1]; info[14] = v[2]; info[15] = v[3];   // v_pred: sum, sum of squares, max, -min
       }
     }
   }
@@ -796,7 +818,10 @@ static int resolve_pf_wgs(int n_wg, int n_wg_pf) { return n_wg_pf > 0 ? n_wg_pf 
 
 extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream) {
   if (!p) { trl_set_error("ppo_grad: null descriptor"); return TRL_EINVAL; }
-  TRL_REQUIRE(p->obs && p->acts && p->advs && p->rets && p->old_values && p->old_logp, "null rollout tensor");
+  TRL_REQUIRE(p->obs && p->acts && p->advs && p->rets, "null rollout tensor");
+  TRL_REQUIRE(p->loss_mode == TRL_LOSS_PPO_CLIP || p->loss_mode == TRL_LOSS_A2C, "unknown loss_mode");
+  TRL_REQUIRE(p->loss_mode == TRL_LOSS_A2C || p->old_logp, "the clipped surrogate needs old_logp");
+  TRL_REQUIRE(!p->clipped_value_loss || p->old_values, "the clipped value loss needs old_values");
   TRL_REQUIRE(p->adv_raw && p->pf_params && p->vf_params && p->partial && p->scal_partial, "null pointer");
   TRL_REQUIRE(p->rows_mb > 0 && p->N > 0, "empty minibatch");
   TRL_REQUIRE(p->n_wg >= 2, "n_wg must be >= 2");
@@ -808,7 +833,7 @@ extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream
   d.old_logp = p->old_logp; d.row_idx = p->row_idx; d.rows_mb = p->rows_mb; d.N = p->N;
   d.adv_raw = p->adv_raw; d.n_global = p->n_global; d.pf_params = p->pf_params; d.vf_params = p->vf_params;
   d.clip_para = p->clip_para; d.entropy_coeff = p->entropy_coeff;
-  d.clipped_value_loss = p->clipped_value_loss; d.tanh_action = p->tanh_action;
+  d.clipped_value_loss = p->clipped_value_loss; d.tanh_action = p->tanh_action; d.loss_mode = p->loss_mode;
   d.partial = p->partial; d.scal_partial = p->scal_partial; d.n_wg = p->n_wg;
   d.n_pf = resolve_pf_wgs(p->n_wg, p->n_wg_pf);
   hipStream_t s = (hipStream_t)stream;
