@@ -260,7 +260,17 @@ int trl_sac_losses_f32(const float* q1, const float* q2, const float* tq1, const
                        const float* q1n, const float* q2n, const float* logp, const float* alpha,
                        float gamma, int B, float* dq1, float* dq2, float* dq1n, float* dq2n,
                        double* sums, void* stream);
-/* out (rows, A) = x1[:, off:off+A] + x2[:, off:off+A]  (d policy_loss / d action through both Q nets) */
+/* DDPG / TD3 (torchrl/algo/off_policy/ddpg.py:42-110, td3.py:57-154): TD target with Q' = tq1 or
+ * min(tq1, tq2) (tq2 NULL: single critic), MSE of one or two critics + output gradients; with qn also the
+ * policy loss -mean(Q(s, pi(s))) and dqn = -1/B.  sums (4 doubles): q1 loss sum, q2 loss sum, sum(-qn), sum(r) */
+int trl_detac_losses_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
+                         const float* rewards, const float* terminals, const float* qn, float gamma, int B,
+                         float* dq1, float* dq2, float* dqn, double* sums, void* stream);
+/* out = clamp(act + clamp(sigma * eps, +-noise_clip), lo, hi): FixGuassianContPolicy.explore
+ * (continuous_policy.py:67-74) and TD3's target-policy smoothing (td3.py:75-82) */
+int trl_noisy_action_f32(const float* act, const float* eps, float sigma, float noise_clip, float lo, float hi,
+                         float* out, int64_t n, void* stream);
+/* out (rows, A) = x1[:, off:off+A] + x2[:, off:off+A]  (d policy_loss / d action through both Q nets; x2 may be NULL) */
 int trl_slice_add_f32(const float* x1, const float* x2, float* out, int rows, int ld, int off, int A,
                       void* stream);
 /* K13: target <- (1 - tau) target + tau source  (torchrl/algo/utils.py:16-20) */

@@ -477,6 +477,63 @@ def case_a2c_update():
     save("a2c_update", **out)
 
 
+def case_ddpg_td3():
+    """DDPG.update (ddpg.py:42-110) and TD3.update (td3.py:57-154) on random batches with FixGuassianContPolicy:
+    info dicts, the N(0,1) draws TD3 consumes, post-update online and target parameters."""
+    import gym
+    import torchrl.policies as policies
+    import torchrl.networks as networks
+    from torchrl.algo import DDPG, TD3
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    D, A, H, B = 17, 6, 64, 96
+    common = dict(replay_buffer=None, collector=_StubCollector(), logger=NullLogger(), discount=0.99, num_epochs=10,
+                  batch_size=B, device=torch.device("cpu"), tau=0.005, use_soft_update=True, opt_times=1)
+    for tag, clip in (("ddpg", None), ("ddpg_clip", 1.0), ("td3", None), ("td3_clip", 0.5)):
+        torch.manual_seed(41)
+        net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+        pf = policies.FixGuassianContPolicy(input_shape=D, output_shape=A, tanh_action=True, norm_std_explore=0.1, **net)
+        qf1 = networks.QNet(input_shape=D + A, output_shape=1, **net)
+        qf2 = networks.QNet(input_shape=D + A, output_shape=1, **net)
+        env = SynthVecEnvCPU(4)
+        env.action_space = gym.spaces.Box(-1, 1, (A,))
+        kw = dict(common, env=env, grad_clip=clip, save_dir=tempfile.mkdtemp(prefix="trl_save_"))
+        if tag.startswith("ddpg"):
+            agent = DDPG(pf=pf, qf=qf1, plr=3e-4, qlr=1e-3, **kw)
+            mods = (("pf", pf), ("qf1", qf1))
+            tmods = (("tpf", agent.target_pf), ("tqf1", agent.target_qf))
+        else:
+            agent = TD3(pf=pf, qf1=qf1, qf2=qf2, plr=3e-4, qlr=1e-3, policy_update_delay=2, norm_std_policy=0.2,
+                        noise_clip=0.5, **kw)
+            mods = (("pf", pf), ("qf1", qf1), ("qf2", qf2))
+            tmods = (("tpf", agent.target_pf), ("tqf1", agent.target_qf1), ("tqf2", agent.target_qf2))
+        for name, mod in mods:
+            out.update(state_arrays(f"{tag}_{name}0_", mod))
+        rs = np.random.RandomState(19)
+        steps = 3
+        for s_ in range(steps):
+            batch = {"obs": rs.randn(B, D).astype(np.float32), "next_obs": rs.randn(B, D).astype(np.float32),
+                     "acts": np.tanh(rs.randn(B, A)).astype(np.float32), "rewards": rs.randn(B, 1).astype(np.float32),
+                     "terminals": (rs.rand(B, 1) < 0.1).astype(np.float32)}
+            out.update({f"{tag}_s{s_}_batch_{k}": v for k, v in batch.items()})
+            torch.manual_seed(200 + s_)
+            state = torch.get_rng_state()
+            info = agent.update(batch)
+            after = torch.get_rng_state()
+            torch.set_rng_state(state)
+            if tag.startswith("td3"):                      # explore noise of target_pf, then the smoothing noise
+                out[f"{tag}_s{s_}_eps_explore"] = torch.randn(B, A).numpy()
+                out[f"{tag}_s{s_}_eps_smooth"] = torch.randn(B, A).numpy()
+            assert torch.equal(torch.get_rng_state(), after), "noise stream mismatch"
+            keys = sorted(info.keys())
+            out[f"{tag}_s{s_}_info_keys"] = np.array(keys)
+            out[f"{tag}_s{s_}_info_vals"] = np.array([float(info[k]) for k in keys], dtype=np.float64)
+        for name, mod in mods + tmods:
+            out.update(state_arrays(f"{tag}_{name}1_", mod))
+        out[f"{tag}_args"] = np.array([B, H, clip if clip else 0.0, steps], dtype=np.float64)
+    save("ddpg_td3", **out)
+
+
 def case_obs_norm():
     """Running observation normaliser (env/base_wrapper.py:44-121): Normalizer.update_estimate / filt on a
     sequence of batches, and NormObs wrapped around the synthetic vector env under
@@ -540,7 +597,7 @@ def case_obs_norm():
 
 CASES = {"gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
-         "obs_norm": case_obs_norm, "a2c_update": case_a2c_update}
+         "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3}
 
 if __name__ == "__main__":
     install_stubs()

@@ -107,3 +107,22 @@ def test_a2c_epoch_matches_oracle():
     np.testing.assert_allclose(got, np.array([[i[k] for k in keys] for i in want]), rtol=3e-4, atol=5e-5)
     for a, b in zip(pf._mlp2_param_list() + [pf.logstd] + vf._mlp2_param_list(), o.pf + [o.logstd] + o.vf):
         assert (a.detach().cpu() - b.detach()).abs().max().item() < 3e-6
+
+
+def test_a2c_example_script_runs(tmp_path):
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = json.load(open(os.path.join(repo, "config", "a2c_synth_halfcheetah.json")))
+    params["replay_buffer"]["size"] = 64 * 32
+    params["collector"]["epoch_frames"] = 64 * 32
+    params["general_setting"].update(num_epochs=2, batch_size=512, eval_interval=1)
+    cfg = tmp_path / "a2c_small.json"
+    cfg.write_text(json.dumps(params))
+    out = subprocess.run([sys.executable, os.path.join(repo, "examples", "a2c_continuous_vec.py"), "--config", str(cfg),
+                          "--vec_env_nums", "64", "--seed", "1", "--log_dir", str(tmp_path / "log"), "--overwrite"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "EPOCH:1" in out.stdout

@@ -308,3 +308,30 @@ def test_a2c_update_oracle_matches_reference(golden, tag):
         want_vf, _ = params_from(g, f"{tag}_vf{s + 1}_", False)
         for a, b in zip(o.pf + [o.logstd] + o.vf, want_pf + [want_ls] + want_vf):
             np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["ddpg", "ddpg_clip", "td3", "td3_clip"])
+def test_ddpg_td3_oracle_matches_reference(golden, tag):
+    from oracle.detac import DDPGOracle, TD3Oracle
+    g = golden("ddpg_td3")
+    B, H, clip, steps = g[tag + "_args"]
+    clip = float(clip) or None
+    get = lambda name, k: sac_params(g, f"{tag}_{name}{k}_")
+    if tag.startswith("ddpg"):
+        o = DDPGOracle(get("pf", 0), get("qf1", 0), plr=3e-4, qlr=1e-3, grad_clip=clip)
+        pairs = (("pf", o.pf), ("qf1", o.qf), ("tpf", o.tpf), ("tqf1", o.tqf))
+    else:
+        o = TD3Oracle(get("pf", 0), get("qf1", 0), get("qf2", 0), plr=3e-4, qlr=1e-3, grad_clip=clip)
+        pairs = (("pf", o.pf), ("qf1", o.q1), ("qf2", o.q2), ("tpf", o.tpf), ("tqf1", o.tq1), ("tqf2", o.tq2))
+    for s in range(int(steps)):
+        batch = {k: g[f"{tag}_s{s}_batch_{k}"] for k in ("obs", "next_obs", "acts", "rewards", "terminals")}
+        if tag.startswith("ddpg"):
+            info = o.update(batch)
+        else:
+            info = o.update(batch, g[f"{tag}_s{s}_eps_explore"], g[f"{tag}_s{s}_eps_smooth"])
+        keys = [str(k) for k in g[f"{tag}_s{s}_info_keys"]]
+        assert sorted(info.keys()) == keys, (s, sorted(info.keys()), keys)
+        np.testing.assert_allclose([info[k] for k in keys], g[f"{tag}_s{s}_info_vals"], rtol=2e-5, atol=2e-6)
+    for name, params in pairs:
+        for a, b in zip(params, get(name, 1)):
+            np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=1e-6)

@@ -88,6 +88,8 @@ SIGNATURES = {
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_minibatch_grad_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p]),
     "trl_ppo_wg_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "trl_detac_losses_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_int] + [C.c_void_p] * 5),
+    "trl_noisy_action_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "trl_gauss_explore_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_onpolicy_bookkeep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -377,7 +379,7 @@ def sac_losses(q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp, alpha, ga
 def slice_add(x1, x2, off, A):
     rows, ld = int(x1.shape[0]), int(x1.shape[1])
     out = torch.empty((rows, A), dtype=torch.float32, device=x1.device)
-    check(lib().trl_slice_add_f32(dev_ptr(x1, name="x1"), dev_ptr(x2, name="x2"), dev_ptr(out, name="out"), rows, ld,
+    check(lib().trl_slice_add_f32(dev_ptr(x1, name="x1"), dev_ptr(x2, name="x2", allow_none=True), dev_ptr(out, name="out"), rows, ld,
                                   off, A, stream_ptr(x1.device)), "trl_slice_add_f32")
     return out
 
@@ -560,4 +562,25 @@ def norm_filt(x, state, out, clip):
     N, D = int(x.shape[0]), int(x.shape[1])
     check(lib().trl_norm_filt_f32(dev_ptr(x, name="x"), dev_ptr(state, torch.float64, "state"), dev_ptr(out, name="out"),
                                   N, D, float(clip), stream_ptr(x.device)), "trl_norm_filt_f32")
+    return out
+
+
+def detac_losses(q1, q2, tq1, tq2, rew, term, qn, gamma, sums):
+    """DDPG / TD3 losses; q2 / tq2 / qn may be None.  Returns (dq1, dq2, dqn)."""
+    B = int(q1.numel())
+    mk = lambda ref: torch.empty_like(ref) if ref is not None else None
+    dq1, dq2, dqn = mk(q1), mk(q2), mk(qn)
+    p = lambda t, n: dev_ptr(t, name=n, allow_none=True)
+    check(lib().trl_detac_losses_f32(p(q1, "q1"), p(q2, "q2"), p(tq1, "tq1"), p(tq2, "tq2"), p(rew, "rew"), p(term, "term"),
+                                     p(qn, "qn"), float(gamma), B, p(dq1, "dq1"), p(dq2, "dq2"), p(dqn, "dqn"),
+                                     dev_ptr(sums, torch.float64, "sums"), stream_ptr(q1.device)), "trl_detac_losses_f32")
+    return dq1, dq2, dqn
+
+
+def noisy_action(act, eps, sigma, noise_clip=float("inf"), lo=-float("inf"), hi=float("inf"), out=None):
+    if out is None:
+        out = torch.empty_like(act)
+    check(lib().trl_noisy_action_f32(dev_ptr(act, name="act"), dev_ptr(eps, name="eps"), float(sigma), float(noise_clip),
+                                     float(lo), float(hi), dev_ptr(out, name="out"), int(act.numel()),
+                                     stream_ptr(act.device)), "trl_noisy_action_f32")
     return out

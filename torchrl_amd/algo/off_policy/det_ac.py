@@ -1,0 +1,278 @@
+"""DDPG and TD3 on the HIP path (reference: torchrl/algo/off_policy/ddpg.py:10-140, td3.py:10-190).
+
+Both are deterministic actor-critic updates over MLPs, so they run on the same launch sequence as
+TwinSACQ with an explicit chain rule instead of autograd:
+  dense layers ............ trl_linear_{fwd,bwd_input,bwd_weight}_f32 (fp32 MFMA, k_gemm.hip); the policy's
+                            tanh is the activation of its last layer's epilogue and gates its backward
+  target smoothing (TD3) .. trl_noisy_action_f32 (explore noise of target_pf, then the clipped smoothing noise)
+  TD target, MSE, dQ ...... trl_detac_losses_f32 (also -mean Q(s, pi(s)) and its gradient)
+  dL/da through the critic  bwd_input of the Q net + trl_slice_add_f32
+  clip + Adam ............. trl_clip_adam_f32 on one flat [pf | qf (| qf2)] buffer
+  target update ........... trl_polyak_f32 on the flat buffers (policy AND critics, as the reference does)
+The reference's order of operations is kept, including TD3's delayed policy step, which is taken when
+`training_update_num % policy_update_delay != 0` (td3.py:124, as written) and evaluates Q1 AFTER its step.
+TD3's two N(0,1) draws per update come from the CPU torch generator (reference parity) or from the device
+Philox stream (`noise_mode="device"`).
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ... import _C, ops
+from ...networks import flatten_into
+from .off_rl_algo import OffRLAlgo
+
+
+class DDPG(OffRLAlgo):
+    def __init__(self, pf, qf, plr, qlr, optimizer_class=optim.Adam, **kwargs):
+        super().__init__(**kwargs)
+        self.pf, self.qf = pf, qf
+        self.target_pf, self.target_qf = copy.deepcopy(pf), copy.deepcopy(qf)
+        self.to(self.device)
+        self.plr, self.qlr = plr, qlr
+        self.optimizer_class = optimizer_class
+        self.pf_optimizer = optimizer_class(self.pf.parameters(), lr=self.plr)
+        self.qf_optimizer = optimizer_class(self.qf.parameters(), lr=self.qlr)
+        self._engine = None
+
+    @property
+    def networks(self):
+        return [self.pf, self.qf, self.target_pf, self.target_qf]
+
+    @property
+    def snapshot_networks(self):
+        return [["pf", self.pf], ["qf", self.qf]]
+
+    @property
+    def target_networks(self):
+        return [(self.pf, self.target_pf), (self.qf, self.target_qf)]
+
+    def engine(self):
+        if self._engine is None:
+            self._engine = _FusedDetAC(self, [self.pf, self.qf], [self.target_pf, self.target_qf],
+                                       [self.pf_optimizer, self.qf_optimizer])
+        return self._engine
+
+    def update(self, batch):
+        self.training_update_num += 1
+        return self.engine().update_ddpg(batch)
+
+
+class TD3(OffRLAlgo):
+    def __init__(self, pf, qf1, qf2, plr, qlr, optimizer_class=optim.Adam, policy_update_delay=2,
+                 norm_std_policy=0.2, noise_clip=0.5, noise_mode="host", **kwargs):
+        super().__init__(**kwargs)
+        self.pf, self.qf1, self.qf2 = pf, qf1, qf2
+        self.target_pf, self.target_qf1, self.target_qf2 = copy.deepcopy(pf), copy.deepcopy(qf1), copy.deepcopy(qf2)
+        self.to(self.device)
+        self.plr, self.qlr = plr, qlr
+        self.optimizer_class = optimizer_class
+        self.pf_optimizer = optimizer_class(self.pf.parameters(), lr=self.plr)
+        self.qf1_optimizer = optimizer_class(self.qf1.parameters(), lr=self.qlr)
+        self.qf2_optimizer = optimizer_class(self.qf2.parameters(), lr=self.qlr)
+        self.policy_update_delay = policy_update_delay
+        self.norm_std_policy, self.noise_clip = norm_std_policy, noise_clip
+        if noise_mode not in ("host", "device"):
+            raise ValueError("noise_mode must be 'host' or 'device'")
+        self.noise_mode = noise_mode
+        self._engine = None
+
+    @property
+    def networks(self):
+        return [self.pf, self.qf1, self.qf2, self.target_pf, self.target_qf1, self.target_qf2]
+
+    @property
+    def snapshot_networks(self):
+        return [["pf", self.pf], ["qf1", self.qf1], ["qf2", self.qf2]]
+
+    @property
+    def target_networks(self):
+        return [(self.pf, self.target_pf), (self.qf1, self.target_qf1), (self.qf2, self.target_qf2)]
+
+    def engine(self):
+        if self._engine is None:
+            self._engine = _FusedDetAC(self, [self.pf, self.qf1, self.qf2],
+                                       [self.target_pf, self.target_qf1, self.target_qf2],
+                                       [self.pf_optimizer, self.qf1_optimizer, self.qf2_optimizer])
+        return self._engine
+
+    def update(self, batch):
+        self.training_update_num += 1
+        return self.engine().update_td3(batch)
+
+
+class _FusedDetAC:
+    """Flat [pf | qf1 (| qf2)] parameter / gradient / Adam-state buffers and the two launch sequences."""
+
+    def __init__(self, algo, nets, targets, optimizers):
+        if algo.optimizer_class is not optim.Adam:
+            raise _C.TrlError("the fused DDPG / TD3 step implements torch.optim.Adam only")
+        self.algo = algo
+        self.dev = next(nets[0].parameters()).device
+        if self.dev.type != "cuda":
+            raise _C.TrlError("networks live on %s: the HIP path needs a GPU (no CPU path exists)" % self.dev)
+        self.act = ops.act_code(nets[0])
+        if any(ops.act_code(n) != self.act for n in nets[1:]):
+            raise _C.TrlError("policy and critics must use the same activation")
+        self.pf_last = _C.ACT_TANH if getattr(nets[0], "tanh_action", False) else _C.ACT_NONE
+        self.sigma_explore = float(getattr(nets[0], "norm_std_explore", 0.0))
+        self.layers = [ops.linear_layers(n) for n in nets]
+        self.tlayers = [ops.linear_layers(n) for n in targets]
+        plists = [[t for wb in ls for t in wb] for ls in self.layers]
+        self.sizes = [sum(p.numel() for p in pl) for pl in plists]
+        self.flat = flatten_into([p for pl in plists for p in pl])
+        self.tflat = flatten_into([t for ls in self.tlayers for wb in ls for t in wb])
+        self.grads = torch.zeros_like(self.flat)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.gviews, off = [], 0
+        for ls in self.layers:
+            views = []
+            for w, b in ls:
+                gw = self.grads[off:off + w.numel()].view(w.shape); off += w.numel()
+                gb = self.grads[off:off + b.numel()].view(b.shape); off += b.numel()
+                views.append((gw, gb))
+            self.gviews.append(views)
+        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(int)
+        off = 0
+        for opt, pl in zip(optimizers, plists):
+            for p in pl:
+                n = p.numel()
+                opt.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.m[off:off + n].view(p.shape),
+                                "exp_avg_sq": self.v[off:off + n].view(p.shape)}
+                off += n
+        self.optimizers = optimizers
+        self.steps = [0] * len(nets)                                       # per-network Adam step counts (TD3's policy lags)
+        self.sums = torch.zeros(4, dtype=torch.float64, device=self.dev)
+        self.sums_p = torch.zeros(4, dtype=torch.float64, device=self.dev)
+        self.mom = torch.zeros(4, dtype=torch.float64, device=self.dev)
+        self.norms = torch.zeros(len(nets), device=self.dev)
+        self.workspace = None
+        self.D = int(self.layers[0][0][0].shape[1])
+        self.A = int(self.layers[0][-1][0].shape[0])
+        self.noise_ctr, self.noise_seed = 0, 0x7D3
+
+    # ---- helpers ----
+    def _ws(self, B):
+        need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
+                   for ls in self.layers for w, _ in ls)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, device=self.dev)
+        return self.workspace
+
+    def _noise(self, B):
+        if getattr(self.algo, "noise_mode", "host") == "host":              # CPU generator draw (reference stream)
+            return torch.randn(B, self.A).to(self.dev, non_blocking=True)
+        self.noise_ctr += 1
+        return _C.philox_normal(torch.empty(B, self.A, device=self.dev), self.noise_seed, self.noise_ctr)
+
+    def _batch(self, batch):
+        as_t = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
+            .to(device=self.dev, dtype=torch.float32).contiguous()
+        return (as_t(batch['obs']), as_t(batch['acts']), as_t(batch['next_obs']),
+                as_t(batch['rewards']).reshape(-1), as_t(batch['terminals']).reshape(-1))
+
+    def _adam(self, which):
+        """clip_grad_norm_ + Adam for the networks in `which` (indices into the flat buffer), one launch each
+        contiguous run; every network keeps its own step count."""
+        algo = self.algo
+        for k in which:
+            self.steps[k] += 1
+            a = _C.AdamArgs()
+            o = int(self.offsets[k]) * 4
+            a.params, a.grads = self.flat.data_ptr() + o, self.grads.data_ptr() + o
+            a.exp_avg, a.exp_avg_sq = self.m.data_ptr() + o, self.v.data_ptr() + o
+            a.n_groups = 1
+            a.group_sizes[0] = self.sizes[k]
+            a.group_lr[0] = self.optimizers[k].param_groups[0]['lr']
+            a.max_norm = float(algo.grad_clip) if algo.grad_clip else 0.0
+            a.beta1, a.beta2, a.eps, a.grad_scale = 0.9, 0.999, 1e-8, 1.0
+            a.step_count, a.norms_out = self.steps[k], self.norms.data_ptr() + 4 * k
+            _C.clip_adam(a, self.dev)
+
+    def _target_update(self):
+        algo = self.algo
+        if algo.use_soft_update:
+            _C.polyak(self.tflat, self.flat, algo.tau)
+        elif algo.training_update_num % algo.target_hard_update_period == 0:
+            _C.polyak(self.tflat, self.flat, 1.0)
+
+    def _policy_grad(self, obs, q_layers, ws):
+        """-mean(Q(s, pi(s))) and its gradient into the policy block; returns (new actions, tape pieces)."""
+        new_a, tape_pf = ops.mlp_forward(self.layers[0], obs, self.act, last_act=self.pf_last)
+        qn, tape_qn = ops.mlp_forward(q_layers, _C.concat2(obs, new_a), self.act)
+        return new_a, tape_pf, qn, tape_qn
+
+    def _stats(self, info, new_a):
+        _C.moments(new_a, self.mom, ld=1)
+        m = self.mom.cpu().numpy()
+        info['new_actions/mean'], info['new_actions/std'], info['new_actions/max'], info['new_actions/min'] = \
+            float(m[0]), float(m[1]), float(m[2]), float(m[3])
+
+    # ---- DDPG (ddpg.py:42-110) ----
+    def update_ddpg(self, batch):
+        algo, D, A = self.algo, self.D, self.A
+        obs, acts, nobs, rew, term = self._batch(batch)
+        B = int(obs.shape[0])
+        ws = self._ws(B)
+        pf_l, qf_l = self.layers
+        new_a, tape_pf, qn, tape_qn = self._policy_grad(obs, qf_l, ws)
+        ta, _ = ops.mlp_forward(self.tlayers[0], nobs, self.act, last_act=self.pf_last)
+        tq, _ = ops.mlp_forward(self.tlayers[1], _C.concat2(nobs, ta), self.act)
+        qp, tape_q = ops.mlp_forward(qf_l, _C.concat2(obs, acts), self.act)
+        dq, _, dqn = _C.detac_losses(qp, None, tq, None, rew, term, qn, algo.discount, self.sums)
+        dx = ops.mlp_backward(tape_qn, dqn, grads=None, need_input=True)
+        ops.mlp_backward(tape_pf, _C.slice_add(dx, None, D, A), grads=self.gviews[0], workspace=ws)
+        ops.mlp_backward(tape_q, dq, grads=self.gviews[1], workspace=ws)
+        self._adam((0, 1))
+        self._target_update()
+        sums, norms = self.sums.cpu().numpy(), self.norms.cpu().numpy()
+        info = {'Reward_Mean': sums[3] / B, 'Training/policy_loss': sums[2] / B, 'Training/qf_loss': sums[0] / B}
+        if algo.grad_clip is not None:
+            info['Training/pf_grad_norm'], info['Training/qf_grad_norm'] = float(norms[0]), float(norms[1])
+        self._stats(info, new_a)
+        return info
+
+    # ---- TD3 (td3.py:57-154) ----
+    def update_td3(self, batch):
+        algo, D, A = self.algo, self.D, self.A
+        obs, acts, nobs, rew, term = self._batch(batch)
+        B = int(obs.shape[0])
+        ws = self._ws(B)
+        pf_l, q1_l, q2_l = self.layers
+        # target_pf.explore draws only for policies with exploration noise; then the smoothing draw
+        eps_explore = self._noise(B) if self.sigma_explore else None
+        eps_smooth = self._noise(B)
+        ta, _ = ops.mlp_forward(self.tlayers[0], nobs, self.act, last_act=self.pf_last)
+        if self.sigma_explore:
+            ta = _C.noisy_action(ta, eps_explore, self.sigma_explore)
+        ta = _C.noisy_action(ta, eps_smooth, algo.norm_std_policy, algo.noise_clip, -1.0, 1.0)
+        x_next = _C.concat2(nobs, ta)
+        tq1, _ = ops.mlp_forward(self.tlayers[1], x_next, self.act)
+        tq2, _ = ops.mlp_forward(self.tlayers[2], x_next, self.act)
+        x_sa = _C.concat2(obs, acts)
+        q1p, tape_q1 = ops.mlp_forward(q1_l, x_sa, self.act)
+        q2p, tape_q2 = ops.mlp_forward(q2_l, x_sa, self.act)
+        dq1, dq2, _ = _C.detac_losses(q1p, q2p, tq1, tq2, rew, term, None, algo.discount, self.sums)
+        ops.mlp_backward(tape_q1, dq1, grads=self.gviews[1], workspace=ws)
+        ops.mlp_backward(tape_q2, dq2, grads=self.gviews[2], workspace=ws)
+        self._adam((1, 2))
+        delayed = bool(algo.training_update_num % algo.policy_update_delay)
+        if delayed:                                                          # policy step on the UPDATED Q1
+            new_a, tape_pf, qn, tape_qn = self._policy_grad(obs, q1_l, ws)
+            _, _, dqn = _C.detac_losses(q1p, None, tq1, None, rew, term, qn, algo.discount, self.sums_p)
+            dx = ops.mlp_backward(tape_qn, dqn, grads=None, need_input=True)
+            ops.mlp_backward(tape_pf, _C.slice_add(dx, None, D, A), grads=self.gviews[0], workspace=ws)
+            self._adam((0,))
+            self._target_update()
+        sums, norms = self.sums.cpu().numpy(), self.norms.cpu().numpy()
+        info = {'Reward_Mean': sums[3] / B, 'Training/qf1_loss': sums[0] / B, 'Training/qf2_loss': sums[1] / B}
+        if algo.grad_clip is not None:
+            info['Training/qf1_grad_norm'], info['Training/qf2_grad_norm'] = float(norms[1]), float(norms[2])
+        if delayed:
+            info['Training/policy_loss'] = float(self.sums_p.cpu().numpy()[2]) / B
+            if algo.grad_clip is not None:
+                info['Training/pf_grad_norm'] = float(norms[0])
+            self._stats(info, new_a)
+        return info

@@ -135,6 +135,19 @@ class VecCollector(BaseCollector):
             if deterministic:
                 return torch.as_tensor(pf.eval_act(env.cur_obs)).to(env.device).reshape(-1).contiguous()
             return pf.explore(env.cur_obs)["action"].reshape(-1).contiguous()
+        if hasattr(pf, "norm_std_explore") or type(pf).__name__ == "DetContPolicy":
+            # deterministic policies (continuous_policy.py:28-74): [tanh](mlp(obs)) (+ N(0, norm_std_explore))
+            last = _C.ACT_TANH if pf.tanh_action else _C.ACT_NONE
+            act, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf), last_act=last)
+            sigma = float(getattr(pf, "norm_std_explore", 0.0))
+            if deterministic or not sigma:
+                return act
+            if self.noise_mode == "host":
+                eps = torch.randn(env.env_nums, env.act_dim).to(env.device, non_blocking=True)
+            else:
+                eps = _C.philox_normal(torch.empty(env.env_nums, env.act_dim, device=env.device), self._noise_seed,
+                                       self.global_step)
+            return _C.noisy_action(act, eps, sigma)
         if not hasattr(pf, "tanh_action") or hasattr(pf, "logstd"):
             raise _C.TrlError("VecCollector's kernel path expects a GuassianContPolicy (mean | log_std head); "
                               "state-independent-std policies use VecOnPolicyCollector")

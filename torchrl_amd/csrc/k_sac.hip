@@ -219,19 +219,83 @@ extern "C" int trl_sac_losses_f32(const float* q1, const float* q2, const float*
   return TRL_OK;
 }
 
+// ---------------------------------------------------------------- DDPG / TD3 losses (deterministic actor-critic)
+// TD target r + (1 - d) gamma Q'(s', a') with Q' = tq1 or min(tq1, tq2), MSE of one or two critics and their
+// output gradients (ddpg.py:68-73, td3.py:85-97); with qn given also the policy loss -mean(Q(s, pi(s)))
+// and its gradient -1/B (ddpg.py:59-62, td3.py:128-130).  sums (double[4]): q1 loss sum, q2 loss sum,
+// sum(-qn), sum rewards.
+__global__ __launch_bounds__(SAC_THREADS) void detac_losses_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                                                   const float* __restrict__ tq1, const float* __restrict__ tq2,
+                                                                   const float* __restrict__ rew, const float* __restrict__ term,
+                                                                   const float* __restrict__ qn, float gamma, int B,
+                                                                   float* __restrict__ dq1, float* __restrict__ dq2,
+                                                                   float* __restrict__ dqn, double* __restrict__ sums) {
+  __shared__ double smem[SAC_THREADS / 64];
+  const float inv_b = 1.0f / (float)B;
+  double s1 = 0, s2 = 0, sp = 0, sr = 0;
+  for (int b = threadIdx.x; b < B; b += SAC_THREADS) {
+    const float tv = tq2 ? fminf(tq1[b], tq2[b]) : tq1[b];
+    const float qt = rew[b] + (1.0f - term[b]) * gamma * tv;
+    const float e1 = q1[b] - qt;
+    dq1[b] = 2.0f * e1 * inv_b;
+    s1 += (double)e1 * e1;
+    if (q2) { const float e2 = q2[b] - qt; dq2[b] = 2.0f * e2 * inv_b; s2 += (double)e2 * e2; }
+    if (qn) { dqn[b] = -inv_b; sp -= (double)qn[b]; }
+    sr += (double)rew[b];
+  }
+  s1 = block_sum(s1, smem); s2 = block_sum(s2, smem); sp = block_sum(sp, smem); sr = block_sum(sr, smem);
+  if (threadIdx.x == 0) { sums[0] = s1; sums[1] = s2; sums[2] = sp; sums[3] = sr; }
+}
+extern "C" int trl_detac_losses_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
+                                    const float* rew, const float* term, const float* qn, float gamma, int B,
+                                    float* dq1, float* dq2, float* dqn, double* sums, void* stream) {
+  TRL_REQUIRE(B > 0, "empty batch");
+  TRL_REQUIRE(q1 && tq1 && rew && term && dq1 && sums, "null pointer");
+  TRL_REQUIRE((q2 == nullptr) == (dq2 == nullptr) && (qn == nullptr) == (dqn == nullptr), "q2/dq2 and qn/dqn come in pairs");
+  // one workgroup: B is a few thousand and the sums must be order-deterministic
+  hipLaunchKernelGGL(detac_losses_kernel, dim3(1), dim3(SAC_THREADS), 0, (hipStream_t)stream, q1, q2, tq1, tq2, rew, term,
+                     qn, gamma, B, dq1, dq2, dqn, sums);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// out = clamp(a + clamp(sigma * eps, -noise_clip, noise_clip), lo, hi): exploration noise of
+// FixGuassianContPolicy.explore (continuous_policy.py:67-74; noise_clip = lo = -inf.. pass +-inf) and the
+// target-policy smoothing of TD3 (td3.py:75-82)
+__global__ __launch_bounds__(SAC_THREADS) void noisy_action_kernel(const float* __restrict__ a, const float* __restrict__ eps,
+                                                                   float sigma, float noise_clip, float lo, float hi,
+                                                                   float* __restrict__ out, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * SAC_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * SAC_THREADS) {
+    const float nz = fminf(fmaxf(sigma * eps[e], -noise_clip), noise_clip);
+    out[e] = fminf(fmaxf(a[e] + nz, lo), hi);
+  }
+}
+extern "C" int trl_noisy_action_f32(const float* act, const float* eps, float sigma, float noise_clip, float lo, float hi,
+                                    float* out, int64_t n, void* stream) {
+  TRL_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return TRL_OK;
+  TRL_REQUIRE(act && eps && out, "null pointer");
+  int grid = trl_ceil_div(n, SAC_THREADS);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(noisy_action_kernel, dim3(grid), dim3(SAC_THREADS), 0, (hipStream_t)stream, act, eps, sigma,
+                     noise_clip, lo, hi, out, n);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 // ---------------------------------------------------------------- d(policy loss)/d(action): columns [off, off+A) of dx1 + dx2
 __global__ __launch_bounds__(SAC_THREADS) void slice_add_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                                 float* __restrict__ out, int rows, int ld, int off, int A) {
   const int e = blockIdx.x * SAC_THREADS + threadIdx.x;
   if (e >= rows * A) return;
   const int r = e / A, c = e - r * A;
-  out[e] = x1[(size_t)r * ld + off + c] + x2[(size_t)r * ld + off + c];
+  out[e] = x1[(size_t)r * ld + off + c] + (x2 ? x2[(size_t)r * ld + off + c] : 0.0f);
 }
 extern "C" int trl_slice_add_f32(const float* x1, const float* x2, float* out, int rows, int ld, int off, int A,
                                  void* stream) {
   TRL_REQUIRE(rows >= 0 && A > 0 && off >= 0 && off + A <= ld, "bad sizes");
   if (rows == 0) return TRL_OK;
-  TRL_REQUIRE(x1 && x2 && out, "null pointer");
+  TRL_REQUIRE(x1 && out, "null pointer");
   hipLaunchKernelGGL(slice_add_kernel, dim3(trl_ceil_div((int64_t)rows * A, SAC_THREADS)), dim3(SAC_THREADS), 0,
                      (hipStream_t)stream, x1, x2, out, rows, ld, off, A);
   TRL_LAUNCH_CHECK();

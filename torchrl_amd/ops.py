@@ -30,17 +30,19 @@ def act_code(net):
 
 
 class Tape:
-    __slots__ = ("x", "outs", "layers", "act")
+    __slots__ = ("x", "outs", "layers", "act", "last_act")
 
 
-def mlp_forward(layers, x, act):
-    """layers: [(W, b), ...] (nn.Linear layout); returns (out, tape)."""
+def mlp_forward(layers, x, act, last_act=None):
+    """layers: [(W, b), ...] (nn.Linear layout); returns (out, tape).  `last_act` (an ACT_* code) is applied to
+    the head output inside the last layer's epilogue (deterministic policies: tanh(mlp(x)))."""
     t = Tape()
     t.x, t.layers, t.act, t.outs = x, layers, act, []
+    t.last_act = _C.ACT_NONE if last_act is None else last_act
     h = x
     for k, (w, b) in enumerate(layers):
         last = k == len(layers) - 1
-        h = _C.linear_fwd(h, w, b, _C.ACT_NONE if last else act)
+        h = _C.linear_fwd(h, w, b, t.last_act if last else act)
         t.outs.append(h)
     return h, t
 
@@ -52,12 +54,14 @@ def mlp_backward(tape, d_out, grads=None, need_input=False, workspace=None):
     n = len(tape.layers)
     for k in range(n - 1, -1, -1):
         w, _b = tape.layers[k]
-        gate = None if k == n - 1 else tape.outs[k]                 # hidden outputs gate through act'
+        last = k == n - 1
+        gate_act = tape.last_act if last else tape.act
+        gate = None if (last and gate_act == _C.ACT_NONE) else tape.outs[k]   # outputs gate through act'
         inp = tape.x if k == 0 else tape.outs[k - 1]
         if grads is not None:
-            _C.linear_bwd_weight(d, gate, tape.act, inp, dw=grads[k][0], db=grads[k][1], workspace=workspace)
+            _C.linear_bwd_weight(d, gate, gate_act, inp, dw=grads[k][0], db=grads[k][1], workspace=workspace)
         if k > 0 or need_input:
-            d = _C.linear_bwd_input(d, gate, tape.act, w)
+            d = _C.linear_bwd_input(d, gate, gate_act, w)
     return d if need_input else None
 
 

@@ -1,4 +1,4 @@
 from .continuous_policy import (GuassianContPolicy, GuassianContPolicyBasicBias, GuassianContPolicyBase,
-                                FixGuassianContPolicy, UniformPolicyContinuous)
+                                FixGuassianContPolicy, DetContPolicy, UniformPolicyContinuous)
 from .discrete_policies import EpsilonGreedyDQNDiscretePolicy, EpsilonGreedyQRDQNDiscretePolicy
 from .distribution import TanhNormal

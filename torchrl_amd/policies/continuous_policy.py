@@ -104,6 +104,26 @@ class GuassianContPolicyBasicBias(networks.Net, GuassianContPolicyBase):
         return mean, std, logstd
 
 
+class DetContPolicy(networks.Net):
+    """Deterministic policy (torchrl/policies/continuous_policy.py:28-47): action = [tanh](mlp(x))."""
+
+    def __init__(self, tanh_action=False, **kwargs):
+        super().__init__(**kwargs)
+        self.continuous = True
+        self.tanh_action = tanh_action
+
+    def forward(self, x):
+        out = super().forward(x)
+        return torch.tanh(out) if self.tanh_action else out
+
+    def eval_act(self, x):
+        with torch.no_grad():
+            return self.forward(x).squeeze(0).detach().cpu().numpy()
+
+    def explore(self, x):
+        return {"action": self.forward(x).squeeze(0)}
+
+
 class FixGuassianContPolicy(networks.Net):
     def __init__(self, norm_std_explore, tanh_action=False, **kwargs):
         super().__init__(**kwargs)
