@@ -328,6 +328,19 @@ int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, int32_t* t_en
 int trl_synth_frames_reset_u8(uint8_t* frames, int32_t* t_env, int64_t env_seed_base,
                               const uint8_t* mask, int N, int C, int HW, void* stream);
 
+/* --- K6b: frame-deduplicating replay (torchrl/replay_buffers/memory_efficient_replay_buffer.py:5-33,
+ * LazyFrames / FrameStack, torchrl/env/atari_wrapper.py:142-227).  stream: (S, N, HW) uint8 ring of single
+ * frames per env; head[n]: monotone int32 position of env n's newest frame (slot = position % S).
+ *   append  n_frames == 1: the newest frame (channel C-1) of stacks (N, C, HW); n_frames == C: the whole
+ *           stack (episode start); mask (nullable) selects envs; head advances by n_frames
+ *   gather  out (n_rows * N, C, HW): the k-stack whose newest frame sits at pos[row][n] + shift
+ *           (shift 0 = obs, 1 = next_obs); *overrun |= 1 if a requested frame was already overwritten */
+int trl_frame_stream_append_u8(const uint8_t* stacks, uint8_t* stream, int32_t* head, const uint8_t* mask,
+                               int n_frames, int S, int N, int C, int HW, void* stream_);
+int trl_frame_stream_gather_u8(const uint8_t* stream, const int32_t* pos, const int64_t* row_idx, int n_rows,
+                               int shift, uint8_t* out, const int32_t* head, int32_t* overrun, int S, int N,
+                               int C, int HW, void* stream_);
+
 /* --- K1..K3 stand-alone: one VecOnPolicyCollector.take_actions as separate launches
  * (torchrl/collector/on_policy.py:90-155), for envs the persistent rollout kernel cannot carry
  * (a running observation normaliser needs all-env statistics before every policy forward).

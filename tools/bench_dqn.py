@@ -22,13 +22,13 @@ class NullLog:
     def finish(self): pass
 
 
-def run(Q, epochs, cpu):
+def run(Q, epochs, cpu, dedup=False):
     import torchrl.networks as networks
     import torchrl.policies as policies
     from torchrl.algo import DQN, QRDQN
     from torchrl.collector import VecCollector
     from torchrl.env import get_vec_env
-    from torchrl.replay_buffers import BaseReplayBuffer
+    from torchrl.replay_buffers import BaseReplayBuffer, MemoryEfficientReplayBuffer
     dev = torch.device("cuda:0")
     torch.manual_seed(0); np.random.seed(0)
     qf = networks.Net(output_shape=A * Q, base_type=networks.CNNBase, append_hidden_shapes=[512],
@@ -37,7 +37,7 @@ def run(Q, epochs, cpu):
     eval_env = get_vec_env("SynthAtari-v0", {"reward_scale": 1}, N)
     kwp = dict(qf=qf, start_epsilon=1, end_epsilon=0.1, decay_frames=1000000, action_shape=A)
     pf = policies.EpsilonGreedyQRDQNDiscretePolicy(quantile_num=Q, **kwp) if Q > 1 else policies.EpsilonGreedyDQNDiscretePolicy(**kwp)
-    buf = BaseReplayBuffer(ROWS * N, env_nums=N)
+    buf = MemoryEfficientReplayBuffer(ROWS * N, env_nums=N, min_episode_frames=999) if dedup else BaseReplayBuffer(ROWS * N, env_nums=N)
     col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * STEPS,
                        max_episode_frames=999)
     kw = dict(qf=qf, pf=pf, qlr=2.5e-4, env=env, replay_buffer=buf, collector=col, logger=NullLog(), discount=0.99,
@@ -56,7 +56,10 @@ def run(Q, epochs, cpu):
                        % ("QRDQN" if Q > 1 else "DQN", N, ROWS, B, ", Q=%d" % Q if Q > 1 else ""),
            "env_steps_per_s": epochs * N * STEPS / el, "updates_per_s": epochs * OPT / tu,
            "ms_per_update": 1e3 * tu / (epochs * OPT), "ms_per_vector_step": 1e3 * tc / (epochs * STEPS),
-           "update_gflop": 38e-3 * B}
+           "update_gflop": 38e-3 * B, "replay": "frame-dedup" if dedup else "plain",
+           "replay_frame_bytes": int(buf._stream.numel()) if dedup else int(buf._obs.numel() + buf._next_obs.numel())}
+    if dedup:
+        buf.check_overrun()
     if cpu:
         from oracle.dqn import DQNOracle
         from torchrl_amd import ops
@@ -76,5 +79,6 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--quantiles", type=int, default=1)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--dedup", action="store_true", help="frame-deduplicating replay (MemoryEfficientReplayBuffer)")
     a = ap.parse_args()
-    run(a.quantiles, a.epochs, a.cpu)
+    run(a.quantiles, a.epochs, a.cpu, a.dedup)

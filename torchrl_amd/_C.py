@@ -88,6 +88,9 @@ SIGNATURES = {
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_minibatch_grad_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p]),
     "trl_ppo_wg_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "trl_frame_stream_append_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_frame_stream_gather_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_detac_losses_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_int] + [C.c_void_p] * 5),
     "trl_noisy_action_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "trl_gauss_explore_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -583,4 +586,29 @@ def noisy_action(act, eps, sigma, noise_clip=float("inf"), lo=-float("inf"), hi=
     check(lib().trl_noisy_action_f32(dev_ptr(act, name="act"), dev_ptr(eps, name="eps"), float(sigma), float(noise_clip),
                                      float(lo), float(hi), dev_ptr(out, name="out"), int(act.numel()),
                                      stream_ptr(act.device)), "trl_noisy_action_f32")
+    return out
+
+
+def frame_stream_append(stacks, stream, head, mask, n_frames):
+    """stacks (N, C, H, W) uint8; stream (S, N, H*W) uint8; head (N) int32."""
+    N, Cc = int(stacks.shape[0]), int(stacks.shape[1])
+    HW = int(stacks[0, 0].numel())
+    check(lib().trl_frame_stream_append_u8(dev_ptr(stacks, torch.uint8, "stacks"), dev_ptr(stream, torch.uint8, "stream"),
+                                           dev_ptr(head, torch.int32, "head"),
+                                           dev_ptr(mask, torch.uint8, "mask", allow_none=True), int(n_frames),
+                                           int(stream.shape[0]), N, Cc, HW, stream_ptr(stacks.device)),
+          "trl_frame_stream_append_u8")
+
+
+def frame_stream_gather(stream, pos, row_idx, shift, frame_shape, head, overrun):
+    """-> (n_rows * N, C, H, W) uint8 stacks rebuilt from the per-env frame stream."""
+    S, N = int(stream.shape[0]), int(stream.shape[1])
+    Cc, H, W = frame_shape
+    nr = int(row_idx.numel())
+    out = torch.empty((nr * N, Cc, H, W), dtype=torch.uint8, device=stream.device)
+    check(lib().trl_frame_stream_gather_u8(dev_ptr(stream, torch.uint8, "stream"), dev_ptr(pos, torch.int32, "pos"),
+                                           dev_ptr(row_idx, torch.int64, "row_idx"), nr, int(shift),
+                                           dev_ptr(out, torch.uint8, "out"), dev_ptr(head, torch.int32, "head"),
+                                           dev_ptr(overrun, torch.int32, "overrun"), S, N, Cc, H * W,
+                                           stream_ptr(stream.device)), "trl_frame_stream_gather_u8")
     return out

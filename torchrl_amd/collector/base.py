@@ -197,7 +197,17 @@ class VecCollector(BaseCollector):
         buf = self.replay_buffer
         n, shape = env.env_nums, env.frame_shape
         act = self._policy_action(env, deterministic)                       # (N,) int64
-        if store:
+        dedup = store and hasattr(buf, "append_step")                    # frame-deduplicating replay
+        if dedup:
+            if buf._stream is None:
+                buf.begin_episodes(env.cur_obs)                             # stacks of the running episodes
+            row = buf._top
+            buf.mark_obs_row()
+            buf._ensure_key("acts", (n, 1))[row].copy_(act.unsqueeze(-1))
+            nxt = None
+            rew = buf._ensure_key("rewards", (n, 1))[row]
+            done = buf._ensure_key("terminals", (n, 1))[row]
+        elif store:
             row = buf._top
             buf._ensure_key("obs", (n,) + shape, dtype=torch.uint8)[row].copy_(env.cur_obs)
             buf._ensure_key("acts", (n, 1))[row].copy_(act.unsqueeze(-1))
@@ -209,12 +219,16 @@ class VecCollector(BaseCollector):
             rew = torch.empty(n, 1, device=env.device)
             done = torch.empty(n, 1, device=env.device)
         _C.synth_frames_step(env.cur_obs, act, env.t_env, env.seed_base, env.horizon, env.action_num, nxt, rew, done)
+        if dedup:
+            buf.append_step(env.cur_obs)                                    # the one new frame of next_obs
         if store:
             buf._ensure_key("time_limits", (n, 1))[row].copy_(done)
         _C.collector_bookkeep(rew, done, env.cur_step, env.ep_return,
                               self.max_episode_frames if max_frames is None else max_frames, self._mask,
                               self._epoch_reward, self._ep_count, self._ep_log, self.global_step)
         _C.synth_frames_reset(env.cur_obs, env.t_env, env.seed_base, self._mask)
+        if dedup:
+            buf.begin_episodes(env.cur_obs, self._mask)                     # fresh stacks of the envs just reset
         if store:
             buf._advance()
         self.global_step += 1
