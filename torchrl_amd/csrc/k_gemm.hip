@@ -8,17 +8,18 @@
 //     weight-grad dW[N,K] = dZ[M,N]^T . X[M,K]   (split over M, deterministic two-pass fold)
 //     dZ = dY * act'(Y)  and  db = column sums of dZ are fused into the operand loads / a side output.
 // Exact fp32 on v_mfma_f32_32x32x2_f32: a workgroup of 4 waves owns a 64x64 C tile (each wave one
-// 32x32 quadrant), K is walked in steps of 16 through padded LDS tiles (A as [m][k] stride 17, B as
-// [k][n] stride 65 -- both conflict free for the MFMA operand reads).  Arbitrary M, N, K (zero fill).
+// 32x32 quadrant), K is walked in steps of GK = 32 through LDS tiles that are BOTH k-contiguous (A as [m][k],
+// B as [n][k], row stride GK + 4 floats).  The k index of MFMA step s is (GK / 2) * (lane >> 5) + s, so a
+// lane's operands of a K-step are consecutive floats: one ds_read_b128 per operand per 4 MFMAs instead of 4
+// ds_read_b32 (the operand reads, not the MFMAs, paced the first version).  Arbitrary M, N, K (zero fill).
 #include "trl_common.h"
 #include "trl_mlp.h"
 
 #define GM 64
 #define GN 64
 #define GK 32
-#define LDA_S (GK + 1)
-#define LDB_S (GN + 1)
-#define A_PER_T (GM * GK / 256)     // 16 staged A elements per thread
+#define LDK (GK + 4)                // LDS row stride of both operand tiles: 16-byte aligned rows of k
+#define A_PER_T (GM * GK / 256)     //  8 staged A elements per thread
 #define B_PER_T (GK * GN / 256)     //  8 staged B elements per thread
 
 // act'(y) expressed through the activation OUTPUT y (tanh: 1 - y^2, relu: y > 0, none: 1)
@@ -46,8 +47,8 @@ struct GemmDev {
 // MFMAs (register double buffering).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
-  __shared__ float As[GM * LDA_S];
-  __shared__ float Bs[GK * LDB_S];
+  __shared__ __attribute__((aligned(16))) float As[GM * LDK];      // [m][k]
+  __shared__ __attribute__((aligned(16))) float Bs[GN * LDK];      // [n][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
   int k_lo = 0, k_hi = g.K;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
       const int e = tid + 256 * t;
       int m, k;
       if (!TA) { m = e / GK; k = e - m * GK; } else { k = e / GM; m = e - k * GM; }
-      As[m * LDA_S + k] = ra[t];
+      As[m * LDK + k] = ra[t];
       if (want_colsum) csum += ra[t];              // TA: e % GM == tid % 64 for every t -> fixed column
     }
 #pragma unroll
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
       const int e = tid + 256 * t;
       int n, k;
       if (!TB) { k = e / GN; n = e - k * GN; } else { n = e / GK; k = e - n * GK; }
-      Bs[k * LDB_S + n] = rb[t];
+      Bs[n * LDK + k] = rb[t];
     }
   };
 
@@ -114,9 +115,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
     stash();
     __syncthreads();
     if (k0 + GK < k_hi) fetch(k0 + GK);            // next step's loads fly under this step's MFMAs
+    {
+      const float* ap = As + (32 * wm + i) * LDK + (GK / 2) * hi;
+      const float* bp = Bs + (32 * wn + i) * LDK + (GK / 2) * hi;
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 2)
-      acc0 = mfma32(As[(32 * wm + i) * LDA_S + kk + hi], Bs[(kk + hi) * LDB_S + 32 * wn + i], acc0);
+      for (int q = 0; q < GK / 8; ++q) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 4 * q);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc0 = mfma32(av[r], bv[r], acc0);
+      }
+    }
     __syncthreads();
   }
   // ---- epilogue ----
