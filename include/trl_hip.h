@@ -126,8 +126,23 @@ typedef struct trl_rollout_t {
   float*   ep_log;            /* (cap, 3): step, env, return */
   int ep_cap;
   int step0;                  /* value written as `step` for the first step */
+  /* running observation normaliser of the env (NormObs, torchrl/env/base_wrapper.py:98-121); norm_state
+   * NULL = none.  With it, cur_obs stays the env's RAW state and policy_obs (N, D; in/out) is what the
+   * policy sees; stored obs = policy input, stored next_obs = normalised next observation.  When
+   * norm_update != 0 the statistics are updated every step from ALL envs: the workgroups rendezvous once
+   * per step, so N must not exceed trl_rollout_norm_max_envs(); after any reset the next policy input is
+   * the RAW observation of all envs, as the reference's forwarded partial_reset delivers it
+   * (normalize_partial_reset != 0: the filtered one instead). */
+  double* norm_state;         /* (2D + 1) mean | var | count, see trl_norm_update_filt_f32 */
+  float*  policy_obs;
+  double* norm_workspace;     /* trl_rollout_norm_workspace(N) doubles, zeroed once by the caller */
+  float norm_clip;
+  int norm_update;
+  int normalize_partial_reset;
 } trl_rollout_t;
 int trl_rollout_synth_f32(const trl_rollout_t* args, void* stream);
+int trl_rollout_norm_workspace(int N);
+int trl_rollout_norm_max_envs(int D, int H, int A, int act);
 
 /* synthetic env (re)start: for every env i with mask[i] != 0 (mask NULL = all):
  * episode_idx += 1, obs ~ N(0,1) from the Philox reset stream keyed

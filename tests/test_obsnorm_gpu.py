@@ -82,11 +82,15 @@ def _build(g, tag, N, T, horizon, max_frames, seed, **wrap):
     return env, buf, col
 
 
+@pytest.mark.parametrize("per_step", [False, True])
 @pytest.mark.parametrize("tag", ["flow", "flow_surpass"])
-def test_normobs_collect_matches_reference(golden, tag):
+def test_normobs_collect_matches_reference(golden, tag, per_step):
+    """per_step False: the cooperative persistent kernel (one grid rendezvous per step pools the statistics);
+    True: the per-step launch sequence (what env shards on several GPUs use)."""
     g = golden("obs_norm")
     N, T, horizon, max_frames, seed = (int(v) for v in g[tag + "_args"])
     env, buf, col = _build(g, tag, N, T, horizon, max_frames, seed)
+    col.force_per_step = per_step
     np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_ob0"], rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(env._obs_normalizer.state.cpu().numpy(), g[tag + "_state0"], rtol=2e-6, atol=1e-7)
     assert col.eval_env._obs_normalizer is env._obs_normalizer            # collector/base.py:33-34
@@ -145,3 +149,41 @@ def test_example_script_runs_with_obs_norm(tmp_path):
     assert os.path.exists(model_dir / "model_pf_finish.pth")
     pkls = [f for f in os.listdir(model_dir) if f.startswith("_obs_normalizer_")]
     assert pkls, os.listdir(model_dir)
+
+
+def test_cooperative_and_per_step_paths_agree_at_full_size():
+    """2048 envs x 32 steps with resets: both collection paths must produce the same ring and statistics
+    (fp32 vs fp64 partial sums of the batch moments aside)."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env.base_wrapper import NormObs
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    from torchrl_amd import _C
+    dev = torch.device(DEV)
+    N, T, horizon = 2048, 32, 6
+    assert _C.lib().trl_rollout_norm_max_envs(17, 64, 6, _C.ACT_TANH) >= N
+    out = []
+    for per_step in (False, True):
+        torch.manual_seed(7)
+        net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+        pf = policies.GuassianContPolicyBasicBias(input_shape=17, output_shape=6, tanh_action=True, **net)
+        vf = networks.Net(input_shape=(17,), output_shape=1, **net)
+        env, ev = NormObs(SynthVecEnv(N, horizon=horizon, device=dev)), NormObs(SynthVecEnv(N, horizon=horizon, device=dev))
+        env.seed(3)
+        buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+        col = VecOnPolicyCollector(vf, env=env, eval_env=ev, pf=pf, replay_buffer=buf, device=dev, train_render=False,
+                                   epoch_frames=N * T, max_episode_frames=1000, eval_episodes=1, noise_mode="host")
+        col.force_per_step = per_step
+        torch.manual_seed(11)                                    # same CPU noise draws on both paths
+        res = col.train_one_epoch()
+        out.append((buf, env._obs_normalizer.state.cpu().numpy(), res, col.current_ob.cpu().numpy()))
+    (b0, s0, r0, o0), (b1, s1, r1, o1) = out
+    np.testing.assert_allclose(s0, s1, rtol=1e-5, atol=1e-6)
+    for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits", "old_logp"):
+        x0, x1 = getattr(b0, "_" + k).cpu().numpy(), getattr(b1, "_" + k).cpu().numpy()
+        assert np.abs(x0 - x1).max() < 2e-4, (k, np.abs(x0 - x1).max())
+    np.testing.assert_allclose(o0, o1, atol=2e-4)
+    assert abs(r0["train_epoch_reward"] - r1["train_epoch_reward"]) < 1e-2 * max(1.0, abs(r1["train_epoch_reward"]))
+    assert len(r0["train_rewards"]) == len(r1["train_rewards"]) > 0

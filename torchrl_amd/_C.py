@@ -45,6 +45,8 @@ class RolloutArgs(C.Structure):
         ("max_episode_frames", C.c_int), ("discount", C.c_float),
         ("epoch_reward", C.c_void_p), ("ep_count", C.c_void_p), ("ep_log", C.c_void_p),
         ("ep_cap", C.c_int), ("step0", C.c_int),
+        ("norm_state", C.c_void_p), ("policy_obs", C.c_void_p), ("norm_workspace", C.c_void_p),
+        ("norm_clip", C.c_float), ("norm_update", C.c_int), ("normalize_partial_reset", C.c_int),
     ]
 
 
@@ -88,6 +90,8 @@ SIGNATURES = {
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_minibatch_grad_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p]),
     "trl_ppo_wg_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "trl_rollout_norm_workspace": (C.c_int, [C.c_int]),
+    "trl_rollout_norm_max_envs": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "trl_frame_stream_append_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_frame_stream_gather_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

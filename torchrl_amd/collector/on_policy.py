@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from .. import _C
+from .. import dist
 from .base import VecCollector, BaseCollector
 
 
@@ -59,10 +60,33 @@ class VecOnPolicyCollector(VecCollector):
         self._spec = ps
 
     # ---- launch ----
-    def _launch(self, env, n_steps, store, deterministic, noise, max_frames=None):
+    def _fused_norm_ok(self, env, update):
+        """The persistent kernel carries a normalised env when its workgroups can all be resident (they meet once
+        per step to pool the observation statistics) and the statistics are not shared between GPUs."""
+        if not hasattr(env, "_obs_normalizer") or getattr(self, "force_per_step", False):
+            return False
+        if update and dist.collectives_active():
+            return False
+        if getattr(self, "_norm_cap", None) is None:
+            D, H, A, act = self._spec
+            self._norm_cap = _C.lib().trl_rollout_norm_max_envs(D, H, A, act)
+        return (not update) or env.env_nums <= self._norm_cap
+
+    def _launch(self, env, n_steps, store, deterministic, noise, max_frames=None, policy_ob=None):
         D, H, A, act = self._spec
         buf = self.replay_buffer
         a = _C.RolloutArgs()
+        nz = getattr(env, "_obs_normalizer", None)
+        if nz is not None:
+            N_ = env.env_nums
+            if getattr(self, "_norm_ws", None) is None or self._norm_ws_n != N_:
+                self._norm_ws = torch.zeros(_C.lib().trl_rollout_norm_workspace(N_), dtype=torch.float64, device=env.device)
+                self._norm_ws_n = N_
+            update = bool(env.training and nz.should_estimate)
+            a.norm_state, a.policy_obs = nz.state.data_ptr(), policy_ob.data_ptr()
+            a.norm_workspace, a.norm_clip = self._norm_ws.data_ptr(), float(nz.clip)
+            a.norm_update = int(update)
+            a.normalize_partial_reset = int(bool(getattr(env, "normalize_partial_reset", False)))
         a.pf_params = self.pf.flat_params().data_ptr()
         a.vf_params = self.vf.flat_params().data_ptr()
         a.D, a.H, a.A, a.act = D, H, A, act
@@ -172,7 +196,16 @@ class VecOnPolicyCollector(VecCollector):
         """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""
         self.env.train()
         if hasattr(self.env, "_obs_normalizer"):
-            return self._rollout_normed(n_steps)
+            nz = self.env._obs_normalizer
+            if not self._fused_norm_ok(self.env, self.env.training and nz.should_estimate):
+                return self._rollout_normed(n_steps)
+            ob = torch.as_tensor(self.current_ob).to(device=self.env.device, dtype=torch.float32).contiguous().clone()
+            noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
+            self._launch(self.env, n_steps, True, False, noise, policy_ob=ob)
+            self.global_step += n_steps
+            self.current_ob = ob
+            self._check_rendezvous = True                       # read with the epoch header (no sync here)
+            return
         noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
         self._launch(self.env, n_steps, True, False, noise)
         self.global_step += n_steps
@@ -181,6 +214,10 @@ class VecOnPolicyCollector(VecCollector):
     def train_one_epoch(self):
         self.rollout(self.sample_epoch_frames)
         self.train_epoch_reward, cnt = self._read_header()                # one 16-byte D2H per epoch ...
+        if getattr(self, "_check_rendezvous", False):
+            self._check_rendezvous = False
+            if int(self._norm_ws[:2].view(torch.int32)[2].item()) != 0:
+                raise _C.TrlError("rollout: grid rendezvous timed out (workgroups were not co-resident)")
         log = self._finished_episodes(cnt)                                 # ... plus the episode log when any ended
         self.train_rews = [np.float32(r) for r in log[:, 2]]
         return {'train_rewards': self.train_rews, 'train_epoch_reward': self.train_epoch_reward}
@@ -199,7 +236,9 @@ class VecOnPolicyCollector(VecCollector):
         rews, lens = [], []
         for _ in range(self.eval_episodes):
             ob = env.reset()
-            if hasattr(env, "_obs_normalizer"):
+            if hasattr(env, "_obs_normalizer") and self._fused_norm_ok(env, False):
+                self._launch(env, env.horizon, False, True, None, max_frames=2 ** 31 - 1, policy_ob=ob.contiguous().clone())
+            elif hasattr(env, "_obs_normalizer"):
                 self._clear_header()
                 for t in range(env.horizon):
                     ob = self._step_normed(env, ob, False, True, None, t, max_frames=2 ** 31 - 1)

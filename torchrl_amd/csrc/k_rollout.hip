@@ -54,7 +54,39 @@ struct RolloutDev {
   int rows, top, N, n_steps, max_episode_frames; float discount;
   double* epoch_reward; int32_t* ep_count; float* ep_log; int ep_cap; int step0;
   int tanh_action, deterministic, store;
+  // running observation normaliser (NORM instantiation only)
+  double* norm_state; float* policy_obs; double* norm_ws; float norm_clip; int norm_update, norm_partial_reset;
 };
+
+// ---- grid-wide rendezvous of the (always co-resident) rollout workgroups ----
+// ws header (as uint32): [0] ticket, [1] generation, [2] error flag.  Everything exchanged travels through
+// agent-scope relaxed atomics; the spin is capped so a scheduling accident raises a flag instead of hanging the GPU.
+__device__ __forceinline__ void grid_rendezvous(unsigned* hdr, unsigned n_wg, unsigned g_start, unsigned k) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(hdr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == n_wg - 1) {
+      __hip_atomic_store(hdr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      int it = 0;
+      while ((unsigned)(__hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g_start) < k) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++it > (1 << 22)) { __hip_atomic_store(hdr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ float ro_row_sum16(float v) {          // sum over the 16 env lanes of a lane group
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));
+  return v;
+}
+#define NORM_SLOT 40                                 // doubles per workgroup partial: sum x [D] | sum x^2 [D] | any flag
 
 template <int D, int H, int A> struct RoShape {
   static_assert(H == 64 && D > 16 && D <= 20 && A <= 8, "instantiated for 16 < D <= 20, H == 64, A <= 8");
@@ -63,7 +95,7 @@ template <int D, int H, int A> struct RoShape {
                        O_EPS = O_HP + 4 * 8 * 16, LDS_FLOATS = O_EPS + RO_NB * 8 * 16;
 };
 
-template <int D, int H, int A, int ACT>
+template <int D, int H, int A, int ACT, bool NORM>
 __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   using S = RoShape<D, H, A>;
   using FP = MlpFlat<D, H, A>;
@@ -129,6 +161,25 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) xb[r] = valid ? a.cur_obs[(size_t)n * D + 4 * g + r] : 0.0f;
   xb[4] = (valid && 16 + g < D) ? a.cur_obs[(size_t)n * D + 16 + g] : 0.0f;
+  // NORM: xb is the env's RAW state (it drives the dynamics), xp what the policy sees (normalised, or raw right
+  // after a partial reset -- the reference's behaviour); without a normaliser they are the same.
+  float xp[5];
+  __shared__ double s_mean[NORM ? D : 1], s_var[NORM ? D : 1], s_sum[NORM ? 2 * D + 1 : 1];
+  __shared__ double s_cnt;
+  unsigned* nhdr = NORM ? reinterpret_cast<unsigned*>(a.norm_ws) : nullptr;
+  unsigned g_start = 0, n_sync = 0;
+  if constexpr (NORM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xp[r] = valid ? a.policy_obs[(size_t)n * D + 4 * g + r] : 0.0f;
+    xp[4] = (valid && g == 0) ? a.policy_obs[(size_t)n * D + 16] : 0.0f;
+    if (tid < D) { s_mean[tid] = a.norm_state[tid]; s_var[tid] = a.norm_state[D + tid]; }
+    if (tid == 0) s_cnt = a.norm_state[2 * D];
+    g_start = __hip_atomic_load(nhdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody bumps it before all arrive
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) xp[q] = xb[q];
+  }
   int t_env = valid ? a.t_env[n] : 0;
   int cur_step = valid ? a.cur_step[n] : 0;
   int ep_idx = valid ? a.episode_idx[n] : 0;
@@ -171,7 +222,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
     // ---- policy forward ----
     f32x4 h1 = *reinterpret_cast<const f32x4*>(b1s);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) h1 = mfma16(w1r[q], xb[q], h1);
+    for (int q = 0; q < 5; ++q) h1 = mfma16(w1r[q], xp[q], h1);
     // the observation part of the env step does not wait for the action: it runs in the shadow of the barriers
     f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f};
     float p16 = 0.0f;
@@ -239,6 +290,65 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
     t_env += 1; cur_step += 1;
     const bool done = t_env >= a.horizon;
     const bool surpass = cur_step >= a.max_episode_frames;
+    // ---- NormObs.observation(next_obs) (base_wrapper.py:116-119): statistics over ALL envs, then the filter ----
+    float nxn[5];                                           // what is stored as next_obs / fed to the policy
+    bool any_reset = false;
+    if constexpr (NORM) {
+      if (a.norm_update) {
+        double* part = a.norm_ws + 2 + (size_t)((t & 1) * gridDim.x + blockIdx.x) * NORM_SLOT;
+        if (mo == 0) {                                        // every wave holds the same 16 envs: wave 0 publishes
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            const float v = (valid && (q < 4 || g == 0)) ? nx[q] : 0.0f;
+            const float s1 = ro_row_sum16(v), s2 = ro_row_sum16(v * v);
+            const int f = q < 4 ? 4 * g + q : 16;
+            if (j == 0 && (q < 4 || g == 0)) {
+              __hip_atomic_store(part + f, (double)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(part + D + f, (double)s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          const bool fl = __ballot(valid && (done || surpass)) != 0ull;
+          if (lane == 0) __hip_atomic_store(part + 2 * D, fl ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before this workgroup's ticket is drawn
+        }
+        grid_rendezvous(nhdr, gridDim.x, g_start, ++n_sync);
+        if (tid < 2 * D + 1) {                                // fixed-order fold over the workgroups, 8 loads in flight
+          const double* col = a.norm_ws + 2 + (size_t)((t & 1) * gridDim.x) * NORM_SLOT + tid;
+          double acc = 0.0;
+          int w = 0;
+          for (; w + 8 <= (int)gridDim.x; w += 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = __hip_atomic_load(col + (size_t)(w + k) * NORM_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+          }
+          for (; w < (int)gridDim.x; ++w) acc += __hip_atomic_load(col + (size_t)w * NORM_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_sum[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < D) {                                        // Chan merge (update_mean_var_count, :44-60), same in every workgroup
+          const double bn = (double)a.N, cnt = s_cnt;
+          const double bmean = s_sum[tid] / bn, bvar = fmax(s_sum[D + tid] / bn - bmean * bmean, 0.0);
+          const double delta = bmean - s_mean[tid], tot = cnt + bn;
+          const double m2 = s_var[tid] * cnt + bvar * bn + delta * delta * cnt * bn / tot;
+          s_mean[tid] += delta * bn / tot;
+          s_var[tid] = m2 / tot;
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt += (double)a.N;
+        any_reset = s_sum[2 * D] != 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int f = q < 4 ? 4 * g + q : 16;
+        const double z = ((double)nx[q] - s_mean[f]) / (sqrt(s_var[f]) + 1e-4);
+        nxn[q] = (q < 4 || g == 0) ? (float)fmin(fmax(z, -(double)a.norm_clip), (double)a.norm_clip) : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) nxn[q] = nx[q];
+    }
     ep_ret += raw_rew;
     if (mo == 0 && g == 0 && valid) {
       rew_sum += (double)raw_rew;
@@ -269,12 +379,12 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
     if (valid && a.store) {
       if (mo == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.obs[cell * D + 4 * g + r] = xb[r];
-        if (g == 0) a.obs[cell * D + 16] = xb[4];
+        for (int r = 0; r < 4; ++r) a.obs[cell * D + 4 * g + r] = xp[r];
+        if (g == 0) a.obs[cell * D + 16] = xp[4];
       } else if (mo == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.next_obs[cell * D + 4 * g + r] = nx[r];
-        if (g == 0) a.next_obs[cell * D + 16] = nx[4];
+        for (int r = 0; r < 4; ++r) a.next_obs[cell * D + 4 * g + r] = nxn[r];
+        if (g == 0) a.next_obs[cell * D + 16] = nxn[4];
       } else if (mo == 2) {
         if (has_lo) a.acts[cell * A + g] = act_lo;
         if (has_hi) a.acts[cell * A + 4 + g] = act_hi;
@@ -288,9 +398,37 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
         if (g == 0 && a.old_logp) a.old_logp[cell] = logp;
       }
     }
+    if constexpr (NORM) {
+      // partial_reset hands the collector the RAW observations of ALL envs whenever any env was reset
+      // (base_wrapper.py:23-26, vecenv.py:47-51); otherwise the policy sees the normalised next_obs
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        float alt = xn[q];
+        if (a.norm_partial_reset) {
+          const int f = q < 4 ? 4 * g + q : 16;
+          const double z = ((double)xn[q] - s_mean[f]) / (sqrt(s_var[f]) + 1e-4);
+          alt = (q < 4 || g == 0) ? (float)fmin(fmax(z, -(double)a.norm_clip), (double)a.norm_clip) : 0.0f;
+        }
+        xp[q] = any_reset ? alt : nxn[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) xp[q] = xn[q];
+    }
 #pragma unroll
     for (int q = 0; q < 5; ++q) xb[q] = xn[q];
     CLK(7)
+  }
+  if constexpr (NORM) {
+    if (mo == 0 && valid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a.policy_obs[(size_t)n * D + 4 * g + r] = xp[r];
+      if (g == 0) a.policy_obs[(size_t)n * D + 16] = xp[4];
+    }
+    if (blockIdx.x == 0 && a.norm_update) {
+      if (tid < D) { a.norm_state[tid] = s_mean[tid]; a.norm_state[D + tid] = s_var[tid]; }
+      if (tid == 0) a.norm_state[2 * D] = s_cnt;
+    }
   }
 #ifdef TRL_EXP_CLK
   if (blockIdx.x == 0 && lane == 0)
@@ -407,9 +545,31 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_pass_kernel(ValueDev a) {
   }
 }
 
+// Envs the normalised (cooperative) rollout can carry: its workgroups rendezvous once per step, so all of them
+// must be resident at the same time.
+template <int D, int H, int A, int ACT>
+static int rollout_norm_capacity() {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rollout_kernel<D, H, A, ACT, true>, RO_THREADS, 0) != hipSuccess)
+    return 0;
+  return cus * per_cu * RO_ENVS;
+}
+
 template <int D, int H, int A, int ACT>
 static int launch_rollout(const RolloutDev& d, hipStream_t s) {
-  hipLaunchKernelGGL((rollout_kernel<D, H, A, ACT>), dim3(trl_ceil_div(d.N, RO_ENVS)), dim3(RO_THREADS), 0, s, d);
+  const int n_wg = trl_ceil_div(d.N, RO_ENVS);
+  if (d.norm_state) {
+    const int cap = rollout_norm_capacity<D, H, A, ACT>();
+    if (d.norm_update && d.N > cap) {
+      trl_set_error("rollout: %d envs with a running normaliser exceed the %d that can be co-resident", d.N, cap);
+      return TRL_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL((rollout_kernel<D, H, A, ACT, true>), dim3(n_wg), dim3(RO_THREADS), 0, s, d);
+  } else {
+    hipLaunchKernelGGL((rollout_kernel<D, H, A, ACT, false>), dim3(n_wg), dim3(RO_THREADS), 0, s, d);
+  }
   TRL_LAUNCH_CHECK();
   if (d.store) {
     ValueDev v{d.vf_params, d.obs, d.next_obs, d.values, d.rewards, d.rows, d.top, d.N, d.n_steps, d.discount};
@@ -445,12 +605,28 @@ extern "C" int trl_rollout_synth_f32(const trl_rollout_t* p, void* stream) {
   d.max_episode_frames = p->max_episode_frames; d.discount = p->discount;
   d.epoch_reward = p->epoch_reward; d.ep_count = p->ep_count; d.ep_log = p->ep_log; d.ep_cap = p->ep_cap;
   d.step0 = p->step0; d.tanh_action = p->tanh_action; d.deterministic = p->deterministic; d.store = all_ring ? 1 : 0;
+  d.norm_state = p->norm_state; d.policy_obs = p->policy_obs; d.norm_ws = p->norm_workspace; d.norm_clip = p->norm_clip;
+  d.norm_update = p->norm_update; d.norm_partial_reset = p->normalize_partial_reset;
+  TRL_REQUIRE(!p->norm_state || (p->policy_obs && p->norm_workspace), "normaliser needs policy_obs and its workspace");
   hipStream_t s = (hipStream_t)stream;
   if (p->D == 17 && p->H == 64 && p->A == 6) {
     if (p->act == TRL_ACT_TANH) return launch_rollout<17, 64, 6, TRL_ACT_TANH>(d, s);
     if (p->act == TRL_ACT_RELU) return launch_rollout<17, 64, 6, TRL_ACT_RELU>(d, s);
   }
   trl_set_error("rollout: shape D=%d H=%d A=%d act=%d not instantiated", p->D, p->H, p->A, p->act);
+  return TRL_EUNSUPPORTED;
+}
+
+extern "C" int trl_rollout_norm_workspace(int N) {
+  if (N <= 0) { trl_set_error("trl_rollout_norm_workspace: N must be positive"); return TRL_EINVAL; }
+  return 2 + 2 * trl_ceil_div(N, RO_ENVS) * NORM_SLOT;                 // doubles: header + two parities of partials
+}
+extern "C" int trl_rollout_norm_max_envs(int D, int H, int A, int act) {
+  if (D == 17 && H == 64 && A == 6) {
+    if (act == TRL_ACT_TANH) return rollout_norm_capacity<17, 64, 6, TRL_ACT_TANH>();
+    if (act == TRL_ACT_RELU) return rollout_norm_capacity<17, 64, 6, TRL_ACT_RELU>();
+  }
+  trl_set_error("rollout: shape D=%d H=%d A=%d act=%d not instantiated", D, H, A, act);
   return TRL_EUNSUPPORTED;
 }
 
