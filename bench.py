@@ -181,7 +181,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    forced = os.environ.get("TRL_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ   # 1-GPU smoke test of the RCCL path
+    if args.gpus > 1 or world > 1 or forced:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -224,6 +225,7 @@ def main():
         elapsed = float(tmax.item())
 
     if rank != 0:
+        _shutdown_dist()
         return
     env_steps = world * N_PER_GPU * T * args.steps
     grad_ms = [s.elapsed_time(e) for s, e in probes]
@@ -249,6 +251,13 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_subprocess()
     print(json.dumps(out))
+    _shutdown_dist()
+
+
+def _shutdown_dist():
+    import torch.distributed as td
+    if td.is_available() and td.is_initialized():
+        td.destroy_process_group()
 
 
 def pmc_traffic():
