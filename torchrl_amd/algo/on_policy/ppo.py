@@ -17,6 +17,7 @@ of all minibatches and the logger receives the same info dicts, in order.
 `update(batch)` keeps the reference's single-minibatch entry point (ppo.py:124-152).
 """
 import copy
+import os
 import math
 
 import numpy as np

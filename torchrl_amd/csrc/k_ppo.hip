@@ -537,14 +537,13 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
   if (p < pn) {
     const float* src = partial + (size_t)row0 * p_stride + p;
     int w = wave;
-    for (; w + 60 < nrow; w += 64) {
+    for (; w < nrow; w += 64) {                    // predicated: a ragged row count must not fall back to a serial tail
       float v[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = src[(size_t)(w + 4 * k) * p_stride];
+      for (int k = 0; k < 16; ++k) v[k] = (w + 4 * k < nrow) ? src[(size_t)(w + 4 * k) * p_stride] : 0.0f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[k] += v[k];
     }
-    for (; w < nrow; w += 4) acc[0] += src[(size_t)w * p_stride];
   }
 #pragma unroll
   for (int st = 8; st > 0; st >>= 1)
@@ -558,9 +557,11 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
     grads[(net == 0 ? 0 : p_pf) + p] = gval;
   }
   // scalar statistics: one wave per network, lanes stride over the workgroup partials (independent
-  // loads, shuffle reduction) -- a serial 128-deep dependent-load chain here cost 50 us
-  if (blockIdx.x == 0 && blockIdx.y == 0 && wave < 2) {
-    const int srow0 = wave == 0 ? 0 : n_pf, snrow = wave == 0 ? n_pf : n_wg - n_pf;
+  // loads, shuffle reduction) -- a serial 128-deep dependent-load chain here cost 50 us.  Waves 2 / 3 do it:
+  // wave 0 owns this block's gradient values and, in the fused kernel, its rendezvous ticket.
+  if (blockIdx.x == 0 && blockIdx.y == 0 && wave >= 2) {
+    const int sw = wave - 2;
+    const int srow0 = sw == 0 ? 0 : n_pf, snrow = sw == 0 ? n_pf : n_wg - n_pf;
     const double* base = scal + (size_t)srow0 * 8;
     double v[7];
 #pragma unroll
@@ -575,7 +576,7 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
 #pragma unroll
     for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? wave_max(v[k]) : wave_sum(v[k]);
     if (lane == 0) {
-      if (wave == 0) {
+      if (sw == 0) {
         info[0] = v[6]; info[1] = v[0]; info[2] = v[1]; info[3] = v[2]; info[4] = v[3]; info[5] = v[4]; info[6] = v[5];
         if (logstd) {                                        // log_std/{mean,std,max,min} (ppo.py:82-85)
           double sm = 0, sq = 0, mx = -INFINITY, mn = INFINITY;
