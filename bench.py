@@ -149,6 +149,46 @@ def cpu_baseline(budget_s=25.0):
                                                                  threads, t_upd, full)}
 
 
+def cpu_baseline_offpolicy(kind):
+    """CPU baseline of the secondary workloads (tools/bench_sac.py, tools/bench_dqn.py): the oracle's update on a
+    bounded sample (2 timed updates after 1 warm-up) of the same batch shape.  kind: sac | dqn | qrdqn."""
+    import numpy as np
+    import torch
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    rs = np.random.RandomState(0)
+    if kind == "sac":
+        from oracle import nets
+        from oracle.sac import TwinSACQOracle
+        B, H = 4096, 256
+        gen = torch.Generator().manual_seed(0)
+        o = TwinSACQOracle(nets.init_mlp(17, [H, H], 12, generator=gen), nets.init_mlp(23, [H, H], 1, generator=gen),
+                           nets.init_mlp(23, [H, H], 1, generator=gen), w_std=0, w_mean=0)
+        batch = {"obs": rs.randn(B, 17), "next_obs": rs.randn(B, 17), "acts": np.tanh(rs.randn(B, 6)),
+                 "rewards": rs.randn(B, 1), "terminals": np.zeros((B, 1))}
+        step = lambda: o.update(batch, torch.randn(B, 6), torch.randn(B, 6))
+        sample = "TwinSACQ update, B=4096, MLP 256x256"
+    else:
+        from oracle.dqn import DQNOracle
+        import torchrl_amd.networks as networks
+        from torchrl_amd import ops
+        B, A, Q = 512, 6, (200 if kind == "qrdqn" else 1)
+        torch.manual_seed(0)
+        qf = networks.Net(output_shape=A * Q, base_type=networks.CNNBase, append_hidden_shapes=[512],
+                          activation_func=torch.nn.Tanh, input_shape=(4, 84, 84),
+                          hidden_shapes=[[16, 8, 4, 0], [32, 4, 2, 0], [64, 3, 1, 0]])
+        o = DQNOracle([p.detach().cpu() for p in ops.cnn_param_list(qf)], [4, 2, 1], quantile_num=Q, action_num=A)
+        batch = {"obs": rs.randint(0, 256, (B, 4, 84, 84)).astype(np.uint8),
+                 "next_obs": rs.randint(0, 256, (B, 4, 84, 84)).astype(np.uint8),
+                 "acts": rs.randint(0, A, (B,)), "rewards": rs.randn(B, 1), "terminals": np.zeros((B, 1))}
+        step = lambda: o.update(batch)
+        sample = "%s update, B=512, conv 16/32/64 + fc512%s" % ("QRDQN" if Q > 1 else "DQN", ", Q=200" if Q > 1 else "")
+    step()
+    t0 = time.perf_counter()
+    step(); step()
+    return {"value": 1e3 * (time.perf_counter() - t0) / 2, "unit": "ms/update", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "2 timed " + sample}
+
+
 def cpu_baseline_subprocess(timeout_s=240):
     """Run the CPU leg in its own interpreter (own torch thread pool, spawn-safe, hard time limit)."""
     import subprocess
@@ -172,9 +212,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--workload", default="ppo", choices=["ppo", "sac", "dqn", "qrdqn"],
+                    help="with --cpu-baseline-only: which workload's CPU baseline to time (tools/bench_{sac,dqn}.py)")
     args = ap.parse_args()
     if args.cpu_baseline_only:                      # child mode of the cpu_baseline leg
-        print("CPU_BASELINE " + json.dumps(cpu_baseline()), flush=True)
+        res = cpu_baseline() if args.workload == "ppo" else cpu_baseline_offpolicy(args.workload)
+        print("CPU_BASELINE " + json.dumps(res), flush=True)
         return
     import torch
 

@@ -61,17 +61,21 @@ def run(Q, epochs, cpu, dedup=False):
     if dedup:
         buf.check_overrun()
     if cpu:
-        from oracle.dqn import DQNOracle
-        from torchrl_amd import ops
-        torch.set_num_threads(min(os.cpu_count() or 1, 32))
-        o = DQNOracle([p.detach().cpu() for p in ops.cnn_param_list(qf)], [4, 2, 1], quantile_num=Q, action_num=A)
-        rs = np.random.RandomState(0)
-        batch = {"obs": rs.randint(0, 256, (B, 4, 84, 84)).astype(np.uint8), "next_obs": rs.randint(0, 256, (B, 4, 84, 84)).astype(np.uint8),
-                 "acts": rs.randint(0, A, (B,)), "rewards": rs.randn(B, 1), "terminals": np.zeros((B, 1))}
-        o.update(batch)
-        t0 = time.perf_counter(); o.update(batch); o.update(batch)
-        out["cpu_oracle_ms_per_update"] = 1e3 * (time.perf_counter() - t0) / 2
+        out["cpu_oracle_ms_per_update"] = cpu_baseline_via_bench("qrdqn" if Q > 1 else "dqn")["value"]
     print(json.dumps(out))
+
+
+def cpu_baseline_via_bench(workload):
+    """The oracle-based CPU baseline lives in bench.py's cpu_baseline leg (the only non-test place that may touch
+    oracle/); this runs it as a subprocess and returns its JSON."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--cpu-baseline-only", "--workload", workload],
+                         capture_output=True, text=True, timeout=900)
+    for line in res.stdout.splitlines():
+        if line.startswith("CPU_BASELINE "):
+            return json.loads(line[len("CPU_BASELINE "):])
+    raise RuntimeError("cpu baseline failed: " + res.stderr[-500:])
 
 
 if __name__ == "__main__":

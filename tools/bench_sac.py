@@ -1,6 +1,6 @@
 """Secondary measurement: Twin-Q SAC at BASELINE cfg 3 (1024 envs, 1e6-transition replay = 976 rows,
 B = 4096, MLP 256x256 ReLU): per epoch 16 vector steps (16 384 env-steps) + 16 updates.
-Prints one JSON line; `--cpu` also times the CPU oracle on a bounded sample (2 updates)."""
+Prints one JSON line; `--cpu` adds bench.py's CPU baseline of the same update (bounded sample: 2 updates)."""
 import argparse
 import json
 import os
@@ -63,22 +63,22 @@ def main():
            "env_steps_per_s": args.epochs * N * STEPS / el, "updates_per_s": args.epochs * OPT / tu,
            "ms_per_update": 1e3 * tu / (args.epochs * OPT), "ms_per_vector_step": 1e3 * tc / (args.epochs * STEPS)}
     if args.cpu:
-        from oracle import nets
-        from oracle.sac import TwinSACQOracle
-        torch.set_num_threads(min(os.cpu_count() or 1, 32))
-        gen = torch.Generator().manual_seed(0)
-        o = TwinSACQOracle(nets.init_mlp(17, [H, H], 12, generator=gen), nets.init_mlp(23, [H, H], 1, generator=gen),
-                           nets.init_mlp(23, [H, H], 1, generator=gen), w_std=0, w_mean=0)
-        rs = np.random.RandomState(0)
-        batch = {"obs": rs.randn(B, 17), "next_obs": rs.randn(B, 17), "acts": np.tanh(rs.randn(B, 6)),
-                 "rewards": rs.randn(B, 1), "terminals": np.zeros((B, 1))}
-        o.update(batch, torch.randn(B, 6), torch.randn(B, 6))
-        t0 = time.perf_counter()
-        for _ in range(2):
-            o.update(batch, torch.randn(B, 6), torch.randn(B, 6))
-        out["cpu_oracle_ms_per_update"] = 1e3 * (time.perf_counter() - t0) / 2
-        out["cpu_threads"] = torch.get_num_threads()
+        base = cpu_baseline_via_bench("sac")
+        out["cpu_oracle_ms_per_update"], out["cpu_threads"] = base["value"], base["cores"]
     print(json.dumps(out))
+
+
+def cpu_baseline_via_bench(workload):
+    """The oracle-based CPU baseline lives in bench.py's cpu_baseline leg (the only non-test place that may touch
+    oracle/); this runs it as a subprocess and returns its JSON."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--cpu-baseline-only", "--workload", workload],
+                         capture_output=True, text=True, timeout=900)
+    for line in res.stdout.splitlines():
+        if line.startswith("CPU_BASELINE "):
+            return json.loads(line[len("CPU_BASELINE "):])
+    raise RuntimeError("cpu baseline failed: " + res.stderr[-500:])
 
 
 if __name__ == "__main__":
