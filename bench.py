@@ -175,7 +175,7 @@ def cpu_baseline_offpolicy(kind):
         torch.manual_seed(0)
         qf = networks.Net(output_shape=A * Q, base_type=networks.CNNBase, append_hidden_shapes=[512],
                           activation_func=torch.nn.Tanh, input_shape=(4, 84, 84),
-                          hidden_shapes=[[16, 8, 4, 0], [32, 4, 2, 0], [64, 3, 1, 0]])
+                          hidden_shapes=[[16, [8, 8], [4, 4], [0, 0]], [32, [4, 4], [2, 2], [0, 0]], [64, [3, 3], [1, 1], [0, 0]]])
         o = DQNOracle([p.detach().cpu() for p in ops.cnn_param_list(qf)], [4, 2, 1], quantile_num=Q, action_num=A)
         batch = {"obs": rs.randint(0, 256, (B, 4, 84, 84)).astype(np.uint8),
                  "next_obs": rs.randint(0, 256, (B, 4, 84, 84)).astype(np.uint8),
