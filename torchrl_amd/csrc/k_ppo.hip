@@ -676,51 +676,42 @@ __device__ __forceinline__ void adam_element(const AdamDev& a, int e, float gr) 
 }
 
 // Single-GPU path: partial reduce + clip_grad_norm_ + Adam in ONE launch.  Every block folds its 64
-// parameters and publishes their sum of squares, then all blocks of the (small, always co-resident:
-// 2 x 90 blocks on 256 CUs) grid rendezvous on a ticket counter; after the rendezvous every block
-// derives the two group norms from the published partials in the same fixed order (deterministic,
-// identical in all blocks) and takes the Adam step for its own 64 parameters straight from registers.
-// ws: [0] ticket (returns to 0), [1] generation, [16..] partials.
+// parameters and publishes their sum of squares as ONE 64-bit agent-scope store {ss, epoch}; every block
+// then polls the 2 x 90 slots until all carry the epoch of this launch (the blocks are always
+// co-resident: 180 small blocks on 256 CUs), derives the two group norms from them in the same fixed
+// order (deterministic, identical in all blocks) and takes the Adam step for its own 64 parameters straight
+// from registers.  No ticket, no reset: a slot is valid iff its epoch matches (epoch = Adam step count > 0;
+// the workspace starts zeroed).  The poll is capped: a scheduling accident trips ws[0] instead of hanging.
 __global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const float* __restrict__ partial,
                                                               const double* __restrict__ scal, int n_wg, int n_pf,
                                                               int p_stride, int p_pf, int p_vf,
                                                               const float* __restrict__ logstd, int n_act,
                                                               float* __restrict__ grads, double* __restrict__ info,
-                                                              AdamDev a, float* __restrict__ ws) {
+                                                              AdamDev a, float* __restrict__ ws, unsigned epoch) {
   __shared__ float s_coef[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned* ticket = reinterpret_cast<unsigned*>(ws);
-  unsigned* gen = ticket + 1;
-  float* ss_part = ws + 16;                                    // [2 nets][nb]
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(ws + 16);    // [2 nets][nb] {ss bits, epoch}
   const int nb = gridDim.x;
-  unsigned g0 = 0;
-  if (tid == 0) g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float gval = ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
   if (wave == 0) {
     const float ss = wave_sum(gval * gval);
-    if (lane == 0) {
-      // Everything exchanged here travels through agent-scope atomics (they bypass the non-coherent
-      // cache levels), so ordering only needs the store to be acknowledged before the ticket is drawn --
-      // no release/acquire fences: those write back / invalidate whole caches and cost ~10 us here.
-      __hip_atomic_store(ss_part + blockIdx.y * nb + blockIdx.x, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (unsigned)(2 * nb - 1)) {                       // last arrival opens the gate
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) __builtin_amdgcn_s_sleep(1);
-      }
-      asm volatile("" ::: "memory");
-    }
+    if (lane == 0)
+      __hip_atomic_store(slots + blockIdx.y * nb + blockIdx.x,
+                         ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(ss),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();
-  // ---- group norms (pf, vf): fixed summation order, same in every block ----
+  // ---- group norms (pf, vf): wave w polls net w's slots, then sums them in fixed order ----
   if (wave < 2) {
     float acc = 0.0f;
-    for (int b = lane; b < nb; b += 64)
-      acc += __hip_atomic_load(ss_part + wave * nb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int b = lane; b < nb; b += 64) {
+      unsigned long long v;
+      int it = 0;
+      while ((unsigned)((v = __hip_atomic_load(slots + wave * nb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++it > (1 << 22)) { __hip_atomic_store(reinterpret_cast<unsigned*>(ws), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      acc += __uint_as_float((unsigned)v);
+    }
     acc = wave_sum(acc) * a.grad_scale * a.grad_scale;
     if (lane == 0) {
       const float norm = sqrtf(acc);
@@ -885,7 +876,7 @@ static int fill_adam(const trl_adam_t* p, AdamDev& d) {
 extern "C" int trl_ppo_reduce_adam_workspace(int D, int H, int A) {
   const int ps = trl_ppo_partial_stride(D, H, A);
   if (ps < 0) return ps;
-  return 16 + 2 * trl_ceil_div(ps, RED_CHUNK);
+  return 16 + 4 * trl_ceil_div(ps, RED_CHUNK);       // header + {ss, epoch} per block and network
 }
 
 extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
@@ -904,7 +895,7 @@ extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_
   TRL_REQUIRE(adam->grads == grads, "adam->grads must be the reduce output");
   hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(trl_ceil_div(ps, RED_CHUNK), 2), dim3(256), 0, (hipStream_t)stream,
                      partial, scal_partial, n_wg, resolve_pf_wgs(n_wg, n_wg_pf), ps, p_pf, p_vf,
-                     (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace);
+                     (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace, (unsigned)adam->step_count);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }

@@ -58,27 +58,11 @@ struct RolloutDev {
   double* norm_state; float* policy_obs; double* norm_ws; float norm_clip; int norm_update, norm_partial_reset;
 };
 
-// ---- grid-wide rendezvous of the (always co-resident) rollout workgroups ----
-// ws header (as uint32): [0] ticket, [1] generation, [2] error flag.  Everything exchanged travels through
-// agent-scope relaxed atomics; the spin is capped so a scheduling accident raises a flag instead of hanging the GPU.
-__device__ __forceinline__ void grid_rendezvous(unsigned* hdr, unsigned n_wg, unsigned g_start, unsigned k) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(hdr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == n_wg - 1) {
-      __hip_atomic_store(hdr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      int it = 0;
-      while ((unsigned)(__hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g_start) < k) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++it > (1 << 22)) { __hip_atomic_store(hdr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-    }
-  }
-  __syncthreads();
-}
+// ---- grid-wide exchange between the (always co-resident) rollout workgroups ----
+// No ticket counter: a workgroup publishes its partials, waits for the stores to be acknowledged and then
+// stamps its slot of the epoch table with the (launch-unique, monotone) step number; readers poll the
+// stamps.  Everything travels through agent-scope relaxed atomics; the poll is capped so a scheduling
+// accident raises the error word (ws header [2]) instead of hanging the GPU.
 __device__ __forceinline__ float ro_row_sum16(float v) {          // sum over the 16 env lanes of a lane group
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));
@@ -86,7 +70,7 @@ __device__ __forceinline__ float ro_row_sum16(float v) {          // sum over th
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));
   return v;
 }
-#define NORM_SLOT 40                                 // doubles per workgroup partial: sum x [D] | sum x^2 [D] | any flag
+#define NORM_SLOT 40                                 // doubles per workgroup partial: sum x [D] | sum x^2 [D] | any flag | .. | stamp
 
 template <int D, int H, int A> struct RoShape {
   static_assert(H == 64 && D > 16 && D <= 20 && A <= 8, "instantiated for 16 < D <= 20, H == 64, A <= 8");
@@ -167,14 +151,12 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   __shared__ double s_mean[NORM ? D : 1], s_var[NORM ? D : 1], s_sum[NORM ? 2 * D + 1 : 1];
   __shared__ double s_cnt;
   unsigned* nhdr = NORM ? reinterpret_cast<unsigned*>(a.norm_ws) : nullptr;
-  unsigned g_start = 0, n_sync = 0;
   if constexpr (NORM) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) xp[r] = valid ? a.policy_obs[(size_t)n * D + 4 * g + r] : 0.0f;
     xp[4] = (valid && g == 0) ? a.policy_obs[(size_t)n * D + 16] : 0.0f;
     if (tid < D) { s_mean[tid] = a.norm_state[tid]; s_var[tid] = a.norm_state[D + tid]; }
     if (tid == 0) s_cnt = a.norm_state[2 * D];
-    g_start = __hip_atomic_load(nhdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody bumps it before all arrive
     __syncthreads();
   } else {
 #pragma unroll
@@ -309,9 +291,23 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
           }
           const bool fl = __ballot(valid && (done || surpass)) != 0ull;
           if (lane == 0) __hip_atomic_store(part + 2 * D, fl ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before this workgroup's ticket is drawn
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partials acknowledged before the stamp goes out
+          const unsigned long long stamp = (unsigned long long)(a.noise_step0 + t + 1);
+          if (lane == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + NORM_SLOT - 1), stamp, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          // wave 0 polls every workgroup's stamp (lanes stride over the workgroups)
+          for (int w = lane; w < (int)gridDim.x; w += 64) {
+            const unsigned long long* st = reinterpret_cast<const unsigned long long*>(
+                a.norm_ws + 2 + (size_t)((t & 1) * gridDim.x + w) * NORM_SLOT + NORM_SLOT - 1);
+            int it = 0;
+            while (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) {
+              __builtin_amdgcn_s_sleep(1);
+              if (++it > (1 << 22)) { __hip_atomic_store(nhdr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+          }
         }
-        grid_rendezvous(nhdr, gridDim.x, g_start, ++n_sync);
+        __syncthreads();
         if (tid < 2 * D + 1) {                                // fixed-order fold over the workgroups, 8 loads in flight
           const double* col = a.norm_ws + 2 + (size_t)((t & 1) * gridDim.x) * NORM_SLOT + tid;
           double acc = 0.0;
