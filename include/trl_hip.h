@@ -218,6 +218,10 @@ typedef struct trl_adam_t {
   int step_count;
   float grad_scale;           /* grads are multiplied by this first (1/world_size) */
   float* norms_out;           /* (n_groups) pre-clip global norms */
+  int device_state;           /* trl_ppo_reduce_adam_f32 only: 1 = take the step count and the two learning
+                                 rates from its workspace header instead of step_count / group_lr
+                                 (ws[1]: steps taken so far, uint32, bumped by the kernel; ws[2], ws[3]: lr),
+                                 so that no launch argument changes between replays of a captured graph */
 } trl_adam_t;
 int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
 /* Single-process fast path: trl_ppo_reduce_f32 + trl_clip_adam_f32 in one launch (the block that

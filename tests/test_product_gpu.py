@@ -170,3 +170,27 @@ def test_example_script_runs_unchanged_api(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "EPOCH:1" in out.stdout
     assert os.path.exists(tmp_path / "log" / "ppo_small" / "SynthHalfCheetah-v0" / "1" / "model" / "model_pf_finish.pth")
+
+
+def test_graph_replay_matches_eager_launches(golden, monkeypatch):
+    """The captured-and-replayed minibatch loop (third and later epochs of a shape) must be bit-identical to
+    launching the same kernels one by one: same parameters, same Adam state, same info dicts."""
+    g = golden("collect_epoch")
+    tag = "mixed"
+    N, T, horizon, max_frames, B, seed = (int(x) for x in g[f"{tag}_args"])
+    results = []
+    for no_graph in ("1", "0"):
+        monkeypatch.setenv("TRL_NO_GRAPH", no_graph)
+        pf, vf, env, buf, col, agent, logger = build(g, tag, N, T, horizon, max_frames, B, seed, noise_mode="device")
+        for epoch in range(4):
+            col.train_one_epoch()
+            agent.current_epoch = epoch
+            np.random.seed(seed + epoch)
+            agent.update_per_epoch()
+        eng = agent.engine()
+        assert (eng._graph is not None) == (no_graph == "0")
+        assert int(eng.red_ws[:2].view(torch.int32)[1].item()) == eng.step_count == len(logger.infos)
+        results.append((eng.flat.clone(), eng.m.clone(), eng.v.clone(), logger.infos))
+    (f0, m0, v0, i0), (f1, m1, v1, i1) = results
+    assert torch.equal(f0, f1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert len(i0) == len(i1) and all(a == b for a, b in zip(i0, i1))

@@ -169,26 +169,51 @@ class _FusedPPO:
             raise _C.TrlError("trl_ppo_wg_split(%d tiles, %d workgroups) returned %d" % (tiles, n_wg, n_pf))
         return n_wg, n_pf
 
+    def _buffers(self, K, rows_mb):
+        """Persistent per-shape device buffers: minibatch row indices and the statistics block
+        raw (K,4) f64 | info (K,24) f64 | norms (K,2) f32 (one memset, one D2H per run; stable addresses
+        so that a captured launch sequence can be replayed)."""
+        key = (K, rows_mb)
+        if getattr(self, "_buf_key", None) != key:
+            self._buf_key = key
+            self._idx_buf = torch.zeros(K * rows_mb, dtype=torch.int64, device=self.dev)
+            self._stats = torch.zeros(29 * K, dtype=torch.float64, device=self.dev)
+            self._graph = None
+        return self._idx_buf, self._stats
+
+    def _set_device_hyper(self, lr_pf, lr_vf):
+        hyper = (float(lr_pf), float(lr_vf))
+        if getattr(self, "_hyper", None) != hyper:
+            self._hyper = hyper
+            self.red_ws[2:4].copy_(torch.tensor(hyper, dtype=torch.float32), non_blocking=True)
+
     def run(self, t, row_idx, N):
         """t: dict of (rows, N, feat) device tensors; row_idx: (K, rows_mb) host int64.
-        Runs K minibatch updates back to back; returns K info dicts (one host sync at the end)."""
+        Runs K minibatch updates back to back; returns K info dicts (one host sync at the end).
+        Single process: the K x {gradient kernel, fused reduce/clip/Adam} launches are captured into a HIP
+        graph the first time a shape is seen and replayed afterwards (dependent launches start ~2.5 us earlier
+        each inside a graph on this machine); the Adam step count and learning rates live on the device so no
+        launch argument changes between replays."""
         algo, dev = self.algo, self.dev
         K, rows_mb = row_idx.shape
         world = dist.world_size()
         n_local = rows_mb * N
         n_global = float(n_local * world)
-        idx_dev = torch.from_numpy(np.ascontiguousarray(row_idx)).to(dev)
+        idx_dev, stats = self._buffers(K, rows_mb)
+        idx_dev.copy_(torch.from_numpy(np.ascontiguousarray(row_idx).reshape(-1)), non_blocking=True)
+        stats.zero_()
         rows_total = t["advs"].shape[0]
-        # one statistics buffer (one memset, one D2H at the end): raw (K,4) f64 | info (K,24) f64 | norms (K,2) f32
-        stats = torch.zeros(29 * K, dtype=torch.float64, device=dev)
         raw, info = stats[:4 * K].view(K, 4), stats[4 * K:28 * K].view(K, 24)
         norms = stats[28 * K:].view(torch.float32).view(K, 2)
-        _C.adv_stats(t["advs"].reshape(rows_total, N), idx_dev, raw)
-        dist.reduce_adv_raw_(raw)
         n_wg, n_wg_pf = self._n_wg(n_local)
+        loss_mode = int(getattr(algo, "loss_mode", _C.LOSS_PPO_CLIP))
+        probe = getattr(self, "probe", None)                           # bench.py: HIP events around the grad kernel
+        fused = not dist.collectives_active()
+        lr_pf, lr_vf = algo.pf_optimizer.param_groups[0]['lr'], algo.vf_optimizer.param_groups[0]['lr']
+        if fused:
+            self._set_device_hyper(lr_pf, lr_vf)
 
         g = _C.PpoBatchArgs()
-        loss_mode = int(getattr(algo, "loss_mode", _C.LOSS_PPO_CLIP))
         for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"):
             setattr(g, k, _C.dev_ptr(t[k], name=k).value if t.get(k) is not None else None)
         g.loss_mode = loss_mode
@@ -205,39 +230,60 @@ class _FusedPPO:
                                                       self.m.data_ptr(), self.v.data_ptr())
         a.n_groups = 2
         a.group_sizes[0], a.group_sizes[1] = self.P_pf, self.P_vf
-        a.group_lr[0] = algo.pf_optimizer.param_groups[0]['lr']
-        a.group_lr[1] = algo.vf_optimizer.param_groups[0]['lr']
+        a.group_lr[0], a.group_lr[1] = lr_pf, lr_vf
         a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = 0.5, 0.9, 0.999, 1e-5, 1.0
+        a.device_state = int(fused)                                    # step count / lr from the workspace header
 
         idx_base, raw_base, info_base, norm_base = idx_dev.data_ptr(), raw.data_ptr(), info.data_ptr(), norms.data_ptr()
-        lib, stream = _C.lib(), _C.stream_ptr(dev)
+        lib = _C.lib()
         import ctypes as C
-        probe = getattr(self, "probe", None)                           # bench.py: HIP events around the grad kernel
-        fused = not dist.collectives_active()
-        for k in range(K):
-            g.row_idx = idx_base + 8 * rows_mb * k
-            g.adv_raw = raw_base + 32 * k
-            if probe is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "trl_ppo_minibatch_grad_f32")
-            if probe is not None:
-                ev[1].record()
-                probe.append(ev)
-            self.step_count += 1
-            a.step_count = self.step_count
-            a.norms_out = norm_base + 8 * k
-            if fused:                                                  # one process: reduce + clip + Adam in one launch
-                _C.check(lib.trl_ppo_reduce_adam_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf,
-                                                     self.D, self.H, self.A, self.grads.data_ptr(), info_base + 192 * k,
-                                                     C.byref(a), self.red_ws.data_ptr(), stream),
-                         "trl_ppo_reduce_adam_f32")
-                continue
-            _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf, self.D, self.H,
-                                            self.A, self.flat.data_ptr(), self.grads.data_ptr(),
-                                            info_base + 192 * k, stream), "trl_ppo_reduce_f32")
-            dist.all_reduce_sum_(self.grads)                           # C1: gradient SUM over ranks
-            _C.check(lib.trl_clip_adam_f32(C.byref(a), stream), "trl_clip_adam_f32")
+
+        def launch_all():
+            stream = _C.stream_ptr(dev)
+            _C.adv_stats(t["advs"].reshape(rows_total, N), idx_dev.view(K, rows_mb), raw)
+            dist.reduce_adv_raw_(raw)
+            for k in range(K):
+                g.row_idx = idx_base + 8 * rows_mb * k
+                g.adv_raw = raw_base + 32 * k
+                if probe is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "trl_ppo_minibatch_grad_f32")
+                if probe is not None:
+                    ev[1].record()
+                    probe.append(ev)
+                a.step_count = self.step_count + k + 1
+                a.norms_out = norm_base + 8 * k
+                if fused:                                              # one process: reduce + clip + Adam in one launch
+                    _C.check(lib.trl_ppo_reduce_adam_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf,
+                                                         self.D, self.H, self.A, self.grads.data_ptr(), info_base + 192 * k,
+                                                         C.byref(a), self.red_ws.data_ptr(), stream),
+                             "trl_ppo_reduce_adam_f32")
+                    continue
+                _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf, self.D,
+                                                self.H, self.A, self.flat.data_ptr(), self.grads.data_ptr(),
+                                                info_base + 192 * k, stream), "trl_ppo_reduce_f32")
+                dist.all_reduce_sum_(self.grads)                       # C1: gradient SUM over ranks
+                _C.check(lib.trl_clip_adam_f32(C.byref(a), stream), "trl_clip_adam_f32")
+
+        use_graph = fused and probe is None and os.environ.get("TRL_NO_GRAPH") != "1"
+        key = (n_wg, n_wg_pf, loss_mode, g.clip_para, g.entropy_coeff, g.clipped_value_loss, g.tanh_action, n_global,
+               rows_total, N) + tuple(getattr(g, k) for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
+        if not use_graph:
+            launch_all()
+        elif getattr(self, "_graph", None) is not None and self._graph_key == key:
+            self._graph.replay()
+        elif getattr(self, "_graph_seen", None) != key:
+            self._graph_seen = key                                     # first visit of a shape: run eagerly (warm-up)
+            self._graph = None
+            launch_all()
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                launch_all()
+            self._graph, self._graph_key = graph, key
+            graph.replay()
+        self.step_count += K
         for s in self._opt_steps:
             s.fill_(float(self.step_count))
         dist.reduce_info_(info)

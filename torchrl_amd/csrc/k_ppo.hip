@@ -694,9 +694,28 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
                                                               int p_stride, int p_pf, int p_vf,
                                                               const float* __restrict__ logstd, int n_act,
                                                               float* __restrict__ grads, double* __restrict__ info,
-                                                              AdamDev a, float* __restrict__ ws, unsigned epoch) {
+                                                              AdamDev a, float* __restrict__ ws, unsigned epoch,
+                                                              int device_state) {
   __shared__ float s_coef[2];
+  __shared__ float s_hyper[4];                                    // bc1, bc2_sqrt, lr_pf, lr_vf
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Graph-replayable form: the Adam step count and the learning rates live in the workspace header
+  // (ws[1] = steps taken so far as uint32, ws[2..3] = lr), so no launch argument changes between replays.
+  // Every block reads the count BEFORE it publishes its slot; block (0, 0) bumps it only after it has seen
+  // all slots, i.e. after every block has read it.
+  if (device_state) {
+    if (tid == 0) {
+      const unsigned step = __hip_atomic_load(reinterpret_cast<unsigned*>(ws) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      s_hyper[0] = (float)(1.0 - pow((double)a.beta1, (double)step));
+      s_hyper[1] = (float)sqrt(1.0 - pow((double)a.beta2, (double)step));
+      s_hyper[2] = ws[2]; s_hyper[3] = ws[3];
+      s_coef[0] = __uint_as_float(step);                            // broadcast slot (overwritten below)
+    }
+    __syncthreads();
+    epoch = __float_as_uint(s_coef[0]);
+    a.bc1 = s_hyper[0]; a.bc2_sqrt = s_hyper[1]; a.lr[0] = s_hyper[2]; a.lr[1] = s_hyper[3];
+    __syncthreads();
+  }
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(ws + 16);    // [2 nets][nb] {ss bits, epoch}
   const int nb = gridDim.x;
   const float gval = ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
@@ -727,6 +746,8 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
     }
   }
   __syncthreads();
+  if (device_state && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int net = blockIdx.y;
   const int p = blockIdx.x * RED_CHUNK + lane;
   if (wave == 0 && p < (net == 0 ? p_pf : p_vf))
@@ -863,7 +884,7 @@ static int fill_adam(const trl_adam_t* p, AdamDev& d) {
   if (!p) { trl_set_error("clip_adam: null descriptor"); return TRL_EINVAL; }
   TRL_REQUIRE(p->params && p->grads && p->exp_avg && p->exp_avg_sq, "null pointer");
   TRL_REQUIRE(p->n_groups >= 1 && p->n_groups <= 4, "n_groups must be 1..4");
-  TRL_REQUIRE(p->step_count >= 1, "step_count starts at 1");
+  TRL_REQUIRE(p->step_count >= 1 || p->device_state, "step_count starts at 1");
   d.params = p->params; d.grads = p->grads; d.m = p->exp_avg; d.v = p->exp_avg_sq;
   d.n_groups = p->n_groups; d.off[0] = 0;
   for (int g = 0; g < p->n_groups; ++g) {
@@ -902,7 +923,8 @@ extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_
   TRL_REQUIRE(adam->grads == grads, "adam->grads must be the reduce output");
   hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(trl_ceil_div(ps, RED_CHUNK), 2), dim3(64 * RED_WAVES), 0, (hipStream_t)stream,
                      partial, scal_partial, n_wg, resolve_pf_wgs(n_wg, n_wg_pf), ps, p_pf, p_vf,
-                     (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace, (unsigned)adam->step_count);
+                     (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace, (unsigned)adam->step_count,
+                     adam->device_state);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -911,6 +933,7 @@ extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {
   AdamDev d;
   int rc = fill_adam(p, d);
   if (rc) return rc;
+  TRL_REQUIRE(!p->device_state, "device_state is a feature of trl_ppo_reduce_adam_f32");
   const int total = d.off[p->n_groups];
   if (total == 0) return TRL_OK;
   hipLaunchKernelGGL(clip_adam_kernel, dim3(trl_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, d);
