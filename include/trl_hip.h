@@ -220,7 +220,8 @@ typedef struct trl_adam_t {
   float* norms_out;           /* (n_groups) pre-clip global norms */
   int device_state;           /* trl_ppo_reduce_adam_f32 only: 1 = take the step count and the two learning
                                  rates from its workspace header instead of step_count / group_lr
-                                 (ws[1]: steps taken so far, uint32, bumped by the kernel; ws[2], ws[3]: lr),
+                                 (ws[1]: steps taken so far, uint32; ws[2], ws[3]: lr; ws[4..7]: two doubles
+                                 beta1^steps, beta2^steps -- initialise to 1.0; the kernel advances all of them),
                                  so that no launch argument changes between replays of a captured graph */
 } trl_adam_t;
 int trl_clip_adam_f32(const trl_adam_t* args, void* stream);

@@ -142,7 +142,8 @@ class _FusedPPO:
         self.partial = torch.zeros(self.max_wg, self.p_stride, device=self.dev)
         self.scal = torch.zeros(self.max_wg, 8, dtype=torch.float64, device=self.dev)
         n_ws = _C.lib().trl_ppo_reduce_adam_workspace(self.D, self.H, self.A)
-        self.red_ws = torch.zeros(n_ws, device=self.dev)              # ticket + partial norms of the fused reduce/Adam
+        self.red_ws = torch.zeros(n_ws, device=self.dev)              # header + norm slots of the fused reduce/Adam
+        self.red_ws[4:8].view(torch.float64).fill_(1.0)               # beta1^0, beta2^0 (device-side Adam state)
 
     def _alias_optimizer_state(self, opt, plist, offset):
         self._opt_steps = getattr(self, "_opt_steps", [])

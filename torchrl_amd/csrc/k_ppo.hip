@@ -703,22 +703,24 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   // (ws[1] = steps taken so far as uint32, ws[2..3] = lr), so no launch argument changes between replays.
   // Every block reads the count BEFORE it publishes its slot; block (0, 0) bumps it only after it has seen
   // all slots, i.e. after every block has read it.
+  // (the count was written by the previous launch, so a plain uniform load -- a scalar load that flies under the
+  // reduction's vector loads -- is enough; the bias corrections are computed by an otherwise idle wave)
+  double* bpow = reinterpret_cast<double*>(ws + 4);              // beta1^steps, beta2^steps of the steps taken so far
+  double b1p = 0.0, b2p = 0.0;
+  float lr0 = 0.0f, lr1 = 0.0f;
   if (device_state) {
-    if (tid == 0) {
-      const unsigned step = __hip_atomic_load(reinterpret_cast<unsigned*>(ws) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-      s_hyper[0] = (float)(1.0 - pow((double)a.beta1, (double)step));
-      s_hyper[1] = (float)sqrt(1.0 - pow((double)a.beta2, (double)step));
-      s_hyper[2] = ws[2]; s_hyper[3] = ws[3];
-      s_coef[0] = __uint_as_float(step);                            // broadcast slot (overwritten below)
-    }
-    __syncthreads();
-    epoch = __float_as_uint(s_coef[0]);
-    a.bc1 = s_hyper[0]; a.bc2_sqrt = s_hyper[1]; a.lr[0] = s_hyper[2]; a.lr[1] = s_hyper[3];
-    __syncthreads();
+    epoch = reinterpret_cast<const unsigned*>(ws)[1] + 1u;
+    if (tid == 64 * (RED_WAVES - 1)) { b1p = bpow[0]; b2p = bpow[1]; lr0 = ws[2]; lr1 = ws[3]; }   // issued now, used after the fold
   }
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(ws + 16);    // [2 nets][nb] {ss bits, epoch}
   const int nb = gridDim.x;
   const float gval = ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
+  if (device_state && tid == 64 * (RED_WAVES - 1)) {
+    b1p *= (double)a.beta1; b2p *= (double)a.beta2;
+    s_hyper[0] = (float)(1.0 - b1p);
+    s_hyper[1] = (float)sqrt(1.0 - b2p);
+    s_hyper[2] = lr0; s_hyper[3] = lr1;
+  }
   if (wave == 0) {
     const float ss = wave_sum(gval * gval);
     if (lane == 0)
@@ -746,8 +748,13 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
     }
   }
   __syncthreads();
-  if (device_state && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (device_state) {
+    a.bc1 = s_hyper[0]; a.bc2_sqrt = s_hyper[1]; a.lr[0] = s_hyper[2]; a.lr[1] = s_hyper[3];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                    // every block has read the header by now (see above)
+      if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 64 * (RED_WAVES - 1)) { bpow[0] = b1p; bpow[1] = b2p; }
+    }
+  }
   const int net = blockIdx.y;
   const int p = blockIdx.x * RED_CHUNK + lane;
   if (wave == 0 && p < (net == 0 ? p_pf : p_vf))
