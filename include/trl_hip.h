@@ -223,6 +223,10 @@ typedef struct trl_adam_t {
                                  (ws[1]: steps taken so far, uint32; ws[2], ws[3]: lr; ws[4..7]: two doubles
                                  beta1^steps, beta2^steps -- initialise to 1.0; the kernel advances all of them),
                                  so that no launch argument changes between replays of a captured graph */
+  double* step_state;         /* trl_clip_adam_f32 only, nullable: 4 doubles on the device {steps taken so far,
+                                 beta1^steps, beta2^steps, 0} initialised to {0, 1, 1, 0}.  When set, step_count is
+                                 ignored, the step uses steps + 1 and the kernel advances the state itself (same
+                                 purpose as device_state: a captured graph of a whole update can be replayed) */
 } trl_adam_t;
 int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
 /* Single-process fast path: trl_ppo_reduce_f32 + trl_clip_adam_f32 in one launch (the block that

@@ -71,6 +71,42 @@ def test_ddpg_td3_update_matches_reference(golden, tag):
     assert float(agent.pf_optimizer.state[pf.seq_append_fcs[0].weight]["exp_avg"].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("kind", ["ddpg", "td3"])
+def test_graph_replayed_updates_equal_eager_updates(golden, kind, monkeypatch):
+    """From the third visit of a configuration on, an update replays a captured HIP graph (per-network Adam step
+    counts live on the device; TD3 alternates between two graphs, with and without the delayed policy step):
+    identical launches, so parameters and logged statistics equal the eager sequence bit for bit."""
+    g = golden("ddpg_td3")
+    B = 256
+    gen = torch.Generator().manual_seed(5)
+    batches = [{"obs": torch.randn(B, 17, generator=gen), "next_obs": torch.randn(B, 17, generator=gen),
+                "acts": torch.rand(B, 6, generator=gen) * 2 - 1, "rewards": torch.randn(B, 1, generator=gen),
+                "terminals": (torch.rand(B, 1, generator=gen) < 0.1).float()} for _ in range(8)]
+    results = []
+    for no_graph in ("1", "0"):
+        monkeypatch.setenv("TRL_NO_GRAPH", no_graph)
+        pf, qf1, qf2, kw, DDPG, TD3 = _build(kind, 1.0, B)
+        pf.load_state_dict(_state(g, f"{kind}_pf0_"))
+        qf1.load_state_dict(_state(g, f"{kind}_qf10_"))
+        if kind == "ddpg":
+            agent = DDPG(pf=pf, qf=qf1, plr=3e-4, qlr=1e-3, **kw)
+        else:
+            qf2.load_state_dict(_state(g, f"{kind}_qf20_"))
+            agent = TD3(pf=pf, qf1=qf1, qf2=qf2, plr=3e-4, qlr=1e-3, policy_update_delay=2, norm_std_policy=0.2,
+                        noise_clip=0.5, **kw)
+        infos = []
+        for s, b in enumerate(batches):
+            torch.manual_seed(900 + s)
+            infos.append(agent.update(b))
+        eng = agent.engine()
+        assert len(eng._graphs) == (0 if no_graph == "1" else (1 if kind == "ddpg" else 2))
+        assert eng.step_state[:, 0].cpu().tolist() == [float(n) for n in eng.steps]
+        results.append((infos, eng.flat.cpu().clone(), eng.tflat.cpu().clone()))
+    (ia, fa, ta), (ib, fb, tb) = results
+    assert torch.equal(fa, fb) and torch.equal(ta, tb)
+    assert ia == ib
+
+
 def test_off_policy_collector_with_fixed_std_policy_and_short_training():
     """VecCollector + FixGuassianContPolicy (explore = tanh(mlp) + N(0, sigma), CPU draws) fills the replay ring the
     way the oracle collector does; then DDPG / TD3 train for a few updates from random batches of that ring."""

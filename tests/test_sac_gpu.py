@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("M,K,N", [(256, 23, 256), (4096, 256, 256), (100, 17, 12), (65, 256, 1), (1, 5, 3)])
+@pytest.mark.parametrize("M,K,N", [(256, 23, 256), (4096, 256, 256), (100, 17, 12), (65, 256, 1), (1, 5, 3),
+                                   (300, 132, 70), (515, 392, 96), (130, 260, 68)])
 @pytest.mark.parametrize("act", ["tanh", "relu", "none"])
 def test_linear_layer_kernels_vs_torch(M, K, N, act):
     from torchrl_amd import _C
@@ -123,6 +124,37 @@ def test_twin_sac_q_update_matches_reference(golden, tag):
             assert err < 3e-6, (name, k, err)
     np.testing.assert_allclose(agent.log_alpha.cpu().numpy(), g[f"{tag}_log_alpha"], atol=1e-6)
     assert float(agent.pf_optimizer.state[pf.seq_append_fcs[0].weight]["exp_avg"].abs().sum()) > 0
+
+
+def test_graph_replayed_updates_equal_eager_updates(golden, monkeypatch):
+    """Updates 3+ of a configuration replay a captured HIP graph (the step count, alpha and its moments live on the
+    device): the same launches, so parameters and logged statistics are bit-identical to the eager sequence."""
+    g = golden("twin_sac_q")
+    B, H = int(g["reg_args"][0]), int(g["reg_args"][1])
+    gen = torch.Generator().manual_seed(11)
+    batches = [{"obs": torch.randn(B, 17, generator=gen), "next_obs": torch.randn(B, 17, generator=gen),
+                "acts": torch.rand(B, 6, generator=gen) * 2 - 1, "rewards": torch.randn(B, 1, generator=gen),
+                "terminals": (torch.rand(B, 1, generator=gen) < 0.1).float()} for _ in range(6)]
+    results = []
+    for no_graph in ("1", "0"):
+        monkeypatch.setenv("TRL_NO_GRAPH", no_graph)
+        pf, qf1, qf2, kw, TwinSACQ = build_sac(H, 1e-3, 1.0, B)
+        pf.load_state_dict(sac_state(g, "reg_pf0_"))
+        qf1.load_state_dict(sac_state(g, "reg_qf10_"))
+        qf2.load_state_dict(sac_state(g, "reg_qf20_"))
+        agent = TwinSACQ(pf=pf, qf1=qf1, qf2=qf2, **kw)
+        infos = []
+        for s, b in enumerate(batches):
+            torch.manual_seed(500 + s)
+            infos.append(agent.update(b))
+        eng = agent.engine()
+        assert len(eng._graphs) == (0 if no_graph == "1" else 1)
+        assert eng.step_state.cpu().tolist()[0] == len(batches)
+        results.append((infos, eng.flat.cpu().clone(), eng.tflat.cpu().clone(), agent.log_alpha.cpu().clone()))
+    (ia, fa, ta, la), (ib, fb, tb, lb) = results
+    assert torch.equal(fa, fb) and torch.equal(ta, tb) and torch.equal(la, lb)
+    for x, y in zip(ia, ib):
+        assert x == y
 
 
 def test_env_step_and_off_policy_collector_vs_oracle():

@@ -1,0 +1,80 @@
+"""Development aid: per-launch time of the dense-layer GEMMs (k_gemm.hip) at the SAC / DQN shapes, timed
+with HIP events over back-to-back launches.  TRL_LIB=<path> selects an experimental build."""
+import sys, os, json
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from torchrl_amd import _C
+
+SHAPES = [(4096, 29, 256), (4096, 256, 256), (4096, 256, 1), (4096, 256, 24), (4096, 64, 256), (4096, 128, 256),
+          (4096, 512, 256), (8192, 256, 256), (512, 3136, 512), (512, 512, 6)]
+
+
+def timed(fn, reps=200):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / reps
+
+
+def main():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    out = []
+    for M, K, N in SHAPES:
+        x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05; b = torch.randn(N, device=dev)
+        y = _C.linear_fwd(x, w, b, 1)
+        dy = torch.randn(M, N, device=dev)
+        ws = torch.empty(_C.lib().trl_linear_bwd_weight_workspace(M, K, N), device=dev)
+        dw = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
+        t_f = timed(lambda: _C.linear_fwd(x, w, b, 1))
+        t_i = timed(lambda: _C.linear_bwd_input(dy, y, 1, w))
+        t_w = timed(lambda: _C.linear_bwd_weight(dy, y, 1, x, dw=dw, db=db, workspace=ws))
+        fl = 2.0 * M * K * N
+        out.append(dict(M=M, K=K, N=N, fwd_us=round(t_f, 2), bwd_in_us=round(t_i, 2), bwd_w_us=round(t_w, 2),
+                        fwd_tf=round(fl / t_f * 1e-6, 1), bwd_in_tf=round(fl / t_i * 1e-6, 1), bwd_w_tf=round(fl / t_w * 1e-6, 1)))
+        print(json.dumps(out[-1]), flush=True)
+
+
+def clk(M=4096, K=256, N=256):
+    """TRL_LIB=<clk build>: phase stamps of workgroups 0, 32, .. 224 of one launch of each kernel."""
+    import ctypes as C
+    import numpy as np
+    dev = torch.device("cuda:0")
+    x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05; b = torch.randn(N, device=dev)
+    y = _C.linear_fwd(x, w, b, 1); dy = torch.randn(M, N, device=dev)
+    ws = torch.empty(_C.lib().trl_linear_bwd_weight_workspace(M, K, N), device=dev)
+    names = ["start", "fetch0 issued", "panel0 in LDS", "mfma0 done", "panel1 in LDS", "mfma1 done", "epilogue done"]
+    for tag, fn in (("fwd", lambda: _C.linear_fwd(x, w, b, 1)), ("bwd_in", lambda: _C.linear_bwd_input(dy, y, 1, w)),
+                    ("bwd_w", lambda: _C.linear_bwd_weight(dy, y, 1, x, workspace=ws))):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); e.record()
+        torch.cuda.synchronize()
+        buf = np.zeros(128, dtype=np.int64)
+        _C.lib().trl_dbg_gemm_clk.argtypes = [C.c_void_p]
+        _C.lib().trl_dbg_gemm_clk(buf.ctypes.data)
+        buf = buf.reshape(8, 8, 2)
+        t0 = buf[:, 0, 1].min()
+        print("%s (%d, %d, %d): event time %.1f us" % (tag, M, K, N, a.elapsed_time(e) * 1e3))
+        for wg in range(8):
+            cyc = buf[wg, :7, 0] - buf[wg, 0, 0]
+            rt = (buf[wg, :7, 1] - t0) * 0.01
+            mhz = (buf[wg, 6, 0] - buf[wg, 0, 0]) / max(1e-9, (buf[wg, 6, 1] - buf[wg, 0, 1]) * 0.01)
+            print("  wg %3d: start +%.2f us; cycles %s; us %s; clock %.0f MHz" % (
+                32 * wg, rt[0], " ".join("%d" % c for c in cyc[1:]), " ".join("%.2f" % t for t in (rt[1:] - rt[0])), mhz))
+
+
+if __name__ == "__main__":
+    if "--clk" in sys.argv:
+        clk()
+        sys.exit(0)
+    main()

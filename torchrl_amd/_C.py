@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtrl_hip.so")
+LIB_PATH = os.environ.get("TRL_LIB") or os.path.join(_HERE, "lib", "libtrl_hip.so")   # TRL_LIB: experimental builds
 _lib = None
 
 ACT_TANH, ACT_RELU, ACT_NONE = 0, 1, 2
@@ -73,7 +73,7 @@ class AdamArgs(C.Structure):
         ("n_groups", C.c_int), ("group_sizes", C.c_int * 4), ("group_lr", C.c_float * 4),
         ("max_norm", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("step_count", C.c_int), ("grad_scale", C.c_float), ("norms_out", C.c_void_p),
-        ("device_state", C.c_int),
+        ("device_state", C.c_int), ("step_state", C.c_void_p),
     ]
 
 

@@ -15,6 +15,7 @@ TD3's two N(0,1) draws per update come from the CPU torch generator (reference p
 Philox stream (`noise_mode="device"`).
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -54,6 +55,9 @@ class DDPG(OffRLAlgo):
             self._engine = _FusedDetAC(self, [self.pf, self.qf], [self.target_pf, self.target_qf],
                                        [self.pf_optimizer, self.qf_optimizer])
         return self._engine
+
+    def static_batch(self):
+        return self.engine().static_batch(self.batch_size)
 
     def update(self, batch):
         self.training_update_num += 1
@@ -97,6 +101,9 @@ class TD3(OffRLAlgo):
                                        [self.target_pf, self.target_qf1, self.target_qf2],
                                        [self.pf_optimizer, self.qf1_optimizer, self.qf2_optimizer])
         return self._engine
+
+    def static_batch(self):
+        return self.engine().static_batch(self.batch_size)
 
     def update(self, batch):
         self.training_update_num += 1
@@ -144,10 +151,14 @@ class _FusedDetAC:
                 off += n
         self.optimizers = optimizers
         self.steps = [0] * len(nets)                                       # per-network Adam step counts (TD3's policy lags)
-        self.sums = torch.zeros(4, dtype=torch.float64, device=self.dev)
-        self.sums_p = torch.zeros(4, dtype=torch.float64, device=self.dev)
-        self.mom = torch.zeros(4, dtype=torch.float64, device=self.dev)
-        self.norms = torch.zeros(len(nets), device=self.dev)
+        self._raw = torch.zeros(96 + 16, dtype=torch.uint8, device=self.dev)   # every logged statistic: one D2H per update
+        self.sums = self._raw[0:32].view(torch.float64)
+        self.sums_p = self._raw[32:64].view(torch.float64)
+        self.mom = self._raw[64:96].view(torch.float64)
+        self.norms = self._raw[96:96 + 4 * len(nets)].view(torch.float32)
+        # per-network Adam step state on the device {steps, beta1^steps, beta2^steps, 0}: a captured graph replays unchanged
+        self.step_state = torch.tensor([[0.0, 1.0, 1.0, 0.0]] * len(nets), dtype=torch.float64, device=self.dev)
+        self._static, self._graphs, self._seen = {}, {}, set()
         self.workspace = None
         self.D = int(self.layers[0][0][0].shape[1])
         self.A = int(self.layers[0][-1][0].shape[0])
@@ -161,24 +172,60 @@ class _FusedDetAC:
             self.workspace = torch.empty(need, device=self.dev)
         return self.workspace
 
-    def _noise(self, B):
-        if getattr(self.algo, "noise_mode", "host") == "host":              # CPU generator draw (reference stream)
-            return torch.randn(B, self.A).to(self.dev, non_blocking=True)
-        self.noise_ctr += 1
-        return _C.philox_normal(torch.empty(B, self.A, device=self.dev), self.noise_seed, self.noise_ctr)
+    def static_batch(self, B):
+        """Persistent input tensors of a B-row update (`random_batch(..., out=...)` gathers straight into them)."""
+        st = self._static.get(B)
+        if st is None:
+            f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.dev)
+            st = {"obs": f(B, self.D), "next_obs": f(B, self.D), "acts": f(B, self.A), "rewards": f(B, 1),
+                  "terminals": f(B, 1), "eps_explore": f(B, self.A), "eps_smooth": f(B, self.A)}
+            self._static[B] = st
+        return st
 
-    def _batch(self, batch):
-        as_t = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
-            .to(device=self.dev, dtype=torch.float32).contiguous()
-        return (as_t(batch['obs']), as_t(batch['acts']), as_t(batch['next_obs']),
-                as_t(batch['rewards']).reshape(-1), as_t(batch['terminals']).reshape(-1))
+    def _load(self, batch, noise_keys):
+        B = int(batch['obs'].shape[0])
+        st = self.static_batch(B)
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals"):
+            src = batch[k]
+            if src is st[k]:
+                continue
+            src = src if isinstance(src, torch.Tensor) else torch.as_tensor(np.asarray(src))
+            st[k].copy_(src.to(dtype=torch.float32).reshape(st[k].shape), non_blocking=True)
+        for k in noise_keys:
+            if getattr(self.algo, "noise_mode", "host") == "host":         # CPU generator draw (reference stream)
+                st[k].copy_(torch.randn(B, self.A), non_blocking=True)
+            else:
+                self.noise_ctr += 1
+                _C.philox_normal(st[k], self.noise_seed, self.noise_ctr)
+        return st, B
+
+    def _lrs(self):
+        return tuple(float(o.param_groups[0]['lr']) for o in self.optimizers)
+
+    def _run(self, key, seq):
+        """Eager on the first visit of a configuration, captured into a HIP graph on the second, replayed afterwards
+        (TRL_NO_GRAPH=1 keeps everything eager)."""
+        algo = self.algo
+        key = key + (self._lrs(), algo.grad_clip, algo.tau, algo.discount)
+        if os.environ.get("TRL_NO_GRAPH") == "1":
+            seq()
+        elif key in self._graphs:
+            self._graphs[key].replay()
+        elif key not in self._seen:
+            self._seen.add(key)
+            seq()
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                seq()
+            self._graphs[key] = graph
+            graph.replay()
 
     def _adam(self, which):
-        """clip_grad_norm_ + Adam for the networks in `which` (indices into the flat buffer), one launch each
-        contiguous run; every network keeps its own step count."""
+        """clip_grad_norm_ + Adam for the networks in `which` (indices into the flat buffer), one launch each;
+        every network keeps its own step count, on the device."""
         algo = self.algo
         for k in which:
-            self.steps[k] += 1
             a = _C.AdamArgs()
             o = int(self.offsets[k]) * 4
             a.params, a.grads = self.flat.data_ptr() + o, self.grads.data_ptr() + o
@@ -188,36 +235,31 @@ class _FusedDetAC:
             a.group_lr[0] = self.optimizers[k].param_groups[0]['lr']
             a.max_norm = float(algo.grad_clip) if algo.grad_clip else 0.0
             a.beta1, a.beta2, a.eps, a.grad_scale = 0.9, 0.999, 1e-8, 1.0
-            a.step_count, a.norms_out = self.steps[k], self.norms.data_ptr() + 4 * k
+            a.step_count, a.norms_out = 0, self.norms.data_ptr() + 4 * k
+            a.step_state = self.step_state.data_ptr() + 32 * k
             _C.clip_adam(a, self.dev)
 
-    def _target_update(self):
+    def _hard_update_due(self):
         algo = self.algo
-        if algo.use_soft_update:
-            _C.polyak(self.tflat, self.flat, algo.tau)
-        elif algo.training_update_num % algo.target_hard_update_period == 0:
-            _C.polyak(self.tflat, self.flat, 1.0)
+        return (not algo.use_soft_update) and algo.training_update_num % algo.target_hard_update_period == 0
 
-    def _policy_grad(self, obs, q_layers, ws):
-        """-mean(Q(s, pi(s))) and its gradient into the policy block; returns (new actions, tape pieces)."""
+    def _policy_grad(self, obs, q_layers):
+        """Q(s, pi(s)) with the tapes of both networks."""
         new_a, tape_pf = ops.mlp_forward(self.layers[0], obs, self.act, last_act=self.pf_last)
         qn, tape_qn = ops.mlp_forward(q_layers, _C.concat2(obs, new_a), self.act)
         return new_a, tape_pf, qn, tape_qn
 
-    def _stats(self, info, new_a):
-        _C.moments(new_a, self.mom, ld=1)
-        m = self.mom.cpu().numpy()
-        info['new_actions/mean'], info['new_actions/std'], info['new_actions/max'], info['new_actions/min'] = \
-            float(m[0]), float(m[1]), float(m[2]), float(m[3])
+    @staticmethod
+    def _flat(st):
+        return st["obs"], st["acts"], st["next_obs"], st["rewards"].view(-1), st["terminals"].view(-1)
 
     # ---- DDPG (ddpg.py:42-110) ----
-    def update_ddpg(self, batch):
+    def _seq_ddpg(self, st, soft):
         algo, D, A = self.algo, self.D, self.A
-        obs, acts, nobs, rew, term = self._batch(batch)
-        B = int(obs.shape[0])
-        ws = self._ws(B)
+        obs, acts, nobs, rew, term = self._flat(st)
+        ws = self._ws(int(obs.shape[0]))
         pf_l, qf_l = self.layers
-        new_a, tape_pf, qn, tape_qn = self._policy_grad(obs, qf_l, ws)
+        new_a, tape_pf, qn, tape_qn = self._policy_grad(obs, qf_l)
         ta, _ = ops.mlp_forward(self.tlayers[0], nobs, self.act, last_act=self.pf_last)
         tq, _ = ops.mlp_forward(self.tlayers[1], _C.concat2(nobs, ta), self.act)
         qp, tape_q = ops.mlp_forward(qf_l, _C.concat2(obs, acts), self.act)
@@ -226,28 +268,38 @@ class _FusedDetAC:
         ops.mlp_backward(tape_pf, _C.slice_add(dx, None, D, A), grads=self.gviews[0], workspace=ws)
         ops.mlp_backward(tape_q, dq, grads=self.gviews[1], workspace=ws)
         self._adam((0, 1))
-        self._target_update()
-        sums, norms = self.sums.cpu().numpy(), self.norms.cpu().numpy()
+        if soft:
+            _C.polyak(self.tflat, self.flat, algo.tau)
+        _C.moments(new_a, self.mom, ld=1)
+
+    def update_ddpg(self, batch):
+        algo = self.algo
+        st, B = self._load(batch, ())
+        soft = bool(algo.use_soft_update)
+        self._run(("ddpg", B, soft), lambda: self._seq_ddpg(st, soft))
+        self.steps = [n + 1 for n in self.steps]
+        if self._hard_update_due():
+            _C.polyak(self.tflat, self.flat, 1.0)
+        raw = self._raw.cpu()
+        sums, m = raw[0:32].view(torch.float64).numpy(), raw[64:96].view(torch.float64).numpy()
+        norms = raw[96:].view(torch.float32).numpy()
         info = {'Reward_Mean': sums[3] / B, 'Training/policy_loss': sums[2] / B, 'Training/qf_loss': sums[0] / B}
         if algo.grad_clip is not None:
             info['Training/pf_grad_norm'], info['Training/qf_grad_norm'] = float(norms[0]), float(norms[1])
-        self._stats(info, new_a)
+        info['new_actions/mean'], info['new_actions/std'], info['new_actions/max'], info['new_actions/min'] = \
+            float(m[0]), float(m[1]), float(m[2]), float(m[3])
         return info
 
     # ---- TD3 (td3.py:57-154) ----
-    def update_td3(self, batch):
+    def _seq_td3(self, st, delayed, soft):
         algo, D, A = self.algo, self.D, self.A
-        obs, acts, nobs, rew, term = self._batch(batch)
-        B = int(obs.shape[0])
-        ws = self._ws(B)
+        obs, acts, nobs, rew, term = self._flat(st)
+        ws = self._ws(int(obs.shape[0]))
         pf_l, q1_l, q2_l = self.layers
-        # target_pf.explore draws only for policies with exploration noise; then the smoothing draw
-        eps_explore = self._noise(B) if self.sigma_explore else None
-        eps_smooth = self._noise(B)
         ta, _ = ops.mlp_forward(self.tlayers[0], nobs, self.act, last_act=self.pf_last)
         if self.sigma_explore:
-            ta = _C.noisy_action(ta, eps_explore, self.sigma_explore)
-        ta = _C.noisy_action(ta, eps_smooth, algo.norm_std_policy, algo.noise_clip, -1.0, 1.0)
+            ta = _C.noisy_action(ta, st["eps_explore"], self.sigma_explore)
+        ta = _C.noisy_action(ta, st["eps_smooth"], algo.norm_std_policy, algo.noise_clip, -1.0, 1.0)
         x_next = _C.concat2(nobs, ta)
         tq1, _ = ops.mlp_forward(self.tlayers[1], x_next, self.act)
         tq2, _ = ops.mlp_forward(self.tlayers[2], x_next, self.act)
@@ -258,21 +310,36 @@ class _FusedDetAC:
         ops.mlp_backward(tape_q1, dq1, grads=self.gviews[1], workspace=ws)
         ops.mlp_backward(tape_q2, dq2, grads=self.gviews[2], workspace=ws)
         self._adam((1, 2))
-        delayed = bool(algo.training_update_num % algo.policy_update_delay)
         if delayed:                                                          # policy step on the UPDATED Q1
-            new_a, tape_pf, qn, tape_qn = self._policy_grad(obs, q1_l, ws)
+            new_a, tape_pf, qn, tape_qn = self._policy_grad(obs, q1_l)
             _, _, dqn = _C.detac_losses(q1p, None, tq1, None, rew, term, qn, algo.discount, self.sums_p)
             dx = ops.mlp_backward(tape_qn, dqn, grads=None, need_input=True)
             ops.mlp_backward(tape_pf, _C.slice_add(dx, None, D, A), grads=self.gviews[0], workspace=ws)
             self._adam((0,))
-            self._target_update()
-        sums, norms = self.sums.cpu().numpy(), self.norms.cpu().numpy()
+            if soft:
+                _C.polyak(self.tflat, self.flat, algo.tau)
+            _C.moments(new_a, self.mom, ld=1)
+
+    def update_td3(self, batch):
+        algo = self.algo
+        # target_pf.explore draws only for policies with exploration noise; then the smoothing draw
+        st, B = self._load(batch, (("eps_explore",) if self.sigma_explore else ()) + ("eps_smooth",))
+        delayed = bool(algo.training_update_num % algo.policy_update_delay)
+        soft = bool(algo.use_soft_update)
+        self._run(("td3", B, delayed, soft), lambda: self._seq_td3(st, delayed, soft))
+        self.steps = [self.steps[0] + int(delayed), self.steps[1] + 1, self.steps[2] + 1]
+        if delayed and self._hard_update_due():
+            _C.polyak(self.tflat, self.flat, 1.0)
+        raw = self._raw.cpu()
+        sums, sums_p = raw[0:32].view(torch.float64).numpy(), raw[32:64].view(torch.float64).numpy()
+        m, norms = raw[64:96].view(torch.float64).numpy(), raw[96:].view(torch.float32).numpy()
         info = {'Reward_Mean': sums[3] / B, 'Training/qf1_loss': sums[0] / B, 'Training/qf2_loss': sums[1] / B}
         if algo.grad_clip is not None:
             info['Training/qf1_grad_norm'], info['Training/qf2_grad_norm'] = float(norms[1]), float(norms[2])
         if delayed:
-            info['Training/policy_loss'] = float(self.sums_p.cpu().numpy()[2]) / B
+            info['Training/policy_loss'] = float(sums_p[2]) / B
             if algo.grad_clip is not None:
                 info['Training/pf_grad_norm'] = float(norms[0])
-            self._stats(info, new_a)
+            info['new_actions/mean'], info['new_actions/std'], info['new_actions/max'], info['new_actions/min'] = \
+                float(m[0]), float(m[1]), float(m[2]), float(m[3])
         return info

@@ -20,7 +20,9 @@ class OffRLAlgo(RLAlgo):
         self.sample_key = ["obs", "next_obs", "acts", "rewards", "terminals"]
 
     def _sample_and_update(self):
-        batch = self.replay_buffer.random_batch(self.batch_size, self.sample_key)
+        out = self.static_batch() if hasattr(self, "static_batch") else None     # fixed-address inputs (graph replay)
+        batch = (self.replay_buffer.random_batch(self.batch_size, self.sample_key, out=out) if out is not None
+                 else self.replay_buffer.random_batch(self.batch_size, self.sample_key))
         self.logger.add_update_info(self.update(batch))
 
     def update_per_timestep(self):

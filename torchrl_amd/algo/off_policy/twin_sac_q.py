@@ -17,6 +17,7 @@ The two N(0,1) draws per update come from the CPU torch generator (reference par
 device Philox stream (`noise_mode="device"`).
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -79,6 +80,9 @@ class TwinSACQ(OffRLAlgo):
             self._engine = _FusedSAC(self)
         return self._engine
 
+    def static_batch(self):
+        return self.engine().static_batch(self.batch_size)
+
     def update(self, batch):
         self.training_update_num += 1
         return self.engine().update(batch)
@@ -119,22 +123,19 @@ class _FusedSAC:
                 off += n
         self.step_count = 0
         self.alpha_state = torch.zeros(4, device=self.dev)               # log_alpha, exp_avg, exp_avg_sq, step
-        self.alpha_out = torch.ones(2, device=self.dev)                  # alpha, alpha_loss
-        self.sums = torch.zeros(4, dtype=torch.float64, device=self.dev)
-        self.mom = torch.zeros(3, 4, dtype=torch.float64, device=self.dev)
-        self.norms = torch.zeros(3, device=self.dev)
+        self._raw = torch.zeros(160, dtype=torch.uint8, device=self.dev)  # every logged statistic, one D2H per update
+        self.sums = self._raw[:32].view(torch.float64)
+        self.mom = self._raw[32:128].view(torch.float64).view(3, 4)
+        self.alpha_out = self._raw[128:136].view(torch.float32)         # alpha, alpha_loss
+        self.alpha_out.fill_(1.0)
+        self.norms = self._raw[136:148].view(torch.float32)
         self.workspace = None
         self.D = int(self.layers[0][0][0].shape[1])
         self.A = int(self.layers[0][-1][0].shape[0]) // 2
         self.noise_ctr = 0
         self.noise_seed = 0x5AC
-
-    def _noise(self, B):
-        if self.algo.noise_mode == "host":                               # distribution.py:67-70: CPU generator draw
-            return torch.randn(B, self.A).to(self.dev, non_blocking=True)
-        out = torch.empty(B, self.A, device=self.dev)
-        self.noise_ctr += 1
-        return _C.philox_normal(out, self.noise_seed, self.noise_ctr)
+        self.step_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.dev)
+        self._static, self._graphs, self._seen = {}, {}, set()
 
     def _ws(self, B):
         need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
@@ -143,19 +144,28 @@ class _FusedSAC:
             self.workspace = torch.empty(need, device=self.dev)
         return self.workspace
 
-    def update(self, batch):
+    def static_batch(self, B):
+        """Persistent input tensors of a B-row update (the replay gather can write straight into them:
+        `random_batch(..., out=engine.static_batch(B))`); a captured graph reads these addresses."""
+        st = self._static.get(B)
+        if st is None:
+            f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.dev)
+            st = {"obs": f(B, self.D), "next_obs": f(B, self.D), "acts": f(B, self.A), "rewards": f(B, 1),
+                  "terminals": f(B, 1), "eps1": f(B, self.A), "eps2": f(B, self.A)}
+            self._static[B] = st
+        return st
+
+    def _sequence(self, st, soft):
+        """The fixed launch sequence of one update on the static inputs (eager, or under graph capture)."""
         algo, dev, A, D = self.algo, self.dev, self.A, self.D
-        as_t = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
-            .to(device=dev, dtype=torch.float32).contiguous()
-        obs, acts, nobs = as_t(batch['obs']), as_t(batch['acts']), as_t(batch['next_obs'])
-        rew, term = as_t(batch['rewards']).reshape(-1), as_t(batch['terminals']).reshape(-1)
+        obs, acts, nobs = st["obs"], st["acts"], st["next_obs"]
+        rew, term = st["rewards"].view(-1), st["terminals"].view(-1)
+        eps1, eps2 = st["eps1"], st["eps2"]
         B = int(obs.shape[0])
         ws = self._ws(B)
         pf_l, q1_l, q2_l = self.layers
         tanh_action = bool(algo.pf.tanh_action)
-
         # ---- policy sample on obs, Q(s, a) of the replayed actions ----
-        eps1 = self._noise(B)
         head, tape_pf = ops.mlp_forward(pf_l, obs, self.act)
         new_a, logp = _C.rsample_fwd(head, eps1, tanh_action)
         x_sa = _C.concat2(obs, acts)
@@ -165,7 +175,6 @@ class _FusedSAC:
         if algo.automatic_entropy_tuning:
             _C.sac_alpha_step(logp, algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
         # ---- target branch (no gradient) ----
-        eps2 = self._noise(B)
         head2, _ = ops.mlp_forward(pf_l, nobs, self.act)
         next_a, next_logp = _C.rsample_fwd(head2, eps2, tanh_action)
         x_next = _C.concat2(nobs, next_a)
@@ -188,31 +197,75 @@ class _FusedSAC:
         ops.mlp_backward(tape_q1, dq1, grads=self.gviews[1], workspace=ws)
         ops.mlp_backward(tape_q2, dq2, grads=self.gviews[2], workspace=ws)
         # ---- optimiser steps (pf, qf1, qf2) and target update ----
-        self.step_count += 1
         a = _C.AdamArgs()
         a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
                                                       self.m.data_ptr(), self.v.data_ptr())
         a.n_groups = 3
         for k in range(3):
             a.group_sizes[k] = self.sizes[k]
-        a.group_lr[0] = algo.pf_optimizer.param_groups[0]['lr']
-        a.group_lr[1] = algo.qf1_optimizer.param_groups[0]['lr']
-        a.group_lr[2] = algo.qf2_optimizer.param_groups[0]['lr']
+        for k, lr in enumerate(self._lrs()):
+            a.group_lr[k] = lr
         a.max_norm = float(algo.grad_clip) if algo.grad_clip else 0.0
         a.beta1, a.beta2, a.eps, a.grad_scale = 0.9, 0.999, 1e-8, 1.0
-        a.step_count, a.norms_out = self.step_count, self.norms.data_ptr()
+        a.step_count, a.norms_out = 0, self.norms.data_ptr()
+        a.step_state = self.step_state.data_ptr()                        # the step count lives on the device
         _C.clip_adam(a, dev)
-        src = self.flat[self.sizes[0]:]
-        if algo.use_soft_update:
-            _C.polyak(self.tflat, src, algo.tau)
-        elif algo.training_update_num % algo.target_hard_update_period == 0:
-            _C.polyak(self.tflat, src, 1.0)
-        # ---- logging statistics (one read-back) ----
+        if soft:
+            _C.polyak(self.tflat, self.flat[self.sizes[0]:], algo.tau)
+        # ---- logging statistics ----
         _C.moments(head, self.mom[0], ld=2 * A, off=A, width=A, lo=-20.0, hi=2.0)     # clamped log_std
         _C.moments(logp, self.mom[1], ld=1)
         _C.moments(head, self.mom[2], ld=2 * A, off=0, width=A)
-        sums, mom = self.sums.cpu().numpy(), self.mom.cpu().numpy()
-        aout, norms = self.alpha_out.cpu().numpy(), self.norms.cpu().numpy()
+
+    def _lrs(self):
+        algo = self.algo
+        return tuple(float(o.param_groups[0]['lr']) for o in (algo.pf_optimizer, algo.qf1_optimizer, algo.qf2_optimizer))
+
+    def _run(self, st, soft):
+        """Eager on the first visit of a configuration, captured into a HIP graph on the second, replayed
+        afterwards: ~90 dependent launches per update otherwise pay the eager launch latency each
+        (TRL_NO_GRAPH=1 keeps everything eager)."""
+        key = (int(st["obs"].shape[0]), soft, self._lrs(), self.algo.grad_clip, self.algo.tau, self.algo.discount,
+               bool(self.algo.automatic_entropy_tuning))
+        if os.environ.get("TRL_NO_GRAPH") == "1":
+            self._sequence(st, soft)
+        elif key in self._graphs:
+            self._graphs[key].replay()
+        elif key not in self._seen:
+            self._seen.add(key)
+            self._sequence(st, soft)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._sequence(st, soft)
+            self._graphs[key] = graph
+            graph.replay()
+
+    def update(self, batch):
+        algo, dev, A, D = self.algo, self.dev, self.A, self.D
+        B = int(batch['obs'].shape[0])
+        st = self.static_batch(B)
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals"):
+            src = batch[k]
+            if src is st[k]:
+                continue
+            src = src if isinstance(src, torch.Tensor) else torch.as_tensor(np.asarray(src))
+            st[k].copy_(src.to(dtype=torch.float32).reshape(st[k].shape), non_blocking=True)
+        if algo.noise_mode == "host":                                    # distribution.py:67-70: two CPU generator draws
+            st["eps1"].copy_(torch.randn(B, A), non_blocking=True)       # in the reference's order
+            st["eps2"].copy_(torch.randn(B, A), non_blocking=True)
+        else:
+            for k in ("eps1", "eps2"):
+                self.noise_ctr += 1
+                _C.philox_normal(st[k], self.noise_seed, self.noise_ctr)
+        self._run(st, bool(algo.use_soft_update))
+        self.step_count += 1
+        if not algo.use_soft_update and algo.training_update_num % algo.target_hard_update_period == 0:
+            _C.polyak(self.tflat, self.flat[self.sizes[0]:], 1.0)
+        # ---- logging statistics: one read-back, the only host sync of the update ----
+        raw = self._raw.cpu()
+        sums, mom = raw[:32].view(torch.float64).numpy(), raw[32:128].view(torch.float64).view(3, 4).numpy()
+        aout, norms = raw[128:136].view(torch.float32).numpy(), raw[136:148].view(torch.float32).numpy()
         w_std, w_mean = algo.policy_std_reg_weight, algo.policy_mean_reg_weight
         reg = 0.0
         if w_std or w_mean:

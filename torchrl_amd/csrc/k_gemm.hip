@@ -7,20 +7,28 @@
 //     input-grad dX[M,K] = dZ[M,N] . W[N,K]                          (plain)
 //     weight-grad dW[N,K] = dZ[M,N]^T . X[M,K]   (split over M, deterministic two-pass fold)
 //     dZ = dY * act'(Y)  and  db = column sums of dZ are fused into the operand loads / a side output.
-// Exact fp32 on v_mfma_f32_32x32x2_f32: a workgroup of 4 waves owns a 64x64 C tile (each wave one
-// 32x32 quadrant), K is walked in steps of GK = 32 through LDS tiles that are BOTH k-contiguous (A as [m][k],
-// B as [n][k], row stride GK + 4 floats).  The k index of MFMA step s is (GK / 2) * (lane >> 5) + s, so a
-// lane's operands of a K-step are consecutive floats: one ds_read_b128 per operand per 4 MFMAs instead of 4
-// ds_read_b32 (the operand reads, not the MFMAs, paced the first version).  Arbitrary M, N, K (zero fill).
+// Exact fp32 on v_mfma_f32_32x32x2_f32: a workgroup of 4 waves owns a 64x64 C tile (one 32x32 quadrant per
+// wave).  These layers are a few thousand rows by <= 256..512 columns: the reduction is short, so what paces
+// the kernel is how often it waits for memory, not the MFMAs.  The reduction is therefore walked in PANELS of
+// KC = 128: a panel of each operand (64 x 128 floats) is fetched with 16-byte loads into registers while the
+// previous panel's 64 MFMAs per wave run from LDS (one memory round trip per 128 k, all of a panel's loads in
+// flight together; the first version walked K in steps of 32 and paid a round trip per step, 4 us per step at
+// K = 512 where every workgroup's 128-byte row segments also sat 2 KB apart).  LDS tiles keep the layout the
+// operand has in memory -- [row][k] (row stride KC + 4, read with one ds_read_b128 per 4 MFMAs) when k is the
+// contiguous dimension, [k][col] (row stride 64 + 8, ds_read_b32) when it is not -- so the global->LDS copy
+// never transposes.  MFMA step (q, r) of lane half `hi` takes k = 8q + 4hi + r.  Arbitrary M, N, K: slots that
+// are misaligned or cross an edge fall back to predicated scalar loads (zero fill).
 #include "trl_common.h"
 #include "trl_mlp.h"
 
 #define GM 64
 #define GN 64
-#define GK 32
-#define LDK (GK + 4)                // LDS row stride of both operand tiles: 16-byte aligned rows of k
-#define A_PER_T (GM * GK / 256)     //  8 staged A elements per thread
-#define B_PER_T (GK * GN / 256)     //  8 staged B elements per thread
+#define KC 128                      // reduction panel
+#define LDK (KC + 4)                // [row][k] tile: 16-byte aligned rows, banks rotate by 4 per row
+#define LDN (GN + 8)                // [k][col] tile: rows k and k + 4 (the two lane halves) are 32 banks apart
+#define SLOTS 8                     // 16-byte slots per thread per operand panel (64 * 128 / 4 / 256)
+#define TILE_KMAJ (GM * LDK)        // floats of a [row][k] tile
+#define TILE_RMAJ (KC * LDN)        // floats of a [k][col] tile
 
 // act'(y) expressed through the activation OUTPUT y (tanh: 1 - y^2, relu: y > 0, none: 1)
 __device__ __forceinline__ float dact_from_out(int act, float y) {
@@ -38,19 +46,93 @@ struct GemmDev {
   int gate_act;               // activation whose derivative gates A
   int split_len;              // TA only: rows of the reduction handled by one blockIdx.z
   float* colsum;              // TA only: (splits, M) partial column sums of the gated A (nullable)
+  int tiles_n, tiles;         // C tiles along N, and in total
 };
 
+// development aid (tools/bench_gemm.py --clk): shader-clock and 100 MHz real-time stamps of a few workgroups
+#ifdef TRL_EXP_CLK
+__device__ long long g_gemm_clk[8 * 16];
+#define GCLK(ph) if (tid == 0 && (blockIdx.x & 31) == 0 && blockIdx.x < 256 && blockIdx.z == 0) { \
+    g_gemm_clk[(blockIdx.x >> 5) * 16 + 2 * (ph)] = clock64(); g_gemm_clk[(blockIdx.x >> 5) * 16 + 2 * (ph) + 1] = wall_clock64(); }
+extern "C" int trl_dbg_gemm_clk(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_clk), sizeof(long long) * 8 * 16);
+}
+#else
+#define GCLK(ph)
+#endif
+
+// One operand panel: 64 "rows" (the operand's C-side index) x KC reduction indices, held as 8 16-byte slots
+// per thread.  CONTIG_K: element (r, k) lives at base[(row0 + r) * ld + k0 + k]; otherwise at
+// base[(k0 + k) * ld + row0 + r].  Slot t of thread tid covers 4 consecutive elements of the contiguous dim.
+template <bool CONTIG_K>
+__device__ __forceinline__ void panel_slot(int tid, int t, int& r, int& k) {
+  if (CONTIG_K) { r = 8 * t + (tid >> 5); k = 4 * (tid & 31); }
+  else          { k = 16 * t + (tid >> 4); r = 4 * (tid & 15); }
+}
+
+// whole panel in range and 16-byte loads legal: 8 unconditional loads a fixed stride apart
+template <bool CONTIG_K>
+__device__ __forceinline__ void panel_fetch_fast(const float* __restrict__ base, int ld, int row0, int k0, int tid,
+                                                 f32x4 (&reg)[SLOTS]) {
+  int r, k;
+  panel_slot<CONTIG_K>(tid, 0, r, k);
+  const float* p = CONTIG_K ? base + (size_t)(row0 + r) * ld + k0 + k : base + (size_t)(k0 + k) * ld + row0 + r;
+  const size_t step = (size_t)(CONTIG_K ? 8 : 16) * ld;
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) reg[t] = *reinterpret_cast<const f32x4*>(p + t * step);
+}
+
+// edge / misaligned panel: element-wise predicated loads, zero fill
+template <bool CONTIG_K>
+__device__ __forceinline__ void panel_fetch_edge(const float* __restrict__ base, int ld, int row0, int rows, int k0, int k_hi,
+                                                 int tid, f32x4 (&reg)[SLOTS]) {
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    int r, k;
+    panel_slot<CONTIG_K>(tid, t, r, k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gr = row0 + r + (CONTIG_K ? 0 : j), gk = k0 + k + (CONTIG_K ? j : 0);
+      const bool ok = gr < rows && gk < k_hi;
+      const size_t idx = CONTIG_K ? (size_t)gr * ld + gk : (size_t)gk * ld + gr;
+      reg[t][j] = ok ? base[ok ? idx : 0] : 0.0f;
+    }
+  }
+}
+
+template <bool CONTIG_K>
+__device__ __forceinline__ void panel_stash(float* tile, int tid, const f32x4 (&reg)[SLOTS]) {
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    int r, k;
+    panel_slot<CONTIG_K>(tid, t, r, k);
+    *reinterpret_cast<f32x4*>(tile + (CONTIG_K ? r * LDK + k : k * LDN + r)) = reg[t];
+  }
+}
+
+// the 4 operand values of MFMA steps (q, 0..3) for C-side index `row` (0..63) of this lane half
+template <bool CONTIG_K>
+__device__ __forceinline__ f32x4 panel_operand(const float* tile, int row, int q, int hi) {
+  if (CONTIG_K) return *reinterpret_cast<const f32x4*>(tile + row * LDK + 8 * q + 4 * hi);
+  const float* p = tile + (8 * q + 4 * hi) * LDN + row;
+  f32x4 v = {p[0], p[LDN], p[2 * LDN], p[3 * LDN]};
+  return v;
+}
+
 // TA: A is stored [Kred][M] (we need A^T); TB: B is stored [N][K] (we need B^T).
-// Workgroup = 4 waves, C tile 64 x 64, one 32x32 quadrant per wave (these layers are small -- a few
-// thousand rows by <= 256 columns -- so filling 256 CUs matters more than a fatter tile).  K advances
-// in steps of 32; the next step's global loads are issued into registers before the current step's
-// MFMAs (register double buffering).
-template <bool TA, bool TB>
+// GATE: activation whose derivative (through a_gate) multiplies operand A (TRL_ACT_NONE: no gate).
+template <bool TA, bool TB, int GATE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
-  __shared__ __attribute__((aligned(16))) float As[GM * LDK];      // [m][k]
-  __shared__ __attribute__((aligned(16))) float Bs[GN * LDK];      // [n][k]
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;
+  float* Bs = lds + (TA ? TILE_RMAJ : TILE_KMAJ);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+  // Workgroups are dealt round-robin to the 8 XCDs: renumber so that each XCD owns a contiguous run of tiles
+  // (the tiles_n tiles that share an A panel then share an L2).
+  int tile = blockIdx.x;
+  if ((g.tiles & 7) == 0) tile = (tile & 7) * (g.tiles >> 3) + (tile >> 3);
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * GM, n0 = tn * GN;
   int k_lo = 0, k_hi = g.K;
   float* C = g.C;
   if (TA) {                                        // split the (long) reduction dimension over blockIdx.z
@@ -59,113 +141,141 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
     C += (size_t)blockIdx.z * g.M * g.ldc;
   }
   const int wm = wave >> 1, wn = wave & 1;
-  f32x16 acc0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
-  float csum = 0.0f;                               // TA: column-sum partial of column m = tid & 63
   const int i = lane & 31, hi = lane >> 5;
-  const bool want_colsum = TA && g.colsum && blockIdx.x == 0;
+  const bool a_whole = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 &&
+                       (GATE == TRL_ACT_NONE || (reinterpret_cast<uintptr_t>(g.a_gate) & 15) == 0) && m0 + GM <= g.M;
+  const bool b_whole = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0 && n0 + GN <= g.N;
+  const bool want_colsum = TA && g.colsum && tn == 0;
 
-  float ra[A_PER_T], rb[B_PER_T];
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  f32x4 csum = {0.0f, 0.0f, 0.0f, 0.0f};          // TA: partial column sums of columns 4 * (tid & 15) .. + 3
+  f32x4 ra[SLOTS], rg[SLOTS], rb[SLOTS];
+
   auto fetch = [&](int k0) {
-#pragma unroll
-    for (int t = 0; t < A_PER_T; ++t) {
-      const int e = tid + 256 * t;
-      int m, k;
-      if (!TA) { m = e / GK; k = e - m * GK; } else { k = e / GM; m = e - k * GM; }   // coalesced along the stored-contiguous dim
-      float v = 0.0f;
-      if (m0 + m < g.M && k0 + k < k_hi) {
-        const size_t idx = TA ? (size_t)(k0 + k) * g.lda + m0 + m : (size_t)(m0 + m) * g.lda + k0 + k;
-        v = g.A[idx];
-        if (g.a_gate) v *= dact_from_out(g.gate_act, g.a_gate[idx]);
-      }
-      ra[t] = v;
+    const bool k_whole = k0 + KC <= k_hi;          // uniform: one branch per operand per panel
+    if (a_whole && k_whole) {
+      panel_fetch_fast<!TA>(g.A, g.lda, m0, k0, tid, ra);
+      if (GATE != TRL_ACT_NONE) panel_fetch_fast<!TA>(g.a_gate, g.lda, m0, k0, tid, rg);
+    } else {
+      panel_fetch_edge<!TA>(g.A, g.lda, m0, g.M, k0, k_hi, tid, ra);
+      if (GATE != TRL_ACT_NONE) panel_fetch_edge<!TA>(g.a_gate, g.lda, m0, g.M, k0, k_hi, tid, rg);
     }
-#pragma unroll
-    for (int t = 0; t < B_PER_T; ++t) {
-      const int e = tid + 256 * t;
-      int n, k;
-      if (!TB) { k = e / GN; n = e - k * GN; } else { n = e / GK; k = e - n * GK; }
-      float v = 0.0f;
-      if (k0 + k < k_hi && n0 + n < g.N)
-        v = TB ? g.B[(size_t)(n0 + n) * g.ldb + k0 + k] : g.B[(size_t)(k0 + k) * g.ldb + n0 + n];
-      rb[t] = v;
-    }
+    if (b_whole && k_whole) panel_fetch_fast<TB>(g.B, g.ldb, n0, k0, tid, rb);
+    else                    panel_fetch_edge<TB>(g.B, g.ldb, n0, g.N, k0, k_hi, tid, rb);
   };
   auto stash = [&]() {
+    if (GATE != TRL_ACT_NONE) {
 #pragma unroll
-    for (int t = 0; t < A_PER_T; ++t) {
-      const int e = tid + 256 * t;
-      int m, k;
-      if (!TA) { m = e / GK; k = e - m * GK; } else { k = e / GM; m = e - k * GM; }
-      As[m * LDK + k] = ra[t];
-      if (want_colsum) csum += ra[t];              // TA: e % GM == tid % 64 for every t -> fixed column
-    }
+      for (int t = 0; t < SLOTS; ++t)
 #pragma unroll
-    for (int t = 0; t < B_PER_T; ++t) {
-      const int e = tid + 256 * t;
-      int n, k;
-      if (!TB) { k = e / GN; n = e - k * GN; } else { n = e / GK; k = e - n * GK; }
-      Bs[n * LDK + k] = rb[t];
+        for (int j = 0; j < 4; ++j) ra[t][j] *= dact_from_out(GATE, rg[t][j]);
     }
+    if (want_colsum) {
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) csum += ra[t];
+    }
+    panel_stash<!TA>(As, tid, ra);
+    panel_stash<TB>(Bs, tid, rb);
   };
 
+  GCLK(0)
   if (k_lo < k_hi) fetch(k_lo);
-  for (int k0 = k_lo; k0 < k_hi; k0 += GK) {
+  GCLK(1)
+  for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
     stash();
     __syncthreads();
-    if (k0 + GK < k_hi) fetch(k0 + GK);            // next step's loads fly under this step's MFMAs
-    {
-      const float* ap = As + (32 * wm + i) * LDK + (GK / 2) * hi;
-      const float* bp = Bs + (32 * wn + i) * LDK + (GK / 2) * hi;
+    GCLK(k0 == k_lo ? 2 : 4)
+    if (k0 + KC < k_hi) fetch(k0 + KC);            // the next panel's loads fly under this panel's MFMAs
+    const int nq4 = (min(KC, k_hi - k0) + 31) >> 5;   // 32 reduction indices per round (zero filled above k_hi)
+    for (int q4 = 0; q4 < nq4; ++q4) {
 #pragma unroll
-      for (int q = 0; q < GK / 8; ++q) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 4 * q);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+      for (int qq = 0; qq < 4; ++qq) {
+        const f32x4 av = panel_operand<!TA>(As, 32 * wm + i, 4 * q4 + qq, hi);
+        const f32x4 bv = panel_operand<TB>(Bs, 32 * wn + i, 4 * q4 + qq, hi);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc0 = mfma32(av[r], bv[r], acc0);
+        for (int r = 0; r < 4; ++r) acc = mfma32(av[r], bv[r], acc);
       }
     }
     __syncthreads();
+    GCLK(k0 == k_lo ? 3 : 5)
   }
-  // ---- epilogue ----
+  // ---- epilogue: lane (i, hi) owns column n of rows rowmap(0..15, hi) ----
+  {
+    const int n = n0 + 32 * wn + i, mb = m0 + 32 * wm + 4 * hi;
+    if (n < g.N) {
+      const float bias = g.bias ? g.bias[n] : 0.0f;
+      float v[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + 32 * wm + rowmap(r, hi), n = n0 + 32 * wn + i;
-    if (m < g.M && n < g.N) {
-      float v = acc0[r];
-      if (g.bias) v += g.bias[n];
-      if (g.act == TRL_ACT_TANH) v = trl_tanh(v);
-      else if (g.act == TRL_ACT_RELU) v = fmaxf(v, 0.0f);
-      C[(size_t)m * g.ldc + n] = v;
+      for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
+      if (g.act == TRL_ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = trl_tanh(v[r]);
+      } else if (g.act == TRL_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+      }
+      float* cp = C + (size_t)mb * g.ldc + n;
+      if (m0 + GM <= g.M) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (mb + (r & 3) + 8 * (r >> 2) < g.M) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+      }
     }
   }
+  GCLK(6)
   if (want_colsum) {
-    // threads tid, tid+64, tid+128, tid+192 hold partials of the same column m = tid & 63
+    // thread (tid >> 4, tid & 15) holds partials of columns 4 * (tid & 15) .. + 3: fold the 16 row groups in order
     float* s = As;                                  // reuse (all MFMA reads are behind the last barrier)
-    s[tid] = csum;
+    *reinterpret_cast<f32x4*>(s + (tid >> 4) * GM + 4 * (tid & 15)) = csum;
     __syncthreads();
-    if (tid < GM && m0 + tid < g.M)
-      g.colsum[(size_t)blockIdx.z * g.M + m0 + tid] = (s[tid] + s[tid + 64]) + (s[tid + 128] + s[tid + 192]);
+    if (tid < GM && m0 + tid < g.M) {
+      float a = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) a += s[w * GM + tid];
+      g.colsum[(size_t)blockIdx.z * g.M + m0 + tid] = a;
+    }
   }
 }
 
-// fixed-order fold of split partials: out[e] = sum_s part[s][e]
-__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                            int n, int splits) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+// fixed-order fold of split partials: out[e] = sum_s part[s][e]; a second segment (the bias gradient) rides along
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
+                                                            const float* __restrict__ part2, float* __restrict__ out2,
+                                                            int n2, int splits) {
+  int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) { e -= n; part = part2; out = out2; n = n2; }
   if (e >= n) return;
   float a = 0.0f;
   for (int s = 0; s < splits; ++s) a += part[(size_t)s * n + e];
   out[e] = a;
 }
 
-template <bool TA, bool TB>
-static int launch_gemm(const GemmDev& g, int splits, hipStream_t s) {
-  dim3 grid(trl_ceil_div(g.N, GN), trl_ceil_div(g.M, GM), splits);
-  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB>), grid, dim3(256), 0, s, g);
+template <bool TA, bool TB, int GATE>
+static int launch_gemm_gate(GemmDev g, int splits, hipStream_t s) {
+  const int lds = (int)sizeof(float) * ((TA ? TILE_RMAJ : TILE_KMAJ) + (TB ? TILE_KMAJ : TILE_RMAJ));
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { trl_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  g.tiles_n = trl_ceil_div(g.N, GN);
+  g.tiles = g.tiles_n * trl_ceil_div(g.M, GM);
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE>), dim3(g.tiles, 1, splits), dim3(256), lds, s, g);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
+}
+
+template <bool TA, bool TB>
+static int launch_gemm(const GemmDev& g, int splits, hipStream_t s) {
+  const int gate = g.a_gate ? g.gate_act : TRL_ACT_NONE;
+  if (gate == TRL_ACT_TANH) return launch_gemm_gate<TA, TB, TRL_ACT_TANH>(g, splits, s);
+  if (gate == TRL_ACT_RELU) return launch_gemm_gate<TA, TB, TRL_ACT_RELU>(g, splits, s);
+  return launch_gemm_gate<TA, TB, TRL_ACT_NONE>(g, splits, s);
 }
 
 extern "C" int trl_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
@@ -210,12 +320,9 @@ extern "C" int trl_linear_bwd_weight_f32(const float* dy, const float* y_gate, i
   g.colsum = db ? workspace + (size_t)splits * N * K : nullptr;
   int rc = launch_gemm<true, false>(g, splits, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)N * K, 256)), dim3(256), 0, s, workspace, dw,
-                     N * K, splits);
+  const int n2 = db ? N : 0;
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)N * K + n2, 256)), dim3(256), 0, s, workspace, dw,
+                     N * K, g.colsum, db, n2, splits);
   TRL_LAUNCH_CHECK();
-  if (db) {
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div(N, 256)), dim3(256), 0, s, g.colsum, db, N, splits);
-    TRL_LAUNCH_CHECK();
-  }
   return TRL_OK;
 }

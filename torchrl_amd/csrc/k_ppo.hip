@@ -631,11 +631,21 @@ struct AdamDev {
   int n_groups; int off[5]; float lr[4];
   float max_norm, beta1, beta2, eps, grad_scale, bc1, bc2_sqrt;
   float* norms_out;
+  double* step_state;         // {steps taken, beta1^steps, beta2^steps, arrival counter} or null (then bc1 / bc2_sqrt)
 };
 __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
   __shared__ float s_part[4][4];
   __shared__ float s_coef[4];
+  __shared__ float s_bc[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double st_steps = 0.0, st_b1 = 1.0, st_b2 = 1.0;
+  if (a.step_state && tid == 0) {                              // device-resident step: nothing in the launch changes
+    st_steps = a.step_state[0] + 1.0;                          // between replays of a captured graph
+    st_b1 = a.step_state[1] * (double)a.beta1;
+    st_b2 = a.step_state[2] * (double)a.beta2;
+    s_bc[0] = (float)(1.0 - st_b1);
+    s_bc[1] = (float)sqrt(1.0 - st_b2);
+  }
   const bool need_norm = a.max_norm > 0.0f;                    // no clipping requested: skip the norm pass
   for (int g = 0; g < a.n_groups; ++g) {
     if (!need_norm) { if (lane == 0) s_part[g][wave] = 0.0f; continue; }
@@ -659,16 +669,28 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
     if (blockIdx.x == 0 && a.norms_out) a.norms_out[tid] = norm;
   }
   __syncthreads();
+  const float bc1 = a.step_state ? s_bc[0] : a.bc1, bc2_sqrt = a.step_state ? s_bc[1] : a.bc2_sqrt;
   const int e = blockIdx.x * 256 + tid;
-  if (e >= a.off[a.n_groups]) return;
-  int g = 0;
-  while (e >= a.off[g + 1]) ++g;
-  const float gr = a.grads[e] * a.grad_scale * s_coef[g];
-  const float m = a.beta1 * a.m[e] + (1.0f - a.beta1) * gr;
-  const float v = a.beta2 * a.v[e] + (1.0f - a.beta2) * gr * gr;
-  a.m[e] = m; a.v[e] = v;
-  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-  a.params[e] -= (a.lr[g] / a.bc1) * (m / denom);
+  if (e < a.off[a.n_groups]) {
+    int g = 0;
+    while (e >= a.off[g + 1]) ++g;
+    const float gr = a.grads[e] * a.grad_scale * s_coef[g];
+    const float m = a.beta1 * a.m[e] + (1.0f - a.beta1) * gr;
+    const float v = a.beta2 * a.v[e] + (1.0f - a.beta2) * gr * gr;
+    a.m[e] = m; a.v[e] = v;
+    const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+    a.params[e] -= (a.lr[g] / bc1) * (m / denom);
+  }
+  if (a.step_state && tid == 0) {
+    // every block read the state before arriving here; the last one to arrive advances it
+    unsigned long long* arrivals = reinterpret_cast<unsigned long long*>(a.step_state + 3);
+    __threadfence();
+    if (atomicAdd(arrivals, 1ull) == (unsigned long long)gridDim.x - 1) {
+      a.step_state[0] = st_steps; a.step_state[1] = st_b1; a.step_state[2] = st_b2;
+      *arrivals = 0ull;
+      __threadfence();
+    }
+  }
 }
 
 // Adam update of element e with the clip coefficient of its group
@@ -891,7 +913,7 @@ static int fill_adam(const trl_adam_t* p, AdamDev& d) {
   if (!p) { trl_set_error("clip_adam: null descriptor"); return TRL_EINVAL; }
   TRL_REQUIRE(p->params && p->grads && p->exp_avg && p->exp_avg_sq, "null pointer");
   TRL_REQUIRE(p->n_groups >= 1 && p->n_groups <= 4, "n_groups must be 1..4");
-  TRL_REQUIRE(p->step_count >= 1 || p->device_state, "step_count starts at 1");
+  TRL_REQUIRE(p->step_count >= 1 || p->device_state || p->step_state, "step_count starts at 1");
   d.params = p->params; d.grads = p->grads; d.m = p->exp_avg; d.v = p->exp_avg_sq;
   d.n_groups = p->n_groups; d.off[0] = 0;
   for (int g = 0; g < p->n_groups; ++g) {
@@ -905,6 +927,7 @@ static int fill_adam(const trl_adam_t* p, AdamDev& d) {
   d.bc1 = (float)(1.0 - pow((double)p->beta1, (double)p->step_count));
   d.bc2_sqrt = (float)sqrt(1.0 - pow((double)p->beta2, (double)p->step_count));
   d.norms_out = p->norms_out;
+  d.step_state = p->step_state;
   return TRL_OK;
 }
 

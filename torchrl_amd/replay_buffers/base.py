@@ -68,15 +68,25 @@ class BaseReplayBuffer:
         assert batch_size % self.env_nums == 0, "batch size should be dividable by env_nums"
         return batch_size // self.env_nums
 
-    def _gather(self, key, idx_dev):
-        block = _C.gather_rows(getattr(self, "_" + key), idx_dev)
+    def _gather(self, key, idx_dev, out=None):
+        src = getattr(self, "_" + key)
+        if out is not None:                                              # caller-owned (B, feat) destination
+            if out.dtype != src.dtype or out.numel() != idx_dev.numel() * src[0].numel():
+                raise _C.TrlError("random_batch: out[%r] does not match the batch" % key)
+            _C.gather_rows(src, idx_dev, out=out.view((idx_dev.numel(),) + tuple(src.shape[1:])))
+            return out
+        block = _C.gather_rows(src, idx_dev)
         return block.reshape((block.shape[0] * self.env_nums,) + tuple(block.shape[2:]))
 
-    def random_batch(self, batch_size, sample_key):
+    def random_batch(self, batch_size, sample_key, out=None):
+        """`out` (not in the reference): dict of preallocated (B, feat) device tensors to gather into, so that a
+        captured update graph can read its inputs at fixed addresses; keys missing from it are allocated."""
         nrows = self._rows_per_batch(batch_size)
         indices = np.random.randint(0, self.num_steps_can_sample(), nrows)
         idx_dev = torch.from_numpy(indices.astype(np.int64)).to(self._device(), non_blocking=True)
-        return {key: self._gather(key, idx_dev) for key in sample_key}
+        if out is None:
+            return {key: self._gather(key, idx_dev) for key in sample_key}
+        return {key: self._gather(key, idx_dev, out.get(key)) for key in sample_key}
 
     def num_steps_can_sample(self):
         return self._size

@@ -60,9 +60,9 @@ class MemoryEfficientReplayBuffer(BaseReplayBuffer):
         _C.frame_stream_append(stacks, self._stream, self._head, None, 1)
 
     # ---- sampling ----
-    def _gather(self, key, idx_dev):
+    def _gather(self, key, idx_dev, out=None):
         if key not in self.FRAME_KEYS:
-            return super()._gather(key, idx_dev)
+            return super()._gather(key, idx_dev, out)
         return _C.frame_stream_gather(self._stream, self._pos, idx_dev, 0 if key == "obs" else 1, self.frame_shape,
                                       self._head, self._overrun)
 
