@@ -225,8 +225,9 @@ typedef struct trl_adam_t {
                                  so that no launch argument changes between replays of a captured graph */
   double* step_state;         /* trl_clip_adam_f32 only, nullable: 4 doubles on the device {steps taken so far,
                                  beta1^steps, beta2^steps, 0} initialised to {0, 1, 1, 0}.  When set, step_count is
-                                 ignored, the step uses steps + 1 and the kernel advances the state itself (same
-                                 purpose as device_state: a captured graph of a whole update can be replayed) */
+                                 ignored, the step uses steps + 1 and a one-thread kernel launched behind the
+                                 update advances the state (same purpose as device_state: a captured graph of a
+                                 whole update can be replayed; the 4th double is reserved) */
 } trl_adam_t;
 int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
 /* Single-process fast path: trl_ppo_reduce_f32 + trl_clip_adam_f32 in one launch (the block that

@@ -631,20 +631,16 @@ struct AdamDev {
   int n_groups; int off[5]; float lr[4];
   float max_norm, beta1, beta2, eps, grad_scale, bc1, bc2_sqrt;
   float* norms_out;
-  double* step_state;         // {steps taken, beta1^steps, beta2^steps, arrival counter} or null (then bc1 / bc2_sqrt)
+  double* step_state;         // {steps taken, beta1^steps, beta2^steps, -} or null (then bc1 / bc2_sqrt)
 };
 __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
   __shared__ float s_part[4][4];
   __shared__ float s_coef[4];
   __shared__ float s_bc[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double st_steps = 0.0, st_b1 = 1.0, st_b2 = 1.0;
   if (a.step_state && tid == 0) {                              // device-resident step: nothing in the launch changes
-    st_steps = a.step_state[0] + 1.0;                          // between replays of a captured graph
-    st_b1 = a.step_state[1] * (double)a.beta1;
-    st_b2 = a.step_state[2] * (double)a.beta2;
-    s_bc[0] = (float)(1.0 - st_b1);
-    s_bc[1] = (float)sqrt(1.0 - st_b2);
+    s_bc[0] = (float)(1.0 - a.step_state[1] * (double)a.beta1);   // between replays of a captured graph
+    s_bc[1] = (float)sqrt(1.0 - a.step_state[2] * (double)a.beta2);
   }
   const bool need_norm = a.max_norm > 0.0f;                    // no clipping requested: skip the norm pass
   for (int g = 0; g < a.n_groups; ++g) {
@@ -681,16 +677,11 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
     const float denom = sqrtf(v) / bc2_sqrt + a.eps;
     a.params[e] -= (a.lr[g] / bc1) * (m / denom);
   }
-  if (a.step_state && tid == 0) {
-    // every block read the state before arriving here; the last one to arrive advances it
-    unsigned long long* arrivals = reinterpret_cast<unsigned long long*>(a.step_state + 3);
-    __threadfence();
-    if (atomicAdd(arrivals, 1ull) == (unsigned long long)gridDim.x - 1) {
-      a.step_state[0] = st_steps; a.step_state[1] = st_b1; a.step_state[2] = st_b2;
-      *arrivals = 0ull;
-      __threadfence();
-    }
-  }
+}
+
+// advances the device-resident step state after clip_adam_kernel has read it (stream order: every block is done)
+__global__ void adam_tick_kernel(double* __restrict__ st, float beta1, float beta2) {
+  st[0] += 1.0; st[1] *= (double)beta1; st[2] *= (double)beta2;
 }
 
 // Adam update of element e with the clip coefficient of its group
@@ -968,6 +959,10 @@ extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {
   if (total == 0) return TRL_OK;
   hipLaunchKernelGGL(clip_adam_kernel, dim3(trl_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, d);
   TRL_LAUNCH_CHECK();
+  if (d.step_state) {
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d.step_state, d.beta1, d.beta2);
+    TRL_LAUNCH_CHECK();
+  }
   return TRL_OK;
 }
 

@@ -321,19 +321,32 @@ extern "C" int trl_polyak_f32(float* target, const float* source, int64_t n, flo
 }
 
 // ---------------------------------------------------------------- mean / unbiased std / max / min of a tensor (logging)
-__global__ __launch_bounds__(SAC_THREADS) void moments_kernel(const float* __restrict__ x, int64_t n, int ld, int off,
+#define MOM_THREADS 1024
+__global__ __launch_bounds__(MOM_THREADS) void moments_kernel(const float* __restrict__ x, int64_t n, int ld, int off,
                                                               int width, float lo, float hi_, double* __restrict__ out) {
-  // x viewed as rows of `ld` floats; statistics over columns [off, off+width) of every row
-  __shared__ double smem[SAC_THREADS / 64];
+  // x viewed as rows of `ld` floats; statistics over columns [off, off+width) of every row.  One workgroup of 16
+  // waves (fixed summation order); each thread walks (row, column) incrementally -- no division in the loop.
+  __shared__ double smem[4][MOM_THREADS / 64];
   double s = 0, sq = 0, mx = -INFINITY, nmn = -INFINITY;
   const int64_t rows = n / ld;
-  for (int64_t e = threadIdx.x; e < rows * width; e += SAC_THREADS) {
-    const int64_t r = e / width;
-    const double v = (double)fminf(fmaxf(x[r * ld + off + (e - r * width)], lo), hi_);
+  int64_t r = threadIdx.x / width;
+  int c = threadIdx.x - (int)r * width;
+  const int dr = MOM_THREADS / width, dc = MOM_THREADS - dr * width;
+  for (; r < rows; ) {
+    const double v = (double)fminf(fmaxf(x[r * ld + off + c], lo), hi_);
     s += v; sq += v * v; mx = fmax(mx, v); nmn = fmax(nmn, -v);
+    r += dr; c += dc;
+    if (c >= width) { c -= width; ++r; }
   }
-  s = block_sum(s, smem); sq = block_sum(sq, smem); mx = block_max(mx, smem); nmn = block_max(nmn, smem);
+  s = wave_sum(s); sq = wave_sum(sq); mx = wave_max(mx); nmn = wave_max(nmn);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { smem[0][wave] = s; smem[1][wave] = sq; smem[2][wave] = mx; smem[3][wave] = nmn; }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    s = 0; sq = 0; mx = -INFINITY; nmn = -INFINITY;
+    for (int w = 0; w < MOM_THREADS / 64; ++w) {
+      s += smem[0][w]; sq += smem[1][w]; mx = fmax(mx, smem[2][w]); nmn = fmax(nmn, smem[3][w]);
+    }
     const double cnt = (double)(rows * width), mean = s / cnt;
     out[0] = mean;
     out[1] = cnt > 1 ? sqrt(fmax((sq - s * mean) / (cnt - 1), 0.0)) : NAN;
@@ -344,7 +357,7 @@ extern "C" int trl_moments_f64(const float* x, int64_t n, int ld, int off, int w
                                double* out4, void* stream) {
   TRL_REQUIRE(n > 0 && ld > 0 && off >= 0 && width > 0 && off + width <= ld && n % ld == 0, "bad sizes");
   TRL_REQUIRE(x && out4, "null pointer");
-  hipLaunchKernelGGL(moments_kernel, dim3(1), dim3(SAC_THREADS), 0, (hipStream_t)stream, x, n, ld, off, width, clamp_lo, clamp_hi, out4);
+  hipLaunchKernelGGL(moments_kernel, dim3(1), dim3(MOM_THREADS), 0, (hipStream_t)stream, x, n, ld, off, width, clamp_lo, clamp_hi, out4);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
