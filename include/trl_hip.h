@@ -332,6 +332,23 @@ int trl_col2im_f32(const float* dcols, float* dx_nhwc, int B, int C, int H, int 
 /* out[b][c][p] = in[b][p][c]  (NCHW flatten order in front of the first FC layer, and back) */
 int trl_transpose_bpc_f32(const float* in, float* out, int B, int P, int C, void* stream);
 
+/* --- K16b: first conv layer straight from uint8 frames (implicit GEMM) -------
+ * replaces nn.Conv2d + activation of CNNBase's first layer (torchrl/networks/base.py:59-107) applied to
+ * ScaledFloatFrame(frames) (torchrl/env/atari_wrapper.py:230-240) WITHOUT materialising the im2col matrix:
+ *   y[(b, oy, ox)][co] = act( sum_{c,i,j} (frames[b][c][oy*sh+i][ox*sw+j] * scale + shift) * w[co][c][i][j] + bias[co] )
+ * frames: (B, C, H, W) uint8 NCHW; w: nn.Conv2d weight (Cout, C, kh, kw) as stored; y: (B*Ho*Wo, Cout) = NHWC.
+ * Requires kw, sw and W to be multiples of 4 (each 4 consecutive taps are one aligned dword); other geometries
+ * return TRL_EINVAL and go through trl_im2col_u8_nchw + trl_linear_*.
+ * trl_conv_bwd_weight_u8_f32: dw (Cout, C*kh*kw), db (Cout) (nullable) from dy (B*Ho*Wo, Cout), gated by
+ * act'(y_gate) as in trl_linear_bwd_weight_f32; workspace: trl_conv_bwd_weight_workspace(...) floats. */
+int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias, float* y, int B, int C, int H,
+                        int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
+                        void* stream);
+int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout);
+int trl_conv_bwd_weight_u8_f32(const float* dy, const float* y_gate, int gate_act, const uint8_t* frames,
+                               float* dw, float* db, float* workspace, int B, int C, int H, int W, int kh,
+                               int kw, int sh, int sw, float scale, float shift, int Cout, void* stream);
+
 /* --- K14: DQN TD loss (torchrl/algo/off_policy/dqn.py:53-60): q, q_next (B, A); acts (B) int64;
  * dq (B, A); sums (3 doubles): squared-error sum, q_s_a sum, reward sum */
 int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const float* q_next, const float* rewards,

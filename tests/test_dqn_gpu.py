@@ -41,6 +41,48 @@ def test_cnn_forward_backward_vs_torch(act):
         assert err < 5e-5 * max(1.0, p.grad.abs().max().item()), err
 
 
+@pytest.mark.parametrize("B,C,H,W,kh,kw,sh,sw,Cout", [
+    (5, 4, 84, 84, 8, 8, 4, 4, 16),        # the Atari first layer (dqn_pong.json)
+    (3, 3, 36, 44, 3, 4, 2, 4, 5),         # K = 36 (one partial panel), ragged M, Cout < tile
+    (2, 2, 20, 20, 8, 8, 4, 4, 70),        # Ho * Wo = 16 (power-of-two divisor), two N tiles
+    (7, 1, 9, 8, 2, 8, 1, 4, 3),           # Wo = 1 (division by 1), Ho = 8
+    (130, 5, 16, 16, 4, 4, 4, 4, 33),      # M = 2080: several reduction splits in the weight gradient
+])
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+def test_implicit_gemm_first_conv_layer_vs_torch(B, C, H, W, kh, kw, sh, sw, Cout, act):
+    """trl_conv_fwd_u8_f32 / trl_conv_bwd_weight_u8_f32 (no im2col buffer) against torch's conv2d + autograd on
+    the scaled frames."""
+    from torchrl_amd import _C
+    gen = torch.Generator().manual_seed(B * 1000 + Cout)
+    frames = torch.randint(0, 256, (B, C, H, W), dtype=torch.uint8, generator=gen)
+    w = (torch.randn(Cout, C, kh, kw, generator=gen) / (C * kh * kw) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, generator=gen).requires_grad_(True)
+    f = {"relu": torch.relu, "tanh": torch.tanh}[act]
+    code = {"relu": _C.ACT_RELU, "tanh": _C.ACT_TANH}[act]
+    want = f(F.conv2d(frames.float() / 255.0 - 0.5, w, b, stride=(sh, sw)))           # (B, Cout, Ho, Wo)
+    dy = torch.randn(want.shape, generator=gen)
+    want.backward(dy)
+    assert _C.conv_u8_implicit_ok(frames, kh, kw, sh, sw)
+    wd, bd = w.detach().to(DEV), b.detach().to(DEV)
+    y, (Bo, Ho, Wo) = _C.conv_fwd_u8(frames.to(DEV), wd.view(Cout, -1), bd, kh, kw, sh, sw, 1.0 / 255.0, -0.5, code)
+    got = y.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2).cpu()
+    assert (got - want.detach()).abs().max().item() < 2e-5
+    dy_rows = dy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(DEV)
+    dw, db = torch.empty_like(wd.view(Cout, -1)), torch.empty_like(bd)
+    _C.conv_bwd_weight_u8(dy_rows, y, code, frames.to(DEV), kh, kw, sh, sw, 1.0 / 255.0, -0.5, dw, db)
+    scale = lambda t: max(1.0, t.abs().max().item())
+    assert (dw.cpu().view_as(w) - w.grad).abs().max().item() < 5e-5 * scale(w.grad)
+    assert (db.cpu() - b.grad).abs().max().item() < 5e-5 * scale(b.grad)
+
+
+def test_implicit_gemm_rejects_unaligned_geometry():
+    from torchrl_amd import _C
+    frames = torch.zeros(2, 4, 21, 21, dtype=torch.uint8, device=DEV)
+    assert not _C.conv_u8_implicit_ok(frames, 3, 3, 2, 2)
+    with pytest.raises(_C.TrlError, match="multiples of 4"):
+        _C.conv_fwd_u8(frames, torch.zeros(8, 36, device=DEV), None, 3, 3, 2, 2, 1.0, 0.0, _C.ACT_RELU)
+
+
 def test_im2col_col2im_transpose_vs_torch():
     from torchrl_amd import _C
     x = torch.randn(3, 9, 11, 5)                                             # (B, H, W, C)

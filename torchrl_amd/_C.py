@@ -128,6 +128,10 @@ SIGNATURES = {
     "trl_im2col_u8_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_void_p]),
     "trl_col2im_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_conv_fwd_u8_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "trl_conv_bwd_weight_workspace": (C.c_int, [C.c_int] * 9),
+    "trl_conv_bwd_weight_u8_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 8
+                                   + [C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "trl_dqn_td_loss_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_quantile_huber_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
     "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
@@ -448,6 +452,40 @@ def im2col(x, kh, kw, sh, sw, scale=None, shift=0.0):
         check(lib().trl_im2col_f32(dev_ptr(x, name="x"), dev_ptr(cols, name="cols"), B, Cc, H, W, kh, kw, sh, sw,
                                    stream_ptr(x.device)), "trl_im2col_f32")
     return cols, (B, Ho, Wo)
+
+
+def conv_u8_implicit_ok(frames, kh, kw, sh, sw):
+    """Geometry the implicit-GEMM first-layer kernels accept (include/trl_hip.h K16b)."""
+    return kw % 4 == 0 and sw % 4 == 0 and int(frames.shape[3]) % 4 == 0
+
+
+def conv_fwd_u8(frames, w, bias, kh, kw, sh, sw, scale, shift, act):
+    """act(conv2d(frames * scale + shift, w) + bias) on (B, C, H, W) uint8 frames; returns ((B*Ho*Wo, Cout), (B, Ho, Wo))."""
+    B, Cc, H, W = (int(v) for v in frames.shape)
+    Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
+    Cout = int(w.shape[0])
+    y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=frames.device)
+    check(lib().trl_conv_fwd_u8_f32(dev_ptr(frames, torch.uint8, "frames"), dev_ptr(w, name="w"),
+                                    dev_ptr(bias, name="bias", allow_none=True), dev_ptr(y, name="y"), B, Cc, H, W,
+                                    kh, kw, sh, sw, float(scale), float(shift), Cout, act, stream_ptr(frames.device)),
+          "trl_conv_fwd_u8_f32")
+    return y, (B, Ho, Wo)
+
+
+def conv_bwd_weight_u8(dy, y_gate, gate_act, frames, kh, kw, sh, sw, scale, shift, dw, db, workspace=None):
+    B, Cc, H, W = (int(v) for v in frames.shape)
+    Cout = int(dy.shape[1])
+    need = lib().trl_conv_bwd_weight_workspace(B, Cc, H, W, kh, kw, sh, sw, Cout)
+    if need < 0:
+        raise TrlError("conv_bwd_weight_u8: bad geometry")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.float32, device=dy.device)
+    check(lib().trl_conv_bwd_weight_u8_f32(dev_ptr(dy, name="dy"), dev_ptr(y_gate, name="y_gate", allow_none=True), gate_act,
+                                           dev_ptr(frames, torch.uint8, "frames"), dev_ptr(dw, name="dw"),
+                                           dev_ptr(db, name="db", allow_none=True), dev_ptr(workspace, name="workspace"),
+                                           B, Cc, H, W, kh, kw, sh, sw, float(scale), float(shift), Cout,
+                                           stream_ptr(dy.device)), "trl_conv_bwd_weight_u8_f32")
+    return dw, db
 
 
 def col2im(dcols, B, Cc, H, W, kh, kw, sh, sw):

@@ -18,6 +18,7 @@
 // contiguous dimension, [k][col] (row stride 64 + 8, ds_read_b32) when it is not -- so the global->LDS copy
 // never transposes.  MFMA step (q, r) of lane half `hi` takes k = 8q + 4hi + r.  Arbitrary M, N, K: slots that
 // are misaligned or cross an edge fall back to predicated scalar loads (zero fill).
+#include <algorithm>
 #include "trl_common.h"
 #include "trl_mlp.h"
 
@@ -37,6 +38,42 @@ __device__ __forceinline__ float dact_from_out(int act, float y) {
   return 1.0f;
 }
 
+// Implicit-GEMM operand (first conv layer of CNNBase, networks/base.py:59-107, on the replay buffer's uint8 NCHW
+// frame stacks): row m = (b, oy, ox), reduction index k = (c, i, j) in nn.Conv2d's weight order, element
+//     cols[m][k] = frames[b][c][oy * sh + i][ox * sw + j] * scale + shift          (ScaledFloatFrame on the fly)
+// With kw, sw and W multiples of 4 the 4 consecutive k of a slot are 4 consecutive, 4-byte aligned bytes: one
+// dword load per slot, converted when the panel is written to LDS.  The 210 MB im2col buffer of cfg 5 never exists.
+struct ConvSrc {
+  const uint8_t* frames;
+  int C, H, W, kh, kw, sh, sw, Ho, Wo;
+  float scale, shift;
+  uint32_t hw_magic, hw_shift, w_magic, w_shift;    // division by Ho * Wo and by Wo (multiply-high form)
+};
+
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t d, uint32_t magic, uint32_t shift) {
+  if (d == 1) return n;                             // uniform
+  const uint32_t q = __umulhi(n, magic);
+  return (((n - q) >> 1) + q) >> shift;
+}
+// byte offset of window (b, oy, ox), channel 0, tap (0, 0)
+__device__ __forceinline__ uint32_t conv_row_offset(const ConvSrc& cv, uint32_t m) {
+  const uint32_t hw = (uint32_t)(cv.Ho * cv.Wo);
+  const uint32_t b = fastdiv(m, hw, cv.hw_magic, cv.hw_shift), p = m - b * hw;
+  const uint32_t oy = fastdiv(p, (uint32_t)cv.Wo, cv.w_magic, cv.w_shift), ox = p - oy * cv.Wo;
+  return ((b * cv.C) * cv.H + oy * cv.sh) * cv.W + ox * cv.sw;
+}
+// byte offset of reduction index k = (c, i, j) relative to the window origin
+__device__ __forceinline__ uint32_t conv_tap_offset(const ConvSrc& cv, uint32_t k) {
+  const uint32_t khw = (uint32_t)(cv.kh * cv.kw);
+  const uint32_t c = k / khw, rem = k - c * khw, i = rem / (uint32_t)cv.kw, j = rem - i * cv.kw;
+  return (c * cv.H + i) * cv.W + j;
+}
+__device__ __forceinline__ f32x4 conv_unpack(uint32_t u, float scale, float shift) {
+  f32x4 v = {fmaf((float)(u & 0xffu), scale, shift), fmaf((float)((u >> 8) & 0xffu), scale, shift),
+             fmaf((float)((u >> 16) & 0xffu), scale, shift), fmaf((float)(u >> 24), scale, shift)};
+  return v;
+}
+
 struct GemmDev {
   const float* A; const float* B; float* C;
   const float* bias;          // epilogue: + bias[n]          (nullable)
@@ -47,6 +84,7 @@ struct GemmDev {
   int split_len;              // TA only: rows of the reduction handled by one blockIdx.z
   float* colsum;              // TA only: (splits, M) partial column sums of the gated A (nullable)
   int tiles_n, tiles;         // C tiles along N, and in total
+  ConvSrc cv;                 // CONV != 0: the implicit operand (A when CONV == 1, B when CONV == 2)
 };
 
 // development aid (tools/bench_gemm.py --clk): shader-clock and 100 MHz real-time stamps of a few workgroups
@@ -121,8 +159,11 @@ __device__ __forceinline__ f32x4 panel_operand(const float* tile, int row, int q
 
 // TA: A is stored [Kred][M] (we need A^T); TB: B is stored [N][K] (we need B^T).
 // GATE: activation whose derivative (through a_gate) multiplies operand A (TRL_ACT_NONE: no gate).
-template <bool TA, bool TB, int GATE>
+// CONV: 0 both operands dense; 1 operand A (M x K, forward) is the implicit cols matrix of g.cv; 2 operand B
+// (Kred x N, weight gradient) is.
+template <bool TA, bool TB, int GATE, int CONV>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
+  static_assert(CONV == 0 || (CONV == 1 && !TA && TB) || (CONV == 2 && TA && !TB), "implicit operand orientation");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;
   float* Bs = lds + (TA ? TILE_RMAJ : TILE_KMAJ);
@@ -152,20 +193,63 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   f32x4 csum = {0.0f, 0.0f, 0.0f, 0.0f};          // TA: partial column sums of columns 4 * (tid & 15) .. + 3
   f32x4 ra[SLOTS], rg[SLOTS], rb[SLOTS];
+  // implicit operand: one dword (4 bytes = 4 reduction / column indices) per slot + validity bits
+  uint32_t cu[SLOTS], cmask = 0u, cbase[SLOTS], ctap = 0u;
+  bool ctap_ok = false;
+  if (CONV == 1) {                                 // A rows are fixed for the whole kernel: decode them once
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      const int m = m0 + 8 * t + (tid >> 5);
+      cbase[t] = m < g.M ? conv_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
+    }
+  }
+  if (CONV == 2) {                                 // B columns (the taps) are fixed for the whole kernel
+    const int kc = n0 + 4 * (tid & 15);
+    ctap_ok = kc < g.N;
+    ctap = ctap_ok ? conv_tap_offset(g.cv, (uint32_t)kc) : 0u;
+  }
 
   auto fetch = [&](int k0) {
     const bool k_whole = k0 + KC <= k_hi;          // uniform: one branch per operand per panel
-    if (a_whole && k_whole) {
+    if (CONV == 1) {
+      const int kk = k0 + 4 * (tid & 31);
+      const bool kin = kk < k_hi;
+      const uint32_t tap = kin ? conv_tap_offset(g.cv, (uint32_t)kk) : 0u;
+      cmask = 0u;
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const bool ok = kin && cbase[t] != 0xffffffffu;
+        cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? cbase[t] + tap : 0u)) : 0u;
+        cmask |= ok ? (1u << t) : 0u;
+      }
+    } else if (a_whole && k_whole) {
       panel_fetch_fast<!TA>(g.A, g.lda, m0, k0, tid, ra);
       if (GATE != TRL_ACT_NONE) panel_fetch_fast<!TA>(g.a_gate, g.lda, m0, k0, tid, rg);
     } else {
       panel_fetch_edge<!TA>(g.A, g.lda, m0, g.M, k0, k_hi, tid, ra);
       if (GATE != TRL_ACT_NONE) panel_fetch_edge<!TA>(g.a_gate, g.lda, m0, g.M, k0, k_hi, tid, rg);
     }
-    if (b_whole && k_whole) panel_fetch_fast<TB>(g.B, g.ldb, n0, k0, tid, rb);
-    else                    panel_fetch_edge<TB>(g.B, g.ldb, n0, g.N, k0, k_hi, tid, rb);
+    if (CONV == 2) {
+      cmask = 0u;
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int m = k0 + 16 * t + (tid >> 4);
+        const bool ok = ctap_ok && m < k_hi;
+        cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? conv_row_offset(g.cv, (uint32_t)m) + ctap : 0u)) : 0u;
+        cmask |= ok ? (1u << t) : 0u;
+      }
+    } else if (b_whole && k_whole) panel_fetch_fast<TB>(g.B, g.ldb, n0, k0, tid, rb);
+    else                           panel_fetch_edge<TB>(g.B, g.ldb, n0, g.N, k0, k_hi, tid, rb);
   };
   auto stash = [&]() {
+    if (CONV != 0) {
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const f32x4 v = (cmask >> t) & 1u ? conv_unpack(cu[t], g.cv.scale, g.cv.shift) : zero;
+        if (CONV == 1) ra[t] = v; else rb[t] = v;
+      }
+    }
     if (GATE != TRL_ACT_NONE) {
 #pragma unroll
       for (int t = 0; t < SLOTS; ++t)
@@ -242,40 +326,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   }
 }
 
-// fixed-order fold of split partials: out[e] = sum_s part[s][e]; a second segment (the bias gradient) rides along
+// fixed-order fold of split partials: out[e] = sum_s part[s][e]; a second segment (the bias gradient) rides along.
+// A workgroup owns 64 outputs; its 4 waves each sum every 4th split, then the 4 slices are added in order.
+#define FOLD_OUT 64
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
                                                             const float* __restrict__ part2, float* __restrict__ out2,
                                                             int n2, int splits) {
-  int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) { e -= n; part = part2; out = out2; n = n2; }
-  if (e >= n) return;
+  __shared__ float sl[4][FOLD_OUT];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  int e = blockIdx.x * FOLD_OUT + lane;
+  const bool second = e >= n;                      // per lane: a workgroup may straddle the two segments
+  const float* p = second ? part2 : part;
+  const int nn = second ? n2 : n, ee = second ? e - n : e;
   float a = 0.0f;
-  for (int s = 0; s < splits; ++s) a += part[(size_t)s * n + e];
-  out[e] = a;
+  if (ee < nn)
+    for (int s = slice; s < splits; s += 4) a += p[(size_t)s * nn + ee];
+  sl[slice][lane] = a;
+  __syncthreads();
+  if (slice == 0 && ee < nn) (second ? out2 : out)[ee] = (sl[0][lane] + sl[1][lane]) + (sl[2][lane] + sl[3][lane]);
 }
 
-template <bool TA, bool TB, int GATE>
+template <bool TA, bool TB, int GATE, int CONV>
 static int launch_gemm_gate(GemmDev g, int splits, hipStream_t s) {
   const int lds = (int)sizeof(float) * ((TA ? TILE_RMAJ : TILE_KMAJ) + (TB ? TILE_KMAJ : TILE_RMAJ));
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE, CONV>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { trl_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   g.tiles_n = trl_ceil_div(g.N, GN);
   g.tiles = g.tiles_n * trl_ceil_div(g.M, GM);
-  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE>), dim3(g.tiles, 1, splits), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE, CONV>), dim3(g.tiles, 1, splits), dim3(256), lds, s, g);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int CONV = 0>
 static int launch_gemm(const GemmDev& g, int splits, hipStream_t s) {
   const int gate = g.a_gate ? g.gate_act : TRL_ACT_NONE;
-  if (gate == TRL_ACT_TANH) return launch_gemm_gate<TA, TB, TRL_ACT_TANH>(g, splits, s);
-  if (gate == TRL_ACT_RELU) return launch_gemm_gate<TA, TB, TRL_ACT_RELU>(g, splits, s);
-  return launch_gemm_gate<TA, TB, TRL_ACT_NONE>(g, splits, s);
+  if (gate == TRL_ACT_TANH) return launch_gemm_gate<TA, TB, TRL_ACT_TANH, CONV>(g, splits, s);
+  if (gate == TRL_ACT_RELU) return launch_gemm_gate<TA, TB, TRL_ACT_RELU, CONV>(g, splits, s);
+  return launch_gemm_gate<TA, TB, TRL_ACT_NONE, CONV>(g, splits, s);
+}
+
+// Reduction rows per blockIdx.z of the weight-gradient GEMM: never below 256 (two panels), and long enough that
+// the grid stays near 1024 workgroups when M is huge (conv layers: M = B * Ho * Wo).
+static int bw_split_len(int M, int K, int N) {
+  const int tiles = trl_ceil_div(N, GM) * trl_ceil_div(K, GN);
+  const int want = std::max(1, 1024 / tiles);
+  const int len = trl_ceil_div(trl_ceil_div(M, want), KC) * KC;
+  return std::max(256, len);
 }
 
 extern "C" int trl_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
@@ -303,26 +405,99 @@ extern "C" int trl_linear_bwd_input_f32(const float* dy, const float* y_gate, in
 
 extern "C" int trl_linear_bwd_weight_workspace(int M, int K, int N) {
   // floats of workspace for trl_linear_bwd_weight_f32 (split partials of dW and db)
-  const int splits = M <= 0 ? 1 : (M + 255) / 256;
+  const int splits = M <= 0 ? 1 : trl_ceil_div(M, bw_split_len(M, K, N));
   return splits * (N * K + N);
+}
+
+template <int CONV>
+static int bwd_weight_impl(const float* dy, const float* y_gate, int gate_act, const float* x, const ConvSrc* cv, float* dw,
+                           float* db, float* workspace, int M, int K, int N, hipStream_t s) {
+  const int split_len = bw_split_len(M, K, N);
+  const int splits = trl_ceil_div(M, split_len);
+  GemmDev g{};
+  g.A = dy; g.a_gate = y_gate; g.gate_act = gate_act; g.B = x; g.C = workspace; g.bias = nullptr;
+  g.M = N; g.N = K; g.K = M; g.lda = N; g.ldb = K; g.ldc = K; g.act = TRL_ACT_NONE; g.split_len = split_len;
+  g.colsum = db ? workspace + (size_t)splits * N * K : nullptr;
+  if (cv) g.cv = *cv;
+  int rc = launch_gemm<true, false, CONV>(g, splits, s);
+  if (rc) return rc;
+  const int n2 = db ? N : 0;
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)N * K + n2, FOLD_OUT)), dim3(256), 0, s, workspace, dw,
+                     N * K, g.colsum, db, n2, splits);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
 }
 
 extern "C" int trl_linear_bwd_weight_f32(const float* dy, const float* y_gate, int gate_act, const float* x, float* dw,
                                          float* db, float* workspace, int M, int K, int N, void* stream) {
   TRL_REQUIRE(M > 0 && K > 0 && N > 0, "bad sizes");
   TRL_REQUIRE(dy && x && dw && workspace, "null pointer");
-  const int split_len = 256;
-  const int splits = (M + split_len - 1) / split_len;
-  hipStream_t s = (hipStream_t)stream;
-  GemmDev g{};
-  g.A = dy; g.a_gate = y_gate; g.gate_act = gate_act; g.B = x; g.C = workspace; g.bias = nullptr;
-  g.M = N; g.N = K; g.K = M; g.lda = N; g.ldb = K; g.ldc = K; g.act = TRL_ACT_NONE; g.split_len = split_len;
-  g.colsum = db ? workspace + (size_t)splits * N * K : nullptr;
-  int rc = launch_gemm<true, false>(g, splits, s);
-  if (rc) return rc;
-  const int n2 = db ? N : 0;
-  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)N * K + n2, 256)), dim3(256), 0, s, workspace, dw,
-                     N * K, g.colsum, db, n2, splits);
-  TRL_LAUNCH_CHECK();
+  return bwd_weight_impl<0>(dy, y_gate, gate_act, x, nullptr, dw, db, workspace, M, K, N, (hipStream_t)stream);
+}
+
+// ---- first conv layer on uint8 frames as an implicit GEMM ----
+static void fastdiv_gen(uint32_t d, uint32_t& magic, uint32_t& shift) {
+  if (d <= 1) { magic = 0; shift = 0; return; }
+  const uint32_t L = 31 - (uint32_t)__builtin_clz(d);
+  if ((d & (d - 1)) == 0) { magic = 0; shift = L - 1; return; }
+  const uint64_t num = (uint64_t)1 << (32 + L);
+  uint32_t m = (uint32_t)(num / d);
+  const uint32_t rem = (uint32_t)(num - (uint64_t)m * d);
+  m += m;
+  const uint32_t twice = rem + rem;
+  if (twice >= d || twice < rem) m += 1;
+  magic = m + 1; shift = L;
+}
+
+static int fill_conv(const char* who, const uint8_t* frames, int B, int C, int H, int W, int kh, int kw, int sh, int sw,
+                     float scale, float shift, ConvSrc& cv, int& M, int& K) {
+  if (!(B > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && H >= kh && W >= kw)) {
+    trl_set_error("%s: bad geometry", who); return TRL_EINVAL;
+  }
+  if ((kw & 3) || (sw & 3) || (W & 3) || (reinterpret_cast<uintptr_t>(frames) & 3)) {
+    trl_set_error("%s: the implicit-GEMM path needs kw, sw and W to be multiples of 4 and 4-byte aligned frames "
+                  "(use trl_im2col_u8_nchw + trl_linear_* otherwise)", who);
+    return TRL_EINVAL;
+  }
+  if ((int64_t)B * C * H * W >= ((int64_t)1 << 32) - 1) { trl_set_error("%s: frame batch exceeds 4 GiB", who); return TRL_EINVAL; }
+  cv.frames = frames; cv.C = C; cv.H = H; cv.W = W; cv.kh = kh; cv.kw = kw; cv.sh = sh; cv.sw = sw;
+  cv.Ho = (H - kh) / sh + 1; cv.Wo = (W - kw) / sw + 1; cv.scale = scale; cv.shift = shift;
+  fastdiv_gen((uint32_t)(cv.Ho * cv.Wo), cv.hw_magic, cv.hw_shift);
+  fastdiv_gen((uint32_t)cv.Wo, cv.w_magic, cv.w_shift);
+  const int64_t m = (int64_t)B * cv.Ho * cv.Wo;
+  if (m >= ((int64_t)1 << 31)) { trl_set_error("%s: too many output positions", who); return TRL_EINVAL; }
+  M = (int)m; K = C * kh * kw;
   return TRL_OK;
+}
+
+extern "C" int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias, float* y, int B, int C, int H,
+                                   int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
+                                   void* stream) {
+  TRL_REQUIRE(frames && w && y && Cout > 0, "null pointer / bad Cout");
+  TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
+  GemmDev g{};
+  int M, K;
+  int rc = fill_conv("conv_fwd_u8", frames, B, C, H, W, kh, kw, sh, sw, scale, shift, g.cv, M, K);
+  if (rc) return rc;
+  g.A = nullptr; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
+  g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
+  return launch_gemm<false, true, 1>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout) {
+  if (!(B > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && H >= kh && W >= kw && Cout > 0)) return TRL_EINVAL;
+  const int64_t m = (int64_t)B * ((H - kh) / sh + 1) * ((W - kw) / sw + 1);
+  if (m >= ((int64_t)1 << 31)) return TRL_EINVAL;
+  return trl_linear_bwd_weight_workspace((int)m, C * kh * kw, Cout);
+}
+
+extern "C" int trl_conv_bwd_weight_u8_f32(const float* dy, const float* y_gate, int gate_act, const uint8_t* frames,
+                                          float* dw, float* db, float* workspace, int B, int C, int H, int W, int kh,
+                                          int kw, int sh, int sw, float scale, float shift, int Cout, void* stream) {
+  TRL_REQUIRE(dy && frames && dw && workspace && Cout > 0, "null pointer / bad Cout");
+  ConvSrc cv{};
+  int M, K;
+  int rc = fill_conv("conv_bwd_weight_u8", frames, B, C, H, W, kh, kw, sh, sw, scale, shift, cv, M, K);
+  if (rc) return rc;
+  return bwd_weight_impl<2>(dy, y_gate, gate_act, nullptr, &cv, dw, db, workspace, M, K, Cout, (hipStream_t)stream);
 }

@@ -115,6 +115,13 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
     for k, m in enumerate(conv_layers(net)):
         kh, kw = m.kernel_size
         sh, sw = m.stride
+        if k == 0 and _C.conv_u8_implicit_ok(x, kh, kw, sh, sw):
+            # implicit GEMM straight from the uint8 frames: the im2col matrix (210 MB at cfg 5) never exists
+            wmat = m.weight.view(m.weight.shape[0], -1)
+            y, (B, Ho, Wo) = _C.conv_fwd_u8(x, wmat, m.bias, kh, kw, sh, sw, scale, shift, act)
+            t.convs.append((None, y, wmat, (x, scale, shift), (kh, kw, sh, sw)))
+            x = y.view(B, Ho, Wo, int(wmat.shape[0]))
+            continue
         if k == 0:
             cols, (B, Ho, Wo) = _C.im2col(x, kh, kw, sh, sw, scale=scale, shift=shift)
             in_shape = None
@@ -141,6 +148,11 @@ def cnn_backward(net, tape, d_out, grads, workspace=None):
     for k in range(n_conv - 1, -1, -1):
         cols, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]
         gw, gb = grads[k]
+        if cols is None:                                                     # first layer, implicit GEMM on the frames
+            frames, scale, shift = in_shape
+            _C.conv_bwd_weight_u8(d, y, tape.act, frames, kh, kw, sh, sw, scale, shift, gw.view(wmat.shape), gb,
+                                  workspace=workspace)
+            continue
         _C.linear_bwd_weight(d, y, tape.act, cols, dw=gw.view(wmat.shape), db=gb, workspace=workspace)
         if k > 0:
             dcols = _C.linear_bwd_input(d, y, tape.act, wmat)
