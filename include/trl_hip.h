@@ -252,6 +252,13 @@ int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, in
  * trl_linear_bwd_weight_workspace(M, K, N) floats (split partials, folded in fixed order). */
 int trl_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                        int M, int K, int N, int act, void* stream);
+/* Same result with the reduction split over up to 8 workgroup slices when the layer has few rows and a long
+ * reduction (the conv nets' first FC layer, 512 x 3136 -> 512: 64 output tiles for 256 CUs); partial products
+ * go to `workspace` (trl_linear_fwd_workspace(M, K, N) floats, 0 = the layer is not split and workspace may
+ * be NULL) and are folded in fixed order together with bias and activation. */
+int trl_linear_fwd_workspace(int M, int K, int N);
+int trl_linear_fwd_splitk_f32(const float* x, const float* w, const float* bias, float* y,
+                              int M, int K, int N, int act, float* workspace, void* stream);
 int trl_linear_bwd_input_f32(const float* dy, const float* y_gate, int gate_act, const float* w,
                              float* dx, int M, int K, int N, void* stream);
 int trl_linear_bwd_weight_workspace(int M, int K, int N);

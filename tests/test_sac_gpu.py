@@ -15,7 +15,7 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("M,K,N", [(256, 23, 256), (4096, 256, 256), (100, 17, 12), (65, 256, 1), (1, 5, 3),
-                                   (300, 132, 70), (515, 392, 96), (130, 260, 68)])
+                                   (300, 132, 70), (515, 392, 96), (130, 260, 68), (200, 3136, 96), (64, 1100, 130)])
 @pytest.mark.parametrize("act", ["tanh", "relu", "none"])
 def test_linear_layer_kernels_vs_torch(M, K, N, act):
     from torchrl_amd import _C

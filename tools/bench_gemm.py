@@ -7,7 +7,8 @@ sys.path.insert(0, REPO)
 from torchrl_amd import _C
 
 SHAPES = [(4096, 29, 256), (4096, 256, 256), (4096, 256, 1), (4096, 256, 24), (4096, 64, 256), (4096, 128, 256),
-          (4096, 512, 256), (8192, 256, 256), (512, 3136, 512), (512, 512, 6)]
+          (4096, 512, 256), (8192, 256, 256), (512, 3136, 512), (512, 512, 6), (512, 512, 1200),
+          (204800, 256, 16), (41472, 256, 32), (25088, 288, 64)]
 
 
 def timed(fn, reps=200):

@@ -138,6 +138,8 @@ SIGNATURES = {
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_linear_fwd_workspace": (C.c_int, [C.c_int] * 3),
+    "trl_linear_fwd_splitk_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "trl_linear_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_linear_bwd_weight_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -307,6 +309,14 @@ def linear_fwd(x, w, bias, act):
     M, K = int(x.shape[0]), int(x.shape[1])
     N = int(w.shape[0])
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    need = lib().trl_linear_fwd_workspace(M, K, N)
+    if need > 0:                                                         # few rows, long reduction: split-K + fold
+        ws = torch.empty((need,), dtype=torch.float32, device=x.device)
+        check(lib().trl_linear_fwd_splitk_f32(dev_ptr(x, name="x"), dev_ptr(w, name="w"),
+                                              dev_ptr(bias, name="bias", allow_none=True), dev_ptr(y, name="y"),
+                                              M, K, N, act, dev_ptr(ws, name="workspace"), stream_ptr(x.device)),
+              "trl_linear_fwd_splitk_f32")
+        return y
     check(lib().trl_linear_fwd_f32(dev_ptr(x, name="x"), dev_ptr(w, name="w"),
                                    dev_ptr(bias, name="bias", allow_none=True), dev_ptr(y, name="y"),
                                    M, K, N, act, stream_ptr(x.device)), "trl_linear_fwd_f32")

@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   const int m0 = tm * GM, n0 = tn * GN;
   int k_lo = 0, k_hi = g.K;
   float* C = g.C;
-  if (TA) {                                        // split the (long) reduction dimension over blockIdx.z
-    k_lo = blockIdx.z * g.split_len;
+  if (gridDim.z > 1) {                             // split reduction: blockIdx.z owns split_len indices, writes its own
+    k_lo = blockIdx.z * g.split_len;               // partial C (folded in fixed order by fold_partials_kernel)
     k_hi = min(g.K, k_lo + g.split_len);
     C += (size_t)blockIdx.z * g.M * g.ldc;
   }
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
 #define FOLD_OUT 64
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
                                                             const float* __restrict__ part2, float* __restrict__ out2,
-                                                            int n2, int splits) {
+                                                            int n2, int splits, const float* __restrict__ bias, int n_cols,
+                                                            int act) {
   __shared__ float sl[4][FOLD_OUT];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   int e = blockIdx.x * FOLD_OUT + lane;
@@ -343,7 +344,15 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
     for (int s = slice; s < splits; s += 4) a += p[(size_t)s * nn + ee];
   sl[slice][lane] = a;
   __syncthreads();
-  if (slice == 0 && ee < nn) (second ? out2 : out)[ee] = (sl[0][lane] + sl[1][lane]) + (sl[2][lane] + sl[3][lane]);
+  if (slice == 0 && ee < nn) {
+    float v = (sl[0][lane] + sl[1][lane]) + (sl[2][lane] + sl[3][lane]);
+    if (!second && n_cols > 0) {                   // split-K forward: the epilogue the GEMM skipped
+      if (bias) v += bias[ee % n_cols];
+      if (act == TRL_ACT_TANH) v = trl_tanh(v);
+      else if (act == TRL_ACT_RELU) v = fmaxf(v, 0.0f);
+    }
+    (second ? out2 : out)[ee] = v;
+  }
 }
 
 template <bool TA, bool TB, int GATE, int CONV>
@@ -392,6 +401,39 @@ extern "C" int trl_linear_fwd_f32(const float* x, const float* w, const float* b
   return launch_gemm<false, true>(g, 1, (hipStream_t)stream);
 }
 
+// Split-K forward for few-row layers with a long reduction (the conv nets' first FC layer: 512 x 3136 -> 512 is
+// 64 C tiles for 256 CUs): up to 8 reduction slices write partial products, the fold adds bias and activation.
+static int fwd_split_len(int M, int K, int N) {
+  const int tiles = trl_ceil_div(M, GM) * trl_ceil_div(N, GN);
+  if (tiles >= 192 || K < 8 * KC) return K;
+  const int target = std::min(8, trl_ceil_div(384, tiles));
+  return trl_ceil_div(trl_ceil_div(K, target), KC) * KC;
+}
+extern "C" int trl_linear_fwd_workspace(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  const int splits = trl_ceil_div(K, fwd_split_len(M, K, N));
+  return splits > 1 ? splits * M * N : 0;
+}
+extern "C" int trl_linear_fwd_splitk_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
+                                         int act, float* workspace, void* stream) {
+  TRL_REQUIRE(M >= 0 && K > 0 && N > 0, "bad sizes");
+  if (M == 0) return TRL_OK;
+  const int split_len = fwd_split_len(M, K, N);
+  const int splits = trl_ceil_div(K, split_len);
+  if (splits <= 1) return trl_linear_fwd_f32(x, w, bias, y, M, K, N, act, stream);
+  TRL_REQUIRE(x && w && y && workspace, "null pointer");
+  TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
+  GemmDev g{};
+  g.A = x; g.B = w; g.C = workspace; g.bias = nullptr; g.a_gate = nullptr; g.M = M; g.N = N; g.K = K;
+  g.lda = K; g.ldb = K; g.ldc = N; g.act = TRL_ACT_NONE; g.gate_act = TRL_ACT_NONE; g.split_len = split_len; g.colsum = nullptr;
+  int rc = launch_gemm<false, true>(g, splits, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)M * N, FOLD_OUT)), dim3(256), 0, (hipStream_t)stream,
+                     workspace, y, M * N, (const float*)nullptr, (float*)nullptr, 0, splits, bias, N, act);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 extern "C" int trl_linear_bwd_input_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
                                         int M, int K, int N, void* stream) {
   TRL_REQUIRE(M >= 0 && K > 0 && N > 0, "bad sizes");
@@ -423,7 +465,7 @@ static int bwd_weight_impl(const float* dy, const float* y_gate, int gate_act, c
   if (rc) return rc;
   const int n2 = db ? N : 0;
   hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)N * K + n2, FOLD_OUT)), dim3(256), 0, s, workspace, dw,
-                     N * K, g.colsum, db, n2, splits);
+                     N * K, g.colsum, db, n2, splits, (const float*)nullptr, 0, TRL_ACT_NONE);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
