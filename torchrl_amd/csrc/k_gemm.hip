@@ -22,14 +22,8 @@
 #include "trl_common.h"
 #include "trl_mlp.h"
 
-#define GM 64
-#define GN 64
 #define KC 128                      // reduction panel
 #define LDK (KC + 4)                // [row][k] tile: 16-byte aligned rows, banks rotate by 4 per row
-#define LDN (GN + 8)                // [k][col] tile: rows k and k + 4 (the two lane halves) are 32 banks apart
-#define SLOTS 8                     // 16-byte slots per thread per operand panel (64 * 128 / 4 / 256)
-#define TILE_KMAJ (GM * LDK)        // floats of a [row][k] tile
-#define TILE_RMAJ (KC * LDN)        // floats of a [k][col] tile
 
 // act'(y) expressed through the activation OUTPUT y (tanh: 1 - y^2, relu: y > 0, none: 1)
 __device__ __forceinline__ float dact_from_out(int act, float y) {
@@ -99,35 +93,37 @@ extern "C" int trl_dbg_gemm_clk(long long* out) {
 #define GCLK(ph)
 #endif
 
-// One operand panel: 64 "rows" (the operand's C-side index) x KC reduction indices, held as 8 16-byte slots
-// per thread.  CONTIG_K: element (r, k) lives at base[(row0 + r) * ld + k0 + k]; otherwise at
-// base[(k0 + k) * ld + row0 + r].  Slot t of thread tid covers 4 consecutive elements of the contiguous dim.
-template <bool CONTIG_K>
+// One operand panel: ROWS "rows" (the operand's C-side index; 32, 64 or 128) x KC reduction indices, held as
+// ROWS / 8 16-byte slots per thread.  CONTIG_K: element (r, k) lives at base[(row0 + r) * ld + k0 + k] and the LDS
+// tile is [ROWS][LDK]; otherwise it lives at base[(k0 + k) * ld + row0 + r] and the tile is [KC][ROWS + 8].  Slot t
+// of thread tid covers 4 consecutive elements of the contiguous dim.
+template <bool CONTIG_K, int ROWS>
 __device__ __forceinline__ void panel_slot(int tid, int t, int& r, int& k) {
+  constexpr int TPR = ROWS / 4;                    // threads per reduction row of a [k][row] tile
   if (CONTIG_K) { r = 8 * t + (tid >> 5); k = 4 * (tid & 31); }
-  else          { k = 16 * t + (tid >> 4); r = 4 * (tid & 15); }
+  else          { k = (256 / TPR) * t + tid / TPR; r = 4 * (tid % TPR); }
 }
 
-// whole panel in range and 16-byte loads legal: 8 unconditional loads a fixed stride apart
-template <bool CONTIG_K>
+// whole panel in range and 16-byte loads legal: unconditional loads a fixed stride apart
+template <bool CONTIG_K, int ROWS>
 __device__ __forceinline__ void panel_fetch_fast(const float* __restrict__ base, int ld, int row0, int k0, int tid,
-                                                 f32x4 (&reg)[SLOTS]) {
+                                                 f32x4 (&reg)[ROWS / 8]) {
   int r, k;
-  panel_slot<CONTIG_K>(tid, 0, r, k);
+  panel_slot<CONTIG_K, ROWS>(tid, 0, r, k);
   const float* p = CONTIG_K ? base + (size_t)(row0 + r) * ld + k0 + k : base + (size_t)(k0 + k) * ld + row0 + r;
-  const size_t step = (size_t)(CONTIG_K ? 8 : 16) * ld;
+  const size_t step = (size_t)(CONTIG_K ? 8 : 256 / (ROWS / 4)) * ld;
 #pragma unroll
-  for (int t = 0; t < SLOTS; ++t) reg[t] = *reinterpret_cast<const f32x4*>(p + t * step);
+  for (int t = 0; t < ROWS / 8; ++t) reg[t] = *reinterpret_cast<const f32x4*>(p + t * step);
 }
 
 // edge / misaligned panel: element-wise predicated loads, zero fill
-template <bool CONTIG_K>
+template <bool CONTIG_K, int ROWS>
 __device__ __forceinline__ void panel_fetch_edge(const float* __restrict__ base, int ld, int row0, int rows, int k0, int k_hi,
-                                                 int tid, f32x4 (&reg)[SLOTS]) {
+                                                 int tid, f32x4 (&reg)[ROWS / 8]) {
 #pragma unroll
-  for (int t = 0; t < SLOTS; ++t) {
+  for (int t = 0; t < ROWS / 8; ++t) {
     int r, k;
-    panel_slot<CONTIG_K>(tid, t, r, k);
+    panel_slot<CONTIG_K, ROWS>(tid, t, r, k);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int gr = row0 + r + (CONTIG_K ? 0 : j), gk = k0 + k + (CONTIG_K ? j : 0);
@@ -138,35 +134,42 @@ __device__ __forceinline__ void panel_fetch_edge(const float* __restrict__ base,
   }
 }
 
-template <bool CONTIG_K>
-__device__ __forceinline__ void panel_stash(float* tile, int tid, const f32x4 (&reg)[SLOTS]) {
+template <bool CONTIG_K, int ROWS>
+__device__ __forceinline__ void panel_stash(float* tile, int tid, const f32x4 (&reg)[ROWS / 8]) {
 #pragma unroll
-  for (int t = 0; t < SLOTS; ++t) {
+  for (int t = 0; t < ROWS / 8; ++t) {
     int r, k;
-    panel_slot<CONTIG_K>(tid, t, r, k);
-    *reinterpret_cast<f32x4*>(tile + (CONTIG_K ? r * LDK + k : k * LDN + r)) = reg[t];
+    panel_slot<CONTIG_K, ROWS>(tid, t, r, k);
+    *reinterpret_cast<f32x4*>(tile + (CONTIG_K ? r * LDK + k : k * (ROWS + 8) + r)) = reg[t];
   }
 }
 
-// the 4 operand values of MFMA steps (q, 0..3) for C-side index `row` (0..63) of this lane half
-template <bool CONTIG_K>
+// the 4 operand values of MFMA steps (q, 0..3) for C-side index `row` of this lane half
+template <bool CONTIG_K, int ROWS>
 __device__ __forceinline__ f32x4 panel_operand(const float* tile, int row, int q, int hi) {
   if (CONTIG_K) return *reinterpret_cast<const f32x4*>(tile + row * LDK + 8 * q + 4 * hi);
-  const float* p = tile + (8 * q + 4 * hi) * LDN + row;
-  f32x4 v = {p[0], p[LDN], p[2 * LDN], p[3 * LDN]};
+  constexpr int LD = ROWS + 8;                     // rows k and k + 4 (the two lane halves) are 32 banks apart
+  const float* p = tile + (8 * q + 4 * hi) * LD + row;
+  f32x4 v = {p[0], p[LD], p[2 * LD], p[3 * LD]};
   return v;
 }
+
+template <bool CONTIG_K, int ROWS>
+__host__ __device__ constexpr int tile_floats() { return CONTIG_K ? ROWS * LDK : KC * (ROWS + 8); }
 
 // TA: A is stored [Kred][M] (we need A^T); TB: B is stored [N][K] (we need B^T).
 // GATE: activation whose derivative (through a_gate) multiplies operand A (TRL_ACT_NONE: no gate).
 // CONV: 0 both operands dense; 1 operand A (M x K, forward) is the implicit cols matrix of g.cv; 2 operand B
 // (Kred x N, weight gradient) is.
-template <bool TA, bool TB, int GATE, int CONV>
+// WM: waves along M.  The 4 waves (one 32x32 quadrant each) form a 64 x 64 C tile (WM = 2), a 128 x 32 one
+// (WM = 4, layers with <= 32 outputs: a 64-wide tile would compute 50-75 % padding) or a 32 x 128 one (WM = 1).
+template <bool TA, bool TB, int GATE, int CONV, int WM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   static_assert(CONV == 0 || (CONV == 1 && !TA && TB) || (CONV == 2 && TA && !TB), "implicit operand orientation");
+  constexpr int WN = 4 / WM, GM = 32 * WM, GN = 32 * WN, SA = GM / 8, SB = GN / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;
-  float* Bs = lds + (TA ? TILE_RMAJ : TILE_KMAJ);
+  float* Bs = lds + tile_floats<!TA, GM>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Workgroups are dealt round-robin to the 8 XCDs: renumber so that each XCD owns a contiguous run of tiles
   // (the tiles_n tiles that share an A panel then share an L2).
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
     k_hi = min(g.K, k_lo + g.split_len);
     C += (size_t)blockIdx.z * g.M * g.ldc;
   }
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int i = lane & 31, hi = lane >> 5;
   const bool a_whole = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 &&
                        (GATE == TRL_ACT_NONE || (reinterpret_cast<uintptr_t>(g.a_gate) & 15) == 0) && m0 + GM <= g.M;
@@ -191,20 +194,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  f32x4 csum = {0.0f, 0.0f, 0.0f, 0.0f};          // TA: partial column sums of columns 4 * (tid & 15) .. + 3
-  f32x4 ra[SLOTS], rg[SLOTS], rb[SLOTS];
+  f32x4 csum = {0.0f, 0.0f, 0.0f, 0.0f};          // TA: partial column sums of columns 4 * (tid % (GM / 4)) .. + 3
+  f32x4 ra[SA], rg[SA], rb[SB];
   // implicit operand: one dword (4 bytes = 4 reduction / column indices) per slot + validity bits
-  uint32_t cu[SLOTS], cmask = 0u, cbase[SLOTS], ctap = 0u;
+  constexpr int SC = CONV == 1 ? SA : SB;
+  uint32_t cu[SC], cmask = 0u, cbase[SC], ctap = 0u;
   bool ctap_ok = false;
   if (CONV == 1) {                                 // A rows are fixed for the whole kernel: decode them once
 #pragma unroll
-    for (int t = 0; t < SLOTS; ++t) {
+    for (int t = 0; t < SC; ++t) {
       const int m = m0 + 8 * t + (tid >> 5);
       cbase[t] = m < g.M ? conv_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
     }
   }
   if (CONV == 2) {                                 // B columns (the taps) are fixed for the whole kernel
-    const int kc = n0 + 4 * (tid & 15);
+    const int kc = n0 + 4 * (tid % (GN / 4));
     ctap_ok = kc < g.N;
     ctap = ctap_ok ? conv_tap_offset(g.cv, (uint32_t)kc) : 0u;
   }
@@ -217,51 +221,51 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
       const uint32_t tap = kin ? conv_tap_offset(g.cv, (uint32_t)kk) : 0u;
       cmask = 0u;
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
+      for (int t = 0; t < SC; ++t) {
         const bool ok = kin && cbase[t] != 0xffffffffu;
         cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? cbase[t] + tap : 0u)) : 0u;
         cmask |= ok ? (1u << t) : 0u;
       }
     } else if (a_whole && k_whole) {
-      panel_fetch_fast<!TA>(g.A, g.lda, m0, k0, tid, ra);
-      if (GATE != TRL_ACT_NONE) panel_fetch_fast<!TA>(g.a_gate, g.lda, m0, k0, tid, rg);
+      panel_fetch_fast<!TA, GM>(g.A, g.lda, m0, k0, tid, ra);
+      if (GATE != TRL_ACT_NONE) panel_fetch_fast<!TA, GM>(g.a_gate, g.lda, m0, k0, tid, rg);
     } else {
-      panel_fetch_edge<!TA>(g.A, g.lda, m0, g.M, k0, k_hi, tid, ra);
-      if (GATE != TRL_ACT_NONE) panel_fetch_edge<!TA>(g.a_gate, g.lda, m0, g.M, k0, k_hi, tid, rg);
+      panel_fetch_edge<!TA, GM>(g.A, g.lda, m0, g.M, k0, k_hi, tid, ra);
+      if (GATE != TRL_ACT_NONE) panel_fetch_edge<!TA, GM>(g.a_gate, g.lda, m0, g.M, k0, k_hi, tid, rg);
     }
     if (CONV == 2) {
       cmask = 0u;
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int m = k0 + 16 * t + (tid >> 4);
+      for (int t = 0; t < SC; ++t) {
+        const int m = k0 + (256 / (GN / 4)) * t + tid / (GN / 4);
         const bool ok = ctap_ok && m < k_hi;
         cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? conv_row_offset(g.cv, (uint32_t)m) + ctap : 0u)) : 0u;
         cmask |= ok ? (1u << t) : 0u;
       }
-    } else if (b_whole && k_whole) panel_fetch_fast<TB>(g.B, g.ldb, n0, k0, tid, rb);
-    else                           panel_fetch_edge<TB>(g.B, g.ldb, n0, g.N, k0, k_hi, tid, rb);
+    } else if (b_whole && k_whole) panel_fetch_fast<TB, GN>(g.B, g.ldb, n0, k0, tid, rb);
+    else                           panel_fetch_edge<TB, GN>(g.B, g.ldb, n0, g.N, k0, k_hi, tid, rb);
   };
   auto stash = [&]() {
     if (CONV != 0) {
       const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
+      for (int t = 0; t < SC; ++t) {
         const f32x4 v = (cmask >> t) & 1u ? conv_unpack(cu[t], g.cv.scale, g.cv.shift) : zero;
         if (CONV == 1) ra[t] = v; else rb[t] = v;
       }
     }
     if (GATE != TRL_ACT_NONE) {
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t)
+      for (int t = 0; t < SA; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) ra[t][j] *= dact_from_out(GATE, rg[t][j]);
     }
     if (want_colsum) {
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) csum += ra[t];
+      for (int t = 0; t < SA; ++t) csum += ra[t];
     }
-    panel_stash<!TA>(As, tid, ra);
-    panel_stash<TB>(Bs, tid, rb);
+    panel_stash<!TA, GM>(As, tid, ra);
+    panel_stash<TB, GN>(Bs, tid, rb);
   };
 
   GCLK(0)
@@ -276,8 +280,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
     for (int q4 = 0; q4 < nq4; ++q4) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        const f32x4 av = panel_operand<!TA>(As, 32 * wm + i, 4 * q4 + qq, hi);
-        const f32x4 bv = panel_operand<TB>(Bs, 32 * wn + i, 4 * q4 + qq, hi);
+        const f32x4 av = panel_operand<!TA, GM>(As, 32 * wm + i, 4 * q4 + qq, hi);
+        const f32x4 bv = panel_operand<TB, GN>(Bs, 32 * wn + i, 4 * q4 + qq, hi);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc = mfma32(av[r], bv[r], acc);
       }
@@ -313,14 +317,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   }
   GCLK(6)
   if (want_colsum) {
-    // thread (tid >> 4, tid & 15) holds partials of columns 4 * (tid & 15) .. + 3: fold the 16 row groups in order
+    // thread (tid / TPR, tid % TPR) holds partials of columns 4 * (tid % TPR) .. + 3: fold the row groups in order
+    constexpr int TPR = GM / 4, GROUPS = 256 / TPR;
     float* s = As;                                  // reuse (all MFMA reads are behind the last barrier)
-    *reinterpret_cast<f32x4*>(s + (tid >> 4) * GM + 4 * (tid & 15)) = csum;
+    *reinterpret_cast<f32x4*>(s + (tid / TPR) * GM + 4 * (tid % TPR)) = csum;
     __syncthreads();
     if (tid < GM && m0 + tid < g.M) {
       float a = 0.0f;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) a += s[w * GM + tid];
+      for (int w = 0; w < GROUPS; ++w) a += s[w * GM + tid];
       g.colsum[(size_t)blockIdx.z * g.M + m0 + tid] = a;
     }
   }
@@ -355,21 +360,34 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
   }
 }
 
-template <bool TA, bool TB, int GATE, int CONV>
-static int launch_gemm_gate(GemmDev g, int splits, hipStream_t s) {
-  const int lds = (int)sizeof(float) * ((TA ? TILE_RMAJ : TILE_KMAJ) + (TB ? TILE_KMAJ : TILE_RMAJ));
+template <bool TA, bool TB, int GATE, int CONV, int WM>
+static int launch_gemm_tile(GemmDev g, int splits, hipStream_t s) {
+  constexpr int GM = 32 * WM, GN = 32 * (4 / WM);
+  const int lds = (int)sizeof(float) * (tile_floats<!TA, GM>() + tile_floats<TB, GN>());
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE, CONV>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE, CONV, WM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { trl_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   g.tiles_n = trl_ceil_div(g.N, GN);
   g.tiles = g.tiles_n * trl_ceil_div(g.M, GM);
-  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE, CONV>), dim3(g.tiles, 1, splits), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE, CONV, WM>), dim3(g.tiles, 1, splits), dim3(256), lds, s, g);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
+}
+
+// waves along M of the C tile: narrow outputs get the 128 x 32 tile, few-row ones the 32 x 128 tile
+static int tile_wm(int M, int N) { return N <= 32 ? 4 : (M <= 32 ? 1 : 2); }
+
+template <bool TA, bool TB, int GATE, int CONV>
+static int launch_gemm_gate(const GemmDev& g, int splits, hipStream_t s) {
+  switch (tile_wm(g.M, g.N)) {
+    case 4:  return launch_gemm_tile<TA, TB, GATE, CONV, 4>(g, splits, s);
+    case 1:  return launch_gemm_tile<TA, TB, GATE, CONV, 1>(g, splits, s);
+    default: return launch_gemm_tile<TA, TB, GATE, CONV, 2>(g, splits, s);
+  }
 }
 
 template <bool TA, bool TB, int CONV = 0>
@@ -383,7 +401,8 @@ static int launch_gemm(const GemmDev& g, int splits, hipStream_t s) {
 // Reduction rows per blockIdx.z of the weight-gradient GEMM: never below 256 (two panels), and long enough that
 // the grid stays near 1024 workgroups when M is huge (conv layers: M = B * Ho * Wo).
 static int bw_split_len(int M, int K, int N) {
-  const int tiles = trl_ceil_div(N, GM) * trl_ceil_div(K, GN);
+  const int wm = tile_wm(N, K);                    // the weight-gradient GEMM is (N x K) with reduction M
+  const int tiles = trl_ceil_div(N, 32 * wm) * trl_ceil_div(K, 32 * (4 / wm));
   const int want = std::max(1, 1024 / tiles);
   const int len = trl_ceil_div(trl_ceil_div(M, want), KC) * KC;
   return std::max(256, len);
@@ -404,7 +423,8 @@ extern "C" int trl_linear_fwd_f32(const float* x, const float* w, const float* b
 // Split-K forward for few-row layers with a long reduction (the conv nets' first FC layer: 512 x 3136 -> 512 is
 // 64 C tiles for 256 CUs): up to 8 reduction slices write partial products, the fold adds bias and activation.
 static int fwd_split_len(int M, int K, int N) {
-  const int tiles = trl_ceil_div(M, GM) * trl_ceil_div(N, GN);
+  const int wm = tile_wm(M, N);
+  const int tiles = trl_ceil_div(M, 32 * wm) * trl_ceil_div(N, 32 * (4 / wm));
   if (tiles >= 192 || K < 8 * KC) return K;
   const int target = std::min(8, trl_ceil_div(384, tiles));
   return trl_ceil_div(trl_ceil_div(K, target), KC) * KC;
