@@ -352,6 +352,15 @@ int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias
                         int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
                         void* stream);
 int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout);
+/* The later conv layers, same idea on fp32 channels-last activations x (B, H, W, C), C % 4 == 0: the reduction
+ * runs in (i, j, c) order so that a window row is one contiguous run of kw*C floats; w is still the nn.Conv2d
+ * weight (Cout, C, kh, kw) as stored and dw comes back in that layout.  y: (B*Ho*Wo, Cout) = NHWC.
+ * Workspace of the weight gradient: trl_conv_bwd_weight_workspace. */
+int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
+                          int kh, int kw, int sh, int sw, int Cout, int act, void* stream);
+int trl_conv_bwd_weight_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* x, float* dw,
+                                 float* db, float* workspace, int B, int C, int H, int W, int kh, int kw, int sh,
+                                 int sw, int Cout, void* stream);
 int trl_conv_bwd_weight_u8_f32(const float* dy, const float* y_gate, int gate_act, const uint8_t* frames,
                                float* dw, float* db, float* workspace, int B, int C, int H, int W, int kh,
                                int kw, int sh, int sw, float scale, float shift, int Cout, void* stream);

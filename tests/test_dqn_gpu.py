@@ -75,12 +75,48 @@ def test_implicit_gemm_first_conv_layer_vs_torch(B, C, H, W, kh, kw, sh, sw, Cou
     assert (db.cpu() - b.grad).abs().max().item() < 5e-5 * scale(b.grad)
 
 
+@pytest.mark.parametrize("B,C,H,W,kh,kw,sh,sw,Cout", [
+    (6, 16, 20, 20, 4, 4, 2, 2, 32),       # second Atari layer
+    (6, 32, 9, 9, 3, 3, 1, 1, 64),         # third Atari layer: K = 288 (2.25 panels)
+    (3, 8, 11, 13, 3, 2, 2, 3, 5),         # K = 48, ragged everything, Cout < tile
+    (130, 4, 6, 6, 3, 3, 1, 1, 70),        # M = 2080: reduction splits in the weight gradient; two N tiles
+    (2, 12, 5, 4, 5, 4, 1, 1, 7),          # Ho = Wo = 1
+])
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+def test_implicit_gemm_channels_last_conv_vs_torch(B, C, H, W, kh, kw, sh, sw, Cout, act):
+    """trl_conv_fwd_nhwc_f32 / trl_conv_bwd_weight_nhwc_f32: reduction in (i, j, c) order over (B, H, W, C)
+    activations, nn.Conv2d weight layout in and out, against torch's conv2d + autograd."""
+    from torchrl_amd import _C
+    gen = torch.Generator().manual_seed(B * 100 + Cout)
+    x = torch.randn(B, C, H, W, generator=gen)
+    w = (torch.randn(Cout, C, kh, kw, generator=gen) / (C * kh * kw) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, generator=gen).requires_grad_(True)
+    f = {"relu": torch.relu, "tanh": torch.tanh}[act]
+    code = {"relu": _C.ACT_RELU, "tanh": _C.ACT_TANH}[act]
+    want = f(F.conv2d(x, w, b, stride=(sh, sw)))
+    dy = torch.randn(want.shape, generator=gen)
+    want.backward(dy)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd, bd = w.detach().to(DEV), b.detach().to(DEV)
+    y, (Bo, Ho, Wo) = _C.conv_fwd_nhwc(x_nhwc, wd.view(Cout, -1), bd, kh, kw, sh, sw, code)
+    got = y.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2).cpu()
+    assert (got - want.detach()).abs().max().item() < 2e-5
+    dy_rows = dy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(DEV)
+    dw, db = torch.empty_like(wd.view(Cout, -1)), torch.empty_like(bd)
+    _C.conv_bwd_weight_nhwc(dy_rows, y, code, x_nhwc, kh, kw, sh, sw, dw, db)
+    scale = lambda t: max(1.0, t.abs().max().item())
+    assert (dw.cpu().view_as(w) - w.grad).abs().max().item() < 5e-5 * scale(w.grad)
+    assert (db.cpu() - b.grad).abs().max().item() < 5e-5 * scale(b.grad)
+
+
 def test_implicit_gemm_rejects_unaligned_geometry():
     from torchrl_amd import _C
     frames = torch.zeros(2, 4, 21, 21, dtype=torch.uint8, device=DEV)
     assert not _C.conv_u8_implicit_ok(frames, 3, 3, 2, 2)
     with pytest.raises(_C.TrlError, match="multiples of 4"):
         _C.conv_fwd_u8(frames, torch.zeros(8, 36, device=DEV), None, 3, 3, 2, 2, 1.0, 0.0, _C.ACT_RELU)
+    with pytest.raises(_C.TrlError, match="C % 4"):
+        _C.conv_fwd_nhwc(torch.zeros(2, 8, 8, 6, device=DEV), torch.zeros(8, 54, device=DEV), None, 3, 3, 1, 1, _C.ACT_RELU)
 
 
 def test_im2col_col2im_transpose_vs_torch():

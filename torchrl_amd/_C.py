@@ -130,6 +130,9 @@ SIGNATURES = {
     "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_conv_fwd_u8_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "trl_conv_bwd_weight_workspace": (C.c_int, [C.c_int] * 9),
+    "trl_conv_fwd_nhwc_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
+    "trl_conv_bwd_weight_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 9
+                                     + [C.c_void_p]),
     "trl_conv_bwd_weight_u8_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 8
                                    + [C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "trl_dqn_td_loss_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -495,6 +498,35 @@ def conv_bwd_weight_u8(dy, y_gate, gate_act, frames, kh, kw, sh, sw, scale, shif
                                            dev_ptr(db, name="db", allow_none=True), dev_ptr(workspace, name="workspace"),
                                            B, Cc, H, W, kh, kw, sh, sw, float(scale), float(shift), Cout,
                                            stream_ptr(dy.device)), "trl_conv_bwd_weight_u8_f32")
+    return dw, db
+
+
+def conv_fwd_nhwc(x, w, bias, kh, kw, sh, sw, act):
+    """act(conv2d(x) + bias) on (B, H, W, C) fp32 channels-last activations, C % 4 == 0; w (Cout, C*kh*kw) is the
+    nn.Conv2d weight as stored.  Returns ((B*Ho*Wo, Cout), (B, Ho, Wo))."""
+    B, H, W, Cc = (int(v) for v in x.shape)
+    Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
+    Cout = int(w.shape[0])
+    y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
+    check(lib().trl_conv_fwd_nhwc_f32(dev_ptr(x, name="x"), dev_ptr(w, name="w"), dev_ptr(bias, name="bias", allow_none=True),
+                                      dev_ptr(y, name="y"), B, Cc, H, W, kh, kw, sh, sw, Cout, act, stream_ptr(x.device)),
+          "trl_conv_fwd_nhwc_f32")
+    return y, (B, Ho, Wo)
+
+
+def conv_bwd_weight_nhwc(dy, y_gate, gate_act, x, kh, kw, sh, sw, dw, db, workspace=None):
+    B, H, W, Cc = (int(v) for v in x.shape)
+    Cout = int(dy.shape[1])
+    need = lib().trl_conv_bwd_weight_workspace(B, Cc, H, W, kh, kw, sh, sw, Cout)
+    if need < 0:
+        raise TrlError("conv_bwd_weight_nhwc: bad geometry")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.float32, device=dy.device)
+    check(lib().trl_conv_bwd_weight_nhwc_f32(dev_ptr(dy, name="dy"), dev_ptr(y_gate, name="y_gate", allow_none=True), gate_act,
+                                             dev_ptr(x, name="x"), dev_ptr(dw, name="dw"),
+                                             dev_ptr(db, name="db", allow_none=True), dev_ptr(workspace, name="workspace"),
+                                             B, Cc, H, W, kh, kw, sh, sw, Cout, stream_ptr(dy.device)),
+          "trl_conv_bwd_weight_nhwc_f32")
     return dw, db
 
 

@@ -110,7 +110,7 @@ class _FusedDQN:
         else:
             dq = _C.quantile_huber(q, acts, qn, rew, term, algo.discount, A, Q, self.sums)
             denom = float(B) * Q * Q
-        need = max(_C.lib().trl_linear_bwd_weight_workspace(int(c[1].shape[0]), int(c[2].shape[1]), int(c[2].shape[0]))
+        need = max(_C.lib().trl_linear_bwd_weight_workspace(int(c[2].shape[0]), int(c[3].shape[1]), int(c[3].shape[0]))
                    for c in tape.convs)                                  # (rows of y, C*kh*kw, Cout) per conv layer
         need = max(need, max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
                              for w, _ in ops.fc_layers(algo.qf)))

@@ -37,8 +37,13 @@ __device__ __forceinline__ float dact_from_out(int act, float y) {
 //     cols[m][k] = frames[b][c][oy * sh + i][ox * sw + j] * scale + shift          (ScaledFloatFrame on the fly)
 // With kw, sw and W multiples of 4 the 4 consecutive k of a slot are 4 consecutive, 4-byte aligned bytes: one
 // dword load per slot, converted when the panel is written to LDS.  The 210 MB im2col buffer of cfg 5 never exists.
+// The later conv layers read fp32 channels-last activations (B, H, W, C): with the reduction index ordered
+// k' = (i, j, c) a window row is ONE contiguous run of kw * C floats, so a slot is one 16-byte load (C % 4 == 0);
+// the nn.Conv2d weight stays in its (Cout, C, kh, kw) layout and is gathered with the matching permutation
+// (it is a few thousand floats), and the weight gradient is un-permuted by the fold.
 struct ConvSrc {
-  const uint8_t* frames;
+  const uint8_t* frames;      // uint8 NCHW source (CONV 1 / 2)
+  const float* x;             // fp32 NHWC source (CONV 3 / 4)
   int C, H, W, kh, kw, sh, sw, Ho, Wo;
   float scale, shift;
   uint32_t hw_magic, hw_shift, w_magic, w_shift;    // division by Ho * Wo and by Wo (multiply-high form)
@@ -61,6 +66,18 @@ __device__ __forceinline__ uint32_t conv_tap_offset(const ConvSrc& cv, uint32_t 
   const uint32_t khw = (uint32_t)(cv.kh * cv.kw);
   const uint32_t c = k / khw, rem = k - c * khw, i = rem / (uint32_t)cv.kw, j = rem - i * cv.kw;
   return (c * cv.H + i) * cv.W + j;
+}
+// fp32 NHWC: float offset of window (b, oy, ox), and of reduction index k' = (i, j, c) inside the window
+__device__ __forceinline__ uint32_t nhwc_row_offset(const ConvSrc& cv, uint32_t m) {
+  const uint32_t hw = (uint32_t)(cv.Ho * cv.Wo);
+  const uint32_t b = fastdiv(m, hw, cv.hw_magic, cv.hw_shift), p = m - b * hw;
+  const uint32_t oy = fastdiv(p, (uint32_t)cv.Wo, cv.w_magic, cv.w_shift), ox = p - oy * cv.Wo;
+  return ((b * cv.H + oy * cv.sh) * cv.W + ox * cv.sw) * cv.C;
+}
+__device__ __forceinline__ uint32_t nhwc_tap_offset(const ConvSrc& cv, uint32_t k) {
+  const uint32_t run = (uint32_t)(cv.kw * cv.C);
+  const uint32_t i = k / run;
+  return i * (uint32_t)(cv.W * cv.C) + (k - i * run);
 }
 __device__ __forceinline__ f32x4 conv_unpack(uint32_t u, float scale, float shift) {
   f32x4 v = {fmaf((float)(u & 0xffu), scale, shift), fmaf((float)((u >> 8) & 0xffu), scale, shift),
@@ -159,13 +176,16 @@ __host__ __device__ constexpr int tile_floats() { return CONTIG_K ? ROWS * LDK :
 
 // TA: A is stored [Kred][M] (we need A^T); TB: B is stored [N][K] (we need B^T).
 // GATE: activation whose derivative (through a_gate) multiplies operand A (TRL_ACT_NONE: no gate).
-// CONV: 0 both operands dense; 1 operand A (M x K, forward) is the implicit cols matrix of g.cv; 2 operand B
-// (Kred x N, weight gradient) is.
+// CONV: 0 both operands dense; 1 operand A (M x K, forward) is the implicit cols matrix of g.cv over uint8 NCHW
+// frames; 2 operand B (Kred x N, weight gradient) is; 3 / 4 the same over fp32 NHWC activations with the
+// reduction (3) or column (4) index in (i, j, c) order -- then B of 3 is the permuted view of the conv weight.
 // WM: waves along M.  The 4 waves (one 32x32 quadrant each) form a 64 x 64 C tile (WM = 2), a 128 x 32 one
 // (WM = 4, layers with <= 32 outputs: a 64-wide tile would compute 50-75 % padding) or a 32 x 128 one (WM = 1).
 template <bool TA, bool TB, int GATE, int CONV, int WM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
-  static_assert(CONV == 0 || (CONV == 1 && !TA && TB) || (CONV == 2 && TA && !TB), "implicit operand orientation");
+  static_assert(CONV == 0 || ((CONV == 1 || CONV == 3) && !TA && TB) || ((CONV == 2 || CONV == 4) && TA && !TB),
+                "implicit operand orientation");
+  constexpr bool CA = CONV == 1 || CONV == 3, CB = CONV == 2 || CONV == 4, U8 = CONV == 1 || CONV == 2;
   constexpr int WN = 4 / WM, GM = 32 * WM, GN = 32 * WN, SA = GM / 8, SB = GN / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;
@@ -196,35 +216,41 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   f32x4 csum = {0.0f, 0.0f, 0.0f, 0.0f};          // TA: partial column sums of columns 4 * (tid % (GM / 4)) .. + 3
   f32x4 ra[SA], rg[SA], rb[SB];
-  // implicit operand: one dword (4 bytes = 4 reduction / column indices) per slot + validity bits
-  constexpr int SC = CONV == 1 ? SA : SB;
+  // implicit operand: one dword (uint8: 4 bytes = 4 reduction / column indices) or one 16-byte load (fp32 NHWC)
+  // per slot + validity bits
+  constexpr int SC = CA ? SA : SB;
   uint32_t cu[SC], cmask = 0u, cbase[SC], ctap = 0u;
   bool ctap_ok = false;
-  if (CONV == 1) {                                 // A rows are fixed for the whole kernel: decode them once
+  if (CA) {                                        // A rows are fixed for the whole kernel: decode them once
 #pragma unroll
     for (int t = 0; t < SC; ++t) {
       const int m = m0 + 8 * t + (tid >> 5);
-      cbase[t] = m < g.M ? conv_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
+      cbase[t] = m < g.M ? (U8 ? conv_row_offset(g.cv, (uint32_t)m) : nhwc_row_offset(g.cv, (uint32_t)m)) : 0xffffffffu;
     }
   }
-  if (CONV == 2) {                                 // B columns (the taps) are fixed for the whole kernel
+  if (CB) {                                        // B columns (the taps) are fixed for the whole kernel
     const int kc = n0 + 4 * (tid % (GN / 4));
     ctap_ok = kc < g.N;
-    ctap = ctap_ok ? conv_tap_offset(g.cv, (uint32_t)kc) : 0u;
+    ctap = ctap_ok ? (U8 ? conv_tap_offset(g.cv, (uint32_t)kc) : nhwc_tap_offset(g.cv, (uint32_t)kc)) : 0u;
   }
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
   auto fetch = [&](int k0) {
     const bool k_whole = k0 + KC <= k_hi;          // uniform: one branch per operand per panel
-    if (CONV == 1) {
+    if (CA) {
       const int kk = k0 + 4 * (tid & 31);
       const bool kin = kk < k_hi;
-      const uint32_t tap = kin ? conv_tap_offset(g.cv, (uint32_t)kk) : 0u;
+      const uint32_t tap = kin ? (U8 ? conv_tap_offset(g.cv, (uint32_t)kk) : nhwc_tap_offset(g.cv, (uint32_t)kk)) : 0u;
       cmask = 0u;
 #pragma unroll
       for (int t = 0; t < SC; ++t) {
         const bool ok = kin && cbase[t] != 0xffffffffu;
-        cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? cbase[t] + tap : 0u)) : 0u;
-        cmask |= ok ? (1u << t) : 0u;
+        if (U8) {
+          cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? cbase[t] + tap : 0u)) : 0u;
+          cmask |= ok ? (1u << t) : 0u;
+        } else {
+          ra[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? cbase[t] + tap : 0u)) : zero4;
+        }
       }
     } else if (a_whole && k_whole) {
       panel_fetch_fast<!TA, GM>(g.A, g.lda, m0, k0, tid, ra);
@@ -233,25 +259,43 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
       panel_fetch_edge<!TA, GM>(g.A, g.lda, m0, g.M, k0, k_hi, tid, ra);
       if (GATE != TRL_ACT_NONE) panel_fetch_edge<!TA, GM>(g.a_gate, g.lda, m0, g.M, k0, k_hi, tid, rg);
     }
-    if (CONV == 2) {
+    if (CB) {
       cmask = 0u;
 #pragma unroll
       for (int t = 0; t < SC; ++t) {
         const int m = k0 + (256 / (GN / 4)) * t + tid / (GN / 4);
         const bool ok = ctap_ok && m < k_hi;
-        cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? conv_row_offset(g.cv, (uint32_t)m) + ctap : 0u)) : 0u;
-        cmask |= ok ? (1u << t) : 0u;
+        if (U8) {
+          cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? conv_row_offset(g.cv, (uint32_t)m) + ctap : 0u)) : 0u;
+          cmask |= ok ? (1u << t) : 0u;
+        } else {
+          rb[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? nhwc_row_offset(g.cv, (uint32_t)m) + ctap : 0u)) : zero4;
+        }
+      }
+    } else if (CONV == 3) {
+      // B = conv weight (Cout, C, kh, kw) read in the reduction order k' = (i, j, c): 4 consecutive k' are 4
+      // consecutive channels of one tap, kh * kw floats apart
+      const int kk = k0 + 4 * (tid & 31);
+      const uint32_t khw = (uint32_t)(g.cv.kh * g.cv.kw);
+      const uint32_t ij = (uint32_t)kk / (uint32_t)g.cv.C, c = (uint32_t)kk - ij * g.cv.C;
+      const uint32_t w0 = c * khw + ij;
+#pragma unroll
+      for (int t = 0; t < SB; ++t) {
+        const int n = n0 + 8 * t + (tid >> 5);
+        const bool ok = kk < k_hi && n < g.N;
+        const float* wp = g.B + (ok ? (size_t)n * g.ldb + w0 : 0);
+        f32x4 v = {ok ? wp[0] : 0.0f, ok ? wp[khw] : 0.0f, ok ? wp[2 * khw] : 0.0f, ok ? wp[3 * khw] : 0.0f};
+        rb[t] = v;
       }
     } else if (b_whole && k_whole) panel_fetch_fast<TB, GN>(g.B, g.ldb, n0, k0, tid, rb);
     else                           panel_fetch_edge<TB, GN>(g.B, g.ldb, n0, g.N, k0, k_hi, tid, rb);
   };
   auto stash = [&]() {
-    if (CONV != 0) {
-      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (U8) {
 #pragma unroll
       for (int t = 0; t < SC; ++t) {
-        const f32x4 v = (cmask >> t) & 1u ? conv_unpack(cu[t], g.cv.scale, g.cv.shift) : zero;
-        if (CONV == 1) ra[t] = v; else rb[t] = v;
+        const f32x4 v = (cmask >> t) & 1u ? conv_unpack(cu[t], g.cv.scale, g.cv.shift) : zero4;
+        if (CA) ra[t] = v; else rb[t] = v;
       }
     }
     if (GATE != TRL_ACT_NONE) {
@@ -337,7 +381,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
                                                             const float* __restrict__ part2, float* __restrict__ out2,
                                                             int n2, int splits, const float* __restrict__ bias, int n_cols,
-                                                            int act) {
+                                                            int act, int perm_c, int perm_khw) {
   __shared__ float sl[4][FOLD_OUT];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   int e = blockIdx.x * FOLD_OUT + lane;
@@ -356,7 +400,12 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
       if (act == TRL_ACT_TANH) v = trl_tanh(v);
       else if (act == TRL_ACT_RELU) v = fmaxf(v, 0.0f);
     }
-    (second ? out2 : out)[ee] = v;
+    int eo = ee;
+    if (!second && perm_c > 0) {                   // weight gradient computed in (i, j, c) column order: store as (c, i, j)
+      const int K = perm_c * perm_khw, row = ee / K, kp = ee - row * K, ij = kp / perm_c, c = kp - ij * perm_c;
+      eo = row * K + c * perm_khw + ij;
+    }
+    (second ? out2 : out)[eo] = v;
   }
 }
 
@@ -449,7 +498,7 @@ extern "C" int trl_linear_fwd_splitk_f32(const float* x, const float* w, const f
   int rc = launch_gemm<false, true>(g, splits, (hipStream_t)stream);
   if (rc) return rc;
   hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)M * N, FOLD_OUT)), dim3(256), 0, (hipStream_t)stream,
-                     workspace, y, M * N, (const float*)nullptr, (float*)nullptr, 0, splits, bias, N, act);
+                     workspace, y, M * N, (const float*)nullptr, (float*)nullptr, 0, splits, bias, N, act, 0, 0);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -485,7 +534,8 @@ static int bwd_weight_impl(const float* dy, const float* y_gate, int gate_act, c
   if (rc) return rc;
   const int n2 = db ? N : 0;
   hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)N * K + n2, FOLD_OUT)), dim3(256), 0, s, workspace, dw,
-                     N * K, g.colsum, db, n2, splits, (const float*)nullptr, 0, TRL_ACT_NONE);
+                     N * K, g.colsum, db, n2, splits, (const float*)nullptr, 0, TRL_ACT_NONE, CONV == 4 ? cv->C : 0,
+                     CONV == 4 ? cv->kh * cv->kw : 0);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -522,7 +572,7 @@ static int fill_conv(const char* who, const uint8_t* frames, int B, int C, int H
     return TRL_EINVAL;
   }
   if ((int64_t)B * C * H * W >= ((int64_t)1 << 32) - 1) { trl_set_error("%s: frame batch exceeds 4 GiB", who); return TRL_EINVAL; }
-  cv.frames = frames; cv.C = C; cv.H = H; cv.W = W; cv.kh = kh; cv.kw = kw; cv.sh = sh; cv.sw = sw;
+  cv.frames = frames; cv.x = nullptr; cv.C = C; cv.H = H; cv.W = W; cv.kh = kh; cv.kw = kw; cv.sh = sh; cv.sw = sw;
   cv.Ho = (H - kh) / sh + 1; cv.Wo = (W - kw) / sw + 1; cv.scale = scale; cv.shift = shift;
   fastdiv_gen((uint32_t)(cv.Ho * cv.Wo), cv.hw_magic, cv.hw_shift);
   fastdiv_gen((uint32_t)cv.Wo, cv.w_magic, cv.w_shift);
@@ -544,6 +594,51 @@ extern "C" int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const 
   g.A = nullptr; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
   g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
   return launch_gemm<false, true, 1>(g, 1, (hipStream_t)stream);
+}
+
+static int fill_conv_nhwc(const char* who, const float* x, int B, int C, int H, int W, int kh, int kw, int sh, int sw,
+                          ConvSrc& cv, int& M, int& K) {
+  if (!(B > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && H >= kh && W >= kw)) {
+    trl_set_error("%s: bad geometry", who); return TRL_EINVAL;
+  }
+  if ((C & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) {
+    trl_set_error("%s: the implicit-GEMM path needs C %% 4 == 0 and 16-byte aligned activations "
+                  "(use trl_im2col_f32 + trl_linear_* otherwise)", who);
+    return TRL_EINVAL;
+  }
+  if ((int64_t)B * C * H * W >= ((int64_t)1 << 32) - 1) { trl_set_error("%s: activation tensor too large", who); return TRL_EINVAL; }
+  cv.x = x; cv.frames = nullptr; cv.C = C; cv.H = H; cv.W = W; cv.kh = kh; cv.kw = kw; cv.sh = sh; cv.sw = sw;
+  cv.Ho = (H - kh) / sh + 1; cv.Wo = (W - kw) / sw + 1; cv.scale = 1.0f; cv.shift = 0.0f;
+  fastdiv_gen((uint32_t)(cv.Ho * cv.Wo), cv.hw_magic, cv.hw_shift);
+  fastdiv_gen((uint32_t)cv.Wo, cv.w_magic, cv.w_shift);
+  const int64_t m = (int64_t)B * cv.Ho * cv.Wo;
+  if (m >= ((int64_t)1 << 31)) { trl_set_error("%s: too many output positions", who); return TRL_EINVAL; }
+  M = (int)m; K = C * kh * kw;
+  return TRL_OK;
+}
+
+extern "C" int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
+                                     int kh, int kw, int sh, int sw, int Cout, int act, void* stream) {
+  TRL_REQUIRE(x && w && y && Cout > 0, "null pointer / bad Cout");
+  TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
+  GemmDev g{};
+  int M, K;
+  int rc = fill_conv_nhwc("conv_fwd_nhwc", x, B, C, H, W, kh, kw, sh, sw, g.cv, M, K);
+  if (rc) return rc;
+  g.A = nullptr; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
+  g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
+  return launch_gemm<false, true, 3>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int trl_conv_bwd_weight_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* x, float* dw,
+                                            float* db, float* workspace, int B, int C, int H, int W, int kh, int kw, int sh,
+                                            int sw, int Cout, void* stream) {
+  TRL_REQUIRE(dy && x && dw && workspace && Cout > 0, "null pointer / bad Cout");
+  ConvSrc cv{};
+  int M, K;
+  int rc = fill_conv_nhwc("conv_bwd_weight_nhwc", x, B, C, H, W, kh, kw, sh, sw, cv, M, K);
+  if (rc) return rc;
+  return bwd_weight_impl<4>(dy, y_gate, gate_act, nullptr, &cv, dw, db, workspace, M, K, Cout, (hipStream_t)stream);
 }
 
 extern "C" int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout) {

@@ -119,7 +119,15 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
             # implicit GEMM straight from the uint8 frames: the im2col matrix (210 MB at cfg 5) never exists
             wmat = m.weight.view(m.weight.shape[0], -1)
             y, (B, Ho, Wo) = _C.conv_fwd_u8(x, wmat, m.bias, kh, kw, sh, sw, scale, shift, act)
-            t.convs.append((None, y, wmat, (x, scale, shift), (kh, kw, sh, sw)))
+            t.convs.append(("u8", (x, scale, shift), y, wmat, None, (kh, kw, sh, sw)))
+            x = y.view(B, Ho, Wo, int(wmat.shape[0]))
+            continue
+        if k > 0 and int(x.shape[3]) % 4 == 0:
+            # implicit GEMM on the channels-last activations (reduction in (i, j, c) order: contiguous window rows)
+            wmat = m.weight.view(m.weight.shape[0], -1)
+            in_shape = tuple(int(v) for v in x.shape)
+            y, (B, Ho, Wo) = _C.conv_fwd_nhwc(x, wmat, m.bias, kh, kw, sh, sw, act)
+            t.convs.append(("nhwc", x, y, wmat, in_shape, (kh, kw, sh, sw)))
             x = y.view(B, Ho, Wo, int(wmat.shape[0]))
             continue
         if k == 0:
@@ -130,7 +138,7 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
             cols, (B, Ho, Wo) = _C.im2col(x, kh, kw, sh, sw)
         wmat = m.weight.view(m.weight.shape[0], -1)
         y = _C.linear_fwd(cols, wmat, m.bias, act)                           # (B*Ho*Wo, Cout) == NHWC
-        t.convs.append((cols, y, wmat, in_shape, (kh, kw, sh, sw)))
+        t.convs.append(("im2col", cols, y, wmat, in_shape, (kh, kw, sh, sw)))
         x = y.view(B, Ho, Wo, int(wmat.shape[0]))
     B, Ho, Wo, Cc = (int(v) for v in x.shape)
     t.feat_shape = (Ho * Wo, Cc)
@@ -146,14 +154,16 @@ def cnn_backward(net, tape, d_out, grads, workspace=None):
     P, Cc = tape.feat_shape
     d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P).view(tape.B * P, Cc)   # back to (B, P, C)
     for k in range(n_conv - 1, -1, -1):
-        cols, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]
+        kind, src, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]      # src: cols matrix / input activations / frames
         gw, gb = grads[k]
-        if cols is None:                                                     # first layer, implicit GEMM on the frames
-            frames, scale, shift = in_shape
+        if kind == "nhwc":                                                   # implicit GEMM on channels-last activations
+            _C.conv_bwd_weight_nhwc(d, y, tape.act, src, kh, kw, sh, sw, gw.view(wmat.shape), gb, workspace=workspace)
+        elif kind == "u8":                                                   # first layer, implicit GEMM on the frames
+            frames, scale, shift = src
             _C.conv_bwd_weight_u8(d, y, tape.act, frames, kh, kw, sh, sw, scale, shift, gw.view(wmat.shape), gb,
                                   workspace=workspace)
-            continue
-        _C.linear_bwd_weight(d, y, tape.act, cols, dw=gw.view(wmat.shape), db=gb, workspace=workspace)
+        else:
+            _C.linear_bwd_weight(d, y, tape.act, src, dw=gw.view(wmat.shape), db=gb, workspace=workspace)
         if k > 0:
             dcols = _C.linear_bwd_input(d, y, tape.act, wmat)
             B, H, W, Cin = in_shape
