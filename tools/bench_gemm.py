@@ -74,7 +74,34 @@ def clk(M=4096, K=256, N=256):
                 32 * wg, rt[0], " ".join("%d" % c for c in cyc[1:]), " ".join("%.2f" % t for t in (rt[1:] - rt[0])), mhz))
 
 
+def clk_conv():
+    """TRL_LIB=<clk build>: phase stamps of the implicit first conv layer at cfg 5 (512 x 4 x 84 x 84 uint8, 8x8 s4 -> 16)."""
+    import ctypes as C
+    import numpy as np
+    dev = torch.device("cuda:0")
+    frames = torch.randint(0, 256, (512, 4, 84, 84), dtype=torch.uint8, device=dev)
+    w = torch.randn(16, 256, device=dev) * 0.05; b = torch.randn(16, device=dev)
+    y, _ = _C.conv_fwd_u8(frames, w, b, 8, 8, 4, 4, 1 / 255.0, -0.5, 1)
+    dy = torch.randn_like(y); dw = torch.empty_like(w); db = torch.empty_like(b)
+    names = ["start", "fetch0 issued", "panel0 in LDS", "mfma0 done", "panel1 in LDS", "mfma1 done", "epilogue done"]
+    for tag, fn in (("conv1 fwd", lambda: _C.conv_fwd_u8(frames, w, b, 8, 8, 4, 4, 1 / 255.0, -0.5, 1)),
+                    ("conv1 bwd_w", lambda: _C.conv_bwd_weight_u8(dy, y, 1, frames, 8, 8, 4, 4, 1 / 255.0, -0.5, dw, db))):
+        t_us = timed(fn, 50)
+        torch.cuda.synchronize()
+        buf = np.zeros(128, dtype=np.int64)
+        _C.lib().trl_dbg_gemm_clk.argtypes = [C.c_void_p]
+        _C.lib().trl_dbg_gemm_clk(buf.ctypes.data)
+        buf = buf.reshape(8, 8, 2)
+        print("%s: %.1f us per call" % (tag, t_us))
+        for wg in (0, 3):
+            cyc = buf[wg, :7, 0] - buf[wg, 0, 0]
+            print("  wg %3d: cycles %s" % (32 * wg, " ".join("%d" % c for c in cyc[1:])))
+
+
 if __name__ == "__main__":
+    if "--clk-conv" in sys.argv:
+        clk_conv()
+        sys.exit(0)
     if "--clk" in sys.argv:
         clk()
         sys.exit(0)

@@ -216,41 +216,61 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   f32x4 csum = {0.0f, 0.0f, 0.0f, 0.0f};          // TA: partial column sums of columns 4 * (tid % (GM / 4)) .. + 3
   f32x4 ra[SA], rg[SA], rb[SB];
-  // implicit operand: one dword (uint8: 4 bytes = 4 reduction / column indices) or one 16-byte load (fp32 NHWC)
-  // per slot + validity bits
+  // Implicit operand.  fp32 NHWC: one 16-byte load per slot, same slot map as a dense panel (consecutive lanes read
+  // consecutive pieces of a window row).  uint8 NCHW: one dword per slot with LANES ALONG THE OUTPUT POSITIONS --
+  // neighbouring windows are sw bytes apart, so a wave's load is (nearly) contiguous, where the dense slot map
+  // would gather 64 scattered 4-byte pieces; thread = one operand row, its slots walk the other dimension.
   constexpr int SC = CA ? SA : SB;
   uint32_t cu[SC], cmask = 0u, cbase[SC], ctap = 0u;
   bool ctap_ok = false;
-  if (CA) {                                        // A rows are fixed for the whole kernel: decode them once
+  uint32_t* tap_tab = reinterpret_cast<uint32_t*>(Bs + tile_floats<TB, GN>());   // CONV == 1: tap offset of every k / 4
+  constexpr int GA = 256 / GM;                     // CONV == 1: thread = row tid % GM, slots k4 = tid / GM + GA * t
+  if (CONV == 1) {
+    const int m = m0 + tid % GM;
+    cbase[0] = m < g.M ? conv_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
+    for (int e = tid; 4 * e < g.K; e += 256) tap_tab[e] = conv_tap_offset(g.cv, (uint32_t)(4 * e));
+    __syncthreads();
+  }
+  if (CONV == 2) {                                 // thread = reduction row tid % KC, column slots c4 = tid / KC + 2 * t
+#pragma unroll
+    for (int t = 0; t < SC; ++t) {
+      const int kc = n0 + 4 * (tid / KC + 2 * t);
+      cbase[t] = kc < g.N ? conv_tap_offset(g.cv, (uint32_t)kc) : 0xffffffffu;   // here: the (fixed) tap offsets
+    }
+  }
+  if (CONV == 3) {                                 // A rows are fixed for the whole kernel: decode them once
 #pragma unroll
     for (int t = 0; t < SC; ++t) {
       const int m = m0 + 8 * t + (tid >> 5);
-      cbase[t] = m < g.M ? (U8 ? conv_row_offset(g.cv, (uint32_t)m) : nhwc_row_offset(g.cv, (uint32_t)m)) : 0xffffffffu;
+      cbase[t] = m < g.M ? nhwc_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
     }
   }
-  if (CB) {                                        // B columns (the taps) are fixed for the whole kernel
+  if (CONV == 4) {                                 // B columns (the taps) are fixed for the whole kernel
     const int kc = n0 + 4 * (tid % (GN / 4));
     ctap_ok = kc < g.N;
-    ctap = ctap_ok ? (U8 ? conv_tap_offset(g.cv, (uint32_t)kc) : nhwc_tap_offset(g.cv, (uint32_t)kc)) : 0u;
+    ctap = ctap_ok ? nhwc_tap_offset(g.cv, (uint32_t)kc) : 0u;
   }
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
   auto fetch = [&](int k0) {
     const bool k_whole = k0 + KC <= k_hi;          // uniform: one branch per operand per panel
-    if (CA) {
-      const int kk = k0 + 4 * (tid & 31);
-      const bool kin = kk < k_hi;
-      const uint32_t tap = kin ? (U8 ? conv_tap_offset(g.cv, (uint32_t)kk) : nhwc_tap_offset(g.cv, (uint32_t)kk)) : 0u;
+    if (CONV == 1) {
       cmask = 0u;
 #pragma unroll
       for (int t = 0; t < SC; ++t) {
+        const int k4 = tid / GM + GA * t;
+        const bool ok = k0 + 4 * k4 < k_hi && cbase[0] != 0xffffffffu;
+        cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? cbase[0] + tap_tab[(k0 >> 2) + k4] : 0u)) : 0u;
+        cmask |= ok ? (1u << t) : 0u;
+      }
+    } else if (CONV == 3) {
+      const int kk = k0 + 4 * (tid & 31);
+      const bool kin = kk < k_hi;
+      const uint32_t tap = kin ? nhwc_tap_offset(g.cv, (uint32_t)kk) : 0u;
+#pragma unroll
+      for (int t = 0; t < SC; ++t) {
         const bool ok = kin && cbase[t] != 0xffffffffu;
-        if (U8) {
-          cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? cbase[t] + tap : 0u)) : 0u;
-          cmask |= ok ? (1u << t) : 0u;
-        } else {
-          ra[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? cbase[t] + tap : 0u)) : zero4;
-        }
+        ra[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? cbase[t] + tap : 0u)) : zero4;
       }
     } else if (a_whole && k_whole) {
       panel_fetch_fast<!TA, GM>(g.A, g.lda, m0, k0, tid, ra);
@@ -259,18 +279,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
       panel_fetch_edge<!TA, GM>(g.A, g.lda, m0, g.M, k0, k_hi, tid, ra);
       if (GATE != TRL_ACT_NONE) panel_fetch_edge<!TA, GM>(g.a_gate, g.lda, m0, g.M, k0, k_hi, tid, rg);
     }
-    if (CB) {
+    if (CONV == 2) {
+      const int m = k0 + tid % KC;
+      const bool row_ok = m < k_hi;
+      const uint32_t row = row_ok ? conv_row_offset(g.cv, (uint32_t)m) : 0u;
       cmask = 0u;
+#pragma unroll
+      for (int t = 0; t < SC; ++t) {
+        const bool ok = row_ok && cbase[t] != 0xffffffffu;
+        cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? row + cbase[t] : 0u)) : 0u;
+        cmask |= ok ? (1u << t) : 0u;
+      }
+    } else if (CONV == 4) {
 #pragma unroll
       for (int t = 0; t < SC; ++t) {
         const int m = k0 + (256 / (GN / 4)) * t + tid / (GN / 4);
         const bool ok = ctap_ok && m < k_hi;
-        if (U8) {
-          cu[t] = ok ? *reinterpret_cast<const uint32_t*>(g.cv.frames + (ok ? conv_row_offset(g.cv, (uint32_t)m) + ctap : 0u)) : 0u;
-          cmask |= ok ? (1u << t) : 0u;
-        } else {
-          rb[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? nhwc_row_offset(g.cv, (uint32_t)m) + ctap : 0u)) : zero4;
-        }
+        rb[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? nhwc_row_offset(g.cv, (uint32_t)m) + ctap : 0u)) : zero4;
       }
     } else if (CONV == 3) {
       // B = conv weight (Cout, C, kh, kw) read in the reduction order k' = (i, j, c): 4 consecutive k' are 4
@@ -291,11 +316,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
     else                           panel_fetch_edge<TB, GN>(g.B, g.ldb, n0, g.N, k0, k_hi, tid, rb);
   };
   auto stash = [&]() {
-    if (U8) {
+    if (CONV == 1) {                               // uint8 slots go straight to their (row, k4) place
 #pragma unroll
       for (int t = 0; t < SC; ++t) {
         const f32x4 v = (cmask >> t) & 1u ? conv_unpack(cu[t], g.cv.scale, g.cv.shift) : zero4;
-        if (CA) ra[t] = v; else rb[t] = v;
+        *reinterpret_cast<f32x4*>(As + (tid % GM) * LDK + 4 * (tid / GM + GA * t)) = v;
+      }
+    }
+    if (CONV == 2) {
+#pragma unroll
+      for (int t = 0; t < SC; ++t) {
+        const f32x4 v = (cmask >> t) & 1u ? conv_unpack(cu[t], g.cv.scale, g.cv.shift) : zero4;
+        *reinterpret_cast<f32x4*>(Bs + (tid % KC) * (GN + 8) + 4 * (tid / KC + 2 * t)) = v;
       }
     }
     if (GATE != TRL_ACT_NONE) {
@@ -308,8 +340,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
 #pragma unroll
       for (int t = 0; t < SA; ++t) csum += ra[t];
     }
-    panel_stash<!TA, GM>(As, tid, ra);
-    panel_stash<TB, GN>(Bs, tid, rb);
+    if (CONV != 1) panel_stash<!TA, GM>(As, tid, ra);
+    if (CONV != 2) panel_stash<TB, GN>(Bs, tid, rb);
   };
 
   GCLK(0)
@@ -412,13 +444,15 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
 template <bool TA, bool TB, int GATE, int CONV, int WM>
 static int launch_gemm_tile(GemmDev g, int splits, hipStream_t s) {
   constexpr int GM = 32 * WM, GN = 32 * (4 / WM);
-  const int lds = (int)sizeof(float) * (tile_floats<!TA, GM>() + tile_floats<TB, GN>());
-  static bool attr_set = false;
-  if (!attr_set) {
+  const int tiles_lds = (int)sizeof(float) * (tile_floats<!TA, GM>() + tile_floats<TB, GN>());
+  const int lds = tiles_lds + (CONV == 1 ? g.K : 0);              // CONV 1: + the tap offset table (K / 4 dwords)
+  TRL_REQUIRE(lds <= 160 * 1024, "reduction too long for the implicit first-layer kernel");
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE, CONV, WM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { trl_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
+    attr_lds = lds;
   }
   g.tiles_n = trl_ceil_div(g.N, GN);
   g.tiles = g.tiles_n * trl_ceil_div(g.M, GM);
