@@ -144,15 +144,30 @@ extern "C" int trl_quantile_huber_f32(const float* q, const int64_t* acts, const
 __global__ __launch_bounds__(DQ_THREADS) void eps_greedy_kernel(const float* __restrict__ q, int N, int A, int Q,
                                                                 const float* __restrict__ u, const int64_t* __restrict__ ra,
                                                                 float epsilon, int64_t* __restrict__ action) {
-  const int n = blockIdx.x * DQ_THREADS + threadIdx.x;
-  if (n >= N) return;
+  // Q == 1: a thread per env.  Quantile nets: a wave per env, lanes stride over the quantiles of an action
+  // (coalesced reads of the A * Q row; a thread per env walked it with a stride of A * Q floats).
   int best = 0;
   float bv = -INFINITY;
-  for (int a = 0; a < A; ++a) {
-    float s = 0.0f;
-    for (int i = 0; i < Q; ++i) s += q[((size_t)n * A + a) * Q + i];
-    if (Q > 1) s /= (float)Q;
-    if (s > bv) { bv = s; best = a; }
+  int n;
+  if (Q == 1) {
+    n = blockIdx.x * DQ_THREADS + threadIdx.x;
+    if (n >= N) return;
+    for (int a = 0; a < A; ++a) {
+      const float s = q[(size_t)n * A + a];
+      if (s > bv) { bv = s; best = a; }
+    }
+  } else {
+    const int lane = threadIdx.x & 63;
+    n = blockIdx.x * (DQ_THREADS / 64) + (threadIdx.x >> 6);
+    if (n >= N) return;                                            // wave-uniform
+    for (int a = 0; a < A; ++a) {
+      const float* row = q + ((size_t)n * A + a) * Q;
+      float s = 0.0f;
+      for (int i = lane; i < Q; i += 64) s += row[i];
+      s = wave_sum(s) / (float)Q;
+      if (s > bv) { bv = s; best = a; }
+    }
+    if (lane != 0) return;
   }
   if (u && ra && u[n] < epsilon) best = (int)ra[n];
   action[n] = best;
@@ -162,7 +177,7 @@ extern "C" int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const flo
   TRL_REQUIRE(N >= 0 && A > 0 && Q > 0, "bad sizes");
   if (N == 0) return TRL_OK;
   TRL_REQUIRE(q && action, "null pointer");
-  hipLaunchKernelGGL(eps_greedy_kernel, dim3(trl_ceil_div(N, DQ_THREADS)), dim3(DQ_THREADS), 0, (hipStream_t)stream, q,
+  hipLaunchKernelGGL(eps_greedy_kernel, dim3(trl_ceil_div(N, Q == 1 ? DQ_THREADS : DQ_THREADS / 64)), dim3(DQ_THREADS), 0, (hipStream_t)stream, q,
                      N, A, Q, u, rand_act, epsilon, action);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
