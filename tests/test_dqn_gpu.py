@@ -42,7 +42,11 @@ def test_cnn_forward_backward_vs_torch(act):
 
 
 @pytest.mark.parametrize("B,C,H,W,kh,kw,sh,sw,Cout", [
-    (5, 4, 84, 84, 8, 8, 4, 4, 16),        # the Atari first layer (dqn_pong.json)
+    (5, 4, 84, 84, 8, 8, 4, 4, 16),        # the Atari first layer (dqn_pong.json): direct register-weights kernels
+    (3, 1, 36, 44, 8, 8, 4, 4, 5),         # direct kernels, K = 64, 5 channels, M = 240 (ragged wave)
+    (9, 2, 40, 36, 8, 8, 4, 4, 16),        # direct kernels, K = 128, M = 648
+    (4, 3, 33, 44, 8, 8, 3, 4, 12),        # direct kernels, K = 192, vertical stride 3
+    (70, 4, 84, 84, 8, 8, 4, 4, 16),       # direct kernels, M = 28 000: many workgroups in the weight gradient
     (3, 3, 36, 44, 3, 4, 2, 4, 5),         # K = 36 (one partial panel), ragged M, Cout < tile
     (2, 2, 20, 20, 8, 8, 4, 4, 70),        # Ho * Wo = 16 (power-of-two divisor), two N tiles
     (7, 1, 9, 8, 2, 8, 1, 4, 3),           # Wo = 1 (division by 1), Ho = 8

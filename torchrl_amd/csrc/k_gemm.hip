@@ -7,20 +7,23 @@
 //     input-grad dX[M,K] = dZ[M,N] . W[N,K]                          (plain)
 //     weight-grad dW[N,K] = dZ[M,N]^T . X[M,K]   (split over M, deterministic two-pass fold)
 //     dZ = dY * act'(Y)  and  db = column sums of dZ are fused into the operand loads / a side output.
-// Exact fp32 on v_mfma_f32_32x32x2_f32: a workgroup of 4 waves owns a 64x64 C tile (one 32x32 quadrant per
-// wave).  These layers are a few thousand rows by <= 256..512 columns: the reduction is short, so what paces
+// The conv layers of CNNBase (networks/base.py:59-107) run through the same kernel as IMPLICIT GEMMs (template
+// parameter CONV, entry points trl_conv_*): the im2col matrix is only ever an address computation.
+// Exact fp32 on v_mfma_f32_32x32x2_f32: a workgroup of 4 waves owns a 64x64, 128x32 or 32x128 C tile (one 32x32
+// quadrant per wave; template parameter WM).  These layers are a few thousand rows by <= 256..512 columns: the reduction is short, so what paces
 // the kernel is how often it waits for memory, not the MFMAs.  The reduction is therefore walked in PANELS of
 // KC = 128: a panel of each operand (64 x 128 floats) is fetched with 16-byte loads into registers while the
 // previous panel's 64 MFMAs per wave run from LDS (one memory round trip per 128 k, all of a panel's loads in
 // flight together; the first version walked K in steps of 32 and paid a round trip per step, 4 us per step at
 // K = 512 where every workgroup's 128-byte row segments also sat 2 KB apart).  LDS tiles keep the layout the
 // operand has in memory -- [row][k] (row stride KC + 4, read with one ds_read_b128 per 4 MFMAs) when k is the
-// contiguous dimension, [k][col] (row stride 64 + 8, ds_read_b32) when it is not -- so the global->LDS copy
+// contiguous dimension, [k][col] (row stride rows + 8, ds_read_b32) when it is not -- so the global->LDS copy
 // never transposes.  MFMA step (q, r) of lane half `hi` takes k = 8q + 4hi + r.  Arbitrary M, N, K: slots that
 // are misaligned or cross an edge fall back to predicated scalar loads (zero fill).
 #include <algorithm>
 #include "trl_common.h"
 #include "trl_mlp.h"
+#include "trl_conv.h"
 
 #define KC 128                      // reduction panel
 #define LDK (KC + 4)                // [row][k] tile: 16-byte aligned rows, banks rotate by 4 per row
@@ -30,59 +33,6 @@ __device__ __forceinline__ float dact_from_out(int act, float y) {
   if (act == TRL_ACT_TANH) return 1.0f - y * y;
   if (act == TRL_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
   return 1.0f;
-}
-
-// Implicit-GEMM operand (first conv layer of CNNBase, networks/base.py:59-107, on the replay buffer's uint8 NCHW
-// frame stacks): row m = (b, oy, ox), reduction index k = (c, i, j) in nn.Conv2d's weight order, element
-//     cols[m][k] = frames[b][c][oy * sh + i][ox * sw + j] * scale + shift          (ScaledFloatFrame on the fly)
-// With kw, sw and W multiples of 4 the 4 consecutive k of a slot are 4 consecutive, 4-byte aligned bytes: one
-// dword load per slot, converted when the panel is written to LDS.  The 210 MB im2col buffer of cfg 5 never exists.
-// The later conv layers read fp32 channels-last activations (B, H, W, C): with the reduction index ordered
-// k' = (i, j, c) a window row is ONE contiguous run of kw * C floats, so a slot is one 16-byte load (C % 4 == 0);
-// the nn.Conv2d weight stays in its (Cout, C, kh, kw) layout and is gathered with the matching permutation
-// (it is a few thousand floats), and the weight gradient is un-permuted by the fold.
-struct ConvSrc {
-  const uint8_t* frames;      // uint8 NCHW source (CONV 1 / 2)
-  const float* x;             // fp32 NHWC source (CONV 3 / 4)
-  int C, H, W, kh, kw, sh, sw, Ho, Wo;
-  float scale, shift;
-  uint32_t hw_magic, hw_shift, w_magic, w_shift;    // division by Ho * Wo and by Wo (multiply-high form)
-};
-
-__device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t d, uint32_t magic, uint32_t shift) {
-  if (d == 1) return n;                             // uniform
-  const uint32_t q = __umulhi(n, magic);
-  return (((n - q) >> 1) + q) >> shift;
-}
-// byte offset of window (b, oy, ox), channel 0, tap (0, 0)
-__device__ __forceinline__ uint32_t conv_row_offset(const ConvSrc& cv, uint32_t m) {
-  const uint32_t hw = (uint32_t)(cv.Ho * cv.Wo);
-  const uint32_t b = fastdiv(m, hw, cv.hw_magic, cv.hw_shift), p = m - b * hw;
-  const uint32_t oy = fastdiv(p, (uint32_t)cv.Wo, cv.w_magic, cv.w_shift), ox = p - oy * cv.Wo;
-  return ((b * cv.C) * cv.H + oy * cv.sh) * cv.W + ox * cv.sw;
-}
-// byte offset of reduction index k = (c, i, j) relative to the window origin
-__device__ __forceinline__ uint32_t conv_tap_offset(const ConvSrc& cv, uint32_t k) {
-  const uint32_t khw = (uint32_t)(cv.kh * cv.kw);
-  const uint32_t c = k / khw, rem = k - c * khw, i = rem / (uint32_t)cv.kw, j = rem - i * cv.kw;
-  return (c * cv.H + i) * cv.W + j;
-}
-// fp32 NHWC: float offset of window (b, oy, ox), and of reduction index k' = (i, j, c) inside the window
-__device__ __forceinline__ uint32_t nhwc_row_offset(const ConvSrc& cv, uint32_t m) {
-  const uint32_t hw = (uint32_t)(cv.Ho * cv.Wo);
-  const uint32_t b = fastdiv(m, hw, cv.hw_magic, cv.hw_shift), p = m - b * hw;
-  const uint32_t oy = fastdiv(p, (uint32_t)cv.Wo, cv.w_magic, cv.w_shift), ox = p - oy * cv.Wo;
-  return ((b * cv.H + oy * cv.sh) * cv.W + ox * cv.sw) * cv.C;
-}
-__device__ __forceinline__ uint32_t nhwc_tap_offset(const ConvSrc& cv, uint32_t k) {
-  const uint32_t run = (uint32_t)(cv.kw * cv.C);
-  const uint32_t i = k / run;
-  return i * (uint32_t)(cv.W * cv.C) + (k - i * run);
-}
-__device__ __forceinline__ f32x4 conv_unpack(uint32_t u, float scale, float shift) {
-  f32x4 v = {fmaf((float)(u & 0xffu), scale, shift), fmaf((float)((u >> 8) & 0xffu), scale, shift),
-             fmaf((float)((u >> 16) & 0xffu), scale, shift), fmaf((float)(u >> 24), scale, shift)};
-  return v;
 }
 
 struct GemmDev {
@@ -441,6 +391,14 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
   }
 }
 
+int trl_fold_partials(const float* part, float* out, int n, const float* part2, float* out2, int n2, int splits,
+                      hipStream_t stream) {
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)n + n2, FOLD_OUT)), dim3(256), 0, stream, part, out, n,
+                     part2, out2, n2, splits, (const float*)nullptr, 0, TRL_ACT_NONE, 0, 0);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 template <bool TA, bool TB, int GATE, int CONV, int WM>
 static int launch_gemm_tile(GemmDev g, int splits, hipStream_t s) {
   constexpr int GM = 32 * WM, GN = 32 * (4 / WM);
@@ -582,19 +540,6 @@ extern "C" int trl_linear_bwd_weight_f32(const float* dy, const float* y_gate, i
 }
 
 // ---- first conv layer on uint8 frames as an implicit GEMM ----
-static void fastdiv_gen(uint32_t d, uint32_t& magic, uint32_t& shift) {
-  if (d <= 1) { magic = 0; shift = 0; return; }
-  const uint32_t L = 31 - (uint32_t)__builtin_clz(d);
-  if ((d & (d - 1)) == 0) { magic = 0; shift = L - 1; return; }
-  const uint64_t num = (uint64_t)1 << (32 + L);
-  uint32_t m = (uint32_t)(num / d);
-  const uint32_t rem = (uint32_t)(num - (uint64_t)m * d);
-  m += m;
-  const uint32_t twice = rem + rem;
-  if (twice >= d || twice < rem) m += 1;
-  magic = m + 1; shift = L;
-}
-
 static int fill_conv(const char* who, const uint8_t* frames, int B, int C, int H, int W, int kh, int kw, int sh, int sw,
                      float scale, float shift, ConvSrc& cv, int& M, int& K) {
   if (!(B > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && H >= kh && W >= kw)) {
@@ -625,6 +570,8 @@ extern "C" int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const 
   int M, K;
   int rc = fill_conv("conv_fwd_u8", frames, B, C, H, W, kh, kw, sh, sw, scale, shift, g.cv, M, K);
   if (rc) return rc;
+  if (trl_conv1_direct_ok(K, Cout, w))               // narrow first layer: register-weights kernel, no LDS staging
+    return trl_conv1_direct_fwd(g.cv, w, bias, y, M, K, Cout, act, (hipStream_t)stream);
   g.A = nullptr; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
   g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
   return launch_gemm<false, true, 1>(g, 1, (hipStream_t)stream);
@@ -679,7 +626,11 @@ extern "C" int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh,
   if (!(B > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && H >= kh && W >= kw && Cout > 0)) return TRL_EINVAL;
   const int64_t m = (int64_t)B * ((H - kh) / sh + 1) * ((W - kw) / sw + 1);
   if (m >= ((int64_t)1 << 31)) return TRL_EINVAL;
-  return trl_linear_bwd_weight_workspace((int)m, C * kh * kw, Cout);
+  const int K = C * kh * kw;
+  const int generic = trl_linear_bwd_weight_workspace((int)m, K, Cout);
+  // the uint8 entry point may take the direct kernel (weights are not known here: size for both)
+  const int direct = (Cout <= 16 && K <= 256 && (K & 63) == 0) ? trl_conv1_direct_bwdw_workspace((int)m, K, Cout) : 0;
+  return std::max(generic, direct);
 }
 
 extern "C" int trl_conv_bwd_weight_u8_f32(const float* dy, const float* y_gate, int gate_act, const uint8_t* frames,
@@ -690,5 +641,7 @@ extern "C" int trl_conv_bwd_weight_u8_f32(const float* dy, const float* y_gate, 
   int M, K;
   int rc = fill_conv("conv_bwd_weight_u8", frames, B, C, H, W, kh, kw, sh, sw, scale, shift, cv, M, K);
   if (rc) return rc;
+  if (trl_conv1_direct_ok(K, Cout, dw))
+    return trl_conv1_direct_bwdw(cv, dy, y_gate, gate_act, dw, db, workspace, M, K, Cout, (hipStream_t)stream);
   return bwd_weight_impl<2>(dy, y_gate, gate_act, nullptr, &cv, dw, db, workspace, M, K, Cout, (hipStream_t)stream);
 }

@@ -1,0 +1,82 @@
+// Shared by k_gemm.hip (implicit-GEMM conv modes) and k_conv1.hip (direct first-layer kernels): the virtual im2col
+// matrix of a conv window over the input, as address arithmetic.
+#pragma once
+#include "trl_common.h"
+
+// Implicit-GEMM operand (first conv layer of CNNBase, networks/base.py:59-107, on the replay buffer's uint8 NCHW
+// frame stacks): row m = (b, oy, ox), reduction index k = (c, i, j) in nn.Conv2d's weight order, element
+//     cols[m][k] = frames[b][c][oy * sh + i][ox * sw + j] * scale + shift          (ScaledFloatFrame on the fly)
+// With kw, sw and W multiples of 4 the 4 consecutive k of a slot are 4 consecutive, 4-byte aligned bytes: one
+// dword load per slot, converted when the panel is written to LDS.  The 210 MB im2col buffer of cfg 5 never exists.
+// The later conv layers read fp32 channels-last activations (B, H, W, C): with the reduction index ordered
+// k' = (i, j, c) a window row is ONE contiguous run of kw * C floats, so a slot is one 16-byte load (C % 4 == 0);
+// the nn.Conv2d weight stays in its (Cout, C, kh, kw) layout and is gathered with the matching permutation
+// (it is a few thousand floats), and the weight gradient is un-permuted by the fold.
+struct ConvSrc {
+  const uint8_t* frames;      // uint8 NCHW source (CONV 1 / 2)
+  const float* x;             // fp32 NHWC source (CONV 3 / 4)
+  int C, H, W, kh, kw, sh, sw, Ho, Wo;
+  float scale, shift;
+  uint32_t hw_magic, hw_shift, w_magic, w_shift;    // division by Ho * Wo and by Wo (multiply-high form)
+};
+
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t d, uint32_t magic, uint32_t shift) {
+  if (d == 1) return n;                             // uniform
+  const uint32_t q = __umulhi(n, magic);
+  return (((n - q) >> 1) + q) >> shift;
+}
+// byte offset of window (b, oy, ox), channel 0, tap (0, 0)
+__device__ __forceinline__ uint32_t conv_row_offset(const ConvSrc& cv, uint32_t m) {
+  const uint32_t hw = (uint32_t)(cv.Ho * cv.Wo);
+  const uint32_t b = fastdiv(m, hw, cv.hw_magic, cv.hw_shift), p = m - b * hw;
+  const uint32_t oy = fastdiv(p, (uint32_t)cv.Wo, cv.w_magic, cv.w_shift), ox = p - oy * cv.Wo;
+  return ((b * cv.C) * cv.H + oy * cv.sh) * cv.W + ox * cv.sw;
+}
+// byte offset of reduction index k = (c, i, j) relative to the window origin
+__device__ __forceinline__ uint32_t conv_tap_offset(const ConvSrc& cv, uint32_t k) {
+  const uint32_t khw = (uint32_t)(cv.kh * cv.kw);
+  const uint32_t c = k / khw, rem = k - c * khw, i = rem / (uint32_t)cv.kw, j = rem - i * cv.kw;
+  return (c * cv.H + i) * cv.W + j;
+}
+// fp32 NHWC: float offset of window (b, oy, ox), and of reduction index k' = (i, j, c) inside the window
+__device__ __forceinline__ uint32_t nhwc_row_offset(const ConvSrc& cv, uint32_t m) {
+  const uint32_t hw = (uint32_t)(cv.Ho * cv.Wo);
+  const uint32_t b = fastdiv(m, hw, cv.hw_magic, cv.hw_shift), p = m - b * hw;
+  const uint32_t oy = fastdiv(p, (uint32_t)cv.Wo, cv.w_magic, cv.w_shift), ox = p - oy * cv.Wo;
+  return ((b * cv.H + oy * cv.sh) * cv.W + ox * cv.sw) * cv.C;
+}
+__device__ __forceinline__ uint32_t nhwc_tap_offset(const ConvSrc& cv, uint32_t k) {
+  const uint32_t run = (uint32_t)(cv.kw * cv.C);
+  const uint32_t i = k / run;
+  return i * (uint32_t)(cv.W * cv.C) + (k - i * run);
+}
+__device__ __forceinline__ f32x4 conv_unpack(uint32_t u, float scale, float shift) {
+  f32x4 v = {fmaf((float)(u & 0xffu), scale, shift), fmaf((float)((u >> 8) & 0xffu), scale, shift),
+             fmaf((float)((u >> 16) & 0xffu), scale, shift), fmaf((float)(u >> 24), scale, shift)};
+  return v;
+}
+
+// multiply-high constants for fastdiv (round-up method; d >= 2, d == 1 is handled by the caller's branch)
+static inline void fastdiv_gen(uint32_t d, uint32_t& magic, uint32_t& shift) {
+  if (d <= 1) { magic = 0; shift = 0; return; }
+  const uint32_t L = 31 - (uint32_t)__builtin_clz(d);
+  if ((d & (d - 1)) == 0) { magic = 0; shift = L - 1; return; }
+  const uint64_t num = (uint64_t)1 << (32 + L);
+  uint32_t m = (uint32_t)(num / d);
+  const uint32_t rem = (uint32_t)(num - (uint64_t)m * d);
+  m += m;
+  const uint32_t twice = rem + rem;
+  if (twice >= d || twice < rem) m += 1;
+  magic = m + 1; shift = L;
+}
+
+// ---- direct kernels for a narrow first layer (k_conv1.hip); used by the trl_conv_*_u8 entry points when they apply ----
+bool trl_conv1_direct_ok(int K, int Cout, const float* w);
+int trl_conv1_direct_fwd(const ConvSrc& cv, const float* w, const float* bias, float* y, int M, int K, int Cout, int act,
+                         hipStream_t stream);
+int trl_conv1_direct_bwdw_workspace(int M, int K, int Cout);          // floats
+int trl_conv1_direct_bwdw(const ConvSrc& cv, const float* dy, const float* y_gate, int gate_act, float* dw, float* db,
+                          float* workspace, int M, int K, int Cout, hipStream_t stream);
+// out[e] = sum_s part[s][e] (k_gemm.hip's fixed-order fold; second segment for the bias gradient)
+int trl_fold_partials(const float* part, float* out, int n, const float* part2, float* out2, int n2, int splits,
+                      hipStream_t stream);
