@@ -265,6 +265,18 @@ int trl_linear_bwd_weight_workspace(int M, int K, int N);
 int trl_linear_bwd_weight_f32(const float* dy, const float* y_gate, int gate_act, const float* x,
                               float* dw, float* db, float* workspace, int M, int K, int N,
                               void* stream);
+/* Grouped forms: G <= 8 independent layers of IDENTICAL shape in one launch (the twin critics qf1 / qf2 of
+ * twin_sac_q.py:121-150 and td3.py:96-110, their target copies, one network applied to several inputs).
+ * x / w / bias / y ... are HOST arrays of G device pointers; bias (the array, or all of its entries) may be
+ * NULL; either every problem of a group is gated / wants db or none.  Results are identical to G separate
+ * calls (same kernel, same summation order).  bwd_weight_group needs G * trl_linear_bwd_weight_workspace floats. */
+int trl_linear_fwd_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
+                             float* const* y, int M, int K, int N, int act, void* stream);
+int trl_linear_bwd_input_group_f32(int G, const float* const* dy, const float* const* y_gate, int gate_act,
+                                   const float* const* w, float* const* dx, int M, int K, int N, void* stream);
+int trl_linear_bwd_weight_group_f32(int G, const float* const* dy, const float* const* y_gate, int gate_act,
+                                    const float* const* x, float* const* dw, float* const* db, float* workspace,
+                                    int M, int K, int N, void* stream);
 
 /* --- K12 / K13: twin-Q SAC update pieces (torchrl/algo/off_policy/twin_sac_q.py:84-220) ---- */
 /* torch.cat([obs, act], -1) of QNet.forward (torchrl/networks/nets.py:61-68) */

@@ -41,6 +41,33 @@ def test_linear_layer_kernels_vs_torch(M, K, N, act):
     assert _C.linear_bwd_weight(dy.to(DEV), gate, code, x.to(DEV), need_bias=False)[1] is None
 
 
+@pytest.mark.parametrize("M,K,N,G", [(4096, 256, 256, 6), (300, 23, 70, 2), (130, 256, 1, 3)])
+def test_grouped_layer_launches_equal_separate_calls(M, K, N, G):
+    """trl_linear_*_group_f32: G same-shaped layers in one launch give bit-identical results to G separate calls
+    (same kernel, same summation order) -- shared inputs, distinct weights, gated and ungated."""
+    from torchrl_amd import _C
+    gen = torch.Generator().manual_seed(M + G)
+    xs = [torch.randn(M, K, generator=gen).to(DEV) for _ in range(G)]
+    xs[1] = xs[0]                                                    # a shared input (Q1 / Q2 on the same batch)
+    ws = [(torch.randn(N, K, generator=gen) / K ** 0.5).to(DEV) for _ in range(G)]
+    bs = [torch.randn(N, generator=gen).to(DEV) for _ in range(G)]
+    dys = [torch.randn(M, N, generator=gen).to(DEV) for _ in range(G)]
+    ys = _C.linear_fwd_group(xs, ws, bs, _C.ACT_RELU)
+    for g in range(G):
+        assert torch.equal(ys[g], _C.linear_fwd(xs[g], ws[g], bs[g], _C.ACT_RELU))
+    assert torch.equal(_C.linear_fwd_group(xs, ws, [None] * G, _C.ACT_NONE)[G - 1], _C.linear_fwd(xs[-1], ws[-1], None, _C.ACT_NONE))
+    dxs = _C.linear_bwd_input_group(dys, ys, _C.ACT_RELU, ws)
+    dxs_plain = _C.linear_bwd_input_group(dys, [None] * G, _C.ACT_NONE, ws)
+    dws = [torch.empty(N, K, device=DEV) for _ in range(G)]
+    dbs = [torch.empty(N, device=DEV) for _ in range(G)]
+    _C.linear_bwd_weight_group(dys, ys, _C.ACT_RELU, xs, dws, dbs)
+    for g in range(G):
+        assert torch.equal(dxs[g], _C.linear_bwd_input(dys[g], ys[g], _C.ACT_RELU, ws[g]))
+        assert torch.equal(dxs_plain[g], _C.linear_bwd_input(dys[g], None, _C.ACT_NONE, ws[g]))
+        dw, db = _C.linear_bwd_weight(dys[g], ys[g], _C.ACT_RELU, xs[g])
+        assert torch.equal(dws[g], dw) and torch.equal(dbs[g], db)
+
+
 def test_rsample_fwd_bwd_vs_autograd():
     from torchrl_amd import _C
     B, A = 300, 6

@@ -142,6 +142,11 @@ SIGNATURES = {
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_linear_fwd_workspace": (C.c_int, [C.c_int] * 3),
+    "trl_linear_fwd_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    "trl_linear_bwd_input_group_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+                                       + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_linear_bwd_weight_group_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+                                        + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_splitk_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "trl_linear_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -324,6 +329,49 @@ def linear_fwd(x, w, bias, act):
                                    dev_ptr(bias, name="bias", allow_none=True), dev_ptr(y, name="y"),
                                    M, K, N, act, stream_ptr(x.device)), "trl_linear_fwd_f32")
     return y
+
+
+def _ptrs(tensors, name, allow_none=False):
+    """Host array of device pointers for the grouped entry points (None -> NULL array when every entry is None)."""
+    if tensors is None or all(t is None for t in tensors):
+        if not allow_none:
+            raise TrlError("%s: missing tensors" % name)
+        return None
+    return (C.c_void_p * len(tensors))(*[dev_ptr(t, name=name, allow_none=allow_none) for t in tensors])
+
+
+def linear_fwd_group(xs, ws, biases, act):
+    """[act(x_g @ w_g.T + b_g)] for G same-shaped layers in one launch (twin critics, targets, several inputs)."""
+    G = len(xs)
+    M, K, N = int(xs[0].shape[0]), int(xs[0].shape[1]), int(ws[0].shape[0])
+    if any(tuple(x.shape) != (M, K) for x in xs) or any(tuple(w.shape) != (N, K) for w in ws):
+        raise TrlError("linear_fwd_group: the layers of a group must have identical shapes")
+    ys = [torch.empty((M, N), dtype=torch.float32, device=xs[0].device) for _ in range(G)]
+    check(lib().trl_linear_fwd_group_f32(G, _ptrs(xs, "x"), _ptrs(ws, "w"), _ptrs(biases, "bias", True), _ptrs(ys, "y"),
+                                         M, K, N, act, stream_ptr(xs[0].device)), "trl_linear_fwd_group_f32")
+    return ys
+
+
+def linear_bwd_input_group(dys, y_gates, gate_act, ws):
+    G = len(dys)
+    M, N, K = int(dys[0].shape[0]), int(dys[0].shape[1]), int(ws[0].shape[1])
+    dxs = [torch.empty((M, K), dtype=torch.float32, device=dys[0].device) for _ in range(G)]
+    check(lib().trl_linear_bwd_input_group_f32(G, _ptrs(dys, "dy"), _ptrs(y_gates, "y_gate", True), gate_act,
+                                               _ptrs(ws, "w"), _ptrs(dxs, "dx"), M, K, N, stream_ptr(dys[0].device)),
+          "trl_linear_bwd_input_group_f32")
+    return dxs
+
+
+def linear_bwd_weight_group(dys, y_gates, gate_act, xs, dws, dbs, workspace=None):
+    G = len(dys)
+    M, N, K = int(dys[0].shape[0]), int(dys[0].shape[1]), int(xs[0].shape[1])
+    need = G * lib().trl_linear_bwd_weight_workspace(M, K, N)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.float32, device=dys[0].device)
+    check(lib().trl_linear_bwd_weight_group_f32(G, _ptrs(dys, "dy"), _ptrs(y_gates, "y_gate", True), gate_act,
+                                                _ptrs(xs, "x"), _ptrs(dws, "dw"), _ptrs(dbs, "db", True),
+                                                dev_ptr(workspace, name="workspace"), M, K, N,
+                                                stream_ptr(dys[0].device)), "trl_linear_bwd_weight_group_f32")
 
 
 def linear_bwd_input(dy, y_gate, gate_act, w):

@@ -4,7 +4,8 @@
 is re-read AFTER it), no-grad target branch, twin MSE, policy loss through min(Q1, Q2) of the new
 actions, optimiser steps pf -> qf1 -> qf2, Polyak -- but runs as a fixed launch sequence with an
 explicit chain rule instead of autograd:
-  dense layers ............ trl_linear_{fwd,bwd_input,bwd_weight}_f32   (fp32 MFMA, k_gemm.hip)
+  dense layers ............ trl_linear_{fwd,bwd_input,bwd_weight}[_group]_f32   (fp32 MFMA, k_gemm.hip); the six
+                            critic passes, the two policy passes and the twin backward passes are grouped launches
   rsample / its backward .. trl_tanh_gauss_rsample_{fwd,bwd}_f32
   alpha loss + its Adam ... trl_sac_alpha_step_f32 (log_alpha, its moments and alpha stay on device)
   TD target, losses, dQ ... trl_sac_losses_f32
@@ -138,8 +139,8 @@ class _FusedSAC:
         self._static, self._graphs, self._seen = {}, {}, set()
 
     def _ws(self, B):
-        need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
-                   for ls in self.layers for w, _ in ls)
+        need = 2 * max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
+                       for ls in self.layers for w, _ in ls)               # x2: the twin critics' grouped weight gradient
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, device=self.dev)
         return self.workspace
@@ -165,37 +166,27 @@ class _FusedSAC:
         ws = self._ws(B)
         pf_l, q1_l, q2_l = self.layers
         tanh_action = bool(algo.pf.tanh_action)
-        # ---- policy sample on obs, Q(s, a) of the replayed actions ----
-        head, tape_pf = ops.mlp_forward(pf_l, obs, self.act)
+        # ---- policy on obs and next_obs (one grouped launch per layer), both samples ----
+        (head, head2), (tape_pf, _) = ops.mlp_forward_group([pf_l, pf_l], [obs, nobs], self.act)
         new_a, logp = _C.rsample_fwd(head, eps1, tanh_action)
-        x_sa = _C.concat2(obs, acts)
-        q1p, tape_q1 = ops.mlp_forward(q1_l, x_sa, self.act)
-        q2p, tape_q2 = ops.mlp_forward(q2_l, x_sa, self.act)
+        next_a, next_logp = _C.rsample_fwd(head2, eps2, tanh_action)
         # ---- temperature ----
         if algo.automatic_entropy_tuning:
             _C.sac_alpha_step(logp, algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
-        # ---- target branch (no gradient) ----
-        head2, _ = ops.mlp_forward(pf_l, nobs, self.act)
-        next_a, next_logp = _C.rsample_fwd(head2, eps2, tanh_action)
-        x_next = _C.concat2(nobs, next_a)
-        tq1, _ = ops.mlp_forward(self.tlayers[0], x_next, self.act)
-        tq2, _ = ops.mlp_forward(self.tlayers[1], x_next, self.act)
-        # ---- Q of the new actions, all losses and their output gradients ----
-        x_new = _C.concat2(obs, new_a)
-        q1n, tape_q1n = ops.mlp_forward(q1_l, x_new, self.act)
-        q2n, tape_q2n = ops.mlp_forward(q2_l, x_new, self.act)
-        alpha = self.alpha_out[0:1]
+        # ---- all six critic passes as one group: Q1/Q2(s, a), target Q1/Q2(s', a'), Q1/Q2(s, new a) ----
+        x_sa, x_next, x_new = _C.concat2(obs, acts), _C.concat2(nobs, next_a), _C.concat2(obs, new_a)
+        (q1p, q2p, tq1, tq2, q1n, q2n), (tape_q1, tape_q2, _, _, tape_q1n, tape_q2n) = ops.mlp_forward_group(
+            [q1_l, q2_l, self.tlayers[0], self.tlayers[1], q1_l, q2_l], [x_sa, x_sa, x_next, x_next, x_new, x_new], self.act)
+        alpha = self.alpha_out[0:1]                                      # re-read AFTER the alpha step, as the reference does
         dq1, dq2, dq1n, dq2n = _C.sac_losses(q1p, q2p, tq1, tq2, next_logp, rew, term, q1n, q2n, logp, alpha,
                                              algo.discount, self.sums)
         # ---- policy gradient: through both Q nets to the action, then through the sampler ----
-        dx1 = ops.mlp_backward(tape_q1n, dq1n, grads=None, need_input=True)
-        dx2 = ops.mlp_backward(tape_q2n, dq2n, grads=None, need_input=True)
+        dx1, dx2 = ops.mlp_backward_group([tape_q1n, tape_q2n], [dq1n, dq2n], grads_list=None, need_input=True)
         d_act = _C.slice_add(dx1, dx2, D, A)
         d_head = _C.rsample_bwd(head, eps1, new_a, d_act, alpha, 1.0 / B, algo.policy_std_reg_weight,
                                 algo.policy_mean_reg_weight, tanh_action)
         ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], workspace=ws)
-        ops.mlp_backward(tape_q1, dq1, grads=self.gviews[1], workspace=ws)
-        ops.mlp_backward(tape_q2, dq2, grads=self.gviews[2], workspace=ws)
+        ops.mlp_backward_group([tape_q1, tape_q2], [dq1, dq2], grads_list=[self.gviews[1], self.gviews[2]], workspace=ws)
         # ---- optimiser steps (pf, qf1, qf2) and target update ----
         a = _C.AdamArgs()
         a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),

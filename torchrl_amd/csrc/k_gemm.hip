@@ -35,6 +35,12 @@ __device__ __forceinline__ float dact_from_out(int act, float y) {
   return 1.0f;
 }
 
+// Up to 8 independent problems of identical shape in one launch (blockIdx.y): the twin critics and their targets,
+// one network on several inputs.  A 4096 x 256 x 256 layer is 256 workgroups and ~4 us of MFMA behind ~4 us of
+// launch + prologue + epilogue; grouped, the problems' workgroups overlap each other's fixed costs.
+#define GEMM_MAX_GROUPS 8
+struct GemmGroup { const float* A; const float* B; float* C; const float* bias; const float* a_gate; float* colsum; };
+
 struct GemmDev {
   const float* A; const float* B; float* C;
   const float* bias;          // epilogue: + bias[n]          (nullable)
@@ -46,6 +52,8 @@ struct GemmDev {
   float* colsum;              // TA only: (splits, M) partial column sums of the gated A (nullable)
   int tiles_n, tiles;         // C tiles along N, and in total
   ConvSrc cv;                 // CONV != 0: the implicit operand (A when CONV == 1, B when CONV == 2)
+  int groups;                 // > 1: the operand pointers of problem blockIdx.y come from grp[]
+  GemmGroup grp[GEMM_MAX_GROUPS];
 };
 
 // development aid (tools/bench_gemm.py --clk): shader-clock and 100 MHz real-time stamps of a few workgroups
@@ -148,7 +156,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
   const int m0 = tm * GM, n0 = tn * GN;
   int k_lo = 0, k_hi = g.K;
-  float* C = g.C;
+  const float* pA = g.A; const float* pB = g.B; float* C = g.C;
+  const float* pBias = g.bias; const float* pGate = g.a_gate; float* pColsum = g.colsum;
+  if (g.groups > 1) {                              // grouped launch: problem blockIdx.y
+    const GemmGroup& q = g.grp[blockIdx.y];
+    pA = q.A; pB = q.B; C = q.C; pBias = q.bias; pGate = q.a_gate; pColsum = q.colsum;
+  }
   if (gridDim.z > 1) {                             // split reduction: blockIdx.z owns split_len indices, writes its own
     k_lo = blockIdx.z * g.split_len;               // partial C (folded in fixed order by fold_partials_kernel)
     k_hi = min(g.K, k_lo + g.split_len);
@@ -156,10 +169,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   }
   const int wm = wave / WN, wn = wave % WN;
   const int i = lane & 31, hi = lane >> 5;
-  const bool a_whole = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 &&
-                       (GATE == TRL_ACT_NONE || (reinterpret_cast<uintptr_t>(g.a_gate) & 15) == 0) && m0 + GM <= g.M;
-  const bool b_whole = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0 && n0 + GN <= g.N;
-  const bool want_colsum = TA && g.colsum && tn == 0;
+  const bool a_whole = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(pA) & 15) == 0 &&
+                       (GATE == TRL_ACT_NONE || (reinterpret_cast<uintptr_t>(pGate) & 15) == 0) && m0 + GM <= g.M;
+  const bool b_whole = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(pB) & 15) == 0 && n0 + GN <= g.N;
+  const bool want_colsum = TA && pColsum && tn == 0;
 
   f32x16 acc;
 #pragma unroll
@@ -223,11 +236,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
         ra[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? cbase[t] + tap : 0u)) : zero4;
       }
     } else if (a_whole && k_whole) {
-      panel_fetch_fast<!TA, GM>(g.A, g.lda, m0, k0, tid, ra);
-      if (GATE != TRL_ACT_NONE) panel_fetch_fast<!TA, GM>(g.a_gate, g.lda, m0, k0, tid, rg);
+      panel_fetch_fast<!TA, GM>(pA, g.lda, m0, k0, tid, ra);
+      if (GATE != TRL_ACT_NONE) panel_fetch_fast<!TA, GM>(pGate, g.lda, m0, k0, tid, rg);
     } else {
-      panel_fetch_edge<!TA, GM>(g.A, g.lda, m0, g.M, k0, k_hi, tid, ra);
-      if (GATE != TRL_ACT_NONE) panel_fetch_edge<!TA, GM>(g.a_gate, g.lda, m0, g.M, k0, k_hi, tid, rg);
+      panel_fetch_edge<!TA, GM>(pA, g.lda, m0, g.M, k0, k_hi, tid, ra);
+      if (GATE != TRL_ACT_NONE) panel_fetch_edge<!TA, GM>(pGate, g.lda, m0, g.M, k0, k_hi, tid, rg);
     }
     if (CONV == 2) {
       const int m = k0 + tid % KC;
@@ -258,12 +271,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
       for (int t = 0; t < SB; ++t) {
         const int n = n0 + 8 * t + (tid >> 5);
         const bool ok = kk < k_hi && n < g.N;
-        const float* wp = g.B + (ok ? (size_t)n * g.ldb + w0 : 0);
+        const float* wp = pB + (ok ? (size_t)n * g.ldb + w0 : 0);
         f32x4 v = {ok ? wp[0] : 0.0f, ok ? wp[khw] : 0.0f, ok ? wp[2 * khw] : 0.0f, ok ? wp[3 * khw] : 0.0f};
         rb[t] = v;
       }
-    } else if (b_whole && k_whole) panel_fetch_fast<TB, GN>(g.B, g.ldb, n0, k0, tid, rb);
-    else                           panel_fetch_edge<TB, GN>(g.B, g.ldb, n0, g.N, k0, k_hi, tid, rb);
+    } else if (b_whole && k_whole) panel_fetch_fast<TB, GN>(pB, g.ldb, n0, k0, tid, rb);
+    else                           panel_fetch_edge<TB, GN>(pB, g.ldb, n0, g.N, k0, k_hi, tid, rb);
   };
   auto stash = [&]() {
     if (CONV == 1) {                               // uint8 slots go straight to their (row, k4) place
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   {
     const int n = n0 + 32 * wn + i, mb = m0 + 32 * wm + 4 * hi;
     if (n < g.N) {
-      const float bias = g.bias ? g.bias[n] : 0.0f;
+      const float bias = pBias ? pBias[n] : 0.0f;
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
       float a = 0.0f;
 #pragma unroll
       for (int w = 0; w < GROUPS; ++w) a += s[w * GM + tid];
-      g.colsum[(size_t)blockIdx.z * g.M + m0 + tid] = a;
+      pColsum[(size_t)blockIdx.z * g.M + m0 + tid] = a;
     }
   }
 }
@@ -360,43 +373,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
 // fixed-order fold of split partials: out[e] = sum_s part[s][e]; a second segment (the bias gradient) rides along.
 // A workgroup owns 64 outputs; its 4 waves each sum every 4th split, then the 4 slices are added in order.
 #define FOLD_OUT 64
-__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
-                                                            const float* __restrict__ part2, float* __restrict__ out2,
-                                                            int n2, int splits, const float* __restrict__ bias, int n_cols,
-                                                            int act, int perm_c, int perm_khw) {
+struct FoldGroup { const float* part; float* out; const float* part2; float* out2; };
+struct FoldDev {
+  int n, n2, splits;
+  const float* bias; int n_cols, act;             // split-K forward: the epilogue the GEMM skipped (n_cols > 0)
+  int perm_c, perm_khw;                            // conv weight gradient computed in (i, j, c) column order
+  FoldGroup grp[GEMM_MAX_GROUPS];                  // problem blockIdx.y
+};
+__global__ __launch_bounds__(256) void fold_partials_kernel(FoldDev f) {
   __shared__ float sl[4][FOLD_OUT];
+  const FoldGroup& q = f.grp[blockIdx.y];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   int e = blockIdx.x * FOLD_OUT + lane;
-  const bool second = e >= n;                      // per lane: a workgroup may straddle the two segments
-  const float* p = second ? part2 : part;
-  const int nn = second ? n2 : n, ee = second ? e - n : e;
+  const bool second = e >= f.n;                    // per lane: a workgroup may straddle the two segments
+  const float* p = second ? q.part2 : q.part;
+  const int nn = second ? f.n2 : f.n, ee = second ? e - f.n : e;
   float a = 0.0f;
   if (ee < nn)
-    for (int s = slice; s < splits; s += 4) a += p[(size_t)s * nn + ee];
+    for (int s = slice; s < f.splits; s += 4) a += p[(size_t)s * nn + ee];
   sl[slice][lane] = a;
   __syncthreads();
   if (slice == 0 && ee < nn) {
     float v = (sl[0][lane] + sl[1][lane]) + (sl[2][lane] + sl[3][lane]);
-    if (!second && n_cols > 0) {                   // split-K forward: the epilogue the GEMM skipped
-      if (bias) v += bias[ee % n_cols];
-      if (act == TRL_ACT_TANH) v = trl_tanh(v);
-      else if (act == TRL_ACT_RELU) v = fmaxf(v, 0.0f);
+    if (!second && f.n_cols > 0) {
+      if (f.bias) v += f.bias[ee % f.n_cols];
+      if (f.act == TRL_ACT_TANH) v = trl_tanh(v);
+      else if (f.act == TRL_ACT_RELU) v = fmaxf(v, 0.0f);
     }
     int eo = ee;
-    if (!second && perm_c > 0) {                   // weight gradient computed in (i, j, c) column order: store as (c, i, j)
-      const int K = perm_c * perm_khw, row = ee / K, kp = ee - row * K, ij = kp / perm_c, c = kp - ij * perm_c;
-      eo = row * K + c * perm_khw + ij;
+    if (!second && f.perm_c > 0) {                 // store as (c, i, j)
+      const int K = f.perm_c * f.perm_khw, row = ee / K, kp = ee - row * K, ij = kp / f.perm_c, c = kp - ij * f.perm_c;
+      eo = row * K + c * f.perm_khw + ij;
     }
-    (second ? out2 : out)[eo] = v;
+    (second ? q.out2 : q.out)[eo] = v;
   }
+}
+
+static int launch_fold(FoldDev f, int groups, hipStream_t s) {
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)f.n + f.n2, FOLD_OUT), groups), dim3(256), 0, s, f);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
 }
 
 int trl_fold_partials(const float* part, float* out, int n, const float* part2, float* out2, int n2, int splits,
                       hipStream_t stream) {
-  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)n + n2, FOLD_OUT)), dim3(256), 0, stream, part, out, n,
-                     part2, out2, n2, splits, (const float*)nullptr, 0, TRL_ACT_NONE, 0, 0);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
+  FoldDev f{};
+  f.n = n; f.n2 = n2; f.splits = splits;
+  f.grp[0] = FoldGroup{part, out, part2, out2};
+  return launch_fold(f, 1, stream);
 }
 
 template <bool TA, bool TB, int GATE, int CONV, int WM>
@@ -414,7 +438,7 @@ static int launch_gemm_tile(GemmDev g, int splits, hipStream_t s) {
   }
   g.tiles_n = trl_ceil_div(g.N, GN);
   g.tiles = g.tiles_n * trl_ceil_div(g.M, GM);
-  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE, CONV, WM>), dim3(g.tiles, 1, splits), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE, CONV, WM>), dim3(g.tiles, std::max(1, g.groups), splits), dim3(256), lds, s, g);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -433,7 +457,7 @@ static int launch_gemm_gate(const GemmDev& g, int splits, hipStream_t s) {
 
 template <bool TA, bool TB, int CONV = 0>
 static int launch_gemm(const GemmDev& g, int splits, hipStream_t s) {
-  const int gate = g.a_gate ? g.gate_act : TRL_ACT_NONE;
+  const int gate = (g.groups > 1 ? g.grp[0].a_gate : g.a_gate) ? g.gate_act : TRL_ACT_NONE;
   if (gate == TRL_ACT_TANH) return launch_gemm_gate<TA, TB, TRL_ACT_TANH, CONV>(g, splits, s);
   if (gate == TRL_ACT_RELU) return launch_gemm_gate<TA, TB, TRL_ACT_RELU, CONV>(g, splits, s);
   return launch_gemm_gate<TA, TB, TRL_ACT_NONE, CONV>(g, splits, s);
@@ -449,16 +473,30 @@ static int bw_split_len(int M, int K, int N) {
   return std::max(256, len);
 }
 
-extern "C" int trl_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
-                                  int act, void* stream) {
+static int linear_fwd_impl(int G, const float* const* x, const float* const* w, const float* const* bias, float* const* y,
+                           int M, int K, int N, int act, hipStream_t stream) {
+  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..8 problems per grouped launch");
   TRL_REQUIRE(M >= 0 && K > 0 && N > 0, "bad sizes");
   if (M == 0) return TRL_OK;
-  TRL_REQUIRE(x && w && y, "null pointer");
   TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
   GemmDev g{};
-  g.A = x; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = N; g.K = K;
-  g.lda = K; g.ldb = K; g.ldc = N; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
-  return launch_gemm<false, true>(g, 1, (hipStream_t)stream);
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K;
+  g.groups = G;
+  for (int i = 0; i < G; ++i) {
+    TRL_REQUIRE(x[i] && w[i] && y[i], "null pointer");
+    g.grp[i] = GemmGroup{x[i], w[i], y[i], bias ? bias[i] : nullptr, nullptr, nullptr};
+  }
+  g.A = x[0]; g.B = w[0]; g.C = y[0]; g.bias = bias ? bias[0] : nullptr;
+  return launch_gemm<false, true>(g, 1, stream);
+}
+extern "C" int trl_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
+                                  int act, void* stream) {
+  return linear_fwd_impl(1, &x, &w, &bias, &y, M, K, N, act, (hipStream_t)stream);
+}
+extern "C" int trl_linear_fwd_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
+                                        float* const* y, int M, int K, int N, int act, void* stream) {
+  TRL_REQUIRE(x && w && y, "null pointer array");
+  return linear_fwd_impl(G, x, w, bias, y, M, K, N, act, (hipStream_t)stream);
 }
 
 // Split-K forward for few-row layers with a long reduction (the conv nets' first FC layer: 512 x 3136 -> 512 is
@@ -489,21 +527,37 @@ extern "C" int trl_linear_fwd_splitk_f32(const float* x, const float* w, const f
   g.lda = K; g.ldb = K; g.ldc = N; g.act = TRL_ACT_NONE; g.gate_act = TRL_ACT_NONE; g.split_len = split_len; g.colsum = nullptr;
   int rc = launch_gemm<false, true>(g, splits, (hipStream_t)stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)M * N, FOLD_OUT)), dim3(256), 0, (hipStream_t)stream,
-                     workspace, y, M * N, (const float*)nullptr, (float*)nullptr, 0, splits, bias, N, act, 0, 0);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
+  FoldDev f{};
+  f.n = M * N; f.n2 = 0; f.splits = splits; f.bias = bias; f.n_cols = N; f.act = act;
+  f.grp[0] = FoldGroup{workspace, y, nullptr, nullptr};
+  return launch_fold(f, 1, (hipStream_t)stream);
 }
 
-extern "C" int trl_linear_bwd_input_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
-                                        int M, int K, int N, void* stream) {
+static int linear_bwd_input_impl(int G, const float* const* dy, const float* const* y_gate, int gate_act,
+                                 const float* const* w, float* const* dx, int M, int K, int N, hipStream_t stream) {
+  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..8 problems per grouped launch");
   TRL_REQUIRE(M >= 0 && K > 0 && N > 0, "bad sizes");
   if (M == 0) return TRL_OK;
-  TRL_REQUIRE(dy && w && dx, "null pointer");
   GemmDev g{};
-  g.A = dy; g.a_gate = y_gate; g.gate_act = gate_act; g.B = w; g.C = dx; g.bias = nullptr;
-  g.M = M; g.N = K; g.K = N; g.lda = N; g.ldb = K; g.ldc = K; g.act = TRL_ACT_NONE; g.split_len = N; g.colsum = nullptr;
-  return launch_gemm<false, false>(g, 1, (hipStream_t)stream);
+  g.gate_act = gate_act; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldb = K; g.ldc = K; g.act = TRL_ACT_NONE; g.split_len = N;
+  g.groups = G;
+  const bool gated = y_gate && y_gate[0];
+  for (int i = 0; i < G; ++i) {
+    TRL_REQUIRE(dy[i] && w[i] && dx[i], "null pointer");
+    TRL_REQUIRE(!gated || y_gate[i], "either every problem of a group is gated or none");
+    g.grp[i] = GemmGroup{dy[i], w[i], dx[i], nullptr, gated ? y_gate[i] : nullptr, nullptr};
+  }
+  g.A = dy[0]; g.B = w[0]; g.C = dx[0]; g.a_gate = g.grp[0].a_gate;
+  return launch_gemm<false, false>(g, 1, stream);
+}
+extern "C" int trl_linear_bwd_input_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
+                                        int M, int K, int N, void* stream) {
+  return linear_bwd_input_impl(1, &dy, &y_gate, gate_act, &w, &dx, M, K, N, (hipStream_t)stream);
+}
+extern "C" int trl_linear_bwd_input_group_f32(int G, const float* const* dy, const float* const* y_gate, int gate_act,
+                                              const float* const* w, float* const* dx, int M, int K, int N, void* stream) {
+  TRL_REQUIRE(dy && w && dx, "null pointer array");
+  return linear_bwd_input_impl(G, dy, y_gate, gate_act, w, dx, M, K, N, (hipStream_t)stream);
 }
 
 extern "C" int trl_linear_bwd_weight_workspace(int M, int K, int N) {
@@ -513,32 +567,49 @@ extern "C" int trl_linear_bwd_weight_workspace(int M, int K, int N) {
 }
 
 template <int CONV>
-static int bwd_weight_impl(const float* dy, const float* y_gate, int gate_act, const float* x, const ConvSrc* cv, float* dw,
-                           float* db, float* workspace, int M, int K, int N, hipStream_t s) {
+static int bwd_weight_impl(int G, const float* const* dy, const float* const* y_gate, int gate_act, const float* const* x,
+                           const ConvSrc* cv, float* const* dw, float* const* db, float* workspace, int M, int K, int N,
+                           hipStream_t s) {
+  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..8 problems per grouped launch");
   const int split_len = bw_split_len(M, K, N);
   const int splits = trl_ceil_div(M, split_len);
+  const size_t per = (size_t)splits * ((size_t)N * K + N);       // workspace floats of one problem
   GemmDev g{};
-  g.A = dy; g.a_gate = y_gate; g.gate_act = gate_act; g.B = x; g.C = workspace; g.bias = nullptr;
-  g.M = N; g.N = K; g.K = M; g.lda = N; g.ldb = K; g.ldc = K; g.act = TRL_ACT_NONE; g.split_len = split_len;
-  g.colsum = db ? workspace + (size_t)splits * N * K : nullptr;
+  g.gate_act = gate_act; g.M = N; g.N = K; g.K = M; g.lda = N; g.ldb = K; g.ldc = K; g.act = TRL_ACT_NONE;
+  g.split_len = split_len; g.groups = G;
   if (cv) g.cv = *cv;
+  const bool gated = y_gate && y_gate[0];
+  const bool want_db = db && db[0];
+  FoldDev f{};
+  f.n = N * K; f.n2 = want_db ? N : 0; f.splits = splits;
+  f.perm_c = CONV == 4 ? cv->C : 0; f.perm_khw = CONV == 4 ? cv->kh * cv->kw : 0;
+  for (int i = 0; i < G; ++i) {
+    TRL_REQUIRE(dy[i] && dw[i] && (CONV != 0 || x[i]), "null pointer");
+    TRL_REQUIRE(!gated || y_gate[i], "either every problem of a group is gated or none");
+    TRL_REQUIRE(!want_db || db[i], "either every problem of a group wants db or none");
+    float* part = workspace + i * per;
+    float* cpart = want_db ? part + (size_t)splits * N * K : nullptr;
+    g.grp[i] = GemmGroup{dy[i], CONV != 0 ? nullptr : x[i], part, nullptr, gated ? y_gate[i] : nullptr, cpart};
+    f.grp[i] = FoldGroup{part, dw[i], cpart, want_db ? db[i] : nullptr};
+  }
+  g.A = g.grp[0].A; g.B = g.grp[0].B; g.C = g.grp[0].C; g.a_gate = g.grp[0].a_gate; g.colsum = g.grp[0].colsum;
   int rc = launch_gemm<true, false, CONV>(g, splits, s);
   if (rc) return rc;
-  const int n2 = db ? N : 0;
-  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)N * K + n2, FOLD_OUT)), dim3(256), 0, s, workspace, dw,
-                     N * K, g.colsum, db, n2, splits, (const float*)nullptr, 0, TRL_ACT_NONE, CONV == 4 ? cv->C : 0,
-                     CONV == 4 ? cv->kh * cv->kw : 0);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
+  return launch_fold(f, G, s);
 }
-
 extern "C" int trl_linear_bwd_weight_f32(const float* dy, const float* y_gate, int gate_act, const float* x, float* dw,
                                          float* db, float* workspace, int M, int K, int N, void* stream) {
   TRL_REQUIRE(M > 0 && K > 0 && N > 0, "bad sizes");
   TRL_REQUIRE(dy && x && dw && workspace, "null pointer");
-  return bwd_weight_impl<0>(dy, y_gate, gate_act, x, nullptr, dw, db, workspace, M, K, N, (hipStream_t)stream);
+  return bwd_weight_impl<0>(1, &dy, &y_gate, gate_act, &x, nullptr, &dw, &db, workspace, M, K, N, (hipStream_t)stream);
 }
-
+extern "C" int trl_linear_bwd_weight_group_f32(int G, const float* const* dy, const float* const* y_gate, int gate_act,
+                                               const float* const* x, float* const* dw, float* const* db, float* workspace,
+                                               int M, int K, int N, void* stream) {
+  TRL_REQUIRE(M > 0 && K > 0 && N > 0, "bad sizes");
+  TRL_REQUIRE(dy && x && dw && workspace, "null pointer array");
+  return bwd_weight_impl<0>(G, dy, y_gate, gate_act, x, nullptr, dw, db, workspace, M, K, N, (hipStream_t)stream);
+}
 // ---- first conv layer on uint8 frames as an implicit GEMM ----
 static int fill_conv(const char* who, const uint8_t* frames, int B, int C, int H, int W, int kh, int kw, int sh, int sw,
                      float scale, float shift, ConvSrc& cv, int& M, int& K) {
@@ -619,7 +690,7 @@ extern "C" int trl_conv_bwd_weight_nhwc_f32(const float* dy, const float* y_gate
   int M, K;
   int rc = fill_conv_nhwc("conv_bwd_weight_nhwc", x, B, C, H, W, kh, kw, sh, sw, cv, M, K);
   if (rc) return rc;
-  return bwd_weight_impl<4>(dy, y_gate, gate_act, nullptr, &cv, dw, db, workspace, M, K, Cout, (hipStream_t)stream);
+  return bwd_weight_impl<4>(1, &dy, &y_gate, gate_act, nullptr, &cv, &dw, &db, workspace, M, K, Cout, (hipStream_t)stream);
 }
 
 extern "C" int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout) {
@@ -643,5 +714,5 @@ extern "C" int trl_conv_bwd_weight_u8_f32(const float* dy, const float* y_gate, 
   if (rc) return rc;
   if (trl_conv1_direct_ok(K, Cout, dw))
     return trl_conv1_direct_bwdw(cv, dy, y_gate, gate_act, dw, db, workspace, M, K, Cout, (hipStream_t)stream);
-  return bwd_weight_impl<2>(dy, y_gate, gate_act, nullptr, &cv, dw, db, workspace, M, K, Cout, (hipStream_t)stream);
+  return bwd_weight_impl<2>(1, &dy, &y_gate, gate_act, nullptr, &cv, &dw, &db, workspace, M, K, Cout, (hipStream_t)stream);
 }

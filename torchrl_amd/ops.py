@@ -65,6 +65,43 @@ def mlp_backward(tape, d_out, grads=None, need_input=False, workspace=None):
     return d if need_input else None
 
 
+def mlp_forward_group(layers_list, xs, act, last_act=None):
+    """G same-shaped MLPs (or one MLP listed several times) on G inputs, one launch per layer instead of G:
+    returns ([out_g], [tape_g]); every tape works with `mlp_backward` / `mlp_backward_group`."""
+    G = len(layers_list)
+    tapes = []
+    for g in range(G):
+        t = Tape()
+        t.x, t.layers, t.act, t.outs = xs[g], layers_list[g], act, []
+        t.last_act = _C.ACT_NONE if last_act is None else last_act
+        tapes.append(t)
+    hs = list(xs)
+    n = len(layers_list[0])
+    for k in range(n):
+        code = tapes[0].last_act if k == n - 1 else act
+        hs = _C.linear_fwd_group(hs, [ls[k][0] for ls in layers_list], [ls[k][1] for ls in layers_list], code)
+        for t, h in zip(tapes, hs):
+            t.outs.append(h)
+    return hs, tapes
+
+
+def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspace=None):
+    """`mlp_backward` of G same-shaped tapes with grouped launches.  grads_list: [grads of tape g] or None."""
+    ds = list(d_outs)
+    n = len(tapes[0].layers)
+    for k in range(n - 1, -1, -1):
+        last = k == n - 1
+        gate_act = tapes[0].last_act if last else tapes[0].act
+        gates = [None if (last and gate_act == _C.ACT_NONE) else t.outs[k] for t in tapes]
+        if grads_list is not None:
+            inps = [t.x if k == 0 else t.outs[k - 1] for t in tapes]
+            _C.linear_bwd_weight_group(ds, gates, gate_act, inps, [g[k][0] for g in grads_list],
+                                       [g[k][1] for g in grads_list], workspace=workspace)
+        if k > 0 or need_input:
+            ds = _C.linear_bwd_input_group(ds, gates, gate_act, [t.layers[k][0] for t in tapes])
+    return ds if need_input else None
+
+
 # ---------------------------------------------------------------------------------------------
 # Conv trunks (CNNBase, torchrl/networks/base.py:59-107) + FC head, on im2col + the GEMM kernels.
 # Activations are channels-last; the first layer reads uint8 NCHW frame stacks and scales them
