@@ -166,8 +166,8 @@ class _FusedDetAC:
 
     # ---- helpers ----
     def _ws(self, B):
-        need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
-                   for ls in self.layers for w, _ in ls)
+        need = 2 * max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
+                       for ls in self.layers for w, _ in ls)               # x2: the twin critics' grouped weight gradient
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, device=self.dev)
         return self.workspace
@@ -207,8 +207,8 @@ class _FusedDetAC:
         (TRL_NO_GRAPH=1 keeps everything eager)."""
         algo = self.algo
         key = key + (self._lrs(), algo.grad_clip, algo.tau, algo.discount)
-        if os.environ.get("TRL_NO_GRAPH") == "1":
-            seq()
+        if os.environ.get("TRL_NO_GRAPH") == "1" or (key not in self._graphs and len(self._graphs) >= 8):
+            seq()                                                            # (a learning-rate schedule would mint a key per value)
         elif key in self._graphs:
             self._graphs[key].replay()
         elif key not in self._seen:
@@ -259,10 +259,11 @@ class _FusedDetAC:
         obs, acts, nobs, rew, term = self._flat(st)
         ws = self._ws(int(obs.shape[0]))
         pf_l, qf_l = self.layers
-        new_a, tape_pf, qn, tape_qn = self._policy_grad(obs, qf_l)
-        ta, _ = ops.mlp_forward(self.tlayers[0], nobs, self.act, last_act=self.pf_last)
-        tq, _ = ops.mlp_forward(self.tlayers[1], _C.concat2(nobs, ta), self.act)
-        qp, tape_q = ops.mlp_forward(qf_l, _C.concat2(obs, acts), self.act)
+        # policy on obs and target policy on next_obs, then the three critic passes, each as one grouped launch per layer
+        (new_a, ta), (tape_pf, _) = ops.mlp_forward_group([pf_l, self.tlayers[0]], [obs, nobs], self.act,
+                                                          last_act=self.pf_last)
+        (qn, tq, qp), (tape_qn, _, tape_q) = ops.mlp_forward_group(
+            [qf_l, self.tlayers[1], qf_l], [_C.concat2(obs, new_a), _C.concat2(nobs, ta), _C.concat2(obs, acts)], self.act)
         dq, _, dqn = _C.detac_losses(qp, None, tq, None, rew, term, qn, algo.discount, self.sums)
         dx = ops.mlp_backward(tape_qn, dqn, grads=None, need_input=True)
         ops.mlp_backward(tape_pf, _C.slice_add(dx, None, D, A), grads=self.gviews[0], workspace=ws)
@@ -300,15 +301,12 @@ class _FusedDetAC:
         if self.sigma_explore:
             ta = _C.noisy_action(ta, st["eps_explore"], self.sigma_explore)
         ta = _C.noisy_action(ta, st["eps_smooth"], algo.norm_std_policy, algo.noise_clip, -1.0, 1.0)
-        x_next = _C.concat2(nobs, ta)
-        tq1, _ = ops.mlp_forward(self.tlayers[1], x_next, self.act)
-        tq2, _ = ops.mlp_forward(self.tlayers[2], x_next, self.act)
-        x_sa = _C.concat2(obs, acts)
-        q1p, tape_q1 = ops.mlp_forward(q1_l, x_sa, self.act)
-        q2p, tape_q2 = ops.mlp_forward(q2_l, x_sa, self.act)
+        x_next, x_sa = _C.concat2(nobs, ta), _C.concat2(obs, acts)
+        # target Q1 / Q2 (s', a') and Q1 / Q2 (s, a): four same-shaped critics, one grouped launch per layer
+        (tq1, tq2, q1p, q2p), (_, _, tape_q1, tape_q2) = ops.mlp_forward_group(
+            [self.tlayers[1], self.tlayers[2], q1_l, q2_l], [x_next, x_next, x_sa, x_sa], self.act)
         dq1, dq2, _ = _C.detac_losses(q1p, q2p, tq1, tq2, rew, term, None, algo.discount, self.sums)
-        ops.mlp_backward(tape_q1, dq1, grads=self.gviews[1], workspace=ws)
-        ops.mlp_backward(tape_q2, dq2, grads=self.gviews[2], workspace=ws)
+        ops.mlp_backward_group([tape_q1, tape_q2], [dq1, dq2], grads_list=[self.gviews[1], self.gviews[2]], workspace=ws)
         self._adam((1, 2))
         if delayed:                                                          # policy step on the UPDATED Q1
             new_a, tape_pf, qn, tape_qn = self._policy_grad(obs, q1_l)

@@ -218,8 +218,8 @@ class _FusedSAC:
         (TRL_NO_GRAPH=1 keeps everything eager)."""
         key = (int(st["obs"].shape[0]), soft, self._lrs(), self.algo.grad_clip, self.algo.tau, self.algo.discount,
                bool(self.algo.automatic_entropy_tuning))
-        if os.environ.get("TRL_NO_GRAPH") == "1":
-            self._sequence(st, soft)
+        if os.environ.get("TRL_NO_GRAPH") == "1" or (key not in self._graphs and len(self._graphs) >= 8):
+            self._sequence(st, soft)                                     # (a learning-rate schedule would mint a key per value)
         elif key in self._graphs:
             self._graphs[key].replay()
         elif key not in self._seen:
