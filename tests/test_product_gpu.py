@@ -172,6 +172,28 @@ def test_example_script_runs_unchanged_api(tmp_path):
     assert os.path.exists(tmp_path / "log" / "ppo_small" / "SynthHalfCheetah-v0" / "1" / "model" / "model_pf_finish.pth")
 
 
+def test_single_env_example_cfg1(tmp_path):
+    """SURVEY.md 8(d) cfg 1 (pass / fail): the reference's examples/ppo_continuous.py wiring -- `get_env`,
+    `OnPolicyCollectorBase`, `OnPolicyReplayBuffer(size)` -- with config/ppo_halfcheetah.json's hyper-parameters
+    (N = 1, T = 2048, batch 64, 10 opt epochs, obs_norm) on the synthetic env id, a few epochs."""
+    import json
+    params = json.load(open(os.path.join(REPO, "config", "ppo_synth_halfcheetah_single.json")))
+    assert (params["replay_buffer"]["size"], params["general_setting"]["batch_size"], params["ppo"]["opt_epochs"],
+            params["env"]["obs_norm"]) == (2048, 64, 10, True)
+    params["general_setting"].update(num_epochs=3, eval_interval=1)
+    cfg = tmp_path / "ppo_single.json"
+    cfg.write_text(json.dumps(params))
+    out = subprocess.run([sys.executable, os.path.join(REPO, "examples", "ppo_continuous.py"), "--config", str(cfg),
+                          "--seed", "3", "--log_dir", str(tmp_path / "log"), "--overwrite"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "EPOCH:2" in out.stdout
+    assert "nan" not in out.stdout.lower()
+    model_dir = tmp_path / "log" / "ppo_single" / "SynthHalfCheetah-v0" / "3" / "model"
+    assert os.path.exists(model_dir / "model_pf_finish.pth")
+    assert any(f.startswith("_obs_normalizer") or "normalizer" in f for f in os.listdir(model_dir)), os.listdir(model_dir)
+
+
 def test_graph_replay_matches_eager_launches(golden, monkeypatch):
     """The captured-and-replayed minibatch loop (third and later epochs of a shape) must be bit-identical to
     launching the same kernels one by one: same parameters, same Adam state, same info dicts."""

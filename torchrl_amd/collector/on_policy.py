@@ -25,17 +25,6 @@ from .. import dist
 from .base import VecCollector, BaseCollector
 
 
-class OnPolicyCollectorBase(BaseCollector):
-    def __init__(self, vf, discount=0.99, **kwargs):
-        self.vf = vf
-        super().__init__(**kwargs)
-        self.discount = discount
-
-    @property
-    def funcs(self):
-        return {"pf": self.pf, "vf": self.vf}
-
-
 class VecOnPolicyCollector(VecCollector):
     def __init__(self, vf, discount=0.99, noise_mode="host", **kwargs):
         self.vf = vf
@@ -251,3 +240,15 @@ class VecOnPolicyCollector(VecCollector):
             rews += [np.float32(first[i][0]) for i in sorted(first)]
             lens += [first[i][1] for i in sorted(first)]
         return {"eval_rewards": rews, "eval_traj_length": float(np.mean(lens)) if lens else 0.0}
+
+
+class OnPolicyCollectorBase(VecOnPolicyCollector):
+    """The reference's single-env on-policy collector (torchrl/collector/on_policy.py:8-60): here simply the vector
+    collector on a one-env device env (`torchrl.env.get_env`), so `examples/ppo_continuous.py` runs on the same
+    kernels (SURVEY.md 8(d) cfg 1)."""
+
+    def __init__(self, vf, discount=0.99, **kwargs):
+        super().__init__(vf, discount=discount, **kwargs)
+        if self.env.env_nums != 1:
+            raise _C.TrlError("OnPolicyCollectorBase drives a single env (torchrl.env.get_env); "
+                              "use VecOnPolicyCollector for %d envs" % self.env.env_nums)
