@@ -1,0 +1,135 @@
+"""Host Python envs under the device collectors: `torchrl.env.VecEnv` over single-env
+objects with the gym interface, bridged to the same HIP kernels.  The pure-Python stand-in env has the synthetic
+dynamics, so the host path must reproduce what the REFERENCE collected for the same seeds
+(tests/golden/collect_epoch.npz, obs_norm.npz) and what the on-GPU env path stores."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.synth_env import SynthSingleEnvCPU
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def host_vec_env(N, horizon, seed):
+    from torchrl.env import VecEnv
+    # the reference's VecEnv.seed gives env i the seed s * N + i (vecenv.py:63-65)
+    return VecEnv(N, [SynthSingleEnvCPU] * N, [(seed * N + i, horizon) for i in range(N)])
+
+
+def nets(g, pf_prefix, vf_prefix):
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=17, output_shape=6, tanh_action=True, **net)
+    vf = networks.Net(input_shape=(17,), output_shape=1, **net)
+    for prefix, mod in ((pf_prefix, pf), (vf_prefix, vf)):
+        mod.load_state_dict({k[len(prefix):].replace("__", "."): torch.tensor(g[k]) for k in g.files if k.startswith(prefix)})
+    return pf, vf
+
+
+def test_vecenv_protocol():
+    env = host_vec_env(5, horizon=3, seed=2)
+    obs = env.reset()
+    assert obs.shape == (5, 17) and env.env_nums == 5 and env.observation_space.shape == (17,)
+    nxt, rew, done, infos = env.step(np.zeros((5, 6)))
+    assert nxt.shape == (5, 17) and rew.shape == (5, 1) and done.shape == (5, 1) and done.dtype == bool
+    assert infos["time_limit"].shape == (5,)
+    mask = np.array([0, 1, 0, 0, 1], dtype=bool)
+    whole = env.partial_reset(mask)                                    # the WHOLE array comes back (vecenv.py:47-51)
+    assert whole.shape == (5, 17) and np.array_equal(whole[0], nxt[0]) and not np.array_equal(whole[1], nxt[1])
+    assert env.horizon == 3                                            # unknown attributes fall through to envs[0]
+
+
+@pytest.mark.parametrize("tag", ["small", "surpass", "mixed"])
+def test_host_env_collect_matches_reference_and_trains(golden, tag):
+    from torchrl.algo import PPO
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    from test_product_gpu import ListLogger
+    g = golden("collect_epoch")
+    N, T, horizon, max_frames, B, seed = (int(x) for x in g[f"{tag}_args"])
+    pf, vf = nets(g, tag + "_pf0_", tag + "_vf0_")
+    env = host_vec_env(N, horizon, seed)
+    buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+    col = VecOnPolicyCollector(vf, env=env, eval_env=host_vec_env(N, horizon, seed + 1), pf=pf, replay_buffer=buf,
+                               device=torch.device(DEV), train_render=False, epoch_frames=N * T,
+                               max_episode_frames=max_frames, eval_episodes=1)
+    assert col.env.is_host_env and col.env.venv is env
+    torch.manual_seed(seed)
+    res = col.train_one_epoch()
+    for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+        err = np.abs(getattr(buf, "_" + k).cpu().numpy() - g[f"{tag}_buf_{k}"]).max()
+        assert err < 1e-5, (k, err)
+    assert abs(res["train_epoch_reward"] - float(g[f"{tag}_train_epoch_reward"])) < 1e-3
+    np.testing.assert_allclose(np.array(res["train_rewards"], dtype=np.float64), g[f"{tag}_train_rewards"], atol=1e-4)
+    logger = ListLogger()
+    agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=2, tau=0.95, shuffle=True,
+                entropy_coeff=0.005, discount=0.99, num_epochs=10, batch_size=B, gae=True, env=col.env,
+                replay_buffer=buf, collector=col, logger=logger, device=torch.device(DEV), save_dir=None)
+    p0 = pf.flat_params().clone()
+    agent.current_epoch = 0
+    agent.update_per_epoch()
+    assert logger.infos and all(np.isfinite(list(i.values())).all() for i in logger.infos)
+    assert (pf.flat_params() - p0).abs().max() > 0
+    ev = col.eval_one_epoch()
+    assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == horizon
+
+
+@pytest.mark.parametrize("tag", ["flow", "flow_surpass"])
+def test_host_env_with_obs_normaliser_matches_reference(golden, tag):
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env import HostEnvBridge, NormObs
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    g = golden("obs_norm")
+    N, T, horizon, max_frames, seed = (int(v) for v in g[tag + "_args"])
+    pf, vf = nets(g, tag + "_pf_", tag + "_vf_")
+    env = NormObs(HostEnvBridge(host_vec_env(N, horizon, seed), DEV))
+    buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+    col = VecOnPolicyCollector(vf, env=env, eval_env=None, pf=pf, replay_buffer=buf, device=torch.device(DEV),
+                               train_render=False, epoch_frames=N * T, max_episode_frames=max_frames, eval_episodes=1)
+    np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_ob0"], rtol=1e-5, atol=2e-6)
+    torch.manual_seed(seed)
+    res = col.train_one_epoch()
+    for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+        err = np.abs(getattr(buf, "_" + k).cpu().numpy() - g[tag + "_buf_" + k]).max()
+        assert err < 2e-5, (k, err)
+    np.testing.assert_allclose(env._obs_normalizer.state.cpu().numpy(), g[tag + "_state1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_current_ob"], atol=2e-5)
+    assert abs(res["train_epoch_reward"] - float(g[tag + "_train_epoch_reward"])) < 1e-3
+
+
+def test_host_env_off_policy_collector_matches_device_env():
+    """VecCollector (SAC-style policy) on a host VecEnv stores the same replay rows as on the on-GPU env."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector import VecCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    N, steps, horizon, max_frames, seed = 8, 30, 11, 7, 4
+    dev = torch.device(DEV)
+    net = dict(hidden_shapes=[32, 32], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    torch.manual_seed(0)
+    pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net)
+    rows = {}
+    for kind in ("device", "host"):
+        if kind == "device":
+            env = SynthVecEnv(N, horizon=horizon, device=dev)
+            env.seed(seed)
+            eval_env = SynthVecEnv(N, horizon=horizon, device=dev)
+        else:
+            env, eval_env = host_vec_env(N, horizon, seed), host_vec_env(N, horizon, seed + 1)
+        buf = BaseReplayBuffer(N * steps, env_nums=N)
+        col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, train_render=False,
+                           epoch_frames=N * steps, max_episode_frames=max_frames, eval_episodes=1)
+        torch.manual_seed(seed)
+        res = col.train_one_epoch()
+        rows[kind] = ({k: getattr(buf, "_" + k).cpu().numpy().copy() for k in
+                       ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits")}, res)
+        ev = col.eval_one_epoch()
+        assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == horizon
+    for k, v in rows["device"][0].items():
+        np.testing.assert_allclose(rows["host"][0][k], v, atol=2e-6, err_msg=k)
+    assert abs(rows["host"][1]["train_epoch_reward"] - rows["device"][1]["train_epoch_reward"]) < 1e-3
+    np.testing.assert_allclose(rows["host"][1]["train_rewards"], rows["device"][1]["train_rewards"], atol=1e-4)

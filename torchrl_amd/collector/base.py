@@ -21,11 +21,19 @@ from .. import _C
 class BaseCollector:
     def __init__(self, env, eval_env, pf, replay_buffer, epoch_frames, train_render=False,
                  eval_episodes=1, eval_render=False, device='cpu', max_episode_frames=999):
+        from ..env.vecenv import HostEnvBridge, VecEnv
+        if isinstance(env, VecEnv):                                          # host Python envs: bridge to the device path
+            env = HostEnvBridge(env, device)
+        if eval_env is None and getattr(env, "is_host_env", False) and not hasattr(env, "_obs_normalizer"):
+            eval_env = HostEnvBridge(copy.deepcopy(env.venv), device)
+        if isinstance(eval_env, VecEnv):
+            eval_env = HostEnvBridge(eval_env, device)
         self.pf = pf
         self.replay_buffer = replay_buffer
         self.env = env
         self.env.train()
-        self.continuous = isinstance(self.env.action_space, gym.spaces.Box)
+        space = self.env.action_space                                       # Box of this package's shim or of a real gym
+        self.continuous = isinstance(space, gym.spaces.Box) or (hasattr(space, "shape") and not hasattr(space, "n"))
         self.train_render = train_render
         if eval_env is not None:
             self.eval_env = eval_env
@@ -92,9 +100,9 @@ class VecCollector(BaseCollector):
     def __init__(self, noise_mode="host", **kwargs):
         super().__init__(**kwargs)
         self.sample_epoch_frames //= self.env.env_nums
-        if not getattr(self.env, "is_device_env", False):
-            raise _C.TrlError("torchrl_amd collectors need an on-GPU env (torchrl_amd.env.get_vec_env); "
-                              "host gym envs have no kernel path")
+        if not (getattr(self.env, "is_device_env", False) or getattr(self.env, "is_host_env", False)):
+            raise _C.TrlError("torchrl_amd collectors drive an on-GPU env (torchrl_amd.env.get_vec_env) or a host "
+                              "torchrl_amd.env.VecEnv of Python envs")
         if noise_mode not in ("host", "device"):
             raise ValueError("noise_mode must be 'host' or 'device'")
         self.noise_mode = noise_mode
@@ -109,6 +117,23 @@ class VecCollector(BaseCollector):
         self._noise_seed = 0xC011
 
     # ---- pieces shared with the on-policy subclass ----
+    def _env_advance(self, env, act, nxt, rew, done, time_limits=None):
+        """One env.step: fills the device rows next_obs / rewards / dones (/ time_limits)."""
+        if getattr(env, "is_host_env", False):                              # host Python envs: actions out, results in
+            env.host_step(act, nxt, rew, done, time_limits)
+            return
+        _C.synth_env_step(env.cur_obs, act, env.env_A, env.env_B, env.t_env, env.effective_reward_scale,
+                          env.horizon, nxt, rew, done)
+        if time_limits is not None:
+            time_limits.copy_(done)                                         # synthetic env: time_limit == done
+
+    def _env_reset_masked(self, env):
+        """env.partial_reset(self._mask); env.cur_obs then holds the whole (raw) observation array."""
+        if getattr(env, "is_host_env", False):
+            env.host_partial_reset(self._mask)
+        else:
+            _C.synth_reset(env.cur_obs, env.t_env, env.cur_step, env.episode_idx, env.ep_return, self._mask, env.seed_base)
+
     def _read_header(self):
         """(epoch reward, finished-episode count) with a single host sync."""
         h = self._hdr.cpu()
@@ -179,14 +204,11 @@ class VecCollector(BaseCollector):
             nxt = torch.empty(n, d, device=env.device)
             rew = torch.empty(n, 1, device=env.device)
             done = torch.empty(n, 1, device=env.device)
-        _C.synth_env_step(env.cur_obs, act, env.env_A, env.env_B, env.t_env, env.effective_reward_scale,
-                          env.horizon, nxt, rew, done)
-        if store:
-            buf._ensure_key("time_limits", (n, 1))[row].copy_(done)           # synthetic env: time_limit == done
+        self._env_advance(env, act, nxt, rew, done, buf._ensure_key("time_limits", (n, 1))[row] if store else None)
         _C.collector_bookkeep(rew, done, env.cur_step, env.ep_return,
                               self.max_episode_frames if max_frames is None else max_frames, self._mask,
                               self._epoch_reward, self._ep_count, self._ep_log, self.global_step)
-        _C.synth_reset(env.cur_obs, env.t_env, env.cur_step, env.episode_idx, env.ep_return, self._mask, env.seed_base)
+        self._env_reset_masked(env)
         if store:
             buf._advance()
         self.global_step += 1
@@ -252,6 +274,13 @@ class VecCollector(BaseCollector):
         self.rollout(1)
         return float(self._epoch_reward.item())
 
+    def _eval_steps(self, env):
+        """Device envs end every episode at `horizon`; host envs run until each env has reported `done` once
+        (`while not np.all(epi_done)`, base.py:252) -- at most `horizon` steps when they advertise one."""
+        if getattr(env, "is_host_env", False):
+            return int(env.horizon) if env.horizon else 1 << 30
+        return int(env.horizon)
+
     def eval_one_epoch(self):
         """Greedy evaluation (base.py:232-280): action = tanh(mean); first episode of every eval env."""
         env = self.eval_env
@@ -261,8 +290,11 @@ class VecCollector(BaseCollector):
             env.reset()
             self._clear_header()
             step0 = self.global_step
-            for _ in range(env.horizon):
+            for _ in range(self._eval_steps(env)):
                 self._step(env, False, deterministic=True, max_frames=2 ** 31 - 1)
+                if getattr(env, "is_host_env", False) and int(self._ep_count.item()) >= env.env_nums \
+                        and len({int(i) for _, i, _ in self._finished_episodes()}) == env.env_nums:
+                    break                                                   # every env has finished its first episode
             first = {}
             for step, idx, ret in self._finished_episodes():
                 first.setdefault(int(idx), (ret, int(step) - step0 + 1))

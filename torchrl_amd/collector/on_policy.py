@@ -52,7 +52,7 @@ class VecOnPolicyCollector(VecCollector):
     def _fused_norm_ok(self, env, update):
         """The persistent kernel carries a normalised env when its workgroups can all be resident (they meet once
         per step to pool the observation statistics) and the statistics are not shared between GPUs."""
-        if not hasattr(env, "_obs_normalizer") or getattr(self, "force_per_step", False):
+        if not hasattr(env, "_obs_normalizer") or getattr(self, "force_per_step", False) or getattr(env, "is_host_env", False):
             return False
         if update and dist.collectives_active():
             return False
@@ -129,10 +129,13 @@ class VecOnPolicyCollector(VecCollector):
         return sb
 
     def _step_normed(self, env, ob, store, deterministic, noise_t, step, max_frames=None):
-        """One take_actions (torchrl/collector/on_policy.py:90-155) as ~12 launches; `ob` is what the policy
-        sees (normalised, or raw right after a reset -- the reference's Q14); returns the next policy input."""
+        """One take_actions (torchrl/collector/on_policy.py:90-155) as ~12 launches, for envs the persistent rollout
+        kernel cannot carry: a running observation normaliser shared between GPUs or too large for one co-resident
+        grid, and host Python envs (`torchrl_amd.env.VecEnv`).  `ob` is what the policy sees (normalised, or raw
+        right after a reset -- the reference's Q14); returns the next policy input."""
         D, H, A, act = self._spec
-        N, buf, sb, nz = env.env_nums, self.replay_buffer, self._step_buffers(env), env._obs_normalizer
+        N, buf, sb = env.env_nums, self.replay_buffer, self._step_buffers(env)
+        nz = getattr(env, "_obs_normalizer", None)
         if store:
             row = buf._top
             feats = (("obs", D), ("next_obs", D), ("acts", A), ("values", 1), ("rewards", 1), ("terminals", 1),
@@ -151,18 +154,18 @@ class VecOnPolicyCollector(VecCollector):
             eps = _C.philox_normal(sb["eps"], self._noise_seed, self.global_step)
         _C.gauss_explore(mean, self.pf.logstd.detach(), eps, bool(self.pf.tanh_action), act=r["acts"],
                          logp=r["old_logp"].view(N))
-        _C.synth_env_step(env.cur_obs, r["acts"], env.env_A, env.env_B, env.t_env, env.effective_reward_scale,
-                          env.horizon, sb["nxt_raw"], r["rewards"], sb["done"])
-        nz.update_filt(sb["nxt_raw"], update=env.training, out=r["next_obs"])          # NormObs.observation
+        raw_next = sb["nxt_raw"] if nz is not None else r["next_obs"]
+        self._env_advance(env, r["acts"], raw_next, r["rewards"], sb["done"], r["time_limits"])
+        if nz is not None:
+            nz.update_filt(raw_next, update=env.training, out=r["next_obs"])            # NormObs.observation
         _C.mlp2_forward(self.vf.flat_params(), r["next_obs"], D, H, 1, act, out=sb["v_next"])
-        r["time_limits"].copy_(sb["done"])                                            # synthetic env: time_limit == done
         sb["any"].zero_()
         _C.onpolicy_bookkeep(r["rewards"], sb["done"], sb["v_next"], self.discount, r["terminals"], env.cur_step,
                              env.ep_return, self.max_episode_frames if max_frames is None else max_frames, self._mask,
                              sb["any"], self._epoch_reward, self._ep_count, self._ep_log, step)
-        _C.synth_reset(env.cur_obs, env.t_env, env.cur_step, env.episode_idx, env.ep_return, self._mask, env.seed_base)
+        self._env_reset_masked(env)
         # partial_reset returns the RAW observations of all envs (base_wrapper.py:23-26, vecenv.py:47-51)
-        alt = nz.filt(env.cur_obs) if getattr(env, "normalize_partial_reset", False) else env.cur_obs
+        alt = nz.filt(env.cur_obs) if (nz is not None and getattr(env, "normalize_partial_reset", False)) else env.cur_obs
         nxt = torch.empty(N, D, device=env.device)
         _C.select_on_flag(sb["any"], alt, r["next_obs"], nxt)
         if store:
@@ -184,6 +187,8 @@ class VecOnPolicyCollector(VecCollector):
     def rollout(self, n_steps):
         """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""
         self.env.train()
+        if getattr(self.env, "is_host_env", False):                        # host Python envs: per-step launch sequence
+            return self._rollout_normed(n_steps)
         if hasattr(self.env, "_obs_normalizer"):
             nz = self.env._obs_normalizer
             if not self._fused_norm_ok(self.env, self.env.training and nz.should_estimate):
@@ -225,7 +230,13 @@ class VecOnPolicyCollector(VecCollector):
         rews, lens = [], []
         for _ in range(self.eval_episodes):
             ob = env.reset()
-            if hasattr(env, "_obs_normalizer") and self._fused_norm_ok(env, False):
+            if getattr(env, "is_host_env", False):
+                self._clear_header()
+                for t in range(self._eval_steps(env)):
+                    ob = self._step_normed(env, ob, False, True, None, t, max_frames=2 ** 31 - 1)
+                    if len({int(i) for _, i, _ in self._finished_episodes()}) == env.env_nums:
+                        break                                               # every env finished its first episode
+            elif hasattr(env, "_obs_normalizer") and self._fused_norm_ok(env, False):
                 self._launch(env, env.horizon, False, True, None, max_frames=2 ** 31 - 1, policy_ob=ob.contiguous().clone())
             elif hasattr(env, "_obs_normalizer"):
                 self._clear_header()

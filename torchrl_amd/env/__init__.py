@@ -4,3 +4,4 @@ from .base_wrapper import Normalizer, NormObs
 
 VecEnv = SynthVecEnv
 SubProcVecEnv = SynthVecEnv
+from .vecenv import VecEnv, HostEnvBridge
