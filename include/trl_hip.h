@@ -81,6 +81,8 @@ int trl_adv_stats_f64(const float* advs, const int64_t* row_idx, int n_mb, int r
  * and the policy mean.  x: (M, D) -> out: (M, O). */
 int trl_mlp2_forward_f32(const float* params, const float* x, float* out,
                          int M, int D, int H, int O, int act, void* stream);
+/* 1 if trl_mlp2_forward_f32 is instantiated for this shape (callers fall back to trl_linear_fwd_f32 per layer) */
+int trl_mlp2_forward_supported(int D, int H, int O);
 
 /* --- K1+K2+K3: fused vectorised rollout on the synthetic env ---------------
  * replaces VecOnPolicyCollector.take_actions x n_steps
@@ -202,6 +204,24 @@ int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* args, void* stream);
 int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
                        int D, int H, int A, const float* pf_params, float* grads, double* info,
                        void* stream);
+
+/* --- K7/K8 for arbitrary network shapes: the loss half of an update --------
+ * replaces everything of PPO.update_actor / update_critic (ppo.py:41-122) and A2C.update (a2c.py:45-106)
+ * that sits BETWEEN the networks' forward and backward passes, for networks the fused kernel
+ * (trl_ppo_minibatch_grad_f32) is not instantiated for; the layers themselves run on trl_linear_*:
+ *   mean (B, A), v (B): outputs of the policy / value networks on this minibatch;  logstd (A): state-independent
+ *   acts (B, A), advs / rets / v_old / old_logp (B): the stored rows;  adv_raw: the minibatch's {sum, sumsq, ...}
+ *   from trl_adv_stats_f64 and n_global its sample count (advantage normalisation, ppo.py:141-147)
+ *   -> d_mean (B, A), d_v (B), d_logstd (A) and info (24 doubles, trl_ppo_reduce_f32's layout; the sums are
+ *      over the local samples, divide by the count on the host).
+ * Same per-sample arithmetic as the fused kernel.  workspace: trl_ppo_generic_losses_workspace(B, A) doubles. */
+int trl_ppo_generic_losses_workspace(int B, int A);
+int trl_ppo_generic_losses_f32(const float* mean, const float* logstd, const float* acts, const float* advs,
+                               const float* old_logp, const float* v, const float* rets, const float* v_old,
+                               const double* adv_raw, double n_global, int B, int A, float clip_para,
+                               float entropy_coeff, int clipped_value_loss, int tanh_action, int loss_mode,
+                               float* d_mean, float* d_v, float* d_logstd, double* info, double* workspace,
+                               void* stream);
 
 /* --- K11: global-norm clip + Adam ------------------------------------------
  * replaces clip_grad_norm_(params, max_norm) + Adam(eps).step()

@@ -31,8 +31,10 @@ def _nets(g, tag):
     return pf, vf
 
 
+@pytest.mark.parametrize("engine", ["fused", "generic"])
 @pytest.mark.parametrize("tag", ["small", "mid"])
-def test_a2c_update_matches_reference(golden, tag):
+def test_a2c_update_matches_reference(golden, tag, engine, monkeypatch):
+    monkeypatch.setenv("TRL_GENERIC_PPO", "1" if engine == "generic" else "0")   # generic: arbitrary-shape engine
     from torchrl.algo import A2C
     from torchrl.env.synth import SynthVecEnv
     g = golden("a2c_update")

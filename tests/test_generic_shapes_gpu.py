@@ -1,0 +1,137 @@
+"""PPO / A2C for network shapes the fused kernels are not instantiated for (other observation / action sizes,
+widths, depths): dense-layer GEMMs + trl_ppo_generic_losses_f32.  The same engine forced onto the benchmark shape
+is checked against the REFERENCE's outputs in test_product_gpu.py / test_a2c_gpu.py (engine = generic); here the
+shapes differ and the check is against the CPU oracle (itself pinned to those reference outputs)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets
+from oracle.ppo import A2COracle, PPOOracle
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+class _Stub:
+    epoch_frames = 0
+
+
+class _Log:
+    def __init__(self): self.infos = []
+    def add_update_info(self, d): self.infos.append(dict(d))
+    def add_epoch_info(self, *a, **k): pass
+    def log(self, *a): pass
+    def finish(self): pass
+
+
+def build(D, A, hidden, act_cls, tanh_action, algo_cls, **algo_kw):
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.env.synth import SynthVecEnv
+    net = dict(hidden_shapes=hidden, append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=act_cls)
+    torch.manual_seed(D * 100 + A)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A, tanh_action=tanh_action, **net)
+    vf = networks.Net(input_shape=(D,), output_shape=1, **net)
+    with torch.no_grad():                                              # leave the near-zero init of the heads
+        for m in (pf, vf):
+            m.seq_append_fcs[-1].weight.mul_(30.0)
+        pf.logstd.copy_(torch.linspace(-1.5, -0.5, A))
+    flat = lambda m: [p.detach().clone() for l in (list(m.base.seq_fcs) + list(m.seq_append_fcs))
+                      if isinstance(l, torch.nn.Linear) for p in (l.weight, l.bias)]
+    oracle_params = (flat(pf), pf.logstd.detach().clone(), flat(vf))
+    agent = algo_cls(pf=pf, vf=vf, plr=3e-4, vlr=1e-3, tau=0.95, shuffle=True, discount=0.99, num_epochs=10,
+                     batch_size=96, gae=True, env=SynthVecEnv(4, obs_dim=D, act_dim=A, device=DEV), replay_buffer=None,
+                     collector=_Stub(), logger=_Log(), device=DEV, save_dir=None, **algo_kw)
+    return pf, vf, agent, oracle_params
+
+
+@pytest.mark.parametrize("D,A,hidden,act,tanh_action,clipped", [
+    (11, 3, [32, 48, 16], "tanh", True, False),       # Hopper-sized, three uneven hidden layers
+    (3, 1, [40], "relu", False, True),                # Pendulum-sized, one hidden layer, no tanh squashing, clipped value loss
+    (27, 8, [128, 128], "tanh", True, False),         # wide
+])
+def test_ppo_update_other_shapes_vs_oracle(D, A, hidden, act, tanh_action, clipped):
+    from torchrl.algo import PPO
+    act_cls = {"tanh": torch.nn.Tanh, "relu": torch.nn.ReLU}[act]
+    pf, vf, agent, (pf0, ls0, vf0) = build(D, A, hidden, act_cls, tanh_action, PPO, clip_para=0.2, opt_epochs=2,
+                                          entropy_coeff=0.01, clipped_value_loss=clipped)
+    assert type(agent.engine()).__name__ == "_GenericPPO"
+    ref = PPOOracle(pf0, ls0, vf0, plr=3e-4, vlr=1e-3, entropy_coeff=0.01, clip_para=0.2, clipped_value_loss=clipped,
+                    act=act, tanh_action=tanh_action)
+    gen = torch.Generator().manual_seed(7)
+    B = 96
+    for step in range(3):
+        obs = torch.randn(B, D, generator=gen)
+        with torch.no_grad():                                          # actions the CURRENT target policy could have produced
+            mean = nets.mlp(obs, ref.tpf, act)
+            pre = mean + torch.exp(ref.tlogstd) * torch.randn(B, A, generator=gen)
+            acts = torch.tanh(pre) if tanh_action else pre
+        batch = {"obs": obs.numpy(), "acts": acts.numpy(), "advs": torch.randn(B, 1, generator=gen).numpy() * 2 + 0.3,
+                 "values": torch.randn(B, 1, generator=gen).numpy(), "estimate_returns": torch.randn(B, 1, generator=gen).numpy()}
+        want = ref.update(batch)
+        ref.sync_target()                                              # ppo.py:33: target_pf <- pf once per epoch; here per step
+        got = agent.update(batch)
+        agent.engine().sync_target_pf()
+        assert sorted(got) == sorted(want)
+        np.testing.assert_allclose([got[k] for k in sorted(want)], [want[k] for k in sorted(want)], rtol=3e-4, atol=5e-5)
+    for mod, params in ((pf, ref.pf), (vf, ref.vf)):
+        lin = [l for l in (list(mod.base.seq_fcs) + list(mod.seq_append_fcs)) if isinstance(l, torch.nn.Linear)]
+        for k, l in enumerate(lin):
+            assert (l.weight.cpu() - params[2 * k].detach()).abs().max().item() < 3e-6
+            assert (l.bias.cpu() - params[2 * k + 1].detach()).abs().max().item() < 3e-6
+    assert (pf.logstd.cpu() - ref.logstd.detach()).abs().max().item() < 3e-6
+
+
+def test_a2c_update_other_shape_vs_oracle():
+    from torchrl.algo import A2C
+    D, A, hidden = 8, 2, [24, 24, 24]
+    pf, vf, agent, (pf0, ls0, vf0) = build(D, A, hidden, torch.nn.Tanh, True, A2C, entropy_coeff=0.01)
+    assert type(agent.engine()).__name__ == "_GenericPPO"
+    ref = A2COracle(pf0, ls0, vf0, plr=3e-4, vlr=1e-3, entropy_coeff=0.01, act="tanh", tanh_action=True)
+    gen = torch.Generator().manual_seed(3)
+    B = 64
+    batch = {"obs": torch.randn(B, D, generator=gen).numpy(), "acts": (torch.rand(B, A, generator=gen) * 1.6 - 0.8).numpy(),
+             "advs": torch.randn(B, 1, generator=gen).numpy(), "estimate_returns": torch.randn(B, 1, generator=gen).numpy()}
+    for _ in range(2):
+        want, got = ref.update(batch), agent.update(batch)
+        assert sorted(got) == sorted(want)
+        np.testing.assert_allclose([got[k] for k in sorted(want)], [want[k] for k in sorted(want)], rtol=3e-4, atol=5e-5)
+    assert (pf.logstd.cpu() - ref.logstd.detach()).abs().max().item() < 3e-6
+
+
+def test_collect_and_train_on_another_env_shape():
+    """Collector (per-step launch sequence on the dense-layer kernels) + GAE + PPO epochs on an 11-obs / 3-act env."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import PPO
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    N, T, D, A = 32, 16, 11, 3
+    net = dict(hidden_shapes=[32, 48], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A, tanh_action=True, **net)
+    vf = networks.Net(input_shape=(D,), output_shape=1, **net)
+    env, eval_env = (SynthVecEnv(N, obs_dim=D, act_dim=A, horizon=12, device=DEV) for _ in range(2))
+    env.seed(3)
+    buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+    col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=DEV, train_render=False,
+                               epoch_frames=N * T, max_episode_frames=9, eval_episodes=1, noise_mode="device")
+    assert col._spec is None
+    logger = _Log()
+    agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=2, tau=0.95, shuffle=True, entropy_coeff=0.005,
+                discount=0.99, num_epochs=10, batch_size=N * 4, gae=True, env=env, replay_buffer=buf, collector=col,
+                logger=logger, device=DEV, save_dir=None)
+    p0 = torch.cat([p.detach().reshape(-1) for p in pf.parameters()]).clone()
+    for epoch in range(2):
+        res = col.train_one_epoch()
+        assert np.isfinite(res["train_epoch_reward"])
+        agent.current_epoch = epoch
+        agent.update_per_epoch()
+    assert len(logger.infos) == 2 * 2 * (T // 4)
+    assert all(np.isfinite(list(i.values())).all() for i in logger.infos)
+    # first minibatch of an epoch: log pi == log pi_old (same kernels wrote old_logp) -> ratio exactly 1
+    assert logger.infos[0]["ratio/max"] == 1.0 and logger.infos[0]["ratio/min"] == 1.0
+    assert (torch.cat([p.detach().reshape(-1) for p in pf.parameters()]) - p0).abs().max() > 0
+    ev = col.eval_one_epoch()
+    assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == 12

@@ -61,8 +61,12 @@ def build(g, tag, N, T, horizon, max_frames, B, seed, noise_mode="host"):
     return pf, vf, env, buf, col, agent, logger
 
 
+@pytest.mark.parametrize("engine", ["fused", "generic"])
 @pytest.mark.parametrize("tag", ["small", "surpass", "mixed"])
-def test_collect_gae_ppo_epoch_matches_reference(golden, tag):
+def test_collect_gae_ppo_epoch_matches_reference(golden, tag, engine, monkeypatch):
+    """engine = generic: the arbitrary-shape minibatch loop (dense-layer GEMMs + trl_ppo_generic_losses_f32) forced
+    onto the benchmark shape, against the same reference outputs as the fused kernels."""
+    monkeypatch.setenv("TRL_GENERIC_PPO", "1" if engine == "generic" else "0")
     g = golden("collect_epoch")
     N, T, horizon, max_frames, B, seed = (int(x) for x in g[f"{tag}_args"])
     pf, vf, env, buf, col, agent, logger = build(g, tag, N, T, horizon, max_frames, B, seed)
@@ -94,6 +98,7 @@ def test_collect_gae_ppo_epoch_matches_reference(golden, tag):
     # optimiser state is exposed through the torch optimiser objects
     st = agent.pf_optimizer.state[pf.logstd]
     assert float(st["step"]) == len(logger.infos) and st["exp_avg"].abs().sum() > 0
+    assert type(agent.engine()).__name__ == ("_GenericPPO" if engine == "generic" else "_FusedPPO")
 
 
 def test_update_entry_point_and_one_iteration(golden):

@@ -89,6 +89,7 @@ SIGNATURES = {
     "trl_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "trl_mlp2_forward_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_minibatch_grad_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p]),
     "trl_ppo_wg_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "trl_rollout_norm_workspace": (C.c_int, [C.c_int]),
@@ -141,6 +142,9 @@ SIGNATURES = {
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_ppo_generic_losses_workspace": (C.c_int, [C.c_int] * 2),
+    "trl_ppo_generic_losses_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_double, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                                 C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "trl_linear_fwd_workspace": (C.c_int, [C.c_int] * 3),
     "trl_linear_fwd_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "trl_linear_bwd_input_group_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -329,6 +333,28 @@ def linear_fwd(x, w, bias, act):
                                    dev_ptr(bias, name="bias", allow_none=True), dev_ptr(y, name="y"),
                                    M, K, N, act, stream_ptr(x.device)), "trl_linear_fwd_f32")
     return y
+
+
+def ppo_generic_losses(mean, logstd, acts, advs, old_logp, v, rets, v_old, adv_raw, n_global, clip_para, entropy_coeff,
+                       clipped_value_loss, tanh_action, loss_mode, d_logstd, info, workspace=None):
+    """The loss half of a PPO / A2C minibatch for arbitrary network shapes; returns (d_mean (B, A), d_v (B, 1))."""
+    B, A = int(mean.shape[0]), int(mean.shape[1])
+    need = lib().trl_ppo_generic_losses_workspace(B, A)
+    if need < 0:
+        raise TrlError("ppo_generic_losses: unsupported sizes B=%d A=%d" % (B, A))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.float64, device=mean.device)
+    d_mean = torch.empty((B, A), dtype=torch.float32, device=mean.device)
+    d_v = torch.empty((B, 1), dtype=torch.float32, device=mean.device)
+    check(lib().trl_ppo_generic_losses_f32(
+        dev_ptr(mean, name="mean"), dev_ptr(logstd, name="logstd"), dev_ptr(acts, name="acts"), dev_ptr(advs, name="advs"),
+        dev_ptr(old_logp, name="old_logp", allow_none=True), dev_ptr(v, name="v"), dev_ptr(rets, name="rets"),
+        dev_ptr(v_old, name="v_old", allow_none=True), dev_ptr(adv_raw, torch.float64, "adv_raw"), float(n_global), B, A,
+        float(clip_para), float(entropy_coeff), int(bool(clipped_value_loss)), int(bool(tanh_action)), int(loss_mode),
+        dev_ptr(d_mean, name="d_mean"), dev_ptr(d_v, name="d_v"), dev_ptr(d_logstd, name="d_logstd"),
+        dev_ptr(info, torch.float64, "info"), dev_ptr(workspace, torch.float64, "workspace"), stream_ptr(mean.device)),
+        "trl_ppo_generic_losses_f32")
+    return d_mean, d_v
 
 
 def _ptrs(tensors, name, allow_none=False):

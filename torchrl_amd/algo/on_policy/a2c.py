@@ -35,8 +35,8 @@ class A2C(OnRLAlgo):
 
     def engine(self):
         if getattr(self, "_engine", None) is None:
-            from .ppo import _FusedPPO
-            self._engine = _FusedPPO(self)
+            from .ppo import make_engine
+            self._engine = make_engine(self)
         return self._engine
 
     def update_per_epoch(self):

@@ -53,7 +53,7 @@ class PPO(A2C):
         if self._engine is None:
             if self.optimizer_class is not optim.Adam:
                 raise _C.TrlError("the fused PPO step implements torch.optim.Adam only")
-            self._engine = _FusedPPO(self)
+            self._engine = make_engine(self)
         return self._engine
 
     # ---- epoch ----
@@ -326,3 +326,121 @@ class _FusedPPO:
                 'ratio/max': i[5], 'ratio/min': -i[6], 'grad_norm/pf': float(g[0]),
             })
         return out
+
+
+def make_engine(algo):
+    """The fused engine when the networks have the shape its kernels are instantiated for, the generic one otherwise."""
+    pf, vf = algo.pf, algo.vf
+    ps = pf.mlp2_spec() if hasattr(pf, "mlp2_spec") else None
+    vs = vf.mlp2_spec() if hasattr(vf, "mlp2_spec") else None
+    if ps is not None and vs is not None and hasattr(pf, "logstd") and _C.lib().trl_ppo_partial_stride(ps[0], ps[1], ps[2]) > 0 \
+            and os.environ.get("TRL_GENERIC_PPO") != "1":
+        return _FusedPPO(algo)
+    return _GenericPPO(algo)
+
+
+class _GenericPPO(_FusedPPO):
+    """PPO / A2C minibatch loop for ARBITRARY MLP shapes (any observation / action size, width, depth): the layers run
+    on the generic dense-layer kernels (k_gemm.hip, through ops.mlp_forward / mlp_backward), the loss half on
+    trl_ppo_generic_losses_f32, clip + Adam on trl_clip_adam_f32.  Same interface, statistics block and info dicts
+    as the fused engine, same per-sample arithmetic; ~25 launches per minibatch instead of 2 (TRL_GENERIC_PPO=1
+    forces this engine for the benchmark shape too, which is how it is tested against the fused one)."""
+
+    def __init__(self, algo):
+        from ... import ops
+        self.algo, self.ops = algo, ops
+        pf, vf = algo.pf, algo.vf
+        if not hasattr(pf, "logstd"):
+            raise _C.TrlError("PPO / A2C kernels need a state-independent-std policy (GuassianContPolicyBasicBias)")
+        self.dev = next(pf.parameters()).device
+        if self.dev.type != "cuda":
+            raise _C.TrlError("PPO networks live on %s: the HIP path needs a GPU (no CPU path exists)" % self.dev)
+        self.act = ops.act_code(pf)
+        if ops.act_code(vf) != self.act:
+            raise _C.TrlError("policy and value network must use the same activation")
+        self.pf_layers, self.vf_layers = ops.linear_layers(pf), ops.linear_layers(vf)
+        pf_list = [t for wb in self.pf_layers for t in wb] + [pf.logstd]
+        vf_list = [t for wb in self.vf_layers for t in wb]
+        self.P_pf = sum(p.numel() for p in pf_list)
+        self.P_vf = sum(p.numel() for p in vf_list)
+        self.D, self.A = int(self.pf_layers[0][0].shape[1]), int(pf.logstd.numel())
+        self.flat = flatten_into(pf_list + vf_list)                   # [pf | vf], parameters become views
+        self.m, self.v, self.grads = torch.zeros_like(self.flat), torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.step_count = 0
+        tgt = getattr(algo, "target_pf", None)
+        self.target_flat = None
+        if tgt is not None:
+            self.target_flat = flatten_into([t for wb in ops.linear_layers(tgt) for t in wb] + [tgt.logstd])
+        self._alias_optimizer_state(algo.pf_optimizer, pf_list, 0)
+        self._alias_optimizer_state(algo.vf_optimizer, vf_list, self.P_pf)
+        self.gviews, off = [], 0
+        for layers in (self.pf_layers, self.vf_layers):
+            views = []
+            for w, b in layers:
+                gw = self.grads[off:off + w.numel()].view(w.shape); off += w.numel()
+                gb = self.grads[off:off + b.numel()].view(b.shape); off += b.numel()
+                views.append((gw, gb))
+            self.gviews.append(views)
+            if layers is self.pf_layers:
+                self.g_logstd = self.grads[off:off + self.A]; off += self.A
+        self.step_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.dev)
+        self.workspace = None
+
+    def _ws(self, B):
+        need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
+                   for w, _ in self.pf_layers + self.vf_layers)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, device=self.dev)
+        return self.workspace
+
+    def run(self, t, row_idx, N):
+        algo, dev, ops = self.algo, self.dev, self.ops
+        K, rows_mb = row_idx.shape
+        world = dist.world_size()
+        n_local = rows_mb * N
+        n_global = float(n_local * world)
+        idx_dev, stats = self._buffers(K, rows_mb)
+        idx_dev.copy_(torch.from_numpy(np.ascontiguousarray(row_idx).reshape(-1)), non_blocking=True)
+        stats.zero_()
+        rows_total = t["advs"].shape[0]
+        raw, info = stats[:4 * K].view(K, 4), stats[4 * K:28 * K].view(K, 24)
+        norms = stats[28 * K:].view(torch.float32).view(K, 2)
+        loss_mode = int(getattr(algo, "loss_mode", _C.LOSS_PPO_CLIP))
+        ws = self._ws(n_local)
+        idx2d = idx_dev.view(K, rows_mb)
+        _C.adv_stats(t["advs"].reshape(rows_total, N), idx2d, raw)
+        dist.reduce_adv_raw_(raw)
+        gather = lambda key, k: None if t.get(key) is None else \
+            _C.gather_rows(t[key].reshape(rows_total, N, -1), idx2d[k]).reshape(n_local, -1)
+        for k in range(K):
+            obs, acts, advs, rets = gather("obs", k), gather("acts", k), gather("advs", k), gather("rets", k)
+            v_old, old_lp = gather("old_values", k), gather("old_logp", k)
+            mean, tape_pf = ops.mlp_forward(self.pf_layers, obs, self.act)
+            v, tape_vf = ops.mlp_forward(self.vf_layers, obs, self.act)
+            d_mean, d_v = _C.ppo_generic_losses(
+                mean, algo.pf.logstd.detach(), acts, advs.view(-1), None if old_lp is None else old_lp.view(-1),
+                v.view(-1), rets.view(-1), None if v_old is None else v_old.view(-1), raw[k], n_global,
+                float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
+                bool(getattr(algo, "clipped_value_loss", False)), bool(algo.pf.tanh_action), loss_mode,
+                self.g_logstd, info[k])
+            ops.mlp_backward(tape_pf, d_mean, grads=self.gviews[0], workspace=ws)
+            ops.mlp_backward(tape_vf, d_v, grads=self.gviews[1], workspace=ws)
+            dist.all_reduce_sum_(self.grads)                           # C1: gradient SUM over ranks
+            a = _C.AdamArgs()
+            a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
+                                                          self.m.data_ptr(), self.v.data_ptr())
+            a.n_groups = 2
+            a.group_sizes[0], a.group_sizes[1] = self.P_pf, self.P_vf
+            a.group_lr[0] = algo.pf_optimizer.param_groups[0]['lr']
+            a.group_lr[1] = algo.vf_optimizer.param_groups[0]['lr']
+            a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = 0.5, 0.9, 0.999, 1e-5, 1.0
+            a.step_count, a.norms_out = self.step_count + k + 1, norms[k].data_ptr()
+            _C.clip_adam(a, dev)
+        self.step_count += K
+        for s in self._opt_steps:
+            s.fill_(float(self.step_count))
+        dist.reduce_info_(info)
+        host = stats.cpu()                                             # the only host sync of the update
+        make = self._infos_a2c if loss_mode == _C.LOSS_A2C else self._infos
+        return make(host[:4 * K].view(K, 4).numpy(), host[4 * K:28 * K].view(K, 24).numpy(),
+                    host[28 * K:].view(torch.float32).view(K, 2).numpy(), n_global)

@@ -16,6 +16,7 @@ Exploration noise:
     step) -- statistically equivalent, no host work; what bench.py uses.
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -37,16 +38,36 @@ class VecOnPolicyCollector(VecCollector):
         return {"pf": self.pf, "vf": self.vf}
 
     def _check_shapes(self):
-        ps, vs = self.pf.mlp2_spec(), self.vf.mlp2_spec()
-        if ps is None or vs is None:
-            raise _C.TrlError("fused collector needs MLP2 policy/value nets (two equal hidden layers, "
-                              "Tanh or ReLU, no LayerNorm)")
-        if ps[0] != self.env.obs_dim or ps[2] != self.env.act_dim or vs[:2] != ps[:2] or vs[2] != 1 or vs[3] != ps[3]:
-            raise _C.TrlError("policy %s / value %s shapes do not match env (%d obs, %d act)"
-                              % (ps, vs, self.env.obs_dim, self.env.act_dim))
+        """`_spec` = (D, H, A, act) when the persistent rollout kernel is instantiated for these networks; None
+        otherwise -- any other MLP shape is collected by the per-step launch sequence on the generic dense-layer
+        kernels."""
+        from .. import ops
         if not hasattr(self.pf, "logstd"):
-            raise _C.TrlError("fused collector supports GuassianContPolicyBasicBias policies")
-        self._spec = ps
+            raise _C.TrlError("the on-policy collector supports GuassianContPolicyBasicBias policies")
+        ps = self.pf.mlp2_spec() if hasattr(self.pf, "mlp2_spec") else None
+        vs = self.vf.mlp2_spec() if hasattr(self.vf, "mlp2_spec") else None
+        self._act = ops.act_code(self.pf)
+        self._dims = (int(ops.linear_layers(self.pf)[0][0].shape[1]), int(self.pf.logstd.numel()))
+        if self._dims != (self.env.obs_dim, self.env.act_dim) or int(ops.linear_layers(self.vf)[0][0].shape[1]) != self.env.obs_dim:
+            raise _C.TrlError("policy / value input and output sizes %s do not match the env (%d obs, %d act)"
+                              % (self._dims, self.env.obs_dim, self.env.act_dim))
+        mlp2 = (ps is not None and vs is not None and vs[:2] == ps[:2] and vs[2] == 1 and vs[3] == ps[3]
+                and _C.lib().trl_ppo_partial_stride(ps[0], ps[1], ps[2]) > 0 and os.environ.get("TRL_GENERIC_PPO") != "1")
+        self._mlp2 = ps if mlp2 else None                                   # fused 2-layer forward kernel usable
+        self._spec = ps if (mlp2 and not getattr(self.env, "is_host_env", False)) else None   # ... and the rollout kernel
+
+    def _forward(self, net, x, out_dim, out=None):
+        """mean / value of an MLP on the device: the fused 2-layer kernel when instantiated, the dense-layer family
+        otherwise."""
+        if self._mlp2 is not None:
+            D, H, A, act = self._mlp2
+            return _C.mlp2_forward(net.flat_params(), x, D, H, out_dim, act, out=out)
+        from .. import ops
+        y, _ = ops.mlp_forward(ops.linear_layers(net), x, self._act)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
     # ---- launch ----
     def _fused_norm_ok(self, env, update):
@@ -110,7 +131,7 @@ class VecOnPolicyCollector(VecCollector):
             buf._old_logp_fresh = (n_steps == buf._max_replay_buffer_size)
 
     def _host_noise(self, n_steps, env):
-        A = self._spec[2]
+        A = self._dims[1]
         draws = [torch.randn(env.env_nums, A) for _ in range(n_steps)]    # the reference's stream, step by step
         return torch.stack(draws).to(env.device, non_blocking=True).contiguous()
 
@@ -118,7 +139,7 @@ class VecOnPolicyCollector(VecCollector):
     def _step_buffers(self, env):
         sb = getattr(self, "_sb", None)
         if sb is None or sb["N"] != env.env_nums:
-            D, H, A, act = self._spec
+            D, A = self._dims
             N, dev = env.env_nums, env.device
             f = lambda *shape: torch.empty(*shape, device=dev)
             sb = self._sb = {"N": N, "mean": f(N, A), "eps": f(N, A), "nxt_raw": f(N, D), "v_next": f(N, 1),
@@ -133,7 +154,7 @@ class VecOnPolicyCollector(VecCollector):
         kernel cannot carry: a running observation normaliser shared between GPUs or too large for one co-resident
         grid, and host Python envs (`torchrl_amd.env.VecEnv`).  `ob` is what the policy sees (normalised, or raw
         right after a reset -- the reference's Q14); returns the next policy input."""
-        D, H, A, act = self._spec
+        D, A = self._dims
         N, buf, sb = env.env_nums, self.replay_buffer, self._step_buffers(env)
         nz = getattr(env, "_obs_normalizer", None)
         if store:
@@ -144,8 +165,8 @@ class VecOnPolicyCollector(VecCollector):
         else:
             r = sb
         r["obs"].copy_(ob)
-        mean = _C.mlp2_forward(self.pf.flat_params(), ob, D, H, A, act, out=sb["mean"])
-        _C.mlp2_forward(self.vf.flat_params(), ob, D, H, 1, act, out=r["values"])
+        mean = self._forward(self.pf, ob, A, out=sb["mean"])
+        self._forward(self.vf, ob, 1, out=r["values"])
         if deterministic:
             eps = None
         elif noise_t is not None:
@@ -158,7 +179,7 @@ class VecOnPolicyCollector(VecCollector):
         self._env_advance(env, r["acts"], raw_next, r["rewards"], sb["done"], r["time_limits"])
         if nz is not None:
             nz.update_filt(raw_next, update=env.training, out=r["next_obs"])            # NormObs.observation
-        _C.mlp2_forward(self.vf.flat_params(), r["next_obs"], D, H, 1, act, out=sb["v_next"])
+        self._forward(self.vf, r["next_obs"], 1, out=sb["v_next"])
         sb["any"].zero_()
         _C.onpolicy_bookkeep(r["rewards"], sb["done"], sb["v_next"], self.discount, r["terminals"], env.cur_step,
                              env.ep_return, self.max_episode_frames if max_frames is None else max_frames, self._mask,
@@ -187,8 +208,8 @@ class VecOnPolicyCollector(VecCollector):
     def rollout(self, n_steps):
         """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""
         self.env.train()
-        if getattr(self.env, "is_host_env", False):                        # host Python envs: per-step launch sequence
-            return self._rollout_normed(n_steps)
+        if getattr(self.env, "is_host_env", False) or self._spec is None:  # host Python envs / shapes without a fused kernel:
+            return self._rollout_normed(n_steps)                           # per-step launch sequence
         if hasattr(self.env, "_obs_normalizer"):
             nz = self.env._obs_normalizer
             if not self._fused_norm_ok(self.env, self.env.training and nz.should_estimate):
@@ -230,7 +251,7 @@ class VecOnPolicyCollector(VecCollector):
         rews, lens = [], []
         for _ in range(self.eval_episodes):
             ob = env.reset()
-            if getattr(env, "is_host_env", False):
+            if getattr(env, "is_host_env", False) or self._spec is None:
                 self._clear_header()
                 for t in range(self._eval_steps(env)):
                     ob = self._step_normed(env, ob, False, True, None, t, max_frames=2 ** 31 - 1)

@@ -978,6 +978,10 @@ static int launch_fwd(const float* params, const float* x, float* out, int M, in
   return TRL_OK;
 }
 
+extern "C" int trl_mlp2_forward_supported(int D, int H, int O) {
+  return (D == 17 && H == 64 && (O == 6 || O == 1)) ? 1 : 0;     // keep in step with the dispatch below
+}
+
 extern "C" int trl_mlp2_forward_f32(const float* params, const float* x, float* out, int M, int D, int H,
                                     int O, int act, void* stream) {
   TRL_REQUIRE(M >= 0, "negative M");

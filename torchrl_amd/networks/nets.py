@@ -89,12 +89,21 @@ class Net(nn.Module):
     def forward(self, x):
         spec = self.mlp2_spec()
         needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if spec is not None and x.is_cuda and not needs_graph:
-            D, H, O, act = spec
+        if x.is_cuda and not needs_graph:
             lead = x.shape[:-1]
-            x2 = x.reshape(-1, D).float().contiguous()
-            out = _C.mlp2_forward(self.flat_params(), x2, D, H, O, act)
-            return out.reshape(tuple(lead) + (O,))
+            if spec is not None and _C.lib().trl_mlp2_forward_supported(spec[0], spec[1], spec[2]):
+                D, H, O, act = spec                                 # fused 2-layer kernel
+                x2 = x.reshape(-1, D).float().contiguous()
+                return _C.mlp2_forward(self.flat_params(), x2, D, H, O, act).reshape(tuple(lead) + (O,))
+            from .. import ops
+            try:
+                layers, act = ops.linear_layers(self), ops.act_code(self)
+            except _C.TrlError:
+                layers = None                                       # LayerNorm / conv trunk / other activations: torch modules
+            if layers is not None and isinstance(self.base, MLPBase):
+                x2 = x.reshape(-1, int(layers[0][0].shape[1])).float().contiguous()
+                out, _ = ops.mlp_forward([(w.detach(), b.detach()) for w, b in layers], x2, act)   # dense-layer kernels
+                return out.reshape(tuple(lead) + (self.out_dim,))
         return self.seq_append_fcs(self.base(x))
 
 
