@@ -154,3 +154,22 @@ def test_host_env_example_runs(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "EPOCH:2" in out.stdout             # (log_std/std is NaN by construction: unbiased std over ONE action dim)
+
+
+def test_sac_host_env_example_learns(tmp_path):
+    """examples/sac_host_env.py: twin-Q SAC (grouped launches, graph-replayed update) on the pure-Python pendulum through
+    VecEnv.  A real task end to end: the greedy return must improve well beyond what a random policy gets (~ -1200)."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = os.path.join(repo, "config", "sac_pendulum_host.json")
+    assert json.load(open(cfg))["general_setting"]["num_epochs"] == 20
+    out = subprocess.run([sys.executable, os.path.join(repo, "examples", "sac_host_env.py"), "--config", cfg,
+                          "--vec_env_nums", "8", "--seed", "0", "--log_dir", str(tmp_path / "log"), "--overwrite"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    evals = [float(v) for v in re.findall(r"^Running_Average_Rewards\s+(-?[0-9.]+)", out.stdout, flags=re.M)]
+    assert len(evals) >= 5 and evals[-1] > -700.0 and evals[-1] > evals[0] + 400.0, evals
