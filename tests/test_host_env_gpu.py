@@ -29,19 +29,6 @@ def nets(g, pf_prefix, vf_prefix):
     return pf, vf
 
 
-def test_vecenv_protocol():
-    env = host_vec_env(5, horizon=3, seed=2)
-    obs = env.reset()
-    assert obs.shape == (5, 17) and env.env_nums == 5 and env.observation_space.shape == (17,)
-    nxt, rew, done, infos = env.step(np.zeros((5, 6)))
-    assert nxt.shape == (5, 17) and rew.shape == (5, 1) and done.shape == (5, 1) and done.dtype == bool
-    assert infos["time_limit"].shape == (5,)
-    mask = np.array([0, 1, 0, 0, 1], dtype=bool)
-    whole = env.partial_reset(mask)                                    # the WHOLE array comes back (vecenv.py:47-51)
-    assert whole.shape == (5, 17) and np.array_equal(whole[0], nxt[0]) and not np.array_equal(whole[1], nxt[1])
-    assert env.horizon == 3                                            # unknown attributes fall through to envs[0]
-
-
 @pytest.mark.parametrize("tag", ["small", "surpass", "mixed"])
 def test_host_env_collect_matches_reference_and_trains(golden, tag):
     from torchrl.algo import PPO

@@ -143,3 +143,32 @@ def test_linear_lr_schedule_and_param_copy():
     assert torch.equal(tgt.weight, lin.weight)
     atu.soft_update_from_to(torch.nn.Linear(3, 2), tgt, 0.0)
     assert torch.equal(tgt.weight, lin.weight)
+
+
+def test_vecenv_protocol_and_pendulum_env():
+    """torchrl.env.VecEnv over single Python envs (reference protocol, vecenv.py:6-78) -- pure host code."""
+    import numpy as np
+    from oracle.synth_env import SynthSingleEnvCPU
+    from torchrl_amd.env.py_envs import PendulumEnv
+    from torchrl_amd.env.vecenv import VecEnv
+    N, seed = 5, 2
+    env = VecEnv(N, [SynthSingleEnvCPU] * N, [(seed * N + i, 3) for i in range(N)])
+    obs = env.reset()
+    assert obs.shape == (5, 17) and env.env_nums == 5 and env.observation_space.shape == (17,)
+    nxt, rew, done, infos = env.step(np.zeros((5, 6)))
+    assert nxt.shape == (5, 17) and rew.shape == (5, 1) and done.shape == (5, 1) and done.dtype == bool
+    assert infos["time_limit"].shape == (5,)
+    kept = nxt.copy()
+    whole = env.partial_reset(np.array([0, 1, 0, 0, 1], dtype=bool))   # the WHOLE array comes back (vecenv.py:47-51)
+    assert whole.shape == (5, 17) and np.array_equal(whole[0], kept[0]) and not np.array_equal(whole[1], kept[1])
+    assert np.array_equal(nxt, kept)                                   # ... without rewriting what step() returned
+    assert env.horizon == 3                                            # unknown attributes fall through to envs[0]
+    with __import__("pytest").raises(ValueError):
+        VecEnv(3, [SynthSingleEnvCPU] * 2, [(0, 3)] * 2)
+    pend = VecEnv(4, PendulumEnv, ())
+    pend.seed(7)
+    o = pend.reset()
+    assert o.shape == (4, 3) and np.allclose(o[:, 0] ** 2 + o[:, 1] ** 2, 1.0, atol=1e-6)
+    for _ in range(200):
+        o, r, d, info = pend.step(np.ones((4, 1)) * 0.5)
+    assert d.all() and info["time_limit"].all() and (r <= 0).all()     # 200-step time limit, costs only
