@@ -160,3 +160,20 @@ def test_sac_host_env_example_learns(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     evals = [float(v) for v in re.findall(r"^Running_Average_Rewards\s+(-?[0-9.]+)", out.stdout, flags=re.M)]
     assert len(evals) >= 5 and evals[-1] > -700.0 and evals[-1] > evals[0] + 400.0, evals
+
+
+def test_dqn_state_vector_example_learns(tmp_path):
+    """examples/dqn_state_vec.py (the reference's script of that name, config/dqn_cartpole.json hyper-parameters): DQN
+    with an MLP Q-network on a pure-Python cart-pole through VecEnv (discrete actions).  Random play lasts ~10-20
+    steps; the greedy policy must get well past that."""
+    import os
+    import re
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "examples", "dqn_state_vec.py"), "--config",
+                          os.path.join(repo, "config", "dqn_cartpole_host.json"), "--vec_env_nums", "8", "--seed", "0",
+                          "--log_dir", str(tmp_path / "log"), "--overwrite"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    evals = [float(v) for v in re.findall(r"^Running_Average_Rewards\s+(-?[0-9.]+)", out.stdout, flags=re.M)]
+    assert len(evals) >= 5 and max(evals[-3:]) > 80.0, evals

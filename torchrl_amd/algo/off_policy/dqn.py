@@ -69,9 +69,17 @@ class _FusedDQN:
         self.dev = next(algo.qf.parameters()).device
         if self.dev.type != "cuda":
             raise _C.TrlError("DQN networks live on %s: the HIP path needs a GPU (no CPU path exists)" % self.dev)
-        plist = ops.cnn_param_list(algo.qf)
+        from ...networks.base import MLPBase
+        self.is_mlp = isinstance(algo.qf.base, MLPBase)                 # state-vector Q net (examples/dqn_state_vec.py)
+        if self.is_mlp:
+            self.layers, self.tlayers = ops.linear_layers(algo.qf), ops.linear_layers(algo.target_qf)
+            self.act = ops.act_code(algo.qf)
+            plist = [t for wb in self.layers for t in wb]
+            tlist = [t for wb in self.tlayers for t in wb]
+        else:
+            plist, tlist = ops.cnn_param_list(algo.qf), ops.cnn_param_list(algo.target_qf)
         self.flat = flatten_into(plist)
-        self.tflat = flatten_into(ops.cnn_param_list(algo.target_qf))
+        self.tflat = flatten_into(tlist)
         self.grads = torch.zeros_like(self.flat)
         self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         self.gviews, off = [], 0
@@ -94,29 +102,44 @@ class _FusedDQN:
     def update(self, batch):
         algo, dev = self.algo, self.dev
         obs, nobs = batch['obs'], batch['next_obs']
-        if not (isinstance(obs, torch.Tensor) and obs.dtype == torch.uint8):
-            raise _C.TrlError("DQN.update expects uint8 (B, C, H, W) frame stacks from the device replay buffer")
-        obs, nobs = obs.to(dev).contiguous(), nobs.to(dev).contiguous()
+        if self.is_mlp:
+            to_f = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
+                .to(device=dev, dtype=torch.float32).contiguous()
+            obs, nobs = to_f(obs), to_f(nobs)
+        else:
+            if not (isinstance(obs, torch.Tensor) and obs.dtype == torch.uint8):
+                raise _C.TrlError("DQN.update expects uint8 (B, C, H, W) frame stacks from the device replay buffer")
+            obs, nobs = obs.to(dev).contiguous(), nobs.to(dev).contiguous()
         as_f = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
             .to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
         rew, term = as_f(batch['rewards']), as_f(batch['terminals'])
         acts = as_f(batch['acts']).to(torch.int64)
         B, A, Q = int(obs.shape[0]), self.A, int(algo.quantile_num)
-        q, tape = ops.cnn_forward(algo.qf, obs)
-        qn, _ = ops.cnn_forward(algo.target_qf, nobs)
+        if self.is_mlp:
+            q, tape = ops.mlp_forward(self.layers, obs, self.act)
+            qn, _ = ops.mlp_forward(self.tlayers, nobs, self.act)
+        else:
+            q, tape = ops.cnn_forward(algo.qf, obs)
+            qn, _ = ops.cnn_forward(algo.target_qf, nobs)
         if Q == 1:
             dq = _C.dqn_td_loss(q, acts, qn, rew, term, algo.discount, self.sums)
             denom = float(B)
         else:
             dq = _C.quantile_huber(q, acts, qn, rew, term, algo.discount, A, Q, self.sums)
             denom = float(B) * Q * Q
-        need = max(_C.lib().trl_linear_bwd_weight_workspace(int(c[2].shape[0]), int(c[3].shape[1]), int(c[3].shape[0]))
-                   for c in tape.convs)                                  # (rows of y, C*kh*kw, Cout) per conv layer
-        need = max(need, max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
-                             for w, _ in ops.fc_layers(algo.qf)))
+        if self.is_mlp:
+            need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0])) for w, _ in self.layers)
+        else:
+            need = max(_C.lib().trl_linear_bwd_weight_workspace(int(c[2].shape[0]), int(c[3].shape[1]), int(c[3].shape[0]))
+                       for c in tape.convs)                              # (rows of y, C*kh*kw, Cout) per conv layer
+            need = max(need, max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
+                                 for w, _ in ops.fc_layers(algo.qf)))
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, device=dev)
-        ops.cnn_backward(algo.qf, tape, dq, self.gviews, workspace=self.workspace)
+        if self.is_mlp:
+            ops.mlp_backward(tape, dq, grads=self.gviews, workspace=self.workspace)
+        else:
+            ops.cnn_backward(algo.qf, tape, dq, self.gviews, workspace=self.workspace)
         self.step_count += 1
         a = _C.AdamArgs()
         a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),

@@ -196,7 +196,7 @@ class VecCollector(BaseCollector):
         if store:
             row = buf._top
             buf._ensure_key("obs", (n, d))[row].copy_(env.cur_obs)           # before the env advances in place
-            buf._ensure_key("acts", (n, a_dim))[row].copy_(act)
+            buf._ensure_key("acts", (n, a_dim))[row].copy_(act if self.continuous else act.reshape(n, 1))
             nxt = buf._ensure_key("next_obs", (n, d))[row]
             rew = buf._ensure_key("rewards", (n, 1))[row]
             done = buf._ensure_key("terminals", (n, 1))[row]

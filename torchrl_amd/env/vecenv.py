@@ -111,10 +111,13 @@ class HostEnvBridge:
         if self.device.type != "cuda":
             raise ValueError("collectors run their networks on the GPU: pass device='cuda:<n>'")
         obs_shape, act_space = venv.observation_space.shape, venv.action_space
-        if len(obs_shape) != 1 or not hasattr(act_space, "shape") or len(act_space.shape) != 1:
-            raise ValueError("HostEnvBridge drives flat-observation, continuous-action envs "
+        self.discrete = hasattr(act_space, "n")                           # Discrete(n): actions are (N,) integers
+        if len(obs_shape) != 1 or not (self.discrete or (hasattr(act_space, "shape") and len(act_space.shape) == 1)):
+            raise ValueError("HostEnvBridge drives flat-observation envs with Box or Discrete actions "
                              "(got observation %r, action %r)" % (obs_shape, act_space))
-        self.obs_dim, self.act_dim = int(obs_shape[0]), int(act_space.shape[0])
+        self.obs_dim = int(obs_shape[0])
+        self.act_dim = 1 if self.discrete else int(act_space.shape[0])    # stored action width
+        self.action_num = int(act_space.n) if self.discrete else 0
         n = self.env_nums
         self.cur_obs = torch.zeros(n, self.obs_dim, device=self.device)
         self.cur_step = torch.zeros(n, dtype=torch.int32, device=self.device)
@@ -162,7 +165,8 @@ class HostEnvBridge:
     # ---- the two host round trips of a collector step ----
     def host_step(self, act, next_obs, rewards, dones, time_limits=None):
         """act (N, A) device -> envs; fills the device rows next_obs (N, D), rewards, dones, time_limits (N, 1)."""
-        obs, rew, done, infos = self.venv.step(act.detach().cpu().numpy().astype(np.float64))
+        a = act.detach().cpu().numpy()
+        obs, rew, done, infos = self.venv.step(a.reshape(-1).astype(np.int64) if self.discrete else a.astype(np.float64))
         self._upload(obs, next_obs)
         self.cur_obs.copy_(next_obs)
         self._upload(rew, rewards)
