@@ -177,3 +177,19 @@ def test_dqn_state_vector_example_learns(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     evals = [float(v) for v in re.findall(r"^Running_Average_Rewards\s+(-?[0-9.]+)", out.stdout, flags=re.M)]
     assert len(evals) >= 5 and max(evals[-3:]) > 80.0, evals
+
+
+def test_ppo_host_env_example_learns(tmp_path):
+    """examples/ppo_host_env.py at its shipped config: PPO (arbitrary-shape engine: 3 observations, 1 action) on the
+    pure-Python pendulum; the greedy return climbs from the random-policy level (~ -1200) past -600."""
+    import os
+    import re
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "examples", "ppo_host_env.py"), "--config",
+                          os.path.join(repo, "config", "ppo_pendulum_host.json"), "--vec_env_nums", "16", "--seed", "0",
+                          "--log_dir", str(tmp_path / "log"), "--overwrite"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    evals = [float(v) for v in re.findall(r"^Running_Average_Rewards\s+(-?[0-9.]+)", out.stdout, flags=re.M)]
+    assert len(evals) >= 5 and evals[-1] > -600.0 and evals[-1] > evals[0] + 400.0, evals
