@@ -64,6 +64,33 @@ def test_host_env_collect_matches_reference_and_trains(golden, tag):
     assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == horizon
 
 
+def test_subproc_vecenv_under_the_collector_matches_reference(golden):
+    """SubProcVecEnv (2 spawned workers) in place of VecEnv: same collected buffers as the reference."""
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env import SubProcVecEnv
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    g = golden("collect_epoch")
+    tag = "mixed"
+    N, T, horizon, max_frames, B, seed = (int(x) for x in g[f"{tag}_args"])
+    pf, vf = nets(g, tag + "_pf0_", tag + "_vf0_")
+    procs = 2 if N % 2 == 0 else 1
+    env = SubProcVecEnv(procs, N, [SynthSingleEnvCPU] * N, [(seed * N + i, horizon) for i in range(N)])
+    try:
+        buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+        col = VecOnPolicyCollector(vf, env=env, eval_env=None, pf=pf, replay_buffer=buf, device=torch.device(DEV),
+                                   train_render=False, epoch_frames=N * T, max_episode_frames=max_frames, eval_episodes=1)
+        torch.manual_seed(seed)
+        res = col.train_one_epoch()
+        for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+            err = np.abs(getattr(buf, "_" + k).cpu().numpy() - g[f"{tag}_buf_{k}"]).max()
+            assert err < 1e-5, (k, err)
+        assert abs(res["train_epoch_reward"] - float(g[f"{tag}_train_epoch_reward"])) < 1e-3
+        ev = col.eval_one_epoch()                                         # eval env: a deep copy = a second set of workers
+        assert len(ev["eval_rewards"]) == N
+    finally:
+        col.terminate()
+
+
 @pytest.mark.parametrize("tag", ["flow", "flow_surpass"])
 def test_host_env_with_obs_normaliser_matches_reference(golden, tag):
     from torchrl.collector.on_policy import VecOnPolicyCollector

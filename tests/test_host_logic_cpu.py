@@ -172,3 +172,31 @@ def test_vecenv_protocol_and_pendulum_env():
     for _ in range(200):
         o, r, d, info = pend.step(np.ones((4, 1)) * 0.5)
     assert d.all() and info["time_limit"].all() and (r <= 0).all()     # 200-step time limit, costs only
+
+
+def test_subproc_vecenv_matches_vecenv():
+    """SubProcVecEnv (spawned workers, pipes) is the same function of (seed, actions) as the in-process VecEnv."""
+    import numpy as np
+    from torchrl_amd.env import SubProcVecEnv, VecEnv
+    from torchrl_amd.env.py_envs import CartPoleEnv, PendulumEnv
+    for cls, act in ((PendulumEnv, lambda rs: rs.uniform(-1, 1, size=(4, 1))), (CartPoleEnv, lambda rs: rs.randint(0, 2, size=(4,)))):
+        a, b = VecEnv(4, cls, ()), SubProcVecEnv(2, 4, cls, ())
+        try:
+            a.seed(11); b.seed(11)
+            a.train(); b.train()
+            assert np.array_equal(a.reset(), b.reset())
+            assert b.observation_space.shape == a.observation_space.shape
+            rs = np.random.RandomState(0)
+            for t in range(40):
+                acts = act(rs)
+                (oa, ra, da, ia), (ob, rb, db, ib) = a.step(acts), b.step(acts)
+                assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db)
+                assert sorted(ia) == sorted(ib) and all(np.array_equal(ia[k], ib[k]) for k in ia)
+                if da.any() or t % 7 == 3:
+                    mask = da.reshape(-1) | (np.arange(4) == t % 4)
+                    assert np.array_equal(a.partial_reset(mask), b.partial_reset(mask))
+        finally:
+            b.close()
+    import pytest
+    with pytest.raises(ValueError):
+        SubProcVecEnv(3, 4, PendulumEnv, ())

@@ -5,3 +5,4 @@ from .base_wrapper import Normalizer, NormObs
 VecEnv = SynthVecEnv
 SubProcVecEnv = SynthVecEnv
 from .vecenv import VecEnv, HostEnvBridge
+from .subproc_vecenv import SubProcVecEnv
