@@ -67,3 +67,12 @@ class EpsilonGreedyQRDQNDiscretePolicy(EpsilonGreedyDQNDiscretePolicy):
     def __init__(self, quantile_num, **kwargs):
         super().__init__(**kwargs)
         self.quantile_num = quantile_num
+
+
+class CategoricalDisPolicy:
+    """Imported by the reference's discrete on-policy examples (ppo / a2c _discrete_atari_vec.py); the categorical
+    on-policy losses have no kernel path in this build: constructing one fails loudly."""
+
+    def __init__(self, *args, **kwargs):
+        raise _C.TrlError("CategoricalDisPolicy is not built in torchrl_amd: on-policy algorithms here take "
+                          "GuassianContPolicyBasicBias (continuous actions); discrete actions are covered by DQN / QRDQN")
