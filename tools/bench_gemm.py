@@ -43,6 +43,49 @@ def main():
         print(json.dumps(out[-1]), flush=True)
 
 
+def grouped():
+    """Per-launch time and MFMA rate of the grouped dense-layer launches and of the conv kernels at cfg 3 / cfg 5 shapes."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    for G, M, K, N in ((1, 4096, 256, 256), (2, 4096, 256, 256), (6, 4096, 256, 256), (6, 4096, 23, 256), (6, 4096, 256, 1)):
+        xs = [torch.randn(M, K, device=dev) for _ in range(G)]
+        ws = [torch.randn(N, K, device=dev) * 0.05 for _ in range(G)]
+        bs = [torch.randn(N, device=dev) for _ in range(G)]
+        ys = _C.linear_fwd_group(xs, ws, bs, 1)
+        dys = [torch.randn(M, N, device=dev) for _ in range(G)]
+        dws = [torch.empty(N, K, device=dev) for _ in range(G)]; dbs = [torch.empty(N, device=dev) for _ in range(G)]
+        wsp = torch.empty(G * _C.lib().trl_linear_bwd_weight_workspace(M, K, N), device=dev)
+        fl = 2.0 * G * M * K * N
+        t = [timed(lambda: _C.linear_fwd_group(xs, ws, bs, 1)), timed(lambda: _C.linear_bwd_input_group(dys, ys, 1, ws)),
+             timed(lambda: _C.linear_bwd_weight_group(dys, ys, 1, xs, dws, dbs, workspace=wsp))]
+        print(json.dumps(dict(G=G, M=M, K=K, N=N, fwd_us=round(t[0], 1), bwd_in_us=round(t[1], 1), bwd_w_us=round(t[2], 1),
+                              fwd_tf=round(fl / t[0] * 1e-6, 1), bwd_in_tf=round(fl / t[1] * 1e-6, 1),
+                              bwd_w_tf=round(fl / t[2] * 1e-6, 1))), flush=True)
+    B = 512
+    frames = torch.randint(0, 256, (B, 4, 84, 84), dtype=torch.uint8, device=dev)
+    convs = [("conv1 u8 direct", 4, 84, 8, 4, 16), ("conv2 nhwc", 16, 20, 4, 2, 32), ("conv3 nhwc", 32, 9, 3, 1, 64)]
+    x = None
+    for name, C, H, k, s, Co in convs:
+        w = torch.randn(Co, C * k * k, device=dev) * 0.05; b = torch.randn(Co, device=dev)
+        Ho = (H - k) // s + 1
+        if x is None:
+            fwd = lambda: _C.conv_fwd_u8(frames, w, b, k, k, s, s, 1 / 255.0, -0.5, 1)
+        else:
+            xin = x
+            fwd = lambda: _C.conv_fwd_nhwc(xin, w, b, k, k, s, s, 1)
+        y, _ = fwd()
+        dy = torch.randn_like(y); dw = torch.empty_like(w); db = torch.empty_like(b)
+        if x is None:
+            bww = lambda: _C.conv_bwd_weight_u8(dy, y, 1, frames, k, k, s, s, 1 / 255.0, -0.5, dw, db)
+        else:
+            bww = lambda: _C.conv_bwd_weight_nhwc(dy, y, 1, xin, k, k, s, s, dw, db)
+        fl = 2.0 * B * Ho * Ho * C * k * k * Co
+        tf_, tw_ = timed(fwd, 100), timed(bww, 100)
+        print(json.dumps(dict(kernel=name, M=B * Ho * Ho, K=C * k * k, N=Co, fwd_us=round(tf_, 1), bwd_w_us=round(tw_, 1),
+                              fwd_tf=round(fl / tf_ * 1e-6, 1), bwd_w_tf=round(fl / tw_ * 1e-6, 1))), flush=True)
+        x = y.view(B, Ho, Ho, Co)
+
+
 def clk(M=4096, K=256, N=256):
     """TRL_LIB=<clk build>: phase stamps of workgroups 0, 32, .. 224 of one launch of each kernel."""
     import ctypes as C
@@ -99,6 +142,9 @@ def clk_conv():
 
 
 if __name__ == "__main__":
+    if "--grouped" in sys.argv:
+        grouped()
+        sys.exit(0)
     if "--clk-conv" in sys.argv:
         clk_conv()
         sys.exit(0)
