@@ -248,6 +248,8 @@ typedef struct trl_adam_t {
                                  ignored, the step uses steps + 1 and a one-thread kernel launched behind the
                                  update advances the state (same purpose as device_state: a captured graph of a
                                  whole update can be replayed; the 4th double is reserved) */
+  const float* device_lr;     /* trl_clip_adam_f32 only, nullable: n_groups learning rates on the device, used instead
+                                 of group_lr (a linear schedule then changes no launch argument either) */
 } trl_adam_t;
 int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
 /* Single-process fast path: trl_ppo_reduce_f32 + trl_clip_adam_f32 in one launch (the block that

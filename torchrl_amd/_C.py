@@ -73,7 +73,7 @@ class AdamArgs(C.Structure):
         ("n_groups", C.c_int), ("group_sizes", C.c_int * 4), ("group_lr", C.c_float * 4),
         ("max_norm", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("step_count", C.c_int), ("grad_scale", C.c_float), ("norms_out", C.c_void_p),
-        ("device_state", C.c_int), ("step_state", C.c_void_p),
+        ("device_state", C.c_int), ("step_state", C.c_void_p), ("device_lr", C.c_void_p),
     ]
 
 

@@ -384,6 +384,8 @@ class _GenericPPO(_FusedPPO):
             if layers is self.pf_layers:
                 self.g_logstd = self.grads[off:off + self.A]; off += self.A
         self.step_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.dev)
+        self.lr_dev = torch.zeros(2, device=self.dev)
+        self._graphs, self._seen = {}, set()
         self.workspace = None
 
     def _ws(self, B):
@@ -408,34 +410,58 @@ class _GenericPPO(_FusedPPO):
         loss_mode = int(getattr(algo, "loss_mode", _C.LOSS_PPO_CLIP))
         ws = self._ws(n_local)
         idx2d = idx_dev.view(K, rows_mb)
-        _C.adv_stats(t["advs"].reshape(rows_total, N), idx2d, raw)
-        dist.reduce_adv_raw_(raw)
+        replayable = not dist.collectives_active() and os.environ.get("TRL_NO_GRAPH") != "1"
+        lrs = (float(algo.pf_optimizer.param_groups[0]['lr']), float(algo.vf_optimizer.param_groups[0]['lr']))
+        if getattr(self, "_lr_host", None) != lrs:                     # learning rates live on the device: the linear
+            self._lr_host = lrs                                        # schedule changes no launch argument
+            self.lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=True)
         gather = lambda key, k: None if t.get(key) is None else \
             _C.gather_rows(t[key].reshape(rows_total, N, -1), idx2d[k]).reshape(n_local, -1)
-        for k in range(K):
-            obs, acts, advs, rets = gather("obs", k), gather("acts", k), gather("advs", k), gather("rets", k)
-            v_old, old_lp = gather("old_values", k), gather("old_logp", k)
-            mean, tape_pf = ops.mlp_forward(self.pf_layers, obs, self.act)
-            v, tape_vf = ops.mlp_forward(self.vf_layers, obs, self.act)
-            d_mean, d_v = _C.ppo_generic_losses(
-                mean, algo.pf.logstd.detach(), acts, advs.view(-1), None if old_lp is None else old_lp.view(-1),
-                v.view(-1), rets.view(-1), None if v_old is None else v_old.view(-1), raw[k], n_global,
-                float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
-                bool(getattr(algo, "clipped_value_loss", False)), bool(algo.pf.tanh_action), loss_mode,
-                self.g_logstd, info[k])
-            ops.mlp_backward(tape_pf, d_mean, grads=self.gviews[0], workspace=ws)
-            ops.mlp_backward(tape_vf, d_v, grads=self.gviews[1], workspace=ws)
-            dist.all_reduce_sum_(self.grads)                           # C1: gradient SUM over ranks
-            a = _C.AdamArgs()
-            a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
-                                                          self.m.data_ptr(), self.v.data_ptr())
-            a.n_groups = 2
-            a.group_sizes[0], a.group_sizes[1] = self.P_pf, self.P_vf
-            a.group_lr[0] = algo.pf_optimizer.param_groups[0]['lr']
-            a.group_lr[1] = algo.vf_optimizer.param_groups[0]['lr']
-            a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = 0.5, 0.9, 0.999, 1e-5, 1.0
-            a.step_count, a.norms_out = self.step_count + k + 1, norms[k].data_ptr()
-            _C.clip_adam(a, dev)
+        hyper = (float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
+                 bool(getattr(algo, "clipped_value_loss", False)), bool(algo.pf.tanh_action), loss_mode)
+
+        def launch_all():
+            _C.adv_stats(t["advs"].reshape(rows_total, N), idx2d, raw)
+            dist.reduce_adv_raw_(raw)
+            for k in range(K):
+                obs, acts, advs, rets = gather("obs", k), gather("acts", k), gather("advs", k), gather("rets", k)
+                v_old, old_lp = gather("old_values", k), gather("old_logp", k)
+                mean, tape_pf = ops.mlp_forward(self.pf_layers, obs, self.act)
+                v, tape_vf = ops.mlp_forward(self.vf_layers, obs, self.act)
+                d_mean, d_v = _C.ppo_generic_losses(
+                    mean, algo.pf.logstd.detach(), acts, advs.view(-1), None if old_lp is None else old_lp.view(-1),
+                    v.view(-1), rets.view(-1), None if v_old is None else v_old.view(-1), raw[k], n_global, *hyper,
+                    self.g_logstd, info[k])
+                ops.mlp_backward(tape_pf, d_mean, grads=self.gviews[0], workspace=ws)
+                ops.mlp_backward(tape_vf, d_v, grads=self.gviews[1], workspace=ws)
+                dist.all_reduce_sum_(self.grads)                       # C1: gradient SUM over ranks
+                a = _C.AdamArgs()
+                a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
+                                                              self.m.data_ptr(), self.v.data_ptr())
+                a.n_groups = 2
+                a.group_sizes[0], a.group_sizes[1] = self.P_pf, self.P_vf
+                a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = 0.5, 0.9, 0.999, 1e-5, 1.0
+                a.step_count, a.norms_out = 0, norms[k].data_ptr()
+                a.step_state, a.device_lr = self.step_state.data_ptr(), self.lr_dev.data_ptr()   # device-side step count / lr
+                _C.clip_adam(a, dev)
+
+        # eager on the first visit of a configuration, captured into a HIP graph on the second, replayed afterwards
+        key = (K, rows_mb, N, rows_total, n_global, idx_dev.data_ptr(), stats.data_ptr()) + hyper + tuple(
+            0 if t.get(k_) is None else t[k_].data_ptr() for k_ in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
+        graphs = self._graphs
+        if not replayable or (key not in graphs and len(graphs) >= 4):
+            launch_all()
+        elif key in graphs:
+            graphs[key].replay()
+        elif key not in self._seen:
+            self._seen.add(key)
+            launch_all()
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                launch_all()
+            graphs[key] = graph
+            graph.replay()
         self.step_count += K
         for s in self._opt_steps:
             s.fill_(float(self.step_count))

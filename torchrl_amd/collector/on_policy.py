@@ -149,7 +149,7 @@ class VecOnPolicyCollector(VecCollector):
                              "terminals": f(N, 1), "time_limits": f(N, 1), "old_logp": f(N, 1)}
         return sb
 
-    def _step_normed(self, env, ob, store, deterministic, noise_t, step, max_frames=None):
+    def _step_launches(self, env, ob, store, deterministic, noise_t, step, max_frames=None):
         """One take_actions (torchrl/collector/on_policy.py:90-155) as ~12 launches, for envs the persistent rollout
         kernel cannot carry: a running observation normaliser shared between GPUs or too large for one co-resident
         grid, and host Python envs (`torchrl_amd.env.VecEnv`).  `ob` is what the policy sees (normalised, or raw
@@ -193,13 +193,13 @@ class VecOnPolicyCollector(VecCollector):
             buf._advance()
         return nxt
 
-    def _rollout_normed(self, n_steps):
+    def _rollout_per_step(self, n_steps):
         env = self.env
         noise = self._host_noise(n_steps, env) if self.noise_mode == "host" else None
         ob = torch.as_tensor(self.current_ob).to(device=env.device, dtype=torch.float32).contiguous()
         self._clear_header()
         for t in range(n_steps):
-            ob = self._step_normed(env, ob, True, False, None if noise is None else noise[t], t)
+            ob = self._step_launches(env, ob, True, False, None if noise is None else noise[t], t)
             self.global_step += 1
         self.current_ob = ob
         buf = self.replay_buffer
@@ -209,11 +209,11 @@ class VecOnPolicyCollector(VecCollector):
         """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""
         self.env.train()
         if getattr(self.env, "is_host_env", False) or self._spec is None:  # host Python envs / shapes without a fused kernel:
-            return self._rollout_normed(n_steps)                           # per-step launch sequence
+            return self._rollout_per_step(n_steps)                           # per-step launch sequence
         if hasattr(self.env, "_obs_normalizer"):
             nz = self.env._obs_normalizer
             if not self._fused_norm_ok(self.env, self.env.training and nz.should_estimate):
-                return self._rollout_normed(n_steps)
+                return self._rollout_per_step(n_steps)
             ob = torch.as_tensor(self.current_ob).to(device=self.env.device, dtype=torch.float32).contiguous().clone()
             noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
             self._launch(self.env, n_steps, True, False, noise, policy_ob=ob)
@@ -254,7 +254,7 @@ class VecOnPolicyCollector(VecCollector):
             if getattr(env, "is_host_env", False) or self._spec is None:
                 self._clear_header()
                 for t in range(self._eval_steps(env)):
-                    ob = self._step_normed(env, ob, False, True, None, t, max_frames=2 ** 31 - 1)
+                    ob = self._step_launches(env, ob, False, True, None, t, max_frames=2 ** 31 - 1)
                     if len({int(i) for _, i, _ in self._finished_episodes()}) == env.env_nums:
                         break                                               # every env finished its first episode
             elif hasattr(env, "_obs_normalizer") and self._fused_norm_ok(env, False):
@@ -262,7 +262,7 @@ class VecOnPolicyCollector(VecCollector):
             elif hasattr(env, "_obs_normalizer"):
                 self._clear_header()
                 for t in range(env.horizon):
-                    ob = self._step_normed(env, ob, False, True, None, t, max_frames=2 ** 31 - 1)
+                    ob = self._step_launches(env, ob, False, True, None, t, max_frames=2 ** 31 - 1)
             else:
                 self._launch(env, env.horizon, False, True, None, max_frames=2 ** 31 - 1)
             log = self._finished_episodes()

@@ -632,6 +632,7 @@ struct AdamDev {
   float max_norm, beta1, beta2, eps, grad_scale, bc1, bc2_sqrt;
   float* norms_out;
   double* step_state;         // {steps taken, beta1^steps, beta2^steps, -} or null (then bc1 / bc2_sqrt)
+  const float* device_lr;     // per-group learning rates on the device, or null (then lr[])
 };
 __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
   __shared__ float s_part[4][4];
@@ -675,7 +676,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
     const float v = a.beta2 * a.v[e] + (1.0f - a.beta2) * gr * gr;
     a.m[e] = m; a.v[e] = v;
     const float denom = sqrtf(v) / bc2_sqrt + a.eps;
-    a.params[e] -= (a.lr[g] / bc1) * (m / denom);
+    const float lr = a.device_lr ? a.device_lr[g] : a.lr[g];
+    a.params[e] -= (lr / bc1) * (m / denom);
   }
 }
 
@@ -919,6 +921,7 @@ static int fill_adam(const trl_adam_t* p, AdamDev& d) {
   d.bc2_sqrt = (float)sqrt(1.0 - pow((double)p->beta2, (double)p->step_count));
   d.norms_out = p->norms_out;
   d.step_state = p->step_state;
+  d.device_lr = p->device_lr;
   return TRL_OK;
 }
 
