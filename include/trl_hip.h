@@ -223,6 +223,24 @@ int trl_ppo_generic_losses_f32(const float* mean, const float* logstd, const flo
                                float* d_mean, float* d_v, float* d_logstd, double* info, double* workspace,
                                void* stream);
 
+/* --- V-MPO: the loss half of VMPO.update (torchrl/algo/on_policy/v_mpo.py:57-181) ----------------------
+ * trl_adv_normalize_f32: out = (adv - mean) / (std_unbiased + 1e-5) from trl_adv_stats_f64's {sum, sumsq, ..} (:175-177).
+ * trl_mse_value_loss_f32: d_v = 2 (v - R) / n_global and the loss SUM over the local samples (:136-153).
+ * trl_vmpo_losses_f32: on the n samples the host selected (top half by normalised advantage, :64-70):
+ *   phi = softmax(adv_n / eta); L_pi = mean(-phi log pi + alpha KL(pi || pi_target)) -> d_mean (n, A), d_logstd (A);
+ *   gradients of the dual variables and their Adam(dual_lr, eps 1e-5) step, clamped at 1e-8 (:83-117).
+ *   dual_state: 7 floats on the device {eta, alpha, exp_avg x2, exp_avg_sq x2, steps}, initialise {1, 0.1, 0, 0, 0, 0, 0}.
+ *   info (12 doubles): 0 policy loss; 1..4 log pi mean / unbiased std / max / min; 5..8 the same of the KL;
+ *   9 alpha loss; 10 alpha and 11 eta AFTER the step.  workspace: trl_vmpo_losses_workspace(n, A) doubles. */
+int trl_adv_normalize_f32(const float* advs, const double* adv_raw, double n_global, int B, float* out, void* stream);
+int trl_mse_value_loss_f32(const float* v, const float* rets, int B, double n_global, float* d_v, double* loss_sum,
+                           void* stream);
+int trl_vmpo_losses_workspace(int n, int A);
+int trl_vmpo_losses_f32(const float* mean, const float* target_mean, const float* logstd, const float* target_logstd,
+                        const float* acts, const float* adv_n, float* dual_state, int n, int A, int tanh_action,
+                        float eta_eps, float alpha_eps, float dual_lr, float* d_mean, float* d_logstd, double* info,
+                        double* workspace, void* stream);
+
 /* --- K11: global-norm clip + Adam ------------------------------------------
  * replaces clip_grad_norm_(params, max_norm) + Adam(eps).step()
  * (ppo.py:72-74, 117-119; a2c.py:29-39) for up to 4 parameter groups laid out

@@ -477,6 +477,47 @@ def case_a2c_update():
     save("a2c_update", **out)
 
 
+def case_vmpo_update():
+    """VMPO.update (v_mpo.py:57-181) on random batches: info dict, post-step params, eta / alpha; three consecutive steps,
+    with `target_pf <- pf` once before the first (what update_per_epoch does), so the KL term is live from step 2 on."""
+    import gym
+    import torchrl.algo.utils as atu
+    from torchrl.algo import VMPO
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    for tag, B, D, A, H in (("small", 64, 17, 6, 64), ("odd", 97, 11, 3, 32)):
+        pf, vf = build_nets(D, A, H, seed=13)
+        with torch.no_grad():                                   # away from the +-3e-3 head init, logstd spread over the dims
+            pf.seq_append_fcs[-1].weight.mul_(30.0)
+            vf.seq_append_fcs[-1].weight.mul_(30.0)
+            pf.logstd.copy_(torch.linspace(-1.2, -0.4, A))
+        env = SynthVecEnvCPU(4)
+        env.action_space = gym.spaces.Box(-1, 1, (A,))
+        agent = VMPO(pf=pf, vf=vf, plr=1e-3, vlr=1e-3, opt_epochs=2, eta_eps=0.02, alpha_eps=0.1, tau=0.95, shuffle=True,
+                     discount=0.99, num_epochs=10, batch_size=B, gae=True, env=env, replay_buffer=None,
+                     collector=_StubCollector(), logger=NullLogger(), device=torch.device("cpu"),
+                     save_dir=tempfile.mkdtemp(prefix="trl_save_"))
+        atu.copy_model_params_from_to(agent.pf, agent.target_pf)
+        out[f"{tag}_args"] = np.array([B, D, A, H])
+        out.update(state_arrays(f"{tag}_pf0_", pf))
+        out.update(state_arrays(f"{tag}_vf0_", vf))
+        rs = np.random.RandomState(31)
+        for s_ in range(3):
+            batch = {"obs": rs.randn(B, D).astype(np.float32),
+                     "acts": np.tanh(rs.randn(B, A)).astype(np.float32) * 0.98,
+                     "advs": rs.randn(B, 1).astype(np.float32) * 2 + 0.5,
+                     "values": rs.randn(B, 1).astype(np.float32),
+                     "estimate_returns": rs.randn(B, 1).astype(np.float32)}
+            out.update({f"{tag}_s{s_}_batch_{k}": v for k, v in batch.items()})
+            info = agent.update(batch)
+            out[f"{tag}_s{s_}_info_keys"] = np.array(sorted(info.keys()))
+            out[f"{tag}_s{s_}_info_vals"] = np.array([info[k] for k in sorted(info.keys())], dtype=np.float64)
+            out[f"{tag}_s{s_}_eta_alpha"] = np.array([agent.eta.item(), agent.alpha.item()], dtype=np.float64)
+        out.update(state_arrays(f"{tag}_pf1_", pf))
+        out.update(state_arrays(f"{tag}_vf1_", vf))
+    save("vmpo_update", **out)
+
+
 def case_ddpg_td3():
     """DDPG.update (ddpg.py:42-110) and TD3.update (td3.py:57-154) on random batches with FixGuassianContPolicy:
     info dicts, the N(0,1) draws TD3 consumes, post-update online and target parameters."""
@@ -597,7 +638,7 @@ def case_obs_norm():
 
 CASES = {"gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
-         "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3}
+         "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update}
 
 if __name__ == "__main__":
     install_stubs()

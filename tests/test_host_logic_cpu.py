@@ -221,8 +221,8 @@ def test_reference_import_surface():
         m = importlib.import_module(mod)
         for a in attrs:
             assert hasattr(m, a), (mod, a)
-    from torchrl.algo import TRPO, VMPO
+    from torchrl.algo import TRPO
     from torchrl.policies import CategoricalDisPolicy
-    for cls in (TRPO, VMPO, CategoricalDisPolicy):
+    for cls in (TRPO, CategoricalDisPolicy):
         with pytest.raises(_C.TrlError, match="not built"):
             cls()

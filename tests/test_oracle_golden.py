@@ -335,3 +335,31 @@ def test_ddpg_td3_oracle_matches_reference(golden, tag):
     for name, params in pairs:
         for a, b in zip(params, get(name, 1)):
             np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["small", "odd"])
+def test_vmpo_oracle_matches_reference(golden, tag):
+    """oracle/vmpo.py against what the REFERENCE's VMPO.update produced (tests/golden/vmpo_update.npz)."""
+    import torch
+    from oracle.vmpo import VMPOOracle
+    g = golden("vmpo_update")
+    B, D, A, H = (int(v) for v in g[tag + "_args"])
+    def flat(prefix):
+        sd = {k[len(prefix):]: torch.tensor(g[k]) for k in g.files if k.startswith(prefix)}
+        lin = sorted({k.rsplit("__", 1)[0] for k in sd if k.endswith("__weight")},
+                     key=lambda n: (0 if n.startswith("base") else 1, n))
+        return [sd[n + "__" + w] for n in lin for w in ("weight", "bias")], sd
+    pf, sd = flat(tag + "_pf0_")
+    vf, _ = flat(tag + "_vf0_")
+    ref = VMPOOracle(pf, sd["logstd"], vf, plr=1e-3, vlr=1e-3, eta_eps=0.02, alpha_eps=0.1)
+    for s in range(3):
+        batch = {k: g[f"{tag}_s{s}_batch_{k}"] for k in ("obs", "acts", "advs", "values", "estimate_returns")}
+        info = ref.update(batch)
+        keys = [str(k) for k in g[f"{tag}_s{s}_info_keys"]]
+        assert sorted(info) == keys
+        np.testing.assert_allclose([info[k] for k in keys], g[f"{tag}_s{s}_info_vals"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose([ref.eta.item(), ref.alpha.item()], g[f"{tag}_s{s}_eta_alpha"], rtol=1e-6)
+    pf1, sd1 = flat(tag + "_pf1_")
+    for a, b in zip(ref.pf, pf1):
+        assert (a.detach() - b).abs().max().item() < 2e-6
+    assert (ref.logstd.detach() - sd1["logstd"]).abs().max().item() < 2e-6

@@ -142,6 +142,10 @@ SIGNATURES = {
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_adv_normalize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_mse_value_loss_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trl_vmpo_losses_workspace": (C.c_int, [C.c_int] * 2),
+    "trl_vmpo_losses_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_void_p] * 5),
     "trl_ppo_generic_losses_workspace": (C.c_int, [C.c_int] * 2),
     "trl_ppo_generic_losses_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_double, C.c_int, C.c_int, C.c_float, C.c_float,
                                                                  C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
@@ -355,6 +359,39 @@ def ppo_generic_losses(mean, logstd, acts, advs, old_logp, v, rets, v_old, adv_r
         dev_ptr(info, torch.float64, "info"), dev_ptr(workspace, torch.float64, "workspace"), stream_ptr(mean.device)),
         "trl_ppo_generic_losses_f32")
     return d_mean, d_v
+
+
+def adv_normalize(advs, adv_raw, n_global):
+    out = torch.empty(int(advs.numel()), dtype=torch.float32, device=advs.device)
+    check(lib().trl_adv_normalize_f32(dev_ptr(advs, name="advs"), dev_ptr(adv_raw, torch.float64, "adv_raw"), float(n_global),
+                                      int(advs.numel()), dev_ptr(out, name="out"), stream_ptr(advs.device)), "trl_adv_normalize_f32")
+    return out
+
+
+def mse_value_loss(v, rets, n_global, loss_sum):
+    d_v = torch.empty((int(v.numel()), 1), dtype=torch.float32, device=v.device)
+    check(lib().trl_mse_value_loss_f32(dev_ptr(v, name="v"), dev_ptr(rets, name="rets"), int(v.numel()), float(n_global),
+                                       dev_ptr(d_v, name="d_v"), dev_ptr(loss_sum, torch.float64, "loss_sum"),
+                                       stream_ptr(v.device)), "trl_mse_value_loss_f32")
+    return d_v
+
+
+def vmpo_losses(mean, target_mean, logstd, target_logstd, acts, adv_n, dual_state, tanh_action, eta_eps, alpha_eps, dual_lr,
+                d_logstd, info):
+    n, A = int(mean.shape[0]), int(mean.shape[1])
+    need = lib().trl_vmpo_losses_workspace(n, A)
+    if need < 0:
+        raise TrlError("vmpo_losses: unsupported sizes n=%d A=%d" % (n, A))
+    ws = torch.empty((need,), dtype=torch.float64, device=mean.device)
+    d_mean = torch.empty((n, A), dtype=torch.float32, device=mean.device)
+    check(lib().trl_vmpo_losses_f32(dev_ptr(mean, name="mean"), dev_ptr(target_mean, name="target_mean"),
+                                    dev_ptr(logstd, name="logstd"), dev_ptr(target_logstd, name="target_logstd"),
+                                    dev_ptr(acts, name="acts"), dev_ptr(adv_n, name="adv_n"), dev_ptr(dual_state, name="dual"),
+                                    n, A, int(bool(tanh_action)), float(eta_eps), float(alpha_eps), float(dual_lr),
+                                    dev_ptr(d_mean, name="d_mean"), dev_ptr(d_logstd, name="d_logstd"),
+                                    dev_ptr(info, torch.float64, "info"), dev_ptr(ws, torch.float64, "workspace"),
+                                    stream_ptr(mean.device)), "trl_vmpo_losses_f32")
+    return d_mean
 
 
 def _ptrs(tensors, name, allow_none=False):
