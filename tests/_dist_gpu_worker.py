@@ -1,0 +1,68 @@
+"""Worker of tests/test_dist_gpu.py: one rank of an env-sharded PPO run (or the single-process reference run).
+argv: rank world port out_path.  Both ranks use cuda:0; the collectives go through gloo (RCCL refuses two ranks on one
+device), which exercises exactly the code the nccl backend runs: sharded envs, C1 / C2 / C3 reductions, the unfused
+reduce -> all-reduce -> clip + Adam sequence."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+N_TOTAL, T, ROWS_MB, EPOCHS, HORIZON, MAX_FRAMES = 64, 16, 4, 3, 12, 9
+
+
+class Log:
+    def __init__(self): self.infos = []
+    def add_update_info(self, d): self.infos.append(dict(d))
+    def add_epoch_info(self, *a, **k): pass
+    def log(self, *a): pass
+    def finish(self): pass
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    if world > 1:
+        import torch.distributed as td
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        td.init_process_group("gloo", rank=rank, world_size=world)
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import PPO
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)                                                  # identical index streams on every rank
+    net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=17, output_shape=6, tanh_action=True, **net)
+    vf = networks.Net(input_shape=(17,), output_shape=1, **net)
+    n = N_TOTAL // world
+    kw = dict(horizon=HORIZON, device=dev, index_offset=rank * n, total_env_nums=N_TOTAL)
+    env, eval_env = SynthVecEnv(n, **kw), SynthVecEnv(n, **kw)
+    env.seed(3)
+    buf = OnPolicyReplayBuffer(n * T, env_nums=n, time_limit_filter=True, device=dev)
+    col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=n * T,
+                               max_episode_frames=MAX_FRAMES, noise_mode="device")
+    logger = Log()
+    agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=2, tau=0.95, shuffle=True, entropy_coeff=0.005,
+                discount=0.99, num_epochs=10, batch_size=ROWS_MB * n, gae=True, env=env, replay_buffer=buf, collector=col,
+                logger=logger, device=dev, save_dir=None)
+    for epoch in range(EPOCHS):
+        col.rollout(col.sample_epoch_frames)
+        agent.current_epoch = epoch
+        agent.update_per_epoch()
+    keys = sorted(logger.infos[0])
+    np.savez(out, pf=pf.flat_params().cpu().numpy(), vf=vf.flat_params().cpu().numpy(), keys=np.array(keys),
+             infos=np.array([[i[k] for k in keys] for i in logger.infos]),
+             obs=buf._obs.cpu().numpy(), rewards=buf._rewards.cpu().numpy())
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
