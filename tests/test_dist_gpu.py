@@ -22,10 +22,10 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run(world, tmp_path):
+def _run(world, tmp_path, worker="_dist_gpu_worker.py", extra=()):
     port = _free_port()
-    outs = [str(tmp_path / ("w%d_r%d.npz" % (world, r))) for r in range(world)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), str(r), str(world), port, outs[r]],
+    outs = [str(tmp_path / ("%s_w%d_r%d.npz" % (worker[:-3], world, r))) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, worker), str(r), str(world), port, outs[r], *extra],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     for p in procs:
         log, _ = p.communicate(timeout=600)
@@ -47,3 +47,20 @@ def test_two_ranks_reproduce_one_process(tmp_path):
     assert list(r0["keys"]) == list(single["keys"])
     np.testing.assert_allclose(r0["infos"], r1["infos"], rtol=1e-12, atol=0)
     np.testing.assert_allclose(r0["infos"], single["infos"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("noise", ["device", "host"])
+def test_two_ranks_reproduce_one_process_sac(tmp_path, noise):
+    """Twin-Q SAC with the envs and the replay sharded over two ranks: exploration and update noise are the ranks' blocks
+    of the draw for all envs, the temperature step sees the global batch, gradients are summed before clipping."""
+    (single,) = _run(1, tmp_path, "_dist_gpu_worker_sac.py", (noise,))
+    r0, r1 = _run(2, tmp_path, "_dist_gpu_worker_sac.py", (noise,))
+    np.testing.assert_allclose(np.concatenate([r0["obs"], r1["obs"]], axis=1), single["obs"], atol=2e-5)
+    np.testing.assert_allclose(np.concatenate([r0["acts"], r1["acts"]], axis=1), single["acts"], atol=2e-5)
+    assert np.array_equal(r0["flat"], r1["flat"]) and np.array_equal(r0["tflat"], r1["tflat"])
+    np.testing.assert_allclose(r0["flat"], single["flat"], atol=5e-6)
+    np.testing.assert_allclose(r0["tflat"], single["tflat"], atol=5e-6)
+    np.testing.assert_allclose(r0["log_alpha"], single["log_alpha"], atol=2e-6)
+    assert list(r0["keys"]) == list(single["keys"])
+    np.testing.assert_allclose(r0["infos"], r1["infos"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(r0["infos"], single["infos"], rtol=5e-4, atol=5e-5)

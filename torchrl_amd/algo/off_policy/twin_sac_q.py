@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
-from ... import _C, ops
+from ... import _C, dist, ops
 from ...networks import flatten_into
 from .off_rl_algo import OffRLAlgo
 
@@ -171,8 +171,8 @@ class _FusedSAC:
         new_a, logp = _C.rsample_fwd(head, eps1, tanh_action)
         next_a, next_logp = _C.rsample_fwd(head2, eps2, tanh_action)
         # ---- temperature ----
-        if algo.automatic_entropy_tuning:
-            _C.sac_alpha_step(logp, algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
+        if algo.automatic_entropy_tuning:                                # mean over the GLOBAL batch (all ranks' samples)
+            _C.sac_alpha_step(dist.all_gather_cat(logp), algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
         # ---- all six critic passes as one group: Q1/Q2(s, a), target Q1/Q2(s', a'), Q1/Q2(s, new a) ----
         x_sa, x_next, x_new = _C.concat2(obs, acts), _C.concat2(nobs, next_a), _C.concat2(obs, new_a)
         (q1p, q2p, tq1, tq2, q1n, q2n), (tape_q1, tape_q2, _, _, tape_q1n, tape_q2n) = ops.mlp_forward_group(
@@ -197,16 +197,20 @@ class _FusedSAC:
         for k, lr in enumerate(self._lrs()):
             a.group_lr[k] = lr
         a.max_norm = float(algo.grad_clip) if algo.grad_clip else 0.0
-        a.beta1, a.beta2, a.eps, a.grad_scale = 0.9, 0.999, 1e-8, 1.0
+        a.beta1, a.beta2, a.eps = 0.9, 0.999, 1e-8
+        dist.all_reduce_sum_(self.grads)                                 # C1: every loss is a local mean -> SUM / world
+        a.grad_scale = 1.0 / dist.world_size()
         a.step_count, a.norms_out = 0, self.norms.data_ptr()
         a.step_state = self.step_state.data_ptr()                        # the step count lives on the device
         _C.clip_adam(a, dev)
         if soft:
             _C.polyak(self.tflat, self.flat[self.sizes[0]:], algo.tau)
-        # ---- logging statistics ----
-        _C.moments(head, self.mom[0], ld=2 * A, off=A, width=A, lo=-20.0, hi=2.0)     # clamped log_std
-        _C.moments(logp, self.mom[1], ld=1)
-        _C.moments(head, self.mom[2], ld=2 * A, off=0, width=A)
+        # ---- logging statistics (over the global batch) ----
+        dist.all_reduce_sum_(self.sums)
+        head_g, logp_g = dist.all_gather_cat(head), dist.all_gather_cat(logp)
+        _C.moments(head_g, self.mom[0], ld=2 * A, off=A, width=A, lo=-20.0, hi=2.0)   # clamped log_std
+        _C.moments(logp_g, self.mom[1], ld=1)
+        _C.moments(head_g, self.mom[2], ld=2 * A, off=0, width=A)
 
     def _lrs(self):
         algo = self.algo
@@ -218,7 +222,8 @@ class _FusedSAC:
         (TRL_NO_GRAPH=1 keeps everything eager)."""
         key = (int(st["obs"].shape[0]), soft, self._lrs(), self.algo.grad_clip, self.algo.tau, self.algo.discount,
                bool(self.algo.automatic_entropy_tuning))
-        if os.environ.get("TRL_NO_GRAPH") == "1" or (key not in self._graphs and len(self._graphs) >= 8):
+        if os.environ.get("TRL_NO_GRAPH") == "1" or dist.collectives_active() or \
+                (key not in self._graphs and len(self._graphs) >= 8):     # collectives between ranks: eager launches
             self._sequence(st, soft)                                     # (a learning-rate schedule would mint a key per value)
         elif key in self._graphs:
             self._graphs[key].replay()
@@ -242,35 +247,38 @@ class _FusedSAC:
                 continue
             src = src if isinstance(src, torch.Tensor) else torch.as_tensor(np.asarray(src))
             st[k].copy_(src.to(dtype=torch.float32).reshape(st[k].shape), non_blocking=True)
-        if algo.noise_mode == "host":                                    # distribution.py:67-70: two CPU generator draws
-            st["eps1"].copy_(torch.randn(B, A), non_blocking=True)       # in the reference's order
-            st["eps2"].copy_(torch.randn(B, A), non_blocking=True)
-        else:
-            for k in ("eps1", "eps2"):
+        n_env = int(algo.replay_buffer.env_nums) if getattr(algo, "replay_buffer", None) is not None else B
+        rows = B // n_env if B % n_env == 0 else 1                       # batch = sampled time rows x this rank's envs
+        for k in ("eps1", "eps2"):                                       # distribution.py:67-70: two draws, in this order
+            if algo.noise_mode == "host":
+                make = lambda m, f: torch.randn(m, f)                    # the CPU generator (reference stream)
+            else:
                 self.noise_ctr += 1
-                _C.philox_normal(st[k], self.noise_seed, self.noise_ctr)
+                make = lambda m, f: _C.philox_normal(torch.empty(m, f, device=dev), self.noise_seed, self.noise_ctr)
+            st[k].copy_(dist.shard_rows_of_global(make, rows, B // rows, A, dev), non_blocking=True)
         self._run(st, bool(algo.use_soft_update))
         self.step_count += 1
         if not algo.use_soft_update and algo.training_update_num % algo.target_hard_update_period == 0:
             _C.polyak(self.tflat, self.flat[self.sizes[0]:], 1.0)
         # ---- logging statistics: one read-back, the only host sync of the update ----
+        Bg = B * dist.world_size()                                       # the sums were reduced over all ranks
         raw = self._raw.cpu()
         sums, mom = raw[:32].view(torch.float64).numpy(), raw[32:128].view(torch.float64).view(3, 4).numpy()
         aout, norms = raw[128:136].view(torch.float32).numpy(), raw[136:148].view(torch.float32).numpy()
         w_std, w_mean = algo.policy_std_reg_weight, algo.policy_mean_reg_weight
         reg = 0.0
         if w_std or w_mean:
-            n = B * A - 1
+            n = Bg * A - 1
             ms_ls = mom[0][1] ** 2 * n / (n + 1) + mom[0][0] ** 2                     # E[x^2] from mean / unbiased std
             ms_mu = mom[2][1] ** 2 * n / (n + 1) + mom[2][0] ** 2
             reg = w_std * ms_ls + w_mean * ms_mu
-        info = {'Reward_Mean': sums[3] / B}
+        info = {'Reward_Mean': sums[3] / Bg}
         if algo.automatic_entropy_tuning:
             info["Alpha"] = float(aout[0])
             info["Alpha_loss"] = float(aout[1])
-        info['Training/policy_loss'] = sums[2] / B + reg
-        info['Training/qf1_loss'] = sums[0] / B
-        info['Training/qf2_loss'] = sums[1] / B
+        info['Training/policy_loss'] = sums[2] / Bg + reg
+        info['Training/qf1_loss'] = sums[0] / Bg
+        info['Training/qf2_loss'] = sums[1] / Bg
         if algo.grad_clip is not None:
             info['Training/pf_grad_norm'], info['Training/qf1_grad_norm'], info['Training/qf2_grad_norm'] = \
                 float(norms[0]), float(norms[1]), float(norms[2])

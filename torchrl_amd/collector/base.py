@@ -153,6 +153,17 @@ class VecCollector(BaseCollector):
         log = self._ep_log[:cnt].cpu().numpy()
         return log[np.lexsort((log[:, 1], log[:, 0]))]
 
+    def _explore_noise(self, env):
+        """(N, A) standard normals of this vector step: the CPU generator's draw (distribution.py:67-70) or the device
+        Philox stream; with env shards on several ranks, this rank's rows of the draw for ALL envs."""
+        from .. import dist
+        n, a_dim = env.env_nums, env.act_dim
+        if self.noise_mode == "host":
+            make = lambda m, f: torch.randn(m, f)
+        else:
+            make = lambda m, f: _C.philox_normal(torch.empty(m, f, device=env.device), self._noise_seed, self.global_step)
+        return dist.shard_rows_of_global(make, 1, n, a_dim, env.device).to(env.device, non_blocking=True)
+
     def _policy_action(self, env, deterministic):
         from .. import ops
         pf = self.pf
@@ -167,23 +178,13 @@ class VecCollector(BaseCollector):
             sigma = float(getattr(pf, "norm_std_explore", 0.0))
             if deterministic or not sigma:
                 return act
-            if self.noise_mode == "host":
-                eps = torch.randn(env.env_nums, env.act_dim).to(env.device, non_blocking=True)
-            else:
-                eps = _C.philox_normal(torch.empty(env.env_nums, env.act_dim, device=env.device), self._noise_seed,
-                                       self.global_step)
-            return _C.noisy_action(act, eps, sigma)
+            return _C.noisy_action(act, self._explore_noise(env), sigma)
         if not hasattr(pf, "tanh_action") or hasattr(pf, "logstd"):
             raise _C.TrlError("VecCollector's kernel path expects a GuassianContPolicy (mean | log_std head); "
                               "state-independent-std policies use VecOnPolicyCollector")
         n, a_dim = env.env_nums, env.act_dim
         head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf))
-        if deterministic:
-            eps = torch.zeros(n, a_dim, device=env.device)
-        elif self.noise_mode == "host":
-            eps = torch.randn(n, a_dim).to(env.device, non_blocking=True)      # distribution.py:67-70
-        else:
-            eps = _C.philox_normal(torch.empty(n, a_dim, device=env.device), self._noise_seed, self.global_step)
+        eps = torch.zeros(n, a_dim, device=env.device) if deterministic else self._explore_noise(env)
         act, _ = _C.rsample_fwd(head, eps, bool(pf.tanh_action))
         return act
 

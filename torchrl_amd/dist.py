@@ -91,3 +91,24 @@ def reduce_info_(info):
         info[:, INFO_SUM_COLS] = s
         info[:, INFO_MAX_COLS] = m
     return info
+
+
+def all_gather_cat(t):
+    """Rows of every rank's tensor, concatenated in rank order (identity at world size 1)."""
+    if not _active():
+        return t
+    parts = [torch.empty_like(t) for _ in range(world_size())]
+    td.all_gather(parts, t.contiguous())
+    return torch.cat(parts, dim=0)
+
+
+def shard_rows_of_global(make_global, rows, n_local, feat, device):
+    """The (rows * n_local, feat) block of this rank out of a tensor generated for ALL ranks: `make_global(rows * n_total,
+    feat)` is laid out (rows, n_total, feat) -- a sampled time row x all envs -- and the rank owns envs
+    [rank * n_local, (rank + 1) * n_local).  Every rank generates the same global tensor (same seeds), so the union
+    over ranks is exactly what a single process would have drawn."""
+    w, r = world_size(), rank()
+    if w == 1:
+        return make_global(rows * n_local, feat)
+    g = make_global(rows * n_local * w, feat).view(rows, n_local * w, feat)
+    return g[:, r * n_local:(r + 1) * n_local, :].reshape(rows * n_local, feat).to(device).contiguous()
