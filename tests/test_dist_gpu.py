@@ -64,3 +64,19 @@ def test_two_ranks_reproduce_one_process_sac(tmp_path, noise):
     assert list(r0["keys"]) == list(single["keys"])
     np.testing.assert_allclose(r0["infos"], r1["infos"], rtol=1e-12, atol=0)
     np.testing.assert_allclose(r0["infos"], single["infos"], rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("algo", ["td3", "dqn"])
+def test_two_ranks_reproduce_one_process_td3_dqn(tmp_path, algo):
+    """TD3 (target-smoothing and exploration noise sharded like the envs, per-network gradient SUM) and DQN on uint8
+    frames (epsilon-greedy host draws sharded, conv-net gradient SUM) with two ranks against one process."""
+    (single,) = _run(1, tmp_path, "_dist_gpu_worker_sac.py", ("device", algo))
+    r0, r1 = _run(2, tmp_path, "_dist_gpu_worker_sac.py", ("device", algo))
+    np.testing.assert_allclose(np.concatenate([r0["acts"], r1["acts"]], axis=1), single["acts"], atol=2e-5)
+    np.testing.assert_allclose(np.concatenate([r0["rewards"], r1["rewards"]], axis=1), single["rewards"], atol=1e-6)
+    assert np.array_equal(r0["flat"], r1["flat"]) and np.array_equal(r0["tflat"], r1["tflat"])
+    np.testing.assert_allclose(r0["flat"], single["flat"], atol=5e-6)
+    np.testing.assert_allclose(r0["tflat"], single["tflat"], atol=5e-6)
+    assert list(r0["keys"]) == list(single["keys"])
+    np.testing.assert_allclose(r0["infos"], r1["infos"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(r0["infos"], single["infos"], rtol=5e-4, atol=5e-5)

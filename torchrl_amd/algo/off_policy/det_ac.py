@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
-from ... import _C, ops
+from ... import _C, dist, ops
 from ...networks import flatten_into
 from .off_rl_algo import OffRLAlgo
 
@@ -191,12 +191,15 @@ class _FusedDetAC:
                 continue
             src = src if isinstance(src, torch.Tensor) else torch.as_tensor(np.asarray(src))
             st[k].copy_(src.to(dtype=torch.float32).reshape(st[k].shape), non_blocking=True)
-        for k in noise_keys:
+        buf = getattr(self.algo, "replay_buffer", None)
+        n_env = int(buf.env_nums) if buf is not None and B % int(buf.env_nums) == 0 else B
+        for k in noise_keys:                                               # this rank's block of the draw for all envs
             if getattr(self.algo, "noise_mode", "host") == "host":         # CPU generator draw (reference stream)
-                st[k].copy_(torch.randn(B, self.A), non_blocking=True)
+                make = lambda m, f: torch.randn(m, f)
             else:
                 self.noise_ctr += 1
-                _C.philox_normal(st[k], self.noise_seed, self.noise_ctr)
+                make = lambda m, f: _C.philox_normal(torch.empty(m, f, device=self.dev), self.noise_seed, self.noise_ctr)
+            st[k].copy_(dist.shard_rows_of_global(make, B // n_env, n_env, self.A, self.dev), non_blocking=True)
         return st, B
 
     def _lrs(self):
@@ -207,7 +210,8 @@ class _FusedDetAC:
         (TRL_NO_GRAPH=1 keeps everything eager)."""
         algo = self.algo
         key = key + (self._lrs(), algo.grad_clip, algo.tau, algo.discount)
-        if os.environ.get("TRL_NO_GRAPH") == "1" or (key not in self._graphs and len(self._graphs) >= 8):
+        if os.environ.get("TRL_NO_GRAPH") == "1" or dist.collectives_active() or \
+                (key not in self._graphs and len(self._graphs) >= 8):
             seq()                                                            # (a learning-rate schedule would mint a key per value)
         elif key in self._graphs:
             self._graphs[key].replay()
@@ -226,6 +230,7 @@ class _FusedDetAC:
         every network keeps its own step count, on the device."""
         algo = self.algo
         for k in which:
+            dist.all_reduce_sum_(self.grads[int(self.offsets[k]):int(self.offsets[k + 1])])   # C1: local means -> SUM / world
             a = _C.AdamArgs()
             o = int(self.offsets[k]) * 4
             a.params, a.grads = self.flat.data_ptr() + o, self.grads.data_ptr() + o
@@ -234,7 +239,7 @@ class _FusedDetAC:
             a.group_sizes[0] = self.sizes[k]
             a.group_lr[0] = self.optimizers[k].param_groups[0]['lr']
             a.max_norm = float(algo.grad_clip) if algo.grad_clip else 0.0
-            a.beta1, a.beta2, a.eps, a.grad_scale = 0.9, 0.999, 1e-8, 1.0
+            a.beta1, a.beta2, a.eps, a.grad_scale = 0.9, 0.999, 1e-8, 1.0 / dist.world_size()
             a.step_count, a.norms_out = 0, self.norms.data_ptr() + 4 * k
             a.step_state = self.step_state.data_ptr() + 32 * k
             _C.clip_adam(a, self.dev)
@@ -271,7 +276,8 @@ class _FusedDetAC:
         self._adam((0, 1))
         if soft:
             _C.polyak(self.tflat, self.flat, algo.tau)
-        _C.moments(new_a, self.mom, ld=1)
+        dist.all_reduce_sum_(self.sums)
+        _C.moments(dist.all_gather_cat(new_a), self.mom, ld=1)
 
     def update_ddpg(self, batch):
         algo = self.algo
@@ -281,6 +287,7 @@ class _FusedDetAC:
         self.steps = [n + 1 for n in self.steps]
         if self._hard_update_due():
             _C.polyak(self.tflat, self.flat, 1.0)
+        B = B * dist.world_size()                                           # the sums cover every rank's samples
         raw = self._raw.cpu()
         sums, m = raw[0:32].view(torch.float64).numpy(), raw[64:96].view(torch.float64).numpy()
         norms = raw[96:].view(torch.float32).numpy()
@@ -316,7 +323,9 @@ class _FusedDetAC:
             self._adam((0,))
             if soft:
                 _C.polyak(self.tflat, self.flat, algo.tau)
-            _C.moments(new_a, self.mom, ld=1)
+            dist.all_reduce_sum_(self.sums_p)
+            _C.moments(dist.all_gather_cat(new_a), self.mom, ld=1)
+        dist.all_reduce_sum_(self.sums)
 
     def update_td3(self, batch):
         algo = self.algo
@@ -328,6 +337,7 @@ class _FusedDetAC:
         self.steps = [self.steps[0] + int(delayed), self.steps[1] + 1, self.steps[2] + 1]
         if delayed and self._hard_update_due():
             _C.polyak(self.tflat, self.flat, 1.0)
+        B = B * dist.world_size()                                           # the sums cover every rank's samples
         raw = self._raw.cpu()
         sums, sums_p = raw[0:32].view(torch.float64).numpy(), raw[32:64].view(torch.float64).numpy()
         m, norms = raw[64:96].view(torch.float64).numpy(), raw[96:].view(torch.float32).numpy()

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
-from ... import _C, ops
+from ... import _C, dist, ops
 from ...networks import flatten_into
 from .off_rl_algo import OffRLAlgo
 
@@ -149,12 +149,15 @@ class _FusedDQN:
         a.group_lr[0] = algo.qf_optimizer.param_groups[0]['lr']
         a.max_norm, a.beta1, a.beta2 = 0.0, 0.9, 0.999
         a.eps = float(algo.optimizer_info.get("eps", 1e-8))
-        a.grad_scale, a.step_count, a.norms_out = 1.0, self.step_count, None
+        dist.all_reduce_sum_(self.grads)                                 # C1: local-mean gradients -> SUM / world
+        a.grad_scale, a.step_count, a.norms_out = 1.0 / dist.world_size(), self.step_count, None
         _C.clip_adam(a, dev)
         if algo.use_soft_update:
             _C.polyak(self.tflat, self.flat, algo.tau)
         elif algo.training_update_num % algo.target_hard_update_period == 0:
             _C.polyak(self.tflat, self.flat, 1.0)
+        dist.all_reduce_sum_(self.sums)
+        B, denom = B * dist.world_size(), denom * dist.world_size()
         s = self.sums.cpu().numpy()
         return {'Reward_Mean': s[2] / B, 'Training/qf_loss': s[0] / denom, 'epsilon': algo.pf.epsilon,
                 'q_s_a': s[1] / (B * Q)}

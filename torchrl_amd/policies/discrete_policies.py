@@ -45,8 +45,12 @@ class EpsilonGreedyDQNDiscretePolicy:
             self.epsilon = self.end_epsilon
         output = self._q(x)
         n = int(output.shape[0])
-        u = torch.from_numpy(np.random.rand(n, 1).astype(np.float32)).to(output.device)
-        ra = torch.from_numpy(np.random.randint(low=0, high=self.action_shape, size=(n, 1)).astype(np.int64)).to(output.device)
+        from .. import dist
+        w, r = dist.world_size(), dist.rank()                       # env shards on several ranks: this rank's rows of the
+        u = np.random.rand(n * w, 1)[r * n:(r + 1) * n]             # host draws for ALL envs (identical numpy streams)
+        ra = np.random.randint(low=0, high=self.action_shape, size=(n * w, 1))[r * n:(r + 1) * n]
+        u = torch.from_numpy(u.astype(np.float32)).to(output.device)
+        ra = torch.from_numpy(ra.astype(np.int64)).to(output.device)
         action = _C.eps_greedy(output.contiguous(), self.action_shape, self.quantile_num, u.reshape(-1).contiguous(),
                                ra.reshape(-1).contiguous(), self.epsilon).unsqueeze(-1)
         return {"q_value": output, "action": action}
