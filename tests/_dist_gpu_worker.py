@@ -24,6 +24,7 @@ class Log:
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    obs_norm = len(sys.argv) > 5 and sys.argv[5] == "obs_norm"
     if world > 1:
         import torch.distributed as td
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
@@ -43,11 +44,16 @@ def main():
     n = N_TOTAL // world
     kw = dict(horizon=HORIZON, device=dev, index_offset=rank * n, total_env_nums=N_TOTAL)
     env, eval_env = SynthVecEnv(n, **kw), SynthVecEnv(n, **kw)
+    if obs_norm:                                                       # running normaliser shared by all ranks
+        from torchrl.env import NormObs
+        env, eval_env = NormObs(env), NormObs(eval_env)
     env.seed(3)
     buf = OnPolicyReplayBuffer(n * T, env_nums=n, time_limit_filter=True, device=dev)
     col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=n * T,
                                max_episode_frames=MAX_FRAMES, noise_mode="device")
-    logger = Log()
+    if obs_norm:
+        col.force_per_step = True          # single process: the per-step sequence too (its Philox layout differs from the
+    logger = Log()                         # cooperative kernel's), so that the two runs draw the same exploration noise
     agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=2, tau=0.95, shuffle=True, entropy_coeff=0.005,
                 discount=0.99, num_epochs=10, batch_size=ROWS_MB * n, gae=True, env=env, replay_buffer=buf, collector=col,
                 logger=logger, device=dev, save_dir=None)
@@ -58,7 +64,8 @@ def main():
     keys = sorted(logger.infos[0])
     np.savez(out, pf=pf.flat_params().cpu().numpy(), vf=vf.flat_params().cpu().numpy(), keys=np.array(keys),
              infos=np.array([[i[k] for k in keys] for i in logger.infos]),
-             obs=buf._obs.cpu().numpy(), rewards=buf._rewards.cpu().numpy())
+             obs=buf._obs.cpu().numpy(), rewards=buf._rewards.cpu().numpy(),
+             norm_state=env._obs_normalizer.state.cpu().numpy() if obs_norm else np.zeros(1))
     if world > 1:
         td.barrier()
         td.destroy_process_group()

@@ -49,6 +49,19 @@ def test_two_ranks_reproduce_one_process(tmp_path):
     np.testing.assert_allclose(r0["infos"], single["infos"], rtol=2e-4, atol=2e-5)
 
 
+def test_two_ranks_share_the_observation_normaliser(tmp_path):
+    """obs_norm with env shards: every step the ranks pool their batch moments (all-reduce) before the Chan merge, so
+    both hold the statistics of ALL envs -- the single process keeps them inside the cooperative rollout kernel."""
+    (single,) = _run(1, tmp_path, extra=("obs_norm",))
+    r0, r1 = _run(2, tmp_path, extra=("obs_norm",))
+    assert np.array_equal(r0["norm_state"], r1["norm_state"])
+    np.testing.assert_allclose(r0["norm_state"], single["norm_state"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.concatenate([r0["obs"], r1["obs"]], axis=1), single["obs"], atol=5e-5)
+    assert np.array_equal(r0["pf"], r1["pf"])
+    np.testing.assert_allclose(r0["pf"], single["pf"], atol=1e-5)
+    np.testing.assert_allclose(r0["infos"], single["infos"], rtol=2e-3, atol=2e-4)
+
+
 @pytest.mark.parametrize("noise", ["device", "host"])
 def test_two_ranks_reproduce_one_process_sac(tmp_path, noise):
     """Twin-Q SAC with the envs and the replay sharded over two ranks: exploration and update noise are the ranks' blocks

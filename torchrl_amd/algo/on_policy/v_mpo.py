@@ -71,6 +71,10 @@ class _VMPOEngine(_GenericPPO):
         self._zero_idx = torch.zeros(1, 1, dtype=torch.int64, device=self.dev)
 
     def update(self, batch):
+        from ... import dist
+        if dist.collectives_active():
+            raise _C.TrlError("V-MPO selects the top half of the GLOBAL minibatch by advantage; env shards on several "
+                              "ranks are not built for it")
         algo, ops, dev = self.algo, self.ops, self.dev
         as_t = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
             .to(device=dev, dtype=torch.float32).contiguous()

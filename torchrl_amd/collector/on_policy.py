@@ -131,8 +131,10 @@ class VecOnPolicyCollector(VecCollector):
             buf._old_logp_fresh = (n_steps == buf._max_replay_buffer_size)
 
     def _host_noise(self, n_steps, env):
+        """The reference's CPU stream, step by step; with env shards on several ranks, this rank's rows of each draw."""
         A = self._dims[1]
-        draws = [torch.randn(env.env_nums, A) for _ in range(n_steps)]    # the reference's stream, step by step
+        make = lambda m, f: torch.randn(m, f)
+        draws = [dist.shard_rows_of_global(make, 1, env.env_nums, A, "cpu").cpu() for _ in range(n_steps)]
         return torch.stack(draws).to(env.device, non_blocking=True).contiguous()
 
     # ---- per-step launch sequence: envs with a running observation normaliser ----
@@ -171,8 +173,11 @@ class VecOnPolicyCollector(VecCollector):
             eps = None
         elif noise_t is not None:
             eps = noise_t
-        else:
+        elif dist.world_size() == 1:
             eps = _C.philox_normal(sb["eps"], self._noise_seed, self.global_step)
+        else:                                                             # this rank's rows of the draw for ALL envs
+            make = lambda m, f: _C.philox_normal(torch.empty(m, f, device=env.device), self._noise_seed, self.global_step)
+            eps = dist.shard_rows_of_global(make, 1, N, A, env.device)
         _C.gauss_explore(mean, self.pf.logstd.detach(), eps, bool(self.pf.tanh_action), act=r["acts"],
                          logp=r["old_logp"].view(N))
         raw_next = sb["nxt_raw"] if nz is not None else r["next_obs"]
