@@ -220,3 +220,23 @@ def test_ppo_host_env_example_learns(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     evals = [float(v) for v in re.findall(r"^Running_Average_Rewards\s+(-?[0-9.]+)", out.stdout, flags=re.M)]
     assert len(evals) >= 5 and evals[-1] > -600.0 and evals[-1] > evals[0] + 400.0, evals
+
+
+def test_subproc_example_script_runs(tmp_path):
+    """examples/ppo_continuous_vec_subproc.py (reference wiring: get_subprocvec_env(..., 4)) on the host pendulum id."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = json.load(open(os.path.join(repo, "config", "ppo_pendulum_host.json")))
+    params["replay_buffer"]["size"] = params["collector"]["epoch_frames"] = 8 * 208
+    params["general_setting"].update(num_epochs=2, batch_size=8 * 52, eval_interval=1)
+    params["ppo"]["opt_epochs"] = 2
+    cfg = tmp_path / "pendulum_subproc.json"
+    cfg.write_text(json.dumps(params))
+    out = subprocess.run([sys.executable, os.path.join(repo, "examples", "ppo_continuous_vec_subproc.py"), "--config", str(cfg),
+                          "--vec_env_nums", "8", "--seed", "1", "--log_dir", str(tmp_path / "log"), "--overwrite"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "EPOCH:1" in out.stdout
