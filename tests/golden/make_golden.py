@@ -518,6 +518,57 @@ def case_vmpo_update():
     save("vmpo_update", **out)
 
 
+def case_trpo_update():
+    """TRPO.update (trpo.py:154-226: surrogate gradient, conjugate gradient on the KL Hessian, line search) and
+    TRPO.update_vf (:228-251) on random batches; policies without tanh squashing, as examples/trpo_continuous_vec.py builds
+    them.  Two policy steps with a value step in between."""
+    import contextlib
+    import io
+    import gym
+    import torchrl.policies as policies
+    import torchrl.networks as networks
+    from torchrl.algo import TRPO
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    for tag, B, D, A, H in (("small", 256, 17, 6, 64), ("odd", 193, 11, 3, 32)):
+        torch.manual_seed(17)
+        net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+        pf = policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A, **net)
+        vf = networks.Net(input_shape=(D,), output_shape=1, **net)
+        with torch.no_grad():
+            pf.seq_append_fcs[-1].weight.mul_(30.0)
+            vf.seq_append_fcs[-1].weight.mul_(30.0)
+            pf.logstd.copy_(torch.linspace(-1.0, -0.3, A))
+        env = SynthVecEnvCPU(4)
+        env.action_space = gym.spaces.Box(-1, 1, (A,))
+        agent = TRPO(pf=pf, vf=vf, plr=3e-4, vlr=1e-3, max_kl=0.01, cg_damping=0.1, cg_iters=10, residual_tol=1e-10,
+                     entropy_coeff=0.01, shuffle=True, v_opt_times=2, tau=0.95, discount=0.99, num_epochs=10, batch_size=64,
+                     gae=True, env=env, replay_buffer=None, collector=_StubCollector(), logger=NullLogger(),
+                     device=torch.device("cpu"), save_dir=tempfile.mkdtemp(prefix="trl_save_"))
+        out[f"{tag}_args"] = np.array([B, D, A, H])
+        out.update(state_arrays(f"{tag}_pf0_", pf))
+        out.update(state_arrays(f"{tag}_vf0_", vf))
+        rs = np.random.RandomState(41)
+        for s_ in range(2):
+            obs = rs.randn(B, D).astype(np.float32)
+            with torch.no_grad():
+                mean, std, _ = pf(torch.tensor(obs))
+            batch = {"obs": obs, "acts": (mean + std * torch.tensor(rs.randn(B, A).astype(np.float32))).numpy(),
+                     "advs": rs.randn(B, 1).astype(np.float32) * 2 + 0.5,
+                     "estimate_returns": rs.randn(B, 1).astype(np.float32)}
+            out.update({f"{tag}_s{s_}_batch_{k}": v for k, v in batch.items()})
+            with contextlib.redirect_stdout(io.StringIO()):
+                info = agent.update(batch)
+            out[f"{tag}_s{s_}_info_keys"] = np.array(sorted(info.keys()))
+            out[f"{tag}_s{s_}_info_vals"] = np.array([info[k] for k in sorted(info.keys())], dtype=np.float64)
+            out.update(state_arrays(f"{tag}_pf{s_ + 1}_", pf))
+            vinfo = agent.update_vf({"obs": batch["obs"], "estimate_returns": batch["estimate_returns"]})
+            out[f"{tag}_s{s_}_vinfo_keys"] = np.array(sorted(vinfo.keys()))
+            out[f"{tag}_s{s_}_vinfo_vals"] = np.array([vinfo[k] for k in sorted(vinfo.keys())], dtype=np.float64)
+        out.update(state_arrays(f"{tag}_vf1_", vf))
+    save("trpo_update", **out)
+
+
 def case_ddpg_td3():
     """DDPG.update (ddpg.py:42-110) and TD3.update (td3.py:57-154) on random batches with FixGuassianContPolicy:
     info dicts, the N(0,1) draws TD3 consumes, post-update online and target parameters."""
@@ -638,7 +689,7 @@ def case_obs_norm():
 
 CASES = {"gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
-         "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update}
+         "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update, "trpo_update": case_trpo_update}
 
 if __name__ == "__main__":
     install_stubs()

@@ -363,3 +363,36 @@ def test_vmpo_oracle_matches_reference(golden, tag):
     for a, b in zip(ref.pf, pf1):
         assert (a.detach() - b).abs().max().item() < 2e-6
     assert (ref.logstd.detach() - sd1["logstd"]).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("tag", ["small", "odd"])
+def test_trpo_oracle_matches_reference(golden, tag):
+    """oracle/trpo.py against what the REFERENCE's TRPO.update / update_vf produced (tests/golden/trpo_update.npz)."""
+    import torch
+    from oracle.trpo import TRPOOracle
+    g = golden("trpo_update")
+    B, D, A, H = (int(v) for v in g[tag + "_args"])
+    def flat(prefix):
+        sd = {k[len(prefix):]: torch.tensor(g[k]) for k in g.files if k.startswith(prefix)}
+        lin = sorted({k.rsplit("__", 1)[0] for k in sd if k.endswith("__weight")},
+                     key=lambda n: (0 if n.startswith("base") else 1, n))
+        return [sd[n + "__" + w] for n in lin for w in ("weight", "bias")], sd
+    pf, sd = flat(tag + "_pf0_")
+    vf, _ = flat(tag + "_vf0_")
+    ref = TRPOOracle(pf, sd["logstd"], vf, vlr=1e-3)
+    for s in range(2):
+        batch = {k: g[f"{tag}_s{s}_batch_{k}"] for k in ("obs", "acts", "advs", "estimate_returns")}
+        info = ref.update(batch)
+        keys = [str(k) for k in g[f"{tag}_s{s}_info_keys"]]
+        assert sorted(info) == keys
+        np.testing.assert_allclose([info[k] for k in keys], g[f"{tag}_s{s}_info_vals"], rtol=1e-4, atol=2e-6)
+        # Ten fp32 CG iterations never converge (residual_tol = 1e-10) and the iterate is ill-conditioned: perturbing the
+        # initial weights by 1e-7 (relative) moves the first step by 1.2e-5 and the second by 9e-4 (step sizes ~0.04), so
+        # that is the agreement any two implementations can have -- the reference against itself on another BLAS included.
+        tol = (3e-5, 3e-3)[s]
+        pf1, sd1 = flat(f"{tag}_pf{s + 1}_")
+        for a, b in zip(ref.pf, pf1):
+            assert (a.detach() - b).abs().max().item() < tol
+        assert (ref.logstd.detach() - sd1["logstd"]).abs().max().item() < tol
+        vinfo = ref.update_vf(batch)
+        np.testing.assert_allclose([vinfo[k] for k in sorted(vinfo)], g[f"{tag}_s{s}_vinfo_vals"], rtol=1e-4, atol=2e-6)
