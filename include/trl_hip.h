@@ -224,7 +224,8 @@ int trl_ppo_generic_losses_f32(const float* mean, const float* logstd, const flo
                                void* stream);
 
 /* --- V-MPO: the loss half of VMPO.update (torchrl/algo/on_policy/v_mpo.py:57-181) ----------------------
- * trl_adv_normalize_f32: out = (adv - mean) / (std_unbiased + 1e-5) from trl_adv_stats_f64's {sum, sumsq, ..} (:175-177).
+ * trl_adv_normalize_f32: out = (adv - mean) / (std_unbiased + eps) from trl_adv_stats_f64's {sum, sumsq, ..} (:175-177;
+ *   eps = 1e-5 there and in ppo.py / a2c.py, 1e-4 in trpo.py:168).
  * trl_mse_value_loss_f32: d_v = 2 (v - R) / n_global and the loss SUM over the local samples (:136-153).
  * trl_vmpo_losses_f32: on the n samples the host selected (top half by normalised advantage, :64-70):
  *   phi = softmax(adv_n / eta); L_pi = mean(-phi log pi + alpha KL(pi || pi_target)) -> d_mean (n, A), d_logstd (A);
@@ -232,7 +233,8 @@ int trl_ppo_generic_losses_f32(const float* mean, const float* logstd, const flo
  *   dual_state: 7 floats on the device {eta, alpha, exp_avg x2, exp_avg_sq x2, steps}, initialise {1, 0.1, 0, 0, 0, 0, 0}.
  *   info (12 doubles): 0 policy loss; 1..4 log pi mean / unbiased std / max / min; 5..8 the same of the KL;
  *   9 alpha loss; 10 alpha and 11 eta AFTER the step.  workspace: trl_vmpo_losses_workspace(n, A) doubles. */
-int trl_adv_normalize_f32(const float* advs, const double* adv_raw, double n_global, int B, float* out, void* stream);
+int trl_adv_normalize_f32(const float* advs, const double* adv_raw, double n_global, int B, float eps, float* out,
+                          void* stream);
 int trl_mse_value_loss_f32(const float* v, const float* rets, int B, double n_global, float* d_v, double* loss_sum,
                            void* stream);
 int trl_vmpo_losses_workspace(int n, int A);
@@ -240,6 +242,23 @@ int trl_vmpo_losses_f32(const float* mean, const float* target_mean, const float
                         const float* acts, const float* adv_n, float* dual_state, int n, int A, int tanh_action,
                         float eta_eps, float alpha_eps, float dual_lr, float* d_mean, float* d_logstd, double* info,
                         double* workspace, void* stream);
+
+/* --- TRPO: the element-wise pieces of TRPO.update (torchrl/algo/on_policy/trpo.py:28-226) -----------------
+ * trl_trpo_surrogate_f32: L = -mean(p / (p.detach() + 1e-8) * adv_n) - c_ent * mean(ent) (:170-180) on the whole batch:
+ *   d_mean (n, A), d_logstd (A); info (5 doubles): 0 L, 1..4 log pi mean / unbiased std / max / min.
+ *   workspace: trl_trpo_surrogate_workspace(n, A) doubles.
+ * Fisher-vector product F v of the mean KL(pi_theta || pi_theta.detach()) (:62-87) for a diagonal Gaussian policy
+ * = backward(forward-mode(v) * exp(-2 logstd) / n) on the network parameters and 2 v on each logstd:
+ *   trl_jvp_gate_f32: one layer of the forward-mode pass, out = act'(h) * (a + b) (b, h nullable; a = x W_v^T + b_v
+ *   and b = dx W^T come from trl_linear_fwd_f32);  trl_fisher_scale_f32: out = d_mu * exp(-2 logstd) / n.
+ * trl_ratio_loss_f32: the line search's -mean(exp(log pi_new - log pi_old) * adv_n) (:110-128), one double. */
+int trl_trpo_surrogate_workspace(int n, int A);
+int trl_trpo_surrogate_f32(const float* mean, const float* logstd, const float* acts, const float* adv_n, int n, int A,
+                           int tanh_action, float entropy_coeff, float* d_mean, float* d_logstd, double* info,
+                           double* workspace, void* stream);
+int trl_jvp_gate_f32(const float* a, const float* b, const float* h, int act, int64_t n, float* out, void* stream);
+int trl_fisher_scale_f32(const float* d_mu, const float* logstd, int n, int A, float* out, void* stream);
+int trl_ratio_loss_f32(const float* logp_new, const float* logp_old, const float* adv_n, int n, double* out, void* stream);
 
 /* --- K11: global-norm clip + Adam ------------------------------------------
  * replaces clip_grad_norm_(params, max_norm) + Adam(eps).step()

@@ -142,7 +142,12 @@ SIGNATURES = {
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "trl_adv_normalize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_adv_normalize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "trl_trpo_surrogate_workspace": (C.c_int, [C.c_int] * 2),
+    "trl_trpo_surrogate_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float] + [C.c_void_p] * 5),
+    "trl_jvp_gate_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "trl_fisher_scale_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_ratio_loss_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p]),
     "trl_mse_value_loss_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_vmpo_losses_workspace": (C.c_int, [C.c_int] * 2),
     "trl_vmpo_losses_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_void_p] * 5),
@@ -361,10 +366,47 @@ def ppo_generic_losses(mean, logstd, acts, advs, old_logp, v, rets, v_old, adv_r
     return d_mean, d_v
 
 
-def adv_normalize(advs, adv_raw, n_global):
+def adv_normalize(advs, adv_raw, n_global, eps=1e-5):
     out = torch.empty(int(advs.numel()), dtype=torch.float32, device=advs.device)
     check(lib().trl_adv_normalize_f32(dev_ptr(advs, name="advs"), dev_ptr(adv_raw, torch.float64, "adv_raw"), float(n_global),
-                                      int(advs.numel()), dev_ptr(out, name="out"), stream_ptr(advs.device)), "trl_adv_normalize_f32")
+                                      int(advs.numel()), float(eps), dev_ptr(out, name="out"), stream_ptr(advs.device)),
+          "trl_adv_normalize_f32")
+    return out
+
+
+def trpo_surrogate(mean, logstd, acts, adv_n, tanh_action, entropy_coeff, d_logstd, info):
+    n, A = int(mean.shape[0]), int(mean.shape[1])
+    need = lib().trl_trpo_surrogate_workspace(n, A)
+    if need < 0:
+        raise TrlError("trpo_surrogate: unsupported sizes n=%d A=%d" % (n, A))
+    ws = torch.empty((need,), dtype=torch.float64, device=mean.device)
+    d_mean = torch.empty((n, A), dtype=torch.float32, device=mean.device)
+    check(lib().trl_trpo_surrogate_f32(dev_ptr(mean, name="mean"), dev_ptr(logstd, name="logstd"), dev_ptr(acts, name="acts"),
+                                       dev_ptr(adv_n, name="adv_n"), n, A, int(bool(tanh_action)), float(entropy_coeff),
+                                       dev_ptr(d_mean, name="d_mean"), dev_ptr(d_logstd, name="d_logstd"),
+                                       dev_ptr(info, torch.float64, "info"), dev_ptr(ws, torch.float64, "workspace"),
+                                       stream_ptr(mean.device)), "trl_trpo_surrogate_f32")
+    return d_mean
+
+
+def jvp_gate(a, b, h, act):
+    out = torch.empty_like(a)
+    check(lib().trl_jvp_gate_f32(dev_ptr(a, name="a"), dev_ptr(b, name="b", allow_none=True), dev_ptr(h, name="h", allow_none=True),
+                                 act, int(a.numel()), dev_ptr(out, name="out"), stream_ptr(a.device)), "trl_jvp_gate_f32")
+    return out
+
+
+def fisher_scale(d_mu, logstd):
+    out = torch.empty_like(d_mu)
+    check(lib().trl_fisher_scale_f32(dev_ptr(d_mu, name="d_mu"), dev_ptr(logstd, name="logstd"), int(d_mu.shape[0]),
+                                     int(d_mu.shape[1]), dev_ptr(out, name="out"), stream_ptr(d_mu.device)), "trl_fisher_scale_f32")
+    return out
+
+
+def ratio_loss(logp_new, logp_old, adv_n, out):
+    check(lib().trl_ratio_loss_f32(dev_ptr(logp_new, name="logp_new"), dev_ptr(logp_old, name="logp_old"),
+                                   dev_ptr(adv_n, name="adv_n"), int(adv_n.numel()), dev_ptr(out, torch.float64, "out"),
+                                   stream_ptr(adv_n.device)), "trl_ratio_loss_f32")
     return out
 
 

@@ -1,4 +1,4 @@
-"""Names the reference's example scripts import (`from torchrl.algo import TRPO`) whose algorithms have no
+"""Names the reference's example scripts import (the old single-env scripts) whose algorithms have no
 kernel path in this build.  Importing works; constructing one fails loudly instead of silently
 running somewhere else -- there is no CPU / autograd fallback in this package."""
 from ... import _C
@@ -8,12 +8,8 @@ class _NotBuilt:
     _what = ""
 
     def __init__(self, *args, **kwargs):
-        raise _C.TrlError("%s is not built in torchrl_amd (reference: %s): the HIP path covers PPO, A2C, VMPO, TwinSACQ, "
+        raise _C.TrlError("%s is not built in torchrl_amd (reference: %s): the HIP path covers PPO, A2C, TRPO, VMPO, TwinSACQ, "
                           "DQN, QRDQN, DDPG and TD3" % (type(self).__name__, self._what))
-
-
-class TRPO(_NotBuilt):
-    _what = "torchrl/algo/on_policy/trpo.py -- conjugate-gradient natural-gradient step with a KL line search"
 
 
 class Reinforce(_NotBuilt):

@@ -1,7 +1,7 @@
 // V-MPO (torchrl/algo/on_policy/v_mpo.py:57-181) -- the loss half of VMPO.update as stand-alone kernels; the
 // networks' layers run on the dense-layer GEMM family (k_gemm.hip), the host picks the top half of the minibatch by
 // normalised advantage (v_mpo.py:64-70).
-//   trl_adv_normalize_f32     adv_n = (adv - mean) / (std_unbiased + 1e-5) from the minibatch statistics (:175-177)
+//   trl_adv_normalize_f32     adv_n = (adv - mean) / (std_unbiased + eps) from the minibatch statistics (:175-177)
 //   trl_mse_value_loss_f32    MSE(V, R): loss sum and d/dV (:136-153)
 //   trl_vmpo_losses_f32       on the selected samples: phi = softmax(adv_n / eta), log pi (TanhNormal, the PPO helper),
 //                             KL(pi || pi_target) of the diagonal Gaussians, L_pi = mean(-phi log pi + alpha KL);
@@ -29,11 +29,11 @@ __device__ __forceinline__ double vm_block_reduce(double v, bool is_max, double*
 
 __global__ __launch_bounds__(VM_THREADS) void adv_normalize_kernel(const float* __restrict__ advs,
                                                                   const double* __restrict__ raw, double ng, int B,
-                                                                  float* __restrict__ out) {
+                                                                  float eps, float* __restrict__ out) {
   const int b = blockIdx.x * VM_THREADS + threadIdx.x;
   if (b >= B) return;
   const double mean = raw[0] / ng, var = (raw[1] - raw[0] * raw[0] / ng) / (ng - 1.0);
-  out[b] = (advs[b] - (float)mean) * (1.0f / ((float)sqrt(fmax(var, 0.0)) + 1e-5f));
+  out[b] = (advs[b] - (float)mean) * (1.0f / ((float)sqrt(fmax(var, 0.0)) + eps));
 }
 
 __global__ __launch_bounds__(VM_THREADS) void mse_value_kernel(const float* __restrict__ v, const float* __restrict__ rets,
@@ -177,12 +177,12 @@ __global__ __launch_bounds__(VM_THREADS) void vmpo_fold_kernel(const double* __r
   }
 }
 
-extern "C" int trl_adv_normalize_f32(const float* advs, const double* adv_raw, double n_global, int B, float* out,
-                                     void* stream) {
+extern "C" int trl_adv_normalize_f32(const float* advs, const double* adv_raw, double n_global, int B, float eps,
+                                     float* out, void* stream) {
   TRL_REQUIRE(B > 0 && n_global >= 2.0, "need at least two samples");
   TRL_REQUIRE(advs && adv_raw && out, "null pointer");
   hipLaunchKernelGGL(adv_normalize_kernel, dim3(trl_ceil_div(B, VM_THREADS)), dim3(VM_THREADS), 0, (hipStream_t)stream, advs,
-                     adv_raw, n_global, B, out);
+                     adv_raw, n_global, B, eps, out);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
