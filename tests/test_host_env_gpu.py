@@ -240,3 +240,21 @@ def test_subproc_example_script_runs(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "EPOCH:1" in out.stdout
+
+
+def test_single_env_sac_example_runs(tmp_path):
+    """examples/twin_sac_q_continuous.py: `get_env` + `BaseCollector` + `BaseReplayBuffer(size)` (one env)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = json.load(open(os.path.join(repo, "config", "sac_pendulum_single.json")))
+    params["general_setting"].update(num_epochs=2, pretrain_epochs=2, opt_times=5, eval_interval=1)
+    cfg = tmp_path / "sac_single.json"
+    cfg.write_text(json.dumps(params))
+    out = subprocess.run([sys.executable, os.path.join(repo, "examples", "twin_sac_q_continuous.py"), "--config", str(cfg),
+                          "--seed", "1", "--log_dir", str(tmp_path / "log"), "--overwrite"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "EPOCH:1" in out.stdout

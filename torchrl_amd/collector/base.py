@@ -18,7 +18,7 @@ import torch
 from .. import _C
 
 
-class BaseCollector:
+class _CollectorBase:
     def __init__(self, env, eval_env, pf, replay_buffer, epoch_frames, train_render=False,
                  eval_episodes=1, eval_render=False, device='cpu', max_episode_frames=999):
         from ..env.vecenv import HostEnvBridge, VecEnv
@@ -85,7 +85,7 @@ class BaseCollector:
                                   "use VecOnPolicyCollector with a device env")
 
 
-class VecCollector(BaseCollector):
+class VecCollector(_CollectorBase):
     """Off-policy vector collector (torchrl/collector/base.py:176-280) on the device env.
 
     One vector step = policy MLP on the MFMA layer kernels -> reparameterised TanhNormal sample ->
@@ -97,8 +97,8 @@ class VecCollector(BaseCollector):
     """
     EP_LOG_CAP = 1 << 16
 
-    def __init__(self, noise_mode="host", **kwargs):
-        super().__init__(**kwargs)
+    def __init__(self, noise_mode="host", eval_env=None, **kwargs):
+        super().__init__(eval_env=eval_env, **kwargs)
         self.sample_epoch_frames //= self.env.env_nums
         if not (getattr(self.env, "is_device_env", False) or getattr(self.env, "is_host_env", False)):
             raise _C.TrlError("torchrl_amd collectors drive an on-GPU env (torchrl_amd.env.get_vec_env) or a host "
@@ -302,3 +302,14 @@ class VecCollector(BaseCollector):
             rews += [np.float32(first[i][0]) for i in sorted(first)]
             lens += [first[i][1] for i in sorted(first)]
         return {"eval_rewards": rews, "eval_traj_length": float(np.mean(lens)) if lens else 0.0}
+
+
+class BaseCollector(VecCollector):
+    """The reference's single-env off-policy collector (torchrl/collector/base.py:10-174): here the vector collector
+    on a one-env env (`torchrl.env.get_env`), so the single-env example scripts run on the same kernels."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        if self.env.env_nums != 1:
+            raise _C.TrlError("BaseCollector drives a single env (torchrl.env.get_env); use VecCollector for %d envs"
+                              % self.env.env_nums)
