@@ -74,8 +74,11 @@ class EpsilonGreedyQRDQNDiscretePolicy(EpsilonGreedyDQNDiscretePolicy):
 
 
 class CategoricalDisPolicy:
-    """Imported by the reference's discrete on-policy examples (ppo / a2c _discrete_atari_vec.py); the categorical
-    on-policy losses have no kernel path in this build: constructing one fails loudly."""
+    """Imported by the reference's discrete on-policy examples (ppo / a2c _discrete_atari_vec.py).  There is nothing to
+    be faithful to on that path: the reference's PPO.update_actor reads out['log_std'] (ppo.py:52), which this policy's
+    `update` does not return (discrete_policies.py:156-168), and the vector collector stores (N, 1) actions that
+    `Categorical.log_prob` broadcasts against the (B,) batch shape -- the scripts fail at the first update.  No kernel
+    path is built for it; constructing one fails loudly."""
 
     def __init__(self, *args, **kwargs):
         raise _C.TrlError("CategoricalDisPolicy is not built in torchrl_amd: on-policy algorithms here take "
