@@ -135,3 +135,39 @@ def test_collect_and_train_on_another_env_shape():
     assert (torch.cat([p.detach().reshape(-1) for p in pf.parameters()]) - p0).abs().max() > 0
     ev = col.eval_one_epoch()
     assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == 12
+
+
+def test_graph_replayed_per_step_rollout_equals_eager(monkeypatch):
+    """Shapes without a persistent rollout kernel collect through per-step launch sequences; from the third rollout on
+    the whole sequence replays as one HIP graph.  Same launches and the same up-front noise draw: identical buffers."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    N, T, D, A = 16, 12, 9, 2
+    results = []
+    for no_graph in ("1", "0"):
+        monkeypatch.setenv("TRL_NO_GRAPH", no_graph)
+        torch.manual_seed(0)
+        net = dict(hidden_shapes=[24, 40], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+        pf = policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A, tanh_action=True, **net)
+        vf = networks.Net(input_shape=(D,), output_shape=1, **net)
+        env, eval_env = (SynthVecEnv(N, obs_dim=D, act_dim=A, horizon=7, device=DEV) for _ in range(2))
+        env.seed(1)
+        buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+        col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=DEV, train_render=False,
+                                   epoch_frames=N * T, max_episode_frames=5, eval_episodes=1, noise_mode="device")
+        snaps = []
+        for _ in range(4):
+            res = col.train_one_epoch()
+            snaps.append({k: getattr(buf, "_" + k).clone() for k in ("obs", "next_obs", "acts", "values", "rewards",
+                                                                     "terminals", "old_logp")}
+                         | {"reward": res["train_epoch_reward"], "n_eps": len(res["train_rewards"])})
+        assert (col._roll_graph["graph"] is not None) == (no_graph == "0")
+        results.append(snaps)
+    for a, b in zip(*results):
+        assert a["reward"] == b["reward"] and a["n_eps"] == b["n_eps"]
+        for k in a:
+            if isinstance(a[k], torch.Tensor):
+                assert torch.equal(a[k], b[k]), k

@@ -199,15 +199,52 @@ class VecOnPolicyCollector(VecCollector):
         return nxt
 
     def _rollout_per_step(self, n_steps):
-        env = self.env
-        noise = self._host_noise(n_steps, env) if self.noise_mode == "host" else None
+        """`n_steps` vector steps as per-step launch sequences.  On a device env with device noise and a ring that the
+        rollout fills exactly, the whole sequence (~17 launches x n_steps) is captured into a HIP graph on its second
+        visit and replayed afterwards -- the eager sequence is host-launch-bound (~190 us per step); the rollout's
+        exploration noise is then drawn up front in one Philox launch."""
+        env, buf = self.env, self.replay_buffer
+        D, A = self._dims
+        graphable = (self.noise_mode == "device" and not getattr(env, "is_host_env", False) and dist.world_size() == 1
+                     and buf._top == 0 and n_steps == buf._max_replay_buffer_size)
+        capture = os.environ.get("TRL_NO_GRAPH") != "1"                   # same launches and noise either way
         ob = torch.as_tensor(self.current_ob).to(device=env.device, dtype=torch.float32).contiguous()
         self._clear_header()
-        for t in range(n_steps):
-            ob = self._step_launches(env, ob, True, False, None if noise is None else noise[t], t)
-            self.global_step += 1
+        if not graphable:
+            noise = self._host_noise(n_steps, env) if self.noise_mode == "host" else None
+            for t in range(n_steps):
+                ob = self._step_launches(env, ob, True, False, None if noise is None else noise[t], t)
+                self.global_step += 1
+        else:
+            st = getattr(self, "_roll_graph", None)
+            if st is None or st["key"] != (n_steps, env.env_nums):
+                st = self._roll_graph = {"key": (n_steps, env.env_nums), "graph": None, "seen": False,
+                                         "ob0": torch.empty(env.env_nums, D, device=env.device),
+                                         "noise": torch.empty(n_steps, env.env_nums, A, device=env.device), "out": None}
+            st["ob0"].copy_(ob)
+            _C.philox_normal(st["noise"], self._noise_seed, self.global_step)
+
+            def steps():
+                o = st["ob0"]
+                for t in range(n_steps):
+                    o = self._step_launches(env, o, True, False, st["noise"][t], t)
+                buf._top = 0                                              # (the host-side ring cursor is advanced below)
+                return o
+            if st["graph"] is not None:
+                st["graph"].replay()
+            elif not st["seen"] or not capture:
+                st["seen"] = True
+                st["out"] = steps()
+            else:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    st["out"] = steps()
+                st["graph"] = graph
+                graph.replay()
+            ob = st["out"]
+            self.global_step += n_steps
+            buf._advance(n_steps)
         self.current_ob = ob
-        buf = self.replay_buffer
         buf._old_logp_fresh = (n_steps == buf._max_replay_buffer_size)
 
     def rollout(self, n_steps):
