@@ -146,7 +146,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_bwdw_direct_kernel(ConvSrc c
     colsum_part[(size_t)blockIdx.x * Cout + tid] = (cs[tid] + cs[16 + tid]) + (cs[32 + tid] + cs[48 + tid]);
 }
 
-bool trl_conv1_direct_ok(int K, int Cout, const float* w) {
+bool trl_conv1_direct_ok(int K, int Cout, const float* w) {     // w: the forward's weight matrix (16-byte loads), or null
   return Cout <= 16 && K <= 256 && (K & 63) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
 }
 

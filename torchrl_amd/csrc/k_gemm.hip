@@ -712,7 +712,7 @@ extern "C" int trl_conv_bwd_weight_u8_f32(const float* dy, const float* y_gate, 
   int M, K;
   int rc = fill_conv("conv_bwd_weight_u8", frames, B, C, H, W, kh, kw, sh, sw, scale, shift, cv, M, K);
   if (rc) return rc;
-  if (trl_conv1_direct_ok(K, Cout, dw))
+  if (trl_conv1_direct_ok(K, Cout, nullptr))           // (the 16-byte alignment is a requirement of the forward's weight loads)
     return trl_conv1_direct_bwdw(cv, dy, y_gate, gate_act, dw, db, workspace, M, K, Cout, (hipStream_t)stream);
   return bwd_weight_impl<2>(1, &dy, &y_gate, gate_act, nullptr, &cv, &dw, &db, workspace, M, K, Cout, (hipStream_t)stream);
 }
