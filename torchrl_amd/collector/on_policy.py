@@ -205,9 +205,11 @@ class VecOnPolicyCollector(VecCollector):
         exploration noise is then drawn up front in one Philox launch."""
         env, buf = self.env, self.replay_buffer
         D, A = self._dims
-        graphable = (self.noise_mode == "device" and not getattr(env, "is_host_env", False) and dist.world_size() == 1
+        graphable = (self.noise_mode == "device" and not getattr(env, "is_host_env", False)
                      and buf._top == 0 and n_steps == buf._max_replay_buffer_size)
-        capture = os.environ.get("TRL_NO_GRAPH") != "1"                   # same launches and noise either way
+        # same launches and the same noise whether captured or not; env shards on several ranks (collectives between
+        # the steps) run it eagerly on their block of the global draw
+        capture = os.environ.get("TRL_NO_GRAPH") != "1" and dist.world_size() == 1
         ob = torch.as_tensor(self.current_ob).to(device=env.device, dtype=torch.float32).contiguous()
         self._clear_header()
         if not graphable:
@@ -222,7 +224,11 @@ class VecOnPolicyCollector(VecCollector):
                                          "ob0": torch.empty(env.env_nums, D, device=env.device),
                                          "noise": torch.empty(n_steps, env.env_nums, A, device=env.device), "out": None}
             st["ob0"].copy_(ob)
-            _C.philox_normal(st["noise"], self._noise_seed, self.global_step)
+            if dist.world_size() == 1:
+                _C.philox_normal(st["noise"], self._noise_seed, self.global_step)
+            else:                                                         # (T, N_total, A) drawn identically on every rank
+                make = lambda m, f: _C.philox_normal(torch.empty(m, f, device=env.device), self._noise_seed, self.global_step)
+                st["noise"].copy_(dist.shard_rows_of_global(make, n_steps, env.env_nums, A, env.device).view_as(st["noise"]))
 
             def steps():
                 o = st["ob0"]
