@@ -110,6 +110,15 @@ def _worker(rank, world, port, out_dir):
             np.testing.assert_allclose(state[0], ref._mean, rtol=1e-12, atol=1e-13)
             np.testing.assert_allclose(state[1], ref._var, rtol=1e-11, atol=1e-13)
             assert abs(state[2] - ref._count) < 1e-9
+        # noise / host-draw sharding: every rank generates the draw for ALL envs and keeps its own env block, so the
+        # union over ranks is what one process would have drawn (off-policy engines, per-step collection, eps-greedy)
+        rows, n_loc, feat = 3, 4, 2
+        mk = lambda m, f: torch.manual_seed(11) and torch.randn(m, f)
+        mine = dist.shard_rows_of_global(mk, rows, n_loc, feat, "cpu")
+        whole = mk(rows * n_loc * world, feat).view(rows, n_loc * world, feat)
+        assert torch.equal(mine, whole[:, rank * n_loc:(rank + 1) * n_loc].reshape(rows * n_loc, feat))
+        cat = dist.all_gather_cat(mine)
+        assert cat.shape == (world * rows * n_loc, feat) and torch.equal(cat[rank * rows * n_loc:(rank + 1) * rows * n_loc], mine)
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         td.destroy_process_group()
@@ -119,6 +128,13 @@ def test_two_rank_gloo_sharding_and_collectives(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+
+
+def test_single_process_sharding_helpers_are_identities():
+    from torchrl_amd import dist
+    x = torch.arange(12.0).view(6, 2)
+    assert dist.all_gather_cat(x) is x
+    assert torch.equal(dist.shard_rows_of_global(lambda m, f: torch.arange(float(m * f)).view(m, f), 3, 2, 2, "cpu"), x)
 
 
 def test_single_process_helpers_are_noops():
