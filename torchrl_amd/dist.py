@@ -77,12 +77,14 @@ def reduce_adv_raw_(raw):
 
 
 # columns of the per-update info rows (include/trl_hip.h, trl_ppo_reduce_f32)
-INFO_SUM_COLS = [0, 1, 2, 7]
-INFO_MAX_COLS = [3, 4, 5, 6]
+# sums: surrogate, log-prob sum / sum of squares, value loss, value-prediction sum / sum of squares;
+# maxima: max / -min of log-prob, ratio and value prediction.  Slots 8..11 and 16..19 derive from logstd (replicated).
+INFO_SUM_COLS = [0, 1, 2, 7, 12, 13]
+INFO_MAX_COLS = [3, 4, 5, 6, 14, 15]
 
 
 def reduce_info_(info):
-    """info: (K, 16) float64 per-update statistics -> global (C3)."""
+    """info: (K, 24) float64 per-update statistics -> global (C3)."""
     if _active():
         s = info[:, INFO_SUM_COLS].contiguous()
         m = info[:, INFO_MAX_COLS].contiguous()
