@@ -24,14 +24,15 @@ class Log:
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
-    obs_norm = len(sys.argv) > 5 and sys.argv[5] == "obs_norm"
+    mode = sys.argv[5] if len(sys.argv) > 5 else ""
+    obs_norm = mode == "obs_norm"
     if world > 1:
         import torch.distributed as td
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         td.init_process_group("gloo", rank=rank, world_size=world)
     import torchrl.networks as networks
     import torchrl.policies as policies
-    from torchrl.algo import PPO
+    from torchrl.algo import A2C, PPO, TRPO, VMPO
     from torchrl.collector.on_policy import VecOnPolicyCollector
     from torchrl.env.synth import SynthVecEnv
     from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
@@ -54,16 +55,24 @@ def main():
     if obs_norm:
         col.force_per_step = True          # single process: the per-step sequence too (its Philox layout differs from the
     logger = Log()                         # cooperative kernel's), so that the two runs draw the same exploration noise
-    agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=2, tau=0.95, shuffle=True, entropy_coeff=0.005,
-                discount=0.99, num_epochs=10, batch_size=ROWS_MB * n, gae=True, env=env, replay_buffer=buf, collector=col,
-                logger=logger, device=dev, save_dir=None)
+    common = dict(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, tau=0.95, shuffle=True, entropy_coeff=0.005, discount=0.99, num_epochs=10,
+                  batch_size=ROWS_MB * n, gae=True, env=env, replay_buffer=buf, collector=col, logger=logger, device=dev,
+                  save_dir=None)
+    if mode == "a2c":
+        agent = A2C(**common)
+    elif mode == "vmpo":                   # replicated update on the gathered minibatch (global top half by advantage)
+        agent = VMPO(opt_epochs=2, eta_eps=0.02, alpha_eps=0.1, **common)
+    elif mode == "trpo":                   # replicated natural-gradient step on the gathered epoch
+        agent = TRPO(max_kl=0.01, cg_damping=1e-2, v_opt_times=2, cg_iters=10, residual_tol=1e-10, **common)
+    else:
+        agent = PPO(clip_para=0.2, opt_epochs=2, **common)
     for epoch in range(EPOCHS):
         col.rollout(col.sample_epoch_frames)
         agent.current_epoch = epoch
         agent.update_per_epoch()
     keys = sorted(logger.infos[0])
     np.savez(out, pf=pf.flat_params().cpu().numpy(), vf=vf.flat_params().cpu().numpy(), keys=np.array(keys),
-             infos=np.array([[i[k] for k in keys] for i in logger.infos]),
+             infos=np.array([[i[k] for k in keys] for i in logger.infos if sorted(i) == keys]),
              obs=buf._obs.cpu().numpy(), rewards=buf._rewards.cpu().numpy(),
              norm_state=env._obs_normalizer.state.cpu().numpy() if obs_norm else np.zeros(1))
     if world > 1:

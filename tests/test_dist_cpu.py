@@ -78,7 +78,7 @@ def _worker(rank, world, port, out_dir):
         assert (flat - want).abs().max().item() < 1e-6 * max(1.0, want.abs().max().item())
 
         # C3: logging statistics
-        info = torch.zeros(2, 16, dtype=torch.float64)
+        info = torch.zeros(2, 24, dtype=torch.float64)
         info[:, dist.INFO_SUM_COLS] = float(rank + 1)
         info[:, dist.INFO_MAX_COLS] = float(rank)
         info[:, 8] = 7.0                                   # log_std columns are rank-identical: untouched
@@ -117,6 +117,10 @@ def _worker(rank, world, port, out_dir):
         mine = dist.shard_rows_of_global(mk, rows, n_loc, feat, "cpu")
         whole = mk(rows * n_loc * world, feat).view(rows, n_loc * world, feat)
         assert torch.equal(mine, whole[:, rank * n_loc:(rank + 1) * n_loc].reshape(rows * n_loc, feat))
+        # ... and gather_env_shards is its inverse: the shards reassemble into the single-process minibatch (V-MPO, TRPO)
+        assert torch.equal(dist.gather_env_shards(mine, n_loc), whole.reshape(rows * n_loc * world, feat))
+        assert torch.equal(dist.gather_env_shards(mine[:, 0].contiguous().view(-1, 1), n_loc).view(-1),
+                           whole[:, :, 0].reshape(-1))
         cat = dist.all_gather_cat(mine)
         assert cat.shape == (world * rows * n_loc, feat) and torch.equal(cat[rank * rows * n_loc:(rank + 1) * rows * n_loc], mine)
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")

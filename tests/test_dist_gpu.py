@@ -49,6 +49,33 @@ def test_two_ranks_reproduce_one_process(tmp_path):
     np.testing.assert_allclose(r0["infos"], single["infos"], rtol=2e-4, atol=2e-5)
 
 
+def test_two_ranks_reproduce_one_process_a2c(tmp_path):
+    """A2C logs value-prediction statistics (a2c.py:86-105): their sums / extrema are pooled over the ranks as well."""
+    (single,) = _run(1, tmp_path, extra=("a2c",))
+    r0, r1 = _run(2, tmp_path, extra=("a2c",))
+    assert np.array_equal(r0["pf"], r1["pf"]) and np.array_equal(r0["vf"], r1["vf"])
+    np.testing.assert_allclose(r0["pf"], single["pf"], atol=2e-6)
+    np.testing.assert_allclose(r0["vf"], single["vf"], atol=2e-6)
+    assert "v_pred/max" in list(r0["keys"])
+    np.testing.assert_allclose(r0["infos"], r1["infos"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(r0["infos"], single["infos"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("algo,p_tol,i_tol", [("vmpo", 2e-5, 2e-3), ("trpo", 5e-3, None)])
+def test_two_ranks_gather_the_minibatch_for_global_steps(tmp_path, algo, p_tol, i_tol):
+    """V-MPO's top half by advantage and TRPO's natural-gradient solve are steps over the GLOBAL minibatch: the ranks
+    gather their env shards and run the update replicated, so parameters are bit-identical across ranks and follow the
+    single-process run (TRPO up to the conditioning of its ten-iteration fp32 CG, see test_trpo_gpu.py)."""
+    (single,) = _run(1, tmp_path, extra=(algo,))
+    r0, r1 = _run(2, tmp_path, extra=(algo,))
+    assert np.array_equal(r0["pf"], r1["pf"]) and np.array_equal(r0["vf"], r1["vf"])
+    assert np.array_equal(r0["infos"], r1["infos"])
+    np.testing.assert_allclose(r0["pf"], single["pf"], atol=p_tol)
+    np.testing.assert_allclose(r0["vf"], single["vf"], atol=p_tol)
+    if i_tol is not None:
+        np.testing.assert_allclose(r0["infos"], single["infos"], rtol=i_tol, atol=i_tol)
+
+
 def test_two_ranks_share_the_observation_normaliser(tmp_path):
     """obs_norm with env shards: every step the ranks pool their batch moments (all-reduce) before the Chan merge, so
     both hold the statistics of ALL envs -- the single process keeps them inside the cooperative rollout kernel."""

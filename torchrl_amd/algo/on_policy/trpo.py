@@ -17,7 +17,7 @@ Works for any MLP shape; policies are used as built (examples/trpo_continuous_ve
 import numpy as np
 import torch
 
-from ... import _C
+from ... import _C, dist
 from .. import utils as atu
 from .a2c import A2C
 from .ppo import _GenericPPO
@@ -141,6 +141,12 @@ class _TRPOEngine(_GenericPPO):
             .to(device=dev, dtype=torch.float32).contiguous()
         self.obs, self.acts = as_t(batch['obs']), as_t(batch['acts'])
         advs = as_t(batch['advs']).reshape(-1)
+        if dist.collectives_active():
+            # The natural-gradient step (CG on Fisher products, line search) is one global solve: gather the env shards
+            # and run it replicated on the single-process batch -- identical parameters on every rank, no exchange.
+            ne = int(algo.replay_buffer.env_nums)
+            self.obs, self.acts = dist.gather_env_shards(self.obs, ne), dist.gather_env_shards(self.acts, ne)
+            advs = dist.gather_env_shards(advs.view(-1, 1), ne).view(-1)
         self.n = n = int(self.obs.shape[0])
         self.tanh_action = bool(getattr(algo.pf, "tanh_action", False))
         raw, info = self._stat[:4], self._stat[4:9]
@@ -173,6 +179,9 @@ class _TRPOEngine(_GenericPPO):
         as_t = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
             .to(device=dev, dtype=torch.float32).contiguous()
         obs, rets = as_t(batch['obs']), as_t(batch['estimate_returns']).reshape(-1)
+        if dist.collectives_active():
+            ne = int(algo.replay_buffer.env_nums)
+            obs, rets = dist.gather_env_shards(obs, ne), dist.gather_env_shards(rets.view(-1, 1), ne).view(-1)
         B = int(obs.shape[0])
         v, tape = ops.mlp_forward(self.vf_layers, obs, self.act)
         d_v = _C.mse_value_loss(v.view(-1), rets, 2 * B, self._stat[10:11])       # 0.5 * mean((v - R)^2): d = (v - R) / B

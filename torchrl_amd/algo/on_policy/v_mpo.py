@@ -72,14 +72,21 @@ class _VMPOEngine(_GenericPPO):
 
     def update(self, batch):
         from ... import dist
-        if dist.collectives_active():
-            raise _C.TrlError("V-MPO selects the top half of the GLOBAL minibatch by advantage; env shards on several "
-                              "ranks are not built for it")
         algo, ops, dev = self.algo, self.ops, self.dev
         as_t = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
             .to(device=dev, dtype=torch.float32).contiguous()
         obs, acts = as_t(batch['obs']), as_t(batch['acts'])
         advs, rets = as_t(batch['advs']).reshape(-1), as_t(batch['estimate_returns']).reshape(-1)
+        if dist.collectives_active():
+            # The actor step runs on the top half of the GLOBAL minibatch by advantage, which no rank can pick from its
+            # env shard alone: gather the shards (4 small tensors) and run the whole update replicated -- every rank
+            # then holds the single-process minibatch, so no gradient exchange is needed and parameters stay identical.
+            n = int(algo.replay_buffer.env_nums)
+            if obs.shape[0] % n != 0:
+                raise _C.TrlError("minibatch of %d samples is not a whole number of %d-env rows" % (obs.shape[0], n))
+            obs, acts = dist.gather_env_shards(obs, n), dist.gather_env_shards(acts, n)
+            advs = dist.gather_env_shards(advs.view(-1, 1), n).view(-1)
+            rets = dist.gather_env_shards(rets.view(-1, 1), n).view(-1)
         B = int(obs.shape[0])
         raw, info, vloss = self._raw[:4], self._raw[4:16], self._raw[16:17]
         norms = self._raw[17:18].view(torch.float32)

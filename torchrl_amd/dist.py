@@ -104,6 +104,19 @@ def all_gather_cat(t):
     return torch.cat(parts, dim=0)
 
 
+def gather_env_shards(t, n_local):
+    """(rows * n_local, feat) minibatch shard of every rank -> the (rows * n_total, feat) minibatch a single process
+    would hold: row-major over (sampled time row, env), envs in rank order.  Identity at world size 1."""
+    if not _active():
+        return t
+    feat = t.shape[1:]
+    rows = t.shape[0] // n_local
+    parts = [torch.empty_like(t) for _ in range(world_size())]
+    td.all_gather(parts, t.contiguous())
+    whole = torch.cat([p.view(rows, n_local, *feat) for p in parts], dim=1)
+    return whole.reshape(rows * whole.shape[1], *feat).contiguous()
+
+
 def shard_rows_of_global(make_global, rows, n_local, feat, device):
     """The (rows * n_local, feat) block of this rank out of a tensor generated for ALL ranks: `make_global(rows * n_total,
     feat)` is laid out (rows, n_total, feat) -- a sampled time row x all envs -- and the rank owns envs
