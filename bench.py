@@ -208,6 +208,57 @@ def cpu_baseline_subprocess(timeout_s=240):
                 "sample": "failed: exceeded %ds on this host" % timeout_s}
 
 
+def _probe_child():
+    """`bench.py --probe-graph-collectives`: a sacrificial process per rank (own rendezvous port) that captures RCCL
+    all-reduces of the gradient's size into a HIP graph, replays it and checks the sums.  Exit code 0 = usable."""
+    import datetime
+    import torch
+    import torch.distributed as td
+    rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=60))
+    n = 11008                                    # the flat [pf | vf] gradient, 44 KB
+    src = torch.full((n,), rank + 1.0, device=dev)
+    buf = src.clone()
+    td.all_reduce(buf)                           # communicator set-up outside the capture
+    torch.cuda.synchronize()
+    stat = torch.zeros(80, dtype=torch.float64, device=dev)       # the advantage extrema: float64, MAX
+    td.all_reduce(stat, op=td.ReduceOp.MAX)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        stat.fill_(float(rank))
+        td.all_reduce(stat, op=td.ReduceOp.MAX)
+        for _ in range(4):
+            buf.mul_(0.5)
+            td.all_reduce(buf)
+    want = 0.5 * world * (world + 1) / 2 * (0.5 * world) ** 3
+    for _ in range(20):
+        buf.copy_(src)
+        graph.replay()
+    torch.cuda.synchronize()
+    ok = bool(torch.allclose(buf, torch.full_like(buf, want), rtol=1e-5)) and bool((stat == world - 1.0).all())
+    td.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+def probe_graph_collectives(timeout_s=150):
+    """True when graph-captured RCCL collectives work on this node, established in child processes so that a hang or
+    a crash there costs a time-out, not the benchmark (the children are killed by PID)."""
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+    for key in [k for k in env if k.startswith("TORCHELASTIC_")]:     # the children rendezvous on their own TCP store,
+        del env[key]                                                   # not on the launcher's agent store
+    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--probe-graph-collectives"], env=env,
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        return proc.wait(timeout=timeout_s) == 0
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.wait()
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,7 +268,10 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="ppo", choices=["ppo", "sac", "dqn", "qrdqn"],
                     help="with --cpu-baseline-only: which workload's CPU baseline to time (tools/bench_{sac,dqn}.py)")
+    ap.add_argument("--probe-graph-collectives", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.probe_graph_collectives:
+        _probe_child()
     if args.cpu_baseline_only:                      # child mode of the cpu_baseline leg
         res = cpu_baseline() if args.workload == "ppo" else cpu_baseline_offpolicy(args.workload)
         print("CPU_BASELINE " + json.dumps(res), flush=True)
@@ -232,9 +286,21 @@ def main():
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # Graph replay of the multi-rank launch sequence (RCCL all-reduces inside the HIP graph) unless
+        # TRL_GRAPH_COLLECTIVES says otherwise -- but only after child processes have shown that it works here.
+        probed = probe_graph_collectives() if "TRL_GRAPH_COLLECTIVES" not in os.environ else None
         torch.cuda.set_device(local)
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+        import threading
+        guard = threading.Timer(900.0, lambda: os._exit(3))           # a wedged collective must not outlive the run
+        guard.daemon = True
+        guard.start()
+        if probed is not None:
+            flag = torch.tensor([1.0 if probed else 0.0], device=torch.device("cuda", local))
+            td.all_reduce(flag, op=td.ReduceOp.MIN)                    # every rank takes the same route
+            os.environ["TRL_GRAPH_COLLECTIVES"] = "1" if flag.item() == 1.0 else "0"
+            log("graph-captured collectives: %s" % ("on" if flag.item() == 1.0 else "off (probe failed)"))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -253,7 +319,8 @@ def main():
     # HIP events around every launch of the dominant kernel, on the stream it is launched on.  One process: the
     # minibatch loop of the timed region replays a captured HIP graph, whose nodes cannot be bracketed by
     # events, so the same kernel on the same data is timed in a follow-up pass right after the timed region.
-    graph_mode = not dist.collectives_active() and os.environ.get("TRL_NO_GRAPH") != "1"
+    graph_mode = (not dist.collectives_active() or os.environ.get("TRL_GRAPH_COLLECTIVES") == "1") \
+        and os.environ.get("TRL_NO_GRAPH") != "1"
     probes = []
     eng.probe = None if graph_mode else probes
     if dist.initialized():

@@ -26,10 +26,14 @@ def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else ""
     obs_norm = mode == "obs_norm"
-    if world > 1:
+    if world > 1 or mode == "nccl_graph":
         import torch.distributed as td
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-        td.init_process_group("gloo", rank=rank, world_size=world)
+        if mode == "nccl_graph":           # one rank, RCCL backend, collectives forced on (env set by the test)
+            torch.cuda.set_device(0)
+            td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        else:
+            td.init_process_group("gloo", rank=rank, world_size=world)
     import torchrl.networks as networks
     import torchrl.policies as policies
     from torchrl.algo import A2C, PPO, TRPO, VMPO
@@ -75,7 +79,7 @@ def main():
              infos=np.array([[i[k] for k in keys] for i in logger.infos if sorted(i) == keys]),
              obs=buf._obs.cpu().numpy(), rewards=buf._rewards.cpu().numpy(),
              norm_state=env._obs_normalizer.state.cpu().numpy() if obs_norm else np.zeros(1))
-    if world > 1:
+    if world > 1 or mode == "nccl_graph":
         td.barrier()
         td.destroy_process_group()
 

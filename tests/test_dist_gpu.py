@@ -22,11 +22,12 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run(world, tmp_path, worker="_dist_gpu_worker.py", extra=()):
+def _run(world, tmp_path, worker="_dist_gpu_worker.py", extra=(), env=None):
     port = _free_port()
-    outs = [str(tmp_path / ("%s_w%d_r%d.npz" % (worker[:-3], world, r))) for r in range(world)]
+    outs = [str(tmp_path / ("%s_w%d_r%d%s.npz" % (worker[:-3], world, r, "_".join(extra)))) for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, worker), str(r), str(world), port, outs[r], *extra],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=None if env is None else dict(os.environ, **env)) for r in range(world)]
     for p in procs:
         log, _ = p.communicate(timeout=600)
         assert p.returncode == 0, log[-3000:]
@@ -74,6 +75,18 @@ def test_two_ranks_gather_the_minibatch_for_global_steps(tmp_path, algo, p_tol, 
     np.testing.assert_allclose(r0["vf"], single["vf"], atol=p_tol)
     if i_tol is not None:
         np.testing.assert_allclose(r0["infos"], single["infos"], rtol=i_tol, atol=i_tol)
+
+
+def test_rccl_sequence_replays_as_a_graph(tmp_path):
+    """TRL_GRAPH_COLLECTIVES=1: the multi-rank launch sequence (partial fold -> RCCL all-reduce -> clip + Adam, step
+    count and learning rates on the device) captured into a HIP graph and replayed, on a one-rank nccl group with the
+    collectives forced on; it must reproduce the plain single-process run."""
+    (single,) = _run(1, tmp_path)
+    (forced,) = _run(1, tmp_path, extra=("nccl_graph",), env={"TRL_FORCE_COLLECTIVES": "1", "TRL_GRAPH_COLLECTIVES": "1"})
+    np.testing.assert_allclose(forced["obs"], single["obs"], atol=1e-6)
+    np.testing.assert_allclose(forced["pf"], single["pf"], atol=2e-6)
+    np.testing.assert_allclose(forced["vf"], single["vf"], atol=2e-6)
+    np.testing.assert_allclose(forced["infos"], single["infos"], rtol=2e-4, atol=2e-5)
 
 
 def test_two_ranks_share_the_observation_normaliser(tmp_path):

@@ -210,9 +210,20 @@ class _FusedPPO:
         loss_mode = int(getattr(algo, "loss_mode", _C.LOSS_PPO_CLIP))
         probe = getattr(self, "probe", None)                           # bench.py: HIP events around the grad kernel
         fused = not dist.collectives_active()
+        # TRL_GRAPH_COLLECTIVES=1 (opt-in): capture the multi-rank sequence -- RCCL all-reduces included -- into the HIP
+        # graph as well; the Adam step count and learning rates then live on the device like in the fused launch.
+        graph_coll = not fused and os.environ.get("TRL_GRAPH_COLLECTIVES") == "1"
         lr_pf, lr_vf = algo.pf_optimizer.param_groups[0]['lr'], algo.vf_optimizer.param_groups[0]['lr']
         if fused:
             self._set_device_hyper(lr_pf, lr_vf)
+        elif graph_coll:
+            if getattr(self, "step_state", None) is None:
+                n = float(self.step_count)
+                self.step_state = torch.tensor([n, 0.9 ** n, 0.999 ** n, 0.0], dtype=torch.float64, device=dev)
+                self.lr_dev = torch.zeros(2, device=dev)
+            if getattr(self, "_lr_host", None) != (float(lr_pf), float(lr_vf)):
+                self._lr_host = (float(lr_pf), float(lr_vf))
+                self.lr_dev.copy_(torch.tensor(self._lr_host, dtype=torch.float32), non_blocking=True)
 
         g = _C.PpoBatchArgs()
         for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"):
@@ -265,9 +276,11 @@ class _FusedPPO:
                                                 self.H, self.A, self.flat.data_ptr(), self.grads.data_ptr(),
                                                 info_base + 192 * k, stream), "trl_ppo_reduce_f32")
                 dist.all_reduce_sum_(self.grads)                       # C1: gradient SUM over ranks
+                if graph_coll:
+                    a.step_count, a.step_state, a.device_lr = 0, self.step_state.data_ptr(), self.lr_dev.data_ptr()
                 _C.check(lib.trl_clip_adam_f32(C.byref(a), stream), "trl_clip_adam_f32")
 
-        use_graph = fused and probe is None and os.environ.get("TRL_NO_GRAPH") != "1"
+        use_graph = (fused or graph_coll) and probe is None and os.environ.get("TRL_NO_GRAPH") != "1"
         key = (n_wg, n_wg_pf, loss_mode, g.clip_para, g.entropy_coeff, g.clipped_value_loss, g.tanh_action, n_global,
                rows_total, N) + tuple(getattr(g, k) for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
         if not use_graph:
