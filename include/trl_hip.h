@@ -282,9 +282,10 @@ typedef struct trl_adam_t {
                                  so that no launch argument changes between replays of a captured graph */
   double* step_state;         /* trl_clip_adam_f32 only, nullable: 4 doubles on the device {steps taken so far,
                                  beta1^steps, beta2^steps, 0} initialised to {0, 1, 1, 0}.  When set, step_count is
-                                 ignored, the step uses steps + 1 and a one-thread kernel launched behind the
-                                 update advances the state (same purpose as device_state: a captured graph of a
-                                 whole update can be replayed; the 4th double is reserved) */
+                                 ignored, the step uses steps + 1 and the state is advanced behind the update --
+                                 by the last block that has read it (parameter blocks of up to 32 768 elements; the
+                                 4th double is the block counter, zero between launches) or by a one-thread kernel
+                                 (same purpose as device_state: a captured graph of a whole update can be replayed) */
   const float* device_lr;     /* trl_clip_adam_f32 only, nullable: n_groups learning rates on the device, used instead
                                  of group_lr (a linear schedule then changes no launch argument either) */
 } trl_adam_t;

@@ -633,6 +633,7 @@ struct AdamDev {
   float* norms_out;
   double* step_state;         // {steps taken, beta1^steps, beta2^steps, -} or null (then bc1 / bc2_sqrt)
   const float* device_lr;     // per-group learning rates on the device, or null (then lr[])
+  int self_tick;              // small grids: the last block to have read step_state advances it (no tick launch)
 };
 __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
   __shared__ float s_part[4][4];
@@ -642,6 +643,17 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamDev a) {
   if (a.step_state && tid == 0) {                              // device-resident step: nothing in the launch changes
     s_bc[0] = (float)(1.0 - a.step_state[1] * (double)a.beta1);   // between replays of a captured graph
     s_bc[1] = (float)sqrt(1.0 - a.step_state[2] * (double)a.beta2);
+    if (a.self_tick) {
+      // Every block counts itself in AFTER its reads (release); the block that completes the count has therefore
+      // seen all reads done (acquire) and advances the state for the next launch.  The counter lives in the reserved
+      // 4th double and is back at zero when the kernel ends.
+      unsigned* cnt = reinterpret_cast<unsigned*>(a.step_state + 3);
+      const unsigned before = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == gridDim.x - 1) {
+        a.step_state[0] += 1.0; a.step_state[1] *= (double)a.beta1; a.step_state[2] *= (double)a.beta2;
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
   const bool need_norm = a.max_norm > 0.0f;                    // no clipping requested: skip the norm pass
   for (int g = 0; g < a.n_groups; ++g) {
@@ -922,6 +934,7 @@ static int fill_adam(const trl_adam_t* p, AdamDev& d) {
   d.norms_out = p->norms_out;
   d.step_state = p->step_state;
   d.device_lr = p->device_lr;
+  d.self_tick = 0;
   return TRL_OK;
 }
 
@@ -960,9 +973,13 @@ extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {
   TRL_REQUIRE(!p->device_state, "device_state is a feature of trl_ppo_reduce_adam_f32");
   const int total = d.off[p->n_groups];
   if (total == 0) return TRL_OK;
-  hipLaunchKernelGGL(clip_adam_kernel, dim3(trl_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, d);
+  // Up to 128 blocks count themselves through one atomic (a few hundred ns, hidden under the norm pass); larger
+  // parameter blocks would serialise on it (860 blocks: 25 us measured), so they keep the one-thread tick launch.
+  const int blocks = trl_ceil_div(total, 256);
+  d.self_tick = (d.step_state && blocks <= 128) ? 1 : 0;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
   TRL_LAUNCH_CHECK();
-  if (d.step_state) {
+  if (d.step_state && !d.self_tick) {
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d.step_state, d.beta1, d.beta2);
     TRL_LAUNCH_CHECK();
   }
