@@ -5,7 +5,6 @@ sections), pointed at the on-GPU env id:
     python examples/a2c_continuous_vec.py --config config/a2c_synth_halfcheetah.json \
         --vec_env_nums 2048 --seed 0 --overwrite
 """
-import os
 import os.path as osp
 import random
 import sys

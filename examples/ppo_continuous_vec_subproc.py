@@ -3,7 +3,6 @@
 
     python examples/ppo_continuous_vec_subproc.py --config config/ppo_pendulum_host.json --vec_env_nums 16 --seed 0 --overwrite
 """
-import os
 import os.path as osp
 import random
 import sys

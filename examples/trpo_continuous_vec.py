@@ -3,7 +3,6 @@ constructor kwargs; hyper-parameters of its config/para_trpo_halfcheetah.json), 
 
     python examples/trpo_continuous_vec.py --config config/trpo_synth_halfcheetah.json --vec_env_nums 16 --seed 0 --overwrite
 """
-import os
 import os.path as osp
 import random
 import sys

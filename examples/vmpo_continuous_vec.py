@@ -3,7 +3,6 @@ constructor kwargs and JSON sections; hyper-parameters of its config/vmpo_halfch
 
     python examples/vmpo_continuous_vec.py --config config/vmpo_synth_halfcheetah.json --vec_env_nums 16 --seed 0 --overwrite
 """
-import os
 import os.path as osp
 import random
 import sys

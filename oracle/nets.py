@@ -16,7 +16,6 @@ builds from nn.Modules:
   (distribution.py:78-79, continuous_policy.py:100,143).
 """
 import math
-import numpy as np
 import torch
 
 LOG_SIG_MAX = 2.0

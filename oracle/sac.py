@@ -11,7 +11,6 @@ Restates torchrl/algo/off_policy/twin_sac_q.py:84-220 (+ continuous_policy.py:92
   policy loss = mean(alpha logp - min(q1, q2)(obs, new_a)) + w_std mean(log_std^2) + w_mean mean(mean^2)
   steps: pf, qf1, qf2 (each Adam, default eps 1e-8, optional clip_grad_norm_), then Polyak(tau).
 """
-import math
 
 import numpy as np
 import torch

@@ -16,7 +16,6 @@ import numpy as np
 import torch
 
 from ... import _C
-from .. import utils as atu
 from .a2c import A2C
 from .ppo import _GenericPPO
 

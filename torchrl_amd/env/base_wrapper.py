@@ -16,7 +16,6 @@ kept by default because the parity fixtures are generated from the reference;
 The collectors never call `env.step`: they read `env._obs_normalizer` and run the same kernels
 inside their per-step launch sequence (torchrl_amd/collector/on_policy.py).
 """
-import numpy as np
 import torch
 
 from .. import _C

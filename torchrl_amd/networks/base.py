@@ -4,7 +4,6 @@ layer (the last hidden activation is `last_activation_func`, default the same
 class), optional LayerNorm.  The modules only define parameters and structure;
 the arithmetic on the hot path runs in the HIP kernels (see nets.Net.forward)."""
 import numpy as np
-import torch
 import torch.nn as nn
 
 from . import init

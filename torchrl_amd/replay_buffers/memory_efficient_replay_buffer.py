@@ -15,7 +15,6 @@ Same interface as BaseReplayBuffer: `random_batch` draws its row indices with th
 (bit-exact stream) and returns uint8 `(B, C, H, W)` stacks identical to what the plain buffer would hold.
 The collector drives it through `begin_episodes` / `append_step` (torchrl_amd/collector/base.py).
 """
-import numpy as np
 import torch
 
 from .. import _C
