@@ -333,6 +333,55 @@ def case_collect_and_epoch():
     save("collect_epoch", **out)
 
 
+def case_collect_offpolicy():
+    """VecCollector.train_one_epoch (torchrl/collector/base.py:176-230) with a tanh-Gaussian policy on the synthetic env:
+    env time-limit resets, the collector's own max_episode_frames resets, and a ring that wraps -- ring arrays, the
+    N(0,1) draws, logged episode returns, collector state."""
+    import gym
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector.base import VecCollector
+    from torchrl.replay_buffers.base import BaseReplayBuffer
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    for tag, N, steps, rows, horizon, max_frames, seed in (
+            ("env_limit", 8, 12, 16, 5, 999, 3),         # env time-limit every 5 steps
+            ("collector_limit", 8, 12, 16, 1000, 4, 4),   # collector resets every 4 steps
+            ("wrap", 4, 20, 7, 6, 5, 5)):                 # both, and the 7-row ring wraps twice
+        D, A, H = 17, 6, 32
+        torch.manual_seed(seed + 40)
+        net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase,
+                   activation_func=torch.nn.ReLU)
+        pf = policies.GuassianContPolicy(input_shape=D, output_shape=2 * A, tanh_action=True, **net)
+
+        def mk():
+            e = SynthVecEnvCPU(N, horizon=horizon)
+            e.action_space = gym.spaces.Box(-1, 1, (A,))
+            return e
+        env, eval_env = mk(), mk()
+        env.seed(seed)
+        torch.manual_seed(seed)
+        buf = BaseReplayBuffer(N * rows, env_nums=N)
+        col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=torch.device("cpu"),
+                           train_render=False, epoch_frames=N * steps, max_episode_frames=max_frames, eval_episodes=1)
+        out.update(state_arrays(f"{tag}_pf_", pf))
+        noise_state = torch.get_rng_state()
+        res = col.train_one_epoch()
+        after = torch.get_rng_state()
+        torch.set_rng_state(noise_state)
+        out[f"{tag}_noise"] = torch.stack([torch.randn(N, A) for _ in range(steps)]).numpy()
+        assert torch.equal(torch.get_rng_state(), after), "noise stream mismatch"
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+            out[f"{tag}_buf_{k}"] = getattr(buf, "_" + k).copy()
+        out[f"{tag}_top_size"] = np.array([buf._top, buf._size], dtype=np.int64)
+        out[f"{tag}_train_epoch_reward"] = np.array(res["train_epoch_reward"])
+        out[f"{tag}_train_rewards"] = np.array(res["train_rewards"], dtype=np.float64).reshape(-1)
+        out[f"{tag}_current_ob"] = np.asarray(col.current_ob).copy()
+        out[f"{tag}_current_step"] = np.asarray(col.current_step).copy()
+        out[f"{tag}_args"] = np.array([N, steps, rows, horizon, max_frames, seed], dtype=np.int64)
+    save("collect_offpolicy", **out)
+
+
 def case_init():
     """networks.init: basic_init / uniform_init draws under torch.manual_seed (Q9)."""
     out = {}
@@ -687,7 +736,7 @@ def case_obs_norm():
     save("obs_norm", **out)
 
 
-CASES = {"gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
+CASES = {"collect_offpolicy": case_collect_offpolicy, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
          "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update, "trpo_update": case_trpo_update}
 

@@ -180,6 +180,30 @@ def sac_params(g, prefix):
     return [torch.tensor(g[k]) for k in order]
 
 
+@pytest.mark.parametrize("tag", ["env_limit", "collector_limit", "wrap"])
+def test_offpolicy_collector_matches_reference(golden, tag):
+    """VecCollector.train_one_epoch (collector/base.py:176-230) as run by the reference: ring contents (including a ring
+    that wraps), reset bookkeeping and logged episode returns."""
+    from oracle.collector import VecCollectorOracle
+    g = golden("collect_offpolicy")
+    N, steps, rows, horizon, max_frames, seed = (int(x) for x in g[f"{tag}_args"])
+    pf = sac_params(g, f"{tag}_pf_")
+    env = SynthVecEnvCPU(N, horizon=horizon)
+    env.seed(seed)
+    ring = replay.RingOracle(N * rows, env_nums=N)
+    col = VecCollectorOracle(env, ring, pf, epoch_frames=N * steps, max_episode_frames=max_frames, act="relu",
+                             tanh_action=True)
+    res = col.train_one_epoch(noise=torch.tensor(g[f"{tag}_noise"]))
+    for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+        np.testing.assert_allclose(ring.data[k], g[f"{tag}_buf_{k}"], rtol=0, atol=2e-6, err_msg=k)
+    assert (ring.top, ring.size) == tuple(int(x) for x in g[f"{tag}_top_size"])
+    np.testing.assert_allclose(res["train_epoch_reward"], g[f"{tag}_train_epoch_reward"], atol=1e-4)
+    np.testing.assert_allclose(np.array(res["train_rewards"], dtype=np.float64).reshape(-1),
+                               g[f"{tag}_train_rewards"], atol=1e-5)
+    np.testing.assert_allclose(col.current_ob, g[f"{tag}_current_ob"], atol=2e-6)
+    np.testing.assert_array_equal(col.current_step, g[f"{tag}_current_step"])
+
+
 @pytest.mark.parametrize("tag", ["h256", "reg"])
 def test_twin_sac_q_update_matches_reference(golden, tag):
     from oracle.sac import TwinSACQOracle

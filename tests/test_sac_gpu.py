@@ -232,6 +232,39 @@ def test_env_step_and_off_policy_collector_vs_oracle():
     assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == horizon
 
 
+@pytest.mark.parametrize("tag", ["env_limit", "collector_limit", "wrap"])
+def test_off_policy_collector_matches_reference(golden, tag):
+    """VecCollector.train_one_epoch against the ring the REFERENCE's collector filled (collector/base.py:176-230 run on
+    the CPU twin of the synthetic env, tests/golden/collect_offpolicy.npz): env time-limit resets, the collector's
+    max_episode_frames resets, a wrapping ring, logged episode returns, collector state."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector import VecCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    g = golden("collect_offpolicy")
+    N, steps, rows, horizon, max_frames, seed = (int(x) for x in g[f"{tag}_args"])
+    dev = torch.device(DEV)
+    net = dict(hidden_shapes=[32, 32], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net)
+    pf.load_state_dict(sac_state(g, f"{tag}_pf_"))
+    env, eval_env = SynthVecEnv(N, horizon=horizon, device=dev), SynthVecEnv(N, horizon=horizon, device=dev)
+    env.seed(seed)
+    buf = BaseReplayBuffer(N * rows, env_nums=N)
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * steps,
+                       max_episode_frames=max_frames, eval_episodes=1)
+    torch.manual_seed(seed)                                          # the reference's CPU N(0,1) stream (Q5)
+    got = col.train_one_epoch()
+    for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+        err = np.abs(getattr(buf, "_" + k).cpu().numpy().reshape(g[f"{tag}_buf_{k}"].shape) - g[f"{tag}_buf_{k}"]).max()
+        assert err < 2e-5, (k, err)
+    assert (buf._top, buf._size) == tuple(int(x) for x in g[f"{tag}_top_size"])
+    assert abs(got["train_epoch_reward"] - float(g[f"{tag}_train_epoch_reward"])) < 1e-3
+    np.testing.assert_allclose(np.array(got["train_rewards"], dtype=np.float64).reshape(-1), g[f"{tag}_train_rewards"],
+                               atol=1e-4)
+    np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[f"{tag}_current_ob"], atol=2e-5)
+
+
 def test_sac_trains_through_rlalgo_with_device_noise():
     import torchrl.networks as networks
     import torchrl.policies as policies
