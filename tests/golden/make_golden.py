@@ -382,6 +382,41 @@ def case_collect_offpolicy():
     save("collect_offpolicy", **out)
 
 
+def vecenv_script(env, kind, N, steps):
+    """The call sequence both the generator and tests/test_host_logic_cpu.py drive a VecEnv through."""
+    rs = np.random.RandomState(0)
+    env.seed(11)
+    env.train()
+    rec = {"reset": np.array(env.reset(), copy=True), "obs": [], "rew": [], "done": [], "tl": [], "mask": [], "after": []}
+    for t in range(steps):
+        acts = rs.uniform(-1, 1, size=(N, 1)) if kind == "pendulum" else rs.randint(0, 2, size=(N,))
+        obs, rew, done, infos = env.step(acts)
+        rec["obs"].append(np.array(obs, copy=True)); rec["rew"].append(np.array(rew, copy=True))
+        rec["done"].append(np.array(done, copy=True)); rec["tl"].append(np.array(infos["time_limit"], copy=True))
+        if done.any() or (t % 7 == 3 and t < 30):
+            mask = done.reshape(-1) | (np.arange(N) == t % N)
+            rec["mask"].append(np.concatenate([[t], mask.astype(np.int64)]))
+            rec["after"].append(np.array(env.partial_reset(mask), copy=True))
+    return {k: np.stack(v) if isinstance(v, list) else v for k, v in rec.items()}
+
+
+def case_vecenv():
+    """The reference's VecEnv (torchrl/env/vecenv.py:6-78) over this repo's pure-Python single envs: seeding rule
+    seed * N + i, per-env action split / squeeze, stacking of obs / rewards / dones, merged infos, partial_reset
+    returning the whole array."""
+    import importlib.util
+    from torchrl.env.vecenv import VecEnv
+    spec = importlib.util.spec_from_file_location("_py_envs", os.path.join(REPO, "torchrl_amd", "env", "py_envs.py"))
+    py_envs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(py_envs)
+    out = {}
+    for kind, cls, N, steps in (("pendulum", py_envs.PendulumEnv, 4, 230), ("cartpole", py_envs.CartPoleEnv, 4, 60)):
+        rec = vecenv_script(VecEnv(N, cls, ()), kind, N, steps)
+        out.update({f"{kind}_{k}": v for k, v in rec.items()})
+        out[f"{kind}_args"] = np.array([N, steps], dtype=np.int64)
+    save("vecenv", **out)
+
+
 def case_init():
     """networks.init: basic_init / uniform_init draws under torch.manual_seed (Q9)."""
     out = {}
@@ -736,7 +771,7 @@ def case_obs_norm():
     save("obs_norm", **out)
 
 
-CASES = {"collect_offpolicy": case_collect_offpolicy, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
+CASES = {"collect_offpolicy": case_collect_offpolicy, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
          "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update, "trpo_update": case_trpo_update}
 

@@ -174,6 +174,31 @@ def test_vecenv_protocol_and_pendulum_env():
     assert d.all() and info["time_limit"].all() and (r <= 0).all()     # 200-step time limit, costs only
 
 
+def test_vecenv_reproduces_the_reference_vecenv(golden):
+    """The reference's VecEnv, run over the same single envs through the same call sequence (tests/golden/vecenv.npz):
+    every observation, reward, done flag, time-limit info and partial_reset result, bit for bit -- for the in-process
+    VecEnv and for the spawned-worker SubProcVecEnv."""
+    import importlib.util
+    import numpy as np
+    from torchrl_amd.env import SubProcVecEnv, VecEnv
+    from torchrl_amd.env.py_envs import CartPoleEnv, PendulumEnv
+    spec = importlib.util.spec_from_file_location("_make_golden", os.path.join(REPO, "tests", "golden", "make_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    g = golden("vecenv")
+    for kind, cls in (("pendulum", PendulumEnv), ("cartpole", CartPoleEnv)):
+        N, steps = (int(x) for x in g[f"{kind}_args"])
+        for make in (lambda: VecEnv(N, cls, ()), lambda: SubProcVecEnv(2, N, cls, ())):
+            env = make()
+            try:
+                rec = gen.vecenv_script(env, kind, N, steps)
+            finally:
+                env.close()
+            assert rec["mask"].shape[0] >= 5 and rec["done"].any() and (kind != "pendulum" or rec["tl"].any())
+            for k, v in rec.items():
+                assert v.dtype == g[f"{kind}_{k}"].dtype and np.array_equal(v, g[f"{kind}_{k}"]), (kind, k)
+
+
 def test_subproc_vecenv_matches_vecenv():
     """SubProcVecEnv (spawned workers, pipes) is the same function of (seed, actions) as the in-process VecEnv."""
     import numpy as np
