@@ -121,3 +121,28 @@ class VecCollectorOracle:
         for t in range(self.steps_per_epoch):
             total += self.take_actions(None if noise is None else noise[t])
         return {"train_rewards": self.train_rews, "train_epoch_reward": total}
+
+
+def eval_one_epoch(eval_env, act_fn, eval_episodes=1):
+    """Greedy evaluation, restating torchrl/collector/base.py:232-280: per round reset every env, step until each env
+    has finished once (finished envs are reset and keep stepping, their later rewards masked out), collect the return
+    and length of every env's FIRST episode.  `act_fn(obs ndarray) -> actions ndarray` is the policy's eval_act."""
+    eval_env.eval()
+    rews_all, lens_all = [], []
+    n = eval_env.env_nums
+    for _ in range(eval_episodes):
+        epi_done = np.zeros((n, 1), dtype=bool)
+        obs = eval_env.reset()
+        rews = np.zeros((n, 1))
+        traj_len = np.zeros((n, 1))
+        while not np.all(epi_done):
+            obs, r, done, _ = eval_env.step(act_fn(np.asarray(obs)))
+            rews = rews + (1 - epi_done) * r
+            traj_len = traj_len + (1 - epi_done)
+            epi_done = epi_done | done
+            if np.any(done):
+                obs = eval_env.partial_reset(np.squeeze(done, axis=-1))
+        rews_all += list(rews)
+        lens_all += list(traj_len)
+    return {"eval_rewards": rews_all, "eval_traj_length": float(np.mean(lens_all))}
+

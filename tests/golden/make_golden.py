@@ -417,6 +417,65 @@ def case_vecenv():
     save("vecenv", **out)
 
 
+def case_eval_epoch():
+    """VecCollector.eval_one_epoch (torchrl/collector/base.py:232-280): greedy actions, the first episode of every
+    eval env, eval_episodes rounds.  (a) the synthetic env with a tanh-Gaussian policy; (b) the reference's VecEnv over
+    this repo's pure-Python cart-pole with a greedy Q-network policy, where episodes end at different steps."""
+    import importlib.util
+    import gym
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector.base import VecCollector
+    from torchrl.env.vecenv import VecEnv
+    from torchrl.replay_buffers.base import BaseReplayBuffer
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    # (a)
+    N, A, D, H, horizon, episodes, seed = 8, 6, 17, 32, 6, 2, 6
+    torch.manual_seed(seed + 50)
+    net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.GuassianContPolicy(input_shape=D, output_shape=2 * A, tanh_action=True, **net)
+
+    def mk():
+        e = SynthVecEnvCPU(N, horizon=horizon)
+        e.action_space = gym.spaces.Box(-1, 1, (A,))
+        return e
+    env, eval_env = mk(), mk()
+    env.seed(seed)
+    eval_env.seed(seed + 1)
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=BaseReplayBuffer(N * 4, env_nums=N),
+                       device=torch.device("cpu"), train_render=False, epoch_frames=N * 4, max_episode_frames=999,
+                       eval_episodes=episodes)
+    res = col.eval_one_epoch()
+    out.update(state_arrays("synth_pf_", pf))
+    out["synth_eval_rewards"] = np.array(res["eval_rewards"], dtype=np.float64).reshape(-1)
+    out["synth_eval_traj_length"] = np.array(res["eval_traj_length"], dtype=np.float64)
+    out["synth_args"] = np.array([N, horizon, episodes, seed], dtype=np.int64)
+    # (b)
+    spec = importlib.util.spec_from_file_location("_py_envs", os.path.join(REPO, "torchrl_amd", "env", "py_envs.py"))
+    py_envs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(py_envs)
+    N, H, episodes, seed = 6, 32, 2, 9
+    torch.manual_seed(seed + 50)
+    env, eval_env = VecEnv(N, py_envs.CartPoleEnv, ()), VecEnv(N, py_envs.CartPoleEnv, ())
+    env.seed(seed)
+    eval_env.seed(seed + 1)
+    qf = networks.Net(input_shape=4, output_shape=2, hidden_shapes=[H, H], append_hidden_shapes=[],
+                      base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.EpsilonGreedyDQNDiscretePolicy(qf, start_epsilon=1.0, end_epsilon=0.05, decay_frames=1000, action_shape=2)
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=BaseReplayBuffer(N * 4, env_nums=N),
+                       device=torch.device("cpu"), train_render=False, epoch_frames=N * 4, max_episode_frames=999,
+                       eval_episodes=episodes)
+    res = col.eval_one_epoch()
+    out.update(state_arrays("cartpole_qf_", qf))
+    out["cartpole_eval_rewards"] = np.array(res["eval_rewards"], dtype=np.float64).reshape(-1)
+    out["cartpole_eval_traj_length"] = np.array(res["eval_traj_length"], dtype=np.float64)
+    out["cartpole_args"] = np.array([N, H, episodes, seed], dtype=np.int64)
+    print("eval golden:", out["synth_eval_rewards"][:4], out["synth_eval_traj_length"], out["cartpole_eval_rewards"],
+          out["cartpole_eval_traj_length"])
+    save("eval_epoch", **out)
+
+
 def case_init():
     """networks.init: basic_init / uniform_init draws under torch.manual_seed (Q9)."""
     out = {}
@@ -771,7 +830,7 @@ def case_obs_norm():
     save("obs_norm", **out)
 
 
-CASES = {"collect_offpolicy": case_collect_offpolicy, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
+CASES = {"collect_offpolicy": case_collect_offpolicy, "eval_epoch": case_eval_epoch, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
          "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update, "trpo_update": case_trpo_update}
 
