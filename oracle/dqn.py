@@ -122,3 +122,31 @@ class SynthFrameVecEnvCPU:
         rew = (acts == (new.reshape(self.env_nums, -1)[:, 0] % self.action_num)).astype(np.float32)
         done = self.t >= self.horizon
         return self._obs, rew[:, None], done[:, None], {"time_limit": done.copy()}
+
+
+class EpsGreedyOracle:
+    """EpsilonGreedyDQNDiscretePolicy.explore, restating torchrl/policies/discrete_policies.py:43-67: epsilon decays
+    linearly with the call count until `decay_frames`, the greedy action is the argmax (of the quantile mean for
+    quantile_num > 1), and an env takes the random action where its uniform draw -- float32 like the reference's
+    torch.Tensor(np.random.rand(...)) -- is below epsilon.  Draws come from the global numpy stream, rand then randint."""
+
+    def __init__(self, start_epsilon, end_epsilon, decay_frames, action_num, quantile_num=1):
+        self.start, self.end, self.decay, self.A, self.Q = start_epsilon, end_epsilon, decay_frames, action_num, quantile_num
+        self.count, self.epsilon = 0, start_epsilon
+
+    def explore(self, q_values):
+        self.count += 1
+        if self.count < self.decay:
+            self.epsilon = self.start - (self.start - self.end) * (self.count / self.decay)
+        else:
+            self.epsilon = self.end
+        q = np.asarray(q_values, dtype=np.float32)
+        if self.Q > 1:
+            q = q.reshape(q.shape[0], self.A, self.Q).mean(axis=-1)
+        action = q.argmax(axis=-1)[:, None].astype(np.int64)
+        r = np.random.rand(*action.shape).astype(np.float32)
+        random_action = np.random.randint(low=0, high=self.A, size=action.shape)
+        take = r < np.float32(self.epsilon)
+        action[take] = random_action[take]
+        return action
+

@@ -476,6 +476,32 @@ def case_eval_epoch():
     save("eval_epoch", **out)
 
 
+def case_eps_greedy():
+    """EpsilonGreedyDQNDiscretePolicy.explore (torchrl/policies/discrete_policies.py:43-67) called the way VecCollector
+    does: linear epsilon decay per call (through its end), np.random.rand / randint from the global stream, argmax."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    N, A, D, H, calls, decay = 16, 3, 4, 32, 12, 10
+    torch.manual_seed(77)
+    qf = networks.Net(input_shape=D, output_shape=A, hidden_shapes=[H, H], append_hidden_shapes=[],
+                      base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.EpsilonGreedyDQNDiscretePolicy(qf, start_epsilon=0.9, end_epsilon=0.15, decay_frames=decay, action_shape=A)
+    rs = np.random.RandomState(5)
+    obs = rs.randn(calls, N, D).astype(np.float32)
+    np.random.seed(21)
+    acts, eps = [], []
+    for c in range(calls):
+        out_ = pf.explore(torch.Tensor(obs[c]).unsqueeze(0))
+        acts.append(out_["action"].numpy().copy())
+        eps.append(pf.epsilon)
+    out = state_arrays("qf_", qf)
+    out.update(obs=obs, actions=np.stack(acts).astype(np.int64), epsilon=np.array(eps, dtype=np.float64),
+               args=np.array([N, A, D, H, calls, decay], dtype=np.int64))
+    greedy = np.stack([qf(torch.Tensor(o)).max(dim=-1, keepdim=True)[1].numpy() for o in obs])
+    print("eps golden: random fraction", float((out["actions"] != greedy).mean()), out["actions"].shape)
+    save("eps_greedy", **out)
+
+
 def case_init():
     """networks.init: basic_init / uniform_init draws under torch.manual_seed (Q9)."""
     out = {}
@@ -830,7 +856,7 @@ def case_obs_norm():
     save("obs_norm", **out)
 
 
-CASES = {"collect_offpolicy": case_collect_offpolicy, "eval_epoch": case_eval_epoch, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
+CASES = {"collect_offpolicy": case_collect_offpolicy, "eps_greedy": case_eps_greedy, "eval_epoch": case_eval_epoch, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
          "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update, "trpo_update": case_trpo_update}
 

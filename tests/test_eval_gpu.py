@@ -58,3 +58,24 @@ def test_eval_loop_over_host_envs_matches_reference(golden):
     res = col.eval_one_epoch()
     np.testing.assert_array_equal(np.array(res["eval_rewards"], dtype=np.float64).reshape(-1), g["cartpole_eval_rewards"])
     assert abs(res["eval_traj_length"] - float(g["cartpole_eval_traj_length"])) < 1e-9
+
+
+def test_eps_greedy_explore_matches_reference(golden):
+    """EpsilonGreedyDQNDiscretePolicy.explore (discrete_policies.py:43-67): epsilon schedule, host numpy draws and the
+    argmax + mask kernel reproduce the reference's exploration decisions call by call."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    g = golden("eps_greedy")
+    N, A, D, H, calls, decay = (int(x) for x in g["args"])
+    qf = networks.Net(input_shape=D, output_shape=A, hidden_shapes=[H, H], append_hidden_shapes=[],
+                      base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    qf.load_state_dict(state(g, "qf_"))
+    qf.to(DEV)
+    pf = policies.EpsilonGreedyDQNDiscretePolicy(qf, start_epsilon=0.9, end_epsilon=0.15, decay_frames=decay, action_shape=A)
+    np.random.seed(21)
+    for c in range(calls):
+        out = pf.explore(torch.tensor(g["obs"][c], device=DEV).unsqueeze(0))
+        assert out["action"].shape == (N, 1) and out["action"].dtype == torch.int64
+        assert np.array_equal(out["action"].cpu().numpy(), g["actions"][c]), c
+        assert pf.epsilon == float(g["epsilon"][c])
+

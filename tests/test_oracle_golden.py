@@ -204,6 +204,21 @@ def test_offpolicy_collector_matches_reference(golden, tag):
     np.testing.assert_array_equal(col.current_step, g[f"{tag}_current_step"])
 
 
+def test_eps_greedy_explore_matches_reference(golden):
+    from oracle.dqn import EpsGreedyOracle
+    g = golden("eps_greedy")
+    N, A, D, H, calls, decay = (int(x) for x in g["args"])
+    qf = sac_params(g, "qf_")
+    pol = EpsGreedyOracle(0.9, 0.15, decay, A)
+    np.random.seed(21)
+    for c in range(calls):
+        with torch.no_grad():
+            q = nets.mlp(torch.tensor(g["obs"][c]), qf, "relu").numpy()
+        assert np.array_equal(pol.explore(q), g["actions"][c]), c
+        assert pol.epsilon == float(g["epsilon"][c])
+    assert float(g["epsilon"][-1]) == 0.15 and 0.9 > float(g["epsilon"][0]) > 0.8
+
+
 def test_eval_loop_matches_reference(golden):
     """VecCollector.eval_one_epoch (collector/base.py:232-280) as run by the reference: the synthetic env with the greedy
     tanh-Gaussian action, and the in-process VecEnv over the pure-Python cart-pole with a greedy Q-network."""

@@ -37,7 +37,7 @@ class EpsilonGreedyDQNDiscretePolicy:
 
     def explore(self, x):
         self.count += 1
-        if x.dim() in (2, 5):
+        if x.dim() in (3, 5) and x.shape[0] == 1:                    # the collector's unsqueeze(0) (base.py:185-186)
             x = x.squeeze(0)
         if self.count < self.decay_frames:
             self.epsilon = self.start_epsilon - (self.start_epsilon - self.end_epsilon) * (self.count / self.decay_frames)
