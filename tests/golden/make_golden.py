@@ -502,6 +502,37 @@ def case_eps_greedy():
     save("eps_greedy", **out)
 
 
+def subproc_script(env, N, steps):
+    """The call sequence both the generator and tests/test_oracle_golden.py drive a process-parallel vec env through."""
+    rs = np.random.RandomState(3)
+    env.train()
+    rec = {"reset": np.array(env.reset(), copy=True), "obs": [], "rew": [], "done": [], "tl": [], "after": []}
+    for t in range(steps):
+        obs, rew, done, infos = env.step(np.tanh(rs.randn(N, 6)).astype(np.float32))
+        rec["obs"].append(np.array(obs, copy=True)); rec["rew"].append(np.array(rew, copy=True))
+        rec["done"].append(np.array(done, copy=True)); rec["tl"].append(np.array(infos["time_limit"], copy=True))
+        mask = done.reshape(-1) | (np.arange(N) == t % N)
+        rec["after"].append(np.array(env.partial_reset(mask), copy=True))
+    return {k: np.stack(v) if isinstance(v, list) else v for k, v in rec.items()}
+
+
+def case_subproc_vecenv():
+    """The reference's SubProcVecEnv (torchrl/env/subproc_vecenv.py:10-157: spawned workers, pipes, per-env action
+    split, stacked results, partial resets) over oracle.synth_env.SynthSingleEnvCPU -- what the CPU baseline's
+    process-parallel env (oracle.subproc_env.SubProcVecEnvCPU) has to reproduce.  One (env_func, env_args) pair for
+    all envs: the list form trips vecenv.py:19, and the workers ignore the seed command (Q15), so every env has seed 0."""
+    from torchrl.env.subproc_vecenv import SubProcVecEnv
+    from oracle.synth_env import SynthSingleEnvCPU
+    os.environ["PYTHONPATH"] = os.pathsep.join(p for p in sys.path if p)     # for the spawned workers
+    N, procs, steps, horizon = 6, 3, 9, 4
+    env = SubProcVecEnv(procs, N, SynthSingleEnvCPU, (0, horizon))
+    try:
+        rec = subproc_script(env, N, steps)
+    finally:
+        env.close()
+    save("subproc_vecenv", args=np.array([N, procs, steps, horizon], dtype=np.int64), **rec)
+
+
 def case_init():
     """networks.init: basic_init / uniform_init draws under torch.manual_seed (Q9)."""
     out = {}
@@ -856,7 +887,7 @@ def case_obs_norm():
     save("obs_norm", **out)
 
 
-CASES = {"collect_offpolicy": case_collect_offpolicy, "eps_greedy": case_eps_greedy, "eval_epoch": case_eval_epoch, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
+CASES = {"collect_offpolicy": case_collect_offpolicy, "subproc_vecenv": case_subproc_vecenv, "eps_greedy": case_eps_greedy, "eval_epoch": case_eval_epoch, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
          "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update, "trpo_update": case_trpo_update}
 

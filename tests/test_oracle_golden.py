@@ -204,6 +204,30 @@ def test_offpolicy_collector_matches_reference(golden, tag):
     np.testing.assert_array_equal(col.current_step, g[f"{tag}_current_step"])
 
 
+def test_process_parallel_env_of_the_cpu_baseline_matches_reference(golden):
+    """oracle.subproc_env.SubProcVecEnvCPU -- the env side of bench.py's cpu_baseline -- against the reference's
+    SubProcVecEnv run over the same per-env objects (tests/golden/subproc_vecenv.npz), bit for bit."""
+    import functools
+    import importlib.util
+    import os
+    from oracle.subproc_env import SubProcVecEnvCPU
+    from oracle.synth_env import SynthSingleEnvCPU
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("_make_golden", os.path.join(here, "golden", "make_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    g = golden("subproc_vecenv")
+    N, procs, steps, horizon = (int(x) for x in g["args"])
+    env = SubProcVecEnvCPU(procs, N, [functools.partial(SynthSingleEnvCPU, 0, horizon)] * N, SynthSingleEnvCPU(0, horizon))
+    try:
+        rec = gen.subproc_script(env, N, steps)
+    finally:
+        env.close()
+    assert rec["done"].any() and rec["tl"].any()
+    for k, v in rec.items():
+        assert v.dtype == g[k].dtype and np.array_equal(v, g[k]), k
+
+
 def test_eps_greedy_explore_matches_reference(golden):
     from oracle.dqn import EpsGreedyOracle
     g = golden("eps_greedy")
