@@ -9,6 +9,7 @@ code and only exist to let the reference modules import.  What is stored in
 the fixtures is DATA ONLY: seeded inputs and the reference's outputs.
 
     python tests/golden/make_golden.py            # (re)writes the .npz files
+    python tests/golden/make_golden.py --check    # regenerates into a scratch dir, compares with the committed ones
 
 Each fixture records torch / numpy versions in ``meta``.
 """
@@ -891,7 +892,27 @@ CASES = {"collect_offpolicy": case_collect_offpolicy, "subproc_vecenv": case_sub
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
          "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update, "trpo_update": case_trpo_update}
 
+def check(names):
+    """Regenerate into a scratch directory and compare with the committed fixtures (bit for bit)."""
+    global HERE
+    committed, HERE = HERE, tempfile.mkdtemp(prefix="trl_golden_check_")
+    bad = 0
+    for name in names:
+        CASES[name]()
+    for fname in sorted(f for f in os.listdir(HERE) if f.endswith(".npz")):
+        new, old = np.load(os.path.join(HERE, fname)), np.load(os.path.join(committed, fname))
+        same = sorted(new.files) == sorted(old.files) and all(
+            new[k].shape == old[k].shape and np.array_equal(new[k], old[k], equal_nan=new[k].dtype.kind == "f")
+            for k in new.files if k != "meta")
+        bad += not same
+        print("%-24s %s" % (fname, "identical" if same else "DIFFERS"))
+    sys.exit(1 if bad else 0)
+
+
 if __name__ == "__main__":
     install_stubs()
-    for name in (sys.argv[1:] or list(CASES)):               # python make_golden.py [case ...]
+    argv = [a for a in sys.argv[1:] if a != "--check"]
+    if "--check" in sys.argv[1:]:                            # python make_golden.py --check [case ...]
+        check(argv or list(CASES))
+    for name in (argv or list(CASES)):                       # python make_golden.py [case ...]
         CASES[name]()
