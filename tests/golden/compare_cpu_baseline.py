@@ -9,9 +9,10 @@ Times, side by side on this host, the two legs bench.py's `cpu_baseline` reports
   update   the reference's PPO.update   vs   oracle.ppo.PPOOracle.update   on the same B = 65 536 minibatch,
            same torch thread count.
 Needs /root/reference (imported through the stand-in gym / toolz / cv2 modules of tests/golden/make_golden.py), so it
-runs in the build container only; nothing in tests/, bench.py or smoke() uses it.  Prints one JSON line.
+runs in the build container only -- like make_golden.py next to it, a checker of the checker; no test, bench.py or
+smoke() runs it.  Prints one JSON line.
 
-    python tools/compare_cpu_baseline.py [--procs 4] [--steps 12] [--updates 3]
+    python tests/golden/compare_cpu_baseline.py [--procs 4] [--steps 12] [--updates 3]
 """
 import argparse
 import functools
@@ -24,7 +25,7 @@ import time
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N, T, B, D, A, H = 2048, 128, 65536, 17, 6, 64
 
 

@@ -251,3 +251,34 @@ def test_reference_import_surface():
     for cls in (Reinforce, CategoricalDisPolicy):
         with pytest.raises(_C.TrlError, match="not built"):
             cls()
+
+
+def test_oracle_is_test_infrastructure_only():
+    """oracle/ may be imported by tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg -- never by the
+    package or by any other script: scan every Python source for an import of it."""
+    import ast
+    allowed = {"bench.py", "__graft_entry__.py"}
+    offenders = []
+    for root, dirs, files in os.walk(REPO):
+        dirs[:] = [d for d in dirs if d not in (".git", "__pycache__", "gpurun_out", "tests", "oracle", ".pytest_cache")]
+        for name in files:
+            if not name.endswith(".py"):
+                continue
+            path = os.path.join(root, name)
+            rel = os.path.relpath(path, REPO)
+            tree = ast.parse(open(path).read())
+            for node in ast.walk(tree):
+                mods = [a.name for a in node.names] if isinstance(node, ast.Import) else \
+                    [node.module or ""] if isinstance(node, ast.ImportFrom) and node.level == 0 else []
+                if any(m == "oracle" or m.startswith("oracle.") for m in mods) and rel not in allowed:
+                    offenders.append(rel)
+    assert not offenders, offenders
+    # and inside the two allowed files, only in the functions that are the checker legs
+    for rel, legs in (("bench.py", {"cpu_baseline", "cpu_baseline_offpolicy"}), ("__graft_entry__.py", {"smoke", "build"})):
+        tree = ast.parse(open(os.path.join(REPO, rel)).read())
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and
+                       any((getattr(n, "module", None) or a.name).split(".")[0] == "oracle" for a in n.names)
+                       for n in ast.walk(fn))
+            assert not uses or fn.name in legs, (rel, fn.name)
+
