@@ -246,16 +246,21 @@ def probe_graph_collectives(timeout_s=150):
     """True when graph-captured RCCL collectives work on this node, established in child processes so that a hang or
     a crash there costs a time-out, not the benchmark (the children are killed by PID)."""
     import subprocess
-    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
-    for key in [k for k in env if k.startswith("TORCHELASTIC_")]:     # the children rendezvous on their own TCP store,
-        del env[key]                                                   # not on the launcher's agent store
-    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--probe-graph-collectives"], env=env,
-                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        for key in [k for k in env if k.startswith("TORCHELASTIC_")]:  # the children rendezvous on their own TCP store,
+            del env[key]                                                # not on the launcher's agent store
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--probe-graph-collectives"], env=env,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
     try:
         return proc.wait(timeout=timeout_s) == 0
     except subprocess.TimeoutExpired:
         proc.kill()
         proc.wait()
+        return False
+    except Exception:                                                   # the probe must never take the benchmark down
         return False
 
 
