@@ -282,3 +282,63 @@ def test_oracle_is_test_infrastructure_only():
                        for n in ast.walk(fn))
             assert not uses or fn.name in legs, (rel, fn.name)
 
+
+def test_epoch_driver_protocol(tmp_path):
+    """RLAlgo.train (rl_algo.py:96-167) with stand-in collector / logger: call order, evaluation and snapshot cadence,
+    `best` snapshots, the logger row's keys, timers restarting after every logged row, file names on disk."""
+    import torchrl_amd  # noqa: F401  (registers the stand-in `gym` when none is installed)
+    import gym
+    from torchrl_amd.algo.rl_algo import RLAlgo
+    calls, rows = [], []
+
+    class Collector:
+        epoch_frames = 40
+        def train_one_epoch(self):
+            calls.append("collect")
+            return {"train_rewards": [1.0, 3.0] if len([c for c in calls if c == "collect"]) > 1 else [],
+                    "train_epoch_reward": 7.5}
+        def eval_one_epoch(self):
+            calls.append("eval")
+            n = len([c for c in calls if c == "eval"])
+            return {"eval_rewards": [float(n), float(n) + 1.0] if n != 2 else [-5.0], "eval_traj_length": 9.0}
+        def terminate(self): calls.append("terminate")
+
+    class Log:
+        def add_epoch_info(self, epoch, frames, dt, infos, csv_write=True): rows.append((epoch, frames, dict(infos)))
+        def add_update_info(self, d): pass
+        def log(self, *a): pass
+        def finish(self): calls.append("finish")
+
+    class Env:
+        action_space = gym.spaces.Box(-1, 1, (2,))
+        _obs_normalizer = {"mean": 0.5}
+
+    class Algo(RLAlgo):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            self.net = torch.nn.Linear(2, 2)
+        snapshot_networks = property(lambda self: [("pf", self.net)])
+        def update_per_epoch(self): calls.append("update")
+        def finish_epoch(self): return {"extra": 1}
+
+    save = tmp_path / "model"
+    algo = Algo(env=Env(), replay_buffer=None, collector=Collector(), logger=Log(), num_epochs=5, eval_interval=2,
+                save_interval=3, save_dir=str(save), device="cpu")
+    assert algo.continuous and algo.epoch_frames == 40
+    algo.train()
+    assert calls == ["collect", "update", "eval", "collect", "update", "collect", "update", "eval",
+                     "collect", "update", "collect", "update", "eval", "terminate", "finish"]
+    assert [(e, f) for e, f, _ in rows] == [(0, 40), (2, 120), (4, 200)]
+    first = rows[0][2]
+    assert list(first)[:6] == ["Running_Average_Rewards", "Train_Epoch_Reward", "Running_Training_Average_Rewards",
+                               "Explore_Time", "Train___Time", "Eval____Time"]
+    assert first["eval_traj_length"] == 9.0 and first["extra"] == 1 and "eval_rewards" not in first
+    assert np.isnan(first["Running_Training_Average_Rewards"]) and rows[1][2]["Running_Training_Average_Rewards"] == 2.0
+    assert first["Running_Average_Rewards"] == 1.5 and rows[1][2]["Running_Average_Rewards"] == (1 + 2 - 5) / 3
+    assert algo.best_eval == 3.5 and algo.explore_time == 0 and algo.train_time == 0      # evals: 1.5, -5.0, 3.5
+    names = sorted(os.listdir(save))
+    assert names == sorted(["model_pf_best.pth", "model_pf_0.pth", "model_pf_3.pth", "model_pf_finish.pth",
+                            "_obs_normalizer_best.pkl", "_obs_normalizer_0.pkl", "_obs_normalizer_3.pkl",
+                            "_obs_normalizer_finish.pkl"])
+    assert sorted(torch.load(save / "model_pf_finish.pth")) == ["bias", "weight"]
+
