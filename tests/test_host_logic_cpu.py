@@ -342,3 +342,53 @@ def test_epoch_driver_protocol(tmp_path):
                             "_obs_normalizer_finish.pkl"])
     assert sorted(torch.load(save / "model_pf_finish.pth")) == ["bias", "weight"]
 
+
+def test_off_policy_epoch_driver_protocol():
+    """OffRLAlgo (off_rl_algo.py:8-84) with stand-ins: opt_times x {sample -> update -> log}, the fixed-address batch
+    handed to the replay gather when the engine has one, collection-only pretrain epochs and their frame count."""
+    import torchrl_amd  # noqa: F401
+    import gym
+    from torchrl_amd.algo.off_policy.off_rl_algo import OffRLAlgo
+    events, rows, logged = [], [], []
+
+    class Replay:
+        def random_batch(self, batch_size, keys, out=None):
+            events.append(("sample", batch_size, tuple(keys), out))
+            return {"n": len(events)}
+        def num_steps_can_sample(self): return 100
+
+    class Collector:
+        epoch_frames = 16
+        def train_one_epoch(self):
+            events.append("collect")
+            return {"train_rewards": [2.0], "train_epoch_reward": 1.0}
+
+    class Log:
+        def add_epoch_info(self, epoch, frames, dt, infos, csv_write=True): rows.append((epoch, frames, dict(infos), csv_write))
+        def add_update_info(self, d): logged.append(d)
+        def log(self, msg): events.append(msg)
+
+    class Env:
+        action_space = gym.spaces.Discrete(3)
+
+    class Algo(OffRLAlgo):
+        def update(self, batch): return {"seen": batch["n"]}
+
+    algo = Algo(env=Env(), replay_buffer=Replay(), collector=Collector(), logger=Log(), batch_size=32, opt_times=3,
+                pretrain_epochs=2, min_pool=10, device="cpu")
+    assert not algo.continuous and algo.sample_key == ["obs", "next_obs", "acts", "rewards", "terminals"]
+    algo.pretrain()
+    assert events == ["collect", "collect", "Finished Pretrain"] and algo.pretrain_frames == 32
+    assert [(e, f, c) for e, f, _, c in rows] == [(0, 16, False), (1, 32, False)]
+    assert rows[1][2] == {"Train_Epoch_Reward": 1.0, "Running_Training_Average_Rewards": 2.0}
+    del events[:]
+    algo.update_per_epoch()
+    assert events == [("sample", 32, tuple(algo.sample_key), None)] * 3 and [d["seen"] for d in logged] == [1, 2, 3]
+    fixed = {"obs": object()}
+    algo.static_batch = lambda: fixed                              # an engine with fixed-address inputs
+    algo.update_per_timestep()                                     # 100 > max(min_pool, batch_size): opt_times updates
+    assert [e[3] for e in events[3:]] == [fixed] * 3
+    algo.min_pool = 1000
+    algo.update_per_timestep()
+    assert len(events) == 6
+

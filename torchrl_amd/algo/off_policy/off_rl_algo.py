@@ -1,5 +1,9 @@
-"""Off-policy epoch driver (torchrl/algo/off_policy/off_rl_algo.py:8-84): `opt_times` x
-{uniform replay sample -> update -> log} per epoch, collection-only pretrain epochs."""
+"""Off-policy epoch driver (torchrl/algo/off_policy/off_rl_algo.py:8-84).
+
+Per epoch: `opt_times` x {uniform replay sample -> `update` -> log the info dict}.  `pretrain()` runs
+`pretrain_epochs` collection-only epochs (logged without a csv row) and accounts their frames in `pretrain_frames`.
+Engines that replay a captured graph expose `static_batch()`: the replay gather then writes into those fixed-address
+tensors (`random_batch(..., out=)`, an argument the reference does not have)."""
 import time
 
 import numpy as np
@@ -8,45 +12,42 @@ from ..rl_algo import RLAlgo
 
 
 class OffRLAlgo(RLAlgo):
+    sample_key = ("obs", "next_obs", "acts", "rewards", "terminals")
+
     def __init__(self, pretrain_epochs=0, min_pool=0, target_hard_update_period=1000,
                  use_soft_update=True, tau=0.001, opt_times=1, **kwargs):
         super().__init__(**kwargs)
-        self.pretrain_epochs = pretrain_epochs
+        self.sample_key = list(type(self).sample_key)
+        self.pretrain_epochs, self.min_pool, self.opt_times = pretrain_epochs, min_pool, opt_times
+        self.use_soft_update, self.tau = use_soft_update, tau
         self.target_hard_update_period = target_hard_update_period
-        self.use_soft_update = use_soft_update
-        self.tau = tau
-        self.opt_times = opt_times
-        self.min_pool = min_pool
-        self.sample_key = ["obs", "next_obs", "acts", "rewards", "terminals"]
 
-    def _sample_and_update(self):
-        out = self.static_batch() if hasattr(self, "static_batch") else None     # fixed-address inputs (graph replay)
-        batch = (self.replay_buffer.random_batch(self.batch_size, self.sample_key, out=out) if out is not None
-                 else self.replay_buffer.random_batch(self.batch_size, self.sample_key))
+    def _one_update(self):
+        extra = {}
+        static = getattr(self, "static_batch", None)
+        if static is not None:
+            extra["out"] = static()
+        batch = self.replay_buffer.random_batch(self.batch_size, self.sample_key, **extra)
         self.logger.add_update_info(self.update(batch))
-
-    def update_per_timestep(self):
-        if self.replay_buffer.num_steps_can_sample() > max(self.min_pool, self.batch_size):
-            for _ in range(self.opt_times):
-                self._sample_and_update()
 
     def update_per_epoch(self):
         for _ in range(self.opt_times):
-            self._sample_and_update()
+            self._one_update()
+
+    def update_per_timestep(self):
+        if self.replay_buffer.num_steps_can_sample() > max(self.min_pool, self.batch_size):
+            self.update_per_epoch()
 
     def pretrain(self):
-        total_frames = 0
         self.pretrain_frames = self.pretrain_epochs * self.epoch_frames
-        for pretrain_epoch in range(self.pretrain_epochs):
-            start = time.time()
+        for index in range(self.pretrain_epochs):
+            began = time.time()
             self.start_epoch()
-            epoch_info = self.collector.train_one_epoch()
-            self.training_episode_rewards.extend(epoch_info["train_rewards"])
-            finish_info = self.finish_epoch()
-            total_frames += self.epoch_frames
-            infos = {"Train_Epoch_Reward": epoch_info["train_epoch_reward"],
-                     "Running_Training_Average_Rewards":
-                         np.mean(self.training_episode_rewards) if len(self.training_episode_rewards) else float("nan")}
-            infos.update(finish_info)
-            self.logger.add_epoch_info(pretrain_epoch, total_frames, time.time() - start, infos, csv_write=False)
+            collected = self.collector.train_one_epoch()
+            self.training_episode_rewards.extend(collected["train_rewards"])
+            recent = self.training_episode_rewards
+            row = {"Train_Epoch_Reward": collected["train_epoch_reward"],
+                   "Running_Training_Average_Rewards": np.mean(recent) if len(recent) else float("nan")}
+            row.update(self.finish_epoch())
+            self.logger.add_epoch_info(index, (index + 1) * self.epoch_frames, time.time() - began, row, csv_write=False)
         self.logger.log("Finished Pretrain")
