@@ -79,49 +79,45 @@ class Logger:
             self.stored_infos.setdefault(key, []).append(value)
         self.update_count += 1
 
-    def add_epoch_info(self, epoch_num, total_frames, total_time, infos, csv_write=True):
-        if csv_write and epoch_num == 0:
-            self._csv_titles = ["EPOCH", "Time Consumed", "Total Frames"]
-        self.logger.info("EPOCH:{}".format(epoch_num))
-        self.logger.info("Time Consumed:{}s".format(total_time))
-        self.logger.info("Total Frames:{}s".format(total_frames))
-        row = [epoch_num, total_time, total_frames]
-        table = []
-        scalars = {}
-        for key, value in infos.items():
-            scalars[key] = value
-            table.append([key, "{:.5f}".format(float(value))])
-            if csv_write:
-                if epoch_num == 0:
-                    self._csv_titles.append(key)
-                row.append(value)
-        stat_table = []
+    def _update_statistics(self):
+        """[(name, {Mean, Std, Max, Min})] of every scalar logged by add_update_info since the last epoch row."""
+        out = []
         for key, values in self.stored_infos.items():
             arr = np.asarray(values, dtype=np.float64)
-            stats = {"Mean": arr.mean(), "Std": arr.std(), "Max": arr.max(), "Min": arr.min()}
-            stat_table.append([key] + ["{:.5f}".format(v) for v in stats.values()])
-            for name, v in stats.items():
-                scalars["{}_{}".format(key, name)] = v
-                if csv_write:
-                    if epoch_num == 0:
-                        self._csv_titles.append("{}_{}".format(key, name))
-                    row.append(v)
+            out.append((key, {"Mean": arr.mean(), "Std": arr.std(), "Max": arr.max(), "Min": arr.min()}))
+        return out
+
+    def _print_tables(self, epoch_scalars, statistics):
+        table = [[key, "{:.5f}".format(float(value))] for key, value in epoch_scalars.items()]
+        stat_table = [[key] + ["{:.5f}".format(v) for v in stats.values()] for key, stats in statistics]
+        if tabulate is None:
+            for line in table + stat_table:
+                self.logger.info(" ".join(str(x) for x in line))
+            return
+        self.logger.info("\n" + tabulate(table))
+        if stat_table:
+            self.logger.info("\n" + tabulate(stat_table, ["Name", "Mean", "Std", "Max", "Min"]))
+
+    def add_epoch_info(self, epoch_num, total_frames, total_time, infos, csv_write=True):
+        """One row per epoch: the epoch scalars in the order given, then Mean / Std / Max / Min of every per-update
+        scalar; to stdout, tensorboard / wandb when present, and `log.csv` (header written with epoch 0)."""
+        for label, value in (("EPOCH:{}", epoch_num), ("Time Consumed:{}s", total_time), ("Total Frames:{}s", total_frames)):
+            self.logger.info(label.format(value))
+        statistics = self._update_statistics()
+        columns = [("EPOCH", epoch_num), ("Time Consumed", total_time), ("Total Frames", total_frames)]
+        columns += list(infos.items())
+        columns += [("{}_{}".format(key, name), v) for key, stats in statistics for name, v in stats.items()]
+        scalars = dict(columns[3:])
         if self.tf_writer is not None:
             for key, v in scalars.items():
                 self.tf_writer.add_scalar(key, v, total_frames)
         if self.use_wb:
             wandb.log(scalars, step=total_frames)
-        if tabulate is not None:
-            self.logger.info("\n" + tabulate(table))
-            if stat_table:
-                self.logger.info("\n" + tabulate(stat_table, ["Name", "Mean", "Std", "Max", "Min"]))
-        else:
-            for line in table + stat_table:
-                self.logger.info(" ".join(str(x) for x in line))
+        self._print_tables(dict(infos), statistics)
         if csv_write:
-            with open(self.csv_file_path, 'a') as f:
-                writer = csv.writer(f)
+            with open(self.csv_file_path, 'a') as handle:
+                writer = csv.writer(handle)
                 if epoch_num == 0:
-                    writer.writerow(self._csv_titles)
-                writer.writerow(row)
+                    writer.writerow([name for name, _ in columns])
+                writer.writerow([value for _, value in columns])
         self.stored_infos = {}
