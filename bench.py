@@ -67,8 +67,11 @@ def build_agent(dev, world, rank, seed=0):
 
 
 def iteration(agent, col, epoch):
-    """collect -> GAE -> opt_epochs x minibatches; all enqueued, one host read of the update statistics."""
-    col.rollout(col.sample_epoch_frames)
+    """One pass of the reference's loop body (torchrl/algo/rl_algo.py:111-118): `collector.train_one_epoch()` --
+    the rollout plus the per-epoch read-back of the epoch reward and the finished-episode list
+    (collector/on_policy.py:277-286 here) -- then `update_per_epoch()` = GAE + opt_epochs x minibatch updates with one
+    host read of the update statistics."""
+    col.train_one_epoch()
     agent.current_epoch = epoch
     agent.update_per_epoch()
 
@@ -80,15 +83,31 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
+PARITY_STEPS = 3                                  # iterations timed in the reference-parity exploration mode (host noise)
+FLOP_PER_ENV_STEP = 671e3                         # whole iteration, SURVEY.md section 8(d) (log pi_old cached)
 PROBE_STEPS = 5                                   # iterations of the event-probed pass after a graph-replayed timed region
 
 
-def cpu_baseline(budget_s=25.0):
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=27.0):
     """The reference-style CPU path (oracle/, a port), timed on this host on a BOUNDED sample of the
     same workload and scaled to one full iteration: SubProcVecEnv-like stepping of per-env Python
-    objects over pickled pipes + torch-CPU policy/value forward + numpy fp64 ring (collect leg:
-    as many of the T=128 vector steps as fit in ~half the budget), then torch-CPU PPO minibatch
-    updates of the full B=65536 on synthetic rollout data (update leg: as many of the 40 as fit)."""
+    objects over pickled pipes + torch-CPU policy/value forward + numpy fp64 ring (collect leg, timed at the two
+    worker counts SURVEY.md section 8(d) names: proc_nums = 4, the value the reference's example hard-codes
+    (examples/ppo_continuous_vec_subproc.py:31-36), and proc_nums = the host's hardware threads, rounded down to a
+    power of two that divides N; as many of the T=128 vector steps as fit in a third of the budget each), then
+    torch-CPU PPO minibatch updates of the full B=65536 on synthetic rollout data (update leg: as many of the 40 as
+    fit in the last third).  `value` is the faster of the two settings."""
     import functools
     import torch
     from oracle import nets, replay
@@ -97,31 +116,36 @@ def cpu_baseline(budget_s=25.0):
     from oracle.ppo import PPOOracle
     from oracle.synth_env import SynthSingleEnvCPU
     cores = os.cpu_count() or 1
-    procs = 1
-    while procs * 2 <= min(cores, 16) and N_PER_GPU % (procs * 2) == 0:
-        procs *= 2
+    proc_hi = 1
+    while proc_hi * 2 <= cores and N_PER_GPU % (proc_hi * 2) == 0:
+        proc_hi *= 2
     threads = min(cores, 32)
     torch.set_num_threads(threads)
     fns = [functools.partial(SynthSingleEnvCPU, i) for i in range(N_PER_GPU)]
-    log("cpu baseline: spawning %d env workers" % procs)
-    env = SubProcVecEnvCPU(procs, N_PER_GPU, fns, SynthSingleEnvCPU(0))
-    try:
-        gen = torch.Generator().manual_seed(0)
-        pf, vf = nets.init_mlp(D, [H, H], A, generator=gen), nets.init_mlp(D, [H, H], 1, generator=gen)
-        ls = torch.full((A,), float(np.log(0.125)))
-        ring = replay.RingOracle(N_PER_GPU * T, env_nums=N_PER_GPU, time_limit_filter=True)
-        col = VecOnPolicyCollectorOracle(env, ring, pf, ls, vf, epoch_frames=N_PER_GPU * T, max_episode_frames=1000)
-        col.train_rews = []
-        for _ in range(2):
-            col.take_actions()                                   # warm the pipes
-        n_col, t0 = 0, time.perf_counter()
-        while n_col < T and (time.perf_counter() - t0) < 0.5 * budget_s:
-            col.take_actions()
-            n_col += 1
-        t_step = (time.perf_counter() - t0) / n_col
-    finally:
-        env.close()
-    log("cpu baseline: %d collect steps, %.3f s/step" % (n_col, t_step))
+    gen = torch.Generator().manual_seed(0)
+    pf, vf = nets.init_mlp(D, [H, H], A, generator=gen), nets.init_mlp(D, [H, H], 1, generator=gen)
+    ls = torch.full((A,), float(np.log(0.125)))
+    collect = {}
+    for procs in sorted({min(4, proc_hi), proc_hi}):
+        log("cpu baseline: spawning %d env workers" % procs)
+        t_spawn = time.perf_counter()
+        env = SubProcVecEnvCPU(procs, N_PER_GPU, fns, SynthSingleEnvCPU(0))
+        try:
+            ring = replay.RingOracle(N_PER_GPU * T, env_nums=N_PER_GPU, time_limit_filter=True)
+            col = VecOnPolicyCollectorOracle(env, ring, pf, ls, vf, epoch_frames=N_PER_GPU * T, max_episode_frames=1000)
+            col.train_rews = []
+            for _ in range(2):
+                col.take_actions()                                   # warm the pipes
+            t_spawn = time.perf_counter() - t_spawn
+            n_col, t0 = 0, time.perf_counter()
+            while n_col < T and (time.perf_counter() - t0) < budget_s / 3.0:
+                col.take_actions()
+                n_col += 1
+            collect[procs] = ((time.perf_counter() - t0) / n_col, n_col)
+        finally:
+            env.close()
+        log("cpu baseline: proc_nums=%d: %d collect steps, %.4f s/step (workers up in %.1f s)"
+            % (procs, n_col, collect[procs][0], t_spawn))
     # update leg on a full synthetic rollout (values only matter for timing)
     rs = np.random.RandomState(0)
     ring = replay.RingOracle(N_PER_GPU * T, env_nums=N_PER_GPU, time_limit_filter=True)
@@ -136,20 +160,28 @@ def cpu_baseline(budget_s=25.0):
     keys = ["obs", "acts", "advs", "estimate_returns", "values"]
     n_upd, t0 = 0, time.perf_counter()
     n_mb = N_PER_GPU * T // BATCH_PER_GPU
-    while n_upd < OPT_EPOCHS * n_mb and (time.perf_counter() - t0) < 0.5 * budget_s:
+    while n_upd < OPT_EPOCHS * n_mb and (time.perf_counter() - t0) < budget_s / 3.0:
         for _idx, batch in ring.epoch_minibatches(BATCH_PER_GPU, keys, True):
             ppo.update(batch)
             n_upd += 1
     t_upd = (time.perf_counter() - t0) / n_upd
     log("cpu baseline: %d updates, %.3f s/update" % (n_upd, t_upd))
-    full = T * t_step + t_gae + OPT_EPOCHS * n_mb * t_upd
     steps = N_PER_GPU * T
-    return {"value": steps / full, "unit": "env-steps/s", "cores": max(procs, threads), "kind": "port",
-            "sample": "collect: %d of %d vector steps of N=%d (%d env worker processes over pipes, %.0f env-steps/s); "
-                      "GAE %.3fs; update: %d of %d minibatch updates of B=%d (%d torch threads, %.3f s each); "
-                      "scaled to one full iteration = %.1f s" % (n_col, T, N_PER_GPU, procs, N_PER_GPU / t_step,
-                                                                 t_gae, n_upd, OPT_EPOCHS * n_mb, BATCH_PER_GPU,
-                                                                 threads, t_upd, full)}
+    full = {p: T * ts + t_gae + OPT_EPOCHS * n_mb * t_upd for p, (ts, _) in collect.items()}
+    best = min(full, key=full.get)
+    by_procs = {"proc_nums=%d" % p: {"env_steps_per_s": steps / full[p], "collect_env_steps_per_s": N_PER_GPU / collect[p][0],
+                                     "collect_steps_timed": collect[p][1]} for p in sorted(collect)}
+    return {"value": steps / full[best], "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "cpu_model": _cpu_model(), "host_hw_threads": cores, "torch_threads": threads, "env_worker_procs": best,
+            "by_proc_nums": by_procs,
+            "sample": "collect: %s of %d vector steps of N=%d at proc_nums %s (env worker processes over pipes; %s "
+                      "env-steps/s); GAE %.3fs; update: %d of %d minibatch updates of B=%d (%d torch threads, %.3f s each); "
+                      "scaled to one full iteration = %s s; value = proc_nums=%d"
+                      % ("/".join(str(collect[p][1]) for p in sorted(collect)), T, N_PER_GPU,
+                         "/".join(str(p) for p in sorted(collect)),
+                         "/".join("%.0f" % (N_PER_GPU / collect[p][0]) for p in sorted(collect)), t_gae, n_upd,
+                         OPT_EPOCHS * n_mb, BATCH_PER_GPU, threads, t_upd,
+                         "/".join("%.1f" % full[p] for p in sorted(collect)), best)}
 
 
 def cpu_baseline_offpolicy(kind):
@@ -353,6 +385,19 @@ def main():
             iteration(agent, col, args.warmup + args.steps + e)
         torch.cuda.synchronize()
     eng.probe = None
+    # The reference-parity exploration mode (CPU torch.randn per step, the reference's own stream -- what the parity
+    # tests run) next to the device-Philox headline: the same iteration, PARITY_STEPS times.
+    parity_ms = None
+    if world == 1:
+        col.noise_mode = "host"
+        iteration(agent, col, args.warmup + args.steps + PROBE_STEPS)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for e in range(PARITY_STEPS):
+            iteration(agent, col, args.warmup + args.steps + PROBE_STEPS + 1 + e)
+        torch.cuda.synchronize()
+        parity_ms = 1e3 * (time.perf_counter() - tp) / PARITY_STEPS
+        col.noise_mode = "device"
     if dist.initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce_max_(tmax)
@@ -381,10 +426,14 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "ppo_grad_wave_kernel<17,64,6,tanh>", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": pmc_traffic(), "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
+                     "whole_iteration_frac": FLOP_PER_ENV_STEP * env_steps / elapsed / world / 1e12 / MFMA_F32_PEAK_TFLOPS,
                      "launches_timed": len(grad_ms),
                      "timed_in": ("follow-up pass of %d iterations (the timed region replays a HIP graph)" % PROBE_STEPS)
                      if graph_mode else "the timed region"},
     }
+    if parity_ms is not None:
+        out["parity_mode_ms_per_step"] = parity_ms
+        out["config"]["parity_mode"] = "exploration noise from the CPU torch generator per step (reference stream), %d iterations" % PARITY_STEPS
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_subprocess()
     print(json.dumps(out))

@@ -478,7 +478,9 @@ int trl_frame_stream_gather_u8(const uint8_t* stream, const int32_t* pos, const 
  *   onpolicy_bookkeep  after env.step: epoch reward, running returns (logged + cleared on done),
  *                      rewards += discount * v_next * surpass (in place), terminals = reset_mask =
  *                      done | surpass, step counters, *any_flag |= any(reset_mask)   (:124-148)
- *   select_on_flag     out = *flag ? a : b -- partial_reset's whole-array return (:145-147) without a host sync */
+ *   select_on_flag     out = *flag ? a : b -- partial_reset's whole-array return (:145-147) without a host sync
+ *   select_on_mask     out = any(mask[0..N)) ? a : b -- the same for VecCollector.take_actions
+ *                      (torchrl/collector/base.py:220-224), straight from the reset mask */
 int trl_gauss_explore_f32(const float* mean, const float* logstd, const float* eps, float* act, float* logp,
                           int N, int A, int tanh_action, void* stream);
 int trl_onpolicy_bookkeep_f32(float* rewards, const float* dones, const float* v_next, float discount,
@@ -486,6 +488,8 @@ int trl_onpolicy_bookkeep_f32(float* rewards, const float* dones, const float* v
                               uint8_t* reset_mask, int32_t* any_flag, double* epoch_reward, int32_t* ep_count,
                               float* ep_log, int ep_cap, int step, int N, void* stream);
 int trl_select_on_flag_f32(const int32_t* flag, const float* a, const float* b, float* out, int64_t n,
+                           void* stream);
+int trl_select_on_mask_f32(const uint8_t* mask, int N, const float* a, const float* b, float* out, int64_t n,
                            void* stream);
 
 /* --- K18: running observation normaliser (torchrl/env/base_wrapper.py:44-121) --------------

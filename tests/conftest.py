@@ -37,3 +37,35 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return load
+
+
+_PARITY_ERRORS = {}
+
+
+@pytest.fixture
+def errlog(request):
+    """errlog(name, err, tol): record the measured error of a parity check next to its tolerance; the session writes
+    all of them to gpurun_out/parity_errors.json (copied to profiles/ as the measured-error table)."""
+    def rec(name, err, tol):
+        key = "%s::%s" % (request.node.nodeid, name)
+        _PARITY_ERRORS[key] = {"err": float(err), "tol": float(tol)}
+    return rec
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY_ERRORS:
+        return
+    import json
+    out = os.path.join(REPO, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity_errors.json")
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_PARITY_ERRORS)
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

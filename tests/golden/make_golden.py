@@ -888,7 +888,119 @@ def case_obs_norm():
     save("obs_norm", **out)
 
 
-CASES = {"collect_offpolicy": case_collect_offpolicy, "subproc_vecenv": case_subproc_vecenv, "eps_greedy": case_eps_greedy, "eval_epoch": case_eval_epoch, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
+def case_frame_dedup():
+    """LazyFrames / FrameStack / MemoryEfficientReplayBuffer (env/atari_wrapper.py:142-227,
+    replay_buffers/memory_efficient_replay_buffer.py:5-33): the reference classes driven by the single-env collection
+    loop of collector/base.py:60-104 over a prepared frame sequence per env -- ring wrap-around, env `done` resets,
+    collector over-length resets.  Stored: the source frames and actions (inputs) and, for every replay row of every
+    env, the stacks the reference's encode_batchs returns (+ the scalar keys); for the single-env case also the
+    reference's own random_batch draws."""
+    import gym
+    from torchrl.env.atari_wrapper import FrameStack
+    from torchrl.replay_buffers.memory_efficient_replay_buffer import MemoryEfficientReplayBuffer
+    from oracle.frames import FrameSourceCPU, run_single_env
+    np.float = float                                             # memory_efficient_replay_buffer.py:25 (numpy >= 1.24)
+    out = {}
+
+    class Src(FrameSourceCPU):
+        def __init__(self, frames, horizon):
+            super().__init__(frames, horizon)
+            self.observation_space = gym.spaces.Box(0, 255, frames.shape[1:], dtype=np.uint8)
+            self.observation_space.dtype = np.uint8
+            self.action_space = gym.spaces.Discrete(6)
+
+    #            tag       N  rows steps H   W   horizon max_frames seed
+    for tag, N, rows, steps, H, W, horizon, max_frames, seed in (
+            ("done", 4, 6, 17, 12, 12, 5, 1000, 1), ("surpass", 4, 6, 17, 12, 12, 1000, 3, 2),
+            ("mixed", 3, 5, 23, 8, 16, 7, 4, 3), ("single", 1, 9, 31, 12, 12, 6, 5, 5),
+            ("single84", 1, 4, 9, 84, 84, 6, 1000, 4)):
+        rs = np.random.RandomState(seed)
+        n_frames = 2 * steps + 2                                 # more than any env can consume
+        frames = rs.randint(0, 256, size=(N, n_frames, 1, H, W)).astype(np.uint8)
+        acts = rs.randint(0, 6, size=(steps, N))
+        bufs = []
+        for n in range(N):
+            env = FrameStack(Src(frames[n], horizon), 4)
+            buf = MemoryEfficientReplayBuffer(rows)
+            run_single_env(env.reset, env.step, buf.add_sample, acts[:, n], max_frames)
+            bufs.append(buf)
+        allrows = list(range(rows))
+        for key in ("obs", "next_obs"):
+            arr = np.stack([b.encode_batchs(key, allrows) for b in bufs], axis=1)      # (rows, N, 4, H, W) float64
+            assert arr.dtype == np.float64 and np.array_equal(arr, arr.astype(np.uint8))
+            out[f"{tag}_ref_{key}"] = arr.astype(np.uint8)       # exact: the float64 values are the frame bytes
+        for key in ("acts", "rewards", "terminals"):
+            out[f"{tag}_ref_{key}"] = np.stack([b.encode_batchs(key, allrows) for b in bufs], axis=1)
+        out[f"{tag}_frames"] = frames
+        out[f"{tag}_acts"] = acts
+        out[f"{tag}_args"] = np.array([N, rows, steps, H, W, horizon, max_frames, seed], dtype=np.int64)
+        out[f"{tag}_top_size"] = np.array([bufs[0]._top, bufs[0]._size], dtype=np.int64)
+        if tag == "single":                                      # the reference's own uniform sample (index stream + batch)
+            np.random.seed(seed + 50)
+            for k in range(3):
+                batch = bufs[0].random_batch(7, ["obs", "next_obs", "acts", "rewards", "terminals"])
+                for key, v in batch.items():
+                    out[f"{tag}_batch{k}_{key}"] = v.astype(np.uint8) if key in ("obs", "next_obs") else v
+    save("frame_dedup", **out)
+
+
+def case_collect_offpolicy_norm():
+    """VecCollector.train_one_epoch (collector/base.py:176-230) on a NormObs-wrapped synthetic env
+    (env/base_wrapper.py:98-121 as get_vec_env applies it): the ring holds the NORMALISED observations env.step returns,
+    statistics move every step, and after any reset the next policy input is the RAW array partial_reset returns
+    (SURVEY Q14).  Followed by eval_one_epoch (:232-280) with the deep-copied normaliser in eval mode."""
+    import gym
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector.base import VecCollector
+    from torchrl.env.base_wrapper import NormObs
+    from torchrl.replay_buffers.base import BaseReplayBuffer
+    from oracle.synth_env import SynthVecEnvCPU
+    out = {}
+    for tag, N, steps, rows, horizon, max_frames, seed in (("env_limit", 8, 12, 16, 5, 999, 6), ("wrap", 4, 20, 7, 6, 5, 7)):
+        D, A, H = 17, 6, 32
+        torch.manual_seed(seed + 40)
+        net = dict(hidden_shapes=[H, H], append_hidden_shapes=[], base_type=networks.MLPBase,
+                   activation_func=torch.nn.ReLU)
+        pf = policies.GuassianContPolicy(input_shape=D, output_shape=2 * A, tanh_action=True, **net)
+
+        def mk():
+            e = SynthVecEnvCPU(N, horizon=horizon)
+            e.action_space = gym.spaces.Box(-1, 1, (A,))
+            e.observation_space = gym.spaces.Box(-np.inf, np.inf, (D,))
+            return NormObs(e)
+        env, eval_env = mk(), mk()
+        env.seed(seed)
+        eval_env.seed(seed + 1)
+        torch.manual_seed(seed)
+        buf = BaseReplayBuffer(N * rows, env_nums=N)
+        col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=torch.device("cpu"),
+                           train_render=False, epoch_frames=N * steps, max_episode_frames=max_frames, eval_episodes=1)
+        out.update(state_arrays(f"{tag}_pf_", pf))
+        out[f"{tag}_ob0"] = np.asarray(col.current_ob).copy()
+        noise_state = torch.get_rng_state()
+        res = col.train_one_epoch()
+        after = torch.get_rng_state()
+        torch.set_rng_state(noise_state)
+        out[f"{tag}_noise"] = torch.stack([torch.randn(N, A) for _ in range(steps)]).numpy()
+        assert torch.equal(torch.get_rng_state(), after), "noise stream mismatch"
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+            out[f"{tag}_buf_{k}"] = getattr(buf, "_" + k).copy()
+        out[f"{tag}_top_size"] = np.array([buf._top, buf._size], dtype=np.int64)
+        out[f"{tag}_train_epoch_reward"] = np.array(res["train_epoch_reward"])
+        out[f"{tag}_train_rewards"] = np.array(res["train_rewards"], dtype=np.float64).reshape(-1)
+        out[f"{tag}_current_ob"] = np.asarray(col.current_ob).copy()
+        nz = env._obs_normalizer
+        out[f"{tag}_state1"] = np.concatenate([nz._mean, nz._var, [nz._count]])
+        ev = col.eval_one_epoch()
+        out[f"{tag}_eval_rewards"] = np.array(ev["eval_rewards"], dtype=np.float64).reshape(-1)
+        out[f"{tag}_eval_traj_length"] = np.array(ev["eval_traj_length"])
+        assert np.array_equal(np.concatenate([nz._mean, nz._var, [nz._count]]), out[f"{tag}_state1"])   # eval does not update
+        out[f"{tag}_args"] = np.array([N, steps, rows, horizon, max_frames, seed], dtype=np.int64)
+    save("collect_offpolicy_norm", **out)
+
+
+CASES = {"collect_offpolicy_norm": case_collect_offpolicy_norm, "frame_dedup": case_frame_dedup, "collect_offpolicy": case_collect_offpolicy, "subproc_vecenv": case_subproc_vecenv, "eps_greedy": case_eps_greedy, "eval_epoch": case_eval_epoch, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
          "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update, "trpo_update": case_trpo_update}
 

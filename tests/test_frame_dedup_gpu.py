@@ -1,12 +1,117 @@
-"""Frame-deduplicating replay: MemoryEfficientReplayBuffer must hand out exactly
-the batches the plain ring buffer holds -- across ring wrap-around, done resets and over-length resets -- from
-one frame per transition instead of two full stacks."""
+"""Frame-deduplicating replay.
+
+Parity: the device buffer is driven through the calls the collector makes (begin_episodes / mark_obs_row /
+append_step) with the frame events of tests/golden/frame_dedup.npz and must hand back, for every replay row of every
+env, the stacks the REFERENCE's FrameStack + LazyFrames + MemoryEfficientReplayBuffer re-encoded
+(env/atari_wrapper.py:142-227, replay_buffers/memory_efficient_replay_buffer.py:5-33) -- ring wrap-around, done
+resets and over-length resets included; at one env also the reference's own random_batch stream.  The remaining
+tests check the collector integration (same batches as the plain ring on the on-GPU frame env), overrun
+detection and the footprint."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+FRAME_TAGS = ["done", "surpass", "mixed", "single", "single84"]
+
+
+def _drive_from_golden(g, tag, **buf_kw):
+    """Replays the golden's frame events into the device buffer exactly as VecCollector._step_frames drives it; the
+    post-step / post-reset stacks come from oracle.frames.FrameStackOracle (pinned to the reference on the CPU)."""
+    from oracle.frames import FrameSourceCPU, FrameStackOracle
+    from torchrl.replay_buffers import MemoryEfficientReplayBuffer
+    N, rows, steps, H, W, horizon, max_frames, seed = (int(v) for v in g[f"{tag}_args"])
+    srcs = [FrameSourceCPU(g[f"{tag}_frames"][n], horizon) for n in range(N)]
+    stacks = [FrameStackOracle(4) for _ in range(N)]
+    cur = [np.asarray(stacks[n].reset(srcs[n].reset())) for n in range(N)]
+    step_cnt = [0] * N
+    buf = MemoryEfficientReplayBuffer(N * rows, env_nums=N, device=DEV, **buf_kw)
+    up = lambda arrs: torch.tensor(np.stack(arrs), device=DEV)
+    buf.begin_episodes(up(cur))
+    acts = g[f"{tag}_acts"]
+    for t in range(steps):
+        row = buf._top
+        buf.mark_obs_row()
+        rew, done, mask = np.zeros((N, 1), np.float32), np.zeros((N, 1), np.float32), np.zeros(N, np.uint8)
+        for n in range(N):
+            f, r, d, _ = srcs[n].step(acts[t, n])
+            cur[n] = np.asarray(stacks[n].step(f))
+            step_cnt[n] += 1
+            rew[n], done[n] = r, float(d)
+            mask[n] = d or step_cnt[n] >= max_frames
+        buf._ensure_key("acts", (N, 1))[row].copy_(torch.tensor(acts[t].astype(np.float32)).view(N, 1))
+        buf._ensure_key("rewards", (N, 1))[row].copy_(torch.tensor(rew))
+        buf._ensure_key("terminals", (N, 1))[row].copy_(torch.tensor(done))
+        buf.append_step(up(cur))                                         # the one new frame of next_obs
+        for n in range(N):
+            if mask[n]:
+                cur[n] = np.asarray(stacks[n].reset(srcs[n].reset()))
+                step_cnt[n] = 0
+        if mask.any():
+            buf.begin_episodes(up(cur), torch.tensor(mask, device=DEV))
+        buf._advance()
+    return buf
+
+
+@pytest.mark.parametrize("tag", FRAME_TAGS)
+def test_dedup_rows_equal_reference_lazyframes(golden, tag):
+    g = golden("frame_dedup")
+    N, rows, steps, H, W = (int(v) for v in g[f"{tag}_args"][:5])
+    buf = _drive_from_golden(g, tag)
+    assert (buf._top, buf._size) == tuple(int(v) for v in g[f"{tag}_top_size"])
+    idx = torch.arange(rows, device=DEV)
+    for key in ("obs", "next_obs"):
+        got = buf._gather(key, idx).cpu().numpy().reshape(rows, N, 4, H, W)
+        assert np.array_equal(got, g[f"{tag}_ref_{key}"]), key          # bit-exact bytes
+    for key in ("acts", "rewards", "terminals"):
+        got = buf._gather(key, idx).cpu().numpy().reshape(rows, N, 1)
+        assert np.array_equal(got.astype(np.float64), g[f"{tag}_ref_{key}"]), key
+    buf.check_overrun()
+    # the trl_gather_rows_u8 twin of the same data: a plain ring filled with the reference's stacks
+    from torchrl_amd import _C
+    plain = torch.tensor(g[f"{tag}_ref_obs"], device=DEV)
+    pick = torch.tensor([rows - 1, 0, rows // 2], device=DEV)
+    assert torch.equal(_C.gather_rows(plain, pick).reshape(-1, 4, H, W), buf._gather("obs", pick))
+
+
+def test_dedup_random_batch_equals_reference_random_batch(golden):
+    """One env: B // N = B, so the index stream and the batches are the reference buffer's own
+    (memory_efficient_replay_buffer.py:27-33), draw for draw; `out=` destinations are honoured for frame keys."""
+    g = golden("frame_dedup")
+    buf = _drive_from_golden(g, "single")
+    seed = int(g["single_args"][7])
+    keys = ["obs", "next_obs", "acts", "rewards", "terminals"]
+    np.random.seed(seed + 50)
+    for k in range(3):
+        if k == 2:                                                       # fixed-address destinations (graph replay)
+            out = {"obs": torch.zeros(7, 4, 12, 12, dtype=torch.uint8, device=DEV),
+                   "next_obs": torch.zeros(7, 4, 12, 12, dtype=torch.uint8, device=DEV)}
+            batch = buf.random_batch(7, keys, out=out)
+            assert batch["obs"].data_ptr() == out["obs"].data_ptr() and batch["next_obs"].data_ptr() == out["next_obs"].data_ptr()
+        else:
+            batch = buf.random_batch(7, keys)
+        for key in keys:
+            want = g[f"single_batch{k}_{key}"]
+            assert np.array_equal(batch[key].cpu().numpy().reshape(want.shape).astype(np.float64), want.astype(np.float64)), (k, key)
+
+
+def test_dedup_vector_batches_equal_oracle(golden):
+    """Several envs: B // N sampled rows x all envs (replay_buffers/base.py:39-51) from the oracle ring."""
+    from tests.test_oracle_golden import frame_oracle_from_golden
+    g = golden("frame_dedup")
+    for tag in ("done", "mixed"):
+        buf, ring = _drive_from_golden(g, tag), frame_oracle_from_golden(g, tag)
+        N = int(g[f"{tag}_args"][0])
+        for k in range(3):
+            np.random.seed(300 + k)
+            idx, want = ring.random_batch(2 * N, ["obs", "next_obs", "rewards"])
+            np.random.seed(300 + k)
+            got = buf.random_batch(2 * N, ["obs", "next_obs", "rewards"])
+            for key in want:
+                assert np.array_equal(got[key].cpu().numpy().astype(np.float64), want[key]), (tag, k, key)
 
 
 def _run(buf_cls, N, rows, steps, horizon, max_frames, seed, **buf_kw):

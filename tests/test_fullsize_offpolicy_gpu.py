@@ -1,0 +1,239 @@
+"""BASELINE-size checks of the off-policy configurations:
+
+cfg 3 -- TwinSACQ, 1024 envs, 10^6-transition replay (976 rows), B = 4096 (4 rows), MLP 256x256 ReLU
+         (reference shapes: config/twin_sac_q_halfcheetah.json:7-43);
+cfg 5 -- DQN / QR-DQN(Q = 200), 512 envs, 84x84x4 uint8 frames, 195-row replay, B = 512, conv 16/32/64 + fc 512
+         (config/dqn_pong.json:12-19, config/qrdqn.json:21,45).
+
+Collection and sampling are checked against the CPU oracle and through size-independent properties (bit-exact index
+stream, env-shard invariance of the replay rows); ONE update per algorithm on a full-size sampled batch is checked
+end to end against the torch-CPU oracle (oracle/sac.py, oracle/dqn.py -- themselves pinned to the reference's
+outputs in tests/test_oracle_golden.py): logged scalars rel 1e-4 / abs 1e-5, post-step parameters abs 1e-6
+(SURVEY.md 8 a11)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+class _Log:
+    def __init__(self): self.infos = []
+    def add_update_info(self, d): self.infos.append(d)
+    def add_epoch_info(self, *a, **k): pass
+    def log(self, *a): pass
+    def finish(self): pass
+
+
+# ------------------------------------------------------------------------------------------------ cfg 3
+N3, ROWS3, B3, H3, STEPS3 = 1024, 976, 4096, 256, 16
+
+
+def build_cfg3(n_env=N3, offset=0, total=None, seed=0):
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import TwinSACQ
+    from torchrl.collector import VecCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    torch.manual_seed(21)
+    net = dict(hidden_shapes=[H3, H3], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net)
+    qf1 = networks.QNet(input_shape=23, output_shape=1, **net)
+    qf2 = networks.QNet(input_shape=23, output_shape=1, **net)
+    env = SynthVecEnv(n_env, horizon=9, device=DEV, index_offset=offset, total_env_nums=total)
+    ev = SynthVecEnv(n_env, horizon=9, device=DEV, index_offset=offset, total_env_nums=total)
+    env.seed(seed)
+    buf = BaseReplayBuffer(ROWS3 * n_env, env_nums=n_env)
+    col = VecCollector(env=env, eval_env=ev, pf=pf, replay_buffer=buf, device=DEV, epoch_frames=n_env * STEPS3,
+                       max_episode_frames=7, eval_episodes=1)
+    log = _Log()
+    agent = TwinSACQ(pf=pf, qf1=qf1, qf2=qf2, plr=3e-4, qlr=3e-4, policy_std_reg_weight=0, policy_mean_reg_weight=0,
+                     reparameterization=True, automatic_entropy_tuning=True, env=env, replay_buffer=buf, collector=col,
+                     logger=log, discount=0.99, num_epochs=1, batch_size=B3 * n_env // N3, device=DEV, save_dir=None,
+                     tau=0.005, use_soft_update=True, opt_times=1)
+    return pf, qf1, qf2, env, buf, col, agent, log
+
+
+def test_cfg3_collection_ring_and_index_stream_full_size():
+    """1024 envs x 16 steps into the 976-row ring against the CPU oracle collector on the CPU twin of the env
+    (collector/base.py:184-230 with env-limit and collector-limit resets); `random_batch(4096)` draws the reference's
+    index stream `np.random.randint(0, size, 4)` (replay_buffers/base.py:39-51) and gathers those rows bit-exactly."""
+    from oracle import replay
+    from oracle.collector import VecCollectorOracle
+    from oracle.synth_env import SynthVecEnvCPU
+    from torchrl_amd import ops
+    pf, qf1, qf2, env, buf, col, agent, log = build_cfg3()
+    assert buf._max_replay_buffer_size == ROWS3
+    params = [p.detach().cpu().clone() for wb in ops.linear_layers(pf) for p in wb]
+    torch.manual_seed(5)
+    got = col.train_one_epoch()
+    oenv = SynthVecEnvCPU(N3, horizon=9)
+    oenv.seed(0)
+    ring = replay.RingOracle(ROWS3 * N3, env_nums=N3)
+    ocol = VecCollectorOracle(oenv, ring, params, epoch_frames=N3 * STEPS3, max_episode_frames=7, act="relu")
+    torch.manual_seed(5)
+    want = ocol.train_one_epoch()
+    for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+        a = getattr(buf, "_" + k)[:STEPS3].cpu().numpy().astype(np.float64)
+        err = np.abs(a - ring.data[k][:STEPS3].reshape(a.shape)).max()
+        assert err < 3e-5, (k, err)
+    assert (buf._top, buf._size) == (ring.top, ring.size) == (STEPS3, STEPS3)
+    assert float(buf._terminals[:STEPS3].sum()) > 0                   # env-limit resets happened
+    assert abs(got["train_epoch_reward"] - want["train_epoch_reward"]) < 1e-3 * abs(want["train_epoch_reward"]) + 1e-2
+    assert len(got["train_rewards"]) == len(want["train_rewards"]) > 0
+    keys = ["obs", "next_obs", "acts", "rewards", "terminals"]
+    for k in range(3):
+        np.random.seed(40 + k)
+        batch = buf.random_batch(B3, keys)
+        np.random.seed(40 + k)
+        idx = np.random.randint(0, STEPS3, B3 // N3)                  # the reference's draw, bit for bit
+        for key in keys:
+            src = getattr(buf, "_" + key)
+            want_b = src[torch.from_numpy(idx).to(DEV)].reshape(B3, -1)
+            assert torch.equal(batch[key].reshape(B3, -1), want_b), (k, key)
+
+
+def test_cfg3_replay_rows_are_env_shard_invariant():
+    """Two 512-env shards (global env indices 0..511 / 512..1023, the multi-GPU partition) fill replay rows equal to
+    the column blocks of the single-process ring, given their blocks of the same exploration noise."""
+    noise = torch.randn(STEPS3, N3, 6, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def run(n_env, off):
+        pf, qf1, qf2, env, buf, col, agent, log = build_cfg3(n_env, off, N3)
+        step = {"t": 0}
+
+        def fixed_noise(e):
+            t = step["t"]
+            step["t"] += 1
+            return noise[t, off:off + n_env].contiguous()
+        col._explore_noise = fixed_noise
+        col.train_one_epoch()
+        return buf
+    full = run(N3, 0)
+    for off in (0, 512):
+        part = run(512, off)
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals"):
+            a, b = getattr(full, "_" + k)[:STEPS3, off:off + 512], getattr(part, "_" + k)[:STEPS3]
+            assert torch.equal(a, b), (k, off, (a - b).abs().max().item())
+
+
+def test_cfg3_update_on_a_sampled_full_size_batch_vs_oracle(errlog):
+    """One TwinSACQ.update (twin_sac_q.py:84-220) on a B = 4096 batch sampled from the 976-row ring, against the
+    torch-CPU oracle with the same two N(0,1) draws: every logged scalar, post-step pf / qf1 / qf2 / targets, log_alpha."""
+    from oracle.sac import TwinSACQOracle
+    from torchrl_amd import ops
+    pf, qf1, qf2, env, buf, col, agent, log = build_cfg3()
+    lay = lambda m: [p.detach().cpu().clone() for wb in ops.linear_layers(m) for p in wb]
+    o = TwinSACQOracle(lay(pf), lay(qf1), lay(qf2), plr=3e-4, qlr=3e-4, w_std=0, w_mean=0)
+    torch.manual_seed(5)
+    col.train_one_epoch()
+    np.random.seed(9)
+    batch = buf.random_batch(B3, agent.sample_key)
+    host = {k: v.cpu().numpy() for k, v in batch.items()}
+    torch.manual_seed(77)
+    info = agent.update(batch)
+    torch.manual_seed(77)
+    eps1, eps2 = torch.randn(B3, 6), torch.randn(B3, 6)
+    want = o.update(host, eps1, eps2)
+    worst = 0.0
+    for k, w in want.items():
+        assert k in info, k
+        tol = 1e-4 * abs(w) + 1e-5
+        worst = max(worst, abs(info[k] - w) / tol)
+        assert abs(info[k] - w) < tol, (k, info[k], w)
+    errlog("info scalars: max |got - want| / (1e-5 + 1e-4 |want|)", worst, 1.0)
+    perr = 0.0
+    for mod, ref in ((pf, o.pf), (qf1, o.q1), (qf2, o.q2), (agent.target_qf1, o.tq1), (agent.target_qf2, o.tq2)):
+        for a, b in zip(lay(mod), ref):
+            perr = max(perr, (a - b.detach()).abs().max().item())
+    errlog("post-step params abs (one update, B=4096, H=256)", perr, 1e-6)
+    assert perr < 1e-6, perr
+    assert abs(float(agent.log_alpha.cpu()) - float(o.log_alpha.detach())) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ cfg 5
+N5, ROWS5, B5, A5 = 512, 195, 512, 6
+CONVS = [[16, [8, 8], [4, 4], [0, 0]], [32, [4, 4], [2, 2], [0, 0]], [64, [3, 3], [1, 1], [0, 0]]]
+
+
+def build_cfg5(Q, buf_cls=None, steps=3):
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import DQN, QRDQN
+    from torchrl.collector import VecCollector
+    from torchrl.env import get_vec_env
+    from torchrl.replay_buffers import BaseReplayBuffer
+    torch.manual_seed(31)
+    qf = networks.Net(output_shape=A5 * Q, base_type=networks.CNNBase, append_hidden_shapes=[512],
+                      activation_func=torch.nn.Tanh, input_shape=(4, 84, 84), hidden_shapes=CONVS)
+    env = get_vec_env("SynthAtari-v0", {"reward_scale": 1}, N5)
+    eval_env = get_vec_env("SynthAtari-v0", {"reward_scale": 1}, N5)
+    env.horizon = 2
+    env.seed(1)
+    kwp = dict(qf=qf, start_epsilon=1, end_epsilon=0.1, decay_frames=1000000, action_shape=A5)
+    pf = policies.EpsilonGreedyQRDQNDiscretePolicy(quantile_num=Q, **kwp) if Q > 1 else policies.EpsilonGreedyDQNDiscretePolicy(**kwp)
+    buf = (buf_cls or BaseReplayBuffer)(ROWS5 * N5, env_nums=N5)
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=DEV, epoch_frames=N5 * steps,
+                       max_episode_frames=999)
+    kw = dict(qf=qf, pf=pf, qlr=2.5e-4, env=env, replay_buffer=buf, collector=col, logger=_Log(), discount=0.99,
+              num_epochs=1, batch_size=B5, device=DEV, save_dir=None, tau=0.005, opt_times=1)
+    agent = QRDQN(quantile_num=Q, **kw) if Q > 1 else DQN(**kw)
+    return qf, pf, env, buf, col, agent
+
+
+@pytest.mark.parametrize("Q", [1, 200])
+def test_cfg5_update_on_a_sampled_full_size_batch_vs_oracle(Q, errlog):
+    """One DQN.update (dqn.py:38-74) / QRDQN.update (qrdqn.py:22-74, Q = 200) of the full conv 16/32/64 + fc 512 net on
+    a B = 512 batch sampled from the 195-row ring of 512 envs, against the torch-CPU oracle: loss and logged scalars,
+    post-step online and target parameters."""
+    from oracle.dqn import DQNOracle
+    from torchrl_amd import ops
+    qf, pf, env, buf, col, agent = build_cfg5(Q)
+    assert buf._max_replay_buffer_size == ROWS5
+    o = DQNOracle([p.detach().cpu().clone() for p in ops.cnn_param_list(qf)], [4, 2, 1], quantile_num=Q, action_num=A5)
+    np.random.seed(2)
+    col.train_one_epoch()                                             # 3 vector steps of 512 envs (episodes end: horizon 2)
+    assert float(buf._terminals[:3].sum()) > 0
+    np.random.seed(3)
+    batch = buf.random_batch(B5, agent.sample_key)
+    np.random.seed(3)
+    idx = np.random.randint(0, 3, B5 // N5)
+    assert torch.equal(batch["obs"], buf._obs[int(idx[0])]) and batch["obs"].dtype == torch.uint8
+    host = {k: v.cpu().numpy() for k, v in batch.items()}
+    info = agent.update(batch)
+    want = o.update(host)
+    worst = 0.0
+    for k, w in want.items():
+        tol = 1e-4 * abs(w) + 1e-5
+        worst = max(worst, abs(info[k] - w) / tol)
+        assert abs(info[k] - w) < tol, (k, info[k], w)
+    errlog("info scalars: max |got - want| / (1e-5 + 1e-4 |want|)", worst, 1.0)
+    perr = 0.0
+    for mod, ref in ((qf, o.q), (agent.target_qf, o.tq)):
+        for a, b in zip(ops.cnn_param_list(mod), ref):
+            perr = max(perr, (a.detach().cpu() - b.detach()).abs().max().item())
+    errlog("post-step params abs (one update, B=512, Q=%d)" % Q, perr, 1e-6)
+    assert perr < 1e-6, perr
+
+
+def test_cfg5_dedup_ring_equals_plain_ring_full_size():
+    """512 envs, 195 rows: the frame-deduplicating buffer returns byte-identical batches to the plain ring at cfg 5
+    size (its parity against the reference's LazyFrames is pinned at small size in test_frame_dedup_gpu.py), from
+    7.5x less HBM."""
+    from torchrl.replay_buffers import MemoryEfficientReplayBuffer
+    _, _, _, plain, colp, _ = build_cfg5(1, steps=5)
+    _, _, _, dedup, cold, _ = build_cfg5(1, buf_cls=MemoryEfficientReplayBuffer, steps=5)
+    for col in (colp, cold):
+        np.random.seed(4)
+        col.train_one_epoch()
+    for k in range(2):
+        np.random.seed(50 + k)
+        a = plain.random_batch(B5 * 2, ["obs", "next_obs", "acts", "rewards", "terminals"])
+        np.random.seed(50 + k)
+        b = dedup.random_batch(B5 * 2, ["obs", "next_obs", "acts", "rewards", "terminals"])
+        for key in a:
+            assert torch.equal(a[key], b[key]), (k, key)
+    dedup.check_overrun()
+    assert (plain._obs.numel() + plain._next_obs.numel()) / dedup._stream.numel() > 7.0

@@ -385,7 +385,7 @@ class DevicePPO:
 
 
 @pytest.mark.parametrize("tag", ["small", "clipv", "mid"])
-def test_ppo_update_vs_reference_golden(golden, tag):
+def test_ppo_update_vs_reference_golden(golden, tag, errlog):
     """One PPO.update on the reference's batch: gradients vs oracle autograd, losses/statistics
     vs the reference info dict, post-step parameters and Adam moments vs the reference."""
     from torchrl_amd import _C
@@ -422,7 +422,11 @@ def test_ppo_update_vs_reference_golden(golden, tag):
     assert abs(info[0] / B - 0.005 * ent - ref["Training/policy_loss"]) < 1e-4 * abs(ref["Training/policy_loss"]) + 1e-5
     assert abs(info[7] / B - ref["Training/vf_loss"]) < 1e-4 * abs(ref["Training/vf_loss"]) + 1e-5
     assert abs(info[1] / B - ref["logprob/mean"]) < 1e-4 * abs(ref["logprob/mean"]) + 1e-4
-    assert abs(info[3] - ref["logprob/max"]) < 2e-3 and abs(-info[4] - ref["logprob/min"]) < 2e-3 * max(1, abs(ref["logprob/min"]))
+    # extrema of O(100) log-probs: rel 1e-4 / abs 1e-5 like every other scalar
+    for name, got_v in (("logprob/max", info[3]), ("logprob/min", -info[4])):
+        tol_v = 1e-4 * abs(ref[name]) + 1e-5
+        errlog(name, abs(got_v - ref[name]), tol_v)
+        assert abs(got_v - ref[name]) < tol_v, (name, got_v, ref[name])
     assert abs(info[5] - ref["ratio/max"]) < 1e-3 * ref["ratio/max"] and abs(-info[6] - ref["ratio/min"]) < 1e-3
     # optimiser step: post-step parameters within 1e-6 of the reference
     d.step(3e-4, 3e-4)
@@ -430,7 +434,8 @@ def test_ppo_update_vs_reference_golden(golden, tag):
     want_vf, _ = params_from(g, f"{tag}_vf1_", False)
     want_p = torch.cat([flat(want_pf, want_ls), flat(want_vf)]).cpu()
     perr = (d.params.cpu() - want_p).abs().max().item()
-    assert perr < 2e-6, perr
+    errlog("post-step params abs (one update)", perr, 1e-6)
+    assert perr < 1e-6, perr
     norms = d.norms.cpu().numpy()
     assert abs(norms[0] - ref["grad_norm/pf"]) < 1e-4 * ref["grad_norm/pf"] + 1e-6
     assert abs(norms[1] - ref["grad_norm/vf"]) < 1e-4 * ref["grad_norm/vf"] + 1e-6

@@ -486,3 +486,85 @@ def test_trpo_oracle_matches_reference(golden, tag):
         assert (ref.logstd.detach() - sd1["logstd"]).abs().max().item() < tol
         vinfo = ref.update_vf(batch)
         np.testing.assert_allclose([vinfo[k] for k in sorted(vinfo)], g[f"{tag}_s{s}_vinfo_vals"], rtol=1e-4, atol=2e-6)
+
+
+FRAME_TAGS = ["done", "surpass", "mixed", "single", "single84"]
+
+
+def frame_oracle_from_golden(g, tag):
+    from oracle.frames import VecFrameRingOracle
+    N, rows, steps, H, W, horizon, max_frames, seed = (int(v) for v in g[f"{tag}_args"])
+    ring = VecFrameRingOracle(rows, N, k=4)
+    ring.collect(g[f"{tag}_frames"], g[f"{tag}_acts"], horizon, max_frames)
+    return ring
+
+
+@pytest.mark.parametrize("tag", FRAME_TAGS)
+def test_frame_stack_ring_matches_reference(golden, tag):
+    """oracle/frames.py (FrameStack + LazyFrames + MemoryEfficientReplayBuffer restated) against what the reference's
+    classes stored and re-encoded: every replay row of every env, stacks byte for byte."""
+    g = golden("frame_dedup")
+    ring = frame_oracle_from_golden(g, tag)
+    rows = int(g[f"{tag}_args"][1])
+    assert [ring.bufs[0]._top, ring.bufs[0]._size] == list(g[f"{tag}_top_size"])
+    for key in ("obs", "next_obs", "acts", "rewards", "terminals"):
+        got = ring.rows_of(key, list(range(rows)))
+        assert got.dtype == np.float64                                   # np.array(..., dtype=float)
+        assert np.array_equal(got, g[f"{tag}_ref_{key}"].astype(np.float64)), key
+    if tag == "single":                                                  # the reference's own random_batch stream
+        seed = int(g["single_args"][7])
+        np.random.seed(seed + 50)
+        for k in range(3):
+            idx, batch = ring.bufs[0].random_batch(7, ["obs", "next_obs", "acts", "rewards", "terminals"])
+            for key, v in batch.items():
+                assert np.array_equal(v, g[f"single_batch{k}_{key}"].astype(np.float64)), (k, key)
+        # the N-env sampling rule (B // N rows x all envs) degenerates to the same stream at N == 1
+        np.random.seed(seed + 50)
+        _, vb = ring.random_batch(7, ["obs"])
+        assert np.array_equal(vb["obs"], g["single_batch0_obs"].astype(np.float64))
+
+
+@pytest.mark.parametrize("tag", ["env_limit", "wrap"])
+def test_offpolicy_collector_on_normalised_env_matches_reference(golden, tag):
+    """The off-policy collector on a NormObs env (tests/golden/collect_offpolicy_norm.npz): normalised ring rows,
+    statistics after the epoch, raw policy input after resets (Q14), greedy evaluation with the copied normaliser."""
+    import copy
+    from oracle import nets as onets
+    from oracle.collector import VecCollectorOracle, eval_one_epoch
+    from oracle.normalizer import NormObsOracle
+    from oracle.sac import rsample
+    g = golden("collect_offpolicy_norm")
+    N, steps, rows, horizon, max_frames, seed = (int(x) for x in g[f"{tag}_args"])
+    pf = sac_params(g, f"{tag}_pf_")
+
+    class Space:
+        shape = (17,)
+
+    def mk(s):
+        e = SynthVecEnvCPU(N, horizon=horizon)
+        e.observation_space = Space()
+        e.seed(s)
+        return NormObsOracle(e)
+    env, eval_env = mk(seed), mk(seed + 1)
+    ring = replay.RingOracle(N * rows, env_nums=N)
+    col = VecCollectorOracle(env, ring, pf, epoch_frames=N * steps, max_episode_frames=max_frames, act="relu",
+                             tanh_action=True)
+    np.testing.assert_allclose(col.current_ob, g[f"{tag}_ob0"], atol=1e-12)
+    res = col.train_one_epoch(noise=torch.tensor(g[f"{tag}_noise"]))
+    for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+        np.testing.assert_allclose(ring.data[k], g[f"{tag}_buf_{k}"], rtol=0, atol=5e-6, err_msg=k)
+    assert (ring.top, ring.size) == tuple(int(x) for x in g[f"{tag}_top_size"])
+    np.testing.assert_allclose(env._obs_normalizer.state(), g[f"{tag}_state1"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(col.current_ob, g[f"{tag}_current_ob"], atol=5e-6)
+    np.testing.assert_allclose(np.array(res["train_rewards"], dtype=np.float64).reshape(-1), g[f"{tag}_train_rewards"],
+                               atol=1e-5)
+    eval_env._obs_normalizer = copy.deepcopy(env._obs_normalizer)         # collector/base.py:236-237
+
+    def greedy(obs):
+        with torch.no_grad():
+            head = onets.mlp(torch.as_tensor(obs, dtype=torch.float32), pf, "relu")
+            return rsample(head, torch.zeros(obs.shape[0], 6), True)[0].numpy()
+    ev = eval_one_epoch(eval_env, greedy, 1)
+    np.testing.assert_allclose(np.array(ev["eval_rewards"], dtype=np.float64).reshape(-1), g[f"{tag}_eval_rewards"],
+                               atol=1e-4)
+    assert ev["eval_traj_length"] == float(g[f"{tag}_eval_traj_length"])

@@ -63,7 +63,7 @@ def build(g, tag, N, T, horizon, max_frames, B, seed, noise_mode="host"):
 
 @pytest.mark.parametrize("engine", ["fused", "generic"])
 @pytest.mark.parametrize("tag", ["small", "surpass", "mixed"])
-def test_collect_gae_ppo_epoch_matches_reference(golden, tag, engine, monkeypatch):
+def test_collect_gae_ppo_epoch_matches_reference(golden, tag, engine, monkeypatch, errlog):
     """engine = generic: the arbitrary-shape minibatch loop (dense-layer GEMMs + trl_ppo_generic_losses_f32) forced
     onto the benchmark shape, against the same reference outputs as the fused kernels."""
     monkeypatch.setenv("TRL_GENERIC_PPO", "1" if engine == "generic" else "0")
@@ -89,12 +89,18 @@ def test_collect_gae_ppo_epoch_matches_reference(golden, tag, engine, monkeypatc
     assert sorted(logger.infos[0].keys()) == keys and len(logger.infos) == len(g[f"{tag}_infos"])
     got = np.array([[i[k] for k in keys] for i in logger.infos])
     # scalar losses / statistics: rel 1e-4 / abs 1e-5; min/max log-probs are O(100)
-    np.testing.assert_allclose(got, g[f"{tag}_infos"], rtol=2e-4, atol=5e-5)
+    want_i = g[f"{tag}_infos"]
+    errlog("info scalars: max of |got - want| / (1e-5 + 1e-4 |want|)", (np.abs(got - want_i) / (1e-5 + 1e-4 * np.abs(want_i))).max(), 1.0)
+    np.testing.assert_allclose(got, want_i, rtol=1e-4, atol=1e-5)
+    # post-step parameters: the contract is abs 1e-6 after ONE update (checked in test_kernels_gpu.py); this chain takes
+    # len(logger.infos) consecutive Adam steps of 3e-4 each, so round-off differences in the clip coefficient compound
+    perr = 0.0
     for prefix, mod in (("pf1_", pf), ("vf1_", vf)):
         for name, p in mod.state_dict().items():
             want = g[f"{tag}_{prefix}{name.replace('.', '__')}"]
-            err = np.abs(p.cpu().numpy() - want).max()
-            assert err < 2e-6, (name, err)                 # post-step params abs 1e-6 class
+            perr = max(perr, np.abs(p.cpu().numpy() - want).max())
+    errlog("post-epoch params abs (%d updates)" % len(logger.infos), perr, 1e-6)
+    assert perr < 1e-6, perr
     # optimiser state is exposed through the torch optimiser objects
     st = agent.pf_optimizer.state[pf.logstd]
     assert float(st["step"]) == len(logger.infos) and st["exp_avg"].abs().sum() > 0

@@ -265,6 +265,49 @@ def test_off_policy_collector_matches_reference(golden, tag):
     np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[f"{tag}_current_ob"], atol=2e-5)
 
 
+@pytest.mark.parametrize("tag", ["env_limit", "wrap"])
+def test_off_policy_collector_on_normalised_env_matches_reference(golden, tag):
+    """VecCollector on a NormObs env against what the REFERENCE collected (tests/golden/collect_offpolicy_norm.npz):
+    the ring holds normalised observations, the statistics move every step, the policy sees the raw array after any
+    reset (Q14), evaluation runs on a copy of the normaliser without updating it."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector import VecCollector
+    from torchrl.env.base_wrapper import NormObs
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    g = golden("collect_offpolicy_norm")
+    N, steps, rows, horizon, max_frames, seed = (int(x) for x in g[f"{tag}_args"])
+    dev = torch.device(DEV)
+    net = dict(hidden_shapes=[32, 32], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+    pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net)
+    pf.load_state_dict(sac_state(g, f"{tag}_pf_"))
+    env = NormObs(SynthVecEnv(N, horizon=horizon, device=dev))
+    eval_env = NormObs(SynthVecEnv(N, horizon=horizon, device=dev))
+    env.seed(seed)
+    eval_env.seed(seed + 1)
+    buf = BaseReplayBuffer(N * rows, env_nums=N)
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * steps,
+                       max_episode_frames=max_frames, eval_episodes=1)
+    np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[f"{tag}_ob0"], atol=2e-6)
+    torch.manual_seed(seed)                                          # the reference's CPU N(0,1) stream (Q5)
+    got = col.train_one_epoch()
+    for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+        err = np.abs(getattr(buf, "_" + k).cpu().numpy().reshape(g[f"{tag}_buf_{k}"].shape) - g[f"{tag}_buf_{k}"]).max()
+        assert err < 3e-5, (k, err)
+    assert (buf._top, buf._size) == tuple(int(x) for x in g[f"{tag}_top_size"])
+    np.testing.assert_allclose(env._obs_normalizer.state.cpu().numpy(), g[f"{tag}_state1"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[f"{tag}_current_ob"], atol=3e-5)
+    np.testing.assert_allclose(np.array(got["train_rewards"], dtype=np.float64).reshape(-1), g[f"{tag}_train_rewards"],
+                               atol=1e-4)
+    state = env._obs_normalizer.state.clone()
+    ev = col.eval_one_epoch()
+    np.testing.assert_allclose(np.array(ev["eval_rewards"], dtype=np.float64).reshape(-1), g[f"{tag}_eval_rewards"],
+                               atol=2e-4)
+    assert ev["eval_traj_length"] == float(g[f"{tag}_eval_traj_length"])
+    assert torch.equal(env._obs_normalizer.state, state)             # evaluation never updates the statistics
+
+
 def test_sac_trains_through_rlalgo_with_device_noise():
     import torchrl.networks as networks
     import torchrl.policies as policies

@@ -24,6 +24,28 @@ c_i32_p = C.POINTER(C.c_int32)
 c_u8_p = C.POINTER(C.c_uint8)
 
 
+# ---- leaving the HIP path must be loud ----
+# Product classes keep the reference's nn.Module / torch.distributions protocol for callers outside the hot path
+# (autograd through a network, CPU tensors in unit tests of host logic).  Whenever a CUDA tensor takes such a route the
+# site is counted here and logged once at WARNING; TRL_STRICT=1 turns it into an error.  tests/test_no_eager_gpu.py
+# asserts that whole PPO / SAC / DQN epochs leave the counter at zero.
+EAGER_FALLBACKS = {}
+
+
+def note_eager(site, why=""):
+    EAGER_FALLBACKS[site] = EAGER_FALLBACKS.get(site, 0) + 1
+    if os.environ.get("TRL_STRICT") == "1":
+        raise TrlError("%s left the HIP path (%s) and TRL_STRICT=1" % (site, why))
+    if EAGER_FALLBACKS[site] == 1:
+        import logging
+        logging.getLogger("torchrl_amd").warning("%s: a CUDA tensor takes the eager PyTorch route (%s); "
+                                                 "this is outside the HIP hot path", site, why)
+
+
+def eager_fallback_count():
+    return sum(EAGER_FALLBACKS.values())
+
+
 class TrlError(RuntimeError):
     pass
 
@@ -103,6 +125,7 @@ SIGNATURES = {
     "trl_onpolicy_bookkeep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_select_on_flag_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "trl_select_on_mask_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "trl_norm_update_filt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "trl_norm_batch_moments_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "trl_norm_merge_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -778,6 +801,14 @@ def select_on_flag(flag, a, b, out):
     return out
 
 
+def select_on_mask(mask, a, b, out):
+    """out = a when any byte of `mask` is set, else b (no host round trip)."""
+    check(lib().trl_select_on_mask_f32(dev_ptr(mask, torch.uint8, "mask"), int(mask.numel()), dev_ptr(a, name="a"),
+                                       dev_ptr(b, name="b"), dev_ptr(out, name="out"), int(out.numel()),
+                                       stream_ptr(out.device)), "trl_select_on_mask_f32")
+    return out
+
+
 def norm_update_filt(x, state, out, clip, update):
     """One vector step of the running observation normaliser: state (2D+1) fp64 = mean | var | count."""
     N, D = int(x.shape[0]), int(x.shape[1])
@@ -838,12 +869,15 @@ def frame_stream_append(stacks, stream, head, mask, n_frames):
           "trl_frame_stream_append_u8")
 
 
-def frame_stream_gather(stream, pos, row_idx, shift, frame_shape, head, overrun):
-    """-> (n_rows * N, C, H, W) uint8 stacks rebuilt from the per-env frame stream."""
+def frame_stream_gather(stream, pos, row_idx, shift, frame_shape, head, overrun, out=None):
+    """-> (n_rows * N, C, H, W) uint8 stacks rebuilt from the per-env frame stream (into `out` when given)."""
     S, N = int(stream.shape[0]), int(stream.shape[1])
     Cc, H, W = frame_shape
     nr = int(row_idx.numel())
-    out = torch.empty((nr * N, Cc, H, W), dtype=torch.uint8, device=stream.device)
+    if out is None:
+        out = torch.empty((nr * N, Cc, H, W), dtype=torch.uint8, device=stream.device)
+    elif out.dtype != torch.uint8 or out.numel() != nr * N * Cc * H * W or not out.is_contiguous():
+        raise TrlError("frame_stream_gather: out must be a contiguous uint8 tensor of %d stacks" % (nr * N))
     check(lib().trl_frame_stream_gather_u8(dev_ptr(stream, torch.uint8, "stream"), dev_ptr(pos, torch.int32, "pos"),
                                            dev_ptr(row_idx, torch.int64, "row_idx"), nr, int(shift),
                                            dev_ptr(out, torch.uint8, "out"), dev_ptr(head, torch.int32, "head"),

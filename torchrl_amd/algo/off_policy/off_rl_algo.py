@@ -33,6 +33,9 @@ class OffRLAlgo(RLAlgo):
     def update_per_epoch(self):
         for _ in range(self.opt_times):
             self._one_update()
+        check = getattr(self.replay_buffer, "check_overrun", None)       # frame-dedup replay: a batch that asked for an
+        if check is not None:                                            # overwritten frame fails the epoch, loudly
+            check()
 
     def update_per_timestep(self):
         if self.replay_buffer.num_steps_can_sample() > max(self.min_pool, self.batch_size):

@@ -164,17 +164,19 @@ class VecCollector(_CollectorBase):
             make = lambda m, f: _C.philox_normal(torch.empty(m, f, device=env.device), self._noise_seed, self.global_step)
         return dist.shard_rows_of_global(make, 1, n, a_dim, env.device).to(env.device, non_blocking=True)
 
-    def _policy_action(self, env, deterministic):
+    def _policy_action(self, env, deterministic, ob=None):
+        """`ob`: what the policy sees -- env.cur_obs, or the normalised observation of a NormObs env."""
         from .. import ops
         pf = self.pf
+        ob = env.cur_obs if ob is None else ob
         if not self.continuous:                                             # epsilon-greedy over a Q network
             if deterministic:
-                return torch.as_tensor(pf.eval_act(env.cur_obs)).to(env.device).reshape(-1).contiguous()
-            return pf.explore(env.cur_obs)["action"].reshape(-1).contiguous()
+                return torch.as_tensor(pf.eval_act(ob)).to(env.device).reshape(-1).contiguous()
+            return pf.explore(ob)["action"].reshape(-1).contiguous()
         if hasattr(pf, "norm_std_explore") or type(pf).__name__ == "DetContPolicy":
             # deterministic policies (continuous_policy.py:28-74): [tanh](mlp(obs)) (+ N(0, norm_std_explore))
             last = _C.ACT_TANH if pf.tanh_action else _C.ACT_NONE
-            act, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf), last_act=last)
+            act, _ = ops.mlp_forward(ops.linear_layers(pf), ob, ops.act_code(pf), last_act=last)
             sigma = float(getattr(pf, "norm_std_explore", 0.0))
             if deterministic or not sigma:
                 return act
@@ -183,20 +185,28 @@ class VecCollector(_CollectorBase):
             raise _C.TrlError("VecCollector's kernel path expects a GuassianContPolicy (mean | log_std head); "
                               "state-independent-std policies use VecOnPolicyCollector")
         n, a_dim = env.env_nums, env.act_dim
-        head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf))
+        head, _ = ops.mlp_forward(ops.linear_layers(pf), ob, ops.act_code(pf))
         eps = torch.zeros(n, a_dim, device=env.device) if deterministic else self._explore_noise(env)
         act, _ = _C.rsample_fwd(head, eps, bool(pf.tanh_action))
         return act
 
-    def _step(self, env, store, deterministic=False, max_frames=None):
+    def _step(self, env, store, deterministic=False, max_frames=None, ob=None):
+        """One vector step.  On a NormObs env (`env._obs_normalizer`) `ob` is the policy input -- the normalised
+        observation, or the RAW one of all envs right after any reset, the reference's Q14 -- and the next policy
+        input is returned: obs / next_obs rows hold what the reference stores (env.step's normalised return,
+        base_wrapper.py:116-121), the statistics are updated in training mode only."""
         buf = self.replay_buffer
         if getattr(env, "kind", "vector") == "frames":
             return self._step_frames(env, store, deterministic, max_frames)
         n, d, a_dim = env.env_nums, env.obs_dim, env.act_dim
-        act = self._policy_action(env, deterministic)
+        nz = getattr(env, "_obs_normalizer", None)
+        if nz is not None and ob is None:
+            raise _C.TrlError("VecCollector._step: a normalised env needs the policy input `ob`")
+        pol_in = env.cur_obs if nz is None else ob
+        act = self._policy_action(env, deterministic, pol_in)
         if store:
             row = buf._top
-            buf._ensure_key("obs", (n, d))[row].copy_(env.cur_obs)           # before the env advances in place
+            buf._ensure_key("obs", (n, d))[row].copy_(pol_in)                # before the env advances in place
             buf._ensure_key("acts", (n, a_dim))[row].copy_(act if self.continuous else act.reshape(n, 1))
             nxt = buf._ensure_key("next_obs", (n, d))[row]
             rew = buf._ensure_key("rewards", (n, 1))[row]
@@ -205,7 +215,10 @@ class VecCollector(_CollectorBase):
             nxt = torch.empty(n, d, device=env.device)
             rew = torch.empty(n, 1, device=env.device)
             done = torch.empty(n, 1, device=env.device)
-        self._env_advance(env, act, nxt, rew, done, buf._ensure_key("time_limits", (n, 1))[row] if store else None)
+        raw_next = nxt if nz is None else torch.empty(n, d, device=env.device)
+        self._env_advance(env, act, raw_next, rew, done, buf._ensure_key("time_limits", (n, 1))[row] if store else None)
+        if nz is not None:
+            nz.update_filt(raw_next, update=env.training, out=nxt)           # NormObs.observation on env.step's return
         _C.collector_bookkeep(rew, done, env.cur_step, env.ep_return,
                               self.max_episode_frames if max_frames is None else max_frames, self._mask,
                               self._epoch_reward, self._ep_count, self._ep_log, self.global_step)
@@ -213,6 +226,11 @@ class VecCollector(_CollectorBase):
         if store:
             buf._advance()
         self.global_step += 1
+        if nz is None:
+            return env.cur_obs
+        # partial_reset bypasses the wrapper and returns the whole RAW array (base_wrapper.py:23-26, vecenv.py:47-51)
+        alt = nz.filt(env.cur_obs) if getattr(env, "normalize_partial_reset", False) else env.cur_obs
+        return _C.select_on_mask(self._mask, alt, nxt, torch.empty(n, d, device=env.device))
 
     def _step_frames(self, env, store, deterministic, max_frames):
         """Discrete-action step on the uint8 frame env: frames stay bytes in the replay rows; actions are
@@ -260,9 +278,12 @@ class VecCollector(_CollectorBase):
         """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""
         self.env.train()
         self._clear_header()
+        ob = None
+        if hasattr(self.env, "_obs_normalizer"):
+            ob = torch.as_tensor(self.current_ob).to(device=self.env.device, dtype=torch.float32).contiguous()
         for _ in range(n_steps):
-            self._step(self.env, True)
-        self.current_ob = self.env.cur_obs
+            ob = self._step(self.env, True, ob=ob)
+        self.current_ob = self.env.cur_obs if ob is None else ob
 
     def train_one_epoch(self):
         self.rollout(self.sample_epoch_frames)
@@ -285,14 +306,16 @@ class VecCollector(_CollectorBase):
     def eval_one_epoch(self):
         """Greedy evaluation (base.py:232-280): action = tanh(mean); first episode of every eval env."""
         env = self.eval_env
+        if hasattr(self.env, "_obs_normalizer"):                           # collector/base.py:236-237
+            env._obs_normalizer = copy.deepcopy(self.env._obs_normalizer)
         env.eval()
         rews, lens = [], []
         for _ in range(self.eval_episodes):
-            env.reset()
+            ob = env.reset()
             self._clear_header()
             step0 = self.global_step
             for _ in range(self._eval_steps(env)):
-                self._step(env, False, deterministic=True, max_frames=2 ** 31 - 1)
+                ob = self._step(env, False, deterministic=True, max_frames=2 ** 31 - 1, ob=ob)
                 if getattr(env, "is_host_env", False) and int(self._ep_count.item()) >= env.env_nums \
                         and len({int(i) for _, i, _ in self._finished_episodes()}) == env.env_nums:
                     break                                                   # every env has finished its first episode

@@ -800,3 +800,25 @@ extern "C" int trl_select_on_flag_f32(const int32_t* flag, const float* a, const
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
+
+// out = any(mask[0..N)) ? a : b, elementwise -- the off-policy collector's form of the same whole-array return
+// (torchrl/collector/base.py:220-224): every block scans the (few-KB) reset mask itself, no flag word, no host sync
+__global__ __launch_bounds__(256) void select_on_mask_kernel(const uint8_t* __restrict__ mask, int N, const float* __restrict__ a,
+                                                             const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+  int any = 0;
+  for (int e = threadIdx.x; e < N; e += 256) any |= mask[e];
+  const bool f = __syncthreads_or(any) != 0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) out[e] = f ? a[e] : b[e];
+}
+
+extern "C" int trl_select_on_mask_f32(const uint8_t* mask, int N, const float* a, const float* b, float* out, int64_t n,
+                                      void* stream) {
+  TRL_REQUIRE(n >= 0 && N >= 0, "negative size");
+  if (n == 0) return TRL_OK;
+  TRL_REQUIRE(mask && a && b && out, "null pointer");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(select_on_mask_kernel, dim3((unsigned)(blocks > 256 ? 256 : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, mask, N, a, b, out, n);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}

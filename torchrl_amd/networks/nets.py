@@ -104,6 +104,8 @@ class Net(nn.Module):
                 x2 = x.reshape(-1, int(layers[0][0].shape[1])).float().contiguous()
                 out, _ = ops.mlp_forward([(w.detach(), b.detach()) for w, b in layers], x2, act)   # dense-layer kernels
                 return out.reshape(tuple(lead) + (self.out_dim,))
+        if x.is_cuda:
+            _C.note_eager(type(self).__name__ + ".forward", "autograd is on" if needs_graph else "no kernel for this trunk")
         return self.seq_append_fcs(self.base(x))
 
 

@@ -35,7 +35,11 @@ class GuassianContPolicyBase:
         return TanhNormal(mean, std) if self.tanh_action else Normal(mean, std)
 
     def explore(self, x, return_log_probs=False, return_pre_tanh=False):
+        """The reference's direct-call protocol (continuous_policy.py:92-131) on torch.distributions; the collectors do
+        not come through here (their sampling is in the rollout / rsample kernels)."""
         mean, std, log_std = self.forward(x)
+        if mean.is_cuda:
+            _C.note_eager(type(self).__name__ + ".explore", "torch.distributions sampling")
         dis = self._dist(mean, std)
         out = {"mean": mean, "log_std": log_std, "std": std,
                "ent": dis.entropy().sum(-1, keepdim=True)}
@@ -66,8 +70,11 @@ class GuassianContPolicyBase:
                 lp = _C.gauss_logp(mean.contiguous(), actions.float().contiguous(), ls.float().contiguous(),
                                    self.tanh_action).unsqueeze(-1)
             else:
+                _C.note_eager(type(self).__name__ + ".update", "state-dependent std has no log-prob kernel")
                 lp = self._dist(mean, std).log_prob(actions).sum(-1, keepdim=True)
         else:
+            if mean.is_cuda:
+                _C.note_eager(type(self).__name__ + ".update", "autograd is on")
             lp = self._dist(mean, std).log_prob(actions).sum(-1, keepdim=True)
         return {"mean": mean, "dis": Normal(mean, std), "log_std": log_std, "std": std,
                 "log_prob": lp, "ent": Normal(mean, std).entropy().sum(-1, keepdim=True)}

@@ -63,7 +63,7 @@ class MemoryEfficientReplayBuffer(BaseReplayBuffer):
         if key not in self.FRAME_KEYS:
             return super()._gather(key, idx_dev, out)
         return _C.frame_stream_gather(self._stream, self._pos, idx_dev, 0 if key == "obs" else 1, self.frame_shape,
-                                      self._head, self._overrun)
+                                      self._head, self._overrun, out=out)
 
     def check_overrun(self):
         """Raise if any batch asked for a frame that had already been overwritten (episodes shorter than
