@@ -323,9 +323,6 @@ def main():
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        # Graph replay of the multi-rank launch sequence (RCCL all-reduces inside the HIP graph) unless
-        # TRL_GRAPH_COLLECTIVES says otherwise -- but only after child processes have shown that it works here.
-        probed = probe_graph_collectives() if "TRL_GRAPH_COLLECTIVES" not in os.environ else None
         torch.cuda.set_device(local)
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
@@ -333,11 +330,20 @@ def main():
         guard = threading.Timer(900.0, lambda: os._exit(3))           # a wedged collective must not outlive the run
         guard.daemon = True
         guard.start()
-        if probed is not None:
+        # The library's own communicator (include/trl_hip.h, trl_comm_*): RCCL for bandwidth-class messages plus
+        # peer-mapped xGMI buffers for the 44 KB gradient and the statistics vectors.  With the peers up (self-checked
+        # on every rank) the multi-rank sequence consists of plain kernel launches and is graph-replayed like the
+        # single-process one.  Otherwise: RCCL all-reduces, captured into the graph only after child processes have
+        # shown that graph-captured collectives work on this node (TRL_GRAPH_COLLECTIVES overrides the probe).
+        from torchrl_amd import dist as _dist
+        peers = _dist.init_comm(torch.device("cuda", local))
+        log("peer transport: %s" % ("up (self-check passed on every rank)" if peers else "unavailable -> RCCL all-reduces"))
+        if not peers and "TRL_GRAPH_COLLECTIVES" not in os.environ:
+            probed = probe_graph_collectives()
             flag = torch.tensor([1.0 if probed else 0.0], device=torch.device("cuda", local))
             td.all_reduce(flag, op=td.ReduceOp.MIN)                    # every rank takes the same route
             os.environ["TRL_GRAPH_COLLECTIVES"] = "1" if flag.item() == 1.0 else "0"
-            log("graph-captured collectives: %s" % ("on" if flag.item() == 1.0 else "off (probe failed)"))
+            log("graph-captured RCCL collectives: %s" % ("on" if flag.item() == 1.0 else "off (probe failed)"))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -364,7 +370,7 @@ def main():
     # HIP events around every launch of the dominant kernel, on the stream it is launched on.  One process: the
     # minibatch loop of the timed region replays a captured HIP graph, whose nodes cannot be bracketed by
     # events, so the same kernel on the same data is timed in a follow-up pass right after the timed region.
-    graph_mode = (not dist.collectives_active() or os.environ.get("TRL_GRAPH_COLLECTIVES") == "1") \
+    graph_mode = (not dist.collectives_active() or dist.peer_ready() or os.environ.get("TRL_GRAPH_COLLECTIVES") == "1") \
         and os.environ.get("TRL_NO_GRAPH") != "1"
     probes = []
     eng.probe = None if graph_mode else probes
@@ -422,7 +428,9 @@ def main():
                    "envs_per_gpu": N_PER_GPU, "rollout_steps": T, "batch_per_gpu": BATCH_PER_GPU,
                    "opt_epochs": OPT_EPOCHS, "exploration_noise": "device Philox4x32-10",
                    "setup_iterations": setup,
-                   "parallelism": "env-sharded dp%d, RCCL grad all-reduce" % world},
+                   "parallelism": "env-sharded dp%d, gradient SUM %s" % (
+                       world, "inside the fold/clip/Adam launch over peer-mapped xGMI buffers" if dist.peer_ready()
+                       else ("by RCCL all-reduce" if dist.collectives_active() else "not needed (one rank)"))},
         "roofline": {"bound": "mfma", "kernel": "ppo_grad_wave_kernel<17,64,6,tanh>", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": pmc_traffic(), "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
@@ -442,6 +450,8 @@ def main():
 
 def _shutdown_dist():
     import torch.distributed as td
+    from torchrl_amd import dist as _dist
+    _dist.destroy_comm()
     if td.is_available() and td.is_initialized():
         td.destroy_process_group()
 

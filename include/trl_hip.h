@@ -301,6 +301,47 @@ int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, in
                             int D, int H, int A, float* grads, double* info,
                             const trl_adam_t* adam, float* workspace, void* stream);
 
+/* --- C1 / C2 / C3: collectives of the multi-GPU path ---------------
+ * The reference has no distributed backend; with envs sharded by index over one process per GPU
+ * these are the calls its update loop makes between backward and clip_grad_norm_
+ * (torchrl/algo/on_policy/ppo.py:72-74, 117-119 -- the clip sees the whole-minibatch gradient; SAC:
+ * twin_sac_q.py:166-185) and around the advantage statistics (ppo.py:141-147).
+ * trl_comm_t is the one opaque object the library owns.  Two transports:
+ *   RCCL       ncclAllReduce on the caller's stream (loaded with dlopen; bandwidth-class messages);
+ *   peer       8-byte {value, epoch} granules pushed into peer-mapped (hipIpc / xGMI) uncached buffers and summed
+ *              in rank order by every rank: one kernel, no separate barrier, identical results on all ranks,
+ *              capturable into a HIP graph like any other launch (latency-class messages).
+ * Set-up (host, once): rank 0 calls trl_comm_get_unique_id and the caller's rendezvous distributes the
+ * trl_comm_unique_id_bytes() bytes; every rank calls trl_comm_init (unique_id NULL = no RCCL communicator),
+ * trl_comm_peer_export, all-gathers the trl_comm_peer_handle_bytes()-byte handles and calls trl_comm_peer_open.
+ * All ranks must issue the same sequence of collective calls.  A peer wait that times out (a rank is missing)
+ * does not hang the GPU: it sets a flag that trl_comm_error() returns (and clears). */
+typedef struct trl_comm trl_comm_t;
+int trl_comm_unique_id_bytes(void);
+int trl_comm_peer_handle_bytes(void);
+int trl_comm_max_ranks(void);
+int trl_comm_get_unique_id(void* id_out);
+int trl_comm_init(trl_comm_t** comm, int rank, int world, const void* unique_id);
+int trl_comm_peer_export(trl_comm_t* comm, void* handle_out);
+int trl_comm_peer_open(trl_comm_t* comm, const void* handles);
+int trl_comm_peer_ready(const trl_comm_t* comm);
+int trl_comm_peer_enable(trl_comm_t* comm, int on);   /* 0 after a failed self-check: everything takes the RCCL route */
+int trl_comm_has_rccl(const trl_comm_t* comm);
+int trl_comm_error(trl_comm_t* comm);
+int trl_comm_destroy(trl_comm_t* comm);
+/* buf <- SUM over ranks, in place, n floats (C1).  Peer transport up to 4096 floats, RCCL beyond. */
+int trl_allreduce_sum_f32(float* buf, int64_t n, trl_comm_t* comm, void* stream);
+/* buf <- reduction over ranks, in place, n doubles (C2 / C3): element i is MAXed when bit (i % period) of
+ * max_mask is set, SUMmed otherwise (the {sum, sum of squares, max, -min} rows of trl_adv_stats_f64 are
+ * period 4, max_mask 0xC).  Peer transport (n <= 2048); a pure SUM falls back to RCCL. */
+int trl_allreduce_f64(double* buf, int64_t n, int period, uint64_t max_mask, trl_comm_t* comm, void* stream);
+/* trl_ppo_reduce_adam_f32 with the gradient SUM over ranks between the fold and the clip, in the same launch:
+ * per-sample gradients already carry 1 / n_global, every rank ends with bit-identical parameters.  The step
+ * count / learning rates come from the workspace header (adam->device_state = 1). */
+int trl_ppo_reduce_adam_xrank_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
+                                  int D, int H, int A, float* grads, double* info,
+                                  const trl_adam_t* adam, float* workspace, trl_comm_t* comm, void* stream);
+
 /* --- K10 (generic): dense layers of any shape on fp32 MFMA -----------------
  * replaces nn.Linear + activation forward/backward (torchrl/networks/base.py:30-44,
  * nets.py:34-52) for networks the fused PPO kernels are not instantiated for

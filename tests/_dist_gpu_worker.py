@@ -22,11 +22,16 @@ class Log:
     def finish(self): pass
 
 
+def _lib():
+    from torchrl_amd import _C
+    return _C.lib()
+
+
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else ""
     obs_norm = mode == "obs_norm"
-    if world > 1 or mode == "nccl_graph":
+    if (world > 1 or mode == "nccl_graph") and mode != "nccl_peer":
         import torch.distributed as td
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         if mode == "nccl_graph":           # one rank, RCCL backend, collectives forced on (env set by the test)
@@ -34,6 +39,20 @@ def main():
             td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         else:
             td.init_process_group("gloo", rank=rank, world_size=world)
+    peer = False
+    if mode in ("peer", "nccl_peer", "nccl_graph"):
+        # the library's own communicator (include/trl_hip.h: trl_comm_*): peer-mapped buffers between the two processes
+        # sharing cuda:0 (no RCCL communicator: it refuses two ranks per device), or RCCL + peers on a one-rank group
+        if mode == "nccl_peer":
+            torch.cuda.set_device(0)
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+            import torch.distributed as td
+            td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from torchrl_amd import dist as trl_dist
+        if mode != "nccl_graph":
+            peer = trl_dist.init_comm(torch.device("cuda:0"), use_rccl=(mode == "nccl_peer"))
+            assert peer, "peer transport did not come up"
+            assert bool(_lib().trl_comm_has_rccl(trl_dist.comm_handle())) == (mode == "nccl_peer")
     import torchrl.networks as networks
     import torchrl.policies as policies
     from torchrl.algo import A2C, PPO, TRPO, VMPO
@@ -78,8 +97,12 @@ def main():
     np.savez(out, pf=pf.flat_params().cpu().numpy(), vf=vf.flat_params().cpu().numpy(), keys=np.array(keys),
              infos=np.array([[i[k] for k in keys] for i in logger.infos if sorted(i) == keys]),
              obs=buf._obs.cpu().numpy(), rewards=buf._rewards.cpu().numpy(),
-             norm_state=env._obs_normalizer.state.cpu().numpy() if obs_norm else np.zeros(1))
-    if world > 1 or mode == "nccl_graph":
+             norm_state=env._obs_normalizer.state.cpu().numpy() if obs_norm else np.zeros(1),
+             peer=np.array(int(peer)), graph=np.array(int(getattr(agent.engine(), "_graph", None) is not None)))
+    if world > 1 or mode in ("nccl_graph", "nccl_peer"):
+        import torch.distributed as td
+        from torchrl_amd import dist as trl_dist
+        trl_dist.destroy_comm()
         td.barrier()
         td.destroy_process_group()
 

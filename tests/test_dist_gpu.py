@@ -89,6 +89,33 @@ def test_rccl_sequence_replays_as_a_graph(tmp_path):
     np.testing.assert_allclose(forced["infos"], single["infos"], rtol=2e-4, atol=2e-5)
 
 
+def test_two_ranks_over_the_peer_transport_replay_a_graph(tmp_path):
+    """The library's own communicator (trl_comm_*, include/trl_hip.h) between two processes sharing cuda:0: peer-mapped
+    hipIpc buffers, the gradient SUM inside the fold / clip / Adam launch (trl_ppo_reduce_adam_xrank_f32), the
+    statistics through the one-kernel all-reduce -- and the whole sequence graph-replayed from the third epoch on.  Same
+    bar as the gloo run: bit-identical parameters across ranks, the single-process run up to summation order."""
+    (single,) = _run(1, tmp_path)
+    r0, r1 = _run(2, tmp_path, extra=("peer",))
+    assert int(r0["peer"]) == 1 and int(r1["peer"]) == 1 and int(r0["graph"]) == 1
+    np.testing.assert_allclose(np.concatenate([r0["obs"], r1["obs"]], axis=1), single["obs"], atol=1e-6)
+    assert np.array_equal(r0["pf"], r1["pf"]) and np.array_equal(r0["vf"], r1["vf"])
+    np.testing.assert_allclose(r0["pf"], single["pf"], atol=2e-6)
+    np.testing.assert_allclose(r0["vf"], single["vf"], atol=2e-6)
+    np.testing.assert_allclose(r0["infos"], r1["infos"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(r0["infos"], single["infos"], rtol=2e-4, atol=2e-5)
+
+
+def test_one_rank_rccl_communicator_with_peer_transport(tmp_path):
+    """World size 1 on the nccl backend with the collectives forced on: ncclCommInitRank through the C ABI, the peer
+    buffer mapped onto itself, the cross-rank launch sequence graph-replayed; it must reproduce the plain run."""
+    (single,) = _run(1, tmp_path)
+    (forced,) = _run(1, tmp_path, extra=("nccl_peer",), env={"TRL_FORCE_COLLECTIVES": "1"})
+    assert int(forced["peer"]) == 1 and int(forced["graph"]) == 1
+    np.testing.assert_allclose(forced["pf"], single["pf"], atol=2e-6)
+    np.testing.assert_allclose(forced["vf"], single["vf"], atol=2e-6)
+    np.testing.assert_allclose(forced["infos"], single["infos"], rtol=2e-4, atol=2e-5)
+
+
 def test_two_ranks_share_the_observation_normaliser(tmp_path):
     """obs_norm with env shards: every step the ranks pool their batch moments (all-reduce) before the Chan merge, so
     both hold the statistics of ALL envs -- the single process keeps them inside the cooperative rollout kernel."""

@@ -125,6 +125,22 @@ SIGNATURES = {
     "trl_onpolicy_bookkeep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_select_on_flag_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "trl_comm_unique_id_bytes": (C.c_int, []),
+    "trl_comm_peer_handle_bytes": (C.c_int, []),
+    "trl_comm_max_ranks": (C.c_int, []),
+    "trl_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "trl_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
+    "trl_comm_peer_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "trl_comm_peer_open": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "trl_comm_peer_ready": (C.c_int, [C.c_void_p]),
+    "trl_comm_peer_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "trl_comm_has_rccl": (C.c_int, [C.c_void_p]),
+    "trl_comm_error": (C.c_int, [C.c_void_p]),
+    "trl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "trl_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "trl_allreduce_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "trl_ppo_reduce_adam_xrank_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_select_on_mask_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "trl_norm_update_filt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "trl_norm_batch_moments_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -59,28 +59,38 @@ class PPO(A2C):
     # ---- epoch ----
     def _fill_old_logp(self):
         """log pi_old of every stored (obs, act) under target_pf (ppo.py:54-56), computed once per
-        epoch; skipped when the collector kernel already wrote it with the same parameters."""
+        epoch; update_per_epoch skips it when the collector kernel already wrote it with the same parameters."""
         buf = self.replay_buffer
-        if getattr(buf, "_old_logp_fresh", False):
-            buf._old_logp_fresh = False
-            return
         rows, n = buf._max_replay_buffer_size, buf.env_nums
-        with torch.no_grad():
-            out = self.target_pf.update(buf._obs.reshape(rows * n, -1), buf._acts.reshape(rows * n, -1))
-        buf._ensure_key("old_logp", (n, 1)).copy_(out["log_prob"].reshape(rows, n, 1))
+        tgt = self.target_pf
+        with torch.no_grad():                                          # kernels only: MLP forward + trl_gauss_logp_f32
+            mean, _, log_std = tgt.forward(buf._obs.reshape(rows * n, -1))
+            _C.gauss_logp(mean.contiguous(), buf._acts.reshape(rows * n, -1), log_std.float().contiguous(),
+                          bool(tgt.tanh_action), out=buf._ensure_key("old_logp", (n, 1)).view(rows * n))
 
     def update_per_epoch(self):
-        self.process_epoch_samples()
+        """ppo.py:27-39.  Everything the host decides -- the linear LR decay and the `opt_epochs` permutations of the
+        time rows (global numpy stream, one per pass) -- is done first; everything on the device -- last value + GAE
+        scan (on_rl_algo.py:22-33), `target_pf <- pf`, log pi_old, then all minibatch updates -- is handed to the engine
+        as ONE launch sequence, which a single process replays as one HIP graph from its third visit on."""
         atu.update_linear_schedule(self.pf_optimizer, self.current_epoch, self.num_epochs, self.plr)
         atu.update_linear_schedule(self.vf_optimizer, self.current_epoch, self.num_epochs, self.vlr)
-        self.engine().sync_target_pf()                                 # target_pf <- pf (utils.py:23-26), one D2D copy
-        self._fill_old_logp()
         buf = self.replay_buffer
+        buf._scan_inputs()                                             # advs / estimate_returns exist before they are named
+        buf._ensure_key("old_logp", (buf.env_nums, 1))
         passes = [buf.epoch_row_indices(self.batch_size, self.shuffle) for _ in range(self.opt_epochs)]
         row_idx = np.concatenate(passes, axis=0)                       # (E * n_mb, B // N)
         tensors = {"obs": buf._obs, "acts": buf._acts, "advs": buf._advs, "rets": buf._estimate_returns,
                    "old_values": buf._values, "old_logp": buf._old_logp}
-        infos = self.engine().run(tensors, row_idx, buf.env_nums)
+        fresh = bool(getattr(buf, "_old_logp_fresh", False))          # the collector kernel wrote log pi_old already
+        buf._old_logp_fresh = False
+
+        def device_prologue():
+            self.process_epoch_samples()
+            self.engine().sync_target_pf()                             # target_pf <- pf (utils.py:23-26), one D2D copy
+            if not fresh:
+                self._fill_old_logp()
+        infos = self.engine().run(tensors, row_idx, buf.env_nums, pre=device_prologue, pre_key=(fresh, self.gae))
         self.training_update_num += len(infos)
         for info in infos:
             self.logger.add_update_info(info)
@@ -171,14 +181,17 @@ class _FusedPPO:
         return n_wg, n_pf
 
     def _buffers(self, K, rows_mb):
-        """Persistent per-shape device buffers: minibatch row indices and the statistics block
-        raw (K,4) f64 | info (K,24) f64 | norms (K,2) f32 (one memset, one D2H per run; stable addresses
-        so that a captured launch sequence can be replayed)."""
+        """Persistent per-shape buffers: minibatch row indices and the statistics block
+        raw (K,4) f64 | info (K,24) f64 | norms (K,2) f32 on the device (stable addresses, so that a captured launch
+        sequence can be replayed), plus their page-locked host twins: the per-epoch H2D of the indices and D2H of the
+        statistics are asynchronous copies, the only host wait of an update is the one at its end."""
         key = (K, rows_mb)
         if getattr(self, "_buf_key", None) != key:
             self._buf_key = key
             self._idx_buf = torch.zeros(K * rows_mb, dtype=torch.int64, device=self.dev)
             self._stats = torch.zeros(29 * K, dtype=torch.float64, device=self.dev)
+            self._idx_host = torch.zeros(K * rows_mb, dtype=torch.int64).pin_memory()
+            self._stats_host = torch.zeros(29 * K, dtype=torch.float64).pin_memory()
             self._graph = None
         return self._idx_buf, self._stats
 
@@ -186,14 +199,20 @@ class _FusedPPO:
         hyper = (float(lr_pf), float(lr_vf))
         if getattr(self, "_hyper", None) != hyper:
             self._hyper = hyper
-            self.red_ws[2:4].copy_(torch.tensor(hyper, dtype=torch.float32), non_blocking=True)
+            if getattr(self, "_hyper_host", None) is None:
+                self._hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+            self._hyper_host[0], self._hyper_host[1] = hyper
+            self.red_ws[2:4].copy_(self._hyper_host, non_blocking=True)
 
-    def run(self, t, row_idx, N):
+    def run(self, t, row_idx, N, pre=None, pre_key=None):
         """t: dict of (rows, N, feat) device tensors; row_idx: (K, rows_mb) host int64.
         Runs K minibatch updates back to back; returns K info dicts (one host sync at the end).
-        Single process: the K x {gradient kernel, fused reduce/clip/Adam} launches are captured into a HIP
-        graph the first time a shape is seen and replayed afterwards (dependent launches start ~2.5 us earlier
-        each inside a graph on this machine); the Adam step count and learning rates live on the device so no
+        `pre` (optional): a callable that enqueues device work which must precede the updates (PPO: last value + GAE
+        scan, target_pf copy); it becomes part of the same launch sequence.
+        Single process: the whole sequence -- `pre`, the statistics memset, the advantage statistics and the
+        K x {gradient kernel, fused reduce/clip/Adam} launches -- is captured into a HIP graph the second time a shape
+        is seen and replayed afterwards (dependent launches start ~2.5 us earlier each inside a graph on this machine,
+        and the host issues one call instead of ~90); the Adam step count and learning rates live on the device so no
         launch argument changes between replays."""
         algo, dev = self.algo, self.dev
         K, rows_mb = row_idx.shape
@@ -201,8 +220,8 @@ class _FusedPPO:
         n_local = rows_mb * N
         n_global = float(n_local * world)
         idx_dev, stats = self._buffers(K, rows_mb)
-        idx_dev.copy_(torch.from_numpy(np.ascontiguousarray(row_idx).reshape(-1)), non_blocking=True)
-        stats.zero_()
+        self._idx_host.numpy()[:] = row_idx.reshape(-1)
+        idx_dev.copy_(self._idx_host, non_blocking=True)
         rows_total = t["advs"].shape[0]
         raw, info = stats[:4 * K].view(K, 4), stats[4 * K:28 * K].view(K, 24)
         norms = stats[28 * K:].view(torch.float32).view(K, 2)
@@ -210,11 +229,15 @@ class _FusedPPO:
         loss_mode = int(getattr(algo, "loss_mode", _C.LOSS_PPO_CLIP))
         probe = getattr(self, "probe", None)                           # bench.py: HIP events around the grad kernel
         fused = not dist.collectives_active()
-        # TRL_GRAPH_COLLECTIVES=1 (opt-in): capture the multi-rank sequence -- RCCL all-reduces included -- into the HIP
-        # graph as well; the Adam step count and learning rates then live on the device like in the fused launch.
-        graph_coll = not fused and os.environ.get("TRL_GRAPH_COLLECTIVES") == "1"
+        # Env shards on several ranks with the peer transport up (dist.init_comm): the gradient SUM over ranks happens
+        # INSIDE the fold / clip / Adam launch (trl_ppo_reduce_adam_xrank_f32) and the statistics go through the
+        # one-kernel all-reduce -- plain launches, so the sequence is graph-replayed exactly like the single-process one.
+        xrank = not fused and dist.peer_ready() and os.environ.get("TRL_NO_XRANK") != "1"
+        # TRL_GRAPH_COLLECTIVES=1 (opt-in, RCCL route): capture the multi-rank sequence -- RCCL all-reduces included -- into
+        # the HIP graph as well; the Adam step count and learning rates then live on the device like in the fused launch.
+        graph_coll = not fused and not xrank and os.environ.get("TRL_GRAPH_COLLECTIVES") == "1"
         lr_pf, lr_vf = algo.pf_optimizer.param_groups[0]['lr'], algo.vf_optimizer.param_groups[0]['lr']
-        if fused:
+        if fused or xrank:
             self._set_device_hyper(lr_pf, lr_vf)
         elif graph_coll:
             if getattr(self, "step_state", None) is None:
@@ -224,33 +247,36 @@ class _FusedPPO:
             if getattr(self, "_lr_host", None) != (float(lr_pf), float(lr_vf)):
                 self._lr_host = (float(lr_pf), float(lr_vf))
                 self.lr_dev.copy_(torch.tensor(self._lr_host, dtype=torch.float32), non_blocking=True)
-
-        g = _C.PpoBatchArgs()
-        for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"):
-            setattr(g, k, _C.dev_ptr(t[k], name=k).value if t.get(k) is not None else None)
-        g.loss_mode = loss_mode
-        g.rows_mb, g.N, g.n_global = rows_mb, N, n_global
-        g.pf_params, g.vf_params = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.P_pf
-        g.D, g.H, g.A, g.act = self.D, self.H, self.A, self.act
-        g.clip_para, g.entropy_coeff = float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff)
-        g.clipped_value_loss = int(bool(getattr(algo, "clipped_value_loss", False)))
-        g.tanh_action = int(bool(algo.pf.tanh_action))
-        g.partial, g.scal_partial, g.n_wg, g.n_wg_pf = self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf
-
-        a = _C.AdamArgs()
-        a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
-                                                      self.m.data_ptr(), self.v.data_ptr())
-        a.n_groups = 2
-        a.group_sizes[0], a.group_sizes[1] = self.P_pf, self.P_vf
-        a.group_lr[0], a.group_lr[1] = lr_pf, lr_vf
-        a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = 0.5, 0.9, 0.999, 1e-5, 1.0
-        a.device_state = int(fused)                                    # step count / lr from the workspace header
-
-        idx_base, raw_base, info_base, norm_base = idx_dev.data_ptr(), raw.data_ptr(), info.data_ptr(), norms.data_ptr()
-        lib = _C.lib()
-        import ctypes as C
+        hyper = (float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
+                 int(bool(getattr(algo, "clipped_value_loss", False))), int(bool(algo.pf.tanh_action)))
+        use_graph = (fused or xrank or graph_coll) and probe is None and os.environ.get("TRL_NO_GRAPH") != "1"
+        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, xrank) + hyper + tuple(
+            0 if t.get(k) is None else t[k].data_ptr() for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
 
         def launch_all():
+            import ctypes as C
+            g = _C.PpoBatchArgs()
+            for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"):
+                setattr(g, k, _C.dev_ptr(t[k], name=k).value if t.get(k) is not None else None)
+            g.loss_mode = loss_mode
+            g.rows_mb, g.N, g.n_global = rows_mb, N, n_global
+            g.pf_params, g.vf_params = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.P_pf
+            g.D, g.H, g.A, g.act = self.D, self.H, self.A, self.act
+            g.clip_para, g.entropy_coeff, g.clipped_value_loss, g.tanh_action = hyper
+            g.partial, g.scal_partial, g.n_wg, g.n_wg_pf = self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf
+            a = _C.AdamArgs()
+            a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
+                                                          self.m.data_ptr(), self.v.data_ptr())
+            a.n_groups = 2
+            a.group_sizes[0], a.group_sizes[1] = self.P_pf, self.P_vf
+            a.group_lr[0], a.group_lr[1] = lr_pf, lr_vf
+            a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = 0.5, 0.9, 0.999, 1e-5, 1.0
+            a.device_state = int(fused or xrank)                       # step count / lr from the workspace header
+            idx_base, raw_base, info_base, norm_base = idx_dev.data_ptr(), raw.data_ptr(), info.data_ptr(), norms.data_ptr()
+            lib = _C.lib()
+            if pre is not None:
+                pre()
+            stats.zero_()
             stream = _C.stream_ptr(dev)
             _C.adv_stats(t["advs"].reshape(rows_total, N), idx_dev.view(K, rows_mb), raw)
             dist.reduce_adv_raw_(raw)
@@ -272,6 +298,12 @@ class _FusedPPO:
                                                          C.byref(a), self.red_ws.data_ptr(), stream),
                              "trl_ppo_reduce_adam_f32")
                     continue
+                if xrank:                                              # the same launch with the cross-rank SUM inside
+                    _C.check(lib.trl_ppo_reduce_adam_xrank_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf,
+                                                               self.D, self.H, self.A, self.grads.data_ptr(),
+                                                               info_base + 192 * k, C.byref(a), self.red_ws.data_ptr(),
+                                                               dist.comm_handle(), stream), "trl_ppo_reduce_adam_xrank_f32")
+                    continue
                 _C.check(lib.trl_ppo_reduce_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf, self.D,
                                                 self.H, self.A, self.flat.data_ptr(), self.grads.data_ptr(),
                                                 info_base + 192 * k, stream), "trl_ppo_reduce_f32")
@@ -280,9 +312,6 @@ class _FusedPPO:
                     a.step_count, a.step_state, a.device_lr = 0, self.step_state.data_ptr(), self.lr_dev.data_ptr()
                 _C.check(lib.trl_clip_adam_f32(C.byref(a), stream), "trl_clip_adam_f32")
 
-        use_graph = (fused or graph_coll) and probe is None and os.environ.get("TRL_NO_GRAPH") != "1"
-        key = (n_wg, n_wg_pf, loss_mode, g.clip_para, g.entropy_coeff, g.clipped_value_loss, g.tanh_action, n_global,
-               rows_total, N) + tuple(getattr(g, k) for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
         if not use_graph:
             launch_all()
         elif getattr(self, "_graph", None) is not None and self._graph_key == key:
@@ -298,10 +327,14 @@ class _FusedPPO:
             self._graph, self._graph_key = graph, key
             graph.replay()
         self.step_count += K
-        for s in self._opt_steps:
-            s.fill_(float(self.step_count))
         dist.reduce_info_(info)
-        host = stats.cpu()                                             # the only host sync of the update
+        self._stats_host.copy_(stats, non_blocking=True)
+        for s in self._opt_steps:                                      # host bookkeeping under the device's shadow
+            s.fill_(float(self.step_count))
+        torch.cuda.current_stream(dev).synchronize()                   # the only host wait of the update
+        if xrank:
+            dist.check_comm()                                          # a rank that never delivered: raise, do not hang
+        host = self._stats_host
         make = self._infos_a2c if loss_mode == _C.LOSS_A2C else self._infos
         return make(host[:4 * K].view(K, 4).numpy(), host[4 * K:28 * K].view(K, 24).numpy(),
                     host[28 * K:].view(torch.float32).view(K, 2).numpy(), n_global)
@@ -324,21 +357,22 @@ class _FusedPPO:
         return out
 
     def _infos(self, raw, info, norms, n):
-        out = []
+        """K info dicts with the keys of PPO.update (ppo.py:76-90, 120-122, 141-146), assembled column-wise."""
         c_ent = float(self.algo.entropy_coeff)
-        for r, i, g in zip(raw, info, norms):
-            adv_var = max((r[1] - r[0] * r[0] / n) / (n - 1), 0.0)
-            lp_var = max((i[2] - i[1] * i[1] / n) / (n - 1), 0.0)
-            ent = self.A * _HALF_LOG_2PI_PLUS_HALF + self.A * i[8]
-            out.append({
-                'advs/mean': r[0] / n, 'advs/std': math.sqrt(adv_var), 'advs/max': r[2], 'advs/min': -r[3],
-                'Training/vf_loss': i[7] / n, 'grad_norm/vf': float(g[1]),
-                'Training/policy_loss': i[0] / n - c_ent * ent,
-                'logprob/mean': i[1] / n, 'logprob/std': math.sqrt(lp_var), 'logprob/max': i[3], 'logprob/min': -i[4],
-                'log_std/mean': i[8], 'log_std/std': i[9], 'log_std/max': i[10], 'log_std/min': i[11],
-                'ratio/max': i[5], 'ratio/min': -i[6], 'grad_norm/pf': float(g[0]),
-            })
-        return out
+        r, i = raw, info
+        adv_var = np.maximum((r[:, 1] - r[:, 0] * r[:, 0] / n) / (n - 1), 0.0)
+        lp_var = np.maximum((i[:, 2] - i[:, 1] * i[:, 1] / n) / (n - 1), 0.0)
+        ent = self.A * _HALF_LOG_2PI_PLUS_HALF + self.A * i[:, 8]
+        cols = (('advs/mean', r[:, 0] / n), ('advs/std', np.sqrt(adv_var)), ('advs/max', r[:, 2]), ('advs/min', -r[:, 3]),
+                ('Training/vf_loss', i[:, 7] / n), ('grad_norm/vf', norms[:, 1].astype(np.float64)),
+                ('Training/policy_loss', i[:, 0] / n - c_ent * ent),
+                ('logprob/mean', i[:, 1] / n), ('logprob/std', np.sqrt(lp_var)), ('logprob/max', i[:, 3]),
+                ('logprob/min', -i[:, 4]), ('log_std/mean', i[:, 8]), ('log_std/std', i[:, 9]), ('log_std/max', i[:, 10]),
+                ('log_std/min', i[:, 11]), ('ratio/max', i[:, 5]), ('ratio/min', -i[:, 6]),
+                ('grad_norm/pf', norms[:, 0].astype(np.float64)))
+        keys = [k for k, _ in cols]
+        table = np.stack([v for _, v in cols], axis=1).tolist()
+        return [dict(zip(keys, row)) for row in table]
 
 
 def make_engine(algo):
@@ -408,7 +442,7 @@ class _GenericPPO(_FusedPPO):
             self.workspace = torch.empty(need, device=self.dev)
         return self.workspace
 
-    def run(self, t, row_idx, N):
+    def run(self, t, row_idx, N, pre=None, pre_key=None):
         algo, dev, ops = self.algo, self.dev, self.ops
         K, rows_mb = row_idx.shape
         world = dist.world_size()
@@ -416,7 +450,6 @@ class _GenericPPO(_FusedPPO):
         n_global = float(n_local * world)
         idx_dev, stats = self._buffers(K, rows_mb)
         idx_dev.copy_(torch.from_numpy(np.ascontiguousarray(row_idx).reshape(-1)), non_blocking=True)
-        stats.zero_()
         rows_total = t["advs"].shape[0]
         raw, info = stats[:4 * K].view(K, 4), stats[4 * K:28 * K].view(K, 24)
         norms = stats[28 * K:].view(torch.float32).view(K, 2)
@@ -434,6 +467,9 @@ class _GenericPPO(_FusedPPO):
                  bool(getattr(algo, "clipped_value_loss", False)), bool(algo.pf.tanh_action), loss_mode)
 
         def launch_all():
+            if pre is not None:
+                pre()
+            stats.zero_()
             _C.adv_stats(t["advs"].reshape(rows_total, N), idx2d, raw)
             dist.reduce_adv_raw_(raw)
             for k in range(K):
@@ -459,7 +495,7 @@ class _GenericPPO(_FusedPPO):
                 _C.clip_adam(a, dev)
 
         # eager on the first visit of a configuration, captured into a HIP graph on the second, replayed afterwards
-        key = (K, rows_mb, N, rows_total, n_global, idx_dev.data_ptr(), stats.data_ptr()) + hyper + tuple(
+        key = (K, rows_mb, N, rows_total, n_global, idx_dev.data_ptr(), stats.data_ptr(), pre_key, pre is not None) + hyper + tuple(
             0 if t.get(k_) is None else t[k_].data_ptr() for k_ in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
         graphs = self._graphs
         if not replayable or (key not in graphs and len(graphs) >= 4):

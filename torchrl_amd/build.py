@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libtrl_hip.so")
-SOURCES = ["trl_host.cpp", "k_gae.hip", "k_gather.hip", "k_ppo.hip", "k_ppo_generic.hip", "k_vmpo.hip", "k_trpo.hip", "k_rollout.hip", "k_gemm.hip", "k_conv1.hip", "k_sac.hip", "k_conv.hip", "k_dqn.hip", "k_norm.hip", "k_frames.hip"]
+SOURCES = ["trl_host.cpp", "k_gae.hip", "k_gather.hip", "k_ppo.hip", "k_ppo_generic.hip", "k_vmpo.hip", "k_trpo.hip", "k_rollout.hip", "k_gemm.hip", "k_conv1.hip", "k_sac.hip", "k_conv.hip", "k_dqn.hip", "k_norm.hip", "k_frames.hip", "k_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable"]
 
@@ -46,7 +46,7 @@ def build(force=False, verbose=True, extra_flags=(), lib=None):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
         if verbose and out.strip():
             print(out.decode())
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     for o in objs:
         os.remove(o)

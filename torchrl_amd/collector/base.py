@@ -135,8 +135,13 @@ class VecCollector(_CollectorBase):
             _C.synth_reset(env.cur_obs, env.t_env, env.cur_step, env.episode_idx, env.ep_return, self._mask, env.seed_base)
 
     def _read_header(self):
-        """(epoch reward, finished-episode count) with a single host sync."""
-        h = self._hdr.cpu()
+        """(epoch reward, finished-episode count) with a single host sync (asynchronous copy into page-locked memory,
+        then one wait on the stream)."""
+        if getattr(self, "_hdr_host", None) is None:
+            self._hdr_host = torch.zeros(2, dtype=torch.float64).pin_memory()
+        self._hdr_host.copy_(self._hdr, non_blocking=True)
+        torch.cuda.current_stream(self._hdr.device).synchronize()
+        h = self._hdr_host
         return float(h[0]), int(h[1:].view(torch.int32)[0])
 
     def _clear_header(self):

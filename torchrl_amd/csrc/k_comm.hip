@@ -1,0 +1,249 @@
+// C1 / C2 / C3 -- the collectives of the multi-GPU path behind the C ABI.
+//
+// The reference has no distributed backend; these entry points are what its update loop would call between
+// `loss.backward()` and `clip_grad_norm_` (torchrl/algo/on_policy/ppo.py:72-74, 117-119: the clip must see the
+// reduced gradient) and around the advantage statistics (ppo.py:141-147).
+//
+// Two transports behind one `trl_comm_t`:
+//   * RCCL (ncclAllReduce on the caller's stream, in place) -- bandwidth-class messages (the 6.6 MB conv gradient) and
+//     the fallback for everything; loaded with dlopen so the library itself has no link-time RCCL dependency;
+//   * peer-mapped granule exchange (trl_comm.h) -- latency-class messages: the 44 KB PPO gradient (fused into
+//     trl_ppo_reduce_adam_xrank_f32, k_ppo.hip) and the few-KB statistics vectors (trl_allreduce_*_f64 here): one
+//     kernel, one xGMI hop, no rendezvous kernel, graph-capturable like any other launch.
+// The peer buffer is the one allocation the library owns (it must be exported with hipIpcGetMemHandle); everything else
+// keeps the no-allocation contract of include/trl_hip.h.
+#include <dlfcn.h>
+#include <string.h>
+#include "trl_comm.h"
+
+typedef struct { char internal[128]; } trl_nccl_uid;                   // ncclUniqueId
+typedef void* trl_nccl_comm;
+struct RcclApi {
+  void* handle;
+  int (*GetUniqueId)(trl_nccl_uid*);
+  int (*CommInitRank)(trl_nccl_comm*, int, trl_nccl_uid, int);
+  int (*CommDestroy)(trl_nccl_comm);
+  int (*AllReduce)(const void*, void*, size_t, int, int, trl_nccl_comm, hipStream_t);
+  const char* (*GetErrorString)(int);
+};
+static RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+static int load_rccl() {
+  if (g_rccl.handle) return TRL_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) { trl_set_error("trl_comm: cannot load librccl.so.1: %s", dlerror()); return TRL_EUNSUPPORTED; }
+  g_rccl.GetUniqueId = (int (*)(trl_nccl_uid*))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(trl_nccl_comm*, int, trl_nccl_uid, int))dlsym(h, "ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(trl_nccl_comm))dlsym(h, "ncclCommDestroy");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, trl_nccl_comm, hipStream_t))dlsym(h, "ncclAllReduce");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) {
+    trl_set_error("trl_comm: librccl lacks a required symbol");
+    return TRL_EUNSUPPORTED;
+  }
+  g_rccl.handle = h;
+  return TRL_OK;
+}
+
+struct trl_comm {
+  int rank, world;
+  trl_nccl_comm rccl;                              // null: no RCCL communicator (peer transport only)
+  unsigned long long* local;                       // this rank's peer buffer (uncached device memory)
+  void* opened[TRL_MAX_RANKS];                     // hipIpcOpenMemHandle results (null for self / not opened)
+  XrArgs xr;                                       // device-side view; xr.peer[] valid once peers are open
+  int peers_ready;
+};
+
+#define HIP_TRY(expr)                                                                         \
+  do { hipError_t e_ = (expr);                                                                \
+       if (e_ != hipSuccess) { trl_set_error("%s: %s: %s", __func__, #expr, hipGetErrorString(e_)); return (int)e_; } } while (0)
+
+extern "C" int trl_comm_unique_id_bytes(void) { return (int)sizeof(trl_nccl_uid); }
+extern "C" int trl_comm_peer_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+extern "C" int trl_comm_max_ranks(void) { return TRL_MAX_RANKS; }
+
+extern "C" int trl_comm_get_unique_id(void* id_out) {
+  TRL_REQUIRE(id_out, "null pointer");
+  int rc = load_rccl();
+  if (rc) return rc;
+  trl_nccl_uid id;
+  const int e = g_rccl.GetUniqueId(&id);
+  if (e) { trl_set_error("ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return 1000 + e; }
+  memcpy(id_out, &id, sizeof(id));
+  return TRL_OK;
+}
+
+// unique_id: the bytes rank 0 obtained from trl_comm_get_unique_id, distributed out of band by the caller (the host
+// framework's rendezvous); NULL = no RCCL communicator (peer transport only, e.g. several ranks on one device).
+extern "C" int trl_comm_init(trl_comm_t** out, int rank, int world, const void* unique_id) {
+  TRL_REQUIRE(out, "null pointer");
+  TRL_REQUIRE(world >= 1 && world <= TRL_MAX_RANKS && rank >= 0 && rank < world, "need 0 <= rank < world <= 16");
+  trl_comm* c = new trl_comm();
+  memset(c, 0, sizeof(*c));
+  c->rank = rank; c->world = world;
+  c->xr.rank = rank; c->xr.world = world;
+  if (unique_id) {
+    int rc = load_rccl();
+    if (rc) { delete c; return rc; }
+    trl_nccl_uid id;
+    memcpy(&id, unique_id, sizeof(id));
+    const int e = g_rccl.CommInitRank(&c->rccl, world, id, rank);
+    if (e) {
+      trl_set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error");
+      delete c;
+      return 1000 + e;
+    }
+  }
+  *out = c;
+  return TRL_OK;
+}
+
+// Allocates this rank's peer buffer and returns its IPC handle (to be all-gathered by the caller).
+extern "C" int trl_comm_peer_export(trl_comm_t* c, void* handle_out) {
+  TRL_REQUIRE(c && handle_out, "null pointer");
+  if (!c->local) {
+    const size_t bytes = xr_buffer_granules(c->world) * sizeof(unsigned long long);
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipMalloc(&p, bytes)); }
+    HIP_TRY(hipMemset(p, 0, bytes));
+    void* ctl = nullptr;
+    HIP_TRY(hipMalloc(&ctl, 64));
+    HIP_TRY(hipMemset(ctl, 0, 64));
+    HIP_TRY(hipDeviceSynchronize());
+    c->local = (unsigned long long*)p;
+    c->xr.ctl = (unsigned*)ctl;
+    c->xr.peer[c->rank] = c->local;
+  }
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, c->local));
+  memcpy(handle_out, &h, sizeof(h));
+  return TRL_OK;
+}
+
+// handles: world x trl_comm_peer_handle_bytes() bytes in rank order (the own entry is ignored).
+extern "C" int trl_comm_peer_open(trl_comm_t* c, const void* handles) {
+  TRL_REQUIRE(c && handles && c->local, "export the local buffer first");
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank || c->opened[r]) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)handles + (size_t)r * sizeof(h), sizeof(h));
+    void* p = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    c->opened[r] = p;
+    c->xr.peer[r] = (unsigned long long*)p;
+  }
+  c->peers_ready = 1;
+  return TRL_OK;
+}
+
+extern "C" int trl_comm_peer_ready(const trl_comm_t* c) { return (c && c->peers_ready) ? 1 : 0; }
+// 0: stop using the peer transport (e.g. after a failed self-check); all calls then take the RCCL route
+extern "C" int trl_comm_peer_enable(trl_comm_t* c, int on) {
+  TRL_REQUIRE(c, "null communicator");
+  TRL_REQUIRE(!on || c->local, "peers were never mapped");
+  c->peers_ready = on ? 1 : 0;
+  return TRL_OK;
+}
+extern "C" int trl_comm_has_rccl(const trl_comm_t* c) { return (c && c->rccl) ? 1 : 0; }
+
+// 1 when a peer wait timed out since the last call (and clears the flag); synchronises the device.
+extern "C" int trl_comm_error(trl_comm_t* c) {
+  if (!c || !c->xr.ctl) return 0;
+  unsigned v = 0;
+  if (hipMemcpy(&v, c->xr.ctl + 2, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  if (v) (void)hipMemset(c->xr.ctl + 2, 0, sizeof(v));
+  return v ? 1 : 0;
+}
+
+extern "C" int trl_comm_destroy(trl_comm_t* c) {
+  if (!c) return TRL_OK;
+  for (int r = 0; r < c->world; ++r)
+    if (c->opened[r]) (void)hipIpcCloseMemHandle(c->opened[r]);
+  if (c->local) (void)hipFree(c->local);
+  if (c->xr.ctl) (void)hipFree(c->xr.ctl);
+  if (c->rccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->rccl);
+  delete c;
+  return TRL_OK;
+}
+
+// the device-side view, for the fused kernels in other translation units (k_ppo.hip)
+const XrArgs* trl_comm_xr(const trl_comm_t* c) { return (c && c->peers_ready) ? &c->xr : nullptr; }
+
+// ---------------------------------------------------------------- small one-shot all-reduce
+// buf[i] <- reduce over ranks of buf[i]; element i is SUMmed, or MAXed when bit (i % period) of max_mask is set.
+// WORDS = 32-bit words per element (1: float, 2: double).  Epoch of the call = ctl[0] + 1, advanced by the last
+// block to finish (every block has read it by then), so a captured launch replays with no argument change.
+template <typename T, int WORDS>
+__global__ __launch_bounds__(256) void xr_allreduce_kernel(T* __restrict__ buf, int n, int period, unsigned long long max_mask,
+                                                           XrArgs x) {
+  const unsigned epoch = __hip_atomic_load(x.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    union { T v; unsigned w[WORDS]; } u;
+    u.v = buf[i];
+    for (int p = 0; p < x.world; ++p)
+#pragma unroll
+      for (int k = 0; k < WORDS; ++k)
+        xr_store(x.peer[p] + xr_small_off(x.world, epoch, x.rank, WORDS * i + k), epoch, u.w[k]);
+    unsigned long long* mine = x.peer[x.rank];
+    const bool is_max = (max_mask >> (i % period)) & 1ull;
+    T acc = (T)0;
+    for (int q = 0; q < x.world; ++q) {
+#pragma unroll
+      for (int k = 0; k < WORDS; ++k) u.w[k] = xr_wait(mine + xr_small_off(x.world, epoch, q, WORDS * i + k), epoch, x.ctl);
+      acc = (q == 0) ? u.v : (is_max ? (u.v > acc ? u.v : acc) : acc + u.v);
+    }
+    buf[i] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned before = __hip_atomic_fetch_add(x.ctl + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == gridDim.x - 1) {
+      __hip_atomic_store(x.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(x.ctl, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <typename T, int WORDS>
+static int launch_small(T* buf, int64_t n, int period, unsigned long long mask, trl_comm_t* c, hipStream_t s) {
+  hipLaunchKernelGGL((xr_allreduce_kernel<T, WORDS>), dim3(trl_ceil_div(n, 256)), dim3(256), 0, s, buf, (int)n, period, mask, c->xr);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// In-place SUM of n floats over all ranks, on `stream` (C1 of SURVEY.md 8(e)).  Latency transport for n up to
+// TRL_XR_CAP_SMALL words when the peers are mapped, RCCL ring otherwise.
+extern "C" int trl_allreduce_sum_f32(float* buf, int64_t n, trl_comm_t* c, void* stream) {
+  TRL_REQUIRE(c && n >= 0, "null communicator / negative size");
+  if (n == 0) return TRL_OK;
+  TRL_REQUIRE(buf, "null pointer");
+  if (c->peers_ready && n <= TRL_XR_CAP_SMALL) return launch_small<float, 1>(buf, n, 1, 0ull, c, (hipStream_t)stream);
+  if (c->rccl) {
+    const int e = g_rccl.AllReduce(buf, buf, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->rccl, (hipStream_t)stream);
+    if (e) { trl_set_error("ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return 1000 + e; }
+    return TRL_OK;
+  }
+  trl_set_error("trl_allreduce_sum_f32: %lld floats exceed the peer transport and no RCCL communicator exists", (long long)n);
+  return TRL_EUNSUPPORTED;
+}
+
+// In-place reduction of n doubles (C2 / C3: advantage and logging statistics): element i is MAXed when bit
+// (i % period) of max_mask is set, SUMmed otherwise.  Peer transport only (2 n <= TRL_XR_CAP_SMALL); a pure SUM
+// (max_mask == 0) falls back to RCCL.
+extern "C" int trl_allreduce_f64(double* buf, int64_t n, int period, uint64_t max_mask, trl_comm_t* c, void* stream) {
+  TRL_REQUIRE(c && n >= 0 && period >= 1 && period <= 64, "bad arguments");
+  if (n == 0) return TRL_OK;
+  TRL_REQUIRE(buf, "null pointer");
+  if (c->peers_ready && 2 * n <= TRL_XR_CAP_SMALL)
+    return launch_small<double, 2>(buf, n, period, (unsigned long long)max_mask, c, (hipStream_t)stream);
+  if (c->rccl && max_mask == 0) {
+    const int e = g_rccl.AllReduce(buf, buf, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->rccl, (hipStream_t)stream);
+    if (e) { trl_set_error("ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return 1000 + e; }
+    return TRL_OK;
+  }
+  trl_set_error("trl_allreduce_f64: message too large for the peer transport (or peers not mapped)");
+  return TRL_EUNSUPPORTED;
+}

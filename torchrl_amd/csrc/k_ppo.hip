@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include "trl_common.h"
 #include "trl_mlp.h"
+#include "trl_comm.h"
 
 struct PpoDev {
   const float *obs, *acts, *advs, *rets, *old_values, *old_logp;
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
                                                               const float* __restrict__ logstd, int n_act,
                                                               float* __restrict__ grads, double* __restrict__ info,
                                                               AdamDev a, float* __restrict__ ws, unsigned epoch,
-                                                              int device_state) {
+                                                              int device_state, int xrank, XrArgs xr) {
   __shared__ float s_coef[2];
   __shared__ float s_hyper[4];                                    // bc1, bc2_sqrt, lr_pf, lr_vf
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -741,7 +742,19 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   }
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(ws + 16);    // [2 nets][nb] {ss bits, epoch}
   const int nb = gridDim.x;
-  const float gval = ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
+  // env shards on several ranks: the epoch of the cross-rank exchange is the communicator's own count of completed
+  // gradient exchanges (read by every block before it publishes anything, advanced by block (0, 0) at the end)
+  const unsigned xepoch = xrank ? __hip_atomic_load(xr.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
+  float gval = ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
+  if (xrank && wave == 0) {
+    // C1 of SURVEY.md 8(e) inside the launch: every rank pushes its 64 folded values into its slot on all ranks and
+    // sums the slots in rank order (trl_comm.h) -- the gradient every rank clips and steps with is the same, bit for bit
+    const int pe = blockIdx.x * RED_CHUNK + lane;
+    const bool act = pe < (blockIdx.y == 0 ? p_pf : p_vf);
+    const int ge = (blockIdx.y == 0 ? 0 : p_pf) + pe;
+    gval = xr_allsum_f32(xr, xepoch, act ? ge : 0, gval, act);
+    if (act) grads[ge] = gval;
+  }
   if (device_state && tid == 64 * (RED_WAVES - 1)) {
     b1p *= (double)a.beta1; b2p *= (double)a.beta2;
     s_hyper[0] = (float)(1.0 - b1p);
@@ -760,10 +773,18 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
     float acc = 0.0f;
     for (int b = lane; b < nb; b += 64) {
       unsigned long long v;
-      int it = 0;
+      unsigned it = 0;
+      unsigned long long t0 = 0;
       while ((unsigned)((v = __hip_atomic_load(slots + wave * nb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
         __builtin_amdgcn_s_sleep(1);
-        if (++it > (1 << 22)) { __hip_atomic_store(reinterpret_cast<unsigned*>(ws), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((++it & 1023u) == 0) {                                // bounded by wall-clock time (100 MHz counter): ~2 s alone,
+          const unsigned long long now = wall_clock64();          // ~25 s when other ranks' gradients are being waited for
+          if (t0 == 0) t0 = now;
+          if (now - t0 > (xrank ? 2500000000ull : 200000000ull)) {
+            __hip_atomic_store(reinterpret_cast<unsigned*>(ws), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
       }
       acc += __uint_as_float((unsigned)v);
     }
@@ -782,6 +803,9 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
       if (tid == 64 * (RED_WAVES - 1)) { bpow[0] = b1p; bpow[1] = b2p; }
     }
   }
+  // (every block has passed its exchange by the time block (0, 0) has seen all norm slots)
+  if (xrank && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+    __hip_atomic_store(xr.ctl + 4, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int net = blockIdx.y;
   const int p = blockIdx.x * RED_CHUNK + lane;
   if (wave == 0 && p < (net == 0 ? p_pf : p_vf))
@@ -944,9 +968,9 @@ extern "C" int trl_ppo_reduce_adam_workspace(int D, int H, int A) {
   return 16 + 4 * trl_ceil_div(ps, RED_CHUNK);       // header + {ss, epoch} per block and network
 }
 
-extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
-                                       int D, int H, int A, float* grads, double* info, const trl_adam_t* adam,
-                                       float* workspace, void* stream) {
+static int launch_reduce_adam(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf, int D, int H, int A,
+                              float* grads, double* info, const trl_adam_t* adam, float* workspace, const XrArgs* xr,
+                              void* stream) {
   TRL_REQUIRE(partial && scal_partial && grads && info && workspace, "null pointer");
   TRL_REQUIRE(n_wg >= 2 && n_wg_pf >= 0 && n_wg_pf < n_wg, "need n_wg >= 2 and n_wg_pf in [0, n_wg)");
   const int ps = trl_ppo_partial_stride(D, H, A);
@@ -958,12 +982,33 @@ extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_
   TRL_REQUIRE(adam->n_groups == 2 && adam->group_sizes[0] == p_pf && adam->group_sizes[1] == p_vf,
               "optimiser groups must be [policy | value] of this shape");
   TRL_REQUIRE(adam->grads == grads, "adam->grads must be the reduce output");
+  TRL_REQUIRE(!xr || p_pf + p_vf <= TRL_XR_CAP_GRAD, "gradient exceeds the peer buffer");
+  XrArgs none;
+  none.rank = 0; none.world = 1; none.ctl = nullptr;
+  for (int r = 0; r < TRL_MAX_RANKS; ++r) none.peer[r] = nullptr;
   hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(trl_ceil_div(ps, RED_CHUNK), 2), dim3(64 * RED_WAVES), 0, (hipStream_t)stream,
                      partial, scal_partial, n_wg, resolve_pf_wgs(n_wg, n_wg_pf), ps, p_pf, p_vf,
                      (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace, (unsigned)adam->step_count,
-                     adam->device_state);
+                     adam->device_state, xr ? 1 : 0, xr ? *xr : none);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
+}
+
+extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
+                                       int D, int H, int A, float* grads, double* info, const trl_adam_t* adam,
+                                       float* workspace, void* stream) {
+  return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, nullptr, stream);
+}
+
+// Env shards on several ranks: the same launch with the gradient SUM over ranks between the fold and the clip
+// (torchrl/algo/on_policy/ppo.py:72-74, 117-119: clip_grad_norm_ sees the whole-minibatch gradient).  Needs a
+// communicator whose peers are mapped (trl_comm_peer_open).
+extern "C" int trl_ppo_reduce_adam_xrank_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
+                                             int D, int H, int A, float* grads, double* info, const trl_adam_t* adam,
+                                             float* workspace, trl_comm_t* comm, void* stream) {
+  const XrArgs* xr = trl_comm_xr(comm);
+  if (!xr) { trl_set_error("trl_ppo_reduce_adam_xrank_f32: communicator without mapped peers"); return TRL_EINVAL; }
+  return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, xr, stream);
 }
 
 extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {

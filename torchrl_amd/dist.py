@@ -1,5 +1,4 @@
-"""Multi-GPU glue: one process per GPU, envs sharded by index, RCCL collectives
-through torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" in CPU tests).
+"""Multi-GPU glue: one process per GPU, envs sharded by index.
 
 The reference has no distributed path.  What makes sharding exact here is its
 minibatch definition -- `B // N` time rows x ALL N envs
@@ -10,15 +9,32 @@ needs no collective; only three small reductions exist:
   C1  flat gradient SUM (per-sample grads already carry 1/n_global),
   C2  advantage statistics {sum, sumsq} SUM and {max, -min} MAX, once per epoch,
   C3  logging statistics, once per epoch.
+
+Transport.  `torch.distributed` provides the rendezvous (process group "nccl" ==
+RCCL on ROCm, "gloo" in CPU tests).  After `init_comm()` the collectives themselves
+go through the library's own C ABI (include/trl_hip.h, csrc/k_comm.hip): a
+`trl_comm_t` holding an RCCL communicator for bandwidth-class messages and
+peer-mapped (hipIpc / xGMI) buffers for the latency-class ones -- the 44 KB PPO
+gradient is exchanged INSIDE the fold/clip/Adam launch, the statistics vectors by
+a one-kernel all-reduce; both are ordinary kernel launches, so the whole
+multi-rank update sequence replays as one HIP graph.  Without `init_comm()` (CPU
+tests, or when the peer set-up fails its self-check) the same calls fall back to
+`torch.distributed` collectives.
 """
+import ctypes as C
 import os
 
 import torch
 import torch.distributed as td
 
 # TRL_FORCE_COLLECTIVES=1 issues the collectives even at world size 1 (single-GPU smoke test of the
-# RCCL call path: dtypes, in-place views, stream ordering)
+# call path: dtypes, in-place views, stream ordering)
 _FORCE = os.environ.get("TRL_FORCE_COLLECTIVES", "0") == "1"
+
+_comm = None            # ctypes handle of the trl_comm_t
+_peer_ok = False        # peers mapped AND the self-check passed on every rank
+_has_rccl = False
+_SMALL_CAP = 4096       # TRL_XR_CAP_SMALL: 32-bit words per message of the peer transport
 
 
 def initialized():
@@ -52,21 +68,148 @@ def collectives_active():
     return _active()
 
 
+# ------------------------------------------------------------------ the library's own communicator
+def comm_handle():
+    return _comm
+
+
+def peer_ready():
+    """True when the latency transport (peer-mapped buffers) is usable on every rank."""
+    return _comm is not None and _peer_ok
+
+
+def _all_agree(flag):
+    votes = [None] * world_size()
+    td.all_gather_object(votes, bool(flag))
+    return all(votes)
+
+
+def init_comm(device=None, use_rccl=None, peers=True):
+    """Create the trl_comm_t of this process group (idempotent).  `use_rccl` defaults to "the process group is
+    nccl" (several ranks per device, as in the single-GPU tests, cannot form an RCCL communicator).  Every step is
+    voted on by all ranks, so all of them end up on the same transport.  Returns peer_ready()."""
+    global _comm, _peer_ok, _has_rccl
+    if _comm is not None or not initialized():
+        return peer_ready()
+    from . import _C
+    lib = _C.lib()
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    torch.cuda.set_device(dev)
+    w, r = world_size(), rank()
+    if w > lib.trl_comm_max_ranks():
+        return False
+    if use_rccl is None:
+        use_rccl = td.get_backend() == "nccl"
+    uid = None
+    if use_rccl:
+        payload = [None]
+        if r == 0:
+            buf = C.create_string_buffer(lib.trl_comm_unique_id_bytes())
+            payload = [buf.raw if lib.trl_comm_get_unique_id(buf) == 0 else None]
+        td.broadcast_object_list(payload, src=0)
+        uid = payload[0]
+    handle = C.c_void_p()
+    rc = lib.trl_comm_init(C.byref(handle), r, w, uid)
+    if not _all_agree(rc == 0):
+        if rc == 0:
+            lib.trl_comm_destroy(handle)
+        return False
+    _comm, _has_rccl = handle, bool(lib.trl_comm_has_rccl(handle))
+    if peers and os.environ.get("TRL_NO_PEER") != "1":
+        nb = lib.trl_comm_peer_handle_bytes()
+        mine = C.create_string_buffer(nb)
+        ok = lib.trl_comm_peer_export(handle, mine) == 0
+        gathered = [None] * w
+        td.all_gather_object(gathered, (ok, mine.raw))
+        if all(g[0] for g in gathered):
+            blob = C.create_string_buffer(b"".join(g[1] for g in gathered), nb * w)
+            ok = lib.trl_comm_peer_open(handle, blob) == 0
+        else:
+            ok = False
+        if _all_agree(ok):
+            _peer_ok = True
+            _peer_ok = _all_agree(_self_check(dev))
+        if not _peer_ok and ok:
+            lib.trl_comm_peer_enable(handle, 0)
+    return peer_ready()
+
+
+def _self_check(dev):
+    """The peer transport against closed-form sums, both buffer halves, every supported element kind."""
+    from . import _C
+    lib = _C.lib()
+    w, r = world_size(), rank()
+    stream = _C.stream_ptr(dev)
+    try:
+        for rep in range(4):
+            n = 3000 + rep
+            x = (torch.arange(n, device=dev, dtype=torch.float32) % 97 + 1) * (r + 1 + rep)
+            if lib.trl_allreduce_sum_f32(x.data_ptr(), n, _comm, stream) != 0:
+                return False
+            want = (torch.arange(n, device=dev, dtype=torch.float32) % 97 + 1) * sum(q + 1 + rep for q in range(w))
+            d = torch.arange(1500, device=dev, dtype=torch.float64).view(-1, 4) * 0 + (r + 1.5 + rep)
+            d[:, 3] = -(r + 0.25)
+            if lib.trl_allreduce_f64(d.data_ptr(), d.numel(), 4, 0xC, _comm, stream) != 0:
+                return False
+            torch.cuda.synchronize(dev)
+            if lib.trl_comm_error(_comm) != 0 or not torch.equal(x, want):
+                return False
+            if not (bool((d[:, :2] == sum(q + 1.5 + rep for q in range(w))).all()) and bool((d[:, 2] == w - 1 + 1.5 + rep).all())
+                    and bool((d[:, 3] == -0.25).all())):
+                return False
+        return True
+    except Exception:
+        return False
+
+
+def destroy_comm():
+    global _comm, _peer_ok, _has_rccl
+    if _comm is not None:
+        from . import _C
+        _C.lib().trl_comm_destroy(_comm)
+    _comm, _peer_ok, _has_rccl = None, False, False
+
+
+def check_comm():
+    """Raise if a peer wait timed out since the last check (a rank went missing); one small synchronous read."""
+    if _comm is not None and _peer_ok:
+        from . import _C
+        if _C.lib().trl_comm_error(_comm) != 0:
+            raise _C.TrlError("cross-rank exchange timed out: a rank did not deliver its contribution")
+
+
+def _via_abi(t, period, max_mask):
+    """Route one in-place reduction through the C ABI when it can carry it; False = use torch.distributed."""
+    if _comm is None or not t.is_cuda or not t.is_contiguous():
+        return False
+    from . import _C
+    lib = _C.lib()
+    n = t.numel()
+    stream = _C.stream_ptr(t.device)
+    if t.dtype == torch.float32 and max_mask == 0 and ((_peer_ok and n <= _SMALL_CAP) or _has_rccl):
+        _C.check(lib.trl_allreduce_sum_f32(t.data_ptr(), n, _comm, stream), "trl_allreduce_sum_f32")
+        return True
+    if t.dtype == torch.float64 and ((_peer_ok and 2 * n <= _SMALL_CAP) or (_has_rccl and max_mask == 0)):
+        _C.check(lib.trl_allreduce_f64(t.data_ptr(), n, int(period), int(max_mask), _comm, stream), "trl_allreduce_f64")
+        return True
+    return False
+
+
 def all_reduce_sum_(t):
-    if _active():
+    if _active() and not _via_abi(t, 1, 0):
         td.all_reduce(t, op=td.ReduceOp.SUM)
     return t
 
 
 def all_reduce_max_(t):
-    if _active():
+    if _active() and not _via_abi(t, 1, 1):
         td.all_reduce(t, op=td.ReduceOp.MAX)
     return t
 
 
 def reduce_adv_raw_(raw):
     """raw: (K, 4) float64 {sum, sumsq, max, -min} -> global statistics (C2)."""
-    if _active():
+    if _active() and not _via_abi(raw, 4, 0xC):
         s = raw[:, :2].contiguous()
         m = raw[:, 2:].contiguous()
         all_reduce_sum_(s)
@@ -81,11 +224,12 @@ def reduce_adv_raw_(raw):
 # maxima: max / -min of log-prob, ratio and value prediction.  Slots 8..11 and 16..19 derive from logstd (replicated).
 INFO_SUM_COLS = [0, 1, 2, 7, 12, 13]
 INFO_MAX_COLS = [3, 4, 5, 6, 14, 15]
+_INFO_MAX_MASK = sum(1 << c for c in range(24) if c not in INFO_SUM_COLS)     # replicated / unused columns: MAX is idempotent
 
 
 def reduce_info_(info):
     """info: (K, 24) float64 per-update statistics -> global (C3)."""
-    if _active():
+    if _active() and not (info.shape[-1] == 24 and _via_abi(info, 24, _INFO_MAX_MASK)):
         s = info[:, INFO_SUM_COLS].contiguous()
         m = info[:, INFO_MAX_COLS].contiguous()
         all_reduce_sum_(s)
