@@ -378,13 +378,16 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for e in range(args.steps):
         iteration(agent, col, args.warmup + e)
+        marks.append(time.perf_counter())                              # (every iteration ends in a host wait already)
     torch.cuda.synchronize()
     if dist.initialized():
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     log("timed %d iterations in %.3f s" % (args.steps, elapsed))
+    log("per-iteration ms: " + " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip([t0] + marks[:-1], marks)))
     if graph_mode:
         eng.probe = probes
         for e in range(PROBE_STEPS):

@@ -412,6 +412,11 @@ class _GenericPPO(_FusedPPO):
         self.P_vf = sum(p.numel() for p in vf_list)
         self.D, self.A = int(self.pf_layers[0][0].shape[1]), int(pf.logstd.numel())
         self.flat = flatten_into(pf_list + vf_list)                   # [pf | vf], parameters become views
+        # nets that are MLP2 blocks hand their own flat view to the fused inference kernel (Net.flat_params): it must
+        # be THIS storage, or the first forward after the engine exists would re-home the parameters away from it
+        for net, lo, hi in ((pf, 0, self.P_pf), (vf, self.P_pf, self.P_pf + self.P_vf)):
+            if getattr(net, "mlp2_spec", lambda: None)() is not None:
+                net._flat = self.flat[lo:hi]
         self.m, self.v, self.grads = torch.zeros_like(self.flat), torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         self.step_count = 0
         tgt = getattr(algo, "target_pf", None)

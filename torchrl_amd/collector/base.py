@@ -113,6 +113,7 @@ class VecCollector(_CollectorBase):
         self._epoch_reward = self._hdr[:1]
         self._ep_count = self._hdr[1:].view(torch.int32)[:1]
         self._ep_log = torch.zeros(self.EP_LOG_CAP, 3, device=dev)
+        self._ep_log_host = torch.zeros(self.EP_LOG_CAP, 3).pin_memory() if torch.cuda.is_available() else None
         self._mask = torch.zeros(self.env.env_nums, dtype=torch.uint8, device=dev)
         self._noise_seed = 0xC011
 
@@ -155,7 +156,9 @@ class VecCollector(_CollectorBase):
         cnt = min(cnt, self.EP_LOG_CAP)
         if not cnt:
             return np.zeros((0, 3), dtype=np.float32)
-        log = self._ep_log[:cnt].cpu().numpy()
+        self._ep_log_host[:cnt].copy_(self._ep_log[:cnt], non_blocking=True)
+        torch.cuda.current_stream(self._ep_log.device).synchronize()
+        log = self._ep_log_host[:cnt].numpy().copy()
         return log[np.lexsort((log[:, 1], log[:, 0]))]
 
     def _explore_noise(self, env):
@@ -293,7 +296,7 @@ class VecCollector(_CollectorBase):
     def train_one_epoch(self):
         self.rollout(self.sample_epoch_frames)
         log = self._finished_episodes()
-        self.train_rews = [np.float32(r) for r in log[:, 2]]
+        self.train_rews = list(log[:, 2])                            # np.float32 scalars
         self.train_epoch_reward = float(self._epoch_reward.item())
         return {'train_rewards': self.train_rews, 'train_epoch_reward': self.train_epoch_reward}
 

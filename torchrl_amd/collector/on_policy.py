@@ -282,7 +282,7 @@ class VecOnPolicyCollector(VecCollector):
             if int(self._norm_ws[:2].view(torch.int32)[2].item()) != 0:
                 raise _C.TrlError("rollout: grid rendezvous timed out (workgroups were not co-resident)")
         log = self._finished_episodes(cnt)                                 # ... plus the episode log when any ended
-        self.train_rews = [np.float32(r) for r in log[:, 2]]
+        self.train_rews = list(log[:, 2])                            # np.float32 scalars
         return {'train_rewards': self.train_rews, 'train_epoch_reward': self.train_epoch_reward}
 
     def take_actions(self):
