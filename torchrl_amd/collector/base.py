@@ -114,6 +114,12 @@ class VecCollector(_CollectorBase):
         self._ep_count = self._hdr[1:].view(torch.int32)[:1]
         self._ep_log = torch.zeros(self.EP_LOG_CAP, 3, device=dev)
         self._ep_log_host = torch.zeros(self.EP_LOG_CAP, 3).pin_memory() if torch.cuda.is_available() else None
+        if self._ep_log_host is not None:
+            # the runtime sets up its device-to-host copy path for a size class on first use (milliseconds): pay that
+            # here, not in the first epoch in which episodes end
+            for n in (64, 4096, self.EP_LOG_CAP):
+                self._ep_log_host[:n].copy_(self._ep_log[:n], non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
         self._mask = torch.zeros(self.env.env_nums, dtype=torch.uint8, device=dev)
         self._noise_seed = 0xC011
 

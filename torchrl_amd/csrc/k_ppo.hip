@@ -235,6 +235,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     for (int q = 0; q < 6; ++q) lin[q] = lq[q];
     const float x16 = xb[4];
 
+#ifdef TRL_EXP_OLDTILE
     // ---- forward layer 1: 4 independent slices ----
     f32x4 h1[4], h2[4];
 #pragma unroll
@@ -433,6 +434,239 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 #pragma unroll
       for (int q = 0; q < 4; ++q) gW1[so] = mfma16(za[q], xt[q], gW1[so]);
     }
+#else
+    // LDS operand reads are issued one phase AHEAD of the MFMAs that consume them (PIN_DS keeps the compiler from
+    // sinking them back next to their use): the ~130-cycle LDS round trip then runs under the previous phase's matrix
+    // work instead of stalling the in-order wave in front of every 4-MFMA group.  Arithmetic and summation order are
+    // those of the TRL_EXP_OLDTILE body, bit for bit.
+#define PIN_DS() __builtin_amdgcn_sched_barrier(0x676)   /* VALU / SALU / VMEM / DS writes / transcendentals may cross; DS reads and MFMAs may not */
+    // ---- forward layer 1: 4 independent slices ----
+    f32x4 h1[4], h2[4];
+    f32x4 wq[4], bq;                                   // W2 operand slices / b2 slice of the NEXT L2 output slice
+#pragma unroll
+    for (int so = 0; so < 4; ++so) h1[so] = lds4(lds + S::O_B1 + 16 * so + 4 * g);
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) wq[sl] = lds4(W2F + i * LDW + 16 * sl + 4 * g);
+    bq = lds4(lds + S::O_B2 + 4 * g);
+    PIN_DS();
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+      for (int so = 0; so < 4; ++so) h1[so] = mfma16(w1[so][q], xb[q], h1[so]);
+#pragma unroll
+    for (int so = 0; so < 4; ++so)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h1[so][r] = act_fn<ACT>(h1[so][r]);
+        H1S[(16 * so + 4 * g + r) * LDT + j] = h1[so][r];        // H1^T[f][s] for dW2
+      }
+    WCLK(1)
+    // ---- forward layer 2 ----
+#pragma unroll
+    for (int so = 0; so < 4; ++so) {
+      f32x4 acc = bq;
+      f32x4 wc[4];
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) wc[sl] = wq[sl];
+      if (so < 3) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) wq[sl] = lds4(W2F + (16 * (so + 1) + i) * LDW + 16 * sl + 4 * g);
+        bq = lds4(lds + S::O_B2 + 16 * (so + 1) + 4 * g);
+        PIN_DS();
+      }
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(wc[sl][r], h1[sl][r], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h2[so][r] = act_fn<ACT>(acc[r]);
+    }
+
+    // Next tile's loads are issued HERE, mid-tile: at the top of the loop every outstanding load is then
+    // half a tile old, and no wait next to the first MFMAs can stall on a load that was just issued.
+    {
+      const int nt = tile + tile_stride;            // loads of tile t+1 (addresses were resolved a tile ago) ...
+      const int64_t pn = (nt * 16 + j < B) ? ridx_nn * a.N + e_nn : 0;
+      fetch_inputs(pn, nt * 16);
+      fetch_row(nt + tile_stride);                  // ... and the row index of tile t+2
+    }
+    WCLK(2)
+    // ---- head, loss, d(loss)/d(out), dZ2 ----
+    f32x4 dz2[4];
+    f32x4 wb[4];                                       // W2^T operand slices of the next dH1 k-slice
+    if constexpr (IS_PF) {
+#pragma unroll
+      for (int so = 0; so < 4; ++so)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H2S[(16 * so + 4 * g + r) * LDT + j] = h2[so][r];            // H2^T[f][s] for dW3
+      // out^T[o][s]: two interleaved accumulation chains over the 64 features
+      f32x4 oa = f32x4{b3v[0], b3v[1], b3v[2], b3v[3]}, ob = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sl = 0; sl < 4; sl += 2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { oa = mfma16(w3h[sl][r], h2[sl][r], oa); ob = mfma16(w3h[sl + 1][r], h2[sl + 1][r], ob); }
+      // lane (j, g < 2) owns outputs o = 4g + r of sample j
+      float zc[4], lp = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        zc[r] = 0.0f;
+        if (4 * g + r < O) lp += gauss_logp_term(valid ? lin[r] : 0.0f, oa[r] + ob[r], ivv[r], lsv[r], a.tanh_action, zc[r]);
+      }
+      lp += __shfl_xor(lp, 16, 64);                                // outputs 0..3 (g = 0) + 4..7 (g = 1)
+      const float advn = valid ? (lin[4] - adv_mu) * adv_rstd : 0.0f;
+      float ratio, s1, s2, g_lp;
+      if (a.loss_mode == TRL_LOSS_A2C) {                            // L = -mean(log pi * adv) (a2c.py:69-70)
+        ratio = 1.0f;
+        s1 = s2 = lp * advn;
+        g_lp = (valid && g < 2) ? -advn * inv_b : 0.0f;
+      } else {                                                     // clipped surrogate (ppo.py:58-66)
+        ratio = __expf(lp - lin[5]);
+        s1 = ratio * advn;
+        s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
+        g_lp = (valid && g < 2 && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
+      }
+      float dout[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool own = valid && g < 2 && 4 * g + r < O;
+        dout[r] = own ? g_lp * zc[r] * ivv[r] : 0.0f;
+        db3[r] += dout[r];
+        dls[r] += own ? lspass[r] * (g_lp * (zc[r] * zc[r] * ivv[r] - 1.0f) - a.entropy_coeff * inv_b) : 0.0f;
+        if (g < 2) DOS[(4 * g + r) * LDT + j] = dout[r];           // dout^T[o][s] for dW3
+      }
+      if (valid && g == 0) {
+        stv[0] += lp; stv[1] = fmaf(lp, lp, stv[1]); stv[6] -= fminf(s1, s2);
+        stv[2] = fmaxf(stv[2], lp); stv[3] = fmaxf(stv[3], -lp);
+        stv[4] = fmaxf(stv[4], ratio); stv[5] = fmaxf(stv[5], -ratio);
+      }
+      // operands of dW3 (and of the first dH1 k-slice) are requested now and arrive under the dH2 MFMAs
+      const f32x4 da = lds4(DOS + i * LDT + 4 * g);
+      f32x4 hb3[4];
+#pragma unroll
+      for (int so = 0; so < 4; ++so) hb3[so] = lds4(H2S + (16 * so + j) * LDT + 4 * g);
+#pragma unroll
+      for (int so = 0; so < 4; ++so) wb[so] = lds4(W2B + (16 * so + i) * LDW + 4 * g);
+      PIN_DS();
+      // dH2^T[f][s] = sum_o W3[o][f] dout[o][s];  dZ2 = dH2 * act'(H2)
+#pragma unroll
+      for (int so = 0; so < 4; ++so) dz2[so] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int so = 0; so < 4; ++so) dz2[so] = mfma16(w3t[so][r], dout[r], dz2[so]);
+      // dW3[o][f] += sum_s dout[s][o] H2[s][f]   (K step q is sample 4g + q)
+#pragma unroll
+      for (int so = 0; so < 4; ++so)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gW3[so] = mfma16(da[q], hb3[so][q], gW3[so]);
+    } else {
+#pragma unroll
+      for (int so = 0; so < 4; ++so) wb[so] = lds4(W2B + (16 * so + i) * LDW + 4 * g);
+      PIN_DS();
+      float v = 0.0f;
+#pragma unroll
+      for (int so = 0; so < 4; ++so)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v = fmaf(w3h[so][r], h2[so][r], v);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      v += vb3;
+      const float R = lin[4];
+      float dv, l;
+      if (a.clipped_value_loss) {                                  // ppo.py:104-111
+        const float vo = lin[5];
+        const float dc = v - vo;
+        const float vc = vo + fminf(fmaxf(dc, -a.clip_para), a.clip_para);
+        const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+        const float wa = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), wb_ = 1.0f - wa;
+        const float pass = (dc >= -a.clip_para && dc <= a.clip_para) ? 1.0f : 0.0f;
+        l = 0.5f * fmaxf(l1, l2);
+        dv = inv_b * (wa * (v - R) + wb_ * pass * (vc - R));
+      } else {                                                     // nn.MSELoss, a2c.py:43
+        l = (v - R) * (v - R);
+        dv = 2.0f * (v - R) * inv_b;
+      }
+      dv = valid ? dv : 0.0f;
+      if (valid && g == 0) {
+        stv[6] += l; db3[0] += dv;
+        stv[0] += v; stv[1] = fmaf(v, v, stv[1]); stv[2] = fmaxf(stv[2], v); stv[3] = fmaxf(stv[3], -v);   // v_pred/*
+      }
+#pragma unroll
+      for (int so = 0; so < 4; ++so)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dz2[so][r] = dv * w3h[so][r];
+          gW3[so][r] = fmaf(dv, h2[so][r], gW3[so][r]);             // per-lane dW3[f] partial (own sample)
+        }
+    }
+#pragma unroll
+    for (int so = 0; so < 4; ++so)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dz2[so][r] *= act_grad<ACT>(h2[so][r]);
+        gb2[so][r] += dz2[so][r];
+        DZ2S[(16 * so + 4 * g + r) * LDT + j] = dz2[so][r];        // dZ2^T[f][s] for dW2
+      }
+
+    WCLK(3)
+    // ---- dH1^T (all slices) = W2^T dZ2^T ; dZ1 = dH1 * act'(H1) ----
+    f32x4 dz1[4];
+    f32x4 hb[4], za2;                                  // dW2 operands: H1 rows (all four slices), dZ2 rows of the next slice
+#pragma unroll
+    for (int so = 0; so < 4; ++so) dz1[so] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      f32x4 w[4];
+#pragma unroll
+      for (int so = 0; so < 4; ++so) w[so] = wb[so];
+      if (sl < 3) {
+#pragma unroll
+        for (int so = 0; so < 4; ++so) wb[so] = lds4(W2B + (16 * so + i) * LDW + 16 * (sl + 1) + 4 * g);
+      } else {                                         // last k-slice: the dW2 operands are requested under it
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hb[c] = lds4(H1S + (16 * c + j) * LDT + 4 * g);
+        za2 = lds4(DZ2S + i * LDT + 4 * g);
+      }
+      PIN_DS();
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int so = 0; so < 4; ++so) dz1[so] = mfma16(w[so][r], dz2[sl][r], dz1[so]);
+    }
+#pragma unroll
+    for (int so = 0; so < 4; ++so)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dz1[so][r] *= act_grad<ACT>(h1[so][r]);
+        gb1[so][r] += dz1[so][r];
+        gW1c[so][r] = fmaf(dz1[so][r], x16, gW1c[so][r]);
+        H2S[(16 * so + 4 * g + r) * LDT + j] = dz1[so][r];         // dZ1^T[f][s] for dW1 (H2^T is consumed)
+      }
+    // the dW1 operands (dZ1 rows) are requested now and arrive under the dW2 MFMAs
+    f32x4 za1[4];
+#pragma unroll
+    for (int so = 0; so < 4; ++so) za1[so] = lds4(H2S + (16 * so + i) * LDT + 4 * g);
+    PIN_DS();
+
+    WCLK(4)
+    // ---- dW2[f2][f1] += sum_s dZ2[s][f2] H1[s][f1]  (K step q is sample 4g + q) ----
+#pragma unroll
+    for (int so = 0; so < 4; ++so) {
+      const f32x4 za = za2;
+      if (so < 3) { za2 = lds4(DZ2S + (16 * (so + 1) + i) * LDT + 4 * g); PIN_DS(); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gW2[so][c] = mfma16(za[q], hb[c][q], gW2[so][c]);
+    }
+    WCLK(5)
+    // ---- dW1[f1][k < 16] += sum_s dZ1[s][f1] X[s][k] ----
+#pragma unroll
+    for (int so = 0; so < 4; ++so)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gW1[so] = mfma16(za1[so][q], xt[q], gW1[so]);
+#undef PIN_DS
+#endif
     WCLK(6)
   }
 
