@@ -27,7 +27,7 @@ def main():
     t = {"obs": buf._obs, "acts": buf._acts, "advs": buf._advs, "rets": buf._estimate_returns,
          "old_values": buf._values, "old_logp": buf._old_logp}
     eng._n_wg = lambda n: (eng.max_wg, _C.lib().trl_ppo_wg_split(17, 64, 6, (n + 15) // 16, eng.max_wg))                      # always the full grid, to expose the fixed cost
-    for rows in (32, 16, 8, 2, 1):
+    for rows in (32,):
         idx = np.random.permutation(128)[:4 * rows].reshape(4, rows).astype(np.int64)
         probes = []
         eng.probe = probes
@@ -38,12 +38,14 @@ def main():
         print("%s grad kernel rows_mb=%2d (B=%6d): mean %.1f us  min %.1f us  (n=%d)" % (
             os.environ.get("TRL_LIB", "default"), rows, rows * buf.env_nums, ms.mean() * 1e3, ms.min() * 1e3, len(ms)))
         if "clk" in os.environ.get("TRL_LIB", ""):
-            names = ["prologue", "L1+st", "L2+tanh", "head/loss/dW3/dH2", "dz2st+dH1+dz1st", "dW2", "dW1", "images", "fold"]
+            names = {0: "prologue", 9: "top+prefetch", 10: "L1 mfma", 1: "L1 act+st", 11: "L2 mfma", 12: "L2 act", 2: "fetch next",
+                     14: "H2st+head mfma", 15: "logp+dout", 16: "dz2+dW3 mfma", 3: "act'+dz2 st", 17: "dH1 mfma", 4: "act'+dz1 st",
+                     5: "dW2", 6: "dW1", 7: "images", 8: "fold"}
             part = eng.partial.cpu().numpy()
-            half = part.shape[0] // 2
-            for net, sl in (("pf", slice(0, half)), ("vf", slice(half, None))):
-                c = part[sl, eng.p_stride - 16: eng.p_stride - 7].mean(axis=0)
-                print("   %s wave-0 cycles: " % net + "  ".join("%s %.0f" % (n, x) for n, x in zip(names, c)) + "  | total %.0f" % c.sum())
+            n_pf = _C.lib().trl_ppo_wg_split(17, 64, 6, (rows * buf.env_nums + 15) // 16, eng.max_wg)
+            for net, sl in (("pf", slice(0, n_pf)), ("vf", slice(n_pf, None))):
+                c = part[sl, eng.p_stride - 40: eng.p_stride - 16].mean(axis=0)
+                print("   %s wave-0 ticks: " % net + "  ".join("%s %.0f" % (names[k], c[k]) for k in names) + "  | total %.0f" % c.sum())
 
 
 if __name__ == "__main__":

@@ -57,8 +57,8 @@ template <int D, int H, int A> struct PpoShape {
 #define WV_WAVES 4
 // development aid (tools/time_grad.py): per-phase cycle totals of every wave 0 into the spare tail of `partial`
 #ifdef TRL_EXP_CLK
-#define WCLK_DECL long long clk_prev = clock64(); float clk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define WCLK(ph) { const long long c_ = clock64(); clk_acc[ph] += (float)(c_ - clk_prev); clk_prev = c_; }
+#define WCLK_DECL long long clk_prev = clock64(); float clk_acc[24]; for (int q_ = 0; q_ < 24; ++q_) clk_acc[q_] = 0.f;
+#define WCLK(ph) { __builtin_amdgcn_sched_barrier(0); const long long c_ = clock64(); clk_acc[ph] += (float)(c_ - clk_prev); clk_prev = c_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define WCLK_DECL
 #define WCLK(ph)
@@ -88,7 +88,7 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
-template <int D, int H, int A, int ACT, bool IS_PF>
+template <int D, int H, int A, int ACT, bool IS_PF, bool CONTIG>
 __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
   constexpr int O = IS_PF ? A : 1;
   using S = WvShape<D, H, A>;
@@ -179,24 +179,65 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 
   const int B = a.rows_mb * a.N;
   const int n_tiles = (B + 15) / 16;
-  const bool contig = (a.N % 16) == 0;
   const int tile_stride = n_wg_net * WV_WAVES;
 
   // Inputs are fetched ONE TILE AHEAD as raw values (masks are applied when they are consumed, so no wait
   // sits next to the loads) and the minibatch row index TWO tiles ahead (the dependent load behind it is
   // then off the critical path): x operand (5), X^T for dW1 (4), loss inputs (6 / 2).
-  auto row_of = [&](int smp, int& e) -> int { const int sm = smp < B ? smp : 0; const int r = sm / a.N; e = sm - r * a.N; return r; };
   float xq[5], xtq[4], lq[6];
+  int tile = wg_in_net * WV_WAVES + wave;
+  // ---- CONTIG (N % 16 == 0, hence B % 16 == 0: every tile is 16 consecutive envs of ONE time row, all samples valid) ----
+  // The tile position (row, column tile) and the row's base addresses are wave-uniform: they live in scalar registers
+  // and are advanced incrementally (no per-lane division, no 64-bit per-lane address arithmetic); each lane adds a
+  // constant 32-bit byte offset, so a load is `global_load_dword v, v_off, s[base]` with nothing to compute in front.
+  const int tpr = a.N >> 4;                                           // tiles per time row
+  int p1r = 0, p1c = 0, p2r = 0, p2c = 0, st_r = 0, st_c = 0;         // positions of tile t+1 / t+2 (in strides), stride split
+  int64_t ridx1 = 0, ridx2 = 0;
+  const unsigned ox = (unsigned)(j * D + 4 * g) * 4u, ox16 = (unsigned)(j * D + 16) * 4u, os = (unsigned)j * 4u;
+  unsigned oxt[4], oa_[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    oxt[q] = (unsigned)((4 * g + q) * D + i) * 4u;
+    oa_[q] = (unsigned)(j * O + (4 * g + q < O ? 4 * g + q : 0)) * 4u;
+  }
+  auto ldb = [](const float* base, unsigned byte_off) -> float {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  auto pos_advance = [&](int& r, int& c) { c += st_c; r += st_r; if (c >= tpr) { c -= tpr; ++r; } };
+  auto load_ridx = [&](int r) -> int64_t {
+    const int rr = r < a.rows_mb ? r : 0;                             // tiles past the end: any in-range row
+    return a.row_idx ? a.row_idx[rr] : (int64_t)rr;
+  };
+  auto fetch_contig = [&](int64_t ridx, int r, int c) {
+    const int64_t cell0 = (r < a.rows_mb) ? ridx * a.N + 16 * c : 0;  // wave-uniform
+    const float* ob = a.obs + cell0 * D;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xq[q] = ldb(ob, ox + 4u * q);
+    xq[4] = ldb(ob, ox16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xtq[q] = ldb(ob, oxt[q]);           // X[sample 4g + q][feature j]: B operand of the dW1 GEMM
+    if constexpr (IS_PF) {
+      const float* ab = a.acts + cell0 * O;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lq[q] = ldb(ab, oa_[q]);
+      lq[4] = ldb(a.advs + cell0, os);
+      lq[5] = a.old_logp ? ldb(a.old_logp + cell0, os) : 0.0f;
+    } else {
+      lq[0] = lq[1] = lq[2] = lq[3] = 0.0f;
+      lq[4] = ldb(a.rets + cell0, os);
+      lq[5] = a.clipped_value_loss ? ldb(a.old_values + cell0, os) : 0.0f;
+    }
+  };
+  // ---- generic path: any N, ragged last tile; per-lane cell indices ----
+  auto row_of = [&](int smp, int& e) -> int { const int sm = smp < B ? smp : 0; const int r = sm / a.N; e = sm - r * a.N; return r; };
   auto fetch_inputs = [&](int64_t p, int s0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) xq[r] = a.obs[p * D + 4 * g + r];
     xq[4] = a.obs[p * D + 16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                   // X[sample 4g + q][feature j]: B operand of the dW1 GEMM
+    for (int q = 0; q < 4; ++q) {
       const int sj = 4 * g + q;
-      int64_t pr;
-      if (contig) pr = p - j + sj;                  // N % 16 == 0: the tile is one contiguous run of cells
-      else        pr = __shfl(p, sj, 64);
+      const int64_t pr = __shfl(p, sj, 64);
       xtq[q] = a.obs[(s0 + sj < B ? pr : 0) * D + i];
     }
     if constexpr (IS_PF) {
@@ -208,15 +249,38 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       lq[4] = a.rets[p]; lq[5] = a.clipped_value_loss ? a.old_values[p] : 0.0f;
     }
   };
-  int tile = wg_in_net * WV_WAVES + wave;
-  // pipeline registers: (row index, env) of the tile after next
   int e_nn = 0;
   int64_t ridx_nn = 0;
   auto fetch_row = [&](int t) {
     const int r = row_of(t * 16 + j, e_nn);
     ridx_nn = a.row_idx ? a.row_idx[r] : (int64_t)r;
   };
-  {
+  // loads of tile `nt` (= current + stride) and the row index of the tile after it
+  auto prefetch_next = [&](int nt) {
+    if constexpr (CONTIG) {
+      fetch_contig(ridx1, p1r, p1c);
+      p1r = p2r; p1c = p2c; ridx1 = ridx2;
+      pos_advance(p2r, p2c);
+      ridx2 = load_ridx(p2r);
+    } else {
+      const int64_t pn = (nt * 16 + j < B) ? ridx_nn * a.N + e_nn : 0;
+      fetch_inputs(pn, nt * 16);
+      fetch_row(nt + tile_stride);
+    }
+  };
+  if constexpr (CONTIG) {
+    const int t0 = __builtin_amdgcn_readfirstlane(tile);
+    const int ts = __builtin_amdgcn_readfirstlane(tile_stride);
+    st_r = ts / tpr; st_c = ts - st_r * tpr;
+    int r0 = t0 / tpr, c0 = t0 - (t0 / tpr) * tpr;
+    fetch_contig(load_ridx(r0), r0, c0);                              // tile t (dependent pair of loads, once per kernel)
+    p1r = r0; p1c = c0;
+    pos_advance(p1r, p1c);
+    ridx1 = load_ridx(p1r);
+    p2r = p1r; p2c = p1c;
+    pos_advance(p2r, p2c);
+    ridx2 = load_ridx(p2r);
+  } else {
     fetch_row(tile);
     const int64_t p0 = (tile * 16 + j < B) ? ridx_nn * a.N + e_nn : 0;
     fetch_inputs(p0, tile * 16);
@@ -225,12 +289,12 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   WCLK(0)
   for (; tile < n_tiles; tile += tile_stride) {
     const int s = tile * 16 + j;
-    const bool valid = s < B;
+    const bool valid = CONTIG ? true : (s < B);
     float xb[5], xt[4], lin[6];
 #pragma unroll
     for (int r = 0; r < 5; ++r) xb[r] = valid ? xq[r] : 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xt[q] = (tile * 16 + 4 * g + q < B) ? xtq[q] : 0.0f;
+    for (int q = 0; q < 4; ++q) xt[q] = (CONTIG || tile * 16 + 4 * g + q < B) ? xtq[q] : 0.0f;
 #pragma unroll
     for (int q = 0; q < 6; ++q) lin[q] = lq[q];
     const float x16 = xb[4];
@@ -269,12 +333,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 
     // Next tile's loads are issued HERE, mid-tile: at the top of the loop every outstanding load is then
     // half a tile old, and no wait next to the first MFMAs can stall on a load that was just issued.
-    {
-      const int nt = tile + tile_stride;            // loads of tile t+1 (addresses were resolved a tile ago) ...
-      const int64_t pn = (nt * 16 + j < B) ? ridx_nn * a.N + e_nn : 0;
-      fetch_inputs(pn, nt * 16);
-      fetch_row(nt + tile_stride);                  // ... and the row index of tile t+2
-    }
+    prefetch_next(tile + tile_stride);            // loads of tile t+1 (addresses were resolved a tile ago), row index of tile t+2
     WCLK(2)
     // ---- head, loss, d(loss)/d(out), dZ2 ----
     f32x4 dz2[4];
@@ -292,9 +351,12 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       // lane (j, g < 2) owns outputs o = 4g + r of sample j
       float zc[4], lp = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        zc[r] = 0.0f;
-        if (4 * g + r < O) lp += gauss_logp_term(valid ? lin[r] : 0.0f, oa[r] + ob[r], ivv[r], lsv[r], a.tanh_action, zc[r]);
+      for (int r = 0; r < 4; ++r) {                                  // branch-free: lanes without an output compute on zeros
+        const bool has = 4 * g + r < O;
+        const float t = gauss_logp_term((valid && has) ? lin[r] : 0.0f, has ? oa[r] + ob[r] : 0.0f, ivv[r], lsv[r],
+                                        a.tanh_action, zc[r]);
+        lp += has ? t : 0.0f;
+        zc[r] = has ? zc[r] : 0.0f;
       }
       lp += __shfl_xor(lp, 16, 64);                                // outputs 0..3 (g = 0) + 4..7 (g = 1)
       const float advn = valid ? (lin[4] - adv_mu) * adv_rstd : 0.0f;
@@ -449,10 +511,12 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     for (int sl = 0; sl < 4; ++sl) wq[sl] = lds4(W2F + i * LDW + 16 * sl + 4 * g);
     bq = lds4(lds + S::O_B2 + 4 * g);
     PIN_DS();
+    WCLK(9)
 #pragma unroll
     for (int q = 0; q < 5; ++q)
 #pragma unroll
       for (int so = 0; so < 4; ++so) h1[so] = mfma16(w1[so][q], xb[q], h1[so]);
+    WCLK(10)
 #pragma unroll
     for (int so = 0; so < 4; ++so)
 #pragma unroll
@@ -478,18 +542,15 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       for (int sl = 0; sl < 4; ++sl)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc = mfma16(wc[sl][r], h1[sl][r], acc);
+      WCLK(11)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h2[so][r] = act_fn<ACT>(acc[r]);
+      WCLK(12)
     }
 
     // Next tile's loads are issued HERE, mid-tile: at the top of the loop every outstanding load is then
     // half a tile old, and no wait next to the first MFMAs can stall on a load that was just issued.
-    {
-      const int nt = tile + tile_stride;            // loads of tile t+1 (addresses were resolved a tile ago) ...
-      const int64_t pn = (nt * 16 + j < B) ? ridx_nn * a.N + e_nn : 0;
-      fetch_inputs(pn, nt * 16);
-      fetch_row(nt + tile_stride);                  // ... and the row index of tile t+2
-    }
+    prefetch_next(tile + tile_stride);            // loads of tile t+1 (addresses were resolved a tile ago), row index of tile t+2
     WCLK(2)
     // ---- head, loss, d(loss)/d(out), dZ2 ----
     f32x4 dz2[4];
@@ -505,12 +566,16 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       for (int sl = 0; sl < 4; sl += 2)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { oa = mfma16(w3h[sl][r], h2[sl][r], oa); ob = mfma16(w3h[sl + 1][r], h2[sl + 1][r], ob); }
+      WCLK(14)
       // lane (j, g < 2) owns outputs o = 4g + r of sample j
       float zc[4], lp = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        zc[r] = 0.0f;
-        if (4 * g + r < O) lp += gauss_logp_term(valid ? lin[r] : 0.0f, oa[r] + ob[r], ivv[r], lsv[r], a.tanh_action, zc[r]);
+      for (int r = 0; r < 4; ++r) {                                  // branch-free: lanes without an output compute on zeros
+        const bool has = 4 * g + r < O;
+        const float t = gauss_logp_term((valid && has) ? lin[r] : 0.0f, has ? oa[r] + ob[r] : 0.0f, ivv[r], lsv[r],
+                                        a.tanh_action, zc[r]);
+        lp += has ? t : 0.0f;
+        zc[r] = has ? zc[r] : 0.0f;
       }
       lp += __shfl_xor(lp, 16, 64);                                // outputs 0..3 (g = 0) + 4..7 (g = 1)
       const float advn = valid ? (lin[4] - adv_mu) * adv_rstd : 0.0f;
@@ -539,6 +604,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
         stv[2] = fmaxf(stv[2], lp); stv[3] = fmaxf(stv[3], -lp);
         stv[4] = fmaxf(stv[4], ratio); stv[5] = fmaxf(stv[5], -ratio);
       }
+      WCLK(15)
       // operands of dW3 (and of the first dH1 k-slice) are requested now and arrive under the dH2 MFMAs
       const f32x4 da = lds4(DOS + i * LDT + 4 * g);
       f32x4 hb3[4];
@@ -559,6 +625,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       for (int so = 0; so < 4; ++so)
 #pragma unroll
         for (int q = 0; q < 4; ++q) gW3[so] = mfma16(da[q], hb3[so][q], gW3[so]);
+      WCLK(16)
     } else {
 #pragma unroll
       for (int so = 0; so < 4; ++so) wb[so] = lds4(W2B + (16 * so + i) * LDW + 4 * g);
@@ -633,6 +700,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 #pragma unroll
         for (int so = 0; so < 4; ++so) dz1[so] = mfma16(w[so][r], dz2[sl][r], dz1[so]);
     }
+    WCLK(17)
 #pragma unroll
     for (int so = 0; so < 4; ++so)
 #pragma unroll
@@ -712,7 +780,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   }
   WCLK(8)
 #ifdef TRL_EXP_CLK
-  if (tid == 0) for (int ph = 0; ph < 9; ++ph) a.partial[(size_t)wg * a.p_stride + S::P_STRIDE - 16 + ph] = clk_acc[ph];
+  if (tid == 0) for (int ph = 0; ph < 24; ++ph) a.partial[(size_t)wg * a.p_stride + S::P_STRIDE - 40 + ph] = clk_acc[ph];
 #endif
   // ---- scalar statistics ----
   __syncthreads();
@@ -739,11 +807,11 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   }
 }
 
-template <int D, int H, int A, int ACT>
+template <int D, int H, int A, int ACT, bool CONTIG>
 __global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x < a.n_pf) ppo_wave_pass<D, H, A, ACT, true>(a, lds, blockIdx.x, a.n_pf);
-  else                          ppo_wave_pass<D, H, A, ACT, false>(a, lds, blockIdx.x - a.n_pf, a.n_wg - a.n_pf);
+  if ((int)blockIdx.x < a.n_pf) ppo_wave_pass<D, H, A, ACT, true, CONTIG>(a, lds, blockIdx.x, a.n_pf);
+  else                          ppo_wave_pass<D, H, A, ACT, false, CONTIG>(a, lds, blockIdx.x - a.n_pf, a.n_wg - a.n_pf);
 }
 
 // ---------------------------------------------------------------- partial reduce
@@ -751,14 +819,22 @@ __global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) 
 //  0 policy surrogate sum (-min(s1,s2))   1 sum logp   2 sum logp^2   3 max logp   4 -min logp
 //  5 max ratio   6 -min ratio   7 value-loss sum
 #define RED_CHUNK 64
-#define RED_WAVES 4                               // 256 threads (16 waves measured slower: 9.4 vs 8.6 us fused)
+// waves per block of 64 parameters / partial rows a lane has in flight per round.  Measured on MI355X at 147 + 109 rows
+// (iteration time of bench.py, A/B in one session): 4 x 16 -> 3.14-3.15 ms, 8 x 32 (the whole fold in one memory round
+// trip) -> 3.15-3.16 ms, 16 x 16 -> 3.23 ms: the launch is bound by its rendezvous and launch latencies, not by the fold.
+#ifndef RED_WAVES
+#define RED_WAVES 4
+#endif
+#ifndef RED_DEPTH
+#define RED_DEPTH 16
+#endif
 // returns (wave 0 lanes) this block's reduced gradient value, 0 outside the parameter range
 __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ partial,
                                                   const double* __restrict__ scal, int n_wg, int n_pf,
                                                   int p_stride, int p_pf, int p_vf,
                                                   const float* __restrict__ logstd, int n_act,
                                                   float* __restrict__ grads, double* __restrict__ info) {
-  // block = 64 consecutive parameters x RED_WAVES waves; wave w folds partials w, w + RED_WAVES, ... with 16
+  // block = 64 consecutive parameters x RED_WAVES waves; wave w folds partials w, w + RED_WAVES, ... with RED_DEPTH
   // independent accumulators (fixed order => deterministic), then the waves fold through LDS.
   __shared__ float s_acc[RED_WAVES][RED_CHUNK];
   const int net = blockIdx.y;
@@ -767,22 +843,22 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
   const int p = blockIdx.x * RED_CHUNK + lane;
   const int pn = net == 0 ? p_pf : p_vf;
   // 16 independent loads in flight per lane and round: the fold is latency-, not bandwidth-bound
-  float acc[16];
+  float acc[RED_DEPTH];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+  for (int k = 0; k < RED_DEPTH; ++k) acc[k] = 0.0f;
   if (p < pn) {
     const float* src = partial + (size_t)row0 * p_stride + p;
     int w = wave;
-    for (; w < nrow; w += 16 * RED_WAVES) {        // predicated: a ragged row count must not fall back to a serial tail
-      float v[16];
+    for (; w < nrow; w += RED_DEPTH * RED_WAVES) { // predicated: a ragged row count must not fall back to a serial tail
+      float v[RED_DEPTH];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = (w + RED_WAVES * k < nrow) ? src[(size_t)(w + RED_WAVES * k) * p_stride] : 0.0f;
+      for (int k = 0; k < RED_DEPTH; ++k) v[k] = (w + RED_WAVES * k < nrow) ? src[(size_t)(w + RED_WAVES * k) * p_stride] : 0.0f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) acc[k] += v[k];
+      for (int k = 0; k < RED_DEPTH; ++k) acc[k] += v[k];
     }
   }
 #pragma unroll
-  for (int st = 8; st > 0; st >>= 1)
+  for (int st = RED_DEPTH / 2; st > 0; st >>= 1)
 #pragma unroll
     for (int k = 0; k < st; ++k) acc[k] += acc[k + st];
   s_acc[wave][lane] = acc[0];
@@ -1002,6 +1078,12 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
                          ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(ss),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // the optimiser state of this block's parameters is requested now and arrives while the norm slots are polled
+  const int pe_ = blockIdx.x * RED_CHUNK + lane;
+  const bool own_ = wave == 0 && pe_ < (blockIdx.y == 0 ? p_pf : p_vf);
+  const int ge_ = (blockIdx.y == 0 ? 0 : p_pf) + pe_;
+  float m_old = 0.0f, v_old = 0.0f, p_old = 0.0f;
+  if (own_) { m_old = a.m[ge_]; v_old = a.v[ge_]; p_old = a.params[ge_]; }
   // ---- group norms (pf, vf): wave w polls net w's slots, then sums them in fixed order ----
   if (wave < 2) {
     float acc = 0.0f;
@@ -1040,10 +1122,15 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   // (every block has passed its exchange by the time block (0, 0) has seen all norm slots)
   if (xrank && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
     __hip_atomic_store(xr.ctl + 4, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int net = blockIdx.y;
-  const int p = blockIdx.x * RED_CHUNK + lane;
-  if (wave == 0 && p < (net == 0 ? p_pf : p_vf))
-    adam_element(a, (net == 0 ? 0 : p_pf) + p, gval * a.grad_scale * s_coef[net]);
+  if (own_) {                                                      // adam_element on the prefetched state
+    const int net = blockIdx.y;
+    const float gr = gval * a.grad_scale * s_coef[net];
+    const float m = a.beta1 * m_old + (1.0f - a.beta1) * gr;
+    const float v = a.beta2 * v_old + (1.0f - a.beta2) * gr * gr;
+    a.m[ge_] = m; a.v[ge_] = v;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    a.params[ge_] = p_old - (a.lr[net] / a.bc1) * (m / denom);
+  }
 }
 
 // ---------------------------------------------------------------- MLP inference
@@ -1093,20 +1180,25 @@ extern "C" int trl_ppo_partial_stride(int D, int H, int A) {
 // and a PAIR of waves per tile with two waves per SIMD (75 us) -- on gfx950 the fp32 MFMA and the VALU do not
 // overlap across the two waves of a SIMD (tools/ubench/mfma_valu.hip: an MFMA-only wave and a VALU-only wave
 // on one SIMD take the SUM of their times), so a second wave only adds its duplicated loss / fetch work.
-template <int D, int H, int A, int ACT>
-static int launch_ppo(const PpoDev& d, hipStream_t s) {
+template <int D, int H, int A, int ACT, bool CONTIG>
+static int launch_ppo_v(const PpoDev& d, hipStream_t s) {
   using S = WvShape<D, H, A>;
   const size_t lds = S::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wave_kernel<D, H, A, ACT>,
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wave_kernel<D, H, A, ACT, CONTIG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { trl_set_error("ppo_grad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_grad_wave_kernel<D, H, A, ACT>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d);
+  hipLaunchKernelGGL((ppo_grad_wave_kernel<D, H, A, ACT, CONTIG>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
+}
+// N % 16 == 0 (every tile = 16 consecutive envs of one time row): scalar tile addressing; any other N: per-lane cells
+template <int D, int H, int A, int ACT>
+static int launch_ppo(const PpoDev& d, hipStream_t s) {
+  return (d.N % 16 == 0) ? launch_ppo_v<D, H, A, ACT, true>(d, s) : launch_ppo_v<D, H, A, ACT, false>(d, s);
 }
 
 // Policy / value split of the grid.  A policy tile costs more than a value tile (head, log-prob loss,

@@ -35,30 +35,34 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// tanh(x) = 1 - 2/(exp(2x)+1) on v_exp_f32 / v_rcp_f32 (valid for both signs, saturates cleanly),
-// x - x^3/3 for |x| < 0.04 where the subtraction would cancel.  abs error < 2e-7 over the real line
-// (tests/test_kernels_gpu.py checks it on device against float64 tanh).
+// tanh(x) = 1 - 2 / (2^(x * 2 log2 e) + 1): one multiply, v_exp_f32, one add, v_rcp_f32, one fma -- valid for both signs,
+// saturates cleanly (2^inf -> rcp 0 -> 1; 2^-inf -> rcp 1 -> -1).  Absolute error < 2e-7 over the real line
+// (tests/test_kernels_gpu.py checks the dense-layer kernels built on it against float64 tanh); near zero the error
+// is absolute, not relative -- |x| <= 1e-3 costs up to 1e-4 of tanh(x) itself, invisible next to fp32 GEMM round-off.
+// A vector instruction takes 4 cycles per wave on gfx950 and a transcendental 16 (tools/time_grad.py phase clocks: 63 ticks
+// per tanh with the former 12-instruction form that also carried an x - x^3/3 branch for |x| < 0.04), and fp32 MFMA does
+// not overlap with vector work (tools/ubench/mfma_valu.hip), so every instruction here is wall-clock time in the kernels.
 __device__ __forceinline__ float trl_tanh(float x) {
 #ifdef TRL_EXP_NOTANH
   return x * 0.5f;
 #endif
-  const float e = __expf(2.0f * x);
-  const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-  const float small = x * fmaf(x * x, -0.33333333333f, 1.0f);
-  return fabsf(x) < 0.04f ? small : big;
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 // One action dimension of log pi(a|s) for a (Tanh)Normal policy, the reference's formula
 // (torchrl/policies/distribution.py:33-45): atanh(a) = log((1+a)/(1-a))/2, Normal log-density
 // minus log(1 - a^2 + 1e-6).  Shared by the collector, the PPO loss and trl_gauss_logp_f32 so
 // that log pi and log pi_old of the same (s, a, params) are bit-identical (ratio == 1).
-// v_log_f32 / v_rcp_f32 based: rel. error ~1e-6 of each log term.  zc = atanh(a) - mean is returned.
+// Both logarithms are v_log_f32 (log2, ~1 ulp; arguments are normal numbers: (1+a)/(1-a) in [3e-8, 7e7], 1 - a^2 + 1e-6
+// >= 1e-6) times ln 2: rel. error ~1e-7 of each log term.  (`__logf` expands to a 15-instruction denormal-safe,
+// extended-precision sequence here -- 2.5 k ticks per 16-sample policy tile for the four terms.)  zc = atanh(a) - mean.
 __device__ __forceinline__ float gauss_logp_term(float act, float mean, float inv_var, float ls, int tanh_action,
                                                  float& zc) {
   float pre = act, corr = 0.0f;
   if (tanh_action) {
-    pre = 0.5f * __logf((1.0f + act) * __builtin_amdgcn_rcpf(1.0f - act));
-    corr = __logf(fmaf(-act, act, 1.0f) + 1e-6f);
+    pre = 0.34657359027997264f * __builtin_amdgcn_logf((1.0f + act) * __builtin_amdgcn_rcpf(1.0f - act));   // ln 2 / 2
+    corr = 0.6931471805599453f * __builtin_amdgcn_logf(fmaf(-act, act, 1.0f) + 1e-6f);
   }
   zc = pre - mean;
   return -(zc * zc) * 0.5f * inv_var - ls - 0.91893853320467274f - corr;
