@@ -39,7 +39,7 @@ def main():
             os.environ.get("TRL_LIB", "default"), rows, rows * buf.env_nums, ms.mean() * 1e3, ms.min() * 1e3, len(ms)))
         if "clk" in os.environ.get("TRL_LIB", ""):
             names = {0: "prologue", 9: "top+prefetch", 10: "L1 mfma", 1: "L1 act+st", 11: "L2 mfma", 12: "L2 act", 2: "fetch next",
-                     14: "H2st+head mfma", 15: "logp+dout", 16: "dz2+dW3 mfma", 3: "act'+dz2 st", 17: "dH1 mfma", 4: "act'+dz1 st",
+                     14: "H2st+head mfma", 18: "logp terms", 19: "shfl", 20: "ratio/loss", 21: "dout+DOS st", 15: "stats", 16: "dz2+dW3 mfma", 3: "act'+dz2 st", 17: "dH1 mfma", 4: "act'+dz1 st",
                      5: "dW2", 6: "dW1", 7: "images", 8: "fold"}
             part = eng.partial.cpu().numpy()
             n_pf = _C.lib().trl_ppo_wg_split(17, 64, 6, (rows * buf.env_nums + 15) // 16, eng.max_wg)

@@ -583,7 +583,9 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
         lp += has ? t : 0.0f;
         zc[r] = has ? zc[r] : 0.0f;
       }
+      WCLK(18)
       lp += __shfl_xor(lp, 16, 64);                                // outputs 0..3 (g = 0) + 4..7 (g = 1)
+      WCLK(19)
       const float advn = valid ? (lin[4] - adv_mu) * adv_rstd : 0.0f;
       float ratio, s1, s2, g_lp;
       if (a.loss_mode == TRL_LOSS_A2C) {                            // L = -mean(log pi * adv) (a2c.py:69-70)
@@ -596,6 +598,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
         s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
         g_lp = (valid && g < 2 && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
       }
+      WCLK(20)
       float dout[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -605,6 +608,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
         dls[r] += own ? lspass[r] * (g_lp * (zc[r] * zc[r] * ivv[r] - 1.0f) - a.entropy_coeff * inv_b) : 0.0f;
         if (g < 2) DOS[(4 * g + r) * LDT + j] = dout[r];           // dout^T[o][s] for dW3
       }
+      WCLK(21)
       if (valid && g == 0) {
         stv[0] += lp; stv[1] = fmaf(lp, lp, stv[1]); stv[6] -= fminf(s1, s2);
         stv[2] = fmaxf(stv[2], lp); stv[3] = fmaxf(stv[3], -lp);
