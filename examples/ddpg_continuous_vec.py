@@ -25,6 +25,8 @@ def main():
     args = get_args()
     params = get_params(args.config)
     device = torch.device("cuda:{}".format(args.device) if args.cuda else "cpu")
+    if device.type == "cuda":
+        torch.cuda.set_device(device)                    # envs / replay buffers allocate on the current device
     env = get_vec_env(params["env_name"], params["env"], args.vec_env_nums)
     eval_env = get_vec_env(params["env_name"], params["env"], args.vec_env_nums)
     env.seed(args.seed)

@@ -72,14 +72,17 @@ class RLAlgo:
 
     # ---- snapshots ----
     def snapshot(self, prefix, epoch):
-        if prefix is None:
+        """rl_algo.py:83-94.  With one process per GPU every rank holds identical parameters: rank 0 writes.  Parameters
+        are views of one flat buffer here, so each tensor is cloned -- a .pth holds that network only."""
+        if prefix is None or int(os.environ.get("RANK", "0")) != 0:
             return
         normalizer = getattr(self.env, "_obs_normalizer", None)
         if normalizer is not None:
             with open(os.path.join(prefix, "_obs_normalizer_%s.pkl" % (epoch,)), "wb") as handle:
                 pickle.dump(normalizer, handle)
         for name, network in self.snapshot_networks:
-            torch.save(network.state_dict(), os.path.join(prefix, "model_%s_%s.pth" % (name, epoch)))
+            state = {k: v.detach().clone() for k, v in network.state_dict().items()}
+            torch.save(state, os.path.join(prefix, "model_%s_%s.pth" % (name, epoch)))
 
     # ---- the loop ----
     @contextmanager

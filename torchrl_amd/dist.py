@@ -186,10 +186,13 @@ def _via_abi(t, period, max_mask):
     lib = _C.lib()
     n = t.numel()
     stream = _C.stream_ptr(t.device)
-    if t.dtype == torch.float32 and max_mask == 0 and ((_peer_ok and n <= _SMALL_CAP) or _has_rccl):
+    # the peer transport is plain kernel launches (capturable); the library's RCCL communicator is only used outside
+    # stream capture -- captured RCCL calls go through torch.distributed's communicator, the one bench.py probes
+    rccl_ok = _has_rccl and not torch.cuda.is_current_stream_capturing()
+    if t.dtype == torch.float32 and max_mask == 0 and ((_peer_ok and n <= _SMALL_CAP) or rccl_ok):
         _C.check(lib.trl_allreduce_sum_f32(t.data_ptr(), n, _comm, stream), "trl_allreduce_sum_f32")
         return True
-    if t.dtype == torch.float64 and ((_peer_ok and 2 * n <= _SMALL_CAP) or (_has_rccl and max_mask == 0)):
+    if t.dtype == torch.float64 and ((_peer_ok and 2 * n <= _SMALL_CAP) or (rccl_ok and max_mask == 0)):
         _C.check(lib.trl_allreduce_f64(t.data_ptr(), n, int(period), int(max_mask), _comm, stream), "trl_allreduce_f64")
         return True
     return False

@@ -48,19 +48,23 @@ class Logger:
         self.logger.setLevel(logging.INFO)
 
         self.work_dir = os.path.join(log_dir, experiment_id, env_name, str(seed))
-        if os.path.exists(self.work_dir):
-            assert overwrite, "Experiment Exists and Did not set overwrite"
-            shutil.rmtree(self.work_dir)
-        os.makedirs(self.work_dir, exist_ok=True)
-        self.tf_writer = tensorboardX.SummaryWriter(self.work_dir) if tensorboardX is not None else None
+        # one process per GPU: only rank 0 touches the log directory (every rank holds the same global statistics)
+        self.is_writer = int(os.environ.get("RANK", "0")) == 0
+        if self.is_writer:
+            if os.path.exists(self.work_dir):
+                assert overwrite, "Experiment Exists and Did not set overwrite"
+                shutil.rmtree(self.work_dir)
+            os.makedirs(self.work_dir, exist_ok=True)
+        self.tf_writer = tensorboardX.SummaryWriter(self.work_dir) if (tensorboardX is not None and self.is_writer) else None
         self.csv_file_path = os.path.join(self.work_dir, 'log.csv')
         self.update_count = 0
         self.stored_infos = {}
-        with open(os.path.join(self.work_dir, 'params.json'), 'w') as f:
-            json.dump(_jsonable(params), f, indent=2)
+        if self.is_writer:
+            with open(os.path.join(self.work_dir, 'params.json'), 'w') as f:
+                json.dump(_jsonable(params), f, indent=2)
         self.logger.info("Experiment Name:{}".format(experiment_id))
         params["name_combine"] = "{}_{}".format(experiment_id, env_name)
-        self.use_wb = wandb is not None and params.get('project') is not None
+        self.use_wb = wandb is not None and params.get('project') is not None and self.is_writer
         if self.use_wb:
             wandb.init(project=params['project'], name="{}_{}_{}".format(experiment_id, env_name, str(seed)),
                        group="{}_{}".format(experiment_id, env_name), config=_jsonable(params))
@@ -114,10 +118,10 @@ class Logger:
         if self.use_wb:
             wandb.log(scalars, step=total_frames)
         self._print_tables(dict(infos), statistics)
-        if csv_write:
-            with open(self.csv_file_path, 'a') as handle:
-                writer = csv.writer(handle)
+        if csv_write and self.is_writer:                                 # values formatted as the reference writes them
+            with open(self.csv_file_path, 'a') as handle:                  # (utils/logger.py:108-130: '{:.5f}' after the
+                writer = csv.writer(handle)                                #  three leading columns)
                 if epoch_num == 0:
                     writer.writerow([name for name, _ in columns])
-                writer.writerow([value for _, value in columns])
+                writer.writerow([value for _, value in columns[:3]] + ["{:.5f}".format(float(v)) for _, v in columns[3:]])
         self.stored_infos = {}
