@@ -392,3 +392,15 @@ def test_off_policy_epoch_driver_protocol():
     algo.update_per_timestep()
     assert len(events) == 6
 
+
+
+def test_one_block_of_host_noise_equals_per_step_draws():
+    """VecOnPolicyCollector._host_noise draws the whole rollout's exploration noise in ONE torch.randn call when
+    N * A is a multiple of 16; that must reproduce the reference's per-step stream (distribution.py:67-70) bit for bit."""
+    for N, A, T in ((2048, 6, 16), (8, 6, 5), (64, 3, 4)):
+        assert (N * A) % 16 == 0
+        torch.manual_seed(3)
+        per_step = torch.stack([torch.randn(N, A) for _ in range(T)])
+        torch.manual_seed(3)
+        block = torch.randn(T * N, A).view(T, N, A)
+        assert torch.equal(per_step, block), (N, A)
