@@ -13,9 +13,13 @@
 // end with a per-env carry, so any T fits in LDS.
 //
 // HBM traffic: 16 B read + 8 B written per env-step (V_{t+1} re-reads hit L1/L2).
+// Round 2 (cfg 2, 128 x 2048, rocprofv3): 10.1 -> 6.7 us = 0.94 TB/s of algorithmic traffic -- all of a thread's loads of a
+// chunk in flight at once (one memory round trip instead of one per 16 time steps), no second read of V in the write-back,
+// the wave's envs scanned in lockstep (their shuffle chains overlap), 8 envs per workgroup (256 workgroups at N = 2048
+// instead of 128 on 256 CUs).  What is left is launch + three dependent phases (load, LDS scan, store) of a 6 MB kernel.
 #include "trl_common.h"
 
-#define ENV_TILE 16
+#define ENV_TILE 8
 #define T_CHUNK 256
 #define GAE_THREADS 256
 
@@ -47,54 +51,92 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_scan_kernel(
     const int len = t_hi - t_lo;
     __syncthreads();
     // ---- stage coefficients ----
-    for (int tt = t_ld; tt < len; tt += GAE_THREADS / ENV_TILE) {
+    // All of a thread's loads of the chunk are issued before the first one is consumed (fixed trip count, predicated):
+    // the chunk then costs ONE memory round trip instead of one per 16 time steps (the 128 x 2048 scan of cfg 2 went
+    // from 8 dependent round trips to 1).
+    constexpr int TPT = T_CHUNK / (GAE_THREADS / ENV_TILE);        // time steps per thread and chunk (16)
+    float lr[TPT], lv[TPT], ld[TPT], ltl[TPT], lvn[TPT];
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      const int tt = t_ld + q * (GAE_THREADS / ENV_TILE);
       const int t = t_lo + tt;
-      float a = 0.f, c = 0.f;
-      if (n_ld < N) {
-        const size_t i = (size_t)t * N + n_ld;
-        const float r = rew[i], v = val[i], nd = 1.0f - term[i];
-        const float tlv = tl_filter ? tl[i] : 0.0f;
-        if (MODE == 0) {
-          const float vn = (t + 1 < T) ? val[i + N] : s_lastv[e_ld];
-          const float f = 1.0f - tlv;
-          a = (r + nd * gamma * vn - v) * f;
-          c = nd * gamma * tau * f;
-        } else {
-          a = r + tlv * v;
-          c = nd * gamma * (1.0f - tlv);
+      const bool ok = tt < len && n_ld < N;
+      const size_t i = ok ? (size_t)t * N + n_ld : 0;
+      lr[q] = ok ? rew[i] : 0.0f;
+      lv[q] = ok ? val[i] : 0.0f;
+      ld[q] = ok ? term[i] : 0.0f;
+      ltl[q] = (ok && tl_filter) ? tl[i] : 0.0f;
+      lvn[q] = (MODE == 0 && ok && t + 1 < T) ? val[i + N] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      const int tt = t_ld + q * (GAE_THREADS / ENV_TILE);
+      if (tt < len) {
+        const int t = t_lo + tt;
+        float a = 0.f, c = 0.f;
+        if (n_ld < N) {
+          const float r = lr[q], v = lv[q], nd = 1.0f - ld[q];
+          const float tlv = ltl[q];
+          if (MODE == 0) {
+            const float vn = (t + 1 < T) ? lvn[q] : s_lastv[e_ld];
+            const float f = 1.0f - tlv;
+            a = (r + nd * gamma * vn - v) * f;
+            c = nd * gamma * tau * f;
+          } else {
+            a = r + tlv * v;
+            c = nd * gamma * (1.0f - tlv);
+          }
         }
+        s_a[e_ld * LDT + tt] = a;
+        s_c[e_ld * LDT + tt] = c;
       }
-      s_a[e_ld * LDT + tt] = a;
-      s_c[e_ld * LDT + tt] = c;
     }
     __syncthreads();
     // ---- scan: wave w handles envs w, w+4, ... ; lane owns steps [lo, hi) of the chunk ----
     const int seg = (len + 63) >> 6;
-    for (int e = wave; e < ENV_TILE; e += GAE_THREADS / 64) {
+    // The wave's ENV_TILE / 4 envs advance in lockstep: their lane-composition scans are independent chains, so the
+    // cross-lane shuffles of one env travel under those of the others (12 dependent shuffles per env otherwise).
+    constexpr int EPW = ENV_TILE / (GAE_THREADS / 64);
+    const int lo = min(lane * seg, len), hi = min(lo + seg, len);
+    float fa[EPW], fb[EPW];                       // y_lo = fa + fb * y_hi
+#pragma unroll
+    for (int u = 0; u < EPW; ++u) {
+      const float* pa = s_a + (wave + u * (GAE_THREADS / 64)) * LDT;
+      const float* pc = s_c + (wave + u * (GAE_THREADS / 64)) * LDT;
+      fa[u] = 0.f; fb[u] = 1.f;
+      for (int t = hi - 1; t >= lo; --t) { fa[u] = pa[t] + pc[t] * fa[u]; fb[u] = pc[t] * fb[u]; }
+    }
+    // inclusive suffix scan over lanes: S_l = F_l o F_{l+1} o ... o F_63
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      float a2[EPW], b2[EPW];
+#pragma unroll
+      for (int u = 0; u < EPW; ++u) { a2[u] = __shfl_down(fa[u], o, 64); b2[u] = __shfl_down(fb[u], o, 64); }
+      if (lane + o < 64) {
+#pragma unroll
+        for (int u = 0; u < EPW; ++u) { fa[u] = fa[u] + fb[u] * a2[u]; fb[u] = fb[u] * b2[u]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EPW; ++u) {
+      const int e = wave + u * (GAE_THREADS / 64);
       float* pa = s_a + e * LDT;
       const float* pc = s_c + e * LDT;
-      const int lo = min(lane * seg, len), hi = min(lo + seg, len);
-      float fa = 0.f, fb = 1.f;                 // y_lo = fa + fb * y_hi
-      for (int t = hi - 1; t >= lo; --t) { fa = pa[t] + pc[t] * fa; fb = pc[t] * fb; }
-      // inclusive suffix scan over lanes: S_l = F_l o F_{l+1} o ... o F_63
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const float a2 = __shfl_down(fa, o, 64), b2 = __shfl_down(fb, o, 64);
-        if (lane + o < 64) { fa = fa + fb * a2; fb = fb * b2; }
-      }
       const float carry = s_carry[e];
-      const float a_nx = __shfl_down(fa, 1, 64), b_nx = __shfl_down(fb, 1, 64);
+      const float a_nx = __shfl_down(fa[u], 1, 64), b_nx = __shfl_down(fb[u], 1, 64);
       float y = (lane == 63) ? carry : (a_nx + b_nx * carry);   // value entering this lane's run
       for (int t = hi - 1; t >= lo; --t) { y = pa[t] + pc[t] * y; pa[t] = y; }
-      const float y0 = __shfl(fa, 0, 64) + __shfl(fb, 0, 64) * carry;
+      const float y0 = __shfl(fa[u], 0, 64) + __shfl(fb[u], 0, 64) * carry;
       if (lane == 0) s_carry[e] = y0;
     }
     __syncthreads();
-    // ---- write back ----
-    for (int tt = t_ld; tt < len; tt += GAE_THREADS / ENV_TILE) {
-      if (n_ld < N) {
+    // ---- write back (values still in the staging registers: no second read of V) ----
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      const int tt = t_ld + q * (GAE_THREADS / ENV_TILE);
+      if (tt < len && n_ld < N) {
         const size_t i = (size_t)(t_lo + tt) * N + n_ld;
-        const float y = s_a[e_ld * LDT + tt], v = val[i];
+        const float y = s_a[e_ld * LDT + tt], v = lv[q];
         if (MODE == 0) { adv[i] = y; ret[i] = y + v; }
         else           { ret[i] = y; adv[i] = y - v; }
       }
