@@ -340,7 +340,7 @@ int trl_comm_peer_enable(trl_comm_t* comm, int on);   /* 0 after a failed self-c
 int trl_comm_has_rccl(const trl_comm_t* comm);
 int trl_comm_error(trl_comm_t* comm);
 int trl_comm_destroy(trl_comm_t* comm);
-/* buf <- SUM over ranks, in place, n floats (C1).  Peer transport up to 4096 floats, RCCL beyond. */
+/* buf <- SUM over ranks, in place, n floats (C1).  Peer transport up to 12 288 floats, RCCL beyond. */
 int trl_allreduce_sum_f32(float* buf, int64_t n, trl_comm_t* comm, void* stream);
 /* buf <- reduction over ranks, in place, n doubles (C2 / C3): element i is MAXed when bit (i % period) of
  * max_mask is set, SUMmed otherwise (the {sum, sum of squares, max, -min} rows of trl_adv_stats_f64 are

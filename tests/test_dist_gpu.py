@@ -116,6 +116,27 @@ def test_one_rank_rccl_communicator_with_peer_transport(tmp_path):
     np.testing.assert_allclose(forced["infos"], single["infos"], rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+def test_abi_collectives_small_mid_large_and_graph_replay(tmp_path, world, backend):
+    """trl_allreduce_sum_f32 / trl_allreduce_f64 through torchrl_amd.dist on their own: the statistics region (<= 4096 words),
+    the gradient region (<= 12 288 floats), beyond it (RCCL on the nccl group, torch.distributed on the gloo one), the
+    mixed SUM / MAX statistics rows, and a captured all-reduce replayed three times."""
+    outs = _run(world, tmp_path, "_dist_gpu_worker_comm.py", (backend,))
+    tot = sum(r + 1 for r in range(world))
+    for r, o in enumerate(outs):
+        for n in (1, 100, 4096, 4097, 11085, 12288, 20000):
+            want = (np.arange(n, dtype=np.float32) % 13 - 6) * tot
+            assert np.array_equal(o["f32_%d" % n], want), (r, n)
+        raw = o["adv_raw"]
+        assert np.all(raw[:, 0] == tot) and np.all(raw[:, 1] == sum((q + 1.0) ** 2 for q in range(world)))
+        assert np.all(raw[:, 2] == world - 1 - 5.0) and np.all(raw[:, 3] == -2.0)
+        info = o["info"]
+        for c in range(24):
+            assert np.all(info[:, c] == (tot if c in (0, 1, 2, 7, 12, 13) else world)), c
+        assert o["max"][0] == world - 0.5
+        assert np.all(o["graph"] == tot)
+
+
 def test_two_ranks_share_the_observation_normaliser(tmp_path):
     """obs_norm with env shards: every step the ranks pool their batch moments (all-reduce) before the Chan merge, so
     both hold the statistics of ALL envs -- the single process keeps them inside the cooperative rollout kernel."""

@@ -207,6 +207,25 @@ __global__ __launch_bounds__(256) void xr_allreduce_kernel(T* __restrict__ buf, 
   }
 }
 
+// Mid-size float vectors (up to TRL_XR_CAP_GRAD: the PPO gradient and anything like it) through the GRADIENT region, with
+// the same epoch counter (ctl[4]) and slot arithmetic as the exchange inside trl_ppo_reduce_adam_xrank_f32 -- which this
+// kernel therefore also exercises in the communicator's self-check.  ctl[5] is its block ticket.
+__global__ __launch_bounds__(256) void xr_allreduce_grad_kernel(float* __restrict__ buf, int n, XrArgs x) {
+  const unsigned epoch = __hip_atomic_load(x.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool act = i < n;
+  const float v = xr_allsum_f32(x, epoch, act ? i : 0, act ? buf[i] : 0.0f, act);
+  if (act) buf[i] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned before = __hip_atomic_fetch_add(x.ctl + 5, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == gridDim.x - 1) {
+      __hip_atomic_store(x.ctl + 5, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(x.ctl + 4, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 template <typename T, int WORDS>
 static int launch_small(T* buf, int64_t n, int period, unsigned long long mask, trl_comm_t* c, hipStream_t s) {
   hipLaunchKernelGGL((xr_allreduce_kernel<T, WORDS>), dim3(trl_ceil_div(n, 256)), dim3(256), 0, s, buf, (int)n, period, mask, c->xr);
@@ -215,12 +234,17 @@ static int launch_small(T* buf, int64_t n, int period, unsigned long long mask, 
 }
 
 // In-place SUM of n floats over all ranks, on `stream` (C1 of SURVEY.md 8(e)).  Latency transport for n up to
-// TRL_XR_CAP_SMALL words when the peers are mapped, RCCL ring otherwise.
+// TRL_XR_CAP_GRAD (12 288) floats when the peers are mapped, RCCL ring otherwise.
 extern "C" int trl_allreduce_sum_f32(float* buf, int64_t n, trl_comm_t* c, void* stream) {
   TRL_REQUIRE(c && n >= 0, "null communicator / negative size");
   if (n == 0) return TRL_OK;
   TRL_REQUIRE(buf, "null pointer");
   if (c->peers_ready && n <= TRL_XR_CAP_SMALL) return launch_small<float, 1>(buf, n, 1, 0ull, c, (hipStream_t)stream);
+  if (c->peers_ready && n <= TRL_XR_CAP_GRAD) {
+    hipLaunchKernelGGL(xr_allreduce_grad_kernel, dim3(trl_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, buf, (int)n, c->xr);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+  }
   if (c->rccl) {
     const int e = g_rccl.AllReduce(buf, buf, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->rccl, (hipStream_t)stream);
     if (e) { trl_set_error("ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return 1000 + e; }

@@ -20,7 +20,7 @@ struct XrArgs {                                    // passed by value to kernels
   int rank, world;
   unsigned long long* peer[TRL_MAX_RANKS];         // base of every rank's buffer as mapped into THIS process
   unsigned* ctl;                                   // local control words: [0] small-region epochs done, [1] ticket, [2] error,
-};                                                 //                      [4] gradient-region epochs done
+};                                                 //                      [4] gradient-region epochs done, [5] its block ticket
 
 struct trl_comm;
 const XrArgs* trl_comm_xr(const trl_comm* c);      // device-side view of a communicator whose peers are mapped, else null

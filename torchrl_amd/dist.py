@@ -34,7 +34,8 @@ _FORCE = os.environ.get("TRL_FORCE_COLLECTIVES", "0") == "1"
 _comm = None            # ctypes handle of the trl_comm_t
 _peer_ok = False        # peers mapped AND the self-check passed on every rank
 _has_rccl = False
-_SMALL_CAP = 4096       # TRL_XR_CAP_SMALL: 32-bit words per message of the peer transport
+_SMALL_CAP = 4096       # TRL_XR_CAP_SMALL: 32-bit words per message of the peer transport (statistics region)
+_GRAD_CAP = 12288       # TRL_XR_CAP_GRAD: floats per message of its gradient region
 
 
 def initialized():
@@ -151,8 +152,12 @@ def _self_check(dev):
             d[:, 3] = -(r + 0.25)
             if lib.trl_allreduce_f64(d.data_ptr(), d.numel(), 4, 0xC, _comm, stream) != 0:
                 return False
+            g = (torch.arange(11085, device=dev, dtype=torch.float32) % 61 - 30) * (0.5 * (r + 1) + rep)   # gradient region
+            if lib.trl_allreduce_sum_f32(g.data_ptr(), g.numel(), _comm, stream) != 0:
+                return False
+            g_want = (torch.arange(11085, device=dev, dtype=torch.float32) % 61 - 30) * sum(0.5 * (q + 1) + rep for q in range(w))
             torch.cuda.synchronize(dev)
-            if lib.trl_comm_error(_comm) != 0 or not torch.equal(x, want):
+            if lib.trl_comm_error(_comm) != 0 or not torch.equal(x, want) or not torch.equal(g, g_want):
                 return False
             if not (bool((d[:, :2] == sum(q + 1.5 + rep for q in range(w))).all()) and bool((d[:, 2] == w - 1 + 1.5 + rep).all())
                     and bool((d[:, 3] == -0.25).all())):
@@ -189,7 +194,7 @@ def _via_abi(t, period, max_mask):
     # the peer transport is plain kernel launches (capturable); the library's RCCL communicator is only used outside
     # stream capture -- captured RCCL calls go through torch.distributed's communicator, the one bench.py probes
     rccl_ok = _has_rccl and not torch.cuda.is_current_stream_capturing()
-    if t.dtype == torch.float32 and max_mask == 0 and ((_peer_ok and n <= _SMALL_CAP) or rccl_ok):
+    if t.dtype == torch.float32 and max_mask == 0 and ((_peer_ok and n <= _GRAD_CAP) or rccl_ok):
         _C.check(lib.trl_allreduce_sum_f32(t.data_ptr(), n, _comm, stream), "trl_allreduce_sum_f32")
         return True
     if t.dtype == torch.float64 and ((_peer_ok and 2 * n <= _SMALL_CAP) or (rccl_ok and max_mask == 0)):
