@@ -66,6 +66,10 @@ int trl_gather_rows_f32(const float* src, const int64_t* row_idx, float* dst,
                         int n_rows, int64_t row_elems, int64_t src_rows, void* stream);
 int trl_gather_rows_u8(const uint8_t* src, const int64_t* row_idx, uint8_t* dst,
                        int n_rows, int64_t row_bytes, int64_t src_rows, void* stream);
+/* the same gather for up to 8 keys of one replay sample (random_batch's loop over sample_key, base.py:46-50) in one
+ * launch: dst[k][i, :] = src[k][row_idx[i], :], rows of row_bytes[k] bytes; every src[k] has src_rows rows. */
+int trl_gather_rows_multi(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
+                          const int64_t* row_idx, int n_rows, int64_t src_rows, void* stream);
 
 /* --- K7: per-minibatch advantage statistics --------------------------------
  * replaces advs.mean()/std()/max()/min() of PPO.update (ppo.py:141-144) for

@@ -1,0 +1,120 @@
+"""The epoch's `opt_times` updates launched back to back with ONE read-back of their logged statistics
+(OffRLAlgo.update_per_epoch over `update_deferred` / `resolve_updates`) against the reference's update-by-update loop
+(off_rl_algo.py:33-47): same index stream, same launches, so the info dicts and the parameters are bit-identical;
+and the one-launch multi-key replay gather against per-key gathers."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class _Rec:
+    def __init__(self): self.infos = []
+    def add_update_info(self, d): self.infos.append(dict(d))
+    def add_epoch_info(self, *a, **k): pass
+    def log(self, *a): pass
+    def finish(self): pass
+
+
+def _sac_run(deferred, opt_times=5):
+    from test_fullsize_offpolicy_gpu import build_cfg3
+    pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=256)
+    agent.noise_mode, col.noise_mode = "device", "device"
+    agent.logger = _Rec()
+    agent.opt_times = opt_times
+    torch.manual_seed(5)
+    col.train_one_epoch()
+    np.random.seed(9)
+    for _ in range(2):                                                   # second epoch: the update graph is replayed
+        if deferred:
+            agent.update_per_epoch()
+        else:
+            for _ in range(opt_times):
+                agent._one_update()
+    eng = agent.engine()
+    return agent.logger.infos, eng.flat.cpu().clone(), eng.tflat.cpu().clone(), agent.log_alpha.cpu().clone()
+
+
+def test_sac_epoch_of_deferred_updates_equals_update_by_update():
+    ia, fa, ta, la = _sac_run(False)
+    ib, fb, tb, lb = _sac_run(True)
+    assert len(ia) == len(ib) == 10
+    assert torch.equal(fa, fb) and torch.equal(ta, tb) and torch.equal(la, lb)
+    for x, y in zip(ia, ib):
+        assert x == y
+    assert len({i["Training/qf1_loss"] for i in ib}) == 10               # every slot carries its own update
+
+
+@pytest.mark.parametrize("Q", [1, 8])
+def test_dqn_epoch_of_deferred_updates_equals_update_by_update(Q):
+    from test_fullsize_offpolicy_gpu import build_cfg5
+    res = []
+    for deferred in (False, True):
+        qf, pf, env, buf, col, agent = build_cfg5(Q)
+        agent.logger = _Rec()
+        agent.opt_times = 4
+        np.random.seed(2)
+        col.train_one_epoch()
+        np.random.seed(3)
+        if deferred:
+            agent.update_per_epoch()
+        else:
+            for _ in range(4):
+                agent._one_update()
+        res.append((agent.logger.infos, agent.engine().flat.cpu().clone(), agent.engine().tflat.cpu().clone()))
+    (ia, fa, ta), (ib, fb, tb) = res
+    assert len(ia) == len(ib) == 4 and torch.equal(fa, fb) and torch.equal(ta, tb)
+    for x, y in zip(ia, ib):
+        assert x == y
+    assert len({i["Training/qf_loss"] for i in ib}) == 4
+
+
+def test_more_pending_updates_than_ring_slots_still_resolve_in_order():
+    from test_fullsize_offpolicy_gpu import build_cfg3
+    pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=64)
+    agent.noise_mode, col.noise_mode = "device", "device"
+    torch.manual_seed(5)
+    col.train_one_epoch()
+    np.random.seed(1)
+    handles = [agent.update_deferred(agent._sample()) for _ in range(70)]          # ring = 64 slots
+    infos = agent.resolve_updates(handles)
+    assert len(infos) == 70 and len({id(h[0]) for h in handles}) == 2
+    assert len({i["Training/qf1_loss"] for i in infos}) == 70
+    one = agent.update(agent._sample())                                  # the plain call keeps working afterwards
+    assert np.isfinite(list(one.values())).all()
+
+
+def test_multi_key_gather_equals_per_key_gathers():
+    from torchrl_amd import _C
+    from torchrl_amd.replay_buffers import BaseReplayBuffer
+    rows, n = 37, 8
+    srcs = [torch.randn(rows, n, 17, device=DEV), torch.randn(rows, n, 17, device=DEV), torch.randn(rows, n, 6, device=DEV),
+            torch.randn(rows, n, 1, device=DEV), (torch.rand(rows, n, 3, 5, device=DEV) * 255).to(torch.uint8)]
+    idx = torch.tensor([36, 0, 5, 5, 12], device=DEV)
+    outs = [torch.empty((5 * n,) + tuple(s.shape[2:]), dtype=s.dtype, device=DEV) for s in srcs]
+    _C.gather_rows_multi(srcs, idx, outs)
+    for s, o in zip(srcs, outs):
+        assert torch.equal(o, s[idx].reshape(o.shape))
+    # out-of-range rows are skipped, never copied from wild memory
+    outs2 = [torch.full_like(o, 7) for o in outs]
+    _C.gather_rows_multi(srcs, torch.tensor([99, 1, -1, 2, 3], device=DEV), outs2)
+    assert torch.equal(outs2[0][:n], torch.full_like(outs2[0][:n], 7)) and torch.equal(outs2[0][n:2 * n], srcs[0][1])
+    with pytest.raises(_C.TrlError):
+        _C.gather_rows_multi(srcs[:2], idx, [outs[0], outs[2]])
+    # the replay buffer's sample uses it: same batch as key-by-key gathers, into caller-owned tensors too
+    buf = BaseReplayBuffer(rows * n, env_nums=n, device=DEV)
+    for key, s in zip(("obs", "next_obs", "acts", "rewards"), srcs):
+        setattr(buf, "_" + key, s); buf._keys.append(key)
+    buf._size = rows
+    np.random.seed(4)
+    got = buf.random_batch(3 * n, ["obs", "next_obs", "acts", "rewards"])
+    np.random.seed(4)
+    pick = torch.as_tensor(np.random.randint(0, rows, 3)).to(DEV)
+    for key, s in zip(("obs", "next_obs", "acts", "rewards"), srcs):
+        assert torch.equal(got[key], s[pick].reshape(got[key].shape)) and got[key].shape[0] == 3 * n
+    static = {"obs": torch.empty(3 * n, 17, device=DEV), "acts": torch.empty(3 * n, 6, device=DEV)}
+    np.random.seed(4)
+    again = buf.random_batch(3 * n, ["obs", "next_obs", "acts", "rewards"], out=static)
+    assert again["obs"] is static["obs"] and torch.equal(static["acts"], got["acts"]) and torch.equal(again["rewards"], got["rewards"])

@@ -107,6 +107,8 @@ SIGNATURES = {
     "trl_discount_reward_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "trl_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "trl_gather_rows_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "trl_gather_rows_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64,
+                                       C.c_void_p]),
     "trl_adv_stats_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "trl_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
@@ -298,6 +300,23 @@ def gather_rows(src, row_idx, out=None):
     check(fn(dev_ptr(src, src.dtype, "src"), dev_ptr(row_idx, torch.int64, "row_idx"),
              dev_ptr(out, src.dtype, "out"), n, row_elems, int(src.shape[0]), stream_ptr(src.device)), name)
     return out
+
+
+def gather_rows_multi(srcs, row_idx, outs):
+    """outs[k][i] = srcs[k][row_idx[i]] for every key k in one launch (all srcs share the leading row count)."""
+    n, k = int(row_idx.numel()), len(srcs)
+    rows = int(srcs[0].shape[0])
+    if any(int(s.shape[0]) != rows for s in srcs):
+        raise TrlError("gather_rows_multi: keys with different row counts")
+    sp, dp, nb = (C.c_void_p * k)(), (C.c_void_p * k)(), (C.c_int64 * k)()
+    for j, (s, o) in enumerate(zip(srcs, outs)):
+        if s.dtype != o.dtype or o.numel() != n * s[0].numel():
+            raise TrlError("gather_rows_multi: out[%d] does not match the batch" % j)
+        sp[j], dp[j] = dev_ptr(s, s.dtype, "src"), dev_ptr(o, o.dtype, "out")
+        nb[j] = s[0].numel() * s.element_size()
+    check(lib().trl_gather_rows_multi(sp, dp, nb, k, dev_ptr(row_idx, torch.int64, "row_idx"), n, rows,
+                                      stream_ptr(srcs[0].device)), "trl_gather_rows_multi")
+    return outs
 
 
 def adv_stats(advs, row_idx_2d, raw_out):

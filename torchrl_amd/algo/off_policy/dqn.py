@@ -56,6 +56,14 @@ class DQN(OffRLAlgo):
         self.training_update_num += 1
         return self.engine().update(batch)
 
+    def update_deferred(self, batch):
+        """`update` without its read-back (see OffRLAlgo.update_per_epoch): returns a handle for `resolve_updates`."""
+        self.training_update_num += 1
+        return self.engine().enqueue(batch)
+
+    def resolve_updates(self, handles):
+        return self.engine().resolve(handles)
+
 
 class QRDQN(DQN):
     def __init__(self, quantile_num=100, **kwargs):
@@ -98,8 +106,27 @@ class _FusedDQN:
         self.sums = torch.zeros(3, dtype=torch.float64, device=self.dev)
         self.A = int(algo.env.action_space.n)
         self.workspace = None
+        self._ring, self._ring_used = None, 0
 
     def update(self, batch):
+        return self.resolve([self.enqueue(batch)])[0]
+
+    def resolve(self, handles):
+        """Info dicts of enqueued updates, in order, after one D2H per ring of loss sums (the only host sync)."""
+        host = {}
+        for h in handles:
+            if id(h[0]) not in host:
+                host[id(h[0])] = h[0].cpu().numpy()
+        if self._ring is not None and all(h[0] is self._ring for h in handles) and len(handles) == self._ring_used:
+            self._ring_used = 0
+        out = []
+        for ring, slot, B, denom, Q, eps in handles:
+            s = host[id(ring)][slot]
+            out.append({'Reward_Mean': s[2] / B, 'Training/qf_loss': s[0] / denom, 'epsilon': eps, 'q_s_a': s[1] / (B * Q)})
+        return out
+
+    def enqueue(self, batch):
+        """Launch one update without waiting for it; its loss sums are copied (stream-ordered) into a ring slot."""
         algo, dev = self.algo, self.dev
         obs, nobs = batch['obs'], batch['next_obs']
         if self.is_mlp:
@@ -158,6 +185,9 @@ class _FusedDQN:
             _C.polyak(self.tflat, self.flat, 1.0)
         dist.all_reduce_sum_(self.sums)
         B, denom = B * dist.world_size(), denom * dist.world_size()
-        s = self.sums.cpu().numpy()
-        return {'Reward_Mean': s[2] / B, 'Training/qf_loss': s[0] / denom, 'epsilon': algo.pf.epsilon,
-                'q_s_a': s[1] / (B * Q)}
+        if self._ring is None or self._ring_used == self._ring.shape[0]:
+            self._ring = torch.zeros(max(64, int(getattr(algo, "opt_times", 1))), 3, dtype=torch.float64, device=dev)
+            self._ring_used = 0
+        slot, self._ring_used = self._ring_used, self._ring_used + 1
+        self._ring[slot].copy_(self.sums, non_blocking=True)
+        return (self._ring, slot, B, denom, Q, algo.pf.epsilon)

@@ -23,16 +23,27 @@ class OffRLAlgo(RLAlgo):
         self.target_hard_update_period = target_hard_update_period
 
     def _one_update(self):
+        self.logger.add_update_info(self.update(self._sample()))
+
+    def _sample(self):
         extra = {}
         static = getattr(self, "static_batch", None)
         if static is not None:
             extra["out"] = static()
-        batch = self.replay_buffer.random_batch(self.batch_size, self.sample_key, **extra)
-        self.logger.add_update_info(self.update(batch))
+        return self.replay_buffer.random_batch(self.batch_size, self.sample_key, **extra)
 
     def update_per_epoch(self):
-        for _ in range(self.opt_times):
-            self._one_update()
+        deferred = getattr(self, "update_deferred", None)
+        if deferred is None:
+            for _ in range(self.opt_times):
+                self._one_update()
+        else:
+            # sample -> update x opt_times launched back to back (the host never waits inside the loop, so the next
+            # sample's index upload and launches overlap the running update); the info dicts reach the logger in the
+            # reference's order after one read-back
+            pending = [deferred(self._sample()) for _ in range(self.opt_times)]
+            for info in self.resolve_updates(pending):
+                self.logger.add_update_info(info)
         check = getattr(self.replay_buffer, "check_overrun", None)       # frame-dedup replay: a batch that asked for an
         if check is not None:                                            # overwritten frame fails the epoch, loudly
             check()

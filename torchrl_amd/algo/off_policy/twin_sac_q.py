@@ -88,6 +88,15 @@ class TwinSACQ(OffRLAlgo):
         self.training_update_num += 1
         return self.engine().update(batch)
 
+    def update_deferred(self, batch):
+        """`update` without its read-back: OffRLAlgo.update_per_epoch enqueues all `opt_times` updates of an epoch and
+        resolves their info dicts with one D2H (`resolve_updates`)."""
+        self.training_update_num += 1
+        return self.engine().enqueue(batch)
+
+    def resolve_updates(self, handles):
+        return self.engine().resolve(handles)
+
 
 class _FusedSAC:
     def __init__(self, algo):
@@ -137,6 +146,7 @@ class _FusedSAC:
         self.noise_seed = 0x5AC
         self.step_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.dev)
         self._static, self._graphs, self._seen = {}, {}, set()
+        self._ring, self._ring_used = None, 0
 
     def _ws(self, B):
         need = 2 * max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
@@ -237,7 +247,10 @@ class _FusedSAC:
             self._graphs[key] = graph
             graph.replay()
 
-    def update(self, batch):
+    def enqueue(self, batch):
+        """Launch one update without waiting for it; returns the handle `resolve` turns into the info dict.  The logged
+        statistics of the update are copied (stream-ordered) into a slot of a device ring, so that an epoch's
+        `opt_times` updates need ONE read-back instead of one host sync each."""
         algo, dev, A, D = self.algo, self.dev, self.A, self.D
         B = int(batch['obs'].shape[0])
         st = self.static_batch(B)
@@ -254,15 +267,40 @@ class _FusedSAC:
                 make = lambda m, f: torch.randn(m, f)                    # the CPU generator (reference stream)
             else:
                 self.noise_ctr += 1
+                if dist.world_size() == 1:                               # straight into the graph's input
+                    _C.philox_normal(st[k], self.noise_seed, self.noise_ctr)
+                    continue
                 make = lambda m, f: _C.philox_normal(torch.empty(m, f, device=dev), self.noise_seed, self.noise_ctr)
             st[k].copy_(dist.shard_rows_of_global(make, rows, B // rows, A, dev), non_blocking=True)
         self._run(st, bool(algo.use_soft_update))
         self.step_count += 1
         if not algo.use_soft_update and algo.training_update_num % algo.target_hard_update_period == 0:
             _C.polyak(self.tflat, self.flat[self.sizes[0]:], 1.0)
-        # ---- logging statistics: one read-back, the only host sync of the update ----
+        if self._ring is None or self._ring_used == self._ring.shape[0]:  # full: later handles go to a fresh ring
+            self._ring = torch.zeros(max(64, int(getattr(algo, "opt_times", 1))), self._raw.numel(), dtype=torch.uint8,
+                                     device=dev)
+            self._ring_used = 0
+        slot, self._ring_used = self._ring_used, self._ring_used + 1
+        self._ring[slot].copy_(self._raw, non_blocking=True)
+        return (self._ring, slot, B)
+
+    def resolve(self, handles):
+        """Info dicts of enqueued updates, in order: one D2H per ring (normally one per call), the only host sync."""
+        host = {}
+        for ring, _, _ in handles:
+            if id(ring) not in host:
+                host[id(ring)] = ring.cpu()
+        if self._ring is not None and all(r is self._ring for r, _, _ in handles) and \
+                len(handles) == self._ring_used:
+            self._ring_used = 0                                          # everything outstanding was read: reuse the ring
+        return [self._info(host[id(ring)][slot], B) for ring, slot, B in handles]
+
+    def update(self, batch):
+        return self.resolve([self.enqueue(batch)])[0]
+
+    def _info(self, raw, B):
+        algo, A = self.algo, self.A
         Bg = B * dist.world_size()                                       # the sums were reduced over all ranks
-        raw = self._raw.cpu()
         sums, mom = raw[:32].view(torch.float64).numpy(), raw[32:128].view(torch.float64).view(3, 4).numpy()
         aout, norms = raw[128:136].view(torch.float32).numpy(), raw[136:148].view(torch.float32).numpy()
         w_std, w_mean = algo.policy_std_reg_weight, algo.policy_mean_reg_weight

@@ -6,6 +6,7 @@
 // host-generated int64 index (bit-exact with numpy's legacy RNG, see
 // torchrl/replay_buffers/base.py:44, on_policy.py:76-78).  16-byte vector
 // loads/stores when the row size allows; HBM-bound: row_bytes read + written.
+#include <algorithm>
 #include "trl_common.h"
 
 template <typename VecT>
@@ -26,8 +27,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const VecT* __restrict
 template <typename VecT>
 static int launch_gather(const void* src, const int64_t* idx, void* dst, int n_rows, int64_t row_vecs,
                          int64_t src_rows, hipStream_t s) {
+  // enough workgroups to fill the chip whatever the row count: a cfg 5 sample is ONE 14 MB row (B = env_nums), which
+  // 64 workgroups copied at 1 TB/s
   int bx = (int)((row_vecs + 255) / 256);
-  if (bx > 64) bx = 64;
+  const int cap = std::max(64, (4096 + n_rows - 1) / std::max(n_rows, 1));
+  if (bx > cap) bx = cap;
   if (bx < 1) bx = 1;
   dim3 grid(bx, n_rows), block(256);
   hipLaunchKernelGGL(gather_rows_kernel<VecT>, grid, block, 0, s, (const VecT*)src, idx, (VecT*)dst,
@@ -47,6 +51,46 @@ static int gather_bytes(const void* src, const int64_t* idx, void* dst, int n_ro
   if ((al & 15) == 0) return launch_gather<uint4>(src, idx, dst, n_rows, row_bytes / 16, src_rows, s);
   if ((al & 3) == 0) return launch_gather<uint32_t>(src, idx, dst, n_rows, row_bytes / 4, src_rows, s);
   return launch_gather<uint8_t>(src, idx, dst, n_rows, row_bytes, src_rows, s);
+}
+
+// Several keys of one replay sample in ONE launch (the uniform sample gathers obs / next_obs / acts / rewards /
+// terminals with the same row index: five ~3 us dependent launches otherwise).  blockIdx.z = key.
+#define GATHER_MAX_KEYS 8
+struct GatherSet { const uint8_t* src[GATHER_MAX_KEYS]; uint8_t* dst[GATHER_MAX_KEYS]; int64_t row_bytes[GATHER_MAX_KEYS]; };
+__global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherSet g, const int64_t* __restrict__ idx, int64_t src_rows) {
+  const int row = blockIdx.y, key = blockIdx.z;
+  const int64_t s = idx[row], nb = g.row_bytes[key];
+  if (s < 0 || s >= src_rows) return;
+  const uint8_t* sp = g.src[key] + s * nb;
+  uint8_t* dp = g.dst[key] + (int64_t)row * nb;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, dt = (int64_t)gridDim.x * blockDim.x;
+  if ((((uintptr_t)sp | (uintptr_t)dp | (uintptr_t)nb) & 15) == 0) {
+    for (int64_t i = t0; i < nb / 16; i += dt) reinterpret_cast<uint4*>(dp)[i] = reinterpret_cast<const uint4*>(sp)[i];
+  } else if ((((uintptr_t)sp | (uintptr_t)dp | (uintptr_t)nb) & 3) == 0) {
+    for (int64_t i = t0; i < nb / 4; i += dt) reinterpret_cast<uint32_t*>(dp)[i] = reinterpret_cast<const uint32_t*>(sp)[i];
+  } else {
+    for (int64_t i = t0; i < nb; i += dt) dp[i] = sp[i];
+  }
+}
+extern "C" int trl_gather_rows_multi(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
+                                     const int64_t* row_idx, int n_rows, int64_t src_rows, void* stream) {
+  TRL_REQUIRE(n_keys >= 1 && n_keys <= GATHER_MAX_KEYS, "gather_rows_multi: 1..8 keys");
+  TRL_REQUIRE(n_rows >= 0 && src_rows >= 0 && n_rows <= 65535, "gather_rows_multi: bad row count");
+  if (n_rows == 0) return TRL_OK;
+  TRL_REQUIRE(src && dst && row_bytes && row_idx, "gather_rows_multi: null pointer");
+  GatherSet g;
+  int64_t widest = 0;
+  for (int k = 0; k < n_keys; ++k) {
+    TRL_REQUIRE(src[k] && dst[k] && row_bytes[k] > 0, "gather_rows_multi: null key / empty row");
+    g.src[k] = (const uint8_t*)src[k]; g.dst[k] = (uint8_t*)dst[k]; g.row_bytes[k] = row_bytes[k];
+    widest = std::max(widest, row_bytes[k]);
+  }
+  int bx = (int)((widest / 16 + 255) / 256);
+  const int cap = std::max(64, (4096 + n_rows - 1) / n_rows);
+  bx = std::min(std::max(bx, 1), cap);
+  hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(bx, n_rows, n_keys), dim3(256), 0, (hipStream_t)stream, g, row_idx, src_rows);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
 }
 
 extern "C" int trl_gather_rows_f32(const float* src, const int64_t* row_idx, float* dst, int n_rows,

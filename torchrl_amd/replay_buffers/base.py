@@ -84,9 +84,30 @@ class BaseReplayBuffer:
         nrows = self._rows_per_batch(batch_size)
         indices = np.random.randint(0, self.num_steps_can_sample(), nrows)
         idx_dev = torch.from_numpy(indices.astype(np.int64)).to(self._device(), non_blocking=True)
-        if out is None:
-            return {key: self._gather(key, idx_dev) for key in sample_key}
-        return {key: self._gather(key, idx_dev, out.get(key)) for key in sample_key}
+        out = out or {}
+        plain = [k for k in sample_key if self._plain_key(k)]
+        if len(plain) < 2 or len(plain) > 8:
+            return {key: self._gather(key, idx_dev, out.get(key)) for key in sample_key}
+        # every plainly stored key in ONE launch (trl_gather_rows_multi); keys a subclass stores differently go alone
+        batch, srcs, dsts = {}, [], []
+        for key in plain:
+            src, dst = getattr(self, "_" + key), out.get(key)
+            if dst is None:
+                dst = torch.empty((nrows * self.env_nums,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+            elif dst.dtype != src.dtype or dst.numel() != nrows * src[0].numel():
+                raise _C.TrlError("random_batch: out[%r] does not match the batch" % key)
+            batch[key] = dst
+            srcs.append(src); dsts.append(dst)
+        _C.gather_rows_multi(srcs, idx_dev, dsts)
+        for key in sample_key:
+            if key not in batch:
+                batch[key] = self._gather(key, idx_dev, out.get(key))
+        return {key: batch[key] for key in sample_key}
+
+    def _plain_key(self, key):
+        """True when `_key[rows, N, ...]` is gathered by time row as stored (subclasses override for keys they keep
+        in another form)."""
+        return True
 
     def num_steps_can_sample(self):
         return self._size

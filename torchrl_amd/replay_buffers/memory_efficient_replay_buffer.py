@@ -59,6 +59,9 @@ class MemoryEfficientReplayBuffer(BaseReplayBuffer):
         _C.frame_stream_append(stacks, self._stream, self._head, None, 1)
 
     # ---- sampling ----
+    def _plain_key(self, key):
+        return key not in self.FRAME_KEYS
+
     def _gather(self, key, idx_dev, out=None):
         if key not in self.FRAME_KEYS:
             return super()._gather(key, idx_dev, out)
