@@ -394,6 +394,18 @@ int trl_linear_bwd_weight_group_f32(int G, const float* const* dy, const float* 
                                     const float* const* x, float* const* dw, float* const* db, float* workspace,
                                     int M, int K, int N, void* stream);
 
+/* Deferred folds: the GEMM half of trl_linear_bwd_weight_group_f32 only.  Problem i leaves
+ * S = trl_linear_bwd_weight_splits(M, K, N) partials of dW at workspace + i * S * (N*K + N), laid out [S][N*K], followed
+ * (want_db != 0) by S partials of db, [S][N].  trl_fold_partials_multi_f32 then folds up to 32 such (partials -> out)
+ * pairs of n[k] floats in splits[k] partials in ONE launch -- every layer of a backward pass at once -- in the summation
+ * order of the folding entry points. */
+int trl_linear_bwd_weight_splits(int M, int K, int N);
+int trl_linear_bwd_weight_partials_group_f32(int G, const float* const* dy, const float* const* y_gate, int gate_act,
+                                             const float* const* x, int want_db, float* workspace, int M, int K,
+                                             int N, void* stream);
+int trl_fold_partials_multi_f32(int count, const float* const* part, float* const* out, const int* n,
+                                const int* splits, void* stream);
+
 /* --- K12 / K13: twin-Q SAC update pieces (torchrl/algo/off_policy/twin_sac_q.py:84-220) ---- */
 /* torch.cat([obs, act], -1) of QNet.forward (torchrl/networks/nets.py:61-68) */
 int trl_concat2_f32(const float* a, const float* b, float* out, int rows, int fa, int fb, void* stream);
@@ -408,6 +420,19 @@ int trl_tanh_gauss_rsample_bwd_f32(const float* head, const float* eps, const fl
                                    const float* d_act, const float* d_logp_ptr, float d_logp_mul,
                                    float w_std, float w_mean, float* d_head, int B, int A,
                                    int tanh_action, void* stream);
+/* the same with d_act = dx1[:, off:off+A] + dx2[:, off:off+A] read in place (rows of ld floats, dx2 may be NULL): the
+ * twin critics' input gradients on [obs | new_a] (twin_sac_q.py:152-155) without a slice-and-add launch */
+int trl_tanh_gauss_rsample_bwd_cols_f32(const float* head, const float* eps, const float* act, const float* dx1,
+                                        const float* dx2, int ld, int off, const float* d_logp_ptr,
+                                        float d_logp_mul, float w_std, float w_mean, float* d_head, int B,
+                                        int A, int tanh_action, void* stream);
+/* both policy samples of one update and the three critic inputs in ONE launch (twin_sac_q.py:93-106, 125-131,
+ * 146-151): (new_a, logp) from head = pf(obs) with eps1, (next_a, next_logp) from head2 = pf(next_obs) with eps2,
+ * x_sa = [obs | acts], x_next = [next_obs | next_a], x_new = [obs | new_a]  (each (B, D + A)) */
+int trl_sac_samples_f32(const float* head, const float* head2, const float* eps1, const float* eps2,
+                        const float* obs, const float* acts, const float* next_obs, float* new_a, float* logp,
+                        float* next_a, float* next_logp, float* x_sa, float* x_next, float* x_new, int B, int D,
+                        int A, int tanh_action, void* stream);
 /* alpha loss + Adam step on log_alpha + alpha = exp(log_alpha) (twin_sac_q.py:111-120).
  * state (4): log_alpha, exp_avg, exp_avg_sq, step; out (2): alpha, alpha_loss */
 int trl_sac_alpha_step_f32(const float* logp, int B, float target_entropy, float lr, float beta1,
@@ -439,6 +464,10 @@ int trl_polyak_f32(float* target, const float* source, int64_t n, float tau, voi
  * each value clamped to [clamp_lo, clamp_hi] first (the logged log_std is the clamped one) */
 int trl_moments_f64(const float* x, int64_t n, int ld, int off, int width, float clamp_lo,
                     float clamp_hi, double* out4, void* stream);
+/* `count` (1..4) of those statistics in one launch: arrays of the arguments above, one entry per statistic */
+int trl_moments_multi_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
+                          const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
+                          void* stream);
 /* N(0,1) fill from the Philox4x32-10 stream (device exploration / rsample noise) */
 int trl_philox_normal_f32(float* out, int64_t n, int64_t seed, int64_t counter, void* stream);
 /* K1 stand-alone: one VecEnv.step of the synthetic env (torchrl/env/vecenv.py:53-61); cur_obs is

@@ -68,6 +68,32 @@ def test_grouped_layer_launches_equal_separate_calls(M, K, N, G):
         assert torch.equal(dws[g], dw) and torch.equal(dbs[g], db)
 
 
+@pytest.mark.parametrize("M,K,N,G", [(4096, 256, 256, 2), (4096, 23, 256, 2), (4096, 256, 1, 2), (300, 17, 12, 1)])
+def test_deferred_folds_equal_the_folding_entry_point(M, K, N, G):
+    """Split weight-gradient GEMMs whose partials are folded later, several layers per launch
+    (trl_linear_bwd_weight_partials_group_f32 + trl_fold_partials_multi_f32), against the entry point that folds at
+    once: the same partials summed in the same order."""
+    from torchrl_amd import _C
+    gen = torch.Generator().manual_seed(M + K + N)
+    r = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    dys, ys, xs = [r(M, N) for _ in range(G)], [r(M, N) for _ in range(G)], [r(M, K) for _ in range(G)]
+    want_w, want_b = [torch.empty(N, K, device=DEV) for _ in range(G)], [torch.empty(N, device=DEV) for _ in range(G)]
+    _C.linear_bwd_weight_group(dys, ys, _C.ACT_RELU, xs, want_w, want_b)
+    need = 2 * G * _C.lib().trl_linear_bwd_weight_workspace(M, K, N)
+    plan = _C.FoldPlan(torch.empty(need, device=DEV))
+    got_w, got_b = [torch.zeros(N, K, device=DEV) for _ in range(G)], [torch.zeros(N, device=DEV) for _ in range(G)]
+    other_w, other_b = [torch.zeros(N, K, device=DEV) for _ in range(G)], [torch.zeros(N, device=DEV) for _ in range(G)]
+    _C.linear_bwd_weight_partials_group(dys, ys, _C.ACT_RELU, xs, got_w, got_b, plan)
+    _C.linear_bwd_weight_partials_group(dys[::-1], ys[::-1], _C.ACT_RELU, xs[::-1], other_w, other_b, plan)   # a second "layer"
+    assert len(plan.entries) == 4 * G
+    plan.run()
+    for g in range(G):
+        assert torch.equal(got_w[g], want_w[g]) and torch.equal(got_b[g], want_b[g])
+        assert torch.equal(other_w[g], want_w[G - 1 - g]) and torch.equal(other_b[g], want_b[G - 1 - g])
+    with pytest.raises(_C.TrlError):
+        _C.linear_bwd_weight_partials_group(dys, ys, _C.ACT_RELU, xs, got_w, got_b, _C.FoldPlan(torch.empty(8, device=DEV)))
+
+
 def test_rsample_fwd_bwd_vs_autograd():
     from torchrl_amd import _C
     B, A = 300, 6
@@ -94,6 +120,66 @@ def test_rsample_fwd_bwd_vs_autograd():
     err = (d_head.cpu() - hr.grad)[okr].abs().max().item()
     assert err < 5e-5 * max(1.0, hr.grad[okr].abs().max().item()), err
     assert d_head[0, A].item() == 0.0 and d_head[1, A + 1].item() == 0.0
+
+
+def test_one_launch_forms_equal_the_separate_kernels():
+    """trl_sac_samples_f32 = 2 x rsample_fwd + 3 x concat2; trl_tanh_gauss_rsample_bwd_cols_f32 = slice_add +
+    rsample_bwd; trl_moments_multi_f64 = 3 x moments: bit for bit (same arithmetic, fewer launches)."""
+    from torchrl_amd import _C
+    B, A, D = 777, 6, 17
+    gen = torch.Generator().manual_seed(8)
+    r = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    head, head2, eps1, eps2, obs, acts, nobs = r(B, 2 * A), r(B, 2 * A), r(B, A), r(B, A), r(B, D), r(B, A), r(B, D)
+    new_a, logp, next_a, next_logp, x_sa, x_next, x_new = _C.sac_samples(head, head2, eps1, eps2, obs, acts, nobs)
+    a1, l1 = _C.rsample_fwd(head, eps1)
+    a2, l2 = _C.rsample_fwd(head2, eps2)
+    assert torch.equal(new_a, a1) and torch.equal(logp, l1) and torch.equal(next_a, a2) and torch.equal(next_logp, l2)
+    assert torch.equal(x_sa, _C.concat2(obs, acts)) and torch.equal(x_next, _C.concat2(nobs, a2))
+    assert torch.equal(x_new, _C.concat2(obs, a1))
+    dx1, dx2, alpha = r(B, D + A), r(B, D + A), torch.tensor([0.4], device=DEV)
+    want = _C.rsample_bwd(head, eps1, a1, _C.slice_add(dx1, dx2, D, A), alpha, 1.0 / B, 1e-3, 2e-3)
+    assert torch.equal(_C.rsample_bwd_cols(head, eps1, a1, dx1, dx2, D, alpha, 1.0 / B, 1e-3, 2e-3), want)
+    one = _C.rsample_bwd(head, eps1, a1, _C.slice_add(dx1, None, D, A), alpha, 1.0 / B, 0.0, 0.0)
+    assert torch.equal(_C.rsample_bwd_cols(head, eps1, a1, dx1, None, D, alpha, 1.0 / B, 0.0, 0.0), one)
+    got, ref = torch.zeros(3, 4, dtype=torch.float64, device=DEV), torch.zeros(3, 4, dtype=torch.float64, device=DEV)
+    inf = float("inf")
+    _C.moments_multi([(head, got[0], 2 * A, A, A, -20.0, 2.0), (logp, got[1], 1, 0, 1, -inf, inf),
+                      (head, got[2], 2 * A, 0, A, -inf, inf)])
+    _C.moments(head, ref[0], ld=2 * A, off=A, width=A, lo=-20.0, hi=2.0)
+    _C.moments(logp, ref[1], ld=1)
+    _C.moments(head, ref[2], ld=2 * A, off=0, width=A)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("n", [300, 40000, 400000])
+def test_clip_adam_advances_the_device_step_itself(n):
+    """Device-resident step state {t, beta1^t, beta2^t}: small grids advance it themselves (block count), large grids
+    through the one-thread tick launch; three calls leave exactly three steps of torch.optim.Adam."""
+    from torchrl_amd import _C
+    gen = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=gen)
+    gs = [torch.randn(n, generator=gen) for _ in range(3)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    p, g = p0.to(DEV).clone(), torch.zeros(n, device=DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=DEV)
+    a = _C.AdamArgs()
+    a.params, a.grads, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+    a.n_groups = 1
+    a.group_sizes[0] = n
+    a.group_lr[0] = 1e-2
+    a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = 0.0, 0.9, 0.999, 1e-8, 1.0
+    a.step_count, a.norms_out, a.step_state = 0, None, state.data_ptr()
+    for k in range(3):
+        g.copy_(gs[k])
+        _C.clip_adam(a, torch.device(DEV))
+        ref.grad = gs[k].clone()
+        opt.step()
+        st = state.cpu()
+        assert st[0].item() == k + 1 and abs(st[1].item() - float(np.float32(0.9)) ** (k + 1)) < 1e-12
+        assert state[3:].view(torch.int32)[0].item() == 0               # the block counter is back at zero
+    assert (p.cpu() - ref.detach()).abs().max().item() < 2e-6
 
 
 def sac_state(g, prefix):

@@ -160,6 +160,10 @@ SIGNATURES = {
     "trl_concat2_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_tanh_gauss_rsample_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_tanh_gauss_rsample_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float] * 3 + [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_tanh_gauss_rsample_bwd_cols_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_void_p] + [C.c_float] * 3 +
+                                            [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int] * 4 + [C.c_void_p]),
+    "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
     "trl_collector_bookkeep_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_sac_alpha_step_f32": (C.c_int, [C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_void_p] * 3),
     "trl_sac_losses_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
@@ -207,6 +211,10 @@ SIGNATURES = {
     "trl_linear_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_linear_bwd_weight_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "trl_linear_bwd_weight_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "trl_linear_bwd_weight_partials_group_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                          C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_fold_partials_multi_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),
     "trl_linear_bwd_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
@@ -539,6 +547,54 @@ def linear_bwd_weight_group(dys, y_gates, gate_act, xs, dws, dbs, workspace=None
                                                 stream_ptr(dys[0].device)), "trl_linear_bwd_weight_group_f32")
 
 
+class FoldPlan:
+    """Weight-gradient folds deferred to ONE launch at the end of a backward pass: `linear_bwd_weight_group(...,
+    plan=)` runs only the split GEMM, leaving its partials in a slice of the plan's workspace, and `run()` folds every
+    recorded (partials -> dW / db view) pair with trl_fold_partials_multi_f32."""
+
+    def __init__(self, workspace):
+        self.ws, self.used, self.entries = workspace, 0, []
+
+    def take(self, n):
+        if self.used + n > self.ws.numel():
+            raise TrlError("FoldPlan: workspace of %d floats is too small (need %d more)" % (self.ws.numel(), n))
+        out = self.ws[self.used:self.used + n]
+        self.used += n
+        return out
+
+    def run(self):
+        k = len(self.entries)
+        if k == 0:
+            return
+        for lo in range(0, k, 32):
+            chunk = self.entries[lo:lo + 32]
+            c = len(chunk)
+            parts, outs, ns, sp = (C.c_void_p * c)(), (C.c_void_p * c)(), (C.c_int * c)(), (C.c_int * c)()
+            for j, (part, out, n, splits) in enumerate(chunk):
+                parts[j], outs[j], ns[j], sp[j] = dev_ptr(part, name="partials"), dev_ptr(out, name="grad view"), n, splits
+            check(lib().trl_fold_partials_multi_f32(c, parts, outs, ns, sp, stream_ptr(self.ws.device)),
+                  "trl_fold_partials_multi_f32")
+        self.entries, self.used = [], 0
+
+
+def linear_bwd_weight_partials_group(dys, y_gates, gate_act, xs, dws, dbs, plan):
+    G = len(dys)
+    M, N, K = int(dys[0].shape[0]), int(dys[0].shape[1]), int(xs[0].shape[1])
+    splits = lib().trl_linear_bwd_weight_splits(M, K, N)
+    per = splits * (N * K + N)
+    ws = plan.take(G * per)
+    want_db = dbs is not None and dbs[0] is not None
+    check(lib().trl_linear_bwd_weight_partials_group_f32(G, _ptrs(dys, "dy"), _ptrs(y_gates, "y_gate", True), gate_act,
+                                                         _ptrs(xs, "x"), int(want_db), dev_ptr(ws, name="workspace"),
+                                                         M, K, N, stream_ptr(dys[0].device)),
+          "trl_linear_bwd_weight_partials_group_f32")
+    for i in range(G):
+        base = i * per
+        plan.entries.append((ws[base:base + splits * N * K], dws[i], N * K, splits))
+        if want_db:
+            plan.entries.append((ws[base + splits * N * K:base + per], dbs[i], N, splits))
+
+
 def linear_bwd_input(dy, y_gate, gate_act, w):
     M, N = int(dy.shape[0]), int(dy.shape[1])
     K = int(w.shape[1])
@@ -598,6 +654,33 @@ def rsample_bwd(head, eps, act, d_act, d_logp_ptr, d_logp_mul, w_std, w_mean, ta
     return d_head
 
 
+def rsample_bwd_cols(head, eps, act, dx1, dx2, off, d_logp_ptr, d_logp_mul, w_std, w_mean, tanh_action=True):
+    """rsample_bwd with d_act = dx1[:, off:off+A] + dx2[:, off:off+A] read in place (dx2 may be None)."""
+    B, A = int(eps.shape[0]), int(eps.shape[1])
+    d_head = torch.empty((B, 2 * A), dtype=torch.float32, device=head.device)
+    check(lib().trl_tanh_gauss_rsample_bwd_cols_f32(
+        dev_ptr(head, name="head"), dev_ptr(eps, name="eps"), dev_ptr(act, name="act"), dev_ptr(dx1, name="dx1"),
+        dev_ptr(dx2, name="dx2", allow_none=True), int(dx1.shape[1]), int(off),
+        dev_ptr(d_logp_ptr, name="d_logp_ptr", allow_none=True), float(d_logp_mul), float(w_std), float(w_mean),
+        dev_ptr(d_head, name="d_head"), B, A, int(bool(tanh_action)), stream_ptr(head.device)),
+        "trl_tanh_gauss_rsample_bwd_cols_f32")
+    return d_head
+
+
+def sac_samples(head, head2, eps1, eps2, obs, acts, next_obs, tanh_action=True):
+    """(new_a, logp, next_a, next_logp, x_sa, x_next, x_new) of one SAC update in one launch."""
+    B, A, D = int(eps1.shape[0]), int(eps1.shape[1]), int(obs.shape[1])
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=head.device)
+    new_a, logp, next_a, next_logp = f(B, A), f(B), f(B, A), f(B)
+    x_sa, x_next, x_new = f(B, D + A), f(B, D + A), f(B, D + A)
+    ins = [dev_ptr(t, name=n) for t, n in ((head, "head"), (head2, "head2"), (eps1, "eps1"), (eps2, "eps2"), (obs, "obs"),
+                                           (acts, "acts"), (next_obs, "next_obs"))]
+    outs = [dev_ptr(t, name="out") for t in (new_a, logp, next_a, next_logp, x_sa, x_next, x_new)]
+    check(lib().trl_sac_samples_f32(*ins, *outs, B, D, A, int(bool(tanh_action)), stream_ptr(head.device)),
+          "trl_sac_samples_f32")
+    return new_a, logp, next_a, next_logp, x_sa, x_next, x_new
+
+
 def sac_alpha_step(logp, target_entropy, lr, state, out, beta1=0.9, beta2=0.999, eps=1e-8):
     check(lib().trl_sac_alpha_step_f32(dev_ptr(logp, name="logp"), int(logp.numel()), float(target_entropy),
                                        float(lr), beta1, beta2, eps, dev_ptr(state, name="state"),
@@ -632,6 +715,21 @@ def moments(x, out4, ld=None, off=0, width=None, lo=float("-inf"), hi=float("inf
     width = ld - off if width is None else width
     check(lib().trl_moments_f64(dev_ptr(x, name="x"), int(x.numel()), ld, off, width, lo, hi,
                                 dev_ptr(out4, torch.float64, "out4"), stream_ptr(x.device)), "trl_moments_f64")
+
+
+def moments_multi(specs):
+    """Several `moments` in one launch; specs: up to 4 of (x, out4, ld, off, width, lo, hi)."""
+    k = len(specs)
+    xs, outs = (C.c_void_p * k)(), (C.c_void_p * k)()
+    ns, lds, offs, ws = (C.c_int64 * k)(), (C.c_int * k)(), (C.c_int * k)(), (C.c_int * k)()
+    los, his = (C.c_float * k)(), (C.c_float * k)()
+    for j, (x, out4, ld, off, width, lo, hi) in enumerate(specs):
+        ld = int(x.shape[-1]) if ld is None else ld
+        xs[j], outs[j] = dev_ptr(x, name="x"), dev_ptr(out4, torch.float64, "out4")
+        ns[j], lds[j], offs[j], ws[j] = int(x.numel()), ld, off, (ld - off if width is None else width)
+        los[j], his[j] = lo, hi
+    check(lib().trl_moments_multi_f64(k, xs, ns, lds, offs, ws, los, his, outs, stream_ptr(specs[0][0].device)),
+          "trl_moments_multi_f64")
 
 
 def philox_normal(out, seed, counter):

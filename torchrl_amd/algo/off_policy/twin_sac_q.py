@@ -149,8 +149,8 @@ class _FusedSAC:
         self._ring, self._ring_used = None, 0
 
     def _ws(self, B):
-        need = 2 * max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
-                       for ls in self.layers for w, _ in ls)               # x2: the twin critics' grouped weight gradient
+        need = sum(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
+                   for ls in self.layers for w, _ in ls)                  # every layer's partials live until the one fold
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, device=self.dev)
         return self.workspace
@@ -178,13 +178,14 @@ class _FusedSAC:
         tanh_action = bool(algo.pf.tanh_action)
         # ---- policy on obs and next_obs (one grouped launch per layer), both samples ----
         (head, head2), (tape_pf, _) = ops.mlp_forward_group([pf_l, pf_l], [obs, nobs], self.act)
-        new_a, logp = _C.rsample_fwd(head, eps1, tanh_action)
-        next_a, next_logp = _C.rsample_fwd(head2, eps2, tanh_action)
+        # both samples (distribution.py:67-70 order) and the three critic inputs [obs | acts], [next_obs | next_a],
+        # [obs | new_a]: one launch
+        new_a, logp, next_a, next_logp, x_sa, x_next, x_new = _C.sac_samples(head, head2, eps1, eps2, obs, acts, nobs,
+                                                                             tanh_action)
         # ---- temperature ----
         if algo.automatic_entropy_tuning:                                # mean over the GLOBAL batch (all ranks' samples)
             _C.sac_alpha_step(dist.all_gather_cat(logp), algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
         # ---- all six critic passes as one group: Q1/Q2(s, a), target Q1/Q2(s', a'), Q1/Q2(s, new a) ----
-        x_sa, x_next, x_new = _C.concat2(obs, acts), _C.concat2(nobs, next_a), _C.concat2(obs, new_a)
         (q1p, q2p, tq1, tq2, q1n, q2n), (tape_q1, tape_q2, _, _, tape_q1n, tape_q2n) = ops.mlp_forward_group(
             [q1_l, q2_l, self.tlayers[0], self.tlayers[1], q1_l, q2_l], [x_sa, x_sa, x_next, x_next, x_new, x_new], self.act)
         alpha = self.alpha_out[0:1]                                      # re-read AFTER the alpha step, as the reference does
@@ -192,11 +193,12 @@ class _FusedSAC:
                                              algo.discount, self.sums)
         # ---- policy gradient: through both Q nets to the action, then through the sampler ----
         dx1, dx2 = ops.mlp_backward_group([tape_q1n, tape_q2n], [dq1n, dq2n], grads_list=None, need_input=True)
-        d_act = _C.slice_add(dx1, dx2, D, A)
-        d_head = _C.rsample_bwd(head, eps1, new_a, d_act, alpha, 1.0 / B, algo.policy_std_reg_weight,
-                                algo.policy_mean_reg_weight, tanh_action)
-        ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], workspace=ws)
-        ops.mlp_backward_group([tape_q1, tape_q2], [dq1, dq2], grads_list=[self.gviews[1], self.gviews[2]], workspace=ws)
+        d_head = _C.rsample_bwd_cols(head, eps1, new_a, dx1, dx2, D, alpha, 1.0 / B, algo.policy_std_reg_weight,
+                                     algo.policy_mean_reg_weight, tanh_action)    # d_act = (dx1 + dx2)[:, D:]
+        plan = _C.FoldPlan(ws)                                           # weight gradients: split GEMMs now, ONE fold below
+        ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], plan=plan)
+        ops.mlp_backward_group([tape_q1, tape_q2], [dq1, dq2], grads_list=[self.gviews[1], self.gviews[2]], plan=plan)
+        plan.run()
         # ---- optimiser steps (pf, qf1, qf2) and target update ----
         a = _C.AdamArgs()
         a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
@@ -218,9 +220,10 @@ class _FusedSAC:
         # ---- logging statistics (over the global batch) ----
         dist.all_reduce_sum_(self.sums)
         head_g, logp_g = dist.all_gather_cat(head), dist.all_gather_cat(logp)
-        _C.moments(head_g, self.mom[0], ld=2 * A, off=A, width=A, lo=-20.0, hi=2.0)   # clamped log_std
-        _C.moments(logp_g, self.mom[1], ld=1)
-        _C.moments(head_g, self.mom[2], ld=2 * A, off=0, width=A)
+        inf = float("inf")
+        _C.moments_multi([(head_g, self.mom[0], 2 * A, A, A, -20.0, 2.0),              # clamped log_std
+                          (logp_g, self.mom[1], 1, 0, 1, -inf, inf),
+                          (head_g, self.mom[2], 2 * A, 0, A, -inf, inf)])
 
     def _lrs(self):
         algo = self.algo

@@ -371,8 +371,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
 }
 
 // fixed-order fold of split partials: out[e] = sum_s part[s][e]; a second segment (the bias gradient) rides along.
-// A workgroup owns 64 outputs; its 4 waves each sum every 4th split, then the 4 slices are added in order.
+// A workgroup owns 64 outputs; its W waves (4, or 16 when there are many splits and few outputs -- a conv layer's
+// weight gradient is a few thousand floats in hundreds of partials, and 4 waves x 65 workgroups walked them for 32 us)
+// each sum every W-th split, then the W slices are added in order.
 #define FOLD_OUT 64
+#define FOLD_MAX_WAVES 16
 struct FoldGroup { const float* part; float* out; const float* part2; float* out2; };
 struct FoldDev {
   int n, n2, splits;
@@ -380,21 +383,29 @@ struct FoldDev {
   int perm_c, perm_khw;                            // conv weight gradient computed in (i, j, c) column order
   FoldGroup grp[GEMM_MAX_GROUPS];                  // problem blockIdx.y
 };
-__global__ __launch_bounds__(256) void fold_partials_kernel(FoldDev f) {
-  __shared__ float sl[4][FOLD_OUT];
+__global__ __launch_bounds__(64 * FOLD_MAX_WAVES) void fold_partials_kernel(FoldDev f) {
+  __shared__ float sl[FOLD_MAX_WAVES][FOLD_OUT];
   const FoldGroup& q = f.grp[blockIdx.y];
-  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6, waves = blockDim.x >> 6;
   int e = blockIdx.x * FOLD_OUT + lane;
   const bool second = e >= f.n;                    // per lane: a workgroup may straddle the two segments
   const float* p = second ? q.part2 : q.part;
   const int nn = second ? f.n2 : f.n, ee = second ? e - f.n : e;
   float a = 0.0f;
-  if (ee < nn)
-    for (int s = slice; s < f.splits; s += 4) a += p[(size_t)s * nn + ee];
+  if (ee < nn) {
+    int s = slice;
+    for (; s + 3 * waves < f.splits; s += 4 * waves) {           // 4 loads in flight, added in split order
+      const float x0 = p[(size_t)s * nn + ee], x1 = p[(size_t)(s + waves) * nn + ee];
+      const float x2 = p[(size_t)(s + 2 * waves) * nn + ee], x3 = p[(size_t)(s + 3 * waves) * nn + ee];
+      a += x0; a += x1; a += x2; a += x3;
+    }
+    for (; s < f.splits; s += waves) a += p[(size_t)s * nn + ee];
+  }
   sl[slice][lane] = a;
   __syncthreads();
   if (slice == 0 && ee < nn) {
     float v = (sl[0][lane] + sl[1][lane]) + (sl[2][lane] + sl[3][lane]);
+    for (int w = 4; w < waves; w += 4) v += (sl[w][lane] + sl[w + 1][lane]) + (sl[w + 2][lane] + sl[w + 3][lane]);
     if (!second && f.n_cols > 0) {
       if (f.bias) v += f.bias[ee % f.n_cols];
       if (f.act == TRL_ACT_TANH) v = trl_tanh(v);
@@ -410,7 +421,57 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(FoldDev f) {
 }
 
 static int launch_fold(FoldDev f, int groups, hipStream_t s) {
-  hipLaunchKernelGGL(fold_partials_kernel, dim3(trl_ceil_div((int64_t)f.n + f.n2, FOLD_OUT), groups), dim3(256), 0, s, f);
+  const int blocks = trl_ceil_div((int64_t)f.n + f.n2, FOLD_OUT);
+  // many splits behind few workgroups: 16 waves share them (latency-bound walk); otherwise 4
+  const int waves = (f.splits >= 32 && (int64_t)blocks * groups < 2048) ? FOLD_MAX_WAVES : 4;
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(blocks, groups), dim3(64 * waves), 0, s, f);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// Several independent folds in ONE launch: the weight (and bias) gradients of every layer of a backward pass leave
+// their partials in place (trl_linear_bwd_weight_partials_group_f32) and are folded together at the end -- a 256-wide
+// MLP's six per-layer folds are ~5 us of dependent launch each for a few hundred KB of work.
+#define FOLD_MULTI_MAX 32
+struct FoldMulti {
+  int count;
+  int first_block[FOLD_MULTI_MAX + 1];             // entry k owns blocks [first_block[k], first_block[k + 1])
+  int n[FOLD_MULTI_MAX], splits[FOLD_MULTI_MAX];
+  const float* part[FOLD_MULTI_MAX]; float* out[FOLD_MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void fold_multi_kernel(FoldMulti f) {
+  __shared__ float sl[4][FOLD_OUT];
+  int k = 0;
+  while (k + 1 < f.count && (int)blockIdx.x >= f.first_block[k + 1]) ++k;
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = (blockIdx.x - f.first_block[k]) * FOLD_OUT + lane, nn = f.n[k], splits = f.splits[k];
+  const float* p = f.part[k];
+  float a = 0.0f;
+  if (e < nn) {
+    int s = slice;
+    for (; s + 12 < splits; s += 16) {
+      const float x0 = p[(size_t)s * nn + e], x1 = p[(size_t)(s + 4) * nn + e];
+      const float x2 = p[(size_t)(s + 8) * nn + e], x3 = p[(size_t)(s + 12) * nn + e];
+      a += x0; a += x1; a += x2; a += x3;
+    }
+    for (; s < splits; s += 4) a += p[(size_t)s * nn + e];
+  }
+  sl[slice][lane] = a;
+  __syncthreads();
+  if (slice == 0 && e < nn) f.out[k][e] = (sl[0][lane] + sl[1][lane]) + (sl[2][lane] + sl[3][lane]);   // = fold_partials_kernel
+}
+extern "C" int trl_fold_partials_multi_f32(int count, const float* const* part, float* const* out, const int* n,
+                                           const int* splits, void* stream) {
+  TRL_REQUIRE(count >= 1 && count <= FOLD_MULTI_MAX, "fold_multi: 1..32 folds per launch");
+  TRL_REQUIRE(part && out && n && splits, "null pointer");
+  FoldMulti f{};
+  f.count = count;
+  for (int k = 0; k < count; ++k) {
+    TRL_REQUIRE(part[k] && out[k] && n[k] > 0 && splits[k] >= 1, "fold_multi: bad entry");
+    f.part[k] = part[k]; f.out[k] = out[k]; f.n[k] = n[k]; f.splits[k] = splits[k];
+    f.first_block[k + 1] = f.first_block[k] + trl_ceil_div(n[k], FOLD_OUT);
+  }
+  hipLaunchKernelGGL(fold_multi_kernel, dim3(f.first_block[count]), dim3(256), 0, (hipStream_t)stream, f);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -569,7 +630,7 @@ extern "C" int trl_linear_bwd_weight_workspace(int M, int K, int N) {
 template <int CONV>
 static int bwd_weight_impl(int G, const float* const* dy, const float* const* y_gate, int gate_act, const float* const* x,
                            const ConvSrc* cv, float* const* dw, float* const* db, float* workspace, int M, int K, int N,
-                           hipStream_t s) {
+                           hipStream_t s, bool fold = true) {
   TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..8 problems per grouped launch");
   const int split_len = bw_split_len(M, K, N);
   const int splits = trl_ceil_div(M, split_len);
@@ -584,7 +645,7 @@ static int bwd_weight_impl(int G, const float* const* dy, const float* const* y_
   f.n = N * K; f.n2 = want_db ? N : 0; f.splits = splits;
   f.perm_c = CONV == 4 ? cv->C : 0; f.perm_khw = CONV == 4 ? cv->kh * cv->kw : 0;
   for (int i = 0; i < G; ++i) {
-    TRL_REQUIRE(dy[i] && dw[i] && (CONV != 0 || x[i]), "null pointer");
+    TRL_REQUIRE(dy[i] && (dw[i] || !fold) && (CONV != 0 || x[i]), "null pointer");
     TRL_REQUIRE(!gated || y_gate[i], "either every problem of a group is gated or none");
     TRL_REQUIRE(!want_db || db[i], "either every problem of a group wants db or none");
     float* part = workspace + i * per;
@@ -594,7 +655,7 @@ static int bwd_weight_impl(int G, const float* const* dy, const float* const* y_
   }
   g.A = g.grp[0].A; g.B = g.grp[0].B; g.C = g.grp[0].C; g.a_gate = g.grp[0].a_gate; g.colsum = g.grp[0].colsum;
   int rc = launch_gemm<true, false, CONV>(g, splits, s);
-  if (rc) return rc;
+  if (rc || !fold) return rc;
   return launch_fold(f, G, s);
 }
 extern "C" int trl_linear_bwd_weight_f32(const float* dy, const float* y_gate, int gate_act, const float* x, float* dw,
@@ -609,6 +670,23 @@ extern "C" int trl_linear_bwd_weight_group_f32(int G, const float* const* dy, co
   TRL_REQUIRE(M > 0 && K > 0 && N > 0, "bad sizes");
   TRL_REQUIRE(dy && x && dw && workspace, "null pointer array");
   return bwd_weight_impl<0>(G, dy, y_gate, gate_act, x, nullptr, dw, db, workspace, M, K, N, (hipStream_t)stream);
+}
+extern "C" int trl_linear_bwd_weight_splits(int M, int K, int N) {
+  return M <= 0 ? 1 : trl_ceil_div(M, bw_split_len(M, K, N));
+}
+// The GEMM half only: problem i leaves S = trl_linear_bwd_weight_splits(M, K, N) partials of dW at
+// workspace + i * S * (N * K + N) ([S][N * K]) followed, when want_db, by S partials of db ([S][N]); fold them with
+// trl_fold_partials_multi_f32 (same summation order as the folding entry points: bit-identical results).
+extern "C" int trl_linear_bwd_weight_partials_group_f32(int G, const float* const* dy, const float* const* y_gate,
+                                                        int gate_act, const float* const* x, int want_db,
+                                                        float* workspace, int M, int K, int N, void* stream) {
+  TRL_REQUIRE(M > 0 && K > 0 && N > 0, "bad sizes");
+  TRL_REQUIRE(dy && x && workspace && G >= 1 && G <= GEMM_MAX_GROUPS, "null pointer array / bad group count");
+  float* none[GEMM_MAX_GROUPS] = {};
+  float* some[GEMM_MAX_GROUPS];
+  for (int i = 0; i < GEMM_MAX_GROUPS; ++i) some[i] = workspace;     // only "is a bias gradient wanted" is read
+  return bwd_weight_impl<0>(G, dy, y_gate, gate_act, x, nullptr, none, want_db ? some : none, workspace, M, K, N,
+                            (hipStream_t)stream, false);
 }
 // ---- first conv layer on uint8 frames as an implicit GEMM ----
 static int fill_conv(const char* who, const uint8_t* frames, int B, int C, int H, int W, int kh, int kw, int sh, int sw,

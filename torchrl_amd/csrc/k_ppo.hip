@@ -1671,6 +1671,8 @@ extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {
   // Up to 128 blocks count themselves through one atomic (a few hundred ns, hidden under the norm pass); larger
   // parameter blocks would serialise on it (860 blocks: 25 us measured), so they keep the one-thread tick launch.
   const int blocks = trl_ceil_div(total, 256);
+  // (counting RETIRED blocks with a relaxed add at the end of each block instead was measured too: SAC cfg 3, 852 blocks,
+  // 0.392 ms per update against 0.381 ms with the tick launch)
   d.self_tick = (d.step_state && blocks <= 128) ? 1 : 0;
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
   TRL_LAUNCH_CHECK();

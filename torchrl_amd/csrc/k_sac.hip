@@ -58,26 +58,30 @@ extern "C" int trl_concat2_f32(const float* a, const float* b, float* out, int r
 // clamp log_std to [-20, 2]); z = mean + std * eps; action = tanh(z);
 // log_prob = sum_a Normal(mean, std).log_prob(z) - log(1 - action^2 + 1e-6)   (distribution.py:33-45,
 // with pre_tanh_value = z as explore(return_log_probs=True) passes it, continuous_policy.py:108-114).
+__device__ __forceinline__ float rsample_row(const float* __restrict__ head, const float* __restrict__ eps,
+                                             float* __restrict__ act, int A, int tanh_action) {
+  float lp = 0.0f;                                 // head / eps / act point at row b
+  for (int o = 0; o < A; ++o) {
+    const float mean = head[o];
+    const float ls = fminf(fmaxf(head[A + o], -20.0f), 2.0f);
+    const float sd = __expf(ls), e = eps[o];
+    const float z = fmaf(sd, e, mean);
+    const float zc = z - mean;
+    float lpo = -(zc * zc) / (2.0f * sd * sd) - ls - 0.91893853320467274f;
+    float a = z;
+    if (tanh_action) { a = trl_tanh(z); lpo -= __logf(fmaf(-a, a, 1.0f) + 1e-6f); }
+    act[o] = a;
+    lp += lpo;
+  }
+  return lp;
+}
 __global__ __launch_bounds__(SAC_THREADS) void rsample_fwd_kernel(const float* __restrict__ head,
                                                                   const float* __restrict__ eps,
                                                                   float* __restrict__ act, float* __restrict__ logp,
                                                                   int B, int A, int tanh_action) {
   const int b = blockIdx.x * SAC_THREADS + threadIdx.x;
   if (b >= B) return;
-  float lp = 0.0f;
-  for (int o = 0; o < A; ++o) {
-    const float mean = head[(size_t)b * 2 * A + o];
-    const float ls = fminf(fmaxf(head[(size_t)b * 2 * A + A + o], -20.0f), 2.0f);
-    const float sd = __expf(ls), e = eps[(size_t)b * A + o];
-    const float z = fmaf(sd, e, mean);
-    const float zc = z - mean;
-    float lpo = -(zc * zc) / (2.0f * sd * sd) - ls - 0.91893853320467274f;
-    float a = z;
-    if (tanh_action) { a = trl_tanh(z); lpo -= __logf(fmaf(-a, a, 1.0f) + 1e-6f); }
-    act[(size_t)b * A + o] = a;
-    lp += lpo;
-  }
-  logp[b] = lp;
+  logp[b] = rsample_row(head + (size_t)b * 2 * A, eps + (size_t)b * A, act + (size_t)b * A, A, tanh_action);
 }
 extern "C" int trl_tanh_gauss_rsample_fwd_f32(const float* head, const float* eps, float* act, float* logp, int B,
                                               int A, int tanh_action, void* stream) {
@@ -86,6 +90,50 @@ extern "C" int trl_tanh_gauss_rsample_fwd_f32(const float* head, const float* ep
   TRL_REQUIRE(head && eps && act && logp, "null pointer");
   hipLaunchKernelGGL(rsample_fwd_kernel, dim3(trl_ceil_div(B, SAC_THREADS)), dim3(SAC_THREADS), 0,
                      (hipStream_t)stream, head, eps, act, logp, B, A, tanh_action);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// Both policy samples of one SAC update and the three critic inputs in one launch (twin_sac_q.py:93-106, :125-131,
+// :146-151): new_a / logp from head(obs) with eps1, next_a / next_logp from head(next_obs) with eps2, and
+// x_sa = [obs | acts], x_next = [next_obs | next_a], x_new = [obs | new_a].  One thread per batch row -- the whole
+// batch is ~1 MB, what is saved is four dependent launches.
+__global__ __launch_bounds__(SAC_THREADS) void sac_samples_kernel(const float* __restrict__ head, const float* __restrict__ head2,
+                                                                  const float* __restrict__ eps1, const float* __restrict__ eps2,
+                                                                  const float* __restrict__ obs, const float* __restrict__ acts,
+                                                                  const float* __restrict__ nobs, float* __restrict__ new_a,
+                                                                  float* __restrict__ logp, float* __restrict__ next_a,
+                                                                  float* __restrict__ next_logp, float* __restrict__ x_sa,
+                                                                  float* __restrict__ x_next, float* __restrict__ x_new,
+                                                                  int B, int D, int A, int tanh_action) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float* na = new_a + (size_t)b * A;
+  float* xa = next_a + (size_t)b * A;
+  logp[b] = rsample_row(head + (size_t)b * 2 * A, eps1 + (size_t)b * A, na, A, tanh_action);
+  next_logp[b] = rsample_row(head2 + (size_t)b * 2 * A, eps2 + (size_t)b * A, xa, A, tanh_action);
+  const int F = D + A;
+  for (int k = 0; k < D; ++k) {
+    const float o = obs[(size_t)b * D + k];
+    x_sa[(size_t)b * F + k] = o; x_new[(size_t)b * F + k] = o;
+    x_next[(size_t)b * F + k] = nobs[(size_t)b * D + k];
+  }
+  for (int k = 0; k < A; ++k) {
+    x_sa[(size_t)b * F + D + k] = acts[(size_t)b * A + k];
+    x_new[(size_t)b * F + D + k] = na[k];
+    x_next[(size_t)b * F + D + k] = xa[k];
+  }
+}
+extern "C" int trl_sac_samples_f32(const float* head, const float* head2, const float* eps1, const float* eps2,
+                                   const float* obs, const float* acts, const float* next_obs, float* new_a, float* logp,
+                                   float* next_a, float* next_logp, float* x_sa, float* x_next, float* x_new, int B, int D,
+                                   int A, int tanh_action, void* stream) {
+  TRL_REQUIRE(B >= 0 && A > 0 && D > 0, "bad sizes");
+  if (B == 0) return TRL_OK;
+  TRL_REQUIRE(head && head2 && eps1 && eps2 && obs && acts && next_obs, "null input");
+  TRL_REQUIRE(new_a && logp && next_a && next_logp && x_sa && x_next && x_new, "null output");
+  hipLaunchKernelGGL(sac_samples_kernel, dim3(trl_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, head, head2, eps1,
+                     eps2, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next, x_new, B, D, A, tanh_action);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -99,6 +147,7 @@ __global__ __launch_bounds__(SAC_THREADS) void rsample_bwd_kernel(const float* _
                                                                   const float* __restrict__ eps,
                                                                   const float* __restrict__ act,
                                                                   const float* __restrict__ d_act,
+                                                                  const float* __restrict__ d_act2, int ld, int off,
                                                                   const float* __restrict__ d_logp_ptr, float d_logp_mul,
                                                                   float w_std, float w_mean,
                                                                   float* __restrict__ d_head, int B, int A,
@@ -116,7 +165,10 @@ __global__ __launch_bounds__(SAC_THREADS) void rsample_bwd_kernel(const float* _
     const float a = act[(size_t)b * A + o];
     float da_dz = 1.0f, t = 0.0f;
     if (tanh_action) { da_dz = fmaf(-a, a, 1.0f); t = 2.0f * a * da_dz / (da_dz + 1e-6f); }
-    const float g_z = d_act[(size_t)b * A + o] * da_dz + d_logp * t;   // through z
+    // d(loss)/d(action) = columns [off, off + A) of d_act (+ d_act2: the twin critics' input gradients, :152-155)
+    float da = d_act[(size_t)b * ld + off + o];
+    if (d_act2) da += d_act2[(size_t)b * ld + off + o];
+    const float g_z = da * da_dz + d_logp * t;                         // through z
     d_head[(size_t)b * 2 * A + o] = g_z + w_mean * reg * mean;
     d_head[(size_t)b * 2 * A + A + o] = pass * (g_z * se - d_logp + w_std * reg * ls);
   }
@@ -128,7 +180,23 @@ extern "C" int trl_tanh_gauss_rsample_bwd_f32(const float* head, const float* ep
   if (B == 0) return TRL_OK;
   TRL_REQUIRE(head && eps && act && d_act && d_head, "null pointer");
   hipLaunchKernelGGL(rsample_bwd_kernel, dim3(trl_ceil_div(B, SAC_THREADS)), dim3(SAC_THREADS), 0,
-                     (hipStream_t)stream, head, eps, act, d_act, d_logp_ptr, d_logp_mul, w_std, w_mean, d_head, B, A, tanh_action);
+                     (hipStream_t)stream, head, eps, act, d_act, (const float*)nullptr, A, 0, d_logp_ptr, d_logp_mul, w_std,
+                     w_mean, d_head, B, A, tanh_action);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+// the same with d_act = dx1[:, off:off+A] + dx2[:, off:off+A] read in place (rows of ld floats; dx2 nullable): the input
+// gradients of the twin critics on [obs | new_a] need no slice-and-add launch in between
+extern "C" int trl_tanh_gauss_rsample_bwd_cols_f32(const float* head, const float* eps, const float* act, const float* dx1,
+                                                   const float* dx2, int ld, int off, const float* d_logp_ptr,
+                                                   float d_logp_mul, float w_std, float w_mean, float* d_head, int B, int A,
+                                                   int tanh_action, void* stream) {
+  TRL_REQUIRE(B >= 0 && A > 0 && off >= 0 && off + A <= ld, "bad sizes");
+  if (B == 0) return TRL_OK;
+  TRL_REQUIRE(head && eps && act && dx1 && d_head, "null pointer");
+  hipLaunchKernelGGL(rsample_bwd_kernel, dim3(trl_ceil_div(B, SAC_THREADS)), dim3(SAC_THREADS), 0,
+                     (hipStream_t)stream, head, eps, act, dx1, dx2, ld, off, d_logp_ptr, d_logp_mul, w_std, w_mean, d_head, B,
+                     A, tanh_action);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -200,7 +268,7 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_losses_kernel(const float* __
     s1 += (double)e1 * e1; s2 += (double)e2 * e2; sp += (double)(alpha * logp[b] - fminf(a, c)); sr += (double)rew[b];
   }
   s1 = block_sum(s1, smem); s2 = block_sum(s2, smem); sp = block_sum(sp, smem); sr = block_sum(sr, smem);
-  if (threadIdx.x == 0) { atomicAdd(&sums[0], s1); atomicAdd(&sums[1], s2); atomicAdd(&sums[2], sp); atomicAdd(&sums[3], sr); }
+  if (threadIdx.x == 0) { sums[0] = s1; sums[1] = s2; sums[2] = sp; sums[3] = sr; }     // ONE workgroup (launcher)
 }
 extern "C" int trl_sac_losses_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
                                   const float* logp_next, const float* rew, const float* term, const float* q1n,
@@ -210,8 +278,6 @@ extern "C" int trl_sac_losses_f32(const float* q1, const float* q2, const float*
   TRL_REQUIRE(q1 && q2 && tq1 && tq2 && logp_next && rew && term && q1n && q2n && logp && alpha, "null input");
   TRL_REQUIRE(dq1 && dq2 && dq1n && dq2n && sums, "null output");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, 4 * sizeof(double), s);
-  if (e != hipSuccess) { trl_set_error("sac_losses: memset: %s", hipGetErrorString(e)); return (int)e; }
   // one workgroup: B is a few thousand and the sums must be order-deterministic
   hipLaunchKernelGGL(sac_losses_kernel, dim3(1), dim3(SAC_THREADS), 0, s, q1, q2, tq1, tq2, logp_next, rew, term, q1n,
                      q2n, logp, alpha, gamma, B, dq1, dq2, dq1n, dq2n, sums);
@@ -322,8 +388,8 @@ extern "C" int trl_polyak_f32(float* target, const float* source, int64_t n, flo
 
 // ---------------------------------------------------------------- mean / unbiased std / max / min of a tensor (logging)
 #define MOM_THREADS 1024
-__global__ __launch_bounds__(MOM_THREADS) void moments_kernel(const float* __restrict__ x, int64_t n, int ld, int off,
-                                                              int width, float lo, float hi_, double* __restrict__ out) {
+__device__ __forceinline__ void moments_block(const float* __restrict__ x, int64_t n, int ld, int off,
+                                              int width, float lo, float hi_, double* __restrict__ out) {
   // x viewed as rows of `ld` floats; statistics over columns [off, off+width) of every row.  One workgroup of 16
   // waves (fixed summation order); each thread walks (row, column) incrementally -- no division in the loop.
   __shared__ double smem[4][MOM_THREADS / 64];
@@ -352,6 +418,34 @@ __global__ __launch_bounds__(MOM_THREADS) void moments_kernel(const float* __res
     out[1] = cnt > 1 ? sqrt(fmax((sq - s * mean) / (cnt - 1), 0.0)) : NAN;
     out[2] = mx; out[3] = -nmn;
   }
+}
+__global__ __launch_bounds__(MOM_THREADS) void moments_kernel(const float* __restrict__ x, int64_t n, int ld, int off,
+                                                              int width, float lo, float hi_, double* __restrict__ out) {
+  moments_block(x, n, ld, off, width, lo, hi_, out);
+}
+// up to 4 of the above in one launch (blockIdx.x = statistic): the three logged tensors of a SAC update
+#define MOM_MAX 4
+struct MomSet { const float* x[MOM_MAX]; int64_t n[MOM_MAX]; int ld[MOM_MAX], off[MOM_MAX], width[MOM_MAX];
+                float lo[MOM_MAX], hi[MOM_MAX]; double* out[MOM_MAX]; };
+__global__ __launch_bounds__(MOM_THREADS) void moments_multi_kernel(MomSet m) {
+  const int k = blockIdx.x;
+  moments_block(m.x[k], m.n[k], m.ld[k], m.off[k], m.width[k], m.lo[k], m.hi[k], m.out[k]);
+}
+extern "C" int trl_moments_multi_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
+                                     const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
+                                     void* stream) {
+  TRL_REQUIRE(count >= 1 && count <= MOM_MAX, "moments_multi: 1..4 statistics");
+  TRL_REQUIRE(x && n && ld && off && width && clamp_lo && clamp_hi && out4, "null pointer");
+  MomSet m;
+  for (int k = 0; k < count; ++k) {
+    TRL_REQUIRE(n[k] > 0 && ld[k] > 0 && off[k] >= 0 && width[k] > 0 && off[k] + width[k] <= ld[k] && n[k] % ld[k] == 0, "bad sizes");
+    TRL_REQUIRE(x[k] && out4[k], "null pointer");
+    m.x[k] = x[k]; m.n[k] = n[k]; m.ld[k] = ld[k]; m.off[k] = off[k]; m.width[k] = width[k];
+    m.lo[k] = clamp_lo[k]; m.hi[k] = clamp_hi[k]; m.out[k] = out4[k];
+  }
+  hipLaunchKernelGGL(moments_multi_kernel, dim3(count), dim3(MOM_THREADS), 0, (hipStream_t)stream, m);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
 }
 extern "C" int trl_moments_f64(const float* x, int64_t n, int ld, int off, int width, float clamp_lo, float clamp_hi,
                                double* out4, void* stream) {

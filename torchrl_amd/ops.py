@@ -47,9 +47,13 @@ def mlp_forward(layers, x, act, last_act=None):
     return h, t
 
 
-def mlp_backward(tape, d_out, grads=None, need_input=False, workspace=None):
+def mlp_backward(tape, d_out, grads=None, need_input=False, workspace=None, plan=None):
     """d_out: gradient w.r.t. the network output.  grads: [(dW_view, db_view), ...] to fill (or None
-    to skip weight gradients).  Returns d(input) if need_input."""
+    to skip weight gradients).  Returns d(input) if need_input.  plan (_C.FoldPlan): the weight gradients are only
+    final after `plan.run()` (one fold launch for the whole pass)."""
+    if plan is not None:
+        out = mlp_backward_group([tape], [d_out], None if grads is None else [grads], need_input, plan=plan)
+        return out[0] if need_input else None
     d = d_out
     n = len(tape.layers)
     for k in range(n - 1, -1, -1):
@@ -85,7 +89,7 @@ def mlp_forward_group(layers_list, xs, act, last_act=None):
     return hs, tapes
 
 
-def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspace=None):
+def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspace=None, plan=None):
     """`mlp_backward` of G same-shaped tapes with grouped launches.  grads_list: [grads of tape g] or None."""
     ds = list(d_outs)
     n = len(tapes[0].layers)
@@ -95,8 +99,12 @@ def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspa
         gates = [None if (last and gate_act == _C.ACT_NONE) else t.outs[k] for t in tapes]
         if grads_list is not None:
             inps = [t.x if k == 0 else t.outs[k - 1] for t in tapes]
-            _C.linear_bwd_weight_group(ds, gates, gate_act, inps, [g[k][0] for g in grads_list],
-                                       [g[k][1] for g in grads_list], workspace=workspace)
+            if plan is not None:
+                _C.linear_bwd_weight_partials_group(ds, gates, gate_act, inps, [g[k][0] for g in grads_list],
+                                                    [g[k][1] for g in grads_list], plan)
+            else:
+                _C.linear_bwd_weight_group(ds, gates, gate_act, inps, [g[k][0] for g in grads_list],
+                                           [g[k][1] for g in grads_list], workspace=workspace)
         if k > 0 or need_input:
             ds = _C.linear_bwd_input_group(ds, gates, gate_act, [t.layers[k][0] for t in tapes])
     return ds if need_input else None
