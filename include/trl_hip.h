@@ -493,6 +493,17 @@ int trl_im2col_u8_nchw(const uint8_t* in_nchw, float* cols, int B, int C, int H,
                        int sh, int sw, float scale, float shift, void* stream);
 int trl_col2im_f32(const float* dcols, float* dx_nhwc, int B, int C, int H, int W, int kh, int kw,
                    int sh, int sw, void* stream);
+/* d(input) of a conv layer on channels-last activations WITHOUT the cols matrix (autograd's conv2d input gradient in
+ * the reference, networks/base.py:59-107): dx (B, H, W, Cin) from dy (B, Ho, Wo, Cout) gated by act'(y_gate) (y_gate =
+ * the layer's activation output, nullable) and the nn.Conv2d weight (Cout, Cin, kh, kw) as stored.  An implicit
+ * transposed convolution per stride-parity class on the MFMA units; trl_conv_bwd_input_nhwc_ok says whether a geometry
+ * is covered (Cin a multiple of 16 up to 64, Cout 16 / 32 / 64, stride <= kernel) -- otherwise trl_linear_bwd_input_f32 +
+ * col2im. */
+int trl_conv_bwd_input_nhwc_ok(int Cin, int Cout, int kh, int kw, int sh, int sw);
+int trl_conv_bwd_input_nhwc_workspace(int Cin, int Cout, int kh, int kw);   /* floats: the weights re-ordered per call */
+int trl_conv_bwd_input_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
+                                float* workspace, int B, int Cin, int H, int W, int kh, int kw, int sh, int sw,
+                                int Cout, void* stream);
 /* out[b][c][p] = in[b][p][c]  (NCHW flatten order in front of the first FC layer, and back) */
 int trl_transpose_bpc_f32(const float* in, float* out, int B, int P, int C, void* stream);
 

@@ -113,6 +113,49 @@ def test_implicit_gemm_channels_last_conv_vs_torch(B, C, H, W, kh, kw, sh, sw, C
     assert (db.cpu() - b.grad).abs().max().item() < 5e-5 * scale(b.grad)
 
 
+@pytest.mark.parametrize("B,C,H,W,kh,kw,sh,sw,Cout", [
+    (512, 16, 20, 20, 4, 4, 2, 2, 32),     # cfg 5 conv 2 at full size: four parity classes of 51 200 positions
+    (512, 32, 9, 9, 3, 3, 1, 1, 64),       # cfg 5 conv 3: one class, nine taps, 74 KB of weights in LDS
+    (3, 16, 11, 13, 3, 3, 2, 2, 16),       # (H - kh) % sh != 0: trailing rows no window covers (gradient 0); classes
+    (2, 48, 9, 8, 5, 4, 3, 2, 32),         #   with different tap counts; three column blocks
+    (5, 64, 6, 6, 3, 3, 1, 1, 16),         # four column blocks; 180 positions: partial last tile
+    (2, 16, 5, 4, 5, 4, 1, 1, 16),         # Ho = Wo = 1
+])
+@pytest.mark.parametrize("act", ["relu", "tanh", "none"])
+def test_implicit_transposed_conv_input_gradient_vs_torch(B, C, H, W, kh, kw, sh, sw, Cout, act):
+    """trl_conv_bwd_input_nhwc_f32 (no cols matrix) against autograd's conv2d input gradient, and against the
+    cols-GEMM + col2im pair it replaces."""
+    from torchrl_amd import _C
+    gen = torch.Generator().manual_seed(B * 10 + C + Cout)
+    x = torch.randn(B, C, H, W, generator=gen).requires_grad_(True)
+    w = torch.randn(Cout, C, kh, kw, generator=gen) / (C * kh * kw) ** 0.5
+    f = {"relu": torch.relu, "tanh": torch.tanh, "none": lambda t: t}[act]
+    code = {"relu": _C.ACT_RELU, "tanh": _C.ACT_TANH, "none": _C.ACT_NONE}[act]
+    y = f(F.conv2d(x, w, None, stride=(sh, sw)))
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    assert _C.conv_bwd_input_ok(C, Cout, kh, kw, sh, sw)
+    rows = lambda t: t.detach().permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(DEV)
+    wd = w.view(Cout, -1).to(DEV)
+    gate = rows(y) if act != "none" else None
+    got = _C.conv_bwd_input_nhwc(rows(dy), gate, code, wd, B, C, H, W, kh, kw, sh, sw)
+    want = x.grad.permute(0, 2, 3, 1)
+    scale = max(1.0, want.abs().max().item())
+    assert (got.cpu() - want).abs().max().item() < 2e-5 * scale
+    old = _C.col2im(_C.linear_bwd_input(rows(dy), gate, code, wd), B, C, H, W, kh, kw, sh, sw)
+    assert (got - old).abs().max().item() < 2e-5 * scale
+
+
+def test_implicit_transposed_conv_coverage_and_errors():
+    from torchrl_amd import _C
+    assert not _C.conv_bwd_input_ok(4, 16, 8, 8, 4, 4) and not _C.conv_bwd_input_ok(16, 24, 3, 3, 1, 1)
+    assert not _C.conv_bwd_input_ok(128, 16, 3, 3, 1, 1) and not _C.conv_bwd_input_ok(16, 16, 2, 2, 3, 3)
+    assert not _C.conv_bwd_input_ok(64, 64, 5, 5, 1, 1)                      # 25 taps x 64 x 64 floats > LDS
+    with pytest.raises(_C.TrlError, match="multiple of 16"):
+        _C.conv_bwd_input_nhwc(torch.zeros(8, 16, device=DEV), None, _C.ACT_NONE, torch.zeros(16, 4 * 9, device=DEV),
+                               2, 4, 4, 4, 3, 3, 1, 1)
+
+
 def test_implicit_gemm_rejects_unaligned_geometry():
     from torchrl_amd import _C
     frames = torch.zeros(2, 4, 21, 21, dtype=torch.uint8, device=DEV)

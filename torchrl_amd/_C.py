@@ -175,6 +175,10 @@ SIGNATURES = {
     "trl_im2col_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "trl_im2col_u8_nchw": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_void_p]),
     "trl_col2im_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "trl_conv_bwd_input_nhwc_ok": (C.c_int, [C.c_int] * 6),
+    "trl_conv_bwd_input_nhwc_workspace": (C.c_int, [C.c_int] * 4),
+    "trl_conv_bwd_input_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] +
+                                    [C.c_int] * 9 + [C.c_void_p]),
     "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_conv_fwd_u8_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "trl_conv_bwd_weight_workspace": (C.c_int, [C.c_int] * 9),
@@ -845,6 +849,22 @@ def col2im(dcols, B, Cc, H, W, kh, kw, sh, sw):
     dx = torch.empty((B, H, W, Cc), dtype=torch.float32, device=dcols.device)
     check(lib().trl_col2im_f32(dev_ptr(dcols, name="dcols"), dev_ptr(dx, name="dx"), B, Cc, H, W, kh, kw, sh, sw,
                                stream_ptr(dcols.device)), "trl_col2im_f32")
+    return dx
+
+
+def conv_bwd_input_ok(Cin, Cout, kh, kw, sh, sw):
+    return bool(lib().trl_conv_bwd_input_nhwc_ok(int(Cin), int(Cout), kh, kw, sh, sw))
+
+
+def conv_bwd_input_nhwc(dy, y_gate, gate_act, weight, B, Cin, H, W, kh, kw, sh, sw):
+    """dx (B, H, W, Cin) of a conv layer from dy (B*Ho*Wo, Cout), its activation output and the (Cout, Cin*kh*kw) weight."""
+    Cout = int(weight.shape[0])
+    dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
+    ws = torch.empty((lib().trl_conv_bwd_input_nhwc_workspace(Cin, Cout, kh, kw),), dtype=torch.float32, device=dy.device)
+    check(lib().trl_conv_bwd_input_nhwc_f32(dev_ptr(dy, name="dy"), dev_ptr(y_gate, name="y_gate", allow_none=True),
+                                            gate_act, dev_ptr(weight, name="weight"), dev_ptr(dx, name="dx"),
+                                            dev_ptr(ws, name="workspace"), B, Cin, H, W, kh, kw, sh, sw, Cout,
+                                            stream_ptr(dy.device)), "trl_conv_bwd_input_nhwc_f32")
     return dx
 
 

@@ -1,0 +1,246 @@
+// K10c -- input gradient of a conv layer on channels-last activations as an IMPLICIT transposed convolution.
+//
+// Replaces, for the conv trunk of CNNBase (torchrl/networks/base.py:59-107; autograd's conv2d backward w.r.t. the
+// input in the reference), the pair  dcols = dZ . W  (a (B Ho Wo) x (Cin kh kw) matrix: 42 MB at cfg 5's second layer,
+// written and read back) + gather-form col2im.  Here the cols matrix never exists:
+//     dX[b, y, x, c] = sum over taps (i, j) with i = y (mod sh), j = x (mod sw), and over co, of
+//                      dZ[b, (y - i) / sh, (x - j) / sw, co] * W[co, c, i, j],        dZ = dY * act'(Y).
+// Pixels with the same (y mod sh, x mod sw) -- a parity CLASS -- see the same taps, so each class is a dense product
+// (positions of the class) x (taps_of_class * Cout) . (taps_of_class * Cout) x Cin.
+//   * a prep launch re-orders the weights once per call into [class][tap][MFMA B-operand order] (a few thousand
+//     floats), so that a workgroup stages its class's block into LDS with contiguous 16-byte loads and reads it
+//     lane-linearly (conflict free);
+//   * a workgroup = one class (blockIdx.y) x a run of 64-position tiles; wave w owns positions [16 w, 16 w + 16) of a
+//     tile and all Cin / 16 column blocks (v_mfma_f32_16x16x4_f32: rows = positions, columns = input channels,
+//     k = 4 output channels);
+//   * the A operand (gated dZ) comes straight from global / L1 with 16-byte loads, 4 - 8 taps x all Cout in flight at
+//     once.  A tile's footprint of dZ is ~10 KB, re-read once per tap: L1 hits.
+#include <algorithm>
+#include <cstdlib>
+#include "trl_common.h"
+#include "trl_mlp.h"
+
+struct DxGeom {
+  int B, Cin, H, W, kh, kw, sh, sw, Ho, Wo, Cout;
+  int gate_act, tiles_per_wg;
+  int dbg;                      // TRL_EXP_DX builds only (tools/bench_convdx.py): phases to skip
+};
+
+__device__ __forceinline__ float dx_dact(int act, float y) {
+  if (act == TRL_ACT_TANH) return 1.0f - y * y;
+  if (act == TRL_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+  return 1.0f;
+}
+// n / d for 0 <= n < 2^23 through the float reciprocal (runtime integer division is ~45 VALU instructions, and a lane
+// decodes five positions per tile)
+__device__ __forceinline__ int dx_div(int n, int d, float inv) {
+  int q = (int)((float)n * inv);
+  int r = n - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
+__host__ __device__ inline int dx_class_taps(const DxGeom& g, int py, int px) {
+  const int nti = py < g.kh ? (g.kh - py + g.sh - 1) / g.sh : 0, ntj = px < g.kw ? (g.kw - px + g.sw - 1) / g.sw : 0;
+  return nti * ntj;
+}
+
+// wprep[class block][tap][co / 16][r][cb][gq][j] = W[co = 16 chunk + 4 gq + r][c = 16 cb + j][i][j_tap]: MFMA step
+// (chunk, r) of column block cb reads 64 consecutive floats.  Class blocks follow each other in class order.
+__global__ __launch_bounds__(256) void conv_dx_prep_kernel(const float* __restrict__ w, float* __restrict__ wprep, DxGeom g) {
+  const int total = g.Cout * g.Cin * g.kh * g.kw, CB = g.Cin >> 4, tap_floats = g.Cout * g.Cin;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int jt = e % g.kw, it = (e / g.kw) % g.kh, c = (e / (g.kw * g.kh)) % g.Cin, co = e / (g.kw * g.kh * g.Cin);
+    const int py = it % g.sh, px = jt % g.sw, ti = it / g.sh, tj = jt / g.sw;
+    int off = 0;
+    for (int cls = 0; cls < py * g.sw + px; ++cls) off += dx_class_taps(g, cls / g.sw, cls % g.sw) * tap_floats;
+    const int ntj = (g.kw - px + g.sw - 1) / g.sw;
+    const int chunk = co >> 4, gq = (co >> 2) & 3, r = co & 3, cb = c >> 4, j = c & 15;
+    wprep[off + (ti * ntj + tj) * tap_floats + (((chunk * 4 + r) * CB + cb) * 4 + gq) * 16 + j] = w[e];
+  }
+}
+
+template <int CB, int NCH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv_dx_kernel(const float* __restrict__ dy, const float* __restrict__ yg,
+                                                      const float* __restrict__ wprep, float* __restrict__ dx, DxGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float Ws[];
+  constexpr int TAP = 16 * NCH * 16 * CB;                        // floats of one tap's weights
+  const int py = blockIdx.y / g.sw, px = blockIdx.y - py * g.sw;
+  const int Hc = py < g.H ? (g.H - py + g.sh - 1) / g.sh : 0, Wc = px < g.W ? (g.W - px + g.sw - 1) / g.sw : 0;
+  const int rows = g.B * Hc * Wc;
+  constexpr int TILE = 16 * WAVES, THREADS = 64 * WAVES;
+  int row0 = blockIdx.x * g.tiles_per_wg * TILE;
+  if (row0 >= rows) return;
+  const int nti = py < g.kh ? (g.kh - py + g.sh - 1) / g.sh : 0, ntj = px < g.kw ? (g.kw - px + g.sw - 1) / g.sw : 0;
+  const int ntap = nti * ntj;
+  {
+    int off = 0;
+    for (int cls = 0; cls < (int)blockIdx.y; ++cls) off += dx_class_taps(g, cls / g.sw, cls % g.sw) * TAP;
+    const f32x4* src = reinterpret_cast<const f32x4*>(wprep + off);
+    f32x4* dst = reinterpret_cast<f32x4*>(Ws);
+#ifdef TRL_EXP_DX
+    const int n4 = (g.dbg & 1) ? 0 : ntap * (TAP / 4);
+#else
+    const int n4 = ntap * (TAP / 4);
+#endif
+    for (int e = threadIdx.x; e < n4; e += 8 * THREADS) {        // 8 loads in flight per thread
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (e + THREADS * k < n4) v[k] = src[e + THREADS * k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (e + THREADS * k < n4) dst[e + THREADS * k] = v[k];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, gq = lane >> 4;
+  const bool gated = yg != nullptr && g.gate_act != TRL_ACT_NONE;
+  const float inv_wc = 1.0f / (float)Wc, inv_hc = 1.0f / (float)Hc, inv_ntj = 1.0f / (float)ntj;
+  for (int tile = 0; tile < g.tiles_per_wg && row0 < rows; ++tile, row0 += TILE) {
+    const int row = row0 + 16 * wave + j;                        // A row of this lane
+    const bool row_ok = row < rows;
+    int b = 0, yq = 0, xq = 0;
+    if (row_ok) { const int t = dx_div(row, Wc, inv_wc); xq = row - t * Wc; b = dx_div(t, Hc, inv_hc); yq = t - b * Hc; }
+    f32x4 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // Taps in groups of G: every load of a group (G taps x all Cout of dY and of the gate) is issued before the
+    // group's MFMAs -- one memory round trip per group instead of one per tap (a tap's 32 MFMAs are 0.4 us, a
+    // round trip under load ~2 us).
+    constexpr int G = 8 / NCH;
+    f32x4 a[G][NCH], y[G][NCH];
+    for (int t0 = 0; t0 < ntap; t0 += G) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int t = t0 + u;
+        if (t >= ntap) break;
+        const int ti = dx_div(t, ntj, inv_ntj), tj = t - ti * ntj;
+        const int oy = yq - ti, ox = xq - tj;
+#ifdef TRL_EXP_DX
+        const bool ok = !(g.dbg & 2) && row_ok && oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo;
+#else
+        const bool ok = row_ok && oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo;
+#endif
+        const size_t base = ok ? (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.Cout + 4 * gq : 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          a[u][ch] = ok ? *reinterpret_cast<const f32x4*>(dy + base + 16 * ch) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          if (gated) y[u][ch] = ok ? *reinterpret_cast<const f32x4*>(yg + base + 16 * ch) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (t0 + u >= ntap) break;
+#ifdef TRL_EXP_DX
+        if (g.dbg & 8) { acc[0][0] += a[u][0][0]; continue; }
+#endif
+        const float* wt = Ws + (t0 + u) * TAP + lane;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          f32x4 av = a[u][ch];
+          if (gated) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[r] *= dx_dact(g.gate_act, y[u][ch][r]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+              acc[cb] = mfma16(av[r], wt[((ch * 4 + r) * CB + cb) * 64], acc[cb]);
+        }
+      }
+    }
+    // C reg r of lane (j, gq): position 4 gq + r of the wave's block, input channel 16 cb + j
+    const int orow0 = row0 + 16 * wave + 4 * gq;
+    const int t0o = dx_div(orow0, Wc, inv_wc);
+    int xo = orow0 - t0o * Wc, bo = dx_div(t0o, Hc, inv_hc), yo = t0o - bo * Hc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (orow0 + r >= rows) break;
+#ifdef TRL_EXP_DX
+      if ((g.dbg & 4) && acc[0][r] != 12345.0f) continue;
+#endif
+      if (r > 0 && ++xo == Wc) { xo = 0; if (++yo == Hc) { yo = 0; ++bo; } }   // the next position of the class
+      float* p = dx + (((size_t)bo * g.H + (g.sh * yo + py)) * g.W + (g.sw * xo + px)) * g.Cin + j;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) p[16 * cb] = acc[cb][r];
+    }
+  }
+}
+
+template <int CB, int NCH, int WAVES>
+static int launch_dx_waves(const float* dy, const float* yg, const float* w, float* wprep, float* dx, DxGeom g, int lds,
+                           hipStream_t s) {
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_dx_kernel<CB, NCH, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { trl_set_error("conv_bwd_input: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_lds = lds;
+  }
+  const int total = g.Cout * g.Cin * g.kh * g.kw;
+  hipLaunchKernelGGL(conv_dx_prep_kernel, dim3(std::min(64, trl_ceil_div(total, 256))), dim3(256), 0, s, w, wprep, g);
+  TRL_LAUNCH_CHECK();
+  const int64_t rows_max = (int64_t)g.B * trl_ceil_div(g.H, g.sh) * trl_ceil_div(g.W, g.sw);   // class (0, 0) is the largest
+  const int tiles = trl_ceil_div(rows_max, 16 * WAVES), classes = g.sh * g.sw;
+  // enough workgroups for ~8 per CU (what hides the loads is waves in flight); beyond that a workgroup walks several
+  // tiles on one staging of the weights
+  g.tiles_per_wg = std::max(1, std::min(8, (int)((int64_t)tiles * classes / 2048)));
+#ifdef TRL_EXP_DX
+  g.dbg = getenv("TRL_DX_DBG") ? atoi(getenv("TRL_DX_DBG")) : 0;
+  if (getenv("TRL_DX_TPW")) g.tiles_per_wg = atoi(getenv("TRL_DX_TPW"));
+#endif
+  hipLaunchKernelGGL((conv_dx_kernel<CB, NCH, WAVES>), dim3(trl_ceil_div(tiles, g.tiles_per_wg), classes), dim3(64 * WAVES),
+                     lds, s, dy, yg, wprep, dx, g);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+template <int CB, int NCH>
+static int launch_dx(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const DxGeom& g, hipStream_t s) {
+  const int max_taps = trl_ceil_div(g.kh, g.sh) * trl_ceil_div(g.kw, g.sw);
+  const int lds = max_taps * g.Cout * g.Cin * (int)sizeof(float);
+  TRL_REQUIRE(lds <= 160 * 1024, "conv_bwd_input: one parity class of the weights exceeds the LDS");
+  // a class's weights above ~40 KB leave room for two or three workgroups per CU: make them 8 waves each
+  if (lds > 40 * 1024) return launch_dx_waves<CB, NCH, 8>(dy, yg, w, wprep, dx, g, lds, s);
+  return launch_dx_waves<CB, NCH, 4>(dy, yg, w, wprep, dx, g, lds, s);
+}
+
+template <int CB>
+static int launch_dx_cout(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const DxGeom& g,
+                          hipStream_t s) {
+  switch (g.Cout >> 4) {
+    case 1: return launch_dx<CB, 1>(dy, yg, w, wprep, dx, g, s);
+    case 2: return launch_dx<CB, 2>(dy, yg, w, wprep, dx, g, s);
+    default: return launch_dx<CB, 4>(dy, yg, w, wprep, dx, g, s);
+  }
+}
+
+extern "C" int trl_conv_bwd_input_nhwc_ok(int Cin, int Cout, int kh, int kw, int sh, int sw) {
+  if (Cin <= 0 || (Cin & 15) || Cin > 64 || (Cout != 16 && Cout != 32 && Cout != 64)) return 0;
+  if (kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || sh > kh || sw > kw) return 0;
+  return (int64_t)trl_ceil_div(kh, sh) * trl_ceil_div(kw, sw) * Cout * Cin * 4 <= 160 * 1024;
+}
+
+extern "C" int trl_conv_bwd_input_nhwc_workspace(int Cin, int Cout, int kh, int kw) {
+  if (Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return 0;
+  return Cin * Cout * kh * kw;                       // floats: the re-ordered weights
+}
+
+extern "C" int trl_conv_bwd_input_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
+                                           float* workspace, int B, int Cin, int H, int W, int kh, int kw, int sh, int sw,
+                                           int Cout, void* stream) {
+  TRL_REQUIRE(B >= 0 && H >= kh && W >= kw, "bad geometry");
+  TRL_REQUIRE(trl_conv_bwd_input_nhwc_ok(Cin, Cout, kh, kw, sh, sw),
+              "needs Cin a multiple of 16 (<= 64), Cout 16 / 32 / 64, stride <= kernel (else trl_linear_bwd_input_f32 + trl_col2im_f32)");
+  if (B == 0) return TRL_OK;
+  TRL_REQUIRE(dy && w && dx && workspace, "null pointer");
+  TRL_REQUIRE(gate_act == TRL_ACT_TANH || gate_act == TRL_ACT_RELU || gate_act == TRL_ACT_NONE, "unknown activation");
+  TRL_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(y_gate) & 15) == 0 &&
+              (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "dy / y_gate / workspace must be 16-byte aligned");
+  TRL_REQUIRE((int64_t)B * H * W * Cin < ((int64_t)1 << 31) && (int64_t)B * H * W < ((int64_t)1 << 23), "tensor too large");
+  DxGeom g{B, Cin, H, W, kh, kw, sh, sw, (H - kh) / sh + 1, (W - kw) / sw + 1, Cout, gate_act, 1};
+  hipStream_t s = (hipStream_t)stream;
+  switch (Cin >> 4) {
+    case 1: return launch_dx_cout<1>(dy, y_gate, w, workspace, dx, g, s);
+    case 2: return launch_dx_cout<2>(dy, y_gate, w, workspace, dx, g, s);
+    case 3: return launch_dx_cout<3>(dy, y_gate, w, workspace, dx, g, s);
+    default: return launch_dx_cout<4>(dy, y_gate, w, workspace, dx, g, s);
+  }
+}

@@ -7,6 +7,8 @@ activation, then a linear head.  `mlp_forward` keeps the layer outputs (the "tap
 gradient buffer, and optionally d(input).  act'(.) is applied inside the kernels through the
 stored layer OUTPUTS, so no pre-activation tensors are kept.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -210,6 +212,10 @@ def cnn_backward(net, tape, d_out, grads, workspace=None):
         else:
             _C.linear_bwd_weight(d, y, tape.act, src, dw=gw.view(wmat.shape), db=gb, workspace=workspace)
         if k > 0:
-            dcols = _C.linear_bwd_input(d, y, tape.act, wmat)
             B, H, W, Cin = in_shape
-            d = _C.col2im(dcols, B, Cin, H, W, kh, kw, sh, sw).view(B * H * W, Cin)
+            if _C.conv_bwd_input_ok(Cin, int(wmat.shape[0]), kh, kw, sh, sw) and os.environ.get("TRL_CONV_DX_COLS") != "1":
+                # implicit transposed convolution: no (B Ho Wo) x (Cin kh kw) matrix in between
+                d = _C.conv_bwd_input_nhwc(d, y, tape.act, wmat, B, Cin, H, W, kh, kw, sh, sw).view(B * H * W, Cin)
+            else:
+                dcols = _C.linear_bwd_input(d, y, tape.act, wmat)
+                d = _C.col2im(dcols, B, Cin, H, W, kh, kw, sh, sw).view(B * H * W, Cin)
