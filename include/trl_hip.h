@@ -501,11 +501,16 @@ int trl_col2im_f32(const float* dcols, float* dx_nhwc, int B, int C, int H, int 
  * col2im. */
 int trl_conv_bwd_input_nhwc_ok(int Cin, int Cout, int kh, int kw, int sh, int sw);
 int trl_conv_bwd_input_nhwc_workspace(int Cin, int Cout, int kh, int kw);   /* floats: the weights re-ordered per call */
+/* x_gate (nullable, laid out like dx) with x_gate_act: the result is multiplied by act'(x_gate) on the way out, i.e. the
+ * previous layer receives its dZ instead of its dY and gates nothing itself */
 int trl_conv_bwd_input_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
-                                float* workspace, int B, int Cin, int H, int W, int kh, int kw, int sh, int sw,
-                                int Cout, void* stream);
+                                const float* x_gate, int x_gate_act, float* workspace, int B, int Cin, int H, int W,
+                                int kh, int kw, int sh, int sw, int Cout, void* stream);
 /* out[b][c][p] = in[b][p][c]  (NCHW flatten order in front of the first FC layer, and back) */
 int trl_transpose_bpc_f32(const float* in, float* out, int B, int P, int C, void* stream);
+/* the same with out[e] *= act'(y_gate[e]) (y_gate laid out like out): d(features) -> the last conv layer's dZ */
+int trl_transpose_bpc_gate_f32(const float* in, const float* y_gate, int gate_act, float* out, int B, int P, int C,
+                               void* stream);
 
 /* --- K16b: first conv layer straight from uint8 frames (implicit GEMM) -------
  * replaces nn.Conv2d + activation of CNNBase's first layer (torchrl/networks/base.py:59-107) applied to

@@ -144,6 +144,16 @@ def test_implicit_transposed_conv_input_gradient_vs_torch(B, C, H, W, kh, kw, sh
     assert (got.cpu() - want).abs().max().item() < 2e-5 * scale
     old = _C.col2im(_C.linear_bwd_input(rows(dy), gate, code, wd), B, C, H, W, kh, kw, sh, sw)
     assert (got - old).abs().max().item() < 2e-5 * scale
+    # epilogue gate: the layer below receives dZ = dX * act'(its own output)
+    below = torch.tanh(torch.randn(B, H, W, C, generator=gen)).to(DEV)
+    gated = _C.conv_bwd_input_nhwc(rows(dy), gate, code, wd, B, C, H, W, kh, kw, sh, sw, x_gate=below.view(-1, C),
+                                   x_gate_act=_C.ACT_TANH)
+    assert torch.allclose(gated, got * (1.0 - below * below), rtol=1e-6, atol=1e-7)   # (1 - y y) contracts to an fma
+    # ... and the un-flattening transpose gates the same way
+    feat = torch.randn(B, C, H * W, generator=gen).to(DEV)
+    yb = below.view(B, H * W, C)
+    assert torch.allclose(_C.transpose_bpc(feat, B, C, H * W, y_gate=yb, gate_act=_C.ACT_TANH),
+                          _C.transpose_bpc(feat, B, C, H * W) * (1.0 - yb * yb), rtol=1e-6, atol=1e-7)
 
 
 def test_implicit_transposed_conv_coverage_and_errors():

@@ -177,8 +177,9 @@ SIGNATURES = {
     "trl_col2im_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "trl_conv_bwd_input_nhwc_ok": (C.c_int, [C.c_int] * 6),
     "trl_conv_bwd_input_nhwc_workspace": (C.c_int, [C.c_int] * 4),
-    "trl_conv_bwd_input_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] +
-                                    [C.c_int] * 9 + [C.c_void_p]),
+    "trl_conv_bwd_input_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
+    "trl_transpose_bpc_gate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_conv_fwd_u8_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "trl_conv_bwd_weight_workspace": (C.c_int, [C.c_int] * 9),
@@ -856,20 +857,29 @@ def conv_bwd_input_ok(Cin, Cout, kh, kw, sh, sw):
     return bool(lib().trl_conv_bwd_input_nhwc_ok(int(Cin), int(Cout), kh, kw, sh, sw))
 
 
-def conv_bwd_input_nhwc(dy, y_gate, gate_act, weight, B, Cin, H, W, kh, kw, sh, sw):
-    """dx (B, H, W, Cin) of a conv layer from dy (B*Ho*Wo, Cout), its activation output and the (Cout, Cin*kh*kw) weight."""
+def conv_bwd_input_nhwc(dy, y_gate, gate_act, weight, B, Cin, H, W, kh, kw, sh, sw, x_gate=None, x_gate_act=ACT_NONE):
+    """dx (B, H, W, Cin) of a conv layer from dy (B*Ho*Wo, Cout), its activation output and the (Cout, Cin*kh*kw) weight;
+    with x_gate (the layer's INPUT activations) the result is already multiplied by act'(x_gate)."""
     Cout = int(weight.shape[0])
     dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
     ws = torch.empty((lib().trl_conv_bwd_input_nhwc_workspace(Cin, Cout, kh, kw),), dtype=torch.float32, device=dy.device)
     check(lib().trl_conv_bwd_input_nhwc_f32(dev_ptr(dy, name="dy"), dev_ptr(y_gate, name="y_gate", allow_none=True),
                                             gate_act, dev_ptr(weight, name="weight"), dev_ptr(dx, name="dx"),
+                                            dev_ptr(x_gate, name="x_gate", allow_none=True), x_gate_act,
                                             dev_ptr(ws, name="workspace"), B, Cin, H, W, kh, kw, sh, sw, Cout,
                                             stream_ptr(dy.device)), "trl_conv_bwd_input_nhwc_f32")
     return dx
 
 
-def transpose_bpc(x, B, P, Cc):
+def transpose_bpc(x, B, P, Cc, y_gate=None, gate_act=ACT_NONE):
     out = torch.empty((B, Cc, P), dtype=torch.float32, device=x.device)
+    if y_gate is not None:                                              # out *= act'(y_gate), y_gate laid out like out
+        if y_gate.numel() != out.numel():
+            raise TrlError("transpose_bpc: gate does not match the output")
+        check(lib().trl_transpose_bpc_gate_f32(dev_ptr(x, name="x"), dev_ptr(y_gate, name="y_gate"), gate_act,
+                                               dev_ptr(out, name="out"), B, P, Cc, stream_ptr(x.device)),
+              "trl_transpose_bpc_gate_f32")
+        return out
     check(lib().trl_transpose_bpc_f32(dev_ptr(x, name="x"), dev_ptr(out, name="out"), B, P, Cc,
                                       stream_ptr(x.device)), "trl_transpose_bpc_f32")
     return out

@@ -59,12 +59,16 @@ __global__ __launch_bounds__(CV_THREADS) void col2im_kernel(const float* __restr
 }
 
 // out[b][c][p] = in[b][p][c]
+// (yg, act: optional gate -- out[e] *= act'(yg[e]) with yg laid out like `out`: the backward pass turns d(features) into
+// the last conv layer's dZ in the same pass)
 __global__ __launch_bounds__(CV_THREADS) void transpose_bpc_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                   int B, int P, int C) {
+                                                                   int B, int P, int C, const float* __restrict__ yg, int act) {
   const int64_t total = (int64_t)B * P * C;
   for (int64_t e = (int64_t)blockIdx.x * CV_THREADS + threadIdx.x; e < total; e += (int64_t)gridDim.x * CV_THREADS) {
     const int p = (int)(e % P), c = (int)((e / P) % C), b = (int)(e / ((int64_t)P * C));
-    out[e] = in[((int64_t)b * P + p) * C + c];
+    float v = in[((int64_t)b * P + p) * C + c];
+    if (yg) { const float y = yg[e]; v *= act == TRL_ACT_TANH ? 1.0f - y * y : (act == TRL_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : 1.0f); }
+    out[e] = v;
   }
 }
 
@@ -124,7 +128,18 @@ extern "C" int trl_transpose_bpc_f32(const float* in, float* out, int B, int P, 
   if (B == 0) return TRL_OK;
   TRL_REQUIRE(in && out, "null pointer");
   hipLaunchKernelGGL(transpose_bpc_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(CV_THREADS), 0,
-                     (hipStream_t)stream, in, out, B, P, C);
+                     (hipStream_t)stream, in, out, B, P, C, (const float*)nullptr, TRL_ACT_NONE);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+extern "C" int trl_transpose_bpc_gate_f32(const float* in, const float* y_gate, int gate_act, float* out, int B, int P, int C,
+                                          void* stream) {
+  TRL_REQUIRE(B >= 0 && P > 0 && C > 0, "bad sizes");
+  if (B == 0) return TRL_OK;
+  TRL_REQUIRE(in && out && y_gate, "null pointer");
+  TRL_REQUIRE(gate_act == TRL_ACT_TANH || gate_act == TRL_ACT_RELU || gate_act == TRL_ACT_NONE, "unknown activation");
+  hipLaunchKernelGGL(transpose_bpc_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(CV_THREADS), 0,
+                     (hipStream_t)stream, in, out, B, P, C, y_gate, gate_act);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }

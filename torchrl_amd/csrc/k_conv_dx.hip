@@ -22,7 +22,7 @@
 
 struct DxGeom {
   int B, Cin, H, W, kh, kw, sh, sw, Ho, Wo, Cout;
-  int gate_act, tiles_per_wg;
+  int gate_act, x_gate_act, tiles_per_wg;
   int dbg;                      // TRL_EXP_DX builds only (tools/bench_convdx.py): phases to skip
 };
 
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void conv_dx_prep_kernel(const float* __restri
 
 template <int CB, int NCH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void conv_dx_kernel(const float* __restrict__ dy, const float* __restrict__ yg,
-                                                      const float* __restrict__ wprep, float* __restrict__ dx, DxGeom g) {
+                                                      const float* __restrict__ wprep, float* __restrict__ dx,
+                                                      const float* __restrict__ xg, DxGeom g) {
   extern __shared__ __attribute__((aligned(16))) float Ws[];
   constexpr int TAP = 16 * NCH * 16 * CB;                        // floats of one tap's weights
   const int py = blockIdx.y / g.sw, px = blockIdx.y - py * g.sw;
@@ -159,16 +160,20 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_kernel(const float* __rest
       if ((g.dbg & 4) && acc[0][r] != 12345.0f) continue;
 #endif
       if (r > 0 && ++xo == Wc) { xo = 0; if (++yo == Hc) { yo = 0; ++bo; } }   // the next position of the class
-      float* p = dx + (((size_t)bo * g.H + (g.sh * yo + py)) * g.W + (g.sw * xo + px)) * g.Cin + j;
+      const size_t o = (((size_t)bo * g.H + (g.sh * yo + py)) * g.W + (g.sw * xo + px)) * g.Cin + j;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) p[16 * cb] = acc[cb][r];
+      for (int cb = 0; cb < CB; ++cb) {
+        float v = acc[cb][r];
+        if (xg) v *= dx_dact(g.x_gate_act, xg[o + 16 * cb]);     // hand the previous layer its dZ, not its dY
+        dx[o + 16 * cb] = v;
+      }
     }
   }
 }
 
 template <int CB, int NCH, int WAVES>
-static int launch_dx_waves(const float* dy, const float* yg, const float* w, float* wprep, float* dx, DxGeom g, int lds,
-                           hipStream_t s) {
+static int launch_dx_waves(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
+                           DxGeom g, int lds, hipStream_t s) {
   static int attr_lds = 0;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_dx_kernel<CB, NCH, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -188,27 +193,28 @@ static int launch_dx_waves(const float* dy, const float* yg, const float* w, flo
   if (getenv("TRL_DX_TPW")) g.tiles_per_wg = atoi(getenv("TRL_DX_TPW"));
 #endif
   hipLaunchKernelGGL((conv_dx_kernel<CB, NCH, WAVES>), dim3(trl_ceil_div(tiles, g.tiles_per_wg), classes), dim3(64 * WAVES),
-                     lds, s, dy, yg, wprep, dx, g);
+                     lds, s, dy, yg, wprep, dx, xg, g);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
 template <int CB, int NCH>
-static int launch_dx(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const DxGeom& g, hipStream_t s) {
+static int launch_dx(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
+                     const DxGeom& g, hipStream_t s) {
   const int max_taps = trl_ceil_div(g.kh, g.sh) * trl_ceil_div(g.kw, g.sw);
   const int lds = max_taps * g.Cout * g.Cin * (int)sizeof(float);
   TRL_REQUIRE(lds <= 160 * 1024, "conv_bwd_input: one parity class of the weights exceeds the LDS");
   // a class's weights above ~40 KB leave room for two or three workgroups per CU: make them 8 waves each
-  if (lds > 40 * 1024) return launch_dx_waves<CB, NCH, 8>(dy, yg, w, wprep, dx, g, lds, s);
-  return launch_dx_waves<CB, NCH, 4>(dy, yg, w, wprep, dx, g, lds, s);
+  if (lds > 40 * 1024) return launch_dx_waves<CB, NCH, 8>(dy, yg, w, wprep, dx, xg, g, lds, s);
+  return launch_dx_waves<CB, NCH, 4>(dy, yg, w, wprep, dx, xg, g, lds, s);
 }
 
 template <int CB>
-static int launch_dx_cout(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const DxGeom& g,
-                          hipStream_t s) {
+static int launch_dx_cout(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
+                          const DxGeom& g, hipStream_t s) {
   switch (g.Cout >> 4) {
-    case 1: return launch_dx<CB, 1>(dy, yg, w, wprep, dx, g, s);
-    case 2: return launch_dx<CB, 2>(dy, yg, w, wprep, dx, g, s);
-    default: return launch_dx<CB, 4>(dy, yg, w, wprep, dx, g, s);
+    case 1: return launch_dx<CB, 1>(dy, yg, w, wprep, dx, xg, g, s);
+    case 2: return launch_dx<CB, 2>(dy, yg, w, wprep, dx, xg, g, s);
+    default: return launch_dx<CB, 4>(dy, yg, w, wprep, dx, xg, g, s);
   }
 }
 
@@ -224,23 +230,24 @@ extern "C" int trl_conv_bwd_input_nhwc_workspace(int Cin, int Cout, int kh, int 
 }
 
 extern "C" int trl_conv_bwd_input_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
-                                           float* workspace, int B, int Cin, int H, int W, int kh, int kw, int sh, int sw,
-                                           int Cout, void* stream) {
+                                           const float* x_gate, int x_gate_act, float* workspace, int B, int Cin, int H,
+                                           int W, int kh, int kw, int sh, int sw, int Cout, void* stream) {
   TRL_REQUIRE(B >= 0 && H >= kh && W >= kw, "bad geometry");
   TRL_REQUIRE(trl_conv_bwd_input_nhwc_ok(Cin, Cout, kh, kw, sh, sw),
               "needs Cin a multiple of 16 (<= 64), Cout 16 / 32 / 64, stride <= kernel (else trl_linear_bwd_input_f32 + trl_col2im_f32)");
   if (B == 0) return TRL_OK;
   TRL_REQUIRE(dy && w && dx && workspace, "null pointer");
   TRL_REQUIRE(gate_act == TRL_ACT_TANH || gate_act == TRL_ACT_RELU || gate_act == TRL_ACT_NONE, "unknown activation");
+  TRL_REQUIRE(x_gate_act == TRL_ACT_TANH || x_gate_act == TRL_ACT_RELU || x_gate_act == TRL_ACT_NONE, "unknown activation");
   TRL_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(y_gate) & 15) == 0 &&
               (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "dy / y_gate / workspace must be 16-byte aligned");
   TRL_REQUIRE((int64_t)B * H * W * Cin < ((int64_t)1 << 31) && (int64_t)B * H * W < ((int64_t)1 << 23), "tensor too large");
-  DxGeom g{B, Cin, H, W, kh, kw, sh, sw, (H - kh) / sh + 1, (W - kw) / sw + 1, Cout, gate_act, 1};
+  DxGeom g{B, Cin, H, W, kh, kw, sh, sw, (H - kh) / sh + 1, (W - kw) / sw + 1, Cout, gate_act, x_gate_act, 1};
   hipStream_t s = (hipStream_t)stream;
   switch (Cin >> 4) {
-    case 1: return launch_dx_cout<1>(dy, y_gate, w, workspace, dx, g, s);
-    case 2: return launch_dx_cout<2>(dy, y_gate, w, workspace, dx, g, s);
-    case 3: return launch_dx_cout<3>(dy, y_gate, w, workspace, dx, g, s);
-    default: return launch_dx_cout<4>(dy, y_gate, w, workspace, dx, g, s);
+    case 1: return launch_dx_cout<1>(dy, y_gate, w, workspace, dx, x_gate, g, s);
+    case 2: return launch_dx_cout<2>(dy, y_gate, w, workspace, dx, x_gate, g, s);
+    case 3: return launch_dx_cout<3>(dy, y_gate, w, workspace, dx, x_gate, g, s);
+    default: return launch_dx_cout<4>(dy, y_gate, w, workspace, dx, x_gate, g, s);
   }
 }

@@ -195,27 +195,40 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
 
 
 def cnn_backward(net, tape, d_out, grads, workspace=None):
-    """grads: [(dW_view, db_view), ...] in cnn_param_list order (conv layers, then FC layers)."""
+    """grads: [(dW_view, db_view), ...] in cnn_param_list order (conv layers, then FC layers).
+    The gradient flowing down the trunk is gated ONCE, where it is produced (dZ = dY * act'(Y): in the transpose that
+    un-flattens d(features), and in the epilogue of each implicit input-gradient kernel), so the weight- and
+    input-gradient kernels of a layer read one tensor instead of two."""
     n_conv = len(tape.convs)
     d_feat = mlp_backward(tape.fc, d_out, grads=grads[n_conv:], need_input=True, workspace=workspace)
     P, Cc = tape.feat_shape
-    d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P).view(tape.B * P, Cc)   # back to (B, P, C)
+    pregate = os.environ.get("TRL_CONV_DX_COLS") != "1"
+    top_y = tape.convs[-1][2]
+    d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P, y_gate=top_y if pregate else None,
+                         gate_act=tape.act).view(tape.B * P, Cc)         # back to (B, P, C)
+    gated = pregate                                                      # d is dZ of layer k (else dY)
     for k in range(n_conv - 1, -1, -1):
         kind, src, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]      # src: cols matrix / input activations / frames
         gw, gb = grads[k]
+        yg, ga = (None, _C.ACT_NONE) if gated else (y, tape.act)
         if kind == "nhwc":                                                   # implicit GEMM on channels-last activations
-            _C.conv_bwd_weight_nhwc(d, y, tape.act, src, kh, kw, sh, sw, gw.view(wmat.shape), gb, workspace=workspace)
+            _C.conv_bwd_weight_nhwc(d, yg, ga, src, kh, kw, sh, sw, gw.view(wmat.shape), gb, workspace=workspace)
         elif kind == "u8":                                                   # first layer, implicit GEMM on the frames
             frames, scale, shift = src
-            _C.conv_bwd_weight_u8(d, y, tape.act, frames, kh, kw, sh, sw, scale, shift, gw.view(wmat.shape), gb,
+            _C.conv_bwd_weight_u8(d, yg, ga, frames, kh, kw, sh, sw, scale, shift, gw.view(wmat.shape), gb,
                                   workspace=workspace)
         else:
-            _C.linear_bwd_weight(d, y, tape.act, src, dw=gw.view(wmat.shape), db=gb, workspace=workspace)
+            _C.linear_bwd_weight(d, yg, ga, src, dw=gw.view(wmat.shape), db=gb, workspace=workspace)
         if k > 0:
             B, H, W, Cin = in_shape
-            if _C.conv_bwd_input_ok(Cin, int(wmat.shape[0]), kh, kw, sh, sw) and os.environ.get("TRL_CONV_DX_COLS") != "1":
-                # implicit transposed convolution: no (B Ho Wo) x (Cin kh kw) matrix in between
-                d = _C.conv_bwd_input_nhwc(d, y, tape.act, wmat, B, Cin, H, W, kh, kw, sh, sw).view(B * H * W, Cin)
+            if pregate and _C.conv_bwd_input_ok(Cin, int(wmat.shape[0]), kh, kw, sh, sw):
+                # implicit transposed convolution: no (B Ho Wo) x (Cin kh kw) matrix in between; its epilogue applies
+                # the NEXT layer down's act'
+                below = tape.convs[k - 1][2]
+                d = _C.conv_bwd_input_nhwc(d, yg, ga, wmat, B, Cin, H, W, kh, kw, sh, sw, x_gate=below,
+                                           x_gate_act=tape.act).view(B * H * W, Cin)
+                gated = True
             else:
-                dcols = _C.linear_bwd_input(d, y, tape.act, wmat)
+                dcols = _C.linear_bwd_input(d, yg, ga, wmat)
                 d = _C.col2im(dcols, B, Cin, H, W, kh, kw, sh, sw).view(B * H * W, Cin)
+                gated = False
