@@ -71,9 +71,10 @@ def iteration(agent, col, epoch):
     the rollout plus the per-epoch read-back of the epoch reward and the finished-episode list
     (collector/on_policy.py:277-286 here) -- then `update_per_epoch()` = GAE + opt_epochs x minibatch updates with one
     host read of the update statistics."""
-    col.train_one_epoch()
+    collected = col.train_one_epoch()
     agent.current_epoch = epoch
     agent.update_per_epoch()
+    return len(collected["train_rewards"]), collected["train_epoch_reward"]   # consumed where RLAlgo.train consumes it
 
 
 def log(msg):

@@ -119,10 +119,12 @@ class RLAlgo:
             self.current_epoch = epoch
             self.start_epoch()
             with self._timed("explore_time"):
-                collected = self.collector.train_one_epoch()
-                self.training_episode_rewards.extend(collected["train_rewards"])
+                collected = self.collector.train_one_epoch()                 # device collectors: read back on first access
             with self._timed("train_time"):
                 self.update_per_epoch()
+            # after the update has been launched: the collector's read-back then overlaps it instead of idling the GPU
+            # (the two timers measure host time; on the device path the rollout's wait shows up under Train___Time)
+            self.training_episode_rewards.extend(collected["train_rewards"])
             extra = self.finish_epoch()
             total_frames += self.epoch_frames
             if epoch % self.eval_interval == 0:
