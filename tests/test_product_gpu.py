@@ -166,6 +166,35 @@ def test_device_noise_training_runs_and_eval():
     assert len(ev["eval_rewards"]) == 64 and ev["eval_traj_length"] == 40
 
 
+def test_epoch_result_read_back_on_first_access_equals_the_immediate_one(monkeypatch):
+    """train_one_epoch returns a mapping that is read back when first looked at (header + head of the episode log copied
+    behind the rollout in stream order): same values as the immediate read-back, also when the update -- or the next
+    rollout, which resolves a result nobody looked at -- is launched in between, and when more episodes ended than the
+    speculative copy holds."""
+    def run(eager, rows=None):
+        torch.manual_seed(0)                                                # same initial networks in every run
+        monkeypatch.setenv("TRL_EAGER_EPOCH_RESULT", "1" if eager else "0")
+        pf, vf, env, buf, col, agent, logger = build(None, "", 64, 16, 5, 1000, 256, 3, noise_mode="device")
+        if rows is not None:
+            col.SPECULATIVE_ROWS = rows
+        out = []
+        for epoch in range(3):
+            res = col.train_one_epoch()
+            assert isinstance(res, dict) == eager
+            np.random.seed(epoch)
+            agent.current_epoch = epoch
+            agent.update_per_epoch()                                        # launched before the result is looked at
+            out.append((list(res["train_rewards"]), res["train_epoch_reward"], list(col.train_rews)))
+        first = col.train_one_epoch()
+        second = col.train_one_epoch()                                      # resolves `first` before reusing the log
+        out.append((list(first["train_rewards"]), first["train_epoch_reward"], None))
+        out.append((list(second["train_rewards"]), second["train_epoch_reward"], list(col.train_rews)))
+        return out, pf.flat_params().cpu().clone()
+    (want, pw), (got, pg), (small, ps) = run(True), run(False), run(False, rows=8)
+    assert len(want[0][0]) == 64 * 3                                        # horizon 5: three episode ends per env per epoch
+    assert want == got == small and torch.equal(pw, pg) and torch.equal(pw, ps)
+
+
 def test_example_script_runs_unchanged_api(tmp_path):
     """The example mirrors the reference script's wiring through the `torchrl` alias package."""
     cfg = tmp_path / "ppo_small.json"
