@@ -358,6 +358,32 @@ def main():
     # the second time and replays it from the third: with fewer than 3 warm-up steps the capture is done here, as
     # set-up, so that the timed region always measures the steady state.
     setup = max(0, 3 - args.warmup) if os.environ.get("TRL_NO_GRAPH") != "1" else 0
+    if world > 1 and dist.peer_ready():
+        # Insurance for the peer transport: its first three iterations (stream launches, graph capture, first replay)
+        # run guarded.  A rank whose bounded waits trip raises; every rank then votes, and on any failure ALL ranks drop
+        # the peer buffers and continue on RCCL all-reduces with a fresh agent, instead of losing the run.
+        import torch.distributed as td
+        ok = 1.0
+        try:
+            for e in range(3):
+                iteration(agent, col, e)
+                torch.cuda.synchronize()
+        except Exception as exc:                                          # noqa: BLE001 -- anything: fall back, loudly
+            log("peer transport failed in the first iterations: %r" % (exc,))
+            ok = 0.0
+        vote = torch.tensor([ok], device=dev)
+        td.all_reduce(vote, op=td.ReduceOp.MIN)
+        if vote.item() != 1.0:
+            log("falling back to RCCL all-reduces on every rank")
+            dist.destroy_comm()
+            dist.init_comm(dev, peers=False)
+            os.environ.setdefault("TRL_GRAPH_COLLECTIVES", "0")
+            agent, col = build_agent(dev, world, rank)
+            col.env.reset()
+            eng = agent.engine()
+            torch.cuda.synchronize()
+        else:
+            log("peer transport: three guarded iterations completed on every rank")
     for e in range(setup):
         iteration(agent, col, e)
         torch.cuda.synchronize()

@@ -405,6 +405,15 @@ int trl_linear_bwd_weight_partials_group_f32(int G, const float* const* dy, cons
                                              int N, void* stream);
 int trl_fold_partials_multi_f32(int count, const float* const* part, float* const* out, const int* n,
                                 const int* splits, void* stream);
+/* The weight gradients of up to 12 layers of DIFFERENT widths (K[i] inputs, N[i] outputs, the same batch M) as ONE
+ * launch of split GEMMs: problem i leaves S_i = trl_linear_bwd_weight_multi_splits(M, K[i], N[i]) partials of dW_i at
+ * workspace[i] ([S_i][N_i * K_i]) followed (want_db) by S_i partials of db_i ([S_i][N_i]); y_gate[i] may be NULL (no
+ * activation behind that layer).  Nothing on a backward pass waits for a weight gradient before the optimiser step, so
+ * they need not be one dependent launch per layer. */
+int trl_linear_bwd_weight_multi_splits(int M, int K, int N);
+int trl_linear_bwd_weight_partials_multi_f32(int G, const float* const* dy, const float* const* y_gate, int gate_act,
+                                             const float* const* x, const int* K, const int* N, int want_db,
+                                             float* const* workspace, int M, void* stream);
 
 /* --- K12 / K13: twin-Q SAC update pieces (torchrl/algo/off_policy/twin_sac_q.py:84-220) ---- */
 /* torch.cat([obs, act], -1) of QNet.forward (torchrl/networks/nets.py:61-68) */

@@ -94,6 +94,35 @@ def test_deferred_folds_equal_the_folding_entry_point(M, K, N, G):
         _C.linear_bwd_weight_partials_group(dys, ys, _C.ACT_RELU, xs, got_w, got_b, _C.FoldPlan(torch.empty(8, device=DEV)))
 
 
+def test_weight_gradients_of_layers_of_different_widths_in_one_launch():
+    """trl_linear_bwd_weight_partials_multi_f32: nine layers of a SAC update (17 / 23 / 256 inputs, 256 / 12 / 1 outputs,
+    gated and ungated) as one launch of split GEMMs + one fold, against one folding call per layer."""
+    from torchrl_amd import _C
+    M = 4096
+    gen = torch.Generator().manual_seed(77)
+    r = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    shapes = [(17, 256, True), (256, 256, True), (256, 12, False), (23, 256, True), (256, 256, True), (256, 1, False),
+              (23, 256, True), (256, 256, True), (256, 1, False), (70, 33, True)]
+    need = sum(_C.lib().trl_linear_bwd_weight_multi_splits(M, K, N) * (N * K + N) for K, N, _ in shapes)
+    plan = _C.FoldPlan(torch.empty(need, device=DEV), defer_gemm=True)
+    want, got = [], []
+    for K, N, gated in shapes:
+        dy, y, x = r(M, N), r(M, N), r(M, K)
+        ww, wb = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        act = _C.ACT_RELU if gated else _C.ACT_NONE
+        _C.linear_bwd_weight(dy, y if gated else None, act, x, dw=ww, db=wb)
+        gw, gb = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        _C.linear_bwd_weight_partials_group([dy], [y if gated else None], act, [x], [gw], [gb], plan)
+        want.append((ww, wb)); got.append((gw, gb))
+    assert len(plan.problems) == 10 and len(plan.entries) == 20
+    plan.run()
+    assert not plan.problems and not plan.entries
+    for (ww, wb), (gw, gb), (K, N, _) in zip(want, got, shapes):
+        scale = max(1.0, ww.abs().max().item())
+        assert (gw - ww).abs().max().item() < 2e-5 * scale, (K, N)        # other split counts: another summation order
+        assert (gb - wb).abs().max().item() < 2e-5 * max(1.0, wb.abs().max().item()), (K, N)
+
+
 def test_rsample_fwd_bwd_vs_autograd():
     from torchrl_amd import _C
     B, A = 300, 6

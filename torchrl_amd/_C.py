@@ -220,6 +220,9 @@ SIGNATURES = {
     "trl_linear_bwd_weight_partials_group_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_fold_partials_multi_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "trl_linear_bwd_weight_multi_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "trl_linear_bwd_weight_partials_multi_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                          C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "trl_linear_bwd_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
@@ -557,8 +560,11 @@ class FoldPlan:
     plan=)` runs only the split GEMM, leaving its partials in a slice of the plan's workspace, and `run()` folds every
     recorded (partials -> dW / db view) pair with trl_fold_partials_multi_f32."""
 
-    def __init__(self, workspace):
+    def __init__(self, workspace, defer_gemm=False):
         self.ws, self.used, self.entries = workspace, 0, []
+        # defer_gemm: the split GEMMs themselves wait too and run as ONE launch over all recorded layers
+        # (trl_linear_bwd_weight_partials_multi_f32) in front of the fold
+        self.defer_gemm, self.problems = defer_gemm, []
 
     def take(self, n):
         if self.used + n > self.ws.numel():
@@ -567,7 +573,30 @@ class FoldPlan:
         self.used += n
         return out
 
+    def _run_gemms(self):
+        probs, self.problems = self.problems, []
+        for lo in range(0, len(probs), 12):
+            chunk = probs[lo:lo + 12]
+            g = len(chunk)
+            act = {p[2] for p in chunk if p[1] is not None}
+            if len(act) > 1:
+                raise TrlError("FoldPlan: one launch gates with one activation")
+            M = int(chunk[0][0].shape[0])
+            dys, gates, xs, wss = (C.c_void_p * g)(), (C.c_void_p * g)(), (C.c_void_p * g)(), (C.c_void_p * g)()
+            Ks, Ns = (C.c_int * g)(), (C.c_int * g)()
+            for j, (dy, gate, _act, x, ws, K, N) in enumerate(chunk):
+                if int(dy.shape[0]) != M:
+                    raise TrlError("FoldPlan: layers of one launch share the batch size")
+                dys[j], xs[j], wss[j] = dev_ptr(dy, name="dy"), dev_ptr(x, name="x"), dev_ptr(ws, name="workspace")
+                gates[j] = dev_ptr(gate, name="y_gate", allow_none=True)
+                Ks[j], Ns[j] = K, N
+            check(lib().trl_linear_bwd_weight_partials_multi_f32(g, dys, gates, act.pop() if act else ACT_NONE, xs, Ks, Ns, 1,
+                                                                 wss, M, stream_ptr(self.ws.device)),
+                  "trl_linear_bwd_weight_partials_multi_f32")
+
     def run(self):
+        if self.problems:
+            self._run_gemms()
         k = len(self.entries)
         if k == 0:
             return
@@ -585,6 +614,15 @@ class FoldPlan:
 def linear_bwd_weight_partials_group(dys, y_gates, gate_act, xs, dws, dbs, plan):
     G = len(dys)
     M, N, K = int(dys[0].shape[0]), int(dys[0].shape[1]), int(xs[0].shape[1])
+    if plan.defer_gemm and dbs is not None and dbs[0] is not None:
+        splits = lib().trl_linear_bwd_weight_multi_splits(M, K, N)
+        for i in range(G):
+            ws = plan.take(splits * (N * K + N))
+            gate = y_gates[i] if (y_gates is not None and gate_act != ACT_NONE) else None
+            plan.problems.append((dys[i], gate, gate_act, xs[i], ws, K, N))
+            plan.entries.append((ws[:splits * N * K], dws[i], N * K, splits))
+            plan.entries.append((ws[splits * N * K:], dbs[i], N, splits))
+        return
     splits = lib().trl_linear_bwd_weight_splits(M, K, N)
     per = splits * (N * K + N)
     ws = plan.take(G * per)

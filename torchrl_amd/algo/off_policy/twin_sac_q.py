@@ -149,7 +149,9 @@ class _FusedSAC:
         self._ring, self._ring_used = None, 0
 
     def _ws(self, B):
-        need = sum(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
+        lib = _C.lib()
+        need = sum(max(lib.trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0])),
+                       lib.trl_linear_bwd_weight_multi_splits(B, int(w.shape[1]), int(w.shape[0])) * (w.numel() + int(w.shape[0])))
                    for ls in self.layers for w, _ in ls)                  # every layer's partials live until the one fold
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, device=self.dev)
@@ -195,7 +197,8 @@ class _FusedSAC:
         dx1, dx2 = ops.mlp_backward_group([tape_q1n, tape_q2n], [dq1n, dq2n], grads_list=None, need_input=True)
         d_head = _C.rsample_bwd_cols(head, eps1, new_a, dx1, dx2, D, alpha, 1.0 / B, algo.policy_std_reg_weight,
                                      algo.policy_mean_reg_weight, tanh_action)    # d_act = (dx1 + dx2)[:, D:]
-        plan = _C.FoldPlan(ws)                                           # weight gradients: split GEMMs now, ONE fold below
+        # weight gradients of all nine layers: ONE launch of split GEMMs + ONE fold, after the two input-gradient chains
+        plan = _C.FoldPlan(ws, defer_gemm=os.environ.get("TRL_SAC_DW_PER_LAYER") != "1")
         ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], plan=plan)
         ops.mlp_backward_group([tape_q1, tape_q2], [dq1, dq2], grads_list=[self.gviews[1], self.gviews[2]], plan=plan)
         plan.run()

@@ -38,8 +38,11 @@ __device__ __forceinline__ float dact_from_out(int act, float y) {
 // Up to 8 independent problems of identical shape in one launch (blockIdx.y): the twin critics and their targets,
 // one network on several inputs.  A 4096 x 256 x 256 layer is 256 workgroups and ~4 us of MFMA behind ~4 us of
 // launch + prologue + epilogue; grouped, the problems' workgroups overlap each other's fixed costs.
-#define GEMM_MAX_GROUPS 8
+#define GEMM_MAX_GROUPS 12
 struct GemmGroup { const float* A; const float* B; float* C; const float* bias; const float* a_gate; float* colsum; };
+// Problems of DIFFERENT shapes in one launch (the weight gradients of every layer of a backward pass: nothing waits
+// for them until the optimiser step, so they need not be six dependent launches of 32 - 256 workgroups each)
+struct GemmShape { int M, N, K, lda, ldb, ldc, split_len, tiles_n, tiles, splits; };
 
 struct GemmDev {
   const float* A; const float* B; float* C;
@@ -54,6 +57,8 @@ struct GemmDev {
   ConvSrc cv;                 // CONV != 0: the implicit operand (A when CONV == 1, B when CONV == 2)
   int groups;                 // > 1: the operand pointers of problem blockIdx.y come from grp[]
   GemmGroup grp[GEMM_MAX_GROUPS];
+  int hetero;                 // != 0: problem blockIdx.y also has its own shape (the grid is sized for the largest)
+  GemmShape shp[GEMM_MAX_GROUPS];
 };
 
 // development aid (tools/bench_gemm.py --clk): shader-clock and 100 MHz real-time stamps of a few workgroups
@@ -151,11 +156,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Workgroups are dealt round-robin to the 8 XCDs: renumber so that each XCD owns a contiguous run of tiles
   // (the tiles_n tiles that share an A panel then share an L2).
+  // the problem's shape: the launch's, or (hetero) this problem's own -- surplus workgroups of the common grid leave.
+  // (Locals, not writes into `g`: a modified kernel-argument struct is demoted to scratch memory.)
+  int g_M = g.M, g_N = g.N, g_K = g.K, g_lda = g.lda, g_ldb = g.ldb, g_ldc = g.ldc, g_split_len = g.split_len,
+      g_tiles_n = g.tiles_n, g_tiles = g.tiles;
+  if (g.hetero) {
+    const GemmShape& h = g.shp[blockIdx.y];
+    if ((int)blockIdx.x >= h.tiles || (int)blockIdx.z >= h.splits) return;
+    g_M = h.M; g_N = h.N; g_K = h.K; g_lda = h.lda; g_ldb = h.ldb; g_ldc = h.ldc;
+    g_split_len = h.split_len; g_tiles_n = h.tiles_n; g_tiles = h.tiles;
+  }
   int tile = blockIdx.x;
-  if ((g.tiles & 7) == 0) tile = (tile & 7) * (g.tiles >> 3) + (tile >> 3);
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  if ((g_tiles & 7) == 0) tile = (tile & 7) * (g_tiles >> 3) + (tile >> 3);
+  const int tm = tile / g_tiles_n, tn = tile - tm * g_tiles_n;
   const int m0 = tm * GM, n0 = tn * GN;
-  int k_lo = 0, k_hi = g.K;
+  int k_lo = 0, k_hi = g_K;
   const float* pA = g.A; const float* pB = g.B; float* C = g.C;
   const float* pBias = g.bias; const float* pGate = g.a_gate; float* pColsum = g.colsum;
   if (g.groups > 1) {                              // grouped launch: problem blockIdx.y
@@ -163,15 +178,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
     pA = q.A; pB = q.B; C = q.C; pBias = q.bias; pGate = q.a_gate; pColsum = q.colsum;
   }
   if (gridDim.z > 1) {                             // split reduction: blockIdx.z owns split_len indices, writes its own
-    k_lo = blockIdx.z * g.split_len;               // partial C (folded in fixed order by fold_partials_kernel)
-    k_hi = min(g.K, k_lo + g.split_len);
-    C += (size_t)blockIdx.z * g.M * g.ldc;
+    k_lo = blockIdx.z * g_split_len;               // partial C (folded in fixed order by fold_partials_kernel)
+    k_hi = min(g_K, k_lo + g_split_len);
+    C += (size_t)blockIdx.z * g_M * g_ldc;
   }
   const int wm = wave / WN, wn = wave % WN;
   const int i = lane & 31, hi = lane >> 5;
-  const bool a_whole = (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(pA) & 15) == 0 &&
-                       (GATE == TRL_ACT_NONE || (reinterpret_cast<uintptr_t>(pGate) & 15) == 0) && m0 + GM <= g.M;
-  const bool b_whole = (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(pB) & 15) == 0 && n0 + GN <= g.N;
+  const bool a_whole = (g_lda & 3) == 0 && (reinterpret_cast<uintptr_t>(pA) & 15) == 0 &&
+                       (GATE == TRL_ACT_NONE || (reinterpret_cast<uintptr_t>(pGate) & 15) == 0) && m0 + GM <= g_M;
+  const bool b_whole = (g_ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(pB) & 15) == 0 && n0 + GN <= g_N;
   const bool want_colsum = TA && pColsum && tn == 0;
 
   f32x16 acc;
@@ -190,27 +205,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   constexpr int GA = 256 / GM;                     // CONV == 1: thread = row tid % GM, slots k4 = tid / GM + GA * t
   if (CONV == 1) {
     const int m = m0 + tid % GM;
-    cbase[0] = m < g.M ? conv_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
-    for (int e = tid; 4 * e < g.K; e += 256) tap_tab[e] = conv_tap_offset(g.cv, (uint32_t)(4 * e));
+    cbase[0] = m < g_M ? conv_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
+    for (int e = tid; 4 * e < g_K; e += 256) tap_tab[e] = conv_tap_offset(g.cv, (uint32_t)(4 * e));
     __syncthreads();
   }
   if (CONV == 2) {                                 // thread = reduction row tid % KC, column slots c4 = tid / KC + 2 * t
 #pragma unroll
     for (int t = 0; t < SC; ++t) {
       const int kc = n0 + 4 * (tid / KC + 2 * t);
-      cbase[t] = kc < g.N ? conv_tap_offset(g.cv, (uint32_t)kc) : 0xffffffffu;   // here: the (fixed) tap offsets
+      cbase[t] = kc < g_N ? conv_tap_offset(g.cv, (uint32_t)kc) : 0xffffffffu;   // here: the (fixed) tap offsets
     }
   }
   if (CONV == 3) {                                 // A rows are fixed for the whole kernel: decode them once
 #pragma unroll
     for (int t = 0; t < SC; ++t) {
       const int m = m0 + 8 * t + (tid >> 5);
-      cbase[t] = m < g.M ? nhwc_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
+      cbase[t] = m < g_M ? nhwc_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
     }
   }
   if (CONV == 4) {                                 // B columns (the taps) are fixed for the whole kernel
     const int kc = n0 + 4 * (tid % (GN / 4));
-    ctap_ok = kc < g.N;
+    ctap_ok = kc < g_N;
     ctap = ctap_ok ? nhwc_tap_offset(g.cv, (uint32_t)kc) : 0u;
   }
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -236,11 +251,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
         ra[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? cbase[t] + tap : 0u)) : zero4;
       }
     } else if (a_whole && k_whole) {
-      panel_fetch_fast<!TA, GM>(pA, g.lda, m0, k0, tid, ra);
-      if (GATE != TRL_ACT_NONE) panel_fetch_fast<!TA, GM>(pGate, g.lda, m0, k0, tid, rg);
+      panel_fetch_fast<!TA, GM>(pA, g_lda, m0, k0, tid, ra);
+      if (GATE != TRL_ACT_NONE && pGate) panel_fetch_fast<!TA, GM>(pGate, g_lda, m0, k0, tid, rg);
     } else {
-      panel_fetch_edge<!TA, GM>(pA, g.lda, m0, g.M, k0, k_hi, tid, ra);
-      if (GATE != TRL_ACT_NONE) panel_fetch_edge<!TA, GM>(pGate, g.lda, m0, g.M, k0, k_hi, tid, rg);
+      panel_fetch_edge<!TA, GM>(pA, g_lda, m0, g_M, k0, k_hi, tid, ra);
+      if (GATE != TRL_ACT_NONE && pGate) panel_fetch_edge<!TA, GM>(pGate, g_lda, m0, g_M, k0, k_hi, tid, rg);
     }
     if (CONV == 2) {
       const int m = k0 + tid % KC;
@@ -270,13 +285,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
 #pragma unroll
       for (int t = 0; t < SB; ++t) {
         const int n = n0 + 8 * t + (tid >> 5);
-        const bool ok = kk < k_hi && n < g.N;
-        const float* wp = pB + (ok ? (size_t)n * g.ldb + w0 : 0);
+        const bool ok = kk < k_hi && n < g_N;
+        const float* wp = pB + (ok ? (size_t)n * g_ldb + w0 : 0);
         f32x4 v = {ok ? wp[0] : 0.0f, ok ? wp[khw] : 0.0f, ok ? wp[2 * khw] : 0.0f, ok ? wp[3 * khw] : 0.0f};
         rb[t] = v;
       }
-    } else if (b_whole && k_whole) panel_fetch_fast<TB, GN>(pB, g.ldb, n0, k0, tid, rb);
-    else                           panel_fetch_edge<TB, GN>(pB, g.ldb, n0, g.N, k0, k_hi, tid, rb);
+    } else if (b_whole && k_whole) panel_fetch_fast<TB, GN>(pB, g_ldb, n0, k0, tid, rb);
+    else                           panel_fetch_edge<TB, GN>(pB, g_ldb, n0, g_N, k0, k_hi, tid, rb);
   };
   auto stash = [&]() {
     if (CONV == 1) {                               // uint8 slots go straight to their (row, k4) place
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
         *reinterpret_cast<f32x4*>(Bs + (tid % KC) * (GN + 8) + 4 * (tid / KC + 2 * t)) = v;
       }
     }
-    if (GATE != TRL_ACT_NONE) {
+    if (GATE != TRL_ACT_NONE && pGate) {             // (a problem of a mixed launch may come without a gate)
 #pragma unroll
       for (int t = 0; t < SA; ++t)
 #pragma unroll
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   // ---- epilogue: lane (i, hi) owns column n of rows rowmap(0..15, hi) ----
   {
     const int n = n0 + 32 * wn + i, mb = m0 + 32 * wm + 4 * hi;
-    if (n < g.N) {
+    if (n < g_N) {
       const float bias = pBias ? pBias[n] : 0.0f;
       float v[16];
 #pragma unroll
@@ -343,14 +358,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
       }
-      float* cp = C + (size_t)mb * g.ldc + n;
-      if (m0 + GM <= g.M) {
+      float* cp = C + (size_t)mb * g_ldc + n;
+      if (m0 + GM <= g_M) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+        for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g_ldc] = v[r];
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (mb + (r & 3) + 8 * (r >> 2) < g.M) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+          if (mb + (r & 3) + 8 * (r >> 2) < g_M) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g_ldc] = v[r];
       }
     }
   }
@@ -361,11 +376,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
     float* s = As;                                  // reuse (all MFMA reads are behind the last barrier)
     *reinterpret_cast<f32x4*>(s + (tid / TPR) * GM + 4 * (tid % TPR)) = csum;
     __syncthreads();
-    if (tid < GM && m0 + tid < g.M) {
+    if (tid < GM && m0 + tid < g_M) {
       float a = 0.0f;
 #pragma unroll
       for (int w = 0; w < GROUPS; ++w) a += s[w * GM + tid];
-      pColsum[(size_t)blockIdx.z * g.M + m0 + tid] = a;
+      pColsum[(size_t)blockIdx.z * g_M + m0 + tid] = a;
     }
   }
 }
@@ -536,7 +551,7 @@ static int bw_split_len(int M, int K, int N) {
 
 static int linear_fwd_impl(int G, const float* const* x, const float* const* w, const float* const* bias, float* const* y,
                            int M, int K, int N, int act, hipStream_t stream) {
-  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..8 problems per grouped launch");
+  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per grouped launch");
   TRL_REQUIRE(M >= 0 && K > 0 && N > 0, "bad sizes");
   if (M == 0) return TRL_OK;
   TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
@@ -596,7 +611,7 @@ extern "C" int trl_linear_fwd_splitk_f32(const float* x, const float* w, const f
 
 static int linear_bwd_input_impl(int G, const float* const* dy, const float* const* y_gate, int gate_act,
                                  const float* const* w, float* const* dx, int M, int K, int N, hipStream_t stream) {
-  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..8 problems per grouped launch");
+  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per grouped launch");
   TRL_REQUIRE(M >= 0 && K > 0 && N > 0, "bad sizes");
   if (M == 0) return TRL_OK;
   GemmDev g{};
@@ -631,7 +646,7 @@ template <int CONV>
 static int bwd_weight_impl(int G, const float* const* dy, const float* const* y_gate, int gate_act, const float* const* x,
                            const ConvSrc* cv, float* const* dw, float* const* db, float* workspace, int M, int K, int N,
                            hipStream_t s, bool fold = true) {
-  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..8 problems per grouped launch");
+  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per grouped launch");
   const int split_len = bw_split_len(M, K, N);
   const int splits = trl_ceil_div(M, split_len);
   const size_t per = (size_t)splits * ((size_t)N * K + N);       // workspace floats of one problem
@@ -687,6 +702,65 @@ extern "C" int trl_linear_bwd_weight_partials_group_f32(int G, const float* cons
   for (int i = 0; i < GEMM_MAX_GROUPS; ++i) some[i] = workspace;     // only "is a bias gradient wanted" is read
   return bwd_weight_impl<0>(G, dy, y_gate, gate_act, x, nullptr, none, want_db ? some : none, workspace, M, K, N,
                             (hipStream_t)stream, false);
+}
+// ---- weight gradients of SEVERAL layers (different K, N; same batch M) as one launch of split GEMMs ----
+// 64 x 64 tiles for every problem (narrow layers compute padding: they are latency-, not MFMA-bound); splits chosen so
+// that a problem contributes ~256 workgroups.  Partials are left in place for trl_fold_partials_multi_f32.
+static int multi_split_len(int M, int K, int N) {
+  const int tiles = trl_ceil_div(N, 64) * trl_ceil_div(K, 64);
+  const int want = std::max(1, 256 / tiles);
+  return std::max(256, trl_ceil_div(trl_ceil_div(M, want), KC) * KC);
+}
+extern "C" int trl_linear_bwd_weight_multi_splits(int M, int K, int N) {
+  return (M <= 0 || K <= 0 || N <= 0) ? 1 : trl_ceil_div(M, multi_split_len(M, K, N));
+}
+template <int GATE>
+static int launch_bwd_weight_multi(GemmDev& g, int max_tiles, int max_splits, hipStream_t s) {
+  constexpr int lds = (int)sizeof(float) * (tile_floats<false, 64>() + tile_floats<false, 64>());
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<true, false, GATE, 0, 2>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { trl_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_f32_kernel<true, false, GATE, 0, 2>), dim3(max_tiles, g.groups, max_splits), dim3(256), lds, s, g);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+extern "C" int trl_linear_bwd_weight_partials_multi_f32(int G, const float* const* dy, const float* const* y_gate,
+                                                        int gate_act, const float* const* x, const int* K, const int* N,
+                                                        int want_db, float* const* workspace, int M, void* stream) {
+  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per launch");
+  TRL_REQUIRE(dy && x && K && N && workspace && M > 0, "null pointer array / empty batch");
+  TRL_REQUIRE(gate_act == TRL_ACT_TANH || gate_act == TRL_ACT_RELU || gate_act == TRL_ACT_NONE, "unknown activation");
+  GemmDev g{};
+  g.gate_act = gate_act; g.act = TRL_ACT_NONE; g.groups = G; g.hetero = 1;
+  int max_tiles = 0, max_splits = 0;
+  bool any_gate = false;
+  for (int i = 0; i < G; ++i) {
+    TRL_REQUIRE(dy[i] && x[i] && workspace[i] && K[i] > 0 && N[i] > 0, "null pointer / bad layer size");
+    const int split_len = multi_split_len(M, K[i], N[i]);
+    const int splits = trl_ceil_div(M, split_len);
+    GemmShape& h = g.shp[i];
+    h.M = N[i]; h.N = K[i]; h.K = M; h.lda = N[i]; h.ldb = K[i]; h.ldc = K[i];
+    h.split_len = splits > 1 ? split_len : M; h.splits = splits;
+    h.tiles_n = trl_ceil_div(K[i], 64); h.tiles = h.tiles_n * trl_ceil_div(N[i], 64);
+    float* part = workspace[i];
+    float* cpart = want_db ? part + (size_t)splits * N[i] * K[i] : nullptr;
+    const float* gate = (y_gate && gate_act != TRL_ACT_NONE) ? y_gate[i] : nullptr;
+    any_gate |= gate != nullptr;
+    g.grp[i] = GemmGroup{dy[i], x[i], part, nullptr, gate, cpart};
+    max_tiles = std::max(max_tiles, h.tiles); max_splits = std::max(max_splits, splits);
+  }
+  // one z-slice in the grid would read "no split" in the kernel: the shapes' own split_len already cover that case
+  g.A = g.grp[0].A; g.B = g.grp[0].B; g.C = g.grp[0].C; g.a_gate = g.grp[0].a_gate; g.colsum = g.grp[0].colsum;
+  g.M = g.shp[0].M; g.N = g.shp[0].N; g.K = M; g.lda = g.shp[0].lda; g.ldb = g.shp[0].ldb; g.ldc = g.shp[0].ldc;
+  g.split_len = g.shp[0].split_len; g.tiles_n = g.shp[0].tiles_n; g.tiles = g.shp[0].tiles;
+  hipStream_t s = (hipStream_t)stream;
+  if (!any_gate) return launch_bwd_weight_multi<TRL_ACT_NONE>(g, max_tiles, max_splits, s);
+  if (gate_act == TRL_ACT_TANH) return launch_bwd_weight_multi<TRL_ACT_TANH>(g, max_tiles, max_splits, s);
+  return launch_bwd_weight_multi<TRL_ACT_RELU>(g, max_tiles, max_splits, s);
 }
 // ---- first conv layer on uint8 frames as an implicit GEMM ----
 static int fill_conv(const char* who, const uint8_t* frames, int B, int C, int H, int W, int kh, int kw, int sh, int sw,
