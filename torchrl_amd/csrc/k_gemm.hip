@@ -580,7 +580,9 @@ extern "C" int trl_linear_fwd_group_f32(int G, const float* const* x, const floa
 static int fwd_split_len(int M, int K, int N) {
   const int wm = tile_wm(M, N);
   const int tiles = trl_ceil_div(M, 32 * wm) * trl_ceil_div(N, 32 * (4 / wm));
-  if (tiles >= 192 || K < 8 * KC) return K;
+  // (a handful of tiles -- the 6-wide DQN head on 512 rows is FOUR workgroups walking K = 512 panel by panel, 17 us --
+  // splits from 4 panels on)
+  if (tiles >= 192 || K < (tiles <= 16 ? 4 : 8) * KC) return K;
   const int target = std::min(8, trl_ceil_div(384, tiles));
   return trl_ceil_div(trl_ceil_div(K, target), KC) * KC;
 }
