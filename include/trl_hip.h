@@ -477,6 +477,18 @@ int trl_moments_f64(const float* x, int64_t n, int ld, int off, int width, float
 int trl_moments_multi_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
                           const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
                           void* stream);
+/* One VecCollector.take_actions (torchrl/collector/base.py:184-230) on the synthetic vector env in ONE launch, after the
+ * policy MLP: action = rsample(head, eps) (as trl_tanh_gauss_rsample_fwd_f32), obs / acts stored, env.step
+ * (as trl_synth_env_step_f32: cur_obs advanced in place), next_obs / rewards / terminals / time_limits rows written, the
+ * collector's bookkeeping (as trl_collector_bookkeep_f32) and the partial reset of the envs it flags (as
+ * trl_synth_reset_f32 with that mask).  obs_row / acts_row / tl_row may be NULL (evaluation stores nothing). */
+int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* eps, const float* env_A,
+                               const float* env_B, int32_t* t_env, int32_t* cur_step, int32_t* episode_idx,
+                               float* ep_return, float reward_scale, int horizon, int max_episode_frames,
+                               int64_t env_seed_base, float* obs_row, float* acts_row, float* next_row,
+                               float* rew_row, float* done_row, float* tl_row, uint8_t* reset_mask,
+                               double* epoch_reward, int32_t* ep_count, float* ep_log, int ep_cap, int step,
+                               int N, int D, int A, int tanh_action, void* stream);
 /* N(0,1) fill from the Philox4x32-10 stream (device exploration / rsample noise) */
 int trl_philox_normal_f32(float* out, int64_t n, int64_t seed, int64_t counter, void* stream);
 /* K1 stand-alone: one VecEnv.step of the synthetic env (torchrl/env/vecenv.py:53-61); cur_obs is

@@ -423,6 +423,44 @@ def test_off_policy_collector_on_normalised_env_matches_reference(golden, tag):
     assert torch.equal(env._obs_normalizer.state, state)             # evaluation never updates the statistics
 
 
+@pytest.mark.parametrize("max_frames", [100, 5])
+def test_one_launch_vector_step_equals_the_separate_kernels(monkeypatch, max_frames):
+    """trl_synth_collect_step_f32 (sample, store, env.step, bookkeeping, partial reset in one launch) against the eight
+    separate launches: replay rows, env and collector state, epoch reward, finished-episode log and evaluation, bit for
+    bit; resets by the env's time limit (horizon 7) or by the collector's max_episode_frames (5: no episode ever ends)."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector import VecCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    N, dev = 300, torch.device(DEV)
+
+    def run(separate):
+        monkeypatch.setenv("TRL_COLLECT_SEPARATE", "1" if separate else "0")
+        torch.manual_seed(3)
+        net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+        pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net).to(dev)
+        env, ev = SynthVecEnv(N, horizon=7, device=dev), SynthVecEnv(N, horizon=7, device=dev)
+        env.seed(5)
+        buf = BaseReplayBuffer(N * 32, env_nums=N)
+        col = VecCollector(env=env, eval_env=ev, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * 20,
+                           max_episode_frames=max_frames, eval_episodes=1, noise_mode="device")
+        assert col._one_launch_step(env, None) == (not separate)
+        res = [col.train_one_epoch() for _ in range(2)]                      # 40 steps: the 32-row ring wraps
+        evl = col.eval_one_epoch()
+        state = [getattr(buf, "_" + k).clone() for k in ("obs", "acts", "next_obs", "rewards", "terminals", "time_limits")]
+        state += [env.cur_obs.clone(), env.t_env.clone(), env.cur_step.clone(), env.episode_idx.clone(), env.ep_return.clone()]
+        return res, evl, state, buf._top, col.global_step
+    (ra, ea, sa, ta, ga), (rb, eb, sb, tb, gb) = run(True), run(False)
+    assert ta == tb and ga == gb
+    for x, y in zip(sa, sb):
+        assert torch.equal(x, y)
+    for x, y in zip(ra, rb):
+        assert x["train_rewards"] == y["train_rewards"] and (len(x["train_rewards"]) > 0) == (max_frames == 100)
+        assert abs(x["train_epoch_reward"] - y["train_epoch_reward"]) < 1e-9 * max(1.0, abs(x["train_epoch_reward"]))
+    assert ea["eval_rewards"] == eb["eval_rewards"] and ea["eval_traj_length"] == eb["eval_traj_length"] == 7
+
+
 def test_sac_trains_through_rlalgo_with_device_noise():
     import torchrl.networks as networks
     import torchrl.policies as policies

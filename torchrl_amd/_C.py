@@ -164,6 +164,8 @@ SIGNATURES = {
                                             [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int] * 4 + [C.c_void_p]),
     "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
+    "trl_synth_collect_step_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 10 +
+                                   [C.c_int] * 6 + [C.c_void_p]),
     "trl_collector_bookkeep_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_sac_alpha_step_f32": (C.c_int, [C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_void_p] * 3),
     "trl_sac_losses_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
@@ -379,6 +381,26 @@ def ppo_reduce(partial, scal_partial, n_wg, D, H, A, grads, info, pf_params=None
 
 def clip_adam(args, device):
     check(lib().trl_clip_adam_f32(C.byref(args), stream_ptr(device)), "trl_clip_adam_f32")
+
+
+def synth_collect_step(env, head, eps, cur_step, ep_return, max_frames, rows, mask, epoch_reward, ep_count, ep_log, step,
+                       tanh_action):
+    """One off-policy vector step on the synthetic env in one launch; rows = (obs, acts, next_obs, rewards, terminals,
+    time_limits) destination rows (obs / acts / time_limits may be None)."""
+    N, D, A = int(env.cur_obs.shape[0]), int(env.cur_obs.shape[1]), int(eps.shape[1])
+    obs_row, acts_row, next_row, rew_row, done_row, tl_row = rows
+    check(lib().trl_synth_collect_step_f32(
+        dev_ptr(env.cur_obs, name="cur_obs"), dev_ptr(head, name="head"), dev_ptr(eps, name="eps"),
+        dev_ptr(env.env_A, name="env_A"), dev_ptr(env.env_B, name="env_B"), dev_ptr(env.t_env, torch.int32, "t_env"),
+        dev_ptr(cur_step, torch.int32, "cur_step"), dev_ptr(env.episode_idx, torch.int32, "episode_idx"),
+        dev_ptr(ep_return, name="ep_return"), float(env.effective_reward_scale), int(env.horizon), int(max_frames),
+        int(env.seed_base), dev_ptr(obs_row, name="obs_row", allow_none=True),
+        dev_ptr(acts_row, name="acts_row", allow_none=True), dev_ptr(next_row, name="next_row"),
+        dev_ptr(rew_row, name="rew_row"), dev_ptr(done_row, name="done_row"),
+        dev_ptr(tl_row, name="tl_row", allow_none=True), dev_ptr(mask, torch.uint8, "mask"),
+        dev_ptr(epoch_reward, torch.float64, "epoch_reward"), dev_ptr(ep_count, torch.int32, "ep_count"),
+        dev_ptr(ep_log, name="ep_log"), int(ep_log.shape[0]), int(step), N, D, A, int(bool(tanh_action)),
+        stream_ptr(head.device)), "trl_synth_collect_step_f32")
 
 
 def synth_reset(cur_obs, t_env, cur_step, episode_idx, ep_return, mask, seed_base):

@@ -12,6 +12,8 @@ reference.
 import copy
 
 import gym
+import os
+
 import numpy as np
 import torch
 
@@ -114,6 +116,7 @@ class VecCollector(_CollectorBase):
             raise ValueError("noise_mode must be 'host' or 'device'")
         self.noise_mode = noise_mode
         self.global_step = 0
+        self._log_step0 = 0
         dev = self.env.device
         # epoch reward (f64) and finished-episode count (i32) share one 16-byte header: one memset, one D2H
         self._hdr = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -160,6 +163,7 @@ class VecCollector(_CollectorBase):
 
     def _clear_header(self):
         self._hdr.zero_()
+        self._log_step0 = self.global_step      # the device log keeps steps RELATIVE to here (float32 columns: exact to 2^24)
 
     def _finished_episodes(self, cnt=None):
         """(step, env, return) rows of episodes that ended since the log was cleared, in the
@@ -229,6 +233,8 @@ class VecCollector(_CollectorBase):
         if nz is not None and ob is None:
             raise _C.TrlError("VecCollector._step: a normalised env needs the policy input `ob`")
         pol_in = env.cur_obs if nz is None else ob
+        if self._one_launch_step(env, nz):
+            return self._step_one_launch(env, store, deterministic, max_frames)
         act = self._policy_action(env, deterministic, pol_in)
         if store:
             row = buf._top
@@ -247,7 +253,7 @@ class VecCollector(_CollectorBase):
             nz.update_filt(raw_next, update=env.training, out=nxt)           # NormObs.observation on env.step's return
         _C.collector_bookkeep(rew, done, env.cur_step, env.ep_return,
                               self.max_episode_frames if max_frames is None else max_frames, self._mask,
-                              self._epoch_reward, self._ep_count, self._ep_log, self.global_step)
+                              self._epoch_reward, self._ep_count, self._ep_log, self.global_step - self._log_step0)
         self._env_reset_masked(env)
         if store:
             buf._advance()
@@ -257,6 +263,38 @@ class VecCollector(_CollectorBase):
         # partial_reset bypasses the wrapper and returns the whole RAW array (base_wrapper.py:23-26, vecenv.py:47-51)
         alt = nz.filt(env.cur_obs) if getattr(env, "normalize_partial_reset", False) else env.cur_obs
         return _C.select_on_mask(self._mask, alt, nxt, torch.empty(n, d, device=env.device))
+
+    def _one_launch_step(self, env, nz):
+        """Synthetic vector env + reparameterised Gaussian policy, no normaliser: everything after the policy MLP is
+        ONE launch (trl_synth_collect_step_f32) instead of eight (TRL_COLLECT_SEPARATE=1 keeps the separate kernels)."""
+        pf = self.pf
+        return (nz is None and self.continuous and not getattr(env, "is_host_env", False)
+                and hasattr(pf, "tanh_action") and not hasattr(pf, "logstd") and not hasattr(pf, "norm_std_explore")
+                and type(pf).__name__ != "DetContPolicy" and hasattr(env, "env_A")
+                and os.environ.get("TRL_COLLECT_SEPARATE") != "1")
+
+    def _step_one_launch(self, env, store, deterministic, max_frames):
+        from .. import ops
+        buf, pf = self.replay_buffer, self.pf
+        n, d, a_dim = env.env_nums, env.obs_dim, env.act_dim
+        head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf))
+        eps = torch.zeros(n, a_dim, device=env.device) if deterministic else self._explore_noise(env)
+        if store:
+            row = buf._top
+            rows = (buf._ensure_key("obs", (n, d))[row], buf._ensure_key("acts", (n, a_dim))[row],
+                    buf._ensure_key("next_obs", (n, d))[row], buf._ensure_key("rewards", (n, 1))[row],
+                    buf._ensure_key("terminals", (n, 1))[row], buf._ensure_key("time_limits", (n, 1))[row])
+        else:
+            f = lambda *shape: torch.empty(shape, device=env.device)
+            rows = (None, None, f(n, d), f(n, 1), f(n, 1), None)
+        _C.synth_collect_step(env, head, eps, env.cur_step, env.ep_return,
+                              self.max_episode_frames if max_frames is None else max_frames, rows, self._mask,
+                              self._epoch_reward, self._ep_count, self._ep_log, self.global_step - self._log_step0,
+                              bool(pf.tanh_action))
+        if store:
+            buf._advance()
+        self.global_step += 1
+        return env.cur_obs
 
     def _step_frames(self, env, store, deterministic, max_frames):
         """Discrete-action step on the uint8 frame env: frames stay bytes in the replay rows; actions are
@@ -292,7 +330,7 @@ class VecCollector(_CollectorBase):
             buf._ensure_key("time_limits", (n, 1))[row].copy_(done)
         _C.collector_bookkeep(rew, done, env.cur_step, env.ep_return,
                               self.max_episode_frames if max_frames is None else max_frames, self._mask,
-                              self._epoch_reward, self._ep_count, self._ep_log, self.global_step)
+                              self._epoch_reward, self._ep_count, self._ep_log, self.global_step - self._log_step0)
         _C.synth_frames_reset(env.cur_obs, env.t_env, env.seed_base, self._mask)
         if dedup:
             buf.begin_episodes(env.cur_obs, self._mask)                     # fresh stacks of the envs just reset
@@ -339,7 +377,6 @@ class VecCollector(_CollectorBase):
         for _ in range(self.eval_episodes):
             ob = env.reset()
             self._clear_header()
-            step0 = self.global_step
             for _ in range(self._eval_steps(env)):
                 ob = self._step(env, False, deterministic=True, max_frames=2 ** 31 - 1, ob=ob)
                 if getattr(env, "is_host_env", False) and int(self._ep_count.item()) >= env.env_nums \
@@ -347,7 +384,7 @@ class VecCollector(_CollectorBase):
                     break                                                   # every env has finished its first episode
             first = {}
             for step, idx, ret in self._finished_episodes():
-                first.setdefault(int(idx), (ret, int(step) - step0 + 1))
+                first.setdefault(int(idx), (ret, int(step) + 1))   # steps are logged relative to the clear
             rews += [np.float32(first[i][0]) for i in sorted(first)]
             lens += [first[i][1] for i in sorted(first)]
         return {"eval_rewards": rews, "eval_traj_length": float(np.mean(lens)) if lens else 0.0}

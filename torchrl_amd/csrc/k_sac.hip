@@ -524,6 +524,98 @@ extern "C" int trl_synth_env_step_f32(float* cur_obs, const float* act, const fl
   return TRL_OK;
 }
 
+// ---------------------------------------------------------------- one off-policy vector step on the synthetic env, ONE launch
+// VecCollector.take_actions (torchrl/collector/base.py:184-230) for a GuassianContPolicy on the on-GPU vector env, after
+// the policy MLP: sample the action from the head (rsample_fwd_kernel), store obs / acts, env.step (synth_step_kernel),
+// store next_obs / rewards / terminals / time_limits, the collector's bookkeeping (collector_bookkeep_kernel) and the
+// partial reset of finished envs (synth_reset_kernel + synth_bump_episode_kernel) -- eight launches of a few microseconds
+// of work each, host-launch-bound at ~10 us apiece.  One thread per env; same arithmetic, same Philox blocks.
+struct CollectStep {
+  float* cur_obs; const float* head; const float* eps; const float* envA; const float* envB;
+  int32_t* t_env; int32_t* cur_step; int32_t* episode_idx; float* ep_return;
+  float reward_scale; int horizon, max_frames; int64_t seed_base;
+  float* obs_row; float* acts_row; float* next_row; float* rew_row; float* done_row; float* tl_row;   // obs / acts / tl nullable
+  uint8_t* mask; double* epoch_reward; int32_t* ep_count; float* ep_log; int ep_cap, step;
+  int N, D, A, tanh_action;
+};
+__global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(CollectStep c) {
+  extern __shared__ float sm[];                    // envA (D*D) | envB (A*D)
+  __shared__ double red[SAC_THREADS / 64];
+  const int D = c.D, A = c.A;
+  for (int e = threadIdx.x; e < D * D; e += SAC_THREADS) sm[e] = c.envA[e];
+  for (int e = threadIdx.x; e < A * D; e += SAC_THREADS) sm[D * D + e] = c.envB[e];
+  __syncthreads();
+  const int n = blockIdx.x * SAC_THREADS + threadIdx.x;
+  double r = 0.0;
+  if (n < c.N) {
+    float o[32], a[8], nv[32];
+    for (int k = 0; k < D; ++k) o[k] = c.cur_obs[(size_t)n * D + k];
+    rsample_row(c.head + (size_t)n * 2 * A, c.eps + (size_t)n * A, a, A, c.tanh_action);
+    if (c.obs_row) for (int k = 0; k < D; ++k) c.obs_row[(size_t)n * D + k] = o[k];
+    if (c.acts_row) for (int k = 0; k < A; ++k) c.acts_row[(size_t)n * A + k] = a[k];
+    float asq = 0.0f;
+    for (int k = 0; k < A; ++k) asq = fmaf(a[k], a[k], asq);
+    for (int f = 0; f < D; ++f) {                  // obs' = tanh(obs A + act B)
+      float p = 0.0f;
+      for (int k = 0; k < D; ++k) p = fmaf(o[k], sm[k * D + f], p);
+      for (int k = 0; k < A; ++k) p = fmaf(a[k], sm[D * D + k * D + f], p);
+      nv[f] = trl_tanh(p);
+      c.next_row[(size_t)n * D + f] = nv[f];
+    }
+    const int t = c.t_env[n] + 1;
+    const float rew = c.reward_scale * (nv[0] - 0.1f * asq);
+    const bool d = t >= c.horizon;
+    c.rew_row[n] = rew; c.done_row[n] = d ? 1.0f : 0.0f;
+    if (c.tl_row) c.tl_row[n] = d ? 1.0f : 0.0f;   // synthetic env: time_limit == done
+    r = (double)rew;
+    const int cs = c.cur_step[n] + 1;              // ---- collector bookkeeping ----
+    float er = c.ep_return[n] + rew;
+    if (d) {
+      const int slot = atomicAdd(c.ep_count, 1);
+      if (slot < c.ep_cap) { c.ep_log[slot * 3 + 0] = (float)c.step; c.ep_log[slot * 3 + 1] = (float)n; c.ep_log[slot * 3 + 2] = er; }
+      er = 0.0f;
+    }
+    const bool flag = d || cs >= c.max_frames;
+    c.cur_step[n] = flag ? 0 : cs;
+    c.ep_return[n] = er;
+    c.mask[n] = flag ? 1 : 0;
+    if (flag) {                                    // ---- partial reset: a fresh Philox observation, episode counter + 1 ----
+      const int ep = c.episode_idx[n] + 1;
+      for (int b = 0; 4 * b < D; ++b) {
+        float z[4];
+        philox_normals4((uint32_t)ep, 0u, (uint32_t)b, TRL_TAG_RESET, c.seed_base + n, z);
+        for (int q = 0; q < 4; ++q) if (4 * b + q < D) c.cur_obs[(size_t)n * D + 4 * b + q] = z[q];
+      }
+      c.t_env[n] = 0;
+      c.episode_idx[n] = ep;
+    } else {
+      for (int f = 0; f < D; ++f) c.cur_obs[(size_t)n * D + f] = nv[f];
+      c.t_env[n] = t;
+    }
+  }
+  r = block_sum(r, red);
+  if (threadIdx.x == 0 && c.epoch_reward) atomicAdd(c.epoch_reward, r);
+}
+extern "C" int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* eps, const float* env_A,
+                                          const float* env_B, int32_t* t_env, int32_t* cur_step, int32_t* episode_idx,
+                                          float* ep_return, float reward_scale, int horizon, int max_episode_frames,
+                                          int64_t env_seed_base, float* obs_row, float* acts_row, float* next_row,
+                                          float* rew_row, float* done_row, float* tl_row, uint8_t* reset_mask,
+                                          double* epoch_reward, int32_t* ep_count, float* ep_log, int ep_cap, int step,
+                                          int N, int D, int A, int tanh_action, void* stream) {
+  TRL_REQUIRE(N >= 0 && D > 0 && D <= 32 && A > 0 && A <= 8 && ep_cap >= 0, "bad sizes (D <= 32, A <= 8)");
+  if (N == 0) return TRL_OK;
+  TRL_REQUIRE(cur_obs && head && eps && env_A && env_B && t_env && cur_step && episode_idx && ep_return, "null pointer");
+  TRL_REQUIRE(next_row && rew_row && done_row && reset_mask && ep_count && ep_log, "null pointer");
+  CollectStep c{cur_obs, head, eps, env_A, env_B, t_env, cur_step, episode_idx, ep_return, reward_scale, horizon,
+                max_episode_frames, env_seed_base, obs_row, acts_row, next_row, rew_row, done_row, tl_row, reset_mask,
+                epoch_reward, ep_count, ep_log, ep_cap, step, N, D, A, tanh_action};
+  hipLaunchKernelGGL(synth_collect_step_kernel, dim3(trl_ceil_div(N, SAC_THREADS)), dim3(SAC_THREADS),
+                     (D * D + A * D) * sizeof(float), (hipStream_t)stream, c);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 // ---------------------------------------------------------------- off-policy collector bookkeeping
 // VecCollector.take_actions after env.step (torchrl/collector/base.py:205-224): step counters,
 // running returns (logged and cleared on done only), reset mask = done | step >= max_episode_frames.
