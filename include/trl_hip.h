@@ -481,8 +481,11 @@ int trl_moments_multi_f64(int count, const float* const* x, const int64_t* n, co
  * policy MLP: action = rsample(head, eps) (as trl_tanh_gauss_rsample_fwd_f32), obs / acts stored, env.step
  * (as trl_synth_env_step_f32: cur_obs advanced in place), next_obs / rewards / terminals / time_limits rows written, the
  * collector's bookkeeping (as trl_collector_bookkeep_f32) and the partial reset of the envs it flags (as
- * trl_synth_reset_f32 with that mask).  obs_row / acts_row / tl_row may be NULL (evaluation stores nothing). */
-int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* eps, const float* env_A,
+ * trl_synth_reset_f32 with that mask).  obs_row / acts_row / tl_row may be NULL (evaluation stores nothing).  eps NULL:
+ * the noise is rows [noise_row0, noise_row0 + N) of trl_philox_normal_f32's (all envs, A) draw for (noise_seed,
+ * noise_counter), generated in place (same Philox blocks, no separate launch). */
+int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* eps, int64_t noise_seed,
+                               int64_t noise_counter, int noise_row0, const float* env_A,
                                const float* env_B, int32_t* t_env, int32_t* cur_step, int32_t* episode_idx,
                                float* ep_return, float reward_scale, int horizon, int max_episode_frames,
                                int64_t env_seed_base, float* obs_row, float* acts_row, float* next_row,

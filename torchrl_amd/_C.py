@@ -164,8 +164,8 @@ SIGNATURES = {
                                             [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int] * 4 + [C.c_void_p]),
     "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
-    "trl_synth_collect_step_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 10 +
-                                   [C.c_int] * 6 + [C.c_void_p]),
+    "trl_synth_collect_step_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 6 +
+                                   [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 6 + [C.c_void_p]),
     "trl_collector_bookkeep_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_sac_alpha_step_f32": (C.c_int, [C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_void_p] * 3),
     "trl_sac_losses_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
@@ -384,14 +384,16 @@ def clip_adam(args, device):
 
 
 def synth_collect_step(env, head, eps, cur_step, ep_return, max_frames, rows, mask, epoch_reward, ep_count, ep_log, step,
-                       tanh_action):
+                       tanh_action, noise=None):
     """One off-policy vector step on the synthetic env in one launch; rows = (obs, acts, next_obs, rewards, terminals,
-    time_limits) destination rows (obs / acts / time_limits may be None)."""
-    N, D, A = int(env.cur_obs.shape[0]), int(env.cur_obs.shape[1]), int(eps.shape[1])
+    time_limits) destination rows (obs / acts / time_limits may be None).  eps None: `noise` = (seed, counter, first row)
+    of the device Philox draw, generated inside the launch."""
+    N, D, A = int(env.cur_obs.shape[0]), int(env.cur_obs.shape[1]), int(head.shape[1]) // 2
     obs_row, acts_row, next_row, rew_row, done_row, tl_row = rows
+    seed, ctr, row0 = noise if eps is None else (0, 0, 0)
     check(lib().trl_synth_collect_step_f32(
-        dev_ptr(env.cur_obs, name="cur_obs"), dev_ptr(head, name="head"), dev_ptr(eps, name="eps"),
-        dev_ptr(env.env_A, name="env_A"), dev_ptr(env.env_B, name="env_B"), dev_ptr(env.t_env, torch.int32, "t_env"),
+        dev_ptr(env.cur_obs, name="cur_obs"), dev_ptr(head, name="head"), dev_ptr(eps, name="eps", allow_none=True),
+        int(seed), int(ctr), int(row0), dev_ptr(env.env_A, name="env_A"), dev_ptr(env.env_B, name="env_B"), dev_ptr(env.t_env, torch.int32, "t_env"),
         dev_ptr(cur_step, torch.int32, "cur_step"), dev_ptr(env.episode_idx, torch.int32, "episode_idx"),
         dev_ptr(ep_return, name="ep_return"), float(env.effective_reward_scale), int(env.horizon), int(max_frames),
         int(env.seed_base), dev_ptr(obs_row, name="obs_row", allow_none=True),

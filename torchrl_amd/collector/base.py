@@ -278,7 +278,16 @@ class VecCollector(_CollectorBase):
         buf, pf = self.replay_buffer, self.pf
         n, d, a_dim = env.env_nums, env.obs_dim, env.act_dim
         head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf))
-        eps = torch.zeros(n, a_dim, device=env.device) if deterministic else self._explore_noise(env)
+        noise = None
+        if deterministic:
+            if getattr(self, "_zero_eps", None) is None or self._zero_eps.shape[0] != n:
+                self._zero_eps = torch.zeros(n, a_dim, device=env.device)
+            eps = self._zero_eps
+        elif self.noise_mode == "device":                                # drawn inside the launch: this rank's rows of the
+            from .. import dist                                          # (all envs, A) Philox draw of this vector step
+            eps, noise = None, (self._noise_seed, self.global_step, dist.rank() * n)
+        else:
+            eps = self._explore_noise(env)
         if store:
             row = buf._top
             rows = (buf._ensure_key("obs", (n, d))[row], buf._ensure_key("acts", (n, a_dim))[row],
@@ -290,7 +299,7 @@ class VecCollector(_CollectorBase):
         _C.synth_collect_step(env, head, eps, env.cur_step, env.ep_return,
                               self.max_episode_frames if max_frames is None else max_frames, rows, self._mask,
                               self._epoch_reward, self._ep_count, self._ep_log, self.global_step - self._log_step0,
-                              bool(pf.tanh_action))
+                              bool(pf.tanh_action), noise=noise)
         if store:
             buf._advance()
         self.global_step += 1

@@ -532,6 +532,8 @@ extern "C" int trl_synth_env_step_f32(float* cur_obs, const float* act, const fl
 // of work each, host-launch-bound at ~10 us apiece.  One thread per env; same arithmetic, same Philox blocks.
 struct CollectStep {
   float* cur_obs; const float* head; const float* eps; const float* envA; const float* envB;
+  int64_t noise_seed, noise_ctr; int noise_row0;   // eps == NULL: the exploration noise of trl_philox_normal_f32(seed, ctr),
+                                                   // rows [noise_row0, noise_row0 + N) of the (all envs, A) draw, made in place
   int32_t* t_env; int32_t* cur_step; int32_t* episode_idx; float* ep_return;
   float reward_scale; int horizon, max_frames; int64_t seed_base;
   float* obs_row; float* acts_row; float* next_row; float* rew_row; float* done_row; float* tl_row;   // obs / acts / tl nullable
@@ -550,7 +552,24 @@ __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(Collect
   if (n < c.N) {
     float o[32], a[8], nv[32];
     for (int k = 0; k < D; ++k) o[k] = c.cur_obs[(size_t)n * D + k];
-    rsample_row(c.head + (size_t)n * 2 * A, c.eps + (size_t)n * A, a, A, c.tanh_action);
+    float ez[8];
+    if (c.eps) {
+      for (int k = 0; k < A; ++k) ez[k] = c.eps[(size_t)n * A + k];
+    } else {                                       // element e of the draw = normal (e & 3) of Philox block e / 4
+      const int64_t e0 = (int64_t)(c.noise_row0 + n) * A;
+      int64_t blk = -1;
+      float z[4];
+      for (int k = 0; k < A; ++k) {
+        const int64_t e = e0 + k;
+        if ((e >> 2) != blk) {
+          blk = e >> 2;
+          philox_normals4((uint32_t)(c.noise_ctr & 0xFFFFFFFFll), (uint32_t)((c.noise_ctr >> 32) & 0xFFFFFFFFll),
+                          (uint32_t)blk, TRL_TAG_NOISE, c.noise_seed, z);
+        }
+        ez[k] = z[e & 3];
+      }
+    }
+    rsample_row(c.head + (size_t)n * 2 * A, ez, a, A, c.tanh_action);
     if (c.obs_row) for (int k = 0; k < D; ++k) c.obs_row[(size_t)n * D + k] = o[k];
     if (c.acts_row) for (int k = 0; k < A; ++k) c.acts_row[(size_t)n * A + k] = a[k];
     float asq = 0.0f;
@@ -596,7 +615,8 @@ __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(Collect
   r = block_sum(r, red);
   if (threadIdx.x == 0 && c.epoch_reward) atomicAdd(c.epoch_reward, r);
 }
-extern "C" int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* eps, const float* env_A,
+extern "C" int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* eps, int64_t noise_seed,
+                                          int64_t noise_counter, int noise_row0, const float* env_A,
                                           const float* env_B, int32_t* t_env, int32_t* cur_step, int32_t* episode_idx,
                                           float* ep_return, float reward_scale, int horizon, int max_episode_frames,
                                           int64_t env_seed_base, float* obs_row, float* acts_row, float* next_row,
@@ -605,9 +625,9 @@ extern "C" int trl_synth_collect_step_f32(float* cur_obs, const float* head, con
                                           int N, int D, int A, int tanh_action, void* stream) {
   TRL_REQUIRE(N >= 0 && D > 0 && D <= 32 && A > 0 && A <= 8 && ep_cap >= 0, "bad sizes (D <= 32, A <= 8)");
   if (N == 0) return TRL_OK;
-  TRL_REQUIRE(cur_obs && head && eps && env_A && env_B && t_env && cur_step && episode_idx && ep_return, "null pointer");
-  TRL_REQUIRE(next_row && rew_row && done_row && reset_mask && ep_count && ep_log, "null pointer");
-  CollectStep c{cur_obs, head, eps, env_A, env_B, t_env, cur_step, episode_idx, ep_return, reward_scale, horizon,
+  TRL_REQUIRE(cur_obs && head && env_A && env_B && t_env && cur_step && episode_idx && ep_return, "null pointer");
+  TRL_REQUIRE(next_row && rew_row && done_row && reset_mask && ep_count && ep_log && noise_row0 >= 0, "null pointer");
+  CollectStep c{cur_obs, head, eps, env_A, env_B, noise_seed, noise_counter, noise_row0, t_env, cur_step, episode_idx, ep_return, reward_scale, horizon,
                 max_episode_frames, env_seed_base, obs_row, acts_row, next_row, rew_row, done_row, tl_row, reset_mask,
                 epoch_reward, ep_count, ep_log, ep_cap, step, N, D, A, tanh_action};
   hipLaunchKernelGGL(synth_collect_step_kernel, dim3(trl_ceil_div(N, SAC_THREADS)), dim3(SAC_THREADS),
