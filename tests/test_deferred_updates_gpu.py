@@ -71,6 +71,48 @@ def test_dqn_epoch_of_deferred_updates_equals_update_by_update(Q):
     assert len({i["Training/qf_loss"] for i in ib}) == 4
 
 
+@pytest.mark.parametrize("kind", ["ddpg", "td3"])
+def test_ddpg_td3_epoch_of_deferred_updates_equals_update_by_update(kind):
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import DDPG, TD3
+    from torchrl.collector import VecCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    N, T, dev = 32, 12, torch.device(DEV)
+    res = []
+    for deferred in (False, True):
+        torch.manual_seed(4)
+        net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+        pf = policies.FixGuassianContPolicy(input_shape=17, output_shape=6, tanh_action=True, norm_std_explore=0.1, **net)
+        env, ev = SynthVecEnv(N, horizon=5, device=dev), SynthVecEnv(N, horizon=5, device=dev)
+        env.seed(2)
+        buf = BaseReplayBuffer(N * T, env_nums=N)
+        col = VecCollector(env=env, eval_env=ev, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * T,
+                           max_episode_frames=1000, eval_episodes=1)
+        col.train_one_epoch()
+        log = _Rec()
+        kw = dict(env=env, replay_buffer=buf, collector=col, logger=log, grad_clip=1.0, discount=0.99, num_epochs=1,
+                  batch_size=N * 4, device=dev, save_dir=None, tau=0.005, use_soft_update=True, opt_times=5)
+        q = lambda: networks.QNet(input_shape=23, output_shape=1, **net)
+        agent = DDPG(pf=pf, qf=q(), plr=3e-4, qlr=1e-3, **kw) if kind == "ddpg" else \
+            TD3(pf=pf, qf1=q(), qf2=q(), plr=3e-4, qlr=1e-3, noise_mode="device", **kw)
+        np.random.seed(6)
+        for _ in range(2):                                                   # the second epoch replays the captured graphs
+            if deferred:
+                agent.update_per_epoch()
+            else:
+                for _ in range(5):
+                    agent._one_update()
+        res.append((log.infos, agent.engine().flat.cpu().clone(), agent.engine().tflat.cpu().clone()))
+    (ia, fa, ta), (ib, fb, tb) = res
+    assert len(ia) == len(ib) == 10 and torch.equal(fa, fb) and torch.equal(ta, tb)
+    for x, y in zip(ia, ib):
+        assert x == y
+    if kind == "td3":                                                        # delayed policy steps keep their own keys
+        assert {len(i) for i in ib} == {len(ib[0]), len(ib[1])} and len(ib[0]) != len(ib[1])
+
+
 def test_more_pending_updates_than_ring_slots_still_resolve_in_order():
     from test_fullsize_offpolicy_gpu import build_cfg3
     pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=64)

@@ -63,6 +63,14 @@ class DDPG(OffRLAlgo):
         self.training_update_num += 1
         return self.engine().update_ddpg(batch)
 
+    def update_deferred(self, batch):
+        """`update` without its read-back (OffRLAlgo.update_per_epoch resolves an epoch's updates with one D2H)."""
+        self.training_update_num += 1
+        return self.engine().enqueue_ddpg(batch)
+
+    def resolve_updates(self, handles):
+        return self.engine().resolve(handles)
+
 
 class TD3(OffRLAlgo):
     def __init__(self, pf, qf1, qf2, plr, qlr, optimizer_class=optim.Adam, policy_update_delay=2,
@@ -108,6 +116,14 @@ class TD3(OffRLAlgo):
     def update(self, batch):
         self.training_update_num += 1
         return self.engine().update_td3(batch)
+
+    def update_deferred(self, batch):
+        """`update` without its read-back (OffRLAlgo.update_per_epoch resolves an epoch's updates with one D2H)."""
+        self.training_update_num += 1
+        return self.engine().enqueue_td3(batch)
+
+    def resolve_updates(self, handles):
+        return self.engine().resolve(handles)
 
 
 class _FusedDetAC:
@@ -279,7 +295,34 @@ class _FusedDetAC:
         dist.all_reduce_sum_(self.sums)
         _C.moments(dist.all_gather_cat(new_a), self.mom, ld=1)
 
+    # ---- launch now, read back later: the statistics of an update go (stream-ordered) into a slot of a device ring ----
+    def _park(self, *extra):
+        if getattr(self, "_ring", None) is None or self._ring_used == self._ring.shape[0]:
+            self._ring = torch.zeros(max(64, int(getattr(self.algo, "opt_times", 1))), self._raw.numel(), dtype=torch.uint8,
+                                     device=self.dev)
+            self._ring_used = 0
+        slot, self._ring_used = self._ring_used, self._ring_used + 1
+        self._ring[slot].copy_(self._raw, non_blocking=True)
+        return (self._ring, slot) + extra
+
+    def resolve(self, handles):
+        """Info dicts of enqueued updates, in order, after one D2H per ring (the only host sync)."""
+        host = {}
+        for h in handles:
+            if id(h[0]) not in host:
+                host[id(h[0])] = h[0].cpu()
+        if getattr(self, "_ring", None) is not None and all(h[0] is self._ring for h in handles) and \
+                len(handles) == self._ring_used:
+            self._ring_used = 0
+        return [h[2](host[id(h[0])][h[1]], *h[3:]) for h in handles]
+
     def update_ddpg(self, batch):
+        return self.resolve([self.enqueue_ddpg(batch)])[0]
+
+    def update_td3(self, batch):
+        return self.resolve([self.enqueue_td3(batch)])[0]
+
+    def enqueue_ddpg(self, batch):
         algo = self.algo
         st, B = self._load(batch, ())
         soft = bool(algo.use_soft_update)
@@ -287,8 +330,10 @@ class _FusedDetAC:
         self.steps = [n + 1 for n in self.steps]
         if self._hard_update_due():
             _C.polyak(self.tflat, self.flat, 1.0)
-        B = B * dist.world_size()                                           # the sums cover every rank's samples
-        raw = self._raw.cpu()
+        return self._park(self._info_ddpg, B * dist.world_size())           # the sums cover every rank's samples
+
+    def _info_ddpg(self, raw, B):
+        algo = self.algo
         sums, m = raw[0:32].view(torch.float64).numpy(), raw[64:96].view(torch.float64).numpy()
         norms = raw[96:].view(torch.float32).numpy()
         info = {'Reward_Mean': sums[3] / B, 'Training/policy_loss': sums[2] / B, 'Training/qf_loss': sums[0] / B}
@@ -327,7 +372,7 @@ class _FusedDetAC:
             _C.moments(dist.all_gather_cat(new_a), self.mom, ld=1)
         dist.all_reduce_sum_(self.sums)
 
-    def update_td3(self, batch):
+    def enqueue_td3(self, batch):
         algo = self.algo
         # target_pf.explore draws only for policies with exploration noise; then the smoothing draw
         st, B = self._load(batch, (("eps_explore",) if self.sigma_explore else ()) + ("eps_smooth",))
@@ -337,8 +382,10 @@ class _FusedDetAC:
         self.steps = [self.steps[0] + int(delayed), self.steps[1] + 1, self.steps[2] + 1]
         if delayed and self._hard_update_due():
             _C.polyak(self.tflat, self.flat, 1.0)
-        B = B * dist.world_size()                                           # the sums cover every rank's samples
-        raw = self._raw.cpu()
+        return self._park(self._info_td3, B * dist.world_size(), delayed)   # the sums cover every rank's samples
+
+    def _info_td3(self, raw, B, delayed):
+        algo = self.algo
         sums, sums_p = raw[0:32].view(torch.float64).numpy(), raw[32:64].view(torch.float64).numpy()
         m, norms = raw[64:96].view(torch.float64).numpy(), raw[96:].view(torch.float32).numpy()
         info = {'Reward_Mean': sums[3] / B, 'Training/qf1_loss': sums[0] / B, 'Training/qf2_loss': sums[1] / B}
