@@ -373,6 +373,9 @@ int trl_linear_fwd_f32(const float* x, const float* w, const float* bias, float*
  * go to `workspace` (trl_linear_fwd_workspace(M, K, N) floats, 0 = the layer is not split and workspace may
  * be NULL) and are folded in fixed order together with bias and activation. */
 int trl_linear_fwd_workspace(int M, int K, int N);
+/* (…_splitk_group_f32: G same-shaped layers, one launch of split GEMMs + one fold; workspace = G x that many floats) */
+int trl_linear_fwd_splitk_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
+                                    float* const* y, int M, int K, int N, int act, float* workspace, void* stream);
 int trl_linear_fwd_splitk_f32(const float* x, const float* w, const float* bias, float* y,
                               int M, int K, int N, int act, float* workspace, void* stream);
 int trl_linear_bwd_input_f32(const float* dy, const float* y_gate, int gate_act, const float* w,
@@ -555,6 +558,11 @@ int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, in
  * Workspace of the weight gradient: trl_conv_bwd_weight_workspace. */
 int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
                           int kh, int kw, int sh, int sw, int Cout, int act, void* stream);
+/* G conv layers of one geometry (different inputs / weights / outputs) in one launch: the online and the target
+ * network of a DQN update (dqn.py:47-52) run the same trunk on obs and next_obs */
+int trl_conv_fwd_nhwc_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
+                                float* const* y, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout,
+                                int act, void* stream);
 int trl_conv_bwd_weight_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* x, float* dw,
                                  float* db, float* workspace, int B, int C, int H, int W, int kh, int kw, int sh,
                                  int sw, int Cout, void* stream);

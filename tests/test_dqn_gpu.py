@@ -166,6 +166,43 @@ def test_implicit_transposed_conv_coverage_and_errors():
                                2, 4, 4, 4, 3, 3, 1, 1)
 
 
+def test_paired_forward_of_online_and_target_net_equals_two_passes():
+    """ops.cnn_forward_pair (conv 2 / 3, the FC layer and the head of both networks as grouped launches) against two
+    ops.cnn_forward passes: outputs and every tape tensor bit for bit, at cfg 5's shapes."""
+    import copy
+    import torchrl.networks as networks
+    from torchrl_amd import ops
+    torch.manual_seed(2)
+    convs = [[16, [8, 8], [4, 4], [0, 0]], [32, [4, 4], [2, 2], [0, 0]], [64, [3, 3], [1, 1], [0, 0]]]
+    qf = networks.Net(output_shape=6, base_type=networks.CNNBase, append_hidden_shapes=[512], activation_func=torch.nn.Tanh,
+                      input_shape=(4, 84, 84), hidden_shapes=convs).to(DEV)
+    tq = copy.deepcopy(qf)
+    with torch.no_grad():
+        for p in tq.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    fa = torch.randint(0, 256, (96, 4, 84, 84), dtype=torch.uint8, device=DEV)
+    fb = torch.randint(0, 256, (96, 4, 84, 84), dtype=torch.uint8, device=DEV)
+    (qa, ta), (qb, tb) = ops.cnn_forward_pair(qf, tq, fa, fb)
+    wa, wta = ops.cnn_forward(qf, fa)
+    wb, wtb = ops.cnn_forward(tq, fb)
+    assert torch.equal(qa, wa) and torch.equal(qb, wb)
+    for got, want in ((ta, wta), (tb, wtb)):
+        assert len(got.convs) == len(want.convs) == 3 and got.feat_shape == want.feat_shape
+        for g, w in zip(got.convs, want.convs):
+            assert g[0] == w[0] and torch.equal(g[2], w[2]) and g[4] == w[4] and g[5] == w[5]
+        for g, w in zip(got.fc.outs, want.fc.outs):
+            assert torch.equal(g, w)
+    # the backward pass runs on a tape of either origin
+    d = torch.randn_like(qa)
+    gp = [torch.zeros_like(p) for p in ops.cnn_param_list(qf)]
+    gw = [torch.zeros_like(p) for p in ops.cnn_param_list(qf)]
+    pair = lambda g: [(g[k], g[k + 1]) for k in range(0, len(g), 2)]
+    ops.cnn_backward(qf, ta, d, pair(gp))
+    ops.cnn_backward(qf, wta, d, pair(gw))
+    for x, y in zip(gp, gw):
+        assert torch.equal(x, y)
+
+
 def test_implicit_gemm_rejects_unaligned_geometry():
     from torchrl_amd import _C
     frames = torch.zeros(2, 4, 21, 21, dtype=torch.uint8, device=DEV)

@@ -214,6 +214,8 @@ SIGNATURES = {
                                        + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_bwd_weight_group_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
                                         + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_linear_fwd_splitk_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
+    "trl_conv_fwd_nhwc_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "trl_linear_fwd_splitk_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "trl_linear_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -552,6 +554,13 @@ def linear_fwd_group(xs, ws, biases, act):
     if any(tuple(x.shape) != (M, K) for x in xs) or any(tuple(w.shape) != (N, K) for w in ws):
         raise TrlError("linear_fwd_group: the layers of a group must have identical shapes")
     ys = [torch.empty((M, N), dtype=torch.float32, device=xs[0].device) for _ in range(G)]
+    need = lib().trl_linear_fwd_workspace(M, K, N)
+    if need > 0:                                                         # few rows, long reduction: split-K + fold, grouped
+        wsp = torch.empty((G * need,), dtype=torch.float32, device=xs[0].device)
+        check(lib().trl_linear_fwd_splitk_group_f32(G, _ptrs(xs, "x"), _ptrs(ws, "w"), _ptrs(biases, "bias", True),
+                                                    _ptrs(ys, "y"), M, K, N, act, dev_ptr(wsp, name="workspace"),
+                                                    stream_ptr(xs[0].device)), "trl_linear_fwd_splitk_group_f32")
+        return ys
     check(lib().trl_linear_fwd_group_f32(G, _ptrs(xs, "x"), _ptrs(ws, "w"), _ptrs(biases, "bias", True), _ptrs(ys, "y"),
                                          M, K, N, act, stream_ptr(xs[0].device)), "trl_linear_fwd_group_f32")
     return ys
@@ -890,6 +899,20 @@ def conv_fwd_nhwc(x, w, bias, kh, kw, sh, sw, act):
                                       dev_ptr(y, name="y"), B, Cc, H, W, kh, kw, sh, sw, Cout, act, stream_ptr(x.device)),
           "trl_conv_fwd_nhwc_f32")
     return y, (B, Ho, Wo)
+
+
+def conv_fwd_nhwc_group(xs, ws, biases, kh, kw, sh, sw, act):
+    """`conv_fwd_nhwc` of G same-geometry layers (different inputs / weights) in one launch; returns ([y_g], (B, Ho, Wo))."""
+    B, H, W, Cc = (int(v) for v in xs[0].shape)
+    if any(tuple(x.shape) != tuple(xs[0].shape) for x in xs) or any(tuple(w.shape) != tuple(ws[0].shape) for w in ws):
+        raise TrlError("conv_fwd_nhwc_group: the layers of a group share one geometry")
+    Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
+    Cout = int(ws[0].shape[0])
+    ys = [torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=xs[0].device) for _ in xs]
+    check(lib().trl_conv_fwd_nhwc_group_f32(len(xs), _ptrs(xs, "x"), _ptrs(ws, "w"), _ptrs(biases, "bias", True),
+                                            _ptrs(ys, "y"), B, Cc, H, W, kh, kw, sh, sw, Cout, act,
+                                            stream_ptr(xs[0].device)), "trl_conv_fwd_nhwc_group_f32")
+    return ys, (B, Ho, Wo)
 
 
 def conv_bwd_weight_nhwc(dy, y_gate, gate_act, x, kh, kw, sh, sw, dw, db, workspace=None):

@@ -146,8 +146,8 @@ class _FusedDQN:
             q, tape = ops.mlp_forward(self.layers, obs, self.act)
             qn, _ = ops.mlp_forward(self.tlayers, nobs, self.act)
         else:
-            q, tape = ops.cnn_forward(algo.qf, obs)
-            qn, _ = ops.cnn_forward(algo.target_qf, nobs)
+            # online net on obs and target net on next_obs: one grouped launch per layer after the first
+            (q, tape), (qn, _) = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs)
         if Q == 1:
             dq = _C.dqn_td_loss(q, acts, qn, rew, term, algo.discount, self.sums)
             denom = float(B)

@@ -173,9 +173,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   int k_lo = 0, k_hi = g_K;
   const float* pA = g.A; const float* pB = g.B; float* C = g.C;
   const float* pBias = g.bias; const float* pGate = g.a_gate; float* pColsum = g.colsum;
+  const float* cvx = g.cv.x;                       // CONV 3: the activations the implicit A operand is read from
   if (g.groups > 1) {                              // grouped launch: problem blockIdx.y
     const GemmGroup& q = g.grp[blockIdx.y];
     pA = q.A; pB = q.B; C = q.C; pBias = q.bias; pGate = q.a_gate; pColsum = q.colsum;
+    if (CONV == 3) cvx = q.A;                      // (a grouped implicit forward carries its input in the free A slot)
   }
   if (gridDim.z > 1) {                             // split reduction: blockIdx.z owns split_len indices, writes its own
     k_lo = blockIdx.z * g_split_len;               // partial C (folded in fixed order by fold_partials_kernel)
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
 #pragma unroll
       for (int t = 0; t < SC; ++t) {
         const bool ok = kin && cbase[t] != 0xffffffffu;
-        ra[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? cbase[t] + tap : 0u)) : zero4;
+        ra[t] = ok ? *reinterpret_cast<const f32x4*>(cvx + (ok ? cbase[t] + tap : 0u)) : zero4;
       }
     } else if (a_whole && k_whole) {
       panel_fetch_fast<!TA, GM>(pA, g_lda, m0, k0, tid, ra);
@@ -395,6 +397,7 @@ struct FoldGroup { const float* part; float* out; const float* part2; float* out
 struct FoldDev {
   int n, n2, splits;
   const float* bias; int n_cols, act;             // split-K forward: the epilogue the GEMM skipped (n_cols > 0)
+  const float* bias_grp[GEMM_MAX_GROUPS];          //   (grouped: the bias of problem blockIdx.y, when gridDim.y > 1)
   int perm_c, perm_khw;                            // conv weight gradient computed in (i, j, c) column order
   FoldGroup grp[GEMM_MAX_GROUPS];                  // problem blockIdx.y
 };
@@ -422,7 +425,8 @@ __global__ __launch_bounds__(64 * FOLD_MAX_WAVES) void fold_partials_kernel(Fold
     float v = (sl[0][lane] + sl[1][lane]) + (sl[2][lane] + sl[3][lane]);
     for (int w = 4; w < waves; w += 4) v += (sl[w][lane] + sl[w + 1][lane]) + (sl[w + 2][lane] + sl[w + 3][lane]);
     if (!second && f.n_cols > 0) {
-      if (f.bias) v += f.bias[ee % f.n_cols];
+      const float* bias = gridDim.y > 1 ? f.bias_grp[blockIdx.y] : f.bias;
+      if (bias) v += bias[ee % f.n_cols];
       if (f.act == TRL_ACT_TANH) v = trl_tanh(v);
       else if (f.act == TRL_ACT_RELU) v = fmaxf(v, 0.0f);
     }
@@ -609,6 +613,38 @@ extern "C" int trl_linear_fwd_splitk_f32(const float* x, const float* w, const f
   f.n = M * N; f.n2 = 0; f.splits = splits; f.bias = bias; f.n_cols = N; f.act = act;
   f.grp[0] = FoldGroup{workspace, y, nullptr, nullptr};
   return launch_fold(f, 1, (hipStream_t)stream);
+}
+
+// the same for G same-shaped layers (one launch of split GEMMs + one fold): workspace = G x trl_linear_fwd_workspace floats
+extern "C" int trl_linear_fwd_splitk_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
+                                               float* const* y, int M, int K, int N, int act, float* workspace,
+                                               void* stream) {
+  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per grouped launch");
+  TRL_REQUIRE(M >= 0 && K > 0 && N > 0 && x && w && y, "bad sizes / null pointer array");
+  if (M == 0) return TRL_OK;
+  const int split_len = fwd_split_len(M, K, N);
+  const int splits = trl_ceil_div(K, split_len);
+  if (splits <= 1) return linear_fwd_impl(G, x, w, bias, y, M, K, N, act, (hipStream_t)stream);
+  TRL_REQUIRE(workspace, "null workspace");
+  TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
+  GemmDev g{};
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.act = TRL_ACT_NONE; g.gate_act = TRL_ACT_NONE;
+  g.split_len = split_len; g.groups = G;
+  FoldDev f{};
+  f.n = M * N; f.n2 = 0; f.splits = splits; f.n_cols = N; f.act = act;
+  const float* bias0 = bias ? bias[0] : nullptr;
+  for (int i = 0; i < G; ++i) {
+    TRL_REQUIRE(x[i] && w[i] && y[i], "null pointer");
+    float* part = workspace + (size_t)i * splits * M * N;
+    g.grp[i] = GemmGroup{x[i], w[i], part, nullptr, nullptr, nullptr};
+    f.grp[i] = FoldGroup{part, y[i], nullptr, nullptr};
+    f.bias_grp[i] = bias ? bias[i] : nullptr;
+  }
+  f.bias = bias0;
+  g.A = x[0]; g.B = w[0]; g.C = g.grp[0].C;
+  int rc = launch_gemm<false, true>(g, splits, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_fold(f, G, (hipStream_t)stream);
 }
 
 static int linear_bwd_input_impl(int G, const float* const* dy, const float* const* y_gate, int gate_act,
@@ -833,6 +869,29 @@ extern "C" int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float
   if (rc) return rc;
   g.A = nullptr; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
   g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
+  return launch_gemm<false, true, 3>(g, 1, (hipStream_t)stream);
+}
+
+// G same-geometry conv layers (different inputs, weights, outputs) in one launch: the online and the target network of
+// a DQN update run the same trunk on obs and next_obs
+extern "C" int trl_conv_fwd_nhwc_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
+                                           float* const* y, int B, int C, int H, int W, int kh, int kw, int sh, int sw,
+                                           int Cout, int act, void* stream) {
+  TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per grouped launch");
+  TRL_REQUIRE(x && w && y && Cout > 0, "null pointer array / bad Cout");
+  TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
+  GemmDev g{};
+  int M, K;
+  for (int i = 0; i < G; ++i) {
+    TRL_REQUIRE(x[i] && w[i] && y[i], "null pointer");
+    int rc = fill_conv_nhwc("conv_fwd_nhwc_group", x[i], B, C, H, W, kh, kw, sh, sw, g.cv, M, K);   // checks every input
+    if (rc) return rc;
+    g.grp[i] = GemmGroup{x[i], w[i], y[i], bias ? bias[i] : nullptr, nullptr, nullptr};
+  }
+  g.groups = G;
+  g.A = nullptr; g.B = w[0]; g.C = y[0]; g.bias = bias ? bias[0] : nullptr; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
+  g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
+  g.cv.x = x[0];
   return launch_gemm<false, true, 3>(g, 1, (hipStream_t)stream);
 }
 

@@ -194,6 +194,56 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
     return out, t
 
 
+def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=-0.5):
+    """`cnn_forward` of two same-architecture networks on two frame batches -- DQN's online net on obs and target net on
+    next_obs -- with every layer after the first as ONE grouped launch (conv 2 / 3 as grouped implicit GEMMs, the FC head
+    as grouped (split-K) layers).  Returns ((out_a, tape_a), (out_b, tape_b)); falls back to two separate passes for
+    geometries outside the grouped paths.  Same kernels and arithmetic as `cnn_forward`."""
+    convs_a, convs_b = conv_layers(net_a), conv_layers(net_b)
+    act = cnn_act_code(net_a)
+    same = (len(convs_a) == len(convs_b) and cnn_act_code(net_b) == act and tuple(frames_a.shape) == tuple(frames_b.shape)
+            and all(ma.weight.shape == mb.weight.shape and ma.kernel_size == mb.kernel_size and ma.stride == mb.stride
+                    for ma, mb in zip(convs_a, convs_b))
+            and [tuple(w.shape) for w, _ in fc_layers(net_a)] == [tuple(w.shape) for w, _ in fc_layers(net_b)])
+    first = convs_a[0] if convs_a else None
+    if not same or first is None or frames_a.dtype != torch.uint8 or \
+            not _C.conv_u8_implicit_ok(frames_a, *first.kernel_size, *first.stride) or \
+            any(int(m.in_channels) % 4 for m in convs_a[1:]):
+        return cnn_forward(net_a, frames_a, scale, shift), cnn_forward(net_b, frames_b, scale, shift)
+    tapes, xs = [], []
+    for net, convs, frames in ((net_a, convs_a, frames_a), (net_b, convs_b, frames_b)):
+        t = ConvTape()
+        t.convs, t.act, t.B = [], act, int(frames.shape[0])
+        m = convs[0]
+        kh, kw = m.kernel_size
+        sh, sw = m.stride
+        wmat = m.weight.view(m.weight.shape[0], -1)
+        fr = frames.contiguous()
+        y, (B, Ho, Wo) = _C.conv_fwd_u8(fr, wmat, m.bias, kh, kw, sh, sw, scale, shift, act)
+        t.convs.append(("u8", (fr, scale, shift), y, wmat, None, (kh, kw, sh, sw)))
+        tapes.append(t)
+        xs.append(y.view(B, Ho, Wo, int(wmat.shape[0])))
+    for k in range(1, len(convs_a)):
+        ma, mb = convs_a[k], convs_b[k]
+        kh, kw = ma.kernel_size
+        sh, sw = ma.stride
+        wmats = [m.weight.view(m.weight.shape[0], -1) for m in (ma, mb)]
+        in_shape = tuple(int(v) for v in xs[0].shape)
+        ys, (B, Ho, Wo) = _C.conv_fwd_nhwc_group(xs, wmats, [ma.bias, mb.bias], kh, kw, sh, sw, act)
+        for t, x, y, wmat in zip(tapes, xs, ys, wmats):
+            t.convs.append(("nhwc", x, y, wmat, in_shape, (kh, kw, sh, sw)))
+        xs = [y.view(B, Ho, Wo, int(wmats[0].shape[0])) for y in ys]
+    B, Ho, Wo, Cc = (int(v) for v in xs[0].shape)
+    feats = []
+    for t, x in zip(tapes, xs):
+        t.feat_shape = (Ho * Wo, Cc)
+        feats.append(_C.transpose_bpc(x, B, Ho * Wo, Cc).view(B, Cc * Ho * Wo))   # PyTorch's NCHW flatten order
+    outs, fcs = mlp_forward_group([fc_layers(net_a), fc_layers(net_b)], feats, act)
+    for t, fc in zip(tapes, fcs):
+        t.fc = fc
+    return (outs[0], tapes[0]), (outs[1], tapes[1])
+
+
 def cnn_backward(net, tape, d_out, grads, workspace=None):
     """grads: [(dW_view, db_view), ...] in cnn_param_list order (conv layers, then FC layers).
     The gradient flowing down the trunk is gated ONCE, where it is produced (dZ = dY * act'(Y): in the transpose that
