@@ -8,6 +8,7 @@ Actions are read as (B,) or (B, 1) and cast to int64 (the reference's two classe
 shape, its Q16).
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -55,6 +56,9 @@ class DQN(OffRLAlgo):
     def update(self, batch):
         self.training_update_num += 1
         return self.engine().update(batch)
+
+    def static_batch(self):
+        return self.engine().static_batch()
 
     def update_deferred(self, batch):
         """`update` without its read-back (see OffRLAlgo.update_per_epoch): returns a handle for `resolve_updates`."""
@@ -107,6 +111,8 @@ class _FusedDQN:
         self.A = int(algo.env.action_space.n)
         self.workspace = None
         self._ring, self._ring_used = None, 0
+        self._static, self._graphs, self._seen = None, {}, set()
+        self.step_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.dev)
 
     def update(self, batch):
         return self.resolve([self.enqueue(batch)])[0]
@@ -125,22 +131,39 @@ class _FusedDQN:
             out.append({'Reward_Mean': s[2] / B, 'Training/qf_loss': s[0] / denom, 'epsilon': eps, 'q_s_a': s[1] / (B * Q)})
         return out
 
-    def enqueue(self, batch):
-        """Launch one update without waiting for it; its loss sums are copied (stream-ordered) into a ring slot."""
+    def static_batch(self):
+        """Fixed-address input tensors of an update (None until the first batch has shown the shapes): the replay gather
+        writes straight into them (`random_batch(..., out=)`) and the captured launch sequence reads them."""
+        return self._static
+
+    def _load(self, batch):
+        dev = self.dev
+        obs = batch['obs']
+        if not self.is_mlp and not (isinstance(obs, torch.Tensor) and obs.dtype == torch.uint8):
+            raise _C.TrlError("DQN.update expects uint8 (B, C, H, W) frame stacks from the device replay buffer")
+        want = torch.uint8 if not self.is_mlp else torch.float32
+        B = int(obs.shape[0])
+        st = self._static
+        if st is None or int(st["obs"].shape[0]) != B:
+            shape = tuple(int(v) for v in (obs.shape if isinstance(obs, torch.Tensor) else np.asarray(obs).shape))
+            f = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+            st = {"obs": torch.zeros(shape, dtype=want, device=dev), "next_obs": torch.zeros(shape, dtype=want, device=dev),
+                  "acts": f(B, 1), "rewards": f(B, 1), "terminals": f(B, 1)}
+            self._static, self._graphs, self._seen = st, {}, set()
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals"):
+            src = batch[k]
+            if src is st[k]:
+                continue
+            src = src if isinstance(src, torch.Tensor) else torch.as_tensor(np.asarray(src))
+            st[k].copy_(src.to(device=dev, dtype=st[k].dtype).reshape(st[k].shape), non_blocking=True)
+        return st, B
+
+    def _sequence(self, st, soft):
+        """The fixed launch sequence of one update on the static inputs (eager, or under graph capture)."""
         algo, dev = self.algo, self.dev
-        obs, nobs = batch['obs'], batch['next_obs']
-        if self.is_mlp:
-            to_f = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
-                .to(device=dev, dtype=torch.float32).contiguous()
-            obs, nobs = to_f(obs), to_f(nobs)
-        else:
-            if not (isinstance(obs, torch.Tensor) and obs.dtype == torch.uint8):
-                raise _C.TrlError("DQN.update expects uint8 (B, C, H, W) frame stacks from the device replay buffer")
-            obs, nobs = obs.to(dev).contiguous(), nobs.to(dev).contiguous()
-        as_f = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))) \
-            .to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
-        rew, term = as_f(batch['rewards']), as_f(batch['terminals'])
-        acts = as_f(batch['acts']).to(torch.int64)
+        obs, nobs = st["obs"], st["next_obs"]
+        rew, term = st["rewards"].view(-1), st["terminals"].view(-1)
+        acts = st["acts"].view(-1).to(torch.int64)
         B, A, Q = int(obs.shape[0]), self.A, int(algo.quantile_num)
         if self.is_mlp:
             q, tape = ops.mlp_forward(self.layers, obs, self.act)
@@ -150,10 +173,8 @@ class _FusedDQN:
             (q, tape), (qn, _) = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs)
         if Q == 1:
             dq = _C.dqn_td_loss(q, acts, qn, rew, term, algo.discount, self.sums)
-            denom = float(B)
         else:
             dq = _C.quantile_huber(q, acts, qn, rew, term, algo.discount, A, Q, self.sums)
-            denom = float(B) * Q * Q
         if self.is_mlp:
             need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0])) for w, _ in self.layers)
         else:
@@ -167,7 +188,6 @@ class _FusedDQN:
             ops.mlp_backward(tape, dq, grads=self.gviews, workspace=self.workspace)
         else:
             ops.cnn_backward(algo.qf, tape, dq, self.gviews, workspace=self.workspace)
-        self.step_count += 1
         a = _C.AdamArgs()
         a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
                                                       self.m.data_ptr(), self.v.data_ptr())
@@ -177,13 +197,46 @@ class _FusedDQN:
         a.max_norm, a.beta1, a.beta2 = 0.0, 0.9, 0.999
         a.eps = float(algo.optimizer_info.get("eps", 1e-8))
         dist.all_reduce_sum_(self.grads)                                 # C1: local-mean gradients -> SUM / world
-        a.grad_scale, a.step_count, a.norms_out = 1.0 / dist.world_size(), self.step_count, None
+        a.grad_scale, a.norms_out = 1.0 / dist.world_size(), None
+        a.step_count, a.step_state = 0, self.step_state.data_ptr()       # the step count lives on the device
         _C.clip_adam(a, dev)
-        if algo.use_soft_update:
+        if soft:
             _C.polyak(self.tflat, self.flat, algo.tau)
-        elif algo.training_update_num % algo.target_hard_update_period == 0:
-            _C.polyak(self.tflat, self.flat, 1.0)
         dist.all_reduce_sum_(self.sums)
+
+    def _run(self, st, soft):
+        """Eager on the first visit of a configuration, captured into a HIP graph on the second, replayed afterwards
+        (TRL_NO_GRAPH=1, or collectives between ranks: eager launches): the host then issues one call per update instead
+        of ~45 and stays ahead of the device."""
+        algo = self.algo
+        key = (int(st["obs"].shape[0]), soft, float(algo.qf_optimizer.param_groups[0]['lr']), float(algo.discount),
+               float(algo.tau), int(algo.quantile_num))
+        if os.environ.get("TRL_NO_GRAPH") == "1" or dist.collectives_active() or \
+                (key not in self._graphs and len(self._graphs) >= 4):
+            self._sequence(st, soft)
+        elif key in self._graphs:
+            self._graphs[key].replay()
+        elif key not in self._seen:
+            self._seen.add(key)
+            self._sequence(st, soft)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._sequence(st, soft)
+            self._graphs[key] = graph
+            graph.replay()
+
+    def enqueue(self, batch):
+        """Launch one update without waiting for it; its loss sums are copied (stream-ordered) into a ring slot."""
+        algo, dev = self.algo, self.dev
+        st, B = self._load(batch)
+        Q = int(algo.quantile_num)
+        denom = float(B) if Q == 1 else float(B) * Q * Q
+        soft = bool(algo.use_soft_update)
+        self._run(st, soft)
+        self.step_count += 1
+        if not soft and algo.training_update_num % algo.target_hard_update_period == 0:
+            _C.polyak(self.tflat, self.flat, 1.0)
         B, denom = B * dist.world_size(), denom * dist.world_size()
         if self._ring is None or self._ring_used == self._ring.shape[0]:
             self._ring = torch.zeros(max(64, int(getattr(algo, "opt_times", 1))), 3, dtype=torch.float64, device=dev)

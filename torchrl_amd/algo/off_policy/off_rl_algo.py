@@ -28,8 +28,9 @@ class OffRLAlgo(RLAlgo):
     def _sample(self):
         extra = {}
         static = getattr(self, "static_batch", None)
-        if static is not None:
-            extra["out"] = static()
+        out = static() if static is not None else None                  # (None until the engine has seen its first batch)
+        if out is not None:
+            extra["out"] = out
         return self.replay_buffer.random_batch(self.batch_size, self.sample_key, **extra)
 
     def update_per_epoch(self):
