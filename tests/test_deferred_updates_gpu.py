@@ -71,6 +71,32 @@ def test_dqn_epoch_of_deferred_updates_equals_update_by_update(Q):
     assert len({i["Training/qf_loss"] for i in ib}) == 4
 
 
+@pytest.mark.parametrize("Q", [1, 8])
+def test_dqn_graph_replayed_updates_equal_eager_launches(Q, monkeypatch):
+    """Updates 3+ of a configuration replay a captured HIP graph (fixed-address inputs filled by the replay gather, Adam
+    step count on the device): same launches, so parameters and logged statistics equal the eager sequence bit for bit."""
+    from test_fullsize_offpolicy_gpu import build_cfg5
+    res = []
+    for no_graph in ("1", "0"):
+        monkeypatch.setenv("TRL_NO_GRAPH", no_graph)
+        qf, pf, env, buf, col, agent = build_cfg5(Q)
+        agent.logger = _Rec()
+        agent.opt_times = 3
+        np.random.seed(2)
+        col.train_one_epoch()
+        np.random.seed(3)
+        for _ in range(2):
+            agent.update_per_epoch()
+        eng = agent.engine()
+        assert len(eng._graphs) == (0 if no_graph == "1" else 1) and eng.step_state.cpu()[0].item() == 6
+        assert eng.static_batch()["obs"].dtype == torch.uint8
+        res.append((agent.logger.infos, eng.flat.cpu().clone(), eng.tflat.cpu().clone()))
+    (ia, fa, ta), (ib, fb, tb) = res
+    assert len(ia) == len(ib) == 6 and torch.equal(fa, fb) and torch.equal(ta, tb)
+    for x, y in zip(ia, ib):
+        assert x == y
+
+
 @pytest.mark.parametrize("kind", ["ddpg", "td3"])
 def test_ddpg_td3_epoch_of_deferred_updates_equals_update_by_update(kind):
     import torchrl.networks as networks
