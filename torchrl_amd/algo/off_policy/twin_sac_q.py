@@ -193,14 +193,17 @@ class _FusedSAC:
         alpha = self.alpha_out[0:1]                                      # re-read AFTER the alpha step, as the reference does
         dq1, dq2, dq1n, dq2n = _C.sac_losses(q1p, q2p, tq1, tq2, next_logp, rew, term, q1n, q2n, logp, alpha,
                                              algo.discount, self.sums)
-        # ---- policy gradient: through both Q nets to the action, then through the sampler ----
-        dx1, dx2 = ops.mlp_backward_group([tape_q1n, tape_q2n], [dq1n, dq2n], grads_list=None, need_input=True)
+        # weight gradients of all nine layers: ONE launch of split GEMMs + ONE fold, after the input-gradient chains
+        plan = _C.FoldPlan(ws, defer_gemm=os.environ.get("TRL_SAC_DW_PER_LAYER") != "1")
+        # ---- the four critic backward passes as one group: through Q1 / Q2 on [obs | new_a] down to the action (policy
+        # gradient, no weight gradients: twin_sac_q.py:152-155 discards them, its Q20) and the Q-loss pass on [obs | acts]
+        # (weight gradients, no input gradient) ----
+        dx1, dx2, _, _ = ops.mlp_backward_group([tape_q1n, tape_q2n, tape_q1, tape_q2], [dq1n, dq2n, dq1, dq2],
+                                                grads_list=[None, None, self.gviews[1], self.gviews[2]],
+                                                need_input=[True, True, False, False], plan=plan)
         d_head = _C.rsample_bwd_cols(head, eps1, new_a, dx1, dx2, D, alpha, 1.0 / B, algo.policy_std_reg_weight,
                                      algo.policy_mean_reg_weight, tanh_action)    # d_act = (dx1 + dx2)[:, D:]
-        # weight gradients of all nine layers: ONE launch of split GEMMs + ONE fold, after the two input-gradient chains
-        plan = _C.FoldPlan(ws, defer_gemm=os.environ.get("TRL_SAC_DW_PER_LAYER") != "1")
         ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], plan=plan)
-        ops.mlp_backward_group([tape_q1, tape_q2], [dq1, dq2], grads_list=[self.gviews[1], self.gviews[2]], plan=plan)
         plan.run()
         # ---- optimiser steps (pf, qf1, qf2) and target update ----
         a = _C.AdamArgs()

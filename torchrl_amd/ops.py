@@ -92,23 +92,36 @@ def mlp_forward_group(layers_list, xs, act, last_act=None):
 
 
 def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspace=None, plan=None):
-    """`mlp_backward` of G same-shaped tapes with grouped launches.  grads_list: [grads of tape g] or None."""
+    """`mlp_backward` of G same-shaped tapes with grouped launches.  grads_list: [grads of tape g] or None; an entry may
+    be None (no weight gradients for that tape).  need_input: one flag, or one per tape -- tapes that do not need
+    d(input) drop out of the first layer's input-gradient launch (their slot of the result is None)."""
     ds = list(d_outs)
     n = len(tapes[0].layers)
+    want_in = list(need_input) if isinstance(need_input, (list, tuple)) else [bool(need_input)] * len(tapes)
+    with_w = [] if grads_list is None else [g for g in range(len(tapes)) if grads_list[g] is not None]
     for k in range(n - 1, -1, -1):
         last = k == n - 1
         gate_act = tapes[0].last_act if last else tapes[0].act
         gates = [None if (last and gate_act == _C.ACT_NONE) else t.outs[k] for t in tapes]
-        if grads_list is not None:
-            inps = [t.x if k == 0 else t.outs[k - 1] for t in tapes]
+        if with_w:
+            inps = [(tapes[g].x if k == 0 else tapes[g].outs[k - 1]) for g in with_w]
+            args = ([ds[g] for g in with_w], [gates[g] for g in with_w], gate_act, inps,
+                    [grads_list[g][k][0] for g in with_w], [grads_list[g][k][1] for g in with_w])
             if plan is not None:
-                _C.linear_bwd_weight_partials_group(ds, gates, gate_act, inps, [g[k][0] for g in grads_list],
-                                                    [g[k][1] for g in grads_list], plan)
+                _C.linear_bwd_weight_partials_group(*args, plan)
             else:
-                _C.linear_bwd_weight_group(ds, gates, gate_act, inps, [g[k][0] for g in grads_list],
-                                           [g[k][1] for g in grads_list], workspace=workspace)
-        if k > 0 or need_input:
+                _C.linear_bwd_weight_group(*args, workspace=workspace)
+        if k > 0:
             ds = _C.linear_bwd_input_group(ds, gates, gate_act, [t.layers[k][0] for t in tapes])
+        elif any(want_in):
+            sel = [g for g in range(len(tapes)) if want_in[g]]
+            dx = _C.linear_bwd_input_group([ds[g] for g in sel], [gates[g] for g in sel], gate_act,
+                                           [tapes[g].layers[0][0] for g in sel])
+            ds = [None] * len(tapes)
+            for g, d in zip(sel, dx):
+                ds[g] = d
+    if isinstance(need_input, (list, tuple)):
+        return ds
     return ds if need_input else None
 
 
