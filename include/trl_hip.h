@@ -445,6 +445,14 @@ int trl_sac_samples_f32(const float* head, const float* head2, const float* eps1
                         const float* obs, const float* acts, const float* next_obs, float* new_a, float* logp,
                         float* next_a, float* next_logp, float* x_sa, float* x_next, float* x_new, int B, int D,
                         int A, int tanh_action, void* stream);
+/* the same with the two noise draws (distribution.py:67-70) made inside the launch: update u -- u = step_state[0], the
+ * device-resident count of optimiser steps taken (trl_adam_t.step_state), so the launch can be graph-replayed -- uses
+ * trl_philox_normal_f32's (B, A) draws for (seed, 2u + 1) and (seed, 2u + 2); eps1_out receives the first one (the
+ * sampler's backward pass reads it) */
+int trl_sac_samples_philox_f32(const float* head, const float* head2, const double* step_state, int64_t seed,
+                               float* eps1_out, const float* obs, const float* acts, const float* next_obs,
+                               float* new_a, float* logp, float* next_a, float* next_logp, float* x_sa, float* x_next,
+                               float* x_new, int B, int D, int A, int tanh_action, void* stream);
 /* alpha loss + Adam step on log_alpha + alpha = exp(log_alpha) (twin_sac_q.py:111-120).
  * state (4): log_alpha, exp_avg, exp_avg_sq, step; out (2): alpha, alpha_loss */
 int trl_sac_alpha_step_f32(const float* logp, int B, float target_entropy, float lr, float beta1,

@@ -47,6 +47,18 @@ def test_sac_epoch_of_deferred_updates_equals_update_by_update():
     assert len({i["Training/qf1_loss"] for i in ib}) == 10               # every slot carries its own update
 
 
+def test_sac_noise_drawn_inside_the_sampling_launch_equals_the_separate_noise_launches(monkeypatch):
+    """trl_sac_samples_philox_f32 makes update u's two draws from the device-resident update count (2u + 1, 2u + 2): the
+    values trl_philox_normal_f32 was launched for before -- parameters, targets, alpha and every logged number agree."""
+    monkeypatch.setenv("TRL_SAC_NOISE_LAUNCHES", "1")
+    ia, fa, ta, la = _sac_run(True)
+    monkeypatch.setenv("TRL_SAC_NOISE_LAUNCHES", "0")
+    ib, fb, tb, lb = _sac_run(True)
+    assert torch.equal(fa, fb) and torch.equal(ta, tb) and torch.equal(la, lb)
+    for x, y in zip(ia, ib):
+        assert x == y
+
+
 @pytest.mark.parametrize("Q", [1, 8])
 def test_dqn_epoch_of_deferred_updates_equals_update_by_update(Q):
     from test_fullsize_offpolicy_gpu import build_cfg5

@@ -163,6 +163,7 @@ SIGNATURES = {
     "trl_tanh_gauss_rsample_bwd_cols_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_void_p] + [C.c_float] * 3 +
                                             [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int] * 4 + [C.c_void_p]),
+    "trl_sac_samples_philox_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
     "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
     "trl_synth_collect_step_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 6 +
                                    [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 6 + [C.c_void_p]),
@@ -743,15 +744,26 @@ def rsample_bwd_cols(head, eps, act, dx1, dx2, off, d_logp_ptr, d_logp_mul, w_st
     return d_head
 
 
-def sac_samples(head, head2, eps1, eps2, obs, acts, next_obs, tanh_action=True):
-    """(new_a, logp, next_a, next_logp, x_sa, x_next, x_new) of one SAC update in one launch."""
+def sac_samples(head, head2, eps1, eps2, obs, acts, next_obs, tanh_action=True, philox=None):
+    """(new_a, logp, next_a, next_logp, x_sa, x_next, x_new) of one SAC update in one launch.  philox = (step_state,
+    seed): the two noise draws are made inside the launch from the device-resident update count; eps1 then RECEIVES the
+    first draw (eps2 is not touched)."""
     B, A, D = int(eps1.shape[0]), int(eps1.shape[1]), int(obs.shape[1])
     f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=head.device)
     new_a, logp, next_a, next_logp = f(B, A), f(B), f(B, A), f(B)
     x_sa, x_next, x_new = f(B, D + A), f(B, D + A), f(B, D + A)
+    outs = [dev_ptr(t, name="out") for t in (new_a, logp, next_a, next_logp, x_sa, x_next, x_new)]
+    if philox is not None:
+        state, seed = philox
+        check(lib().trl_sac_samples_philox_f32(dev_ptr(head, name="head"), dev_ptr(head2, name="head2"),
+                                               dev_ptr(state, torch.float64, "step_state"), int(seed),
+                                               dev_ptr(eps1, name="eps1"), dev_ptr(obs, name="obs"),
+                                               dev_ptr(acts, name="acts"), dev_ptr(next_obs, name="next_obs"), *outs,
+                                               B, D, A, int(bool(tanh_action)), stream_ptr(head.device)),
+              "trl_sac_samples_philox_f32")
+        return new_a, logp, next_a, next_logp, x_sa, x_next, x_new
     ins = [dev_ptr(t, name=n) for t, n in ((head, "head"), (head2, "head2"), (eps1, "eps1"), (eps2, "eps2"), (obs, "obs"),
                                            (acts, "acts"), (next_obs, "next_obs"))]
-    outs = [dev_ptr(t, name="out") for t in (new_a, logp, next_a, next_logp, x_sa, x_next, x_new)]
     check(lib().trl_sac_samples_f32(*ins, *outs, B, D, A, int(bool(tanh_action)), stream_ptr(head.device)),
           "trl_sac_samples_f32")
     return new_a, logp, next_a, next_logp, x_sa, x_next, x_new

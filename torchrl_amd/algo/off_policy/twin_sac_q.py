@@ -182,8 +182,10 @@ class _FusedSAC:
         (head, head2), (tape_pf, _) = ops.mlp_forward_group([pf_l, pf_l], [obs, nobs], self.act)
         # both samples (distribution.py:67-70 order) and the three critic inputs [obs | acts], [next_obs | next_a],
         # [obs | new_a]: one launch
-        new_a, logp, next_a, next_logp, x_sa, x_next, x_new = _C.sac_samples(head, head2, eps1, eps2, obs, acts, nobs,
-                                                                             tanh_action)
+        # (device noise on one rank: the two draws are made inside that launch from the device-resident update count)
+        new_a, logp, next_a, next_logp, x_sa, x_next, x_new = _C.sac_samples(
+            head, head2, eps1, eps2, obs, acts, nobs, tanh_action,
+            philox=(self.step_state, self.noise_seed) if self._inline_noise() else None)
         # ---- temperature ----
         if algo.automatic_entropy_tuning:                                # mean over the GLOBAL batch (all ranks' samples)
             _C.sac_alpha_step(dist.all_gather_cat(logp), algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
@@ -231,6 +233,12 @@ class _FusedSAC:
                           (logp_g, self.mom[1], 1, 0, 1, -inf, inf),
                           (head_g, self.mom[2], 2 * A, 0, A, -inf, inf)])
 
+    def _inline_noise(self):
+        """Device Philox noise on a single rank whose every update so far drew its noise on the device: draw u's counters
+        (2u + 1, 2u + 2) follow from the optimiser step count, so the sampling launch makes them itself."""
+        return (self.algo.noise_mode == "device" and dist.world_size() == 1 and self.noise_ctr == 2 * self.step_count
+                and os.environ.get("TRL_SAC_NOISE_LAUNCHES") != "1")
+
     def _lrs(self):
         algo = self.algo
         return tuple(float(o.param_groups[0]['lr']) for o in (algo.pf_optimizer, algo.qf1_optimizer, algo.qf2_optimizer))
@@ -240,7 +248,7 @@ class _FusedSAC:
         afterwards: ~90 dependent launches per update otherwise pay the eager launch latency each
         (TRL_NO_GRAPH=1 keeps everything eager)."""
         key = (int(st["obs"].shape[0]), soft, self._lrs(), self.algo.grad_clip, self.algo.tau, self.algo.discount,
-               bool(self.algo.automatic_entropy_tuning))
+               bool(self.algo.automatic_entropy_tuning), self._inline_noise())
         if os.environ.get("TRL_NO_GRAPH") == "1" or dist.collectives_active() or \
                 (key not in self._graphs and len(self._graphs) >= 8):     # collectives between ranks: eager launches
             self._sequence(st, soft)                                     # (a learning-rate schedule would mint a key per value)
@@ -271,7 +279,10 @@ class _FusedSAC:
             st[k].copy_(src.to(dtype=torch.float32).reshape(st[k].shape), non_blocking=True)
         n_env = int(algo.replay_buffer.env_nums) if getattr(algo, "replay_buffer", None) is not None else B
         rows = B // n_env if B % n_env == 0 else 1                       # batch = sampled time rows x this rank's envs
+        inline = self._inline_noise()
         for k in ("eps1", "eps2"):                                       # distribution.py:67-70: two draws, in this order
+            if inline:
+                continue
             if algo.noise_mode == "host":
                 make = lambda m, f: torch.randn(m, f)                    # the CPU generator (reference stream)
             else:
@@ -282,6 +293,8 @@ class _FusedSAC:
                 make = lambda m, f: _C.philox_normal(torch.empty(m, f, device=dev), self.noise_seed, self.noise_ctr)
             st[k].copy_(dist.shard_rows_of_global(make, rows, B // rows, A, dev), non_blocking=True)
         self._run(st, bool(algo.use_soft_update))
+        if inline:
+            self.noise_ctr += 2                                          # the two draws the sampling launch made
         self.step_count += 1
         if not algo.use_soft_update and algo.training_update_num % algo.target_hard_update_period == 0:
             _C.polyak(self.tflat, self.flat[self.sizes[0]:], 1.0)

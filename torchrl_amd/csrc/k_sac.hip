@@ -94,6 +94,23 @@ extern "C" int trl_tanh_gauss_rsample_fwd_f32(const float* head, const float* ep
   return TRL_OK;
 }
 
+// row `row` (A values) of the (rows, A) standard-normal draw trl_philox_normal_f32 makes for (seed, ctr): element e is
+// normal (e & 3) of Philox block e / 4
+__device__ __forceinline__ void philox_noise_row(int64_t seed, int64_t ctr, int64_t row, int A, float* out) {
+  const int64_t e0 = row * A;
+  int64_t blk = -1;
+  float z[4];
+  for (int k = 0; k < A; ++k) {
+    const int64_t e = e0 + k;
+    if ((e >> 2) != blk) {
+      blk = e >> 2;
+      philox_normals4((uint32_t)(ctr & 0xFFFFFFFFll), (uint32_t)((ctr >> 32) & 0xFFFFFFFFll), (uint32_t)blk, TRL_TAG_NOISE,
+                      seed, z);
+    }
+    out[k] = z[e & 3];
+  }
+}
+
 // Both policy samples of one SAC update and the three critic inputs in one launch (twin_sac_q.py:93-106, :125-131,
 // :146-151): new_a / logp from head(obs) with eps1, next_a / next_logp from head(next_obs) with eps2, and
 // x_sa = [obs | acts], x_next = [next_obs | next_a], x_new = [obs | new_a].  One thread per batch row -- the whole
@@ -105,13 +122,26 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_samples_kernel(const float* _
                                                                   float* __restrict__ logp, float* __restrict__ next_a,
                                                                   float* __restrict__ next_logp, float* __restrict__ x_sa,
                                                                   float* __restrict__ x_next, float* __restrict__ x_new,
-                                                                  int B, int D, int A, int tanh_action) {
+                                                                  int B, int D, int A, int tanh_action,
+                                                                  const double* __restrict__ step_state, int64_t seed,
+                                                                  float* __restrict__ eps1_out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float* na = new_a + (size_t)b * A;
   float* xa = next_a + (size_t)b * A;
-  logp[b] = rsample_row(head + (size_t)b * 2 * A, eps1 + (size_t)b * A, na, A, tanh_action);
-  next_logp[b] = rsample_row(head2 + (size_t)b * 2 * A, eps2 + (size_t)b * A, xa, A, tanh_action);
+  float e1[8], e2[8];
+  if (step_state) {
+    // the two draws of update u (u = optimiser steps taken so far, device-resident: the launch is graph-replayed) are
+    // trl_philox_normal_f32(seed, 2 u + 1) and (seed, 2 u + 2) -- what the engine launched separately before
+    const int64_t u = (int64_t)step_state[0];
+    philox_noise_row(seed, 2 * u + 1, b, A, e1);
+    philox_noise_row(seed, 2 * u + 2, b, A, e2);
+    for (int k = 0; k < A; ++k) eps1_out[(size_t)b * A + k] = e1[k];        // the sampler's backward pass reads it
+  } else {
+    for (int k = 0; k < A; ++k) { e1[k] = eps1[(size_t)b * A + k]; e2[k] = eps2[(size_t)b * A + k]; }
+  }
+  logp[b] = rsample_row(head + (size_t)b * 2 * A, e1, na, A, tanh_action);
+  next_logp[b] = rsample_row(head2 + (size_t)b * 2 * A, e2, xa, A, tanh_action);
   const int F = D + A;
   for (int k = 0; k < D; ++k) {
     const float o = obs[(size_t)b * D + k];
@@ -124,18 +154,36 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_samples_kernel(const float* _
     x_next[(size_t)b * F + D + k] = xa[k];
   }
 }
+static int sac_samples_impl(const float* head, const float* head2, const float* eps1, const float* eps2,
+                            const float* obs, const float* acts, const float* next_obs, float* new_a, float* logp,
+                            float* next_a, float* next_logp, float* x_sa, float* x_next, float* x_new, int B, int D,
+                            int A, int tanh_action, const double* step_state, int64_t seed, float* eps1_out, void* stream) {
+  TRL_REQUIRE(B >= 0 && A > 0 && A <= 8 && D > 0, "bad sizes (A <= 8)");
+  if (B == 0) return TRL_OK;
+  TRL_REQUIRE(head && head2 && obs && acts && next_obs && ((eps1 && eps2) || (step_state && eps1_out)), "null input");
+  TRL_REQUIRE(new_a && logp && next_a && next_logp && x_sa && x_next && x_new, "null output");
+  hipLaunchKernelGGL(sac_samples_kernel, dim3(trl_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, head, head2, eps1,
+                     eps2, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next, x_new, B, D, A, tanh_action,
+                     step_state, seed, eps1_out);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
 extern "C" int trl_sac_samples_f32(const float* head, const float* head2, const float* eps1, const float* eps2,
                                    const float* obs, const float* acts, const float* next_obs, float* new_a, float* logp,
                                    float* next_a, float* next_logp, float* x_sa, float* x_next, float* x_new, int B, int D,
                                    int A, int tanh_action, void* stream) {
-  TRL_REQUIRE(B >= 0 && A > 0 && D > 0, "bad sizes");
-  if (B == 0) return TRL_OK;
-  TRL_REQUIRE(head && head2 && eps1 && eps2 && obs && acts && next_obs, "null input");
-  TRL_REQUIRE(new_a && logp && next_a && next_logp && x_sa && x_next && x_new, "null output");
-  hipLaunchKernelGGL(sac_samples_kernel, dim3(trl_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, head, head2, eps1,
-                     eps2, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next, x_new, B, D, A, tanh_action);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
+  return sac_samples_impl(head, head2, eps1, eps2, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next, x_new,
+                          B, D, A, tanh_action, nullptr, 0, nullptr, stream);
+}
+// the same with the two noise draws made in place: update u (u = step_state[0], the device-resident count of optimiser
+// steps taken) uses trl_philox_normal_f32's draws for (seed, 2 u + 1) and (seed, 2 u + 2); eps1_out (B, A) receives the
+// first one for the sampler's backward pass
+extern "C" int trl_sac_samples_philox_f32(const float* head, const float* head2, const double* step_state, int64_t seed,
+                                          float* eps1_out, const float* obs, const float* acts, const float* next_obs,
+                                          float* new_a, float* logp, float* next_a, float* next_logp, float* x_sa,
+                                          float* x_next, float* x_new, int B, int D, int A, int tanh_action, void* stream) {
+  return sac_samples_impl(head, head2, nullptr, nullptr, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next,
+                          x_new, B, D, A, tanh_action, step_state, seed, eps1_out, stream);
 }
 
 // backward of the above + the std / mean regularisers of twin_sac_q.py:157-160:
@@ -556,18 +604,7 @@ __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(Collect
     if (c.eps) {
       for (int k = 0; k < A; ++k) ez[k] = c.eps[(size_t)n * A + k];
     } else {                                       // element e of the draw = normal (e & 3) of Philox block e / 4
-      const int64_t e0 = (int64_t)(c.noise_row0 + n) * A;
-      int64_t blk = -1;
-      float z[4];
-      for (int k = 0; k < A; ++k) {
-        const int64_t e = e0 + k;
-        if ((e >> 2) != blk) {
-          blk = e >> 2;
-          philox_normals4((uint32_t)(c.noise_ctr & 0xFFFFFFFFll), (uint32_t)((c.noise_ctr >> 32) & 0xFFFFFFFFll),
-                          (uint32_t)blk, TRL_TAG_NOISE, c.noise_seed, z);
-        }
-        ez[k] = z[e & 3];
-      }
+      philox_noise_row(c.noise_seed, c.noise_ctr, (int64_t)c.noise_row0 + n, A, ez);
     }
     rsample_row(c.head + (size_t)n * 2 * A, ez, a, A, c.tanh_action);
     if (c.obs_row) for (int k = 0; k < D; ++k) c.obs_row[(size_t)n * D + k] = o[k];
