@@ -548,7 +548,9 @@ static int launch_gemm(const GemmDev& g, int splits, hipStream_t s) {
 static int bw_split_len(int M, int K, int N) {
   const int wm = tile_wm(N, K);                    // the weight-gradient GEMM is (N x K) with reduction M
   const int tiles = trl_ceil_div(N, 32 * wm) * trl_ceil_div(K, 32 * (4 / wm));
-  const int want = std::max(1, 1024 / tiles);
+  // (>= 320 tiles already fill the chip: no split, and then no partials and no fold either -- the 512 x 3136 layer of the
+  // conv nets wrote and folded 2 x 6.4 MB for nothing)
+  const int want = tiles >= 320 ? 1 : std::max(1, 1024 / tiles);
   const int len = trl_ceil_div(trl_ceil_div(M, want), KC) * KC;
   return std::max(256, len);
 }
@@ -694,6 +696,7 @@ static int bwd_weight_impl(int G, const float* const* dy, const float* const* y_
   if (cv) g.cv = *cv;
   const bool gated = y_gate && y_gate[0];
   const bool want_db = db && db[0];
+  const bool direct = splits == 1 && CONV == 0 && fold;            // (the conv fold also un-permutes the columns)
   FoldDev f{};
   f.n = N * K; f.n2 = want_db ? N : 0; f.splits = splits;
   f.perm_c = CONV == 4 ? cv->C : 0; f.perm_khw = CONV == 4 ? cv->kh * cv->kw : 0;
@@ -703,12 +706,13 @@ static int bwd_weight_impl(int G, const float* const* dy, const float* const* y_
     TRL_REQUIRE(!want_db || db[i], "either every problem of a group wants db or none");
     float* part = workspace + i * per;
     float* cpart = want_db ? part + (size_t)splits * N * K : nullptr;
+    if (direct) { part = dw[i]; cpart = want_db ? db[i] : nullptr; }   // one slice: the GEMM writes dW / db themselves
     g.grp[i] = GemmGroup{dy[i], CONV != 0 ? nullptr : x[i], part, nullptr, gated ? y_gate[i] : nullptr, cpart};
     f.grp[i] = FoldGroup{part, dw[i], cpart, want_db ? db[i] : nullptr};
   }
   g.A = g.grp[0].A; g.B = g.grp[0].B; g.C = g.grp[0].C; g.a_gate = g.grp[0].a_gate; g.colsum = g.grp[0].colsum;
   int rc = launch_gemm<true, false, CONV>(g, splits, s);
-  if (rc || !fold) return rc;
+  if (rc || !fold || direct) return rc;
   return launch_fold(f, G, s);
 }
 extern "C" int trl_linear_bwd_weight_f32(const float* dy, const float* y_gate, int gate_act, const float* x, float* dw,
