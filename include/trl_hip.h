@@ -418,6 +418,16 @@ int trl_linear_bwd_weight_partials_multi_f32(int G, const float* const* dy, cons
                                              const float* const* x, const int* K, const int* N, int want_db,
                                              float* const* workspace, int M, void* stream);
 
+/* Forward of G MLPs D -> 256 -> 256 -> O (D <= 32, O <= 16: the policy / Q networks of SAC, DDPG, TD3;
+ * networks/base.py:30-44, nets.py:34-68) in ONE launch: hidden activations stay in LDS, W2 is walked in double-buffered
+ * k panels.  h1[k] / h2[k] (M, 256) receive the hidden activations of the networks whose backward pass needs them (the
+ * array or single entries may be NULL); act after both hidden layers, last_act after the head. */
+int trl_mlp3_forward_ok(int D, int H1, int H2, int O);
+int trl_mlp3_forward_group_f32(int G, const float* const* x, const float* const* w1, const float* const* b1,
+                               const float* const* w2, const float* const* b2, const float* const* w3,
+                               const float* const* b3, float* const* h1, float* const* h2, float* const* y, int M,
+                               int D, int O, int act, int last_act, void* stream);
+
 /* --- K12 / K13: twin-Q SAC update pieces (torchrl/algo/off_policy/twin_sac_q.py:84-220) ---- */
 /* torch.cat([obs, act], -1) of QNet.forward (torchrl/networks/nets.py:61-68) */
 int trl_concat2_f32(const float* a, const float* b, float* out, int rows, int fa, int fb, void* stream);

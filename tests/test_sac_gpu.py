@@ -123,6 +123,54 @@ def test_weight_gradients_of_layers_of_different_widths_in_one_launch():
         assert (gb - wb).abs().max().item() < 2e-5 * max(1.0, wb.abs().max().item()), (K, N)
 
 
+@pytest.mark.parametrize("M,D,O,act,last", [(4096, 23, 1, "relu", "none"), (4096, 17, 12, "relu", "none"),
+                                            (1000, 17, 6, "tanh", "tanh"), (33, 32, 16, "relu", "none"), (1, 3, 1, "tanh", "none")])
+def test_fused_three_layer_forward_equals_the_per_layer_launches(M, D, O, act, last, monkeypatch):
+    """trl_mlp3_forward_group_f32 (D -> 256 -> 256 -> O, hidden activations on chip, several networks per launch, hidden
+    tapes only where asked for) against three dense-layer launches: hidden activations bit for bit (same k order), the
+    head within round-off (its reduction is split over four waves); networks at unaligned offsets of a flat block."""
+    from torchrl_amd import _C, ops
+    code = {"relu": _C.ACT_RELU, "tanh": _C.ACT_TANH, "none": _C.ACT_NONE}
+    gen = torch.Generator().manual_seed(M + D + O)
+    G = 3
+    sizes = [256 * D, 256, 256 * 256, 256, O * 256, O]
+    flat = torch.randn(G * sum(sizes) + 7, generator=gen).to(DEV) * 0.1
+    layers_list, off = [], 1                                                # odd offset: the second network's W2 is unaligned
+    for g in range(G):
+        ps = []
+        for n in sizes:
+            ps.append(flat[off:off + n]); off += n
+        layers_list.append([(ps[0].view(256, D), ps[1]), (ps[2].view(256, 256), ps[3]), (ps[4].view(O, 256), ps[5])])
+        off += 1
+    xs = [torch.randn(M, D, generator=gen).to(DEV) for _ in range(G)]
+    assert _C.mlp3_forward_ok(D, 256, 256, O)
+    keep = [True, False, True]
+    outs, tapes = ops.mlp_forward_group(layers_list, xs, code[act], last_act=code[last], keep=keep)
+    monkeypatch.setenv("TRL_MLP3_PER_LAYER", "1")
+    want, wtapes = ops.mlp_forward_group(layers_list, xs, code[act], last_act=code[last])
+    for g in range(G):
+        if keep[g]:
+            assert torch.equal(tapes[g].outs[0], wtapes[g].outs[0]) and torch.equal(tapes[g].outs[1], wtapes[g].outs[1])
+        else:
+            assert tapes[g].outs[0] is None and tapes[g].outs[1] is None
+        err = (outs[g] - want[g]).abs().max().item()
+        assert err < 2e-6 * max(1.0, want[g].abs().max().item()), (g, err)
+    # the backward pass runs on a fused tape as on a per-layer one
+    monkeypatch.setenv("TRL_MLP3_PER_LAYER", "0")
+    d = torch.randn(M, O, generator=gen).to(DEV)
+    mk = lambda: [(torch.zeros(256, D, device=DEV), torch.zeros(256, device=DEV)),
+                  (torch.zeros(256, 256, device=DEV), torch.zeros(256, device=DEV)),
+                  (torch.zeros(O, 256, device=DEV), torch.zeros(O, device=DEV))]
+    ga, gb = mk(), mk()
+    if last == "none":
+        dxa = ops.mlp_backward(tapes[0], d, grads=ga, need_input=True)
+        dxb = ops.mlp_backward(wtapes[0], d, grads=gb, need_input=True)
+        assert torch.equal(dxa, dxb)
+        for (wa, ba), (wb, bb) in zip(ga, gb):
+            assert torch.equal(wa, wb) and torch.equal(ba, bb)
+    assert not _C.mlp3_forward_ok(40, 256, 256, 1) and not _C.mlp3_forward_ok(17, 64, 64, 6) and not _C.mlp3_forward_ok(17, 256, 256, 20)
+
+
 def test_rsample_fwd_bwd_vs_autograd():
     from torchrl_amd import _C
     B, A = 300, 6

@@ -215,6 +215,8 @@ SIGNATURES = {
                                        + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_bwd_weight_group_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
                                         + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_mlp3_forward_ok": (C.c_int, [C.c_int] * 4),
+    "trl_mlp3_forward_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_void_p]),
     "trl_linear_fwd_splitk_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "trl_conv_fwd_nhwc_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
     "trl_linear_fwd_splitk_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
@@ -565,6 +567,31 @@ def linear_fwd_group(xs, ws, biases, act):
     check(lib().trl_linear_fwd_group_f32(G, _ptrs(xs, "x"), _ptrs(ws, "w"), _ptrs(biases, "bias", True), _ptrs(ys, "y"),
                                          M, K, N, act, stream_ptr(xs[0].device)), "trl_linear_fwd_group_f32")
     return ys
+
+
+def mlp3_forward_ok(D, H1, H2, O):
+    return bool(lib().trl_mlp3_forward_ok(int(D), int(H1), int(H2), int(O)))
+
+
+def mlp3_forward_group(layers_list, xs, act, last_act, keep):
+    """G networks D -> 256 -> 256 -> O on G inputs in one launch; keep[g]: write h1 / h2 of network g (its backward pass
+    needs them).  Returns [(h1 or None, h2 or None, y)]."""
+    G = len(xs)
+    M, D = int(xs[0].shape[0]), int(xs[0].shape[1])
+    O = int(layers_list[0][2][0].shape[0])
+    dev = xs[0].device
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    h1s = [f(M, 256) if keep[g] else None for g in range(G)]
+    h2s = [f(M, 256) if keep[g] else None for g in range(G)]
+    ys = [f(M, O) for _ in range(G)]
+    col = lambda k, j: _ptrs([ls[k][j] for ls in layers_list], "param", True)
+
+    def opt_ptrs(ts):                                                   # per-entry NULLs allowed
+        return (C.c_void_p * G)(*[dev_ptr(t, name="h", allow_none=True) for t in ts])
+    check(lib().trl_mlp3_forward_group_f32(G, _ptrs(xs, "x"), col(0, 0), col(0, 1), col(1, 0), col(1, 1), col(2, 0), col(2, 1),
+                                           opt_ptrs(h1s), opt_ptrs(h2s), _ptrs(ys, "y"), M, D, O, act, last_act,
+                                           stream_ptr(dev)), "trl_mlp3_forward_group_f32")
+    return list(zip(h1s, h2s, ys))
 
 
 def linear_bwd_input_group(dys, y_gates, gate_act, ws):

@@ -179,7 +179,7 @@ class _FusedSAC:
         pf_l, q1_l, q2_l = self.layers
         tanh_action = bool(algo.pf.tanh_action)
         # ---- policy on obs and next_obs (one grouped launch per layer), both samples ----
-        (head, head2), (tape_pf, _) = ops.mlp_forward_group([pf_l, pf_l], [obs, nobs], self.act)
+        (head, head2), (tape_pf, _) = ops.mlp_forward_group([pf_l, pf_l], [obs, nobs], self.act, keep=[True, False])
         # both samples (distribution.py:67-70 order) and the three critic inputs [obs | acts], [next_obs | next_a],
         # [obs | new_a]: one launch
         # (device noise on one rank: the two draws are made inside that launch from the device-resident update count)
@@ -191,7 +191,8 @@ class _FusedSAC:
             _C.sac_alpha_step(dist.all_gather_cat(logp), algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
         # ---- all six critic passes as one group: Q1/Q2(s, a), target Q1/Q2(s', a'), Q1/Q2(s, new a) ----
         (q1p, q2p, tq1, tq2, q1n, q2n), (tape_q1, tape_q2, _, _, tape_q1n, tape_q2n) = ops.mlp_forward_group(
-            [q1_l, q2_l, self.tlayers[0], self.tlayers[1], q1_l, q2_l], [x_sa, x_sa, x_next, x_next, x_new, x_new], self.act)
+            [q1_l, q2_l, self.tlayers[0], self.tlayers[1], q1_l, q2_l], [x_sa, x_sa, x_next, x_next, x_new, x_new], self.act,
+            keep=[True, True, False, False, True, True])                 # the target passes leave no tape
         alpha = self.alpha_out[0:1]                                      # re-read AFTER the alpha step, as the reference does
         dq1, dq2, dq1n, dq2n = _C.sac_losses(q1p, q2p, tq1, tq2, next_logp, rew, term, q1n, q2n, logp, alpha,
                                              algo.discount, self.sums)

@@ -71,10 +71,27 @@ def mlp_backward(tape, d_out, grads=None, need_input=False, workspace=None, plan
     return d if need_input else None
 
 
-def mlp_forward_group(layers_list, xs, act, last_act=None):
+def mlp_forward_group(layers_list, xs, act, last_act=None, keep=None):
     """G same-shaped MLPs (or one MLP listed several times) on G inputs, one launch per layer instead of G:
-    returns ([out_g], [tape_g]); every tape works with `mlp_backward` / `mlp_backward_group`."""
+    returns ([out_g], [tape_g]); every tape works with `mlp_backward` / `mlp_backward_group`.
+    keep[g] = False: network g's hidden activations are not needed (no backward pass, e.g. target networks); networks
+    of the shape D -> 256 -> 256 -> O then run through ONE fused launch that leaves their hidden layers on chip."""
     G = len(layers_list)
+    code_last = _C.ACT_NONE if last_act is None else last_act
+    ls0 = layers_list[0]
+    if len(ls0) == 3 and os.environ.get("TRL_MLP3_PER_LAYER") != "1" and \
+            _C.mlp3_forward_ok(ls0[0][0].shape[1], ls0[0][0].shape[0], ls0[1][0].shape[0], ls0[2][0].shape[0]) and \
+            all(b is not None for ls in layers_list for _, b in ls[:2]):
+        keep = [True] * G if keep is None else list(keep)
+        res = _C.mlp3_forward_group(layers_list, xs, act, code_last, keep)
+        tapes, outs = [], []
+        for g, (h1, h2, y) in enumerate(res):
+            t = Tape()
+            t.x, t.layers, t.act, t.last_act = xs[g], layers_list[g], act, code_last
+            t.outs = [h1, h2, y]
+            tapes.append(t)
+            outs.append(y)
+        return outs, tapes
     tapes = []
     for g in range(G):
         t = Tape()
