@@ -3,16 +3,20 @@
 // The 256-wide policy / Q networks of SAC, DDPG and TD3 (torchrl/networks/base.py:30-44, nets.py:34-68: two hidden
 // nn.Linear + activation, a linear head) ran as three launches of the dense-layer GEMM per pass.  Their hidden
 // activations are small enough to stay on chip: a workgroup owns 32 batch rows, keeps the 32 x 256 activation tile of
-// the current layer in LDS, and walks W2 in 16-wide k panels (double buffered: the next panel's global loads fly under
-// the current panel's MFMAs, one barrier per panel).  Wave w owns hidden columns [64 w, 64 w + 64): two 32 x 32
-// accumulators, so one A read and two B reads from LDS feed eight v_mfma_f32_32x32x2_f32.  The head (O <= 16 columns)
-// splits its reduction over the four waves and folds the four partial tiles in wave order.
+// the current layer in LDS, and walks W2 in 16-wide k panels through a double-buffered LDS stage, one barrier per panel.
+// A panel is only ~0.5 us of MFMAs per SIMD, far less than an L2 round trip under load, so panels are requested 4 - 5
+// ahead into registers (first version, one panel ahead: slower than the three separate launches).  8 waves per workgroup
+// (wave w owns hidden columns [32 w, 32 w + 32), 128 registers: two workgroups = 4 waves per SIMD) beat 4 waves with two
+// accumulators each (measured 19.9 / 48.5 us against 24.8 / 57.2 us for the 2- and 6-network launches of a SAC update;
+// the per-layer GEMM launches took 33.7 / 73.9 us).  The head (O <= 16 columns) splits its reduction over the waves and
+// folds the partial tiles in wave order.
 // h1 / h2 are written to global memory only for the networks whose backward pass needs them (tape): the target networks
 // and the next-state policy pass leave nothing behind but their outputs.
 // k order and per-element operation order of layers 1 and 2 are those of gemm_f32_kernel (k = 8 q + 4 hi + r ascending,
 // bias, activation): bit-identical hidden activations; the head sums four k-quarters, which is a different rounding
 // order than the GEMM's single chain.
 #include <algorithm>
+#include <cstdlib>
 #include "trl_common.h"
 #include "trl_mlp.h"
 
@@ -39,7 +43,12 @@ __device__ __forceinline__ float m3_act(int act, float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void mlp3_fwd_kernel(Mlp3Dev g) {
+// NW waves per workgroup; wave w owns hidden columns [CW w, CW w + CW), CW = 256 / NW = 32 CB
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void mlp3_fwd_kernel(Mlp3Dev g) {
+  constexpr int DIST = NW == 8 ? 4 : M3_DIST;       // panels requested ahead (8 waves hide more themselves)
+  constexpr int NT = 64 * NW, CB = M3_H / (32 * NW), CW = 32 * CB, PJ = M3_H * 4 / NT;   // PJ: 16-byte panel slots per thread
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Xs = lds;                                   // [M3_R][M3_LDX]
   float* Hs = Xs + M3_R * M3_LDX;                    // [M3_R][M3_LDH]: H1, later H2
@@ -49,49 +58,56 @@ __global__ __launch_bounds__(256) void mlp3_fwd_kernel(Mlp3Dev g) {
   const int row0 = blockIdx.x * M3_R, D = g.D, M = g.M;
 
   // the first W2 panels are requested before anything else: they travel while X / W1 are staged and layer 1 runs
-  const int prow = tid >> 2, ppiece = tid & 3;       // panel slot: rows prow + 64 j, floats 4 ppiece .. + 3
-  f32x4 pw[M3_DIST][4];                              // panels p .. p + DIST - 1 in flight (registers), loaded DIST panels ahead:
+  const int prow = tid >> 2, ppiece = tid & 3;       // panel slot: rows prow + (NT / 4) j, floats 4 ppiece .. + 3
+  f32x4 pw[DIST][PJ];                             // panels p .. p + DIST - 1 in flight (registers)
   const bool w2_vec = (reinterpret_cast<uintptr_t>(P.w2) & 15) == 0;   // (a network at an odd offset of a flat parameter
-  auto fetch_panel = [&](int p, f32x4 (&dst)[4]) {                      //  block: dword loads)
+  auto fetch_panel = [&](int p, f32x4 (&dst)[PJ]) {                     //  block: dword loads)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float* src = P.w2 + (size_t)(prow + 64 * j) * M3_H + M3_KP * p + 4 * ppiece;
+    for (int j = 0; j < PJ; ++j) {
+      const float* src = P.w2 + (size_t)(prow + (NT / 4) * j) * M3_H + M3_KP * p + 4 * ppiece;
       if (w2_vec) dst[j] = *reinterpret_cast<const f32x4*>(src);
       else        dst[j] = f32x4{src[0], src[1], src[2], src[3]};
     }
   };
-  auto stash_panel = [&](int buf, const f32x4 (&src)[4]) {
+  auto stash_panel = [&](int buf, const f32x4 (&src)[PJ]) {
     float* dst = Pan + buf * (M3_H * M3_LDP);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (prow + 64 * j) * M3_LDP + 4 * ppiece) = src[j];
+    for (int j = 0; j < PJ; ++j) *reinterpret_cast<f32x4*>(dst + (prow + (NT / 4) * j) * M3_LDP + 4 * ppiece) = src[j];
   };
-  // a panel is 16 MFMAs per wave (~0.5 us): one panel of look-ahead does not cover an L2 round trip under load, DIST do
+  // a panel is 16 MFMAs per SIMD (~0.5 us): one panel of look-ahead does not cover an L2 round trip under load, DIST do
 #pragma unroll
-  for (int d = 0; d < M3_DIST; ++d) fetch_panel(d, pw[d]);
-  // the head's weights (O x 256 <= 4096 floats): 16 per thread, requested now, parked in LDS after layer 2
-  float w3r[M3_OMAX];
+  for (int d = 0; d < DIST; ++d) fetch_panel(d, pw[d]);
+  // the head's weights (O x 256 <= 4096 floats), requested now, parked in LDS after layer 2
+  constexpr int W3R = M3_OMAX * M3_H / NT;
+  float w3r[W3R];
 #pragma unroll
-  for (int u = 0; u < M3_OMAX; ++u) w3r[u] = u < g.O ? P.w3[(size_t)u * M3_H + tid] : 0.0f;
+  for (int u = 0; u < W3R; ++u) {
+    const int e = tid + NT * u, o = e >> 8;
+    w3r[u] = o < g.O ? P.w3[e] : 0.0f;
+  }
   // ---- stage X (32 x D) and W1 (256 x D), zero padded to 32 columns ----
   {
-    const int k = tid & 31, rg = tid >> 5;           // 8 row groups
-    for (int r = rg; r < M3_R; r += 8)
+    const int k = tid & 31, rg = tid >> 5;           // NT / 32 row groups
+    for (int r = rg; r < M3_R; r += NT / 32)
       Xs[r * M3_LDX + k] = (k < D && row0 + r < M) ? P.x[(size_t)(row0 + r) * D + k] : 0.0f;
     float* W1s = Pan;
-    for (int r0 = rg; r0 < M3_H; r0 += 64) {         // 8 loads in flight per thread
-      float v[8];
+    constexpr int RG = NT / 32, U = M3_H / RG >= 8 ? 8 : M3_H / RG;
+    for (int r0 = rg; r0 < M3_H; r0 += RG * U) {      // U loads in flight per thread
+      float v[U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = k < D ? P.w1[(size_t)(r0 + 8 * u) * D + k] : 0.0f;
+      for (int u = 0; u < U; ++u) v[u] = k < D ? P.w1[(size_t)(r0 + RG * u) * D + k] : 0.0f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) W1s[(r0 + 8 * u) * M3_LDX + k] = v[u];
+      for (int u = 0; u < U; ++u) W1s[(r0 + RG * u) * M3_LDX + k] = v[u];
     }
   }
   __syncthreads();
 
-  f32x16 acc0, acc1;
+  f32x16 acc[CB];
   auto zero = [&]() {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
   };
   // ---- layer 1: K = D (padded to a multiple of 8) ----
   zero();
@@ -100,31 +116,34 @@ __global__ __launch_bounds__(256) void mlp3_fwd_kernel(Mlp3Dev g) {
     const int nq = (D + 7) >> 3;
     for (int q = 0; q < nq; ++q) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(Xs + i * M3_LDX + 8 * q + 4 * hi);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(W1s + (64 * wave + i) * M3_LDX + 8 * q + 4 * hi);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(W1s + (64 * wave + 32 + i) * M3_LDX + 8 * q + 4 * hi);
+      f32x4 b[CB];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { acc0 = mfma32(a[r], b0[r], acc0); acc1 = mfma32(a[r], b1[r], acc1); }
+      for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<const f32x4*>(W1s + (CW * wave + 32 * c + i) * M3_LDX + 8 * q + 4 * hi);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[c] = mfma32(a[r], b[c][r], acc[c]);
     }
   }
-  // bias + activation, lane (i, hi) owns hidden columns 64 wave + i and + 32 of rows rowmap(r, hi)
+  // bias + activation, lane (i, hi) owns hidden columns CW wave + 32 c + i of rows rowmap(r, hi)
   auto finish_hidden = [&](const float* bias, float* out_global) {
-    const int n0 = 64 * wave + i, n1 = n0 + 32;
-    const float bb0 = bias[n0], bb1 = bias[n1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float v0 = m3_act(g.act, acc0[r] + bb0), v1 = m3_act(g.act, acc1[r] + bb1);
-      Hs[row * M3_LDH + n0] = v0; Hs[row * M3_LDH + n1] = v1;
-      if (out_global && row0 + row < M) {
-        out_global[(size_t)(row0 + row) * M3_H + n0] = v0;
-        out_global[(size_t)(row0 + row) * M3_H + n1] = v1;
+    for (int c = 0; c < CB; ++c) {
+      const int n = CW * wave + 32 * c + i;
+      const float bb = bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float v = m3_act(g.act, acc[c][r] + bb);
+        Hs[row * M3_LDH + n] = v;
+        if (out_global && row0 + row < M) out_global[(size_t)(row0 + row) * M3_H + n] = v;
       }
     }
   };
   __syncthreads();                                   // W1s is dead
   finish_hidden(P.b1, P.h1);
   stash_panel(0, pw[0]);
-  if (M3_DIST < M3_H / M3_KP) fetch_panel(M3_DIST, pw[0]);
+  if (DIST < M3_H / M3_KP) fetch_panel(DIST, pw[0]);
   __syncthreads();
 
   // ---- layer 2: 16 panels of 16 k (fully unrolled: the register ring is indexed statically) ----
@@ -135,14 +154,17 @@ __global__ __launch_bounds__(256) void mlp3_fwd_kernel(Mlp3Dev g) {
 #pragma unroll
     for (int q = 0; q < M3_KP / 8; ++q) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(Hs + i * M3_LDH + M3_KP * p + 8 * q + 4 * hi);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + (64 * wave + i) * M3_LDP + 8 * q + 4 * hi);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + (64 * wave + 32 + i) * M3_LDP + 8 * q + 4 * hi);
+      f32x4 b[CB];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { acc0 = mfma32(a[r], b0[r], acc0); acc1 = mfma32(a[r], b1[r], acc1); }
+      for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<const f32x4*>(Ws + (CW * wave + 32 * c + i) * M3_LDP + 8 * q + 4 * hi);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[c] = mfma32(a[r], b[c][r], acc[c]);
     }
     if (p + 1 < M3_H / M3_KP) {
-      stash_panel((p + 1) & 1, pw[(p + 1) % M3_DIST]);             // loaded DIST panels ago
-      if (p + 1 + M3_DIST < M3_H / M3_KP) fetch_panel(p + 1 + M3_DIST, pw[(p + 1) % M3_DIST]);
+      stash_panel((p + 1) & 1, pw[(p + 1) % DIST]);             // loaded DIST panels ago
+      if (p + 1 + DIST < M3_H / M3_KP) fetch_panel(p + 1 + DIST, pw[(p + 1) % DIST]);
     }
     __syncthreads();
   }
@@ -150,30 +172,39 @@ __global__ __launch_bounds__(256) void mlp3_fwd_kernel(Mlp3Dev g) {
   // take the panel space
   finish_hidden(P.b2, P.h2);
   float* W3s = Pan;                                  // [16][M3_LDH], rows >= O zero
-  float* Red = Pan + M3_OMAX * M3_LDH;               // [4 waves][32 rows][16]
+  float* Red = Pan + M3_OMAX * M3_LDH;               // [NW waves][32 rows][16]
 #pragma unroll
-  for (int u = 0; u < M3_OMAX; ++u) W3s[u * M3_LDH + tid] = w3r[u];      // thread = k, register = output row
+  for (int u = 0; u < W3R; ++u) {
+    const int e = tid + NT * u;
+    W3s[(e >> 8) * M3_LDH + (e & 255)] = w3r[u];
+  }
   __syncthreads();
 
-  // ---- head: wave w reduces k in [64 w, 64 w + 64); output columns = lanes i < 16 ----
-  zero();
+  // ---- head: wave w reduces k in [KW w, KW w + KW), KW = 256 / NW; output columns = lanes i < 16 ----
+  constexpr int KW = M3_H / NW;
+  f32x16 hacc;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(Hs + i * M3_LDH + 64 * wave + 8 * q + 4 * hi);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(W3s + (i & 15) * M3_LDH + 64 * wave + 8 * q + 4 * hi);
+  for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc0 = mfma32(a[r], b[r], acc0);
+  for (int q = 0; q < KW / 8; ++q) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(Hs + i * M3_LDH + KW * wave + 8 * q + 4 * hi);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(W3s + (i & 15) * M3_LDH + KW * wave + 8 * q + 4 * hi);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hacc = mfma32(a[r], b[r], hacc);
   }
   if (i < M3_OMAX) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Red[(wave * M3_R + (r & 3) + 8 * (r >> 2) + 4 * hi) * M3_OMAX + i] = acc0[r];
+    for (int r = 0; r < 16; ++r) Red[(wave * M3_R + (r & 3) + 8 * (r >> 2) + 4 * hi) * M3_OMAX + i] = hacc[r];
   }
   __syncthreads();
-  for (int e = tid; e < M3_R * M3_OMAX; e += 256) {
+  for (int e = tid; e < M3_R * M3_OMAX; e += NT) {
     const int row = e >> 4, o = e & 15;
     if (o < g.O && row0 + row < M) {
-      float v = (Red[(0 * M3_R + row) * M3_OMAX + o] + Red[(1 * M3_R + row) * M3_OMAX + o]) +
-                (Red[(2 * M3_R + row) * M3_OMAX + o] + Red[(3 * M3_R + row) * M3_OMAX + o]);
+      float v = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; w += 4)                  // k-quarters (or -eighths) in wave order, four at a time
+        v += (Red[((w + 0) * M3_R + row) * M3_OMAX + o] + Red[((w + 1) * M3_R + row) * M3_OMAX + o]) +
+             (Red[((w + 2) * M3_R + row) * M3_OMAX + o] + Red[((w + 3) * M3_R + row) * M3_OMAX + o]);
       v += P.b3 ? P.b3[o] : 0.0f;
       P.y[(size_t)(row0 + row) * g.O + o] = m3_act(g.last_act, v);
     }
@@ -202,14 +233,17 @@ extern "C" int trl_mlp3_forward_group_f32(int G, const float* const* x, const fl
                       h2 ? h2[k] : nullptr, y[k]};
   }
   constexpr int lds = (M3_R * M3_LDX + M3_R * M3_LDH + M3_PAN) * (int)sizeof(float);
-  static_assert(M3_H * M3_LDX <= M3_PAN && M3_OMAX * M3_LDH + 4 * M3_R * M3_OMAX <= M3_PAN, "aliases fit the panel space");
+  static_assert(M3_H * M3_LDX <= M3_PAN && M3_OMAX * M3_LDH + 8 * M3_R * M3_OMAX <= M3_PAN, "aliases fit the panel space");
+  static const int nw = getenv("TRL_MLP3_WAVES") ? atoi(getenv("TRL_MLP3_WAVES")) : 8;     // A/B switch (4 or 8)
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp3_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)mlp3_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp3_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { trl_set_error("mlp3_forward: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(mlp3_fwd_kernel, dim3(trl_ceil_div(M, M3_R), G), dim3(256), lds, (hipStream_t)stream, g);
+  if (nw == 8) hipLaunchKernelGGL(mlp3_fwd_kernel<8>, dim3(trl_ceil_div(M, M3_R), G), dim3(512), lds, (hipStream_t)stream, g);
+  else         hipLaunchKernelGGL(mlp3_fwd_kernel<4>, dim3(trl_ceil_div(M, M3_R), G), dim3(256), lds, (hipStream_t)stream, g);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
