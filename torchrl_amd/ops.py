@@ -38,6 +38,10 @@ class Tape:
 def mlp_forward(layers, x, act, last_act=None):
     """layers: [(W, b), ...] (nn.Linear layout); returns (out, tape).  `last_act` (an ACT_* code) is applied to
     the head output inside the last layer's epilogue (deterministic policies: tanh(mlp(x)))."""
+    if len(layers) == 3 and os.environ.get("TRL_MLP3_PER_LAYER") != "1" and all(b is not None for _, b in layers[:2]) and \
+            _C.mlp3_forward_ok(layers[0][0].shape[1], layers[0][0].shape[0], layers[1][0].shape[0], layers[2][0].shape[0]):
+        outs, tapes = mlp_forward_group([layers], [x], act, last_act=last_act)      # one fused launch
+        return outs[0], tapes[0]
     t = Tape()
     t.x, t.layers, t.act, t.outs = x, layers, act, []
     t.last_act = _C.ACT_NONE if last_act is None else last_act
