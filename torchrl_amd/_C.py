@@ -636,8 +636,16 @@ class FoldPlan:
 
     def _run_gemms(self):
         probs, self.problems = self.problems, []
-        for lo in range(0, len(probs), 12):
-            chunk = probs[lo:lo + 12]
+        # Layers narrower than a 64 x 64 tile (first / last layers: 17, 23 inputs, 1, 12 outputs) go in their own launch:
+        # mixed with the 256 x 256 ones the common grid is mostly empty workgroups and the launch takes 62 us at SAC's
+        # shapes, the two separate ones 30 + 20 us (TRL_DW_ONE_LAUNCH=1: everything in one).
+        if os.environ.get("TRL_DW_ONE_LAUNCH") == "1":
+            groups = [probs]
+        else:
+            wide = [p for p in probs if p[5] >= 64 and p[6] >= 64]
+            groups = [g for g in (wide, [p for p in probs if not (p[5] >= 64 and p[6] >= 64)]) if g]
+        chunks = [g[lo:lo + 12] for g in groups for lo in range(0, len(g), 12)]
+        for chunk in chunks:
             g = len(chunk)
             act = {p[2] for p in chunk if p[1] is not None}
             if len(act) > 1:
