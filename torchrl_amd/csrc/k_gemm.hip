@@ -751,7 +751,7 @@ extern "C" int trl_linear_bwd_weight_partials_group_f32(int G, const float* cons
 static int multi_split_len(int M, int K, int N) {
   const int tiles = trl_ceil_div(N, 64) * trl_ceil_div(K, 64);
   const int want = std::max(1, 256 / tiles);
-  return std::max(256, trl_ceil_div(trl_ceil_div(M, want), KC) * KC);
+  return std::max(tiles <= 8 ? KC : 256, trl_ceil_div(trl_ceil_div(M, want), KC) * KC);   // (a handful of tiles: one panel per slice)
 }
 extern "C" int trl_linear_bwd_weight_multi_splits(int M, int K, int N) {
   return (M <= 0 || K <= 0 || N <= 0) ? 1 : trl_ceil_div(M, multi_split_len(M, K, N));
