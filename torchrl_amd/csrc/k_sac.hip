@@ -125,33 +125,39 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_samples_kernel(const float* _
                                                                   int B, int D, int A, int tanh_action,
                                                                   const double* __restrict__ step_state, int64_t seed,
                                                                   float* __restrict__ eps1_out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  // two threads per batch row: thread (b, 0) draws / samples from head(obs) and writes x_sa, x_new; thread (b, 1) does the
+  // next-state pair and x_next -- the Philox + Box-Muller chain per draw is what this kernel spends its time in
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;               // (whole waves take one side: no divergence)
+  const int b = ((t >> 7) << 6) | (t & 63), which = (t >> 6) & 1;
   if (b >= B) return;
-  float* na = new_a + (size_t)b * A;
-  float* xa = next_a + (size_t)b * A;
-  float e1[8], e2[8];
+  const int F = D + A;
+  float e[8];
   if (step_state) {
     // the two draws of update u (u = optimiser steps taken so far, device-resident: the launch is graph-replayed) are
     // trl_philox_normal_f32(seed, 2 u + 1) and (seed, 2 u + 2) -- what the engine launched separately before
     const int64_t u = (int64_t)step_state[0];
-    philox_noise_row(seed, 2 * u + 1, b, A, e1);
-    philox_noise_row(seed, 2 * u + 2, b, A, e2);
-    for (int k = 0; k < A; ++k) eps1_out[(size_t)b * A + k] = e1[k];        // the sampler's backward pass reads it
+    philox_noise_row(seed, 2 * u + 1 + which, b, A, e);
+    if (which == 0) for (int k = 0; k < A; ++k) eps1_out[(size_t)b * A + k] = e[k];   // the sampler's backward pass reads it
   } else {
-    for (int k = 0; k < A; ++k) { e1[k] = eps1[(size_t)b * A + k]; e2[k] = eps2[(size_t)b * A + k]; }
+    const float* src = which == 0 ? eps1 : eps2;
+    for (int k = 0; k < A; ++k) e[k] = src[(size_t)b * A + k];
   }
-  logp[b] = rsample_row(head + (size_t)b * 2 * A, e1, na, A, tanh_action);
-  next_logp[b] = rsample_row(head2 + (size_t)b * 2 * A, e2, xa, A, tanh_action);
-  const int F = D + A;
-  for (int k = 0; k < D; ++k) {
-    const float o = obs[(size_t)b * D + k];
-    x_sa[(size_t)b * F + k] = o; x_new[(size_t)b * F + k] = o;
-    x_next[(size_t)b * F + k] = nobs[(size_t)b * D + k];
-  }
-  for (int k = 0; k < A; ++k) {
-    x_sa[(size_t)b * F + D + k] = acts[(size_t)b * A + k];
-    x_new[(size_t)b * F + D + k] = na[k];
-    x_next[(size_t)b * F + D + k] = xa[k];
+  if (which == 0) {
+    float* na = new_a + (size_t)b * A;
+    logp[b] = rsample_row(head + (size_t)b * 2 * A, e, na, A, tanh_action);
+    for (int k = 0; k < D; ++k) {
+      const float o = obs[(size_t)b * D + k];
+      x_sa[(size_t)b * F + k] = o; x_new[(size_t)b * F + k] = o;
+    }
+    for (int k = 0; k < A; ++k) {
+      x_sa[(size_t)b * F + D + k] = acts[(size_t)b * A + k];
+      x_new[(size_t)b * F + D + k] = na[k];
+    }
+  } else {
+    float* xa = next_a + (size_t)b * A;
+    next_logp[b] = rsample_row(head2 + (size_t)b * 2 * A, e, xa, A, tanh_action);
+    for (int k = 0; k < D; ++k) x_next[(size_t)b * F + k] = nobs[(size_t)b * D + k];
+    for (int k = 0; k < A; ++k) x_next[(size_t)b * F + D + k] = xa[k];
   }
 }
 static int sac_samples_impl(const float* head, const float* head2, const float* eps1, const float* eps2,
@@ -162,7 +168,7 @@ static int sac_samples_impl(const float* head, const float* head2, const float* 
   if (B == 0) return TRL_OK;
   TRL_REQUIRE(head && head2 && obs && acts && next_obs && ((eps1 && eps2) || (step_state && eps1_out)), "null input");
   TRL_REQUIRE(new_a && logp && next_a && next_logp && x_sa && x_next && x_new, "null output");
-  hipLaunchKernelGGL(sac_samples_kernel, dim3(trl_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, head, head2, eps1,
+  hipLaunchKernelGGL(sac_samples_kernel, dim3(2 * trl_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, head, head2, eps1,
                      eps2, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next, x_new, B, D, A, tanh_action,
                      step_state, seed, eps1_out);
   TRL_LAUNCH_CHECK();
