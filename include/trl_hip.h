@@ -294,6 +294,11 @@ typedef struct trl_adam_t {
                                  of group_lr (a linear schedule then changes no launch argument either) */
 } trl_adam_t;
 int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
+/* the same followed by the Polyak step target <- (1 - tau) target + tau source of n floats (rl_algo.py:169-176,
+ * utils.py:16-20) as two launches: where the device-resident step state would need the one-thread tick launch, the Polyak
+ * kernel advances it */
+int trl_clip_adam_polyak_f32(const trl_adam_t* args, float* target, const float* source, int64_t n, float tau,
+                             void* stream);
 /* Single-process fast path: trl_ppo_reduce_f32 + trl_clip_adam_f32 in one launch (the block that
  * finishes the reduction last takes the optimiser step; fixed summation orders, deterministic).
  * adam->grads must equal `grads`, the two groups must be [policy | value]; logstd statistics are read

@@ -152,6 +152,7 @@ SIGNATURES = {
     "trl_norm_filt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "trl_ppo_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_clip_adam_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
+    "trl_clip_adam_polyak_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "trl_ppo_reduce_adam_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_reduce_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
@@ -386,6 +387,12 @@ def ppo_reduce(partial, scal_partial, n_wg, D, H, A, grads, info, pf_params=None
 
 def clip_adam(args, device):
     check(lib().trl_clip_adam_f32(C.byref(args), stream_ptr(device)), "trl_clip_adam_f32")
+
+
+def clip_adam_polyak(args, target, source, tau, device):
+    """clip + Adam, then target <- (1 - tau) target + tau source (the Polyak kernel also advances the device step state)."""
+    check(lib().trl_clip_adam_polyak_f32(C.byref(args), dev_ptr(target, name="target"), dev_ptr(source, name="source"),
+                                         int(target.numel()), float(tau), stream_ptr(device)), "trl_clip_adam_polyak_f32")
 
 
 def synth_collect_step(env, head, eps, cur_step, ep_return, max_frames, rows, mask, epoch_reward, ep_count, ep_log, step,

@@ -199,9 +199,10 @@ class _FusedDQN:
         dist.all_reduce_sum_(self.grads)                                 # C1: local-mean gradients -> SUM / world
         a.grad_scale, a.norms_out = 1.0 / dist.world_size(), None
         a.step_count, a.step_state = 0, self.step_state.data_ptr()       # the step count lives on the device
-        _C.clip_adam(a, dev)
-        if soft:
-            _C.polyak(self.tflat, self.flat, algo.tau)
+        if soft:                                                         # Adam, then Polyak (which also advances the step state)
+            _C.clip_adam_polyak(a, self.tflat, self.flat, algo.tau, dev)
+        else:
+            _C.clip_adam(a, dev)
         dist.all_reduce_sum_(self.sums)
 
     def _run(self, st, soft):

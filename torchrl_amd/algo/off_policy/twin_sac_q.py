@@ -223,9 +223,10 @@ class _FusedSAC:
         a.grad_scale = 1.0 / dist.world_size()
         a.step_count, a.norms_out = 0, self.norms.data_ptr()
         a.step_state = self.step_state.data_ptr()                        # the step count lives on the device
-        _C.clip_adam(a, dev)
-        if soft:
-            _C.polyak(self.tflat, self.flat[self.sizes[0]:], algo.tau)
+        if soft:                                                         # Adam, then Polyak (which also advances the step state)
+            _C.clip_adam_polyak(a, self.tflat, self.flat[self.sizes[0]:], algo.tau, dev)
+        else:
+            _C.clip_adam(a, dev)
         # ---- logging statistics (over the global batch) ----
         dist.all_reduce_sum_(self.sums)
         head_g, logp_g = dist.all_gather_cat(head), dist.all_gather_cat(logp)

@@ -1661,7 +1661,33 @@ extern "C" int trl_ppo_step_f32(const trl_ppo_batch_t* p, float* grads, double* 
   return TRL_EUNSUPPORTED;
 }
 
-extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {
+#define TICK_PENDING 0x70000001                    /* clip_adam_launch: the step state still has to be advanced */
+static int clip_adam_launch(const trl_adam_t* p, void* stream, bool tick_here);
+extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) { return clip_adam_launch(p, stream, true); }
+
+// clip + Adam followed by the Polyak step of the target networks (rl_algo.py:169-176 / utils.py:16-20), two launches:
+// when the device-resident step state needs the one-thread tick kernel (large parameter blocks), the Polyak kernel's
+// first thread advances it instead -- it runs behind the Adam kernel in stream order, i.e. after every block has read it.
+__global__ __launch_bounds__(256) void polyak_tick_kernel(float* __restrict__ tgt, const float* __restrict__ src, int64_t n,
+                                                          float tau, double* __restrict__ st, float beta1, float beta2) {
+  if (st && blockIdx.x == 0 && threadIdx.x == 0) { st[0] += 1.0; st[1] *= (double)beta1; st[2] *= (double)beta2; }
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+    tgt[e] = tgt[e] * (1.0f - tau) + src[e] * tau;
+}
+extern "C" int trl_clip_adam_polyak_f32(const trl_adam_t* p, float* target, const float* source, int64_t n, float tau,
+                                        void* stream) {
+  TRL_REQUIRE(n > 0 && target && source, "polyak: empty / null");
+  int rc = clip_adam_launch(p, stream, false);
+  if (rc != TRL_OK && rc != TICK_PENDING) return rc;
+  int grid = trl_ceil_div(n, 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(polyak_tick_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, target, source, n, tau,
+                     rc == TICK_PENDING ? p->step_state : (double*)nullptr, p->beta1, p->beta2);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+static int clip_adam_launch(const trl_adam_t* p, void* stream, bool tick_here) {
   AdamDev d;
   int rc = fill_adam(p, d);
   if (rc) return rc;
@@ -1677,6 +1703,7 @@ extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) {
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
   TRL_LAUNCH_CHECK();
   if (d.step_state && !d.self_tick) {
+    if (!tick_here) return TICK_PENDING;             // the caller's next kernel advances the state
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d.step_state, d.beta1, d.beta2);
     TRL_LAUNCH_CHECK();
   }
