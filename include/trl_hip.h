@@ -493,6 +493,11 @@ int trl_noisy_action_f32(const float* act, const float* eps, float sigma, float 
 /* out (rows, A) = x1[:, off:off+A] + x2[:, off:off+A]  (d policy_loss / d action through both Q nets; x2 may be NULL) */
 int trl_slice_add_f32(const float* x1, const float* x2, float* out, int rows, int ld, int off, int A,
                       void* stream);
+/* d(input) of a layer with ONE output, already gated for the layer below: out[m][f] = dq[m] * w[f] * act'(h[m][f])
+ * (h = that layer's activation output, (M, N) like out; N % 4 == 0, 16-byte aligned h / out); G problems per launch.
+ * Replaces a K = 1 trl_linear_bwd_input_f32 and the gate operand of the GEMMs that consume its result. */
+int trl_outer_gate_group_f32(int G, const float* const* dq, const float* const* w, const float* const* h,
+                             float* const* out, int M, int N, int act, void* stream);
 /* K13: target <- (1 - tau) target + tau source  (torchrl/algo/utils.py:16-20) */
 int trl_polyak_f32(float* target, const float* source, int64_t n, float tau, void* stream);
 /* logging: mean / unbiased std / max / min over columns [off, off+width) of rows of `ld` floats,

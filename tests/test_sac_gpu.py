@@ -171,6 +171,42 @@ def test_fused_three_layer_forward_equals_the_per_layer_launches(M, D, O, act, l
     assert not _C.mlp3_forward_ok(40, 256, 256, 1) and not _C.mlp3_forward_ok(17, 64, 64, 6) and not _C.mlp3_forward_ok(17, 256, 256, 20)
 
 
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+def test_one_output_head_backward_through_the_rank_one_kernel(act, monkeypatch):
+    """mlp_backward_group on networks with a ONE-output head: d(hidden) = dq w^T comes from trl_outer_gate_group_f32 already
+    gated, the layer below then runs ungated -- against the K = 1 GEMM + gate-operand path: input gradients and every
+    weight / bias gradient (twin group, one network at an odd parameter offset)."""
+    from torchrl_amd import _C, ops
+    code = {"relu": _C.ACT_RELU, "tanh": _C.ACT_TANH}[act]
+    gen = torch.Generator().manual_seed(5)
+    M, D, H, G = 520, 23, 256, 2
+    sizes = [H * D, H, H * H, H, H, 1]
+    flat = torch.randn(G * (sum(sizes) + 1) + 8, generator=gen).to(DEV) * 0.1
+    layers_list, off = [], 0
+    for g in range(G):
+        ps = []
+        for n in sizes:
+            ps.append(flat[off:off + n]); off += n
+        layers_list.append([(ps[0].view(H, D), ps[1]), (ps[2].view(H, H), ps[3]), (ps[4].view(1, H), ps[5])])
+        off += 1                                                            # the second network starts at an odd offset
+    xs = [torch.randn(M, D, generator=gen).to(DEV) for _ in range(G)]
+    dqs = [torch.randn(M, 1, generator=gen).to(DEV) for _ in range(G)]
+    res = []
+    for off_switch in ("1", "0"):
+        monkeypatch.setenv("TRL_NO_OUTER_GATE", off_switch)
+        outs, tapes = ops.mlp_forward_group(layers_list, xs, code)
+        grads = [[(torch.zeros_like(w), torch.zeros_like(b)) for w, b in ls] for ls in layers_list]
+        dxs = ops.mlp_backward_group(tapes, dqs, grads_list=grads, need_input=True)
+        res.append((dxs, grads))
+    (dxa, ga), (dxb, gb) = res
+    for g in range(G):
+        scale = max(1.0, dxa[g].abs().max().item())
+        assert (dxa[g] - dxb[g]).abs().max().item() < 1e-6 * scale
+        for (wa, ba), (wb, bb) in zip(ga[g], gb[g]):
+            assert (wa - wb).abs().max().item() < 2e-5 * max(1.0, wa.abs().max().item())
+            assert (ba - bb).abs().max().item() < 2e-5 * max(1.0, ba.abs().max().item())
+
+
 def test_rsample_fwd_bwd_vs_autograd():
     from torchrl_amd import _C
     B, A = 300, 6

@@ -216,6 +216,7 @@ SIGNATURES = {
                                        + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_bwd_weight_group_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
                                         + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_outer_gate_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_mlp3_forward_ok": (C.c_int, [C.c_int] * 4),
     "trl_mlp3_forward_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_void_p]),
     "trl_linear_fwd_splitk_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
@@ -574,6 +575,15 @@ def linear_fwd_group(xs, ws, biases, act):
     check(lib().trl_linear_fwd_group_f32(G, _ptrs(xs, "x"), _ptrs(ws, "w"), _ptrs(biases, "bias", True), _ptrs(ys, "y"),
                                          M, K, N, act, stream_ptr(xs[0].device)), "trl_linear_fwd_group_f32")
     return ys
+
+
+def outer_gate_group(dqs, ws, hs, act):
+    """[dq_g w_g^T * act'(h_g)]: the gated input gradient of G one-output layers in one streaming launch."""
+    M, N = int(hs[0].shape[0]), int(hs[0].shape[1])
+    outs = [torch.empty((M, N), dtype=torch.float32, device=hs[0].device) for _ in hs]
+    check(lib().trl_outer_gate_group_f32(len(hs), _ptrs(dqs, "dq"), _ptrs(ws, "w"), _ptrs(hs, "h"), _ptrs(outs, "out"),
+                                         M, N, act, stream_ptr(hs[0].device)), "trl_outer_gate_group_f32")
+    return outs
 
 
 def mlp3_forward_ok(D, H1, H2, O):

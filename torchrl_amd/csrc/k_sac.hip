@@ -422,6 +422,52 @@ extern "C" int trl_slice_add_f32(const float* x1, const float* x2, float* out, i
   return TRL_OK;
 }
 
+// ---------------------------------------------------------------- input gradient of a 1-wide head, gated
+// out[m][f] = dq[m] * w[f] * act'(h[m][f]): dH = dq w^T of a layer with ONE output is a rank-1 product, and the layer
+// below wants it gated by its own activation -- one streaming pass (h read, out written) instead of a K = 1 GEMM plus a
+// gate operand in the two GEMMs that consume it.  Up to 12 problems per launch (blockIdx.y).
+#define OG_MAX 12
+struct OuterGate { const float* dq[OG_MAX]; const float* w[OG_MAX]; const float* h[OG_MAX]; float* out[OG_MAX]; };
+__global__ __launch_bounds__(SAC_THREADS) void outer_gate_kernel(OuterGate g, int M, int N4, int act) {
+  const int p = blockIdx.y;
+  const f32x4* h4 = reinterpret_cast<const f32x4*>(g.h[p]);
+  const float* wp = g.w[p];                          // (a parameter view: no alignment promise, and only N floats)
+  f32x4* o4 = reinterpret_cast<f32x4*>(g.out[p]);
+  const int64_t total = (int64_t)M * N4;
+  for (int64_t e = (int64_t)blockIdx.x * SAC_THREADS + threadIdx.x; e < total; e += (int64_t)gridDim.x * SAC_THREADS) {
+    const int m = (int)(e / N4), c = (int)(e - (int64_t)m * N4);
+    const float d = g.dq[p][m];
+    const f32x4 h = h4[e];
+    const f32x4 w = {wp[4 * c], wp[4 * c + 1], wp[4 * c + 2], wp[4 * c + 3]};
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ga = act == TRL_ACT_TANH ? 1.0f - h[r] * h[r] : (act == TRL_ACT_RELU ? (h[r] > 0.0f ? 1.0f : 0.0f) : 1.0f);
+      o[r] = d * w[r] * ga;
+    }
+    o4[e] = o;
+  }
+}
+extern "C" int trl_outer_gate_group_f32(int G, const float* const* dq, const float* const* w, const float* const* h,
+                                        float* const* out, int M, int N, int act, void* stream) {
+  TRL_REQUIRE(G >= 1 && G <= OG_MAX && M >= 0 && N > 0 && (N & 3) == 0, "1..12 problems, N a multiple of 4");
+  TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
+  if (M == 0) return TRL_OK;
+  TRL_REQUIRE(dq && w && h && out, "null pointer array");
+  OuterGate g;
+  for (int k = 0; k < G; ++k) {
+    TRL_REQUIRE(dq[k] && w[k] && h[k] && out[k], "null pointer");
+    TRL_REQUIRE(((reinterpret_cast<uintptr_t>(h[k]) | reinterpret_cast<uintptr_t>(out[k])) & 15) == 0,
+                "h / out must be 16-byte aligned");
+    g.dq[k] = dq[k]; g.w[k] = w[k]; g.h[k] = h[k]; g.out[k] = out[k];
+  }
+  int grid = trl_ceil_div((int64_t)M * (N / 4), SAC_THREADS);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(outer_gate_kernel, dim3(grid, G), dim3(SAC_THREADS), 0, (hipStream_t)stream, g, M, N / 4, act);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 // ---------------------------------------------------------------- K13 Polyak target update
 // target <- (1 - tau) target + tau source   (atu.soft_update_from_to, torchrl/algo/utils.py:16-20)
 __global__ __launch_bounds__(SAC_THREADS) void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src,

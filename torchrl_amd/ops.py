@@ -120,10 +120,13 @@ def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspa
     n = len(tapes[0].layers)
     want_in = list(need_input) if isinstance(need_input, (list, tuple)) else [bool(need_input)] * len(tapes)
     with_w = [] if grads_list is None else [g for g in range(len(tapes)) if grads_list[g] is not None]
+    pregated = False                                  # ds already carries act' of layer k (see the one-output head below)
     for k in range(n - 1, -1, -1):
         last = k == n - 1
         gate_act = tapes[0].last_act if last else tapes[0].act
         gates = [None if (last and gate_act == _C.ACT_NONE) else t.outs[k] for t in tapes]
+        if pregated:
+            gates, gate_act, pregated = [None] * len(tapes), _C.ACT_NONE, False
         if with_w:
             inps = [(tapes[g].x if k == 0 else tapes[g].outs[k - 1]) for g in with_w]
             args = ([ds[g] for g in with_w], [gates[g] for g in with_w], gate_act, inps,
@@ -132,7 +135,15 @@ def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspa
                 _C.linear_bwd_weight_partials_group(*args, plan)
             else:
                 _C.linear_bwd_weight_group(*args, workspace=workspace)
-        if k > 0:
+        if k > 0 and last and gate_act == _C.ACT_NONE and int(tapes[0].layers[k][0].shape[0]) == 1 and \
+                int(tapes[0].layers[k][0].shape[1]) % 4 == 0 and os.environ.get("TRL_NO_OUTER_GATE") != "1" and \
+                all(t.outs[k - 1].data_ptr() % 16 == 0 for t in tapes):
+            # a head with ONE output: d(hidden) = dq w^T is rank 1 -- produced already gated for the layer below by one
+            # streaming launch, and that layer's GEMMs then read one operand instead of two
+            ds = _C.outer_gate_group([d.reshape(-1) for d in ds], [t.layers[k][0].reshape(-1) for t in tapes],
+                                     [t.outs[k - 1] for t in tapes], tapes[0].act)
+            pregated = True
+        elif k > 0:
             ds = _C.linear_bwd_input_group(ds, gates, gate_act, [t.layers[k][0] for t in tapes])
         elif any(want_in):
             sel = [g for g in range(len(tapes)) if want_in[g]]
