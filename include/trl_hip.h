@@ -523,6 +523,18 @@ int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* e
                                float* rew_row, float* done_row, float* tl_row, uint8_t* reset_mask,
                                double* epoch_reward, int32_t* ep_count, float* ep_log, int ep_cap, int step,
                                int N, int D, int A, int tanh_action, void* stream);
+/* The same with every per-step quantity on the device, so that the launch (and the policy pass in front of it) is captured
+ * once and replayed for every vector step: state = 3 int64 {global step, ring row, first step of the epoch} followed by a
+ * zeroed 32-bit block counter at state + 3 (32 bytes in all); obs / acts / next_obs / rewards / terminals / time_limits
+ * are the whole ring tensors (n_rows time rows of N envs); the exploration noise is drawn in place (counter = global
+ * step).  The launch stores into row state[1] and advances state[0] and state[1] itself. */
+int trl_synth_collect_step_dyn_f32(float* cur_obs, const float* head, int64_t noise_seed, int noise_row0,
+                                   const float* env_A, const float* env_B, int32_t* t_env, int32_t* cur_step,
+                                   int32_t* episode_idx, float* ep_return, float reward_scale, int horizon,
+                                   int max_episode_frames, int64_t env_seed_base, float* obs, float* acts,
+                                   float* next_obs, float* rewards, float* terminals, float* time_limits, int n_rows,
+                                   int64_t* state, uint8_t* reset_mask, double* epoch_reward, int32_t* ep_count,
+                                   float* ep_log, int ep_cap, int N, int D, int A, int tanh_action, void* stream);
 /* N(0,1) fill from the Philox4x32-10 stream (device exploration / rsample noise) */
 int trl_philox_normal_f32(float* out, int64_t n, int64_t seed, int64_t counter, void* stream);
 /* K1 stand-alone: one VecEnv.step of the synthetic env (torchrl/env/vecenv.py:53-61); cur_obs is

@@ -510,8 +510,9 @@ def test_off_policy_collector_on_normalised_env_matches_reference(golden, tag):
 @pytest.mark.parametrize("max_frames", [100, 5])
 def test_one_launch_vector_step_equals_the_separate_kernels(monkeypatch, max_frames):
     """trl_synth_collect_step_f32 (sample, store, env.step, bookkeeping, partial reset in one launch) against the eight
-    separate launches: replay rows, env and collector state, epoch reward, finished-episode log and evaluation, bit for
-    bit; resets by the env's time limit (horizon 7) or by the collector's max_episode_frames (5: no episode ever ends)."""
+    separate launches, and its graph-replayed form (trl_synth_collect_step_dyn_f32: step counter / ring row on the device,
+    the 32-row ring wraps under replay): replay rows, env and collector state, epoch reward, finished-episode log and
+    evaluation, bit for bit; resets by the env's time limit (horizon 7) or by max_episode_frames (5: no episode ends)."""
     import torchrl.networks as networks
     import torchrl.policies as policies
     from torchrl.collector import VecCollector
@@ -519,8 +520,9 @@ def test_one_launch_vector_step_equals_the_separate_kernels(monkeypatch, max_fra
     from torchrl.replay_buffers import BaseReplayBuffer
     N, dev = 300, torch.device(DEV)
 
-    def run(separate):
+    def run(separate, eager=False):
         monkeypatch.setenv("TRL_COLLECT_SEPARATE", "1" if separate else "0")
+        monkeypatch.setenv("TRL_COLLECT_EAGER", "1" if eager else "0")
         torch.manual_seed(3)
         net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
         pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net).to(dev)
@@ -536,9 +538,11 @@ def test_one_launch_vector_step_equals_the_separate_kernels(monkeypatch, max_fra
         state += [env.cur_obs.clone(), env.t_env.clone(), env.cur_step.clone(), env.episode_idx.clone(), env.ep_return.clone()]
         return res, evl, state, buf._top, col.global_step
     (ra, ea, sa, ta, ga), (rb, eb, sb, tb, gb) = run(True), run(False)
-    assert ta == tb and ga == gb
-    for x, y in zip(sa, sb):
-        assert torch.equal(x, y)
+    rc, ec, sc, tc, gc = run(False, eager=True)      # the same launch with host-side step / row arguments, not replayed
+    assert ta == tb == tc and ga == gb == gc
+    for x, y, z in zip(sa, sb, sc):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    assert [r["train_rewards"] for r in rc] == [r["train_rewards"] for r in rb] and ec["eval_rewards"] == eb["eval_rewards"]
     for x, y in zip(ra, rb):
         assert x["train_rewards"] == y["train_rewards"] and (len(x["train_rewards"]) > 0) == (max_frames == 100)
         assert abs(x["train_epoch_reward"] - y["train_epoch_reward"]) < 1e-9 * max(1.0, abs(x["train_epoch_reward"]))

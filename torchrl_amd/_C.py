@@ -168,6 +168,9 @@ SIGNATURES = {
     "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
     "trl_synth_collect_step_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 6 +
                                    [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 6 + [C.c_void_p]),
+    "trl_synth_collect_step_dyn_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int] + [C.c_void_p] * 6 +
+                                       [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 6 + [C.c_int] +
+                                       [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
     "trl_collector_bookkeep_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_sac_alpha_step_f32": (C.c_int, [C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_void_p] * 3),
     "trl_sac_losses_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
@@ -416,6 +419,23 @@ def synth_collect_step(env, head, eps, cur_step, ep_return, max_frames, rows, ma
         dev_ptr(epoch_reward, torch.float64, "epoch_reward"), dev_ptr(ep_count, torch.int32, "ep_count"),
         dev_ptr(ep_log, name="ep_log"), int(ep_log.shape[0]), int(step), N, D, A, int(bool(tanh_action)),
         stream_ptr(head.device)), "trl_synth_collect_step_f32")
+
+
+def synth_collect_step_dyn(env, head, cur_step, ep_return, max_frames, ring, state, mask, epoch_reward, ep_count, ep_log,
+                           tanh_action, noise_seed, noise_row0):
+    """`synth_collect_step` with the step counter / ring row / epoch start on the device (`state`, 4 int64): graph-replayable.
+    ring = the six whole ring tensors (obs, acts, next_obs, rewards, terminals, time_limits)."""
+    N, D, A = int(env.cur_obs.shape[0]), int(env.cur_obs.shape[1]), int(head.shape[1]) // 2
+    check(lib().trl_synth_collect_step_dyn_f32(
+        dev_ptr(env.cur_obs, name="cur_obs"), dev_ptr(head, name="head"), int(noise_seed), int(noise_row0),
+        dev_ptr(env.env_A, name="env_A"), dev_ptr(env.env_B, name="env_B"), dev_ptr(env.t_env, torch.int32, "t_env"),
+        dev_ptr(cur_step, torch.int32, "cur_step"), dev_ptr(env.episode_idx, torch.int32, "episode_idx"),
+        dev_ptr(ep_return, name="ep_return"), float(env.effective_reward_scale), int(env.horizon), int(max_frames),
+        int(env.seed_base), *[dev_ptr(t, name="ring") for t in ring], int(ring[0].shape[0]),
+        dev_ptr(state, torch.int64, "state"), dev_ptr(mask, torch.uint8, "mask"),
+        dev_ptr(epoch_reward, torch.float64, "epoch_reward"), dev_ptr(ep_count, torch.int32, "ep_count"),
+        dev_ptr(ep_log, name="ep_log"), int(ep_log.shape[0]), N, D, A, int(bool(tanh_action)), stream_ptr(head.device)),
+        "trl_synth_collect_step_dyn_f32")
 
 
 def synth_reset(cur_obs, t_env, cur_step, episode_idx, ep_return, mask, seed_base):

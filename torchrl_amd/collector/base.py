@@ -347,10 +347,58 @@ class VecCollector(_CollectorBase):
             buf._advance()
         self.global_step += 1
 
+    def _replayed_rollout(self, n_steps):
+        """Training collection on the synthetic vector env with device noise, one rank: a vector step = the policy pass +
+        trl_synth_collect_step_dyn_f32, whose step counter / ring row / epoch start live on the device -- captured into
+        a HIP graph on the second step and replayed afterwards (the host issues one call per step instead of a dozen).
+        Returns False when the configuration is outside that path."""
+        from .. import dist, ops
+        env, buf, pf = self.env, self.replay_buffer, self.pf
+        if not (self._one_launch_step(env, getattr(env, "_obs_normalizer", None)) and self.noise_mode == "device"
+                and dist.world_size() == 1 and os.environ.get("TRL_NO_GRAPH") != "1"
+                and os.environ.get("TRL_COLLECT_EAGER") != "1" and hasattr(buf, "_obs") and buf._max_replay_buffer_size > 0):
+            return False
+        n, d, a_dim = env.env_nums, env.obs_dim, env.act_dim
+        ring = [buf._ensure_key("obs", (n, d)), buf._ensure_key("acts", (n, a_dim)), buf._ensure_key("next_obs", (n, d)),
+                buf._ensure_key("rewards", (n, 1)), buf._ensure_key("terminals", (n, 1)), buf._ensure_key("time_limits", (n, 1))]
+        if getattr(self, "_dyn", None) is None:
+            self._dyn = torch.zeros(4, dtype=torch.int64, device=env.device)
+            self._dyn_host = torch.zeros(4, dtype=torch.int64).pin_memory()
+            self._step_graph, self._step_key, self._step_seen = None, None, None
+        self._dyn_host[0], self._dyn_host[1], self._dyn_host[2], self._dyn_host[3] = \
+            self.global_step, buf._top, self._log_step0, 0
+        self._dyn.copy_(self._dyn_host, non_blocking=True)                 # one 32-byte upload per epoch
+        key = tuple(t.data_ptr() for t in ring) + (env.cur_obs.data_ptr(), n, d, a_dim, int(self.max_episode_frames),
+                                                   bool(pf.tanh_action), int(env.horizon))
+
+        def one_step():
+            head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf))
+            _C.synth_collect_step_dyn(env, head, env.cur_step, env.ep_return, self.max_episode_frames, ring, self._dyn,
+                                      self._mask, self._epoch_reward, self._ep_count, self._ep_log, bool(pf.tanh_action),
+                                      self._noise_seed, 0)
+        for _ in range(n_steps):
+            if self._step_graph is not None and self._step_key == key:
+                self._step_graph.replay()
+            elif self._step_seen != key:
+                self._step_seen, self._step_graph = key, None              # first visit: eager (warm-up)
+                one_step()
+            else:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    one_step()
+                self._step_graph, self._step_key = graph, key
+                graph.replay()
+            buf._advance()
+            self.global_step += 1
+        return True
+
     def rollout(self, n_steps):
         """Enqueue `n_steps` vector steps into the replay buffer; no host sync."""
         self.env.train()
         self._clear_header()
+        if self._replayed_rollout(n_steps):
+            self.current_ob = self.env.cur_obs
+            return
         ob = None
         if hasattr(self.env, "_obs_normalizer"):
             ob = torch.as_tensor(self.current_ob).to(device=self.env.device, dtype=torch.float32).contiguous()

@@ -639,11 +639,29 @@ struct CollectStep {
   float* obs_row; float* acts_row; float* next_row; float* rew_row; float* done_row; float* tl_row;   // obs / acts / tl nullable
   uint8_t* mask; double* epoch_reward; int32_t* ep_count; float* ep_log; int ep_cap, step;
   int N, D, A, tanh_action;
+  // graph-replayable form (dyn != NULL): the step counter, the ring row and the epoch's first step live on the device --
+  // dyn = {global step, ring row, first step of the epoch}; the row pointers above are then the BASES of the ring
+  // tensors (n_rows rows); the block that retires last advances dyn[0] and dyn[1] (done: its counter, zero between launches)
+  int64_t* dyn; int n_rows; unsigned* done;
 };
 __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(CollectStep c) {
   extern __shared__ float sm[];                    // envA (D*D) | envB (A*D)
   __shared__ double red[SAC_THREADS / 64];
   const int D = c.D, A = c.A;
+  // (locals, not writes into `c`: a modified kernel-argument struct is demoted to scratch memory)
+  int64_t dyn_gs = 0, dyn_row = 0, noise_ctr = c.noise_ctr;
+  int step = c.step;
+  float* obs_row = c.obs_row; float* acts_row = c.acts_row; float* next_row = c.next_row;
+  float* rew_row = c.rew_row; float* done_row = c.done_row; float* tl_row = c.tl_row;
+  if (c.dyn) {                                     // uniform: every block reads the state before any block can retire
+    dyn_gs = c.dyn[0]; dyn_row = c.dyn[1];
+    noise_ctr = dyn_gs; step = (int)(dyn_gs - c.dyn[2]);
+    const size_t r = (size_t)dyn_row * c.N;
+    if (obs_row) obs_row += r * D;
+    if (acts_row) acts_row += r * A;
+    next_row += r * D; rew_row += r; done_row += r;
+    if (tl_row) tl_row += r;
+  }
   for (int e = threadIdx.x; e < D * D; e += SAC_THREADS) sm[e] = c.envA[e];
   for (int e = threadIdx.x; e < A * D; e += SAC_THREADS) sm[D * D + e] = c.envB[e];
   __syncthreads();
@@ -656,11 +674,11 @@ __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(Collect
     if (c.eps) {
       for (int k = 0; k < A; ++k) ez[k] = c.eps[(size_t)n * A + k];
     } else {                                       // element e of the draw = normal (e & 3) of Philox block e / 4
-      philox_noise_row(c.noise_seed, c.noise_ctr, (int64_t)c.noise_row0 + n, A, ez);
+      philox_noise_row(c.noise_seed, noise_ctr, (int64_t)c.noise_row0 + n, A, ez);
     }
     rsample_row(c.head + (size_t)n * 2 * A, ez, a, A, c.tanh_action);
-    if (c.obs_row) for (int k = 0; k < D; ++k) c.obs_row[(size_t)n * D + k] = o[k];
-    if (c.acts_row) for (int k = 0; k < A; ++k) c.acts_row[(size_t)n * A + k] = a[k];
+    if (obs_row) for (int k = 0; k < D; ++k) obs_row[(size_t)n * D + k] = o[k];
+    if (acts_row) for (int k = 0; k < A; ++k) acts_row[(size_t)n * A + k] = a[k];
     float asq = 0.0f;
     for (int k = 0; k < A; ++k) asq = fmaf(a[k], a[k], asq);
     for (int f = 0; f < D; ++f) {                  // obs' = tanh(obs A + act B)
@@ -668,19 +686,19 @@ __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(Collect
       for (int k = 0; k < D; ++k) p = fmaf(o[k], sm[k * D + f], p);
       for (int k = 0; k < A; ++k) p = fmaf(a[k], sm[D * D + k * D + f], p);
       nv[f] = trl_tanh(p);
-      c.next_row[(size_t)n * D + f] = nv[f];
+      next_row[(size_t)n * D + f] = nv[f];
     }
     const int t = c.t_env[n] + 1;
     const float rew = c.reward_scale * (nv[0] - 0.1f * asq);
     const bool d = t >= c.horizon;
-    c.rew_row[n] = rew; c.done_row[n] = d ? 1.0f : 0.0f;
-    if (c.tl_row) c.tl_row[n] = d ? 1.0f : 0.0f;   // synthetic env: time_limit == done
+    rew_row[n] = rew; done_row[n] = d ? 1.0f : 0.0f;
+    if (tl_row) tl_row[n] = d ? 1.0f : 0.0f;   // synthetic env: time_limit == done
     r = (double)rew;
     const int cs = c.cur_step[n] + 1;              // ---- collector bookkeeping ----
     float er = c.ep_return[n] + rew;
     if (d) {
       const int slot = atomicAdd(c.ep_count, 1);
-      if (slot < c.ep_cap) { c.ep_log[slot * 3 + 0] = (float)c.step; c.ep_log[slot * 3 + 1] = (float)n; c.ep_log[slot * 3 + 2] = er; }
+      if (slot < c.ep_cap) { c.ep_log[slot * 3 + 0] = (float)step; c.ep_log[slot * 3 + 1] = (float)n; c.ep_log[slot * 3 + 2] = er; }
       er = 0.0f;
     }
     const bool flag = d || cs >= c.max_frames;
@@ -703,6 +721,13 @@ __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(Collect
   }
   r = block_sum(r, red);
   if (threadIdx.x == 0 && c.epoch_reward) atomicAdd(c.epoch_reward, r);
+  if (c.dyn && threadIdx.x == 0) {                 // (block_sum's barriers: every thread of this block is done with dyn)
+    const unsigned before = __hip_atomic_fetch_add(c.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == gridDim.x - 1) {
+      c.dyn[0] = dyn_gs + 1; c.dyn[1] = dyn_row + 1 == c.n_rows ? 0 : dyn_row + 1;
+      __hip_atomic_store(c.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 extern "C" int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* eps, int64_t noise_seed,
                                           int64_t noise_counter, int noise_row0, const float* env_A,
@@ -718,7 +743,32 @@ extern "C" int trl_synth_collect_step_f32(float* cur_obs, const float* head, con
   TRL_REQUIRE(next_row && rew_row && done_row && reset_mask && ep_count && ep_log && noise_row0 >= 0, "null pointer");
   CollectStep c{cur_obs, head, eps, env_A, env_B, noise_seed, noise_counter, noise_row0, t_env, cur_step, episode_idx, ep_return, reward_scale, horizon,
                 max_episode_frames, env_seed_base, obs_row, acts_row, next_row, rew_row, done_row, tl_row, reset_mask,
-                epoch_reward, ep_count, ep_log, ep_cap, step, N, D, A, tanh_action};
+                epoch_reward, ep_count, ep_log, ep_cap, step, N, D, A, tanh_action, nullptr, 0, nullptr};
+  hipLaunchKernelGGL(synth_collect_step_kernel, dim3(trl_ceil_div(N, SAC_THREADS)), dim3(SAC_THREADS),
+                     (D * D + A * D) * sizeof(float), (hipStream_t)stream, c);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+// The same with every per-step quantity on the device, so that the launch (and the policy pass in front of it) can be
+// captured once and replayed for every vector step: state = {global step, ring row, first step of the epoch} (3 int64)
+// followed by a zeroed 32-bit block counter at state + 3; obs / acts / next_obs / rewards / terminals / time_limits are
+// the ring tensors (n_rows time rows); noise is always drawn in place (counter = global step).  The launch stores into
+// row state[1] and advances state[0] and state[1] itself.
+extern "C" int trl_synth_collect_step_dyn_f32(float* cur_obs, const float* head, int64_t noise_seed, int noise_row0,
+                                              const float* env_A, const float* env_B, int32_t* t_env, int32_t* cur_step,
+                                              int32_t* episode_idx, float* ep_return, float reward_scale, int horizon,
+                                              int max_episode_frames, int64_t env_seed_base, float* obs, float* acts,
+                                              float* next_obs, float* rewards, float* terminals, float* time_limits,
+                                              int n_rows, int64_t* state, uint8_t* reset_mask, double* epoch_reward,
+                                              int32_t* ep_count, float* ep_log, int ep_cap, int N, int D, int A,
+                                              int tanh_action, void* stream) {
+  TRL_REQUIRE(N > 0 && D > 0 && D <= 32 && A > 0 && A <= 8 && ep_cap >= 0 && n_rows > 0, "bad sizes (D <= 32, A <= 8)");
+  TRL_REQUIRE(cur_obs && head && env_A && env_B && t_env && cur_step && episode_idx && ep_return && state, "null pointer");
+  TRL_REQUIRE(obs && acts && next_obs && rewards && terminals && reset_mask && ep_count && ep_log, "null pointer");
+  CollectStep c{cur_obs, head, nullptr, env_A, env_B, noise_seed, 0, noise_row0, t_env, cur_step, episode_idx, ep_return,
+                reward_scale, horizon, max_episode_frames, env_seed_base, obs, acts, next_obs, rewards, terminals,
+                time_limits, reset_mask, epoch_reward, ep_count, ep_log, ep_cap, 0, N, D, A, tanh_action, state, n_rows,
+                reinterpret_cast<unsigned*>(state + 3)};
   hipLaunchKernelGGL(synth_collect_step_kernel, dim3(trl_ceil_div(N, SAC_THREADS)), dim3(SAC_THREADS),
                      (D * D + A * D) * sizeof(float), (hipStream_t)stream, c);
   TRL_LAUNCH_CHECK();
