@@ -350,7 +350,7 @@ class VecCollector(_CollectorBase):
     def _replayed_rollout(self, n_steps):
         """Training collection on the synthetic vector env with device noise, one rank: a vector step = the policy pass +
         trl_synth_collect_step_dyn_f32, whose step counter / ring row / epoch start live on the device -- captured into
-        a HIP graph on the second step and replayed afterwards (the host issues one call per step instead of a dozen).
+        a HIP graph (all `n_steps` of the call) on the second call and replayed afterwards: one host call per epoch.
         Returns False when the configuration is outside that path."""
         from .. import dist, ops
         env, buf, pf = self.env, self.replay_buffer, self.pf
@@ -369,27 +369,29 @@ class VecCollector(_CollectorBase):
             self.global_step, buf._top, self._log_step0, 0
         self._dyn.copy_(self._dyn_host, non_blocking=True)                 # one 32-byte upload per epoch
         key = tuple(t.data_ptr() for t in ring) + (env.cur_obs.data_ptr(), n, d, a_dim, int(self.max_episode_frames),
-                                                   bool(pf.tanh_action), int(env.horizon))
+                                                   bool(pf.tanh_action), int(env.horizon), n_steps)
 
         def one_step():
             head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf))
             _C.synth_collect_step_dyn(env, head, env.cur_step, env.ep_return, self.max_episode_frames, ring, self._dyn,
                                       self._mask, self._epoch_reward, self._ep_count, self._ep_log, bool(pf.tanh_action),
                                       self._noise_seed, 0)
-        for _ in range(n_steps):
-            if self._step_graph is not None and self._step_key == key:
-                self._step_graph.replay()
-            elif self._step_seen != key:
-                self._step_seen, self._step_graph = key, None              # first visit: eager (warm-up)
+        # all n_steps of the call are ONE graph (the per-step state is on the device): one host call per epoch
+        if self._step_graph is not None and self._step_key == key:
+            self._step_graph.replay()
+        elif self._step_seen != key:
+            self._step_seen, self._step_graph = key, None                  # first visit: eager (warm-up)
+            for _ in range(n_steps):
                 one_step()
-            else:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(n_steps):
                     one_step()
-                self._step_graph, self._step_key = graph, key
-                graph.replay()
-            buf._advance()
-            self.global_step += 1
+            self._step_graph, self._step_key = graph, key
+            graph.replay()
+        buf._advance(n_steps)
+        self.global_step += n_steps
         return True
 
     def rollout(self, n_steps):
