@@ -70,6 +70,13 @@ int trl_gather_rows_u8(const uint8_t* src, const int64_t* row_idx, uint8_t* dst,
  * launch: dst[k][i, :] = src[k][row_idx[i], :], rows of row_bytes[k] bytes; every src[k] has src_rows rows. */
 int trl_gather_rows_multi(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
                           const int64_t* row_idx, int n_rows, int64_t src_rows, void* stream);
+/* the same with the index row set picked on the device: slab = {first, sets, idx[sets][n_rows]} (int64), set =
+ * (int64)update_count[0] - first; outside [0, sets) nothing is copied.  The `opt_times` samples of one
+ * OffRLAlgo.update_per_epoch (off_rl_algo.py:58-66) are drawn up front on the host, in the reference's order, uploaded
+ * once, and each update of the captured epoch graph gathers its own. */
+int trl_gather_rows_multi_dyn(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
+                              const int64_t* slab, const double* update_count, int n_rows, int64_t src_rows,
+                              void* stream);
 
 /* --- K7: per-minibatch advantage statistics --------------------------------
  * replaces advs.mean()/std()/max()/min() of PPO.update (ppo.py:141-144) for
@@ -508,6 +515,13 @@ int trl_moments_f64(const float* x, int64_t n, int ld, int off, int width, float
 int trl_moments_multi_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
                           const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
                           void* stream);
+/* the same launch also files the update's statistics block `raw` (raw_bytes, a multiple of 8; every out4[k] lies inside
+ * it) into slot ((int64)update_count[0] - 1) mod slots of `ring` (slots x raw_bytes): the deferred-update protocol reads
+ * a whole epoch's info dicts (off_rl_algo.py:62-64, logger.add_update_info) back in one copy. */
+int trl_moments_multi_ring_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
+                               const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
+                               const void* raw, int raw_bytes, void* ring, int slots, const double* update_count,
+                               void* stream);
 /* One VecCollector.take_actions (torchrl/collector/base.py:184-230) on the synthetic vector env in ONE launch, after the
  * policy MLP: action = rsample(head, eps) (as trl_tanh_gauss_rsample_fwd_f32), obs / acts stored, env.step
  * (as trl_synth_env_step_f32: cur_obs advanced in place), next_obs / rewards / terminals / time_limits rows written, the
@@ -620,6 +634,16 @@ int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const float* q_next
 int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* q_next,
                            const float* rewards, const float* terminals, float gamma, int B, int A,
                            int Q, float* dq, double* workspace, double* sums, void* stream);
+/* K14 / K15 as one step of a captured update: the actions as the floats the replay buffer stores (the reference's
+ * `actions.long()` cast, dqn.py:47, happens at the read) and, with `ring` (slots x 3 doubles, may be NULL), the three sums
+ * also filed into row ((int64)update_count[0] mod slots) -- the count of updates finished before this one. */
+int trl_dqn_td_loss_filed_f32(const float* q, const float* acts_f, const float* q_next, const float* rewards,
+                              const float* terminals, float gamma, int B, int A, float* dq, double* sums,
+                              double* ring, int slots, const double* update_count, void* stream);
+int trl_quantile_huber_filed_f32(const float* q, const float* acts_f, const float* q_next, const float* rewards,
+                                 const float* terminals, float gamma, int B, int A, int Q, float* dq,
+                                 double* workspace, double* sums, double* ring, int slots,
+                                 const double* update_count, void* stream);
 /* --- K17: greedy / epsilon-greedy action (torchrl/policies/discrete_policies.py:40-67, 86-89):
  * argmax_a of Q (Q == 1) or of the mean over Q quantiles; where u[n] < epsilon -> rand_act[n] */
 int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const float* u, const int64_t* rand_act,

@@ -18,7 +18,7 @@ class _Rec:
     def finish(self): pass
 
 
-def _sac_run(deferred, opt_times=5):
+def _sac_run(deferred, opt_times=5, epochs=2):
     from test_fullsize_offpolicy_gpu import build_cfg3
     pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=256)
     agent.noise_mode, col.noise_mode = "device", "device"
@@ -27,7 +27,7 @@ def _sac_run(deferred, opt_times=5):
     torch.manual_seed(5)
     col.train_one_epoch()
     np.random.seed(9)
-    for _ in range(2):                                                   # second epoch: the update graph is replayed
+    for _ in range(epochs):                                              # second epoch: the update graph is replayed
         if deferred:
             agent.update_per_epoch()
         else:
@@ -45,6 +45,82 @@ def test_sac_epoch_of_deferred_updates_equals_update_by_update():
     for x, y in zip(ia, ib):
         assert x == y
     assert len({i["Training/qf1_loss"] for i in ib}) == 10               # every slot carries its own update
+
+
+def test_sac_epoch_as_one_graph_equals_sample_and_enqueue_one_by_one(monkeypatch):
+    """TwinSACQ.update_epoch_deferred: the epoch's index sets uploaded as one slab, every update of the one captured graph
+    gathering its own set and filing its statistics by the device-resident update count (eager, captured, replayed twice)
+    against the per-update {random_batch, enqueue} loop."""
+    monkeypatch.setenv("TRL_SAC_EPOCH_GRAPH", "0")
+    ia, fa, ta, la = _sac_run(True, epochs=4)
+    monkeypatch.setenv("TRL_SAC_EPOCH_GRAPH", "1")
+    ib, fb, tb, lb = _sac_run(True, epochs=4)
+    assert len(ia) == len(ib) == 20
+    assert torch.equal(fa, fb) and torch.equal(ta, tb) and torch.equal(la, lb)
+    for x, y in zip(ia, ib):
+        assert x == y
+    assert len({i["Training/qf1_loss"] for i in ib}) == 20
+
+
+def test_sac_epoch_graph_is_declined_when_its_conditions_do_not_hold(monkeypatch):
+    from test_fullsize_offpolicy_gpu import build_cfg3
+    pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=64)
+    agent.noise_mode, col.noise_mode = "host", "host"
+    col.train_one_epoch()
+    state = np.random.get_state()[1].copy()
+    assert agent.update_epoch_deferred(3) is None                        # host noise: one by one
+    assert (np.random.get_state()[1] == state).all()                     # ... and no index was drawn
+    agent.noise_mode = "device"
+    agent.use_soft_update = False
+    assert agent.update_epoch_deferred(3) is None                        # hard target updates: one by one
+    agent.use_soft_update = True
+    handles = agent.update_epoch_deferred(3)
+    assert handles is not None and len(handles) == 3 and agent.training_update_num == 3
+    infos = agent.resolve_updates(handles)
+    assert len({i["Training/qf1_loss"] for i in infos}) == 3
+
+
+def test_index_slab_gather_picks_the_set_of_the_device_counter():
+    from torchrl_amd import _C
+    rows, n, sets, nrows = 29, 4, 3, 5
+    srcs = [torch.randn(rows, n, 7, device=DEV), torch.randn(rows, n, 1, device=DEV)]
+    idx = torch.randint(0, rows, (sets, nrows))
+    slab = torch.cat([torch.tensor([10, sets]), idx.reshape(-1)]).to(DEV)
+    counter = torch.zeros(4, dtype=torch.float64, device=DEV)
+    for step in (10, 11, 12):
+        counter[0] = step
+        outs = [torch.empty(nrows * n, 7, device=DEV), torch.empty(nrows * n, 1, device=DEV)]
+        _C.gather_rows_multi(srcs, slab, outs, slab_counter=counter, n_rows=nrows)
+        for s_, o in zip(srcs, outs):
+            assert torch.equal(o, s_[idx[step - 10].to(DEV)].reshape(o.shape))
+    for step in (9, 13):                                                 # outside the slab: nothing is copied
+        counter[0] = step
+        outs = [torch.full((nrows * n, 7), 3.0, device=DEV), torch.full((nrows * n, 1), 3.0, device=DEV)]
+        _C.gather_rows_multi(srcs, slab, outs, slab_counter=counter, n_rows=nrows)
+        assert all(bool((o == 3.0).all()) for o in outs)
+
+
+def test_moments_launch_files_the_statistics_block_into_its_ring_slot():
+    from torchrl_amd import _C
+    raw = torch.zeros(160, dtype=torch.uint8, device=DEV)
+    sums, mom = raw[:32].view(torch.float64), raw[32:128].view(torch.float64).view(3, 4)
+    tail = raw[128:160].view(torch.float32)
+    ring = torch.zeros(4, 160, dtype=torch.uint8, device=DEV)
+    counter = torch.zeros(4, dtype=torch.float64, device=DEV)
+    x = torch.randn(64, 6, device=DEV)
+    for done in (1, 2, 6):                                               # slots 0, 1, 5 % 4 = 1
+        counter[0] = done
+        sums.copy_(torch.arange(4, dtype=torch.float64) + done); tail.fill_(float(done))
+        x.mul_(1.5)
+        _C.moments_multi([(x, mom[0], 6, 3, 3, -1.0, 1.0), (x, mom[1], 6, 0, 1, -9.0, 9.0), (x, mom[2], 6, 0, 3, -9.0, 9.0)],
+                         ring=(raw, ring, counter))
+        ref = torch.zeros_like(mom)
+        _C.moments_multi([(x, ref[0], 6, 3, 3, -1.0, 1.0), (x, ref[1], 6, 0, 1, -9.0, 9.0), (x, ref[2], 6, 0, 3, -9.0, 9.0)])
+        assert torch.equal(mom, ref)
+        assert torch.equal(ring[(done - 1) % 4], raw)
+    assert bool((ring[2] == 0).all()) and bool((ring[3] == 0).all())
+    with pytest.raises(_C.TrlError):                                     # a statistic outside the block cannot be filed
+        _C.moments_multi([(x, torch.zeros(4, dtype=torch.float64, device=DEV), 6, 0, 3, -9.0, 9.0)], ring=(raw, ring, counter))
 
 
 def test_sac_noise_drawn_inside_the_sampling_launch_equals_the_separate_noise_launches(monkeypatch):
@@ -81,6 +157,57 @@ def test_dqn_epoch_of_deferred_updates_equals_update_by_update(Q):
     for x, y in zip(ia, ib):
         assert x == y
     assert len({i["Training/qf_loss"] for i in ib}) == 4
+
+
+@pytest.mark.parametrize("Q,soft", [(1, True), (8, True), (1, False)])
+def test_dqn_epoch_as_one_graph_equals_sample_and_enqueue_one_by_one(Q, soft, monkeypatch):
+    """DQN.update_epoch_deferred (first epoch one by one -- no update seen yet --, then eager, captured, replayed) against
+    the per-update {random_batch, enqueue} loop; with hard target copies the epochs a copy falls into go one by one."""
+    from test_fullsize_offpolicy_gpu import build_cfg5
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("TRL_DQN_EPOCH_GRAPH", flag)
+        qf, pf, env, buf, col, agent = build_cfg5(Q)
+        agent.logger = _Rec()
+        agent.opt_times = 3
+        agent.use_soft_update, agent.target_hard_update_period = soft, 7
+        np.random.seed(2)
+        col.train_one_epoch()
+        np.random.seed(3)
+        for _ in range(5):
+            agent.update_per_epoch()
+        eng = agent.engine()
+        assert agent.training_update_num == 15 and eng.step_state.cpu()[0].item() == 15
+        assert len(eng._graphs) == (1 if flag == "0" else 2)
+        res.append((agent.logger.infos, eng.flat.cpu().clone(), eng.tflat.cpu().clone()))
+    (ia, fa, ta), (ib, fb, tb) = res
+    assert len(ia) == len(ib) == 15 and torch.equal(fa, fb) and torch.equal(ta, tb)
+    for x, y in zip(ia, ib):
+        assert x == y
+    assert len({i["Training/qf_loss"] for i in ib}) == 15
+
+
+@pytest.mark.parametrize("Q", [1, 5])
+def test_loss_launch_with_stored_float_actions_files_its_sums(Q):
+    from torchrl_amd import _C
+    torch.manual_seed(Q)
+    B, A = 96, 6
+    q, qn = torch.randn(B, A * Q, device=DEV), torch.randn(B, A * Q, device=DEV)
+    acts = torch.randint(0, A, (B,), device=DEV)
+    rew, term = torch.randn(B, device=DEV), (torch.rand(B, device=DEV) < 0.1).float()
+    s_i, s_f = torch.zeros(3, dtype=torch.float64, device=DEV), torch.zeros(3, dtype=torch.float64, device=DEV)
+    ring = torch.zeros(4, 3, dtype=torch.float64, device=DEV)
+    counter = torch.tensor([6.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=DEV)    # 6 updates done: row 6 % 4
+    if Q == 1:
+        d_i = _C.dqn_td_loss(q, acts, qn, rew, term, 0.99, s_i)
+        d_f = _C.dqn_td_loss(q, acts.float(), qn, rew, term, 0.99, s_f, ring=(ring, counter))
+    else:
+        d_i = _C.quantile_huber(q, acts, qn, rew, term, 0.99, A, Q, s_i)
+        d_f = _C.quantile_huber(q, acts.float(), qn, rew, term, 0.99, A, Q, s_f, ring=(ring, counter))
+    assert torch.equal(d_i, d_f) and torch.equal(s_i, s_f) and torch.equal(ring[2], s_f)
+    assert bool((ring[[0, 1, 3]] == 0).all())
+    with pytest.raises(_C.TrlError):
+        _C.dqn_td_loss(q[:, :A].contiguous(), acts, qn[:, :A].contiguous(), rew, term, 0.99, s_i, ring=(ring, counter))
 
 
 @pytest.mark.parametrize("Q", [1, 8])

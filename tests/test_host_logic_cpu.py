@@ -393,6 +393,54 @@ def test_off_policy_epoch_driver_protocol():
     assert len(events) == 6
 
 
+def test_whole_epoch_hook_of_the_off_policy_driver_and_its_index_draw():
+    """`update_epoch_deferred(opt_times)`: taken when the engine accepts (no per-update sample), else the per-update loop;
+    `draw_indices` = the index sets `count` random_batch calls would draw, generator state included."""
+    import torchrl_amd  # noqa: F401
+    import gym
+    from torchrl_amd.algo.off_policy.off_rl_algo import OffRLAlgo
+    from torchrl_amd.replay_buffers import BaseReplayBuffer
+    calls, logged = [], []
+
+    class Replay:
+        def random_batch(self, batch_size, keys, out=None):
+            calls.append("sample")
+            return {}
+        def num_steps_can_sample(self): return 100
+
+    class Log:
+        def add_update_info(self, d): logged.append(d)
+
+    class Env:
+        action_space = gym.spaces.Discrete(3)
+
+    class Collector:
+        epoch_frames = 16
+
+    class Algo(OffRLAlgo):
+        accept = True
+        def update_deferred(self, batch): calls.append("one"); return len(calls)
+        def update_epoch_deferred(self, count): calls.append(("epoch", count)); return list(range(count)) if self.accept else None
+        def resolve_updates(self, handles): return [{"h": h} for h in handles]
+
+    algo = Algo(env=Env(), replay_buffer=Replay(), collector=Collector(), logger=Log(), batch_size=32, opt_times=3,
+                device="cpu")
+    algo.update_per_epoch()
+    assert calls == [("epoch", 3)] and logged == [{"h": 0}, {"h": 1}, {"h": 2}]
+    del calls[:], logged[:]
+    algo.accept = False
+    algo.update_per_epoch()
+    assert calls == [("epoch", 3), "sample", "one", "sample", "one", "sample", "one"] and len(logged) == 3
+
+    buf = BaseReplayBuffer(40 * 8, env_nums=8, device="cpu")
+    buf._size = 37
+    np.random.seed(11)
+    want = np.stack([np.random.randint(0, 37, 4) for _ in range(5)])
+    after = np.random.randint(0, 1 << 30)
+    np.random.seed(11)
+    got = buf.draw_indices(32, 5)
+    assert got.dtype == np.int64 and (got == want).all() and np.random.randint(0, 1 << 30) == after
+
 
 def test_one_block_of_host_noise_equals_per_step_draws():
     """VecOnPolicyCollector._host_noise draws the whole rollout's exploration noise in ONE torch.randn call when

@@ -43,7 +43,7 @@ def run(Q, epochs, cpu, dedup=False):
     kw = dict(qf=qf, pf=pf, qlr=2.5e-4, env=env, replay_buffer=buf, collector=col, logger=NullLog(), discount=0.99,
               num_epochs=1, batch_size=B, device=dev, save_dir=None, tau=0.005, opt_times=OPT)
     agent = QRDQN(quantile_num=Q, **kw) if Q > 1 else DQN(**kw)
-    for _ in range(2):
+    for _ in range(4):                                                   # (one by one, eager epoch, captured epoch, replayed)
         col.rollout(STEPS); agent.update_per_epoch()
     torch.cuda.synchronize()
     t0 = time.perf_counter(); tc = tu = 0.0

@@ -109,6 +109,8 @@ SIGNATURES = {
     "trl_gather_rows_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "trl_gather_rows_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64,
                                        C.c_void_p]),
+    "trl_gather_rows_multi_dyn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_int64, C.c_void_p]),
     "trl_adv_stats_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "trl_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
@@ -166,6 +168,8 @@ SIGNATURES = {
     "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int] * 4 + [C.c_void_p]),
     "trl_sac_samples_philox_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
     "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
+    "trl_moments_multi_ring_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                                             C.c_void_p]),
     "trl_synth_collect_step_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 6 +
                                    [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 6 + [C.c_void_p]),
     "trl_synth_collect_step_dyn_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int] + [C.c_void_p] * 6 +
@@ -197,6 +201,10 @@ SIGNATURES = {
                                    + [C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "trl_dqn_td_loss_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_quantile_huber_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "trl_dqn_td_loss_filed_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_quantile_huber_filed_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 +
+                                     [C.c_int, C.c_void_p, C.c_void_p]),
     "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
@@ -284,6 +292,23 @@ def dev_ptr(t, dtype=torch.float32, name="tensor", allow_none=False):
     return C.c_void_p(t.data_ptr())
 
 
+def capture_graph(launches):
+    """`launches()` captured into a HIP graph; returns (graph, what launches() returned).  The Python garbage collector is
+    paused meanwhile: a collection that frees a page-locked tensor makes torch's host allocator query its events, which
+    HIP refuses while a stream is capturing (seen as an abort of the process in the middle of a capture)."""
+    import gc
+    graph = torch.cuda.CUDAGraph()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            out = launches()
+    finally:
+        if was_enabled:
+            gc.enable()
+    return graph, out
+
+
 # ------------------------------------------------------------------ thin op wrappers
 def gae(rewards, values, terminals, time_limits, last_value, advs, rets, gamma, tau, tl_filter,
         last_terminal=None):
@@ -330,9 +355,11 @@ def gather_rows(src, row_idx, out=None):
     return out
 
 
-def gather_rows_multi(srcs, row_idx, outs):
-    """outs[k][i] = srcs[k][row_idx[i]] for every key k in one launch (all srcs share the leading row count)."""
-    n, k = int(row_idx.numel()), len(srcs)
+def gather_rows_multi(srcs, row_idx, outs, slab_counter=None, n_rows=None):
+    """outs[k][i] = srcs[k][row_idx[i]] for every key k in one launch (all srcs share the leading row count).
+    With `slab_counter` (a device float64 update counter) `row_idx` is an index SLAB {first, sets, idx[sets][n_rows]} and
+    the set (counter - first) is gathered."""
+    n, k = int(row_idx.numel()) if slab_counter is None else int(n_rows), len(srcs)
     rows = int(srcs[0].shape[0])
     if any(int(s.shape[0]) != rows for s in srcs):
         raise TrlError("gather_rows_multi: keys with different row counts")
@@ -342,6 +369,11 @@ def gather_rows_multi(srcs, row_idx, outs):
             raise TrlError("gather_rows_multi: out[%d] does not match the batch" % j)
         sp[j], dp[j] = dev_ptr(s, s.dtype, "src"), dev_ptr(o, o.dtype, "out")
         nb[j] = s[0].numel() * s.element_size()
+    if slab_counter is not None:
+        check(lib().trl_gather_rows_multi_dyn(sp, dp, nb, k, dev_ptr(row_idx, torch.int64, "slab"),
+                                              dev_ptr(slab_counter, torch.float64, "counter"), n, rows,
+                                              stream_ptr(srcs[0].device)), "trl_gather_rows_multi_dyn")
+        return outs
     check(lib().trl_gather_rows_multi(sp, dp, nb, k, dev_ptr(row_idx, torch.int64, "row_idx"), n, rows,
                                       stream_ptr(srcs[0].device)), "trl_gather_rows_multi")
     return outs
@@ -877,8 +909,10 @@ def moments(x, out4, ld=None, off=0, width=None, lo=float("-inf"), hi=float("inf
                                 dev_ptr(out4, torch.float64, "out4"), stream_ptr(x.device)), "trl_moments_f64")
 
 
-def moments_multi(specs):
-    """Several `moments` in one launch; specs: up to 4 of (x, out4, ld, off, width, lo, hi)."""
+def moments_multi(specs, ring=None):
+    """Several `moments` in one launch; specs: up to 4 of (x, out4, ld, off, width, lo, hi).
+    ring = (raw uint8 block holding every out4, ring (slots, raw bytes) uint8, device float64 update counter): the launch
+    also files `raw` into ring[(counter - 1) % slots]."""
     k = len(specs)
     xs, outs = (C.c_void_p * k)(), (C.c_void_p * k)()
     ns, lds, offs, ws = (C.c_int64 * k)(), (C.c_int * k)(), (C.c_int * k)(), (C.c_int * k)()
@@ -888,6 +922,15 @@ def moments_multi(specs):
         xs[j], outs[j] = dev_ptr(x, name="x"), dev_ptr(out4, torch.float64, "out4")
         ns[j], lds[j], offs[j], ws[j] = int(x.numel()), ld, off, (ld - off if width is None else width)
         los[j], his[j] = lo, hi
+    if ring is not None:
+        raw, slots, counter = ring
+        if slots.dim() != 2 or int(slots.shape[1]) != raw.numel() or not slots.is_contiguous():
+            raise TrlError("moments_multi: ring rows must be statistics blocks")
+        check(lib().trl_moments_multi_ring_f64(k, xs, ns, lds, offs, ws, los, his, outs, dev_ptr(raw, torch.uint8, "raw"),
+                                               int(raw.numel()), dev_ptr(slots, torch.uint8, "ring"), int(slots.shape[0]),
+                                               dev_ptr(counter, torch.float64, "counter"),
+                                               stream_ptr(specs[0][0].device)), "trl_moments_multi_ring_f64")
+        return
     check(lib().trl_moments_multi_f64(k, xs, ns, lds, offs, ws, los, his, outs, stream_ptr(specs[0][0].device)),
           "trl_moments_multi_f64")
 
@@ -1054,9 +1097,29 @@ def transpose_bpc(x, B, P, Cc, y_gate=None, gate_act=ACT_NONE):
     return out
 
 
-def dqn_td_loss(q, acts, q_next, rew, term, gamma, sums):
+def _ring_args(ring):
+    """(ring (slots, 3) float64, device update counter) -> the three C arguments; None -> no filing."""
+    if ring is None:
+        return None, 0, None
+    rows, counter = ring
+    if rows.dim() != 2 or int(rows.shape[1]) != 3 or not rows.is_contiguous():
+        raise TrlError("loss ring: (slots, 3) float64 rows")
+    return dev_ptr(rows, torch.float64, "ring"), int(rows.shape[0]), dev_ptr(counter, torch.float64, "counter")
+
+
+def dqn_td_loss(q, acts, q_next, rew, term, gamma, sums, ring=None):
+    """`acts` int64, or float32 as the replay buffer stores them (then also `ring`: see trl_dqn_td_loss_filed_f32)."""
     B, A = int(q.shape[0]), int(q.shape[1])
     dq = torch.empty_like(q)
+    if acts.dtype == torch.float32:
+        rp, slots, cp = _ring_args(ring)
+        check(lib().trl_dqn_td_loss_filed_f32(dev_ptr(q, name="q"), dev_ptr(acts, name="acts"), dev_ptr(q_next, name="q_next"),
+                                              dev_ptr(rew, name="rew"), dev_ptr(term, name="term"), float(gamma), B, A,
+                                              dev_ptr(dq, name="dq"), dev_ptr(sums, torch.float64, "sums"), rp, slots, cp,
+                                              stream_ptr(q.device)), "trl_dqn_td_loss_filed_f32")
+        return dq
+    if ring is not None:
+        raise TrlError("dqn_td_loss: the filing form takes float32 actions")
     check(lib().trl_dqn_td_loss_f32(dev_ptr(q, name="q"), dev_ptr(acts, torch.int64, "acts"),
                                     dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"), dev_ptr(term, name="term"),
                                     float(gamma), B, A, dev_ptr(dq, name="dq"), dev_ptr(sums, torch.float64, "sums"),
@@ -1064,10 +1127,20 @@ def dqn_td_loss(q, acts, q_next, rew, term, gamma, sums):
     return dq
 
 
-def quantile_huber(q, acts, q_next, rew, term, gamma, A, Q, sums):
+def quantile_huber(q, acts, q_next, rew, term, gamma, A, Q, sums, ring=None):
     B = int(q.shape[0])
     dq = torch.empty_like(q)
     ws = torch.empty(2 * B, dtype=torch.float64, device=q.device)
+    if acts.dtype == torch.float32:
+        rp, slots, cp = _ring_args(ring)
+        check(lib().trl_quantile_huber_filed_f32(dev_ptr(q, name="q"), dev_ptr(acts, name="acts"),
+                                                 dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"),
+                                                 dev_ptr(term, name="term"), float(gamma), B, A, Q, dev_ptr(dq, name="dq"),
+                                                 dev_ptr(ws, torch.float64, "ws"), dev_ptr(sums, torch.float64, "sums"),
+                                                 rp, slots, cp, stream_ptr(q.device)), "trl_quantile_huber_filed_f32")
+        return dq
+    if ring is not None:
+        raise TrlError("quantile_huber: the filing form takes float32 actions")
     check(lib().trl_quantile_huber_f32(dev_ptr(q, name="q"), dev_ptr(acts, torch.int64, "acts"),
                                        dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"),
                                        dev_ptr(term, name="term"), float(gamma), B, A, Q, dev_ptr(dq, name="dq"),

@@ -1,0 +1,77 @@
+"""Device-side pieces of the deferred-update protocol of the off-policy engines (`update_deferred` / `resolve_updates` /
+`update_epoch_deferred`, see OffRLAlgo.update_per_epoch): where the logged numbers of an update wait for their one
+read-back per epoch, and the replay indices of a whole epoch as one upload.  Neither exists in the reference, whose
+update returns Python floats one `.item()` at a time (torchrl/algo/off_policy/twin_sac_q.py:181-207, dqn.py:62-72)."""
+import numpy as np
+import torch
+
+
+class _Ref:
+    """Where a handle's statistics live: the ring, or the copy made of it before it wrapped."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+class StatRing:
+    """`slots` statistics blocks of `width` elements: update u's block is row u % slots, written on the device (by a launch
+    of the update itself that reads the device-resident update count, or by a stream-ordered copy).  The tensor's address
+    never changes -- captured graphs hold it; if `slots` unread updates are pending when more are launched, the pending
+    handles are re-pointed at a copy.
+    (Measured and dropped: the ring in pinned host memory written through its device-mapped address -- the read-back is
+    then only a stream synchronisation, but an epoch's resolve took the same 55 / 90 us (DQN / SAC), and page-locked
+    tensors that torch copies asynchronously carry allocator events whose query aborts a graph capture in progress.)"""
+
+    def __init__(self, slots, width, dtype, device):
+        self.t = torch.zeros(int(slots), int(width), dtype=dtype, device=device)
+        self._ref, self._used = _Ref(self.t), 0
+
+    @property
+    def slots(self):
+        return int(self.t.shape[0])
+
+    def make_room(self, count):
+        """Call BEFORE launching `count` more updates."""
+        if self._used + count > self.slots:
+            self._ref.t = self.t.clone()                                 # (stream-ordered: after every pending update)
+            self._ref, self._used = _Ref(self.t), 0
+
+    def handles(self, first, count):
+        """(ref, row) of updates first .. first + count - 1, just launched."""
+        self._used += count
+        return [(self._ref, (first + k) % self.slots) for k in range(count)]
+
+    def read(self, pairs):
+        """Host rows of the given (ref, row) pairs, stacked in their order: one D2H per ring (copy); the only host sync."""
+        if not pairs:
+            return torch.zeros(0, int(self.t.shape[1]), dtype=self.t.dtype).numpy()
+        if all(ref is self._ref for ref, _ in pairs):                    # the usual case: one ring, nothing wrapped
+            if len(pairs) == self._used:
+                self._used = 0                                           # everything outstanding was read
+            return self.t.cpu().numpy()[[row for _, row in pairs]]
+        rows_of = {}
+        for ref, row in pairs:
+            rows_of.setdefault(id(ref), (ref, []))[1].append(row)
+        host = {key: iter(ref.t.cpu().numpy()[rows]) for key, (ref, rows) in rows_of.items()}
+        return np.stack([next(host[id(ref)]) for ref, _ in pairs])
+
+
+class IndexSlab:
+    """The index sets of an epoch's `count` replay samples as ONE upload: {first update count, count, idx[count][nrows]}
+    (int64) at a fixed device address per (count, nrows); trl_gather_rows_multi_dyn picks the set of the device-resident
+    update count."""
+
+    def __init__(self, device):
+        self.device, self._bufs = device, {}
+
+    def upload(self, first, index_sets):
+        count, nrows = index_sets.shape
+        if (count, nrows) not in self._bufs:
+            self._bufs[(count, nrows)] = torch.zeros(2 + count * nrows, dtype=torch.int64, device=self.device)
+        slab = self._bufs[(count, nrows)]
+        host = np.empty(2 + count * nrows, dtype=np.int64)
+        host[0], host[1] = int(first), count
+        host[2:] = index_sets.reshape(-1)
+        slab.copy_(torch.from_numpy(host))                               # (pageable source: staged before the call returns)
+        return slab

@@ -23,6 +23,7 @@ import torch.optim as optim
 
 from ... import _C, dist, ops
 from ...networks import flatten_into
+from ._deferred import StatRing
 from .off_rl_algo import OffRLAlgo
 
 
@@ -235,9 +236,7 @@ class _FusedDetAC:
             self._seen.add(key)
             seq()
         else:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                seq()
+            graph, _ = _C.capture_graph(seq)
             self._graphs[key] = graph
             graph.replay()
 
@@ -297,24 +296,21 @@ class _FusedDetAC:
 
     # ---- launch now, read back later: the statistics of an update go (stream-ordered) into a slot of a device ring ----
     def _park(self, *extra):
-        if getattr(self, "_ring", None) is None or self._ring_used == self._ring.shape[0]:
-            self._ring = torch.zeros(max(64, int(getattr(self.algo, "opt_times", 1))), self._raw.numel(), dtype=torch.uint8,
-                                     device=self.dev)
-            self._ring_used = 0
-        slot, self._ring_used = self._ring_used, self._ring_used + 1
-        self._ring[slot].copy_(self._raw, non_blocking=True)
-        return (self._ring, slot) + extra
+        if getattr(self, "_ring", None) is None:
+            self._ring = StatRing(max(64, int(getattr(self.algo, "opt_times", 1))), self._raw.numel(), torch.uint8, self.dev)
+            self._parked = 0
+        self._ring.make_room(1)
+        (ref, row), = self._ring.handles(self._parked, 1)
+        self._parked += 1
+        self._ring.t[row].copy_(self._raw, non_blocking=True)
+        return (ref, row) + extra
 
     def resolve(self, handles):
         """Info dicts of enqueued updates, in order, after one D2H per ring (the only host sync)."""
-        host = {}
-        for h in handles:
-            if id(h[0]) not in host:
-                host[id(h[0])] = h[0].cpu()
-        if getattr(self, "_ring", None) is not None and all(h[0] is self._ring for h in handles) and \
-                len(handles) == self._ring_used:
-            self._ring_used = 0
-        return [h[2](host[id(h[0])][h[1]], *h[3:]) for h in handles]
+        if not handles:
+            return []
+        rows = torch.from_numpy(self._ring.read([(h[0], h[1]) for h in handles]))
+        return [h[2](raw, *h[3:]) for raw, h in zip(rows, handles)]
 
     def update_ddpg(self, batch):
         return self.resolve([self.enqueue_ddpg(batch)])[0]

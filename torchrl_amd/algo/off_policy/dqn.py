@@ -4,8 +4,8 @@
 as stored and scaled in the first im2col), the TD / quantile-Huber loss kernel returns the loss
 sums and dL/dQ, the backward pass fills one flat gradient buffer, trl_clip_adam_f32 steps it,
 trl_polyak_f32 (soft) or a full copy every `target_hard_update_period` updates the target net.
-Actions are read as (B,) or (B, 1) and cast to int64 (the reference's two classes disagree on the
-shape, its Q16).
+Actions are read as (B,) or (B, 1) floats as the replay buffer stores them and cast to an index inside the
+loss launch (the reference's two classes disagree on the shape, its Q16).
 """
 import copy
 import os
@@ -16,6 +16,7 @@ import torch.optim as optim
 
 from ... import _C, dist, ops
 from ...networks import flatten_into
+from ._deferred import IndexSlab, StatRing
 from .off_rl_algo import OffRLAlgo
 
 
@@ -65,6 +66,13 @@ class DQN(OffRLAlgo):
         self.training_update_num += 1
         return self.engine().enqueue(batch)
 
+    def update_epoch_deferred(self, count):
+        """All `count` {uniform sample -> update} pairs of an epoch as one replayed graph, or None (one by one then)."""
+        handles = self.engine().enqueue_epoch(count)
+        if handles is not None:
+            self.training_update_num += count
+        return handles
+
     def resolve_updates(self, handles):
         return self.engine().resolve(handles)
 
@@ -110,7 +118,9 @@ class _FusedDQN:
         self.sums = torch.zeros(3, dtype=torch.float64, device=self.dev)
         self.A = int(algo.env.action_space.n)
         self.workspace = None
-        self._ring, self._ring_used = None, 0
+        # update u's three sums are filed into ring row u % slots by its loss launch (one rank), or copied there
+        self._ring = StatRing(max(64, int(getattr(algo, "opt_times", 1))), 3, torch.float64, self.dev)
+        self._slab = IndexSlab(self.dev)
         self._static, self._graphs, self._seen = None, {}, set()
         self.step_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.dev)
 
@@ -119,17 +129,9 @@ class _FusedDQN:
 
     def resolve(self, handles):
         """Info dicts of enqueued updates, in order, after one D2H per ring of loss sums (the only host sync)."""
-        host = {}
-        for h in handles:
-            if id(h[0]) not in host:
-                host[id(h[0])] = h[0].cpu().numpy()
-        if self._ring is not None and all(h[0] is self._ring for h in handles) and len(handles) == self._ring_used:
-            self._ring_used = 0
-        out = []
-        for ring, slot, B, denom, Q, eps in handles:
-            s = host[id(ring)][slot]
-            out.append({'Reward_Mean': s[2] / B, 'Training/qf_loss': s[0] / denom, 'epsilon': eps, 'q_s_a': s[1] / (B * Q)})
-        return out
+        rows = self._ring.read([(h[0], h[1]) for h in handles]).tolist()
+        return [{'Reward_Mean': s[2] / B, 'Training/qf_loss': s[0] / denom, 'epsilon': eps, 'q_s_a': s[1] / (B * Q)}
+                for s, (_, _, B, denom, Q, eps) in zip(rows, handles)]
 
     def static_batch(self):
         """Fixed-address input tensors of an update (None until the first batch has shown the shapes): the replay gather
@@ -163,7 +165,8 @@ class _FusedDQN:
         algo, dev = self.algo, self.dev
         obs, nobs = st["obs"], st["next_obs"]
         rew, term = st["rewards"].view(-1), st["terminals"].view(-1)
-        acts = st["acts"].view(-1).to(torch.int64)
+        acts = st["acts"].view(-1)                                       # floats as stored; the loss launch casts at the read
+        ring = (self._ring.t, self.step_state) if dist.world_size() == 1 else None    # (else: copied after the all-reduce)
         B, A, Q = int(obs.shape[0]), self.A, int(algo.quantile_num)
         if self.is_mlp:
             q, tape = ops.mlp_forward(self.layers, obs, self.act)
@@ -172,9 +175,9 @@ class _FusedDQN:
             # online net on obs and target net on next_obs: one grouped launch per layer after the first
             (q, tape), (qn, _) = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs)
         if Q == 1:
-            dq = _C.dqn_td_loss(q, acts, qn, rew, term, algo.discount, self.sums)
+            dq = _C.dqn_td_loss(q, acts, qn, rew, term, algo.discount, self.sums, ring=ring)
         else:
-            dq = _C.quantile_huber(q, acts, qn, rew, term, algo.discount, A, Q, self.sums)
+            dq = _C.quantile_huber(q, acts, qn, rew, term, algo.discount, A, Q, self.sums, ring=ring)
         if self.is_mlp:
             need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0])) for w, _ in self.layers)
         else:
@@ -221,27 +224,72 @@ class _FusedDQN:
             self._seen.add(key)
             self._sequence(st, soft)
         else:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._sequence(st, soft)
+            graph, _ = _C.capture_graph(lambda: self._sequence(st, soft))
             self._graphs[key] = graph
             graph.replay()
 
     def enqueue(self, batch):
-        """Launch one update without waiting for it; its loss sums are copied (stream-ordered) into a ring slot."""
-        algo, dev = self.algo, self.dev
+        """Launch one update without waiting for it; its loss sums wait in their ring row for `resolve`."""
+        algo = self.algo
         st, B = self._load(batch)
-        Q = int(algo.quantile_num)
-        denom = float(B) if Q == 1 else float(B) * Q * Q
         soft = bool(algo.use_soft_update)
+        self._ring.make_room(1)
         self._run(st, soft)
         self.step_count += 1
         if not soft and algo.training_update_num % algo.target_hard_update_period == 0:
             _C.polyak(self.tflat, self.flat, 1.0)
-        B, denom = B * dist.world_size(), denom * dist.world_size()
-        if self._ring is None or self._ring_used == self._ring.shape[0]:
-            self._ring = torch.zeros(max(64, int(getattr(algo, "opt_times", 1))), 3, dtype=torch.float64, device=dev)
-            self._ring_used = 0
-        slot, self._ring_used = self._ring_used, self._ring_used + 1
-        self._ring[slot].copy_(self.sums, non_blocking=True)
-        return (self._ring, slot, B, denom, Q, algo.pf.epsilon)
+        handle = self._handles(1, B)[0]
+        if dist.world_size() > 1:
+            self._ring.t[handle[1]].copy_(self.sums, non_blocking=True)
+        return handle
+
+    def _handles(self, count, B):
+        algo, world = self.algo, dist.world_size()
+        Q = int(algo.quantile_num)
+        denom = (float(B) if Q == 1 else float(B) * Q * Q) * world
+        return [(ref, row, B * world, denom, Q, algo.pf.epsilon)
+                for ref, row in self._ring.handles(self.step_count - count, count)]
+
+    def enqueue_epoch(self, count):
+        """`count` x {uniform replay sample -> update} as ONE graph launch (see _FusedSAC.enqueue_epoch): index sets drawn on
+        the host in the reference's order and uploaded once, each update of the graph gathering the set the device-resident
+        update count selects.  None when it does not apply: several ranks, a hard target copy due inside the epoch, a
+        replay buffer that stores the sampled keys differently (frame-dedup), no update seen yet, TRL_NO_GRAPH=1,
+        TRL_DQN_EPOCH_GRAPH=0."""
+        algo = self.algo
+        buf, B, st = getattr(algo, "replay_buffer", None), int(algo.batch_size), self._static
+        soft = bool(algo.use_soft_update)
+        period, done = int(algo.target_hard_update_period), int(algo.training_update_num)
+        if buf is None or st is None or count < 1 or count > self._ring.slots or dist.world_size() != 1 or \
+                dist.collectives_active() or os.environ.get("TRL_NO_GRAPH") == "1" or \
+                os.environ.get("TRL_DQN_EPOCH_GRAPH") == "0" or not hasattr(buf, "gather_sources") or \
+                int(st["obs"].shape[0]) != B or (not soft and any((done + j) % period == 0 for j in range(1, count + 1))):
+            return None
+        keys = ("obs", "next_obs", "acts", "rewards", "terminals")
+        srcs = buf.gather_sources(keys)
+        nrows = buf._rows_per_batch(B)
+        if srcs is None or any(s.dtype != st[k].dtype or s[0].numel() * nrows != st[k].numel() for s, k in zip(srcs, keys)):
+            return None
+        key = ("epoch", count, B, nrows, tuple(s.data_ptr() for s in srcs), soft,
+               float(algo.qf_optimizer.param_groups[0]['lr']), float(algo.discount), float(algo.tau), int(algo.quantile_num))
+        if key not in self._graphs and len(self._graphs) >= 4:
+            return None
+        self._ring.make_room(count)
+        slab = self._slab.upload(self.step_count, buf.draw_indices(B, count))
+        dsts = [st[k] for k in keys]
+
+        def launches():
+            for _ in range(count):
+                _C.gather_rows_multi(srcs, slab, dsts, slab_counter=self.step_state, n_rows=nrows)
+                self._sequence(st, soft)
+        if key in self._graphs:
+            self._graphs[key].replay()
+        elif key not in self._seen:                                      # first visit eager, captured on the second
+            self._seen.add(key)
+            launches()
+        else:
+            graph, _ = _C.capture_graph(launches)
+            self._graphs[key] = graph
+            graph.replay()
+        self.step_count += count
+        return self._handles(count, B)

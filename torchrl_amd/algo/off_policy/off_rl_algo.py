@@ -42,7 +42,12 @@ class OffRLAlgo(RLAlgo):
             # sample -> update x opt_times launched back to back (the host never waits inside the loop, so the next
             # sample's index upload and launches overlap the running update); the info dicts reach the logger in the
             # reference's order after one read-back
-            pending = [deferred(self._sample()) for _ in range(self.opt_times)]
+            # (an engine with `update_epoch_deferred` takes all `opt_times` samples + updates as one replayed graph when
+            # its conditions hold -- the index sets are drawn here on the host in the same order -- else returns None)
+            whole = getattr(self, "update_epoch_deferred", None)
+            pending = whole(self.opt_times) if whole is not None else None
+            if pending is None:
+                pending = [deferred(self._sample()) for _ in range(self.opt_times)]
             for info in self.resolve_updates(pending):
                 self.logger.add_update_info(info)
         check = getattr(self.replay_buffer, "check_overrun", None)       # frame-dedup replay: a batch that asked for an

@@ -26,6 +26,7 @@ import torch.optim as optim
 
 from ... import _C, dist, ops
 from ...networks import flatten_into
+from ._deferred import IndexSlab, StatRing
 from .off_rl_algo import OffRLAlgo
 
 
@@ -94,6 +95,14 @@ class TwinSACQ(OffRLAlgo):
         self.training_update_num += 1
         return self.engine().enqueue(batch)
 
+    def update_epoch_deferred(self, count):
+        """All `count` {uniform sample -> update} pairs of an epoch as one replayed graph (None when the engine's
+        conditions for it do not hold: the caller then samples and enqueues one by one)."""
+        handles = self.engine().enqueue_epoch(count)
+        if handles is not None:
+            self.training_update_num += count
+        return handles
+
     def resolve_updates(self, handles):
         return self.engine().resolve(handles)
 
@@ -146,7 +155,9 @@ class _FusedSAC:
         self.noise_seed = 0x5AC
         self.step_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.dev)
         self._static, self._graphs, self._seen = {}, {}, set()
-        self._ring, self._ring_used = None, 0
+        # the statistics block of update u is filed into ring row u % slots by the update's last launch
+        self._ring = StatRing(max(64, int(getattr(algo, "opt_times", 1))), self._raw.numel(), torch.uint8, self.dev)
+        self._slab = IndexSlab(self.dev)
 
     def _ws(self, B):
         lib = _C.lib()
@@ -233,7 +244,8 @@ class _FusedSAC:
         inf = float("inf")
         _C.moments_multi([(head_g, self.mom[0], 2 * A, A, A, -20.0, 2.0),              # clamped log_std
                           (logp_g, self.mom[1], 1, 0, 1, -inf, inf),
-                          (head_g, self.mom[2], 2 * A, 0, A, -inf, inf)])
+                          (head_g, self.mom[2], 2 * A, 0, A, -inf, inf)],
+                         ring=(self._raw, self._ring.t, self.step_state))                # ... and files the update's numbers
 
     def _inline_noise(self):
         """Device Philox noise on a single rank whose every update so far drew its noise on the device: draw u's counters
@@ -260,9 +272,7 @@ class _FusedSAC:
             self._seen.add(key)
             self._sequence(st, soft)
         else:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._sequence(st, soft)
+            graph, _ = _C.capture_graph(lambda: self._sequence(st, soft))
             self._graphs[key] = graph
             graph.replay()
 
@@ -294,30 +304,71 @@ class _FusedSAC:
                     continue
                 make = lambda m, f: _C.philox_normal(torch.empty(m, f, device=dev), self.noise_seed, self.noise_ctr)
             st[k].copy_(dist.shard_rows_of_global(make, rows, B // rows, A, dev), non_blocking=True)
+        self._ring.make_room(1)
         self._run(st, bool(algo.use_soft_update))
         if inline:
             self.noise_ctr += 2                                          # the two draws the sampling launch made
         self.step_count += 1
         if not algo.use_soft_update and algo.training_update_num % algo.target_hard_update_period == 0:
             _C.polyak(self.tflat, self.flat[self.sizes[0]:], 1.0)
-        if self._ring is None or self._ring_used == self._ring.shape[0]:  # full: later handles go to a fresh ring
-            self._ring = torch.zeros(max(64, int(getattr(algo, "opt_times", 1))), self._raw.numel(), dtype=torch.uint8,
-                                     device=dev)
-            self._ring_used = 0
-        slot, self._ring_used = self._ring_used, self._ring_used + 1
-        self._ring[slot].copy_(self._raw, non_blocking=True)
-        return (self._ring, slot, B)
+        return self._handles(1, B)[0]
+
+    def _handles(self, count, B):
+        """Handles of the `count` updates just launched (`step_count` mirrors the device-resident count the filing launch
+        reads)."""
+        return [(ref, row, B) for ref, row in self._ring.handles(self.step_count - count, count)]
+
+    def enqueue_epoch(self, count):
+        """`count` x {uniform replay sample -> update} as ONE graph launch: the index sets are drawn on the host in the
+        order `count` random_batch calls would draw them and uploaded once; every update of the graph gathers the set
+        the device-resident update count selects (trl_gather_rows_multi_dyn), draws its own noise from that count and files
+        its statistics into its ring slot.  Returns the handles, or None when this path does not apply (host noise,
+        several ranks, hard target updates, a replay buffer that does not store the sampled keys plainly, TRL_NO_GRAPH=1,
+        TRL_SAC_EPOCH_GRAPH=0)."""
+        algo = self.algo
+        buf, B = getattr(algo, "replay_buffer", None), int(algo.batch_size)
+        if buf is None or count < 1 or count > self._ring.slots or not algo.use_soft_update or \
+                not self._inline_noise() or dist.collectives_active() or os.environ.get("TRL_NO_GRAPH") == "1" or \
+                os.environ.get("TRL_SAC_EPOCH_GRAPH") == "0" or not hasattr(buf, "gather_sources"):
+            return None
+        keys = ("obs", "next_obs", "acts", "rewards", "terminals")
+        srcs = buf.gather_sources(keys)
+        st = self.static_batch(B)
+        if srcs is None or any(s.dtype != torch.float32 or s[0].numel() * buf._rows_per_batch(B) != st[k].numel()
+                               for s, k in zip(srcs, keys)):
+            return None
+        nrows = buf._rows_per_batch(B)
+        key = ("epoch", count, B, nrows, tuple(s.data_ptr() for s in srcs), self._lrs(), algo.grad_clip, algo.tau,
+               algo.discount, bool(algo.automatic_entropy_tuning))
+        if key not in self._graphs and len(self._graphs) >= 8:
+            return None
+        self._ring.make_room(count)
+        slab = self._slab.upload(self.step_count, buf.draw_indices(B, count))
+        dsts = [st[k] for k in keys]
+
+        def launches(n):
+            for _ in range(n):
+                _C.gather_rows_multi(srcs, slab, dsts, slab_counter=self.step_state, n_rows=nrows)
+                self._sequence(st, True)
+        if key in self._graphs:
+            self._graphs[key].replay()
+        elif key not in self._seen:                                      # first visit eager, captured on the second
+            self._seen.add(key)
+            launches(count)
+        else:
+            graph, _ = _C.capture_graph(lambda: launches(count))
+            self._graphs[key] = graph
+            graph.replay()
+        self.noise_ctr += 2 * count
+        self.step_count += count
+        return self._handles(count, B)
 
     def resolve(self, handles):
         """Info dicts of enqueued updates, in order: one D2H per ring (normally one per call), the only host sync."""
-        host = {}
-        for ring, _, _ in handles:
-            if id(ring) not in host:
-                host[id(ring)] = ring.cpu()
-        if self._ring is not None and all(r is self._ring for r, _, _ in handles) and \
-                len(handles) == self._ring_used:
-            self._ring_used = 0                                          # everything outstanding was read: reuse the ring
-        return [self._info(host[id(ring)][slot], B) for ring, slot, B in handles]
+        raw = self._ring.read([(ref, row) for ref, row, _ in handles])   # (n, 160) bytes -> nested lists of Python floats:
+        parts = (raw[:, :32].view(np.float64).tolist(), raw[:, 32:128].view(np.float64).tolist(),   # one conversion, not
+                 raw[:, 128:136].view(np.float32).tolist(), raw[:, 136:148].view(np.float32).tolist())  # views per update
+        return [self._info(part, h[2]) for part, h in zip(zip(*parts), handles)]
 
     def update(self, batch):
         return self.resolve([self.enqueue(batch)])[0]
@@ -325,26 +376,22 @@ class _FusedSAC:
     def _info(self, raw, B):
         algo, A = self.algo, self.A
         Bg = B * dist.world_size()                                       # the sums were reduced over all ranks
-        sums, mom = raw[:32].view(torch.float64).numpy(), raw[32:128].view(torch.float64).view(3, 4).numpy()
-        aout, norms = raw[128:136].view(torch.float32).numpy(), raw[136:148].view(torch.float32).numpy()
+        sums, mom, aout, norms = raw                                     # 4 sums, 3 x (mean, std, max, min), (alpha, loss), 3 norms
         w_std, w_mean = algo.policy_std_reg_weight, algo.policy_mean_reg_weight
         reg = 0.0
         if w_std or w_mean:
             n = Bg * A - 1
-            ms_ls = mom[0][1] ** 2 * n / (n + 1) + mom[0][0] ** 2                     # E[x^2] from mean / unbiased std
-            ms_mu = mom[2][1] ** 2 * n / (n + 1) + mom[2][0] ** 2
+            ms_ls = mom[1] ** 2 * n / (n + 1) + mom[0] ** 2                           # E[x^2] from mean / unbiased std
+            ms_mu = mom[9] ** 2 * n / (n + 1) + mom[8] ** 2
             reg = w_std * ms_ls + w_mean * ms_mu
         info = {'Reward_Mean': sums[3] / Bg}
         if algo.automatic_entropy_tuning:
-            info["Alpha"] = float(aout[0])
-            info["Alpha_loss"] = float(aout[1])
+            info["Alpha"], info["Alpha_loss"] = aout
         info['Training/policy_loss'] = sums[2] / Bg + reg
         info['Training/qf1_loss'] = sums[0] / Bg
         info['Training/qf2_loss'] = sums[1] / Bg
         if algo.grad_clip is not None:
-            info['Training/pf_grad_norm'], info['Training/qf1_grad_norm'], info['Training/qf2_grad_norm'] = \
-                float(norms[0]), float(norms[1]), float(norms[2])
-        for key, row in (("log_std", mom[0]), ("log_probs", mom[1]), ("mean", mom[2])):
-            info[key + '/mean'], info[key + '/std'], info[key + '/max'], info[key + '/min'] = \
-                float(row[0]), float(row[1]), float(row[2]), float(row[3])
+            info['Training/pf_grad_norm'], info['Training/qf1_grad_norm'], info['Training/qf2_grad_norm'] = norms
+        for k, key in enumerate(("log_std", "log_probs", "mean")):
+            info[key + '/mean'], info[key + '/std'], info[key + '/max'], info[key + '/min'] = mom[4 * k:4 * k + 4]
         return info

@@ -334,9 +334,7 @@ class _FusedPPO:
             self._graph = None
             launch_all()
         else:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                launch_all()
+            graph, _ = _C.capture_graph(launch_all)
             self._graph, self._graph_key = graph, key
             graph.replay()
         self.step_count += K
@@ -524,9 +522,7 @@ class _GenericPPO(_FusedPPO):
             self._seen.add(key)
             launch_all()
         else:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                launch_all()
+            graph, _ = _C.capture_graph(launch_all)
             graphs[key] = graph
             graph.replay()
         self.step_count += K

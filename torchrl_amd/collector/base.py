@@ -384,10 +384,7 @@ class VecCollector(_CollectorBase):
             for _ in range(n_steps):
                 one_step()
         else:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for _ in range(n_steps):
-                    one_step()
+            graph, _ = _C.capture_graph(lambda: [one_step() for _ in range(n_steps)])
             self._step_graph, self._step_key = graph, key
             graph.replay()
         buf._advance(n_steps)

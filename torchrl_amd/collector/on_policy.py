@@ -279,10 +279,8 @@ class VecOnPolicyCollector(VecCollector):
                 st["seen"] = True
                 st["out"] = steps()
             else:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    st["out"] = steps()
-                st["graph"] = graph
+                st["graph"], st["out"] = _C.capture_graph(steps)
+                graph = st["graph"]
                 graph.replay()
             ob = st["out"]
             self.global_step += n_steps

@@ -24,17 +24,27 @@ __device__ __forceinline__ double dq_block_sum(double v, double* smem) {
 // q_s_a = Q(s)[a];  target = r + gamma (1 - d) max_a' Q'(s')[a'];  loss = mean (q_s_a - target)^2
 // dq (B, A) is zero except 2 (q_s_a - target) / B at the taken action.
 // sums (3 doubles): loss sum, q_s_a sum, reward sum.
+// Actions come as int64 (`act`) or as the floats the replay buffer stores (`act_f`, exactly one is non-null); with `ring`
+// the three sums are also filed into row (update count % slots) of a (slots, 3) ring, read back once per epoch.
+struct DqRing { double* ring; const double* step; int slots; };
+__device__ __forceinline__ void dq_file(const DqRing& r, double a, double b, double c) {
+  if (!r.ring) return;
+  const int64_t u = (int64_t)r.step[0];                                // (the optimiser step of this update comes later)
+  double* row = r.ring + 3 * (((u % r.slots) + r.slots) % r.slots);
+  row[0] = a; row[1] = b; row[2] = c;
+}
 __global__ __launch_bounds__(DQ_THREADS) void dqn_td_kernel(const float* __restrict__ q, const int64_t* __restrict__ act,
+                                                            const float* __restrict__ act_f,
                                                             const float* __restrict__ qn, const float* __restrict__ rew,
                                                             const float* __restrict__ term, float gamma, int B, int A,
-                                                            float* __restrict__ dq, double* __restrict__ sums) {
+                                                            float* __restrict__ dq, double* __restrict__ sums, DqRing ring) {
   __shared__ double smem[DQ_THREADS / 64];
   double sl = 0, sq = 0, sr = 0;
   const float inv_b = 1.0f / (float)B;
   for (int b = threadIdx.x; b < B; b += DQ_THREADS) {
     float mx = -INFINITY;
     for (int a = 0; a < A; ++a) mx = fmaxf(mx, qn[(size_t)b * A + a]);
-    const int at = (int)act[b];
+    const int at = act ? (int)act[b] : (int)act_f[b];
     const float qsa = q[(size_t)b * A + at];
     const float tgt = rew[b] + gamma * (1.0f - term[b]) * mx;
     const float e = qsa - tgt;
@@ -42,17 +52,28 @@ __global__ __launch_bounds__(DQ_THREADS) void dqn_td_kernel(const float* __restr
     sl += (double)e * e; sq += (double)qsa; sr += (double)rew[b];
   }
   sl = dq_block_sum(sl, smem); sq = dq_block_sum(sq, smem); sr = dq_block_sum(sr, smem);
-  if (threadIdx.x == 0) { sums[0] = sl; sums[1] = sq; sums[2] = sr; }
+  if (threadIdx.x == 0) { sums[0] = sl; sums[1] = sq; sums[2] = sr; dq_file(ring, sl, sq, sr); }
+}
+static int dqn_td(const float* q, const int64_t* acts, const float* acts_f, const float* q_next, const float* rewards,
+                  const float* terminals, float gamma, int B, int A, float* dq, double* sums, DqRing ring, void* stream) {
+  TRL_REQUIRE(B > 0 && A > 0, "bad sizes");
+  TRL_REQUIRE(q && (acts || acts_f) && q_next && rewards && terminals && dq && sums, "null pointer");
+  hipLaunchKernelGGL(dqn_td_kernel, dim3(1), dim3(DQ_THREADS), 0, (hipStream_t)stream, q, acts, acts_f, q_next, rewards,
+                     terminals, gamma, B, A, dq, sums, ring);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
 }
 extern "C" int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const float* q_next, const float* rewards,
                                    const float* terminals, float gamma, int B, int A, float* dq, double* sums,
                                    void* stream) {
-  TRL_REQUIRE(B > 0 && A > 0, "bad sizes");
-  TRL_REQUIRE(q && acts && q_next && rewards && terminals && dq && sums, "null pointer");
-  hipLaunchKernelGGL(dqn_td_kernel, dim3(1), dim3(DQ_THREADS), 0, (hipStream_t)stream, q, acts, q_next, rewards,
-                     terminals, gamma, B, A, dq, sums);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
+  return dqn_td(q, acts, nullptr, q_next, rewards, terminals, gamma, B, A, dq, sums, DqRing{nullptr, nullptr, 0}, stream);
+}
+extern "C" int trl_dqn_td_loss_filed_f32(const float* q, const float* acts_f, const float* q_next, const float* rewards,
+                                         const float* terminals, float gamma, int B, int A, float* dq, double* sums,
+                                         double* ring, int slots, const double* update_count, void* stream) {
+  TRL_REQUIRE(!ring || (slots > 0 && update_count), "dqn_td_loss_filed: ring without slots / counter");
+  return dqn_td(q, nullptr, acts_f, q_next, rewards, terminals, gamma, B, A, dq, sums, DqRing{ring, update_count, slots},
+                stream);
 }
 
 // ---------------------------------------------------------------- K15
@@ -62,6 +83,7 @@ extern "C" int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const fl
 // One workgroup per sample: T and theta staged in LDS, thread j owns theta_j's column of the
 // Q x Q table (Q^2 = 40 000 Huber terms per sample at Q = 200 -- VALU-bound, 1.6 KB of input).
 __global__ __launch_bounds__(DQ_THREADS) void quantile_huber_kernel(const float* __restrict__ q, const int64_t* __restrict__ act,
+                                                                    const float* __restrict__ act_f,
                                                                     const float* __restrict__ qn, const float* __restrict__ rew,
                                                                     const float* __restrict__ term, float gamma, int B, int A,
                                                                     int Q, float* __restrict__ dq,
@@ -89,7 +111,7 @@ __global__ __launch_bounds__(DQ_THREADS) void quantile_huber_kernel(const float*
     s_astar = best;
   }
   __syncthreads();
-  const int at = (int)act[b], as = s_astar;
+  const int at = act ? (int)act[b] : (int)act_f[b], as = s_astar;
   const float r = rew[b], nd = gamma * (1.0f - term[b]);
   for (int i = threadIdx.x; i < Q; i += DQ_THREADS) { T[i] = r + nd * nb[as * Q + i]; th[i] = qb[at * Q + i]; }
   for (int e = threadIdx.x; e < A * Q; e += DQ_THREADS) dq[(size_t)b * A * Q + e] = 0.0f;
@@ -115,23 +137,40 @@ __global__ __launch_bounds__(DQ_THREADS) void quantile_huber_kernel(const float*
 }
 __global__ __launch_bounds__(DQ_THREADS) void quantile_fold_kernel(const double* __restrict__ part,
                                                                    const float* __restrict__ rew, int B,
-                                                                   double* __restrict__ sums) {
+                                                                   double* __restrict__ sums, DqRing ring) {
   __shared__ double smem[DQ_THREADS / 64];
   double a = 0, c = 0, r = 0;
   for (int b = threadIdx.x; b < B; b += DQ_THREADS) { a += part[b * 2]; c += part[b * 2 + 1]; r += (double)rew[b]; }
   a = dq_block_sum(a, smem); c = dq_block_sum(c, smem); r = dq_block_sum(r, smem);
-  if (threadIdx.x == 0) { sums[0] = a; sums[1] = c; sums[2] = r; }
+  if (threadIdx.x == 0) { sums[0] = a; sums[1] = c; sums[2] = r; dq_file(ring, a, c, r); }
 }
+static int quantile_huber(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,
+                          const float* rewards, const float* terminals, float gamma, int B, int A, int Q, float* dq,
+                          double* workspace, double* sums, DqRing ring, void* stream);
 extern "C" int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* q_next, const float* rewards,
                                       const float* terminals, float gamma, int B, int A, int Q, float* dq,
                                       double* workspace /* 2B doubles */, double* sums, void* stream) {
+  return quantile_huber(q, acts, nullptr, q_next, rewards, terminals, gamma, B, A, Q, dq, workspace, sums,
+                        DqRing{nullptr, nullptr, 0}, stream);
+}
+extern "C" int trl_quantile_huber_filed_f32(const float* q, const float* acts_f, const float* q_next, const float* rewards,
+                                            const float* terminals, float gamma, int B, int A, int Q, float* dq,
+                                            double* workspace, double* sums, double* ring, int slots,
+                                            const double* update_count, void* stream) {
+  TRL_REQUIRE(!ring || (slots > 0 && update_count), "quantile_huber_filed: ring without slots / counter");
+  return quantile_huber(q, nullptr, acts_f, q_next, rewards, terminals, gamma, B, A, Q, dq, workspace, sums,
+                        DqRing{ring, update_count, slots}, stream);
+}
+static int quantile_huber(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,
+                          const float* rewards, const float* terminals, float gamma, int B, int A, int Q, float* dq,
+                          double* workspace, double* sums, DqRing ring, void* stream) {
   TRL_REQUIRE(B > 0 && A > 0 && Q > 0 && A <= 64 && Q <= 4096, "bad sizes");
-  TRL_REQUIRE(q && acts && q_next && rewards && terminals && dq && workspace && sums, "null pointer");
+  TRL_REQUIRE(q && (acts || acts_f) && q_next && rewards && terminals && dq && workspace && sums, "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(quantile_huber_kernel, dim3(B), dim3(DQ_THREADS), (2 * Q + A) * sizeof(float), s, q, acts, q_next,
-                     rewards, terminals, gamma, B, A, Q, dq, workspace);
+  hipLaunchKernelGGL(quantile_huber_kernel, dim3(B), dim3(DQ_THREADS), (2 * Q + A) * sizeof(float), s, q, acts, acts_f,
+                     q_next, rewards, terminals, gamma, B, A, Q, dq, workspace);
   TRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(quantile_fold_kernel, dim3(1), dim3(DQ_THREADS), 0, s, workspace, rewards, B, sums);
+  hipLaunchKernelGGL(quantile_fold_kernel, dim3(1), dim3(DQ_THREADS), 0, s, workspace, rewards, B, sums, ring);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }

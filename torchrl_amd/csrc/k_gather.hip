@@ -57,8 +57,16 @@ static int gather_bytes(const void* src, const int64_t* idx, void* dst, int n_ro
 // terminals with the same row index: five ~3 us dependent launches otherwise).  blockIdx.z = key.
 #define GATHER_MAX_KEYS 8
 struct GatherSet { const uint8_t* src[GATHER_MAX_KEYS]; uint8_t* dst[GATHER_MAX_KEYS]; int64_t row_bytes[GATHER_MAX_KEYS]; };
-__global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherSet g, const int64_t* __restrict__ idx, int64_t src_rows) {
+// `step` (optional): idx is then a SLAB {first update count, row sets, idx[row sets][gridDim.y]} and the row set is picked by
+// the device-resident update counter -- a captured graph of several updates gathers a different sample in each.
+__global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherSet g, const int64_t* __restrict__ idx, int64_t src_rows,
+                                                                const double* __restrict__ step) {
   const int row = blockIdx.y, key = blockIdx.z;
+  if (step) {
+    const int64_t set = (int64_t)step[0] - idx[0];
+    if (set < 0 || set >= idx[1]) return;                              // outside the slab: nothing is copied
+    idx += 2 + set * (int64_t)gridDim.y;
+  }
   const int64_t s = idx[row], nb = g.row_bytes[key];
   if (s < 0 || s >= src_rows) return;
   const uint8_t* sp = g.src[key] + s * nb;
@@ -72,8 +80,8 @@ __global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherSet g, con
     for (int64_t i = t0; i < nb; i += dt) dp[i] = sp[i];
   }
 }
-extern "C" int trl_gather_rows_multi(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
-                                     const int64_t* row_idx, int n_rows, int64_t src_rows, void* stream) {
+static int gather_multi(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
+                        const int64_t* row_idx, int n_rows, int64_t src_rows, const double* step, void* stream) {
   TRL_REQUIRE(n_keys >= 1 && n_keys <= GATHER_MAX_KEYS, "gather_rows_multi: 1..8 keys");
   TRL_REQUIRE(n_rows >= 0 && src_rows >= 0 && n_rows <= 65535, "gather_rows_multi: bad row count");
   if (n_rows == 0) return TRL_OK;
@@ -88,9 +96,20 @@ extern "C" int trl_gather_rows_multi(const void* const* src, void* const* dst, c
   int bx = (int)((widest / 16 + 255) / 256);
   const int cap = std::max(64, (4096 + n_rows - 1) / n_rows);
   bx = std::min(std::max(bx, 1), cap);
-  hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(bx, n_rows, n_keys), dim3(256), 0, (hipStream_t)stream, g, row_idx, src_rows);
+  hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(bx, n_rows, n_keys), dim3(256), 0, (hipStream_t)stream, g, row_idx,
+                     src_rows, step);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
+}
+extern "C" int trl_gather_rows_multi(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
+                                     const int64_t* row_idx, int n_rows, int64_t src_rows, void* stream) {
+  return gather_multi(src, dst, row_bytes, n_keys, row_idx, n_rows, src_rows, nullptr, stream);
+}
+extern "C" int trl_gather_rows_multi_dyn(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
+                                         const int64_t* slab, const double* update_count, int n_rows, int64_t src_rows,
+                                         void* stream) {
+  TRL_REQUIRE(update_count, "gather_rows_multi_dyn: null counter");
+  return gather_multi(src, dst, row_bytes, n_keys, slab, n_rows, src_rows, update_count, stream);
 }
 
 extern "C" int trl_gather_rows_f32(const float* src, const int64_t* row_idx, float* dst, int n_rows,

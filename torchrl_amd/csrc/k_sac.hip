@@ -489,7 +489,8 @@ extern "C" int trl_polyak_f32(float* target, const float* source, int64_t n, flo
 // ---------------------------------------------------------------- mean / unbiased std / max / min of a tensor (logging)
 #define MOM_THREADS 1024
 __device__ __forceinline__ void moments_block(const float* __restrict__ x, int64_t n, int ld, int off,
-                                              int width, float lo, float hi_, double* __restrict__ out) {
+                                              int width, float lo, float hi_, double* __restrict__ out,
+                                              double* __restrict__ out2 = nullptr) {
   // x viewed as rows of `ld` floats; statistics over columns [off, off+width) of every row.  One workgroup of 16
   // waves (fixed summation order); each thread walks (row, column) incrementally -- no division in the loop.
   __shared__ double smem[4][MOM_THREADS / 64];
@@ -514,9 +515,9 @@ __device__ __forceinline__ void moments_block(const float* __restrict__ x, int64
       s += smem[0][w]; sq += smem[1][w]; mx = fmax(mx, smem[2][w]); nmn = fmax(nmn, smem[3][w]);
     }
     const double cnt = (double)(rows * width), mean = s / cnt;
-    out[0] = mean;
-    out[1] = cnt > 1 ? sqrt(fmax((sq - s * mean) / (cnt - 1), 0.0)) : NAN;
-    out[2] = mx; out[3] = -nmn;
+    const double sd = cnt > 1 ? sqrt(fmax((sq - s * mean) / (cnt - 1), 0.0)) : NAN;
+    out[0] = mean; out[1] = sd; out[2] = mx; out[3] = -nmn;
+    if (out2) { out2[0] = mean; out2[1] = sd; out2[2] = mx; out2[3] = -nmn; }      // (the ring slot's copy)
   }
 }
 __global__ __launch_bounds__(MOM_THREADS) void moments_kernel(const float* __restrict__ x, int64_t n, int ld, int off,
@@ -527,13 +528,33 @@ __global__ __launch_bounds__(MOM_THREADS) void moments_kernel(const float* __res
 #define MOM_MAX 4
 struct MomSet { const float* x[MOM_MAX]; int64_t n[MOM_MAX]; int ld[MOM_MAX], off[MOM_MAX], width[MOM_MAX];
                 float lo[MOM_MAX], hi[MOM_MAX]; double* out[MOM_MAX]; };
-__global__ __launch_bounds__(MOM_THREADS) void moments_multi_kernel(MomSet m) {
+// `ring` (optional): the statistics block `raw` (which holds every out[k]) is also filed into slot (update count - 1) mod
+// slots of a device ring -- the last launch of an update archives its logged numbers, no copy command per update.
+struct MomRing { const uint8_t* raw; uint8_t* ring; const double* step; int raw_bytes, slots; };
+__global__ __launch_bounds__(MOM_THREADS) void moments_multi_kernel(MomSet m, MomRing r, int count) {
   const int k = blockIdx.x;
-  moments_block(m.x[k], m.n[k], m.ld[k], m.off[k], m.width[k], m.lo[k], m.hi[k], m.out[k]);
+  if (!r.ring) {
+    moments_block(m.x[k], m.n[k], m.ld[k], m.off[k], m.width[k], m.lo[k], m.hi[k], m.out[k]);
+    return;
+  }
+  const int64_t done = (int64_t)r.step[0] - 1;                         // (the step state was advanced earlier in the update)
+  uint8_t* slot = r.ring + (int64_t)(((done % r.slots) + r.slots) % r.slots) * r.raw_bytes;
+  if (k == 0)                                                          // everything earlier launches left in `raw`
+    for (int w = threadIdx.x; w < r.raw_bytes / 4; w += MOM_THREADS) {
+      const uint8_t* at = r.raw + 4 * w;
+      bool mine = true;
+      for (int j = 0; j < count; ++j) {
+        const uint8_t* o = reinterpret_cast<const uint8_t*>(m.out[j]);
+        if (at >= o && at < o + 32) mine = false;
+      }
+      if (mine) reinterpret_cast<uint32_t*>(slot)[w] = reinterpret_cast<const uint32_t*>(r.raw)[w];
+    }
+  moments_block(m.x[k], m.n[k], m.ld[k], m.off[k], m.width[k], m.lo[k], m.hi[k], m.out[k],   // this block's own four numbers
+                reinterpret_cast<double*>(slot + (reinterpret_cast<const uint8_t*>(m.out[k]) - r.raw)));
 }
-extern "C" int trl_moments_multi_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
-                                     const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
-                                     void* stream) {
+static int moments_multi(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
+                         const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
+                         MomRing ring, void* stream) {
   TRL_REQUIRE(count >= 1 && count <= MOM_MAX, "moments_multi: 1..4 statistics");
   TRL_REQUIRE(x && n && ld && off && width && clamp_lo && clamp_hi && out4, "null pointer");
   MomSet m;
@@ -543,9 +564,27 @@ extern "C" int trl_moments_multi_f64(int count, const float* const* x, const int
     m.x[k] = x[k]; m.n[k] = n[k]; m.ld[k] = ld[k]; m.off[k] = off[k]; m.width[k] = width[k];
     m.lo[k] = clamp_lo[k]; m.hi[k] = clamp_hi[k]; m.out[k] = out4[k];
   }
-  hipLaunchKernelGGL(moments_multi_kernel, dim3(count), dim3(MOM_THREADS), 0, (hipStream_t)stream, m);
+  if (ring.ring)
+    for (int k = 0; k < count; ++k) {
+      const uint8_t* o = reinterpret_cast<const uint8_t*>(out4[k]);
+      TRL_REQUIRE(o >= ring.raw && o + 32 <= ring.raw + ring.raw_bytes, "moments_multi_ring: out4 outside the statistics block");
+    }
+  hipLaunchKernelGGL(moments_multi_kernel, dim3(count), dim3(MOM_THREADS), 0, (hipStream_t)stream, m, ring, count);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
+}
+extern "C" int trl_moments_multi_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
+                                     const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
+                                     void* stream) {
+  return moments_multi(count, x, n, ld, off, width, clamp_lo, clamp_hi, out4, MomRing{nullptr, nullptr, nullptr, 0, 0}, stream);
+}
+extern "C" int trl_moments_multi_ring_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
+                                          const int* width, const float* clamp_lo, const float* clamp_hi,
+                                          double* const* out4, const void* raw, int raw_bytes, void* ring, int slots,
+                                          const double* update_count, void* stream) {
+  TRL_REQUIRE(raw && ring && update_count && raw_bytes > 0 && raw_bytes % 8 == 0 && slots > 0, "moments_multi_ring: bad ring");
+  return moments_multi(count, x, n, ld, off, width, clamp_lo, clamp_hi, out4,
+                       MomRing{(const uint8_t*)raw, (uint8_t*)ring, update_count, raw_bytes, slots}, stream);
 }
 extern "C" int trl_moments_f64(const float* x, int64_t n, int ld, int off, int width, float clamp_lo, float clamp_hi,
                                double* out4, void* stream) {

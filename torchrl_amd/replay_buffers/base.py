@@ -104,6 +104,20 @@ class BaseReplayBuffer:
                 batch[key] = self._gather(key, idx_dev, out.get(key))
         return {key: batch[key] for key in sample_key}
 
+    def draw_indices(self, batch_size, count):
+        """The row indices `count` successive `random_batch(batch_size, ...)` calls would draw, in that order from the same
+        global numpy stream: (count, batch_size // env_nums) int64 on the host (not in the reference)."""
+        # (one call: the legacy generator fills a (count, nrows) request element by element in C order, the values and the
+        # generator state afterwards are those of `count` calls of size nrows -- tests/test_host_logic_cpu.py)
+        return np.random.randint(0, self.num_steps_can_sample(), (count, self._rows_per_batch(batch_size))).astype(np.int64)
+
+    def gather_sources(self, sample_key):
+        """The stored (rows, N, ...) tensors of `sample_key` when every key is gathered by time row as stored (an update
+        engine can then gather a sample itself from inside its captured graph), else None."""
+        if not (2 <= len(sample_key) <= 8) or not all(self._plain_key(k) and hasattr(self, "_" + k) for k in sample_key):
+            return None
+        return [getattr(self, "_" + k) for k in sample_key]
+
     def _plain_key(self, key):
         """True when `_key[rows, N, ...]` is gathered by time row as stored (subclasses override for keys they keep
         in another form)."""
