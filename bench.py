@@ -32,8 +32,27 @@ FLOP_PER_SAMPLE = 3 * (11136 + 10496)
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-class NullLogger:
-    def add_update_info(self, d): pass
+class CountingLogger:
+    """Takes the per-update info dicts the way torchrl_amd.utils.Logger does between two rows -- `add_update_info(dict)`, or
+    `add_update_infos_later(resolve)` for updates that were launched but not waited for -- and counts them; `drain()` reads
+    whatever is still outstanding (`iteration` calls it once per iteration, the timed region once more before its clock
+    stops: every iteration's statistics are read inside the timed region)."""
+
+    def __init__(self):
+        self.updates, self._later = 0, []
+
+    def add_update_info(self, d):
+        self.drain()
+        self.updates += 1
+
+    def add_update_infos_later(self, resolve):
+        self._later.append(resolve)
+
+    def drain(self):
+        later, self._later = self._later, []
+        for resolve in later:
+            self.updates += len(resolve())
+
     def add_epoch_info(self, *a, **k): pass
     def log(self, *a): pass
     def finish(self): pass
@@ -62,7 +81,7 @@ def build_agent(dev, world, rank, seed=0):
                                epoch_frames=N_PER_GPU * T, max_episode_frames=1000, noise_mode="device")
     agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=OPT_EPOCHS, tau=0.95, shuffle=True,
                 entropy_coeff=0.005, discount=0.99, num_epochs=100000, batch_size=BATCH_PER_GPU, gae=True,
-                env=env, replay_buffer=buf, collector=col, logger=NullLogger(), device=dev, save_dir=None)
+                env=env, replay_buffer=buf, collector=col, logger=CountingLogger(), device=dev, save_dir=None)
     return agent, col
 
 
@@ -70,10 +89,13 @@ def iteration(agent, col, epoch):
     """One pass of the reference's loop body (torchrl/algo/rl_algo.py:111-118): `collector.train_one_epoch()` --
     the rollout plus the per-epoch read-back of the epoch reward and the finished-episode list
     (collector/on_policy.py:277-286 here) -- then `update_per_epoch()` = GAE + opt_epochs x minibatch updates with one
-    host read of the update statistics."""
+    host read of the update statistics.  That read is pipelined by one iteration, as in RLAlgo.train with the package's
+    Logger (the dicts are taken when the next log row needs them): the update is launched, and its 40 info dicts are read
+    and assembled while the NEXT rollout runs on the device instead of while the device idles."""
     collected = col.train_one_epoch()
+    agent.logger.drain()                          # the previous update's statistics, read while this rollout runs
     agent.current_epoch = epoch
-    agent.update_per_epoch()
+    agent.update_per_epoch()                      # launched; its statistics are read in the next iteration (or at the end)
     return len(collected["train_rewards"]), collected["train_epoch_reward"]   # consumed where RLAlgo.train consumes it
 
 
@@ -404,11 +426,15 @@ def main():
     if dist.initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    agent.logger.drain()
+    agent.logger.updates = 0
     t0 = time.perf_counter()
     marks = []
     for e in range(args.steps):
         iteration(agent, col, args.warmup + e)
         marks.append(time.perf_counter())                              # (every iteration ends in a host wait already)
+    agent.logger.drain()                                               # the last iteration's update statistics
+    infos_read = agent.logger.updates
     torch.cuda.synchronize()
     if dist.initialized():
         torch.distributed.barrier()
@@ -458,6 +484,9 @@ def main():
                    "envs_per_gpu": N_PER_GPU, "rollout_steps": T, "batch_per_gpu": BATCH_PER_GPU,
                    "opt_epochs": OPT_EPOCHS, "exploration_noise": "device Philox4x32-10",
                    "setup_iterations": setup,
+                   "update_infos_read_in_timed_region": infos_read,
+                   "host_pipeline": "the info dicts of iteration i's updates are read while iteration i+1's rollout runs "
+                                    "(the last ones before the clock stops); TRL_EAGER_UPDATE_INFOS=1 reads them in place",
                    "parallelism": "env-sharded dp%d, gradient SUM %s" % (
                        world, "inside the fold/clip/Adam launch over peer-mapped xGMI buffers" if dist.peer_ready()
                        else ("by RCCL all-reduce" if dist.collectives_active() else "not needed (one rank)"))},

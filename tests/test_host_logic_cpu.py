@@ -132,6 +132,32 @@ def test_args_params_logger(tmp_path):
         Logger("exp", "SynthHalfCheetah-v0", 0, dict(params), str(tmp_path), overwrite=False)
 
 
+def test_logger_takes_deferred_update_infos_in_order(tmp_path):
+    """Logger.add_update_infos_later: dicts of launched-but-not-awaited updates are taken when the next dict arrives or the
+    next row is written, in arrival order; the row equals the one the immediate calls give."""
+    from torchrl_amd.utils import Logger
+    rows = []
+    for deferred in (False, True):
+        log = Logger("exp%d" % deferred, "Env-v0", 0, {}, log_dir=str(tmp_path), overwrite=True)
+        a, b, c = [{"x": 1.0, "y": 2.0}, {"x": 3.0, "y": 0.0}], [{"x": 5.0, "y": 1.0}], {"x": -1.0, "y": 4.0}
+        calls = []
+        if deferred:
+            log.add_update_infos_later(lambda: calls.append("a") or a)
+            log.add_update_infos_later(lambda: calls.append("b") or b)
+            assert calls == [] and log.update_count == 0
+            log.add_update_info(c)
+            assert calls == ["a", "b"] and log.stored_infos["x"] == [1.0, 3.0, 5.0, -1.0]
+            log.add_update_infos_later(lambda: calls.append("a2") or a)
+        else:
+            for d in a + b + [c] + a:
+                log.add_update_info(d)
+        log.add_epoch_info(0, 10, 1.0, {"r": 1.0})
+        assert log.update_count == 6 and log.stored_infos == {}
+        rows.append(open(log.csv_file_path).read().splitlines())
+        log.finish()
+    assert rows[0][0] == rows[1][0] and rows[0][1].split(",")[3:] == rows[1][1].split(",")[3:]
+
+
 def test_linear_lr_schedule_and_param_copy():
     from torchrl.algo import utils as atu
     lin = torch.nn.Linear(3, 2)

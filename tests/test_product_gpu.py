@@ -195,6 +195,42 @@ def test_epoch_result_read_back_on_first_access_equals_the_immediate_one(monkeyp
     assert want == got == small and torch.equal(pw, pg) and torch.equal(pw, ps)
 
 
+def test_update_infos_taken_later_equal_the_ones_read_in_place(monkeypatch):
+    """PPO.update_per_epoch with a logger that accepts `add_update_infos_later`: the update is launched and its info dicts
+    are assembled when asked for -- by the logger, or by the engine's next run before it reuses the host twin of the
+    statistics -- with the next rollout already launched in between; same dicts in the same order, same parameters."""
+    class Later:
+        def __init__(self): self.infos, self.later, self.calls = [], [], 0
+        def add_update_info(self, d): self.drain(); self.infos.append(dict(d))
+        def add_update_infos_later(self, resolve): self.calls += 1; self.later.append(resolve)
+        def drain(self):
+            later, self.later = self.later, []
+            for r in later:
+                self.infos.extend(dict(d) for d in r())
+        def add_epoch_info(self, *a, **k): pass
+        def log(self, *a): pass
+
+    def run(deferred):
+        torch.manual_seed(0)
+        monkeypatch.setenv("TRL_EAGER_UPDATE_INFOS", "0" if deferred else "1")
+        pf, vf, env, buf, col, agent, logger = build(None, "", 64, 16, 5, 1000, 256, 3, noise_mode="device")
+        log = agent.logger = Later()
+        for epoch in range(4):
+            col.train_one_epoch()
+            np.random.seed(epoch)
+            agent.current_epoch = epoch
+            agent.update_per_epoch()
+            if deferred and epoch == 1:
+                log.drain()                                                 # the logger asks first ...
+        if deferred:                                                        # ... or the engine did, at its next run
+            assert log.calls == 4 and len(log.infos) == 2 * 2 * 4 and agent.training_update_num == 4 * 2 * 4
+            assert agent.engine()._pending is not None
+        log.drain()
+        return log.infos, pf.flat_params().cpu().clone()
+    (want, pw), (got, pg) = run(False), run(True)
+    assert len(want) == 4 * 2 * 4 and want == got and torch.equal(pw, pg)
+
+
 def test_example_script_runs_unchanged_api(tmp_path):
     """The example mirrors the reference script's wiring through the `torchrl` alias package."""
     cfg = tmp_path / "ppo_small.json"

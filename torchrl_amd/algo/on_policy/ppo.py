@@ -90,7 +90,16 @@ class PPO(A2C):
             self.engine().sync_target_pf()                             # target_pf <- pf (utils.py:23-26), one D2D copy
             if not fresh:
                 self._fill_old_logp()
-        infos = self.engine().run(tensors, row_idx, buf.env_nums, pre=device_prologue, pre_key=(fresh, self.gae))
+        eng = self.engine()
+        later = getattr(self.logger, "add_update_infos_later", None)
+        if later is not None and getattr(eng, "defers", False) and os.environ.get("TRL_EAGER_UPDATE_INFOS") != "1":
+            # launched, not awaited: the logger resolves the statistics at its next row (or the engine at its next run,
+            # under the next rollout's shadow) -- between two iterations the device never waits for the host
+            pending = eng.run(tensors, row_idx, buf.env_nums, pre=device_prologue, pre_key=(fresh, self.gae), defer=True)
+            self.training_update_num += len(pending)
+            later(pending.resolve)
+            return
+        infos = eng.run(tensors, row_idx, buf.env_nums, pre=device_prologue, pre_key=(fresh, self.gae))
         self.training_update_num += len(infos)
         for info in infos:
             self.logger.add_update_info(info)
@@ -205,9 +214,15 @@ class _FusedPPO:
             self._hyper_host[0], self._hyper_host[1] = hyper
             self.red_ws[2:4].copy_(self._hyper_host, non_blocking=True)
 
-    def run(self, t, row_idx, N, pre=None, pre_key=None):
+    defers = True                                                      # run(..., defer=True) is implemented
+
+    def run(self, t, row_idx, N, pre=None, pre_key=None, defer=False):
         """t: dict of (rows, N, feat) device tensors; row_idx: (K, rows_mb) host int64.
         Runs K minibatch updates back to back; returns K info dicts (one host sync at the end).
+        `defer=True`: returns a `_PendingInfos` right after the launches instead -- the wait for the statistics and the
+        assembly of the K dicts happen when somebody asks for them (the logger at its next row) or at the start of the
+        next `run`, by which time the next rollout is already running on the device: the host never idles the GPU
+        between two iterations.
         `pre` (optional): a callable that enqueues device work which must precede the updates (PPO: last value + GAE
         scan, target_pf copy); it becomes part of the same launch sequence.
         Single process: the whole sequence -- `pre`, the statistics memset, the advantage statistics and the
@@ -220,6 +235,10 @@ class _FusedPPO:
         world = dist.world_size()
         n_local = rows_mb * N
         n_global = float(n_local * world)
+        last = getattr(self, "_pending", None)
+        if last is not None:                                           # its statistics still sit in the host twin this
+            last.resolve()                                             # run is about to reuse
+            self._pending = None
         idx_dev, stats = self._buffers(K, rows_mb)
         self._idx_host.numpy()[:] = row_idx.reshape(-1)
         idx_dev.copy_(self._idx_host, non_blocking=True)
@@ -340,15 +359,23 @@ class _FusedPPO:
         self.step_count += K
         dist.reduce_info_(info)
         self._stats_host.copy_(stats, non_blocking=True)
+        landed = torch.cuda.Event()
+        landed.record()
         for s in self._opt_steps:                                      # host bookkeeping under the device's shadow
             s.fill_(float(self.step_count))
-        torch.cuda.current_stream(dev).synchronize()                   # the only host wait of the update
-        if xrank:
-            dist.check_comm()                                          # a rank that never delivered: raise, do not hang
         host = self._stats_host
         make = self._infos_a2c if loss_mode == _C.LOSS_A2C else self._infos
-        return make(host[:4 * K].view(K, 4).numpy(), host[4 * K:28 * K].view(K, 24).numpy(),
-                    host[28 * K:].view(torch.float32).view(K, 2).numpy(), n_global)
+
+        def build():
+            if xrank:
+                dist.check_comm()                                      # a rank that never delivered: raise, do not hang
+            return make(host[:4 * K].view(K, 4).numpy(), host[4 * K:28 * K].view(K, 24).numpy(),
+                        host[28 * K:].view(torch.float32).view(K, 2).numpy(), n_global)
+        pending = _PendingInfos(K, landed, build)
+        if defer:
+            self._pending = pending
+            return pending
+        return pending.resolve()                                       # the only host wait of the update
 
     def _infos_a2c(self, raw, info, norms, n):
         """The info dict of A2C.update (a2c.py:86-105); `std` is (B, A) there, each dim repeated B times."""
@@ -386,6 +413,23 @@ class _FusedPPO:
         return [dict(zip(keys, row)) for row in table]
 
 
+class _PendingInfos:
+    """The K info dicts of a launched update sequence: `resolve()` waits for the statistics' D2H copy (an event, not the
+    whole stream) and assembles them, once."""
+
+    def __init__(self, count, landed, build):
+        self.count, self._landed, self._build, self._infos = count, landed, build, None
+
+    def __len__(self):
+        return self.count
+
+    def resolve(self):
+        if self._infos is None:
+            self._landed.synchronize()
+            self._infos, self._build = self._build(), None
+        return self._infos
+
+
 def make_engine(algo):
     """The fused engine when the networks have the shape its kernels are instantiated for, the generic one otherwise."""
     pf, vf = algo.pf, algo.vf
@@ -398,6 +442,7 @@ def make_engine(algo):
 
 
 class _GenericPPO(_FusedPPO):
+    defers = False                                                     # (its run returns the dicts)
     """PPO / A2C minibatch loop for ARBITRARY MLP shapes (any observation / action size, width, depth): the layers run
     on the generic dense-layer kernels (k_gemm.hip, through ops.mlp_forward / mlp_backward), the loss half on
     trl_ppo_generic_losses_f32, clip + Adam on trl_clip_adam_f32.  Same interface, statistics block and info dicts

@@ -59,6 +59,7 @@ class Logger:
         self.csv_file_path = os.path.join(self.work_dir, 'log.csv')
         self.update_count = 0
         self.stored_infos = {}
+        self._later = []
         if self.is_writer:
             with open(os.path.join(self.work_dir, 'params.json'), 'w') as f:
                 json.dump(_jsonable(params), f, indent=2)
@@ -79,12 +80,28 @@ class Logger:
         self.logger.info(info)
 
     def add_update_info(self, infos):
+        self._drain()                                                    # (keeps the order of arrival)
         for key, value in infos.items():
             self.stored_infos.setdefault(key, []).append(value)
         self.update_count += 1
 
+    def add_update_infos_later(self, resolve):
+        """Not in the reference: `resolve()` returns the info dicts of updates that have been launched on the device but
+        not waited for; they are taken (in order) when the next row is written or the next dict arrives.  The epoch
+        loop can then launch the next rollout before the update's statistics have come back."""
+        self._later.append(resolve)
+
+    def _drain(self):
+        later, self._later = self._later, []
+        for resolve in later:
+            for infos in resolve():
+                for key, value in infos.items():
+                    self.stored_infos.setdefault(key, []).append(value)
+                self.update_count += 1
+
     def _update_statistics(self):
         """[(name, {Mean, Std, Max, Min})] of every scalar logged by add_update_info since the last epoch row."""
+        self._drain()
         out = []
         for key, values in self.stored_infos.items():
             arr = np.asarray(values, dtype=np.float64)
