@@ -62,6 +62,47 @@ def test_sac_epoch_as_one_graph_equals_sample_and_enqueue_one_by_one(monkeypatch
     assert len({i["Training/qf1_loss"] for i in ib}) == 20
 
 
+class _Later(_Rec):
+    """A logger that takes launched-but-not-awaited updates (as torchrl_amd.utils.Logger does)."""
+    def __init__(self): super().__init__(); self.later = []
+    def add_update_info(self, d): self.drain(); self.infos.append(dict(d))
+    def add_update_infos_later(self, resolve): self.later.append(resolve)
+    def drain(self):
+        later, self.later = self.later, []
+        for resolve in later:
+            self.infos.extend(dict(d) for d in resolve())
+
+
+@pytest.mark.parametrize("noise", ["device", "host"])
+def test_off_policy_epochs_without_a_host_wait_equal_the_waiting_loop(noise, monkeypatch):
+    """RLAlgo.train's order -- collect, update, look at the collector's result -- with the collector's result read on first
+    access and the update's info dicts taken later by the logger: three epochs are launched with the only waits being the
+    looks at the (already finished) rollout; same episode returns, info dicts and parameters as the loop that reads
+    everything back in place."""
+    from test_fullsize_offpolicy_gpu import build_cfg3
+
+    def run(lazy):
+        monkeypatch.setenv("TRL_EAGER_EPOCH_RESULT", "0" if lazy else "1")
+        monkeypatch.setenv("TRL_EAGER_UPDATE_INFOS", "0" if lazy else "1")
+        pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=64)
+        agent.noise_mode = col.noise_mode = noise
+        log = agent.logger = _Later()
+        agent.opt_times = 3
+        torch.manual_seed(5); np.random.seed(9)
+        out = []
+        for _ in range(4):
+            res = col.train_one_epoch()
+            assert isinstance(res, dict) != lazy
+            agent.update_per_epoch()
+            assert bool(log.later) == lazy
+            out.append((list(res["train_rewards"]), res["train_epoch_reward"]))
+        log.drain()
+        eng = agent.engine()
+        return out, log.infos, eng.flat.cpu().clone(), eng.tflat.cpu().clone()
+    (ra, ia, fa, ta), (rb, ib, fb, tb) = run(False), run(True)
+    assert len(ra[0][0]) > 0 and ra == rb and len(ia) == 12 and ia == ib and torch.equal(fa, fb) and torch.equal(ta, tb)
+
+
 def test_sac_epoch_graph_is_declined_when_its_conditions_do_not_hold(monkeypatch):
     from test_fullsize_offpolicy_gpu import build_cfg3
     pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=64)

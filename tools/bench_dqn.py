@@ -15,8 +15,16 @@ N, ROWS, B, STEPS, OPT, A = 512, 195, 512, 8, 8, 6
 CONVS = [[16, [8, 8], [4, 4], [0, 0]], [32, [4, 4], [2, 2], [0, 0]], [64, [3, 3], [1, 1], [0, 0]]]
 
 
-class NullLog:
-    def add_update_info(self, d): pass
+class CountingLog:
+    """Takes the info dicts as torchrl_amd.utils.Logger does between two rows (now, or `later` for updates that were
+    launched but not waited for) and counts them; `drain()` reads what is outstanding."""
+    def __init__(self): self.updates, self._later = 0, []
+    def add_update_info(self, d): self.drain(); self.updates += 1
+    def add_update_infos_later(self, resolve): self._later.append(resolve)
+    def drain(self):
+        later, self._later = self._later, []
+        for resolve in later:
+            self.updates += len(resolve())
     def add_epoch_info(self, *a, **k): pass
     def log(self, *a): pass
     def finish(self): pass
@@ -40,21 +48,35 @@ def run(Q, epochs, cpu, dedup=False):
     buf = MemoryEfficientReplayBuffer(ROWS * N, env_nums=N, min_episode_frames=999) if dedup else BaseReplayBuffer(ROWS * N, env_nums=N)
     col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=N * STEPS,
                        max_episode_frames=999)
-    kw = dict(qf=qf, pf=pf, qlr=2.5e-4, env=env, replay_buffer=buf, collector=col, logger=NullLog(), discount=0.99,
+    kw = dict(qf=qf, pf=pf, qlr=2.5e-4, env=env, replay_buffer=buf, collector=col, logger=CountingLog(), discount=0.99,
               num_epochs=1, batch_size=B, device=dev, save_dir=None, tau=0.005, opt_times=OPT)
     agent = QRDQN(quantile_num=Q, **kw) if Q > 1 else DQN(**kw)
     for _ in range(4):                                                   # (one by one, eager epoch, captured epoch, replayed)
         col.rollout(STEPS); agent.update_per_epoch()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter(); tc = tu = 0.0
+    log = agent.logger
+    log.drain(); torch.cuda.synchronize()
+    # (1) the two phases timed apart: a host wait after each (the update window includes reading its info dicts)
+    tc = tu = 0.0
     for _ in range(epochs):
         a = time.perf_counter(); col.rollout(STEPS); torch.cuda.synchronize()
-        b = time.perf_counter(); agent.update_per_epoch(); torch.cuda.synchronize()
+        b = time.perf_counter(); agent.update_per_epoch(); log.drain(); torch.cuda.synchronize()
         tc += b - a; tu += time.perf_counter() - b
+    # (2) whole epochs in RLAlgo.train's order (rl_algo.py:111-118): collect, update, then look at the collector's result;
+    # the update's info dicts are read when the logger would need them (here: one epoch later), nothing else waits
+    log.updates = 0
+    t0 = time.perf_counter(); seen = 0
+    for _ in range(epochs):
+        res = col.train_one_epoch()
+        log.drain()
+        agent.update_per_epoch()
+        seen += len(res["train_rewards"])
+    log.drain(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    assert log.updates == epochs * OPT
     out = {"workload": "%s cfg5: %d envs, 84x84x4 u8 frames, %d-row replay, B=%d, conv 16/32/64 + fc512%s"
                        % ("QRDQN" if Q > 1 else "DQN", N, ROWS, B, ", Q=%d" % Q if Q > 1 else ""),
-           "env_steps_per_s": epochs * N * STEPS / el, "updates_per_s": epochs * OPT / tu,
+           "env_steps_per_s": epochs * N * STEPS / el,
+           "env_steps_per_s_phases_timed_apart": epochs * N * STEPS / (tc + tu), "updates_per_s": epochs * OPT / tu,
            "ms_per_update": 1e3 * tu / (epochs * OPT), "ms_per_vector_step": 1e3 * tc / (epochs * STEPS),
            "update_gflop": 38e-3 * B, "replay": "frame-dedup" if dedup else "plain",
            "replay_frame_bytes": int(buf._stream.numel()) if dedup else int(buf._obs.numel() + buf._next_obs.numel())}

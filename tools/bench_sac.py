@@ -16,8 +16,16 @@ sys.path.insert(0, REPO)
 N, ROWS, B, H, STEPS, OPT = 1024, 976, 4096, 256, 16, 16
 
 
-class NullLog:
-    def add_update_info(self, d): pass
+class CountingLog:
+    """Takes the info dicts as torchrl_amd.utils.Logger does between two rows (now, or `later` for updates that were
+    launched but not waited for) and counts them; `drain()` reads what is outstanding."""
+    def __init__(self): self.updates, self._later = 0, []
+    def add_update_info(self, d): self.drain(); self.updates += 1
+    def add_update_infos_later(self, resolve): self._later.append(resolve)
+    def drain(self):
+        later, self._later = self._later, []
+        for resolve in later:
+            self.updates += len(resolve())
     def add_epoch_info(self, *a, **k): pass
     def log(self, *a): pass
     def finish(self): pass
@@ -47,20 +55,34 @@ def main():
                        max_episode_frames=999, noise_mode="device")
     agent = TwinSACQ(pf=pf, qf1=qf1, qf2=qf2, plr=3e-4, qlr=3e-4, policy_std_reg_weight=0, policy_mean_reg_weight=0,
                      automatic_entropy_tuning=True, noise_mode="device", env=env, replay_buffer=buf, collector=col,
-                     logger=NullLog(), discount=0.99, num_epochs=1, batch_size=B, device=dev, save_dir=None, tau=0.005,
+                     logger=CountingLog(), discount=0.99, num_epochs=1, batch_size=B, device=dev, save_dir=None, tau=0.005,
                      opt_times=OPT)
+    log = agent.logger
     for _ in range(3):
         col.rollout(STEPS); agent.update_per_epoch()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter(); tc = tu = 0.0
+    log.drain(); torch.cuda.synchronize()
+    # (1) the two phases timed apart: a host wait after each (the update window includes reading its info dicts)
+    tc = tu = 0.0
     for _ in range(args.epochs):
         a = time.perf_counter(); col.rollout(STEPS); torch.cuda.synchronize()
-        b = time.perf_counter(); agent.update_per_epoch(); torch.cuda.synchronize()
+        b = time.perf_counter(); agent.update_per_epoch(); log.drain(); torch.cuda.synchronize()
         tc += b - a; tu += time.perf_counter() - b
+    # (2) whole epochs in RLAlgo.train's order (rl_algo.py:111-118): collect, update, then look at the collector's result;
+    # the update's info dicts are read when the logger would need them (here: one epoch later), nothing else waits
+    log.updates = 0
+    t0 = time.perf_counter(); seen = 0
+    for _ in range(args.epochs):
+        res = col.train_one_epoch()
+        log.drain()
+        agent.update_per_epoch()
+        seen += len(res["train_rewards"])
+    log.drain(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    assert log.updates == args.epochs * OPT
     out = {"workload": "TwinSACQ cfg3: %d envs, %d-row replay, B=%d, MLP %dx%d relu, %d steps + %d updates / epoch"
                        % (N, ROWS, B, H, H, STEPS, OPT),
-           "env_steps_per_s": args.epochs * N * STEPS / el, "updates_per_s": args.epochs * OPT / tu,
+           "env_steps_per_s": args.epochs * N * STEPS / el,
+           "env_steps_per_s_phases_timed_apart": args.epochs * N * STEPS / (tc + tu), "updates_per_s": args.epochs * OPT / tu,
            "ms_per_update": 1e3 * tu / (args.epochs * OPT), "ms_per_vector_step": 1e3 * tc / (args.epochs * STEPS)}
     if args.cpu:
         base = cpu_baseline_via_bench("sac")

@@ -8,6 +8,8 @@ L_pi = -mean(log pi(a|s) * adv_normalised) - c_ent * mean(ent), L_v = MSE(V(s), 
 clip_grad_norm_(0.5) + Adam for each net.  `update_per_epoch` keeps the reference's loop
 (on_rl_algo.py:35-40: one pass of `one_iteration` minibatches) but runs it through the minibatch row
 indices on the device-resident buffer instead of materialising batches."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -45,7 +47,21 @@ class A2C(OnRLAlgo):
         row_idx = buf.epoch_row_indices(self.batch_size, self.shuffle)      # one pass (on_rl_algo.py:37-40)
         tensors = {"obs": buf._obs, "acts": buf._acts, "advs": buf._advs, "rets": buf._estimate_returns,
                    "old_values": None, "old_logp": None}
-        infos = self.engine().run(tensors, row_idx, buf.env_nums)
+        self._run_and_log(tensors, row_idx, buf.env_nums)
+
+    def _run_and_log(self, tensors, row_idx, n_envs, **prologue):
+        """The epoch's minibatch updates through the engine and their info dicts to the logger.  With a logger that takes
+        `add_update_infos_later` and the fused engine the updates are launched, not awaited: the logger resolves the
+        statistics at its next row (or the engine at its next run, under the next rollout's shadow) -- between two
+        iterations the device never waits for the host (TRL_EAGER_UPDATE_INFOS=1: read in place)."""
+        eng = self.engine()
+        later = getattr(self.logger, "add_update_infos_later", None)
+        if later is not None and getattr(eng, "defers", False) and os.environ.get("TRL_EAGER_UPDATE_INFOS") != "1":
+            pending = eng.run(tensors, row_idx, n_envs, defer=True, **prologue)
+            self.training_update_num += len(pending)
+            later(pending.resolve)
+            return
+        infos = eng.run(tensors, row_idx, n_envs, **prologue)
         self.training_update_num += len(infos)
         for info in infos:
             self.logger.add_update_info(info)

@@ -90,19 +90,7 @@ class PPO(A2C):
             self.engine().sync_target_pf()                             # target_pf <- pf (utils.py:23-26), one D2D copy
             if not fresh:
                 self._fill_old_logp()
-        eng = self.engine()
-        later = getattr(self.logger, "add_update_infos_later", None)
-        if later is not None and getattr(eng, "defers", False) and os.environ.get("TRL_EAGER_UPDATE_INFOS") != "1":
-            # launched, not awaited: the logger resolves the statistics at its next row (or the engine at its next run,
-            # under the next rollout's shadow) -- between two iterations the device never waits for the host
-            pending = eng.run(tensors, row_idx, buf.env_nums, pre=device_prologue, pre_key=(fresh, self.gae), defer=True)
-            self.training_update_num += len(pending)
-            later(pending.resolve)
-            return
-        infos = eng.run(tensors, row_idx, buf.env_nums, pre=device_prologue, pre_key=(fresh, self.gae))
-        self.training_update_num += len(infos)
-        for info in infos:
-            self.logger.add_update_info(info)
+        self._run_and_log(tensors, row_idx, buf.env_nums, pre=device_prologue, pre_key=(fresh, self.gae))
 
     # ---- single minibatch (reference entry point) ----
     def update(self, batch):

@@ -17,43 +17,13 @@ Exploration noise:
 """
 import copy
 import os
-from collections.abc import Mapping
 
 import numpy as np
 import torch
 
 from .. import _C
 from .. import dist
-from .base import VecCollector, BaseCollector
-
-
-class _EpochResult(Mapping):
-    """train_one_epoch's result, read back when first looked at (see VecOnPolicyCollector.train_one_epoch)."""
-
-    def __init__(self, col, event):
-        self._col, self._event, self._data = col, event, None
-
-    def resolve(self):
-        if self._data is None:
-            col = self._col
-            self._event.synchronize()
-            h = col._hdr_host
-            col.train_epoch_reward, cnt = float(h[0]), int(h[1:].view(torch.int32)[0])
-            col._rendezvous_check()
-            if cnt <= col.SPECULATIVE_ROWS:                                 # everything is already on the host
-                log = col._ep_log_host[:cnt].numpy().copy()
-                log = log[np.lexsort((log[:, 1], log[:, 0]))] if cnt else np.zeros((0, 3), dtype=np.float32)
-            else:
-                log = col._finished_episodes(cnt)
-            col.train_rews = list(log[:, 2])
-            self._data = {'train_rewards': col.train_rews, 'train_epoch_reward': col.train_epoch_reward}
-            if col._pending is self:
-                col._pending = None
-        return self._data
-
-    def __getitem__(self, key): return self.resolve()[key]
-    def __iter__(self): return iter(self.resolve())
-    def __len__(self): return len(self.resolve())
+from .base import VecCollector, BaseCollector, _EpochResult
 
 
 class VecOnPolicyCollector(VecCollector):
@@ -309,39 +279,6 @@ class VecOnPolicyCollector(VecCollector):
         self._launch(self.env, n_steps, True, False, noise)
         self.global_step += n_steps
         self.current_ob = self.env.cur_obs
-
-    SPECULATIVE_ROWS = 4096             # episode-log rows copied along with the header before their count is known
-
-    def train_one_epoch(self):
-        """Returns the reference's {'train_rewards', 'train_epoch_reward'} (on_policy.py:277-286) as a mapping that is
-        read back on FIRST ACCESS: the header and the head of the episode log are copied to page-locked memory behind the
-        rollout in stream order, so a caller that launches the update before looking at the result (RLAlgo.train does)
-        never leaves the GPU idle for the read-back.  The next rollout resolves a result nobody looked at."""
-        self._resolve_pending()
-        self.rollout(self.sample_epoch_frames)
-        if os.environ.get("TRL_EAGER_EPOCH_RESULT") == "1" or self._ep_log_host is None:
-            return self._epoch_result_now()
-        if getattr(self, "_hdr_host", None) is None:
-            self._hdr_host = torch.zeros(2, dtype=torch.float64).pin_memory()
-        k = self.SPECULATIVE_ROWS
-        self._hdr_host.copy_(self._hdr, non_blocking=True)
-        self._ep_log_host[:k].copy_(self._ep_log[:k], non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(self._hdr.device))
-        self._pending = _EpochResult(self, done)
-        return self._pending
-
-    def _resolve_pending(self):
-        pending = getattr(self, "_pending", None)
-        if pending is not None:
-            pending.resolve()
-
-    def _epoch_result_now(self):
-        self.train_epoch_reward, cnt = self._read_header()                # one 16-byte D2H per epoch ...
-        self._rendezvous_check()
-        log = self._finished_episodes(cnt)                                 # ... plus the episode log when any ended
-        self.train_rews = list(log[:, 2])                            # np.float32 scalars
-        return {'train_rewards': self.train_rews, 'train_epoch_reward': self.train_epoch_reward}
 
     def _rendezvous_check(self):
         if getattr(self, "_check_rendezvous", False):
