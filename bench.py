@@ -389,6 +389,7 @@ def main():
         try:
             for e in range(3):
                 iteration(agent, col, e)
+                agent.logger.drain()                                      # (check_comm runs where the statistics are read)
                 torch.cuda.synchronize()
         except Exception as exc:                                          # noqa: BLE001 -- anything: fall back, loudly
             log("peer transport failed in the first iterations: %r" % (exc,))

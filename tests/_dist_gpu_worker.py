@@ -15,8 +15,15 @@ N_TOTAL, T, ROWS_MB, EPOCHS, HORIZON, MAX_FRAMES = 64, 16, 4, 3, 12, 9
 
 
 class Log:
-    def __init__(self): self.infos = []
-    def add_update_info(self, d): self.infos.append(dict(d))
+    """Takes launched-but-not-awaited updates like torchrl_amd.utils.Logger: the multi-rank runs go through the deferred
+    read of the statistics (the comm check then happens where they are read)."""
+    def __init__(self): self.infos, self.later = [], []
+    def add_update_info(self, d): self.drain(); self.infos.append(dict(d))
+    def add_update_infos_later(self, resolve): self.later.append(resolve)
+    def drain(self):
+        later, self.later = self.later, []
+        for resolve in later:
+            self.infos.extend(dict(d) for d in resolve())
     def add_epoch_info(self, *a, **k): pass
     def log(self, *a): pass
     def finish(self): pass
@@ -93,6 +100,7 @@ def main():
         col.rollout(col.sample_epoch_frames)
         agent.current_epoch = epoch
         agent.update_per_epoch()
+    logger.drain()
     keys = sorted(logger.infos[0])
     np.savez(out, pf=pf.flat_params().cpu().numpy(), vf=vf.flat_params().cpu().numpy(), keys=np.array(keys),
              infos=np.array([[i[k] for k in keys] for i in logger.infos if sorted(i) == keys]),
