@@ -306,6 +306,10 @@ int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
  * kernel advances it */
 int trl_clip_adam_polyak_f32(const trl_adam_t* args, float* target, const float* source, int64_t n, float tau,
                              void* stream);
+/* ... whose Polyak launch (the last one of an update) also archives the update's statistics block `raw` (raw_bytes, a
+ * multiple of 4) into row (optimiser steps taken before this update) mod slots of `ring`; p->step_state is required */
+int trl_clip_adam_polyak_file_f32(const trl_adam_t* p, float* target, const float* source, int64_t n, float tau,
+                                  const void* raw, int raw_bytes, void* ring, int slots, void* stream);
 /* Single-process fast path: trl_ppo_reduce_f32 + trl_clip_adam_f32 in one launch (the block that
  * finishes the reduction last takes the optimiser step; fixed summation orders, deterministic).
  * adam->grads must equal `grads`, the two groups must be [policy | value]; logstd statistics are read
@@ -487,6 +491,25 @@ int trl_sac_losses_f32(const float* q1, const float* q2, const float* tq1, const
                        const float* q1n, const float* q2n, const float* logp, const float* alpha,
                        float gamma, int B, float* dq1, float* dq2, float* dq1n, float* dq2n,
                        double* sums, void* stream);
+/* The same launch with two optional extras that each save a launch of a single-rank update:
+ *  - alpha_state / alpha_out non-NULL: the entropy-temperature step of trl_sac_alpha_step_f32 (twin_sac_q.py:111-120) is
+ *    taken first, on `logp`, and its alpha is the one used (the `alpha` argument is ignored);
+ *  - mom_part non-NULL: the per-wave partial moments written by trl_sac_samples_stats_f32 (ceil(B/64) rows of 12 doubles)
+ *    are folded into mom_out[12] = {mean, unbiased std, max, min} of the clamped log_std, of log_prob and of the mean
+ *    (the numbers trl_moments_multi_f64 gives on the policy head, twin_sac_q.py:190-207). */
+int trl_sac_losses_fold_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
+                            const float* logp_next, const float* rew, const float* term, const float* q1n,
+                            const float* q2n, const float* logp, const float* alpha, float gamma, int B,
+                            float* dq1, float* dq2, float* dq1n, float* dq2n, double* sums,
+                            float* alpha_state, float* alpha_out, float target_entropy, float lr, float beta1,
+                            float beta2, float eps, const double* mom_part, int A, double* mom_out, void* stream);
+/* trl_sac_samples_f32 (step_state NULL: eps1 / eps2 are read) or trl_sac_samples_philox_f32 (step_state given: drawn in
+ * place, eps1 receives the first draw) with the partial moments above as a by-product */
+int trl_sac_samples_stats_f32(const float* head, const float* head2, float* eps1, const float* eps2,
+                              const double* step_state, int64_t seed, const float* obs, const float* acts,
+                              const float* next_obs, float* new_a, float* logp, float* next_a, float* next_logp,
+                              float* x_sa, float* x_next, float* x_new, int B, int D, int A, int tanh_action,
+                              double* mom_part, void* stream);
 /* DDPG / TD3 (torchrl/algo/off_policy/ddpg.py:42-110, td3.py:57-154): TD target with Q' = tq1 or
  * min(tq1, tq2) (tq2 NULL: single critic), MSE of one or two critics + output gradients; with qn also the
  * policy loss -mean(Q(s, pi(s))) and dqn = -1/B.  sums (4 doubles): q1 loss sum, q2 loss sum, sum(-qn), sum(r) */

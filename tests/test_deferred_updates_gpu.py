@@ -164,6 +164,26 @@ def test_moments_launch_files_the_statistics_block_into_its_ring_slot():
         _C.moments_multi([(x, torch.zeros(4, dtype=torch.float64, device=DEV), 6, 0, 3, -9.0, 9.0)], ring=(raw, ring, counter))
 
 
+def test_sac_statistics_riding_on_the_update_s_own_launches_equal_the_separate_launches(monkeypatch):
+    """One rank, soft target updates: the temperature step inside the loss launch, the logged moments from per-wave partials
+    of the sampling launch folded by the loss launch, the statistics block filed by the Polyak launch -- against
+    trl_sac_alpha_step_f32 / trl_moments_multi_ring_f64 as launches of their own.  Same arithmetic for everything that
+    feeds back into the update (parameters, targets, alpha bit-identical); the moments are summed in another order."""
+    monkeypatch.setenv("TRL_SAC_STAT_LAUNCHES", "1")
+    ia, fa, ta, la = _sac_run(True, epochs=3)
+    monkeypatch.setenv("TRL_SAC_STAT_LAUNCHES", "0")
+    ib, fb, tb, lb = _sac_run(True, epochs=3)
+    assert len(ia) == len(ib) == 15
+    assert torch.equal(fa, fb) and torch.equal(ta, tb) and torch.equal(la, lb)
+    for x, y in zip(ia, ib):
+        assert list(x) == list(y)
+        for k in x:
+            if k.split("/")[0] in ("log_std", "log_probs", "mean"):
+                assert y[k] == pytest.approx(x[k], rel=1e-11, abs=1e-13), k
+            else:
+                assert x[k] == y[k], k
+
+
 def test_sac_noise_drawn_inside_the_sampling_launch_equals_the_separate_noise_launches(monkeypatch):
     """trl_sac_samples_philox_f32 makes update u's two draws from the device-resident update count (2u + 1, 2u + 2): the
     values trl_philox_normal_f32 was launched for before -- parameters, targets, alpha and every logged number agree."""

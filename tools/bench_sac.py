@@ -61,6 +61,8 @@ def main():
     for _ in range(3):
         col.rollout(STEPS); agent.update_per_epoch()
     log.drain(); torch.cuda.synchronize()
+    import gc
+    gc.collect(); gc.freeze()       # (a generation-2 collection costs ~70 ms with torch loaded: keep it out of either loop)
     # (1) the two phases timed apart: a host wait after each (the update window includes reading its info dicts)
     tc = tu = 0.0
     for _ in range(args.epochs):

@@ -168,6 +168,12 @@ SIGNATURES = {
     "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int] * 4 + [C.c_void_p]),
     "trl_sac_samples_philox_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
     "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
+    "trl_sac_samples_stats_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 4 +
+                                  [C.c_void_p, C.c_void_p]),
+    "trl_sac_losses_fold_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_int] + [C.c_void_p] * 7 + [C.c_float] * 5 +
+                                [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_clip_adam_polyak_file_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_int, C.c_void_p]),
     "trl_moments_multi_ring_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                                              C.c_void_p]),
     "trl_synth_collect_step_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 6 +
@@ -425,8 +431,19 @@ def clip_adam(args, device):
     check(lib().trl_clip_adam_f32(C.byref(args), stream_ptr(device)), "trl_clip_adam_f32")
 
 
-def clip_adam_polyak(args, target, source, tau, device):
-    """clip + Adam, then target <- (1 - tau) target + tau source (the Polyak kernel also advances the device step state)."""
+def clip_adam_polyak(args, target, source, tau, device, file=None):
+    """clip + Adam, then target <- (1 - tau) target + tau source (the Polyak kernel also advances the device step state).
+    file = (raw uint8 statistics block, ring (slots, raw bytes) uint8): the Polyak launch also archives `raw` into ring row
+    (steps taken before this update) % slots."""
+    if file is not None:
+        raw, ring = file
+        if ring.dim() != 2 or int(ring.shape[1]) != raw.numel() or not ring.is_contiguous():
+            raise TrlError("clip_adam_polyak: ring rows must be statistics blocks")
+        check(lib().trl_clip_adam_polyak_file_f32(C.byref(args), dev_ptr(target, name="target"), dev_ptr(source, name="source"),
+                                                  int(target.numel()), float(tau), dev_ptr(raw, torch.uint8, "raw"),
+                                                  int(raw.numel()), dev_ptr(ring, torch.uint8, "ring"), int(ring.shape[0]),
+                                                  stream_ptr(device)), "trl_clip_adam_polyak_file_f32")
+        return
     check(lib().trl_clip_adam_polyak_f32(C.byref(args), dev_ptr(target, name="target"), dev_ptr(source, name="source"),
                                          int(target.numel()), float(tau), stream_ptr(device)), "trl_clip_adam_polyak_f32")
 
@@ -848,15 +865,28 @@ def rsample_bwd_cols(head, eps, act, dx1, dx2, off, d_logp_ptr, d_logp_mul, w_st
     return d_head
 
 
-def sac_samples(head, head2, eps1, eps2, obs, acts, next_obs, tanh_action=True, philox=None):
+def sac_samples(head, head2, eps1, eps2, obs, acts, next_obs, tanh_action=True, philox=None, mom_part=None):
     """(new_a, logp, next_a, next_logp, x_sa, x_next, x_new) of one SAC update in one launch.  philox = (step_state,
     seed): the two noise draws are made inside the launch from the device-resident update count; eps1 then RECEIVES the
-    first draw (eps2 is not touched)."""
+    first draw (eps2 is not touched).  mom_part (ceil(B / 64), 12) float64: also receives the per-wave partial moments
+    of the clamped log_std / log_prob / mean that `sac_losses(..., fold=)` turns into the logged statistics."""
     B, A, D = int(eps1.shape[0]), int(eps1.shape[1]), int(obs.shape[1])
     f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=head.device)
     new_a, logp, next_a, next_logp = f(B, A), f(B), f(B, A), f(B)
     x_sa, x_next, x_new = f(B, D + A), f(B, D + A), f(B, D + A)
     outs = [dev_ptr(t, name="out") for t in (new_a, logp, next_a, next_logp, x_sa, x_next, x_new)]
+    if mom_part is not None:
+        if mom_part.numel() < 12 * ((B + 63) // 64):
+            raise TrlError("sac_samples: mom_part holds fewer than ceil(B / 64) rows of 12")
+        state, seed = philox if philox is not None else (None, 0)
+        check(lib().trl_sac_samples_stats_f32(dev_ptr(head, name="head"), dev_ptr(head2, name="head2"),
+                                              dev_ptr(eps1, name="eps1"), dev_ptr(eps2, name="eps2"),
+                                              dev_ptr(state, torch.float64, "step_state", allow_none=True), int(seed),
+                                              dev_ptr(obs, name="obs"), dev_ptr(acts, name="acts"),
+                                              dev_ptr(next_obs, name="next_obs"), *outs, B, D, A, int(bool(tanh_action)),
+                                              dev_ptr(mom_part, torch.float64, "mom_part"), stream_ptr(head.device)),
+              "trl_sac_samples_stats_f32")
+        return new_a, logp, next_a, next_logp, x_sa, x_next, x_new
     if philox is not None:
         state, seed = philox
         check(lib().trl_sac_samples_philox_f32(dev_ptr(head, name="head"), dev_ptr(head2, name="head2"),
@@ -879,9 +909,24 @@ def sac_alpha_step(logp, target_entropy, lr, state, out, beta1=0.9, beta2=0.999,
                                        dev_ptr(out, name="out"), stream_ptr(logp.device)), "trl_sac_alpha_step_f32")
 
 
-def sac_losses(q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp, alpha, gamma, sums):
+def sac_losses(q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp, alpha, gamma, sums, alpha_step=None, fold=None):
+    """alpha_step = (target_entropy, lr, state, out): the temperature step is taken inside the launch (then `alpha` may be
+    None); fold = (mom_part, A, mom_out12): sac_samples' partial moments are folded into the logged statistics."""
     B = int(q1.numel())
     outs = [torch.empty((B, 1), dtype=torch.float32, device=q1.device) for _ in range(4)]
+    if alpha_step is not None or fold is not None:
+        ent, lr, state, aout = alpha_step if alpha_step is not None else (0.0, 0.0, None, None)
+        part, A, mom_out = fold if fold is not None else (None, 0, None)
+        ins = [q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp]
+        check(lib().trl_sac_losses_fold_f32(*[dev_ptr(t, name="in%d" % i) for i, t in enumerate(ins)],
+                                            dev_ptr(alpha, name="alpha", allow_none=alpha_step is not None), float(gamma), B,
+                                            *[dev_ptr(t, name="out") for t in outs], dev_ptr(sums, torch.float64, "sums"),
+                                            dev_ptr(state, name="alpha_state", allow_none=True),
+                                            dev_ptr(aout, name="alpha_out", allow_none=True), float(ent), float(lr),
+                                            0.9, 0.999, 1e-8, dev_ptr(part, torch.float64, "mom_part", allow_none=True), int(A),
+                                            dev_ptr(mom_out, torch.float64, "mom_out", allow_none=True),
+                                            stream_ptr(q1.device)), "trl_sac_losses_fold_f32")
+        return outs
     ins = [q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp, alpha]
     check(lib().trl_sac_losses_f32(*[dev_ptr(t, name="in%d" % i) for i, t in enumerate(ins)], float(gamma), B,
                                    *[dev_ptr(t, name="out") for t in outs], dev_ptr(sums, torch.float64, "sums"),

@@ -158,6 +158,7 @@ class _FusedSAC:
         # the statistics block of update u is filed into ring row u % slots by the update's last launch
         self._ring = StatRing(max(64, int(getattr(algo, "opt_times", 1))), self._raw.numel(), torch.uint8, self.dev)
         self._slab = IndexSlab(self.dev)
+        self._mom_part = None
 
     def _ws(self, B):
         lib = _C.lib()
@@ -194,19 +195,29 @@ class _FusedSAC:
         # both samples (distribution.py:67-70 order) and the three critic inputs [obs | acts], [next_obs | next_a],
         # [obs | new_a]: one launch
         # (device noise on one rank: the two draws are made inside that launch from the device-resident update count)
+        # One rank with soft target updates: the temperature step, the logged moments and the filing of the statistics block
+        # ride on launches the update has anyway (sampling -> partial moments, loss launch -> temperature step + fold of
+        # the partials, Polyak launch -> filing); otherwise they are the separate launches sac_alpha / moments_multi.
+        ride = dist.world_size() == 1 and soft and os.environ.get("TRL_SAC_STAT_LAUNCHES") != "1"
+        if ride and (self._mom_part is None or self._mom_part.shape[0] != (B + 63) // 64):
+            self._mom_part = torch.zeros((B + 63) // 64, 12, dtype=torch.float64, device=dev)
         new_a, logp, next_a, next_logp, x_sa, x_next, x_new = _C.sac_samples(
             head, head2, eps1, eps2, obs, acts, nobs, tanh_action,
-            philox=(self.step_state, self.noise_seed) if self._inline_noise() else None)
+            philox=(self.step_state, self.noise_seed) if self._inline_noise() else None,
+            mom_part=self._mom_part if ride else None)
         # ---- temperature ----
-        if algo.automatic_entropy_tuning:                                # mean over the GLOBAL batch (all ranks' samples)
+        if algo.automatic_entropy_tuning and not ride:                   # mean over the GLOBAL batch (all ranks' samples)
             _C.sac_alpha_step(dist.all_gather_cat(logp), algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
         # ---- all six critic passes as one group: Q1/Q2(s, a), target Q1/Q2(s', a'), Q1/Q2(s, new a) ----
         (q1p, q2p, tq1, tq2, q1n, q2n), (tape_q1, tape_q2, _, _, tape_q1n, tape_q2n) = ops.mlp_forward_group(
             [q1_l, q2_l, self.tlayers[0], self.tlayers[1], q1_l, q2_l], [x_sa, x_sa, x_next, x_next, x_new, x_new], self.act,
             keep=[True, True, False, False, True, True])                 # the target passes leave no tape
         alpha = self.alpha_out[0:1]                                      # re-read AFTER the alpha step, as the reference does
-        dq1, dq2, dq1n, dq2n = _C.sac_losses(q1p, q2p, tq1, tq2, next_logp, rew, term, q1n, q2n, logp, alpha,
-                                             algo.discount, self.sums)
+        dq1, dq2, dq1n, dq2n = _C.sac_losses(
+            q1p, q2p, tq1, tq2, next_logp, rew, term, q1n, q2n, logp, alpha, algo.discount, self.sums,
+            alpha_step=(algo.target_entropy, algo.plr, self.alpha_state, self.alpha_out)
+            if ride and algo.automatic_entropy_tuning else None,
+            fold=(self._mom_part, A, self.mom) if ride else None)
         # weight gradients of all nine layers: ONE launch of split GEMMs + ONE fold, after the input-gradient chains
         plan = _C.FoldPlan(ws, defer_gemm=os.environ.get("TRL_SAC_DW_PER_LAYER") != "1")
         # ---- the four critic backward passes as one group: through Q1 / Q2 on [obs | new_a] down to the action (policy
@@ -235,9 +246,12 @@ class _FusedSAC:
         a.step_count, a.norms_out = 0, self.norms.data_ptr()
         a.step_state = self.step_state.data_ptr()                        # the step count lives on the device
         if soft:                                                         # Adam, then Polyak (which also advances the step state)
-            _C.clip_adam_polyak(a, self.tflat, self.flat[self.sizes[0]:], algo.tau, dev)
+            _C.clip_adam_polyak(a, self.tflat, self.flat[self.sizes[0]:], algo.tau, dev,
+                                file=(self._raw, self._ring.t) if ride else None)
         else:
             _C.clip_adam(a, dev)
+        if ride:
+            return
         # ---- logging statistics (over the global batch) ----
         dist.all_reduce_sum_(self.sums)
         head_g, logp_g = dist.all_gather_cat(head), dist.all_gather_cat(logp)

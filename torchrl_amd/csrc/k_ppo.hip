@@ -1668,23 +1668,44 @@ extern "C" int trl_clip_adam_f32(const trl_adam_t* p, void* stream) { return cli
 // clip + Adam followed by the Polyak step of the target networks (rl_algo.py:169-176 / utils.py:16-20), two launches:
 // when the device-resident step state needs the one-thread tick kernel (large parameter blocks), the Polyak kernel's
 // first thread advances it instead -- it runs behind the Adam kernel in stream order, i.e. after every block has read it.
+// `file` (optional): block 0 also archives the update's statistics block into row (updates finished before this one) mod
+// slots of a ring -- the last launch of the update, every statistic has been written by then.
+struct FileRing { const uint32_t* raw; uint32_t* ring; const double* count; int words, slots, ticked; };
 __global__ __launch_bounds__(256) void polyak_tick_kernel(float* __restrict__ tgt, const float* __restrict__ src, int64_t n,
-                                                          float tau, double* __restrict__ st, float beta1, float beta2) {
+                                                          float tau, double* __restrict__ st, float beta1, float beta2,
+                                                          FileRing file) {
+  if (file.ring && blockIdx.x == 0) {
+    const int64_t u = (int64_t)file.count[0] - file.ticked;            // (read by every thread BEFORE thread 0 advances it)
+    __syncthreads();
+    uint32_t* row = file.ring + (int64_t)(((u % file.slots) + file.slots) % file.slots) * file.words;
+    for (int w = threadIdx.x; w < file.words; w += 256) row[w] = file.raw[w];
+  }
   if (st && blockIdx.x == 0 && threadIdx.x == 0) { st[0] += 1.0; st[1] *= (double)beta1; st[2] *= (double)beta2; }
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
     tgt[e] = tgt[e] * (1.0f - tau) + src[e] * tau;
 }
-extern "C" int trl_clip_adam_polyak_f32(const trl_adam_t* p, float* target, const float* source, int64_t n, float tau,
-                                        void* stream) {
+static int clip_adam_polyak(const trl_adam_t* p, float* target, const float* source, int64_t n, float tau,
+                            const void* raw, int raw_bytes, void* ring, int slots, void* stream) {
   TRL_REQUIRE(n > 0 && target && source, "polyak: empty / null");
   int rc = clip_adam_launch(p, stream, false);
   if (rc != TRL_OK && rc != TICK_PENDING) return rc;
   int grid = trl_ceil_div(n, 256);
   if (grid > 1024) grid = 1024;
+  FileRing file = {(const uint32_t*)raw, (uint32_t*)ring, p->step_state, raw_bytes / 4, slots, rc == TICK_PENDING ? 0 : 1};
   hipLaunchKernelGGL(polyak_tick_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, target, source, n, tau,
-                     rc == TICK_PENDING ? p->step_state : (double*)nullptr, p->beta1, p->beta2);
+                     rc == TICK_PENDING ? p->step_state : (double*)nullptr, p->beta1, p->beta2, file);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
+}
+extern "C" int trl_clip_adam_polyak_f32(const trl_adam_t* p, float* target, const float* source, int64_t n, float tau,
+                                        void* stream) {
+  return clip_adam_polyak(p, target, source, n, tau, nullptr, 0, nullptr, 0, stream);
+}
+extern "C" int trl_clip_adam_polyak_file_f32(const trl_adam_t* p, float* target, const float* source, int64_t n, float tau,
+                                             const void* raw, int raw_bytes, void* ring, int slots, void* stream) {
+  TRL_REQUIRE(raw && ring && raw_bytes > 0 && raw_bytes % 4 == 0 && slots > 0, "clip_adam_polyak_file: bad ring");
+  TRL_REQUIRE(p && p->step_state, "clip_adam_polyak_file: the row is picked by the device-resident step state");
+  return clip_adam_polyak(p, target, source, n, tau, raw, raw_bytes, ring, slots, stream);
 }
 
 static int clip_adam_launch(const trl_adam_t* p, void* stream, bool tick_here) {

@@ -10,7 +10,8 @@
 
 #define SAC_THREADS 256
 
-// block-wide sum into thread 0 (double) -- deterministic tree
+// block-wide sum into thread 0 (double) -- deterministic tree; smem holds one double per wave of the block
+#define SAC_WIDE 1024                               /* the single-workgroup reductions over a batch: 16 waves */
 __device__ __forceinline__ double block_sum(double v, double* smem) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -18,7 +19,7 @@ __device__ __forceinline__ double block_sum(double v, double* smem) {
   if (lane == 0) smem[wave] = v;
   __syncthreads();
   double r = 0.0;
-  for (int w = 0; w < SAC_THREADS / 64; ++w) r += smem[w];
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += smem[w];
   return r;
 }
 __device__ __forceinline__ double block_max(double v, double* smem) {
@@ -28,7 +29,7 @@ __device__ __forceinline__ double block_max(double v, double* smem) {
   if (lane == 0) smem[wave] = v;
   __syncthreads();
   double r = -INFINITY;
-  for (int w = 0; w < SAC_THREADS / 64; ++w) r = fmax(r, smem[w]);
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r = fmax(r, smem[w]);
   return r;
 }
 
@@ -124,53 +125,81 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_samples_kernel(const float* _
                                                                   float* __restrict__ x_next, float* __restrict__ x_new,
                                                                   int B, int D, int A, int tanh_action,
                                                                   const double* __restrict__ step_state, int64_t seed,
-                                                                  float* __restrict__ eps1_out) {
+                                                                  float* __restrict__ eps1_out,
+                                                                  double* __restrict__ mom_part) {
   // two threads per batch row: thread (b, 0) draws / samples from head(obs) and writes x_sa, x_new; thread (b, 1) does the
   // next-state pair and x_next -- the Philox + Box-Muller chain per draw is what this kernel spends its time in
   const int t = blockIdx.x * blockDim.x + threadIdx.x;               // (whole waves take one side: no divergence)
   const int b = ((t >> 7) << 6) | (t & 63), which = (t >> 6) & 1;
-  if (b >= B) return;
-  const int F = D + A;
-  float e[8];
-  if (step_state) {
-    // the two draws of update u (u = optimiser steps taken so far, device-resident: the launch is graph-replayed) are
-    // trl_philox_normal_f32(seed, 2 u + 1) and (seed, 2 u + 2) -- what the engine launched separately before
-    const int64_t u = (int64_t)step_state[0];
-    philox_noise_row(seed, 2 * u + 1 + which, b, A, e);
-    if (which == 0) for (int k = 0; k < A; ++k) eps1_out[(size_t)b * A + k] = e[k];   // the sampler's backward pass reads it
-  } else {
-    const float* src = which == 0 ? eps1 : eps2;
-    for (int k = 0; k < A; ++k) e[k] = src[(size_t)b * A + k];
+  const bool stats = mom_part && which == 0, live = b < B;           // (a stats wave stays whole for its reductions)
+  if (!live && !stats) return;
+  float lp0 = 0.0f;
+  if (live) {
+    const int F = D + A;
+    float e[8];
+    if (step_state) {
+      // the two draws of update u (u = optimiser steps taken so far, device-resident: the launch is graph-replayed) are
+      // trl_philox_normal_f32(seed, 2 u + 1) and (seed, 2 u + 2) -- what the engine launched separately before
+      const int64_t u = (int64_t)step_state[0];
+      philox_noise_row(seed, 2 * u + 1 + which, b, A, e);
+      if (which == 0) for (int k = 0; k < A; ++k) eps1_out[(size_t)b * A + k] = e[k];   // the sampler's backward pass reads it
+    } else {
+      const float* src = which == 0 ? eps1 : eps2;
+      for (int k = 0; k < A; ++k) e[k] = src[(size_t)b * A + k];
+    }
+    if (which == 0) {
+      float* na = new_a + (size_t)b * A;
+      lp0 = rsample_row(head + (size_t)b * 2 * A, e, na, A, tanh_action);
+      logp[b] = lp0;
+      for (int k = 0; k < D; ++k) {
+        const float o = obs[(size_t)b * D + k];
+        x_sa[(size_t)b * F + k] = o; x_new[(size_t)b * F + k] = o;
+      }
+      for (int k = 0; k < A; ++k) {
+        x_sa[(size_t)b * F + D + k] = acts[(size_t)b * A + k];
+        x_new[(size_t)b * F + D + k] = na[k];
+      }
+    } else {
+      float* xa = next_a + (size_t)b * A;
+      next_logp[b] = rsample_row(head2 + (size_t)b * 2 * A, e, xa, A, tanh_action);
+      for (int k = 0; k < D; ++k) x_next[(size_t)b * F + k] = nobs[(size_t)b * D + k];
+      for (int k = 0; k < A; ++k) x_next[(size_t)b * F + D + k] = xa[k];
+    }
   }
-  if (which == 0) {
-    float* na = new_a + (size_t)b * A;
-    logp[b] = rsample_row(head + (size_t)b * 2 * A, e, na, A, tanh_action);
-    for (int k = 0; k < D; ++k) {
-      const float o = obs[(size_t)b * D + k];
-      x_sa[(size_t)b * F + k] = o; x_new[(size_t)b * F + k] = o;
+  if (stats) {
+    // the logged moments of the policy head on obs -- clamped log_std, mean -- and of log_prob (twin_sac_q.py:190-207) as
+    // per-wave partials {sum, sum of squares, max, -min} x {log_std, log_prob, mean}: row b >> 6 of mom_part (12 doubles);
+    // trl_sac_losses_fold_f32 folds them (the separate trl_moments_multi_f64 launch re-read head and logp for this)
+    double ps[3] = {0, 0, 0}, pq[3] = {0, 0, 0}, pm[3] = {-INFINITY, -INFINITY, -INFINITY}, pn[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (live) {
+      for (int k = 0; k < A; ++k) {
+        const double mu = (double)head[(size_t)b * 2 * A + k];
+        const double ls = (double)fminf(fmaxf(head[(size_t)b * 2 * A + A + k], -20.0f), 2.0f);
+        ps[0] += ls; pq[0] += ls * ls; pm[0] = fmax(pm[0], ls); pn[0] = fmax(pn[0], -ls);
+        ps[2] += mu; pq[2] += mu * mu; pm[2] = fmax(pm[2], mu); pn[2] = fmax(pn[2], -mu);
+      }
+      ps[1] = (double)lp0; pq[1] = (double)lp0 * lp0; pm[1] = (double)lp0; pn[1] = -(double)lp0;
     }
-    for (int k = 0; k < A; ++k) {
-      x_sa[(size_t)b * F + D + k] = acts[(size_t)b * A + k];
-      x_new[(size_t)b * F + D + k] = na[k];
+    double* row = mom_part + (size_t)(b >> 6) * 12;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double a0 = wave_sum(ps[j]), a1 = wave_sum(pq[j]), a2 = wave_max(pm[j]), a3 = wave_max(pn[j]);
+      if ((threadIdx.x & 63) == 0) { row[4 * j] = a0; row[4 * j + 1] = a1; row[4 * j + 2] = a2; row[4 * j + 3] = a3; }
     }
-  } else {
-    float* xa = next_a + (size_t)b * A;
-    next_logp[b] = rsample_row(head2 + (size_t)b * 2 * A, e, xa, A, tanh_action);
-    for (int k = 0; k < D; ++k) x_next[(size_t)b * F + k] = nobs[(size_t)b * D + k];
-    for (int k = 0; k < A; ++k) x_next[(size_t)b * F + D + k] = xa[k];
   }
 }
 static int sac_samples_impl(const float* head, const float* head2, const float* eps1, const float* eps2,
                             const float* obs, const float* acts, const float* next_obs, float* new_a, float* logp,
                             float* next_a, float* next_logp, float* x_sa, float* x_next, float* x_new, int B, int D,
-                            int A, int tanh_action, const double* step_state, int64_t seed, float* eps1_out, void* stream) {
+                            int A, int tanh_action, const double* step_state, int64_t seed, float* eps1_out,
+                            double* mom_part, void* stream) {
   TRL_REQUIRE(B >= 0 && A > 0 && A <= 8 && D > 0, "bad sizes (A <= 8)");
   if (B == 0) return TRL_OK;
   TRL_REQUIRE(head && head2 && obs && acts && next_obs && ((eps1 && eps2) || (step_state && eps1_out)), "null input");
   TRL_REQUIRE(new_a && logp && next_a && next_logp && x_sa && x_next && x_new, "null output");
   hipLaunchKernelGGL(sac_samples_kernel, dim3(2 * trl_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, head, head2, eps1,
                      eps2, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next, x_new, B, D, A, tanh_action,
-                     step_state, seed, eps1_out);
+                     step_state, seed, eps1_out, mom_part);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -179,7 +208,7 @@ extern "C" int trl_sac_samples_f32(const float* head, const float* head2, const 
                                    float* next_a, float* next_logp, float* x_sa, float* x_next, float* x_new, int B, int D,
                                    int A, int tanh_action, void* stream) {
   return sac_samples_impl(head, head2, eps1, eps2, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next, x_new,
-                          B, D, A, tanh_action, nullptr, 0, nullptr, stream);
+                          B, D, A, tanh_action, nullptr, 0, nullptr, nullptr, stream);
 }
 // the same with the two noise draws made in place: update u (u = step_state[0], the device-resident count of optimiser
 // steps taken) uses trl_philox_normal_f32's draws for (seed, 2 u + 1) and (seed, 2 u + 2); eps1_out (B, A) receives the
@@ -189,7 +218,21 @@ extern "C" int trl_sac_samples_philox_f32(const float* head, const float* head2,
                                           float* new_a, float* logp, float* next_a, float* next_logp, float* x_sa,
                                           float* x_next, float* x_new, int B, int D, int A, int tanh_action, void* stream) {
   return sac_samples_impl(head, head2, nullptr, nullptr, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next,
-                          x_new, B, D, A, tanh_action, step_state, seed, eps1_out, stream);
+                          x_new, B, D, A, tanh_action, step_state, seed, eps1_out, nullptr, stream);
+}
+// either of the two with the logged moments' per-wave partials as a by-product: mom_part holds ceil(B / 64) rows of 12 doubles;
+// step_state NULL -> eps1 / eps2 are read, else they are drawn in place (eps1 receives the first draw)
+extern "C" int trl_sac_samples_stats_f32(const float* head, const float* head2, float* eps1, const float* eps2,
+                                         const double* step_state, int64_t seed, const float* obs, const float* acts,
+                                         const float* next_obs, float* new_a, float* logp, float* next_a, float* next_logp,
+                                         float* x_sa, float* x_next, float* x_new, int B, int D, int A, int tanh_action,
+                                         double* mom_part, void* stream) {
+  TRL_REQUIRE(mom_part, "sac_samples_stats: null partials");
+  if (step_state)
+    return sac_samples_impl(head, head2, nullptr, nullptr, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next,
+                            x_new, B, D, A, tanh_action, step_state, seed, eps1, mom_part, stream);
+  return sac_samples_impl(head, head2, eps1, eps2, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next, x_new,
+                          B, D, A, tanh_action, nullptr, 0, nullptr, mom_part, stream);
 }
 
 // backward of the above + the std / mean regularisers of twin_sac_q.py:157-160:
@@ -258,14 +301,15 @@ extern "C" int trl_tanh_gauss_rsample_bwd_cols_f32(const float* head, const floa
 // ---------------------------------------------------------------- entropy temperature step
 // alpha_loss = -mean(log_alpha * (log_prob + target_entropy)); Adam step on log_alpha;
 // alpha = exp(log_alpha) AFTER the step (twin_sac_q.py:111-120, its Q19 ordering).
-// state: [log_alpha, exp_avg, exp_avg_sq, step]; out: [alpha, alpha_loss].   Single workgroup.
-__global__ __launch_bounds__(SAC_THREADS) void sac_alpha_kernel(const float* __restrict__ logp, int B,
+// state: [log_alpha, exp_avg, exp_avg_sq, step]; out: [alpha, alpha_loss].   Single workgroup of 16 waves: a thread's loads
+// are dependent round trips (~0.5 us each), so the batch is spread over as many threads as a workgroup has.
+__global__ __launch_bounds__(SAC_WIDE) void sac_alpha_kernel(const float* __restrict__ logp, int B,
                                                                 float target_entropy, float lr, float beta1,
                                                                 float beta2, float eps, float* __restrict__ state,
                                                                 float* __restrict__ out) {
-  __shared__ double smem[SAC_THREADS / 64];
+  __shared__ double smem[SAC_WIDE / 64];
   double s = 0.0;
-  for (int b = threadIdx.x; b < B; b += SAC_THREADS) s += (double)logp[b];
+  for (int b = threadIdx.x; b < B; b += SAC_WIDE) s += (double)logp[b];
   s = block_sum(s, smem);
   if (threadIdx.x == 0) {
     const float mean_term = (float)(s / B) + target_entropy;     // mean(log_prob + H_target)
@@ -285,7 +329,7 @@ extern "C" int trl_sac_alpha_step_f32(const float* logp, int B, float target_ent
                                       float beta2, float eps, float* state, float* out, void* stream) {
   TRL_REQUIRE(B > 0, "empty batch");
   TRL_REQUIRE(logp && state && out, "null pointer");
-  hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(SAC_THREADS), 0, (hipStream_t)stream, logp, B, target_entropy,
+  hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(SAC_WIDE), 0, (hipStream_t)stream, logp, B, target_entropy,
                      lr, beta1, beta2, eps, state, out);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
@@ -298,7 +342,31 @@ extern "C" int trl_sac_alpha_step_f32(const float* logp, int B, float target_ent
 //   dq1n = -(q1n < q2n ? 1 : q1n == q2n ? .5 : 0) / B,  dq2n likewise.
 // alpha_ptr: device scalar written by the alpha step (or a constant 1 when tuning is off).
 // sums (double[4]): qf1 loss sum, qf2 loss sum, sum(alpha logp - min q_new), sum rewards.
-__global__ __launch_bounds__(SAC_THREADS) void sac_losses_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+// Extras of the fused form (trl_sac_losses_fold_f32), each optional:
+//  * the temperature step (sac_alpha_kernel's arithmetic) at the top, its alpha used below -- one launch less;
+//  * the fold of trl_sac_samples_stats_f32's per-wave partial moments into {mean, unbiased std, max, min} x {log_std,
+//    log_prob, mean} (12 doubles at mom_out), done by the last wave while the others reduce the loss sums.
+struct LossExtras {
+  float* alpha_state; float* alpha_out; float target_entropy, lr, beta1, beta2, eps;       // alpha_state NULL: no step
+  const double* mom_part; int parts; int A; double* mom_out;                               // mom_part NULL: no fold
+};
+__device__ __forceinline__ float alpha_adam_step(double logp_sum, int B, const LossExtras& x) {
+  const float mean_term = (float)(logp_sum / B) + x.target_entropy;     // mean(log_prob + H_target)
+  float* state = x.alpha_state;
+  const float la = state[0];
+  x.alpha_out[1] = -la * mean_term;                                     // alpha_loss
+  const float g = -mean_term;
+  const float t = state[3] + 1.0f;
+  const float m = x.beta1 * state[1] + (1.0f - x.beta1) * g;
+  const float v = x.beta2 * state[2] + (1.0f - x.beta2) * g * g;
+  const float bc1 = 1.0f - powf(x.beta1, t), bc2 = 1.0f - powf(x.beta2, t);
+  const float la_new = la - (x.lr / bc1) * (m / (sqrtf(v) / sqrtf(bc2) + x.eps));
+  state[0] = la_new; state[1] = m; state[2] = v; state[3] = t;
+  const float alpha = __expf(la_new);
+  x.alpha_out[0] = alpha;
+  return alpha;
+}
+__global__ __launch_bounds__(SAC_WIDE) void sac_losses_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
                                                                  const float* __restrict__ tq1, const float* __restrict__ tq2,
                                                                  const float* __restrict__ logp_next,
                                                                  const float* __restrict__ rew, const float* __restrict__ term,
@@ -306,12 +374,24 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_losses_kernel(const float* __
                                                                  const float* __restrict__ logp, const float* __restrict__ alpha_ptr,
                                                                  float gamma, int B, float* __restrict__ dq1,
                                                                  float* __restrict__ dq2, float* __restrict__ dq1n,
-                                                                 float* __restrict__ dq2n, double* __restrict__ sums) {
-  __shared__ double smem[SAC_THREADS / 64];
-  const float alpha = *alpha_ptr;
+                                                                 float* __restrict__ dq2n, double* __restrict__ sums,
+                                                                 LossExtras x) {
+  __shared__ double smem[SAC_WIDE / 64];
+  __shared__ float s_alpha;
+  float alpha;
+  if (x.alpha_state) {                                                 // (one workgroup: the launcher's contract)
+    double s = 0.0;
+    for (int b = threadIdx.x; b < B; b += SAC_WIDE) s += (double)logp[b];
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) s_alpha = alpha_adam_step(s, B, x);
+    __syncthreads();
+    alpha = s_alpha;
+  } else {
+    alpha = *alpha_ptr;
+  }
   const float inv_b = 1.0f / (float)B;
   double s1 = 0, s2 = 0, sp = 0, sr = 0;
-  for (int b = blockIdx.x * SAC_THREADS + threadIdx.x; b < B; b += gridDim.x * SAC_THREADS) {
+  for (int b = blockIdx.x * SAC_WIDE + threadIdx.x; b < B; b += gridDim.x * SAC_WIDE) {
     const float tv = fminf(tq1[b], tq2[b]) - alpha * logp_next[b];
     const float qt = rew[b] + (1.0f - term[b]) * gamma * tv;
     const float e1 = q1[b] - qt, e2 = q2[b] - qt;
@@ -320,6 +400,24 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_losses_kernel(const float* __
     dq1n[b] = -(a < c ? 1.0f : (a == c ? 0.5f : 0.0f)) * inv_b;
     dq2n[b] = -(c < a ? 1.0f : (a == c ? 0.5f : 0.0f)) * inv_b;
     s1 += (double)e1 * e1; s2 += (double)e2 * e2; sp += (double)(alpha * logp[b] - fminf(a, c)); sr += (double)rew[b];
+  }
+  if (x.mom_part && (threadIdx.x >> 6) == (blockDim.x >> 6) - 1) {     // the last wave: no barrier in here
+    const int lane = threadIdx.x & 63;
+    for (int j = 0; j < 3; ++j) {
+      double a = 0, c = 0, mx = -INFINITY, nmn = -INFINITY;
+      for (int p = lane; p < x.parts; p += 64) {
+        const double* row = x.mom_part + (size_t)p * 12 + 4 * j;
+        a += row[0]; c += row[1]; mx = fmax(mx, row[2]); nmn = fmax(nmn, row[3]);
+      }
+      a = wave_sum(a); c = wave_sum(c); mx = wave_max(mx); nmn = wave_max(nmn);
+      if (lane == 0) {
+        const double cnt = (double)B * (j == 1 ? 1 : x.A), mean = a / cnt;
+        double* o = x.mom_out + 4 * j;
+        o[0] = mean;
+        o[1] = cnt > 1 ? sqrt(fmax((c - a * mean) / (cnt - 1), 0.0)) : NAN;
+        o[2] = mx; o[3] = -nmn;
+      }
+    }
   }
   s1 = block_sum(s1, smem); s2 = block_sum(s2, smem); sp = block_sum(sp, smem); sr = block_sum(sr, smem);
   if (threadIdx.x == 0) { sums[0] = s1; sums[1] = s2; sums[2] = sp; sums[3] = sr; }     // ONE workgroup (launcher)
@@ -333,8 +431,27 @@ extern "C" int trl_sac_losses_f32(const float* q1, const float* q2, const float*
   TRL_REQUIRE(dq1 && dq2 && dq1n && dq2n && sums, "null output");
   hipStream_t s = (hipStream_t)stream;
   // one workgroup: B is a few thousand and the sums must be order-deterministic
-  hipLaunchKernelGGL(sac_losses_kernel, dim3(1), dim3(SAC_THREADS), 0, s, q1, q2, tq1, tq2, logp_next, rew, term, q1n,
-                     q2n, logp, alpha, gamma, B, dq1, dq2, dq1n, dq2n, sums);
+  LossExtras none = {};
+  hipLaunchKernelGGL(sac_losses_kernel, dim3(1), dim3(SAC_WIDE), 0, s, q1, q2, tq1, tq2, logp_next, rew, term, q1n,
+                     q2n, logp, alpha, gamma, B, dq1, dq2, dq1n, dq2n, sums, none);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+extern "C" int trl_sac_losses_fold_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
+                                       const float* logp_next, const float* rew, const float* term, const float* q1n,
+                                       const float* q2n, const float* logp, const float* alpha, float gamma, int B,
+                                       float* dq1, float* dq2, float* dq1n, float* dq2n, double* sums,
+                                       float* alpha_state, float* alpha_out, float target_entropy, float lr, float beta1,
+                                       float beta2, float eps, const double* mom_part, int A, double* mom_out,
+                                       void* stream) {
+  TRL_REQUIRE(B > 0, "empty batch");
+  TRL_REQUIRE(q1 && q2 && tq1 && tq2 && logp_next && rew && term && q1n && q2n && logp, "null input");
+  TRL_REQUIRE(dq1 && dq2 && dq1n && dq2n && sums, "null output");
+  TRL_REQUIRE((alpha_state && alpha_out) || (!alpha_state && alpha), "alpha: a step state + output, or a value");
+  TRL_REQUIRE(!mom_part || (mom_out && A > 0), "moments fold: null output / bad A");
+  LossExtras x = {alpha_state, alpha_out, target_entropy, lr, beta1, beta2, eps, mom_part, trl_ceil_div(B, 64), A, mom_out};
+  hipLaunchKernelGGL(sac_losses_kernel, dim3(1), dim3(SAC_WIDE), 0, (hipStream_t)stream, q1, q2, tq1, tq2, logp_next, rew,
+                     term, q1n, q2n, logp, alpha, gamma, B, dq1, dq2, dq1n, dq2n, sums, x);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -496,14 +613,30 @@ __device__ __forceinline__ void moments_block(const float* __restrict__ x, int64
   __shared__ double smem[4][MOM_THREADS / 64];
   double s = 0, sq = 0, mx = -INFINITY, nmn = -INFINITY;
   const int64_t rows = n / ld;
-  int64_t r = threadIdx.x / width;
-  int c = threadIdx.x - (int)r * width;
-  const int dr = MOM_THREADS / width, dc = MOM_THREADS - dr * width;
-  for (; r < rows; ) {
-    const double v = (double)fminf(fmaxf(x[r * ld + off + c], lo), hi_);
-    s += v; sq += v * v; mx = fmax(mx, v); nmn = fmax(nmn, -v);
-    r += dr; c += dc;
-    if (c >= width) { c -= width; ++r; }
+  // four independent element streams per thread (elements tid + j * 1024, then strides of 4096): their loads are in flight
+  // together -- one stream per thread was a chain of dependent round trips, 24 of them at B = 4096 x 6 columns
+  int64_t r[4];
+  int c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = threadIdx.x + j * MOM_THREADS;
+    r[j] = e / width;
+    c[j] = e - (int)r[j] * width;
+  }
+  const int dr = 4 * MOM_THREADS / width, dc = 4 * MOM_THREADS - dr * width;
+  while (r[0] < rows) {                                                // (stream 0 is the one that runs out last)
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = r[j] < rows ? x[r[j] * ld + off + c[j]] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (r[j] < rows) {
+        const double d = (double)fminf(fmaxf(v[j], lo), hi_);
+        s += d; sq += d * d; mx = fmax(mx, d); nmn = fmax(nmn, -d);
+      }
+      r[j] += dr; c[j] += dc;
+      if (c[j] >= width) { c[j] -= width; ++r[j]; }
+    }
   }
   s = wave_sum(s); sq = wave_sum(sq); mx = wave_max(mx); nmn = wave_max(nmn);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
