@@ -411,6 +411,14 @@ def main():
         iteration(agent, col, e)
         torch.cuda.synchronize()
         log("set-up iteration %d done (graph capture)" % e)
+    # A full (generation 2) collection of the interpreter's heap costs tens of milliseconds with torch loaded -- as long as the
+    # whole timed region -- and when one falls due is a matter of allocation counts: the objects alive after set-up are
+    # moved out of the collector's reach so that the timed region measures the loop, not the dice (seen in
+    # tools/bench_sac.py as a 70 ms hole in one of two timed loops, at random).  Before the warm-up, which absorbs the
+    # collection's own after-effects.
+    import gc
+    gc.collect()
+    gc.freeze()
     log("warmup x%d" % args.warmup)
     for e in range(args.warmup):
         iteration(agent, col, e)
@@ -429,13 +437,6 @@ def main():
     torch.cuda.synchronize()
     agent.logger.drain()
     agent.logger.updates = 0
-    # A full (generation 2) collection of the interpreter's heap costs tens of milliseconds with torch loaded -- as long as the
-    # whole timed region -- and when one falls due is a matter of allocation counts: the objects alive after warm-up are
-    # moved out of the collector's reach so that the timed region measures the loop, not the dice (seen in
-    # tools/bench_sac.py as a 70 ms hole in one of two timed loops, at random).
-    import gc
-    gc.collect()
-    gc.freeze()
     t0 = time.perf_counter()
     marks = []
     for e in range(args.steps):
