@@ -309,7 +309,13 @@ __global__ __launch_bounds__(SAC_WIDE) void sac_alpha_kernel(const float* __rest
                                                                 float* __restrict__ out) {
   __shared__ double smem[SAC_WIDE / 64];
   double s = 0.0;
-  for (int b = threadIdx.x; b < B; b += SAC_WIDE) s += (double)logp[b];
+  for (int b0 = threadIdx.x; b0 < B; b0 += 4 * SAC_WIDE) {             // four loads in flight, summed in ascending b
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = b0 + j * SAC_WIDE < B ? logp[b0 + j * SAC_WIDE] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (b0 + j * SAC_WIDE < B) s += (double)v[j];
+  }
   s = block_sum(s, smem);
   if (threadIdx.x == 0) {
     const float mean_term = (float)(s / B) + target_entropy;     // mean(log_prob + H_target)
@@ -378,10 +384,28 @@ __global__ __launch_bounds__(SAC_WIDE) void sac_losses_kernel(const float* __res
                                                                  LossExtras x) {
   __shared__ double smem[SAC_WIDE / 64];
   __shared__ float s_alpha;
+  // Rows are taken four per thread (b, b + 1024, ...): all forty loads of a group are in flight together, and the first
+  // group is requested BEFORE the temperature step, whose reduction and one-thread Adam arithmetic then run under those
+  // loads instead of in front of them (a thread's accumulation order -- ascending b -- is that of the row-by-row loop).
+  constexpr int R = 4;
+  float in[R][10];
+  auto request = [&](int b0) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int b = b0 + j * SAC_WIDE;
+      if (b < B) {
+        in[j][0] = tq1[b]; in[j][1] = tq2[b]; in[j][2] = logp_next[b]; in[j][3] = rew[b]; in[j][4] = term[b];
+        in[j][5] = q1[b]; in[j][6] = q2[b]; in[j][7] = q1n[b]; in[j][8] = q2n[b]; in[j][9] = logp[b];
+      }
+    }
+  };
+  request(threadIdx.x);
   float alpha;
   if (x.alpha_state) {                                                 // (one workgroup: the launcher's contract)
     double s = 0.0;
-    for (int b = threadIdx.x; b < B; b += SAC_WIDE) s += (double)logp[b];
+#pragma unroll
+    for (int j = 0; j < R; ++j) if ((int)threadIdx.x + j * SAC_WIDE < B) s += (double)in[j][9];
+    for (int b = threadIdx.x + R * SAC_WIDE; b < B; b += SAC_WIDE) s += (double)logp[b];
     s = block_sum(s, smem);
     if (threadIdx.x == 0) s_alpha = alpha_adam_step(s, B, x);
     __syncthreads();
@@ -391,15 +415,21 @@ __global__ __launch_bounds__(SAC_WIDE) void sac_losses_kernel(const float* __res
   }
   const float inv_b = 1.0f / (float)B;
   double s1 = 0, s2 = 0, sp = 0, sr = 0;
-  for (int b = blockIdx.x * SAC_WIDE + threadIdx.x; b < B; b += gridDim.x * SAC_WIDE) {
-    const float tv = fminf(tq1[b], tq2[b]) - alpha * logp_next[b];
-    const float qt = rew[b] + (1.0f - term[b]) * gamma * tv;
-    const float e1 = q1[b] - qt, e2 = q2[b] - qt;
-    dq1[b] = 2.0f * e1 * inv_b; dq2[b] = 2.0f * e2 * inv_b;
-    const float a = q1n[b], c = q2n[b];
-    dq1n[b] = -(a < c ? 1.0f : (a == c ? 0.5f : 0.0f)) * inv_b;
-    dq2n[b] = -(c < a ? 1.0f : (a == c ? 0.5f : 0.0f)) * inv_b;
-    s1 += (double)e1 * e1; s2 += (double)e2 * e2; sp += (double)(alpha * logp[b] - fminf(a, c)); sr += (double)rew[b];
+  for (int b0 = threadIdx.x; b0 < B; b0 += R * SAC_WIDE) {
+    if (b0 != (int)threadIdx.x) request(b0);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int b = b0 + j * SAC_WIDE;
+      if (b >= B) break;
+      const float tv = fminf(in[j][0], in[j][1]) - alpha * in[j][2];
+      const float qt = in[j][3] + (1.0f - in[j][4]) * gamma * tv;
+      const float e1 = in[j][5] - qt, e2 = in[j][6] - qt;
+      dq1[b] = 2.0f * e1 * inv_b; dq2[b] = 2.0f * e2 * inv_b;
+      const float a = in[j][7], c = in[j][8];
+      dq1n[b] = -(a < c ? 1.0f : (a == c ? 0.5f : 0.0f)) * inv_b;
+      dq2n[b] = -(c < a ? 1.0f : (a == c ? 0.5f : 0.0f)) * inv_b;
+      s1 += (double)e1 * e1; s2 += (double)e2 * e2; sp += (double)(alpha * in[j][9] - fminf(a, c)); sr += (double)in[j][3];
+    }
   }
   if (x.mom_part && (threadIdx.x >> 6) == (blockDim.x >> 6) - 1) {     // the last wave: no barrier in here
     const int lane = threadIdx.x & 63;
