@@ -18,9 +18,9 @@ class _Rec:
     def finish(self): pass
 
 
-def _sac_run(deferred, opt_times=5, epochs=2):
+def _sac_run(deferred, opt_times=5, epochs=2, n_env=256):
     from test_fullsize_offpolicy_gpu import build_cfg3
-    pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=256)
+    pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=n_env)
     agent.noise_mode, col.noise_mode = "device", "device"
     agent.logger = _Rec()
     agent.opt_times = opt_times
@@ -164,15 +164,16 @@ def test_moments_launch_files_the_statistics_block_into_its_ring_slot():
         _C.moments_multi([(x, torch.zeros(4, dtype=torch.float64, device=DEV), 6, 0, 3, -9.0, 9.0)], ring=(raw, ring, counter))
 
 
-def test_sac_statistics_riding_on_the_update_s_own_launches_equal_the_separate_launches(monkeypatch):
+@pytest.mark.parametrize("n_env", [256, 24])                            # B = 1024, and B = 96: a half-empty statistics wave
+def test_sac_statistics_riding_on_the_update_s_own_launches_equal_the_separate_launches(n_env, monkeypatch):
     """One rank, soft target updates: the temperature step inside the loss launch, the logged moments from per-wave partials
     of the sampling launch folded by the loss launch, the statistics block filed by the Polyak launch -- against
     trl_sac_alpha_step_f32 / trl_moments_multi_ring_f64 as launches of their own.  Same arithmetic for everything that
     feeds back into the update (parameters, targets, alpha bit-identical); the moments are summed in another order."""
     monkeypatch.setenv("TRL_SAC_STAT_LAUNCHES", "1")
-    ia, fa, ta, la = _sac_run(True, epochs=3)
+    ia, fa, ta, la = _sac_run(True, epochs=3, n_env=n_env)
     monkeypatch.setenv("TRL_SAC_STAT_LAUNCHES", "0")
-    ib, fb, tb, lb = _sac_run(True, epochs=3)
+    ib, fb, tb, lb = _sac_run(True, epochs=3, n_env=n_env)
     assert len(ia) == len(ib) == 15
     assert torch.equal(fa, fb) and torch.equal(ta, tb) and torch.equal(la, lb)
     for x, y in zip(ia, ib):

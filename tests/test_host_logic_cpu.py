@@ -132,6 +132,37 @@ def test_args_params_logger(tmp_path):
         Logger("exp", "SynthHalfCheetah-v0", 0, dict(params), str(tmp_path), overwrite=False)
 
 
+def test_statistics_ring_and_index_slab_bookkeeping():
+    """algo/off_policy/_deferred.py on CPU tensors: update u sits in row u % slots; when more updates are launched than
+    unread rows fit, the pending handles are re-pointed at a copy; reads come back in handle order; the index slab is
+    {first update count, sets, idx...}."""
+    from torchrl_amd.algo.off_policy._deferred import IndexSlab, StatRing
+    ring = StatRing(4, 2, torch.float64, "cpu")
+
+    def launch(first, count):                                            # what an engine does around `count` updates
+        ring.make_room(count)
+        for u in range(first, first + count):
+            ring.t[u % 4] = torch.tensor([float(u), -float(u)])          # (the device writes the row; here the host)
+        return ring.handles(first, count)
+    h = launch(0, 3)
+    assert [r for _, r in h] == [0, 1, 2] and ring.read(h).tolist() == [[0, 0], [1, -1], [2, -2]]
+    h1 = launch(3, 3)                                                    # rows 3, 0, 1: everything before was read
+    assert h1[0][0] is h[0][0] and [r for _, r in h1] == [3, 0, 1]
+    h2 = launch(6, 2)                                                    # 3 unread + 2 > 4 rows: h1 moves to a copy
+    assert h2[0][0] is not h1[0][0] and h1[0][0].t is not ring.t and h2[0][0].t is ring.t
+    mixed = [h2[1], h1[0], h1[2], h2[0]]
+    assert ring.read(mixed).tolist() == [[7, -7], [3, -3], [5, -5], [6, -6]]
+    assert ring.read(h2).tolist() == [[6, -6], [7, -7]] and ring.read([]).shape == (0, 2)
+    h3 = launch(8, 4)                                                    # h2 was read in full: no copy needed
+    assert h3[0][0] is h2[0][0] and ring.read(h3)[:, 0].tolist() == [8, 9, 10, 11]
+
+    slab = IndexSlab("cpu")
+    idx = np.arange(12).reshape(3, 4)
+    dev = slab.upload(17, idx)
+    assert dev.dtype == torch.int64 and dev.tolist() == [17, 3] + list(range(12))
+    assert slab.upload(20, idx + 1) is dev and dev[:3].tolist() == [20, 3, 1]
+
+
 def test_logger_takes_deferred_update_infos_in_order(tmp_path):
     """Logger.add_update_infos_later: dicts of launched-but-not-awaited updates are taken when the next dict arrives or the
     next row is written, in arrival order; the row equals the one the immediate calls give."""
