@@ -73,5 +73,9 @@ class IndexSlab:
         host = np.empty(2 + count * nrows, dtype=np.int64)
         host[0], host[1] = int(first), count
         host[2:] = index_sets.reshape(-1)
-        slab.copy_(torch.from_numpy(host))                               # (pageable source: staged before the call returns)
+        # pageable source, asynchronous call: the runtime stages it before returning and the copy itself is stream-ordered
+        # (as BaseReplayBuffer.random_batch uploads its indices); a blocking copy would make the host wait for everything
+        # queued on the stream -- the collection just launched -- before it may launch the update
+        self._staged = torch.from_numpy(host)                            # (kept until the next upload)
+        slab.copy_(self._staged, non_blocking=True)
         return slab
