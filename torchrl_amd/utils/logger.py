@@ -90,6 +90,8 @@ class Logger:
         not waited for; they are taken (in order) when the next row is written or the next dict arrives.  The epoch
         loop can then launch the next rollout before the update's statistics have come back."""
         self._later.append(resolve)
+        if len(self._later) >= 64:                                       # a row is a long way off: do not let the launched
+            self._drain()                                                # updates' device-side statistics pile up
 
     def _drain(self):
         later, self._later = self._later, []
