@@ -9,6 +9,7 @@ the reference's RLAlgo.train loop body does between evaluations
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...          (no launcher: the script spawns its N ranks itself, one per GPU)
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
@@ -58,7 +59,7 @@ class CountingLogger:
     def finish(self): pass
 
 
-def build_agent(dev, world, rank, seed=0):
+def build_agent(dev, world, rank, seed=0, noise_mode="device"):
     import torch
     import torchrl.networks as networks
     import torchrl.policies as policies
@@ -78,7 +79,7 @@ def build_agent(dev, world, rank, seed=0):
     env.seed(seed)
     buf = OnPolicyReplayBuffer(N_PER_GPU * T, env_nums=N_PER_GPU, time_limit_filter=True, device=dev)
     col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev,
-                               epoch_frames=N_PER_GPU * T, max_episode_frames=1000, noise_mode="device")
+                               epoch_frames=N_PER_GPU * T, max_episode_frames=1000, noise_mode=noise_mode)
     agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=OPT_EPOCHS, tau=0.95, shuffle=True,
                 entropy_coeff=0.005, discount=0.99, num_epochs=100000, batch_size=BATCH_PER_GPU, gae=True,
                 env=env, replay_buffer=buf, collector=col, logger=CountingLogger(), device=dev, save_dir=None)
@@ -106,7 +107,6 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
-PARITY_STEPS = 3                                  # iterations timed in the reference-parity exploration mode (host noise)
 FLOP_PER_ENV_STEP = 671e3                         # whole iteration, SURVEY.md section 8(d) (log pi_old cached)
 PROBE_STEPS = 5                                   # iterations of the event-probed pass after a graph-replayed timed region
 
@@ -263,6 +263,19 @@ def cpu_baseline_subprocess(timeout_s=240):
                 "sample": "failed: exceeded %ds on this host" % timeout_s}
 
 
+def _device_map(world):
+    """Device index of every local rank.  Default: rank r on GPU r.  TRL_BENCH_DEVICE_MAP="0,0" (tests) places several ranks
+    on one device -- RCCL refuses that, so the process group is then gloo and the library's communicator runs without RCCL
+    (peer buffers through hipIpc, or torch.distributed with TRL_NO_PEER=1)."""
+    spec = os.environ.get("TRL_BENCH_DEVICE_MAP", "").strip()
+    if not spec:
+        return list(range(world))
+    devs = [int(x) for x in spec.split(",")]
+    if len(devs) < world:
+        raise SystemExit("TRL_BENCH_DEVICE_MAP=%s names %d devices for %d ranks" % (spec, len(devs), world))
+    return devs[:world]
+
+
 def _probe_child():
     """`bench.py --probe-graph-collectives`: a sacrificial process per rank (own rendezvous port) that captures RCCL
     all-reduces of the gradient's size into a HIP graph, replays it and checks the sums.  Exit code 0 = usable."""
@@ -270,6 +283,7 @@ def _probe_child():
     import torch
     import torch.distributed as td
     rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    local = _device_map(world)[local]
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=60))
@@ -319,12 +333,162 @@ def probe_graph_collectives(timeout_s=150):
         return False
 
 
+SPAWN_LIMIT_S = 1200.0                            # the whole multi-rank job, children killed by PID afterwards
+RANK_GUARD_S = 900.0                              # a rank's own guard against a wedged collective
+
+
+def self_spawn(n, argv, script=None):
+    """`python bench.py --gpus N` without a launcher (no RANK / WORLD_SIZE in the environment): this process becomes the
+    launcher -- N children of this same script, one rank per GPU (LOCAL_RANK = rank), a free rendezvous port on
+    127.0.0.1 -- relays rank 0's stdout (the ONE JSON line) and exits with the first non-zero child exit code.  A child
+    that dies takes the others down (a collective would wait for it forever); nothing outlives SPAWN_LIMIT_S."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    log("no launcher environment: spawning %d ranks (rendezvous 127.0.0.1:%d)" % (n, port))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRL_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      text=True if r == 0 else None))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.read().splitlines()), daemon=True)
+    reader.start()
+    deadline, rc = time.time() + SPAWN_LIMIT_S, 0
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            rc = next((c for c in codes if c), 0)
+            break
+        bad = next((c for c in codes if c not in (None, 0)), None)
+        if bad is not None or time.time() > deadline:
+            rc = bad if bad is not None else 3
+            log("rank exit code %s%s: stopping the other ranks" % (rc, "" if bad is not None else " (time limit)"))
+            time.sleep(3.0)                                             # let the survivors report their own error first
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                            # by PID: exactly the children started above
+            break
+        time.sleep(0.1)
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10)
+    for line in lines:
+        print(line, flush=True)
+    return rc
+
+
+def measure_peaks(dev):
+    """the ACHIEVABLE peaks of this box next to the nominal ones -- a 1-GiB 16-byte-access copy kernel
+    (HBM), a register-resident fp32 MFMA issue loop (matrix pipe) and a 4096^3 product on the library's own dense-layer
+    kernel (what a whole GEMM of its inner loop reaches).  A few hundred milliseconds, after the timed region."""
+    import torch
+    from torchrl_amd import _C
+    lib, stream = _C.lib(), _C.stream_ptr(dev)
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) * 1e-3 / reps
+    out = {"nominal": {"hbm_TBps": 8.0, "f32_mfma_TFLOPs": MFMA_F32_PEAK_TFLOPS}}
+    try:
+        n = 1 << 28                                                     # 1 GiB of floats
+        src, dst = torch.empty(n, device=dev).fill_(1.5), torch.empty(n, device=dev)
+        t = timed(lambda: _C.check(lib.trl_peak_copy_f32(src.data_ptr(), dst.data_ptr(), n, stream), "trl_peak_copy_f32"), 3, 10)
+        out["hbm_copy_TBps"] = 2 * 4 * n / t / 1e12
+        del src, dst
+        wgs, iters = 1024, 10000
+        sink = torch.empty(wgs * 256, device=dev)
+        t = timed(lambda: _C.check(lib.trl_peak_mfma_f32(sink.data_ptr(), wgs, iters, stream), "trl_peak_mfma_f32"), 2, 5)
+        out["f32_mfma_TFLOPs"] = wgs * 4 * iters * 4 * 4096 / t / 1e12
+        m = 4096
+        x, w = torch.randn(m, m, device=dev), torch.randn(m, m, device=dev)
+        t = timed(lambda: _C.linear_fwd(x, w, None, _C.ACT_NONE), 2, 5)
+        out["f32_gemm_4096_TFLOPs"] = 2.0 * m * m * m / t / 1e12
+        out["how"] = ("hbm: trl_peak_copy_f32, 1 GiB read + 1 GiB written, 10 launches; mfma: trl_peak_mfma_f32, %d workgroups x 4 "
+                      "waves x %d x 4 v_mfma_f32_32x32x2_f32 from registers; gemm: trl_linear_fwd_f32 4096^3" % (wgs, iters))
+    except Exception as exc:                                            # noqa: BLE001 -- calibration must not cost the line
+        out["error"] = repr(exc)
+    return out
+
+
+SECONDARY = (("sac_cfg3", ["tools/bench_sac.py", "--epochs", "10"], 2.59e6 * 4096 / 1e9),
+             ("dqn_cfg5", ["tools/bench_dqn.py", "--epochs", "4"], 38e6 * 512 / 1e9),
+             ("qrdqn_cfg5", ["tools/bench_dqn.py", "--epochs", "4", "--quantiles", "200"], (4 * 10.9e6 + 12 * 200 * 200) * 512 / 1e9))
+
+
+def secondary_workloads(timeout_s=150):
+    """BASELINE cfg 3 / cfg 5 in the driver-run record: the epochs of tools/bench_{sac,dqn}.py, each in its own interpreter
+    (own device memory, a failure costs its entry only), after the headline's timed region.  roofline_frac = the update's
+    algorithmic FLOPs / ms_per_update / the nominal fp32 matrix peak."""
+    import subprocess
+    out = {}
+    for name, cmd, gflop in SECONDARY:
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run([sys.executable, os.path.join(REPO, cmd[0])] + cmd[1:], timeout=timeout_s,
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith("{")), None)
+            if res.returncode != 0 or line is None:
+                out[name] = {"error": "rc=%d %s" % (res.returncode, res.stderr[-300:])}
+                continue
+            d = json.loads(line)
+            out[name] = {"ms_per_update": d["ms_per_update"], "updates_per_s": d["updates_per_s"],
+                         "env_steps_per_s": d["env_steps_per_s"], "ms_per_vector_step": d["ms_per_vector_step"],
+                         "update_gflop": gflop, "roofline_frac": gflop / d["ms_per_update"] / MFMA_F32_PEAK_TFLOPS,
+                         "workload": d["workload"]}
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "exceeded %ds" % timeout_s}
+        except Exception as exc:                                        # noqa: BLE001
+            out[name] = {"error": repr(exc)}
+        log("secondary %s: %s (%.1f s)" % (name, {k: v for k, v in out[name].items() if k != "workload"}, time.perf_counter() - t0))
+    return out
+
+
+def time_collectives(dist, dev, reps=50):
+    """Stand-alone cost of the three exchanges at their real sizes (C1 44 KB gradient SUM, C2 advantage statistics of 40
+    minibatches, C3 logging statistics), host-timed over `reps` back-to-back calls with one device wait at the end."""
+    import torch
+    g = torch.zeros(11085, device=dev)
+    raw = torch.zeros(40, 4, dtype=torch.float64, device=dev)
+    info = torch.zeros(40, 24, dtype=torch.float64, device=dev)
+    out = {}
+    for name, fn in (("c1_grad_sum_44KB_us", lambda: dist.all_reduce_sum_(g)), ("c2_adv_stats_us", lambda: dist.reduce_adv_raw_(raw)),
+                     ("c3_info_stats_us", lambda: dist.reduce_info_(info))):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        out[name] = 1e6 * (time.perf_counter() - t0) / reps
+    return out
+
+
+PARITY_SLACK = 1.15                               # headline = the reference's noise stream when it costs at most this factor
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg 3 / cfg 5 epochs and the peak calibration")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="ppo", choices=["ppo", "sac", "dqn", "qrdqn"],
                     help="with --cpu-baseline-only: which workload's CPU baseline to time (tools/bench_{sac,dqn}.py)")
@@ -336,21 +500,34 @@ def main():
         res = cpu_baseline() if args.workload == "ppo" else cpu_baseline_offpolicy(args.workload)
         print("CPU_BASELINE " + json.dumps(res), flush=True)
         return
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args.gpus, sys.argv[1:]))   # plain `python bench.py --gpus N`: be the launcher
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and "RANK" in os.environ:
+        log("WORLD_SIZE=%d from the launcher overrides --gpus %d" % (world, args.gpus))
+    devmap = _device_map(max(world, local + 1))
+    local_dev = devmap[local]
+    if local_dev >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants cuda:%d but %d device(s) are visible" % (rank, local_dev, torch.cuda.device_count()))
+    backend, comm_info = None, {}
     forced = os.environ.get("TRL_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ   # 1-GPU smoke test of the RCCL path
-    if args.gpus > 1 or world > 1 or forced:
+    if world > 1 or forced:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local)
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+        torch.cuda.set_device(local_dev)
+        shared = len(set(devmap[:world])) < world                         # several ranks per device (tests): no RCCL
+        backend = "gloo" if shared else "nccl"
+        if shared:
+            td.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
         import threading
-        guard = threading.Timer(900.0, lambda: os._exit(3))           # a wedged collective must not outlive the run
+        guard = threading.Timer(RANK_GUARD_S, lambda: os._exit(3))           # a wedged collective must not outlive the run
         guard.daemon = True
         guard.start()
         # The library's own communicator (include/trl_hip.h, trl_comm_*): RCCL for bandwidth-class messages plus
@@ -359,15 +536,20 @@ def main():
         # single-process one.  Otherwise: RCCL all-reduces, captured into the graph only after child processes have
         # shown that graph-captured collectives work on this node (TRL_GRAPH_COLLECTIVES overrides the probe).
         from torchrl_amd import dist as _dist
-        peers = _dist.init_comm(torch.device("cuda", local))
-        log("peer transport: %s" % ("up (self-check passed on every rank)" if peers else "unavailable -> RCCL all-reduces"))
+        peers = _dist.init_comm(torch.device("cuda", local_dev))
+        comm_info["peer_self_check"] = "passed on every rank" if peers else \
+            ("disabled (TRL_NO_PEER=1)" if os.environ.get("TRL_NO_PEER") == "1" else "failed or unavailable")
+        log("peer transport: %s" % ("up (self-check passed on every rank)" if peers else "unavailable -> all-reduce calls"))
         if not peers and "TRL_GRAPH_COLLECTIVES" not in os.environ:
-            probed = probe_graph_collectives()
-            flag = torch.tensor([1.0 if probed else 0.0], device=torch.device("cuda", local))
-            td.all_reduce(flag, op=td.ReduceOp.MIN)                    # every rank takes the same route
-            os.environ["TRL_GRAPH_COLLECTIVES"] = "1" if flag.item() == 1.0 else "0"
-            log("graph-captured RCCL collectives: %s" % ("on" if flag.item() == 1.0 else "off (probe failed)"))
-    dev = torch.device("cuda", local)
+            if backend == "nccl":
+                probed = probe_graph_collectives()
+                flag = torch.tensor([1.0 if probed else 0.0], device=torch.device("cuda", local_dev))
+                td.all_reduce(flag, op=td.ReduceOp.MIN)                    # every rank takes the same route
+                os.environ["TRL_GRAPH_COLLECTIVES"] = "1" if flag.item() == 1.0 else "0"
+                log("graph-captured RCCL collectives: %s" % ("on" if flag.item() == 1.0 else "off (probe failed)"))
+            else:
+                os.environ["TRL_GRAPH_COLLECTIVES"] = "0"                  # host-staged gloo calls cannot be captured
+    dev = torch.device("cuda", local_dev)
     torch.cuda.set_device(dev)
 
     from torchrl_amd import dist
@@ -380,15 +562,26 @@ def main():
     # the second time and replays it from the third: with fewer than 3 warm-up steps the capture is done here, as
     # set-up, so that the timed region always measures the steady state.
     setup = max(0, 3 - args.warmup) if os.environ.get("TRL_NO_GRAPH") != "1" else 0
+    epoch = [0]
+
+    def run_iterations(n, sync_each=False, note=None):
+        for _ in range(n):
+            iteration(agent, col, epoch[0])
+            epoch[0] += 1
+            if sync_each:
+                torch.cuda.synchronize()
+                if note:
+                    log(note % (epoch[0] - 1))
+
     if world > 1 and dist.peer_ready():
         # Insurance for the peer transport: its first three iterations (stream launches, graph capture, first replay)
         # run guarded.  A rank whose bounded waits trip raises; every rank then votes, and on any failure ALL ranks drop
-        # the peer buffers and continue on RCCL all-reduces with a fresh agent, instead of losing the run.
+        # the peer buffers and continue on all-reduce calls with a fresh agent, instead of losing the run.
         import torch.distributed as td
         ok = 1.0
         try:
-            for e in range(3):
-                iteration(agent, col, e)
+            for _ in range(3):
+                run_iterations(1)
                 agent.logger.drain()                                      # (check_comm runs where the statistics are read)
                 torch.cuda.synchronize()
         except Exception as exc:                                          # noqa: BLE001 -- anything: fall back, loudly
@@ -397,20 +590,20 @@ def main():
         vote = torch.tensor([ok], device=dev)
         td.all_reduce(vote, op=td.ReduceOp.MIN)
         if vote.item() != 1.0:
-            log("falling back to RCCL all-reduces on every rank")
+            log("falling back to all-reduce calls on every rank")
+            comm_info["guarded_iterations"] = "failed on some rank -> fell back to all-reduce calls"
             dist.destroy_comm()
             dist.init_comm(dev, peers=False)
             os.environ.setdefault("TRL_GRAPH_COLLECTIVES", "0")
             agent, col = build_agent(dev, world, rank)
             col.env.reset()
             eng = agent.engine()
+            epoch[0] = 0
             torch.cuda.synchronize()
         else:
+            comm_info["guarded_iterations"] = "3 completed on every rank"
             log("peer transport: three guarded iterations completed on every rank")
-    for e in range(setup):
-        iteration(agent, col, e)
-        torch.cuda.synchronize()
-        log("set-up iteration %d done (graph capture)" % e)
+    run_iterations(setup, True, "set-up iteration %d done (graph capture)")
     # A full (generation 2) collection of the interpreter's heap costs tens of milliseconds with torch loaded -- as long as the
     # whole timed region -- and when one falls due is a matter of allocation counts: the objects alive after set-up are
     # moved out of the collector's reach so that the timed region measures the loop, not the dice (seen in
@@ -420,10 +613,27 @@ def main():
     gc.collect()
     gc.freeze()
     log("warmup x%d" % args.warmup)
-    for e in range(args.warmup):
-        iteration(agent, col, e)
+    run_iterations(args.warmup, True, "warmup iteration %d done")
+
+    def timed_region():
+        """EXACTLY `--steps` iterations between {barrier, device wait} pairs; every iteration's update statistics are read
+        inside (the last ones before the clock stops).  Returns (seconds, per-iteration marks, info dicts read)."""
+        if dist.initialized():
+            torch.distributed.barrier()
         torch.cuda.synchronize()
-        log("warmup iteration %d done" % e)
+        agent.logger.drain()
+        agent.logger.updates = 0
+        t0 = time.perf_counter()
+        marks = [t0]
+        for _ in range(args.steps):
+            run_iterations(1)
+            marks.append(time.perf_counter())
+        agent.logger.drain()                                               # the last iteration's update statistics
+        read = agent.logger.updates
+        torch.cuda.synchronize()
+        if dist.initialized():
+            torch.distributed.barrier()
+        return time.perf_counter() - t0, marks, read
 
     # HIP events around every launch of the dominant kernel, on the stream it is launched on.  One process: the
     # minibatch loop of the timed region replays a captured HIP graph, whose nodes cannot be bracketed by
@@ -432,47 +642,35 @@ def main():
         and os.environ.get("TRL_NO_GRAPH") != "1"
     probes = []
     eng.probe = None if graph_mode else probes
-    if dist.initialized():
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    agent.logger.drain()
-    agent.logger.updates = 0
-    t0 = time.perf_counter()
-    marks = []
-    for e in range(args.steps):
-        iteration(agent, col, args.warmup + e)
-        marks.append(time.perf_counter())                              # (every iteration ends in a host wait already)
-    agent.logger.drain()                                               # the last iteration's update statistics
-    infos_read = agent.logger.updates
-    torch.cuda.synchronize()
-    if dist.initialized():
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    log("timed %d iterations in %.3f s" % (args.steps, elapsed))
-    log("per-iteration ms: " + " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip([t0] + marks[:-1], marks)))
+    elapsed, marks, infos_read = timed_region()
+    log("device-noise mode: timed %d iterations in %.3f s" % (args.steps, elapsed))
+    log("per-iteration ms: " + " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip(marks[:-1], marks[1:])))
     if graph_mode:
         eng.probe = probes
-        for e in range(PROBE_STEPS):
-            iteration(agent, col, args.warmup + args.steps + e)
+        run_iterations(PROBE_STEPS)
         torch.cuda.synchronize()
     eng.probe = None
-    # The reference-parity exploration mode (CPU torch.randn per step, the reference's own stream -- what the parity
-    # tests run) next to the device-Philox headline: the same iteration, PARITY_STEPS times.
-    parity_ms = None
+    # The reference's exploration-noise stream (CPU torch generator, distribution.py:60-76 -- what the parity tests run)
+    # at one rank: the same iteration with the NEXT rollout's block drawn by a host thread while the device works
+    # (collector/on_policy.py::_NoisePrefetcher; bit-identical buffers and parameters to the in-place draws,
+    # tests/test_noise_prefetch_gpu.py).  Timed with the same protocol; it is the headline when it costs <= PARITY_SLACK.
+    device_elapsed, parity_elapsed = elapsed, None
     if world == 1:
-        col.noise_mode = "host"
-        iteration(agent, col, args.warmup + args.steps + PROBE_STEPS)
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        for e in range(PARITY_STEPS):
-            iteration(agent, col, args.warmup + args.steps + PROBE_STEPS + 1 + e)
-        torch.cuda.synchronize()
-        parity_ms = 1e3 * (time.perf_counter() - tp) / PARITY_STEPS
-        col.noise_mode = "device"
+        col.noise_mode, col.prefetch_noise = "host", True
+        run_iterations(2, True)                                            # (first block drawn in place, pipeline primed)
+        parity_elapsed, pmarks, pread = timed_region()
+        log("reference-noise mode: timed %d iterations in %.3f s" % (args.steps, parity_elapsed))
+        log("per-iteration ms: " + " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip(pmarks[:-1], pmarks[1:])))
+        col.stop_noise_prefetch()
+        col.noise_mode, col.prefetch_noise = "device", False
+        if parity_elapsed <= PARITY_SLACK * device_elapsed:
+            elapsed, infos_read = parity_elapsed, pread
+    headline_parity = parity_elapsed is not None and elapsed == parity_elapsed
     if dist.initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce_max_(tmax)
         elapsed = float(tmax.item())
+    coll_us = time_collectives(dist, dev) if (dist.initialized() and dist.collectives_active()) else None
 
     if rank != 0:
         _shutdown_dist()
@@ -482,6 +680,7 @@ def main():
     avg_s = float(np.mean(grad_ms)) * 1e-3 if grad_ms else float("nan")
     flops = FLOP_PER_SAMPLE * BATCH_PER_GPU
     achieved = flops / avg_s / 1e12
+    transport = dist.transport() if dist.collectives_active() else "none (one rank)"
     out = {
         "metric": "env_steps_per_sec_ppo_2048env_halfcheetah_shape",
         "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -491,14 +690,18 @@ def main():
                                "%d opt epochs x %d minibatches of %d, MLP 17-64-64-{6,1} tanh"
                                % (N_PER_GPU, T, OPT_EPOCHS, N_PER_GPU * T // BATCH_PER_GPU, BATCH_PER_GPU),
                    "envs_per_gpu": N_PER_GPU, "rollout_steps": T, "batch_per_gpu": BATCH_PER_GPU,
-                   "opt_epochs": OPT_EPOCHS, "exploration_noise": "device Philox4x32-10",
+                   "opt_epochs": OPT_EPOCHS,
+                   "exploration_noise": ("CPU torch generator = the reference's stream (bit-parity configuration), the next "
+                                         "rollout's block drawn by a host thread while the device works") if headline_parity
+                   else "device Philox4x32-10 keyed by the global env index",
                    "setup_iterations": setup,
                    "update_infos_read_in_timed_region": infos_read,
                    "host_pipeline": "the info dicts of iteration i's updates are read while iteration i+1's rollout runs "
                                     "(the last ones before the clock stops); TRL_EAGER_UPDATE_INFOS=1 reads them in place",
+                   "transport": transport,
                    "parallelism": "env-sharded dp%d, gradient SUM %s" % (
                        world, "inside the fold/clip/Adam launch over peer-mapped xGMI buffers" if dist.peer_ready()
-                       else ("by RCCL all-reduce" if dist.collectives_active() else "not needed (one rank)"))},
+                       else ("by all-reduce calls (%s)" % transport if dist.collectives_active() else "not needed (one rank)"))},
         "roofline": {"bound": "mfma", "kernel": "ppo_grad_wave_kernel<17,64,6,tanh>", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": pmc_traffic(), "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
@@ -507,9 +710,25 @@ def main():
                      "timed_in": ("follow-up pass of %d iterations (the timed region replays a HIP graph)" % PROBE_STEPS)
                      if graph_mode else "the timed region"},
     }
-    if parity_ms is not None:
-        out["parity_mode_ms_per_step"] = parity_ms
-        out["config"]["parity_mode"] = "exploration noise from the CPU torch generator per step (reference stream), %d iterations" % PARITY_STEPS
+    if backend is not None:
+        out["config"]["process_group_backend"] = backend
+        out["config"].update(comm_info)
+        out["config"]["collective_us"] = coll_us
+        if os.environ.get("TRL_BENCH_SPAWNED") == "1":
+            out["config"]["launcher"] = "bench.py spawned its own ranks"
+    if parity_elapsed is not None:
+        out["device_noise_ms_per_step"] = 1e3 * device_elapsed / args.steps
+        out["parity_mode_ms_per_step"] = 1e3 * parity_elapsed / args.steps
+        out["config"]["headline_mode"] = "parity" if headline_parity else \
+            "device (the reference-noise mode cost more than %.2fx on this host)" % PARITY_SLACK
+        out["config"]["parity_mode"] = ("exploration noise from the CPU torch generator (reference stream, prefetched one rollout "
+                                        "ahead), %d iterations timed like the headline" % args.steps)
+    if world == 1 and not args.no_secondary:
+        out["peaks_measured"] = measure_peaks(dev)
+        mf = out["peaks_measured"].get("f32_mfma_TFLOPs")
+        if mf:
+            out["roofline"]["frac_of_measured_peak"] = achieved / mf
+        out["secondary"] = secondary_workloads()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_subprocess()
     print(json.dumps(out))

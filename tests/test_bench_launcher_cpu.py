@@ -1,0 +1,56 @@
+"""bench.py's own launcher (`python bench.py --gpus N` with no RANK / WORLD_SIZE in the environment): rank environment,
+relay of rank 0's line, exit-code propagation, and that a dead rank stops the job -- with stub children, no GPU."""
+import contextlib
+import importlib.util
+import io
+import os
+import textwrap
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+STUB = textwrap.dedent('''
+    import os, sys, time
+    r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+    assert os.environ["LOCAL_RANK"] == str(r) and os.environ["LOCAL_WORLD_SIZE"] == str(w)
+    assert not [k for k in os.environ if k.startswith("TORCHELASTIC_")]
+    mode = sys.argv[1]
+    if mode == "ok":
+        time.sleep(0.2 * r)
+        print('{"n_gpus": %d}' % w if r == 0 else "only rank 0 is relayed")
+    elif mode == "die" and r == 1:
+        sys.exit(7)
+    else:
+        time.sleep(120)
+''')
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_self_spawn_relays_rank0_and_propagates_exit_codes(tmp_path, monkeypatch):
+    bench = _bench_module()
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "stale")                    # a launcher's leftovers must not reach the ranks
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        rc = bench.self_spawn(3, ["ok"], script=str(stub))
+    assert rc == 0 and out.getvalue() == '{"n_gpus": 3}\n'
+    out, t0 = io.StringIO(), time.time()
+    with contextlib.redirect_stdout(out):
+        rc = bench.self_spawn(3, ["die"], script=str(stub))
+    assert rc == 7 and out.getvalue() == "" and time.time() - t0 < 30      # the sleeping ranks were stopped
+
+
+def test_device_map(monkeypatch):
+    bench = _bench_module()
+    monkeypatch.delenv("TRL_BENCH_DEVICE_MAP", raising=False)
+    assert bench._device_map(4) == [0, 1, 2, 3]
+    monkeypatch.setenv("TRL_BENCH_DEVICE_MAP", "0,0")
+    assert bench._device_map(2) == [0, 0]

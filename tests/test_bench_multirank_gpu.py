@@ -1,0 +1,60 @@
+"""bench.py itself at N > 1 on ONE GPU (BASELINE cfg 4's launch path): plain `python bench.py --gpus 2`
+with no launcher environment must spawn its own ranks, rendezvous, run the env-sharded iteration and print ONE valid JSON
+line.  Both ranks are pinned to cuda:0 through the test-only TRL_BENCH_DEVICE_MAP; RCCL refuses two ranks per device, so
+the process group is gloo and the two routes below are what a single GPU can exercise: the library's peer transport
+(hipIpc-mapped buffers, gradient SUM inside the fold / clip / Adam launch) and the torch.distributed fallback."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_env, gpus=2):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(TRL_BENCH_DEVICE_MAP="0,0", **extra_env)
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "3",
+                          "--no-cpu-baseline", "--no-secondary"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                       # rank 0 prints ONE line, the other rank nothing
+    return json.loads(lines[0]), res.stderr
+
+
+def test_plain_python_two_ranks_over_the_peer_transport():
+    out, err = _bench({})
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    cfg = out["config"]
+    assert cfg["transport"] == "peer", (cfg, err[-2000:])
+    assert cfg["peer_self_check"].startswith("passed") and cfg["guarded_iterations"].startswith("3 completed")
+    assert cfg["process_group_backend"] == "gloo" and cfg["launcher"].startswith("bench.py spawned")
+    assert out["value"] > 0 and abs(out["value"] - 2 * 2048 * 128 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert all(v > 0 for v in cfg["collective_us"].values())
+    assert out["roofline"]["launches_timed"] > 0 and 0 < out["roofline"]["frac"] < 1
+
+
+def test_plain_python_two_ranks_on_the_all_reduce_fallback():
+    out, err = _bench({"TRL_NO_PEER": "1"})
+    cfg = out["config"]
+    assert out["n_gpus"] == 2
+    assert cfg["transport"] == "torch.distributed:gloo", (cfg, err[-2000:])
+    assert cfg["peer_self_check"].startswith("disabled")
+    assert all(v > 0 for v in cfg["collective_us"].values())
+
+
+def test_a_rank_that_dies_takes_the_job_down_with_its_exit_code():
+    """Three ranks mapped onto two devices of which only one exists: rank 2 exits before the rendezvous completes; the
+    launcher must stop the others and return non-zero instead of waiting for a collective forever."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(TRL_BENCH_DEVICE_MAP="0,0,63")
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-secondary"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert res.returncode != 0
+    assert "wants cuda:63" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

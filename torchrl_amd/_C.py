@@ -215,6 +215,8 @@ SIGNATURES = {
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_peak_copy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "trl_peak_mfma_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "trl_adv_normalize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "trl_trpo_surrogate_workspace": (C.c_int, [C.c_int] * 2),
     "trl_trpo_surrogate_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float] + [C.c_void_p] * 5),
@@ -313,6 +315,38 @@ def capture_graph(launches):
         if was_enabled:
             gc.enable()
     return graph, out
+
+
+class PinnedStager:
+    """Small host -> device uploads by a host that runs AHEAD of the device (replayed graphs: whole epochs).  An
+    asynchronous copy reads its page-locked source when the stream gets there, not when it is issued, so a single staging
+    buffer rewritten for the next upload races with the previous one.  `depth` buffers in rotation, each with the event of
+    its last copy: `stage()` hands out the next buffer once that copy has been executed (normally long ago), `upload(dst)`
+    issues the copy and records the event.  The buffers live as long as the stager (nothing page-locked is ever freed
+    while a stream captures, see capture_graph)."""
+
+    def __init__(self, nelem, dtype, depth=4):
+        pin = torch.cuda.is_available()
+        self._bufs = [torch.zeros(int(nelem), dtype=dtype) for _ in range(depth)]
+        if pin:
+            self._bufs = [b.pin_memory() for b in self._bufs]
+        self._events, self._k = [None] * depth, 0
+
+    def stage(self):
+        ev = self._events[self._k]
+        if ev is not None:
+            ev.synchronize()
+        return self._bufs[self._k]
+
+    def upload(self, dst):
+        k = self._k
+        dst.copy_(self._bufs[k], non_blocking=True)
+        if dst.is_cuda:
+            ev = self._events[k] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dst.device))
+            self._events[k] = ev
+        self._k = (k + 1) % len(self._bufs)
+        return dst
 
 
 # ------------------------------------------------------------------ thin op wrappers

@@ -63,19 +63,20 @@ class IndexSlab:
     update count."""
 
     def __init__(self, device):
-        self.device, self._bufs = device, {}
+        self.device, self._bufs, self._stagers = device, {}, {}
 
     def upload(self, first, index_sets):
+        from ... import _C
         count, nrows = index_sets.shape
-        if (count, nrows) not in self._bufs:
-            self._bufs[(count, nrows)] = torch.zeros(2 + count * nrows, dtype=torch.int64, device=self.device)
-        slab = self._bufs[(count, nrows)]
-        host = np.empty(2 + count * nrows, dtype=np.int64)
+        key = (count, nrows)
+        if key not in self._bufs:
+            self._bufs[key] = torch.zeros(2 + count * nrows, dtype=torch.int64, device=self.device)
+            self._stagers[key] = _C.PinnedStager(2 + count * nrows, torch.int64)
+        slab = self._bufs[key]
+        # page-locked staging buffers in rotation, asynchronous copy: the host never waits for what is queued on the stream
+        # (the collection just launched) before it may launch the update, and a host that runs epochs ahead of the device
+        # does not overwrite a slab whose copy has not been executed yet (_C.PinnedStager)
+        host = self._stagers[key].stage().numpy()
         host[0], host[1] = int(first), count
         host[2:] = index_sets.reshape(-1)
-        # pageable source, asynchronous call: the runtime stages it before returning and the copy itself is stream-ordered
-        # (as BaseReplayBuffer.random_batch uploads its indices); a blocking copy would make the host wait for everything
-        # queued on the stream -- the collection just launched -- before it may launch the update
-        self._staged = torch.from_numpy(host)                            # (kept until the next upload)
-        slab.copy_(self._staged, non_blocking=True)
-        return slab
+        return self._stagers[key].upload(slab)

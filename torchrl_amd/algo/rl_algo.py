@@ -74,8 +74,10 @@ class RLAlgo:
     def snapshot(self, prefix, epoch):
         """rl_algo.py:83-94.  With one process per GPU every rank holds identical parameters: rank 0 writes.  Parameters
         are views of one flat buffer here, so each tensor is cloned -- a .pth holds that network only."""
-        if prefix is None or int(os.environ.get("RANK", "0")) != 0:
-            return
+        from .. import dist
+        if prefix is None or dist.rank() != 0:                            # (rank of THIS package's process group: a process that
+            return                                                     # merely inherited RANK != 0 still writes its files)
+        dist.check_comm()                                              # never snapshot parameters stepped with a partial gradient sum
         normalizer = getattr(self.env, "_obs_normalizer", None)
         if normalizer is not None:
             with open(os.path.join(prefix, "_obs_normalizer_%s.pkl" % (epoch,)), "wb") as handle:
@@ -112,6 +114,11 @@ class RLAlgo:
         self.start = time.time()
 
     def train(self):
+        # This loop is the reference's (rl_algo.py:96-164): between two rollouts nothing draws from the CPU torch generator
+        # (updates and greedy evaluation are deterministic given the batch), so an on-policy collector in the reference's
+        # noise mode may draw the next rollout's exploration noise while the device is busy (TRL_PREFETCH_NOISE=0: in place)
+        if hasattr(self.collector, "prefetch_noise") and os.environ.get("TRL_PREFETCH_NOISE") != "0":
+            self.collector.prefetch_noise = True
         self.pretrain()
         total_frames = getattr(self, "pretrain_frames", 0)
         self.start_epoch()

@@ -393,11 +393,11 @@ class VecCollector(_CollectorBase):
                 buf._ensure_key("rewards", (n, 1)), buf._ensure_key("terminals", (n, 1)), buf._ensure_key("time_limits", (n, 1))]
         if getattr(self, "_dyn", None) is None:
             self._dyn = torch.zeros(4, dtype=torch.int64, device=env.device)
-            self._dyn_host = torch.zeros(4, dtype=torch.int64).pin_memory()
+            self._dyn_stager = _C.PinnedStager(4, torch.int64)              # (the host may be epochs ahead of the device)
             self._step_graph, self._step_key, self._step_seen = None, None, None
-        self._dyn_host[0], self._dyn_host[1], self._dyn_host[2], self._dyn_host[3] = \
-            self.global_step, buf._top, self._log_step0, 0
-        self._dyn.copy_(self._dyn_host, non_blocking=True)                 # one 32-byte upload per epoch
+        host = self._dyn_stager.stage()
+        host[0], host[1], host[2], host[3] = self.global_step, buf._top, self._log_step0, 0
+        self._dyn_stager.upload(self._dyn)                                 # one 32-byte upload per epoch
         key = tuple(t.data_ptr() for t in ring) + (env.cur_obs.data_ptr(), n, d, a_dim, int(self.max_episode_frames),
                                                    bool(pf.tanh_action), int(env.horizon), n_steps)
 

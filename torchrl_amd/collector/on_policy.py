@@ -13,7 +13,13 @@ Exploration noise:
     step from the CPU generator -- the reference's own stream (its Q5) --
     uploaded as a (T, N, A) tensor;
   * noise_mode="device": Philox4x32-10 in the kernel keyed by (env seed, global
-    step) -- statistically equivalent, no host work; what bench.py uses.
+    step) -- statistically equivalent, no host work.
+  * `prefetch_noise=True` (host mode): the NEXT rollout's (T, N, A) block is drawn by
+    a worker thread into page-locked memory and uploaded on a side stream while the
+    current iteration runs on the device -- the same values in the same order from
+    the same generator (nothing else on this path draws from it between two
+    rollouts, torchrl/algo/on_policy/ppo.py:27-152), just earlier; what bench.py's
+    headline uses.  See _NoisePrefetcher.
 """
 import copy
 import os
@@ -26,12 +32,126 @@ from .. import dist
 from .base import VecCollector, BaseCollector, _EpochResult
 
 
+class _NoisePrefetcher:
+    """The reference's exploration-noise stream (CPU torch generator, distribution.py:60-76) one rollout ahead.
+
+    `take(T, N, A)` returns the device tensor of this rollout's draws and immediately starts the draw of the NEXT block of
+    the same shape: a worker thread fills a page-locked buffer with `torch.randn(out=...)` (the op releases the
+    interpreter lock; ~3 ms of host time for 128 x 2048 x 6 that would otherwise sit between two iterations), copies it
+    to one of two device buffers on a side stream and records an event the consuming rollout's stream waits on.  The
+    draw depends on nothing the GPU produces, so the stream of values is the un-prefetched one, bit for bit.
+
+    Guard: the generator state right after the prefetched draw is remembered; if the state found at `take` differs --
+    someone seeded the generator or drew from it in between -- the prefetched block is dropped and the block is drawn
+    in place from the current state, exactly like the un-prefetched path (for a re-seed that IS the reference order).
+    `close()` (or a shape change) drops a pending block the same way and rewinds the generator to where it was before
+    the speculative draw, so an abandoned prefetch leaves no trace in the stream."""
+
+    def __init__(self, device):
+        import threading
+        self.device = torch.device(device)
+        self._side = torch.cuda.Stream(self.device)
+        self._lock = threading.Lock()
+        self._job = None                                   # dict(thread, shape, slot, state0, state1, event, error)
+        self._host, self._dev, self._free = {}, {}, {}
+        self._slot = 0
+
+    def _buffers(self, shape, slot):
+        key = (shape, slot)
+        if key not in self._dev:
+            n = int(np.prod(shape))
+            self._host[key] = torch.empty(n).pin_memory()
+            self._dev[key] = torch.empty(shape, device=self.device)
+        return self._host[key], self._dev[key]
+
+    def _draw_into(self, shape, slot):
+        """Draw into the page-locked buffer of `slot`, upload on the side stream; returns (device tensor, event)."""
+        host, dev = self._buffers(shape, slot)
+        free = self._free.get((shape, slot))
+        if free is not None:
+            free.synchronize()                              # the rollout that read this slot two blocks ago has finished
+        # one (T * N, A) draw == T successive (N, A) draws when N * A is a multiple of 16 (see _host_noise)
+        torch.randn(shape[0] * shape[1], shape[2], out=host.view(shape[0] * shape[1], shape[2]))
+        with torch.cuda.stream(self._side):
+            dev.copy_(host.view(shape), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return dev, ev
+
+    def _start(self, shape):
+        import threading
+        slot = self._slot
+        self._slot ^= 1
+        job = {"shape": shape, "slot": slot, "state0": torch.get_rng_state(), "state1": None, "out": None, "error": None}
+
+        def work():
+            try:
+                job["out"] = self._draw_into(shape, slot)
+                job["state1"] = torch.get_rng_state()
+            except BaseException as exc:                    # noqa: BLE001 -- reported by the consumer
+                job["error"] = exc
+        job["thread"] = threading.Thread(target=work, name="trl-noise-prefetch", daemon=True)
+        self._job = job
+        job["thread"].start()
+
+    def _drop(self, rewind):
+        job, self._job = self._job, None
+        if job is None:
+            return
+        job["thread"].join()
+        if rewind and job["state1"] is not None and torch.equal(torch.get_rng_state(), job["state1"]):
+            torch.set_rng_state(job["state0"])             # nobody drew after the speculative block: give it back
+
+    def take(self, n_steps, n, a_dim, stream):
+        shape = (int(n_steps), int(n), int(a_dim))
+        job = self._job
+        out = None
+        if job is not None:
+            job["thread"].join()
+            self._job = None
+            if job["error"] is not None:
+                raise job["error"]
+            if job["shape"] == shape and torch.equal(torch.get_rng_state(), job["state1"]):
+                out = job["out"]
+                used = job["slot"]
+            elif torch.equal(torch.get_rng_state(), job["state1"]):
+                torch.set_rng_state(job["state0"])         # other shape, untouched generator: undo the speculative draw
+        if out is None:                                     # first call / generator touched in between: draw in place
+            used = self._slot
+            self._slot ^= 1
+            out = self._draw_into(shape, used)
+        dev, ev = out
+        stream.wait_event(ev)
+        self._start(shape)                                  # the next block, under this iteration's device work
+        return dev, used
+
+    def release(self, shape, slot, stream):
+        """Call after the rollout that reads `slot` has been enqueued on `stream`."""
+        ev = self._free.get((shape, slot)) or torch.cuda.Event()
+        ev.record(stream)
+        self._free[(shape, slot)] = ev
+
+    def close(self):
+        self._drop(rewind=True)
+
+
 class VecOnPolicyCollector(VecCollector):
-    def __init__(self, vf, discount=0.99, noise_mode="host", **kwargs):
+    def __init__(self, vf, discount=0.99, noise_mode="host", prefetch_noise=False, **kwargs):
         self.vf = vf
         super().__init__(noise_mode=noise_mode, **kwargs)
         self.discount = discount
+        self.prefetch_noise = bool(prefetch_noise) or os.environ.get("TRL_PREFETCH_NOISE") == "1"
+        self._prefetcher = None
         self._check_shapes()
+
+    def stop_noise_prefetch(self):
+        """Drop a speculatively drawn block and rewind the CPU generator to where the un-prefetched path would be."""
+        if self._prefetcher is not None:
+            self._prefetcher.close()
+
+    def terminate(self):
+        self.stop_noise_prefetch()
+        super().terminate()
 
     @property
     def funcs(self):
@@ -143,6 +263,12 @@ class VecOnPolicyCollector(VecCollector):
             return torch.randn(n_steps * n, A).view(n_steps, n, A).to(env.device, non_blocking=True).contiguous()
         draws = [dist.shard_rows_of_global(make, 1, n, A, "cpu").cpu() for _ in range(n_steps)]
         return torch.stack(draws).to(env.device, non_blocking=True).contiguous()
+
+    def _can_prefetch(self, n_steps):
+        """Prefetch covers what the one-block draw covers: one rank, N * A a multiple of 16 (see _host_noise), and whole
+        rollouts (a one-step take_actions keeps the per-step draw)."""
+        return (self.prefetch_noise and dist.world_size() == 1 and n_steps > 1
+                and (self.env.env_nums * self._dims[1]) % 16 == 0)
 
     # ---- per-step launch sequence: envs with a running observation normaliser ----
     def _step_buffers(self, env):
@@ -275,8 +401,17 @@ class VecOnPolicyCollector(VecCollector):
             self.current_ob = ob
             self._check_rendezvous = True                       # read with the epoch header (no sync here)
             return
-        noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
+        slot = None
+        if self.noise_mode == "host" and self._can_prefetch(n_steps):
+            if self._prefetcher is None:
+                self._prefetcher = _NoisePrefetcher(self.env.device)
+            stream = torch.cuda.current_stream(self.env.device)
+            noise, slot = self._prefetcher.take(n_steps, self.env.env_nums, self._dims[1], stream)
+        else:
+            noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
         self._launch(self.env, n_steps, True, False, noise)
+        if slot is not None:
+            self._prefetcher.release(tuple(noise.shape), slot, stream)
         self.global_step += n_steps
         self.current_ob = self.env.cur_obs
 

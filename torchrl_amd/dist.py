@@ -79,6 +79,19 @@ def peer_ready():
     return _comm is not None and _peer_ok
 
 
+def transport():
+    """Which route the small exchanges (C1-C3) take: "peer" (hipIpc / xGMI-mapped buffers, plain kernel launches), "rccl"
+    (the library's RCCL communicator; torch.distributed's one while a stream captures), "torch.distributed:<backend>", or
+    "none"."""
+    if not _active():
+        return "none"
+    if peer_ready():
+        return "peer"
+    if _comm is not None and _has_rccl:
+        return "rccl"
+    return "torch.distributed:%s" % td.get_backend()
+
+
 def _all_agree(flag):
     votes = [None] * world_size()
     td.all_gather_object(votes, bool(flag))

@@ -49,7 +49,14 @@ class Logger:
 
         self.work_dir = os.path.join(log_dir, experiment_id, env_name, str(seed))
         # one process per GPU: only rank 0 touches the log directory (every rank holds the same global statistics)
-        self.is_writer = int(os.environ.get("RANK", "0")) == 0
+        # -- the rank of the torch.distributed group this package shards over, not the raw RANK variable: an independent
+        # run started under a launcher (a seed sweep under torchrun / SLURM) is no shard and keeps its logs and snapshots
+        from .. import dist
+        self.is_writer = dist.rank() == 0
+        if not dist.initialized() and os.environ.get("RANK", "0") not in ("", "0"):
+            self.logger.warning("RANK=%s is set but no torch.distributed process group exists: this process writes its "
+                                "own logs and snapshots (initialise the group before building the Logger to shard)",
+                                os.environ["RANK"])
         if self.is_writer:
             if os.path.exists(self.work_dir):
                 assert overwrite, "Experiment Exists and Did not set overwrite"
