@@ -729,10 +729,11 @@ int trl_norm_filt_f32(const float* x, const double* state, float* out, int N, in
 
 /* --- calibration of the two rooflines (nominal AND achievable peaks) -------------------
  * No reference counterpart (the reference publishes no measurement); run by bench.py after its timed
- * region.  trl_peak_copy_f32: dst[0..n) = src[0..n) with 16-byte accesses on every CU (HBM bytes moved = 8 n).
+ * region.  trl_peak_copy_f32: dst[0..n) = src[0..n) with 16-byte accesses on every CU (HBM bytes moved = 8 n); mode 0 / 1:
+ * one 16 KB piece per workgroup with plain / non-temporal accesses, mode 2: persistent grid-stride (the caller quotes the best).
  * trl_peak_mfma_f32: `workgroups` x 4 waves each issue `iters` x 4 independent v_mfma_f32_32x32x2_f32 from registers
  * (FLOPs = workgroups * 4 * iters * 4 * 4096); out: workgroups * 256 floats (sink). */
-int trl_peak_copy_f32(const float* src, float* dst, int64_t n, void* stream);
+int trl_peak_copy_f32(const float* src, float* dst, int64_t n, int mode, void* stream);
 int trl_peak_mfma_f32(float* out, int workgroups, int iters, void* stream);
 
 #ifdef __cplusplus

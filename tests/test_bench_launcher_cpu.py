@@ -18,6 +18,7 @@ STUB = textwrap.dedent('''
     mode = sys.argv[1]
     if mode == "ok":
         time.sleep(0.2 * r)
+        print("[Gloo] a library's banner on stdout")
         print('{"n_gpus": %d}' % w if r == 0 else "only rank 0 is relayed")
     elif mode == "die" and r == 1:
         sys.exit(7)

@@ -78,27 +78,38 @@ class _NoisePrefetcher:
             ev.record(self._side)
         return dev, ev
 
-    def _start(self, shape):
-        import threading
-        slot = self._slot
-        self._slot ^= 1
-        job = {"shape": shape, "slot": slot, "state0": torch.get_rng_state(), "state1": None, "out": None, "error": None}
-
-        def work():
+    def _worker(self):
+        """One long-lived thread (no thread start per rollout): takes a job, draws, signals."""
+        while True:
+            job = self._queue.get()
+            if job is None:
+                return
             try:
-                job["out"] = self._draw_into(shape, slot)
+                job["out"] = self._draw_into(job["shape"], job["slot"])
                 job["state1"] = torch.get_rng_state()
             except BaseException as exc:                    # noqa: BLE001 -- reported by the consumer
                 job["error"] = exc
-        job["thread"] = threading.Thread(target=work, name="trl-noise-prefetch", daemon=True)
+            job["done"].set()
+
+    def _start(self, shape):
+        import queue
+        import threading
+        if getattr(self, "_thread", None) is None:
+            self._queue = queue.SimpleQueue()
+            self._thread = threading.Thread(target=self._worker, name="trl-noise-prefetch", daemon=True)
+            self._thread.start()
+        slot = self._slot
+        self._slot ^= 1
+        job = {"shape": shape, "slot": slot, "state0": torch.get_rng_state(), "state1": None, "out": None, "error": None,
+               "done": threading.Event()}
         self._job = job
-        job["thread"].start()
+        self._queue.put(job)
 
     def _drop(self, rewind):
         job, self._job = self._job, None
         if job is None:
             return
-        job["thread"].join()
+        job["done"].wait()
         if rewind and job["state1"] is not None and torch.equal(torch.get_rng_state(), job["state1"]):
             torch.set_rng_state(job["state0"])             # nobody drew after the speculative block: give it back
 
@@ -107,7 +118,7 @@ class _NoisePrefetcher:
         job = self._job
         out = None
         if job is not None:
-            job["thread"].join()
+            job["done"].wait()
             self._job = None
             if job["error"] is not None:
                 raise job["error"]
