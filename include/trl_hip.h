@@ -322,17 +322,6 @@ int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, in
                             const trl_adam_t* adam, float* workspace, void* stream);
 
 typedef struct trl_comm trl_comm_t;   /* opaque communicator, see the collectives section below */
-/* Fused step: trl_ppo_minibatch_grad_f32 followed by trl_ppo_reduce_adam_f32 (comm == NULL) or
- * trl_ppo_reduce_adam_xrank_f32 (comm with mapped peers) as ONE launch per minibatch: the gradient workgroups
- * publish their partial rows inside the launch (write-through stores + epoch flags) and the first
- * 2 x ceil(P / 64) of them become the reducers.  Same arithmetic and summation orders as the two-launch
- * sequence; needs n_wg <= number of CUs (every workgroup resident).  workspace: trl_ppo_step_workspace(D, H, A,
- * n_wg) floats, zeroed once, then owned by this entry point (header as in trl_adam_t.device_state; ws[0] != 0
- * after a launch: a bounded wait inside it timed out). */
-int trl_ppo_step_workspace(int D, int H, int A, int n_wg);
-int trl_ppo_step_f32(const trl_ppo_batch_t* batch, float* grads, double* info, const trl_adam_t* adam,
-                     float* workspace, trl_comm_t* comm, void* stream);
-
 /* --- C1 / C2 / C3: collectives of the multi-GPU path ---------------
  * The reference has no distributed backend; with envs sharded by index over one process per GPU
  * these are the calls its update loop makes between backward and clip_grad_norm_

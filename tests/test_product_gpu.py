@@ -293,28 +293,3 @@ def test_graph_replay_matches_eager_launches(golden, monkeypatch):
     (f0, m0, v0, i0), (f1, m1, v1, i1) = results
     assert torch.equal(f0, f1) and torch.equal(m0, m1) and torch.equal(v0, v1)
     assert len(i0) == len(i1) and all(a == b for a, b in zip(i0, i1))
-
-
-def test_fused_step_launch_equals_two_launch_sequence(golden, monkeypatch):
-    """TRL_PPO_STEP=1: gradient + fold + clip + Adam as ONE launch per minibatch (trl_ppo_step_f32: partial rows published
-    inside the launch, the first workgroups become the reducers).  Same arithmetic and summation orders as
-    trl_ppo_minibatch_grad_f32 + trl_ppo_reduce_adam_f32, so parameters and logged statistics are bit-identical."""
-    g = golden("collect_epoch")
-    tag = "small"
-    N, T, horizon, max_frames, B, seed = (int(x) for x in g[f"{tag}_args"])
-    out = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("TRL_PPO_STEP", mode)
-        pf, vf, env, buf, col, agent, logger = build(g, tag, N, T, horizon, max_frames, B, seed)
-        torch.manual_seed(seed)
-        for epoch in range(3):                                       # eager, captured, replayed
-            col.train_one_epoch()
-            agent.current_epoch = epoch
-            np.random.seed(seed + epoch)
-            agent.update_per_epoch()
-        eng = agent.engine()
-        assert int(eng.red_ws[:1].view(torch.int32).item()) == 0     # no bounded wait timed out
-        out.append((eng.flat.cpu().clone(), [dict(i) for i in logger.infos]))
-    (fa, ia), (fb, ib) = out
-    assert torch.equal(fa, fb)
-    assert ia == ib

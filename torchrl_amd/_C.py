@@ -145,8 +145,6 @@ SIGNATURES = {
     "trl_allreduce_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "trl_ppo_reduce_adam_xrank_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                 C.c_void_p, C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
-    "trl_ppo_step_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "trl_ppo_step_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_select_on_mask_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "trl_norm_update_filt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "trl_norm_batch_moments_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -148,9 +148,8 @@ class _FusedPPO:
         self.max_wg = 2 * max(1, self.n_cu // 2)
         self.partial = torch.zeros(self.max_wg, self.p_stride, device=self.dev)
         self.scal = torch.zeros(self.max_wg, 8, dtype=torch.float64, device=self.dev)
-        n_ws = max(_C.lib().trl_ppo_reduce_adam_workspace(self.D, self.H, self.A),
-                   _C.lib().trl_ppo_step_workspace(self.D, self.H, self.A, self.max_wg))
-        self.red_ws = torch.zeros(n_ws, device=self.dev)              # header + norm slots (+ row flags) of the fused reduce/Adam
+        n_ws = _C.lib().trl_ppo_reduce_adam_workspace(self.D, self.H, self.A)
+        self.red_ws = torch.zeros(n_ws, device=self.dev)              # header + norm slots of the fused reduce/Adam
         self.red_ws[4:8].view(torch.float64).fill_(1.0)               # beta1^0, beta2^0 (device-side Adam state)
 
     def _alias_optimizer_state(self, opt, plist, offset):
@@ -240,7 +239,7 @@ class _FusedPPO:
         # Env shards on several ranks with the peer transport up (dist.init_comm): the gradient SUM over ranks happens
         # INSIDE the fold / clip / Adam launch (trl_ppo_reduce_adam_xrank_f32) and the statistics go through the
         # one-kernel all-reduce -- plain launches, so the sequence is graph-replayed exactly like the single-process one.
-        xrank = not fused and dist.peer_ready() and os.environ.get("TRL_NO_XRANK") != "1"
+        xrank = not fused and dist.peer_ready()
         # TRL_GRAPH_COLLECTIVES=1 (opt-in, RCCL route): capture the multi-rank sequence -- RCCL all-reduces included -- into
         # the HIP graph as well; the Adam step count and learning rates then live on the device like in the fused launch.
         graph_coll = not fused and not xrank and os.environ.get("TRL_GRAPH_COLLECTIVES") == "1"
@@ -257,13 +256,8 @@ class _FusedPPO:
                 self.lr_dev.copy_(torch.tensor(self._lr_host, dtype=torch.float32), non_blocking=True)
         hyper = (float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
                  int(bool(getattr(algo, "clipped_value_loss", False))), int(bool(algo.pf.tanh_action)))
-        # TRL_PPO_STEP=1 (opt-in): one launch per minibatch -- the gradient workgroups turn into the reducers
-        # (trl_ppo_step_f32).  Measured on MI355X at the benchmark shape it is SLOWER than the two launches
-        # (3.17-3.18 vs 3.13-3.14 ms per iteration, A/B in one session): the in-launch hand-off of 256 x 23 KB
-        # write-through partial rows costs more than the kernel boundary and the launch ramp it removes.
-        one_launch = (fused or xrank) and os.environ.get("TRL_PPO_STEP", "0") == "1" and n_wg <= self.n_cu
         use_graph = (fused or xrank or graph_coll) and probe is None and os.environ.get("TRL_NO_GRAPH") != "1"
-        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, xrank, one_launch) + hyper + tuple(
+        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, xrank) + hyper + tuple(
             0 if t.get(k) is None else t[k].data_ptr() for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
 
         def launch_all():
@@ -301,17 +295,10 @@ class _FusedPPO:
                 if probe is not None:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
-                if one_launch:
-                    _C.check(lib.trl_ppo_step_f32(C.byref(g), self.grads.data_ptr(), info_base + 192 * k, C.byref(a),
-                                                  self.red_ws.data_ptr(), dist.comm_handle() if xrank else None, stream),
-                             "trl_ppo_step_f32")
-                else:
-                    _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "trl_ppo_minibatch_grad_f32")
+                _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "trl_ppo_minibatch_grad_f32")
                 if probe is not None:
                     ev[1].record()
                     probe.append(ev)
-                if one_launch:
-                    continue
                 if fused:                                              # one process: reduce + clip + Adam in one launch
                     _C.check(lib.trl_ppo_reduce_adam_f32(self.partial.data_ptr(), self.scal.data_ptr(), n_wg, n_wg_pf,
                                                          self.D, self.H, self.A, self.grads.data_ptr(), info_base + 192 * k,

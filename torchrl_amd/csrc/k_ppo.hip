@@ -88,12 +88,8 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
-// PUBLISH (fused step kernel): the workgroup's partial row and statistics are stored WRITE-THROUGH (sc1, 16 bytes per
-// lane) and announced with an epoch flag, so that other workgroups of the SAME launch can fold them
-// (cdna_hip_programming.md Guideline 16, form R1); otherwise plain stores, consumed by the next launch.
-template <int D, int H, int A, int ACT, bool IS_PF, bool CONTIG, bool PUBLISH = false>
-__device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net, unsigned* pub_flags = nullptr,
-                              unsigned pub_epoch = 0u) {
+template <int D, int H, int A, int ACT, bool IS_PF, bool CONTIG>
+__device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
   constexpr int O = IS_PF ? A : 1;
   using S = WvShape<D, H, A>;
   using F = MlpFlat<D, H, O>;
@@ -305,208 +301,9 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     for (int q = 0; q < 6; ++q) lin[q] = lq[q];
     const float x16 = xb[4];
 
-#ifdef TRL_EXP_OLDTILE
-    // ---- forward layer 1: 4 independent slices ----
-    f32x4 h1[4], h2[4];
-#pragma unroll
-    for (int so = 0; so < 4; ++so) h1[so] = lds4(lds + S::O_B1 + 16 * so + 4 * g);
-#pragma unroll
-    for (int q = 0; q < 5; ++q)
-#pragma unroll
-      for (int so = 0; so < 4; ++so) h1[so] = mfma16(w1[so][q], xb[q], h1[so]);
-#pragma unroll
-    for (int so = 0; so < 4; ++so)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        h1[so][r] = act_fn<ACT>(h1[so][r]);
-        H1S[(16 * so + 4 * g + r) * LDT + j] = h1[so][r];        // H1^T[f][s] for dW2
-      }
-    WCLK(1)
-    // ---- forward layer 2 ----
-    // slice-major: the activation of slice so runs on the VALU under the MFMAs of slice so + 1
-#pragma unroll
-    for (int so = 0; so < 4; ++so) {
-      f32x4 acc = lds4(lds + S::O_B2 + 16 * so + 4 * g);
-#pragma unroll
-      for (int sl = 0; sl < 4; ++sl) {
-        const f32x4 w = lds4(W2F + (16 * so + i) * LDW + 16 * sl + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma16(w[r], h1[sl][r], acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) h2[so][r] = act_fn<ACT>(acc[r]);
-    }
-
-    // Next tile's loads are issued HERE, mid-tile: at the top of the loop every outstanding load is then
-    // half a tile old, and no wait next to the first MFMAs can stall on a load that was just issued.
-    prefetch_next(tile + tile_stride);            // loads of tile t+1 (addresses were resolved a tile ago), row index of tile t+2
-    WCLK(2)
-    // ---- head, loss, d(loss)/d(out), dZ2 ----
-    f32x4 dz2[4];
-    if constexpr (IS_PF) {
-#pragma unroll
-      for (int so = 0; so < 4; ++so)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) H2S[(16 * so + 4 * g + r) * LDT + j] = h2[so][r];            // H2^T[f][s] for dW3
-      // out^T[o][s]: two interleaved accumulation chains over the 64 features
-      f32x4 oa = f32x4{b3v[0], b3v[1], b3v[2], b3v[3]}, ob = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int sl = 0; sl < 4; sl += 2)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { oa = mfma16(w3h[sl][r], h2[sl][r], oa); ob = mfma16(w3h[sl + 1][r], h2[sl + 1][r], ob); }
-      // lane (j, g < 2) owns outputs o = 4g + r of sample j
-      float zc[4], lp = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {                                  // branch-free: lanes without an output compute on zeros
-        const bool has = 4 * g + r < O;
-        const float t = gauss_logp_term((valid && has) ? lin[r] : 0.0f, has ? oa[r] + ob[r] : 0.0f, ivv[r], lsv[r],
-                                        a.tanh_action, zc[r]);
-        lp += has ? t : 0.0f;
-        zc[r] = has ? zc[r] : 0.0f;
-      }
-      lp += __shfl_xor(lp, 16, 64);                                // outputs 0..3 (g = 0) + 4..7 (g = 1)
-      const float advn = valid ? (lin[4] - adv_mu) * adv_rstd : 0.0f;
-      float ratio, s1, s2, g_lp;
-      if (a.loss_mode == TRL_LOSS_A2C) {                            // L = -mean(log pi * adv) (a2c.py:69-70)
-        ratio = 1.0f;
-        s1 = s2 = lp * advn;
-        g_lp = (valid && g < 2) ? -advn * inv_b : 0.0f;
-      } else {                                                     // clipped surrogate (ppo.py:58-66)
-        ratio = __expf(lp - lin[5]);
-        s1 = ratio * advn;
-        s2 = fminf(fmaxf(ratio, 1.0f - a.clip_para), 1.0f + a.clip_para) * advn;
-        g_lp = (valid && g < 2 && s1 <= s2) ? -advn * ratio * inv_b : 0.0f;
-      }
-      float dout[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool own = valid && g < 2 && 4 * g + r < O;
-        dout[r] = own ? g_lp * zc[r] * ivv[r] : 0.0f;
-        db3[r] += dout[r];
-        dls[r] += own ? lspass[r] * (g_lp * (zc[r] * zc[r] * ivv[r] - 1.0f) - a.entropy_coeff * inv_b) : 0.0f;
-        if (g < 2) DOS[(4 * g + r) * LDT + j] = dout[r];           // dout^T[o][s] for dW3
-      }
-      if (valid && g == 0) {
-        stv[0] += lp; stv[1] = fmaf(lp, lp, stv[1]); stv[6] -= fminf(s1, s2);
-        stv[2] = fmaxf(stv[2], lp); stv[3] = fmaxf(stv[3], -lp);
-        stv[4] = fmaxf(stv[4], ratio); stv[5] = fmaxf(stv[5], -ratio);
-      }
-      // dW3[o][f] += sum_s dout[s][o] H2[s][f]   (K step q is sample 4g + q)
-      {
-        const f32x4 da = lds4(DOS + i * LDT + 4 * g);
-#pragma unroll
-        for (int so = 0; so < 4; ++so) {
-          const f32x4 hb = lds4(H2S + (16 * so + j) * LDT + 4 * g);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) gW3[so] = mfma16(da[q], hb[q], gW3[so]);
-        }
-      }
-      // dH2^T[f][s] = sum_o W3[o][f] dout[o][s];  dZ2 = dH2 * act'(H2)
-#pragma unroll
-      for (int so = 0; so < 4; ++so) dz2[so] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int so = 0; so < 4; ++so) dz2[so] = mfma16(w3t[so][r], dout[r], dz2[so]);
-    } else {
-      float v = 0.0f;
-#pragma unroll
-      for (int so = 0; so < 4; ++so)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v = fmaf(w3h[so][r], h2[so][r], v);
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      v += vb3;
-      const float R = lin[4];
-      float dv, l;
-      if (a.clipped_value_loss) {                                  // ppo.py:104-111
-        const float vo = lin[5];
-        const float dc = v - vo;
-        const float vc = vo + fminf(fmaxf(dc, -a.clip_para), a.clip_para);
-        const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
-        const float wa = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), wb = 1.0f - wa;
-        const float pass = (dc >= -a.clip_para && dc <= a.clip_para) ? 1.0f : 0.0f;
-        l = 0.5f * fmaxf(l1, l2);
-        dv = inv_b * (wa * (v - R) + wb * pass * (vc - R));
-      } else {                                                     // nn.MSELoss, a2c.py:43
-        l = (v - R) * (v - R);
-        dv = 2.0f * (v - R) * inv_b;
-      }
-      dv = valid ? dv : 0.0f;
-      if (valid && g == 0) {
-        stv[6] += l; db3[0] += dv;
-        stv[0] += v; stv[1] = fmaf(v, v, stv[1]); stv[2] = fmaxf(stv[2], v); stv[3] = fmaxf(stv[3], -v);   // v_pred/*
-      }
-#pragma unroll
-      for (int so = 0; so < 4; ++so)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dz2[so][r] = dv * w3h[so][r];
-          gW3[so][r] = fmaf(dv, h2[so][r], gW3[so][r]);             // per-lane dW3[f] partial (own sample)
-        }
-    }
-#pragma unroll
-    for (int so = 0; so < 4; ++so)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dz2[so][r] *= act_grad<ACT>(h2[so][r]);
-        gb2[so][r] += dz2[so][r];
-        DZ2S[(16 * so + 4 * g + r) * LDT + j] = dz2[so][r];        // dZ2^T[f][s] for dW2
-      }
-
-    WCLK(3)
-    // ---- dH1^T (all slices) = W2^T dZ2^T ; dZ1 = dH1 * act'(H1) ----
-    f32x4 dz1[4];
-#pragma unroll
-    for (int so = 0; so < 4; ++so) dz1[so] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      f32x4 w[4];
-#pragma unroll
-      for (int so = 0; so < 4; ++so) w[so] = lds4(W2B + (16 * so + i) * LDW + 16 * sl + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int so = 0; so < 4; ++so) dz1[so] = mfma16(w[so][r], dz2[sl][r], dz1[so]);
-    }
-#pragma unroll
-    for (int so = 0; so < 4; ++so)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dz1[so][r] *= act_grad<ACT>(h1[so][r]);
-        gb1[so][r] += dz1[so][r];
-        gW1c[so][r] = fmaf(dz1[so][r], x16, gW1c[so][r]);
-        H2S[(16 * so + 4 * g + r) * LDT + j] = dz1[so][r];         // dZ1^T[f][s] for dW1 (H2^T is consumed)
-      }
-
-    WCLK(4)
-    // ---- dW2[f2][f1] += sum_s dZ2[s][f2] H1[s][f1]  (K step q is sample 4g + q) ----
-    {
-      f32x4 hb[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) hb[c] = lds4(H1S + (16 * c + j) * LDT + 4 * g);
-#pragma unroll
-      for (int so = 0; so < 4; ++so) {
-        const f32x4 za = lds4(DZ2S + (16 * so + i) * LDT + 4 * g);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) gW2[so][c] = mfma16(za[q], hb[c][q], gW2[so][c]);
-      }
-    }
-    WCLK(5)
-    // ---- dW1[f1][k < 16] += sum_s dZ1[s][f1] X[s][k] ----
-#pragma unroll
-    for (int so = 0; so < 4; ++so) {
-      const f32x4 za = lds4(H2S + (16 * so + i) * LDT + 4 * g);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) gW1[so] = mfma16(za[q], xt[q], gW1[so]);
-    }
-#else
     // LDS operand reads are issued one phase AHEAD of the MFMAs that consume them (PIN_DS keeps the compiler from
     // sinking them back next to their use): the ~130-cycle LDS round trip then runs under the previous phase's matrix
-    // work instead of stalling the in-order wave in front of every 4-MFMA group.  Arithmetic and summation order are
-    // those of the TRL_EXP_OLDTILE body, bit for bit.
+    // work instead of stalling the in-order wave in front of every 4-MFMA group.
 #define PIN_DS() __builtin_amdgcn_sched_barrier(0x676)   /* VALU / SALU / VMEM / DS writes / transcendentals may cross; DS reads and MFMAs may not */
     // ---- forward layer 1: 4 independent slices ----
     f32x4 h1[4], h2[4];
@@ -744,7 +541,6 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 #pragma unroll
       for (int q = 0; q < 4; ++q) gW1[so] = mfma16(za1[so][q], xt[q], gW1[so]);
 #undef PIN_DS
-#endif
     WCLK(6)
   }
 
@@ -782,24 +578,11 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   WCLK(7)
   __syncthreads();
   const int wg = blockIdx.x;
-  if constexpr (PUBLISH) {
-    static_assert(S::P_STRIDE % 4 == 0, "partial rows are stored 16 bytes at a time");
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        a.partial + (size_t)wg * a.p_stride, 0, S::P_STRIDE * 4, 0x00020000);
-    for (int e4 = tid; e4 < S::P_STRIDE / 4; e4 += WV_THREADS) {
-      f32x4 acc = lds4(lds + 4 * e4);
+  for (int e = tid; e < S::P_STRIDE; e += WV_THREADS) {
+    float acc = lds[e];
 #pragma unroll
-      for (int w = 1; w < WV_WAVES; ++w) acc += lds4(lds + w * S::P_STRIDE + 4 * e4);      // same order per element
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc), rsrc, 16 * e4, 0, /*sc1*/ 16);
-    }
-  } else {
-    for (int e = tid; e < S::P_STRIDE; e += WV_THREADS) {
-      float acc = lds[e];
-#pragma unroll
-      for (int w = 1; w < WV_WAVES; ++w) acc += lds[w * S::P_STRIDE + e];
-      a.partial[(size_t)wg * a.p_stride + e] = acc;
-    }
+    for (int w = 1; w < WV_WAVES; ++w) acc += lds[w * S::P_STRIDE + e];
+    a.partial[(size_t)wg * a.p_stride + e] = acc;
   }
   WCLK(8)
 #ifdef TRL_EXP_CLK
@@ -826,16 +609,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       const double o = sred[w * 8 + tid];
       r = (tid >= 2 && tid <= 5) ? fmax(r, o) : r + o;
     }
-    if constexpr (PUBLISH)
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.scal_partial + (size_t)wg * 8 + tid),
-                         (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      a.scal_partial[(size_t)wg * 8 + tid] = r;
-  }
-  if constexpr (PUBLISH) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // EVERY storing wave drains its write-through stores
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(pub_flags + wg, pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.scal_partial[(size_t)wg * 8 + tid] = r;
   }
 }
 
@@ -1165,209 +939,6 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   }
 }
 
-// ================================================================ fused step: gradient + fold + clip + Adam in ONE launch
-// The workgroups of ppo_grad_wave_kernel publish their partial rows write-through and flag them with the epoch of the
-// launch; the first 2 x 90 workgroups then become the reducers of ppo_reduce_adam_kernel -- each waits for the flags of
-// its network's rows, folds its 64 parameters with sc1 loads (served from the fabric, never from a stale L2 / L1 line),
-// takes part in the {ss, epoch} norm rendezvous and steps its parameters.  Saves a kernel boundary and the launch ramp
-// of the reduce kernel per minibatch (every workgroup is resident: one per CU, n_wg <= #CUs).  Same arithmetic and
-// summation orders as the two-launch sequence.  Every wait is bounded by wall-clock time (ws[0] is set instead of hanging).
-struct StepDev {
-  int p_pf, p_vf, n_act;
-  const float* logstd;
-  float* grads; double* info;
-  AdamDev adam;
-  float* ws;                                       // header [16] | norm slots [4 nb floats] | row flags [n_wg u32]
-  int device_state; unsigned epoch_arg;
-  int xrank;
-};
-
-__device__ __forceinline__ bool step_wait_u32(const unsigned* p, unsigned want, unsigned* err) {
-  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return true;
-  const unsigned long long t0 = wall_clock64();
-  for (unsigned it = 1;; ++it) {
-    __builtin_amdgcn_s_sleep(1);
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return true;
-    if ((it & 1023u) == 0 && wall_clock64() - t0 > 2500000000ull) {
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
-    }
-  }
-}
-
-template <int P_STRIDE>
-__device__ void ppo_step_tail(const PpoDev& a, const StepDev& st, const XrArgs& xr, float* lds, unsigned epoch, unsigned xepoch) {
-  constexpr int NB = (P_STRIDE + RED_CHUNK - 1) / RED_CHUNK;
-  static_assert(WV_WAVES == 4, "the reducer role is written for 4 waves");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
-  unsigned* ws_u = reinterpret_cast<unsigned*>(st.ws);
-  unsigned long long* slots = reinterpret_cast<unsigned long long*>(st.ws + 16);     // [2 nets][NB] {ss bits, epoch}
-  const unsigned* flags = ws_u + 16 + 4 * NB;
-  float* s_acc = lds;                              // [4][64]   (the gradient images are dead: every wave passed the barrier
-  float* s_coef = lds + 4 * RED_CHUNK;             // [2]         that follows the partial-row stores)
-  float* s_hyper = lds + 4 * RED_CHUNK + 4;        // [4] bc1, bc2_sqrt, lr_pf, lr_vf
-  if (wg >= 2 * NB) return;                        // not a reducer
-  AdamDev ad = st.adam;
-  double* bpow = reinterpret_cast<double*>(st.ws + 4);
-  double b1p = 0.0, b2p = 0.0;
-  float lr0 = 0.0f, lr1 = 0.0f;
-  if (st.device_state && tid == 64 * 3) { b1p = bpow[0]; b2p = bpow[1]; lr0 = st.ws[2]; lr1 = st.ws[3]; }
-  const int n_red = a.n_wg < 2 * NB ? a.n_wg : 2 * NB;            // reducers; each owns chunks wg, wg + n_red, ...
-  // ---- phase A: fold (+ cross-rank SUM) of every own chunk, publish its sum of squares ----
-  for (int c = wg; c < 2 * NB; c += n_red) {
-    const int net = c / NB, chunk = c - net * NB;
-    const int row0 = net == 0 ? 0 : a.n_pf, nrow = net == 0 ? a.n_pf : a.n_wg - a.n_pf;
-    for (int r = tid; r < nrow; r += WV_THREADS) step_wait_u32(flags + row0 + r, epoch, ws_u);
-    __syncthreads();
-    const int p = chunk * RED_CHUNK + lane;
-    const int pn = net == 0 ? st.p_pf : st.p_vf;
-    float acc[RED_DEPTH];
-#pragma unroll
-    for (int k = 0; k < RED_DEPTH; ++k) acc[k] = 0.0f;
-    if (p < pn) {
-      const float* src = a.partial + (size_t)row0 * a.p_stride + p;
-      for (int w = wave; w < nrow; w += RED_DEPTH * 4) {
-        float v[RED_DEPTH];
-#pragma unroll
-        for (int k = 0; k < RED_DEPTH; ++k)
-          v[k] = (w + 4 * k < nrow) ? __hip_atomic_load(src + (size_t)(w + 4 * k) * a.p_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-#pragma unroll
-        for (int k = 0; k < RED_DEPTH; ++k) acc[k] += v[k];
-      }
-    }
-#pragma unroll
-    for (int stp = RED_DEPTH / 2; stp > 0; stp >>= 1)
-#pragma unroll
-      for (int k = 0; k < stp; ++k) acc[k] += acc[k + stp];
-    s_acc[wave * RED_CHUNK + lane] = acc[0];
-    __syncthreads();
-    if (wave == 0) {
-      float gval = 0.0f;
-      const bool act = p < pn;
-      const int ge = (net == 0 ? 0 : st.p_pf) + p;
-      if (act) gval = (s_acc[lane] + s_acc[RED_CHUNK + lane]) + (s_acc[2 * RED_CHUNK + lane] + s_acc[3 * RED_CHUNK + lane]);
-      if (st.xrank) gval = xr_allsum_f32(xr, xepoch, act ? ge : 0, gval, act);
-      if (act) st.grads[ge] = gval;
-      const float ss = wave_sum(gval * gval);
-      if (lane == 0)
-        __hip_atomic_store(slots + net * NB + chunk, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(ss),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // logging statistics of this network: wave 2 of its first chunk (independent loads, shuffle reduction)
-    if (chunk == 0 && wave == 2) {
-      const unsigned long long* base = reinterpret_cast<const unsigned long long*>(a.scal_partial + (size_t)row0 * 8);
-      double v[7];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? -INFINITY : 0.0;
-      for (int w = lane; w < nrow; w += 64) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-          const double o = __longlong_as_double((long long)__hip_atomic_load(base + (size_t)w * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          v[k] = (k >= 2 && k <= 5) ? fmax(v[k], o) : v[k] + o;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? wave_max(v[k]) : wave_sum(v[k]);
-      if (lane == 0) {
-        double* info = st.info;
-        if (net == 0) {
-          info[0] = v[6]; info[1] = v[0]; info[2] = v[1]; info[3] = v[2]; info[4] = v[3]; info[5] = v[4]; info[6] = v[5];
-          if (st.logstd) {                                       // log_std / std statistics, as ppo_reduce_block
-            const int n_act = st.n_act;
-            double sm = 0, sq = 0, mx = -INFINITY, mn = INFINITY, es = 0, eq = 0, emx = -INFINITY, emn = INFINITY;
-            for (int o = 0; o < n_act; ++o) {
-              const double x = fmin(fmax((double)st.logstd[o], -20.0), 2.0), ex = exp(x);
-              sm += x; sq += x * x; mx = fmax(mx, x); mn = fmin(mn, x);
-              es += ex; eq += ex * ex; emx = fmax(emx, ex); emn = fmin(emn, ex);
-            }
-            const double mean = sm / n_act, em = es / n_act;
-            info[8] = mean; info[9] = n_act > 1 ? sqrt(fmax((sq - sm * mean) / (n_act - 1), 0.0)) : NAN;
-            info[10] = mx; info[11] = mn;
-            info[16] = em; info[17] = n_act > 1 ? sqrt(fmax((eq - es * em) / (n_act - 1), 0.0)) : NAN;
-            info[18] = emx; info[19] = emn;
-          }
-        } else {
-          info[7] = v[6];
-          info[12] = v[0]; info[13] = v[1]; info[14] = v[2]; info[15] = v[3];
-        }
-      }
-    }
-    __syncthreads();                               // s_acc is reused by the next chunk
-  }
-  if (st.device_state && tid == 64 * 3) {
-    b1p *= (double)ad.beta1; b2p *= (double)ad.beta2;
-    s_hyper[0] = (float)(1.0 - b1p);
-    s_hyper[1] = (float)sqrt(1.0 - b2p);
-    s_hyper[2] = lr0; s_hyper[3] = lr1;
-  }
-  // ---- group norms (pf, vf): wave w polls net w's slots, sums them in fixed order ----
-  if (wave < 2) {
-    float acc = 0.0f;
-    for (int b = lane; b < NB; b += 64) {
-      unsigned long long v = __hip_atomic_load(slots + wave * NB + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned)(v >> 32) != epoch) {
-        const unsigned long long t0 = wall_clock64();
-        for (unsigned it = 1;; ++it) {
-          __builtin_amdgcn_s_sleep(1);
-          v = __hip_atomic_load(slots + wave * NB + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((unsigned)(v >> 32) == epoch) break;
-          if ((it & 1023u) == 0 && wall_clock64() - t0 > 2500000000ull) {
-            __hip_atomic_store(ws_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      }
-      acc += __uint_as_float((unsigned)v);
-    }
-    acc = wave_sum(acc) * ad.grad_scale * ad.grad_scale;
-    if (lane == 0) {
-      const float norm = sqrtf(acc);
-      s_coef[wave] = (ad.max_norm > 0.0f) ? fminf(ad.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
-      if (ad.norms_out && wg == 0) ad.norms_out[wave] = norm;
-    }
-  }
-  __syncthreads();
-  if (st.device_state) {
-    ad.bc1 = s_hyper[0]; ad.bc2_sqrt = s_hyper[1]; ad.lr[0] = s_hyper[2]; ad.lr[1] = s_hyper[3];
-    if (wg == 0) {                                 // every workgroup has read the header by now (it read it before publishing)
-      if (tid == 0) __hip_atomic_store(ws_u + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tid == 64 * 3) { bpow[0] = b1p; bpow[1] = b2p; }
-    }
-  }
-  if (st.xrank && wg == 0 && tid == 0) __hip_atomic_store(xr.ctl + 4, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- phase B: Adam on every own chunk ----
-  if (wave == 0) {
-    for (int c = wg; c < 2 * NB; c += n_red) {
-      const int net = c / NB, chunk = c - net * NB;
-      const int p = chunk * RED_CHUNK + lane;
-      if (p < (net == 0 ? st.p_pf : st.p_vf)) {
-        const int ge = (net == 0 ? 0 : st.p_pf) + p;
-        const float gr = st.grads[ge] * ad.grad_scale * s_coef[net];   // this lane's own store of phase A
-        const float m = ad.beta1 * ad.m[ge] + (1.0f - ad.beta1) * gr;
-        const float v = ad.beta2 * ad.v[ge] + (1.0f - ad.beta2) * gr * gr;
-        ad.m[ge] = m; ad.v[ge] = v;
-        const float denom = sqrtf(v) / ad.bc2_sqrt + ad.eps;
-        ad.params[ge] -= (ad.lr[net] / ad.bc1) * (m / denom);
-      }
-    }
-  }
-}
-
-template <int D, int H, int A, int ACT, bool CONTIG>
-__global__ __launch_bounds__(WV_THREADS, 1) void ppo_step_wave_kernel(PpoDev a, StepDev st, XrArgs xr) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int P_STRIDE = PpoShape<D, H, A>::P_STRIDE;
-  constexpr int NB = (P_STRIDE + RED_CHUNK - 1) / RED_CHUNK;
-  // epoch of this launch: read by EVERY workgroup before it publishes anything, advanced by workgroup 0 at the very end
-  unsigned* ws_u = reinterpret_cast<unsigned*>(st.ws);
-  const unsigned epoch = st.device_state ? __hip_atomic_load(ws_u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : st.epoch_arg;
-  const unsigned xepoch = st.xrank ? __hip_atomic_load(xr.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
-  unsigned* flags = ws_u + 16 + 4 * NB;
-  if ((int)blockIdx.x < a.n_pf) ppo_wave_pass<D, H, A, ACT, true, CONTIG, true>(a, lds, blockIdx.x, a.n_pf, flags, epoch);
-  else                          ppo_wave_pass<D, H, A, ACT, false, CONTIG, true>(a, lds, blockIdx.x - a.n_pf, a.n_wg - a.n_pf, flags, epoch);
-  ppo_step_tail<P_STRIDE>(a, st, xr, lds, epoch, xepoch);
-}
-
 // ---------------------------------------------------------------- MLP inference
 template <int D, int H, int O, int ACT>
 __global__ __launch_bounds__(256) void mlp2_forward_kernel(const float* __restrict__ params,
@@ -1570,95 +1141,6 @@ extern "C" int trl_ppo_reduce_adam_xrank_f32(const float* partial, const double*
   const XrArgs* xr = trl_comm_xr(comm);
   if (!xr) { trl_set_error("trl_ppo_reduce_adam_xrank_f32: communicator without mapped peers"); return TRL_EINVAL; }
   return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, xr, stream);
-}
-
-// ---- fused step: trl_ppo_minibatch_grad_f32 + trl_ppo_reduce_adam[_xrank]_f32 in ONE launch ----
-extern "C" int trl_ppo_step_workspace(int D, int H, int A, int n_wg) {
-  const int ps = trl_ppo_partial_stride(D, H, A);
-  if (ps < 0) return ps;
-  if (n_wg < 2) { trl_set_error("trl_ppo_step_workspace: n_wg must be >= 2"); return TRL_EINVAL; }
-  return 16 + 4 * trl_ceil_div(ps, RED_CHUNK) + n_wg;             // header | norm slots | one flag per workgroup
-}
-
-template <int D, int H, int A, int ACT, bool CONTIG>
-static int launch_step_v(const PpoDev& d, const StepDev& st, const XrArgs& xr, hipStream_t s) {
-  using S = WvShape<D, H, A>;
-  const size_t lds = S::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_step_wave_kernel<D, H, A, ACT, CONTIG>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { trl_set_error("ppo_step: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((ppo_step_wave_kernel<D, H, A, ACT, CONTIG>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d, st, xr);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
-}
-
-// One launch per minibatch: the gradient workgroups publish their partial rows inside the launch and the first
-// 2 x ceil(P / 64) of them fold, (sum over ranks,) clip and step.  Requires every workgroup to be resident at once:
-// n_wg <= number of CUs (one workgroup occupies a CU).  comm: NULL, or a communicator with mapped peers (the gradient
-// SUM over ranks then happens inside the launch as in trl_ppo_reduce_adam_xrank_f32).  workspace:
-// trl_ppo_step_workspace(D, H, A, n_wg) floats, zeroed once by the caller; its header is the one of
-// trl_ppo_reduce_adam_f32 (ws[0] != 0 afterwards: a wait inside the launch timed out).
-extern "C" int trl_ppo_step_f32(const trl_ppo_batch_t* p, float* grads, double* info, const trl_adam_t* adam,
-                                float* workspace, trl_comm_t* comm, void* stream) {
-  if (!p) { trl_set_error("ppo_step: null descriptor"); return TRL_EINVAL; }
-  TRL_REQUIRE(p->obs && p->acts && p->advs && p->rets, "null rollout tensor");
-  TRL_REQUIRE(p->loss_mode == TRL_LOSS_PPO_CLIP || p->loss_mode == TRL_LOSS_A2C, "unknown loss_mode");
-  TRL_REQUIRE(p->loss_mode == TRL_LOSS_A2C || p->old_logp, "the clipped surrogate needs old_logp");
-  TRL_REQUIRE(!p->clipped_value_loss || p->old_values, "the clipped value loss needs old_values");
-  TRL_REQUIRE(p->adv_raw && p->pf_params && p->vf_params && p->partial && p->scal_partial, "null pointer");
-  TRL_REQUIRE(grads && info && workspace, "null pointer");
-  TRL_REQUIRE(p->rows_mb > 0 && p->N > 0, "empty minibatch");
-  TRL_REQUIRE(p->n_wg >= 2, "n_wg must be >= 2");
-  TRL_REQUIRE(p->n_wg_pf >= 0 && p->n_wg_pf < p->n_wg, "n_wg_pf must be 0 (even split) or in [1, n_wg)");
-  TRL_REQUIRE(p->n_global > 1.0, "n_global must exceed 1 (unbiased std)");
-  int n_cu = 0, dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
-  TRL_REQUIRE(n_cu == 0 || p->n_wg <= n_cu, "n_wg exceeds the CU count: the workgroups of a fused step must all be resident");
-  const int D = p->D, H = p->H, A = p->A;
-  const int ps = trl_ppo_partial_stride(D, H, A);
-  if (ps < 0) return ps;
-  StepDev st;
-  int rc = fill_adam(adam, st.adam);
-  if (rc) return rc;
-  st.p_pf = H * D + H + H * H + H + A * H + A + A; st.p_vf = H * D + H + H * H + H + H + 1; st.n_act = A;
-  TRL_REQUIRE(adam->n_groups == 2 && adam->group_sizes[0] == st.p_pf && adam->group_sizes[1] == st.p_vf,
-              "optimiser groups must be [policy | value] of this shape");
-  TRL_REQUIRE(adam->grads == grads, "adam->grads must be the reduce output");
-  st.logstd = adam->params + (st.p_pf - A);
-  st.grads = grads; st.info = info; st.ws = workspace;
-  st.device_state = adam->device_state; st.epoch_arg = (unsigned)adam->step_count;
-  const XrArgs* xrp = comm ? trl_comm_xr(comm) : nullptr;
-  if (comm && !xrp) { trl_set_error("ppo_step: communicator without mapped peers"); return TRL_EINVAL; }
-  TRL_REQUIRE(!xrp || st.p_pf + st.p_vf <= TRL_XR_CAP_GRAD, "gradient exceeds the peer buffer");
-  st.xrank = xrp ? 1 : 0;
-  XrArgs none;
-  none.rank = 0; none.world = 1; none.ctl = nullptr;
-  for (int r = 0; r < TRL_MAX_RANKS; ++r) none.peer[r] = nullptr;
-  PpoDev d;
-  d.obs = p->obs; d.acts = p->acts; d.advs = p->advs; d.rets = p->rets; d.old_values = p->old_values;
-  d.old_logp = p->old_logp; d.row_idx = p->row_idx; d.rows_mb = p->rows_mb; d.N = p->N;
-  d.adv_raw = p->adv_raw; d.n_global = p->n_global; d.pf_params = p->pf_params; d.vf_params = p->vf_params;
-  d.clip_para = p->clip_para; d.entropy_coeff = p->entropy_coeff;
-  d.clipped_value_loss = p->clipped_value_loss; d.tanh_action = p->tanh_action; d.loss_mode = p->loss_mode;
-  d.partial = p->partial; d.scal_partial = p->scal_partial; d.n_wg = p->n_wg;
-  d.n_pf = resolve_pf_wgs(p->n_wg, p->n_wg_pf);
-  d.p_stride = ps;
-  hipStream_t s = (hipStream_t)stream;
-  const bool contig = p->N % 16 == 0;
-  if (SHAPE_IS(17, 64, 6)) {
-    if (p->act == TRL_ACT_TANH)
-      return contig ? launch_step_v<17, 64, 6, TRL_ACT_TANH, true>(d, st, xrp ? *xrp : none, s)
-                    : launch_step_v<17, 64, 6, TRL_ACT_TANH, false>(d, st, xrp ? *xrp : none, s);
-    if (p->act == TRL_ACT_RELU)
-      return contig ? launch_step_v<17, 64, 6, TRL_ACT_RELU, true>(d, st, xrp ? *xrp : none, s)
-                    : launch_step_v<17, 64, 6, TRL_ACT_RELU, false>(d, st, xrp ? *xrp : none, s);
-  }
-  trl_set_error("ppo_step: shape D=%d H=%d A=%d act=%d not instantiated", D, H, A, p->act);
-  return TRL_EUNSUPPORTED;
 }
 
 #define TICK_PENDING 0x70000001                    /* clip_adam_launch: the step state still has to be advanced */
