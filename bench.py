@@ -703,7 +703,7 @@ def main():
                    "setup_iterations": setup,
                    "update_infos_read_in_timed_region": infos_read,
                    "host_pipeline": "the info dicts of iteration i's updates are read while iteration i+1's rollout runs "
-                                    "(the last ones before the clock stops); TRL_EAGER_UPDATE_INFOS=1 reads them in place",
+                                    "(the last ones before the clock stops); `algo.eager_update_infos = True` reads them in place",
                    "transport": transport,
                    "parallelism": "env-sharded dp%d, gradient SUM %s" % (
                        world, "inside the fold/clip/Adam launch over peer-mapped xGMI buffers" if dist.peer_ready()

@@ -67,16 +67,14 @@ int trl_gather_rows_f32(const float* src, const int64_t* row_idx, float* dst,
 int trl_gather_rows_u8(const uint8_t* src, const int64_t* row_idx, uint8_t* dst,
                        int n_rows, int64_t row_bytes, int64_t src_rows, void* stream);
 /* the same gather for up to 8 keys of one replay sample (random_batch's loop over sample_key, base.py:46-50) in one
- * launch: dst[k][i, :] = src[k][row_idx[i], :], rows of row_bytes[k] bytes; every src[k] has src_rows rows. */
+ * launch: dst[k][i, :] = src[k][row_idx[i], :], rows of row_bytes[k] bytes; every src[k] has src_rows rows.
+ * update_count (nullable): the index row set is then picked on the device -- row_idx is a SLAB {first, sets,
+ * idx[sets][n_rows]} (int64), set = (int64)update_count[0] - first; outside [0, sets) nothing is copied.  The `opt_times`
+ * samples of one OffRLAlgo.update_per_epoch (off_rl_algo.py:58-66) are drawn up front on the host, in the reference's
+ * order, uploaded once, and each update of the captured epoch graph gathers its own. */
 int trl_gather_rows_multi(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
-                          const int64_t* row_idx, int n_rows, int64_t src_rows, void* stream);
-/* the same with the index row set picked on the device: slab = {first, sets, idx[sets][n_rows]} (int64), set =
- * (int64)update_count[0] - first; outside [0, sets) nothing is copied.  The `opt_times` samples of one
- * OffRLAlgo.update_per_epoch (off_rl_algo.py:58-66) are drawn up front on the host, in the reference's order, uploaded
- * once, and each update of the captured epoch graph gathers its own. */
-int trl_gather_rows_multi_dyn(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
-                              const int64_t* slab, const double* update_count, int n_rows, int64_t src_rows,
-                              void* stream);
+                          const int64_t* row_idx, const double* update_count, int n_rows, int64_t src_rows,
+                          void* stream);
 
 /* --- K7: per-minibatch advantage statistics --------------------------------
  * replaces advs.mean()/std()/max()/min() of PPO.update (ppo.py:141-144) for
@@ -303,13 +301,11 @@ typedef struct trl_adam_t {
 int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
 /* the same followed by the Polyak step target <- (1 - tau) target + tau source of n floats (rl_algo.py:169-176,
  * utils.py:16-20) as two launches: where the device-resident step state would need the one-thread tick launch, the Polyak
- * kernel advances it */
+ * kernel advances it.  ring (nullable): the Polyak launch -- the last one of an update -- also archives the update's
+ * statistics block `raw` (raw_bytes, a multiple of 4) into row (optimiser steps taken before this update) mod slots of
+ * `ring`; args->step_state is then required */
 int trl_clip_adam_polyak_f32(const trl_adam_t* args, float* target, const float* source, int64_t n, float tau,
-                             void* stream);
-/* ... whose Polyak launch (the last one of an update) also archives the update's statistics block `raw` (raw_bytes, a
- * multiple of 4) into row (optimiser steps taken before this update) mod slots of `ring`; p->step_state is required */
-int trl_clip_adam_polyak_file_f32(const trl_adam_t* p, float* target, const float* source, int64_t n, float tau,
-                                  const void* raw, int raw_bytes, void* ring, int slots, void* stream);
+                             const void* raw, int raw_bytes, void* ring, int slots, void* stream);
 /* Single-process fast path: trl_ppo_reduce_f32 + trl_clip_adam_f32 in one launch (the block that
  * finishes the reduction last takes the optimiser step; fixed summation orders, deterministic).
  * adam->grads must equal `grads`, the two groups must be [policy | value]; logstd statistics are read
@@ -455,50 +451,36 @@ int trl_tanh_gauss_rsample_bwd_cols_f32(const float* head, const float* eps, con
                                         int A, int tanh_action, void* stream);
 /* both policy samples of one update and the three critic inputs in ONE launch (twin_sac_q.py:93-106, 125-131,
  * 146-151): (new_a, logp) from head = pf(obs) with eps1, (next_a, next_logp) from head2 = pf(next_obs) with eps2,
- * x_sa = [obs | acts], x_next = [next_obs | next_a], x_new = [obs | new_a]  (each (B, D + A)) */
-int trl_sac_samples_f32(const float* head, const float* head2, const float* eps1, const float* eps2,
-                        const float* obs, const float* acts, const float* next_obs, float* new_a, float* logp,
-                        float* next_a, float* next_logp, float* x_sa, float* x_next, float* x_new, int B, int D,
-                        int A, int tanh_action, void* stream);
-/* the same with the two noise draws (distribution.py:67-70) made inside the launch: update u -- u = step_state[0], the
- * device-resident count of optimiser steps taken (trl_adam_t.step_state), so the launch can be graph-replayed -- uses
- * trl_philox_normal_f32's (B, A) draws for (seed, 2u + 1) and (seed, 2u + 2); eps1_out receives the first one (the
- * sampler's backward pass reads it) */
-int trl_sac_samples_philox_f32(const float* head, const float* head2, const double* step_state, int64_t seed,
-                               float* eps1_out, const float* obs, const float* acts, const float* next_obs,
-                               float* new_a, float* logp, float* next_a, float* next_logp, float* x_sa, float* x_next,
-                               float* x_new, int B, int D, int A, int tanh_action, void* stream);
+ * x_sa = [obs | acts], x_next = [next_obs | next_a], x_new = [obs | new_a]  (each (B, D + A)).
+ * step_state (nullable): the two noise draws (distribution.py:67-70) are then made inside the launch: update u -- u =
+ * step_state[0], the device-resident count of optimiser steps taken (trl_adam_t.step_state), so the launch can be
+ * graph-replayed -- uses trl_philox_normal_f32's (B, A) draws for (seed, 2u + 1) and (seed, 2u + 2); eps1 RECEIVES the
+ * first one (the sampler's backward pass reads it), eps2 is not touched.
+ * mom_part (nullable): per-wave partial moments of the clamped log_std / log_prob / mean as a by-product (ceil(B/64) rows
+ * of 12 doubles), folded by trl_sac_losses_f32. */
+int trl_sac_samples_f32(const float* head, const float* head2, float* eps1, const float* eps2,
+                        const double* step_state, int64_t seed, const float* obs, const float* acts,
+                        const float* next_obs, float* new_a, float* logp, float* next_a, float* next_logp,
+                        float* x_sa, float* x_next, float* x_new, int B, int D, int A, int tanh_action,
+                        double* mom_part, void* stream);
 /* alpha loss + Adam step on log_alpha + alpha = exp(log_alpha) (twin_sac_q.py:111-120).
  * state (4): log_alpha, exp_avg, exp_avg_sq, step; out (2): alpha, alpha_loss */
 int trl_sac_alpha_step_f32(const float* logp, int B, float target_entropy, float lr, float beta1,
                            float beta2, float eps, float* state, float* out, void* stream);
 /* TD target, twin MSE losses and all loss gradients w.r.t. the Q outputs (twin_sac_q.py:125-155).
  * every tensor (B); alpha: device scalar; sums (4 doubles): qf1 loss sum, qf2 loss sum,
- * sum(alpha logp - min(q1n, q2n)), sum(rewards) */
-int trl_sac_losses_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
-                       const float* logp_next, const float* rewards, const float* terminals,
-                       const float* q1n, const float* q2n, const float* logp, const float* alpha,
-                       float gamma, int B, float* dq1, float* dq2, float* dq1n, float* dq2n,
-                       double* sums, void* stream);
-/* The same launch with two optional extras that each save a launch of a single-rank update:
+ * sum(alpha logp - min(q1n, q2n)), sum(rewards).  Two optional extras that each save a launch of a single-rank update:
  *  - alpha_state / alpha_out non-NULL: the entropy-temperature step of trl_sac_alpha_step_f32 (twin_sac_q.py:111-120) is
- *    taken first, on `logp`, and its alpha is the one used (the `alpha` argument is ignored);
- *  - mom_part non-NULL: the per-wave partial moments written by trl_sac_samples_stats_f32 (ceil(B/64) rows of 12 doubles)
+ *    taken first, on `logp`, and its alpha is the one used (the `alpha` argument is ignored and may be NULL);
+ *  - mom_part non-NULL: the per-wave partial moments written by trl_sac_samples_f32 (ceil(B/64) rows of 12 doubles)
  *    are folded into mom_out[12] = {mean, unbiased std, max, min} of the clamped log_std, of log_prob and of the mean
  *    (the numbers trl_moments_multi_f64 gives on the policy head, twin_sac_q.py:190-207). */
-int trl_sac_losses_fold_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
-                            const float* logp_next, const float* rew, const float* term, const float* q1n,
-                            const float* q2n, const float* logp, const float* alpha, float gamma, int B,
-                            float* dq1, float* dq2, float* dq1n, float* dq2n, double* sums,
-                            float* alpha_state, float* alpha_out, float target_entropy, float lr, float beta1,
-                            float beta2, float eps, const double* mom_part, int A, double* mom_out, void* stream);
-/* trl_sac_samples_f32 (step_state NULL: eps1 / eps2 are read) or trl_sac_samples_philox_f32 (step_state given: drawn in
- * place, eps1 receives the first draw) with the partial moments above as a by-product */
-int trl_sac_samples_stats_f32(const float* head, const float* head2, float* eps1, const float* eps2,
-                              const double* step_state, int64_t seed, const float* obs, const float* acts,
-                              const float* next_obs, float* new_a, float* logp, float* next_a, float* next_logp,
-                              float* x_sa, float* x_next, float* x_new, int B, int D, int A, int tanh_action,
-                              double* mom_part, void* stream);
+int trl_sac_losses_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
+                       const float* logp_next, const float* rew, const float* term, const float* q1n,
+                       const float* q2n, const float* logp, const float* alpha, float gamma, int B,
+                       float* dq1, float* dq2, float* dq1n, float* dq2n, double* sums,
+                       float* alpha_state, float* alpha_out, float target_entropy, float lr, float beta1,
+                       float beta2, float eps, const double* mom_part, int A, double* mom_out, void* stream);
 /* DDPG / TD3 (torchrl/algo/off_policy/ddpg.py:42-110, td3.py:57-154): TD target with Q' = tq1 or
  * min(tq1, tq2) (tq2 NULL: single critic), MSE of one or two critics + output gradients; with qn also the
  * policy loss -mean(Q(s, pi(s))) and dqn = -1/B.  sums (4 doubles): q1 loss sum, q2 loss sum, sum(-qn), sum(r) */
@@ -519,48 +501,37 @@ int trl_outer_gate_group_f32(int G, const float* const* dq, const float* const* 
                              float* const* out, int M, int N, int act, void* stream);
 /* K13: target <- (1 - tau) target + tau source  (torchrl/algo/utils.py:16-20) */
 int trl_polyak_f32(float* target, const float* source, int64_t n, float tau, void* stream);
-/* logging: mean / unbiased std / max / min over columns [off, off+width) of rows of `ld` floats,
- * each value clamped to [clamp_lo, clamp_hi] first (the logged log_std is the clamped one) */
-int trl_moments_f64(const float* x, int64_t n, int ld, int off, int width, float clamp_lo,
-                    float clamp_hi, double* out4, void* stream);
-/* `count` (1..4) of those statistics in one launch: arrays of the arguments above, one entry per statistic */
+/* logging: `count` (1..4) statistics in one launch, one entry of every array per statistic: mean / unbiased std / max /
+ * min over columns [off, off+width) of rows of `ld` floats, each value clamped to [clamp_lo, clamp_hi] first (the logged
+ * log_std is the clamped one).  ring (nullable): the launch also files the update's statistics block `raw` (raw_bytes, a
+ * multiple of 8; every out4[k] lies inside it) into slot ((int64)update_count[0] - 1) mod slots of `ring` (slots x
+ * raw_bytes): the deferred-update protocol reads a whole epoch's info dicts (off_rl_algo.py:62-64,
+ * logger.add_update_info) back in one copy. */
 int trl_moments_multi_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
                           const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
+                          const void* raw, int raw_bytes, void* ring, int slots, const double* update_count,
                           void* stream);
-/* the same launch also files the update's statistics block `raw` (raw_bytes, a multiple of 8; every out4[k] lies inside
- * it) into slot ((int64)update_count[0] - 1) mod slots of `ring` (slots x raw_bytes): the deferred-update protocol reads
- * a whole epoch's info dicts (off_rl_algo.py:62-64, logger.add_update_info) back in one copy. */
-int trl_moments_multi_ring_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
-                               const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
-                               const void* raw, int raw_bytes, void* ring, int slots, const double* update_count,
-                               void* stream);
 /* One VecCollector.take_actions (torchrl/collector/base.py:184-230) on the synthetic vector env in ONE launch, after the
  * policy MLP: action = rsample(head, eps) (as trl_tanh_gauss_rsample_fwd_f32), obs / acts stored, env.step
  * (as trl_synth_env_step_f32: cur_obs advanced in place), next_obs / rewards / terminals / time_limits rows written, the
  * collector's bookkeeping (as trl_collector_bookkeep_f32) and the partial reset of the envs it flags (as
- * trl_synth_reset_f32 with that mask).  obs_row / acts_row / tl_row may be NULL (evaluation stores nothing).  eps NULL:
- * the noise is rows [noise_row0, noise_row0 + N) of trl_philox_normal_f32's (all envs, A) draw for (noise_seed,
- * noise_counter), generated in place (same Philox blocks, no separate launch). */
+ * trl_synth_reset_f32 with that mask).
+ * state NULL: the six pointers are THE rows to write (obs / acts / time_limits may be NULL: evaluation stores nothing),
+ * `step` is the logged step; eps NULL: the noise is rows [noise_row0, noise_row0 + N) of trl_philox_normal_f32's (all
+ * envs, A) draw for (noise_seed, noise_counter), generated in place (same Philox blocks, no separate launch).
+ * state given: every per-step quantity lives on the device, so that the launch (and the policy pass in front of it) is
+ * captured once and replayed for every vector step: state = 3 int64 {global step, ring row, first step of the epoch}
+ * followed by a zeroed 32-bit block counter at state + 3 (32 bytes in all); the six pointers are the whole ring tensors
+ * (n_rows time rows of N envs); the noise is drawn in place (counter = global step, eps must be NULL); the launch stores
+ * into row state[1] and advances state[0] and state[1] itself. */
 int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* eps, int64_t noise_seed,
                                int64_t noise_counter, int noise_row0, const float* env_A,
                                const float* env_B, int32_t* t_env, int32_t* cur_step, int32_t* episode_idx,
                                float* ep_return, float reward_scale, int horizon, int max_episode_frames,
-                               int64_t env_seed_base, float* obs_row, float* acts_row, float* next_row,
-                               float* rew_row, float* done_row, float* tl_row, uint8_t* reset_mask,
-                               double* epoch_reward, int32_t* ep_count, float* ep_log, int ep_cap, int step,
-                               int N, int D, int A, int tanh_action, void* stream);
-/* The same with every per-step quantity on the device, so that the launch (and the policy pass in front of it) is captured
- * once and replayed for every vector step: state = 3 int64 {global step, ring row, first step of the epoch} followed by a
- * zeroed 32-bit block counter at state + 3 (32 bytes in all); obs / acts / next_obs / rewards / terminals / time_limits
- * are the whole ring tensors (n_rows time rows of N envs); the exploration noise is drawn in place (counter = global
- * step).  The launch stores into row state[1] and advances state[0] and state[1] itself. */
-int trl_synth_collect_step_dyn_f32(float* cur_obs, const float* head, int64_t noise_seed, int noise_row0,
-                                   const float* env_A, const float* env_B, int32_t* t_env, int32_t* cur_step,
-                                   int32_t* episode_idx, float* ep_return, float reward_scale, int horizon,
-                                   int max_episode_frames, int64_t env_seed_base, float* obs, float* acts,
-                                   float* next_obs, float* rewards, float* terminals, float* time_limits, int n_rows,
-                                   int64_t* state, uint8_t* reset_mask, double* epoch_reward, int32_t* ep_count,
-                                   float* ep_log, int ep_cap, int N, int D, int A, int tanh_action, void* stream);
+                               int64_t env_seed_base, float* obs, float* acts, float* next_obs, float* rewards,
+                               float* terminals, float* time_limits, int n_rows, int64_t* state,
+                               uint8_t* reset_mask, double* epoch_reward, int32_t* ep_count, float* ep_log,
+                               int ep_cap, int step, int N, int D, int A, int tanh_action, void* stream);
 /* N(0,1) fill from the Philox4x32-10 stream (device exploration / rsample noise) */
 int trl_philox_normal_f32(float* out, int64_t n, int64_t seed, int64_t counter, void* stream);
 /* K1 stand-alone: one VecEnv.step of the synthetic env (torchrl/env/vecenv.py:53-61); cur_obs is
@@ -636,26 +607,21 @@ int trl_conv_bwd_weight_u8_f32(const float* dy, const float* y_gate, int gate_ac
                                float* dw, float* db, float* workspace, int B, int C, int H, int W, int kh,
                                int kw, int sh, int sw, float scale, float shift, int Cout, void* stream);
 
-/* --- K14: DQN TD loss (torchrl/algo/off_policy/dqn.py:53-60): q, q_next (B, A); acts (B) int64;
- * dq (B, A); sums (3 doubles): squared-error sum, q_s_a sum, reward sum */
-int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const float* q_next, const float* rewards,
-                        const float* terminals, float gamma, int B, int A, float* dq, double* sums,
-                        void* stream);
+/* --- K14: DQN TD loss (torchrl/algo/off_policy/dqn.py:53-60): q, q_next (B, A); dq (B, A); sums (3 doubles):
+ * squared-error sum, q_s_a sum, reward sum.  The actions come as int64 (`acts`) or as the floats the replay buffer stores
+ * (`acts_f`; the reference's `actions.long()` cast, dqn.py:47, then happens at the read) -- exactly one of the two is
+ * non-NULL; a stored value outside [0, A) (or NaN) is clamped instead of indexing out of bounds.  ring (slots x 3
+ * doubles, nullable): the three sums are also filed into row ((int64)update_count[0] mod slots) -- the count of updates
+ * finished before this one -- so that a captured update needs no copy command for its statistics. */
+int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,
+                        const float* rewards, const float* terminals, float gamma, int B, int A, float* dq,
+                        double* sums, double* ring, int slots, const double* update_count, void* stream);
 /* --- K15: QR-DQN quantile-Huber loss + output gradient (qrdqn.py:39-60, algo/utils.py:5-13):
- * q, q_next, dq (B, A*Q); workspace 2B doubles; sums as above (loss sum is over B*Q*Q terms) */
-int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* q_next,
-                           const float* rewards, const float* terminals, float gamma, int B, int A,
-                           int Q, float* dq, double* workspace, double* sums, void* stream);
-/* K14 / K15 as one step of a captured update: the actions as the floats the replay buffer stores (the reference's
- * `actions.long()` cast, dqn.py:47, happens at the read) and, with `ring` (slots x 3 doubles, may be NULL), the three sums
- * also filed into row ((int64)update_count[0] mod slots) -- the count of updates finished before this one. */
-int trl_dqn_td_loss_filed_f32(const float* q, const float* acts_f, const float* q_next, const float* rewards,
-                              const float* terminals, float gamma, int B, int A, float* dq, double* sums,
-                              double* ring, int slots, const double* update_count, void* stream);
-int trl_quantile_huber_filed_f32(const float* q, const float* acts_f, const float* q_next, const float* rewards,
-                                 const float* terminals, float gamma, int B, int A, int Q, float* dq,
-                                 double* workspace, double* sums, double* ring, int slots,
-                                 const double* update_count, void* stream);
+ * q, q_next, dq (B, A*Q); workspace 2B doubles; acts / acts_f / sums / ring as above (loss sum is over B*Q*Q terms) */
+int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,
+                           const float* rewards, const float* terminals, float gamma, int B, int A, int Q,
+                           float* dq, double* workspace, double* sums, double* ring, int slots,
+                           const double* update_count, void* stream);
 /* --- K17: greedy / epsilon-greedy action (torchrl/policies/discrete_policies.py:40-67, 86-89):
  * argmax_a of Q (Q == 1) or of the mean over Q quantiles; where u[n] < epsilon -> rand_act[n] */
 int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const float* u, const int64_t* rand_act,

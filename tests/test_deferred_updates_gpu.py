@@ -51,9 +51,10 @@ def test_sac_epoch_as_one_graph_equals_sample_and_enqueue_one_by_one(monkeypatch
     """TwinSACQ.update_epoch_deferred: the epoch's index sets uploaded as one slab, every update of the one captured graph
     gathering its own set and filing its statistics by the device-resident update count (eager, captured, replayed twice)
     against the per-update {random_batch, enqueue} loop."""
-    monkeypatch.setenv("TRL_SAC_EPOCH_GRAPH", "0")
-    ia, fa, ta, la = _sac_run(True, epochs=4)
-    monkeypatch.setenv("TRL_SAC_EPOCH_GRAPH", "1")
+    from torchrl.algo import TwinSACQ
+    with monkeypatch.context() as m:                                     # the whole-epoch hook declines: one by one
+        m.setattr(TwinSACQ, "update_epoch_deferred", lambda self, count: None)
+        ia, fa, ta, la = _sac_run(True, epochs=4)
     ib, fb, tb, lb = _sac_run(True, epochs=4)
     assert len(ia) == len(ib) == 20
     assert torch.equal(fa, fb) and torch.equal(ta, tb) and torch.equal(la, lb)
@@ -82,9 +83,8 @@ def test_off_policy_epochs_without_a_host_wait_equal_the_waiting_loop(noise, mon
     from test_fullsize_offpolicy_gpu import build_cfg3
 
     def run(lazy):
-        monkeypatch.setenv("TRL_EAGER_EPOCH_RESULT", "0" if lazy else "1")
-        monkeypatch.setenv("TRL_EAGER_UPDATE_INFOS", "0" if lazy else "1")
         pf, qf1, qf2, env, buf, col, agent, _ = build_cfg3(n_env=64)
+        col.eager_epoch_result = agent.eager_update_infos = not lazy
         agent.noise_mode = col.noise_mode = noise
         log = agent.logger = _Later()
         agent.opt_times = 3
@@ -168,11 +168,13 @@ def test_moments_launch_files_the_statistics_block_into_its_ring_slot():
 def test_sac_statistics_riding_on_the_update_s_own_launches_equal_the_separate_launches(n_env, monkeypatch):
     """One rank, soft target updates: the temperature step inside the loss launch, the logged moments from per-wave partials
     of the sampling launch folded by the loss launch, the statistics block filed by the Polyak launch -- against
-    trl_sac_alpha_step_f32 / trl_moments_multi_ring_f64 as launches of their own.  Same arithmetic for everything that
-    feeds back into the update (parameters, targets, alpha bit-identical); the moments are summed in another order."""
-    monkeypatch.setenv("TRL_SAC_STAT_LAUNCHES", "1")
-    ia, fa, ta, la = _sac_run(True, epochs=3, n_env=n_env)
-    monkeypatch.setenv("TRL_SAC_STAT_LAUNCHES", "0")
+    trl_sac_alpha_step_f32 / trl_moments_multi_f64 (+ ring) as launches of their own, the route env shards on several ranks
+    take (forced here on one rank).  Same arithmetic for everything that feeds back into the update (parameters, targets,
+    alpha bit-identical); the moments are summed in another order."""
+    from torchrl_amd.algo.off_policy.twin_sac_q import _FusedSAC
+    with monkeypatch.context() as m:
+        m.setattr(_FusedSAC, "_stats_ride_along", lambda self, soft: False)
+        ia, fa, ta, la = _sac_run(True, epochs=3, n_env=n_env)
     ib, fb, tb, lb = _sac_run(True, epochs=3, n_env=n_env)
     assert len(ia) == len(ib) == 15
     assert torch.equal(fa, fb) and torch.equal(ta, tb) and torch.equal(la, lb)
@@ -186,11 +188,13 @@ def test_sac_statistics_riding_on_the_update_s_own_launches_equal_the_separate_l
 
 
 def test_sac_noise_drawn_inside_the_sampling_launch_equals_the_separate_noise_launches(monkeypatch):
-    """trl_sac_samples_philox_f32 makes update u's two draws from the device-resident update count (2u + 1, 2u + 2): the
-    values trl_philox_normal_f32 was launched for before -- parameters, targets, alpha and every logged number agree."""
-    monkeypatch.setenv("TRL_SAC_NOISE_LAUNCHES", "1")
-    ia, fa, ta, la = _sac_run(True)
-    monkeypatch.setenv("TRL_SAC_NOISE_LAUNCHES", "0")
+    """trl_sac_samples_f32 with a step state makes update u's two draws from the device-resident update count (2u + 1,
+    2u + 2): the values trl_philox_normal_f32 is launched for where the draws are sharded over ranks (forced here on one
+    rank) -- parameters, targets, alpha and every logged number agree."""
+    from torchrl_amd.algo.off_policy.twin_sac_q import _FusedSAC
+    with monkeypatch.context() as m:
+        m.setattr(_FusedSAC, "_inline_noise", lambda self: False)
+        ia, fa, ta, la = _sac_run(True)
     ib, fb, tb, lb = _sac_run(True)
     assert torch.equal(fa, fb) and torch.equal(ta, tb) and torch.equal(la, lb)
     for x, y in zip(ia, ib):
@@ -228,8 +232,9 @@ def test_dqn_epoch_as_one_graph_equals_sample_and_enqueue_one_by_one(Q, soft, mo
     from test_fullsize_offpolicy_gpu import build_cfg5
     res = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("TRL_DQN_EPOCH_GRAPH", flag)
         qf, pf, env, buf, col, agent = build_cfg5(Q)
+        if flag == "0":                                                  # the whole-epoch hook declines: one by one
+            agent.update_epoch_deferred = lambda count: None
         agent.logger = _Rec()
         agent.opt_times = 3
         agent.use_soft_update, agent.target_hard_update_period = soft, 7

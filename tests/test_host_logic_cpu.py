@@ -155,6 +155,14 @@ def test_statistics_ring_and_index_slab_bookkeeping():
     assert ring.read(h2).tolist() == [[6, -6], [7, -7]] and ring.read([]).shape == (0, 2)
     h3 = launch(8, 4)                                                    # h2 was read in full: no copy needed
     assert h3[0][0] is h2[0][0] and ring.read(h3)[:, 0].tolist() == [8, 9, 10, 11]
+    # handles resolved piecemeal (every epoch's on their own) and twice: rows are free once read, whatever the order
+    h4 = launch(12, 2)                                                   # rows 0, 1
+    assert ring.read(h4[:1]).tolist() == [[12, -12]] and ring.read(h4[:1]).tolist() == [[12, -12]]
+    h5 = launch(14, 3)                                                   # rows 2, 3, 0: row 0 was read, row 1 is not touched
+    assert h5[0][0] is h4[0][0]
+    h6 = launch(17, 4)                                                   # rows 1, 2, 3, 0: unread updates 13, 14, 15, 16
+    assert h6[0][0] is not h5[0][0] and ring.read([h4[1]] + h5)[:, 0].tolist() == [13, 14, 15, 16]
+    assert ring.read(h6)[:, 0].tolist() == [17, 18, 19, 20]
 
     slab = IndexSlab("cpu")
     idx = np.arange(12).reshape(3, 4)

@@ -173,8 +173,8 @@ def test_epoch_result_read_back_on_first_access_equals_the_immediate_one(monkeyp
     speculative copy holds."""
     def run(eager, rows=None):
         torch.manual_seed(0)                                                # same initial networks in every run
-        monkeypatch.setenv("TRL_EAGER_EPOCH_RESULT", "1" if eager else "0")
         pf, vf, env, buf, col, agent, logger = build(None, "", 64, 16, 5, 1000, 256, 3, noise_mode="device")
+        col.eager_epoch_result = eager
         if rows is not None:
             col.SPECULATIVE_ROWS = rows
         out = []
@@ -212,8 +212,8 @@ def test_update_infos_taken_later_equal_the_ones_read_in_place(monkeypatch):
 
     def run(deferred):
         torch.manual_seed(0)
-        monkeypatch.setenv("TRL_EAGER_UPDATE_INFOS", "0" if deferred else "1")
         pf, vf, env, buf, col, agent, logger = build(None, "", 64, 16, 5, 1000, 256, 3, noise_mode="device")
+        agent.eager_update_infos = not deferred
         log = agent.logger = Later()
         for epoch in range(4):
             col.train_one_epoch()

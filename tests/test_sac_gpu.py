@@ -146,8 +146,16 @@ def test_fused_three_layer_forward_equals_the_per_layer_launches(M, D, O, act, l
     assert _C.mlp3_forward_ok(D, 256, 256, O)
     keep = [True, False, True]
     outs, tapes = ops.mlp_forward_group(layers_list, xs, code[act], last_act=code[last], keep=keep)
-    monkeypatch.setenv("TRL_MLP3_PER_LAYER", "1")
-    want, wtapes = ops.mlp_forward_group(layers_list, xs, code[act], last_act=code[last])
+    want, wtapes = [], []                                                  # the three dense-layer launches of each network
+    for ls, x in zip(layers_list, xs):
+        t = ops.Tape()
+        t.x, t.layers, t.act, t.last_act, t.outs = x, ls, code[act], code[last], []
+        h = x
+        for k, (w, b) in enumerate(ls):
+            h = _C.linear_fwd(h, w, b, code[last] if k == 2 else code[act])
+            t.outs.append(h)
+        want.append(h)
+        wtapes.append(t)
     for g in range(G):
         if keep[g]:
             assert torch.equal(tapes[g].outs[0], wtapes[g].outs[0]) and torch.equal(tapes[g].outs[1], wtapes[g].outs[1])
@@ -156,7 +164,6 @@ def test_fused_three_layer_forward_equals_the_per_layer_launches(M, D, O, act, l
         err = (outs[g] - want[g]).abs().max().item()
         assert err < 2e-6 * max(1.0, want[g].abs().max().item()), (g, err)
     # the backward pass runs on a fused tape as on a per-layer one
-    monkeypatch.setenv("TRL_MLP3_PER_LAYER", "0")
     d = torch.randn(M, O, generator=gen).to(DEV)
     mk = lambda: [(torch.zeros(256, D, device=DEV), torch.zeros(256, device=DEV)),
                   (torch.zeros(256, 256, device=DEV), torch.zeros(256, device=DEV)),
@@ -174,7 +181,7 @@ def test_fused_three_layer_forward_equals_the_per_layer_launches(M, D, O, act, l
 @pytest.mark.parametrize("act", ["relu", "tanh"])
 def test_one_output_head_backward_through_the_rank_one_kernel(act, monkeypatch):
     """mlp_backward_group on networks with a ONE-output head: d(hidden) = dq w^T comes from trl_outer_gate_group_f32 already
-    gated, the layer below then runs ungated -- against the K = 1 GEMM + gate-operand path: input gradients and every
+    gated, the layer below then runs ungated -- against float64 autograd: input gradients and every
     weight / bias gradient (twin group, one network at an odd parameter offset)."""
     from torchrl_amd import _C, ops
     code = {"relu": _C.ACT_RELU, "tanh": _C.ACT_TANH}[act]
@@ -191,20 +198,19 @@ def test_one_output_head_backward_through_the_rank_one_kernel(act, monkeypatch):
         off += 1                                                            # the second network starts at an odd offset
     xs = [torch.randn(M, D, generator=gen).to(DEV) for _ in range(G)]
     dqs = [torch.randn(M, 1, generator=gen).to(DEV) for _ in range(G)]
-    res = []
-    for off_switch in ("1", "0"):
-        monkeypatch.setenv("TRL_NO_OUTER_GATE", off_switch)
-        outs, tapes = ops.mlp_forward_group(layers_list, xs, code)
-        grads = [[(torch.zeros_like(w), torch.zeros_like(b)) for w, b in ls] for ls in layers_list]
-        dxs = ops.mlp_backward_group(tapes, dqs, grads_list=grads, need_input=True)
-        res.append((dxs, grads))
-    (dxa, ga), (dxb, gb) = res
-    for g in range(G):
-        scale = max(1.0, dxa[g].abs().max().item())
-        assert (dxa[g] - dxb[g]).abs().max().item() < 1e-6 * scale
-        for (wa, ba), (wb, bb) in zip(ga[g], gb[g]):
-            assert (wa - wb).abs().max().item() < 2e-5 * max(1.0, wa.abs().max().item())
-            assert (ba - bb).abs().max().item() < 2e-5 * max(1.0, ba.abs().max().item())
+    outs, tapes = ops.mlp_forward_group(layers_list, xs, code)
+    grads = [[(torch.zeros_like(w), torch.zeros_like(b)) for w, b in ls] for ls in layers_list]
+    dxs = ops.mlp_backward_group(tapes, dqs, grads_list=grads, need_input=True)
+    fn = torch.relu if act == "relu" else torch.tanh
+    for g in range(G):                                                      # float64 autograd on the CPU as the reference
+        ps = [p.detach().double().cpu().requires_grad_(True) for wb in layers_list[g] for p in wb]
+        x = xs[g].double().cpu().requires_grad_(True)
+        h = fn(fn(x @ ps[0].T + ps[1]) @ ps[2].T + ps[3])
+        ((h @ ps[4].T + ps[5]) * dqs[g].double().cpu()).sum().backward()
+        assert (dxs[g].double().cpu() - x.grad).abs().max().item() < 1e-5 * max(1.0, x.grad.abs().max().item())
+        for (wa, ba), pw, pb in zip(grads[g], ps[0::2], ps[1::2]):
+            assert (wa.double().cpu() - pw.grad).abs().max().item() < 2e-5 * max(1.0, pw.grad.abs().max().item())
+            assert (ba.double().cpu() - pb.grad).abs().max().item() < 2e-5 * max(1.0, pb.grad.abs().max().item())
 
 
 def test_rsample_fwd_bwd_vs_autograd():
@@ -510,7 +516,7 @@ def test_off_policy_collector_on_normalised_env_matches_reference(golden, tag):
 @pytest.mark.parametrize("max_frames", [100, 5])
 def test_one_launch_vector_step_equals_the_separate_kernels(monkeypatch, max_frames):
     """trl_synth_collect_step_f32 (sample, store, env.step, bookkeeping, partial reset in one launch) against the eight
-    separate launches, and its graph-replayed form (trl_synth_collect_step_dyn_f32: step counter / ring row on the device,
+    separate launches, and its graph-replayed form (the same entry point with its device-side state: step counter / ring row,
     the 32-row ring wraps under replay): replay rows, env and collector state, epoch reward, finished-episode log and
     evaluation, bit for bit; resets by the env's time limit (horizon 7) or by max_episode_frames (5: no episode ends)."""
     import torchrl.networks as networks
@@ -519,10 +525,12 @@ def test_one_launch_vector_step_equals_the_separate_kernels(monkeypatch, max_fra
     from torchrl.env.synth import SynthVecEnv
     from torchrl.replay_buffers import BaseReplayBuffer
     N, dev = 300, torch.device(DEV)
+    one_launch = VecCollector._one_launch_step
 
     def run(separate, eager=False):
-        monkeypatch.setenv("TRL_COLLECT_SEPARATE", "1" if separate else "0")
-        monkeypatch.setenv("TRL_COLLECT_EAGER", "1" if eager else "0")
+        # the separate launches are what normalised / host / frame envs run: forced here by declining the one-launch form
+        monkeypatch.setattr(VecCollector, "_one_launch_step", (lambda self, env, nz: False) if separate else one_launch)
+        monkeypatch.setenv("TRL_NO_GRAPH", "1" if eager else "0")
         torch.manual_seed(3)
         net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
         pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net).to(dev)

@@ -107,10 +107,8 @@ SIGNATURES = {
     "trl_discount_reward_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "trl_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "trl_gather_rows_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
-    "trl_gather_rows_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64,
-                                       C.c_void_p]),
-    "trl_gather_rows_multi_dyn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                           C.c_int64, C.c_void_p]),
+    "trl_gather_rows_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_int64, C.c_void_p]),
     "trl_adv_stats_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "trl_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
@@ -152,7 +150,8 @@ SIGNATURES = {
     "trl_norm_filt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "trl_ppo_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_clip_adam_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
-    "trl_clip_adam_polyak_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "trl_clip_adam_polyak_f32": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_int, C.c_void_p]),
     "trl_ppo_reduce_adam_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_reduce_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
@@ -163,28 +162,18 @@ SIGNATURES = {
     "trl_tanh_gauss_rsample_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float] * 3 + [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_tanh_gauss_rsample_bwd_cols_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_void_p] + [C.c_float] * 3 +
                                             [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
-    "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int] * 4 + [C.c_void_p]),
-    "trl_sac_samples_philox_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 11 + [C.c_int] * 4 + [C.c_void_p]),
-    "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9),
-    "trl_sac_samples_stats_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 4 +
-                                  [C.c_void_p, C.c_void_p]),
-    "trl_sac_losses_fold_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_int] + [C.c_void_p] * 7 + [C.c_float] * 5 +
-                                [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "trl_clip_adam_polyak_file_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int,
-                                               C.c_void_p, C.c_int, C.c_void_p]),
-    "trl_moments_multi_ring_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p,
-                                                                             C.c_void_p]),
+    "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 4 +
+                            [C.c_void_p, C.c_void_p]),
+    "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_sac_losses_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_int] + [C.c_void_p] * 7 + [C.c_float] * 5 +
+                           [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "trl_synth_collect_step_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 6 +
-                                   [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 6 + [C.c_void_p]),
-    "trl_synth_collect_step_dyn_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int] + [C.c_void_p] * 6 +
-                                       [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 6 + [C.c_int] +
-                                       [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
+                                   [C.c_float, C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p] +
+                                   [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
     "trl_collector_bookkeep_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_sac_alpha_step_f32": (C.c_int, [C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_void_p] * 3),
-    "trl_sac_losses_f32": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_int] + [C.c_void_p] * 6),
     "trl_slice_add_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "trl_polyak_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
-    "trl_moments_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "trl_philox_normal_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "trl_synth_env_step_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_im2col_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
@@ -203,12 +192,10 @@ SIGNATURES = {
                                      + [C.c_void_p]),
     "trl_conv_bwd_weight_u8_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 8
                                    + [C.c_float, C.c_float, C.c_int, C.c_void_p]),
-    "trl_dqn_td_loss_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "trl_quantile_huber_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
-    "trl_dqn_td_loss_filed_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                           C.c_int, C.c_void_p, C.c_void_p]),
-    "trl_quantile_huber_filed_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 +
-                                     [C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_dqn_td_loss_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_quantile_huber_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 +
+                               [C.c_int, C.c_void_p, C.c_void_p]),
     "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
@@ -407,12 +394,8 @@ def gather_rows_multi(srcs, row_idx, outs, slab_counter=None, n_rows=None):
             raise TrlError("gather_rows_multi: out[%d] does not match the batch" % j)
         sp[j], dp[j] = dev_ptr(s, s.dtype, "src"), dev_ptr(o, o.dtype, "out")
         nb[j] = s[0].numel() * s.element_size()
-    if slab_counter is not None:
-        check(lib().trl_gather_rows_multi_dyn(sp, dp, nb, k, dev_ptr(row_idx, torch.int64, "slab"),
-                                              dev_ptr(slab_counter, torch.float64, "counter"), n, rows,
-                                              stream_ptr(srcs[0].device)), "trl_gather_rows_multi_dyn")
-        return outs
-    check(lib().trl_gather_rows_multi(sp, dp, nb, k, dev_ptr(row_idx, torch.int64, "row_idx"), n, rows,
+    check(lib().trl_gather_rows_multi(sp, dp, nb, k, dev_ptr(row_idx, torch.int64, "row_idx"),
+                                      dev_ptr(slab_counter, torch.float64, "counter", allow_none=True), n, rows,
                                       stream_ptr(srcs[0].device)), "trl_gather_rows_multi")
     return outs
 
@@ -467,17 +450,15 @@ def clip_adam_polyak(args, target, source, tau, device, file=None):
     """clip + Adam, then target <- (1 - tau) target + tau source (the Polyak kernel also advances the device step state).
     file = (raw uint8 statistics block, ring (slots, raw bytes) uint8): the Polyak launch also archives `raw` into ring row
     (steps taken before this update) % slots."""
-    if file is not None:
-        raw, ring = file
-        if ring.dim() != 2 or int(ring.shape[1]) != raw.numel() or not ring.is_contiguous():
-            raise TrlError("clip_adam_polyak: ring rows must be statistics blocks")
-        check(lib().trl_clip_adam_polyak_file_f32(C.byref(args), dev_ptr(target, name="target"), dev_ptr(source, name="source"),
-                                                  int(target.numel()), float(tau), dev_ptr(raw, torch.uint8, "raw"),
-                                                  int(raw.numel()), dev_ptr(ring, torch.uint8, "ring"), int(ring.shape[0]),
-                                                  stream_ptr(device)), "trl_clip_adam_polyak_file_f32")
-        return
+    raw, ring = file if file is not None else (None, None)
+    if ring is not None and (ring.dim() != 2 or int(ring.shape[1]) != raw.numel() or not ring.is_contiguous()):
+        raise TrlError("clip_adam_polyak: ring rows must be statistics blocks")
     check(lib().trl_clip_adam_polyak_f32(C.byref(args), dev_ptr(target, name="target"), dev_ptr(source, name="source"),
-                                         int(target.numel()), float(tau), stream_ptr(device)), "trl_clip_adam_polyak_f32")
+                                         int(target.numel()), float(tau), dev_ptr(raw, torch.uint8, "raw", allow_none=True),
+                                         0 if raw is None else int(raw.numel()),
+                                         dev_ptr(ring, torch.uint8, "ring", allow_none=True),
+                                         0 if ring is None else int(ring.shape[0]), stream_ptr(device)),
+          "trl_clip_adam_polyak_f32")
 
 
 def synth_collect_step(env, head, eps, cur_step, ep_return, max_frames, rows, mask, epoch_reward, ep_count, ep_log, step,
@@ -496,7 +477,7 @@ def synth_collect_step(env, head, eps, cur_step, ep_return, max_frames, rows, ma
         int(env.seed_base), dev_ptr(obs_row, name="obs_row", allow_none=True),
         dev_ptr(acts_row, name="acts_row", allow_none=True), dev_ptr(next_row, name="next_row"),
         dev_ptr(rew_row, name="rew_row"), dev_ptr(done_row, name="done_row"),
-        dev_ptr(tl_row, name="tl_row", allow_none=True), dev_ptr(mask, torch.uint8, "mask"),
+        dev_ptr(tl_row, name="tl_row", allow_none=True), 0, None, dev_ptr(mask, torch.uint8, "mask"),
         dev_ptr(epoch_reward, torch.float64, "epoch_reward"), dev_ptr(ep_count, torch.int32, "ep_count"),
         dev_ptr(ep_log, name="ep_log"), int(ep_log.shape[0]), int(step), N, D, A, int(bool(tanh_action)),
         stream_ptr(head.device)), "trl_synth_collect_step_f32")
@@ -507,16 +488,16 @@ def synth_collect_step_dyn(env, head, cur_step, ep_return, max_frames, ring, sta
     """`synth_collect_step` with the step counter / ring row / epoch start on the device (`state`, 4 int64): graph-replayable.
     ring = the six whole ring tensors (obs, acts, next_obs, rewards, terminals, time_limits)."""
     N, D, A = int(env.cur_obs.shape[0]), int(env.cur_obs.shape[1]), int(head.shape[1]) // 2
-    check(lib().trl_synth_collect_step_dyn_f32(
-        dev_ptr(env.cur_obs, name="cur_obs"), dev_ptr(head, name="head"), int(noise_seed), int(noise_row0),
+    check(lib().trl_synth_collect_step_f32(
+        dev_ptr(env.cur_obs, name="cur_obs"), dev_ptr(head, name="head"), None, int(noise_seed), 0, int(noise_row0),
         dev_ptr(env.env_A, name="env_A"), dev_ptr(env.env_B, name="env_B"), dev_ptr(env.t_env, torch.int32, "t_env"),
         dev_ptr(cur_step, torch.int32, "cur_step"), dev_ptr(env.episode_idx, torch.int32, "episode_idx"),
         dev_ptr(ep_return, name="ep_return"), float(env.effective_reward_scale), int(env.horizon), int(max_frames),
         int(env.seed_base), *[dev_ptr(t, name="ring") for t in ring], int(ring[0].shape[0]),
         dev_ptr(state, torch.int64, "state"), dev_ptr(mask, torch.uint8, "mask"),
         dev_ptr(epoch_reward, torch.float64, "epoch_reward"), dev_ptr(ep_count, torch.int32, "ep_count"),
-        dev_ptr(ep_log, name="ep_log"), int(ep_log.shape[0]), N, D, A, int(bool(tanh_action)), stream_ptr(head.device)),
-        "trl_synth_collect_step_dyn_f32")
+        dev_ptr(ep_log, name="ep_log"), int(ep_log.shape[0]), 0, N, D, A, int(bool(tanh_action)), stream_ptr(head.device)),
+        "trl_synth_collect_step_f32")
 
 
 def synth_reset(cur_obs, t_env, cur_step, episode_idx, ep_return, mask, seed_base):
@@ -756,12 +737,9 @@ class FoldPlan:
         probs, self.problems = self.problems, []
         # Layers narrower than a 64 x 64 tile (first / last layers: 17, 23 inputs, 1, 12 outputs) go in their own launch:
         # mixed with the 256 x 256 ones the common grid is mostly empty workgroups and the launch takes 62 us at SAC's
-        # shapes, the two separate ones 30 + 20 us (TRL_DW_ONE_LAUNCH=1: everything in one).
-        if os.environ.get("TRL_DW_ONE_LAUNCH") == "1":
-            groups = [probs]
-        else:
-            wide = [p for p in probs if p[5] >= 64 and p[6] >= 64]
-            groups = [g for g in (wide, [p for p in probs if not (p[5] >= 64 and p[6] >= 64)]) if g]
+        # shapes, the two separate ones 30 + 20 us.
+        wide = [p for p in probs if p[5] >= 64 and p[6] >= 64]
+        groups = [g for g in (wide, [p for p in probs if not (p[5] >= 64 and p[6] >= 64)]) if g]
         chunks = [g[lo:lo + 12] for g in groups for lo in range(0, len(g), 12)]
         for chunk in chunks:
             g = len(chunk)
@@ -907,30 +885,15 @@ def sac_samples(head, head2, eps1, eps2, obs, acts, next_obs, tanh_action=True, 
     new_a, logp, next_a, next_logp = f(B, A), f(B), f(B, A), f(B)
     x_sa, x_next, x_new = f(B, D + A), f(B, D + A), f(B, D + A)
     outs = [dev_ptr(t, name="out") for t in (new_a, logp, next_a, next_logp, x_sa, x_next, x_new)]
-    if mom_part is not None:
-        if mom_part.numel() < 12 * ((B + 63) // 64):
-            raise TrlError("sac_samples: mom_part holds fewer than ceil(B / 64) rows of 12")
-        state, seed = philox if philox is not None else (None, 0)
-        check(lib().trl_sac_samples_stats_f32(dev_ptr(head, name="head"), dev_ptr(head2, name="head2"),
-                                              dev_ptr(eps1, name="eps1"), dev_ptr(eps2, name="eps2"),
-                                              dev_ptr(state, torch.float64, "step_state", allow_none=True), int(seed),
-                                              dev_ptr(obs, name="obs"), dev_ptr(acts, name="acts"),
-                                              dev_ptr(next_obs, name="next_obs"), *outs, B, D, A, int(bool(tanh_action)),
-                                              dev_ptr(mom_part, torch.float64, "mom_part"), stream_ptr(head.device)),
-              "trl_sac_samples_stats_f32")
-        return new_a, logp, next_a, next_logp, x_sa, x_next, x_new
-    if philox is not None:
-        state, seed = philox
-        check(lib().trl_sac_samples_philox_f32(dev_ptr(head, name="head"), dev_ptr(head2, name="head2"),
-                                               dev_ptr(state, torch.float64, "step_state"), int(seed),
-                                               dev_ptr(eps1, name="eps1"), dev_ptr(obs, name="obs"),
-                                               dev_ptr(acts, name="acts"), dev_ptr(next_obs, name="next_obs"), *outs,
-                                               B, D, A, int(bool(tanh_action)), stream_ptr(head.device)),
-              "trl_sac_samples_philox_f32")
-        return new_a, logp, next_a, next_logp, x_sa, x_next, x_new
-    ins = [dev_ptr(t, name=n) for t, n in ((head, "head"), (head2, "head2"), (eps1, "eps1"), (eps2, "eps2"), (obs, "obs"),
-                                           (acts, "acts"), (next_obs, "next_obs"))]
-    check(lib().trl_sac_samples_f32(*ins, *outs, B, D, A, int(bool(tanh_action)), stream_ptr(head.device)),
+    if mom_part is not None and mom_part.numel() < 12 * ((B + 63) // 64):
+        raise TrlError("sac_samples: mom_part holds fewer than ceil(B / 64) rows of 12")
+    state, seed = philox if philox is not None else (None, 0)
+    check(lib().trl_sac_samples_f32(dev_ptr(head, name="head"), dev_ptr(head2, name="head2"),
+                                    dev_ptr(eps1, name="eps1"), dev_ptr(eps2, name="eps2", allow_none=philox is not None),
+                                    dev_ptr(state, torch.float64, "step_state", allow_none=True), int(seed),
+                                    dev_ptr(obs, name="obs"), dev_ptr(acts, name="acts"),
+                                    dev_ptr(next_obs, name="next_obs"), *outs, B, D, A, int(bool(tanh_action)),
+                                    dev_ptr(mom_part, torch.float64, "mom_part", allow_none=True), stream_ptr(head.device)),
           "trl_sac_samples_f32")
     return new_a, logp, next_a, next_logp, x_sa, x_next, x_new
 
@@ -946,22 +909,16 @@ def sac_losses(q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp, alpha, ga
     None); fold = (mom_part, A, mom_out12): sac_samples' partial moments are folded into the logged statistics."""
     B = int(q1.numel())
     outs = [torch.empty((B, 1), dtype=torch.float32, device=q1.device) for _ in range(4)]
-    if alpha_step is not None or fold is not None:
-        ent, lr, state, aout = alpha_step if alpha_step is not None else (0.0, 0.0, None, None)
-        part, A, mom_out = fold if fold is not None else (None, 0, None)
-        ins = [q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp]
-        check(lib().trl_sac_losses_fold_f32(*[dev_ptr(t, name="in%d" % i) for i, t in enumerate(ins)],
-                                            dev_ptr(alpha, name="alpha", allow_none=alpha_step is not None), float(gamma), B,
-                                            *[dev_ptr(t, name="out") for t in outs], dev_ptr(sums, torch.float64, "sums"),
-                                            dev_ptr(state, name="alpha_state", allow_none=True),
-                                            dev_ptr(aout, name="alpha_out", allow_none=True), float(ent), float(lr),
-                                            0.9, 0.999, 1e-8, dev_ptr(part, torch.float64, "mom_part", allow_none=True), int(A),
-                                            dev_ptr(mom_out, torch.float64, "mom_out", allow_none=True),
-                                            stream_ptr(q1.device)), "trl_sac_losses_fold_f32")
-        return outs
-    ins = [q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp, alpha]
-    check(lib().trl_sac_losses_f32(*[dev_ptr(t, name="in%d" % i) for i, t in enumerate(ins)], float(gamma), B,
+    ent, lr, state, aout = alpha_step if alpha_step is not None else (0.0, 0.0, None, None)
+    part, A, mom_out = fold if fold is not None else (None, 0, None)
+    ins = [q1, q2, tq1, tq2, logp_next, rew, term, q1n, q2n, logp]
+    check(lib().trl_sac_losses_f32(*[dev_ptr(t, name="in%d" % i) for i, t in enumerate(ins)],
+                                   dev_ptr(alpha, name="alpha", allow_none=alpha_step is not None), float(gamma), B,
                                    *[dev_ptr(t, name="out") for t in outs], dev_ptr(sums, torch.float64, "sums"),
+                                   dev_ptr(state, name="alpha_state", allow_none=True),
+                                   dev_ptr(aout, name="alpha_out", allow_none=True), float(ent), float(lr),
+                                   0.9, 0.999, 1e-8, dev_ptr(part, torch.float64, "mom_part", allow_none=True), int(A),
+                                   dev_ptr(mom_out, torch.float64, "mom_out", allow_none=True),
                                    stream_ptr(q1.device)), "trl_sac_losses_f32")
     return outs
 
@@ -980,10 +937,7 @@ def polyak(target, source, tau):
 
 
 def moments(x, out4, ld=None, off=0, width=None, lo=float("-inf"), hi=float("inf")):
-    ld = int(x.shape[-1]) if ld is None else ld
-    width = ld - off if width is None else width
-    check(lib().trl_moments_f64(dev_ptr(x, name="x"), int(x.numel()), ld, off, width, lo, hi,
-                                dev_ptr(out4, torch.float64, "out4"), stream_ptr(x.device)), "trl_moments_f64")
+    moments_multi([(x, out4, ld, off, width, lo, hi)])
 
 
 def moments_multi(specs, ring=None):
@@ -999,17 +953,15 @@ def moments_multi(specs, ring=None):
         xs[j], outs[j] = dev_ptr(x, name="x"), dev_ptr(out4, torch.float64, "out4")
         ns[j], lds[j], offs[j], ws[j] = int(x.numel()), ld, off, (ld - off if width is None else width)
         los[j], his[j] = lo, hi
-    if ring is not None:
-        raw, slots, counter = ring
-        if slots.dim() != 2 or int(slots.shape[1]) != raw.numel() or not slots.is_contiguous():
-            raise TrlError("moments_multi: ring rows must be statistics blocks")
-        check(lib().trl_moments_multi_ring_f64(k, xs, ns, lds, offs, ws, los, his, outs, dev_ptr(raw, torch.uint8, "raw"),
-                                               int(raw.numel()), dev_ptr(slots, torch.uint8, "ring"), int(slots.shape[0]),
-                                               dev_ptr(counter, torch.float64, "counter"),
-                                               stream_ptr(specs[0][0].device)), "trl_moments_multi_ring_f64")
-        return
-    check(lib().trl_moments_multi_f64(k, xs, ns, lds, offs, ws, los, his, outs, stream_ptr(specs[0][0].device)),
-          "trl_moments_multi_f64")
+    raw, slots, counter = ring if ring is not None else (None, None, None)
+    if slots is not None and (slots.dim() != 2 or int(slots.shape[1]) != raw.numel() or not slots.is_contiguous()):
+        raise TrlError("moments_multi: ring rows must be statistics blocks")
+    check(lib().trl_moments_multi_f64(k, xs, ns, lds, offs, ws, los, his, outs,
+                                      dev_ptr(raw, torch.uint8, "raw", allow_none=True), 0 if raw is None else int(raw.numel()),
+                                      dev_ptr(slots, torch.uint8, "ring", allow_none=True),
+                                      0 if slots is None else int(slots.shape[0]),
+                                      dev_ptr(counter, torch.float64, "counter", allow_none=True),
+                                      stream_ptr(specs[0][0].device)), "trl_moments_multi_f64")
 
 
 def philox_normal(out, seed, counter):
@@ -1184,23 +1136,24 @@ def _ring_args(ring):
     return dev_ptr(rows, torch.float64, "ring"), int(rows.shape[0]), dev_ptr(counter, torch.float64, "counter")
 
 
+def _acts_ptrs(acts):
+    """(int64 pointer, float32 pointer) of the stored actions -- exactly one is non-null."""
+    if acts.dtype == torch.float32:
+        return None, dev_ptr(acts, name="acts")
+    return dev_ptr(acts, torch.int64, "acts"), None
+
+
 def dqn_td_loss(q, acts, q_next, rew, term, gamma, sums, ring=None):
-    """`acts` int64, or float32 as the replay buffer stores them (then also `ring`: see trl_dqn_td_loss_filed_f32)."""
+    """`acts` int64, or float32 as the replay buffer stores them; `ring` = (rows (slots, 3) float64, device update counter):
+    the three sums are also filed into row (counter mod slots)."""
     B, A = int(q.shape[0]), int(q.shape[1])
     dq = torch.empty_like(q)
-    if acts.dtype == torch.float32:
-        rp, slots, cp = _ring_args(ring)
-        check(lib().trl_dqn_td_loss_filed_f32(dev_ptr(q, name="q"), dev_ptr(acts, name="acts"), dev_ptr(q_next, name="q_next"),
-                                              dev_ptr(rew, name="rew"), dev_ptr(term, name="term"), float(gamma), B, A,
-                                              dev_ptr(dq, name="dq"), dev_ptr(sums, torch.float64, "sums"), rp, slots, cp,
-                                              stream_ptr(q.device)), "trl_dqn_td_loss_filed_f32")
-        return dq
-    if ring is not None:
-        raise TrlError("dqn_td_loss: the filing form takes float32 actions")
-    check(lib().trl_dqn_td_loss_f32(dev_ptr(q, name="q"), dev_ptr(acts, torch.int64, "acts"),
-                                    dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"), dev_ptr(term, name="term"),
-                                    float(gamma), B, A, dev_ptr(dq, name="dq"), dev_ptr(sums, torch.float64, "sums"),
-                                    stream_ptr(q.device)), "trl_dqn_td_loss_f32")
+    ai, af = _acts_ptrs(acts)
+    rp, slots, cp = _ring_args(ring)
+    check(lib().trl_dqn_td_loss_f32(dev_ptr(q, name="q"), ai, af, dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"),
+                                    dev_ptr(term, name="term"), float(gamma), B, A, dev_ptr(dq, name="dq"),
+                                    dev_ptr(sums, torch.float64, "sums"), rp, slots, cp, stream_ptr(q.device)),
+          "trl_dqn_td_loss_f32")
     return dq
 
 
@@ -1208,21 +1161,12 @@ def quantile_huber(q, acts, q_next, rew, term, gamma, A, Q, sums, ring=None):
     B = int(q.shape[0])
     dq = torch.empty_like(q)
     ws = torch.empty(2 * B, dtype=torch.float64, device=q.device)
-    if acts.dtype == torch.float32:
-        rp, slots, cp = _ring_args(ring)
-        check(lib().trl_quantile_huber_filed_f32(dev_ptr(q, name="q"), dev_ptr(acts, name="acts"),
-                                                 dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"),
-                                                 dev_ptr(term, name="term"), float(gamma), B, A, Q, dev_ptr(dq, name="dq"),
-                                                 dev_ptr(ws, torch.float64, "ws"), dev_ptr(sums, torch.float64, "sums"),
-                                                 rp, slots, cp, stream_ptr(q.device)), "trl_quantile_huber_filed_f32")
-        return dq
-    if ring is not None:
-        raise TrlError("quantile_huber: the filing form takes float32 actions")
-    check(lib().trl_quantile_huber_f32(dev_ptr(q, name="q"), dev_ptr(acts, torch.int64, "acts"),
-                                       dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"),
+    ai, af = _acts_ptrs(acts)
+    rp, slots, cp = _ring_args(ring)
+    check(lib().trl_quantile_huber_f32(dev_ptr(q, name="q"), ai, af, dev_ptr(q_next, name="q_next"), dev_ptr(rew, name="rew"),
                                        dev_ptr(term, name="term"), float(gamma), B, A, Q, dev_ptr(dq, name="dq"),
                                        dev_ptr(ws, torch.float64, "ws"), dev_ptr(sums, torch.float64, "sums"),
-                                       stream_ptr(q.device)), "trl_quantile_huber_f32")
+                                       rp, slots, cp, stream_ptr(q.device)), "trl_quantile_huber_f32")
     return dq
 
 

@@ -25,30 +25,39 @@ class StatRing:
 
     def __init__(self, slots, width, dtype, device):
         self.t = torch.zeros(int(slots), int(width), dtype=dtype, device=device)
-        self._ref, self._used = _Ref(self.t), 0
+        # rows of the ring whose update has been launched but not read yet, and the row the next update will be filed into
+        self._ref, self._unread, self._next = _Ref(self.t), set(), None
 
     @property
     def slots(self):
         return int(self.t.shape[0])
 
     def make_room(self, count):
-        """Call BEFORE launching `count` more updates."""
-        if self._used + count > self.slots:
-            self._ref.t = self.t.clone()                                 # (stream-ordered: after every pending update)
-            self._ref, self._used = _Ref(self.t), 0
+        """Call BEFORE launching `count` more updates: if one of the rows they will be filed into still holds an unread
+        update, the pending handles are re-pointed at a copy of the ring (stream-ordered: after every pending update)."""
+        if not self._unread:
+            return
+        nxt = 0 if self._next is None else self._next
+        if count >= self.slots or any((nxt + k) % self.slots in self._unread for k in range(count)):
+            self._ref.t = self.t.clone()
+            self._ref, self._unread = _Ref(self.t), set()
 
     def handles(self, first, count):
         """(ref, row) of updates first .. first + count - 1, just launched."""
-        self._used += count
-        return [(self._ref, (first + k) % self.slots) for k in range(count)]
+        rows = [(first + k) % self.slots for k in range(count)]
+        self._unread.update(rows)
+        self._next = (first + count) % self.slots
+        return [(self._ref, row) for row in rows]
 
     def read(self, pairs):
-        """Host rows of the given (ref, row) pairs, stacked in their order: one D2H per ring (copy); the only host sync."""
+        """Host rows of the given (ref, row) pairs, stacked in their order: one D2H per ring (copy); the only host sync.
+        Reading a handle twice is harmless; a row counts as free once its handle has been read."""
         if not pairs:
             return torch.zeros(0, int(self.t.shape[1]), dtype=self.t.dtype).numpy()
+        for ref, row in pairs:
+            if ref is self._ref:
+                self._unread.discard(row)
         if all(ref is self._ref for ref, _ in pairs):                    # the usual case: one ring, nothing wrapped
-            if len(pairs) == self._used:
-                self._used = 0                                           # everything outstanding was read
             return self.t.cpu().numpy()[[row for _, row in pairs]]
         rows_of = {}
         for ref, row in pairs:

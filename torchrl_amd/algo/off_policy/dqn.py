@@ -254,15 +254,13 @@ class _FusedDQN:
         """`count` x {uniform replay sample -> update} as ONE graph launch (see _FusedSAC.enqueue_epoch): index sets drawn on
         the host in the reference's order and uploaded once, each update of the graph gathering the set the device-resident
         update count selects.  None when it does not apply: several ranks, a hard target copy due inside the epoch, a
-        replay buffer that stores the sampled keys differently (frame-dedup), no update seen yet, TRL_NO_GRAPH=1,
-        TRL_DQN_EPOCH_GRAPH=0."""
+        replay buffer that stores the sampled keys differently (frame-dedup), no update seen yet, TRL_NO_GRAPH=1."""
         algo = self.algo
         buf, B, st = getattr(algo, "replay_buffer", None), int(algo.batch_size), self._static
         soft = bool(algo.use_soft_update)
         period, done = int(algo.target_hard_update_period), int(algo.training_update_num)
         if buf is None or st is None or count < 1 or count > self._ring.slots or dist.world_size() != 1 or \
-                dist.collectives_active() or os.environ.get("TRL_NO_GRAPH") == "1" or \
-                os.environ.get("TRL_DQN_EPOCH_GRAPH") == "0" or not hasattr(buf, "gather_sources") or \
+                dist.collectives_active() or os.environ.get("TRL_NO_GRAPH") == "1" or not hasattr(buf, "gather_sources") or \
                 int(st["obs"].shape[0]) != B or (not soft and any((done + j) % period == 0 for j in range(1, count + 1))):
             return None
         keys = ("obs", "next_obs", "acts", "rewards", "terminals")

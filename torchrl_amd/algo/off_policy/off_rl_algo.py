@@ -4,7 +4,6 @@ Per epoch: `opt_times` x {uniform replay sample -> `update` -> log the info dict
 `pretrain_epochs` collection-only epochs (logged without a csv row) and accounts their frames in `pretrain_frames`.
 Engines that replay a captured graph expose `static_batch()`: the replay gather then writes into those fixed-address
 tensors (`random_batch(..., out=)`, an argument the reference does not have)."""
-import os
 import time
 
 import numpy as np
@@ -50,7 +49,7 @@ class OffRLAlgo(RLAlgo):
             if pending is None:
                 pending = [deferred(self._sample()) for _ in range(self.opt_times)]
             later = getattr(self.logger, "add_update_infos_later", None)
-            if later is not None and os.environ.get("TRL_EAGER_UPDATE_INFOS") != "1":
+            if later is not None and not getattr(self, "eager_update_infos", False):
                 later(lambda: self.resolve_updates(pending))             # read when the logger writes its next row: the
             else:                                                        # next epoch's collection is launched meanwhile
                 for info in self.resolve_updates(pending):

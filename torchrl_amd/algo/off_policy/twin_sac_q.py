@@ -198,7 +198,7 @@ class _FusedSAC:
         # One rank with soft target updates: the temperature step, the logged moments and the filing of the statistics block
         # ride on launches the update has anyway (sampling -> partial moments, loss launch -> temperature step + fold of
         # the partials, Polyak launch -> filing); otherwise they are the separate launches sac_alpha / moments_multi.
-        ride = dist.world_size() == 1 and soft and os.environ.get("TRL_SAC_STAT_LAUNCHES") != "1"
+        ride = self._stats_ride_along(soft)
         if ride and (self._mom_part is None or self._mom_part.shape[0] != (B + 63) // 64):
             self._mom_part = torch.zeros((B + 63) // 64, 12, dtype=torch.float64, device=dev)
         new_a, logp, next_a, next_logp, x_sa, x_next, x_new = _C.sac_samples(
@@ -219,7 +219,7 @@ class _FusedSAC:
             if ride and algo.automatic_entropy_tuning else None,
             fold=(self._mom_part, A, self.mom) if ride else None)
         # weight gradients of all nine layers: ONE launch of split GEMMs + ONE fold, after the input-gradient chains
-        plan = _C.FoldPlan(ws, defer_gemm=os.environ.get("TRL_SAC_DW_PER_LAYER") != "1")
+        plan = _C.FoldPlan(ws, defer_gemm=True)
         # ---- the four critic backward passes as one group: through Q1 / Q2 on [obs | new_a] down to the action (policy
         # gradient, no weight gradients: twin_sac_q.py:152-155 discards them, its Q20) and the Q-loss pass on [obs | acts]
         # (weight gradients, no input gradient) ----
@@ -261,11 +261,15 @@ class _FusedSAC:
                           (head_g, self.mom[2], 2 * A, 0, A, -inf, inf)],
                          ring=(self._raw, self._ring.t, self.step_state))                # ... and files the update's numbers
 
+    def _stats_ride_along(self, soft):
+        """One rank with soft target updates: temperature step, logged moments and the filing of the statistics block ride
+        on launches the update has anyway; several ranks pool log pi / the moments first, so they keep their own launches."""
+        return dist.world_size() == 1 and soft
+
     def _inline_noise(self):
         """Device Philox noise on a single rank whose every update so far drew its noise on the device: draw u's counters
         (2u + 1, 2u + 2) follow from the optimiser step count, so the sampling launch makes them itself."""
-        return (self.algo.noise_mode == "device" and dist.world_size() == 1 and self.noise_ctr == 2 * self.step_count
-                and os.environ.get("TRL_SAC_NOISE_LAUNCHES") != "1")
+        return self.algo.noise_mode == "device" and dist.world_size() == 1 and self.noise_ctr == 2 * self.step_count
 
     def _lrs(self):
         algo = self.algo
@@ -335,15 +339,14 @@ class _FusedSAC:
     def enqueue_epoch(self, count):
         """`count` x {uniform replay sample -> update} as ONE graph launch: the index sets are drawn on the host in the
         order `count` random_batch calls would draw them and uploaded once; every update of the graph gathers the set
-        the device-resident update count selects (trl_gather_rows_multi_dyn), draws its own noise from that count and files
+        the device-resident update count selects (trl_gather_rows_multi with its update counter), draws its own noise from that count and files
         its statistics into its ring slot.  Returns the handles, or None when this path does not apply (host noise,
-        several ranks, hard target updates, a replay buffer that does not store the sampled keys plainly, TRL_NO_GRAPH=1,
-        TRL_SAC_EPOCH_GRAPH=0)."""
+        several ranks, hard target updates, a replay buffer that does not store the sampled keys plainly, TRL_NO_GRAPH=1)."""
         algo = self.algo
         buf, B = getattr(algo, "replay_buffer", None), int(algo.batch_size)
         if buf is None or count < 1 or count > self._ring.slots or not algo.use_soft_update or \
                 not self._inline_noise() or dist.collectives_active() or os.environ.get("TRL_NO_GRAPH") == "1" or \
-                os.environ.get("TRL_SAC_EPOCH_GRAPH") == "0" or not hasattr(buf, "gather_sources"):
+                not hasattr(buf, "gather_sources"):
             return None
         keys = ("obs", "next_obs", "acts", "rewards", "terminals")
         srcs = buf.gather_sources(keys)

@@ -8,7 +8,6 @@ L_pi = -mean(log pi(a|s) * adv_normalised) - c_ent * mean(ent), L_v = MSE(V(s), 
 clip_grad_norm_(0.5) + Adam for each net.  `update_per_epoch` keeps the reference's loop
 (on_rl_algo.py:35-40: one pass of `one_iteration` minibatches) but runs it through the minibatch row
 indices on the device-resident buffer instead of materialising batches."""
-import os
 
 import numpy as np
 import torch
@@ -53,10 +52,10 @@ class A2C(OnRLAlgo):
         """The epoch's minibatch updates through the engine and their info dicts to the logger.  With a logger that takes
         `add_update_infos_later` and the fused engine the updates are launched, not awaited: the logger resolves the
         statistics at its next row (or the engine at its next run, under the next rollout's shadow) -- between two
-        iterations the device never waits for the host (TRL_EAGER_UPDATE_INFOS=1: read in place)."""
+        iterations the device never waits for the host (`algo.eager_update_infos = True`: read in place)."""
         eng = self.engine()
         later = getattr(self.logger, "add_update_infos_later", None)
-        if later is not None and getattr(eng, "defers", False) and os.environ.get("TRL_EAGER_UPDATE_INFOS") != "1":
+        if later is not None and getattr(eng, "defers", False) and not getattr(self, "eager_update_infos", False):
             pending = eng.run(tensors, row_idx, n_envs, defer=True, **prologue)
             self.training_update_num += len(pending)
             later(pending.resolve)

@@ -145,6 +145,7 @@ class VecCollector(_CollectorBase):
         if noise_mode not in ("host", "device"):
             raise ValueError("noise_mode must be 'host' or 'device'")
         self.noise_mode = noise_mode
+        self.eager_epoch_result = False         # True: train_one_epoch waits for its result instead of handing back a lazy mapping
         self.global_step = 0
         self._log_step0 = 0
         dev = self.env.device
@@ -296,12 +297,11 @@ class VecCollector(_CollectorBase):
 
     def _one_launch_step(self, env, nz):
         """Synthetic vector env + reparameterised Gaussian policy, no normaliser: everything after the policy MLP is
-        ONE launch (trl_synth_collect_step_f32) instead of eight (TRL_COLLECT_SEPARATE=1 keeps the separate kernels)."""
+        ONE launch (trl_synth_collect_step_f32) instead of eight."""
         pf = self.pf
         return (nz is None and self.continuous and not getattr(env, "is_host_env", False)
                 and hasattr(pf, "tanh_action") and not hasattr(pf, "logstd") and not hasattr(pf, "norm_std_explore")
-                and type(pf).__name__ != "DetContPolicy" and hasattr(env, "env_A")
-                and os.environ.get("TRL_COLLECT_SEPARATE") != "1")
+                and type(pf).__name__ != "DetContPolicy" and hasattr(env, "env_A"))
 
     def _step_one_launch(self, env, store, deterministic, max_frames):
         from .. import ops
@@ -379,14 +379,14 @@ class VecCollector(_CollectorBase):
 
     def _replayed_rollout(self, n_steps):
         """Training collection on the synthetic vector env with device noise, one rank: a vector step = the policy pass +
-        trl_synth_collect_step_dyn_f32, whose step counter / ring row / epoch start live on the device -- captured into
+        trl_synth_collect_step_f32 with its device-side state, whose step counter / ring row / epoch start live on the device -- captured into
         a HIP graph (all `n_steps` of the call) on the second call and replayed afterwards: one host call per epoch.
         Returns False when the configuration is outside that path."""
         from .. import dist, ops
         env, buf, pf = self.env, self.replay_buffer, self.pf
         if not (self._one_launch_step(env, getattr(env, "_obs_normalizer", None)) and self.noise_mode == "device"
                 and dist.world_size() == 1 and os.environ.get("TRL_NO_GRAPH") != "1"
-                and os.environ.get("TRL_COLLECT_EAGER") != "1" and hasattr(buf, "_obs") and buf._max_replay_buffer_size > 0):
+                and hasattr(buf, "_obs") and buf._max_replay_buffer_size > 0):
             return False
         n, d, a_dim = env.env_nums, env.obs_dim, env.act_dim
         ring = [buf._ensure_key("obs", (n, d)), buf._ensure_key("acts", (n, a_dim)), buf._ensure_key("next_obs", (n, d)),
@@ -443,10 +443,10 @@ class VecCollector(_CollectorBase):
         mapping that is read back on FIRST ACCESS: the header and the head of the episode log are copied to page-locked
         memory behind the rollout in stream order, so a caller that launches the update before looking at the result
         (RLAlgo.train does) never leaves the GPU idle for the read-back.  The next rollout resolves a result nobody looked
-        at (TRL_EAGER_EPOCH_RESULT=1: read back before returning)."""
+        at (`collector.eager_epoch_result = True`: read back before returning)."""
         self._resolve_pending()
         self.rollout(self.sample_epoch_frames)
-        if os.environ.get("TRL_EAGER_EPOCH_RESULT") == "1" or self._ep_log_host is None \
+        if self.eager_epoch_result or self._ep_log_host is None \
                 or getattr(self.env, "is_host_env", False):
             return self._epoch_result_now()
         if getattr(self, "_hdr_host", None) is None:

@@ -83,6 +83,11 @@ extern "C" int trl_comm_init(trl_comm_t** out, int rank, int world, const void* 
   memset(c, 0, sizeof(*c));
   c->rank = rank; c->world = world;
   c->xr.rank = rank; c->xr.world = world;
+  {                                               // bound of every peer wait: 20 s of the 100 MHz wall clock unless configured
+    const char* t = getenv("TRL_COMM_TIMEOUT_S"); // (a first graph capture, or rank-0-only I/O, on a slow host may need more)
+    const double secs = t ? atof(t) : 20.0;
+    c->xr.wait_ticks = (unsigned long long)((secs > 0.001 ? secs : 20.0) * 1e8);
+  }
   if (unique_id) {
     int rc = load_rccl();
     if (rc) { delete c; return rc; }
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void xr_allreduce_kernel(T* __restrict__ buf, 
     T acc = (T)0;
     for (int q = 0; q < x.world; ++q) {
 #pragma unroll
-      for (int k = 0; k < WORDS; ++k) u.w[k] = xr_wait(mine + xr_small_off(x.world, epoch, q, WORDS * i + k), epoch, x.ctl);
+      for (int k = 0; k < WORDS; ++k) u.w[k] = xr_wait(mine + xr_small_off(x.world, epoch, q, WORDS * i + k), epoch, x.ctl, x.wait_ticks);
       acc = (q == 0) ? u.v : (is_max ? (u.v > acc ? u.v : acc) : acc + u.v);
     }
     buf[i] = acc;

@@ -27,6 +27,16 @@ __device__ __forceinline__ double dq_block_sum(double v, double* smem) {
 // Actions come as int64 (`act`) or as the floats the replay buffer stores (`act_f`, exactly one is non-null); with `ring`
 // the three sums are also filed into row (update count % slots) of a (slots, 3) ring, read back once per epoch.
 struct DqRing { double* ring; const double* step; int slots; };
+// The stored action of sample b as an index in [0, A): a NaN or out-of-range stored value (an uninitialised row, a host env
+// that returned a float action) must not turn into an out-of-bounds read of q and write of dq inside a replayed graph --
+// it is clamped (NaN -> 0).  The reference raises an IndexError there (dqn.py:54, `gather`); the host side validates the
+// actions it stores.
+__device__ __forceinline__ int dq_action(const int64_t* act, const float* act_f, int b, int A) {
+  int at;
+  if (act) { const int64_t a = act[b]; at = a < 0 ? 0 : (a >= A ? A - 1 : (int)a); }
+  else { const float a = act_f[b]; at = (a >= 0.0f) ? (a < (float)A ? (int)a : A - 1) : 0; }
+  return at;
+}
 __device__ __forceinline__ void dq_file(const DqRing& r, double a, double b, double c) {
   if (!r.ring) return;
   const int64_t u = (int64_t)r.step[0];                                // (the optimiser step of this update comes later)
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(DQ_THREADS) void dqn_td_kernel(const float* __restr
   for (int b = threadIdx.x; b < B; b += DQ_THREADS) {
     float mx = -INFINITY;
     for (int a = 0; a < A; ++a) mx = fmaxf(mx, qn[(size_t)b * A + a]);
-    const int at = act ? (int)act[b] : (int)act_f[b];
+    const int at = dq_action(act, act_f, b, A);
     const float qsa = q[(size_t)b * A + at];
     const float tgt = rew[b] + gamma * (1.0f - term[b]) * mx;
     const float e = qsa - tgt;
@@ -63,17 +73,12 @@ static int dqn_td(const float* q, const int64_t* acts, const float* acts_f, cons
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
-extern "C" int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const float* q_next, const float* rewards,
-                                   const float* terminals, float gamma, int B, int A, float* dq, double* sums,
-                                   void* stream) {
-  return dqn_td(q, acts, nullptr, q_next, rewards, terminals, gamma, B, A, dq, sums, DqRing{nullptr, nullptr, 0}, stream);
-}
-extern "C" int trl_dqn_td_loss_filed_f32(const float* q, const float* acts_f, const float* q_next, const float* rewards,
-                                         const float* terminals, float gamma, int B, int A, float* dq, double* sums,
-                                         double* ring, int slots, const double* update_count, void* stream) {
-  TRL_REQUIRE(!ring || (slots > 0 && update_count), "dqn_td_loss_filed: ring without slots / counter");
-  return dqn_td(q, nullptr, acts_f, q_next, rewards, terminals, gamma, B, A, dq, sums, DqRing{ring, update_count, slots},
-                stream);
+extern "C" int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,
+                                   const float* rewards, const float* terminals, float gamma, int B, int A, float* dq,
+                                   double* sums, double* ring, int slots, const double* update_count, void* stream) {
+  TRL_REQUIRE(!acts != !acts_f, "dqn_td_loss: exactly one of acts (int64) / acts_f (float)");
+  TRL_REQUIRE(!ring || (slots > 0 && update_count), "dqn_td_loss: ring without slots / counter");
+  return dqn_td(q, acts, acts_f, q_next, rewards, terminals, gamma, B, A, dq, sums, DqRing{ring, update_count, slots}, stream);
 }
 
 // ---------------------------------------------------------------- K15
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(DQ_THREADS) void quantile_huber_kernel(const float*
     s_astar = best;
   }
   __syncthreads();
-  const int at = act ? (int)act[b] : (int)act_f[b], as = s_astar;
+  const int at = dq_action(act, act_f, b, A), as = s_astar;
   const float r = rew[b], nd = gamma * (1.0f - term[b]);
   for (int i = threadIdx.x; i < Q; i += DQ_THREADS) { T[i] = r + nd * nb[as * Q + i]; th[i] = qb[at * Q + i]; }
   for (int e = threadIdx.x; e < A * Q; e += DQ_THREADS) dq[(size_t)b * A * Q + e] = 0.0f;
@@ -147,18 +152,13 @@ __global__ __launch_bounds__(DQ_THREADS) void quantile_fold_kernel(const double*
 static int quantile_huber(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,
                           const float* rewards, const float* terminals, float gamma, int B, int A, int Q, float* dq,
                           double* workspace, double* sums, DqRing ring, void* stream);
-extern "C" int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* q_next, const float* rewards,
-                                      const float* terminals, float gamma, int B, int A, int Q, float* dq,
-                                      double* workspace /* 2B doubles */, double* sums, void* stream) {
-  return quantile_huber(q, acts, nullptr, q_next, rewards, terminals, gamma, B, A, Q, dq, workspace, sums,
-                        DqRing{nullptr, nullptr, 0}, stream);
-}
-extern "C" int trl_quantile_huber_filed_f32(const float* q, const float* acts_f, const float* q_next, const float* rewards,
-                                            const float* terminals, float gamma, int B, int A, int Q, float* dq,
-                                            double* workspace, double* sums, double* ring, int slots,
-                                            const double* update_count, void* stream) {
-  TRL_REQUIRE(!ring || (slots > 0 && update_count), "quantile_huber_filed: ring without slots / counter");
-  return quantile_huber(q, nullptr, acts_f, q_next, rewards, terminals, gamma, B, A, Q, dq, workspace, sums,
+extern "C" int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,
+                                      const float* rewards, const float* terminals, float gamma, int B, int A, int Q,
+                                      float* dq, double* workspace /* 2B doubles */, double* sums, double* ring, int slots,
+                                      const double* update_count, void* stream) {
+  TRL_REQUIRE(!acts != !acts_f, "quantile_huber: exactly one of acts (int64) / acts_f (float)");
+  TRL_REQUIRE(!ring || (slots > 0 && update_count), "quantile_huber: ring without slots / counter");
+  return quantile_huber(q, acts, acts_f, q_next, rewards, terminals, gamma, B, A, Q, dq, workspace, sums,
                         DqRing{ring, update_count, slots}, stream);
 }
 static int quantile_huber(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,

@@ -102,14 +102,9 @@ static int gather_multi(const void* const* src, void* const* dst, const int64_t*
   return TRL_OK;
 }
 extern "C" int trl_gather_rows_multi(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
-                                     const int64_t* row_idx, int n_rows, int64_t src_rows, void* stream) {
-  return gather_multi(src, dst, row_bytes, n_keys, row_idx, n_rows, src_rows, nullptr, stream);
-}
-extern "C" int trl_gather_rows_multi_dyn(const void* const* src, void* const* dst, const int64_t* row_bytes, int n_keys,
-                                         const int64_t* slab, const double* update_count, int n_rows, int64_t src_rows,
-                                         void* stream) {
-  TRL_REQUIRE(update_count, "gather_rows_multi_dyn: null counter");
-  return gather_multi(src, dst, row_bytes, n_keys, slab, n_rows, src_rows, update_count, stream);
+                                     const int64_t* row_idx, const double* update_count, int n_rows, int64_t src_rows,
+                                     void* stream) {
+  return gather_multi(src, dst, row_bytes, n_keys, row_idx, n_rows, src_rows, update_count, stream);
 }
 
 extern "C" int trl_gather_rows_f32(const float* src, const int64_t* row_idx, float* dst, int n_rows,

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
         if ((++it & 1023u) == 0) {                                // bounded by wall-clock time (100 MHz counter): ~2 s alone,
           const unsigned long long now = wall_clock64();          // ~25 s when other ranks' gradients are being waited for
           if (t0 == 0) t0 = now;
-          if (now - t0 > (xrank ? 2500000000ull : 200000000ull)) {
+          if (now - t0 > (xrank ? xr.wait_ticks + xr.wait_ticks / 4 : 200000000ull)) {
             __hip_atomic_store(reinterpret_cast<unsigned*>(ws), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
@@ -928,7 +928,11 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   // (every block has passed its exchange by the time block (0, 0) has seen all norm slots)
   if (xrank && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
     __hip_atomic_store(xr.ctl + 4, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (own_) {                                                      // adam_element on the prefetched state
+  // A cross-rank wait that timed out left a PARTIAL gradient sum: no parameter is written then (every block has finished
+  // its exchange before any block sees all norm slots, so the flag is final here and all blocks decide alike); the host
+  // raises through trl_comm_error at its next check.
+  const bool xfail = xrank && __hip_atomic_load(xr.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  if (own_ && !xfail) {                                            // adam_element on the prefetched state
     const int net = blockIdx.y;
     const float gr = gval * a.grad_scale * s_coef[net];
     const float m = a.beta1 * m_old + (1.0f - a.beta1) * gr;
@@ -1116,7 +1120,7 @@ static int launch_reduce_adam(const float* partial, const double* scal_partial, 
   TRL_REQUIRE(adam->grads == grads, "adam->grads must be the reduce output");
   TRL_REQUIRE(!xr || p_pf + p_vf <= TRL_XR_CAP_GRAD, "gradient exceeds the peer buffer");
   XrArgs none;
-  none.rank = 0; none.world = 1; none.ctl = nullptr;
+  none.rank = 0; none.world = 1; none.ctl = nullptr; none.wait_ticks = 0;
   for (int r = 0; r < TRL_MAX_RANKS; ++r) none.peer[r] = nullptr;
   hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(trl_ceil_div(ps, RED_CHUNK), 2), dim3(64 * RED_WAVES), 0, (hipStream_t)stream,
                      partial, scal_partial, n_wg, resolve_pf_wgs(n_wg, n_wg_pf), ps, p_pf, p_vf,
@@ -1180,13 +1184,10 @@ static int clip_adam_polyak(const trl_adam_t* p, float* target, const float* sou
   return TRL_OK;
 }
 extern "C" int trl_clip_adam_polyak_f32(const trl_adam_t* p, float* target, const float* source, int64_t n, float tau,
-                                        void* stream) {
-  return clip_adam_polyak(p, target, source, n, tau, nullptr, 0, nullptr, 0, stream);
-}
-extern "C" int trl_clip_adam_polyak_file_f32(const trl_adam_t* p, float* target, const float* source, int64_t n, float tau,
-                                             const void* raw, int raw_bytes, void* ring, int slots, void* stream) {
-  TRL_REQUIRE(raw && ring && raw_bytes > 0 && raw_bytes % 4 == 0 && slots > 0, "clip_adam_polyak_file: bad ring");
-  TRL_REQUIRE(p && p->step_state, "clip_adam_polyak_file: the row is picked by the device-resident step state");
+                                        const void* raw, int raw_bytes, void* ring, int slots, void* stream) {
+  if (!ring) return clip_adam_polyak(p, target, source, n, tau, nullptr, 0, nullptr, 0, stream);
+  TRL_REQUIRE(raw && raw_bytes > 0 && raw_bytes % 4 == 0 && slots > 0, "clip_adam_polyak: bad ring");
+  TRL_REQUIRE(p && p->step_state, "clip_adam_polyak: the ring row is picked by the device-resident step state");
   return clip_adam_polyak(p, target, source, n, tau, raw, raw_bytes, ring, slots, stream);
 }
 

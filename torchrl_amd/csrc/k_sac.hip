@@ -169,7 +169,7 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_samples_kernel(const float* _
   if (stats) {
     // the logged moments of the policy head on obs -- clamped log_std, mean -- and of log_prob (twin_sac_q.py:190-207) as
     // per-wave partials {sum, sum of squares, max, -min} x {log_std, log_prob, mean}: row b >> 6 of mom_part (12 doubles);
-    // trl_sac_losses_fold_f32 folds them (the separate trl_moments_multi_f64 launch re-read head and logp for this)
+    // trl_sac_losses_f32 folds them (the separate trl_moments_multi_f64 launch re-read head and logp for this)
     double ps[3] = {0, 0, 0}, pq[3] = {0, 0, 0}, pm[3] = {-INFINITY, -INFINITY, -INFINITY}, pn[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (live) {
       for (int k = 0; k < A; ++k) {
@@ -203,31 +203,16 @@ static int sac_samples_impl(const float* head, const float* head2, const float* 
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
-extern "C" int trl_sac_samples_f32(const float* head, const float* head2, const float* eps1, const float* eps2,
-                                   const float* obs, const float* acts, const float* next_obs, float* new_a, float* logp,
-                                   float* next_a, float* next_logp, float* x_sa, float* x_next, float* x_new, int B, int D,
-                                   int A, int tanh_action, void* stream) {
-  return sac_samples_impl(head, head2, eps1, eps2, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next, x_new,
-                          B, D, A, tanh_action, nullptr, 0, nullptr, nullptr, stream);
-}
-// the same with the two noise draws made in place: update u (u = step_state[0], the device-resident count of optimiser
-// steps taken) uses trl_philox_normal_f32's draws for (seed, 2 u + 1) and (seed, 2 u + 2); eps1_out (B, A) receives the
-// first one for the sampler's backward pass
-extern "C" int trl_sac_samples_philox_f32(const float* head, const float* head2, const double* step_state, int64_t seed,
-                                          float* eps1_out, const float* obs, const float* acts, const float* next_obs,
-                                          float* new_a, float* logp, float* next_a, float* next_logp, float* x_sa,
-                                          float* x_next, float* x_new, int B, int D, int A, int tanh_action, void* stream) {
-  return sac_samples_impl(head, head2, nullptr, nullptr, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next,
-                          x_new, B, D, A, tanh_action, step_state, seed, eps1_out, nullptr, stream);
-}
-// either of the two with the logged moments' per-wave partials as a by-product: mom_part holds ceil(B / 64) rows of 12 doubles;
-// step_state NULL -> eps1 / eps2 are read, else they are drawn in place (eps1 receives the first draw)
-extern "C" int trl_sac_samples_stats_f32(const float* head, const float* head2, float* eps1, const float* eps2,
-                                         const double* step_state, int64_t seed, const float* obs, const float* acts,
-                                         const float* next_obs, float* new_a, float* logp, float* next_a, float* next_logp,
-                                         float* x_sa, float* x_next, float* x_new, int B, int D, int A, int tanh_action,
-                                         double* mom_part, void* stream) {
-  TRL_REQUIRE(mom_part, "sac_samples_stats: null partials");
+// Both policy samples of one update and the three critic inputs in ONE launch.  step_state NULL: eps1 / eps2 are read;
+// step_state given: update u (u = step_state[0], the device-resident count of optimiser steps taken) draws
+// trl_philox_normal_f32's values for (seed, 2 u + 1) and (seed, 2 u + 2) in place and eps1 (B, A) receives the first draw
+// for the sampler's backward pass.  mom_part (nullable): the logged moments' per-wave partials as a by-product,
+// ceil(B / 64) rows of 12 doubles (folded by trl_sac_losses_f32).
+extern "C" int trl_sac_samples_f32(const float* head, const float* head2, float* eps1, const float* eps2,
+                                   const double* step_state, int64_t seed, const float* obs, const float* acts,
+                                   const float* next_obs, float* new_a, float* logp, float* next_a, float* next_logp,
+                                   float* x_sa, float* x_next, float* x_new, int B, int D, int A, int tanh_action,
+                                   double* mom_part, void* stream) {
   if (step_state)
     return sac_samples_impl(head, head2, nullptr, nullptr, obs, acts, next_obs, new_a, logp, next_a, next_logp, x_sa, x_next,
                             x_new, B, D, A, tanh_action, step_state, seed, eps1, mom_part, stream);
@@ -348,9 +333,9 @@ extern "C" int trl_sac_alpha_step_f32(const float* logp, int B, float target_ent
 //   dq1n = -(q1n < q2n ? 1 : q1n == q2n ? .5 : 0) / B,  dq2n likewise.
 // alpha_ptr: device scalar written by the alpha step (or a constant 1 when tuning is off).
 // sums (double[4]): qf1 loss sum, qf2 loss sum, sum(alpha logp - min q_new), sum rewards.
-// Extras of the fused form (trl_sac_losses_fold_f32), each optional:
+// Extras of trl_sac_losses_f32, each optional:
 //  * the temperature step (sac_alpha_kernel's arithmetic) at the top, its alpha used below -- one launch less;
-//  * the fold of trl_sac_samples_stats_f32's per-wave partial moments into {mean, unbiased std, max, min} x {log_std,
+//  * the fold of trl_sac_samples_f32's per-wave partial moments into {mean, unbiased std, max, min} x {log_std,
 //    log_prob, mean} (12 doubles at mom_out), done by the last wave while the others reduce the loss sums.
 struct LossExtras {
   float* alpha_state; float* alpha_out; float target_entropy, lr, beta1, beta2, eps;       // alpha_state NULL: no step
@@ -453,21 +438,6 @@ __global__ __launch_bounds__(SAC_WIDE) void sac_losses_kernel(const float* __res
   if (threadIdx.x == 0) { sums[0] = s1; sums[1] = s2; sums[2] = sp; sums[3] = sr; }     // ONE workgroup (launcher)
 }
 extern "C" int trl_sac_losses_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
-                                  const float* logp_next, const float* rew, const float* term, const float* q1n,
-                                  const float* q2n, const float* logp, const float* alpha, float gamma, int B,
-                                  float* dq1, float* dq2, float* dq1n, float* dq2n, double* sums, void* stream) {
-  TRL_REQUIRE(B > 0, "empty batch");
-  TRL_REQUIRE(q1 && q2 && tq1 && tq2 && logp_next && rew && term && q1n && q2n && logp && alpha, "null input");
-  TRL_REQUIRE(dq1 && dq2 && dq1n && dq2n && sums, "null output");
-  hipStream_t s = (hipStream_t)stream;
-  // one workgroup: B is a few thousand and the sums must be order-deterministic
-  LossExtras none = {};
-  hipLaunchKernelGGL(sac_losses_kernel, dim3(1), dim3(SAC_WIDE), 0, s, q1, q2, tq1, tq2, logp_next, rew, term, q1n,
-                     q2n, logp, alpha, gamma, B, dq1, dq2, dq1n, dq2n, sums, none);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
-}
-extern "C" int trl_sac_losses_fold_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
                                        const float* logp_next, const float* rew, const float* term, const float* q1n,
                                        const float* q2n, const float* logp, const float* alpha, float gamma, int B,
                                        float* dq1, float* dq2, float* dq1n, float* dq2n, double* sums,
@@ -683,10 +653,6 @@ __device__ __forceinline__ void moments_block(const float* __restrict__ x, int64
     if (out2) { out2[0] = mean; out2[1] = sd; out2[2] = mx; out2[3] = -nmn; }      // (the ring slot's copy)
   }
 }
-__global__ __launch_bounds__(MOM_THREADS) void moments_kernel(const float* __restrict__ x, int64_t n, int ld, int off,
-                                                              int width, float lo, float hi_, double* __restrict__ out) {
-  moments_block(x, n, ld, off, width, lo, hi_, out);
-}
 // up to 4 of the above in one launch (blockIdx.x = statistic): the three logged tensors of a SAC update
 #define MOM_MAX 4
 struct MomSet { const float* x[MOM_MAX]; int64_t n[MOM_MAX]; int ld[MOM_MAX], off[MOM_MAX], width[MOM_MAX];
@@ -736,26 +702,17 @@ static int moments_multi(int count, const float* const* x, const int64_t* n, con
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
+// `count` (1..4) statistics in one launch; with `ring` (nullable) the launch also files the update's statistics block
+// `raw` into slot ((int64)update_count[0] - 1) mod slots
 extern "C" int trl_moments_multi_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
                                      const int* width, const float* clamp_lo, const float* clamp_hi, double* const* out4,
+                                     const void* raw, int raw_bytes, void* ring, int slots, const double* update_count,
                                      void* stream) {
-  return moments_multi(count, x, n, ld, off, width, clamp_lo, clamp_hi, out4, MomRing{nullptr, nullptr, nullptr, 0, 0}, stream);
-}
-extern "C" int trl_moments_multi_ring_f64(int count, const float* const* x, const int64_t* n, const int* ld, const int* off,
-                                          const int* width, const float* clamp_lo, const float* clamp_hi,
-                                          double* const* out4, const void* raw, int raw_bytes, void* ring, int slots,
-                                          const double* update_count, void* stream) {
-  TRL_REQUIRE(raw && ring && update_count && raw_bytes > 0 && raw_bytes % 8 == 0 && slots > 0, "moments_multi_ring: bad ring");
+  if (!ring)
+    return moments_multi(count, x, n, ld, off, width, clamp_lo, clamp_hi, out4, MomRing{nullptr, nullptr, nullptr, 0, 0}, stream);
+  TRL_REQUIRE(raw && update_count && raw_bytes > 0 && raw_bytes % 8 == 0 && slots > 0, "moments_multi: bad ring");
   return moments_multi(count, x, n, ld, off, width, clamp_lo, clamp_hi, out4,
                        MomRing{(const uint8_t*)raw, (uint8_t*)ring, update_count, raw_bytes, slots}, stream);
-}
-extern "C" int trl_moments_f64(const float* x, int64_t n, int ld, int off, int width, float clamp_lo, float clamp_hi,
-                               double* out4, void* stream) {
-  TRL_REQUIRE(n > 0 && ld > 0 && off >= 0 && width > 0 && off + width <= ld && n % ld == 0, "bad sizes");
-  TRL_REQUIRE(x && out4, "null pointer");
-  hipLaunchKernelGGL(moments_kernel, dim3(1), dim3(MOM_THREADS), 0, (hipStream_t)stream, x, n, ld, off, width, clamp_lo, clamp_hi, out4);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
 }
 
 // ---------------------------------------------------------------- N(0,1) fill from the Philox stream
@@ -931,46 +888,30 @@ __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(Collect
     }
   }
 }
+// `state` NULL: one step with host-side bookkeeping -- the six row pointers are THE rows to write (obs / acts / tl may be
+// NULL: evaluation stores nothing), eps is read (NULL: drawn in place for (noise_seed, noise_counter)), `step` is the
+// logged step.  `state` given: every per-step quantity is on the device, so that the launch (and the policy pass in front
+// of it) is captured once and replayed for every vector step: state = {global step, ring row, first step of the epoch}
+// (3 int64) followed by a zeroed 32-bit block counter at state + 3; the six pointers are then the whole ring tensors
+// (n_rows time rows of N envs), the noise is drawn in place (counter = global step), the launch stores into row state[1]
+// and advances state[0] and state[1] itself.
 extern "C" int trl_synth_collect_step_f32(float* cur_obs, const float* head, const float* eps, int64_t noise_seed,
                                           int64_t noise_counter, int noise_row0, const float* env_A,
                                           const float* env_B, int32_t* t_env, int32_t* cur_step, int32_t* episode_idx,
                                           float* ep_return, float reward_scale, int horizon, int max_episode_frames,
-                                          int64_t env_seed_base, float* obs_row, float* acts_row, float* next_row,
-                                          float* rew_row, float* done_row, float* tl_row, uint8_t* reset_mask,
-                                          double* epoch_reward, int32_t* ep_count, float* ep_log, int ep_cap, int step,
-                                          int N, int D, int A, int tanh_action, void* stream) {
+                                          int64_t env_seed_base, float* obs, float* acts, float* next_obs,
+                                          float* rewards, float* terminals, float* time_limits, int n_rows, int64_t* state,
+                                          uint8_t* reset_mask, double* epoch_reward, int32_t* ep_count, float* ep_log,
+                                          int ep_cap, int step, int N, int D, int A, int tanh_action, void* stream) {
   TRL_REQUIRE(N >= 0 && D > 0 && D <= 32 && A > 0 && A <= 8 && ep_cap >= 0, "bad sizes (D <= 32, A <= 8)");
   if (N == 0) return TRL_OK;
   TRL_REQUIRE(cur_obs && head && env_A && env_B && t_env && cur_step && episode_idx && ep_return, "null pointer");
-  TRL_REQUIRE(next_row && rew_row && done_row && reset_mask && ep_count && ep_log && noise_row0 >= 0, "null pointer");
-  CollectStep c{cur_obs, head, eps, env_A, env_B, noise_seed, noise_counter, noise_row0, t_env, cur_step, episode_idx, ep_return, reward_scale, horizon,
-                max_episode_frames, env_seed_base, obs_row, acts_row, next_row, rew_row, done_row, tl_row, reset_mask,
-                epoch_reward, ep_count, ep_log, ep_cap, step, N, D, A, tanh_action, nullptr, 0, nullptr};
-  hipLaunchKernelGGL(synth_collect_step_kernel, dim3(trl_ceil_div(N, SAC_THREADS)), dim3(SAC_THREADS),
-                     (D * D + A * D) * sizeof(float), (hipStream_t)stream, c);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
-}
-// The same with every per-step quantity on the device, so that the launch (and the policy pass in front of it) can be
-// captured once and replayed for every vector step: state = {global step, ring row, first step of the epoch} (3 int64)
-// followed by a zeroed 32-bit block counter at state + 3; obs / acts / next_obs / rewards / terminals / time_limits are
-// the ring tensors (n_rows time rows); noise is always drawn in place (counter = global step).  The launch stores into
-// row state[1] and advances state[0] and state[1] itself.
-extern "C" int trl_synth_collect_step_dyn_f32(float* cur_obs, const float* head, int64_t noise_seed, int noise_row0,
-                                              const float* env_A, const float* env_B, int32_t* t_env, int32_t* cur_step,
-                                              int32_t* episode_idx, float* ep_return, float reward_scale, int horizon,
-                                              int max_episode_frames, int64_t env_seed_base, float* obs, float* acts,
-                                              float* next_obs, float* rewards, float* terminals, float* time_limits,
-                                              int n_rows, int64_t* state, uint8_t* reset_mask, double* epoch_reward,
-                                              int32_t* ep_count, float* ep_log, int ep_cap, int N, int D, int A,
-                                              int tanh_action, void* stream) {
-  TRL_REQUIRE(N > 0 && D > 0 && D <= 32 && A > 0 && A <= 8 && ep_cap >= 0 && n_rows > 0, "bad sizes (D <= 32, A <= 8)");
-  TRL_REQUIRE(cur_obs && head && env_A && env_B && t_env && cur_step && episode_idx && ep_return && state, "null pointer");
-  TRL_REQUIRE(obs && acts && next_obs && rewards && terminals && reset_mask && ep_count && ep_log, "null pointer");
-  CollectStep c{cur_obs, head, nullptr, env_A, env_B, noise_seed, 0, noise_row0, t_env, cur_step, episode_idx, ep_return,
-                reward_scale, horizon, max_episode_frames, env_seed_base, obs, acts, next_obs, rewards, terminals,
-                time_limits, reset_mask, epoch_reward, ep_count, ep_log, ep_cap, 0, N, D, A, tanh_action, state, n_rows,
-                reinterpret_cast<unsigned*>(state + 3)};
+  TRL_REQUIRE(next_obs && rewards && terminals && reset_mask && ep_count && ep_log && noise_row0 >= 0, "null pointer");
+  TRL_REQUIRE(!state || (obs && acts && n_rows > 0 && !eps), "device-side step state: whole ring tensors, noise drawn in place");
+  CollectStep c{cur_obs, head, eps, env_A, env_B, noise_seed, state ? 0 : noise_counter, noise_row0, t_env, cur_step,
+                episode_idx, ep_return, reward_scale, horizon, max_episode_frames, env_seed_base, obs, acts, next_obs,
+                rewards, terminals, time_limits, reset_mask, epoch_reward, ep_count, ep_log, ep_cap, state ? 0 : step, N, D,
+                A, tanh_action, state, state ? n_rows : 0, state ? reinterpret_cast<unsigned*>(state + 3) : nullptr};
   hipLaunchKernelGGL(synth_collect_step_kernel, dim3(trl_ceil_div(N, SAC_THREADS)), dim3(SAC_THREADS),
                      (D * D + A * D) * sizeof(float), (hipStream_t)stream, c);
   TRL_LAUNCH_CHECK();

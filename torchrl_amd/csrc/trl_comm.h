@@ -20,7 +20,9 @@ struct XrArgs {                                    // passed by value to kernels
   int rank, world;
   unsigned long long* peer[TRL_MAX_RANKS];         // base of every rank's buffer as mapped into THIS process
   unsigned* ctl;                                   // local control words: [0] small-region epochs done, [1] ticket, [2] error,
-};                                                 //                      [4] gradient-region epochs done, [5] its block ticket
+                                                   //                      [4] gradient-region epochs done, [5] its block ticket
+  unsigned long long wait_ticks;                   // bound of a peer wait in 100 MHz wall-clock ticks (TRL_COMM_TIMEOUT_S, 20 s)
+};
 
 struct trl_comm;
 const XrArgs* trl_comm_xr(const trl_comm* c);      // device-side view of a communicator whose peers are mapped, else null
@@ -40,9 +42,11 @@ __host__ __device__ inline size_t xr_buffer_granules(int world) {
 __device__ __forceinline__ void xr_store(unsigned long long* p, unsigned epoch, unsigned bits) {
   __hip_atomic_store(p, ((unsigned long long)epoch << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// polls one local granule until its tag is `epoch`; bounded by wall-clock time (100 MHz counter, ~20 s) so that a
-// missing rank trips ctl[2] instead of hanging the GPU
-__device__ __forceinline__ unsigned xr_wait(unsigned long long* p, unsigned epoch, unsigned* ctl) {
+// polls one local granule until its tag is `epoch`; bounded by wall-clock time (100 MHz counter; `ticks`, 20 s unless the
+// communicator was created under another TRL_COMM_TIMEOUT_S) so that a missing rank trips ctl[2] instead of hanging the GPU.
+// A caller that goes on to WRITE state (the Adam step) must look at ctl[2] first: the sum is partial after a time-out.
+__device__ __forceinline__ unsigned xr_wait(unsigned long long* p, unsigned epoch, unsigned* ctl,
+                                            unsigned long long ticks = 2000000000ull) {
   unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if ((unsigned)(v >> 32) == epoch) return (unsigned)v;
   const unsigned long long t0 = wall_clock64();
@@ -50,7 +54,7 @@ __device__ __forceinline__ unsigned xr_wait(unsigned long long* p, unsigned epoc
     __builtin_amdgcn_s_sleep(2);
     v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(v >> 32) == epoch) return (unsigned)v;
-    if ((it & 1023u) == 0 && wall_clock64() - t0 > 2000000000ull) {
+    if ((it & 1023u) == 0 && wall_clock64() - t0 > ticks) {
       __hip_atomic_store(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return 0u;
     }
@@ -64,6 +68,7 @@ __device__ __forceinline__ float xr_allsum_f32(const XrArgs& x, unsigned epoch, 
   for (int p = 0; p < x.world; ++p) xr_store(x.peer[p] + xr_grad_off(x.world, epoch, x.rank, i), epoch, bits);
   float s = 0.0f;
   unsigned long long* mine = x.peer[x.rank];
-  for (int q = 0; q < x.world; ++q) s += __uint_as_float(xr_wait(mine + xr_grad_off(x.world, epoch, q, i), epoch, x.ctl));
+  for (int q = 0; q < x.world; ++q)
+    s += __uint_as_float(xr_wait(mine + xr_grad_off(x.world, epoch, q, i), epoch, x.ctl, x.wait_ticks));
   return s;
 }

@@ -28,10 +28,6 @@ __host__ __device__ constexpr int ksteps_for(int d) {
 __host__ __device__ constexpr int align4(int x) { return (x + 3) & ~3; }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-#ifdef TRL_EXP_NOMFMA
-  c[0] = fmaf(a, b, c[0]);
-  return c;
-#endif
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
@@ -43,9 +39,6 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // per tanh with the former 12-instruction form that also carried an x - x^3/3 branch for |x| < 0.04), and fp32 MFMA does
 // not overlap with vector work (tools/ubench/mfma_valu.hip), so every instruction here is wall-clock time in the kernels.
 __device__ __forceinline__ float trl_tanh(float x) {
-#ifdef TRL_EXP_NOTANH
-  return x * 0.5f;
-#endif
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
@@ -260,10 +253,6 @@ __device__ __forceinline__ f32x16 tile_load_N(const float* T, int m, int i, int 
 // g = lane >> 4).  A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], C/D reg r <-> row 4g + r.
 #define TL 17                                   // LDS staging row stride (16 samples + 1)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-#ifdef TRL_EXP_NOMFMA
-  c[0] = fmaf(a, b, c[0]);
-  return c;
-#endif
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 

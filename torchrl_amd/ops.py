@@ -7,7 +7,6 @@ activation, then a linear head.  `mlp_forward` keeps the layer outputs (the "tap
 gradient buffer, and optionally d(input).  act'(.) is applied inside the kernels through the
 stored layer OUTPUTS, so no pre-activation tensors are kept.
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -38,7 +37,7 @@ class Tape:
 def mlp_forward(layers, x, act, last_act=None):
     """layers: [(W, b), ...] (nn.Linear layout); returns (out, tape).  `last_act` (an ACT_* code) is applied to
     the head output inside the last layer's epilogue (deterministic policies: tanh(mlp(x)))."""
-    if len(layers) == 3 and os.environ.get("TRL_MLP3_PER_LAYER") != "1" and all(b is not None for _, b in layers[:2]) and \
+    if len(layers) == 3 and all(b is not None for _, b in layers[:2]) and \
             _C.mlp3_forward_ok(layers[0][0].shape[1], layers[0][0].shape[0], layers[1][0].shape[0], layers[2][0].shape[0]):
         outs, tapes = mlp_forward_group([layers], [x], act, last_act=last_act)      # one fused launch
         return outs[0], tapes[0]
@@ -83,8 +82,7 @@ def mlp_forward_group(layers_list, xs, act, last_act=None, keep=None):
     G = len(layers_list)
     code_last = _C.ACT_NONE if last_act is None else last_act
     ls0 = layers_list[0]
-    if len(ls0) == 3 and os.environ.get("TRL_MLP3_PER_LAYER") != "1" and \
-            _C.mlp3_forward_ok(ls0[0][0].shape[1], ls0[0][0].shape[0], ls0[1][0].shape[0], ls0[2][0].shape[0]) and \
+    if len(ls0) == 3 and _C.mlp3_forward_ok(ls0[0][0].shape[1], ls0[0][0].shape[0], ls0[1][0].shape[0], ls0[2][0].shape[0]) and \
             all(b is not None for ls in layers_list for _, b in ls[:2]):
         keep = [True] * G if keep is None else list(keep)
         res = _C.mlp3_forward_group(layers_list, xs, act, code_last, keep)
@@ -136,7 +134,7 @@ def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspa
             else:
                 _C.linear_bwd_weight_group(*args, workspace=workspace)
         if k > 0 and last and gate_act == _C.ACT_NONE and int(tapes[0].layers[k][0].shape[0]) == 1 and \
-                int(tapes[0].layers[k][0].shape[1]) % 4 == 0 and os.environ.get("TRL_NO_OUTER_GATE") != "1" and \
+                int(tapes[0].layers[k][0].shape[1]) % 4 == 0 and \
                 all(t.outs[k - 1].data_ptr() % 16 == 0 for t in tapes):
             # a head with ONE output: d(hidden) = dq w^T is rank 1 -- produced already gated for the layer below by one
             # streaming launch, and that layer's GEMMs then read one operand instead of two
@@ -297,11 +295,10 @@ def cnn_backward(net, tape, d_out, grads, workspace=None):
     n_conv = len(tape.convs)
     d_feat = mlp_backward(tape.fc, d_out, grads=grads[n_conv:], need_input=True, workspace=workspace)
     P, Cc = tape.feat_shape
-    pregate = os.environ.get("TRL_CONV_DX_COLS") != "1"
     top_y = tape.convs[-1][2]
-    d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P, y_gate=top_y if pregate else None,
+    d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P, y_gate=top_y,
                          gate_act=tape.act).view(tape.B * P, Cc)         # back to (B, P, C)
-    gated = pregate                                                      # d is dZ of layer k (else dY)
+    gated = True                                                         # d is dZ of layer k (else dY)
     for k in range(n_conv - 1, -1, -1):
         kind, src, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]      # src: cols matrix / input activations / frames
         gw, gb = grads[k]
@@ -316,7 +313,7 @@ def cnn_backward(net, tape, d_out, grads, workspace=None):
             _C.linear_bwd_weight(d, yg, ga, src, dw=gw.view(wmat.shape), db=gb, workspace=workspace)
         if k > 0:
             B, H, W, Cin = in_shape
-            if pregate and _C.conv_bwd_input_ok(Cin, int(wmat.shape[0]), kh, kw, sh, sw):
+            if _C.conv_bwd_input_ok(Cin, int(wmat.shape[0]), kh, kw, sh, sw):
                 # implicit transposed convolution: no (B Ho Wo) x (Cin kh kw) matrix in between; its epilogue applies
                 # the NEXT layer down's act'
                 below = tape.convs[k - 1][2]
