@@ -682,6 +682,14 @@ int trl_norm_merge_f64(double* state, const double* sums, int D, void* stream);
 int trl_norm_filt_f32(const float* x, const double* state, float* out, int N, int D, float clip,
                       void* stream);
 
+/* --- host side of the reference's exploration-noise stream (torchrl/policies/distribution.py:60-76) ------------
+ * The reference draws `Normal(0, 1).sample()` from the CPU torch generator = MT19937 (one engine call per float32 element
+ * of a normal_() of n >= 16, n % 16 == 0 elements).  trl_mt19937_advance moves an engine state {state[624], left, next}
+ * (the fields of torch's CPU generator state) forward by `calls` engine calls without producing outputs, so that the
+ * state at any prefix of a block can be handed to another torch.Generator and several host threads draw the segments of
+ * ONE torch.randn block concurrently, bit for bit.  Host code, no device work. */
+int trl_mt19937_advance(uint32_t* state, int32_t* left, int64_t* next, int64_t calls);
+
 /* --- calibration of the two rooflines (nominal AND achievable peaks) -------------------
  * No reference counterpart (the reference publishes no measurement); run by bench.py after its timed
  * region.  trl_peak_copy_f32: dst[0..n) = src[0..n) with 16-byte accesses on every CU (HBM bytes moved = 8 n); mode 0 / 1:

@@ -273,8 +273,17 @@ def test_loss_launch_with_stored_float_actions_files_its_sums(Q):
         d_f = _C.quantile_huber(q, acts.float(), qn, rew, term, 0.99, A, Q, s_f, ring=(ring, counter))
     assert torch.equal(d_i, d_f) and torch.equal(s_i, s_f) and torch.equal(ring[2], s_f)
     assert bool((ring[[0, 1, 3]] == 0).all())
-    with pytest.raises(_C.TrlError):
-        _C.dqn_td_loss(q[:, :A].contiguous(), acts, qn[:, :A].contiguous(), rew, term, 0.99, s_i, ring=(ring, counter))
+    # a stored action outside [0, A) (or NaN) is clamped inside the kernel instead of indexing out of bounds
+    bad = acts.float().clone()
+    bad[0], bad[1], bad[2] = float("nan"), -3.0, 1e9
+    fixed = acts.clone()
+    fixed[0], fixed[1], fixed[2] = 0, 0, A - 1
+    if Q == 1:
+        assert torch.equal(_C.dqn_td_loss(q, bad, qn, rew, term, 0.99, s_f), _C.dqn_td_loss(q, fixed, qn, rew, term, 0.99, s_i))
+    else:
+        assert torch.equal(_C.quantile_huber(q, bad, qn, rew, term, 0.99, A, Q, s_f),
+                           _C.quantile_huber(q, fixed, qn, rew, term, 0.99, A, Q, s_i))
+    assert torch.equal(s_i, s_f)
 
 
 @pytest.mark.parametrize("Q", [1, 8])

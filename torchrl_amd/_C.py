@@ -200,6 +200,7 @@ SIGNATURES = {
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_mt19937_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "trl_peak_copy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "trl_peak_mfma_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "trl_adv_normalize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

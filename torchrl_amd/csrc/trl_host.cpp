@@ -14,3 +14,42 @@ void trl_set_error(const char* fmt, ...) {
 
 extern "C" const char* trl_last_error(void) { return g_err; }
 extern "C" int trl_abi_version(void) { return 1; }
+
+// ---- MT19937 state advance (host) ---------------------------------------------------------------------------------
+// The reference draws its exploration noise from the CPU torch generator (torch/policies/distribution.py:60-76), whose
+// engine is MT19937 (ATen/core/MT19937RNGEngine.h): a call does `if (--left == 0) next_state(); y = state[next++];` and a
+// float32 normal_() of n >= 16 elements (n % 16 == 0) makes exactly n calls.  Advancing the STATE by n calls without
+// producing outputs costs one in-place twist of the 624 words per 624 calls (three loops with dependency distances 397 /
+// 227, so the compiler vectorises them): the state after any prefix of a large draw can be handed to another generator,
+// and P host threads then produce the P segments of ONE torch.randn block concurrently -- the same values in the same
+// places, bit for bit (torchrl_amd/collector/noise.py; tests/test_host_logic_cpu.py).
+static inline uint32_t mt_twist(uint32_t u, uint32_t v) {
+  return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+static void mt_next_state(uint32_t* st) {
+  enum { N = 624, M = 397 };
+  uint32_t first = st[0];
+  for (int i = 0; i < N - M; ++i) st[i] = st[i + M] ^ mt_twist(st[i], st[i + 1]);          // reads old words only
+  for (int i = N - M; i < N - 1; ++i) st[i] = st[i + M - N] ^ mt_twist(st[i], st[i + 1]);  // st[i - 227]: new words
+  (void)first;
+  st[N - 1] = st[M - 1] ^ mt_twist(st[N - 1], st[0]);                                      // wraps to the NEW st[0]
+}
+extern "C" int trl_mt19937_advance(uint32_t* state, int32_t* left, int64_t* next, int64_t calls) {
+  if (!state || !left || !next || calls < 0 || *left < 1 || *left > 624 || *next < 0 || *next > 624) {
+    trl_set_error("trl_mt19937_advance: bad state (left %d, next %lld, calls %lld)", left ? *left : -1,
+                  next ? (long long)*next : -1ll, (long long)calls);
+    return TRL_EINVAL;
+  }
+  int64_t k = calls;
+  int lf = *left;
+  int64_t nx = *next;
+  while (k > 0) {
+    const int64_t avail = lf - 1;                 // calls that do not regenerate
+    if (k <= avail) { lf -= (int)k; nx += k; k = 0; break; }
+    k -= avail;                                   // (left is 1 now: the next call regenerates and consumes word 0)
+    mt_next_state(state);
+    lf = 624; nx = 1; k -= 1;
+  }
+  *left = lf; *next = nx;
+  return TRL_OK;
+}
