@@ -517,3 +517,53 @@ def test_one_block_of_host_noise_equals_per_step_draws():
         torch.manual_seed(3)
         block = torch.randn(T * N, A).view(T, N, A)
         assert torch.equal(per_step, block), (N, A)
+
+
+@pytest.mark.parametrize("n", [1 << 16, 128 * 64 * 6 * 4, 16 * 4099])
+def test_parallel_reference_noise_equals_one_randn_call(n):
+    """torchrl_amd/collector/noise.py: a block of the reference's exploration noise (CPU torch generator,
+    torchrl/policies/distribution.py:60-76) drawn by P threads from the engine states trl_mt19937_advance derives is the
+    block ONE torch.randn call returns, element for element, and leaves the default generator where that call leaves it --
+    from an arbitrary position of the stream, for thread counts that do and do not divide the block."""
+    import torch
+    from torchrl_amd.collector import noise
+    torch.manual_seed(n)
+    torch.randn(37)                                                        # somewhere inside a 624-word state block
+    start = torch.get_rng_state()
+    want = torch.randn(n)
+    end, tail = torch.get_rng_state(), torch.randn(5)
+    for threads in (2, 3, 8):
+        torch.set_rng_state(start)
+        got = noise.randn_into(torch.empty(n), threads=threads)
+        assert torch.equal(got, want), threads
+        assert torch.equal(torch.get_rng_state(), end)
+        assert torch.equal(torch.randn(5), tail)
+    torch.set_rng_state(start)                                             # 2-D tensors are filled in memory order
+    assert torch.equal(noise.randn_into(torch.empty(n // 2, 2), threads=4).view(-1), want)
+
+
+def test_parallel_reference_noise_falls_back_for_small_or_ragged_blocks():
+    import torch
+    from torchrl_amd.collector import noise
+    for n in (5, 48, noise.MIN_PARALLEL - 16, noise.MIN_PARALLEL + 7):    # below the threshold / not a multiple of 16
+        torch.manual_seed(1)
+        want = torch.randn(n)
+        torch.manual_seed(1)
+        assert torch.equal(noise.randn_into(torch.empty(n), threads=4), want)
+    with pytest.raises(Exception):
+        noise.randn_into(torch.empty(64, dtype=torch.float64))
+
+
+def test_mt19937_advance_matches_the_engine():
+    """The state after k engine calls, for k around the 624-word regeneration boundaries, equals the default generator's
+    state after a k-element float32 normal_() (one call per element for k >= 16, k % 16 == 0)."""
+    import torch
+    from torchrl_amd.collector import noise
+    torch.manual_seed(99)
+    base = torch.get_rng_state()
+    for k in (16, 608, 624, 640, 1248, 624 * 5 + 16, 100000 - 100000 % 16):
+        torch.set_rng_state(base)
+        torch.randn(k)
+        want = torch.get_rng_state()
+        bounds, states = noise.segment_states(base, k, 1)
+        assert bounds == [0, k] and torch.equal(states[1], want), k

@@ -29,6 +29,7 @@ import torch
 
 from .. import _C
 from .. import dist
+from . import noise
 from .base import VecCollector, BaseCollector, _EpochResult
 
 
@@ -37,7 +38,8 @@ class _NoisePrefetcher:
 
     `take(T, N, A)` returns the device tensor of this rollout's draws and immediately starts the draw of the NEXT block of
     the same shape: a worker thread fills a page-locked buffer with `torch.randn(out=...)` (the op releases the
-    interpreter lock; ~3 ms of host time for 128 x 2048 x 6 that would otherwise sit between two iterations), copies it
+    interpreter lock, and the block is cut into segments drawn by several threads at once: ~1 ms of host time for
+    128 x 2048 x 6 instead of ~3, which would otherwise sit between two iterations), copies it
     to one of two device buffers on a side stream and records an event the consuming rollout's stream waits on.  The
     draw depends on nothing the GPU produces, so the stream of values is the un-prefetched one, bit for bit.
 
@@ -70,8 +72,9 @@ class _NoisePrefetcher:
         free = self._free.get((shape, slot))
         if free is not None:
             free.synchronize()                              # the rollout that read this slot two blocks ago has finished
-        # one (T * N, A) draw == T successive (N, A) draws when N * A is a multiple of 16 (see _host_noise)
-        torch.randn(shape[0] * shape[1], shape[2], out=host.view(shape[0] * shape[1], shape[2]))
+        # one (T * N, A) draw == T successive (N, A) draws when N * A is a multiple of 16 (see _host_noise); the block itself
+        # is produced by several host threads, each starting from the engine state at its segment (collector/noise.py)
+        noise.randn_into(host)
         with torch.cuda.stream(self._side):
             dev.copy_(host.view(shape), non_blocking=True)
             ev = torch.cuda.Event()
@@ -270,8 +273,10 @@ class VecOnPolicyCollector(VecCollector):
             # torch's CPU normal_ draws its uniforms sequentially over the whole tensor and transforms them in blocks of
             # 16, so ONE (n_steps * N, A) draw is bit-identical to n_steps successive (N, A) draws whenever N * A is a
             # multiple of 16 (checked on torch 2.10: equal for 2048 x 6 and 8 x 6, different for 7 x 6) -- a third of the
-            # host time of the per-step loop
-            return torch.randn(n_steps * n, A).view(n_steps, n, A).to(env.device, non_blocking=True).contiguous()
+            # host time of the per-step loop; the block is cut into segments that several host threads draw at once, each from
+            # the engine state at its first element (collector/noise.py: same values, same generator state afterwards)
+            block = noise.randn_into(torch.empty(n_steps * n, A))
+            return block.view(n_steps, n, A).to(env.device, non_blocking=True).contiguous()
         draws = [dist.shard_rows_of_global(make, 1, n, A, "cpu").cpu() for _ in range(n_steps)]
         return torch.stack(draws).to(env.device, non_blocking=True).contiguous()
 

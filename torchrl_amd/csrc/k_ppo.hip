@@ -217,20 +217,25 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     fetch_row(tile + tile_stride);
   }
   // ---- one-time setup ----
+  constexpr int NV = H * H / (4 * WV_THREADS);    // all loads in flight before the first LDS store
+  f32x4 wv[NV], wt[NV];
+  const int tc = tid & 63, tq = tid >> 6;
+  const float bias1 = tid < H ? gp[F::B1 + tid] : 0.0f, bias2 = tid < H ? gp[F::B2 + tid] : 0.0f;
   {
-    constexpr int NV = H * H / (4 * WV_THREADS);    // all loads in flight before the first LDS store
-    f32x4 wv[NV];
+    // W2 is staged twice, row-major (forward A operand: W2[own row][k]) and transposed (backward A operand: W2[k][own
+    // column]).  Both copies are written with 16-byte LDS stores: the transposed one from a second, column-wise read of
+    // the 16 KB block (coalesced along the column index, served by L1 / L2) -- scattering the row-wise registers instead
+    // took 64 four-byte stores per thread whose 16 lanes of a row hit two banks.
+    // Every global load of the set-up (these, and the register-resident weight slices below) is requested before the
+    // first LDS store waits for one of them.
+    static_assert(WV_THREADS == 256 && H == 64, "the transposed staging maps (column, 4 rows) onto 256 threads");
 #pragma unroll
     for (int t = 0; t < NV; ++t) wv[t] = *reinterpret_cast<const f32x4*>(gp + F::W2 + 4 * (tid + WV_THREADS * t));
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      const int e = 4 * (tid + WV_THREADS * t), r = e / H, c = e - r * H;
-      *reinterpret_cast<f32x4*>(W2F + r * LDW + c) = wv[t];      // forward A operand:  W2[own row][k]
+    for (int t = 0; t < NV; ++t)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) W2B[(c + x) * LDW + r] = wv[t][x];   // backward A operand: W2[k][own column]
-    }
+      for (int x = 0; x < 4; ++x) wt[t][x] = gp[F::W2 + (4 * (tq + 4 * t) + x) * H + tc];       // W2[r4 + x][column tc]
   }
-  for (int e = tid; e < H; e += WV_THREADS) { lds[S::O_B1 + e] = gp[F::B1 + e]; lds[S::O_B2 + e] = gp[F::B2 + e]; }
   for (int e = lane; e < 16 * LDT; e += 64) DOS[e] = 0.0f;       // dout rows >= O stay zero
   // register-resident A operands, lane (i, g): k index of MFMA step (slice sl, r) is feature 16 sl + 4 g + r
   float w1[4][5], w3h[4][4], w3t[4][4];
@@ -264,6 +269,13 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     b3v[r] = (o < O) ? gp[F::B3 + (o < O ? o : 0)] : 0.0f;
   }
   const float vb3 = IS_PF ? 0.0f : gp[F::B3];
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const int e = 4 * (tid + WV_THREADS * t), r = e / H, c = e - r * H;
+    *reinterpret_cast<f32x4*>(W2F + r * LDW + c) = wv[t];
+    *reinterpret_cast<f32x4*>(W2B + tc * LDW + 4 * (tq + 4 * t)) = wt[t];
+  }
+  if (tid < H) { lds[S::O_B1 + tid] = bias1; lds[S::O_B2 + tid] = bias2; }
   __syncthreads();
 
   // advantage normalisation constants (ppo.py:141-147): mean, unbiased std
@@ -578,11 +590,12 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   WCLK(7)
   __syncthreads();
   const int wg = blockIdx.x;
-  for (int e = tid; e < S::P_STRIDE; e += WV_THREADS) {
-    float acc = lds[e];
+  static_assert(S::P_STRIDE % 4 == 0, "partial rows are folded and stored 16 bytes at a time");
+  for (int e4 = tid; e4 < S::P_STRIDE / 4; e4 += WV_THREADS) {
+    f32x4 acc = lds4(lds + 4 * e4);
 #pragma unroll
-    for (int w = 1; w < WV_WAVES; ++w) acc += lds[w * S::P_STRIDE + e];
-    a.partial[(size_t)wg * a.p_stride + e] = acc;
+    for (int w = 1; w < WV_WAVES; ++w) acc += lds4(lds + w * S::P_STRIDE + 4 * e4);          // same order per element
+    *reinterpret_cast<f32x4*>(a.partial + (size_t)wg * a.p_stride + 4 * e4) = acc;
   }
   WCLK(8)
 #ifdef TRL_EXP_CLK
@@ -680,53 +693,59 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
     for (int q = 1; q < RED_WAVES / 4; ++q) gval += t4[q];
     grads[(net == 0 ? 0 : p_pf) + p] = gval;
   }
-  // scalar statistics: one wave per network, lanes stride over the workgroup partials (independent
-  // loads, shuffle reduction) -- a serial 128-deep dependent-load chain here cost 50 us.  Waves 2 / 3 do it:
-  // wave 0 owns this block's gradient values and, in the fused kernel, its rendezvous ticket.
-  if (blockIdx.x == 0 && blockIdx.y == 0 && (wave == 2 || wave == 3)) {
-    const int sw = wave - 2;
-    const int srow0 = sw == 0 ? 0 : n_pf, snrow = sw == 0 ? n_pf : n_wg - n_pf;
-    const double* base = scal + (size_t)srow0 * 8;
+  // Scalar statistics.  They used to sit in block (0, 0) -- three dependent rounds of loads over the workgroup partials and
+  // then the log_std / std statistics as a serial double-precision loop (six exp() in ONE lane): ~5 us that the whole
+  // launch waited for, twice the time of the fold itself.  Now the LAST block of each network's row takes them, off the
+  // path of the blocks whose 64 parameters matter: wave 2 its network's loss / log-prob / value statistics with every row
+  // requested at once (4 x 7 loads in flight per lane: up to 256 workgroups per network in one round trip; the per-lane
+  // accumulation order is the one of the strided loop), wave 3 of the policy's block log_std and std with one action
+  // dimension per lane.
+  const bool stat_block = blockIdx.x == gridDim.x - 1;
+  if (stat_block && wave == 2) {
+    const double* base = scal + (size_t)row0 * 8;
     double v[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? -INFINITY : 0.0;
-    for (int w = lane; w < snrow; w += 64) {
+    for (int w0 = 0; w0 < nrow; w0 += 256) {
+      double o[4][7];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const double o = base[(size_t)w * 8 + k];
-        v[k] = (k >= 2 && k <= 5) ? fmax(v[k], o) : v[k] + o;
+      for (int q = 0; q < 4; ++q) {
+        const int w = w0 + lane + 64 * q;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[q][k] = (w < nrow) ? base[(size_t)w * 8 + k] : ((k >= 2 && k <= 5) ? -INFINITY : 0.0);
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? fmax(v[k], o[q][k]) : v[k] + o[q][k];
     }
 #pragma unroll
     for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? wave_max(v[k]) : wave_sum(v[k]);
     if (lane == 0) {
-      if (sw == 0) {
+      if (net == 0) {
         info[0] = v[6]; info[1] = v[0]; info[2] = v[1]; info[3] = v[2]; info[4] = v[3]; info[5] = v[4]; info[6] = v[5];
-        if (logstd) {                                        // log_std/{mean,std,max,min} (ppo.py:82-85)
-          double sm = 0, sq = 0, mx = -INFINITY, mn = INFINITY;
-          for (int o = 0; o < n_act; ++o) {
-            const double x = fmin(fmax((double)logstd[o], -20.0), 2.0);
-            sm += x; sq += x * x; mx = fmax(mx, x); mn = fmin(mn, x);
-          }
-          const double mean = sm / n_act;
-          info[8] = mean;
-          info[9] = n_act > 1 ? sqrt(fmax((sq - sm * mean) / (n_act - 1), 0.0)) : NAN;
-          info[10] = mx; info[11] = mn;
-          // the same four for std = exp(clamped logstd) (a2c.py:95-100 logs std/*)
-          double es = 0, eq = 0, emx = -INFINITY, emn = INFINITY;
-          for (int o = 0; o < n_act; ++o) {
-            const double x = exp(fmin(fmax((double)logstd[o], -20.0), 2.0));
-            es += x; eq += x * x; emx = fmax(emx, x); emn = fmin(emn, x);
-          }
-          const double em = es / n_act;
-          info[16] = em;
-          info[17] = n_act > 1 ? sqrt(fmax((eq - es * em) / (n_act - 1), 0.0)) : NAN;
-          info[18] = emx; info[19] = emn;
-        }
       } else {
         info[7] = v[6];
         info[12] = v[0]; info[13] = v[1]; info[14] = v[2]; info[15] = v[3];   // v_pred: sum, sum of squares, max, -min
       }
+    }
+  }
+  if (stat_block && net == 0 && wave == 3 && logstd) {
+    // log_std/{mean,std,max,min} (ppo.py:82-85) and the same four for std = exp(clamped logstd) (a2c.py:95-100)
+    const bool has = lane < n_act;
+    const double x = has ? fmin(fmax((double)logstd[has ? lane : 0], -20.0), 2.0) : 0.0;
+    const double e = has ? exp(x) : 0.0;
+    const double sm = wave_sum(x), sq = wave_sum(x * x), es = wave_sum(e), eq = wave_sum(e * e);
+    const double mx = wave_max(has ? x : -INFINITY), mn = -wave_max(has ? -x : -INFINITY);
+    const double emx = wave_max(has ? e : -INFINITY), emn = -wave_max(has ? -e : -INFINITY);
+    if (lane == 0) {
+      const double mean = sm / n_act, em = es / n_act;
+      info[8] = mean;
+      info[9] = n_act > 1 ? sqrt(fmax((sq - sm * mean) / (n_act - 1), 0.0)) : NAN;
+      info[10] = mx; info[11] = mn;
+      info[16] = em;
+      info[17] = n_act > 1 ? sqrt(fmax((eq - es * em) / (n_act - 1), 0.0)) : NAN;
+      info[18] = emx; info[19] = emn;
     }
   }
   return gval;
@@ -1041,6 +1060,8 @@ extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream
   TRL_REQUIRE(p->n_wg >= 2, "n_wg must be >= 2");
   TRL_REQUIRE(p->n_wg_pf >= 0 && p->n_wg_pf < p->n_wg, "n_wg_pf must be 0 (even split) or in [1, n_wg)");
   TRL_REQUIRE(p->n_global > 1.0, "n_global must exceed 1 (unbiased std)");
+  TRL_REQUIRE((((uintptr_t)p->partial | (uintptr_t)p->pf_params | (uintptr_t)p->vf_params) & 15) == 0,
+              "partial / parameter blocks must be 16-byte aligned");
   const int D = p->D, H = p->H, A = p->A;
   PpoDev d;
   d.obs = p->obs; d.acts = p->acts; d.advs = p->advs; d.rets = p->rets; d.old_values = p->old_values;
