@@ -171,3 +171,90 @@ def test_graph_replayed_per_step_rollout_equals_eager(monkeypatch):
         for k in a:
             if isinstance(a[k], torch.Tensor):
                 assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("D,A,act,tanh_action,clipped,B", [
+    (11, 3, "tanh", True, False, 96),        # Hopper-sized: the runtime-dims instantiation of the fused kernels
+    (8, 2, "relu", True, True, 100),         # Swimmer-sized, clipped value loss, a batch that is no multiple of 16
+    (4, 1, "tanh", False, False, 96),        # a single action, no tanh squashing
+    (17, 8, "tanh", True, False, 112),       # the full tile: 17 inputs, 8 actions
+    (16, 6, "relu", True, False, 96),        # no 17th feature
+    (2, 5, "tanh", True, True, 100),
+])
+def test_fused_ppo_update_at_other_input_and_action_sizes_vs_oracle(D, A, act, tanh_action, clipped, B, errlog):
+    """64-wide two-layer networks with any D in [2, 17], A in [1, 8] stay on the fused two-launch update
+    (trl_ppo_minibatch_grad_f32's runtime-dims instantiation + trl_ppo_reduce_adam_f32): three chained updates against
+    the CPU oracle at the contract of the benchmark shape (scalars rel 1e-4 / abs 1e-5, post-step parameters abs 1e-6)."""
+    from torchrl.algo import PPO
+    act_cls = {"tanh": torch.nn.Tanh, "relu": torch.nn.ReLU}[act]
+    pf, vf, agent, (pf0, ls0, vf0) = build(D, A, [64, 64], act_cls, tanh_action, PPO, clip_para=0.2, opt_epochs=2,
+                                          entropy_coeff=0.01, clipped_value_loss=clipped)
+    assert type(agent.engine()).__name__ == "_FusedPPO"
+    ref = PPOOracle(pf0, ls0, vf0, plr=3e-4, vlr=1e-3, entropy_coeff=0.01, clip_para=0.2, clipped_value_loss=clipped,
+                    act=act, tanh_action=tanh_action)
+    gen = torch.Generator().manual_seed(11 * D + A)
+    for step in range(3):
+        obs = torch.randn(B, D, generator=gen)
+        with torch.no_grad():
+            mean = nets.mlp(obs, ref.tpf, act)
+            pre = mean + torch.exp(ref.tlogstd) * torch.randn(B, A, generator=gen)
+            acts = torch.tanh(pre) if tanh_action else pre
+        batch = {"obs": obs.numpy(), "acts": acts.numpy(), "advs": torch.randn(B, 1, generator=gen).numpy() * 2 + 0.3,
+                 "values": torch.randn(B, 1, generator=gen).numpy(), "estimate_returns": torch.randn(B, 1, generator=gen).numpy()}
+        want = ref.update(batch)
+        ref.sync_target()
+        got = agent.update(batch)
+        agent.engine().sync_target_pf()
+        assert sorted(got) == sorted(want)
+        g, w = np.array([got[k] for k in sorted(want)]), np.array([want[k] for k in sorted(want)])
+        errlog("step %d info scalars: max |got - want| / (1e-5 + 1e-4 |want|)" % step, (np.abs(g - w) / (1e-5 + 1e-4 * np.abs(w))).max(), 1.0)
+        np.testing.assert_allclose(g, w, rtol=1e-4, atol=1e-5)
+    perr = 0.0
+    for mod, params in ((pf, ref.pf), (vf, ref.vf)):
+        lin = [l for l in (list(mod.base.seq_fcs) + list(mod.seq_append_fcs)) if isinstance(l, torch.nn.Linear)]
+        for k, l in enumerate(lin):
+            perr = max(perr, (l.weight.cpu() - params[2 * k].detach()).abs().max().item(),
+                       (l.bias.cpu() - params[2 * k + 1].detach()).abs().max().item())
+    perr = max(perr, (pf.logstd.cpu() - ref.logstd.detach()).abs().max().item())
+    errlog("post-step params abs (3 updates)", perr, 1e-6)
+    assert perr < 1e-6, perr
+
+
+def test_collect_and_train_with_the_fused_update_on_a_hopper_sized_env():
+    """11 observations / 3 actions, 64-wide networks: the per-step collector (dense-layer kernels) feeds the fused update
+    kernels; log pi_old comes from another forward kernel than log pi, so the first ratio is 1 up to round-off."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.algo import PPO
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    N, T, D, A = 32, 16, 11, 3
+    net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+    torch.manual_seed(1)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A, tanh_action=True, **net)
+    vf = networks.Net(input_shape=(D,), output_shape=1, **net)
+    env, eval_env = (SynthVecEnv(N, obs_dim=D, act_dim=A, horizon=12, device=DEV) for _ in range(2))
+    env.seed(3)
+    buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+    col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=DEV, train_render=False,
+                               epoch_frames=N * T, max_episode_frames=9, eval_episodes=1, noise_mode="device")
+    assert col._spec is None and col._mlp2 is None                      # no persistent rollout kernel for this shape ...
+    logger = _Log()
+    agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=2, tau=0.95, shuffle=True, entropy_coeff=0.005,
+                discount=0.99, num_epochs=10, batch_size=N * 4, gae=True, env=env, replay_buffer=buf, collector=col,
+                logger=logger, device=DEV, save_dir=None)
+    assert type(agent.engine()).__name__ == "_FusedPPO"                 # ... but the fused update
+    p0 = pf.flat_params().clone()
+    for epoch in range(3):                                              # eager, captured, replayed
+        res = col.train_one_epoch()
+        assert np.isfinite(res["train_epoch_reward"])
+        agent.current_epoch = epoch
+        agent.update_per_epoch()
+    torch.cuda.synchronize()
+    assert len(logger.infos) == 3 * 2 * (T // 4)
+    assert all(np.isfinite(list(i.values())).all() for i in logger.infos)
+    assert abs(logger.infos[0]["ratio/max"] - 1.0) < 1e-5 and abs(logger.infos[0]["ratio/min"] - 1.0) < 1e-5
+    assert (pf.flat_params() - p0).abs().max() > 0
+    ev = col.eval_one_epoch()
+    assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == 12

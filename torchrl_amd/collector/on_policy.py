@@ -185,8 +185,13 @@ class VecOnPolicyCollector(VecCollector):
         if self._dims != (self.env.obs_dim, self.env.act_dim) or int(ops.linear_layers(self.vf)[0][0].shape[1]) != self.env.obs_dim:
             raise _C.TrlError("policy / value input and output sizes %s do not match the env (%d obs, %d act)"
                               % (self._dims, self.env.obs_dim, self.env.act_dim))
+        # the persistent rollout kernel and the fused 2-layer forward are instantiated for the benchmark shape
+        # (trl_mlp2_forward_supported); other shapes the fused UPDATE kernels carry (trl_ppo_partial_stride > 0: D <= 17,
+        # A <= 8, H = 64) are collected by the per-step launch sequence on the dense-layer kernels
+        lib = _C.lib()
         mlp2 = (ps is not None and vs is not None and vs[:2] == ps[:2] and vs[2] == 1 and vs[3] == ps[3]
-                and _C.lib().trl_ppo_partial_stride(ps[0], ps[1], ps[2]) > 0 and os.environ.get("TRL_GENERIC_PPO") != "1")
+                and lib.trl_mlp2_forward_supported(ps[0], ps[1], ps[2]) and lib.trl_mlp2_forward_supported(ps[0], ps[1], 1)
+                and os.environ.get("TRL_GENERIC_PPO") != "1")
         self._mlp2 = ps if mlp2 else None                                   # fused 2-layer forward kernel usable
         self._spec = ps if (mlp2 and not getattr(self.env, "is_host_env", False)) else None   # ... and the rollout kernel
 

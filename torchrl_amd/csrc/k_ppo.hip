@@ -36,6 +36,7 @@ struct PpoDev {
   float* partial;
   double* scal_partial;
   int n_wg, n_pf, p_stride;                  // workgroups [0, n_pf) run the policy, [n_pf, n_wg) the value net
+  int D, A;                                  // actual input / action dims (runtime-dims instantiation of the kernel)
 };
 
 template <int D, int H, int A> struct PpoShape {
@@ -88,11 +89,20 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
-template <int D, int H, int A, int ACT, bool IS_PF, bool CONTIG>
+// RT = false: the network dims are the template's (the benchmark shape, everything folds to constants).
+// RT = true: D and A are UPPER BOUNDS (17, 8) and the actual dims come from the launch (a.D in [2, 17], a.A in [1, 8]):
+// the same 16 + 1-feature tile with the missing input features and outputs masked to zero where they are loaded, the flat
+// parameter offsets and row strides computed from the actual dims -- Hopper / Swimmer / Walker / Reacher-shaped tasks
+// (torchrl/networks/base.py:8-44 is shape-generic) stay on the two-launch path.
+template <int D, int H, int A, int ACT, bool IS_PF, bool CONTIG, bool RT>
 __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
-  constexpr int O = IS_PF ? A : 1;
   using S = WvShape<D, H, A>;
-  using F = MlpFlat<D, H, O>;
+  const int Dr = RT ? a.D : D;                       // input features = row stride of obs and of W1
+  const int O = IS_PF ? (RT ? a.A : A) : 1;          // outputs
+  // offsets inside the flat parameter block for the actual dims (MlpFlat, trl_mlp.h)
+  const int F_W1 = 0, F_B1 = H * Dr, F_W2 = F_B1 + H, F_B2 = F_W2 + H * H, F_W3 = F_B2 + H, F_B3 = F_W3 + O * H,
+            F_LS = F_B3 + O, F_END = F_LS + O;
+  const int PS = RT ? a.p_stride : S::P_STRIDE;      // floats of a partial row (the LDS images keep the template's stride)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4, i = j;
   const float* gp = IS_PF ? a.pf_params : a.vf_params;
@@ -123,11 +133,17 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   const int tpr = a.N >> 4;                                           // tiles per time row
   int p1r = 0, p1c = 0, p2r = 0, p2c = 0, st_r = 0, st_c = 0;         // positions of tile t+1 / t+2 (in strides), stride split
   int64_t ridx1 = 0, ridx2 = 0;
-  const unsigned ox = (unsigned)(j * D + 4 * g) * 4u, ox16 = (unsigned)(j * D + 16) * 4u, os = (unsigned)j * 4u;
-  unsigned oxt[4], oa_[4];
+  // which of the tile's input features exist (RT): features 4g + q of the lane's x operand, feature 16, and feature j of
+  // the lane's X^T operand; a missing feature is read from an in-range address and replaced by zero when it is consumed
+  bool fv[4];
+  const bool f16 = !RT || Dr > 16, jv = !RT || i < Dr;
+  const unsigned ox16 = (unsigned)(j * Dr + (f16 ? 16 : 0)) * 4u, os = (unsigned)j * 4u;
+  unsigned oxq[4], oxt[4], oa_[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    oxt[q] = (unsigned)((4 * g + q) * D + i) * 4u;
+    fv[q] = !RT || 4 * g + q < Dr;
+    oxq[q] = (unsigned)(j * Dr + (fv[q] ? 4 * g + q : 0)) * 4u;
+    oxt[q] = (unsigned)((4 * g + q) * Dr + (jv ? i : 0)) * 4u;
     oa_[q] = (unsigned)(j * O + (4 * g + q < O ? 4 * g + q : 0)) * 4u;
   }
   auto ldb = [](const float* base, unsigned byte_off) -> float {
@@ -140,9 +156,9 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   };
   auto fetch_contig = [&](int64_t ridx, int r, int c) {
     const int64_t cell0 = (r < a.rows_mb) ? ridx * a.N + 16 * c : 0;  // wave-uniform
-    const float* ob = a.obs + cell0 * D;
+    const float* ob = a.obs + cell0 * Dr;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xq[q] = ldb(ob, ox + 4u * q);
+    for (int q = 0; q < 4; ++q) xq[q] = ldb(ob, oxq[q]);
     xq[4] = ldb(ob, ox16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) xtq[q] = ldb(ob, oxt[q]);           // X[sample 4g + q][feature j]: B operand of the dW1 GEMM
@@ -162,13 +178,13 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   auto row_of = [&](int smp, int& e) -> int { const int sm = smp < B ? smp : 0; const int r = sm / a.N; e = sm - r * a.N; return r; };
   auto fetch_inputs = [&](int64_t p, int s0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xq[r] = a.obs[p * D + 4 * g + r];
-    xq[4] = a.obs[p * D + 16];
+    for (int r = 0; r < 4; ++r) xq[r] = a.obs[p * Dr + (fv[r] ? 4 * g + r : 0)];
+    xq[4] = a.obs[p * Dr + (f16 ? 16 : 0)];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int sj = 4 * g + q;
       const int64_t pr = __shfl(p, sj, 64);
-      xtq[q] = a.obs[(s0 + sj < B ? pr : 0) * D + i];
+      xtq[q] = a.obs[(s0 + sj < B ? pr : 0) * Dr + (jv ? i : 0)];
     }
     if constexpr (IS_PF) {
 #pragma unroll
@@ -220,7 +236,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   constexpr int NV = H * H / (4 * WV_THREADS);    // all loads in flight before the first LDS store
   f32x4 wv[NV], wt[NV];
   const int tc = tid & 63, tq = tid >> 6;
-  const float bias1 = tid < H ? gp[F::B1 + tid] : 0.0f, bias2 = tid < H ? gp[F::B2 + tid] : 0.0f;
+  const float bias1 = tid < H ? gp[F_B1 + tid] : 0.0f, bias2 = tid < H ? gp[F_B2 + tid] : 0.0f;
   {
     // W2 is staged twice, row-major (forward A operand: W2[own row][k]) and transposed (backward A operand: W2[k][own
     // column]).  Both copies are written with 16-byte LDS stores: the transposed one from a second, column-wise read of
@@ -229,12 +245,20 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     // Every global load of the set-up (these, and the register-resident weight slices below) is requested before the
     // first LDS store waits for one of them.
     static_assert(WV_THREADS == 256 && H == 64, "the transposed staging maps (column, 4 rows) onto 256 threads");
+    // (runtime dims: the value block starts P_PF floats into the flat buffer, which is a multiple of 4 only for even A)
+    const bool w2_al = !RT || ((reinterpret_cast<uintptr_t>(gp + F_W2) & 15) == 0);
 #pragma unroll
-    for (int t = 0; t < NV; ++t) wv[t] = *reinterpret_cast<const f32x4*>(gp + F::W2 + 4 * (tid + WV_THREADS * t));
+    for (int t = 0; t < NV; ++t) {
+      if (w2_al) wv[t] = *reinterpret_cast<const f32x4*>(gp + F_W2 + 4 * (tid + WV_THREADS * t));
+      else {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) wv[t][x] = gp[F_W2 + 4 * (tid + WV_THREADS * t) + x];
+      }
+    }
 #pragma unroll
     for (int t = 0; t < NV; ++t)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) wt[t][x] = gp[F::W2 + (4 * (tq + 4 * t) + x) * H + tc];       // W2[r4 + x][column tc]
+      for (int x = 0; x < 4; ++x) wt[t][x] = gp[F_W2 + (4 * (tq + 4 * t) + x) * H + tc];       // W2[r4 + x][column tc]
   }
   for (int e = lane; e < 16 * LDT; e += 64) DOS[e] = 0.0f;       // dout rows >= O stay zero
   // register-resident A operands, lane (i, g): k index of MFMA step (slice sl, r) is feature 16 sl + 4 g + r
@@ -243,16 +267,16 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   for (int so = 0; so < 4; ++so) {
     const int row = 16 * so + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w1[so][r] = gp[F::W1 + row * D + 4 * g + r];
-    w1[so][4] = (g == 0) ? gp[F::W1 + row * D + 16] : 0.0f;
+    for (int r = 0; r < 4; ++r) w1[so][r] = fv[r] ? gp[F_W1 + row * Dr + (fv[r] ? 4 * g + r : 0)] : 0.0f;
+    w1[so][4] = (g == 0 && f16) ? gp[F_W1 + row * Dr + (f16 ? 16 : 0)] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if constexpr (IS_PF) {
-        w3h[so][r] = (i < O) ? gp[F::W3 + (i < O ? i : 0) * H + 16 * so + 4 * g + r] : 0.0f;     // head: W3[o = i][k]
+        w3h[so][r] = (i < O) ? gp[F_W3 + (i < O ? i : 0) * H + 16 * so + 4 * g + r] : 0.0f;     // head: W3[o = i][k]
         const int o = 4 * g + r;
-        w3t[so][r] = (o < O) ? gp[F::W3 + (o < O ? o : 0) * H + row] : 0.0f;                     // dH2: W3[k = o][own f]
+        w3t[so][r] = (o < O) ? gp[F_W3 + (o < O ? o : 0) * H + row] : 0.0f;                     // dH2: W3[k = o][own f]
       } else {
-        w3h[so][r] = gp[F::W3 + 16 * so + 4 * g + r];                                            // per-lane head weights
+        w3h[so][r] = gp[F_W3 + 16 * so + 4 * g + r];                                            // per-lane head weights
         w3t[so][r] = 0.0f;
       }
     }
@@ -262,13 +286,13 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int o = 4 * g + r;
-    const float raw = (IS_PF && o < O) ? gp[F::LS + (o < O ? o : 0)] : 0.0f;
+    const float raw = (IS_PF && o < O) ? gp[F_LS + (o < O ? o : 0)] : 0.0f;
     lsv[r] = fminf(fmaxf(raw, -20.0f), 2.0f);                   // continuous_policy.py:8-9,185
     ivv[r] = __expf(-2.0f * lsv[r]);
     lspass[r] = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;   // clamp passes gradient inside [-20, 2]
-    b3v[r] = (o < O) ? gp[F::B3 + (o < O ? o : 0)] : 0.0f;
+    b3v[r] = (o < O) ? gp[F_B3 + (o < O ? o : 0)] : 0.0f;
   }
-  const float vb3 = IS_PF ? 0.0f : gp[F::B3];
+  const float vb3 = IS_PF ? 0.0f : gp[F_B3];
 #pragma unroll
   for (int t = 0; t < NV; ++t) {
     const int e = 4 * (tid + WV_THREADS * t), r = e / H, c = e - r * H;
@@ -306,9 +330,10 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     const bool valid = CONTIG ? true : (s < B);
     float xb[5], xt[4], lin[6];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) xb[r] = valid ? xq[r] : 0.0f;
+    for (int r = 0; r < 4; ++r) xb[r] = (valid && fv[r]) ? xq[r] : 0.0f;
+    xb[4] = (valid && f16) ? xq[4] : 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xt[q] = (CONTIG || tile * 16 + 4 * g + q < B) ? xtq[q] : 0.0f;
+    for (int q = 0; q < 4; ++q) xt[q] = (jv && (CONTIG || tile * 16 + 4 * g + q < B)) ? xtq[q] : 0.0f;
 #pragma unroll
     for (int q = 0; q < 6; ++q) lin[q] = lq[q];
     const float x16 = xb[4];
@@ -559,23 +584,23 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   // ---- epilogue: every wave writes its gradient image, then all threads add the 4 images in fixed order ----
   __syncthreads();                                                 // staging / weight copies are dead from here
   float* gimg = lds + wave * S::P_STRIDE;            // every parameter slot below is written exactly once
-  for (int e = F::P_PF + lane; e < S::P_STRIDE; e += 64) gimg[e] = 0.0f;   // padding (and logstd slots of the value net)
+  for (int e = F_END + lane; e < PS; e += 64) gimg[e] = 0.0f;              // padding (and logstd slots of the value net)
 #pragma unroll
   for (int so = 0; so < 4; ++so)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = 16 * so + 4 * g + r;                           // output feature (row of W2 / W1)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) gimg[F::W2 + f * H + 16 * c + j] = gW2[so][c][r];
-      gimg[F::W1 + f * D + j] = gW1[so][r];
+      for (int c = 0; c < 4; ++c) gimg[F_W2 + f * H + 16 * c + j] = gW2[so][c][r];
+      if (jv) gimg[F_W1 + f * Dr + j] = gW1[so][r];
       const float c16 = row_sum16(gW1c[so][r]), s1 = row_sum16(gb1[so][r]), s2 = row_sum16(gb2[so][r]);
-      if (j == 0) { gimg[F::W1 + f * D + 16] = c16; gimg[F::B1 + f] = s1; gimg[F::B2 + f] = s2; }
+      if (j == 0) { if (f16) gimg[F_W1 + f * Dr + 16] = c16; gimg[F_B1 + f] = s1; gimg[F_B2 + f] = s2; }
       if constexpr (IS_PF) {
         const int o = 4 * g + r;                                   // gW3 rows are outputs
-        if (o < O) gimg[F::W3 + o * H + 16 * so + j] = gW3[so][r];
+        if (o < O) gimg[F_W3 + o * H + 16 * so + j] = gW3[so][r];
       } else {
         const float w3s = row_sum16(gW3[so][r]);
-        if (j == 0) gimg[F::W3 + f] = w3s;
+        if (j == 0) gimg[F_W3 + f] = w3s;
       }
     }
 #pragma unroll
@@ -583,15 +608,15 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     const int o = 4 * g + r;
     const float b3 = row_sum16(db3[r]), dl = row_sum16(dls[r]);
     if (j == 0 && o < O) {
-      gimg[F::B3 + o] = b3;
-      if (IS_PF) gimg[F::LS + o] = dl;
+      gimg[F_B3 + o] = b3;
+      if (IS_PF) gimg[F_LS + o] = dl;
     }
   }
   WCLK(7)
   __syncthreads();
   const int wg = blockIdx.x;
   static_assert(S::P_STRIDE % 4 == 0, "partial rows are folded and stored 16 bytes at a time");
-  for (int e4 = tid; e4 < S::P_STRIDE / 4; e4 += WV_THREADS) {
+  for (int e4 = tid; e4 < PS / 4; e4 += WV_THREADS) {
     f32x4 acc = lds4(lds + 4 * e4);
 #pragma unroll
     for (int w = 1; w < WV_WAVES; ++w) acc += lds4(lds + w * S::P_STRIDE + 4 * e4);          // same order per element
@@ -599,7 +624,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   }
   WCLK(8)
 #ifdef TRL_EXP_CLK
-  if (tid == 0) for (int ph = 0; ph < 24; ++ph) a.partial[(size_t)wg * a.p_stride + S::P_STRIDE - 40 + ph] = clk_acc[ph];
+  if (tid == 0) for (int ph = 0; ph < 24; ++ph) a.partial[(size_t)wg * a.p_stride + PS - 40 + ph] = clk_acc[ph];
 #endif
   // ---- scalar statistics ----
   __syncthreads();
@@ -626,11 +651,11 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   }
 }
 
-template <int D, int H, int A, int ACT, bool CONTIG>
+template <int D, int H, int A, int ACT, bool CONTIG, bool RT>
 __global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x < a.n_pf) ppo_wave_pass<D, H, A, ACT, true, CONTIG>(a, lds, blockIdx.x, a.n_pf);
-  else                          ppo_wave_pass<D, H, A, ACT, false, CONTIG>(a, lds, blockIdx.x - a.n_pf, a.n_wg - a.n_pf);
+  if ((int)blockIdx.x < a.n_pf) ppo_wave_pass<D, H, A, ACT, true, CONTIG, RT>(a, lds, blockIdx.x, a.n_pf);
+  else                          ppo_wave_pass<D, H, A, ACT, false, CONTIG, RT>(a, lds, blockIdx.x - a.n_pf, a.n_wg - a.n_pf);
 }
 
 // ---------------------------------------------------------------- partial reduce
@@ -998,8 +1023,15 @@ __global__ __launch_bounds__(256) void mlp2_forward_kernel(const float* __restri
 // ================================================================ host side
 #define SHAPE_IS(d, h, o) (D == (d) && H == (h) && A == (o))
 
+// Shapes the fused minibatch kernels carry: the benchmark shape as a compile-time instantiation, and any D in [2, 17],
+// A in [1, 8] at H = 64 through the runtime-dims instantiation (ppo_wave_pass<..., RT = true>).
+static bool ppo_shape_rt(int D, int H, int A) { return H == 64 && D >= 2 && D <= 17 && A >= 1 && A <= 8; }
 extern "C" int trl_ppo_partial_stride(int D, int H, int A) {
   if (SHAPE_IS(17, 64, 6)) return PpoShape<17, 64, 6>::P_STRIDE;
+  if (ppo_shape_rt(D, H, A)) {
+    const int p_pf = H * D + H + H * H + H + A * H + A + A, p_vf = H * D + H + H * H + H + H + 1;
+    return ((p_pf > p_vf ? p_pf : p_vf) + 63) & ~63;
+  }
   trl_set_error("trl_ppo_partial_stride: shape D=%d H=%d A=%d not instantiated", D, H, A);
   return TRL_EUNSUPPORTED;
 }
@@ -1009,25 +1041,25 @@ extern "C" int trl_ppo_partial_stride(int D, int H, int A) {
 // and a PAIR of waves per tile with two waves per SIMD (75 us) -- on gfx950 the fp32 MFMA and the VALU do not
 // overlap across the two waves of a SIMD (tools/ubench/mfma_valu.hip: an MFMA-only wave and a VALU-only wave
 // on one SIMD take the SUM of their times), so a second wave only adds its duplicated loss / fetch work.
-template <int D, int H, int A, int ACT, bool CONTIG>
+template <int D, int H, int A, int ACT, bool CONTIG, bool RT>
 static int launch_ppo_v(const PpoDev& d, hipStream_t s) {
   using S = WvShape<D, H, A>;
   const size_t lds = S::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wave_kernel<D, H, A, ACT, CONTIG>,
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wave_kernel<D, H, A, ACT, CONTIG, RT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { trl_set_error("ppo_grad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_grad_wave_kernel<D, H, A, ACT, CONTIG>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d);
+  hipLaunchKernelGGL((ppo_grad_wave_kernel<D, H, A, ACT, CONTIG, RT>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
 // N % 16 == 0 (every tile = 16 consecutive envs of one time row): scalar tile addressing; any other N: per-lane cells
-template <int D, int H, int A, int ACT>
+template <int D, int H, int A, int ACT, bool RT>
 static int launch_ppo(const PpoDev& d, hipStream_t s) {
-  return (d.N % 16 == 0) ? launch_ppo_v<D, H, A, ACT, true>(d, s) : launch_ppo_v<D, H, A, ACT, false>(d, s);
+  return (d.N % 16 == 0) ? launch_ppo_v<D, H, A, ACT, true, RT>(d, s) : launch_ppo_v<D, H, A, ACT, false, RT>(d, s);
 }
 
 // Policy / value split of the grid.  A policy tile costs more than a value tile (head, log-prob loss,
@@ -1060,9 +1092,11 @@ extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream
   TRL_REQUIRE(p->n_wg >= 2, "n_wg must be >= 2");
   TRL_REQUIRE(p->n_wg_pf >= 0 && p->n_wg_pf < p->n_wg, "n_wg_pf must be 0 (even split) or in [1, n_wg)");
   TRL_REQUIRE(p->n_global > 1.0, "n_global must exceed 1 (unbiased std)");
-  TRL_REQUIRE((((uintptr_t)p->partial | (uintptr_t)p->pf_params | (uintptr_t)p->vf_params) & 15) == 0,
-              "partial / parameter blocks must be 16-byte aligned");
   const int D = p->D, H = p->H, A = p->A;
+  TRL_REQUIRE(((uintptr_t)p->partial & 15) == 0 && (((uintptr_t)p->pf_params | (uintptr_t)p->vf_params) & 3) == 0,
+              "partial rows must be 16-byte aligned, parameter blocks 4-byte aligned");
+  TRL_REQUIRE(!SHAPE_IS(17, 64, 6) || (((uintptr_t)p->pf_params | (uintptr_t)p->vf_params) & 15) == 0,
+              "parameter blocks of the benchmark shape must be 16-byte aligned");
   PpoDev d;
   d.obs = p->obs; d.acts = p->acts; d.advs = p->advs; d.rets = p->rets; d.old_values = p->old_values;
   d.old_logp = p->old_logp; d.row_idx = p->row_idx; d.rows_mb = p->rows_mb; d.N = p->N;
@@ -1071,11 +1105,16 @@ extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream
   d.clipped_value_loss = p->clipped_value_loss; d.tanh_action = p->tanh_action; d.loss_mode = p->loss_mode;
   d.partial = p->partial; d.scal_partial = p->scal_partial; d.n_wg = p->n_wg;
   d.n_pf = resolve_pf_wgs(p->n_wg, p->n_wg_pf);
+  d.D = D; d.A = A;
   hipStream_t s = (hipStream_t)stream;
   if (SHAPE_IS(17, 64, 6)) {
     d.p_stride = PpoShape<17, 64, 6>::P_STRIDE;
-    if (p->act == TRL_ACT_TANH) return launch_ppo<17, 64, 6, TRL_ACT_TANH>(d, s);
-    if (p->act == TRL_ACT_RELU) return launch_ppo<17, 64, 6, TRL_ACT_RELU>(d, s);
+    if (p->act == TRL_ACT_TANH) return launch_ppo<17, 64, 6, TRL_ACT_TANH, false>(d, s);
+    if (p->act == TRL_ACT_RELU) return launch_ppo<17, 64, 6, TRL_ACT_RELU, false>(d, s);
+  } else if (ppo_shape_rt(D, H, A)) {                 // actual dims at run time inside the (17, 64, 8) tile
+    d.p_stride = trl_ppo_partial_stride(D, H, A);
+    if (p->act == TRL_ACT_TANH) return launch_ppo<17, 64, 8, TRL_ACT_TANH, true>(d, s);
+    if (p->act == TRL_ACT_RELU) return launch_ppo<17, 64, 8, TRL_ACT_RELU, true>(d, s);
   }
   trl_set_error("ppo_grad: shape D=%d H=%d A=%d act=%d not instantiated", D, H, A, p->act);
   return TRL_EUNSUPPORTED;
