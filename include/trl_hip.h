@@ -693,7 +693,8 @@ int trl_mt19937_advance(uint32_t* state, int32_t* left, int64_t* next, int64_t c
 /* --- calibration of the two rooflines (nominal AND achievable peaks) -------------------
  * No reference counterpart (the reference publishes no measurement); run by bench.py after its timed
  * region.  trl_peak_copy_f32: dst[0..n) = src[0..n) with 16-byte accesses on every CU (HBM bytes moved = 8 n); mode 0 / 1:
- * one 16 KB piece per workgroup with plain / non-temporal accesses, mode 2: persistent grid-stride (the caller quotes the best).
+ * one 16 KB piece per workgroup with plain / non-temporal accesses, mode 2: persistent grid-stride (the caller quotes the best),
+ * mode 3: 4-byte accesses (calibrates the profiler's FETCH_SIZE / WRITE_SIZE for the gradient kernel's access width).
  * trl_peak_mfma_f32: `workgroups` x 4 waves each issue `iters` x 4 independent v_mfma_f32_32x32x2_f32 from registers
  * (FLOPs = workgroups * 4 * iters * 4 * 4096); out: workgroups * 256 floats (sink). */
 int trl_peak_copy_f32(const float* src, float* dst, int64_t n, int mode, void* stream);

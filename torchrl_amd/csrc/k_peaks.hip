@@ -44,13 +44,28 @@ __global__ __launch_bounds__(256) void peak_copy_stride_kernel(const f32x4* __re
   for (; i < n_vec; i += stride) dst[i] = src[i];
 }
 
+// mode 3: 4-byte accesses (one dword per lane and instruction, 4 in flight) -- not a bandwidth figure: the pattern of the
+// gradient kernel's input loads, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE for that access width
+__global__ __launch_bounds__(256) void peak_copy_dword_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int64_t i = base + 256 * k; v[k] = i < n ? src[i] : 0.0f; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int64_t i = base + 256 * k; if (i < n) dst[i] = v[k]; }
+}
+
 extern "C" int trl_peak_copy_f32(const float* src, float* dst, int64_t n, int mode, void* stream) {
   TRL_REQUIRE(src && dst && n > 0 && (n & 3) == 0, "src / dst non-null, n a positive multiple of 4");
   TRL_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "16-byte aligned pointers");
-  TRL_REQUIRE(mode >= 0 && mode <= 2, "mode 0..2");
+  TRL_REQUIRE(mode >= 0 && mode <= 3, "mode 0..3");
   const int64_t n_vec = n / 4;
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 2) {
+  if (mode == 3) {
+    const int64_t wg = (n + 1023) / 1024;
+    TRL_REQUIRE(wg < (1ll << 31), "too large");
+    hipLaunchKernelGGL(peak_copy_dword_kernel, dim3((unsigned)wg), dim3(256), 0, s, src, dst, n);
+  } else if (mode == 2) {
     int64_t wg = (n_vec + 255) / 256;
     if (wg > 256 * 16) wg = 256 * 16;
     hipLaunchKernelGGL(peak_copy_stride_kernel, dim3((unsigned)wg), dim3(256), 0, s, (const f32x4*)src, (f32x4*)dst, n_vec);

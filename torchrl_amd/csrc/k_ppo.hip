@@ -962,8 +962,11 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
     }
   }
   __syncthreads();
+  // (locals, not fields of `a`: writing into the by-value argument struct moves it to scratch memory and turns every access
+  // through its pointers into a flat instruction)
+  float bc1 = a.bc1, bc2_sqrt = a.bc2_sqrt, lr_pf = a.lr[0], lr_vf = a.lr[1];
   if (device_state) {
-    a.bc1 = s_hyper[0]; a.bc2_sqrt = s_hyper[1]; a.lr[0] = s_hyper[2]; a.lr[1] = s_hyper[3];
+    bc1 = s_hyper[0]; bc2_sqrt = s_hyper[1]; lr_pf = s_hyper[2]; lr_vf = s_hyper[3];
     if (blockIdx.x == 0 && blockIdx.y == 0) {                    // every block has read the header by now (see above)
       if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tid == 64 * (RED_WAVES - 1)) { bpow[0] = b1p; bpow[1] = b2p; }
@@ -982,8 +985,8 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
     const float m = a.beta1 * m_old + (1.0f - a.beta1) * gr;
     const float v = a.beta2 * v_old + (1.0f - a.beta2) * gr * gr;
     a.m[ge_] = m; a.v[ge_] = v;
-    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-    a.params[ge_] = p_old - (a.lr[net] / a.bc1) * (m / denom);
+    const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+    a.params[ge_] = p_old - ((net == 0 ? lr_pf : lr_vf) / bc1) * (m / denom);
   }
 }
 
