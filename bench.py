@@ -661,10 +661,7 @@ def main():
     device_elapsed, parity_elapsed = elapsed, None
     if world == 1:
         col.noise_mode, col.prefetch_noise = "host", True
-        # ten host threads now share the interpreter; with the default 5 ms switch interval a thread that needs the lock back
-        # can wait that long once in a few hundred iterations (seen as a single 8 ms iteration among 300 of 2.9 ms)
-        sys.setswitchinterval(5e-4)
-        run_iterations(2, True)                                            # (first block drawn in place, pipeline primed)
+        run_iterations(5, True)                                            # (first block drawn in place, pipeline primed)
         gc.collect()
         gc.freeze()                                                        # (as before the first timed region)
         parity_elapsed, pmarks, pread = timed_region()

@@ -664,10 +664,11 @@ __global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) 
 //  5 max ratio   6 -min ratio   7 value-loss sum
 #define RED_CHUNK 64
 // waves per block of 64 parameters / partial rows a lane has in flight per round.  Measured on MI355X at 147 + 109 rows
-// (iteration time of bench.py, A/B in one session): 4 x 16 -> 3.14-3.15 ms, 8 x 32 (the whole fold in one memory round
-// trip) -> 3.15-3.16 ms, 16 x 16 -> 3.23 ms: the launch is bound by its rendezvous and launch latencies, not by the fold.
+// (rocprofv3 mean of the fused launch, round 3, after its argument struct stopped going through scratch memory):
+// 4 x 16 -> 7.9 us, 8 x 16 -> 7.4 us, 8 x 32 -> 7.8 us, 16 x 16 -> 7.8 us (profiles/r03_grad_kernel_experiments.txt); the
+// launch is bound by its rendezvous and launch latencies: without any partial-row load it still takes ~6 us.
 #ifndef RED_WAVES
-#define RED_WAVES 4
+#define RED_WAVES 8
 #endif
 #ifndef RED_DEPTH
 #define RED_DEPTH 16
