@@ -698,7 +698,7 @@ def main():
                    "envs_per_gpu": N_PER_GPU, "rollout_steps": T, "batch_per_gpu": BATCH_PER_GPU,
                    "opt_epochs": OPT_EPOCHS,
                    "exploration_noise": ("CPU torch generator = the reference's stream (bit-parity configuration), the next "
-                                         "rollout's block drawn by a host thread while the device works") if headline_parity
+                                         "rollout's block drawn by host threads while the device works") if headline_parity
                    else "device Philox4x32-10 keyed by the global env index",
                    "setup_iterations": setup,
                    "update_infos_read_in_timed_region": infos_read,

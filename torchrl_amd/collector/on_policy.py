@@ -15,8 +15,8 @@ Exploration noise:
   * noise_mode="device": Philox4x32-10 in the kernel keyed by (env seed, global
     step) -- statistically equivalent, no host work.
   * `prefetch_noise=True` (host mode): the NEXT rollout's (T, N, A) block is drawn by
-    a worker thread into page-locked memory and uploaded on a side stream while the
-    current iteration runs on the device -- the same values in the same order from
+    worker threads into page-locked memory while the current iteration runs on the
+    device, and uploaded right in front of its rollout -- the same values in the same order from
     the same generator (nothing else on this path draws from it between two
     rollouts, torchrl/algo/on_policy/ppo.py:27-152), just earlier; what bench.py's
     headline uses.  See _NoisePrefetcher.
@@ -39,8 +39,8 @@ class _NoisePrefetcher:
     `take(T, N, A)` returns the device tensor of this rollout's draws and immediately starts the draw of the NEXT block of
     the same shape: a worker thread fills a page-locked buffer with `torch.randn(out=...)` (the op releases the
     interpreter lock, and the block is cut into segments drawn by several threads at once: ~1 ms of host time for
-    128 x 2048 x 6 instead of ~3, which would otherwise sit between two iterations), copies it
-    to one of two device buffers on a side stream and records an event the consuming rollout's stream waits on.  The
+    128 x 2048 x 6 instead of ~3, which would otherwise sit between two iterations); the NEXT `take` copies it to one of two
+    device buffers on the rollout's stream (the worker threads never call into the HIP runtime).  The
     draw depends on nothing the GPU produces, so the stream of values is the un-prefetched one, bit for bit.
 
     Guard: the generator state right after the prefetched draw is remembered; if the state found at `take` differs --
@@ -52,10 +52,10 @@ class _NoisePrefetcher:
     def __init__(self, device):
         import threading
         self.device = torch.device(device)
-        self._side = torch.cuda.Stream(self.device)
         self._lock = threading.Lock()
         self._job = None                                   # dict(thread, shape, slot, state0, state1, event, error)
-        self._host, self._dev, self._free = {}, {}, {}
+        self._host, self._dev = {}, {}
+        self._free = {}                                    # per slot: the event of its last upload (page-locked buffer reusable)
         self._slot = 0
 
     def _buffers(self, shape, slot):
@@ -67,19 +67,25 @@ class _NoisePrefetcher:
         return self._host[key], self._dev[key]
 
     def _draw_into(self, shape, slot):
-        """Draw into the page-locked buffer of `slot`, upload on the side stream; returns (device tensor, event)."""
-        host, dev = self._buffers(shape, slot)
-        free = self._free.get((shape, slot))
-        if free is not None:
-            free.synchronize()                              # the rollout that read this slot two blocks ago has finished
+        """Draw into the page-locked buffer of `slot` (host work only: the worker thread never talks to the HIP runtime)."""
+        host, _ = self._buffers(shape, slot)
         # one (T * N, A) draw == T successive (N, A) draws when N * A is a multiple of 16 (see _host_noise); the block itself
         # is produced by several host threads, each starting from the engine state at its segment (collector/noise.py)
         noise.randn_into(host)
-        with torch.cuda.stream(self._side):
-            dev.copy_(host.view(shape), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self._side)
-        return dev, ev
+        return slot
+
+    def _upload(self, shape, slot, stream):
+        """Page-locked block -> device, on the rollout's own stream right in front of it (0.13 ms for cfg 2's 6.3 MB).
+        A side stream would hide that copy under the running update -- built and measured in round 3: the iteration then
+        runs at the device-noise speed, but the cross-stream dependency costs a 5-50 ms host stall once every ~100
+        iterations on this runtime (none in 800 iterations with the copy on the rollout's stream;
+        profiles/r03_grad_kernel_experiments.txt)."""
+        host, dev = self._buffers(shape, slot)
+        dev.copy_(host.view(shape), non_blocking=True)
+        ev = self._free.get((shape, slot)) or torch.cuda.Event()
+        ev.record(stream)
+        self._free[(shape, slot)] = ev
+        return dev
 
     def _worker(self):
         """One long-lived thread (no thread start per rollout): takes a job, draws, signals."""
@@ -103,6 +109,10 @@ class _NoisePrefetcher:
             self._thread.start()
         slot = self._slot
         self._slot ^= 1
+        self._buffers(shape, slot)                          # (allocated by this thread)
+        free = self._free.get((shape, slot))
+        if free is not None and not free.query():           # the upload that read this page-locked buffer two blocks ago
+            free.synchronize()                              # (long finished; checked here so that the worker never waits on HIP)
         job = {"shape": shape, "slot": slot, "state0": torch.get_rng_state(), "state1": None, "out": None, "error": None,
                "done": threading.Event()}
         self._job = job
@@ -126,24 +136,19 @@ class _NoisePrefetcher:
             if job["error"] is not None:
                 raise job["error"]
             if job["shape"] == shape and torch.equal(torch.get_rng_state(), job["state1"]):
-                out = job["out"]
-                used = job["slot"]
+                out = used = job["slot"]
             elif torch.equal(torch.get_rng_state(), job["state1"]):
                 torch.set_rng_state(job["state0"])         # other shape, untouched generator: undo the speculative draw
         if out is None:                                     # first call / generator touched in between: draw in place
             used = self._slot
             self._slot ^= 1
-            out = self._draw_into(shape, used)
-        dev, ev = out
-        stream.wait_event(ev)
+            free = self._free.get((shape, used))
+            if free is not None:
+                free.synchronize()
+            self._draw_into(shape, used)
+        dev = self._upload(shape, used, stream)
         self._start(shape)                                  # the next block, under this iteration's device work
         return dev, used
-
-    def release(self, shape, slot, stream):
-        """Call after the rollout that reads `slot` has been enqueued on `stream`."""
-        ev = self._free.get((shape, slot)) or torch.cuda.Event()
-        ev.record(stream)
-        self._free[(shape, slot)] = ev
 
     def close(self):
         self._drop(rewind=True)
@@ -431,8 +436,6 @@ class VecOnPolicyCollector(VecCollector):
         else:
             noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
         self._launch(self.env, n_steps, True, False, noise)
-        if slot is not None:
-            self._prefetcher.release(tuple(noise.shape), slot, stream)
         self.global_step += n_steps
         self.current_ob = self.env.cur_obs
 
