@@ -572,9 +572,10 @@ int trl_conv_bwd_input_nhwc_f32(const float* dy, const float* y_gate, int gate_a
                                 int kh, int kw, int sh, int sw, int Cout, void* stream);
 /* out[b][c][p] = in[b][p][c]  (NCHW flatten order in front of the first FC layer, and back) */
 int trl_transpose_bpc_f32(const float* in, float* out, int B, int P, int C, void* stream);
-/* the same with out[e] *= act'(y_gate[e]) (y_gate laid out like out): d(features) -> the last conv layer's dZ */
-int trl_transpose_bpc_gate_f32(const float* in, const float* y_gate, int gate_act, float* out, int B, int P, int C,
-                               void* stream);
+/* the same with out[e] *= act'(y_gate[..]): d(features) -> the last conv layer's dZ.  gate_like_in == 0: y_gate is laid
+ * out like out; != 0: like in (the last conv layer's output kept in the flattened order, trl_conv_fwd_nhwc_f32 out_chw) */
+int trl_transpose_bpc_gate_f32(const float* in, const float* y_gate, int gate_act, int gate_like_in, float* out, int B,
+                               int P, int C, void* stream);
 
 /* --- K16b: first conv layer straight from uint8 frames (implicit GEMM) -------
  * replaces nn.Conv2d + activation of CNNBase's first layer (torchrl/networks/base.py:59-107) applied to
@@ -591,15 +592,17 @@ int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias
 int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout);
 /* The later conv layers, same idea on fp32 channels-last activations x (B, H, W, C), C % 4 == 0: the reduction
  * runs in (i, j, c) order so that a window row is one contiguous run of kw*C floats; w is still the nn.Conv2d
- * weight (Cout, C, kh, kw) as stored and dw comes back in that layout.  y: (B*Ho*Wo, Cout) = NHWC.
+ * weight (Cout, C, kh, kw) as stored and dw comes back in that layout.  y: (B*Ho*Wo, Cout) = NHWC, or with
+ * out_chw != 0 (B, Cout, Ho*Wo): what nn.Flatten hands the FC layers (networks/base.py:100-107), written by the
+ * layer's own epilogue instead of a transposing launch.
  * Workspace of the weight gradient: trl_conv_bwd_weight_workspace. */
 int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
-                          int kh, int kw, int sh, int sw, int Cout, int act, void* stream);
+                          int kh, int kw, int sh, int sw, int Cout, int act, int out_chw, void* stream);
 /* G conv layers of one geometry (different inputs / weights / outputs) in one launch: the online and the target
  * network of a DQN update (dqn.py:47-52) run the same trunk on obs and next_obs */
 int trl_conv_fwd_nhwc_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
                                 float* const* y, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout,
-                                int act, void* stream);
+                                int act, int out_chw, void* stream);
 int trl_conv_bwd_weight_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* x, float* dw,
                                  float* db, float* workspace, int B, int C, int H, int W, int kh, int kw, int sh,
                                  int sw, int Cout, void* stream);

@@ -354,3 +354,32 @@ def test_frame_env_policy_and_collector_vs_oracle():
     assert np.array_equal(pq.eval_act(env.cur_obs)[:, 0], want)
     ev = col.eval_one_epoch()
     assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == horizon
+
+
+@pytest.mark.parametrize("Cout,group", [(64, False), (32, False), (64, True)])
+def test_last_conv_layer_stores_the_flattened_features_itself(Cout, group):
+    """`out_chw` of the channels-last conv layer: the same values as the NHWC result, stored in nn.Flatten's (c, oy, ox)
+    order by the layer's epilogue (bit for bit what the transposing launch produced), at sizes with a ragged last tile;
+    and the un-flattening transpose of the backward pass gated by an output kept in that order."""
+    from torchrl_amd import _C
+    torch.manual_seed(5)
+    B, H, W, Cin, kh, kw, sh, sw = 37, 9, 9, 32, 3, 3, 1, 1
+    x = torch.randn(B, H, W, Cin, device=DEV)
+    ws = [torch.randn(Cout, Cin * kh * kw, device=DEV) * 0.05 for _ in range(2)]
+    bs = [torch.randn(Cout, device=DEV) for _ in range(2)]
+    if group:
+        xs = [x, torch.randn_like(x)]
+        want, (_, Ho, Wo) = _C.conv_fwd_nhwc_group(xs, ws, bs, kh, kw, sh, sw, _C.ACT_RELU)
+        got, _ = _C.conv_fwd_nhwc_group(xs, ws, bs, kh, kw, sh, sw, _C.ACT_RELU, out_chw=True)
+    else:
+        w0, (_, Ho, Wo) = _C.conv_fwd_nhwc(x, ws[0], bs[0], kh, kw, sh, sw, _C.ACT_RELU)
+        g0, _ = _C.conv_fwd_nhwc(x, ws[0], bs[0], kh, kw, sh, sw, _C.ACT_RELU, out_chw=True)
+        want, got = [w0], [g0]
+    P = Ho * Wo
+    for w, g in zip(want, got):
+        assert g.shape == (B, Cout * P)
+        assert torch.equal(g.view(B, Cout, P), w.view(B, P, Cout).transpose(1, 2))
+    d = torch.randn(B, Cout * P, device=DEV)
+    a = _C.transpose_bpc(d.view(B, Cout, P), B, Cout, P, y_gate=want[0], gate_act=_C.ACT_RELU)
+    b = _C.transpose_bpc(d.view(B, Cout, P), B, Cout, P, y_gate=got[0], gate_act=_C.ACT_RELU, gate_like_in=True)
+    assert torch.equal(a, b)

@@ -183,11 +183,12 @@ SIGNATURES = {
     "trl_conv_bwd_input_nhwc_workspace": (C.c_int, [C.c_int] * 4),
     "trl_conv_bwd_input_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
-    "trl_transpose_bpc_gate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_transpose_bpc_gate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 3
+                                   + [C.c_void_p]),
     "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_conv_fwd_u8_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "trl_conv_bwd_weight_workspace": (C.c_int, [C.c_int] * 9),
-    "trl_conv_fwd_nhwc_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
+    "trl_conv_fwd_nhwc_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 11 + [C.c_void_p]),
     "trl_conv_bwd_weight_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 9
                                      + [C.c_void_p]),
     "trl_conv_bwd_weight_u8_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 8
@@ -225,7 +226,7 @@ SIGNATURES = {
     "trl_mlp3_forward_ok": (C.c_int, [C.c_int] * 4),
     "trl_mlp3_forward_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_void_p]),
     "trl_linear_fwd_splitk_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
-    "trl_conv_fwd_nhwc_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]),
+    "trl_conv_fwd_nhwc_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 11 + [C.c_void_p]),
     "trl_linear_fwd_splitk_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "trl_linear_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -1045,29 +1046,31 @@ def conv_bwd_weight_u8(dy, y_gate, gate_act, frames, kh, kw, sh, sw, scale, shif
     return dw, db
 
 
-def conv_fwd_nhwc(x, w, bias, kh, kw, sh, sw, act):
+def conv_fwd_nhwc(x, w, bias, kh, kw, sh, sw, act, out_chw=False):
     """act(conv2d(x) + bias) on (B, H, W, C) fp32 channels-last activations, C % 4 == 0; w (Cout, C*kh*kw) is the
-    nn.Conv2d weight as stored.  Returns ((B*Ho*Wo, Cout), (B, Ho, Wo))."""
+    nn.Conv2d weight as stored.  Returns ((B*Ho*Wo, Cout), (B, Ho, Wo)); with `out_chw` the result is stored
+    (B, Cout, Ho*Wo) -- nn.Flatten's order -- and returned as (B, Cout*Ho*Wo)."""
     B, H, W, Cc = (int(v) for v in x.shape)
     Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
     Cout = int(w.shape[0])
-    y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, Cout * Ho * Wo) if out_chw else (B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
     check(lib().trl_conv_fwd_nhwc_f32(dev_ptr(x, name="x"), dev_ptr(w, name="w"), dev_ptr(bias, name="bias", allow_none=True),
-                                      dev_ptr(y, name="y"), B, Cc, H, W, kh, kw, sh, sw, Cout, act, stream_ptr(x.device)),
-          "trl_conv_fwd_nhwc_f32")
+                                      dev_ptr(y, name="y"), B, Cc, H, W, kh, kw, sh, sw, Cout, act, int(bool(out_chw)),
+                                      stream_ptr(x.device)), "trl_conv_fwd_nhwc_f32")
     return y, (B, Ho, Wo)
 
 
-def conv_fwd_nhwc_group(xs, ws, biases, kh, kw, sh, sw, act):
+def conv_fwd_nhwc_group(xs, ws, biases, kh, kw, sh, sw, act, out_chw=False):
     """`conv_fwd_nhwc` of G same-geometry layers (different inputs / weights) in one launch; returns ([y_g], (B, Ho, Wo))."""
     B, H, W, Cc = (int(v) for v in xs[0].shape)
     if any(tuple(x.shape) != tuple(xs[0].shape) for x in xs) or any(tuple(w.shape) != tuple(ws[0].shape) for w in ws):
         raise TrlError("conv_fwd_nhwc_group: the layers of a group share one geometry")
     Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
     Cout = int(ws[0].shape[0])
-    ys = [torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=xs[0].device) for _ in xs]
+    ys = [torch.empty((B, Cout * Ho * Wo) if out_chw else (B * Ho * Wo, Cout), dtype=torch.float32, device=xs[0].device)
+          for _ in xs]
     check(lib().trl_conv_fwd_nhwc_group_f32(len(xs), _ptrs(xs, "x"), _ptrs(ws, "w"), _ptrs(biases, "bias", True),
-                                            _ptrs(ys, "y"), B, Cc, H, W, kh, kw, sh, sw, Cout, act,
+                                            _ptrs(ys, "y"), B, Cc, H, W, kh, kw, sh, sw, Cout, act, int(bool(out_chw)),
                                             stream_ptr(xs[0].device)), "trl_conv_fwd_nhwc_group_f32")
     return ys, (B, Ho, Wo)
 
@@ -1113,13 +1116,14 @@ def conv_bwd_input_nhwc(dy, y_gate, gate_act, weight, B, Cin, H, W, kh, kw, sh, 
     return dx
 
 
-def transpose_bpc(x, B, P, Cc, y_gate=None, gate_act=ACT_NONE):
+def transpose_bpc(x, B, P, Cc, y_gate=None, gate_act=ACT_NONE, gate_like_in=False):
     out = torch.empty((B, Cc, P), dtype=torch.float32, device=x.device)
-    if y_gate is not None:                                              # out *= act'(y_gate), y_gate laid out like out
+    if y_gate is not None:                                 # out *= act'(y_gate), y_gate laid out like out (or like x)
         if y_gate.numel() != out.numel():
             raise TrlError("transpose_bpc: gate does not match the output")
         check(lib().trl_transpose_bpc_gate_f32(dev_ptr(x, name="x"), dev_ptr(y_gate, name="y_gate"), gate_act,
-                                               dev_ptr(out, name="out"), B, P, Cc, stream_ptr(x.device)),
+                                               int(bool(gate_like_in)), dev_ptr(out, name="out"), B, P, Cc,
+                                               stream_ptr(x.device)),
               "trl_transpose_bpc_gate_f32")
         return out
     check(lib().trl_transpose_bpc_f32(dev_ptr(x, name="x"), dev_ptr(out, name="out"), B, P, Cc,

@@ -62,12 +62,14 @@ __global__ __launch_bounds__(CV_THREADS) void col2im_kernel(const float* __restr
 // (yg, act: optional gate -- out[e] *= act'(yg[e]) with yg laid out like `out`: the backward pass turns d(features) into
 // the last conv layer's dZ in the same pass)
 __global__ __launch_bounds__(CV_THREADS) void transpose_bpc_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                   int B, int P, int C, const float* __restrict__ yg, int act) {
+                                                                   int B, int P, int C, const float* __restrict__ yg, int act,
+                                                                   int gate_like_in) {
   const int64_t total = (int64_t)B * P * C;
   for (int64_t e = (int64_t)blockIdx.x * CV_THREADS + threadIdx.x; e < total; e += (int64_t)gridDim.x * CV_THREADS) {
     const int p = (int)(e % P), c = (int)((e / P) % C), b = (int)(e / ((int64_t)P * C));
-    float v = in[((int64_t)b * P + p) * C + c];
-    if (yg) { const float y = yg[e]; v *= act == TRL_ACT_TANH ? 1.0f - y * y : (act == TRL_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : 1.0f); }
+    const int64_t src = ((int64_t)b * P + p) * C + c;
+    float v = in[src];
+    if (yg) { const float y = yg[gate_like_in ? src : e]; v *= act == TRL_ACT_TANH ? 1.0f - y * y : (act == TRL_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : 1.0f); }
     out[e] = v;
   }
 }
@@ -83,6 +85,55 @@ static int grid_for(int64_t total) {
   int64_t g = (total + CV_THREADS - 1) / CV_THREADS;
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
+
+// The same through LDS, one (P x C) matrix per workgroup pass: reads of `in` (and of a gate laid out like it) and
+// writes of `out` are both contiguous; the naive kernel's reads are C floats apart.  Rows padded to an odd stride.
+#define TR_LDS_MAX 8192
+__global__ __launch_bounds__(CV_THREADS) void transpose_bpc_lds_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                       int B, int P, int C, const float* __restrict__ yg,
+                                                                       int act, int gate_like_in) {
+  extern __shared__ float sm[];
+  const int PC = P * C, ld = C | 1;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* src = in + (size_t)b * PC;
+    const float* gs = yg ? yg + (size_t)b * PC : nullptr;
+    for (int e = threadIdx.x; e < PC; e += CV_THREADS) {
+      float v = src[e];
+      if (gs && gate_like_in) {
+        const float y = gs[e];
+        v *= act == TRL_ACT_TANH ? 1.0f - y * y : (act == TRL_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : 1.0f);
+      }
+      const int p = e / C, c = e - p * C;
+      sm[p * ld + c] = v;
+    }
+    __syncthreads();
+    float* dst = out + (size_t)b * PC;
+    for (int e = threadIdx.x; e < PC; e += CV_THREADS) {
+      const int c = e / P, p = e - c * P;
+      float v = sm[p * ld + c];
+      if (gs && !gate_like_in) {
+        const float y = gs[e];
+        v *= act == TRL_ACT_TANH ? 1.0f - y * y : (act == TRL_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : 1.0f);
+      }
+      dst[e] = v;
+    }
+    __syncthreads();
+  }
+}
+static int launch_transpose(const float* in, float* out, int B, int P, int C, const float* yg, int act, int gate_like_in,
+                            hipStream_t s) {
+  const int floats = P * (C | 1);
+  if ((int64_t)P * C <= TR_LDS_MAX) {
+    hipLaunchKernelGGL(transpose_bpc_lds_kernel, dim3(std::min(B, 4096)), dim3(CV_THREADS), floats * sizeof(float), s, in, out,
+                       B, P, C, yg, act, gate_like_in);
+  } else {
+    hipLaunchKernelGGL(transpose_bpc_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(CV_THREADS), 0, s, in, out, B, P, C, yg,
+                       act, gate_like_in);
+  }
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 
 extern "C" int trl_im2col_f32(const float* in_nhwc, float* cols, int B, int C, int H, int W, int kh, int kw, int sh,
                               int sw, void* stream) {
@@ -127,19 +178,13 @@ extern "C" int trl_transpose_bpc_f32(const float* in, float* out, int B, int P, 
   TRL_REQUIRE(B >= 0 && P > 0 && C > 0, "bad sizes");
   if (B == 0) return TRL_OK;
   TRL_REQUIRE(in && out, "null pointer");
-  hipLaunchKernelGGL(transpose_bpc_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(CV_THREADS), 0,
-                     (hipStream_t)stream, in, out, B, P, C, (const float*)nullptr, TRL_ACT_NONE);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
+  return launch_transpose(in, out, B, P, C, nullptr, TRL_ACT_NONE, 0, (hipStream_t)stream);
 }
-extern "C" int trl_transpose_bpc_gate_f32(const float* in, const float* y_gate, int gate_act, float* out, int B, int P, int C,
-                                          void* stream) {
+extern "C" int trl_transpose_bpc_gate_f32(const float* in, const float* y_gate, int gate_act, int gate_like_in, float* out,
+                                          int B, int P, int C, void* stream) {
   TRL_REQUIRE(B >= 0 && P > 0 && C > 0, "bad sizes");
   if (B == 0) return TRL_OK;
   TRL_REQUIRE(in && out && y_gate, "null pointer");
   TRL_REQUIRE(gate_act == TRL_ACT_TANH || gate_act == TRL_ACT_RELU || gate_act == TRL_ACT_NONE, "unknown activation");
-  hipLaunchKernelGGL(transpose_bpc_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(CV_THREADS), 0,
-                     (hipStream_t)stream, in, out, B, P, C, y_gate, gate_act);
-  TRL_LAUNCH_CHECK();
-  return TRL_OK;
+  return launch_transpose(in, out, B, P, C, y_gate, gate_act, gate_like_in, (hipStream_t)stream);
 }

@@ -55,6 +55,7 @@ struct GemmDev {
   float* colsum;              // TA only: (splits, M) partial column sums of the gated A (nullable)
   int tiles_n, tiles;         // C tiles along N, and in total
   ConvSrc cv;                 // CONV != 0: the implicit operand (A when CONV == 1, B when CONV == 2)
+  int chw_p;                  // CONV == 3, != 0: C is stored (b, n, p) with p = m % chw_p (= Ho * Wo), nn.Flatten's order
   int groups;                 // > 1: the operand pointers of problem blockIdx.y come from grp[]
   GemmGroup grp[GEMM_MAX_GROUPS];
   int hetero;                 // != 0: problem blockIdx.y also has its own shape (the grid is sized for the largest)
@@ -361,7 +362,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
       }
       float* cp = C + (size_t)mb * g_ldc + n;
-      if (m0 + GM <= g_M) {
+      if (CONV == 3 && g.chw_p) {
+        // the trunk's last layer: the FC layers above read (b, c, oy, ox)-flattened features, so the tile is stored in that
+        // order here (a lane's 4 consecutive rows are 16 contiguous bytes) instead of being transposed by a launch of its own
+        const uint32_t P = (uint32_t)g.chw_p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                // rows mb + 8 q .. + 3: one position run of one sample, mostly
+          const uint32_t m = (uint32_t)(mb + 8 * q);
+          const uint32_t b = fastdiv(m, P, g.cv.hw_magic, g.cv.hw_shift), p = m - b * P;
+          float* dst = C + ((size_t)b * g_N + n) * P + p;
+          if ((int)m + 3 < g_M && p + 3 < P) {
+            f32x4 pk = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            __builtin_memcpy(dst, &pk, 16);          // (4-byte aligned: P is odd for the 7 x 7 maps)
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t mj = m + j;
+              if ((int)mj < g_M) {
+                const uint32_t bj = fastdiv(mj, P, g.cv.hw_magic, g.cv.hw_shift);
+                C[((size_t)bj * g_N + n) * P + (mj - bj * P)] = v[4 * q + j];
+              }
+            }
+          }
+        }
+      } else if (m0 + GM <= g_M) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g_ldc] = v[r];
       } else {
@@ -864,7 +888,7 @@ static int fill_conv_nhwc(const char* who, const float* x, int B, int C, int H, 
 }
 
 extern "C" int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
-                                     int kh, int kw, int sh, int sw, int Cout, int act, void* stream) {
+                                     int kh, int kw, int sh, int sw, int Cout, int act, int out_chw, void* stream) {
   TRL_REQUIRE(x && w && y && Cout > 0, "null pointer / bad Cout");
   TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
   GemmDev g{};
@@ -873,6 +897,7 @@ extern "C" int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float
   if (rc) return rc;
   g.A = nullptr; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
   g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
+  g.chw_p = out_chw ? g.cv.Ho * g.cv.Wo : 0;
   return launch_gemm<false, true, 3>(g, 1, (hipStream_t)stream);
 }
 
@@ -880,7 +905,7 @@ extern "C" int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float
 // a DQN update run the same trunk on obs and next_obs
 extern "C" int trl_conv_fwd_nhwc_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
                                            float* const* y, int B, int C, int H, int W, int kh, int kw, int sh, int sw,
-                                           int Cout, int act, void* stream) {
+                                           int Cout, int act, int out_chw, void* stream) {
   TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per grouped launch");
   TRL_REQUIRE(x && w && y && Cout > 0, "null pointer array / bad Cout");
   TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
@@ -896,6 +921,7 @@ extern "C" int trl_conv_fwd_nhwc_group_f32(int G, const float* const* x, const f
   g.A = nullptr; g.B = w[0]; g.C = y[0]; g.bias = bias ? bias[0] : nullptr; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
   g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
   g.cv.x = x[0];
+  g.chw_p = out_chw ? g.cv.Ho * g.cv.Wo : 0;
   return launch_gemm<false, true, 3>(g, 1, (hipStream_t)stream);
 }
 

@@ -160,7 +160,8 @@ def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspa
 # Activations are channels-last; the first layer reads uint8 NCHW frame stacks and scales them
 # in-kernel (x / 255 - 0.5, ScaledFloatFrame).
 class ConvTape:
-    __slots__ = ("convs", "fc", "B", "act", "feat_shape")
+    # feat_chw: the last conv layer's output (convs[-1][2]) is kept as (B, C, Ho*Wo) -- the flattened features themselves
+    __slots__ = ("convs", "fc", "B", "act", "feat_shape", "feat_chw")
 
 
 def conv_layers(net):
@@ -200,9 +201,10 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
         raise _C.TrlError("cnn_forward expects (B, C, H, W) uint8 frame stacks")
     act = cnn_act_code(net)
     t = ConvTape()
-    t.convs, t.act, t.B = [], act, int(frames_u8.shape[0])
+    t.convs, t.act, t.B, t.feat_chw = [], act, int(frames_u8.shape[0]), False
     x, geom_in = frames_u8.contiguous(), None
-    for k, m in enumerate(conv_layers(net)):
+    layers = conv_layers(net)
+    for k, m in enumerate(layers):
         kh, kw = m.kernel_size
         sh, sw = m.stride
         if k == 0 and _C.conv_u8_implicit_ok(x, kh, kw, sh, sw):
@@ -214,10 +216,16 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
             continue
         if k > 0 and int(x.shape[3]) % 4 == 0:
             # implicit GEMM on the channels-last activations (reduction in (i, j, c) order: contiguous window rows)
+            # (the last layer stores its output in nn.Flatten's (c, oy, ox) order: no transposing launch in front of the FCs)
             wmat = m.weight.view(m.weight.shape[0], -1)
             in_shape = tuple(int(v) for v in x.shape)
-            y, (B, Ho, Wo) = _C.conv_fwd_nhwc(x, wmat, m.bias, kh, kw, sh, sw, act)
+            t.feat_chw = k == len(layers) - 1
+            y, (B, Ho, Wo) = _C.conv_fwd_nhwc(x, wmat, m.bias, kh, kw, sh, sw, act, out_chw=t.feat_chw)
             t.convs.append(("nhwc", x, y, wmat, in_shape, (kh, kw, sh, sw)))
+            if t.feat_chw:
+                t.feat_shape = (Ho * Wo, int(wmat.shape[0]))
+                out, t.fc = mlp_forward(fc_layers(net), y, act)
+                return out, t
             x = y.view(B, Ho, Wo, int(wmat.shape[0]))
             continue
         if k == 0:
@@ -256,7 +264,7 @@ def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=
     tapes, xs = [], []
     for net, convs, frames in ((net_a, convs_a, frames_a), (net_b, convs_b, frames_b)):
         t = ConvTape()
-        t.convs, t.act, t.B = [], act, int(frames.shape[0])
+        t.convs, t.act, t.B, t.feat_chw = [], act, int(frames.shape[0]), False
         m = convs[0]
         kh, kw = m.kernel_size
         sh, sw = m.stride
@@ -272,15 +280,23 @@ def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=
         sh, sw = ma.stride
         wmats = [m.weight.view(m.weight.shape[0], -1) for m in (ma, mb)]
         in_shape = tuple(int(v) for v in xs[0].shape)
-        ys, (B, Ho, Wo) = _C.conv_fwd_nhwc_group(xs, wmats, [ma.bias, mb.bias], kh, kw, sh, sw, act)
+        last = k == len(convs_a) - 1
+        ys, (B, Ho, Wo) = _C.conv_fwd_nhwc_group(xs, wmats, [ma.bias, mb.bias], kh, kw, sh, sw, act, out_chw=last)
         for t, x, y, wmat in zip(tapes, xs, ys, wmats):
             t.convs.append(("nhwc", x, y, wmat, in_shape, (kh, kw, sh, sw)))
+            t.feat_chw = last
+        if last:
+            feats = ys
+            for t in tapes:
+                t.feat_shape = (Ho * Wo, int(wmats[0].shape[0]))
+            break
         xs = [y.view(B, Ho, Wo, int(wmats[0].shape[0])) for y in ys]
-    B, Ho, Wo, Cc = (int(v) for v in xs[0].shape)
-    feats = []
-    for t, x in zip(tapes, xs):
-        t.feat_shape = (Ho * Wo, Cc)
-        feats.append(_C.transpose_bpc(x, B, Ho * Wo, Cc).view(B, Cc * Ho * Wo))   # PyTorch's NCHW flatten order
+    else:                                                      # a one-layer trunk: features of the uint8 layer
+        B, Ho, Wo, Cc = (int(v) for v in xs[0].shape)
+        feats = []
+        for t, x in zip(tapes, xs):
+            t.feat_shape = (Ho * Wo, Cc)
+            feats.append(_C.transpose_bpc(x, B, Ho * Wo, Cc).view(B, Cc * Ho * Wo))   # PyTorch's NCHW flatten order
     outs, fcs = mlp_forward_group([fc_layers(net_a), fc_layers(net_b)], feats, act)
     for t, fc in zip(tapes, fcs):
         t.fc = fc
@@ -296,8 +312,8 @@ def cnn_backward(net, tape, d_out, grads, workspace=None):
     d_feat = mlp_backward(tape.fc, d_out, grads=grads[n_conv:], need_input=True, workspace=workspace)
     P, Cc = tape.feat_shape
     top_y = tape.convs[-1][2]
-    d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P, y_gate=top_y,
-                         gate_act=tape.act).view(tape.B * P, Cc)         # back to (B, P, C)
+    d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P, y_gate=top_y, gate_act=tape.act,
+                         gate_like_in=tape.feat_chw).view(tape.B * P, Cc)   # back to (B, P, C)
     gated = True                                                         # d is dZ of layer k (else dY)
     for k in range(n_conv - 1, -1, -1):
         kind, src, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]      # src: cols matrix / input activations / frames
