@@ -619,6 +619,23 @@ int trl_conv_bwd_weight_u8_f32(const float* dy, const float* y_gate, int gate_ac
 int trl_dqn_td_loss_f32(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,
                         const float* rewards, const float* terminals, float gamma, int B, int A, float* dq,
                         double* sums, double* ring, int slots, const double* update_count, void* stream);
+/* --- K14b: the linear head of a DQN update in one launch (dqn.py:47-60 and nn.Linear's autograd, nets.py:34-52):
+ * from the last hidden activations h (online net on obs) and h_next (target net on next_obs), both (B, H):
+ *   q = h w^T + bias, q_next = h_next w_t^T + bias_t   ((B, A); written to q_out / qn_out when non-NULL),
+ *   K14's loss, sums and ring row,
+ *   dh (B, H) = dq w,  dw (A, H) = dq^T h,  db (A) = column sums of dq      (dq as K14 defines it)
+ * -- what trl_linear_fwd_*, trl_dqn_td_loss_f32, trl_linear_bwd_weight_f32 and trl_linear_bwd_input_f32 compute as
+ * seven launches.  Deterministic (fixed sample -> wave map, fixed fold order).  Shapes: trl_dqn_head_supported
+ * (H % 4 == 0, H <= 1024, A <= 8); workspace: trl_dqn_head_workspace bytes, 16-byte aligned, ZEROED ONCE before the
+ * first call and then left alone (it holds the launch-to-launch arrival counter of the kernel's internal rendezvous);
+ * calls sharing a workspace must be stream-ordered. */
+int trl_dqn_head_supported(int H, int A);
+int64_t trl_dqn_head_workspace(int H, int A);
+int trl_dqn_head_f32(const float* h, const float* h_next, const float* w, const float* bias, const float* w_t,
+                     const float* bias_t, const int64_t* acts, const float* acts_f, const float* rewards,
+                     const float* terminals, float gamma, int B, int H, int A, float* dh, float* dw, float* db,
+                     float* q_out, float* qn_out, double* sums, double* ring, int slots, const double* update_count,
+                     void* workspace, void* stream);
 /* --- K15: QR-DQN quantile-Huber loss + output gradient (qrdqn.py:39-60, algo/utils.py:5-13):
  * q, q_next, dq (B, A*Q); workspace 2B doubles; acts / acts_f / sums / ring as above (loss sum is over B*Q*Q terms) */
 int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* acts_f, const float* q_next,

@@ -383,3 +383,52 @@ def test_last_conv_layer_stores_the_flattened_features_itself(Cout, group):
     a = _C.transpose_bpc(d.view(B, Cout, P), B, Cout, P, y_gate=want[0], gate_act=_C.ACT_RELU)
     b = _C.transpose_bpc(d.view(B, Cout, P), B, Cout, P, y_gate=got[0], gate_act=_C.ACT_RELU, gate_like_in=True)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,H,A,float_acts", [(512, 512, 6, True), (37, 64, 3, False), (130, 1024, 8, True), (1100, 256, 2, False), (5, 4, 1, False)])
+def test_one_launch_dqn_head_equals_the_layer_kernels_and_the_loss_launch(B, H, A, float_acts):
+    """`trl_dqn_head_f32` (both head forwards, the TD loss and the head's backward in one launch) against the launches
+    it replaces -- linear_fwd x 2, dqn_td_loss, linear_bwd_weight, linear_bwd_input -- and against autograd in float64;
+    run twice on one workspace (the arrival counter carries over) with bit-identical results."""
+    from torchrl_amd import _C
+    torch.manual_seed(B + A)
+    h, hn = torch.randn(B, H, device=DEV), torch.randn(B, H, device=DEV)
+    w, wt = torch.randn(A, H, device=DEV) * 0.1, torch.randn(A, H, device=DEV) * 0.1
+    b, bt = torch.randn(A, device=DEV), torch.randn(A, device=DEV)
+    acts_i = torch.randint(0, A, (B,), device=DEV)
+    acts = acts_i.float() if float_acts else acts_i
+    rew, term = torch.randn(B, device=DEV), (torch.rand(B, device=DEV) < 0.2).float()
+    gamma = 0.97
+    # the separate launches
+    q, qn = _C.linear_fwd(h, w, b, _C.ACT_NONE), _C.linear_fwd(hn, wt, bt, _C.ACT_NONE)
+    sums0 = torch.zeros(3, dtype=torch.float64, device=DEV)
+    dq = _C.dqn_td_loss(q, acts, qn, rew, term, gamma, sums0)
+    dw0, db0 = torch.zeros_like(w), torch.zeros_like(b)
+    _C.linear_bwd_weight(dq, None, _C.ACT_NONE, h, dw=dw0, db=db0)
+    dh0 = _C.linear_bwd_input(dq, None, _C.ACT_NONE, w)
+    # one launch
+    ws = _C.dqn_head_workspace(H, A, DEV)
+    outs = []
+    for _ in range(2):
+        sums, dw, db = torch.zeros(3, dtype=torch.float64, device=DEV), torch.zeros_like(w), torch.zeros_like(b)
+        dh, q1, qn1 = _C.dqn_head(h, hn, w, b, wt, bt, acts, rew, term, gamma, dw, db, sums, ws, want_q=True)
+        outs.append((dh, q1, qn1, dw, db, sums))
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    dh, q1, qn1, dw, db, sums = outs[0]
+    torch.testing.assert_close(q1, q, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(qn1, qn, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dh, dh0, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(dw, dw0, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(db, db0, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(sums, sums0, rtol=1e-5, atol=1e-7)
+    # float64 autograd
+    h64, w64, b64 = h.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    qq = h64 @ w64.t() + b64
+    tgt = rew.double() + gamma * (1 - term.double()) * (hn.double() @ wt.double().t() + bt.double()).max(1).values
+    loss = ((qq.gather(1, acts_i[:, None]).squeeze(1) - tgt) ** 2).mean()
+    loss.backward()
+    torch.testing.assert_close(dh.double(), h64.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(dw.double(), w64.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(db.double(), b64.grad, rtol=1e-4, atol=1e-6)
+    assert abs(sums[0].item() / B - loss.item()) <= 1e-5 * max(1.0, abs(loss.item()))

@@ -195,6 +195,10 @@ SIGNATURES = {
                                    + [C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "trl_dqn_td_loss_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_dqn_head_supported": (C.c_int, [C.c_int, C.c_int]),
+    "trl_dqn_head_workspace": (C.c_int64, [C.c_int, C.c_int]),
+    "trl_dqn_head_f32": (C.c_int, [C.c_void_p] * 10 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 +
+                         [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_quantile_huber_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 +
                                [C.c_int, C.c_void_p, C.c_void_p]),
     "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
@@ -1160,6 +1164,35 @@ def dqn_td_loss(q, acts, q_next, rew, term, gamma, sums, ring=None):
                                     dev_ptr(sums, torch.float64, "sums"), rp, slots, cp, stream_ptr(q.device)),
           "trl_dqn_td_loss_f32")
     return dq
+
+
+def dqn_head_supported(H, A):
+    return bool(lib().trl_dqn_head_supported(int(H), int(A)))
+
+
+def dqn_head_workspace(H, A, device):
+    """Zeroed workspace of `dqn_head` (keep it: it carries the kernel's arrival counter from launch to launch)."""
+    return torch.zeros(int(lib().trl_dqn_head_workspace(int(H), int(A))), dtype=torch.uint8, device=device)
+
+
+def dqn_head(h, h_next, w, bias, w_t, bias_t, acts, rew, term, gamma, dw, db, sums, workspace, ring=None, want_q=False):
+    """The DQN head's forward, loss and backward in one launch (include/trl_hip.h K14b).  Fills dw (A, H), db (A), sums;
+    returns dh (B, H), or (dh, q, q_next) with `want_q`."""
+    B, H, A = int(h.shape[0]), int(h.shape[1]), int(w.shape[0])
+    dh = torch.empty_like(h)
+    q = torch.empty((B, A), dtype=torch.float32, device=h.device) if want_q else None
+    qn = torch.empty((B, A), dtype=torch.float32, device=h.device) if want_q else None
+    ai, af = _acts_ptrs(acts)
+    rp, slots, cp = _ring_args(ring)
+    check(lib().trl_dqn_head_f32(dev_ptr(h, name="h"), dev_ptr(h_next, name="h_next"), dev_ptr(w, name="w"),
+                                 dev_ptr(bias, name="bias", allow_none=True), dev_ptr(w_t, name="w_t"),
+                                 dev_ptr(bias_t, name="bias_t", allow_none=True), ai, af, dev_ptr(rew, name="rew"),
+                                 dev_ptr(term, name="term"), float(gamma), B, H, A, dev_ptr(dh, name="dh"),
+                                 dev_ptr(dw, name="dw"), dev_ptr(db, name="db"), dev_ptr(q, name="q", allow_none=True),
+                                 dev_ptr(qn, name="q_next", allow_none=True), dev_ptr(sums, torch.float64, "sums"),
+                                 rp, slots, cp, dev_ptr(workspace, torch.uint8, "workspace"), stream_ptr(h.device)),
+          "trl_dqn_head_f32")
+    return (dh, q, qn) if want_q else dh
 
 
 def quantile_huber(q, acts, q_next, rew, term, gamma, A, Q, sums, ring=None):

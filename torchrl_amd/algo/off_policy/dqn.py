@@ -123,6 +123,7 @@ class _FusedDQN:
         self._slab = IndexSlab(self.dev)
         self._static, self._graphs, self._seen = None, {}, set()
         self.step_state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.dev)
+        self._head_ws = None                                            # workspace of the one-launch head (conv nets, Q = 1)
 
     def update(self, batch):
         return self.resolve([self.enqueue(batch)])[0]
@@ -168,13 +169,27 @@ class _FusedDQN:
         acts = st["acts"].view(-1)                                       # floats as stored; the loss launch casts at the read
         ring = (self._ring.t, self.step_state) if dist.world_size() == 1 else None    # (else: copied after the all-reduce)
         B, A, Q = int(obs.shape[0]), self.A, int(algo.quantile_num)
+        pair = None
         if self.is_mlp:
             q, tape = ops.mlp_forward(self.layers, obs, self.act)
             qn, _ = ops.mlp_forward(self.tlayers, nobs, self.act)
         else:
             # online net on obs and target net on next_obs: one grouped launch per layer after the first
-            (q, tape), (qn, _) = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs)
-        if Q == 1:
+            (hw, hb), (tw, tb) = ops.fc_layers(algo.qf)[-1], ops.fc_layers(algo.target_qf)[-1]
+            if Q == 1 and hb is not None and _C.dqn_head_supported(int(hw.shape[1]), A) and \
+                    hw.data_ptr() % 16 == 0 and tw.data_ptr() % 16 == 0:
+                pair = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs, head=False)
+            if pair is None:
+                (q, tape), (qn, _) = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs)
+        if pair is not None:
+            # the A-wide head: both forward passes, the loss and its whole backward pass in one launch
+            (h, tape), (hn, _) = pair
+            if self._head_ws is None:
+                self._head_ws = _C.dqn_head_workspace(int(hw.shape[1]), A, dev)
+            gw, gb = self.gviews[-1]
+            dq = _C.dqn_head(h, hn, hw, hb, tw, tb, acts, rew, term, algo.discount, gw, gb, self.sums, self._head_ws,
+                             ring=ring)                                  # = d loss / d h
+        elif Q == 1:
             dq = _C.dqn_td_loss(q, acts, qn, rew, term, algo.discount, self.sums, ring=ring)
         else:
             dq = _C.quantile_huber(q, acts, qn, rew, term, algo.discount, A, Q, self.sums, ring=ring)

@@ -175,6 +175,292 @@ static int quantile_huber(const float* q, const int64_t* acts, const float* acts
   return TRL_OK;
 }
 
+// ---------------------------------------------------------------- K14b
+// The linear head of a (non-quantile) DQN update as ONE launch: Q(s) = h W^T + b and Q'(s') = h' W'^T + b' on the last
+// hidden activations of the online / target net, K14's loss and sums, and the head's whole backward pass
+//     dh[b, :] = dq[b, a_b] W[a_b, :],   dW[a, :] = sum_b dq[b, a] h[b, :],   db[a] = sum_b dq[b, a]
+// (dqn.py:47-60 + the autograd of nn.Linear).  With A = 6 outputs these were seven launches -- two split-K GEMMs with
+// their folds, the loss, a weight-gradient GEMM of 8 workgroups with its fold, an input-gradient GEMM -- of 5-11 us each,
+// every one latency-bound.  Here a wave owns a sample: the two rows of activations are 2 x H floats in registers, W and W'
+// sit in LDS; the eight samples of a pass leave their activations and their loss factor in LDS, and every thread adds
+// them -- in wave order -- into its own slice of the workgroup's dW; that partial leaves the workgroup as self-validating
+// granules and each of the 64 workgroups folds a slice of the outputs over all partials in fixed order.  Deterministic.
+#define DQH_WGS 64
+#define DQH_WAVES 8
+#define DQH_THREADS (64 * DQH_WAVES)
+#define DQH_MAX_A 8
+#define DQH_MAX_H 1024
+#define DQH_MAX_GRP 4                             // float4 groups of dW per thread: A * H <= 8192
+struct DqHead {
+  const float* h; const float* hn; const float* w; const float* bias; const float* wt; const float* bias_t;
+  const int64_t* act; const float* act_f; const float* rew; const float* term;
+  float gamma; int B, H, A;
+  float* dh; float* dw; float* db; float* q_out; float* qn_out; double* sums; DqRing ring;
+  unsigned long long* part;                       // [DQH_WGS][A * H + A + 6] granules {launch epoch, value bits}
+  unsigned long long* arrive;                     // launches so far x DQH_WGS: where the launch epoch comes from
+};
+#ifdef TRL_EXP_CLK                                // development aid (tools/bench_dqn_head.py): 100 MHz stamps of workgroups 0 and 63
+__device__ long long g_dqh_clk[2 * 8];
+#define HCLK(ph) if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == DQH_WGS - 1)) g_dqh_clk[(blockIdx.x ? 8 : 0) + (ph)] = wall_clock64();
+extern "C" int trl_dbg_dqh_clk(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dqh_clk), sizeof(long long) * 16); }
+#else
+#define HCLK(ph)
+#endif
+// A partial leaves its workgroup as 8-byte granules {epoch, value}, written and read with device-scope accesses that
+// bypass the (per-XCD, non-coherent) L2: a reader that sees this launch's epoch in a granule has its value.  No fence
+// (a device-scope release / acquire pair writes back and invalidates a whole L2: 7 us each, measured) and no barrier.
+__device__ __forceinline__ void dqh_put(unsigned long long* p, unsigned epoch, float v) {
+  __hip_atomic_store(p, ((unsigned long long)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float dqh_get(const unsigned long long* p, unsigned epoch) {
+  unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while ((unsigned)(g >> 32) != epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return __uint_as_float((unsigned)g);
+}
+template <int CH>                                 // chunks of 256 floats per activation row: H <= 256 CH
+__global__ __launch_bounds__(DQH_THREADS) void dqn_head_kernel(DqHead d) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  __shared__ float swave[DQH_WAVES][6];           // loss / q_s_a / reward sums as (hi, lo) float pairs
+  __shared__ float sbias[DQH_WAVES][DQH_MAX_A];
+  __shared__ float comb[DQH_WAVES][64];
+  __shared__ float hb[2][DQH_MAX_A];
+  __shared__ float meta_g[DQH_WAVES];
+  __shared__ int meta_at[DQH_WAVES];
+  __shared__ unsigned s_epoch;
+  const int H = d.H, A = d.A, AH = A * H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  HCLK(0)
+  if (tid == 0)                                   // launches are stream-ordered: all 64 arrivals of a launch share old / 64
+    s_epoch = (unsigned)(__hip_atomic_fetch_add(d.arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / DQH_WGS) + 1u;
+  float* Ws = dsm;                                // [A][H]
+  float* Wts = dsm + AH;                          // [A][H]
+  float* rowbuf = dsm + 2 * AH;                   // [8 waves][H]: the activations of the samples of one pass
+  for (int e = tid * 4; e < AH; e += DQH_THREADS * 4) {
+    *reinterpret_cast<f32x4*>(Ws + e) = *reinterpret_cast<const f32x4*>(d.w + e);
+    *reinterpret_cast<f32x4*>(Wts + e) = *reinterpret_cast<const f32x4*>(d.wt + e);
+  }
+  if (tid < DQH_MAX_A) hb[0][tid] = (d.bias && tid < A) ? d.bias[tid] : 0.0f;
+  else if (tid < 2 * DQH_MAX_A) hb[1][tid - DQH_MAX_A] = (d.bias_t && tid - DQH_MAX_A < A) ? d.bias_t[tid - DQH_MAX_A] : 0.0f;
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  // this THREAD's slice of the workgroup's dW: float4 groups tid + 512 k of the (A, H) matrix
+  f32x4 gw[DQH_MAX_GRP];
+#pragma unroll
+  for (int k = 0; k < DQH_MAX_GRP; ++k) gw[k] = zero4;
+  float gb[DQH_MAX_A];                            // this WAVE's db (wave-uniform)
+#pragma unroll
+  for (int a = 0; a < DQH_MAX_A; ++a) gb[a] = 0.0f;
+  __syncthreads();
+  HCLK(1)
+  const unsigned epoch = s_epoch;
+  const float inv_b = 1.0f / (float)d.B;
+  double sl = 0.0, sq = 0.0, sr = 0.0;
+  for (int b0 = blockIdx.x * DQH_WAVES; b0 < d.B; b0 += DQH_WGS * DQH_WAVES) {       // a pass: one sample per wave
+    const int b = b0 + wave;
+    float g = 0.0f;
+    int at = 0;
+    if (b < d.B) {
+      f32x4 hv[CH], nv[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = c * 256 + lane * 4;
+        hv[c] = j < H ? *reinterpret_cast<const f32x4*>(d.h + (size_t)b * H + j) : zero4;
+        nv[c] = j < H ? *reinterpret_cast<const f32x4*>(d.hn + (size_t)b * H + j) : zero4;
+      }
+      at = dq_action(d.act, d.act_f, b, A);
+      const float r = d.rew[b], nd = d.gamma * (1.0f - d.term[b]);
+      // the 2 A dot products: lane partials first, then ONE butterfly over all of them (independent shuffles pipeline;
+      // a reduction per dot product is 12 dependent chains of 6 LDS round trips)
+      float s[DQH_MAX_A], sn[DQH_MAX_A];
+#pragma unroll
+      for (int a = 0; a < DQH_MAX_A; ++a) {
+        s[a] = 0.0f; sn[a] = 0.0f;
+        if (a < A) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const int j = c * 256 + lane * 4;
+            if (j < H) {
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(Ws + a * H + j), tv = *reinterpret_cast<const f32x4*>(Wts + a * H + j);
+              s[a] = fmaf(hv[c][0], wv[0], s[a]); s[a] = fmaf(hv[c][1], wv[1], s[a]);
+              s[a] = fmaf(hv[c][2], wv[2], s[a]); s[a] = fmaf(hv[c][3], wv[3], s[a]);
+              sn[a] = fmaf(nv[c][0], tv[0], sn[a]); sn[a] = fmaf(nv[c][1], tv[1], sn[a]);
+              sn[a] = fmaf(nv[c][2], tv[2], sn[a]); sn[a] = fmaf(nv[c][3], tv[3], sn[a]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int a = 0; a < DQH_MAX_A; ++a)
+          if (a < A) { s[a] += __shfl_xor(s[a], o, 64); sn[a] += __shfl_xor(sn[a], o, 64); }
+      }
+      float mx = -INFINITY, qsa = 0.0f;
+#pragma unroll
+      for (int a = 0; a < DQH_MAX_A; ++a) {
+        if (a < A) {
+          const float qa = s[a] + hb[0][a], qna = sn[a] + hb[1][a];
+          if (lane == 0 && d.q_out) d.q_out[(size_t)b * A + a] = qa;
+          if (lane == 0 && d.qn_out) d.qn_out[(size_t)b * A + a] = qna;
+          mx = fmaxf(mx, qna);
+          qsa = a == at ? qa : qsa;
+        }
+      }
+      const float tgt = r + nd * mx;
+      const float e = qsa - tgt;
+      g = 2.0f * e * inv_b;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = c * 256 + lane * 4;
+        if (j < H) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(Ws + at * H + j);
+          f32x4 o = {g * wv[0], g * wv[1], g * wv[2], g * wv[3]};
+          *reinterpret_cast<f32x4*>(d.dh + (size_t)b * H + j) = o;
+          *reinterpret_cast<f32x4*>(rowbuf + wave * H + j) = hv[c];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < DQH_MAX_A; ++a) gb[a] += a == at ? g : 0.0f;
+      sl += (double)e * e; sq += (double)qsa; sr += (double)r;
+    }
+    if (lane == 0) { meta_g[wave] = g; meta_at[wave] = at; }
+    __syncthreads();
+    // dW += sum over the pass's samples, in wave order: row a_b of the matrix gets g_b h_b, the other rows nothing
+#pragma unroll
+    for (int k = 0; k < DQH_MAX_GRP; ++k) {
+      const int e4 = 4 * (tid + DQH_THREADS * k);
+      if (e4 < AH) {
+        const int a = e4 / H, j = e4 - a * H;
+#pragma unroll
+        for (int w = 0; w < DQH_WAVES; ++w) {
+          const float ga = meta_at[w] == a ? meta_g[w] : 0.0f;
+          const f32x4 x = *reinterpret_cast<const f32x4*>(rowbuf + w * H + j);
+          gw[k][0] = fmaf(ga, x[0], gw[k][0]); gw[k][1] = fmaf(ga, x[1], gw[k][1]);
+          gw[k][2] = fmaf(ga, x[2], gw[k][2]); gw[k][3] = fmaf(ga, x[3], gw[k][3]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  HCLK(2)
+  if (lane == 0) {
+    // a double travels as two floats (hi + lo): the granules carry 32 value bits
+    const float lh = (float)sl, qh = (float)sq, rh = (float)sr;
+    swave[wave][0] = lh; swave[wave][1] = (float)(sl - (double)lh);
+    swave[wave][2] = qh; swave[wave][3] = (float)(sq - (double)qh);
+    swave[wave][4] = rh; swave[wave][5] = (float)(sr - (double)rh);
+#pragma unroll
+    for (int a = 0; a < DQH_MAX_A; ++a) sbias[wave][a] = gb[a];
+  }
+  const int n_out = AH + A, n_gran = n_out + 6;
+  unsigned long long* part = d.part + (size_t)blockIdx.x * n_gran;
+#pragma unroll
+  for (int k = 0; k < DQH_MAX_GRP; ++k) {
+    const int e4 = 4 * (tid + DQH_THREADS * k);
+    if (e4 < AH) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dqh_put(part + e4 + i, epoch, gw[k][i]);
+    }
+  }
+  __syncthreads();
+  HCLK(3)
+  if (wave == 1 && lane < A) {
+    float v = 0.0f;
+    for (int w = 0; w < DQH_WAVES; ++w) v += sbias[w][lane];
+    dqh_put(part + AH + lane, epoch, v);
+  }
+  if (wave == 2 && lane < 3) {                      // this workgroup's three sums, again as (hi, lo)
+    double v = 0.0;
+    for (int w = 0; w < DQH_WAVES; ++w) v += (double)swave[w][2 * lane] + (double)swave[w][2 * lane + 1];
+    const float hi = (float)v;
+    dqh_put(part + n_out + 2 * lane, epoch, hi);
+    dqh_put(part + n_out + 2 * lane + 1, epoch, (float)(v - (double)hi));
+  }
+  HCLK(4)
+  // fold over the workgroups: a pass = 64 outputs, wave w adds partials 8 w .. 8 w + 7 (all loads in flight), then the
+  // eight sub-sums are added in order
+  for (int e0 = blockIdx.x * 64; e0 < n_out; e0 += DQH_WGS * 64) {
+    const int e = e0 + lane;
+    float x[DQH_WGS / DQH_WAVES];
+#pragma unroll
+    for (int i = 0; i < DQH_WGS / DQH_WAVES; ++i)
+      x[i] = e < n_out ? dqh_get(d.part + (size_t)(wave * (DQH_WGS / DQH_WAVES) + i) * n_gran + e, epoch) : 0.0f;
+    float v = x[0];
+#pragma unroll
+    for (int i = 1; i < DQH_WGS / DQH_WAVES; ++i) v += x[i];
+    comb[wave][lane] = v;
+    __syncthreads();
+    if (wave == 0 && e < n_out) {
+      float t = comb[0][lane];
+      for (int w = 1; w < DQH_WAVES; ++w) t += comb[w][lane];
+      if (e < AH) d.dw[e] = t; else d.db[e - AH] = t;
+    }
+    __syncthreads();
+  }
+  HCLK(5)
+  if (blockIdx.x == DQH_WGS - 1 && wave == DQH_WAVES - 1) {
+    // the three sums: lane g fetches workgroup g's pairs; added in workgroup order by lane 0
+    double mine[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const unsigned long long* q = d.part + (size_t)lane * n_gran + n_out + 2 * k;
+      mine[k] = (double)dqh_get(q, epoch) + (double)dqh_get(q + 1, epoch);
+    }
+    double tot[3] = {0.0, 0.0, 0.0};
+    for (int g = 0; g < DQH_WGS; ++g) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tot[k] += __shfl(mine[k], g, 64);
+    }
+    if (lane == 0) {
+      d.sums[0] = tot[0]; d.sums[1] = tot[1]; d.sums[2] = tot[2];
+      dq_file(d.ring, tot[0], tot[1], tot[2]);
+    }
+  }
+  HCLK(6)
+}
+template <int CH>
+static int launch_dqn_head(const DqHead& d, int lds, hipStream_t s) {
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)dqn_head_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { trl_set_error("dqn_head: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(dqn_head_kernel<CH>, dim3(DQH_WGS), dim3(DQH_THREADS), lds, s, d);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+extern "C" int trl_dqn_head_supported(int H, int A) {
+  return H >= 4 && (H & 3) == 0 && H <= DQH_MAX_H && A >= 1 && A <= DQH_MAX_A &&
+         A * H <= 2048 * DQH_MAX_GRP;
+}
+extern "C" int64_t trl_dqn_head_workspace(int H, int A) {           // bytes; zero them once (the arrival counter lives there)
+  if (!trl_dqn_head_supported(H, A)) return 0;
+  return (int64_t)DQH_WGS * (A * H + A + 6) * sizeof(unsigned long long) + 16;
+}
+extern "C" int trl_dqn_head_f32(const float* h, const float* h_next, const float* w, const float* bias, const float* w_t,
+                                const float* bias_t, const int64_t* acts, const float* acts_f, const float* rewards,
+                                const float* terminals, float gamma, int B, int H, int A, float* dh, float* dw, float* db,
+                                float* q_out, float* qn_out, double* sums, double* ring, int slots,
+                                const double* update_count, void* workspace, void* stream) {
+  TRL_REQUIRE(B > 0 && trl_dqn_head_supported(H, A), "dqn_head: H % 4 == 0, H <= 1024, A <= 8 (use the layer kernels + trl_dqn_td_loss_f32)");
+  TRL_REQUIRE(h && h_next && w && w_t && rewards && terminals && dh && dw && db && sums && workspace, "null pointer");
+  TRL_REQUIRE(!acts != !acts_f, "dqn_head: exactly one of acts (int64) / acts_f (float)");
+  TRL_REQUIRE(!ring || (slots > 0 && update_count), "dqn_head: ring without slots / counter");
+  TRL_REQUIRE(((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(h_next) | reinterpret_cast<uintptr_t>(w) |
+                reinterpret_cast<uintptr_t>(w_t) | reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
+              "dqn_head: 16-byte aligned activations, weights, dh and workspace");
+  DqHead d{};
+  d.h = h; d.hn = h_next; d.w = w; d.bias = bias; d.wt = w_t; d.bias_t = bias_t; d.act = acts; d.act_f = acts_f;
+  d.rew = rewards; d.term = terminals; d.gamma = gamma; d.B = B; d.H = H; d.A = A; d.dh = dh; d.dw = dw; d.db = db;
+  d.q_out = q_out; d.qn_out = qn_out; d.sums = sums; d.ring = DqRing{ring, update_count, slots};
+  d.part = (unsigned long long*)workspace;
+  d.arrive = d.part + (size_t)DQH_WGS * (A * H + A + 6);
+  const int lds = (2 * A * H + DQH_WAVES * H) * (int)sizeof(float);
+  return H <= 512 ? launch_dqn_head<2>(d, lds, (hipStream_t)stream) : launch_dqn_head<4>(d, lds, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------- K17
 // action[n] = argmax_a score(n, a)  with score = Q (DQN) or mean over quantiles (QR-DQN);
 // where u[n] < epsilon the action is replaced by rand_act[n]

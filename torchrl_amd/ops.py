@@ -245,11 +245,14 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
     return out, t
 
 
-def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=-0.5):
+def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=-0.5, head=True):
     """`cnn_forward` of two same-architecture networks on two frame batches -- DQN's online net on obs and target net on
     next_obs -- with every layer after the first as ONE grouped launch (conv 2 / 3 as grouped implicit GEMMs, the FC head
     as grouped (split-K) layers).  Returns ((out_a, tape_a), (out_b, tape_b)); falls back to two separate passes for
-    geometries outside the grouped paths.  Same kernels and arithmetic as `cnn_forward`."""
+    geometries outside the grouped paths.  Same kernels and arithmetic as `cnn_forward`.
+    head=False: the pass stops at the last HIDDEN activations (the caller runs the linear head itself, `_C.dqn_head`);
+    the tapes then end at that layer and `cnn_backward` takes the gradient w.r.t. those activations.  Returns None when
+    the grouped path does not apply (the caller then runs the full pass)."""
     convs_a, convs_b = conv_layers(net_a), conv_layers(net_b)
     act = cnn_act_code(net_a)
     same = (len(convs_a) == len(convs_b) and cnn_act_code(net_b) == act and tuple(frames_a.shape) == tuple(frames_b.shape)
@@ -260,7 +263,11 @@ def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=
     if not same or first is None or frames_a.dtype != torch.uint8 or \
             not _C.conv_u8_implicit_ok(frames_a, *first.kernel_size, *first.stride) or \
             any(int(m.in_channels) % 4 for m in convs_a[1:]):
+        if not head:
+            return None
         return cnn_forward(net_a, frames_a, scale, shift), cnn_forward(net_b, frames_b, scale, shift)
+    if not head and len(fc_layers(net_a)) < 2:
+        return None
     tapes, xs = [], []
     for net, convs, frames in ((net_a, convs_a, frames_a), (net_b, convs_b, frames_b)):
         t = ConvTape()
@@ -297,7 +304,10 @@ def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=
         for t, x in zip(tapes, xs):
             t.feat_shape = (Ho * Wo, Cc)
             feats.append(_C.transpose_bpc(x, B, Ho * Wo, Cc).view(B, Cc * Ho * Wo))   # PyTorch's NCHW flatten order
-    outs, fcs = mlp_forward_group([fc_layers(net_a), fc_layers(net_b)], feats, act)
+    if head:
+        outs, fcs = mlp_forward_group([fc_layers(net_a), fc_layers(net_b)], feats, act)
+    else:
+        outs, fcs = mlp_forward_group([fc_layers(net_a)[:-1], fc_layers(net_b)[:-1]], feats, act, last_act=act)
     for t, fc in zip(tapes, fcs):
         t.fc = fc
     return (outs[0], tapes[0]), (outs[1], tapes[1])
