@@ -788,7 +788,7 @@ extern "C" int trl_synth_env_step_f32(float* cur_obs, const float* act, const fl
 // the policy MLP: sample the action from the head (rsample_fwd_kernel), store obs / acts, env.step (synth_step_kernel),
 // store next_obs / rewards / terminals / time_limits, the collector's bookkeeping (collector_bookkeep_kernel) and the
 // partial reset of finished envs (synth_reset_kernel + synth_bump_episode_kernel) -- eight launches of a few microseconds
-// of work each, host-launch-bound at ~10 us apiece.  One thread per env; same arithmetic, same Philox blocks.
+// of work each, host-launch-bound at ~10 us apiece.  Same arithmetic, same Philox blocks.
 struct CollectStep {
   float* cur_obs; const float* head; const float* eps; const float* envA; const float* envB;
   int64_t noise_seed, noise_ctr; int noise_row0;   // eps == NULL: the exploration noise of trl_philox_normal_f32(seed, ctr),
@@ -803,9 +803,17 @@ struct CollectStep {
   // tensors (n_rows rows); the block that retires last advances dyn[0] and dyn[1] (done: its counter, zero between launches)
   int64_t* dyn; int n_rows; unsigned* done;
 };
+// Workgroup = 8 envs x 32 feature slots (D <= 32, A <= 8): the observation and the action of an env sit in LDS, lane f of
+// the env's 32 computes feature f of the next observation (the same dot products in the same order as one thread per env
+// made them -- bit-identical -- but 17 of them side by side and the rows written as contiguous runs), lane 0 does the
+// env's bookkeeping.  One thread per env was 4 workgroups at N = 1024 walking 391 dependent FMAs and ~100 stores 68
+// bytes apart each: 28 us per vector step.
+#define CS_EPB (SAC_THREADS / 32)
 __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(CollectStep c) {
   extern __shared__ float sm[];                    // envA (D*D) | envB (A*D)
   __shared__ double red[SAC_THREADS / 64];
+  __shared__ float so[CS_EPB][32], sa[CS_EPB][8];
+  __shared__ int sflag[CS_EPB], sep[CS_EPB];
   const int D = c.D, A = c.A;
   // (locals, not writes into `c`: a modified kernel-argument struct is demoted to scratch memory)
   int64_t dyn_gs = 0, dyn_row = 0, noise_ctr = c.noise_ctr;
@@ -823,35 +831,50 @@ __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(Collect
   }
   for (int e = threadIdx.x; e < D * D; e += SAC_THREADS) sm[e] = c.envA[e];
   for (int e = threadIdx.x; e < A * D; e += SAC_THREADS) sm[D * D + e] = c.envB[e];
-  __syncthreads();
-  const int n = blockIdx.x * SAC_THREADS + threadIdx.x;
-  double r = 0.0;
-  if (n < c.N) {
-    float o[32], a[8], nv[32];
-    for (int k = 0; k < D; ++k) o[k] = c.cur_obs[(size_t)n * D + k];
-    float ez[8];
+  const int le = threadIdx.x >> 5, f = threadIdx.x & 31;
+  const int n = blockIdx.x * CS_EPB + le;
+  const bool live = n < c.N;
+  if (live && f < D) so[le][f] = c.cur_obs[(size_t)n * D + f];
+  if (live && f < A) {                             // action element f of the env: TanhNormal sample from the head
+    float ez;
     if (c.eps) {
-      for (int k = 0; k < A; ++k) ez[k] = c.eps[(size_t)n * A + k];
+      ez = c.eps[(size_t)n * A + f];
     } else {                                       // element e of the draw = normal (e & 3) of Philox block e / 4
-      philox_noise_row(c.noise_seed, noise_ctr, (int64_t)c.noise_row0 + n, A, ez);
+      const int64_t e = ((int64_t)c.noise_row0 + n) * A + f;
+      float z[4];
+      philox_normals4((uint32_t)(noise_ctr & 0xFFFFFFFFll), (uint32_t)((noise_ctr >> 32) & 0xFFFFFFFFll),
+                      (uint32_t)(e >> 2), TRL_TAG_NOISE, c.noise_seed, z);
+      const int q = (int)(e & 3);
+      ez = q == 0 ? z[0] : (q == 1 ? z[1] : (q == 2 ? z[2] : z[3]));
     }
-    rsample_row(c.head + (size_t)n * 2 * A, ez, a, A, c.tanh_action);
-    if (obs_row) for (int k = 0; k < D; ++k) obs_row[(size_t)n * D + k] = o[k];
-    if (acts_row) for (int k = 0; k < A; ++k) acts_row[(size_t)n * A + k] = a[k];
+    const float* head = c.head + (size_t)n * 2 * A;
+    const float mean = head[f];
+    const float sd = __expf(fminf(fmaxf(head[A + f], -20.0f), 2.0f));
+    const float z = fmaf(sd, ez, mean);
+    const float a = c.tanh_action ? trl_tanh(z) : z;
+    sa[le][f] = a;
+    if (acts_row) acts_row[(size_t)n * A + f] = a;
+  }
+  __syncthreads();
+  float nv = 0.0f;
+  if (live && f < D) {                             // obs' = tanh(obs A + act B), feature f
+    if (obs_row) obs_row[(size_t)n * D + f] = so[le][f];
+    float p = 0.0f;
+    for (int k = 0; k < D; ++k) p = fmaf(so[le][k], sm[k * D + f], p);
+    for (int k = 0; k < A; ++k) p = fmaf(sa[le][k], sm[D * D + k * D + f], p);
+    nv = trl_tanh(p);
+    next_row[(size_t)n * D + f] = nv;
+  }
+  double r = 0.0;
+  int t = 0;
+  if (live && f == 0) {
     float asq = 0.0f;
-    for (int k = 0; k < A; ++k) asq = fmaf(a[k], a[k], asq);
-    for (int f = 0; f < D; ++f) {                  // obs' = tanh(obs A + act B)
-      float p = 0.0f;
-      for (int k = 0; k < D; ++k) p = fmaf(o[k], sm[k * D + f], p);
-      for (int k = 0; k < A; ++k) p = fmaf(a[k], sm[D * D + k * D + f], p);
-      nv[f] = trl_tanh(p);
-      next_row[(size_t)n * D + f] = nv[f];
-    }
-    const int t = c.t_env[n] + 1;
-    const float rew = c.reward_scale * (nv[0] - 0.1f * asq);
+    for (int k = 0; k < A; ++k) asq = fmaf(sa[le][k], sa[le][k], asq);
+    t = c.t_env[n] + 1;
+    const float rew = c.reward_scale * (nv - 0.1f * asq);
     const bool d = t >= c.horizon;
     rew_row[n] = rew; done_row[n] = d ? 1.0f : 0.0f;
-    if (tl_row) tl_row[n] = d ? 1.0f : 0.0f;   // synthetic env: time_limit == done
+    if (tl_row) tl_row[n] = d ? 1.0f : 0.0f;       // synthetic env: time_limit == done
     r = (double)rew;
     const int cs = c.cur_step[n] + 1;              // ---- collector bookkeeping ----
     float er = c.ep_return[n] + rew;
@@ -864,18 +887,20 @@ __global__ __launch_bounds__(SAC_THREADS) void synth_collect_step_kernel(Collect
     c.cur_step[n] = flag ? 0 : cs;
     c.ep_return[n] = er;
     c.mask[n] = flag ? 1 : 0;
-    if (flag) {                                    // ---- partial reset: a fresh Philox observation, episode counter + 1 ----
-      const int ep = c.episode_idx[n] + 1;
-      for (int b = 0; 4 * b < D; ++b) {
-        float z[4];
-        philox_normals4((uint32_t)ep, 0u, (uint32_t)b, TRL_TAG_RESET, c.seed_base + n, z);
-        for (int q = 0; q < 4; ++q) if (4 * b + q < D) c.cur_obs[(size_t)n * D + 4 * b + q] = z[q];
-      }
-      c.t_env[n] = 0;
-      c.episode_idx[n] = ep;
+    const int ep = c.episode_idx[n] + 1;
+    sflag[le] = flag ? 1 : 0; sep[le] = ep;
+    c.t_env[n] = flag ? 0 : t;
+    if (flag) c.episode_idx[n] = ep;
+  }
+  __syncthreads();
+  if (live && f < D) {
+    if (sflag[le]) {                               // ---- partial reset: a fresh Philox observation (episode counter + 1) ----
+      float z[4];
+      philox_normals4((uint32_t)sep[le], 0u, (uint32_t)(f >> 2), TRL_TAG_RESET, c.seed_base + n, z);
+      const int q = f & 3;
+      c.cur_obs[(size_t)n * D + f] = q == 0 ? z[0] : (q == 1 ? z[1] : (q == 2 ? z[2] : z[3]));
     } else {
-      for (int f = 0; f < D; ++f) c.cur_obs[(size_t)n * D + f] = nv[f];
-      c.t_env[n] = t;
+      c.cur_obs[(size_t)n * D + f] = nv;
     }
   }
   r = block_sum(r, red);
@@ -912,7 +937,7 @@ extern "C" int trl_synth_collect_step_f32(float* cur_obs, const float* head, con
                 episode_idx, ep_return, reward_scale, horizon, max_episode_frames, env_seed_base, obs, acts, next_obs,
                 rewards, terminals, time_limits, reset_mask, epoch_reward, ep_count, ep_log, ep_cap, state ? 0 : step, N, D,
                 A, tanh_action, state, state ? n_rows : 0, state ? reinterpret_cast<unsigned*>(state + 3) : nullptr};
-  hipLaunchKernelGGL(synth_collect_step_kernel, dim3(trl_ceil_div(N, SAC_THREADS)), dim3(SAC_THREADS),
+  hipLaunchKernelGGL(synth_collect_step_kernel, dim3(trl_ceil_div(N, CS_EPB)), dim3(SAC_THREADS),
                      (D * D + A * D) * sizeof(float), (hipStream_t)stream, c);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
