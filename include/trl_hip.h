@@ -449,6 +449,17 @@ int trl_tanh_gauss_rsample_bwd_cols_f32(const float* head, const float* eps, con
                                         const float* dx2, int ld, int off, const float* d_logp_ptr,
                                         float d_logp_mul, float w_std, float w_mean, float* d_head, int B,
                                         int A, int tanh_action, void* stream);
+/* The policy gradient from the critics' first hidden layer to the policy head in one streaming launch
+ * (twin_sac_q.py:146-160): critic i (n = 1 or 2) contributes dZ_i = dy[i] * act'(y[i]) (both (B, H); y NULL or
+ * gate_act NONE: dy is dZ already) times the ACTION columns [off, off + A) of its first-layer weight w[i] (H, ldw),
+ *   d_act = sum_i dZ_i w[i][:, off:off+A],   d_head = what trl_tanh_gauss_rsample_bwd_f32 makes of d_act
+ * -- the input-gradient GEMM of that layer (whose other columns nobody reads) and the sampler's backward launch in one.
+ * H % 4 == 0, H <= 1024, A <= 8 (trl_sac_policy_grad_supported), 16-byte aligned rows. */
+int trl_sac_policy_grad_supported(int H, int A);
+int trl_sac_policy_grad_f32(int n, const float* const* dy, const float* const* y, int gate_act, const float* const* w,
+                            int H, int ldw, int off, const float* head, const float* eps, const float* act,
+                            const float* d_logp_ptr, float d_logp_mul, float w_std, float w_mean, float* d_head, int B,
+                            int A, int tanh_action, void* stream);
 /* both policy samples of one update and the three critic inputs in ONE launch (twin_sac_q.py:93-106, 125-131,
  * 146-151): (new_a, logp) from head = pf(obs) with eps1, (next_a, next_logp) from head2 = pf(next_obs) with eps2,
  * x_sa = [obs | acts], x_next = [next_obs | next_a], x_new = [obs | new_a]  (each (B, D + A)).

@@ -389,6 +389,58 @@ def test_graph_replayed_updates_equal_eager_updates(golden, monkeypatch):
         assert x == y
 
 
+@pytest.mark.parametrize("B,H,D,A,n,act", [(4096, 256, 17, 6, 2, "relu"), (133, 64, 5, 3, 1, "tanh"), (70, 1024, 3, 8, 2, "none")])
+def test_one_launch_policy_gradient_equals_the_layer_gemm_and_the_sampler_backward(B, H, D, A, n, act):
+    """`trl_sac_policy_grad_f32` against what it replaces -- linear_bwd_input of the critics' first layer (all D + A
+    columns) + rsample_bwd_cols on its action columns -- and determinism."""
+    from torchrl_amd import _C
+    torch.manual_seed(B + H)
+    code = {"relu": _C.ACT_RELU, "tanh": _C.ACT_TANH, "none": _C.ACT_NONE}[act]
+    dev = torch.device(DEV)
+    dys = [torch.randn(B, H, device=dev) for _ in range(n)]
+    ys = [torch.tanh(torch.randn(B, H, device=dev)) for _ in range(n)] if act != "none" else [None] * n
+    if act == "relu":
+        ys = [y.clamp_min(0.0) for y in ys]
+    ws = [torch.randn(H, D + A, device=dev) * 0.1 for _ in range(n)]
+    head, eps = torch.randn(B, 2 * A, device=dev), torch.randn(B, A, device=dev)
+    head[:, A:] *= 8.0                                               # some log_stds outside the clamp
+    actv = torch.tanh(head[:, :A] + head[:, A:].clamp(-20, 2).exp() * eps)
+    alpha = torch.tensor([0.37], device=dev)
+    dxs = [_C.linear_bwd_input(dy, y, code, w) for dy, y, w in zip(dys, ys, ws)]
+    want = _C.rsample_bwd_cols(head, eps, actv, dxs[0], dxs[1] if n == 2 else None, D, alpha, 1.0 / B, 1e-3, 2e-3, True)
+    assert _C.sac_policy_grad_ok(dys, ws, A)
+    got = _C.sac_policy_grad(head, eps, actv, dys, ys, code, ws, D, alpha, 1.0 / B, 1e-3, 2e-3, True)
+    again = _C.sac_policy_grad(head, eps, actv, dys, ys, code, ws, D, alpha, 1.0 / B, 1e-3, 2e-3, True)
+    assert torch.equal(got, again)
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-5 * max(scale, 1.0), ((got - want).abs().max().item(), scale)
+
+
+def test_sac_update_with_the_streaming_policy_gradient_equals_the_gemm_path(golden):
+    """Whole updates with the one-launch policy gradient and with the layer GEMM + sampler launch it replaces: the same
+    numbers up to the summation order of 256-term dot products."""
+    g = golden("twin_sac_q")
+    B, H = int(g["reg_args"][0]), int(g["reg_args"][1])
+    gen = torch.Generator().manual_seed(12)
+    batches = [{"obs": torch.randn(B, 17, generator=gen), "next_obs": torch.randn(B, 17, generator=gen),
+                "acts": torch.rand(B, 6, generator=gen) * 2 - 1, "rewards": torch.randn(B, 1, generator=gen),
+                "terminals": (torch.rand(B, 1, generator=gen) < 0.1).float()} for _ in range(4)]
+    flats = []
+    for fused in (True, False):
+        pf, qf1, qf2, kw, TwinSACQ = build_sac(H, 1e-3, 1.0, B)
+        pf.load_state_dict(sac_state(g, "reg_pf0_"))
+        qf1.load_state_dict(sac_state(g, "reg_qf10_"))
+        qf2.load_state_dict(sac_state(g, "reg_qf20_"))
+        agent = TwinSACQ(pf=pf, qf1=qf1, qf2=qf2, **kw)
+        agent.engine()._pg_fused = fused
+        for s, b in enumerate(batches):
+            torch.manual_seed(700 + s)
+            agent.update(b)
+        flats.append(agent.engine().flat.cpu().clone())
+    assert (flats[0] - flats[1]).abs().max().item() < 2e-6
+    assert not torch.equal(flats[0], torch.zeros_like(flats[0]))
+
+
 def test_env_step_and_off_policy_collector_vs_oracle():
     import torchrl.networks as networks
     import torchrl.policies as policies

@@ -162,6 +162,9 @@ SIGNATURES = {
     "trl_tanh_gauss_rsample_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float] * 3 + [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_tanh_gauss_rsample_bwd_cols_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_void_p] + [C.c_float] * 3 +
                                             [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_sac_policy_grad_supported": (C.c_int, [C.c_int, C.c_int]),
+    "trl_sac_policy_grad_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] +
+                                [C.c_void_p] * 4 + [C.c_float] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 4 +
                             [C.c_void_p, C.c_void_p]),
     "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -878,6 +881,27 @@ def rsample_bwd_cols(head, eps, act, dx1, dx2, off, d_logp_ptr, d_logp_mul, w_st
         dev_ptr(d_logp_ptr, name="d_logp_ptr", allow_none=True), float(d_logp_mul), float(w_std), float(w_mean),
         dev_ptr(d_head, name="d_head"), B, A, int(bool(tanh_action)), stream_ptr(head.device)),
         "trl_tanh_gauss_rsample_bwd_cols_f32")
+    return d_head
+
+
+def sac_policy_grad_ok(dys, ws, A):
+    H = int(dys[0].shape[1])
+    return len(dys) in (1, 2) and bool(lib().trl_sac_policy_grad_supported(H, int(A))) and \
+        all(d.data_ptr() % 16 == 0 and d.is_contiguous() and d.dtype == torch.float32 for d in dys)
+
+
+def sac_policy_grad(head, eps, act, dys, ys, gate_act, ws, off, d_logp_ptr, d_logp_mul, w_std, w_mean, tanh_action=True):
+    """d_head of the policy loss from the gradients `dys` at the critics' first hidden layer (outputs `ys`, weights `ws`
+    (H, D + A)): the action columns [off, off + A) of that layer's input gradient, summed over the critics, pushed through
+    the sampler's backward -- one launch (include/trl_hip.h trl_sac_policy_grad_f32)."""
+    B, A, H = int(eps.shape[0]), int(eps.shape[1]), int(dys[0].shape[1])
+    d_head = torch.empty((B, 2 * A), dtype=torch.float32, device=head.device)
+    gated = gate_act != ACT_NONE and ys is not None and all(y is not None for y in ys)
+    check(lib().trl_sac_policy_grad_f32(
+        len(dys), _ptrs(dys, "dy"), _ptrs(ys, "y") if gated else None, gate_act if gated else ACT_NONE, _ptrs(ws, "w"), H,
+        int(ws[0].shape[1]), int(off), dev_ptr(head, name="head"), dev_ptr(eps, name="eps"), dev_ptr(act, name="act"),
+        dev_ptr(d_logp_ptr, name="d_logp_ptr", allow_none=True), float(d_logp_mul), float(w_std), float(w_mean),
+        dev_ptr(d_head, name="d_head"), B, A, int(bool(tanh_action)), stream_ptr(head.device)), "trl_sac_policy_grad_f32")
     return d_head
 
 

@@ -159,6 +159,7 @@ class _FusedSAC:
         self._ring = StatRing(max(64, int(getattr(algo, "opt_times", 1))), self._raw.numel(), torch.uint8, self.dev)
         self._slab = IndexSlab(self.dev)
         self._mom_part = None
+        self._pg_fused = True                                           # policy gradient: sac_policy_grad (False: layer GEMM + sampler launch)
 
     def _ws(self, B):
         lib = _C.lib()
@@ -223,11 +224,25 @@ class _FusedSAC:
         # ---- the four critic backward passes as one group: through Q1 / Q2 on [obs | new_a] down to the action (policy
         # gradient, no weight gradients: twin_sac_q.py:152-155 discards them, its Q20) and the Q-loss pass on [obs | acts]
         # (weight gradients, no input gradient) ----
+        # The first critic layer's input gradient is only needed in its A action columns, summed over the twins and pushed
+        # through the sampler's backward: one streaming launch (sac_policy_grad) instead of a (B x 256) . (256 x (D + A)) GEMM
+        # per critic and the sampler launch behind it.
+        first = []
         dx1, dx2, _, _ = ops.mlp_backward_group([tape_q1n, tape_q2n, tape_q1, tape_q2], [dq1n, dq2n, dq1, dq2],
                                                 grads_list=[None, None, self.gviews[1], self.gviews[2]],
-                                                need_input=[True, True, False, False], plan=plan)
-        d_head = _C.rsample_bwd_cols(head, eps1, new_a, dx1, dx2, D, alpha, 1.0 / B, algo.policy_std_reg_weight,
-                                     algo.policy_mean_reg_weight, tanh_action)    # d_act = (dx1 + dx2)[:, D:]
+                                                need_input=[True, True, False, False], plan=plan,
+                                                input_sink=(lambda *a: first.append(a)) if self._pg_fused else None)
+        if first:
+            dys, ys, gate_act, w0 = first[0]
+            if _C.sac_policy_grad_ok(dys, w0, A):
+                d_head = _C.sac_policy_grad(head, eps1, new_a, dys, ys, gate_act, w0, D, alpha, 1.0 / B,
+                                            algo.policy_std_reg_weight, algo.policy_mean_reg_weight, tanh_action)
+            else:                                                         # shapes outside the streaming kernel: the layer GEMM
+                dx1, dx2 = _C.linear_bwd_input_group(dys, ys, gate_act, w0)
+                first = []
+        if not first:
+            d_head = _C.rsample_bwd_cols(head, eps1, new_a, dx1, dx2, D, alpha, 1.0 / B, algo.policy_std_reg_weight,
+                                         algo.policy_mean_reg_weight, tanh_action)    # d_act = (dx1 + dx2)[:, D:]
         ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], plan=plan)
         plan.run()
         # ---- optimiser steps (pf, qf1, qf2) and target update ----

@@ -4,6 +4,7 @@
 //
 // All kernels are memory-bound streaming passes over (B, <=32) fp32 rows; scalar results
 // (losses, means, Adam state of log_alpha) stay on the device.
+#include <algorithm>
 #include "trl_common.h"
 #include "trl_mlp.h"
 #include "trl_philox.h"
@@ -279,6 +280,179 @@ extern "C" int trl_tanh_gauss_rsample_bwd_cols_f32(const float* head, const floa
   hipLaunchKernelGGL(rsample_bwd_kernel, dim3(trl_ceil_div(B, SAC_THREADS)), dim3(SAC_THREADS), 0,
                      (hipStream_t)stream, head, eps, act, dx1, dx2, ld, off, d_logp_ptr, d_logp_mul, w_std, w_mean, d_head, B,
                      A, tanh_action);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
+// The policy gradient's way from the critics' first hidden layer down to the policy head in ONE streaming launch
+// (twin_sac_q.py:146-160): with dZ_i the gradient at critic i's first layer output (pre-activation side: dY_i * act'(Y_i),
+// Y_i the stored activations) and W_i (H, D + A) that layer's weight,
+//     d_act = sum_i dZ_i W_i[:, off : off + A]          -- the ACTION columns of the input gradient; nobody reads the rest
+//     d_head = rsample_bwd(d_act, ...)                  -- as rsample_bwd_kernel above
+// This was a (B x H) . (H x (D + A)) GEMM per critic on 64 workgroups -- 15 us of latency for 6 useful output columns of
+// 23 -- and the sampler's backward launch behind it.  Here a wave owns a row: 4 x H floats stream through, the two
+// A x H weight slices sit in LDS (transposed), the A dot products are reduced by one butterfly, lanes 0..A-1 finish.
+#define PG_MAX_A 8
+#define PG_MAX_CH 4                                 // H <= 1024
+struct PolGrad {
+  const float* dy[2]; const float* y[2]; const float* w[2];   // critic i: dY, Y (B, H); W (H, ldw); y[i] NULL: dy is dZ already
+  int n, H, ldw, off, gate_act;
+};
+#ifdef TRL_EXP_CLK                                  // development aid (tools/bench_policy_grad.py): 100 MHz stamps of 2 workgroups
+__device__ long long g_pg_clk[2 * 8];
+#define PCLK(ph) if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_pg_clk[(blockIdx.x ? 8 : 0) + (ph)] = wall_clock64();
+extern "C" int trl_dbg_pg_clk(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pg_clk), sizeof(long long) * 16); }
+#else
+#define PCLK(ph)
+#endif
+template <int CH>                                   // chunks of 256 floats per row: H <= 256 CH
+__global__ __launch_bounds__(SAC_THREADS) void sac_policy_grad_kernel(PolGrad g, const float* __restrict__ head,
+                                                                      const float* __restrict__ eps, const float* __restrict__ act,
+                                                                      const float* __restrict__ d_logp_ptr, float d_logp_mul,
+                                                                      float w_std, float w_mean, float* __restrict__ d_head,
+                                                                      int B, int A, int tanh_action) {
+  extern __shared__ __attribute__((aligned(16))) float wt[];          // [critic][PG_MAX_A][H]
+  const int H = g.H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  // a row's loads: 2 critics x {dY, Y} x 16 bytes per lane and chunk, and the sampler's inputs for lanes 0..A-1 -- requested
+  // for the FIRST row before the weights are staged (nothing of a row depends on them), and for the next row before the
+  // current one is reduced: one memory round trip per row instead of three
+  f32x4 zv[2][CH], yv[2][CH];
+  float h_mean = 0.0f, h_raw = 0.0f, h_eps = 0.0f, h_act = 0.0f;
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = c * 256 + lane * 4;
+        const bool on = i < g.n && j < H;
+        zv[i][c] = on ? *reinterpret_cast<const f32x4*>(g.dy[i] + (size_t)b * H + j) : zero4;
+        yv[i][c] = (on && g.y[i]) ? *reinterpret_cast<const f32x4*>(g.y[i] + (size_t)b * H + j) : zero4;
+      }
+    if (lane < A) {
+      h_mean = head[(size_t)b * 2 * A + lane]; h_raw = head[(size_t)b * 2 * A + A + lane];
+      h_eps = eps[(size_t)b * A + lane]; h_act = act[(size_t)b * A + lane];
+    }
+  };
+  const int stride = gridDim.x * (SAC_THREADS / 64);
+  int b = blockIdx.x * (SAC_THREADS / 64) + wave;
+  PCLK(0)
+  if (b < B) fetch(b);
+  PCLK(1)
+  // (critic index static: a per-lane index into the argument struct's pointer array costs a dependent load per element;
+  //  o fastest: a weight row's A columns are one run; slices padded to PG_MAX_A rows of zeros: no `o < A` in the row loop)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i < g.n) {
+      const float* __restrict__ wsrc = g.w[i] + g.off;
+#pragma unroll 4
+      for (int r = threadIdx.x; r < A * H; r += SAC_THREADS) {
+        const int j = r / A, o = r - j * A;
+        wt[(i * PG_MAX_A + o) * H + j] = wsrc[(size_t)j * g.ldw + o];
+      }
+      for (int r = A * H + threadIdx.x; r < PG_MAX_A * H; r += SAC_THREADS) wt[i * PG_MAX_A * H + r] = 0.0f;
+    }
+  }
+  __syncthreads();
+  PCLK(2)
+  const float d_logp = (d_logp_ptr ? *d_logp_ptr : 1.0f) * d_logp_mul;     // alpha / B, alpha a device scalar
+  const float reg = 2.0f / ((float)B * (float)A);
+  for (; b < B; b += stride) {
+    float part[PG_MAX_A];
+#pragma unroll
+    for (int o = 0; o < PG_MAX_A; ++o) part[o] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i < g.n) {
+        if (g.y[i]) {                                // act'(Y) from the stored outputs (uniform branches, once per row)
+          if (g.gate_act == TRL_ACT_RELU) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) zv[i][c][q] = yv[i][c][q] > 0.0f ? zv[i][c][q] : 0.0f;
+          } else if (g.gate_act == TRL_ACT_TANH) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) zv[i][c][q] *= 1.0f - yv[i][c][q] * yv[i][c][q];
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int j = c * 256 + lane * 4;
+          if (CH == 1 || j < H) {                    // (out-of-range lanes hold zeros: only the LDS address must stay inside)
+            const f32x4 z = zv[i][c];
+            const int j4 = (j < H ? j : 0) >> 2;
+#pragma unroll
+            for (int o = 0; o < PG_MAX_A; ++o) {
+              const f32x4 wv = reinterpret_cast<const f32x4*>(wt)[(i * PG_MAX_A + o) * (H >> 2) + j4];
+              part[o] = fmaf(z[0], wv[0], part[o]); part[o] = fmaf(z[1], wv[1], part[o]);
+              part[o] = fmaf(z[2], wv[2], part[o]); part[o] = fmaf(z[3], wv[3], part[o]);
+            }
+          }
+        }
+      }
+    }
+    PCLK(3)
+    const float mean = h_mean, raw = h_raw, ev = h_eps, a = h_act;
+    if (b + stride < B) fetch(b + stride);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+#pragma unroll
+      for (int o = 0; o < PG_MAX_A; ++o) part[o] += __shfl_xor(part[o], s, 64);
+    }
+    float da = 0.0f;
+#pragma unroll
+    for (int o = 0; o < PG_MAX_A; ++o) da = lane == o ? part[o] : da;
+    if (lane < A) {
+      const int o = lane;
+      const float ls = fminf(fmaxf(raw, -20.0f), 2.0f);
+      const float pass = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;
+      const float se = __expf(ls) * ev;
+      float da_dz = 1.0f, t = 0.0f;
+      if (tanh_action) { da_dz = fmaf(-a, a, 1.0f); t = 2.0f * a * da_dz / (da_dz + 1e-6f); }
+      const float g_z = da * da_dz + d_logp * t;                         // through z
+      d_head[(size_t)b * 2 * A + o] = g_z + w_mean * reg * mean;
+      d_head[(size_t)b * 2 * A + A + o] = pass * (g_z * se - d_logp + w_std * reg * ls);
+    }
+    PCLK(4)
+  }
+}
+extern "C" int trl_sac_policy_grad_supported(int H, int A) {
+  return H >= 4 && (H & 3) == 0 && H <= 256 * PG_MAX_CH && A >= 1 && A <= PG_MAX_A;
+}
+extern "C" int trl_sac_policy_grad_f32(int n, const float* const* dy, const float* const* y, int gate_act,
+                                       const float* const* w, int H, int ldw, int off, const float* head, const float* eps,
+                                       const float* act, const float* d_logp_ptr, float d_logp_mul, float w_std, float w_mean,
+                                       float* d_head, int B, int A, int tanh_action, void* stream) {
+  TRL_REQUIRE(B >= 0 && (n == 1 || n == 2) && trl_sac_policy_grad_supported(H, A), "policy_grad: 1-2 critics, H % 4 == 0, H <= 1024, A <= 8");
+  TRL_REQUIRE(off >= 0 && off + A <= ldw, "policy_grad: action columns outside the weight");
+  if (B == 0) return TRL_OK;
+  TRL_REQUIRE(dy && w && head && eps && act && d_head, "null pointer");
+  TRL_REQUIRE(gate_act == TRL_ACT_TANH || gate_act == TRL_ACT_RELU || gate_act == TRL_ACT_NONE, "unknown activation");
+  PolGrad g{};
+  g.n = n; g.H = H; g.ldw = ldw; g.off = off; g.gate_act = gate_act;
+  for (int i = 0; i < n; ++i) {
+    TRL_REQUIRE(dy[i] && w[i], "null pointer");
+    g.dy[i] = dy[i]; g.y[i] = (y && gate_act != TRL_ACT_NONE) ? y[i] : nullptr; g.w[i] = w[i];
+    TRL_REQUIRE(((reinterpret_cast<uintptr_t>(g.dy[i]) | reinterpret_cast<uintptr_t>(g.y[i])) & 15) == 0, "policy_grad: 16-byte aligned rows");
+  }
+  const int lds = n * PG_MAX_A * H * (int)sizeof(float);
+  // (a row is one memory round trip of its wave: as many waves as the chip holds, one or two rows each)
+  const int grid = std::max(1, std::min(trl_ceil_div(B, SAC_THREADS / 64), 1024));
+  if (H <= 256) {
+    hipLaunchKernelGGL(sac_policy_grad_kernel<1>, dim3(grid), dim3(SAC_THREADS), lds, (hipStream_t)stream, g, head, eps, act,
+                       d_logp_ptr, d_logp_mul, w_std, w_mean, d_head, B, A, tanh_action);
+  } else {
+    static int attr_lds = 0;
+    if (lds > attr_lds && lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)sac_policy_grad_kernel<PG_MAX_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) { trl_set_error("policy_grad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL(sac_policy_grad_kernel<PG_MAX_CH>, dim3(std::min(grid, 512)), dim3(SAC_THREADS), lds, (hipStream_t)stream,
+                       g, head, eps, act, d_logp_ptr, d_logp_mul, w_std, w_mean, d_head, B, A, tanh_action);
+  }
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }

@@ -110,10 +110,13 @@ def mlp_forward_group(layers_list, xs, act, last_act=None, keep=None):
     return hs, tapes
 
 
-def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspace=None, plan=None):
+def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspace=None, plan=None, input_sink=None):
     """`mlp_backward` of G same-shaped tapes with grouped launches.  grads_list: [grads of tape g] or None; an entry may
     be None (no weight gradients for that tape).  need_input: one flag, or one per tape -- tapes that do not need
-    d(input) drop out of the first layer's input-gradient launch (their slot of the result is None)."""
+    d(input) drop out of the first layer's input-gradient launch (their slot of the result is None).
+    input_sink(dys, ys, gate_act, ws): called INSTEAD of the first layer's input-gradient launch with the gradients at
+    that layer's outputs, the outputs that gate them (or None) and the layer's weights, for the tapes that need d(input)
+    -- a caller that only needs some columns of it (SAC's policy gradient: the action columns) computes them itself."""
     ds = list(d_outs)
     n = len(tapes[0].layers)
     want_in = list(need_input) if isinstance(need_input, (list, tuple)) else [bool(need_input)] * len(tapes)
@@ -143,6 +146,10 @@ def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspa
             pregated = True
         elif k > 0:
             ds = _C.linear_bwd_input_group(ds, gates, gate_act, [t.layers[k][0] for t in tapes])
+        elif any(want_in) and input_sink is not None:
+            sel = [g for g in range(len(tapes)) if want_in[g]]
+            input_sink([ds[g] for g in sel], [gates[g] for g in sel], gate_act, [tapes[g].layers[0][0] for g in sel])
+            ds = [None] * len(tapes)
         elif any(want_in):
             sel = [g for g in range(len(tapes)) if want_in[g]]
             dx = _C.linear_bwd_input_group([ds[g] for g in sel], [gates[g] for g in sel], gate_act,
