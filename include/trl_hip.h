@@ -84,6 +84,19 @@ int trl_gather_rows_multi(const void* const* src, void* const* dst, const int64_
  * (ppo.py:147) from them and the global element count. */
 int trl_adv_stats_f64(const float* advs, const int64_t* row_idx, int n_mb, int rows_mb,
                       int N, double* raw_out, void* stream);
+/* The same as the head of an epoch's update sequence, with what else precedes the minibatch updates riding in the one
+ * launch (ppo.py:27-39, utils.py:23-26): a minibatch's rows are cut into up to 8 slices, one workgroup each (40
+ * minibatches: 320 workgroups), whose partials the last slice to arrive folds in slice order (deterministic; same
+ * quantities as trl_adv_stats_f64, another summation order); `zero_doubles` doubles at `zero` are cleared (the block the
+ * updates file their statistics into) and n_copies (<= 4) runs of copy_words[q] 4-byte words are copied from copy_src[q]
+ * to copy_dst[q] (target_pf <- pf; the row indices and learning rates of the epoch) -- each optional (0).
+ * row_idx and the copy sources may be page-locked HOST memory (the device reads it in place): no copy command in front
+ * of the launch then.  workspace: trl_ppo_epoch_prologue_workspace(n_mb) bytes, zeroed ONCE by the caller and then
+ * left alone (arrival counters); NULL: one workgroup per minibatch, no workspace. */
+int64_t trl_ppo_epoch_prologue_workspace(int n_mb);
+int trl_ppo_epoch_prologue_f64(const float* advs, const int64_t* row_idx, int n_mb, int rows_mb, int N, double* raw_out,
+                               void* workspace, double* zero, int64_t zero_doubles, int n_copies, void* const* copy_dst,
+                               const void* const* copy_src, const int64_t* copy_words, void* stream);
 
 /* --- MLP2 inference -------------------------------------------------------
  * replaces Net.forward (nets.py:49-52) for vf(last_obs) (on_rl_algo.py:25-26)
@@ -150,6 +163,18 @@ typedef struct trl_rollout_t {
   float norm_clip;
   int norm_update;
   int normalize_partial_reset;
+  /* 16 bytes (NULL: none) that the launch sets to zero: the {epoch_reward, ep_count} header of the NEXT launch when the
+   * caller alternates between two headers -- the memset launch in front of every rollout goes away.  Must not be the
+   * header this launch accumulates into. */
+  double* clear_header;
+  /* (N) floats, NULL: none.  V(next_obs) of the LAST of the n_steps stored steps, from the value pass that follows the
+   * rollout in this call (it reads that row anyway): the bootstrap value of on_rl_algo.py:25-26 without a forward launch
+   * of its own.  Only with ring tensors. */
+  float* boot_values;
+  /* publish_words 4-byte words (0: none) copied from publish_src (device) to publish_dst -- page-locked HOST memory,
+   * written in place -- by the value pass: the epoch header and the head of the episode log reach the host without a
+   * copy command behind the launch.  Only with ring tensors; the words are final when the call's launches have completed. */
+  void* publish_dst; const void* publish_src; int64_t publish_words;
 } trl_rollout_t;
 int trl_rollout_synth_f32(const trl_rollout_t* args, void* stream);
 int trl_rollout_norm_workspace(int N);

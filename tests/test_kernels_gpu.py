@@ -495,3 +495,36 @@ def test_clip_adam_multi_step_vs_oracle():
             opt[k].step([p_ref[k]], gk)
             assert abs(d.norms[k].item() - nrm) < 1e-4 * nrm
     assert (d.params.cpu() - torch.cat(p_ref)).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("n_mb,rows_mb,N,T", [(40, 32, 2048, 128), (3, 5, 37, 9), (1, 1, 16, 4), (300, 2, 64, 16)])
+def test_epoch_prologue_equals_adv_stats_and_does_its_side_jobs(n_mb, rows_mb, N, T):
+    """`trl_ppo_epoch_prologue_f64`: sliced minibatches (arrival counters carried over launches) give trl_adv_stats_f64's
+    numbers up to the summation order, bit-identically from launch to launch; the zero and copy side jobs are done."""
+    from torchrl_amd import _C
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n_mb + N)
+    advs = torch.randn(T, N, device=dev) * 3 + 0.5
+    idx = torch.randint(0, T, (n_mb, rows_mb), device=dev)
+    want = _C.adv_stats(advs, idx, torch.zeros(n_mb, 4, dtype=torch.float64, device=dev))
+    ws = _C.ppo_epoch_prologue_workspace(n_mb, dev)
+    junk = torch.full((77,), 3.25, dtype=torch.float64, device=dev)
+    src, dst = torch.randn(1234, device=dev), torch.zeros(1234, device=dev)
+    outs = []
+    for it in range(3):
+        raw = torch.full((n_mb, 4), -7.0, dtype=torch.float64, device=dev)
+        pinned = torch.arange(10, dtype=torch.int64).pin_memory()
+        dev10 = torch.zeros(10, dtype=torch.int64, device=dev)
+        _C.ppo_epoch_prologue(advs, idx.cpu().pin_memory() if it == 1 else idx, raw, ws, zero=junk if it == 0 else None,
+                              copies=[(dst, src), (dev10, pinned)] if it == 0 else [])
+        if it == 0:
+            assert torch.equal(dev10.cpu(), pinned)
+        outs.append(raw)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert torch.equal(junk, torch.zeros_like(junk)) and torch.equal(dst, src)
+    got = outs[0]
+    assert torch.equal(got[:, 2:], want[:, 2:])                            # max / -min: exact
+    torch.testing.assert_close(got[:, :2], want[:, :2], rtol=1e-12, atol=1e-9)
+    a64 = advs.double()[idx]                                               # (n_mb, rows_mb, N)
+    torch.testing.assert_close(got[:, 0], a64.sum((1, 2)), rtol=1e-12, atol=1e-9)
+    torch.testing.assert_close(got[:, 1], (a64 * a64).sum((1, 2)), rtol=1e-12, atol=1e-9)

@@ -69,6 +69,8 @@ class RolloutArgs(C.Structure):
         ("ep_cap", C.c_int), ("step0", C.c_int),
         ("norm_state", C.c_void_p), ("policy_obs", C.c_void_p), ("norm_workspace", C.c_void_p),
         ("norm_clip", C.c_float), ("norm_update", C.c_int), ("normalize_partial_reset", C.c_int),
+        ("clear_header", C.c_void_p), ("boot_values", C.c_void_p),
+        ("publish_dst", C.c_void_p), ("publish_src", C.c_void_p), ("publish_words", C.c_int64),
     ]
 
 
@@ -110,6 +112,9 @@ SIGNATURES = {
     "trl_gather_rows_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int64, C.c_void_p]),
     "trl_adv_stats_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_ppo_epoch_prologue_workspace": (C.c_int64, [C.c_int]),
+    "trl_ppo_epoch_prologue_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -415,6 +420,42 @@ def adv_stats(advs, row_idx_2d, raw_out):
                                   n_mb, rows_mb, int(advs.shape[1]),
                                   dev_ptr(raw_out, torch.float64, "raw_out"), stream_ptr(advs.device)),
           "trl_adv_stats_f64")
+    return raw_out
+
+
+def ppo_epoch_prologue_workspace(n_mb, device):
+    """Zeroed workspace of `ppo_epoch_prologue` (keep it: it carries arrival counters from launch to launch)."""
+    return torch.zeros(int(lib().trl_ppo_epoch_prologue_workspace(int(n_mb))), dtype=torch.uint8, device=device)
+
+
+def _mapped_ptr(t, name):
+    """Device-readable address of a tensor: device memory, or page-locked host memory (which the GPU reads in place)."""
+    if not isinstance(t, torch.Tensor) or not t.is_contiguous():
+        raise TrlError("%s must be a contiguous tensor" % name)
+    if t.device.type != "cuda" and not t.is_pinned():
+        raise TrlError("%s lives in pageable host memory: the device cannot read it" % name)
+    return C.c_void_p(t.data_ptr())
+
+
+def ppo_epoch_prologue(advs, row_idx_2d, raw_out, workspace, zero=None, copies=()):
+    """`adv_stats` over sliced minibatches (>= 256 workgroups) with the clearing of `zero` (float64 tensor) and up to 4
+    copies `(dst, src)` (same byte size, a multiple of 4) riding in the same launch (include/trl_hip.h K7).  row_idx_2d
+    and the copy sources may be page-locked host tensors."""
+    n_mb, rows_mb = int(row_idx_2d.shape[0]), int(row_idx_2d.shape[1])
+    if row_idx_2d.dtype != torch.int64:
+        raise TrlError("row_idx must be int64")
+    n = len(copies)
+    dsts, srcs, words = (C.c_void_p * max(n, 1))(), (C.c_void_p * max(n, 1))(), (C.c_int64 * max(n, 1))()
+    for q, (dst, src) in enumerate(copies):
+        nb = dst.numel() * dst.element_size()
+        if nb != src.numel() * src.element_size() or nb % 4:
+            raise TrlError("ppo_epoch_prologue: copy %d needs two tensors of one byte size, a multiple of 4" % q)
+        dsts[q], srcs[q], words[q] = dev_ptr(dst, dst.dtype, "copy_dst").value, _mapped_ptr(src, "copy_src").value, nb // 4
+    check(lib().trl_ppo_epoch_prologue_f64(
+        dev_ptr(advs, name="advs"), _mapped_ptr(row_idx_2d, "row_idx"), n_mb, rows_mb, int(advs.shape[1]),
+        dev_ptr(raw_out, torch.float64, "raw_out"), dev_ptr(workspace, torch.uint8, "workspace", allow_none=True),
+        dev_ptr(zero, torch.float64, "zero", allow_none=True), 0 if zero is None else zero.numel(),
+        n, dsts, srcs, words, stream_ptr(advs.device)), "trl_ppo_epoch_prologue_f64")
     return raw_out
 
 

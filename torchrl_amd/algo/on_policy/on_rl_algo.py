@@ -27,8 +27,11 @@ class OnRLAlgo(RLAlgo):
     def process_epoch_samples(self):
         buf = self.replay_buffer
         last = buf.last_sample(list(_LAST_ROW_KEYS))
-        with torch.no_grad():
-            bootstrap = self.vf(last["next_obs"].to(self.device))
+        if getattr(buf, "_boot_fresh", False):                           # the fused rollout's value pass left V(next_obs) of
+            bootstrap = buf._boot                                        # the last row (same parameters: nothing stepped since)
+        else:
+            with torch.no_grad():
+                bootstrap = self.vf(last["next_obs"].to(self.device))
         if not self.gae:
             return buf.discount_reward(bootstrap, self.discount, last_terminal=last["terminals"])
         return buf.generalized_advantage_estimation(bootstrap, self.discount, self.tau, last_terminal=last["terminals"])

@@ -87,10 +87,11 @@ class PPO(A2C):
 
         def device_prologue():
             self.process_epoch_samples()
-            self.engine().sync_target_pf()                             # target_pf <- pf (utils.py:23-26), one D2D copy
+            self.engine().sync_target_pf(in_prologue=True)             # target_pf <- pf (utils.py:23-26)
             if not fresh:
                 self._fill_old_logp()
-        self._run_and_log(tensors, row_idx, buf.env_nums, pre=device_prologue, pre_key=(fresh, self.gae))
+        self._run_and_log(tensors, row_idx, buf.env_nums, pre=device_prologue,
+                          pre_key=(fresh, self.gae, bool(getattr(buf, "_boot_fresh", False))))
 
     # ---- single minibatch (reference entry point) ----
     def update(self, batch):
@@ -162,8 +163,12 @@ class _FusedPPO:
             self._opt_steps.append(step)
             offset += n
 
-    def sync_target_pf(self):
-        if self.target_flat is not None:
+    def sync_target_pf(self, in_prologue=False):
+        """target_pf <- pf.  in_prologue (called from an epoch's device prologue): the copy rides in the launch that
+        computes the advantage statistics (`_C.ppo_epoch_prologue`) instead of being a launch of its own."""
+        if self.target_flat is not None and in_prologue:
+            self._copy_in_prologue = True
+        elif self.target_flat is not None:
             self.target_flat.copy_(self.flat[:self.P_pf])
         else:
             atu.copy_model_params_from_to(self.algo.pf, self.algo.target_pf)
@@ -187,19 +192,24 @@ class _FusedPPO:
             self._buf_key = key
             self._idx_buf = torch.zeros(K * rows_mb, dtype=torch.int64, device=self.dev)
             self._stats = torch.zeros(29 * K, dtype=torch.float64, device=self.dev)
-            self._idx_host = torch.zeros(K * rows_mb, dtype=torch.int64).pin_memory()
+            # page-locked slab: the epoch's row indices, then one 8-byte slot for the two learning rates
+            self._slab_host = torch.zeros(K * rows_mb + 1, dtype=torch.int64).pin_memory()
+            self._idx_host = self._slab_host[:K * rows_mb]
+            self._hyper_host = self._slab_host[K * rows_mb:].view(torch.float32)
+            self._hyper = None
             self._stats_host = torch.zeros(29 * K, dtype=torch.float64).pin_memory()
             self._graph = None
         return self._idx_buf, self._stats
 
-    def _set_device_hyper(self, lr_pf, lr_vf):
+    def _set_device_hyper(self, lr_pf, lr_vf, upload=True):
+        """The learning rates into their page-locked slot; upload=False: the epoch prologue launch copies them (and the
+        row indices) itself, reading the slab in place."""
         hyper = (float(lr_pf), float(lr_vf))
-        if getattr(self, "_hyper", None) != hyper:
-            self._hyper = hyper
-            if getattr(self, "_hyper_host", None) is None:
-                self._hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        if getattr(self, "_hyper", None) != hyper or not upload:
+            self._hyper = hyper if upload else None
             self._hyper_host[0], self._hyper_host[1] = hyper
-            self.red_ws[2:4].copy_(self._hyper_host, non_blocking=True)
+            if upload:
+                self.red_ws[2:4].copy_(self._hyper_host, non_blocking=True)
 
     defers = True                                                      # run(..., defer=True) is implemented
 
@@ -228,7 +238,6 @@ class _FusedPPO:
             self._pending = None
         idx_dev, stats = self._buffers(K, rows_mb)
         self._idx_host.numpy()[:] = row_idx.reshape(-1)
-        idx_dev.copy_(self._idx_host, non_blocking=True)
         rows_total = t["advs"].shape[0]
         raw, info = stats[:4 * K].view(K, 4), stats[4 * K:28 * K].view(K, 24)
         norms = stats[28 * K:].view(torch.float32).view(K, 2)
@@ -244,8 +253,14 @@ class _FusedPPO:
         # the HIP graph as well; the Adam step count and learning rates then live on the device like in the fused launch.
         graph_coll = not fused and not xrank and os.environ.get("TRL_GRAPH_COLLECTIVES") == "1"
         lr_pf, lr_vf = algo.pf_optimizer.param_groups[0]['lr'], algo.vf_optimizer.param_groups[0]['lr']
+        # One process: no copy command for the epoch's row indices and learning rates -- the prologue launch reads the
+        # page-locked slab in place and leaves the device copies the update kernels use.  (The slab is rewritten only after
+        # the previous run's statistics have landed, see `last.resolve()` above: that run's launches are done by then.)
+        in_place = fused and probe is None
+        if not in_place:
+            idx_dev.copy_(self._idx_host, non_blocking=True)
         if fused or xrank:
-            self._set_device_hyper(lr_pf, lr_vf)
+            self._set_device_hyper(lr_pf, lr_vf, upload=not in_place)
         elif graph_coll:
             if getattr(self, "step_state", None) is None:
                 n = float(self.step_count)
@@ -257,7 +272,7 @@ class _FusedPPO:
         hyper = (float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
                  int(bool(getattr(algo, "clipped_value_loss", False))), int(bool(algo.pf.tanh_action)))
         use_graph = (fused or xrank or graph_coll) and probe is None and os.environ.get("TRL_NO_GRAPH") != "1"
-        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, xrank) + hyper + tuple(
+        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, xrank, in_place) + hyper + tuple(
             0 if t.get(k) is None else t[k].data_ptr() for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
 
         def launch_all():
@@ -281,11 +296,19 @@ class _FusedPPO:
             a.device_state = int(fused or xrank)                       # step count / lr from the workspace header
             idx_base, raw_base, info_base, norm_base = idx_dev.data_ptr(), raw.data_ptr(), info.data_ptr(), norms.data_ptr()
             lib = _C.lib()
+            self._copy_in_prologue = False
             if pre is not None:
                 pre()
-            stats.zero_()
             stream = _C.stream_ptr(dev)
-            _C.adv_stats(t["advs"].reshape(rows_total, N), idx_dev.view(K, rows_mb), raw)
+            # advantage statistics of all K minibatches; the statistics block cleared and target_pf <- pf in the same launch
+            if getattr(self, "_pro_ws", None) is None or self._pro_ws_k != K:
+                self._pro_ws, self._pro_ws_k = _C.ppo_epoch_prologue_workspace(K, dev), K
+            copies = [(self.target_flat, self.flat[:self.P_pf])] if self._copy_in_prologue else []
+            if in_place:
+                copies += [(idx_dev, self._idx_host), (self.red_ws[2:4], self._hyper_host)]
+            _C.ppo_epoch_prologue(t["advs"].reshape(rows_total, N),
+                                  (self._idx_host if in_place else idx_dev).view(K, rows_mb), raw, self._pro_ws,
+                                  zero=stats[4 * K:], copies=copies)
             dist.reduce_adv_raw_(raw)
             for k in range(K):
                 g.row_idx = idx_base + 8 * rows_mb * k
@@ -423,6 +446,9 @@ class _GenericPPO(_FusedPPO):
     trl_ppo_generic_losses_f32, clip + Adam on trl_clip_adam_f32.  Same interface, statistics block and info dicts
     as the fused engine, same per-sample arithmetic; ~25 launches per minibatch instead of 2 (TRL_GENERIC_PPO=1
     forces this engine for the benchmark shape too, which is how it is tested against the fused one)."""
+
+    def sync_target_pf(self, in_prologue=False):
+        super().sync_target_pf(False)                                  # (this engine's launch sequence has no fused prologue)
 
     def __init__(self, algo):
         from ... import ops

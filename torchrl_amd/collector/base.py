@@ -149,17 +149,21 @@ class VecCollector(_CollectorBase):
         self.global_step = 0
         self._log_step0 = 0
         dev = self.env.device
-        # epoch reward (f64) and finished-episode count (i32) share one 16-byte header: one memset, one D2H
-        self._hdr = torch.zeros(2, dtype=torch.float64, device=dev)
-        self._epoch_reward = self._hdr[:1]
-        self._ep_count = self._hdr[1:].view(torch.int32)[:1]
-        self._ep_log = torch.zeros(self.EP_LOG_CAP, 3, device=dev)
-        self._ep_log_host = torch.zeros(self.EP_LOG_CAP, 3).pin_memory() if torch.cuda.is_available() else None
-        if self._ep_log_host is not None:
+        # Epoch reward (f64) and finished-episode count (i32) share one 16-byte header; TWO such headers (the fused rollout
+        # alternates between them and zeroes the idle one inside its launch: no memset launch per epoch) and the episode
+        # log sit in ONE allocation with a page-locked twin, so that header + the head of the log come back in one D2H.
+        self._blob = torch.zeros(8 + 3 * self.EP_LOG_CAP, device=dev)
+        self._hdr2 = self._blob[:8].view(torch.float64).view(2, 2)
+        self._ep_log = self._blob[8:].view(self.EP_LOG_CAP, 3)
+        self._blob_host = torch.zeros(8 + 3 * self.EP_LOG_CAP).pin_memory() if torch.cuda.is_available() else None
+        self._ep_log_host = None if self._blob_host is None else self._blob_host[8:].view(self.EP_LOG_CAP, 3)
+        self._idle_hdr_clean = False            # the header not in use is known to be zero (a fused rollout cleared it)
+        self._use_header(0)
+        if self._blob_host is not None:
             # the runtime sets up its device-to-host copy path for a size class on first use (milliseconds): pay that
             # here, not in the first epoch in which episodes end
             for n in (64, 4096, self.EP_LOG_CAP):
-                self._ep_log_host[:n].copy_(self._ep_log[:n], non_blocking=True)
+                self._blob_host[:8 + 3 * n].copy_(self._blob[:8 + 3 * n], non_blocking=True)
             torch.cuda.current_stream(dev).synchronize()
         self._mask = torch.zeros(self.env.env_nums, dtype=torch.uint8, device=dev)
         self._noise_seed = 0xC011
@@ -182,19 +186,39 @@ class VecCollector(_CollectorBase):
         else:
             _C.synth_reset(env.cur_obs, env.t_env, env.cur_step, env.episode_idx, env.ep_return, self._mask, env.seed_base)
 
+    def _use_header(self, i):
+        self._hdr_i = i
+        self._hdr = self._hdr2[i]
+        self._epoch_reward = self._hdr[:1]
+        self._ep_count = self._hdr[1:].view(torch.int32)[:1]
+        self._hdr_host = None if self._blob_host is None else self._blob_host[4 * i:4 * i + 4].view(torch.float64)
+
     def _read_header(self):
         """(epoch reward, finished-episode count) with a single host sync (asynchronous copy into page-locked memory,
         then one wait on the stream)."""
-        if getattr(self, "_hdr_host", None) is None:
-            self._hdr_host = torch.zeros(2, dtype=torch.float64).pin_memory()
         self._hdr_host.copy_(self._hdr, non_blocking=True)
         torch.cuda.current_stream(self._hdr.device).synchronize()
         h = self._hdr_host
         return float(h[0]), int(h[1:].view(torch.int32)[0])
 
-    def _clear_header(self):
-        self._hdr.zero_()
+    def _clear_header(self, swap=False, index=None):
+        """Zero {epoch reward, episode count} for the launches that follow.  swap=True (the fused rollout, which clears
+        the idle header inside its launch): switch to the idle header when it is known to be clean instead of launching a
+        memset, and return the header the coming launch shall clear.  index: use THAT header (a captured launch sequence
+        carries the header it was captured with)."""
+        nxt = None
+        if index is not None and index != self._hdr_i:
+            self._use_header(index)
+            self._idle_hdr_clean = False
+        if swap and self._idle_hdr_clean:
+            self._use_header(1 - self._hdr_i)
+        else:
+            self._hdr.zero_()
+        if swap:
+            nxt = self._hdr2[1 - self._hdr_i]
+        self._idle_hdr_clean = False            # (the caller sets it once the clearing launch is enqueued)
         self._log_step0 = self.global_step      # the device log keeps steps RELATIVE to here (float32 columns: exact to 2^24)
+        return nxt
 
     def _finished_episodes(self, cnt=None):
         """(step, env, return) rows of episodes that ended since the log was cleared, in the
@@ -449,11 +473,10 @@ class VecCollector(_CollectorBase):
         if self.eager_epoch_result or self._ep_log_host is None \
                 or getattr(self.env, "is_host_env", False):
             return self._epoch_result_now()
-        if getattr(self, "_hdr_host", None) is None:
-            self._hdr_host = torch.zeros(2, dtype=torch.float64).pin_memory()
-        k = self.SPECULATIVE_ROWS
-        self._hdr_host.copy_(self._hdr, non_blocking=True)
-        self._ep_log_host[:k].copy_(self._ep_log[:k], non_blocking=True)
+        k = self.SPECULATIVE_ROWS                                          # both headers + the head of the log: ONE copy
+        if not getattr(self, "_published", False):                         # (the fused rollout's value pass wrote them already)
+            self._blob_host[:8 + 3 * k].copy_(self._blob[:8 + 3 * k], non_blocking=True)
+        self._published = False
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self._hdr.device))
         self._pending = _EpochResult(self, done)

@@ -226,7 +226,7 @@ class VecOnPolicyCollector(VecCollector):
             self._norm_cap = _C.lib().trl_rollout_norm_max_envs(D, H, A, act)
         return (not update) or env.env_nums <= self._norm_cap
 
-    def _launch(self, env, n_steps, store, deterministic, noise, max_frames=None, policy_ob=None):
+    def _launch(self, env, n_steps, store, deterministic, noise, max_frames=None, policy_ob=None, publish=False):
         D, H, A, act = self._spec
         buf = self.replay_buffer
         a = _C.RolloutArgs()
@@ -259,6 +259,12 @@ class VecOnPolicyCollector(VecCollector):
             for key, f in feats:
                 setattr(a, key, buf._ensure_key(key, (N, f)).data_ptr())
             a.rows, a.top = buf._max_replay_buffer_size, buf._top
+            # a rollout that ends in the ring's last row also leaves V(next_obs) of that row: the epoch's bootstrap value
+            boot = (buf._top + n_steps) % buf._max_replay_buffer_size == 0 and n_steps > 0
+            if boot:
+                if getattr(buf, "_boot", None) is None or buf._boot.shape[0] != N:
+                    buf._boot = torch.empty(N, 1, device=env.device)
+                a.boot_values = buf._boot.data_ptr()
         else:
             a.rows, a.top = 1, 0
         a.N, a.n_steps = N, n_steps
@@ -267,10 +273,21 @@ class VecOnPolicyCollector(VecCollector):
         a.epoch_reward, a.ep_count, a.ep_log = (self._epoch_reward.data_ptr(), self._ep_count.data_ptr(),
                                                 self._ep_log.data_ptr())
         a.ep_cap, a.step0 = self.EP_LOG_CAP, 0
-        self._clear_header()
+        nxt = self._clear_header(swap=True)                            # (may switch headers: read the pointers after it)
+        a.epoch_reward, a.ep_count = self._epoch_reward.data_ptr(), self._ep_count.data_ptr()
+        a.clear_header = nxt.data_ptr()
+        # both headers + the speculative head of the episode log are written to their page-locked twin by the value pass
+        # (train_one_epoch then needs no copy command behind the launch)
+        self._published = False
+        if store and publish and self._blob_host is not None:
+            words = 8 + 3 * self.SPECULATIVE_ROWS
+            a.publish_dst, a.publish_src, a.publish_words = self._blob_host.data_ptr(), self._blob.data_ptr(), words
+            self._published = True
         _C.rollout(a, env.device)
+        self._idle_hdr_clean = True
         if store:
             buf._advance(n_steps)
+            buf._boot_fresh = bool(boot)
             # log pi_old written by the kernel covers the whole ring only for a full-ring launch
             buf._old_logp_fresh = (n_steps == buf._max_replay_buffer_size)
 
@@ -370,8 +387,8 @@ class VecOnPolicyCollector(VecCollector):
         # the steps) run it eagerly on their block of the global draw
         capture = os.environ.get("TRL_NO_GRAPH") != "1" and dist.world_size() == 1
         ob = torch.as_tensor(self.current_ob).to(device=env.device, dtype=torch.float32).contiguous()
-        self._clear_header()
         if not graphable:
+            self._clear_header()
             noise = self._host_noise(n_steps, env) if self.noise_mode == "host" else None
             for t in range(n_steps):
                 ob = self._step_launches(env, ob, True, False, None if noise is None else noise[t], t)
@@ -379,9 +396,10 @@ class VecOnPolicyCollector(VecCollector):
         else:
             st = getattr(self, "_roll_graph", None)
             if st is None or st["key"] != (n_steps, env.env_nums):
-                st = self._roll_graph = {"key": (n_steps, env.env_nums), "graph": None, "seen": False,
+                st = self._roll_graph = {"key": (n_steps, env.env_nums), "graph": None, "seen": False, "hdr": self._hdr_i,
                                          "ob0": torch.empty(env.env_nums, D, device=env.device),
                                          "noise": torch.empty(n_steps, env.env_nums, A, device=env.device), "out": None}
+            self._clear_header(index=st["hdr"])                           # (a captured sequence carries its header's address)
             st["ob0"].copy_(ob)
             if dist.world_size() == 1:
                 _C.philox_normal(st["noise"], self._noise_seed, self.global_step)
@@ -422,7 +440,7 @@ class VecOnPolicyCollector(VecCollector):
                 return self._rollout_per_step(n_steps)
             ob = torch.as_tensor(self.current_ob).to(device=self.env.device, dtype=torch.float32).contiguous().clone()
             noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
-            self._launch(self.env, n_steps, True, False, noise, policy_ob=ob)
+            self._launch(self.env, n_steps, True, False, noise, policy_ob=ob, publish=True)
             self.global_step += n_steps
             self.current_ob = ob
             self._check_rendezvous = True                       # read with the epoch header (no sync here)
@@ -435,7 +453,7 @@ class VecOnPolicyCollector(VecCollector):
             noise, slot = self._prefetcher.take(n_steps, self.env.env_nums, self._dims[1], stream)
         else:
             noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
-        self._launch(self.env, n_steps, True, False, noise)
+        self._launch(self.env, n_steps, True, False, noise, publish=True)
         self.global_step += n_steps
         self.current_ob = self.env.cur_obs
 

@@ -56,6 +56,9 @@ struct RolloutDev {
   int tanh_action, deterministic, store;
   // running observation normaliser (NORM instantiation only)
   double* norm_state; float* policy_obs; double* norm_ws; float norm_clip; int norm_update, norm_partial_reset;
+  double* clear_hdr;          // 16 bytes zeroed by the launch (the next launch's header), or NULL
+  float* boot;                // (N) V(next_obs) of the last stored step, written by the value pass, or NULL
+  uint32_t* pub_dst; const uint32_t* pub_src; int64_t pub_words;     // copied to host memory by the value pass
 };
 
 // ---- grid-wide exchange between the (always co-resident) rollout workgroups ----
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   const float* gp = a.pf_params;
   const bool has_lo = g < A, has_hi = 4 + g < A;            // the lane's two action dims: g and 4 + g
   const int o_lo = has_lo ? g : 0, o_hi = has_hi ? 4 + g : 0;
+  if (blockIdx.x == 0 && tid == 0 && a.clear_hdr) { a.clear_hdr[0] = 0.0; a.clear_hdr[1] = 0.0; }   // the NEXT launch's header
 
   // ---- one-time setup: biases / logstd to LDS, this wave's weight slices to registers ----
   for (int e = tid; e < H; e += RO_THREADS) { lds[S::O_B1 + e] = gp[FP::B1 + e]; lds[S::O_B2 + e] = gp[FP::B2 + e]; }
@@ -457,6 +461,8 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
 struct ValueDev {
   const float* vf_params; const float *obs, *next_obs; float *values, *rewards;
   int rows, top, N, n_steps; float discount;
+  float* boot;                // (N) or NULL: V(next_obs) of the last step's row
+  uint32_t* pub_dst; const uint32_t* pub_src; int64_t pub_words;     // epoch header + episode-log head -> page-locked host memory
 };
 
 template <int D, int H, int ACT>
@@ -523,6 +529,9 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_pass_kernel(ValueDev a) {
     return v + b3;
   };
 
+  // (posted writes into host memory, issued before the tiles: they complete under the pass)
+  for (int64_t e = (int64_t)blockIdx.x * VP_THREADS + tid; e < a.pub_words; e += (int64_t)gridDim.x * VP_THREADS)
+    a.pub_dst[e] = a.pub_src[e];
   const int64_t M = (int64_t)a.n_steps * a.N;
   const int64_t n_tiles = (M + 15) / 16;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
@@ -534,9 +543,11 @@ __global__ __launch_bounds__(VP_THREADS, 2) void value_pass_kernel(ValueDev a) {
     const float marker = ok ? a.values[cell] : 0.0f;
     const float v = forward(a.obs, cell, ok);
     if (ok && g == 0) a.values[cell] = v;
-    if (__ballot(marker != 0.0f) != 0ull) {
+    const bool last = ok && a.boot && t == a.n_steps - 1;              // the row the epoch's bootstrap value comes from
+    if (__ballot(marker != 0.0f || last) != 0ull) {
       const float v2 = forward(a.next_obs, cell, ok);
       if (ok && g == 0 && marker != 0.0f) a.rewards[cell] += a.discount * v2;
+      if (last && g == 0) a.boot[n] = v2;
     }
   }
 }
@@ -568,7 +579,8 @@ static int launch_rollout(const RolloutDev& d, hipStream_t s) {
   }
   TRL_LAUNCH_CHECK();
   if (d.store) {
-    ValueDev v{d.vf_params, d.obs, d.next_obs, d.values, d.rewards, d.rows, d.top, d.N, d.n_steps, d.discount};
+    ValueDev v{d.vf_params, d.obs, d.next_obs, d.values, d.rewards, d.rows, d.top, d.N, d.n_steps, d.discount, d.boot,
+               d.pub_dst, d.pub_src, d.pub_words};
     const int64_t n_tiles = ((int64_t)d.n_steps * d.N + 15) / 16;
     const int grid = (int)(n_tiles / 4 + 1 < 512 ? n_tiles / 4 + 1 : 512);
     hipLaunchKernelGGL((value_pass_kernel<D, H, ACT>), dim3(grid), dim3(VP_THREADS), 0, s, v);
@@ -603,6 +615,13 @@ extern "C" int trl_rollout_synth_f32(const trl_rollout_t* p, void* stream) {
   d.step0 = p->step0; d.tanh_action = p->tanh_action; d.deterministic = p->deterministic; d.store = all_ring ? 1 : 0;
   d.norm_state = p->norm_state; d.policy_obs = p->policy_obs; d.norm_ws = p->norm_workspace; d.norm_clip = p->norm_clip;
   d.norm_update = p->norm_update; d.norm_partial_reset = p->normalize_partial_reset;
+  d.clear_hdr = p->clear_header; d.boot = all_ring ? p->boot_values : nullptr;
+  TRL_REQUIRE(p->publish_words >= 0 && (!p->publish_words || (p->publish_dst && p->publish_src && all_ring)) &&
+              ((reinterpret_cast<uintptr_t>(p->publish_dst) | reinterpret_cast<uintptr_t>(p->publish_src)) & 3) == 0,
+              "publish: needs ring tensors, non-null 4-byte aligned pointers");
+  d.pub_dst = (uint32_t*)p->publish_dst; d.pub_src = (const uint32_t*)p->publish_src; d.pub_words = p->publish_words;
+  TRL_REQUIRE(!p->clear_header || (p->clear_header != p->epoch_reward && (void*)p->clear_header != (void*)p->ep_count),
+              "clear_header must not be the header this launch accumulates into");
   TRL_REQUIRE(!p->norm_state || (p->policy_obs && p->norm_workspace), "normaliser needs policy_obs and its workspace");
   hipStream_t s = (hipStream_t)stream;
   if (p->D == 17 && p->H == 64 && p->A == 6) {

@@ -60,6 +60,7 @@ class BaseReplayBuffer:
         pass
 
     def _advance(self, steps=1):
+        self._boot_fresh = False                                         # (a fused rollout sets it again after its advance)
         self._top = (self._top + steps) % self._max_replay_buffer_size
         self._size = min(self._size + steps, self._max_replay_buffer_size)
 
