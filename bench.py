@@ -49,8 +49,10 @@ class CountingLogger:
     def add_update_infos_later(self, resolve):
         self._later.append(resolve)
 
-    def drain(self):
-        later, self._later = self._later, []
+    def drain(self, leave=0):
+        """leave = 1: everything but the update launched last (whose statistics are still being produced)."""
+        cut = max(len(self._later) - leave, 0)
+        later, self._later = self._later[:cut], self._later[cut:]
         for resolve in later:
             self.updates += len(resolve())
 
@@ -94,9 +96,9 @@ def iteration(agent, col, epoch):
     Logger (the dicts are taken when the next log row needs them): the update is launched, and its 40 info dicts are read
     and assembled while the NEXT rollout runs on the device instead of while the device idles."""
     collected = col.train_one_epoch()
-    agent.logger.drain()                          # the previous update's statistics, read while this rollout runs
     agent.current_epoch = epoch
     agent.update_per_epoch()                      # launched; its statistics are read in the next iteration (or at the end)
+    agent.logger.drain(leave=1)                   # the PREVIOUS update's statistics, assembled while this rollout runs
     return len(collected["train_rewards"]), collected["train_epoch_reward"]   # consumed where RLAlgo.train consumes it
 
 

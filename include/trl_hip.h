@@ -175,8 +175,29 @@ typedef struct trl_rollout_t {
    * written in place -- by the value pass: the epoch header and the head of the episode log reach the host without a
    * copy command behind the launch.  Only with ring tensors; the words are final when the call's launches have completed. */
   void* publish_dst; const void* publish_src; int64_t publish_words;
+  /* noise_flag non-NULL: `noise` is being filled by trl_stage_h2d_f32 on ANOTHER stream; the launch starts its steps
+   * only once *noise_flag == noise_stamp (device-scope loads; bounded wait -- on expiry epoch_reward is set to NaN).
+   * No stream dependency is needed between the staging launch and this one. */
+  const uint32_t* noise_flag; uint32_t noise_stamp;
+  /* stage_n != 0: a few EXTRA workgroups of this launch move the NEXT rollout's noise block -- stage_n floats
+   * (n % 4 == 0) from page-locked host memory stage_src to the device buffer stage_dst -- while the rollout's own
+   * workgroups (half the chip) step the envs: the transfer shares the device with nothing that is sensitive to it.
+   * They start once the host has published *stage_ready == stage_job (page-locked word, written after the block is
+   * complete; they wait ~30 us for it and otherwise leave without a trace: a host that is not running ahead of the device
+   * has not drawn the block yet and stages it itself later), and when the block is in device memory
+   * they set stage_state[0] = stage_job (device memory {stamp, arrival counter}, zeroed by the caller; the next launch's
+   * noise_flag / noise_stamp) and *stage_ack = stage_job (page-locked: the host learns that the block was staged).
+   * Not with a running observation normaliser. */
+  const float* stage_src; float* stage_dst; int64_t stage_n;
+  const uint32_t* stage_ready; uint32_t stage_job; uint32_t* stage_state; uint32_t* stage_ack;
 } trl_rollout_t;
 int trl_rollout_synth_f32(const trl_rollout_t* args, void* stream);
+/* Page-locked host block -> device buffer by a KERNEL (the device reads host memory in place), meant for a stream of
+ * its own next to the one that computes: n floats (n % 4 == 0, 16-byte aligned pointers); when every workgroup's part is
+ * in device memory, state[0] = stamp is stored with device scope -- what a consumer launched on another stream polls
+ * (trl_rollout_t.noise_flag) instead of a stream-to-stream event dependency (which costs sporadic multi-millisecond host
+ * stalls on this runtime).  state: 2 x uint32 of device memory {stamp, arrival counter}, zeroed once by the caller. */
+int trl_stage_h2d_f32(const float* host_src, float* dev_dst, int64_t n, uint32_t* state, uint32_t stamp, void* stream);
 int trl_rollout_norm_workspace(int N);
 int trl_rollout_norm_max_envs(int D, int H, int A, int act);
 

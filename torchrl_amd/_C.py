@@ -71,6 +71,9 @@ class RolloutArgs(C.Structure):
         ("norm_clip", C.c_float), ("norm_update", C.c_int), ("normalize_partial_reset", C.c_int),
         ("clear_header", C.c_void_p), ("boot_values", C.c_void_p),
         ("publish_dst", C.c_void_p), ("publish_src", C.c_void_p), ("publish_words", C.c_int64),
+        ("noise_flag", C.c_void_p), ("noise_stamp", C.c_uint32),
+        ("stage_src", C.c_void_p), ("stage_dst", C.c_void_p), ("stage_n", C.c_int64),
+        ("stage_ready", C.c_void_p), ("stage_job", C.c_uint32), ("stage_state", C.c_void_p), ("stage_ack", C.c_void_p),
     ]
 
 
@@ -117,6 +120,7 @@ SIGNATURES = {
                                            C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
+    "trl_stage_h2d_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_mlp2_forward_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_minibatch_grad_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p]),
@@ -421,6 +425,16 @@ def adv_stats(advs, row_idx_2d, raw_out):
                                   dev_ptr(raw_out, torch.float64, "raw_out"), stream_ptr(advs.device)),
           "trl_adv_stats_f64")
     return raw_out
+
+
+def stage_h2d(host, dev, state, stamp, stream):
+    """`host` (page-locked float32) -> `dev` by a kernel on `stream` (a torch.cuda.Stream); state[0] = stamp (int32 device
+    tensor of 2, zeroed once) tells consumers on other streams that the block has landed."""
+    if not (host.is_pinned() and host.dtype == torch.float32 and host.is_contiguous() and host.numel() == dev.numel()):
+        raise TrlError("stage_h2d: a contiguous page-locked float32 source of the destination's size is required")
+    check(lib().trl_stage_h2d_f32(C.c_void_p(host.data_ptr()), dev_ptr(dev, name="dev"), host.numel(),
+                                  dev_ptr(state, torch.int32, "state"), int(stamp) & 0xFFFFFFFF,
+                                  C.c_void_p(stream.cuda_stream)), "trl_stage_h2d_f32")
 
 
 def ppo_epoch_prologue_workspace(n_mb, device):

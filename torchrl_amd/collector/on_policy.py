@@ -39,8 +39,11 @@ class _NoisePrefetcher:
     `take(T, N, A)` returns the device tensor of this rollout's draws and immediately starts the draw of the NEXT block of
     the same shape: a worker thread fills a page-locked buffer with `torch.randn(out=...)` (the op releases the
     interpreter lock, and the block is cut into segments drawn by several threads at once: ~1 ms of host time for
-    128 x 2048 x 6 instead of ~3, which would otherwise sit between two iterations); the NEXT `take` copies it to one of two
-    device buffers on the rollout's stream (the worker threads never call into the HIP runtime).  The
+    128 x 2048 x 6 instead of ~3, which would otherwise sit between two iterations); the NEXT `take` moves it to one of two
+    device buffers (the worker threads never call into the HIP runtime) -- by a staging KERNEL on a stream of its own
+    that reads the page-locked block in place and stamps a flag in device memory when it has landed; the rollout kernel
+    polls that flag (`trl_rollout_t.noise_flag`), so the two streams share no event: the 0.15 ms transfer runs under the
+    update that precedes the rollout.  (`staged = False`: a copy command on the rollout's own stream, in front of it.)  The
     draw depends on nothing the GPU produces, so the stream of values is the un-prefetched one, bit for bit.
 
     Guard: the generator state right after the prefetched draw is remembered; if the state found at `take` differs --
@@ -56,6 +59,16 @@ class _NoisePrefetcher:
         self._job = None                                   # dict(thread, shape, slot, state0, state1, event, error)
         self._host, self._dev = {}, {}
         self._free = {}                                    # per slot: the event of its last upload (page-locked buffer reusable)
+        self._consumed = {}                                # per slot: the event behind the rollout that read the device buffer
+        self._state, self._stamp = {}, {}                  # per slot: {stamp, arrival counter} on the device / last stamp
+        self._side = None
+        self.staged = True
+        # carry = True: the block is moved to the device by a few extra workgroups of the PREVIOUS rollout launch
+        # (trl_rollout_t.stage_*): per slot a page-locked {ready, ack} pair and a device {stamp, counter} pair
+        self.carry = True
+        self._ctl, self._stg_state = {}, {}
+        self._carrier = None                               # dict(id, key, event): the launch that carries the pending block
+        self._ids = 0
         self._slot = 0
 
     def _buffers(self, shape, slot):
@@ -75,17 +88,41 @@ class _NoisePrefetcher:
         return slot
 
     def _upload(self, shape, slot, stream):
-        """Page-locked block -> device, on the rollout's own stream right in front of it (0.13 ms for cfg 2's 6.3 MB).
-        A side stream would hide that copy under the running update -- built and measured in round 3: the iteration then
-        runs at the device-noise speed, but the cross-stream dependency costs a 5-50 ms host stall once every ~100
-        iterations on this runtime (none in 800 iterations with the copy on the rollout's stream;
-        profiles/r03_grad_kernel_experiments.txt)."""
+        """Page-locked block -> device.  Returns (device tensor, gate): gate = (flag tensor, stamp) the rollout has to
+        wait for, or None when the copy sits on the rollout's own stream in front of it.
+        Staged (default): `trl_stage_h2d_f32` on a side stream, no event between the streams -- an event dependency there
+        costs a 5-50 ms host stall once every ~100 iterations on this runtime (measured in round 3,
+        profiles/r03_grad_kernel_experiments.txt), which is why the first version of the prefetch kept the copy on the
+        rollout's stream and paid its 0.13 ms per iteration."""
         host, dev = self._buffers(shape, slot)
-        dev.copy_(host.view(shape), non_blocking=True)
-        ev = self._free.get((shape, slot)) or torch.cuda.Event()
+        key = (shape, slot)
+        if not self.staged:
+            dev.copy_(host.view(shape), non_blocking=True)
+            ev = self._free.get(key) or torch.cuda.Event()
+            ev.record(stream)
+            self._free[key] = ev
+            return dev, None
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        used = self._consumed.get(key)                      # the rollout that read this device buffer two blocks ago
+        if used is not None and not used.query():
+            used.synchronize()
+        if key not in self._state:
+            self._state[key] = torch.zeros(2, dtype=torch.int32, device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()          # (zeroed before the side stream's first launch)
+        stamp = self._stamp[key] = (self._stamp.get(key, 0) % 0x7FFFFFF0) + 1
+        _C.stage_h2d(host, dev.view(-1), self._state[key], stamp, self._side)
+        ev = self._free.get(key) or torch.cuda.Event()
+        ev.record(self._side)                               # the page-locked buffer is reusable behind the staging launch
+        self._free[key] = ev
+        return dev, (self._state[key], stamp)
+
+    def consumed(self, shape, slot, stream):
+        """Called behind the rollout that read the block: its device buffer may be refilled once that launch has run."""
+        key = (tuple(int(v) for v in shape), slot)
+        ev = self._consumed.get(key) or torch.cuda.Event()
         ev.record(stream)
-        self._free[(shape, slot)] = ev
-        return dev
+        self._consumed[key] = ev
 
     def _worker(self):
         """One long-lived thread (no thread start per rollout): takes a job, draws, signals."""
@@ -96,6 +133,9 @@ class _NoisePrefetcher:
             try:
                 job["out"] = self._draw_into(job["shape"], job["slot"])
                 job["state1"] = torch.get_rng_state()
+                ctl = self._ctl.get((job["shape"], job["slot"]))
+                if ctl is not None:
+                    ctl[0] = job["id"]                      # the block is complete: the stagers of the carrying launch may go
             except BaseException as exc:                    # noqa: BLE001 -- reported by the consumer
                 job["error"] = exc
             job["done"].set()
@@ -113,8 +153,12 @@ class _NoisePrefetcher:
         free = self._free.get((shape, slot))
         if free is not None and not free.query():           # the upload that read this page-locked buffer two blocks ago
             free.synchronize()                              # (long finished; checked here so that the worker never waits on HIP)
+        self._ids = self._ids % 0x7FFFFFF0 + 1
+        if self.staged and self.carry and (shape, slot) not in self._ctl:
+            self._ctl[(shape, slot)] = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._stg_state[(shape, slot)] = torch.zeros(2, dtype=torch.int32, device=self.device)
         job = {"shape": shape, "slot": slot, "state0": torch.get_rng_state(), "state1": None, "out": None, "error": None,
-               "done": threading.Event()}
+               "done": threading.Event(), "id": self._ids}
         self._job = job
         self._queue.put(job)
 
@@ -126,7 +170,35 @@ class _NoisePrefetcher:
         if rewind and job["state1"] is not None and torch.equal(torch.get_rng_state(), job["state1"]):
             torch.set_rng_state(job["state0"])             # nobody drew after the speculative block: give it back
 
+    def _carried_ok(self, job):
+        """Did the launch that carried `job`'s block stage it?  (Its stagers acknowledge in page-locked memory.)"""
+        c = self._carrier
+        if c is None or c["id"] != job["id"]:
+            return False
+        ctl = self._ctl[c["key"]]
+        if int(ctl[1]) != job["id"]:
+            c["event"].synchronize()                        # the carrying launch has run (normally long ago)
+            if int(ctl[1]) != job["id"]:                    # its stagers gave up (the block was published too late):
+                self._stg_state[c["key"]].zero_()           # their arrival counter may be half way
+                return False
+        return True
+
+    def _settle_carrier(self):
+        """No stager of an abandoned block may still be writing when the buffer is refilled another way."""
+        c, self._carrier = self._carrier, None
+        if c is not None:
+            c["event"].synchronize()
+
+    def carried(self, request, stream):
+        """Called behind the rollout launch that was handed `request` (see `take`)."""
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._carrier = {"id": request["id"], "key": request["key"], "event": ev}
+        self._free[request["key"]] = ev                     # (that launch reads the page-locked block)
+
     def take(self, n_steps, n, a_dim, stream):
+        """(device block, slot, gate, request): gate = (flag tensor, stamp) the rollout must wait for (None: the block is
+        stream-ordered in front of it); request (or None) = what the rollout launch shall stage for the NEXT call."""
         shape = (int(n_steps), int(n), int(a_dim))
         job = self._job
         out = None
@@ -139,16 +211,28 @@ class _NoisePrefetcher:
                 out = used = job["slot"]
             elif torch.equal(torch.get_rng_state(), job["state1"]):
                 torch.set_rng_state(job["state0"])         # other shape, untouched generator: undo the speculative draw
-        if out is None:                                     # first call / generator touched in between: draw in place
-            used = self._slot
-            self._slot ^= 1
-            free = self._free.get((shape, used))
-            if free is not None:
-                free.synchronize()
-            self._draw_into(shape, used)
-        dev = self._upload(shape, used, stream)
+        if out is not None and self._carried_ok(job):
+            dev, gate = self._buffers(shape, used)[1], (self._stg_state[(shape, used)], job["id"])
+            self._carrier = None
+        else:
+            self._settle_carrier()
+            if out is None:                                 # first call / generator touched in between: draw in place
+                used = self._slot
+                self._slot ^= 1
+                free = self._free.get((shape, used))
+                if free is not None:
+                    free.synchronize()
+                self._draw_into(shape, used)
+            dev, gate = self._upload(shape, used, stream)
         self._start(shape)                                  # the next block, under this iteration's device work
-        return dev, used
+        request = None
+        nxt = self._job
+        if self.staged and self.carry and nxt is not None:
+            key = (shape, nxt["slot"])
+            host, ndev = self._buffers(shape, nxt["slot"])
+            request = {"id": nxt["id"], "key": key, "src": host, "dst": ndev, "ctl": self._ctl[key],
+                       "state": self._stg_state[key]}
+        return dev, used, gate, request
 
     def close(self):
         self._drop(rewind=True)
@@ -226,7 +310,8 @@ class VecOnPolicyCollector(VecCollector):
             self._norm_cap = _C.lib().trl_rollout_norm_max_envs(D, H, A, act)
         return (not update) or env.env_nums <= self._norm_cap
 
-    def _launch(self, env, n_steps, store, deterministic, noise, max_frames=None, policy_ob=None, publish=False):
+    def _launch(self, env, n_steps, store, deterministic, noise, max_frames=None, policy_ob=None, publish=False,
+                noise_gate=None, stage=None):
         D, H, A, act = self._spec
         buf = self.replay_buffer
         a = _C.RolloutArgs()
@@ -250,6 +335,12 @@ class VecOnPolicyCollector(VecCollector):
         a.cur_obs, a.t_env, a.cur_step = env.cur_obs.data_ptr(), env.t_env.data_ptr(), env.cur_step.data_ptr()
         a.episode_idx, a.ep_return = env.episode_idx.data_ptr(), env.ep_return.data_ptr()
         a.noise = noise.data_ptr() if noise is not None else None
+        if noise is not None and noise_gate is not None:               # staged on another stream: the kernel waits for the stamp
+            a.noise_flag, a.noise_stamp = noise_gate[0].data_ptr(), int(noise_gate[1])
+        if stage is not None:                                          # the NEXT rollout's block rides in on this launch
+            a.stage_src, a.stage_dst, a.stage_n = stage["src"].data_ptr(), stage["dst"].data_ptr(), stage["src"].numel()
+            a.stage_ready, a.stage_ack = stage["ctl"].data_ptr(), stage["ctl"].data_ptr() + 4
+            a.stage_job, a.stage_state = int(stage["id"]), stage["state"].data_ptr()
         a.noise_step0 = self.global_step
         a.deterministic = int(deterministic)
         N = env.env_nums
@@ -450,10 +541,15 @@ class VecOnPolicyCollector(VecCollector):
             if self._prefetcher is None:
                 self._prefetcher = _NoisePrefetcher(self.env.device)
             stream = torch.cuda.current_stream(self.env.device)
-            noise, slot = self._prefetcher.take(n_steps, self.env.env_nums, self._dims[1], stream)
+            noise, slot, gate, request = self._prefetcher.take(n_steps, self.env.env_nums, self._dims[1], stream)
         else:
-            noise = self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None
-        self._launch(self.env, n_steps, True, False, noise, publish=True)
+            noise, gate, request = (self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None), None, None
+        self._launch(self.env, n_steps, True, False, noise, publish=True, noise_gate=gate, stage=request)
+        if slot is not None:
+            stream = torch.cuda.current_stream(self.env.device)
+            self._prefetcher.consumed(noise.shape, slot, stream)
+            if request is not None:
+                self._prefetcher.carried(request, stream)
         self.global_step += n_steps
         self.current_ob = self.env.cur_obs
 

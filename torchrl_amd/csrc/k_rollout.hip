@@ -29,6 +29,7 @@
 // HBM traffic per env-step: 176 B algorithmic (obs 68 + next_obs 68 + act 24 +
 // value/reward/terminal/time_limit 16; the obs read is only at launch) + 4 B
 // old_logp (+24 B if host noise is supplied) + 76 B re-read / marker traffic of the value pass.
+#include <algorithm>
 #include "trl_common.h"
 #include "trl_mlp.h"
 #include "trl_philox.h"
@@ -59,7 +60,12 @@ struct RolloutDev {
   double* clear_hdr;          // 16 bytes zeroed by the launch (the next launch's header), or NULL
   float* boot;                // (N) V(next_obs) of the last stored step, written by the value pass, or NULL
   uint32_t* pub_dst; const uint32_t* pub_src; int64_t pub_words;     // copied to host memory by the value pass
+  const uint32_t* noise_flag; uint32_t noise_stamp;                   // noise staged on another stream: wait for the stamp
+  // workgroups [n_ro_wg, gridDim.x) stage the NEXT rollout's noise block (see trl_rollout_t.stage_*)
+  int n_ro_wg; const f32x4* stg_src; unsigned long long* stg_dst; int64_t stg_n4;
+  const uint32_t* stg_ready; uint32_t stg_job; uint32_t* stg_state; uint32_t* stg_ack;
 };
+#define RO_STAGERS 16
 
 // ---- grid-wide exchange between the (always co-resident) rollout workgroups ----
 // No ticket counter: a workgroup publishes its partials, waits for the stores to be acknowledged and then
@@ -82,11 +88,64 @@ template <int D, int H, int A> struct RoShape {
                        O_EPS = O_HP + 4 * 8 * 16, LDS_FLOATS = O_EPS + RO_NB * 8 * 16;
 };
 
+// Host block -> device buffer with device-scope stores (past the per-XCD L2: nothing to write back or invalidate when the
+// stamp is published), four host reads in flight per thread; the last of `wgs` workgroups to finish resets the arrival
+// counter and publishes the stamp (and, if asked, tells the host).
+__device__ __forceinline__ void stage_block(const f32x4* __restrict__ src, unsigned long long* __restrict__ dst, int64_t n4,
+                                            int wg, int wgs, int threads, uint32_t* __restrict__ state, uint32_t stamp,
+                                            uint32_t* __restrict__ host_ack) {
+  const int64_t stride = (int64_t)wgs * threads;
+  for (int64_t e = (int64_t)wg * threads + threadIdx.x; e < n4; e += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (e + q * stride < n4) v[q] = src[e + q * stride];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (e + q * stride < n4) {
+        const unsigned long long lo = ((unsigned long long)__float_as_uint(v[q][1]) << 32) | __float_as_uint(v[q][0]);
+        const unsigned long long hi = ((unsigned long long)__float_as_uint(v[q][3]) << 32) | __float_as_uint(v[q][2]);
+        __hip_atomic_store(dst + 2 * (e + q * stride), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 2 * (e + q * stride) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's stores are acknowledged ...
+  __syncthreads();                                             // ... and so are the workgroup's
+  if (threadIdx.x == 0) {
+    const unsigned before = __hip_atomic_fetch_add(state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == (unsigned)wgs - 1) {                         // the last workgroup to finish publishes the stamp
+      __hip_atomic_store(state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(state, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (host_ack) __hip_atomic_store(host_ack, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 template <int D, int H, int A, int ACT, bool NORM>
 __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   using S = RoShape<D, H, A>;
   using FP = MlpFlat<D, H, A>;
   __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
+  if (!NORM && (int)blockIdx.x >= a.n_ro_wg) {
+    // ---- a stager: the NEXT rollout's noise block, host -> device, next to this rollout's own workgroups ----
+    __shared__ int s_go;
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = wall_clock64();            // 100 MHz
+      int go = 1;
+      while (__hip_atomic_load(a.stg_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.stg_job) {
+        __builtin_amdgcn_s_sleep(64);
+        // 30 us.  A host that runs ahead of the device published the block long before this launch started; one that does
+        // not is still drawing it (~1 ms), and the rollout must not wait for that -- the stagers leave, the host sees no
+        // acknowledgement and stages the block itself under the update (trl_stage_h2d_f32).
+        if (wall_clock64() - t0 > 3000ull) { go = 0; break; }
+      }
+      s_go = go;
+    }
+    __syncthreads();
+    if (s_go)
+      stage_block(a.stg_src, a.stg_dst, a.stg_n4, (int)blockIdx.x - a.n_ro_wg, (int)gridDim.x - a.n_ro_wg, RO_THREADS,
+                  a.stg_state, a.stg_job, a.stg_ack);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int mo = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it stay scalar
   const int j = lane & 15, g = lane >> 4, i = j;
@@ -96,6 +155,20 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   const bool has_lo = g < A, has_hi = 4 + g < A;            // the lane's two action dims: g and 4 + g
   const int o_lo = has_lo ? g : 0, o_hi = has_hi ? 4 + g : 0;
   if (blockIdx.x == 0 && tid == 0 && a.clear_hdr) { a.clear_hdr[0] = 0.0; a.clear_hdr[1] = 0.0; }   // the NEXT launch's header
+  if (a.noise_flag && tid == 0) {
+    // The noise block is staged by a kernel on another stream (trl_stage_h2d_f32), normally long before this launch
+    // starts -- then its lines cannot be in this XCD's L2 (invalidated at the launch boundary, not read since).  If the
+    // stamp is not there yet, wait for it and then drop whatever the wait may have pulled in.
+    unsigned spins = 0;
+    while (__hip_atomic_load(a.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.noise_stamp) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++spins > (1u << 24)) {                              // ~seconds: the staging launch never ran
+        if (blockIdx.x == 0 && a.epoch_reward) a.epoch_reward[0] = __builtin_nan("");
+        break;
+      }
+    }
+    if (spins) __threadfence();
+  }
 
   // ---- one-time setup: biases / logstd to LDS, this wave's weight slices to registers ----
   for (int e = tid; e < H; e += RO_THREADS) { lds[S::O_B1 + e] = gp[FP::B1 + e]; lds[S::O_B2 + e] = gp[FP::B2 + e]; }
@@ -575,7 +648,9 @@ static int launch_rollout(const RolloutDev& d, hipStream_t s) {
     }
     hipLaunchKernelGGL((rollout_kernel<D, H, A, ACT, true>), dim3(n_wg), dim3(RO_THREADS), 0, s, d);
   } else {
-    hipLaunchKernelGGL((rollout_kernel<D, H, A, ACT, false>), dim3(n_wg), dim3(RO_THREADS), 0, s, d);
+    RolloutDev e = d;
+    e.n_ro_wg = n_wg;
+    hipLaunchKernelGGL((rollout_kernel<D, H, A, ACT, false>), dim3(n_wg + (e.stg_n4 ? RO_STAGERS : 0)), dim3(RO_THREADS), 0, s, e);
   }
   TRL_LAUNCH_CHECK();
   if (d.store) {
@@ -586,6 +661,25 @@ static int launch_rollout(const RolloutDev& d, hipStream_t s) {
     hipLaunchKernelGGL((value_pass_kernel<D, H, ACT>), dim3(grid), dim3(VP_THREADS), 0, s, v);
     TRL_LAUNCH_CHECK();
   }
+  return TRL_OK;
+}
+
+// ---- page-locked host block -> device buffer by a kernel, for a stream of its own ----
+__global__ __launch_bounds__(256) void stage_h2d_kernel(const f32x4* __restrict__ src, unsigned long long* __restrict__ dst,
+                                                        int64_t n4, uint32_t* __restrict__ state, uint32_t stamp) {
+  stage_block(src, dst, n4, (int)blockIdx.x, (int)gridDim.x, 256, state, stamp, nullptr);
+}
+extern "C" int trl_stage_h2d_f32(const float* host_src, float* dev_dst, int64_t n, uint32_t* state, uint32_t stamp,
+                                 void* stream) {
+  TRL_REQUIRE(n >= 0 && (n & 3) == 0, "stage_h2d: n must be a multiple of 4");
+  TRL_REQUIRE(state, "stage_h2d: null state");
+  TRL_REQUIRE(!n || (host_src && dev_dst && ((reinterpret_cast<uintptr_t>(host_src) | reinterpret_cast<uintptr_t>(dev_dst)) & 15) == 0),
+              "stage_h2d: null / misaligned pointer");
+  // few workgroups: the transfer is paced by the host link (~50 GB/s), and they share the chip with the other stream's work
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(16, (n / 4 + 1023) / 1024));
+  hipLaunchKernelGGL(stage_h2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(host_src),
+                     reinterpret_cast<unsigned long long*>(dev_dst), n / 4, state, stamp);
+  TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
 
@@ -620,6 +714,17 @@ extern "C" int trl_rollout_synth_f32(const trl_rollout_t* p, void* stream) {
               ((reinterpret_cast<uintptr_t>(p->publish_dst) | reinterpret_cast<uintptr_t>(p->publish_src)) & 3) == 0,
               "publish: needs ring tensors, non-null 4-byte aligned pointers");
   d.pub_dst = (uint32_t*)p->publish_dst; d.pub_src = (const uint32_t*)p->publish_src; d.pub_words = p->publish_words;
+  d.noise_flag = p->noise ? p->noise_flag : nullptr; d.noise_stamp = p->noise_stamp;
+  d.n_ro_wg = 0; d.stg_n4 = 0;
+  if (p->stage_n) {
+    TRL_REQUIRE(p->stage_n > 0 && (p->stage_n & 3) == 0 && p->stage_src && p->stage_dst && p->stage_ready && p->stage_state &&
+                p->stage_ack && !p->norm_state, "stage: n % 4 == 0, non-null pointers, no observation normaliser");
+    TRL_REQUIRE(((reinterpret_cast<uintptr_t>(p->stage_src) | reinterpret_cast<uintptr_t>(p->stage_dst)) & 15) == 0,
+                "stage: 16-byte aligned blocks");
+    d.stg_src = reinterpret_cast<const f32x4*>(p->stage_src); d.stg_dst = reinterpret_cast<unsigned long long*>(p->stage_dst);
+    d.stg_n4 = p->stage_n / 4; d.stg_ready = p->stage_ready; d.stg_job = p->stage_job; d.stg_state = p->stage_state;
+    d.stg_ack = p->stage_ack;
+  }
   TRL_REQUIRE(!p->clear_header || (p->clear_header != p->epoch_reward && (void*)p->clear_header != (void*)p->ep_count),
               "clear_header must not be the header this launch accumulates into");
   TRL_REQUIRE(!p->norm_state || (p->policy_obs && p->norm_workspace), "normaliser needs policy_obs and its workspace");
