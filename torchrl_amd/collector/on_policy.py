@@ -66,6 +66,8 @@ class _NoisePrefetcher:
         # carry = True: the block is moved to the device by a few extra workgroups of the PREVIOUS rollout launch
         # (trl_rollout_t.stage_*): per slot a page-locked {ready, ack} pair and a device {stamp, counter} pair
         self.carry = True
+        self.wait_for_draw = False                         # test aid: publish the next block BEFORE the carrying launch goes out
+        self.transport_counts = {"carried": 0, "staged": 0, "stream": 0}
         self._ctl, self._stg_state = {}, {}
         self._carrier = None                               # dict(id, key, event): the launch that carries the pending block
         self._ids = 0
@@ -214,6 +216,7 @@ class _NoisePrefetcher:
         if out is not None and self._carried_ok(job):
             dev, gate = self._buffers(shape, used)[1], (self._stg_state[(shape, used)], job["id"])
             self._carrier = None
+            self.transport_counts["carried"] += 1
         else:
             self._settle_carrier()
             if out is None:                                 # first call / generator touched in between: draw in place
@@ -224,9 +227,12 @@ class _NoisePrefetcher:
                     free.synchronize()
                 self._draw_into(shape, used)
             dev, gate = self._upload(shape, used, stream)
+            self.transport_counts["staged" if gate is not None else "stream"] += 1
         self._start(shape)                                  # the next block, under this iteration's device work
         request = None
         nxt = self._job
+        if self.wait_for_draw and nxt is not None:
+            nxt["done"].wait()
         if self.staged and self.carry and nxt is not None:
             key = (shape, nxt["slot"])
             host, ndev = self._buffers(shape, nxt["slot"])
