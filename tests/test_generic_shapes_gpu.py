@@ -180,9 +180,12 @@ def test_graph_replayed_per_step_rollout_equals_eager(monkeypatch):
     (17, 8, "tanh", True, False, 112),       # the full tile: 17 inputs, 8 actions
     (16, 6, "relu", True, False, 96),        # no 17th feature
     (2, 5, "tanh", True, True, 100),
+    (27, 8, "tanh", True, False, 112),       # Ant-sized: the wide tile (a second 16-feature group on the matrix pipe)
+    (18, 2, "relu", True, True, 100),        # one feature into the second group, ragged batch
+    (32, 6, "tanh", False, False, 96),       # the full wide tile
 ])
 def test_fused_ppo_update_at_other_input_and_action_sizes_vs_oracle(D, A, act, tanh_action, clipped, B, errlog):
-    """64-wide two-layer networks with any D in [2, 17], A in [1, 8] stay on the fused two-launch update
+    """64-wide two-layer networks with any D in [2, 32], A in [1, 8] stay on the fused two-launch update
     (trl_ppo_minibatch_grad_f32's runtime-dims instantiation + trl_ppo_reduce_adam_f32): three chained updates against
     the CPU oracle at the contract of the benchmark shape (scalars rel 1e-4 / abs 1e-5, post-step parameters abs 1e-6)."""
     from torchrl.algo import PPO

@@ -281,7 +281,7 @@ class VecOnPolicyCollector(VecCollector):
             raise _C.TrlError("policy / value input and output sizes %s do not match the env (%d obs, %d act)"
                               % (self._dims, self.env.obs_dim, self.env.act_dim))
         # the persistent rollout kernel and the fused 2-layer forward are instantiated for the benchmark shape
-        # (trl_mlp2_forward_supported); other shapes the fused UPDATE kernels carry (trl_ppo_partial_stride > 0: D <= 17,
+        # (trl_mlp2_forward_supported); other shapes the fused UPDATE kernels carry (trl_ppo_partial_stride > 0: D <= 32,
         # A <= 8, H = 64) are collected by the per-step launch sequence on the dense-layer kernels
         lib = _C.lib()
         mlp2 = (ps is not None and vs is not None and vs[:2] == ps[:2] and vs[2] == 1 and vs[3] == ps[3]

@@ -69,7 +69,7 @@ template <int D, int H, int A> struct PpoShape {
 #define LDW 68                                   // W2 operand copies: 64 + 4, ds_read_b128 rows
 
 template <int D, int H, int A> struct WvShape {
-  static_assert(H == 64 && D == 17 && A <= 8, "instantiated for D == 17, H == 64, A <= 8");
+  static_assert(H == 64 && (D == 17 || D == 32) && A <= 8, "instantiated for D == 17 / 32, H == 64, A <= 8");
   // shared: W2 (row-major) | W2^T | b1 | b2 ; per wave: H1^T | H2^T (later dZ1^T) | dZ2^T | dout^T[16]
   static constexpr int O_W2F = 0, O_W2B = H * LDW, O_B1 = 2 * H * LDW, O_B2 = O_B1 + H, O_SCR = O_B2 + H;
   static constexpr int O_H1 = 0, O_H2 = H * LDT, O_DZ2 = 2 * H * LDT, O_DO = 3 * H * LDT, WSCR = O_DO + 16 * LDT;
@@ -94,9 +94,14 @@ __device__ __forceinline__ float row_sum16(float v) {
 // the same 16 + 1-feature tile with the missing input features and outputs masked to zero where they are loaded, the flat
 // parameter offsets and row strides computed from the actual dims -- Hopper / Swimmer / Walker / Reacher-shaped tasks
 // (torchrl/networks/base.py:8-44 is shape-generic) stay on the two-launch path.
+// D = 32 (WIDE, RT only; a.D in [18, 32] -- Ant's 27 observations): input features 16..31 are a SECOND 16-wide k group of
+// the first layer (four more MFMA steps forward, a second accumulator tile per slice for dW1) instead of the single
+// 17th column that rides on the VALU.
 template <int D, int H, int A, int ACT, bool IS_PF, bool CONTIG, bool RT>
 __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
   using S = WvShape<D, H, A>;
+  constexpr bool WIDE = D > 17;                      // a second 16-feature group (features 16 .. 31) on the matrix pipe
+  static_assert(!WIDE || RT, "the wide tile exists as a runtime-dims instantiation only");
   const int Dr = RT ? a.D : D;                       // input features = row stride of obs and of W1
   const int O = IS_PF ? (RT ? a.A : A) : 1;          // outputs
   // offsets inside the flat parameter block for the actual dims (MlpFlat, trl_mlp.h)
@@ -125,6 +130,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   // sits next to the loads) and the minibatch row index TWO tiles ahead (the dependent load behind it is
   // then off the critical path): x operand (5), X^T for dW1 (4), loss inputs (6 / 2).
   float xq[5], xtq[4], lq[6];
+  float xq2[4], xtq2[4];                             // WIDE: features 16 + 4g + q of the x operand / feature 16 + j of X^T
   int tile = wg_in_net * WV_WAVES + wave;
   // ---- CONTIG (N % 16 == 0, hence B % 16 == 0: every tile is 16 consecutive envs of ONE time row, all samples valid) ----
   // The tile position (row, column tile) and the row's base addresses are wave-uniform: they live in scalar registers
@@ -135,15 +141,18 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   int64_t ridx1 = 0, ridx2 = 0;
   // which of the tile's input features exist (RT): features 4g + q of the lane's x operand, feature 16, and feature j of
   // the lane's X^T operand; a missing feature is read from an in-range address and replaced by zero when it is consumed
-  bool fv[4];
-  const bool f16 = !RT || Dr > 16, jv = !RT || i < Dr;
+  bool fv[4], fv2[4];
+  const bool f16 = !WIDE && (!RT || Dr > 16), jv = !RT || i < Dr, jv2 = WIDE && 16 + i < Dr;
   const unsigned ox16 = (unsigned)(j * Dr + (f16 ? 16 : 0)) * 4u, os = (unsigned)j * 4u;
-  unsigned oxq[4], oxt[4], oa_[4];
+  unsigned oxq[4], oxt[4], oa_[4], oxq2[4], oxt2[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     fv[q] = !RT || 4 * g + q < Dr;
+    fv2[q] = WIDE && 16 + 4 * g + q < Dr;
     oxq[q] = (unsigned)(j * Dr + (fv[q] ? 4 * g + q : 0)) * 4u;
     oxt[q] = (unsigned)((4 * g + q) * Dr + (jv ? i : 0)) * 4u;
+    oxq2[q] = (unsigned)(j * Dr + (fv2[q] ? 16 + 4 * g + q : 0)) * 4u;
+    oxt2[q] = (unsigned)((4 * g + q) * Dr + (jv2 ? 16 + i : 0)) * 4u;
     oa_[q] = (unsigned)(j * O + (4 * g + q < O ? 4 * g + q : 0)) * 4u;
   }
   auto ldb = [](const float* base, unsigned byte_off) -> float {
@@ -162,6 +171,10 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     xq[4] = ldb(ob, ox16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) xtq[q] = ldb(ob, oxt[q]);           // X[sample 4g + q][feature j]: B operand of the dW1 GEMM
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { xq2[q] = ldb(ob, oxq2[q]); xtq2[q] = ldb(ob, oxt2[q]); }
+    }
     if constexpr (IS_PF) {
       const float* ab = a.acts + cell0 * O;
 #pragma unroll
@@ -185,6 +198,10 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       const int sj = 4 * g + q;
       const int64_t pr = __shfl(p, sj, 64);
       xtq[q] = a.obs[(s0 + sj < B ? pr : 0) * Dr + (jv ? i : 0)];
+      if constexpr (WIDE) {
+        xq2[q] = a.obs[p * Dr + (fv2[q] ? 16 + 4 * g + q : 0)];
+        xtq2[q] = a.obs[(s0 + sj < B ? pr : 0) * Dr + (jv2 ? 16 + i : 0)];
+      }
     }
     if constexpr (IS_PF) {
 #pragma unroll
@@ -263,12 +280,17 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   for (int e = lane; e < 16 * LDT; e += 64) DOS[e] = 0.0f;       // dout rows >= O stay zero
   // register-resident A operands, lane (i, g): k index of MFMA step (slice sl, r) is feature 16 sl + 4 g + r
   float w1[4][5], w3h[4][4], w3t[4][4];
+  float w1b[4][4];                                   // WIDE: W1[row][16 + 4g + r]
 #pragma unroll
   for (int so = 0; so < 4; ++so) {
     const int row = 16 * so + i;
 #pragma unroll
     for (int r = 0; r < 4; ++r) w1[so][r] = fv[r] ? gp[F_W1 + row * Dr + (fv[r] ? 4 * g + r : 0)] : 0.0f;
     w1[so][4] = (g == 0 && f16) ? gp[F_W1 + row * Dr + (f16 ? 16 : 0)] : 0.0f;
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w1b[so][r] = fv2[r] ? gp[F_W1 + row * Dr + (fv2[r] ? 16 + 4 * g + r : 0)] : 0.0f;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if constexpr (IS_PF) {
@@ -312,11 +334,12 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 
   // ---- gradient accumulators ----
   f32x4 gW2[4][4], gW1[4], gW3[4];                  // MFMA tiles: dW2[f2 slice][f1 slice], dW1[f1 slice][k < 16], dW3
+  f32x4 gW1b[4];                                     // WIDE: dW1[f1 slice][16 <= k < 32]
   float gb1[4][4], gb2[4][4], gW1c[4][4];           // per-lane (own sample) partials: db1, db2, dW1[:, 16]
   float db3[4], dls[4], stv[7];
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
-    gW1[x] = gW3[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gW1[x] = gW3[x] = gW1b[x] = f32x4{0.f, 0.f, 0.f, 0.f};
     db3[x] = dls[x] = 0.0f;
 #pragma unroll
     for (int y = 0; y < 4; ++y) { gW2[x][y] = f32x4{0.f, 0.f, 0.f, 0.f}; gb1[x][y] = gb2[x][y] = gW1c[x][y] = 0.0f; }
@@ -328,12 +351,19 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
   for (; tile < n_tiles; tile += tile_stride) {
     const int s = tile * 16 + j;
     const bool valid = CONTIG ? true : (s < B);
-    float xb[5], xt[4], lin[6];
+    float xb[5], xt[4], lin[6], xb2[4], xt2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) xb[r] = (valid && fv[r]) ? xq[r] : 0.0f;
     xb[4] = (valid && f16) ? xq[4] : 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) xt[q] = (jv && (CONTIG || tile * 16 + 4 * g + q < B)) ? xtq[q] : 0.0f;
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xb2[q] = (valid && fv2[q]) ? xq2[q] : 0.0f;
+        xt2[q] = (jv2 && (CONTIG || tile * 16 + 4 * g + q < B)) ? xtq2[q] : 0.0f;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 6; ++q) lin[q] = lq[q];
     const float x16 = xb[4];
@@ -353,9 +383,15 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     PIN_DS();
     WCLK(9)
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
+    for (int q = 0; q < (WIDE ? 4 : 5); ++q)
 #pragma unroll
       for (int so = 0; so < 4; ++so) h1[so] = mfma16(w1[so][q], xb[q], h1[so]);
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int so = 0; so < 4; ++so) h1[so] = mfma16(w1b[so][q], xb2[q], h1[so]);
+    }
     WCLK(10)
 #pragma unroll
     for (int so = 0; so < 4; ++so)
@@ -551,7 +587,7 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       for (int r = 0; r < 4; ++r) {
         dz1[so][r] *= act_grad<ACT>(h1[so][r]);
         gb1[so][r] += dz1[so][r];
-        gW1c[so][r] = fmaf(dz1[so][r], x16, gW1c[so][r]);
+        if constexpr (!WIDE) gW1c[so][r] = fmaf(dz1[so][r], x16, gW1c[so][r]);
         H2S[(16 * so + 4 * g + r) * LDT + j] = dz1[so][r];         // dZ1^T[f][s] for dW1 (H2^T is consumed)
       }
     // the dW1 operands (dZ1 rows) are requested now and arrive under the dW2 MFMAs
@@ -577,6 +613,12 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     for (int so = 0; so < 4; ++so)
 #pragma unroll
       for (int q = 0; q < 4; ++q) gW1[so] = mfma16(za1[so][q], xt[q], gW1[so]);
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int so = 0; so < 4; ++so)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gW1b[so] = mfma16(za1[so][q], xt2[q], gW1b[so]);
+    }
 #undef PIN_DS
     WCLK(6)
   }
@@ -593,7 +635,8 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 #pragma unroll
       for (int c = 0; c < 4; ++c) gimg[F_W2 + f * H + 16 * c + j] = gW2[so][c][r];
       if (jv) gimg[F_W1 + f * Dr + j] = gW1[so][r];
-      const float c16 = row_sum16(gW1c[so][r]), s1 = row_sum16(gb1[so][r]), s2 = row_sum16(gb2[so][r]);
+      if (WIDE && jv2) gimg[F_W1 + f * Dr + 16 + j] = gW1b[so][r];
+      const float c16 = WIDE ? 0.0f : row_sum16(gW1c[so][r]), s1 = row_sum16(gb1[so][r]), s2 = row_sum16(gb2[so][r]);
       if (j == 0) { if (f16) gimg[F_W1 + f * Dr + 16] = c16; gimg[F_B1 + f] = s1; gimg[F_B2 + f] = s2; }
       if constexpr (IS_PF) {
         const int o = 4 * g + r;                                   // gW3 rows are outputs
@@ -1027,9 +1070,9 @@ __global__ __launch_bounds__(256) void mlp2_forward_kernel(const float* __restri
 // ================================================================ host side
 #define SHAPE_IS(d, h, o) (D == (d) && H == (h) && A == (o))
 
-// Shapes the fused minibatch kernels carry: the benchmark shape as a compile-time instantiation, and any D in [2, 17],
-// A in [1, 8] at H = 64 through the runtime-dims instantiation (ppo_wave_pass<..., RT = true>).
-static bool ppo_shape_rt(int D, int H, int A) { return H == 64 && D >= 2 && D <= 17 && A >= 1 && A <= 8; }
+// Shapes the fused minibatch kernels carry: the benchmark shape as a compile-time instantiation, and any D in [2, 32],
+// A in [1, 8] at H = 64 through the runtime-dims instantiations (ppo_wave_pass<..., RT = true>: the 17- and the 32-wide tile).
+static bool ppo_shape_rt(int D, int H, int A) { return H == 64 && D >= 2 && D <= 32 && A >= 1 && A <= 8; }
 extern "C" int trl_ppo_partial_stride(int D, int H, int A) {
   if (SHAPE_IS(17, 64, 6)) return PpoShape<17, 64, 6>::P_STRIDE;
   if (ppo_shape_rt(D, H, A)) {
@@ -1115,10 +1158,14 @@ extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream
     d.p_stride = PpoShape<17, 64, 6>::P_STRIDE;
     if (p->act == TRL_ACT_TANH) return launch_ppo<17, 64, 6, TRL_ACT_TANH, false>(d, s);
     if (p->act == TRL_ACT_RELU) return launch_ppo<17, 64, 6, TRL_ACT_RELU, false>(d, s);
-  } else if (ppo_shape_rt(D, H, A)) {                 // actual dims at run time inside the (17, 64, 8) tile
+  } else if (ppo_shape_rt(D, H, A) && D <= 17) {      // actual dims at run time inside the (17, 64, 8) tile
     d.p_stride = trl_ppo_partial_stride(D, H, A);
     if (p->act == TRL_ACT_TANH) return launch_ppo<17, 64, 8, TRL_ACT_TANH, true>(d, s);
     if (p->act == TRL_ACT_RELU) return launch_ppo<17, 64, 8, TRL_ACT_RELU, true>(d, s);
+  } else if (ppo_shape_rt(D, H, A)) {                 // 18 .. 32 input features: the (32, 64, 8) tile
+    d.p_stride = trl_ppo_partial_stride(D, H, A);
+    if (p->act == TRL_ACT_TANH) return launch_ppo<32, 64, 8, TRL_ACT_TANH, true>(d, s);
+    if (p->act == TRL_ACT_RELU) return launch_ppo<32, 64, 8, TRL_ACT_RELU, true>(d, s);
   }
   trl_set_error("ppo_grad: shape D=%d H=%d A=%d act=%d not instantiated", D, H, A, p->act);
   return TRL_EUNSUPPORTED;
