@@ -223,16 +223,18 @@ def test_fused_ppo_update_at_other_input_and_action_sizes_vs_oracle(D, A, act, t
     assert perr < 1e-6, perr
 
 
-def test_collect_and_train_with_the_fused_update_on_a_hopper_sized_env():
-    """11 observations / 3 actions, 64-wide networks: the per-step collector (dense-layer kernels) feeds the fused update
-    kernels; log pi_old comes from another forward kernel than log pi, so the first ratio is 1 up to round-off."""
+@pytest.mark.parametrize("D,A", [(11, 3), (27, 8)])
+def test_collect_and_train_with_the_fused_update_on_a_hopper_sized_env(D, A):
+    """11 observations / 3 actions (Hopper) and 27 / 8 (Ant: the wide tile), 64-wide networks: the per-step collector
+    (dense-layer kernels) feeds the fused update kernels; log pi_old comes from another forward kernel than log pi, so the
+    first ratio is 1 up to round-off."""
     import torchrl.networks as networks
     import torchrl.policies as policies
     from torchrl.algo import PPO
     from torchrl.collector.on_policy import VecOnPolicyCollector
     from torchrl.env.synth import SynthVecEnv
     from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
-    N, T, D, A = 32, 16, 11, 3
+    N, T = 32, 16
     net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
     torch.manual_seed(1)
     pf = policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A, tanh_action=True, **net)
