@@ -352,6 +352,19 @@ int trl_clip_adam_f32(const trl_adam_t* args, void* stream);
  * `ring`; args->step_state is then required */
 int trl_clip_adam_polyak_f32(const trl_adam_t* args, float* target, const float* source, int64_t n, float tau,
                              const void* raw, int raw_bytes, void* ring, int slots, void* stream);
+/* The whole tail of an off-policy update as ONE launch (twin_sac_q.py:162-220, algo/utils.py:16-20): the fold of the split
+ * weight-gradient partials of every layer (entry k: splits[k] slices of n[k] floats at part[k]; the entries cover
+ * args->grads -- which receives the folded gradient -- exactly, in order; trl_fold_partials_multi_f32's summation order),
+ * clip_grad_norm_ per group, the Adam steps (args->step_state required: the launch advances it), the Polyak step
+ * target[i] <- (1 - tau) target[i] + tau params[target_off + i] for i < target_n, and (ring non-NULL) the filing of the
+ * statistics block as trl_clip_adam_polyak_f32 does it.  One grid of <= 256 co-resident workgroups with an in-kernel
+ * rendezvous for the norms; workspace: trl_fold_clip_adam_polyak_workspace() bytes, zeroed once (word 0 is set if the
+ * rendezvous ever timed out: the parameters are then left untouched).  One process only (the gradient SUM over ranks
+ * would sit between the fold and the clip). */
+int trl_fold_clip_adam_polyak_workspace(void);
+int trl_fold_clip_adam_polyak_f32(int count, const float* const* part, const int* n, const int* splits,
+                                  const trl_adam_t* args, float* target, int64_t target_off, int64_t target_n, float tau,
+                                  const void* raw, int raw_bytes, void* ring, int slots, void* workspace, void* stream);
 /* Single-process fast path: trl_ppo_reduce_f32 + trl_clip_adam_f32 in one launch (the block that
  * finishes the reduction last takes the optimiser step; fixed summation orders, deterministic).
  * adam->grads must equal `grads`, the two groups must be [policy | value]; logstd statistics are read

@@ -171,6 +171,10 @@ SIGNATURES = {
     "trl_tanh_gauss_rsample_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float] * 3 + [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_tanh_gauss_rsample_bwd_cols_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_void_p] + [C.c_float] * 3 +
                                             [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_fold_clip_adam_polyak_workspace": (C.c_int, []),
+    "trl_fold_clip_adam_polyak_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p,
+                                              C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_void_p]),
     "trl_sac_policy_grad_supported": (C.c_int, [C.c_int, C.c_int]),
     "trl_sac_policy_grad_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] +
                                 [C.c_void_p] * 4 + [C.c_float] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -525,6 +529,10 @@ def clip_adam_polyak(args, target, source, tau, device, file=None):
           "trl_clip_adam_polyak_f32")
 
 
+def fold_clip_adam_polyak_workspace(device):
+    return torch.zeros(int(lib().trl_fold_clip_adam_polyak_workspace()), dtype=torch.uint8, device=device)
+
+
 def synth_collect_step(env, head, eps, cur_step, ep_return, max_frames, rows, mask, epoch_reward, ep_count, ep_log, step,
                        tanh_action, noise=None):
     """One off-policy vector step on the synthetic env in one launch; rows = (obs, acts, next_obs, rewards, terminals,
@@ -837,6 +845,32 @@ class FoldPlan:
                 parts[j], outs[j], ns[j], sp[j] = dev_ptr(part, name="partials"), dev_ptr(out, name="grad view"), n, splits
             check(lib().trl_fold_partials_multi_f32(c, parts, outs, ns, sp, stream_ptr(self.ws.device)),
                   "trl_fold_partials_multi_f32")
+        self.entries, self.used = [], 0
+
+    def run_fused(self, args, grads, target, target_off, tau, workspace, file=None):
+        """`run()` and the update's last two launches in one (include/trl_hip.h trl_fold_clip_adam_polyak_f32): the folds
+        land in `grads` (the flat gradient buffer every recorded view lives in -- the entries must cover it), then clip,
+        Adam (`args`, device-resident step state) and the Polyak step of `target` against params[target_off:]."""
+        if self.problems:
+            self._run_gemms()
+        base, total = grads.data_ptr(), grads.numel()
+        ents = sorted(self.entries, key=lambda t: t[1].data_ptr())
+        c = len(ents)
+        parts, ns, sp = (C.c_void_p * c)(), (C.c_int * c)(), (C.c_int * c)()
+        pos = 0
+        for j, (part, out, n, splits) in enumerate(ents):
+            if out.data_ptr() != base + 4 * pos:
+                raise TrlError("FoldPlan.run_fused: the recorded gradient views do not tile the flat gradient buffer")
+            parts[j], ns[j], sp[j] = dev_ptr(part, name="partials"), n, splits
+            pos += n
+        if pos != total:
+            raise TrlError("FoldPlan.run_fused: %d of %d gradients have a fold entry" % (pos, total))
+        raw, ring = file if file is not None else (None, None)
+        check(lib().trl_fold_clip_adam_polyak_f32(
+            c, parts, ns, sp, C.byref(args), dev_ptr(target, name="target"), int(target_off), int(target.numel()), float(tau),
+            dev_ptr(raw, torch.uint8, "raw", allow_none=True), 0 if raw is None else int(raw.numel()),
+            dev_ptr(ring, torch.uint8, "ring", allow_none=True), 0 if ring is None else int(ring.shape[0]),
+            dev_ptr(workspace, torch.uint8, "workspace"), stream_ptr(grads.device)), "trl_fold_clip_adam_polyak_f32")
         self.entries, self.used = [], 0
 
 

@@ -160,6 +160,7 @@ class _FusedSAC:
         self._slab = IndexSlab(self.dev)
         self._mom_part = None
         self._pg_fused = True                                           # policy gradient: sac_policy_grad (False: layer GEMM + sampler launch)
+        self._fused_tail, self._tail_ws = True, None                    # fold + clip + Adam + Polyak as one launch
 
     def _ws(self, B):
         lib = _C.lib()
@@ -244,7 +245,11 @@ class _FusedSAC:
             d_head = _C.rsample_bwd_cols(head, eps1, new_a, dx1, dx2, D, alpha, 1.0 / B, algo.policy_std_reg_weight,
                                          algo.policy_mean_reg_weight, tanh_action)    # d_act = (dx1 + dx2)[:, D:]
         ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], plan=plan)
-        plan.run()
+        # one process, soft target updates: the folds, the clip, the Adam steps, the Polyak step and the filing of the
+        # statistics are ONE launch (FoldPlan.run_fused); otherwise fold here, (all-reduce,) clip + Adam (+ Polyak) below
+        fused_tail = soft and self._fused_tail and dist.world_size() == 1
+        if not fused_tail:
+            plan.run()
         # ---- optimiser steps (pf, qf1, qf2) and target update ----
         a = _C.AdamArgs()
         a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
@@ -260,7 +265,12 @@ class _FusedSAC:
         a.grad_scale = 1.0 / dist.world_size()
         a.step_count, a.norms_out = 0, self.norms.data_ptr()
         a.step_state = self.step_state.data_ptr()                        # the step count lives on the device
-        if soft:                                                         # Adam, then Polyak (which also advances the step state)
+        if fused_tail:
+            if self._tail_ws is None:
+                self._tail_ws = _C.fold_clip_adam_polyak_workspace(dev)
+            plan.run_fused(a, self.grads, self.tflat, self.sizes[0], algo.tau, self._tail_ws,
+                           file=(self._raw, self._ring.t) if ride else None)
+        elif soft:                                                       # Adam, then Polyak (which also advances the step state)
             _C.clip_adam_polyak(a, self.tflat, self.flat[self.sizes[0]:], algo.tau, dev,
                                 file=(self._raw, self._ring.t) if ride else None)
         else:

@@ -1302,6 +1302,174 @@ extern "C" int trl_clip_adam_polyak_f32(const trl_adam_t* p, float* target, cons
   return clip_adam_polyak(p, target, source, n, tau, raw, raw_bytes, ring, slots, stream);
 }
 
+// ---------------------------------------------------------------- fold + clip + Adam + Polyak, ONE launch
+// The tail of an off-policy update (twin_sac_q.py:162-220): fold of the split weight-gradient partials of every layer
+// (trl_fold_partials_multi_f32's arithmetic and summation order), clip_grad_norm_ per network, the Adam steps, the Polyak
+// step of the target networks (algo/utils.py:16-20), the filing of the update's statistics block -- three launches before
+// (7 + 5 + 5 us for 217 k parameters at cfg 3, each latency-bound).  A grid of <= 256 always co-resident workgroups: a
+// thread folds its parameters and leaves them in `grads`, the workgroup publishes its share of each group's sum of squares as
+// {epoch, value} granules, every workgroup polls all of them (the rendezvous of ppo_reduce_adam_kernel: no ticket, no
+// reset, device-scope relaxed accesses only), derives the clip coefficients in the same fixed order and steps its own
+// parameters and their targets.  The step state is read by every workgroup BEFORE it publishes; workgroup 0 advances it
+// after it has seen every granule.  A poll that does not complete (~1 s) trips workspace word 0 and leaves the parameters
+// untouched.
+#define FAP_THREADS 1024
+#define FAP_MAX_WG 256
+#define FAP_MAX_ENTRIES 32
+struct FapDev {
+  int count;
+  int off[FAP_MAX_ENTRIES + 1];                    // entry k owns grads[off[k] .. off[k + 1])
+  int splits[FAP_MAX_ENTRIES];
+  const float* part[FAP_MAX_ENTRIES];              // [splits][n_k]
+  float* target; int target_off, target_n; float tau;
+  unsigned long long* slots;                       // [4 groups][FAP_MAX_WG] {epoch, ss bits}
+  unsigned* err;
+  float* grads_out;
+};
+__global__ __launch_bounds__(FAP_THREADS) void fold_adam_polyak_kernel(AdamDev a, FapDev f, FileRing file) {
+  __shared__ float s_ss[4][FAP_THREADS / 64];
+  __shared__ float s_coef[4];
+  __shared__ float s_bc[2];
+  __shared__ int s_fail;
+  // (the entry table goes to LDS: a per-lane index into the argument struct would be a dependent load per element)
+  __shared__ int s_off[FAP_MAX_ENTRIES + 1], s_splits[FAP_MAX_ENTRIES];
+  __shared__ const float* s_part[FAP_MAX_ENTRIES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = gridDim.x;
+  if (tid <= f.count) s_off[tid] = f.off[tid];
+  if (tid < f.count) { s_splits[tid] = f.splits[tid]; s_part[tid] = f.part[tid]; }
+  const int total = a.off[a.n_groups];
+  const int per = (total + nb - 1) / nb, lo = blockIdx.x * per, hi = min(total, lo + per);
+  // the step state and the ring row are read before anything is published (workgroup 0 advances the state at the end)
+  const double steps = a.step_state[0];
+  const unsigned epoch = (unsigned)(long long)steps + 1u;
+  if (tid == 0) {
+    s_bc[0] = (float)(1.0 - a.step_state[1] * (double)a.beta1);
+    s_bc[1] = (float)sqrt(1.0 - a.step_state[2] * (double)a.beta2);
+    s_fail = 0;
+  }
+  __syncthreads();
+  // ---- fold (trl_fold_partials_multi_f32's order: four interleaved chains over the splits, then (0 + 1) + (2 + 3)) ----
+  float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int e = lo + tid; e < hi; e += FAP_THREADS) {
+    int k = 0;
+    while (k + 1 < f.count && e >= s_off[k + 1]) ++k;
+    const int n = s_off[k + 1] - s_off[k], splits = s_splits[k];
+    const float* p = s_part[k] + (e - s_off[k]);
+    float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int s0 = 0;
+    for (; s0 + 16 <= splits; s0 += 16) {          // 16 loads in flight: chain j takes splits j, j + 4, j + 8, ...
+      float x[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x[q] = p[(size_t)(s0 + q) * n];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) c[q & 3] += x[q];
+    }
+    for (; s0 < splits; ++s0) c[s0 & 3] += p[(size_t)s0 * n];
+    const float gsum = (c[0] + c[1]) + (c[2] + c[3]);
+    f.grads_out[e] = gsum;
+    int g = 0;
+    while (e >= a.off[g + 1]) ++g;
+    const float gs = gsum * a.grad_scale;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ss[q] = fmaf(q == g ? gs : 0.0f, gs, ss[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float w = wave_sum(ss[q]);
+    if (lane == 0) s_ss[q][wave] = w;
+  }
+  __syncthreads();
+  if (tid < a.n_groups) {
+    float t = 0.0f;
+    for (int w = 0; w < FAP_THREADS / 64; ++w) t += s_ss[tid][w];
+    __hip_atomic_store(f.slots + tid * FAP_MAX_WG + blockIdx.x, ((unsigned long long)epoch << 32) | __float_as_uint(t),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- rendezvous: every workgroup's granules of this launch; group norms in workgroup order ----
+  // wave w polls granules 64 r .. 64 r + 63 of group g (w = 4 g + r): all rounds of all groups fly together
+  {
+    const int g = wave >> 2, r = wave & 3, b = 64 * r + lane;
+    float v = 0.0f;
+    if (g < a.n_groups && b < nb) {
+      const unsigned long long* slot = f.slots + g * FAP_MAX_WG + b;
+      unsigned long long x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = wall_clock64();
+      while ((unsigned)(x >> 32) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wall_clock64() - t0 > 100000000ull) { s_fail = 1; break; }
+      }
+      v = __uint_as_float((unsigned)x);
+    }
+    v = wave_sum(v);                                   // a fixed tree over the round's 64 values
+    if (lane == 0) s_ss[g & 3][r] = v;                 // (s_ss is free again: its sums were published above)
+  }
+  __syncthreads();
+  if (tid < a.n_groups) {
+    const float t = ((s_ss[tid][0] + s_ss[tid][1]) + s_ss[tid][2]) + s_ss[tid][3];      // rounds in order
+    const float norm = sqrtf(t);
+    s_coef[tid] = (a.max_norm > 0.0f) ? fminf(a.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+    if (blockIdx.x == 0 && a.norms_out) a.norms_out[tid] = norm;
+  }
+  __syncthreads();
+  if (s_fail) { if (tid == 0) __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+  // ---- Adam on the own parameters, Polyak on their targets ----
+  const float bc1 = s_bc[0], bc2_sqrt = s_bc[1];
+  for (int e = lo + tid; e < hi; e += FAP_THREADS) {
+    int g = 0;
+    while (e >= a.off[g + 1]) ++g;
+    const float gr = f.grads_out[e] * a.grad_scale * s_coef[g];
+    const float m = a.beta1 * a.m[e] + (1.0f - a.beta1) * gr;
+    const float v = a.beta2 * a.v[e] + (1.0f - a.beta2) * gr * gr;
+    a.m[e] = m; a.v[e] = v;
+    const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+    const float lr = a.device_lr ? a.device_lr[g] : a.lr[g];
+    const float pn = a.params[e] - (lr / bc1) * (m / denom);
+    a.params[e] = pn;
+    const int te = e - f.target_off;
+    if (te >= 0 && te < f.target_n) f.target[te] = f.target[te] * (1.0f - f.tau) + pn * f.tau;
+  }
+  if (blockIdx.x == 0) {
+    if (file.ring) {
+      const int64_t u = (int64_t)steps;
+      uint32_t* row = file.ring + (int64_t)(((u % file.slots) + file.slots) % file.slots) * file.words;
+      for (int w = tid; w < file.words; w += FAP_THREADS) row[w] = file.raw[w];
+    }
+    if (tid == 0) { a.step_state[0] = steps + 1.0; a.step_state[1] *= (double)a.beta1; a.step_state[2] *= (double)a.beta2; }
+  }
+}
+extern "C" int trl_fold_clip_adam_polyak_workspace(void) { return (int)(16 + 4 * FAP_MAX_WG * sizeof(unsigned long long)); }   // bytes, zeroed once
+extern "C" int trl_fold_clip_adam_polyak_f32(int count, const float* const* part, const int* n, const int* splits,
+                                             const trl_adam_t* adam, float* target, int64_t target_off, int64_t target_n,
+                                             float tau, const void* raw, int raw_bytes, void* ring, int slots,
+                                             void* workspace, void* stream) {
+  TRL_REQUIRE(count >= 1 && count <= FAP_MAX_ENTRIES && part && n && splits, "fold_clip_adam_polyak: 1..32 fold entries");
+  TRL_REQUIRE(adam && adam->step_state && workspace, "fold_clip_adam_polyak: needs the device-resident step state and a workspace");
+  TRL_REQUIRE((!target_n) || (target && target_off >= 0), "fold_clip_adam_polyak: bad target range");
+  TRL_REQUIRE(!ring || (raw && raw_bytes > 0 && raw_bytes % 4 == 0 && slots > 0), "fold_clip_adam_polyak: bad ring");
+  AdamDev d;
+  int rc = fill_adam(adam, d);
+  if (rc) return rc;
+  FapDev f{};
+  f.count = count;
+  for (int k = 0; k < count; ++k) {
+    TRL_REQUIRE(part[k] && n[k] > 0 && splits[k] >= 1, "fold_clip_adam_polyak: bad entry");
+    f.part[k] = part[k]; f.splits[k] = splits[k]; f.off[k + 1] = f.off[k] + n[k];
+  }
+  const int total = d.off[d.n_groups];
+  TRL_REQUIRE(f.off[count] == total, "fold_clip_adam_polyak: the fold entries must cover the parameter block exactly, in order");
+  TRL_REQUIRE(target_off + target_n <= total, "fold_clip_adam_polyak: target range outside the parameter block");
+  f.target = target; f.target_off = (int)target_off; f.target_n = (int)target_n; f.tau = tau;
+  f.err = (unsigned*)workspace;
+  f.slots = (unsigned long long*)((char*)workspace + 16);
+  f.grads_out = const_cast<float*>(adam->grads);
+  FileRing file = {(const uint32_t*)raw, (uint32_t*)ring, adam->step_state, raw_bytes / 4, slots, 0};
+  const int grid = std::max(1, std::min(FAP_MAX_WG, trl_ceil_div(total, FAP_THREADS)));
+  hipLaunchKernelGGL(fold_adam_polyak_kernel, dim3(grid), dim3(FAP_THREADS), 0, (hipStream_t)stream, d, f, file);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 static int clip_adam_launch(const trl_adam_t* p, void* stream, bool tick_here) {
   AdamDev d;
   int rc = fill_adam(p, d);
