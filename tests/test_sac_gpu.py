@@ -301,6 +301,76 @@ def test_clip_adam_advances_the_device_step_itself(n):
     assert (p.cpu() - ref.detach()).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("sizes,clip", [((5000, 3000, 7000), 1.0), ((217000 // 3, 70000, 74000), 0.5), ((300, 200, 100), 0.0)])
+def test_one_launch_update_tail_equals_fold_clip_adam_polyak_as_separate_launches(sizes, clip):
+    """`trl_fold_clip_adam_polyak_f32` against trl_fold_partials_multi_f32 -> trl_clip_adam_polyak_f32 on the same
+    partials: folded gradients bit for bit (same summation order), norms / parameters / moments / targets to round-off
+    (the norm is summed in another order), the step state advanced once per call, the statistics block filed."""
+    import ctypes as C
+    from torchrl_amd import _C
+    dev = torch.device(DEV)
+    torch.manual_seed(sum(sizes))
+    total = sum(sizes)
+    # entries: every group is cut into a few "layers" with their own number of splits
+    ents, pos = [], 0
+    for gsz in sizes:
+        left = gsz
+        for frac, splits in ((0.6, 16), (0.3, 32), (0.1, 5)):
+            n = max(1, int(gsz * frac)) if frac != 0.1 else left
+            n = min(n, left)
+            if n > 0:
+                ents.append((pos, n, splits))
+                pos += n; left -= n
+    parts = [torch.randn(sp, n, device=dev) * 0.1 for _, n, sp in ents]
+    p0 = torch.randn(total, device=dev)
+    t_off, t_n = sizes[0], total - sizes[0]
+    tgt0 = torch.randn(t_n, device=dev)
+    raw = torch.arange(64, dtype=torch.uint8, device=dev)
+
+    def make(p, g, m, v, state, norms):
+        a = _C.AdamArgs()
+        a.params, a.grads, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.n_groups = 3
+        for k in range(3):
+            a.group_sizes[k] = sizes[k]
+            a.group_lr[k] = (3e-4, 1e-3, 2e-3)[k]
+        a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = clip, 0.9, 0.999, 1e-8, 1.0
+        a.step_count, a.norms_out, a.step_state = 0, norms.data_ptr(), state.data_ptr()
+        return a
+
+    outs = []
+    for fused in (False, True):
+        p, g = p0.clone(), torch.zeros(total, device=dev)
+        m, v, tgt = torch.zeros(total, device=dev), torch.zeros(total, device=dev), tgt0.clone()
+        state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=dev)
+        norms, ring = torch.zeros(3, device=dev), torch.zeros(4, 64, dtype=torch.uint8, device=dev)
+        a = make(p, g, m, v, state, norms)
+        ws = _C.fold_clip_adam_polyak_workspace(dev)
+        c = len(ents)
+        for step in range(2):
+            pp, nn, ss = (C.c_void_p * c)(), (C.c_int * c)(), (C.c_int * c)()
+            oo = (C.c_void_p * c)()
+            for j, ((off, n, sp), part) in enumerate(zip(ents, parts)):
+                pp[j], nn[j], ss[j], oo[j] = part.data_ptr(), n, sp, g.data_ptr() + 4 * off
+            if fused:
+                _C.check(_C.lib().trl_fold_clip_adam_polyak_f32(c, pp, nn, ss, C.byref(a), tgt.data_ptr(), t_off, t_n, 0.005,
+                                                                raw.data_ptr(), 64, ring.data_ptr(), 4, ws.data_ptr(),
+                                                                _C.stream_ptr(dev)), "fused tail")
+            else:
+                _C.check(_C.lib().trl_fold_partials_multi_f32(c, pp, oo, nn, ss, _C.stream_ptr(dev)), "fold")
+                _C.clip_adam_polyak(a, tgt, p[t_off:], 0.005, dev, file=(raw, ring))
+        assert ws[:4].view(torch.int32)[0].item() == 0                   # the rendezvous never timed out
+        outs.append((g.clone(), p, m, v, tgt, norms.clone(), state.cpu().clone(), ring.cpu().clone()))
+    (g0, p0_, m0, v0, t0, n0, s0, r0), (g1, p1, m1, v1, t1, n1, s1, r1) = outs
+    assert torch.equal(g0, g1)
+    assert s0[0].item() == s1[0].item() == 2.0 and torch.equal(s0[:3], s1[:3])
+    assert torch.equal(r0, r1) and r1[0].tolist() == list(range(64)) and r1[1].tolist() == list(range(64))
+    if clip > 0:
+        torch.testing.assert_close(n1, n0, rtol=1e-5, atol=1e-7)
+    for x, y in ((p1, p0_), (m1, m0), (v1, v0), (t1, t0)):
+        torch.testing.assert_close(x, y, rtol=2e-6, atol=2e-7)
+
+
 def sac_state(g, prefix):
     return {k[len(prefix):].replace("__", "."): torch.tensor(g[k]) for k in g.files if k.startswith(prefix)}
 
