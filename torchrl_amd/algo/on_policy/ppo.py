@@ -301,8 +301,8 @@ class _FusedPPO:
                 pre()
             stream = _C.stream_ptr(dev)
             # advantage statistics of all K minibatches; the statistics block cleared and target_pf <- pf in the same launch
-            if getattr(self, "_pro_ws", None) is None or self._pro_ws_k != K:
-                self._pro_ws, self._pro_ws_k = _C.ppo_epoch_prologue_workspace(K, dev), K
+            if getattr(self, "_pro_ws", None) is None or self._pro_ws_k != (K, rows_mb):   # (its counters assume one slicing)
+                self._pro_ws, self._pro_ws_k = _C.ppo_epoch_prologue_workspace(K, dev), (K, rows_mb)
             copies = [(self.target_flat, self.flat[:self.P_pf])] if self._copy_in_prologue else []
             if in_place:
                 copies += [(idx_dev, self._idx_host), (self.red_ws[2:4], self._hyper_host)]
