@@ -16,7 +16,8 @@ Exploration noise:
     step) -- statistically equivalent, no host work.
   * `prefetch_noise=True` (host mode): the NEXT rollout's (T, N, A) block is drawn by
     worker threads into page-locked memory while the current iteration runs on the
-    device, and uploaded right in front of its rollout -- the same values in the same order from
+    device, and moved to the device by extra workgroups of the rollout launch that runs meanwhile (no copy
+    command, see _NoisePrefetcher) -- the same values in the same order from
     the same generator (nothing else on this path draws from it between two
     rollouts, torchrl/algo/on_policy/ppo.py:27-152), just earlier; what bench.py's
     headline uses.  See _NoisePrefetcher.
