@@ -195,6 +195,48 @@ def test_epoch_result_read_back_on_first_access_equals_the_immediate_one(monkeyp
     assert want == got == small and torch.equal(pw, pg) and torch.equal(pw, ps)
 
 
+def test_alternating_epoch_headers_equal_the_memset_path_with_evaluations_in_between():
+    """The fused rollout alternates between two {epoch reward, episode count} headers and clears the idle one inside its
+    launch; its value pass publishes header + episode log to page-locked memory and leaves the bootstrap value.  Same
+    epoch results, evaluation results, buffers and parameters as with a memset in front of every launch, a copy command
+    behind it and the bootstrap value from a forward launch -- with evaluations (which use the headers too) in between."""
+    def run(plain):
+        torch.manual_seed(0)
+        pf, vf, env, buf, col, agent, logger = build(None, "", 64, 16, 5, 1000, 256, 3, noise_mode="device")
+        if plain:
+            launch = col._launch
+
+            def plain_launch(*a, **k):
+                col._idle_hdr_clean = False                                 # -> memset of the current header, no swap
+                k["publish"] = False                                        # -> copy command behind the launch
+                launch(*a, **k)
+                buf._boot_fresh = False                                     # -> bootstrap value from vf's forward launch
+            col._launch = plain_launch
+        out = []
+        for epoch in range(4):
+            res = col.train_one_epoch()
+            np.random.seed(epoch)
+            agent.current_epoch = epoch
+            agent.update_per_epoch()
+            out.append((list(res["train_rewards"]), res["train_epoch_reward"]))
+            if epoch in (1, 2):
+                ev = col.eval_one_epoch()
+                out.append((list(ev["eval_rewards"]), ev["eval_traj_length"]))
+        torch.cuda.synchronize()
+        return out, pf.flat_params().cpu().clone(), buf._advs.cpu().clone()
+    (want, pw, aw), (got, pg, ag) = run(True), run(False)
+    assert len(want[0][0]) == 64 * 3
+    # The bootstrap value comes from another forward kernel (value pass vs mlp2_forward), so the two runs agree to
+    # round-off, not bit for bit, from the first update on; a header mix-up would be an error of the size of the values.
+    assert want[0] == got[0]                                                # nothing has been updated yet: identical
+    for (wl, ws), (gl, gs) in zip(want, got):
+        assert len(wl) == len(gl)
+        np.testing.assert_allclose(gl, wl, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(gs, ws, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ag, aw, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pg, pw, rtol=1e-5, atol=1e-6)
+
+
 def test_update_infos_taken_later_equal_the_ones_read_in_place(monkeypatch):
     """PPO.update_per_epoch with a logger that accepts `add_update_infos_later`: the update is launched and its info dicts
     are assembled when asked for -- by the logger, or by the engine's next run before it reuses the host twin of the
