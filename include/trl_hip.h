@@ -779,6 +779,14 @@ int trl_norm_filt_f32(const float* x, const double* state, float* out, int N, in
  * state at any prefix of a block can be handed to another torch.Generator and several host threads draw the segments of
  * ONE torch.randn block concurrently, bit for bit.  Host code, no device work. */
 int trl_mt19937_advance(uint32_t* state, int32_t* left, int64_t* next, int64_t calls);
+/* K states of one stream in one pass: record k (state_bytes bytes at out + k * state_bytes) = the generator-state image
+ * `tmpl` with its engine fields -- int32 `left` at off_left, int64 `next` at off_next, 624 x uint64 words at off_mt
+ * (torch's CPU generator state) -- moved forward to engine call pos[k]; pos ascending, relative to tmpl.  What env shards
+ * on several ranks need: rank r's rows of step t's (N_total, A) draw start at call t * N_total * A + r * N_local * A
+ * (torchrl/policies/distribution.py:60-76 draws the tensor for ALL envs; torchrl/replay_buffers/on_policy.py:75-88 is what
+ * makes the column blocks a partition of the reference's minibatch). */
+int trl_mt19937_states_at(const uint8_t* tmpl, int64_t state_bytes, int64_t off_left, int64_t off_next, int64_t off_mt,
+                          const int64_t* pos, int64_t K, uint8_t* out);
 
 /* --- calibration of the two rooflines (nominal AND achievable peaks) -------------------
  * No reference counterpart (the reference publishes no measurement); run by bench.py after its timed

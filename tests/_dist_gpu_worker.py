@@ -37,6 +37,7 @@ def _lib():
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else ""
+    noise_opt = sys.argv[6] if len(sys.argv) > 6 else "device"        # device | host | host_prefetch | host_perstep
     obs_norm = mode == "obs_norm"
     if (world > 1 or mode == "nccl_graph") and mode != "nccl_peer":
         import torch.distributed as td
@@ -81,7 +82,11 @@ def main():
     env.seed(3)
     buf = OnPolicyReplayBuffer(n * T, env_nums=n, time_limit_filter=True, device=dev)
     col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, epoch_frames=n * T,
-                               max_episode_frames=MAX_FRAMES, noise_mode="device")
+                               max_episode_frames=MAX_FRAMES, noise_mode="device" if noise_opt == "device" else "host",
+                               prefetch_noise=(noise_opt == "host_prefetch"))
+    if noise_opt == "host_perstep":        # the reference's literal op sequence: one torch.randn(N_total, A) per vector step
+        from torchrl_amd.collector import noise as _noise
+        _noise._checked = False
     if obs_norm:
         col.force_per_step = True          # single process: the per-step sequence too (its Philox layout differs from the
     logger = Log()                         # cooperative kernel's), so that the two runs draw the same exploration noise
@@ -96,15 +101,22 @@ def main():
         agent = TRPO(max_kl=0.01, cg_damping=1e-2, v_opt_times=2, cg_iters=10, residual_tol=1e-10, **common)
     else:
         agent = PPO(clip_para=0.2, opt_epochs=2, **common)
+    torch.manual_seed(21)                  # the exploration-noise stream of the host modes (the CPU generator)
+    acts = []
     for epoch in range(EPOCHS):
         col.rollout(col.sample_epoch_frames)
+        acts.append(buf._acts.cpu().numpy().copy())
         agent.current_epoch = epoch
         agent.update_per_epoch()
     logger.drain()
+    col.stop_noise_prefetch()
+    tail = torch.randn(5).numpy()          # where the CPU stream stands afterwards
+    pre = col._prefetcher
     keys = sorted(logger.infos[0])
     np.savez(out, pf=pf.flat_params().cpu().numpy(), vf=vf.flat_params().cpu().numpy(), keys=np.array(keys),
              infos=np.array([[i[k] for k in keys] for i in logger.infos if sorted(i) == keys]),
-             obs=buf._obs.cpu().numpy(), rewards=buf._rewards.cpu().numpy(),
+             obs=buf._obs.cpu().numpy(), rewards=buf._rewards.cpu().numpy(), acts=np.stack(acts), tail=tail,
+             prefetched=np.array(0 if pre is None else sum(pre.transport_counts.values()) - pre.dropped_blocks - 1),
              norm_state=env._obs_normalizer.state.cpu().numpy() if obs_norm else np.zeros(1),
              peer=np.array(int(peer)), graph=np.array(int(getattr(agent.engine(), "_graph", None) is not None)))
     if world > 1 or mode in ("nccl_graph", "nccl_peer"):

@@ -77,6 +77,30 @@ def test_two_ranks_gather_the_minibatch_for_global_steps(tmp_path, algo, p_tol, 
         np.testing.assert_allclose(r0["infos"], single["infos"], rtol=i_tol, atol=i_tol)
 
 
+@pytest.mark.parametrize("mode", ["", "peer"])
+def test_two_ranks_draw_their_rows_of_the_reference_noise_stream(tmp_path, mode):
+    """The reference's exploration noise at world size 2: every vector step the reference draws ONE
+    (N_total, A) tensor from the CPU generator (torchrl/policies/distribution.py:60-76); each rank produces only ITS rows of
+    it from the engine state at their position in the stream (collector/noise.py), one rollout ahead when prefetching.
+    The ranks' buffers must be the column blocks of the single-process run that makes the reference's literal per-step
+    draws -- torch.equal, every epoch -- and the generator must end where the draws for all envs leave it."""
+    extra = (mode or "plain",)
+    (single,) = _run(1, tmp_path, extra=("plain", "host_perstep"))
+    (single_block,) = _run(1, tmp_path, extra=("plain", "host"))
+    assert np.array_equal(single_block["acts"], single["acts"]) and np.array_equal(single_block["tail"], single["tail"])
+    for opt in ("host", "host_prefetch"):
+        r0, r1 = _run(2, tmp_path, extra=extra + (opt,))
+        acts = np.concatenate([r0["acts"], r1["acts"]], axis=2)      # (epoch, T, N_total, A)
+        assert np.array_equal(acts[0], single["acts"][0]), opt         # same parameters: the same actions, bit for bit
+        np.testing.assert_allclose(acts, single["acts"], atol=2e-5)    # later epochs: parameters differ by summation order
+        np.testing.assert_allclose(np.concatenate([r0["obs"], r1["obs"]], axis=1), single["obs"], atol=2e-5)
+        assert np.array_equal(r0["tail"], single["tail"]) and np.array_equal(r1["tail"], single["tail"]), opt
+        assert np.array_equal(r0["pf"], r1["pf"]) and np.array_equal(r0["vf"], r1["vf"])
+        np.testing.assert_allclose(r0["pf"], single["pf"], atol=2e-6)
+        if opt == "host_prefetch":                                    # blocks did arrive through the prefetcher
+            assert int(r0["prefetched"]) >= 1 and int(r1["prefetched"]) >= 1, (int(r0["prefetched"]), int(r1["prefetched"]))
+
+
 def test_rccl_sequence_replays_as_a_graph(tmp_path):
     """TRL_GRAPH_COLLECTIVES=1: the multi-rank launch sequence (partial fold -> RCCL all-reduce -> clip + Adam, step
     count and learning rates on the device) captured into a HIP graph and replayed, on a one-rank nccl group with the

@@ -554,6 +554,56 @@ def test_parallel_reference_noise_falls_back_for_small_or_ragged_blocks():
         noise.randn_into(torch.empty(64, dtype=torch.float64))
 
 
+@pytest.mark.parametrize("world,n_local,a_dim,steps", [(2, 32, 6, 16), (8, 2048, 6, 4), (4, 8, 2, 33)])
+def test_sharded_reference_noise_is_the_column_block_of_the_draw_for_all_envs(world, n_local, a_dim, steps):
+    """Env shards on several ranks: the reference draws ONE (N_total, A) tensor per vector step
+    (torchrl/policies/distribution.py:60-76); rank r's rows [r * N_local, (r + 1) * N_local) of every step come out of
+    noise.randn_shard_into without drawing the other ranks' rows, bit for bit, and the default generator ends where the
+    draws for ALL envs leave it -- for one and several host threads."""
+    import torch
+    from torchrl_amd.collector import noise
+    n_total = world * n_local
+    torch.manual_seed(world)
+    torch.randn(21)
+    start = torch.get_rng_state()
+    whole = torch.stack([torch.randn(n_total, a_dim) for _ in range(steps)])
+    end = torch.get_rng_state()
+    for threads in (1, 3, 8):
+        for r in sorted({0, world // 2, world - 1}):
+            torch.set_rng_state(start)
+            got = noise.randn_shard_into(torch.empty(steps, n_local, a_dim), steps, n_local, n_total, r * n_local, a_dim,
+                                         threads=threads)
+            assert torch.equal(got, whole[:, r * n_local:(r + 1) * n_local]), (threads, r)
+            assert torch.equal(torch.get_rng_state(), end)
+    assert not noise.shard_ok(7, 14, 7, 6)                                 # 42 values per chunk: not a multiple of 16
+
+
+def test_draw_block_leaves_the_default_generator_alone_and_falls_back_on_an_unknown_torch():
+    """draw_block works on private generators from a state handed to it (the prefetch worker's call: the default generator
+    belongs to the main thread); when the self-check of the private torch facts fails, randn_into is a plain torch.randn."""
+    import torch
+    from torchrl_amd.collector import noise
+    assert noise._self_check() and noise.fast_path_ok()
+    torch.manual_seed(4)
+    s0 = torch.get_rng_state()
+    n = noise.MIN_PARALLEL * 2
+    want = torch.randn(n)
+    end = torch.get_rng_state()
+    torch.manual_seed(1234)                                                # the default generator is somewhere else entirely
+    before = torch.get_rng_state()
+    got = torch.empty(n)
+    assert torch.equal(noise.draw_block(s0, got, threads=4), end) and torch.equal(got, want)
+    assert torch.equal(torch.get_rng_state(), before)
+    old, noise._checked = noise._checked, False                            # "another torch build"
+    try:
+        torch.set_rng_state(s0)
+        blocks = noise.STATS["blocks"]
+        assert torch.equal(noise.randn_into(torch.empty(n), threads=4), want) and noise.STATS["blocks"] == blocks
+        assert not noise.shard_ok(32, 64, 32, 6)
+    finally:
+        noise._checked = old
+
+
 def test_mt19937_advance_matches_the_engine():
     """The state after k engine calls, for k around the 624-word regeneration boundaries, equals the default generator's
     state after a k-element float32 normal_() (one call per element for k >= 16, k % 16 == 0)."""

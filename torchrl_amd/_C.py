@@ -222,6 +222,7 @@ SIGNATURES = {
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_mt19937_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "trl_mt19937_states_at": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "trl_peak_copy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "trl_peak_mfma_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "trl_adv_normalize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
@@ -846,6 +847,17 @@ class FoldPlan:
             check(lib().trl_fold_partials_multi_f32(c, parts, outs, ns, sp, stream_ptr(self.ws.device)),
                   "trl_fold_partials_multi_f32")
         self.entries, self.used = [], 0
+
+    def tiles(self, grads):
+        """Do the recorded gradient views cover the flat buffer `grads` exactly once, without gaps?  (What run_fused
+        needs; a layer without a bias, or a parameter no fold entry writes, does not -- the caller then takes `run()` and
+        the separate clip / Adam / Polyak launches.)"""
+        pos, base = 0, grads.data_ptr()
+        for part, out, n, splits in sorted(self.entries, key=lambda t: t[1].data_ptr()):
+            if out.data_ptr() != base + 4 * pos:
+                return False
+            pos += n
+        return pos == grads.numel()
 
     def run_fused(self, args, grads, target, target_off, tau, workspace, file=None):
         """`run()` and the update's last two launches in one (include/trl_hip.h trl_fold_clip_adam_polyak_f32): the folds

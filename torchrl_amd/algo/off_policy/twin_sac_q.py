@@ -247,7 +247,7 @@ class _FusedSAC:
         ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], plan=plan)
         # one process, soft target updates: the folds, the clip, the Adam steps, the Polyak step and the filing of the
         # statistics are ONE launch (FoldPlan.run_fused); otherwise fold here, (all-reduce,) clip + Adam (+ Polyak) below
-        fused_tail = soft and self._fused_tail and dist.world_size() == 1
+        fused_tail = soft and self._fused_tail and dist.world_size() == 1 and plan.tiles(self.grads)
         if not fused_tail:
             plan.run()
         # ---- optimiser steps (pf, qf1, qf2) and target update ----

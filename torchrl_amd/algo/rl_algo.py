@@ -116,7 +116,11 @@ class RLAlgo:
     def train(self):
         # This loop is the reference's (rl_algo.py:96-164): between two rollouts nothing draws from the CPU torch generator
         # (updates and greedy evaluation are deterministic given the batch), so an on-policy collector in the reference's
-        # noise mode may draw the next rollout's exploration noise while the device is busy (TRL_PREFETCH_NOISE=0: in place)
+        # noise mode may draw the next rollout's exploration noise while the device is busy (TRL_PREFETCH_NOISE=0: in place).
+        # The worker draws from private generators; the default generator is only read / set on this thread when a block is
+        # taken, and a block is only used if the generator still is where the block started -- a callback or a custom policy
+        # that draws from (or re-seeds) the CPU generator between two rollouts just makes that block be drawn in place, in
+        # the reference's order (collector/on_policy.py::_NoisePrefetcher, logged once).
         if hasattr(self.collector, "prefetch_noise") and os.environ.get("TRL_PREFETCH_NOISE") != "0":
             self.collector.prefetch_noise = True
         self.pretrain()

@@ -469,7 +469,8 @@ class VecCollector(_CollectorBase):
         (RLAlgo.train does) never leaves the GPU idle for the read-back.  The next rollout resolves a result nobody looked
         at (`collector.eager_epoch_result = True`: read back before returning)."""
         self._resolve_pending()
-        self.rollout(self.sample_epoch_frames)
+        self._published = False                                            # only THIS epoch's fused launch may set it (a per-step
+        self.rollout(self.sample_epoch_frames)                             # rollout must not inherit a stale "already published")
         if self.eager_epoch_result or self._ep_log_host is None \
                 or getattr(self.env, "is_host_env", False):
             return self._epoch_result_now()

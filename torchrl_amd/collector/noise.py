@@ -1,4 +1,4 @@
-"""The reference's exploration-noise stream, drawn by several host threads at once.
+"""The reference's exploration-noise stream, drawn by several host threads at once -- and by several ranks.
 
 The reference samples `Normal(zeros, ones).sample()` from the CPU torch generator per vector step
 (torchrl/policies/distribution.py:60-76) -- bit-identical to `torch.randn` on that generator.  One (T, N, A) block of
@@ -8,15 +8,26 @@ takes on the device.  The values do not have to be produced sequentially, though
   * a float32 `normal_()` of n elements (n >= 16, n % 16 == 0) makes exactly n engine calls, element i from call i, and
     transforms the uniforms in aligned groups of 16 -- so a block cut at multiples of 16 is the concatenation of
     independent draws, each started from the engine state at its first element;
-  * that state is obtained without drawing: `trl_mt19937_advance` (include/trl_hip.h, host code) moves an engine state
-    forward by k calls at the cost of the 624-word twist per 624 calls (~0.3 ms for the whole block).
+  * that state is obtained without drawing: `trl_mt19937_states_at` (include/trl_hip.h, host code) moves an engine state
+    forward to any list of call positions at the cost of the 624-word twist per 624 calls (~0.3 ms per 1.5 M calls).
 
-`randn_into(out)` therefore snapshots the default generator's state, derives the P segment states, lets P threads run
-`torch.randn(..., generator=g_p, out=segment_p)` on private generators (the op releases the interpreter lock), and sets
-the default generator to the end-of-block state: same values in the same places as ONE `torch.randn` call, same
-generator state afterwards (tests/test_host_logic_cpu.py::test_parallel_reference_noise_*), ~P times faster.
+`draw_block(state0, out, ...)` derives the chunk states from `state0`, lets P threads run
+`torch.randn(..., generator=g_p, out=chunk)` on PRIVATE generators (the op releases the interpreter lock) and returns the
+state at the end of the block.  It never touches the default generator, so it can run on any thread; `randn_into(out)` is
+the main-thread wrapper that reads the default generator's state, draws, and sets the state the single call would leave.
+
+Env shards on several ranks (`stride` / `offset`): step t of the reference draws ONE (N_total, A) tensor for all envs
+(distribution.py:60-76); the rank that owns envs [e0, e0 + N_local) needs elements [e0 * A, (e0 + N_local) * A) of it,
+i.e. the T chunks at calls t * N_total * A + e0 * A of the stream, and the state after T * N_total * A calls at the end.
+Every rank makes the same pass over the stream and draws only its own 1 / world of the values
+(torchrl/replay_buffers/on_policy.py:75-88 is why column blocks of the global tensor are the right partition).
+
+Nothing here is trusted blindly: the layout of torch's generator state and the block structure of its normal transform
+are private to torch, so the first use runs a self-check against plain `torch.randn` calls (`fast_path_ok()`); when it
+fails -- another torch build -- every caller falls back to the plain per-step draws and a warning is logged once.
 """
 import ctypes as C
+import logging
 import os
 import struct
 import threading
@@ -31,9 +42,13 @@ from .. import _C
 # int32 seeded | uint64 next | uint64 state[624] | normal_x, normal_y, normal_rho (double) | int32 normal_is_valid | pad |
 # float next_float_normal_sample | bool valid | pad = 5056 bytes
 _STATE_BYTES, _OFF_LEFT, _OFF_NEXT, _OFF_MT, _MT_N = 5056, 8, 16, 24, 624
-MIN_PARALLEL = 1 << 16                       # below this a block is drawn by the calling thread
+MIN_PARALLEL = 1 << 16                       # below this a contiguous block is drawn by the calling thread
+_GROUP_CHUNKS = 16                           # chunk states are derived this many at a time, the draws of a group run meanwhile
 
 _pool, _pool_lock, _gens = None, threading.Lock(), threading.local()
+_checked = None                              # None: not yet; True / False: result of the self-check
+_log = logging.getLogger("torchrl_amd")
+STATS = {"blocks": 0, "parallel_blocks": 0, "pieces": 0}     # what draw_block did so far (tests assert the parallel path ran)
 
 
 def default_threads():
@@ -49,65 +64,165 @@ def _executor(threads):
         return _pool
 
 
-def _parse(state):
-    raw = state.numpy().tobytes()
-    if len(raw) != _STATE_BYTES:
-        raise _C.TrlError("CPU generator state of %d bytes: layout unknown to torchrl_amd.collector.noise" % len(raw))
-    left, = struct.unpack_from("<i", raw, _OFF_LEFT)
-    nxt, = struct.unpack_from("<Q", raw, _OFF_NEXT)
-    mt = np.frombuffer(raw, dtype=np.uint64, count=_MT_N, offset=_OFF_MT).astype(np.uint32)
-    return raw, left, nxt, mt
+def _layout_known(state):
+    return state.dtype == torch.uint8 and state.numel() == _STATE_BYTES
 
 
-def _pack(template, left, nxt, mt):
-    buf = bytearray(template)
-    struct.pack_into("<i", buf, _OFF_LEFT, int(left))
-    struct.pack_into("<Q", buf, _OFF_NEXT, int(nxt))
-    buf[_OFF_MT:_OFF_MT + 8 * _MT_N] = mt.astype(np.uint64).tobytes()
-    return torch.frombuffer(buf, dtype=torch.uint8).clone()
+def states_at(state, positions):
+    """uint8 tensor (K, state bytes): `state` moved forward to each of the ascending engine-call positions."""
+    if not _layout_known(state):
+        raise _C.TrlError("CPU generator state of %d bytes: layout unknown to torchrl_amd.collector.noise" % state.numel())
+    pos = np.ascontiguousarray(positions, dtype=np.int64)
+    tmpl = state.contiguous()
+    out = torch.empty(len(pos), _STATE_BYTES, dtype=torch.uint8)
+    _C.check(_C.lib().trl_mt19937_states_at(tmpl.data_ptr(), _STATE_BYTES, _OFF_LEFT, _OFF_NEXT, _OFF_MT,
+                                            pos.ctypes.data_as(C.c_void_p), len(pos), out.data_ptr()),
+             "trl_mt19937_states_at")
+    return out
 
 
 def segment_states(state, n, parts):
     """Engine states at the P segment starts of an n-element block and at its end; returns (bounds, states) with
     bounds[p] .. bounds[p + 1] the elements of segment p (every bound a multiple of 16) and len(states) == P + 1."""
-    raw, left, nxt, mt = _parse(state)
     seg = -(-n // parts)
     seg = (seg + 15) // 16 * 16
     bounds = list(range(0, n, seg)) + [n]
-    lib = _C.lib()
-    mt = np.ascontiguousarray(mt)
-    c_left, c_next = C.c_int32(left), C.c_int64(nxt)
-    states = [state.clone()]
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        _C.check(lib.trl_mt19937_advance(mt.ctypes.data_as(C.c_void_p), C.byref(c_left), C.byref(c_next), b - a),
-                 "trl_mt19937_advance")
-        states.append(_pack(raw, c_left.value, c_next.value, mt))
-    return bounds, states
+    recs = states_at(state, bounds)
+    return bounds, [recs[k] for k in range(len(bounds))]
 
 
 def _draw(state, out):
     g = getattr(_gens, "g", None)
     if g is None:
         g = _gens.g = torch.Generator()
-    g.set_state(state)
+    g.set_state(state.clone())              # (a row VIEW with a storage offset crashes Generator.set_state on torch 2.10)
     torch.randn(out.numel(), generator=g, out=out)
+
+
+def _draw_many(recs, outs):
+    for st, o in zip(recs, outs):
+        _draw(st, o)
+
+
+def _self_check():
+    """The three private facts this module rests on, checked against plain `torch.randn` calls on a private generator:
+    the state layout (a derived state reproduces the engine), one call per element with aligned groups of 16 (a block
+    equals its segments drawn separately), and one (T * n) draw == T successive n-element draws."""
+    try:
+        g = torch.Generator()
+        g.manual_seed(20240917)
+        torch.randn(37, generator=g)                                    # somewhere inside a 624-word block
+        s0 = g.get_state()
+        if not _layout_known(s0):
+            return False
+        n, cut = 2048, [0, 624 - 32, 1248, 2048]
+        want = torch.randn(n, generator=g)
+        end = g.get_state()
+        recs = states_at(s0, cut)
+        got = torch.empty(n)
+        for a, b, st in zip(cut[:-1], cut[1:], recs):
+            _draw(st, got[a:b])
+        if not torch.equal(got, want) or not torch.equal(recs[-1], end):
+            return False
+        g.set_state(s0)
+        steps = torch.cat([torch.randn(32 * 4, generator=g) for _ in range(16)])
+        return bool(torch.equal(steps, want))
+    except Exception:                                                   # noqa: BLE001 -- any surprise = do not trust it
+        return False
+
+
+def fast_path_ok():
+    """True when this torch build's CPU generator behaves as the derived-state draws assume (checked once)."""
+    global _checked
+    if _checked is None:
+        _checked = _self_check()
+        if not _checked:
+            _log.warning("torchrl_amd.collector.noise: this torch build's CPU generator does not match the layout / block "
+                         "structure the parallel reference-noise draw relies on; falling back to plain per-step torch.randn "
+                         "calls (same values, one host thread, no prefetch)")
+    return _checked
+
+
+def draw_block(state0, out, n_chunks=1, stride=None, offset=0, threads=None):
+    """Fill the flat float32 CPU tensor `out` (n_chunks * L elements) with chunk t = elements
+    [t * stride + offset, t * stride + offset + L) of the normal_() stream that starts at generator state `state0`, and
+    return the state after n_chunks * stride elements (stride defaults to L: one contiguous block).  L, stride and offset
+    must be multiples of 16.  Does not touch the default generator; any thread may call it."""
+    n = out.numel()
+    flat = out.view(-1)
+    if n_chunks < 1 or n % n_chunks:
+        raise _C.TrlError("draw_block: %d elements do not split into %d chunks" % (n, n_chunks))
+    L = n // n_chunks
+    stride = L if stride is None else int(stride)
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.device.type != "cpu":
+        raise _C.TrlError("draw_block: a contiguous float32 CPU tensor is required")
+    if L % 16 or stride % 16 or offset % 16 or L < 16 or offset + L > stride:
+        raise _C.TrlError("draw_block: chunk length %d / stride %d / offset %d must be multiples of 16 (chunk inside stride)"
+                          % (L, stride, offset))
+    threads = default_threads() if threads is None else max(1, int(threads))
+    if stride == L:                                                     # contiguous: cut into one segment per thread
+        parts = threads if n >= MIN_PARALLEL else 1
+        seg = (-(-n // parts) + 15) // 16 * 16
+        starts = list(range(0, n, seg))
+        pieces = [(a, a, min(a + seg, n)) for a in starts]             # (stream position, out start, out end)
+    else:
+        pieces = [(t * stride + offset, t * L, (t + 1) * L) for t in range(n_chunks)]
+    end_pos = n_chunks * stride
+    STATS["blocks"] += 1
+    STATS["pieces"] += len(pieces)
+    if len(pieces) == 1 or threads == 1:
+        recs = states_at(state0, [p[0] for p in pieces] + [end_pos])
+        _draw_many(recs[:-1], [flat[a:b] for _, a, b in pieces])
+        return recs[-1].clone()
+    STATS["parallel_blocks"] += 1
+    pool = _executor(threads)
+    jobs, state, at = [], state0, 0
+    # the pass over the stream is sequential; its states are handed out in groups so that the draws of one group run while
+    # the next group's states are derived
+    group = max(_GROUP_CHUNKS, -(-len(pieces) // 64))
+    for g0 in range(0, len(pieces), group):
+        part = pieces[g0:g0 + group]
+        last = g0 + group >= len(pieces)
+        pos = [p[0] - at for p in part] + [(end_pos if last else pieces[g0 + group][0]) - at]
+        recs = states_at(state, pos)
+        per = -(-len(part) // threads)
+        for k in range(0, len(part), per):
+            jobs.append(pool.submit(_draw_many, recs[k:k + per], [flat[a:b] for _, a, b in part[k:k + per]]))
+        state, at = recs[-1], at + pos[-1]
+    for j in jobs:
+        j.result()
+    return state.clone()
 
 
 def randn_into(out, threads=None):
     """Fill the contiguous float32 CPU tensor `out` with what `torch.randn(out.shape)` would return from the default CPU
-    generator, and leave that generator in the state the single call would leave it in."""
+    generator, and leave that generator in the state the single call would leave it in.  Main thread only (it reads and
+    sets the default generator)."""
     n = out.numel()
     flat = out.view(-1)
     threads = default_threads() if threads is None else int(threads)
     if out.dtype != torch.float32 or not out.is_contiguous() or out.device.type != "cpu":
         raise _C.TrlError("randn_into: a contiguous float32 CPU tensor is required")
-    if threads <= 1 or n < MIN_PARALLEL or n % 16 != 0:
+    if threads <= 1 or n < MIN_PARALLEL or n % 16 != 0 or not fast_path_ok():
         torch.randn(n, out=flat)
         return out
-    bounds, states = segment_states(torch.get_rng_state(), n, threads)
-    pool = _executor(threads)
-    jobs = [pool.submit(_draw, states[p], flat[bounds[p]:bounds[p + 1]]) for p in range(len(bounds) - 1)]
-    for j in jobs:
-        j.result()
-    torch.set_rng_state(states[-1])
+    torch.set_rng_state(draw_block(torch.get_rng_state(), flat, threads=threads))
+    return out
+
+
+def shard_ok(n_local, n_total, e0, a_dim):
+    """Can the rank that owns envs [e0, e0 + n_local) of n_total draw its rows of each step's (n_total, A) tensor on its
+    own?  (Chunk, stride and offset multiples of 16, and the self-check passed.)"""
+    L, S, off = n_local * a_dim, n_total * a_dim, e0 * a_dim
+    return L >= 16 and L % 16 == 0 and S % 16 == 0 and off % 16 == 0 and off + L <= S and fast_path_ok()
+
+
+def randn_shard_into(out, n_steps, n_local, n_total, e0, a_dim, threads=None):
+    """`out` (n_steps, n_local, A): rows [e0, e0 + n_local) of n_steps successive `torch.randn(n_total, A)` draws from the
+    default CPU generator, which is left where those n_steps draws would leave it.  Main thread only."""
+    if not shard_ok(n_local, n_total, e0, a_dim):
+        raise _C.TrlError("randn_shard_into: shard not aligned to the generator's blocks of 16")
+    end = draw_block(torch.get_rng_state(), out.view(-1), n_chunks=n_steps, stride=n_total * a_dim, offset=e0 * a_dim,
+                     threads=threads)
+    torch.set_rng_state(end)
     return out

@@ -47,11 +47,16 @@ class _NoisePrefetcher:
     update that precedes the rollout.  (`staged = False`: a copy command on the rollout's own stream, in front of it.)  The
     draw depends on nothing the GPU produces, so the stream of values is the un-prefetched one, bit for bit.
 
-    Guard: the generator state right after the prefetched draw is remembered; if the state found at `take` differs --
-    someone seeded the generator or drew from it in between -- the prefetched block is dropped and the block is drawn
-    in place from the current state, exactly like the un-prefetched path (for a re-seed that IS the reference order).
-    `close()` (or a shape change) drops a pending block the same way and rewinds the generator to where it was before
-    the speculative draw, so an abandoned prefetch leaves no trace in the stream."""
+    Guard: the worker draws from PRIVATE generators started at the state `_start` snapshotted on the main thread
+    (collector/noise.py::draw_block) -- the default generator is read and set on the main thread only, in `take`.  A
+    prefetched block is accepted when the default generator is still in the snapshotted state; the generator is then set
+    to the end-of-block state, exactly where the in-place draws would leave it.  If the state differs -- someone seeded
+    the generator or drew from it in between -- the block is dropped and drawn in place from the current state (for a
+    re-seed that IS the reference order).  The default generator is never advanced speculatively, so `close()` or a
+    shape change only has to wait for the worker: an abandoned prefetch leaves no trace in the stream.
+
+    Env shards on several ranks: `layout = (n_total, e0)` -- the block is this rank's rows [e0, e0 + N) of every step's
+    (n_total, A) draw, T chunks of the stream (noise.py), and the end-of-block state is the one after ALL ranks' rows."""
 
     def __init__(self, device):
         import threading
@@ -68,6 +73,8 @@ class _NoisePrefetcher:
         # (trl_rollout_t.stage_*): per slot a page-locked {ready, ack} pair and a device {stamp, counter} pair
         self.carry = True
         self.wait_for_draw = False                         # test aid: publish the next block BEFORE the carrying launch goes out
+        self.draw_threads = None                           # host threads per block (None: noise.default_threads())
+        self.dropped_blocks = 0                            # prefetched blocks discarded because the generator had moved
         self.transport_counts = {"carried": 0, "staged": 0, "stream": 0}
         self._ctl, self._stg_state = {}, {}
         self._carrier = None                               # dict(id, key, event): the launch that carries the pending block
@@ -82,13 +89,17 @@ class _NoisePrefetcher:
             self._dev[key] = torch.empty(shape, device=self.device)
         return self._host[key], self._dev[key]
 
-    def _draw_into(self, shape, slot):
-        """Draw into the page-locked buffer of `slot` (host work only: the worker thread never talks to the HIP runtime)."""
+    def _draw_into(self, shape, slot, layout, state0):
+        """Draw into the page-locked buffer of `slot` from generator state `state0`; returns the end-of-block state.  Host
+        work only, on private generators: the worker thread never talks to the HIP runtime or to the default generator."""
         host, _ = self._buffers(shape, slot)
+        T, n, a_dim = shape
+        n_total, e0 = layout
         # one (T * N, A) draw == T successive (N, A) draws when N * A is a multiple of 16 (see _host_noise); the block itself
         # is produced by several host threads, each starting from the engine state at its segment (collector/noise.py)
-        noise.randn_into(host)
-        return slot
+        if n_total == n:
+            return noise.draw_block(state0, host, threads=self.draw_threads)
+        return noise.draw_block(state0, host, n_chunks=T, stride=n_total * a_dim, offset=e0 * a_dim, threads=self.draw_threads)
 
     def _upload(self, shape, slot, stream):
         """Page-locked block -> device.  Returns (device tensor, gate): gate = (flag tensor, stamp) the rollout has to
@@ -134,8 +145,8 @@ class _NoisePrefetcher:
             if job is None:
                 return
             try:
-                job["out"] = self._draw_into(job["shape"], job["slot"])
-                job["state1"] = torch.get_rng_state()
+                job["state1"] = self._draw_into(job["shape"], job["slot"], job["layout"], job["state0"])
+                job["out"] = job["slot"]
                 ctl = self._ctl.get((job["shape"], job["slot"]))
                 if ctl is not None:
                     ctl[0] = job["id"]                      # the block is complete: the stagers of the carrying launch may go
@@ -143,7 +154,7 @@ class _NoisePrefetcher:
                 job["error"] = exc
             job["done"].set()
 
-    def _start(self, shape):
+    def _start(self, shape, layout):
         import queue
         import threading
         if getattr(self, "_thread", None) is None:
@@ -160,18 +171,15 @@ class _NoisePrefetcher:
         if self.staged and self.carry and (shape, slot) not in self._ctl:
             self._ctl[(shape, slot)] = torch.zeros(2, dtype=torch.int32).pin_memory()
             self._stg_state[(shape, slot)] = torch.zeros(2, dtype=torch.int32, device=self.device)
-        job = {"shape": shape, "slot": slot, "state0": torch.get_rng_state(), "state1": None, "out": None, "error": None,
-               "done": threading.Event(), "id": self._ids}
+        job = {"shape": shape, "layout": layout, "slot": slot, "state0": torch.get_rng_state(), "state1": None, "out": None,
+               "error": None, "done": threading.Event(), "id": self._ids}
         self._job = job
         self._queue.put(job)
 
-    def _drop(self, rewind):
+    def _drop(self):
         job, self._job = self._job, None
-        if job is None:
-            return
-        job["done"].wait()
-        if rewind and job["state1"] is not None and torch.equal(torch.get_rng_state(), job["state1"]):
-            torch.set_rng_state(job["state0"])             # nobody drew after the speculative block: give it back
+        if job is not None:
+            job["done"].wait()                              # (the default generator never moved: nothing to give back)
 
     def _carried_ok(self, job):
         """Did the launch that carried `job`'s block stage it?  (Its stagers acknowledge in page-locked memory.)"""
@@ -199,21 +207,30 @@ class _NoisePrefetcher:
         self._carrier = {"id": request["id"], "key": request["key"], "event": ev}
         self._free[request["key"]] = ev                     # (that launch reads the page-locked block)
 
-    def take(self, n_steps, n, a_dim, stream):
+    def take(self, n_steps, n, a_dim, stream, layout=None):
         """(device block, slot, gate, request): gate = (flag tensor, stamp) the rollout must wait for (None: the block is
-        stream-ordered in front of it); request (or None) = what the rollout launch shall stage for the NEXT call."""
+        stream-ordered in front of it); request (or None) = what the rollout launch shall stage for the NEXT call.
+        layout = (n_total, e0): this rank's env block within the per-step draw for all envs (default: all of it)."""
         shape = (int(n_steps), int(n), int(a_dim))
+        layout = (int(n), 0) if layout is None else (int(layout[0]), int(layout[1]))
         job = self._job
         out = None
+        cur = torch.get_rng_state()
         if job is not None:
             job["done"].wait()
             self._job = None
             if job["error"] is not None:
                 raise job["error"]
-            if job["shape"] == shape and torch.equal(torch.get_rng_state(), job["state1"]):
+            if job["shape"] == shape and job["layout"] == layout and torch.equal(cur, job["state0"]):
                 out = used = job["slot"]
-            elif torch.equal(torch.get_rng_state(), job["state1"]):
-                torch.set_rng_state(job["state0"])         # other shape, untouched generator: undo the speculative draw
+                torch.set_rng_state(job["state1"])         # where the in-place draws of this block leave the generator
+            else:
+                self.dropped_blocks += 1                   # the generator moved (or the shape changed): draw in place below
+                if self.dropped_blocks == 1:
+                    import logging
+                    logging.getLogger("torchrl_amd").info(
+                        "exploration-noise prefetch: the CPU generator was used or re-seeded between two rollouts (or the "
+                        "rollout shape changed); that block is drawn in place, in the reference's order")
         if out is not None and self._carried_ok(job):
             dev, gate = self._buffers(shape, used)[1], (self._stg_state[(shape, used)], job["id"])
             self._carrier = None
@@ -226,10 +243,10 @@ class _NoisePrefetcher:
                 free = self._free.get((shape, used))
                 if free is not None:
                     free.synchronize()
-                self._draw_into(shape, used)
+                torch.set_rng_state(self._draw_into(shape, used, layout, cur))
             dev, gate = self._upload(shape, used, stream)
             self.transport_counts["staged" if gate is not None else "stream"] += 1
-        self._start(shape)                                  # the next block, under this iteration's device work
+        self._start(shape, layout)                          # the next block, under this iteration's device work
         request = None
         nxt = self._job
         if self.wait_for_draw and nxt is not None:
@@ -242,7 +259,7 @@ class _NoisePrefetcher:
         return dev, used, gate, request
 
     def close(self):
-        self._drop(rewind=True)
+        self._drop()
 
 
 class VecOnPolicyCollector(VecCollector):
@@ -255,7 +272,8 @@ class VecOnPolicyCollector(VecCollector):
         self._check_shapes()
 
     def stop_noise_prefetch(self):
-        """Drop a speculatively drawn block and rewind the CPU generator to where the un-prefetched path would be."""
+        """Drop a speculatively drawn block (the CPU generator was never advanced for it: it already is where the
+        un-prefetched path would be)."""
         if self._prefetcher is not None:
             self._prefetcher.close()
 
@@ -389,27 +407,46 @@ class VecOnPolicyCollector(VecCollector):
             # log pi_old written by the kernel covers the whole ring only for a full-ring launch
             buf._old_logp_fresh = (n_steps == buf._max_replay_buffer_size)
 
+    def _noise_layout(self, env):
+        """(n_total, e0): the env block [e0, e0 + N) this rank owns of the n_total envs whose (n_total, A) noise tensor the
+        reference draws per step (distribution.py:60-76)."""
+        n, w = env.env_nums, dist.world_size()
+        if w == 1:
+            return n, 0
+        return int(getattr(env, "total_env_nums", n * w)), int(getattr(env, "index_offset", dist.rank() * n))
+
     def _host_noise(self, n_steps, env):
         """The reference's CPU stream, step by step; with env shards on several ranks, this rank's rows of each draw."""
         A = self._dims[1]
-        make = lambda m, f: torch.randn(m, f)
         n = env.env_nums
-        if dist.world_size() == 1 and (n * A) % 16 == 0:
+        n_total, e0 = self._noise_layout(env)
+        if n_total == n and (n * A) % 16 == 0 and noise.fast_path_ok():
             # torch's CPU normal_ draws its uniforms sequentially over the whole tensor and transforms them in blocks of
             # 16, so ONE (n_steps * N, A) draw is bit-identical to n_steps successive (N, A) draws whenever N * A is a
-            # multiple of 16 (checked on torch 2.10: equal for 2048 x 6 and 8 x 6, different for 7 x 6) -- a third of the
+            # multiple of 16 (noise.fast_path_ok() checks it on this torch build) -- a third of the
             # host time of the per-step loop; the block is cut into segments that several host threads draw at once, each from
             # the engine state at its first element (collector/noise.py: same values, same generator state afterwards)
             block = noise.randn_into(torch.empty(n_steps * n, A))
             return block.view(n_steps, n, A).to(env.device, non_blocking=True).contiguous()
+        if n_total != n and noise.shard_ok(n, n_total, e0, A):
+            # env shards: only this rank's rows of every step's (n_total, A) draw are produced -- from the engine state at
+            # their position in the stream -- and the generator ends where the draws for ALL envs would leave it
+            block = noise.randn_shard_into(torch.empty(n_steps, n, A), n_steps, n, n_total, e0, A)
+            return block.to(env.device, non_blocking=True).contiguous()
+        make = lambda m, f: torch.randn(m, f)
         draws = [dist.shard_rows_of_global(make, 1, n, A, "cpu").cpu() for _ in range(n_steps)]
         return torch.stack(draws).to(env.device, non_blocking=True).contiguous()
 
     def _can_prefetch(self, n_steps):
-        """Prefetch covers what the one-block draw covers: one rank, N * A a multiple of 16 (see _host_noise), and whole
-        rollouts (a one-step take_actions keeps the per-step draw)."""
-        return (self.prefetch_noise and dist.world_size() == 1 and n_steps > 1
-                and (self.env.env_nums * self._dims[1]) % 16 == 0)
+        """Prefetch covers what the derived-state draws cover: this rank's block of every step's draw aligned to the
+        generator's groups of 16 (see _host_noise), and whole rollouts (a one-step take_actions keeps the per-step draw)."""
+        if not self.prefetch_noise or n_steps <= 1:
+            return False
+        n, A = self.env.env_nums, self._dims[1]
+        n_total, e0 = self._noise_layout(self.env)
+        if n_total == n:
+            return (n * A) % 16 == 0 and noise.fast_path_ok()
+        return noise.shard_ok(n, n_total, e0, A)
 
     # ---- per-step launch sequence: envs with a running observation normaliser ----
     def _step_buffers(self, env):
@@ -548,9 +585,11 @@ class VecOnPolicyCollector(VecCollector):
             if self._prefetcher is None:
                 self._prefetcher = _NoisePrefetcher(self.env.device)
             stream = torch.cuda.current_stream(self.env.device)
-            noise, slot, gate, request = self._prefetcher.take(n_steps, self.env.env_nums, self._dims[1], stream)
+            noise, slot, gate, request = self._prefetcher.take(n_steps, self.env.env_nums, self._dims[1], stream,
+                                                               layout=self._noise_layout(self.env))
         else:
             noise, gate, request = (self._host_noise(n_steps, self.env) if self.noise_mode == "host" else None), None, None
+        self._noise_gated = gate is not None
         self._launch(self.env, n_steps, True, False, noise, publish=True, noise_gate=gate, stage=request)
         if slot is not None:
             stream = torch.cuda.current_stream(self.env.device)
@@ -561,6 +600,11 @@ class VecOnPolicyCollector(VecCollector):
         self.current_ob = self.env.cur_obs
 
     def _rendezvous_check(self):
+        if getattr(self, "_noise_gated", False) and self.train_epoch_reward != self.train_epoch_reward:
+            # the kernel poisons the epoch reward when its wait for the staged noise block times out (k_rollout.hip): that
+            # rollout read a stale block -- an error, not data (the reference stops on NaN too, collector/on_policy.py:102-107)
+            raise _C.TrlError("rollout: NaN epoch reward -- the staged exploration-noise block never arrived (stamp wait "
+                              "timed out) or the policy produced NaN actions; the collected rollout must not be trained on")
         if getattr(self, "_check_rendezvous", False):
             self._check_rendezvous = False
             if int(self._norm_ws[:2].view(torch.int32)[2].item()) != 0:

@@ -1,6 +1,7 @@
 // Host-side glue: thread-local error string + ABI version.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 #include "../../include/trl_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -51,5 +52,38 @@ extern "C" int trl_mt19937_advance(uint32_t* state, int32_t* left, int64_t* next
     lf = 624; nx = 1; k -= 1;
   }
   *left = lf; *next = nx;
+  return TRL_OK;
+}
+
+// K engine states of ONE stream in one call: record k = the generator-state image `tmpl` (state_bytes bytes; engine fields at
+// off_left (int32) / off_next (int64) / off_mt (624 x uint64, torch's CPUGeneratorImplState)) moved forward to engine call
+// pos[k] (ascending, relative to tmpl).  With env shards on several ranks, rank r needs the states at t * N_total * A +
+// r * N_local * A for every step t of a rollout (its rows of each step's (N_total, A) draw, distribution.py:60-76) plus the
+// state at the end of the block: one pass over the stream, no Python per record.
+extern "C" int trl_mt19937_states_at(const uint8_t* tmpl, int64_t state_bytes, int64_t off_left, int64_t off_next,
+                                     int64_t off_mt, const int64_t* pos, int64_t K, uint8_t* out) {
+  if (!tmpl || !pos || !out || K < 0 || off_left < 0 || off_next < 0 || off_mt < 0 || off_left + 4 > state_bytes ||
+      off_next + 8 > state_bytes || off_mt + 624 * 8 > state_bytes) {
+    trl_set_error("trl_mt19937_states_at: bad arguments (state_bytes %lld, K %lld)", (long long)state_bytes, (long long)K);
+    return TRL_EINVAL;
+  }
+  uint32_t st[624];
+  int32_t left;
+  int64_t next;
+  memcpy(&left, tmpl + off_left, 4);
+  memcpy(&next, tmpl + off_next, 8);
+  for (int i = 0; i < 624; ++i) { uint64_t w; memcpy(&w, tmpl + off_mt + 8 * i, 8); st[i] = (uint32_t)w; }
+  int64_t at = 0;
+  for (int64_t k = 0; k < K; ++k) {
+    if (pos[k] < at) { trl_set_error("trl_mt19937_states_at: positions must ascend (pos[%lld])", (long long)k); return TRL_EINVAL; }
+    int rc = trl_mt19937_advance(st, &left, &next, pos[k] - at);
+    if (rc != TRL_OK) return rc;
+    at = pos[k];
+    uint8_t* rec = out + k * state_bytes;
+    memcpy(rec, tmpl, (size_t)state_bytes);
+    memcpy(rec + off_left, &left, 4);
+    memcpy(rec + off_next, &next, 8);
+    for (int i = 0; i < 624; ++i) { uint64_t w = st[i]; memcpy(rec + off_mt + 8 * i, &w, 8); }
+  }
   return TRL_OK;
 }
