@@ -493,6 +493,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl"],
+                    help="multi-rank exchange of the 44 KB gradient / statistics: peer = xGMI-mapped buffers inside the "
+                         "fold launch (fail if the self-check does not pass), rccl = all-reduce calls, auto = peer when its "
+                         "self-check passes on every rank, else rccl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg 3 / cfg 5 epochs and the peak calibration")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -542,9 +546,14 @@ def main():
         # single-process one.  Otherwise: RCCL all-reduces, captured into the graph only after child processes have
         # shown that graph-captured collectives work on this node (TRL_GRAPH_COLLECTIVES overrides the probe).
         from torchrl_amd import dist as _dist
+        if args.transport == "rccl":
+            os.environ["TRL_NO_PEER"] = "1"
         peers = _dist.init_comm(torch.device("cuda", local_dev))
+        comm_info["transport_requested"] = args.transport
         comm_info["peer_self_check"] = "passed on every rank" if peers else \
-            ("disabled (TRL_NO_PEER=1)" if os.environ.get("TRL_NO_PEER") == "1" else "failed or unavailable")
+            ("disabled (--transport rccl / TRL_NO_PEER=1)" if os.environ.get("TRL_NO_PEER") == "1" else "failed or unavailable")
+        if args.transport == "peer" and not peers:
+            raise SystemExit("--transport peer: the peer-mapped transport did not pass its self-check on every rank")
         log("peer transport: %s" % ("up (self-check passed on every rank)" if peers else "unavailable -> all-reduce calls"))
         if not peers and "TRL_GRAPH_COLLECTIVES" not in os.environ:
             if backend == "nccl":
@@ -591,10 +600,13 @@ def main():
                 agent.logger.drain()                                      # (check_comm runs where the statistics are read)
                 torch.cuda.synchronize()
         except Exception as exc:                                          # noqa: BLE001 -- anything: fall back, loudly
-            log("peer transport failed in the first iterations: %r" % (exc,))
+            log("peer transport failed in the first iterations on rank %d (iteration %d): %r; comm error word %s"
+                % (rank, epoch[0], exc, dist.comm_error_detail()))
             ok = 0.0
         vote = torch.tensor([ok], device=dev)
         td.all_reduce(vote, op=td.ReduceOp.MIN)
+        if vote.item() != 1.0 and args.transport == "peer":
+            raise SystemExit("--transport peer: a guarded iteration failed on some rank (see the rank logs)")
         if vote.item() != 1.0:
             log("falling back to all-reduce calls on every rank")
             comm_info["guarded_iterations"] = "failed on some rank -> fell back to all-reduce calls"
@@ -661,7 +673,14 @@ def main():
     # (collector/on_policy.py::_NoisePrefetcher; bit-identical buffers and parameters to the in-place draws,
     # tests/test_noise_prefetch_gpu.py).  Timed with the same protocol; it is the headline when it costs <= PARITY_SLACK.
     device_elapsed, parity_elapsed = elapsed, None
-    if world == 1:
+    col.noise_mode, col.prefetch_noise = "host", True
+    can_parity = col._can_prefetch(T)                                   # this rank's rows of every step's draw, from derived states
+    col.noise_mode, col.prefetch_noise = "device", False
+    if dist.initialized():                                              # every rank takes the same route
+        flag = torch.tensor([1.0 if can_parity else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce_max_(flag.neg_())
+        can_parity = float(flag.item()) == -1.0
+    if can_parity:
         col.noise_mode, col.prefetch_noise = "host", True
         run_iterations(5, True)                                            # (first block drawn in place, pipeline primed)
         gc.collect()
@@ -671,13 +690,15 @@ def main():
         log("per-iteration ms: " + " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip(pmarks[:-1], pmarks[1:])))
         col.stop_noise_prefetch()
         col.noise_mode, col.prefetch_noise = "device", False
-        if parity_elapsed <= PARITY_SLACK * device_elapsed:
-            elapsed, infos_read = parity_elapsed, pread
-    headline_parity = parity_elapsed is not None and elapsed == parity_elapsed
-    if dist.initialized():
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist.initialized():                                              # MAX over ranks of both timings, then ONE decision
+        tmax = torch.tensor([device_elapsed, parity_elapsed if parity_elapsed is not None else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce_max_(tmax)
-        elapsed = float(tmax.item())
+        device_elapsed = float(tmax[0].item())
+        parity_elapsed = float(tmax[1].item()) if parity_elapsed is not None else None
+    elapsed = device_elapsed
+    headline_parity = parity_elapsed is not None and parity_elapsed <= PARITY_SLACK * device_elapsed
+    if headline_parity:
+        elapsed, infos_read = parity_elapsed, pread
     coll_us = time_collectives(dist, dev) if (dist.initialized() and dist.collectives_active()) else None
 
     if rank != 0:
@@ -700,7 +721,9 @@ def main():
                    "envs_per_gpu": N_PER_GPU, "rollout_steps": T, "batch_per_gpu": BATCH_PER_GPU,
                    "opt_epochs": OPT_EPOCHS,
                    "exploration_noise": ("CPU torch generator = the reference's stream (bit-parity configuration), the next "
-                                         "rollout's block drawn by host threads while the device works") if headline_parity
+                                         "rollout's block drawn by host threads while the device works"
+                                         + ("" if world == 1 else "; every rank draws only its rows of each step's (N_total, A) "
+                                            "tensor, from the engine state at their position in the stream")) if headline_parity
                    else "device Philox4x32-10 keyed by the global env index",
                    "setup_iterations": setup,
                    "update_infos_read_in_timed_region": infos_read,
@@ -722,6 +745,11 @@ def main():
         out["config"]["process_group_backend"] = backend
         out["config"].update(comm_info)
         out["config"]["collective_us"] = coll_us
+        n_mb = OPT_EPOCHS * (N_PER_GPU * T // BATCH_PER_GPU)
+        out["config"]["exchanges_per_iteration"] = {
+            "c1_gradient_sum_44KB": n_mb, "c2_advantage_statistics": OPT_EPOCHS, "c3_logging_statistics": 1,
+            "note": "C1 inside the fold/clip/Adam launch on the peer transport; stand-alone costs in collective_us -- "
+                    "the 1 -> N curve decomposes as iteration(1 GPU) + %d x C1 + %d x C2 + C3 + time-skew waits" % (n_mb, OPT_EPOCHS)}
         if os.environ.get("TRL_BENCH_SPAWNED") == "1":
             out["config"]["launcher"] = "bench.py spawned its own ranks"
     if parity_elapsed is not None:

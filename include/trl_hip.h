@@ -403,6 +403,9 @@ int trl_comm_peer_ready(const trl_comm_t* comm);
 int trl_comm_peer_enable(trl_comm_t* comm, int on);   /* 0 after a failed self-check: everything takes the RCCL route */
 int trl_comm_has_rccl(const trl_comm_t* comm);
 int trl_comm_error(trl_comm_t* comm);
+/* what the first timed-out peer wait was waiting for: out[4] = {region (1 gradient, 2 statistics; 0 none), slot = the rank
+ * whose contribution was missing, epoch waited for, epoch tag found}; clears the record (diagnostics of a failed run). */
+int trl_comm_error_detail(trl_comm_t* comm, int32_t* out);
 int trl_comm_destroy(trl_comm_t* comm);
 /* buf <- SUM over ranks, in place, n floats (C1).  Peer transport up to 12 288 floats, RCCL beyond. */
 int trl_allreduce_sum_f32(float* buf, int64_t n, trl_comm_t* comm, void* stream);

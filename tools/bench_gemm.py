@@ -141,7 +141,33 @@ def clk_conv():
             print("  wg %3d: cycles %s" % (32 * wg, " ".join("%d" % c for c in cyc[1:])))
 
 
+def big():
+    """Large dense products (TRL_GEMM_TILE=64 / 128 pins the workgroup tile; TRL_LIB + TRL_LIB_LAX=1: an older build):
+    the three dense-layer GEMMs at 4096^3 / 8192 x 4096 x 4096 / 2048^3, and the vendor library's SGEMM as the yardstick."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    for M, K, N in ((4096, 4096, 4096), (2048, 2048, 2048), (8192, 4096, 4096), (4096, 1024, 1024)):
+        x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.02
+        y = _C.linear_fwd(x, w, None, _C.ACT_NONE)
+        ref = x @ w.t()
+        err = float((y - ref).abs().max() / ref.abs().max())
+        dy = torch.randn(M, N, device=dev)
+        ws = torch.empty(_C.lib().trl_linear_bwd_weight_workspace(M, K, N), device=dev)
+        dw = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
+        fl = 2.0 * M * K * N
+        t_f = timed(lambda: _C.linear_fwd(x, w, None, _C.ACT_NONE), 10)
+        t_i = timed(lambda: _C.linear_bwd_input(dy, y, 1, w), 10)
+        t_w = timed(lambda: _C.linear_bwd_weight(dy, y, 1, x, dw=dw, db=db, workspace=ws), 10)
+        t_l = timed(lambda: torch.mm(x, w.t()), 10)
+        print(json.dumps(dict(M=M, K=K, N=N, tile=os.environ.get("TRL_GEMM_TILE", "auto"), lib=os.path.basename(_C.LIB_PATH),
+                              fwd_tf=round(fl / t_f * 1e-6, 1), bwd_in_tf=round(fl / t_i * 1e-6, 1),
+                              bwd_w_tf=round(fl / t_w * 1e-6, 1), torch_mm_tf=round(fl / t_l * 1e-6, 1), rel_err=err)), flush=True)
+
+
 if __name__ == "__main__":
+    if "--big" in sys.argv:
+        big()
+        sys.exit(0)
     if "--grouped" in sys.argv:
         grouped()
         sys.exit(0)

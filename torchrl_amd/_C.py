@@ -147,6 +147,7 @@ SIGNATURES = {
     "trl_comm_peer_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "trl_comm_has_rccl": (C.c_int, [C.c_void_p]),
     "trl_comm_error": (C.c_int, [C.c_void_p]),
+    "trl_comm_error_detail": (C.c_int, [C.c_void_p, C.c_void_p]),
     "trl_comm_destroy": (C.c_int, [C.c_void_p]),
     "trl_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "trl_allreduce_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -273,7 +274,10 @@ def lib():
                 "libtrl_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `python torchrl_amd/build.py`. torchrl_amd has no CPU fallback." % LIB_PATH)
         handle = C.CDLL(LIB_PATH)
+        lax = os.environ.get("TRL_LIB_LAX") == "1"   # tools/ A/B runs against an older experimental build (TRL_LIB)
         for name, (res, args) in SIGNATURES.items():
+            if lax and not hasattr(handle, name):
+                continue
             fn = getattr(handle, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
         _lib = handle

@@ -162,6 +162,22 @@ extern "C" int trl_comm_error(trl_comm_t* c) {
   return v ? 1 : 0;
 }
 
+// What the first timed-out wait since the last call was waiting for: out[0] = region (1 gradient, 2 statistics; 0 = no
+// time-out recorded), out[1] = slot = the rank whose granules were missing, out[2] = epoch waited for, out[3] = epoch tag
+// found in the granule.  Clears the record; synchronises the device.
+extern "C" int trl_comm_error_detail(trl_comm_t* c, int32_t* out) {
+  if (!out) return TRL_EINVAL;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!c || !c->xr.ctl) return TRL_OK;
+  unsigned v[3] = {0, 0, 0};
+  if (hipMemcpy(v, c->xr.ctl + 8, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return TRL_EINVAL;
+  if (v[0]) {
+    out[0] = (int32_t)((v[0] - 1u) >> 8); out[1] = (int32_t)((v[0] - 1u) & 0xffu); out[2] = (int32_t)v[1]; out[3] = (int32_t)v[2];
+    (void)hipMemset(c->xr.ctl + 8, 0, sizeof(v));
+  }
+  return TRL_OK;
+}
+
 extern "C" int trl_comm_destroy(trl_comm_t* c) {
   if (!c) return TRL_OK;
   for (int r = 0; r < c->world; ++r)
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(256) void xr_allreduce_kernel(T* __restrict__ buf, 
     T acc = (T)0;
     for (int q = 0; q < x.world; ++q) {
 #pragma unroll
-      for (int k = 0; k < WORDS; ++k) u.w[k] = xr_wait(mine + xr_small_off(x.world, epoch, q, WORDS * i + k), epoch, x.ctl, x.wait_ticks);
+      for (int k = 0; k < WORDS; ++k) u.w[k] = xr_wait(mine + xr_small_off(x.world, epoch, q, WORDS * i + k), epoch, x.ctl, x.wait_ticks, 0x200u | (unsigned)q);
       acc = (q == 0) ? u.v : (is_max ? (u.v > acc ? u.v : acc) : acc + u.v);
     }
     buf[i] = acc;

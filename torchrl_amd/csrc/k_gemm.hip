@@ -21,12 +21,12 @@
 // never transposes.  MFMA step (q, r) of lane half `hi` takes k = 8q + 4hi + r.  Arbitrary M, N, K: slots that
 // are misaligned or cross an edge fall back to predicated scalar loads (zero fill).
 #include <algorithm>
+#include <stdlib.h>
 #include "trl_common.h"
 #include "trl_mlp.h"
 #include "trl_conv.h"
 
-#define KC 128                      // reduction panel
-#define LDK (KC + 4)                // [row][k] tile: 16-byte aligned rows, banks rotate by 4 per row
+#define KC 128                      // granule of split-reduction lengths (a multiple of every panel size below)
 
 // act'(y) expressed through the activation OUTPUT y (tanh: 1 - y^2, relu: y > 0, none: 1)
 __device__ __forceinline__ float dact_from_out(int act, float y) {
@@ -74,37 +74,45 @@ extern "C" int trl_dbg_gemm_clk(long long* out) {
 #define GCLK(ph)
 #endif
 
-// One operand panel: ROWS "rows" (the operand's C-side index; 32, 64 or 128) x KC reduction indices, held as
-// ROWS / 8 16-byte slots per thread.  CONTIG_K: element (r, k) lives at base[(row0 + r) * ld + k0 + k] and the LDS
-// tile is [ROWS][LDK]; otherwise it lives at base[(k0 + k) * ld + row0 + r] and the tile is [KC][ROWS + 8].  Slot t
-// of thread tid covers 4 consecutive elements of the contiguous dim.
-template <bool CONTIG_K, int ROWS>
+// One operand panel: ROWS "rows" (the operand's C-side index; 32, 64 or 128) x KP reduction indices (the panel size of
+// the instantiation: 64, or 32 for the 128 x 128 tile), held as ROWS * KP / 1024 16-byte slots per thread.  CONTIG_K:
+// element (r, k) lives at base[(row0 + r) * ld + k0 + k] and the LDS tile is [ROWS][KP + 4] (16-byte aligned rows, banks
+// rotate by 4 per row); otherwise it lives at base[(k0 + k) * ld + row0 + r] and the tile is [KP][ROWS + 8].  Slot t of
+// thread tid covers 4 consecutive elements of the contiguous dim.
+template <int KP> struct PanelGeom {
+  static constexpr int LD_K = KP + 4;               // row stride of a [row][k] tile
+  static constexpr int KT = KP / 4;                 // threads per row of a [row][k] tile
+  static constexpr int RP = 256 / KT;               // rows covered by one slot round of the 256 threads
+};
+template <bool CONTIG_K, int ROWS, int KP> __host__ __device__ constexpr int panel_slots() { return ROWS * KP / 1024; }
+template <bool CONTIG_K, int ROWS, int KP>
 __device__ __forceinline__ void panel_slot(int tid, int t, int& r, int& k) {
+  using G = PanelGeom<KP>;
   constexpr int TPR = ROWS / 4;                    // threads per reduction row of a [k][row] tile
-  if (CONTIG_K) { r = 8 * t + (tid >> 5); k = 4 * (tid & 31); }
+  if (CONTIG_K) { r = G::RP * t + tid / G::KT; k = 4 * (tid % G::KT); }
   else          { k = (256 / TPR) * t + tid / TPR; r = 4 * (tid % TPR); }
 }
 
 // whole panel in range and 16-byte loads legal: unconditional loads a fixed stride apart
-template <bool CONTIG_K, int ROWS>
+template <bool CONTIG_K, int ROWS, int KP>
 __device__ __forceinline__ void panel_fetch_fast(const float* __restrict__ base, int ld, int row0, int k0, int tid,
-                                                 f32x4 (&reg)[ROWS / 8]) {
+                                                 f32x4 (&reg)[ROWS * KP / 1024]) {
   int r, k;
-  panel_slot<CONTIG_K, ROWS>(tid, 0, r, k);
+  panel_slot<CONTIG_K, ROWS, KP>(tid, 0, r, k);
   const float* p = CONTIG_K ? base + (size_t)(row0 + r) * ld + k0 + k : base + (size_t)(k0 + k) * ld + row0 + r;
-  const size_t step = (size_t)(CONTIG_K ? 8 : 256 / (ROWS / 4)) * ld;
+  const size_t step = (size_t)(CONTIG_K ? PanelGeom<KP>::RP : 256 / (ROWS / 4)) * ld;
 #pragma unroll
-  for (int t = 0; t < ROWS / 8; ++t) reg[t] = *reinterpret_cast<const f32x4*>(p + t * step);
+  for (int t = 0; t < ROWS * KP / 1024; ++t) reg[t] = *reinterpret_cast<const f32x4*>(p + t * step);
 }
 
 // edge / misaligned panel: element-wise predicated loads, zero fill
-template <bool CONTIG_K, int ROWS>
+template <bool CONTIG_K, int ROWS, int KP>
 __device__ __forceinline__ void panel_fetch_edge(const float* __restrict__ base, int ld, int row0, int rows, int k0, int k_hi,
-                                                 int tid, f32x4 (&reg)[ROWS / 8]) {
+                                                 int tid, f32x4 (&reg)[ROWS * KP / 1024]) {
 #pragma unroll
-  for (int t = 0; t < ROWS / 8; ++t) {
+  for (int t = 0; t < ROWS * KP / 1024; ++t) {
     int r, k;
-    panel_slot<CONTIG_K, ROWS>(tid, t, r, k);
+    panel_slot<CONTIG_K, ROWS, KP>(tid, t, r, k);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int gr = row0 + r + (CONTIG_K ? 0 : j), gk = k0 + k + (CONTIG_K ? j : 0);
@@ -115,45 +123,61 @@ __device__ __forceinline__ void panel_fetch_edge(const float* __restrict__ base,
   }
 }
 
-template <bool CONTIG_K, int ROWS>
-__device__ __forceinline__ void panel_stash(float* tile, int tid, const f32x4 (&reg)[ROWS / 8]) {
+template <bool CONTIG_K, int ROWS, int KP>
+__device__ __forceinline__ void panel_stash(float* tile, int tid, const f32x4 (&reg)[ROWS * KP / 1024]) {
 #pragma unroll
-  for (int t = 0; t < ROWS / 8; ++t) {
+  for (int t = 0; t < ROWS * KP / 1024; ++t) {
     int r, k;
-    panel_slot<CONTIG_K, ROWS>(tid, t, r, k);
-    *reinterpret_cast<f32x4*>(tile + (CONTIG_K ? r * LDK + k : k * (ROWS + 8) + r)) = reg[t];
+    panel_slot<CONTIG_K, ROWS, KP>(tid, t, r, k);
+    *reinterpret_cast<f32x4*>(tile + (CONTIG_K ? r * PanelGeom<KP>::LD_K + k : k * (ROWS + 8) + r)) = reg[t];
   }
 }
 
 // the 4 operand values of MFMA steps (q, 0..3) for C-side index `row` of this lane half
-template <bool CONTIG_K, int ROWS>
+template <bool CONTIG_K, int ROWS, int KP>
 __device__ __forceinline__ f32x4 panel_operand(const float* tile, int row, int q, int hi) {
-  if (CONTIG_K) return *reinterpret_cast<const f32x4*>(tile + row * LDK + 8 * q + 4 * hi);
+  if (CONTIG_K) return *reinterpret_cast<const f32x4*>(tile + row * PanelGeom<KP>::LD_K + 8 * q + 4 * hi);
   constexpr int LD = ROWS + 8;                     // rows k and k + 4 (the two lane halves) are 32 banks apart
   const float* p = tile + (8 * q + 4 * hi) * LD + row;
   f32x4 v = {p[0], p[LD], p[2 * LD], p[3 * LD]};
   return v;
 }
 
-template <bool CONTIG_K, int ROWS>
-__host__ __device__ constexpr int tile_floats() { return CONTIG_K ? ROWS * LDK : KC * (ROWS + 8); }
+template <bool CONTIG_K, int ROWS, int KP>
+__host__ __device__ constexpr int tile_floats() { return CONTIG_K ? ROWS * (KP + 4) : KP * (ROWS + 8); }
+
+// panel size of an instantiation: 64 reduction indices (32 MFMAs per wave and barrier), 32 for the 2 x 2-block wave tile
+// (64 MFMAs per wave and barrier) -- two panel buffers of either fit twice into a CU's 160 KB (two workgroups per CU)
+template <int TMB> __host__ __device__ constexpr int gemm_panel() { return TMB == 2 ? 32 : 64; }
 
 // TA: A is stored [Kred][M] (we need A^T); TB: B is stored [N][K] (we need B^T).
 // GATE: activation whose derivative (through a_gate) multiplies operand A (TRL_ACT_NONE: no gate).
 // CONV: 0 both operands dense; 1 operand A (M x K, forward) is the implicit cols matrix of g.cv over uint8 NCHW
 // frames; 2 operand B (Kred x N, weight gradient) is; 3 / 4 the same over fp32 NHWC activations with the
 // reduction (3) or column (4) index in (i, j, c) order -- then B of 3 is the permuted view of the conv weight.
-// WM: waves along M.  The 4 waves (one 32x32 quadrant each) form a 64 x 64 C tile (WM = 2), a 128 x 32 one
-// (WM = 4, layers with <= 32 outputs: a 64-wide tile would compute 50-75 % padding) or a 32 x 128 one (WM = 1).
-template <bool TA, bool TB, int GATE, int CONV, int WM>
+// WM: waves along M.  TMB: 32 x 32 accumulator blocks per wave along each of M and N.  With TMB = 1 the 4 waves (one
+// quadrant each) form a 64 x 64 C tile (WM = 2), a 128 x 32 one (WM = 4, layers with <= 32 outputs: a 64-wide tile would
+// compute 50-75 % padding) or a 32 x 128 one (WM = 1); TMB = 2 (WM = 2 only) is the 128 x 128 tile of large products:
+// every operand value read from LDS feeds two MFMAs instead of one.
+//
+// Main loop (round 4): TWO panel buffers in LDS and ONE barrier per panel.  While the MFMAs of panel p run from buffer
+// p & 1, the registers that hold panel p + 1 (fetched one panel earlier) are written to the other buffer and the loads
+// of panel p + 2 are issued -- the register -> LDS hand-off and the global round trip both sit in the shadow of the
+// matrix pipe, where round 3's single buffer had `stash; barrier; fetch; MFMA; barrier` in series (0.64 of the measured
+// MFMA peak at 4096^3).  The k order of every output element is unchanged (panels ascending, k = 8 q + 4 hi + r inside),
+// so results are bit-identical to the one-buffer loop.
+template <bool TA, bool TB, int GATE, int CONV, int WM, int TMB = 1>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   static_assert(CONV == 0 || ((CONV == 1 || CONV == 3) && !TA && TB) || ((CONV == 2 || CONV == 4) && TA && !TB),
                 "implicit operand orientation");
+  static_assert(TMB == 1 || (TMB == 2 && WM == 2 && CONV == 0), "the 2 x 2-block wave tile is dense and square");
   constexpr bool CA = CONV == 1 || CONV == 3, CB = CONV == 2 || CONV == 4, U8 = CONV == 1 || CONV == 2;
-  constexpr int WN = 4 / WM, GM = 32 * WM, GN = 32 * WN, SA = GM / 8, SB = GN / 8;
+  constexpr int KP = gemm_panel<TMB>(), NQ = KP / 8;
+  using PG = PanelGeom<KP>;
+  constexpr int WN = 4 / WM, GM = 32 * WM * TMB, GN = 32 * WN * TMB;
+  constexpr int SA = panel_slots<!TA, GM, KP>(), SB = panel_slots<TB, GN, KP>();
+  constexpr int AF = tile_floats<!TA, GM, KP>(), BF = tile_floats<TB, GN, KP>();
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;
-  float* Bs = lds + tile_floats<!TA, GM>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Workgroups are dealt round-robin to the 8 XCDs: renumber so that each XCD owns a contiguous run of tiles
   // (the tiles_n tiles that share an A panel then share an L2).
@@ -192,9 +216,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   const bool b_whole = (g_ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(pB) & 15) == 0 && n0 + GN <= g_N;
   const bool want_colsum = TA && pColsum && tn == 0;
 
-  f32x16 acc;
+  f32x16 acc[TMB][TMB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int a = 0; a < TMB; ++a)
+#pragma unroll
+    for (int b = 0; b < TMB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
   f32x4 csum = {0.0f, 0.0f, 0.0f, 0.0f};          // TA: partial column sums of columns 4 * (tid % (GM / 4)) .. + 3
   f32x4 ra[SA], rg[SA], rb[SB];
   // Implicit operand.  fp32 NHWC: one 16-byte load per slot, same slot map as a dense panel (consecutive lanes read
@@ -204,25 +232,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   constexpr int SC = CA ? SA : SB;
   uint32_t cu[SC], cmask = 0u, cbase[SC], ctap = 0u;
   bool ctap_ok = false;
-  uint32_t* tap_tab = reinterpret_cast<uint32_t*>(Bs + tile_floats<TB, GN>());   // CONV == 1: tap offset of every k / 4
+  uint32_t* tap_tab = reinterpret_cast<uint32_t*>(lds + 2 * (AF + BF));          // CONV == 1: tap offset of every k / 4
   constexpr int GA = 256 / GM;                     // CONV == 1: thread = row tid % GM, slots k4 = tid / GM + GA * t
+  constexpr int GB = 256 / KP;                     // CONV == 2: thread = reduction row tid % KP, slots c4 = tid / KP + GB * t
   if (CONV == 1) {
     const int m = m0 + tid % GM;
     cbase[0] = m < g_M ? conv_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
     for (int e = tid; 4 * e < g_K; e += 256) tap_tab[e] = conv_tap_offset(g.cv, (uint32_t)(4 * e));
     __syncthreads();
   }
-  if (CONV == 2) {                                 // thread = reduction row tid % KC, column slots c4 = tid / KC + 2 * t
+  if (CONV == 2) {
 #pragma unroll
     for (int t = 0; t < SC; ++t) {
-      const int kc = n0 + 4 * (tid / KC + 2 * t);
+      const int kc = n0 + 4 * (tid / KP + GB * t);
       cbase[t] = kc < g_N ? conv_tap_offset(g.cv, (uint32_t)kc) : 0xffffffffu;   // here: the (fixed) tap offsets
     }
   }
   if (CONV == 3) {                                 // A rows are fixed for the whole kernel: decode them once
 #pragma unroll
     for (int t = 0; t < SC; ++t) {
-      const int m = m0 + 8 * t + (tid >> 5);
+      const int m = m0 + PG::RP * t + tid / PG::KT;
       cbase[t] = m < g_M ? nhwc_row_offset(g.cv, (uint32_t)m) : 0xffffffffu;
     }
   }
@@ -234,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
   auto fetch = [&](int k0) {
-    const bool k_whole = k0 + KC <= k_hi;          // uniform: one branch per operand per panel
+    const bool k_whole = k0 + KP <= k_hi;          // uniform: one branch per operand per panel
     if (CONV == 1) {
       cmask = 0u;
 #pragma unroll
@@ -245,7 +274,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
         cmask |= ok ? (1u << t) : 0u;
       }
     } else if (CONV == 3) {
-      const int kk = k0 + 4 * (tid & 31);
+      const int kk = k0 + 4 * (tid % PG::KT);
       const bool kin = kk < k_hi;
       const uint32_t tap = kin ? nhwc_tap_offset(g.cv, (uint32_t)kk) : 0u;
 #pragma unroll
@@ -254,14 +283,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
         ra[t] = ok ? *reinterpret_cast<const f32x4*>(cvx + (ok ? cbase[t] + tap : 0u)) : zero4;
       }
     } else if (a_whole && k_whole) {
-      panel_fetch_fast<!TA, GM>(pA, g_lda, m0, k0, tid, ra);
-      if (GATE != TRL_ACT_NONE && pGate) panel_fetch_fast<!TA, GM>(pGate, g_lda, m0, k0, tid, rg);
+      panel_fetch_fast<!TA, GM, KP>(pA, g_lda, m0, k0, tid, ra);
+      if (GATE != TRL_ACT_NONE && pGate) panel_fetch_fast<!TA, GM, KP>(pGate, g_lda, m0, k0, tid, rg);
     } else {
-      panel_fetch_edge<!TA, GM>(pA, g_lda, m0, g_M, k0, k_hi, tid, ra);
-      if (GATE != TRL_ACT_NONE && pGate) panel_fetch_edge<!TA, GM>(pGate, g_lda, m0, g_M, k0, k_hi, tid, rg);
+      panel_fetch_edge<!TA, GM, KP>(pA, g_lda, m0, g_M, k0, k_hi, tid, ra);
+      if (GATE != TRL_ACT_NONE && pGate) panel_fetch_edge<!TA, GM, KP>(pGate, g_lda, m0, g_M, k0, k_hi, tid, rg);
     }
     if (CONV == 2) {
-      const int m = k0 + tid % KC;
+      const int m = k0 + tid % KP;
       const bool row_ok = m < k_hi;
       const uint32_t row = row_ok ? conv_row_offset(g.cv, (uint32_t)m) : 0u;
       cmask = 0u;
@@ -281,34 +310,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
     } else if (CONV == 3) {
       // B = conv weight (Cout, C, kh, kw) read in the reduction order k' = (i, j, c): 4 consecutive k' are 4
       // consecutive channels of one tap, kh * kw floats apart
-      const int kk = k0 + 4 * (tid & 31);
+      const int kk = k0 + 4 * (tid % PG::KT);
       const uint32_t khw = (uint32_t)(g.cv.kh * g.cv.kw);
       const uint32_t ij = (uint32_t)kk / (uint32_t)g.cv.C, c = (uint32_t)kk - ij * g.cv.C;
       const uint32_t w0 = c * khw + ij;
 #pragma unroll
       for (int t = 0; t < SB; ++t) {
-        const int n = n0 + 8 * t + (tid >> 5);
+        const int n = n0 + PG::RP * t + tid / PG::KT;
         const bool ok = kk < k_hi && n < g_N;
         const float* wp = pB + (ok ? (size_t)n * g_ldb + w0 : 0);
         f32x4 v = {ok ? wp[0] : 0.0f, ok ? wp[khw] : 0.0f, ok ? wp[2 * khw] : 0.0f, ok ? wp[3 * khw] : 0.0f};
         rb[t] = v;
       }
-    } else if (b_whole && k_whole) panel_fetch_fast<TB, GN>(pB, g_ldb, n0, k0, tid, rb);
-    else                           panel_fetch_edge<TB, GN>(pB, g_ldb, n0, g_N, k0, k_hi, tid, rb);
+    } else if (b_whole && k_whole) panel_fetch_fast<TB, GN, KP>(pB, g_ldb, n0, k0, tid, rb);
+    else                           panel_fetch_edge<TB, GN, KP>(pB, g_ldb, n0, g_N, k0, k_hi, tid, rb);
   };
-  auto stash = [&]() {
+  auto stash = [&](int buf) {
+    float* As = lds + buf * (AF + BF);
+    float* Bs = As + AF;
     if (CONV == 1) {                               // uint8 slots go straight to their (row, k4) place
 #pragma unroll
       for (int t = 0; t < SC; ++t) {
         const f32x4 v = (cmask >> t) & 1u ? conv_unpack(cu[t], g.cv.scale, g.cv.shift) : zero4;
-        *reinterpret_cast<f32x4*>(As + (tid % GM) * LDK + 4 * (tid / GM + GA * t)) = v;
+        *reinterpret_cast<f32x4*>(As + (tid % GM) * PG::LD_K + 4 * (tid / GM + GA * t)) = v;
       }
     }
     if (CONV == 2) {
 #pragma unroll
       for (int t = 0; t < SC; ++t) {
         const f32x4 v = (cmask >> t) & 1u ? conv_unpack(cu[t], g.cv.scale, g.cv.shift) : zero4;
-        *reinterpret_cast<f32x4*>(Bs + (tid % KC) * (GN + 8) + 4 * (tid / KC + 2 * t)) = v;
+        *reinterpret_cast<f32x4*>(Bs + (tid % KP) * (GN + 8) + 4 * (tid / KP + GB * t)) = v;
       }
     }
     if (GATE != TRL_ACT_NONE && pGate) {             // (a problem of a mixed launch may come without a gate)
@@ -321,39 +352,90 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
 #pragma unroll
       for (int t = 0; t < SA; ++t) csum += ra[t];
     }
-    if (CONV != 1) panel_stash<!TA, GM>(As, tid, ra);
-    if (CONV != 2) panel_stash<TB, GN>(Bs, tid, rb);
+    if (CONV != 1) panel_stash<!TA, GM, KP>(As, tid, ra);
+    if (CONV != 2) panel_stash<TB, GN, KP>(Bs, tid, rb);
+  };
+  // the MFMAs of 8-k group q of the panel in buffer `buf`: TMB + TMB operand reads feed 4 TMB^2 MFMAs
+  auto group = [&](int buf, int q) {
+    const float* As = lds + buf * (AF + BF);
+    const float* Bs = As + AF;
+    f32x4 av[TMB], bv[TMB];
+#pragma unroll
+    for (int a = 0; a < TMB; ++a) av[a] = panel_operand<!TA, GM, KP>(As, 32 * (TMB * wm + a) + i, q, hi);
+#pragma unroll
+    for (int b = 0; b < TMB; ++b) bv[b] = panel_operand<TB, GN, KP>(Bs, 32 * (TMB * wn + b) + i, q, hi);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int a = 0; a < TMB; ++a)
+#pragma unroll
+        for (int b = 0; b < TMB; ++b) acc[a][b] = mfma32(av[a][r], bv[b][r], acc[a][b]);
   };
 
   GCLK(0)
-  if (k_lo < k_hi) fetch(k_lo);
-  GCLK(1)
-  for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
-    stash();
+  const int np = (k_hi - k_lo + KP - 1) / KP;      // panels of this workgroup's reduction range
+  // Dense interior tiles walk their WHOLE panels in a loop of their own that contains nothing but unconditional 16-byte
+  // loads, LDS traffic and MFMAs.  (With the predicated edge loads in the same loop body the compiler shares registers
+  // between their temporaries and the MFMA operands and, to keep that safe, waits for ALL outstanding loads at the top
+  // of every panel -- the prefetch distance shrinks from a whole panel to half of one.)  Edge tiles, the reduction's
+  // ragged tail and the implicit-operand modes take the general loop below.
+  const bool fast_ok = CONV == 0 && a_whole && b_whole;
+  const int nw = fast_ok ? (k_hi - k_lo) / KP : 0;
+  if (CONV == 0 && nw > 0) {
+    auto fetch_whole = [&](int k0) {
+      panel_fetch_fast<!TA, GM, KP>(pA, g_lda, m0, k0, tid, ra);
+      if (GATE != TRL_ACT_NONE && pGate) panel_fetch_fast<!TA, GM, KP>(pGate, g_lda, m0, k0, tid, rg);
+      panel_fetch_fast<TB, GN, KP>(pB, g_ldb, n0, k0, tid, rb);
+    };
+    fetch_whole(k_lo);
+    GCLK(1)
+    stash(0);
+    if (nw > 1) fetch_whole(k_lo + KP);
     __syncthreads();
-    GCLK(k0 == k_lo ? 2 : 4)
-    if (k0 + KC < k_hi) fetch(k0 + KC);            // the next panel's loads fly under this panel's MFMAs
-    const int nq4 = (min(KC, k_hi - k0) + 31) >> 5;   // 32 reduction indices per round (zero filled above k_hi)
-    for (int q4 = 0; q4 < nq4; ++q4) {
+    GCLK(2)
+    for (int p = 0; p < nw; ++p) {
+      const int cur = p & 1;
+      // half of the panel's MFMAs; panel p + 1: registers -> the idle buffer (last read before the previous barrier);
+      // panel p + 2: loads in flight across a whole panel; the other half
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const f32x4 av = panel_operand<!TA, GM>(As, 32 * wm + i, 4 * q4 + qq, hi);
-        const f32x4 bv = panel_operand<TB, GN>(Bs, 32 * wn + i, 4 * q4 + qq, hi);
+      for (int q = 0; q < NQ / 2; ++q) group(cur, q);
+      if (p + 1 < nw) stash(cur ^ 1);
+      if (p + 2 < nw) fetch_whole(k_lo + (p + 2) * KP);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma32(av[r], bv[r], acc);
-      }
+      for (int q = NQ / 2; q < NQ; ++q) group(cur, q);
+      __syncthreads();
+      GCLK(p == 0 ? 3 : 5)
     }
-    __syncthreads();
-    GCLK(k0 == k_lo ? 3 : 5)
   }
-  // ---- epilogue: lane (i, hi) owns column n of rows rowmap(0..15, hi) ----
-  {
-    const int n = n0 + 32 * wn + i, mb = m0 + 32 * wm + 4 * hi;
+  if (nw < np) {                                   // general loop: panels [nw, np), same pipeline, edge-capable loads
+    fetch(k_lo + nw * KP);
+    stash(nw & 1);
+    if (nw + 1 < np) fetch(k_lo + (nw + 1) * KP);
+    __syncthreads();
+    for (int p = nw; p < np; ++p) {
+      const int k0 = k_lo + p * KP, cur = p & 1;
+      // 8-k groups that hold data (the tail of the last panel is zero filled: skipping it changes no sum); rounded to the
+      // 32-k rounds of the one-buffer loop so that edge panels walk the same groups as before
+      const int nq = min(NQ, ((min(KP, k_hi - k0) + 31) >> 5) * 4);
+      const int half = min(nq, NQ / 2);
+      for (int q = 0; q < half; ++q) group(cur, q);
+      if (p + 1 < np) stash(cur ^ 1);
+      if (p + 2 < np) fetch(k0 + 2 * KP);
+      for (int q = half; q < nq; ++q) group(cur, q);
+      __syncthreads();
+    }
+  }
+  // ---- epilogue: lane (i, hi) owns column n of rows rowmap(0..15, hi) of each of the wave's blocks ----
+#pragma unroll
+  for (int ab = 0; ab < TMB; ++ab)
+#pragma unroll
+  for (int bb = 0; bb < TMB; ++bb) {
+    const int n = n0 + 32 * (TMB * wn + bb) + i, mb = m0 + 32 * (TMB * wm + ab) + 4 * hi;
     if (n < g_N) {
       const float bias = pBias ? pBias[n] : 0.0f;
       float v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[r] + bias;
+      for (int r = 0; r < 16; ++r) v[r] = acc[ab][bb][r] + bias;
       if (g.act == TRL_ACT_TANH) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = trl_tanh(v[r]);
@@ -399,7 +481,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   if (want_colsum) {
     // thread (tid / TPR, tid % TPR) holds partials of columns 4 * (tid % TPR) .. + 3: fold the row groups in order
     constexpr int TPR = GM / 4, GROUPS = 256 / TPR;
-    float* s = As;                                  // reuse (all MFMA reads are behind the last barrier)
+    float* s = lds;                                 // reuse (all MFMA reads are behind the last barrier)
     *reinterpret_cast<f32x4*>(s + (tid / TPR) * GM + 4 * (tid % TPR)) = csum;
     __syncthreads();
     if (tid < GM && m0 + tid < g_M) {
@@ -527,35 +609,49 @@ int trl_fold_partials(const float* part, float* out, int n, const float* part2, 
   return launch_fold(f, 1, stream);
 }
 
-template <bool TA, bool TB, int GATE, int CONV, int WM>
+template <bool TA, bool TB, int GATE, int CONV, int WM, int TMB = 1>
 static int launch_gemm_tile(GemmDev g, int splits, hipStream_t s) {
-  constexpr int GM = 32 * WM, GN = 32 * (4 / WM);
-  const int tiles_lds = (int)sizeof(float) * (tile_floats<!TA, GM>() + tile_floats<TB, GN>());
+  constexpr int KP = gemm_panel<TMB>();
+  constexpr int GM = 32 * WM * TMB, GN = 32 * (4 / WM) * TMB;
+  const int tiles_lds = 2 * (int)sizeof(float) * (tile_floats<!TA, GM, KP>() + tile_floats<TB, GN, KP>());   // two panel buffers
   const int lds = tiles_lds + (CONV == 1 ? g.K : 0);              // CONV 1: + the tap offset table (K / 4 dwords)
   TRL_REQUIRE(lds <= 160 * 1024, "reduction too long for the implicit first-layer kernel");
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE, CONV, WM>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE, CONV, WM, TMB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { trl_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_lds = lds;
   }
   g.tiles_n = trl_ceil_div(g.N, GN);
   g.tiles = g.tiles_n * trl_ceil_div(g.M, GM);
-  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE, CONV, WM>), dim3(g.tiles, std::max(1, g.groups), splits), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE, CONV, WM, TMB>), dim3(g.tiles, std::max(1, g.groups), splits), dim3(256), lds, s, g);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
 
 // waves along M of the C tile: narrow outputs get the 128 x 32 tile, few-row ones the 32 x 128 tile
 static int tile_wm(int M, int N) { return N <= 32 ? 4 : (M <= 32 ? 1 : 2); }
+// Large dense products take the 128 x 128 tile (2 x 2 accumulator blocks per wave: half the LDS reads per MFMA, 64 MFMAs
+// per wave and barrier) once it still leaves two rounds of workgroups for 256 CUs x 2 resident workgroups; everything
+// smaller keeps the 64 x 64 tile, whose count is what fills the chip.  TRL_GEMM_TILE=64 / 128 pins either (development).
+static bool tile_128(const GemmDev& g, int splits) {
+  static const int pin = [] { const char* e = getenv("TRL_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  if (g.hetero || g.M < 128 || g.N < 128) return false;
+  if (pin == 64) return false;
+  if (pin == 128) return true;
+  const int64_t tiles = (int64_t)trl_ceil_div(g.M, 128) * trl_ceil_div(g.N, 128) * std::max(1, g.groups) * splits;
+  return tiles >= 1024;
+}
 
 template <bool TA, bool TB, int GATE, int CONV>
 static int launch_gemm_gate(const GemmDev& g, int splits, hipStream_t s) {
   switch (tile_wm(g.M, g.N)) {
     case 4:  return launch_gemm_tile<TA, TB, GATE, CONV, 4>(g, splits, s);
     case 1:  return launch_gemm_tile<TA, TB, GATE, CONV, 1>(g, splits, s);
-    default: return launch_gemm_tile<TA, TB, GATE, CONV, 2>(g, splits, s);
+    default:
+      if constexpr (CONV == 0) { if (tile_128(g, splits)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 2>(g, splits, s); }
+      return launch_gemm_tile<TA, TB, GATE, CONV, 2>(g, splits, s);
   }
 }
 
@@ -782,7 +878,7 @@ extern "C" int trl_linear_bwd_weight_multi_splits(int M, int K, int N) {
 }
 template <int GATE>
 static int launch_bwd_weight_multi(GemmDev& g, int max_tiles, int max_splits, hipStream_t s) {
-  constexpr int lds = (int)sizeof(float) * (tile_floats<false, 64>() + tile_floats<false, 64>());
+  constexpr int lds = 2 * (int)sizeof(float) * (tile_floats<false, 64, gemm_panel<1>()>() + tile_floats<false, 64, gemm_panel<1>()>());
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<true, false, GATE, 0, 2>,

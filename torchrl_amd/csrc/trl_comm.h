@@ -20,7 +20,8 @@ struct XrArgs {                                    // passed by value to kernels
   int rank, world;
   unsigned long long* peer[TRL_MAX_RANKS];         // base of every rank's buffer as mapped into THIS process
   unsigned* ctl;                                   // local control words: [0] small-region epochs done, [1] ticket, [2] error,
-                                                   //                      [4] gradient-region epochs done, [5] its block ticket
+                                                   //                      [4] gradient-region epochs done, [5] its block ticket,
+                                                   //                      [8..10] first time-out: where + 1, epoch, tag found
   unsigned long long wait_ticks;                   // bound of a peer wait in 100 MHz wall-clock ticks (TRL_COMM_TIMEOUT_S, 20 s)
 };
 
@@ -45,8 +46,10 @@ __device__ __forceinline__ void xr_store(unsigned long long* p, unsigned epoch, 
 // polls one local granule until its tag is `epoch`; bounded by wall-clock time (100 MHz counter; `ticks`, 20 s unless the
 // communicator was created under another TRL_COMM_TIMEOUT_S) so that a missing rank trips ctl[2] instead of hanging the GPU.
 // A caller that goes on to WRITE state (the Adam step) must look at ctl[2] first: the sum is partial after a time-out.
+// `where` = (region << 8) | slot of the granule (region 1: gradient, 2: statistics): the first wait that times out leaves
+// {where + 1, epoch, tag found} in ctl[8..10] for trl_comm_error_detail -- which rank's contribution was missing.
 __device__ __forceinline__ unsigned xr_wait(unsigned long long* p, unsigned epoch, unsigned* ctl,
-                                            unsigned long long ticks = 2000000000ull) {
+                                            unsigned long long ticks = 2000000000ull, unsigned where = 0u) {
   unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if ((unsigned)(v >> 32) == epoch) return (unsigned)v;
   const unsigned long long t0 = wall_clock64();
@@ -56,6 +59,12 @@ __device__ __forceinline__ unsigned xr_wait(unsigned long long* p, unsigned epoc
     if ((unsigned)(v >> 32) == epoch) return (unsigned)v;
     if ((it & 1023u) == 0 && wall_clock64() - t0 > ticks) {
       __hip_atomic_store(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned expect = 0u;
+      if (__hip_atomic_compare_exchange_strong(ctl + 8, &expect, where + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(ctl + 9, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl + 10, (unsigned)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       return 0u;
     }
   }
@@ -69,6 +78,6 @@ __device__ __forceinline__ float xr_allsum_f32(const XrArgs& x, unsigned epoch, 
   float s = 0.0f;
   unsigned long long* mine = x.peer[x.rank];
   for (int q = 0; q < x.world; ++q)
-    s += __uint_as_float(xr_wait(mine + xr_grad_off(x.world, epoch, q, i), epoch, x.ctl, x.wait_ticks));
+    s += __uint_as_float(xr_wait(mine + xr_grad_off(x.world, epoch, q, i), epoch, x.ctl, x.wait_ticks, 0x100u | (unsigned)q));
   return s;
 }

@@ -193,7 +193,20 @@ def check_comm():
     if _comm is not None and _peer_ok:
         from . import _C
         if _C.lib().trl_comm_error(_comm) != 0:
-            raise _C.TrlError("cross-rank exchange timed out: a rank did not deliver its contribution")
+            raise _C.TrlError("cross-rank exchange timed out: a rank did not deliver its contribution (%s)"
+                              % (comm_error_detail() or "no detail recorded"))
+
+
+def comm_error_detail():
+    """Which contribution the first timed-out peer wait was missing, as text ("" when nothing is recorded)."""
+    if _comm is None:
+        return ""
+    from . import _C
+    out = (C.c_int32 * 4)()
+    if _C.lib().trl_comm_error_detail(_comm, out) != 0 or out[0] == 0:
+        return ""
+    return ("rank %d waited for rank %d's %s granules of exchange %d and found tag %d"
+            % (rank(), out[1], "gradient" if out[0] == 1 else "statistics", out[2], out[3]))
 
 
 def _via_abi(t, period, max_mask):
