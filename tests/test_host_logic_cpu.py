@@ -604,6 +604,37 @@ def test_draw_block_leaves_the_default_generator_alone_and_falls_back_on_an_unkn
         noise._checked = old
 
 
+def test_native_noise_helper_draws_the_chunks_the_python_threads_draw():
+    """include/trl_noise.h (libtrl_noise.so, optional): torch's own normal_() on private generators from plain threads must
+    give the chunks the Python-thread path gives -- contiguous segments and a rank's rows of every step -- and exports
+    the three symbols its header declares."""
+    import ctypes
+    import torch
+    from torchrl_amd.collector import noise
+    lib = noise.native_helper()
+    if lib is None:
+        pytest.skip("libtrl_noise.so is not built on this machine")
+    for name in ("trl_noise_abi_version", "trl_noise_last_error", "trl_noise_draw_chunks"):
+        assert hasattr(lib, name)
+    assert lib.trl_noise_draw_chunks(None, 5056, 1, None, None, None, 1) != 0 and b"bad arguments" in lib.trl_noise_last_error()
+    torch.manual_seed(8)
+    s0 = torch.get_rng_state()
+    a, b = torch.empty(1 << 17), torch.empty(1 << 17)
+    sa, sb = torch.empty(16, 64, 6), torch.empty(16, 64, 6)
+    before = noise.STATS["native_blocks"]
+    end_a = noise.draw_block(s0, a, threads=4)
+    end_sa = noise.draw_block(s0, sa.view(-1), n_chunks=16, stride=4 * 64 * 6, offset=2 * 64 * 6, threads=3)
+    assert noise.STATS["native_blocks"] == before + 2
+    saved, noise._ext_lib = noise._ext_lib, None                           # the Python-thread path
+    try:
+        end_b = noise.draw_block(s0, b, threads=4)
+        end_sb = noise.draw_block(s0, sb.view(-1), n_chunks=16, stride=4 * 64 * 6, offset=2 * 64 * 6, threads=3)
+    finally:
+        noise._ext_lib = saved
+    assert torch.equal(a, b) and torch.equal(end_a, end_b) and torch.equal(sa, sb) and torch.equal(end_sa, end_sb)
+    assert torch.equal(a, torch.randn(1 << 17))                            # (the default generator still stands at s0)
+
+
 def test_mt19937_advance_matches_the_engine():
     """The state after k engine calls, for k around the 624-word regeneration boundaries, equals the default generator's
     state after a k-element float32 normal_() (one call per element for k >= 16, k % 16 == 0)."""

@@ -8,6 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libtrl_hip.so")
+NOISE_LIB = os.path.join(LIB_DIR, "libtrl_noise.so")     # host helper of the reference noise stream; links libtorch (optional)
+NOISE_SRC = "trl_noise_ext.cpp"
 SOURCES = ["trl_host.cpp", "k_gae.hip", "k_gather.hip", "k_ppo.hip", "k_ppo_generic.hip", "k_vmpo.hip", "k_trpo.hip", "k_rollout.hip", "k_gemm.hip", "k_mlp3.hip", "k_conv1.hip", "k_conv_dx.hip", "k_sac.hip", "k_conv.hip", "k_dqn.hip", "k_norm.hip", "k_frames.hip", "k_comm.hip", "k_peaks.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable"]
@@ -17,15 +19,46 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != NOISE_SRC]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "trl_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_noise_helper(force=False, verbose=True):
+    """libtrl_noise.so: csrc/trl_noise_ext.cpp against this interpreter's libtorch (g++, host only).  Optional -- returns
+    None (and says why) when the torch headers or g++ are not there; collector/noise.py then draws from Python threads."""
+    src = os.path.join(CSRC, NOISE_SRC)
+    if not force and os.path.exists(NOISE_LIB) and os.path.getmtime(NOISE_LIB) >= os.path.getmtime(src):
+        return NOISE_LIB
+    try:
+        import torch
+        from torch.utils import cpp_extension as ce
+        gxx = shutil.which("g++")
+        if gxx is None:
+            raise RuntimeError("g++ not found")
+        libp = ce.library_paths()
+        cmd = [gxx, "-O2", "-std=c++17", "-shared", "-fPIC"] + ["-I" + i for i in ce.include_paths()] + \
+              ["-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch.compiled_with_cxx11_abi()), src, "-o", NOISE_LIB] + \
+              ["-L" + p for p in libp] + ["-ltorch_cpu", "-lc10"] + ["-Wl,-rpath," + p for p in libp]
+        os.makedirs(LIB_DIR, exist_ok=True)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if res.returncode != 0:
+            raise RuntimeError(res.stdout.decode()[-2000:])
+        if verbose:
+            print("built", NOISE_LIB)
+        return NOISE_LIB
+    except Exception as exc:                                   # noqa: BLE001 -- the helper is an accelerator, not a requirement
+        if verbose:
+            print("libtrl_noise.so not built (%s): the reference-noise chunks are drawn from Python threads" % (exc,))
+        return None
 
 
 def build(force=False, verbose=True, extra_flags=(), lib=None):
     """`extra_flags` / `lib`: experimental builds for the tools/ scripts (e.g. -DTRL_EXP_CLK)."""
     LIB = lib or globals()["LIB"]
     FLAGS = globals()["FLAGS"] + list(extra_flags)
+    if not lib:
+        build_noise_helper(force=force, verbose=verbose)
     if not force and not lib and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -48,7 +48,7 @@ _GROUP_CHUNKS = 16                           # chunk states are derived this man
 _pool, _pool_lock, _gens = None, threading.Lock(), threading.local()
 _checked = None                              # None: not yet; True / False: result of the self-check
 _log = logging.getLogger("torchrl_amd")
-STATS = {"blocks": 0, "parallel_blocks": 0, "pieces": 0}     # what draw_block did so far (tests assert the parallel path ran)
+STATS = {"blocks": 0, "parallel_blocks": 0, "pieces": 0, "native_blocks": 0}     # what draw_block did so far (tests assert the parallel path ran)
 
 
 def default_threads():
@@ -89,6 +89,37 @@ def segment_states(state, n, parts):
     bounds = list(range(0, n, seg)) + [n]
     recs = states_at(state, bounds)
     return bounds, [recs[k] for k in range(len(bounds))]
+
+
+_ext_lib = False                             # False: not looked for yet; None: not available
+
+
+def native_helper():
+    """libtrl_noise.so (csrc/trl_noise_ext.cpp: torch's own normal_() on private generators from plain threads), or None."""
+    global _ext_lib
+    if _ext_lib is False:
+        _ext_lib = None
+        path = os.path.join(os.path.dirname(_C.LIB_PATH), "libtrl_noise.so")
+        if os.environ.get("TRL_NOISE_HELPER") != "0" and os.path.exists(path):
+            try:
+                lib = C.CDLL(path)
+                lib.trl_noise_draw_chunks.restype = C.c_int
+                lib.trl_noise_draw_chunks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+                lib.trl_noise_last_error.restype = C.c_char_p
+                if lib.trl_noise_abi_version() == 1:
+                    _ext_lib = lib
+            except (OSError, AttributeError):
+                _ext_lib = None
+    return _ext_lib
+
+
+def _draw_native(lib, recs, flat, pieces, threads):
+    off = np.ascontiguousarray([a for _, a, _ in pieces], dtype=np.int64)
+    ln = np.ascontiguousarray([b - a for _, a, b in pieces], dtype=np.int64)
+    rc = lib.trl_noise_draw_chunks(recs.data_ptr(), _STATE_BYTES, len(pieces), flat.data_ptr(), off.ctypes.data_as(C.c_void_p),
+                                   ln.ctypes.data_as(C.c_void_p), int(threads))
+    if rc != 0:
+        raise _C.TrlError("trl_noise_draw_chunks failed (%d): %s" % (rc, lib.trl_noise_last_error().decode()))
 
 
 def _draw(state, out):
@@ -175,6 +206,12 @@ def draw_block(state0, out, n_chunks=1, stride=None, offset=0, threads=None):
         _draw_many(recs[:-1], [flat[a:b] for _, a, b in pieces])
         return recs[-1].clone()
     STATS["parallel_blocks"] += 1
+    ext = native_helper()
+    if ext is not None:                                                 # one pass over the stream, then every chunk natively
+        recs = states_at(state0, [p[0] for p in pieces] + [end_pos])
+        _draw_native(ext, recs, flat, pieces, threads)
+        STATS["native_blocks"] += 1
+        return recs[-1].clone()
     pool = _executor(threads)
     jobs, state, at = [], state0, 0
     # the pass over the stream is sequential; its states are handed out in groups so that the draws of one group run while
