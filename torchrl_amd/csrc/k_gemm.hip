@@ -869,8 +869,9 @@ extern "C" int trl_linear_bwd_weight_partials_group_f32(int G, const float* cons
 // 64 x 64 tiles for every problem (narrow layers compute padding: they are latency-, not MFMA-bound); splits chosen so
 // that a problem contributes ~256 workgroups.  Partials are left in place for trl_fold_partials_multi_f32.
 static int multi_split_len(int M, int K, int N) {
+  static const int target = [] { const char* e = getenv("TRL_BWW_TARGET"); return e ? atoi(e) : 256; }();   // (development)
   const int tiles = trl_ceil_div(N, 64) * trl_ceil_div(K, 64);
-  const int want = std::max(1, 256 / tiles);
+  const int want = std::max(1, target / tiles);
   return std::max(tiles <= 8 ? KC : 256, trl_ceil_div(trl_ceil_div(M, want), KC) * KC);   // (a handful of tiles: one panel per slice)
 }
 extern "C" int trl_linear_bwd_weight_multi_splits(int M, int K, int N) {
