@@ -192,6 +192,11 @@ typedef struct trl_rollout_t {
   const uint32_t* stage_ready; uint32_t stage_job; uint32_t* stage_state; uint32_t* stage_ack;
 } trl_rollout_t;
 int trl_rollout_synth_f32(const trl_rollout_t* args, void* stream);
+/* 1 when trl_rollout_synth_f32 carries networks of this shape (without a running observation normaliser): the
+ * benchmark shape D = 17 / A = 6 as a compile-time instantiation, and any 64-wide two-layer policy / value pair with
+ * 2..32 inputs and 1..8 actions through the runtime-dims instantiations (17- and 32-feature tiles, missing features
+ * and actions masked) -- torchrl/networks/base.py:8-44 and torchrl/collector/on_policy.py:90-155 are shape-generic. */
+int trl_rollout_supported(int D, int H, int A, int act);
 /* Page-locked host block -> device buffer by a KERNEL (the device reads host memory in place), meant for a stream of
  * its own next to the one that computes: n floats (n % 4 == 0, 16-byte aligned pointers); when every workgroup's part is
  * in device memory, state[0] = stamp is stored with device scope -- what a consumer launched on another stream polls

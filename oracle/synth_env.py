@@ -40,14 +40,15 @@ class SynthVecEnvCPU:
     """Vectorised numpy implementation (all N envs in one array op)."""
 
     def __init__(self, env_nums, horizon=1000, reward_scale=1.0,
-                 env_index_offset=0, total_env_nums=None):
+                 env_index_offset=0, total_env_nums=None, obs_dim=OBS_DIM, act_dim=ACT_DIM):
         self.env_nums = env_nums
         self.horizon = horizon
         self._reward_scale = reward_scale
         self.training = True
-        self.A, self.B = dynamics_matrices()
-        self.observation_space = _Box(-np.inf, np.inf, (OBS_DIM,))
-        self.action_space = _Box(-1.0, 1.0, (ACT_DIM,))
+        self.obs_dim, self.act_dim = int(obs_dim), int(act_dim)      # (other task shapes: same dynamics family)
+        self.A, self.B = dynamics_matrices(self.obs_dim, self.act_dim)
+        self.observation_space = _Box(-np.inf, np.inf, (self.obs_dim,))
+        self.action_space = _Box(-1.0, 1.0, (self.act_dim,))
         self._offset = env_index_offset
         self._total = total_env_nums if total_env_nums is not None else env_nums
         self.seed(0)
@@ -71,7 +72,7 @@ class SynthVecEnvCPU:
     def _fresh_obs(self, mask):
         self.episode_idx[mask] += 1
         self.t[mask] = 0
-        return philox.normal_vector(OBS_DIM, self.episode_idx[mask], 0,
+        return philox.normal_vector(self.obs_dim, self.episode_idx[mask], 0,
                                     philox.TAG_RESET, self.env_seed[mask])
 
     def reset(self):
@@ -87,7 +88,7 @@ class SynthVecEnvCPU:
         return self._obs
 
     def step(self, actions):
-        actions = np.asarray(actions, dtype=np.float32).reshape(self.env_nums, ACT_DIM)
+        actions = np.asarray(actions, dtype=np.float32).reshape(self.env_nums, self.act_dim)
         pre = self._obs.astype(np.float32) @ self.A + actions @ self.B
         nxt = np.tanh(pre.astype(np.float32)).astype(np.float32)
         rew = nxt[:, 0] - np.float32(0.1) * np.sum(actions * actions, axis=1, dtype=np.float32)

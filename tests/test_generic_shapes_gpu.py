@@ -225,9 +225,9 @@ def test_fused_ppo_update_at_other_input_and_action_sizes_vs_oracle(D, A, act, t
 
 @pytest.mark.parametrize("D,A", [(11, 3), (27, 8)])
 def test_collect_and_train_with_the_fused_update_on_a_hopper_sized_env(D, A):
-    """11 observations / 3 actions (Hopper) and 27 / 8 (Ant: the wide tile), 64-wide networks: the per-step collector
-    (dense-layer kernels) feeds the fused update kernels; log pi_old comes from another forward kernel than log pi, so the
-    first ratio is 1 up to round-off."""
+    """11 observations / 3 actions (Hopper) and 27 / 8 (Ant: the wide tile), 64-wide networks: ONE rollout launch per
+    epoch (runtime-dims instantiations of the persistent kernel) feeds the fused update kernels -- 2 launches per
+    minibatch; log pi_old comes from the rollout kernel, log pi from the update kernel: the first ratio is 1 up to round-off."""
     import torchrl.networks as networks
     import torchrl.policies as policies
     from torchrl.algo import PPO
@@ -244,12 +244,12 @@ def test_collect_and_train_with_the_fused_update_on_a_hopper_sized_env(D, A):
     buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
     col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=DEV, train_render=False,
                                epoch_frames=N * T, max_episode_frames=9, eval_episodes=1, noise_mode="device")
-    assert col._spec is None and col._mlp2 is None                      # no persistent rollout kernel for this shape ...
+    assert col._mlp2 is None and col._spec == (D, 64, A, 0)             # the runtime-dims rollout kernel (round 4) ...
     logger = _Log()
     agent = PPO(pf=pf, vf=vf, plr=3e-4, vlr=3e-4, clip_para=0.2, opt_epochs=2, tau=0.95, shuffle=True, entropy_coeff=0.005,
                 discount=0.99, num_epochs=10, batch_size=N * 4, gae=True, env=env, replay_buffer=buf, collector=col,
                 logger=logger, device=DEV, save_dir=None)
-    assert type(agent.engine()).__name__ == "_FusedPPO"                 # ... but the fused update
+    assert type(agent.engine()).__name__ == "_FusedPPO"                 # ... and the fused update
     p0 = pf.flat_params().clone()
     for epoch in range(3):                                              # eager, captured, replayed
         res = col.train_one_epoch()
@@ -263,3 +263,72 @@ def test_collect_and_train_with_the_fused_update_on_a_hopper_sized_env(D, A):
     assert (pf.flat_params() - p0).abs().max() > 0
     ev = col.eval_one_epoch()
     assert len(ev["eval_rewards"]) == N and ev["eval_traj_length"] == 12
+
+
+@pytest.mark.parametrize("D,A,act,tanh_action", [(11, 3, "tanh", True), (27, 8, "tanh", True), (8, 2, "relu", True),
+                                                 (17, 6, "tanh", False), (18, 1, "tanh", True), (32, 8, "relu", True),
+                                                 (2, 1, "tanh", True), (16, 4, "tanh", True)])
+def test_runtime_dims_rollout_kernel_matches_the_oracle_collector(D, A, act, tanh_action, errlog, monkeypatch):
+    """the persistent rollout kernel for other task shapes (Hopper 11 / 3, Ant 27 / 8, Swimmer 8 / 2,
+    the edges of both tiles) -- ONE launch for the whole epoch -- against VecOnPolicyCollectorOracle
+    (torchrl/collector/on_policy.py:90-155 restated) on a synthetic env of that shape, in the reference's noise stream:
+    all 7 buffers + log pi_old, the epoch reward and the finished-episode list, with env time-limit resets and the
+    collector's over-length bootstrap both firing.  (D = 17 / A = 6 is the compile-time instantiation, here without tanh
+    squashing; D = 16, 17, 18 and 32 are the edges of the 17- and 32-feature tiles.)"""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env.synth import SynthVecEnv
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    from torchrl_amd import _C
+    from oracle import replay as oreplay
+    from oracle.collector import VecOnPolicyCollectorOracle
+    from oracle.synth_env import SynthVecEnvCPU
+    N, T, horizon, max_frames, seed = 48, 24, 10, 7, 5
+    act_cls = {"tanh": torch.nn.Tanh, "relu": torch.nn.ReLU}[act]
+    net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=act_cls)
+    torch.manual_seed(D * 31 + A)
+    pf = policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A, tanh_action=tanh_action, **net)
+    vf = networks.Net(input_shape=(D,), output_shape=1, **net)
+    with torch.no_grad():
+        for m in (pf, vf):
+            m.seq_append_fcs[-1].weight.mul_(30.0)
+        pf.logstd.copy_(torch.linspace(-1.5, -0.5, A))
+    flat = lambda m: [p.detach().clone() for l in (list(m.base.seq_fcs) + list(m.seq_append_fcs))
+                      if isinstance(l, torch.nn.Linear) for p in (l.weight, l.bias)]
+    pf0, ls0, vf0 = flat(pf), pf.logstd.detach().clone(), flat(vf)
+    env, eval_env = (SynthVecEnv(N, obs_dim=D, act_dim=A, horizon=horizon, device=DEV) for _ in range(2))
+    env.seed(seed)
+    buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+    col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=DEV, train_render=False,
+                               epoch_frames=N * T, max_episode_frames=max_frames, eval_episodes=1, noise_mode="host")
+    assert col._spec == (D, 64, A, {"tanh": 0, "relu": 1}[act])
+    launches = []
+    real = _C.rollout
+    monkeypatch.setattr(_C, "rollout", lambda a, dev: (launches.append(int(a.n_steps)), real(a, dev))[1])
+    torch.manual_seed(seed)
+    res = col.train_one_epoch()
+    got_reward, got_eps = float(res["train_epoch_reward"]), sorted(float(x) for x in res["train_rewards"])
+    assert launches == [T]                                             # the whole epoch was ONE rollout call
+    oenv = SynthVecEnvCPU(N, horizon=horizon, obs_dim=D, act_dim=A)
+    oenv.seed(seed)
+    ring = oreplay.RingOracle(N * T, env_nums=N, time_limit_filter=True)
+    ocol = VecOnPolicyCollectorOracle(oenv, ring, pf0, ls0, vf0, epoch_frames=N * T, max_episode_frames=max_frames,
+                                      act=act, tanh_action=tanh_action)
+    torch.manual_seed(seed)
+    ores = ocol.train_one_epoch()
+    for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+        a, b = getattr(buf, "_" + k).cpu().numpy().astype(np.float64), np.asarray(ring.data[k], dtype=np.float64).reshape(T, N, -1)
+        err = np.abs(a - b).max()
+        errlog("rt rollout %s D=%d A=%d abs" % (k, D, A), err, 1e-5)
+        assert err < 1e-5, (k, err)
+    assert float(buf._terminals.sum()) > 0 and float((buf._terminals - buf._time_limits).abs().sum()) > 0   # both reset kinds
+    assert abs(got_reward - float(ores["train_epoch_reward"])) < 1e-3 * max(1.0, abs(got_reward))
+    np.testing.assert_allclose(got_eps, sorted(float(x) for x in ores["train_rewards"]), atol=1e-4)
+    # log pi_old of the stored actions under the collecting policy (what target_pf recomputes, ppo.py:54-56)
+    from oracle import nets as onets
+    obs_t = torch.as_tensor(ring.data["obs"], dtype=torch.float32).reshape(T * N, D)
+    act_t = torch.as_tensor(ring.data["acts"], dtype=torch.float32).reshape(T * N, A)
+    with torch.no_grad():
+        want_lp = onets.policy_update_terms(obs_t, act_t, pf0, ls0, act, tanh_action)["log_prob"].reshape(T, N, 1).numpy()
+    np.testing.assert_allclose(buf._old_logp.cpu().numpy(), want_lp, rtol=2e-4, atol=2e-4)

@@ -120,6 +120,7 @@ SIGNATURES = {
                                            C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_rollout_synth_f32": (C.c_int, [C.POINTER(RolloutArgs), C.c_void_p]),
+    "trl_rollout_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "trl_stage_h2d_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "trl_ppo_partial_stride": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_mlp2_forward_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),

@@ -299,15 +299,19 @@ class VecOnPolicyCollector(VecCollector):
         if self._dims != (self.env.obs_dim, self.env.act_dim) or int(ops.linear_layers(self.vf)[0][0].shape[1]) != self.env.obs_dim:
             raise _C.TrlError("policy / value input and output sizes %s do not match the env (%d obs, %d act)"
                               % (self._dims, self.env.obs_dim, self.env.act_dim))
-        # the persistent rollout kernel and the fused 2-layer forward are instantiated for the benchmark shape
-        # (trl_mlp2_forward_supported); other shapes the fused UPDATE kernels carry (trl_ppo_partial_stride > 0: D <= 32,
-        # A <= 8, H = 64) are collected by the per-step launch sequence on the dense-layer kernels
+        # the fused 2-layer forward (and the cooperative, normalised rollout) are instantiated for the benchmark shape
+        # (trl_mlp2_forward_supported); the persistent rollout kernel itself also carries every other 64-wide two-layer
+        # pair with 2..32 inputs and 1..8 actions through its runtime-dims instantiations (trl_rollout_supported) -- the
+        # shapes the fused UPDATE kernels carry (trl_ppo_partial_stride > 0); anything else is collected by the per-step
+        # launch sequence on the dense-layer kernels
         lib = _C.lib()
-        mlp2 = (ps is not None and vs is not None and vs[:2] == ps[:2] and vs[2] == 1 and vs[3] == ps[3]
-                and lib.trl_mlp2_forward_supported(ps[0], ps[1], ps[2]) and lib.trl_mlp2_forward_supported(ps[0], ps[1], 1)
-                and os.environ.get("TRL_GENERIC_PPO") != "1")
+        pair = ps is not None and vs is not None and vs[:2] == ps[:2] and vs[2] == 1 and vs[3] == ps[3] and \
+            os.environ.get("TRL_GENERIC_PPO") != "1"
+        mlp2 = pair and lib.trl_mlp2_forward_supported(ps[0], ps[1], ps[2]) and lib.trl_mlp2_forward_supported(ps[0], ps[1], 1)
         self._mlp2 = ps if mlp2 else None                                   # fused 2-layer forward kernel usable
-        self._spec = ps if (mlp2 and not getattr(self.env, "is_host_env", False)) else None   # ... and the rollout kernel
+        roll = pair and bool(lib.trl_rollout_supported(ps[0], ps[1], ps[2], ps[3])) and \
+            os.environ.get("TRL_NO_RT_ROLLOUT") != "1"
+        self._spec = ps if (roll and not getattr(self.env, "is_host_env", False)) else None   # ... and the rollout kernel
 
     def _forward(self, net, x, out_dim, out=None):
         """mean / value of an MLP on the device: the fused 2-layer kernel when instantiated, the dense-layer family
@@ -327,6 +331,8 @@ class VecOnPolicyCollector(VecCollector):
         """The persistent kernel carries a normalised env when its workgroups can all be resident (they meet once
         per step to pool the observation statistics) and the statistics are not shared between GPUs."""
         if not hasattr(env, "_obs_normalizer") or getattr(self, "force_per_step", False) or getattr(env, "is_host_env", False):
+            return False
+        if self._mlp2 is None:                                              # (the cooperative kernel: benchmark shape only)
             return False
         if update and dist.collectives_active():
             return False

@@ -62,6 +62,7 @@ struct RolloutDev {
   uint32_t* pub_dst; const uint32_t* pub_src; int64_t pub_words;     // copied to host memory by the value pass
   const uint32_t* noise_flag; uint32_t noise_stamp;                   // noise staged on another stream: wait for the stamp
   // workgroups [n_ro_wg, gridDim.x) stage the NEXT rollout's noise block (see trl_rollout_t.stage_*)
+  int D, A;                   // runtime dims of the RT instantiations (template D / A are then capacities)
   int n_ro_wg; const f32x4* stg_src; unsigned long long* stg_dst; int64_t stg_n4;
   const uint32_t* stg_ready; uint32_t stg_job; uint32_t* stg_state; uint32_t* stg_ack;
 };
@@ -82,7 +83,7 @@ __device__ __forceinline__ float ro_row_sum16(float v) {          // sum over th
 #define NORM_SLOT 40                                 // doubles per workgroup partial: sum x [D] | sum x^2 [D] | any flag | .. | stamp
 
 template <int D, int H, int A> struct RoShape {
-  static_assert(H == 64 && D > 16 && D <= 20 && A <= 8, "instantiated for 16 < D <= 20, H == 64, A <= 8");
+  static_assert(H == 64 && D > 16 && D <= 32 && A <= 8, "instantiated for 16 < D <= 32, H == 64, A <= 8");
   // LDS: b1[H] | b2[H] | b3[8] | logstd[8] | H1 staging [H][TL] | headp [4][8][16] | eps [RO_NB][8][16]
   static constexpr int O_B1 = 0, O_B2 = H, O_B3 = 2 * H, O_LS = O_B3 + 8, O_H1 = O_LS + 8, O_HP = O_H1 + H * TL,
                        O_EPS = O_HP + 4 * 8 * 16, LDS_FLOATS = O_EPS + RO_NB * 8 * 16;
@@ -120,10 +121,23 @@ __device__ __forceinline__ void stage_block(const f32x4* __restrict__ src, unsig
   }
 }
 
-template <int D, int H, int A, int ACT, bool NORM>
+// RT = false: the dims are the template's (the benchmark shape: 17 observations, 6 actions).
+// RT = true: D and A are CAPACITIES (17 or 32 features, 8 actions) and the actual dims come with the launch (a.D, a.A):
+// missing features / actions are masked to zero where they are loaded and never stored, parameter offsets and row strides
+// follow the actual dims -- Hopper- (11 / 3), Swimmer-, Walker-shaped synthetic tasks collect in the same ONE launch
+// (torchrl/collector/on_policy.py:90-155 and torchrl/networks/base.py:8-44 are shape-generic).  D = 32 (WIDE, a.D in
+// [18, 32] -- Ant's 27 observations): features 16..31 are a second k group of the first layer and a second row block of
+// the env GEMM instead of the single 17th feature that rides on the VALU.
+template <int D, int H, int A, int ACT, bool NORM, bool RT = false>
 __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   using S = RoShape<D, H, A>;
-  using FP = MlpFlat<D, H, A>;
+  constexpr bool WIDE = D > 17;
+  static_assert(!WIDE || RT, "the wide tile exists as a runtime-dims instantiation only");
+  static_assert(!(RT && NORM), "the cooperative (normalised) rollout is instantiated for the benchmark shape");
+  const int Dr = RT ? a.D : D, Ar = RT ? a.A : A;   // actual dims (row strides of obs / acts, parameter offsets)
+  // offsets inside the flat parameter block for the actual dims (MlpFlat, trl_mlp.h)
+  const int F_W1 = 0, F_B1 = H * Dr, F_W2 = F_B1 + H, F_B2 = F_W2 + H * H, F_W3 = F_B2 + H, F_B3 = F_W3 + Ar * H,
+            F_LS = F_B3 + Ar;
   __shared__ __attribute__((aligned(16))) float lds[S::LDS_FLOATS];
   if (!NORM && (int)blockIdx.x >= a.n_ro_wg) {
     // ---- a stager: the NEXT rollout's noise block, host -> device, next to this rollout's own workgroups ----
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   const int n = blockIdx.x * RO_ENVS + j;
   const bool valid = n < a.N;
   const float* gp = a.pf_params;
-  const bool has_lo = g < A, has_hi = 4 + g < A;            // the lane's two action dims: g and 4 + g
+  const bool has_lo = g < Ar, has_hi = 4 + g < Ar;          // the lane's two action dims: g and 4 + g
   const int o_lo = has_lo ? g : 0, o_hi = has_hi ? 4 + g : 0;
   if (blockIdx.x == 0 && tid == 0 && a.clear_hdr) { a.clear_hdr[0] = 0.0; a.clear_hdr[1] = 0.0; }   // the NEXT launch's header
   if (a.noise_flag && tid == 0) {
@@ -171,35 +185,56 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
   }
 
   // ---- one-time setup: biases / logstd to LDS, this wave's weight slices to registers ----
-  for (int e = tid; e < H; e += RO_THREADS) { lds[S::O_B1 + e] = gp[FP::B1 + e]; lds[S::O_B2 + e] = gp[FP::B2 + e]; }
+  for (int e = tid; e < H; e += RO_THREADS) { lds[S::O_B1 + e] = gp[F_B1 + e]; lds[S::O_B2 + e] = gp[F_B2 + e]; }
   if (tid < 8) {
-    lds[S::O_B3 + tid] = tid < A ? gp[FP::B3 + tid] : 0.0f;
-    lds[S::O_LS + tid] = tid < A ? gp[FP::LS + tid] : 0.0f;
+    lds[S::O_B3 + tid] = tid < Ar ? gp[F_B3 + (tid < Ar ? tid : 0)] : 0.0f;
+    lds[S::O_LS + tid] = tid < Ar ? gp[F_LS + (tid < Ar ? tid : 0)] : 0.0f;
   }
+  // which of the tile's input features exist: feature 4g + q of the lane's x operand, feature 16 + g (narrow tile) or
+  // 16 + 4g + q (wide tile); a missing feature is loaded from an in-range address and replaced by zero
+  bool fv[4], fv2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { fv[q] = 4 * g + q < Dr; fv2[q] = WIDE && 16 + 4 * g + q < Dr; }
+  const bool f16 = !WIDE && 16 + g < Dr;             // narrow tile: the 5th k step carries feature 16 + g
+  const bool row_f = i < Dr, row_f2 = WIDE && 16 + i < Dr;   // env GEMM rows (next features i, 16 + i) that exist
   // A operands, lane (i, g): the k index of MFMA step (slice sl, r) is feature 16 sl + 4 g + r
-  float w1r[5], w2r[4][4], w3a[4], we0[7], w16[7];
+  // XK: obs k steps of the lane (4 for features 4g + q, then 1 (narrow: feature 16 + g) or 4 (wide: 16 + 4g + q))
+  constexpr int XK = WIDE ? 8 : 5, EK = XK + 2;      // EK: k steps of the env GEMM (obs steps + the two action steps)
+  float w1r[XK], w2r[4][4], w3a[4], we0[EK], w16[EK], we1[WIDE ? EK : 1];
   {
     const int row = 16 * mo + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w1r[r] = gp[FP::W1 + row * D + 4 * g + r];
-    w1r[4] = (16 + g < D) ? gp[FP::W1 + row * D + (16 + g < D ? 16 + g : 0)] : 0.0f;
+    for (int r = 0; r < 4; ++r) w1r[r] = fv[r] ? gp[F_W1 + row * Dr + (fv[r] ? 4 * g + r : 0)] : 0.0f;
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w1r[4 + r] = fv2[r] ? gp[F_W1 + row * Dr + (fv2[r] ? 16 + 4 * g + r : 0)] : 0.0f;
+    } else {
+      w1r[4] = f16 ? gp[F_W1 + row * Dr + (f16 ? 16 + g : 0)] : 0.0f;
+    }
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) w2r[sl][r] = gp[FP::W2 + row * H + 16 * sl + 4 * g + r];
+      for (int r = 0; r < 4; ++r) w2r[sl][r] = gp[F_W2 + row * H + 16 * sl + 4 * g + r];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w3a[r] = (i < A) ? gp[FP::W3 + (i < A ? i : 0) * H + 16 * mo + 4 * g + r] : 0.0f;
+    for (int r = 0; r < 4; ++r) w3a[r] = (i < Ar) ? gp[F_W3 + (i < Ar ? i : 0) * H + 16 * mo + 4 * g + r] : 0.0f;
     // env GEMM next^T[f][j] = sum_k M[f][k] [obs; act]^T[k][j] for features f = 0..15 (we0, MFMA A operand of
-    // row f = i); feature 16 is a per-lane partial dot over the lane's own 7 inputs (w16) + a lane-group sum
-    static_assert(D == 17, "the env step keeps exactly one feature outside the 16-row MFMA tile");
+    // row f = i) and, wide tile, f = 16..31 (we1); narrow tile: feature 16 is a per-lane partial dot over the lane's own
+    // inputs (w16) + a lane-group sum
+    static_assert(WIDE || D == 17, "the narrow env step keeps exactly one feature outside the 16-row MFMA tile");
+    const bool has16 = !WIDE && Dr > 16;
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-      // k of step q: obs feature 4g + q (q < 4), obs feature 16 + g (q == 4), action g (q == 5), action 4 + g (q == 6)
-      float v0 = 0.0f, v1 = 0.0f;
-      if (q < 4) { const int k = 4 * g + q; v0 = a.env_A[k * D + i]; v1 = a.env_A[k * D + 16]; }
-      else if (q == 4) { const int k = 16 + g; if (k < D) { v0 = a.env_A[k * D + i]; v1 = a.env_A[k * D + 16]; } }
-      else { const int k = (q == 5) ? g : 4 + g; if (k < A) { v0 = a.env_B[k * D + i]; v1 = a.env_B[k * D + 16]; } }
-      we0[q] = v0; w16[q] = v1;
+    for (int q = 0; q < EK; ++q) {
+      // k of step q: obs feature 4g + q (q < 4); narrow: obs feature 16 + g (q == 4); wide: obs feature 16 + 4g + (q - 4)
+      // (4 <= q < 8); then action g and action 4 + g
+      const float* mat = q < XK ? a.env_A : a.env_B;
+      int k; bool kin;
+      if (q < 4) { k = 4 * g + q; kin = k < Dr; }
+      else if (q < XK) { k = WIDE ? 16 + 4 * g + (q - 4) : 16 + g; kin = k < Dr; }
+      else { k = (q == XK) ? g : 4 + g; kin = k < Ar; }
+      const int kc = kin ? k : 0;
+      we0[q] = (kin && row_f) ? mat[kc * Dr + (row_f ? i : 0)] : 0.0f;
+      w16[q] = (kin && has16) ? mat[kc * Dr + (has16 ? 16 : 0)] : 0.0f;
+      if constexpr (WIDE) we1[q] = (kin && row_f2) ? mat[kc * Dr + (row_f2 ? 16 + i : 0)] : 0.0f;
     }
   }
   __syncthreads();
@@ -218,13 +253,18 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
 
   // ---- per-env state (replicated in all 4 waves and all 4 lane groups) ----
   // x operand: lane (env j, g) holds obs features 4g..4g+3 and (g == 0) feature 16
-  float xb[5];
+  float xb[XK];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) xb[r] = valid ? a.cur_obs[(size_t)n * D + 4 * g + r] : 0.0f;
-  xb[4] = (valid && 16 + g < D) ? a.cur_obs[(size_t)n * D + 16 + g] : 0.0f;
+  for (int r = 0; r < 4; ++r) xb[r] = (valid && fv[r]) ? a.cur_obs[(size_t)n * Dr + (fv[r] ? 4 * g + r : 0)] : 0.0f;
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xb[4 + r] = (valid && fv2[r]) ? a.cur_obs[(size_t)n * Dr + (fv2[r] ? 16 + 4 * g + r : 0)] : 0.0f;
+  } else {
+    xb[4] = (valid && f16) ? a.cur_obs[(size_t)n * Dr + (f16 ? 16 + g : 0)] : 0.0f;
+  }
   // NORM: xb is the env's RAW state (it drives the dynamics), xp what the policy sees (normalised, or raw right
   // after a partial reset -- the reference's behaviour); without a normaliser they are the same.
-  float xp[5];
+  float xp[XK];
   __shared__ double s_mean[NORM ? D : 1], s_var[NORM ? D : 1], s_sum[NORM ? 2 * D + 1 : 1];
   __shared__ double s_cnt;
   unsigned* nhdr = NORM ? reinterpret_cast<unsigned*>(a.norm_ws) : nullptr;
@@ -237,7 +277,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
     __syncthreads();
   } else {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) xp[q] = xb[q];
+    for (int q = 0; q < XK; ++q) xp[q] = xb[q];
   }
   int t_env = valid ? a.t_env[n] : 0;
   int cur_step = valid ? a.cur_step[n] : 0;
@@ -259,12 +299,12 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
       const int64_t gs = a.noise_step0 + t + ts;
       float z0[4], z1[4];
       philox_normals4((uint32_t)(gs & 0xFFFFFFFFll), (uint32_t)((gs >> 32) & 0xFFFFFFFFll), 0u, TRL_TAG_NOISE, env_seed, z0);
-      if (A > 4)
+      if (Ar > 4)
         philox_normals4((uint32_t)(gs & 0xFFFFFFFFll), (uint32_t)((gs >> 32) & 0xFFFFFFFFll), 1u, TRL_TAG_NOISE, env_seed, z1);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         S_EPS[(ts * 8 + c) * 16 + j] = z0[c];
-        if (4 + c < A) S_EPS[(ts * 8 + 4 + c) * 16 + j] = z1[c];
+        if (4 + c < Ar) S_EPS[(ts * 8 + 4 + c) * 16 + j] = z1[c];
       }
       __syncthreads();   // readers of the previous batch finished before the barriers of the step that ended it
     }
@@ -273,20 +313,24 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
       eps_lo = S_EPS[((t % RO_NB) * 8 + o_lo) * 16 + j];
       eps_hi = S_EPS[((t % RO_NB) * 8 + o_hi) * 16 + j];
     } else if (a.noise) {
-      eps_lo = valid ? a.noise[((size_t)t * a.N + n) * A + o_lo] : 0.0f;
-      eps_hi = valid ? a.noise[((size_t)t * a.N + n) * A + o_hi] : 0.0f;
+      eps_lo = valid ? a.noise[((size_t)t * a.N + n) * Ar + o_lo] : 0.0f;
+      eps_hi = valid ? a.noise[((size_t)t * a.N + n) * Ar + o_hi] : 0.0f;
     }
 
     CLK(0)
     // ---- policy forward ----
     f32x4 h1 = *reinterpret_cast<const f32x4*>(b1s);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) h1 = mfma16(w1r[q], xp[q], h1);
+    for (int q = 0; q < XK; ++q) h1 = mfma16(w1r[q], xp[q], h1);
     // the observation part of the env step does not wait for the action: it runs in the shadow of the barriers
-    f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f}, e1 = f32x4{0.f, 0.f, 0.f, 0.f};
     float p16 = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { e0 = mfma16(we0[q], xb[q], e0); p16 = fmaf(w16[q], xb[q], p16); }
+    for (int q = 0; q < XK; ++q) {
+      e0 = mfma16(we0[q], xb[q], e0);
+      if constexpr (WIDE) e1 = mfma16(we1[q], xb[q], e1);
+      else p16 = fmaf(w16[q], xb[q], p16);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) h1[r] = act_fn<ACT>(h1[r]);
     store_T(S_H1, mo, h1, j, g);
@@ -321,13 +365,18 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
     const float act_lo = has_lo ? (a.tanh_action ? trl_tanh(z_lo) : z_lo) : 0.0f;
     const float act_hi = has_hi ? (a.tanh_action ? trl_tanh(z_hi) : z_hi) : 0.0f;
     // ---- env step: next^T[f][env] = sum_k M[f][k] [obs; act]^T[k][env] (action part) ----
-    e0 = mfma16(we0[5], act_lo, e0);
-    e0 = mfma16(we0[6], act_hi, e0);
-    p16 = fmaf(w16[5], act_lo, p16);
-    p16 = fmaf(w16[6], act_hi, p16);
+    e0 = mfma16(we0[XK], act_lo, e0);
+    e0 = mfma16(we0[XK + 1], act_hi, e0);
+    if constexpr (WIDE) {
+      e1 = mfma16(we1[XK], act_lo, e1);
+      e1 = mfma16(we1[XK + 1], act_hi, e1);
+    } else {
+      p16 = fmaf(w16[XK], act_lo, p16);
+      p16 = fmaf(w16[XK + 1], act_hi, p16);
+    }
     // lane-group sums (same env, g = 0..3) as ones x value MFMAs: every lane gets the total
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float e16 = mfma16(1.0f, p16, zero4)[0];
+    const float e16 = WIDE ? 0.0f : mfma16(1.0f, p16, zero4)[0];
     const float act_sq = mfma16(1.0f, fmaf(act_lo, act_lo, act_hi * act_hi), zero4)[0];   // all action dims
     float logp = 0.0f;
     if (mo == 3) {                                          // only the wave that stores old_logp needs it
@@ -337,10 +386,15 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
       logp = mfma16(1.0f, lp, zero4)[0];
     }
     CLK(5)
-    float nx[5];
+    float nx[XK];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) nx[r] = trl_tanh(e0[r]);     // features 4g + r
-    nx[4] = (g == 0) ? trl_tanh(e16) : 0.0f;                 // feature 16
+    for (int r = 0; r < 4; ++r) nx[r] = trl_tanh(e0[r]);     // features 4g + r (absent ones: tanh(0) = 0)
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nx[4 + r] = trl_tanh(e1[r]);   // features 16 + 4g + r
+    } else {
+      nx[4] = (g == 0 && Dr > 16) ? trl_tanh(e16) : 0.0f;    // feature 16
+    }
 
     CLK(6)
     // feature 0 lives in lane group 0 (r == 0): broadcast to the other groups with a selector MFMA
@@ -350,7 +404,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
     const bool done = t_env >= a.horizon;
     const bool surpass = cur_step >= a.max_episode_frames;
     // ---- NormObs.observation(next_obs) (base_wrapper.py:116-119): statistics over ALL envs, then the filter ----
-    float nxn[5];                                           // what is stored as next_obs / fed to the policy
+    float nxn[XK];                                          // what is stored as next_obs / fed to the policy
     bool any_reset = false;
     if constexpr (NORM) {
       if (a.norm_update) {
@@ -420,7 +474,7 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 5; ++q) nxn[q] = nx[q];
+      for (int q = 0; q < XK; ++q) nxn[q] = nx[q];
     }
     ep_ret += raw_rew;
     if (mo == 0 && g == 0 && valid) {
@@ -432,35 +486,44 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
     }
     if (done) ep_ret = 0.0f;
 
-    float xn[5];
+    float xn[XK];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) xn[q] = nx[q];
+    for (int q = 0; q < XK; ++q) xn[q] = nx[q];
     if (done || surpass) {                                  // partial_reset (vecenv.py:47-51) + counters (:148)
       ep_idx += 1; t_env = 0; cur_step = 0;
       float z[4];
       philox_normals4((uint32_t)ep_idx, 0u, (uint32_t)g, TRL_TAG_RESET, env_seed, z);     // features 4g..4g+3
 #pragma unroll
-      for (int c = 0; c < 4; ++c) xn[c] = z[c];
-      xn[4] = 0.0f;
-      if (g == 0) {
-        philox_normals4((uint32_t)ep_idx, 0u, 4u, TRL_TAG_RESET, env_seed, z);            // feature 16
-        xn[4] = z[0];
+      for (int c = 0; c < 4; ++c) xn[c] = fv[c] ? z[c] : 0.0f;
+      if constexpr (WIDE) {
+        philox_normals4((uint32_t)ep_idx, 0u, (uint32_t)(4 + g), TRL_TAG_RESET, env_seed, z);   // features 16 + 4g ..
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xn[4 + c] = fv2[c] ? z[c] : 0.0f;
+      } else {
+        xn[4] = 0.0f;
+        if (g == 0 && Dr > 16) {
+          philox_normals4((uint32_t)ep_idx, 0u, 4u, TRL_TAG_RESET, env_seed, z);          // feature 16
+          xn[4] = z[0];
+        }
       }
     }
 
     // ---- ring-buffer row `row` (replay_buffers/base.py:19-29), one key group per wave ----
     if (valid && a.store) {
-      if (mo == 0) {
+      if (mo == 0 || mo == 1) {
+        float* dst = (mo == 0 ? a.obs : a.next_obs) + cell * Dr;
+        const float* src = mo == 0 ? xp : nxn;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.obs[cell * D + 4 * g + r] = xp[r];
-        if (g == 0) a.obs[cell * D + 16] = xp[4];
-      } else if (mo == 1) {
+        for (int r = 0; r < 4; ++r) if (!RT || fv[r]) dst[4 * g + r] = src[r];
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.next_obs[cell * D + 4 * g + r] = nxn[r];
-        if (g == 0) a.next_obs[cell * D + 16] = nxn[4];
+          for (int r = 0; r < 4; ++r) if (fv2[r]) dst[16 + 4 * g + r] = src[4 + r];
+        } else {
+          if (g == 0 && (!RT || Dr > 16)) dst[16] = src[4];
+        }
       } else if (mo == 2) {
-        if (has_lo) a.acts[cell * A + g] = act_lo;
-        if (has_hi) a.acts[cell * A + 4 + g] = act_hi;
+        if (has_lo) a.acts[cell * Ar + g] = act_lo;
+        if (has_hi) a.acts[cell * Ar + 4 + g] = act_hi;
       } else {
         // one store instruction for the four per-cell scalars: lane group g writes key g.  values[cell]
         // carries the over-length marker to the value pass, which overwrites it with V(obs)
@@ -486,10 +549,10 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 5; ++q) xp[q] = xn[q];
+      for (int q = 0; q < XK; ++q) xp[q] = xn[q];
     }
 #pragma unroll
-    for (int q = 0; q < 5; ++q) xb[q] = xn[q];
+    for (int q = 0; q < XK; ++q) xb[q] = xn[q];
     CLK(7)
   }
   if constexpr (NORM) {
@@ -510,10 +573,15 @@ __global__ __launch_bounds__(RO_THREADS, 1) void rollout_kernel(RolloutDev a) {
 
   // ---- persist env / collector state ----
   if (mo == 0 && valid) {
+    float* dst = a.cur_obs + (size_t)n * Dr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a.cur_obs[(size_t)n * D + 4 * g + r] = xb[r];
+    for (int r = 0; r < 4; ++r) if (!RT || fv[r]) dst[4 * g + r] = xb[r];
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (fv2[r]) dst[16 + 4 * g + r] = xb[4 + r];
+    }
     if (g == 0) {
-      a.cur_obs[(size_t)n * D + 16] = xb[4];
+      if (!WIDE && (!RT || Dr > 16)) dst[16] = xb[4];
       a.t_env[n] = t_env; a.cur_step[n] = cur_step; a.episode_idx[n] = ep_idx; a.ep_return[n] = ep_ret;
     }
   }
@@ -536,47 +604,70 @@ struct ValueDev {
   int rows, top, N, n_steps; float discount;
   float* boot;                // (N) or NULL: V(next_obs) of the last step's row
   uint32_t* pub_dst; const uint32_t* pub_src; int64_t pub_words;     // epoch header + episode-log head -> page-locked host memory
+  int D;                      // runtime input size of the RT instantiations
 };
 
-template <int D, int H, int ACT>
-__global__ __launch_bounds__(VP_THREADS, 2) void value_pass_kernel(ValueDev a) {
-  using FV = MlpFlat<D, H, 1>;
-  static_assert(H == 64 && D > 16 && D <= 20, "instantiated for 16 < D <= 20, H == 64");
+// RT: D is a capacity (17 or 32 input features), the actual size comes with the launch (see rollout_kernel)
+template <int D, int H, int ACT, bool RT = false>
+__global__ __launch_bounds__(VP_THREADS, RT ? 1 : 2) void value_pass_kernel(ValueDev a) {
+  static_assert(H == 64 && D > 16 && D <= 32, "instantiated for 16 < D <= 32, H == 64");
+  constexpr bool WIDE = D > 17;
+  static_assert(!WIDE || RT, "the wide tile exists as a runtime-dims instantiation only");
+  constexpr int XK = WIDE ? 8 : 5;
+  const int Dr = RT ? a.D : D;
+  const int F_W1 = 0, F_B1 = H * Dr, F_W2 = F_B1 + H, F_B2 = F_W2 + H * H, F_W3 = F_B2 + H, F_B3 = F_W3 + H;   // MlpFlat<Dr, H, 1>
   __shared__ __attribute__((aligned(16))) float sb[2 * H];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4, i = j;
   const float* gp = a.vf_params;
-  for (int e = tid; e < H; e += VP_THREADS) { sb[e] = gp[FV::B1 + e]; sb[H + e] = gp[FV::B2 + e]; }
-  float w1[4][5], w2[4][4][4], w3[4][4];
+  for (int e = tid; e < H; e += VP_THREADS) { sb[e] = gp[F_B1 + e]; sb[H + e] = gp[F_B2 + e]; }
+  bool fv[4], fv2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { fv[q] = 4 * g + q < Dr; fv2[q] = WIDE && 16 + 4 * g + q < Dr; }
+  const bool f16 = !WIDE && 16 + g < Dr;
+  const bool w2_al = !RT || ((reinterpret_cast<uintptr_t>(gp + F_W2) & 15) == 0);   // (odd D: the block is only 4-byte aligned)
+  float w1[4][XK], w2[4][4][4], w3[4][4];
 #pragma unroll
   for (int so = 0; so < 4; ++so) {
     const int row = 16 * so + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w1[so][r] = gp[FV::W1 + row * D + 4 * g + r];
-    w1[so][4] = (16 + g < D) ? gp[FV::W1 + row * D + (16 + g < D ? 16 + g : 0)] : 0.0f;
+    for (int r = 0; r < 4; ++r) w1[so][r] = fv[r] ? gp[F_W1 + row * Dr + (fv[r] ? 4 * g + r : 0)] : 0.0f;
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w1[so][4 + r] = fv2[r] ? gp[F_W1 + row * Dr + (fv2[r] ? 16 + 4 * g + r : 0)] : 0.0f;
+    } else {
+      w1[so][4] = f16 ? gp[F_W1 + row * Dr + (f16 ? 16 + g : 0)] : 0.0f;
+    }
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(gp + FV::W2 + row * H + 16 * sl + 4 * g);
+      f32x4 w;
+      if (w2_al) w = *reinterpret_cast<const f32x4*>(gp + F_W2 + row * H + 16 * sl + 4 * g);
+      else __builtin_memcpy(&w, gp + F_W2 + row * H + 16 * sl + 4 * g, 16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) w2[so][sl][r] = w[r];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w3[so][r] = gp[FV::W3 + 16 * so + 4 * g + r];
+    for (int r = 0; r < 4; ++r) w3[so][r] = gp[F_W3 + 16 * so + 4 * g + r];
   }
-  const float b3 = gp[FV::B3];
+  const float b3 = gp[F_B3];
   __syncthreads();
 
   auto forward = [&](const float* src, size_t cell, bool ok) -> float {
-    float xb[5];
+    float xb[XK];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xb[r] = ok ? src[cell * D + 4 * g + r] : 0.0f;
-    xb[4] = (ok && 16 + g < D) ? src[cell * D + (16 + g < D ? 16 + g : 0)] : 0.0f;
+    for (int r = 0; r < 4; ++r) xb[r] = (ok && fv[r]) ? src[cell * Dr + (fv[r] ? 4 * g + r : 0)] : 0.0f;
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xb[4 + r] = (ok && fv2[r]) ? src[cell * Dr + (fv2[r] ? 16 + 4 * g + r : 0)] : 0.0f;
+    } else {
+      xb[4] = (ok && f16) ? src[cell * Dr + (f16 ? 16 + g : 0)] : 0.0f;
+    }
     f32x4 h1[4], h2[4];
 #pragma unroll
     for (int so = 0; so < 4; ++so) {
       f32x4 acc = *reinterpret_cast<const f32x4*>(sb + 16 * so + 4 * g);
 #pragma unroll
-      for (int q = 0; q < 5; ++q) acc = mfma16(w1[so][q], xb[q], acc);
+      for (int q = 0; q < XK; ++q) acc = mfma16(w1[so][q], xb[q], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = act_fn<ACT>(acc[r]);
       h1[so] = acc;
@@ -637,10 +728,15 @@ static int rollout_norm_capacity() {
   return cus * per_cu * RO_ENVS;
 }
 
-template <int D, int H, int A, int ACT>
+template <int D, int H, int A, int ACT, bool RT = false>
 static int launch_rollout(const RolloutDev& d, hipStream_t s) {
   const int n_wg = trl_ceil_div(d.N, RO_ENVS);
-  if (d.norm_state) {
+  if constexpr (RT) {
+    if (d.norm_state) { trl_set_error("rollout: the normalised rollout is instantiated for the benchmark shape only"); return TRL_EUNSUPPORTED; }
+    RolloutDev e = d;
+    e.n_ro_wg = n_wg;
+    hipLaunchKernelGGL((rollout_kernel<D, H, A, ACT, false, true>), dim3(n_wg + (e.stg_n4 ? RO_STAGERS : 0)), dim3(RO_THREADS), 0, s, e);
+  } else if (d.norm_state) {
     const int cap = rollout_norm_capacity<D, H, A, ACT>();
     if (d.norm_update && d.N > cap) {
       trl_set_error("rollout: %d envs with a running normaliser exceed the %d that can be co-resident", d.N, cap);
@@ -655,10 +751,10 @@ static int launch_rollout(const RolloutDev& d, hipStream_t s) {
   TRL_LAUNCH_CHECK();
   if (d.store) {
     ValueDev v{d.vf_params, d.obs, d.next_obs, d.values, d.rewards, d.rows, d.top, d.N, d.n_steps, d.discount, d.boot,
-               d.pub_dst, d.pub_src, d.pub_words};
+               d.pub_dst, d.pub_src, d.pub_words, d.D};
     const int64_t n_tiles = ((int64_t)d.n_steps * d.N + 15) / 16;
     const int grid = (int)(n_tiles / 4 + 1 < 512 ? n_tiles / 4 + 1 : 512);
-    hipLaunchKernelGGL((value_pass_kernel<D, H, ACT>), dim3(grid), dim3(VP_THREADS), 0, s, v);
+    hipLaunchKernelGGL((value_pass_kernel<D, H, ACT, RT>), dim3(grid), dim3(VP_THREADS), 0, s, v);
     TRL_LAUNCH_CHECK();
   }
   return TRL_OK;
@@ -681,6 +777,13 @@ extern "C" int trl_stage_h2d_f32(const float* host_src, float* dev_dst, int64_t 
                      reinterpret_cast<unsigned long long*>(dev_dst), n / 4, state, stamp);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
+}
+
+// Shapes the persistent rollout carries without a normaliser: the benchmark shape (compile-time instantiation) and any
+// 64-wide two-layer pair with 2..32 inputs and 1..8 actions (runtime-dims instantiations) -- what the fused update
+// kernels carry (trl_ppo_partial_stride), so such a task is 1 rollout launch + 2 launches per minibatch.
+extern "C" int trl_rollout_supported(int D, int H, int A, int act) {
+  return H == 64 && D >= 2 && D <= 32 && A >= 1 && A <= 8 && (act == TRL_ACT_TANH || act == TRL_ACT_RELU);
 }
 
 extern "C" int trl_rollout_synth_f32(const trl_rollout_t* p, void* stream) {
@@ -729,9 +832,18 @@ extern "C" int trl_rollout_synth_f32(const trl_rollout_t* p, void* stream) {
               "clear_header must not be the header this launch accumulates into");
   TRL_REQUIRE(!p->norm_state || (p->policy_obs && p->norm_workspace), "normaliser needs policy_obs and its workspace");
   hipStream_t s = (hipStream_t)stream;
+  d.D = p->D; d.A = p->A;
   if (p->D == 17 && p->H == 64 && p->A == 6) {
     if (p->act == TRL_ACT_TANH) return launch_rollout<17, 64, 6, TRL_ACT_TANH>(d, s);
     if (p->act == TRL_ACT_RELU) return launch_rollout<17, 64, 6, TRL_ACT_RELU>(d, s);
+  }
+  if (trl_rollout_supported(p->D, p->H, p->A, p->act) && !p->norm_state) {        // runtime-dims instantiations
+    if (p->D <= 17) {
+      if (p->act == TRL_ACT_TANH) return launch_rollout<17, 64, 8, TRL_ACT_TANH, true>(d, s);
+      return launch_rollout<17, 64, 8, TRL_ACT_RELU, true>(d, s);
+    }
+    if (p->act == TRL_ACT_TANH) return launch_rollout<32, 64, 8, TRL_ACT_TANH, true>(d, s);
+    return launch_rollout<32, 64, 8, TRL_ACT_RELU, true>(d, s);
   }
   trl_set_error("rollout: shape D=%d H=%d A=%d act=%d not instantiated", p->D, p->H, p->A, p->act);
   return TRL_EUNSUPPORTED;
