@@ -868,7 +868,20 @@ extern "C" int trl_linear_bwd_weight_partials_group_f32(int G, const float* cons
 // ---- weight gradients of SEVERAL layers (different K, N; same batch M) as one launch of split GEMMs ----
 // 64 x 64 tiles for every problem (narrow layers compute padding: they are latency-, not MFMA-bound); splits chosen so
 // that a problem contributes ~256 workgroups.  Partials are left in place for trl_fold_partials_multi_f32.
+//
+// SKINNY layers -- few inputs (the first layer of an MLP on 17- / 23-wide observations) or few outputs (a 1- / 12-wide
+// head) against a wide other side -- take skinny_bwdw_kernel below instead: dW = dZ^T X is then a (wide x <= 32) outer
+// product summed over the batch, and both operands of a v_mfma_f32_32x32x2_f32 step can be read from global memory
+// DIRECTLY in operand layout (lane (i, hi) of wave w: wide[m + hi][32 w + i] -- 128-byte row pieces -- and
+// narrow[m + hi][i], masked): no LDS, no barrier, no per-element edge code.  Through the generic kernel these layers are
+// all edge tiles (predicated scalar loads: ~9 vector instructions per MFMA measured over a SAC update's launches) and the
+// launch that carries the six of them took as long as the three 256 x 256 layers' (24.5 us for 0.2 GFLOP).
+static bool skinny_layer(int K, int N) {
+  return (K <= 31 && N >= 64 && N <= 256 && (N & 31) == 0) || (N <= 32 && K >= 64 && K <= 256 && (K & 31) == 0);
+}
 static int multi_split_len(int M, int K, int N) {
+  if (skinny_layer(K, N))                                              // batch rows per workgroup: >= 128, ~64 slices
+    return std::max(128, trl_ceil_div(trl_ceil_div(M, 64), KC) * KC);
   static const int target = [] { const char* e = getenv("TRL_BWW_TARGET"); return e ? atoi(e) : 256; }();   // (development)
   const int tiles = trl_ceil_div(N, 64) * trl_ceil_div(K, 64);
   const int want = std::max(1, target / tiles);
@@ -877,6 +890,85 @@ static int multi_split_len(int M, int K, int N) {
 extern "C" int trl_linear_bwd_weight_multi_splits(int M, int K, int N) {
   return (M <= 0 || K <= 0 || N <= 0) ? 1 : trl_ceil_div(M, multi_split_len(M, K, N));
 }
+
+// One skinny layer per blockIdx.y, one batch slice per blockIdx.x.  `wide` is the operand with the many columns (dZ when
+// the layer has few inputs -- wide_is_out -- else the layer input X), `narrow` the other one; the gate (act' through the
+// layer's outputs) belongs to dZ, whichever side that is.  Wave w owns wide columns [32 w, 32 w + 32); its accumulator tile
+// is (wide column) x (narrow column).  The bias gradient (column sums of dZ) rides along: as a column of ones appended to
+// the narrow operand (wide_is_out), or as the per-lane running sum of the narrow operand (else).
+struct SkinnyProb { const float* wide; const float* narrow; const float* gate; float* dw_part; float* db_part;
+                    int wide_n, narrow_n, wide_is_out, split_len, splits; };
+struct SkinnyDev { int M, gate_act; SkinnyProb p[GEMM_MAX_GROUPS]; };
+template <int GATE>                                  // != NONE: some problem of the launch is gated (the others read a dummy)
+__global__ __launch_bounds__(512) void skinny_bwdw_kernel(SkinnyDev g) {
+  constexpr bool GATED = GATE != TRL_ACT_NONE;
+  const SkinnyProb P = g.p[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
+  if ((int)blockIdx.x >= P.splits || 32 * wave >= P.wide_n) return;
+  const int m_lo = blockIdx.x * P.split_len, m_hi = min(g.M, m_lo + P.split_len);
+  const int wn = P.wide_n, nn = P.narrow_n;
+  const bool gate_wide = P.gate && P.wide_is_out, gate_narrow = P.gate && !P.wide_is_out;
+  const bool nin = i < nn;                           // this lane's narrow column exists
+  const bool ones = P.wide_is_out && i == nn && P.db_part;   // ... or is the column of ones that collects db
+  const float* wp = P.wide + 32 * wave + i;
+  const float* np_ = P.narrow + (nin ? i : 0);
+  // (no branch around a load -- the wait-count bookkeeping would have to assume it not taken: an ungated problem of a
+  // gated launch reads its own wide operand as a dummy)
+  const float* gp = P.gate ? (P.wide_is_out ? P.gate + 32 * wave + i : P.gate + (nin ? i : 0)) : wp;
+  const size_t gld = (size_t)((P.wide_is_out || !P.gate) ? wn : nn);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float nsum = 0.0f;                                 // !wide_is_out: running sum of this lane's dZ values (bias gradient)
+  // 8 row pairs per round, one round in flight.  (A second round requested ahead of this one's MFMAs measured SLOWER,
+  // 18-19 us against 16.4 for a SAC update's six skinny layers; so did the same direct-operand scheme for the square
+  // 256 x 256 layers -- 34 us against 28.6 through LDS: 4-byte-per-lane loads move ~10 bytes per clock and CU here, so
+  // this kernel is for layers whose generic tiles are all padding, not a replacement for the LDS-staged panels.)
+  constexpr int U = 8;
+  for (int m0 = m_lo; m0 < m_hi; m0 += 2 * U) {
+    float av[U], bv[U], gv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + 2 * u + hi;
+      const size_t mr = m < m_hi ? (size_t)m : (size_t)m_lo;           // (past the end: an in-range row, zeroed below)
+      av[u] = wp[mr * wn];
+      bv[u] = np_[mr * nn];
+      if (GATED) gv[u] = gp[mr * gld];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = m0 + 2 * u + hi < m_hi;
+      float a = ok ? av[u] : 0.0f, b = ok ? (nin ? bv[u] : (ones ? 1.0f : 0.0f)) : 0.0f;
+      if (GATED) {
+        const float d = dact_from_out(GATE, gv[u]);   // (compile-time activation: a run-time one is a branch chain per element)
+        a *= gate_wide ? d : 1.0f;
+        b *= gate_narrow ? d : 1.0f;
+      }
+      nsum += b;
+      acc = mfma32(a, b, acc);
+    }
+  }
+  // tile element (row = wide column 32 w + rowmap(r, hi), column = narrow column i)
+  float* dw = P.dw_part + (size_t)blockIdx.x * wn * nn;
+  if (P.wide_is_out) {                               // dW[out = wide][in = narrow], db[out]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (nin) dw[(size_t)o * nn + i] = acc[r];
+      else if (ones) P.db_part[(size_t)blockIdx.x * wn + o] = acc[r];
+    }
+  } else {                                           // dW[out = narrow][in = wide], db[out] = sum of the narrow operand
+    if (nin) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dw[(size_t)i * wn + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi] = acc[r];
+    }
+    if (P.db_part && wave == 0) {
+      nsum += __shfl_xor(nsum, 32, 64);              // even + odd rows
+      if (nin && hi == 0) P.db_part[(size_t)blockIdx.x * nn + i] = nsum;
+    }
+  }
+}
+
 template <int GATE>
 static int launch_bwd_weight_multi(GemmDev& g, int max_tiles, int max_splits, hipStream_t s) {
   constexpr int lds = 2 * (int)sizeof(float) * (tile_floats<false, 64, gemm_panel<1>()>() + tile_floats<false, 64, gemm_panel<1>()>());
@@ -897,6 +989,32 @@ extern "C" int trl_linear_bwd_weight_partials_multi_f32(int G, const float* cons
   TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per launch");
   TRL_REQUIRE(dy && x && K && N && workspace && M > 0, "null pointer array / empty batch");
   TRL_REQUIRE(gate_act == TRL_ACT_TANH || gate_act == TRL_ACT_RELU || gate_act == TRL_ACT_NONE, "unknown activation");
+  bool all_skinny = true;
+  for (int i = 0; i < G; ++i) all_skinny = all_skinny && K[i] > 0 && N[i] > 0 && skinny_layer(K[i], N[i]);
+  if (all_skinny) {
+    SkinnyDev sk{};
+    sk.M = M; sk.gate_act = gate_act;
+    int max_splits = 0, max_wide = 0;
+    for (int i = 0; i < G; ++i) {
+      TRL_REQUIRE(dy[i] && x[i] && workspace[i], "null pointer / bad layer size");
+      const int split_len = multi_split_len(M, K[i], N[i]), splits = trl_ceil_div(M, split_len);
+      const bool wide_out = K[i] <= 31;              // few inputs: dZ (M x N) is the wide operand
+      float* part = workspace[i];
+      const float* gate = (y_gate && gate_act != TRL_ACT_NONE) ? y_gate[i] : nullptr;
+      sk.p[i] = SkinnyProb{wide_out ? dy[i] : x[i], wide_out ? x[i] : dy[i], gate, part,
+                           want_db ? part + (size_t)splits * N[i] * K[i] : nullptr,
+                           wide_out ? N[i] : K[i], wide_out ? K[i] : N[i], wide_out ? 1 : 0, split_len, splits};
+      max_splits = std::max(max_splits, splits); max_wide = std::max(max_wide, wide_out ? N[i] : K[i]);
+    }
+    bool any = false;
+    for (int i = 0; i < G; ++i) any = any || sk.p[i].gate != nullptr;
+    const dim3 grid(max_splits, G), block(2 * max_wide);
+    if (any && gate_act == TRL_ACT_TANH)      hipLaunchKernelGGL(skinny_bwdw_kernel<TRL_ACT_TANH>, grid, block, 0, (hipStream_t)stream, sk);
+    else if (any && gate_act == TRL_ACT_RELU) hipLaunchKernelGGL(skinny_bwdw_kernel<TRL_ACT_RELU>, grid, block, 0, (hipStream_t)stream, sk);
+    else                                      hipLaunchKernelGGL(skinny_bwdw_kernel<TRL_ACT_NONE>, grid, block, 0, (hipStream_t)stream, sk);
+    TRL_LAUNCH_CHECK();
+    return TRL_OK;
+  }
   GemmDev g{};
   g.gate_act = gate_act; g.act = TRL_ACT_NONE; g.groups = G; g.hetero = 1;
   int max_tiles = 0, max_splits = 0;
