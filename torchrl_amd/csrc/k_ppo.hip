@@ -122,6 +122,9 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 
   // The first tile's inputs sit behind a dependent pair of loads (row index -> cells): they are requested before
   // anything else, so that they travel while the weights are staged.
+  // (requested before anything else: behind the set-up's barrier these two loads were a memory round trip of their own --
+  // a load cannot be hoisted across a barrier by the compiler)
+  const double adv_s1 = IS_PF ? a.adv_raw[0] : 0.0, adv_s2 = IS_PF ? a.adv_raw[1] : 0.0;
   const int B = a.rows_mb * a.N;
   const int n_tiles = (B + 15) / 16;
   const int tile_stride = n_wg_net * WV_WAVES;
@@ -326,8 +329,8 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
 
   // advantage normalisation constants (ppo.py:141-147): mean, unbiased std
   const double ng = a.n_global;
-  const double adv_mean = a.adv_raw[0] / ng;
-  const double adv_var = (a.adv_raw[1] - a.adv_raw[0] * a.adv_raw[0] / ng) / (ng - 1.0);
+  const double adv_mean = adv_s1 / ng;
+  const double adv_var = (adv_s2 - adv_s1 * adv_s1 / ng) / (ng - 1.0);
   const float adv_mu = (float)adv_mean;
   const float adv_rstd = 1.0f / ((float)sqrt(fmax(adv_var, 0.0)) + 1e-5f);
   const float inv_b = (float)(1.0 / ng);
