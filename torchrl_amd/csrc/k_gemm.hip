@@ -58,6 +58,7 @@ struct GemmDev {
   int chw_p;                  // CONV == 3, != 0: C is stored (b, n, p) with p = m % chw_p (= Ho * Wo), nn.Flatten's order
   int groups;                 // > 1: the operand pointers of problem blockIdx.y come from grp[]
   GemmGroup grp[GEMM_MAX_GROUPS];
+  int prefer128;              // != 0: the caller sized its reduction split for 128 x 128 tiles (split-K forward of few-row layers)
   int hetero;                 // != 0: problem blockIdx.y also has its own shape (the grid is sized for the largest)
   GemmShape shp[GEMM_MAX_GROUPS];
 };
@@ -639,7 +640,7 @@ static bool tile_128(const GemmDev& g, int splits) {
   static const int pin = [] { const char* e = getenv("TRL_GEMM_TILE"); return e ? atoi(e) : 0; }();
   if (g.hetero || g.M < 128 || g.N < 128) return false;
   if (pin == 64) return false;
-  if (pin == 128) return true;
+  if (pin == 128 || g.prefer128) return true;
   const int64_t tiles = (int64_t)trl_ceil_div(g.M, 128) * trl_ceil_div(g.N, 128) * std::max(1, g.groups) * splits;
   return tiles >= 1024;
 }
@@ -703,7 +704,20 @@ extern "C" int trl_linear_fwd_group_f32(int G, const float* const* x, const floa
 
 // Split-K forward for few-row layers with a long reduction (the conv nets' first FC layer: 512 x 3136 -> 512 is
 // 64 C tiles for 256 CUs): up to 8 reduction slices write partial products, the fold adds bias and activation.
-static int fwd_split_len(int M, int K, int N) {
+// Few output tiles and a long reduction (the conv nets' first FC layer: 512 x 3136 -> 512, 64 tiles of 64 x 64): with
+// 128 x 128 tiles and 8 reduction slices a pair of such layers is exactly one workgroup per CU, each on the more
+// efficient tile (5 slices of 64 x 64 tiles were 640 workgroups for 512 resident slots: 44.6 + 8 us per pair).
+// (One such layer alone -- the collection pass -- would be 128 workgroups: it keeps the 64 x 64 tiles.)
+static bool fwd_use_128(int M, int K, int N, int G) {
+  static const bool off = [] { const char* e = getenv("TRL_FWD_SPLIT128"); return e && atoi(e) == 0; }();   // (development A/B)
+  return !off && G >= 2 && M >= 128 && N >= 128 && K >= 1024 && trl_ceil_div(M, 64) * trl_ceil_div(N, 64) <= 96;
+}
+static int fwd_split_len(int M, int K, int N, int G = 1) {
+  if (fwd_use_128(M, K, N, G)) {
+    const int t128 = trl_ceil_div(M, 128) * trl_ceil_div(N, 128);
+    const int target = std::max(1, std::min(8, trl_ceil_div(192, t128)));
+    return trl_ceil_div(trl_ceil_div(K, target), KC) * KC;
+  }
   const int wm = tile_wm(M, N);
   const int tiles = trl_ceil_div(M, 32 * wm) * trl_ceil_div(N, 32 * (4 / wm));
   // (a handful of tiles -- the 6-wide DQN head on 512 rows is FOUR workgroups walking K = 512 panel by panel, 17 us --
@@ -714,7 +728,7 @@ static int fwd_split_len(int M, int K, int N) {
 }
 extern "C" int trl_linear_fwd_workspace(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
-  const int splits = trl_ceil_div(K, fwd_split_len(M, K, N));
+  const int splits = std::max(trl_ceil_div(K, fwd_split_len(M, K, N, 1)), trl_ceil_div(K, fwd_split_len(M, K, N, 2)));   // either policy
   return splits > 1 ? splits * M * N : 0;
 }
 extern "C" int trl_linear_fwd_splitk_f32(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
@@ -744,7 +758,7 @@ extern "C" int trl_linear_fwd_splitk_group_f32(int G, const float* const* x, con
   TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per grouped launch");
   TRL_REQUIRE(M >= 0 && K > 0 && N > 0 && x && w && y, "bad sizes / null pointer array");
   if (M == 0) return TRL_OK;
-  const int split_len = fwd_split_len(M, K, N);
+  const int split_len = fwd_split_len(M, K, N, G);
   const int splits = trl_ceil_div(K, split_len);
   if (splits <= 1) return linear_fwd_impl(G, x, w, bias, y, M, K, N, act, (hipStream_t)stream);
   TRL_REQUIRE(workspace, "null workspace");
@@ -752,6 +766,7 @@ extern "C" int trl_linear_fwd_splitk_group_f32(int G, const float* const* x, con
   GemmDev g{};
   g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.act = TRL_ACT_NONE; g.gate_act = TRL_ACT_NONE;
   g.split_len = split_len; g.groups = G;
+  g.prefer128 = fwd_use_128(M, K, N, G) ? 1 : 0;
   FoldDev f{};
   f.n = M * N; f.n2 = 0; f.splits = splits; f.n_cols = N; f.act = act;
   const float* bias0 = bias ? bias[0] : nullptr;
