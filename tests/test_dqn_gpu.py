@@ -432,3 +432,58 @@ def test_one_launch_dqn_head_equals_the_layer_kernels_and_the_loss_launch(B, H, 
     torch.testing.assert_close(dw.double(), w64.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(db.double(), b64.grad, rtol=1e-4, atol=1e-6)
     assert abs(sums[0].item() / B - loss.item()) <= 1e-5 * max(1.0, abs(loss.item()))
+
+
+@pytest.mark.parametrize("Q,horizon,max_frames", [(1, 3, 5), (8, 5, 4)])      # episodes end by `done` / by the frame cap
+def test_frame_env_rollout_as_a_replayed_graph_equals_the_step_by_step_rollout(Q, horizon, max_frames, monkeypatch):
+    """collector/base.py _replayed_rollout_frames: host draws of all steps staged ahead, the steps of an epoch as ONE graph
+    into staging rows, then copied to the ring (wrapping).  Every epoch (eager first visit, captured, replayed ...) must
+    leave the ring, the epoch results, the env and the policy's epsilon exactly as the step-by-step path does."""
+    from torchrl.collector import VecCollector
+    from torchrl.env import get_vec_env
+    from torchrl.policies import EpsilonGreedyDQNDiscretePolicy, EpsilonGreedyQRDQNDiscretePolicy
+    from torchrl.replay_buffers import BaseReplayBuffer
+    N, A, steps, rows, epochs = 6, 5, 3, 7, 6
+
+    def run(no_graph):
+        if no_graph:
+            monkeypatch.setenv("TRL_NO_GRAPH", "1")
+        else:
+            monkeypatch.delenv("TRL_NO_GRAPH", raising=False)
+        env = get_vec_env("SynthAtari-v0", {"reward_scale": 1}, N)
+        eval_env = get_vec_env("SynthAtari-v0", {"reward_scale": 1}, N)
+        env.horizon = eval_env.horizon = horizon
+        env.seed(4)
+        env.reset()
+        torch.manual_seed(5)
+        qf = small_qnet(A, Q).to(DEV)
+        kw = dict(qf=qf, start_epsilon=0.6, end_epsilon=0.2, decay_frames=10, action_shape=A)
+        pf = EpsilonGreedyQRDQNDiscretePolicy(quantile_num=Q, **kw) if Q > 1 else EpsilonGreedyDQNDiscretePolicy(**kw)
+        buf = BaseReplayBuffer(N * rows, env_nums=N)
+        col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=DEV, epoch_frames=N * steps,
+                           max_episode_frames=max_frames, eval_episodes=1)
+        np.random.seed(12)
+        out = []
+        for e in range(epochs):
+            res = col.train_one_epoch()
+            out.append((float(res["train_epoch_reward"]), [float(x) for x in res["train_rewards"]], pf.epsilon, pf.count,
+                        buf._top, buf._size, col.global_step,
+                        {k: getattr(buf, "_" + k).cpu().numpy().copy() for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits")},
+                        env.cur_obs.cpu().numpy().copy(), env.t_env.cpu().numpy().copy(), env.cur_step.cpu().numpy().copy(),
+                        env.ep_return.cpu().numpy().copy()))
+        ev = col.eval_one_epoch()
+        return out, getattr(col, "_fr", None), ev, np.random.rand(3)
+
+    plain, fr0, ev0, tail0 = run(True)
+    graph, fr1, ev1, tail1 = run(False)
+    assert fr0 is None and fr1 is not None and fr1["graph"] is not None        # the second run did replay a graph
+    assert np.array_equal(tail0, tail1)                                          # the numpy stream is where it would be
+    assert ev0["eval_rewards"] == ev1["eval_rewards"]
+    for e in range(epochs):
+        a, b = plain[e], graph[e]
+        assert a[:7] == b[:7], (e, a[:7], b[:7])
+        for k in a[7]:
+            assert np.array_equal(a[7][k], b[7][k]), (e, k)
+        for i in range(8, 12):
+            assert np.array_equal(a[i], b[i]), (e, i)
+    assert any(len(p[1]) for p in plain) == (horizon < max_frames)               # finished episodes were logged along the way
