@@ -167,13 +167,17 @@ template <int TMB> __host__ __device__ constexpr int gemm_panel() { return TMB =
 // matrix pipe, where round 3's single buffer had `stash; barrier; fetch; MFMA; barrier` in series (0.64 of the measured
 // MFMA peak at 4096^3).  The k order of every output element is unchanged (panels ascending, k = 8 q + 4 hi + r inside),
 // so results are bit-identical to the one-buffer loop.
-template <bool TA, bool TB, int GATE, int CONV, int WM, int TMB = 1>
+// KPX (0: the tile's default): panel size override.  KPX = 32 on the 64 x 64 tile halves the two panel buffers to 36 KB,
+// so FOUR workgroups share a CU instead of two -- for reductions of a few panels per workgroup (K = 256 layers, 256-row
+// slices of a split weight gradient) the prologue / epilogue of one workgroup then hides under the MFMAs of three others.
+template <bool TA, bool TB, int GATE, int CONV, int WM, int TMB = 1, int KPX = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
   static_assert(CONV == 0 || ((CONV == 1 || CONV == 3) && !TA && TB) || ((CONV == 2 || CONV == 4) && TA && !TB),
                 "implicit operand orientation");
   static_assert(TMB == 1 || (TMB == 2 && WM == 2 && CONV == 0), "the 2 x 2-block wave tile is dense and square");
   constexpr bool CA = CONV == 1 || CONV == 3, CB = CONV == 2 || CONV == 4, U8 = CONV == 1 || CONV == 2;
-  constexpr int KP = gemm_panel<TMB>(), NQ = KP / 8;
+  static_assert(KPX == 0 || (KPX == 32 && CONV == 0), "panel override: 32, dense operands");
+  constexpr int KP = KPX ? KPX : gemm_panel<TMB>(), NQ = KP / 8;
   using PG = PanelGeom<KP>;
   constexpr int WN = 4 / WM, GM = 32 * WM * TMB, GN = 32 * WN * TMB;
   constexpr int SA = panel_slots<!TA, GM, KP>(), SB = panel_slots<TB, GN, KP>();
@@ -610,23 +614,23 @@ int trl_fold_partials(const float* part, float* out, int n, const float* part2, 
   return launch_fold(f, 1, stream);
 }
 
-template <bool TA, bool TB, int GATE, int CONV, int WM, int TMB = 1>
+template <bool TA, bool TB, int GATE, int CONV, int WM, int TMB = 1, int KPX = 0>
 static int launch_gemm_tile(GemmDev g, int splits, hipStream_t s) {
-  constexpr int KP = gemm_panel<TMB>();
+  constexpr int KP = KPX ? KPX : gemm_panel<TMB>();
   constexpr int GM = 32 * WM * TMB, GN = 32 * (4 / WM) * TMB;
   const int tiles_lds = 2 * (int)sizeof(float) * (tile_floats<!TA, GM, KP>() + tile_floats<TB, GN, KP>());   // two panel buffers
   const int lds = tiles_lds + (CONV == 1 ? g.K : 0);              // CONV 1: + the tap offset table (K / 4 dwords)
   TRL_REQUIRE(lds <= 160 * 1024, "reduction too long for the implicit first-layer kernel");
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE, CONV, WM, TMB>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<TA, TB, GATE, CONV, WM, TMB, KPX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { trl_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_lds = lds;
   }
   g.tiles_n = trl_ceil_div(g.N, GN);
   g.tiles = g.tiles_n * trl_ceil_div(g.M, GM);
-  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE, CONV, WM, TMB>), dim3(g.tiles, std::max(1, g.groups), splits), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, GATE, CONV, WM, TMB, KPX>), dim3(g.tiles, std::max(1, g.groups), splits), dim3(256), lds, s, g);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -645,13 +649,27 @@ static bool tile_128(const GemmDev& g, int splits) {
   return tiles >= 1024;
 }
 
+// Short reductions on many 64 x 64 tiles (>= 3 rounds of 256 workgroups, <= 8 panels of 64 each): the 32-wide panel,
+// four workgroups per CU.  TRL_GEMM_KP=64 / 32 pins either (development).
+static bool short_reduction(const GemmDev& g, int splits) {
+  static const int pin = [] { const char* e = getenv("TRL_GEMM_KP"); return e ? atoi(e) : 0; }();
+  if (g.hetero || pin == 64) return false;
+  const int64_t wgs = (int64_t)trl_ceil_div(g.M, 64) * trl_ceil_div(g.N, 64) * std::max(1, g.groups) * splits;
+  const int red = splits > 1 ? g.split_len : g.K;
+  if (pin == 32) return true;
+  return wgs >= 768 && red <= 512;
+}
+
 template <bool TA, bool TB, int GATE, int CONV>
 static int launch_gemm_gate(const GemmDev& g, int splits, hipStream_t s) {
   switch (tile_wm(g.M, g.N)) {
     case 4:  return launch_gemm_tile<TA, TB, GATE, CONV, 4>(g, splits, s);
     case 1:  return launch_gemm_tile<TA, TB, GATE, CONV, 1>(g, splits, s);
     default:
-      if constexpr (CONV == 0) { if (tile_128(g, splits)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 2>(g, splits, s); }
+      if constexpr (CONV == 0) {
+        if (tile_128(g, splits)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 2>(g, splits, s);
+        if (short_reduction(g, splits)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 1, 32>(g, splits, s);
+      }
       return launch_gemm_tile<TA, TB, GATE, CONV, 2>(g, splits, s);
   }
 }
@@ -984,19 +1002,31 @@ __global__ __launch_bounds__(512) void skinny_bwdw_kernel(SkinnyDev g) {
   }
 }
 
-template <int GATE>
-static int launch_bwd_weight_multi(GemmDev& g, int max_tiles, int max_splits, hipStream_t s) {
-  constexpr int lds = 2 * (int)sizeof(float) * (tile_floats<false, 64, gemm_panel<1>()>() + tile_floats<false, 64, gemm_panel<1>()>());
+template <int GATE, int KPX>
+static int launch_bwd_weight_multi_kp(GemmDev& g, int max_tiles, int max_splits, hipStream_t s) {
+  constexpr int KP = KPX ? KPX : gemm_panel<1>();
+  constexpr int lds = 2 * (int)sizeof(float) * (tile_floats<false, 64, KP>() + tile_floats<false, 64, KP>());
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<true, false, GATE, 0, 2>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<true, false, GATE, 0, 2, 1, KPX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { trl_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<true, false, GATE, 0, 2>), dim3(max_tiles, g.groups, max_splits), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<true, false, GATE, 0, 2, 1, KPX>), dim3(max_tiles, g.groups, max_splits), dim3(256), lds, s, g);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
+}
+template <int GATE>
+static int launch_bwd_weight_multi(GemmDev& g, int max_tiles, int max_splits, hipStream_t s) {
+  // slices of <= 512 batch rows on >= 768 workgroups: the 32-wide panel, four workgroups per CU (see gemm_f32_kernel)
+  static const int pin = [] { const char* e = getenv("TRL_GEMM_KP"); return e ? atoi(e) : 0; }();
+  int64_t wgs = 0;
+  int longest = 0;
+  for (int i = 0; i < g.groups; ++i) { wgs += (int64_t)g.shp[i].tiles * g.shp[i].splits; longest = std::max(longest, g.shp[i].split_len); }
+  if (pin != 64 && (pin == 32 || (wgs >= 768 && longest <= 512)))
+    return launch_bwd_weight_multi_kp<GATE, 32>(g, max_tiles, max_splits, s);
+  return launch_bwd_weight_multi_kp<GATE, 0>(g, max_tiles, max_splits, s);
 }
 extern "C" int trl_linear_bwd_weight_partials_multi_f32(int G, const float* const* dy, const float* const* y_gate,
                                                         int gate_act, const float* const* x, const int* K, const int* N,
