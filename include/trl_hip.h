@@ -521,12 +521,17 @@ int trl_tanh_gauss_rsample_bwd_cols_f32(const float* head, const float* eps, con
  * gate_act NONE: dy is dZ already) times the ACTION columns [off, off + A) of its first-layer weight w[i] (H, ldw),
  *   d_act = sum_i dZ_i w[i][:, off:off+A],   d_head = what trl_tanh_gauss_rsample_bwd_f32 makes of d_act
  * -- the input-gradient GEMM of that layer (whose other columns nobody reads) and the sampler's backward launch in one.
- * H % 4 == 0, H <= 1024, A <= 8 (trl_sac_policy_grad_supported), 16-byte aligned rows. */
+ * H % 4 == 0, H <= 1024, A <= 8 (trl_sac_policy_grad_supported), 16-byte aligned rows.
+ * head_dz (nullable): the policy's own head backward rides along (GuassianContPolicy's last nn.Linear, (2A, H) weight head_w):
+ *   head_dz = (d_head head_w) * act'(head_h)      (B, H), head_h = that layer's input = the second hidden layer's outputs
+ * i.e. the gradient at the policy's second hidden layer already gated for the layer below (the same hidden width H as the
+ * critics': nets.py builds both from one hidden_shapes list) -- instead of a 2A-deep input-gradient GEMM launch. */
 int trl_sac_policy_grad_supported(int H, int A);
 int trl_sac_policy_grad_f32(int n, const float* const* dy, const float* const* y, int gate_act, const float* const* w,
                             int H, int ldw, int off, const float* head, const float* eps, const float* act,
                             const float* d_logp_ptr, float d_logp_mul, float w_std, float w_mean, float* d_head, int B,
-                            int A, int tanh_action, void* stream);
+                            int A, int tanh_action, const float* head_w, const float* head_h, int head_act, float* head_dz,
+                            void* stream);
 /* both policy samples of one update and the three critic inputs in ONE launch (twin_sac_q.py:93-106, 125-131,
  * 146-151): (new_a, logp) from head = pf(obs) with eps1, (next_a, next_logp) from head2 = pf(next_obs) with eps2,
  * x_sa = [obs | acts], x_next = [next_obs | next_a], x_new = [obs | new_a]  (each (B, D + A)).

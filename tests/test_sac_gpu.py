@@ -484,6 +484,24 @@ def test_one_launch_policy_gradient_equals_the_layer_gemm_and_the_sampler_backwa
     assert torch.equal(got, again)
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= 2e-5 * max(scale, 1.0), ((got - want).abs().max().item(), scale)
+    # the policy's own head backward riding along: dZ2 = (d_head W3) * act'(H2), against the layer launch it replaces
+    # (input-gradient GEMM, gated by the launch below it) and against float64
+    w3 = torch.randn(2 * A, H, device=dev) * 0.1
+    h2 = torch.tanh(torch.randn(B, H, device=dev))
+    if act == "relu":
+        h2 = h2.clamp_min(0.0)
+    d2, dz = _C.sac_policy_grad(head, eps, actv, dys, ys, code, ws, D, alpha, 1.0 / B, 1e-3, 2e-3, True, head_layer=(w3, h2, code))
+    assert torch.equal(d2, got) and dz is not None
+    raw = _C.linear_bwd_input(got, None, _C.ACT_NONE, w3)                       # (B, H), ungated
+    gate = {"relu": (h2 > 0).float(), "tanh": 1.0 - h2 * h2, "none": torch.ones_like(h2)}[act]
+    ref64 = (got.double() @ w3.double()) * gate.double()
+    sc = ref64.abs().max().item()
+    assert (dz.double() - ref64).abs().max().item() <= 2e-6 * max(sc, 1.0)
+    assert (dz - raw * gate).abs().max().item() <= 2e-6 * max(sc, 1.0)
+    # shapes that do not fit (hidden width of the policy != the critics'): no fused output, d_head unchanged
+    d3, none = _C.sac_policy_grad(head, eps, actv, dys, ys, code, ws, D, alpha, 1.0 / B, 1e-3, 2e-3, True,
+                                  head_layer=(torch.randn(2 * A, H + 4, device=dev), torch.randn(B, H + 4, device=dev), code))
+    assert none is None and torch.equal(d3, got)
 
 
 def test_sac_update_with_the_streaming_policy_gradient_equals_the_gemm_path(golden):
@@ -711,3 +729,42 @@ def test_sac_trains_through_rlalgo_with_device_noise():
     agent.train()
     assert len(infos) == 8 and all(np.isfinite(list(i.values())).all() for i in infos)
     assert (pf.seq_append_fcs[0].weight - w0).abs().max() > 0 and infos[-1]["Alpha"] < 1.0
+
+
+@pytest.mark.parametrize("B,D,A", [(777, 17, 6), (64, 2, 1), (130, 32, 8), (4096, 23, 3), (65, 11, 3), (200, 33, 2)])
+def test_sampling_launch_equals_the_separate_kernels_at_other_shapes(B, D, A):
+    """trl_sac_samples_f32 against rsample_fwd / concat2 / philox_normal, bit for bit, in both noise modes and at ragged
+    batch sizes, and its per-wave partial moments against float64 torch sums."""
+    from torchrl_amd import _C
+    gen = torch.Generator().manual_seed(B + D)
+    r = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    head, head2, eps1, eps2, obs, acts, nobs = r(B, 2 * A), r(B, 2 * A), r(B, A), r(B, A), r(B, D), r(B, A), r(B, D)
+    head[:, A:] *= 8.0                                                    # some log_std outside [-20, 2]
+    parts = (B + 63) // 64
+    mom = torch.zeros(parts, 12, dtype=torch.float64, device=DEV)
+    new_a, logp, next_a, next_logp, x_sa, x_next, x_new = _C.sac_samples(head, head2, eps1, eps2, obs, acts, nobs, mom_part=mom)
+    a1, l1 = _C.rsample_fwd(head, eps1)
+    a2, l2 = _C.rsample_fwd(head2, eps2)
+    assert torch.equal(new_a, a1) and torch.equal(logp, l1) and torch.equal(next_a, a2) and torch.equal(next_logp, l2)
+    assert torch.equal(x_sa, _C.concat2(obs, acts)) and torch.equal(x_next, _C.concat2(nobs, a2))
+    assert torch.equal(x_new, _C.concat2(obs, a1))
+    ls = head[:, A:].clamp(-20.0, 2.0).double()
+    mu = head[:, :A].double()
+    lp = l1.double().reshape(-1, 1)
+    for p in range(parts):
+        sl = slice(64 * p, min(B, 64 * p + 64))
+        for j, t in enumerate((ls[sl], lp[sl], mu[sl])):
+            want = torch.stack([t.sum(), (t * t).sum(), t.max(), (-t).max()])
+            assert torch.allclose(mom[p, 4 * j:4 * j + 4], want, rtol=1e-12, atol=1e-12), (p, j)
+    # device noise: update u draws (seed, 2u + 1) and (seed, 2u + 2); eps1 receives the first draw
+    state = torch.tensor([3.0, 1.0, 1.0, 0.0], dtype=torch.float64, device=DEV)
+    e1 = torch.zeros(B, A, device=DEV)
+    outs = _C.sac_samples(head, head2, e1, None, obs, acts, nobs, philox=(state, 77))
+    w1 = _C.philox_normal(torch.empty(B, A, device=DEV), 77, 7)
+    w2 = _C.philox_normal(torch.empty(B, A, device=DEV), 77, 8)
+    assert torch.equal(e1, w1)
+    b1, m1 = _C.rsample_fwd(head, w1)
+    b2, m2 = _C.rsample_fwd(head2, w2)
+    assert torch.equal(outs[0], b1) and torch.equal(outs[1], m1) and torch.equal(outs[2], b2) and torch.equal(outs[3], m2)
+    assert torch.equal(outs[4], _C.concat2(obs, acts)) and torch.equal(outs[5], _C.concat2(nobs, b2))
+    assert torch.equal(outs[6], _C.concat2(obs, b1))

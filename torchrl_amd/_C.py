@@ -179,7 +179,8 @@ SIGNATURES = {
                                               C.c_void_p, C.c_void_p]),
     "trl_sac_policy_grad_supported": (C.c_int, [C.c_int, C.c_int]),
     "trl_sac_policy_grad_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] +
-                                [C.c_void_p] * 4 + [C.c_float] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                [C.c_void_p] * 4 + [C.c_float] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_int] +
+                                [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "trl_sac_samples_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 10 + [C.c_int] * 4 +
                             [C.c_void_p, C.c_void_p]),
     "trl_moments_multi_f64": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -996,19 +997,31 @@ def sac_policy_grad_ok(dys, ws, A):
         all(d.data_ptr() % 16 == 0 and d.is_contiguous() and d.dtype == torch.float32 for d in dys)
 
 
-def sac_policy_grad(head, eps, act, dys, ys, gate_act, ws, off, d_logp_ptr, d_logp_mul, w_std, w_mean, tanh_action=True):
+def sac_policy_grad(head, eps, act, dys, ys, gate_act, ws, off, d_logp_ptr, d_logp_mul, w_std, w_mean, tanh_action=True,
+                    head_layer=None):
     """d_head of the policy loss from the gradients `dys` at the critics' first hidden layer (outputs `ys`, weights `ws`
     (H, D + A)): the action columns [off, off + A) of that layer's input gradient, summed over the critics, pushed through
-    the sampler's backward -- one launch (include/trl_hip.h trl_sac_policy_grad_f32)."""
+    the sampler's backward -- one launch (include/trl_hip.h trl_sac_policy_grad_f32).
+    head_layer = (W3 (2A, H), H2 (B, H), act): also returns dZ2 = (d_head W3) * act'(H2), the gradient at the policy's
+    second hidden layer already gated for the layer below (None when the shapes do not fit: H2's width must be H)."""
     B, A, H = int(eps.shape[0]), int(eps.shape[1]), int(dys[0].shape[1])
     d_head = torch.empty((B, 2 * A), dtype=torch.float32, device=head.device)
     gated = gate_act != ACT_NONE and ys is not None and all(y is not None for y in ys)
+    hw = hh = hdz = None
+    hact = ACT_NONE
+    if head_layer is not None:
+        w3, h2, hact = head_layer
+        if tuple(w3.shape) == (2 * A, H) and tuple(h2.shape) == (B, H) and w3.is_contiguous() and h2.is_contiguous() \
+                and w3.data_ptr() % 16 == 0 and h2.data_ptr() % 16 == 0:
+            hw, hh, hdz = w3, h2, torch.empty((B, H), dtype=torch.float32, device=head.device)
     check(lib().trl_sac_policy_grad_f32(
         len(dys), _ptrs(dys, "dy"), _ptrs(ys, "y") if gated else None, gate_act if gated else ACT_NONE, _ptrs(ws, "w"), H,
         int(ws[0].shape[1]), int(off), dev_ptr(head, name="head"), dev_ptr(eps, name="eps"), dev_ptr(act, name="act"),
         dev_ptr(d_logp_ptr, name="d_logp_ptr", allow_none=True), float(d_logp_mul), float(w_std), float(w_mean),
-        dev_ptr(d_head, name="d_head"), B, A, int(bool(tanh_action)), stream_ptr(head.device)), "trl_sac_policy_grad_f32")
-    return d_head
+        dev_ptr(d_head, name="d_head"), B, A, int(bool(tanh_action)), dev_ptr(hw, name="head_w", allow_none=True),
+        dev_ptr(hh, name="head_h", allow_none=True), int(hact), dev_ptr(hdz, name="head_dz", allow_none=True),
+        stream_ptr(head.device)), "trl_sac_policy_grad_f32")
+    return d_head if head_layer is None else (d_head, hdz)
 
 
 def sac_samples(head, head2, eps1, eps2, obs, acts, next_obs, tanh_action=True, philox=None, mom_part=None):

@@ -228,7 +228,7 @@ class _FusedSAC:
         # The first critic layer's input gradient is only needed in its A action columns, summed over the twins and pushed
         # through the sampler's backward: one streaming launch (sac_policy_grad) instead of a (B x 256) . (256 x (D + A)) GEMM
         # per critic and the sampler launch behind it.
-        first = []
+        first, pol_dz = [], None
         dx1, dx2, _, _ = ops.mlp_backward_group([tape_q1n, tape_q2n, tape_q1, tape_q2], [dq1n, dq2n, dq1, dq2],
                                                 grads_list=[None, None, self.gviews[1], self.gviews[2]],
                                                 need_input=[True, True, False, False], plan=plan,
@@ -236,15 +236,21 @@ class _FusedSAC:
         if first:
             dys, ys, gate_act, w0 = first[0]
             if _C.sac_policy_grad_ok(dys, w0, A):
+                # ... and the policy's own head backward rides along: dZ2 = (d_head W3) * act'(H2) leaves the same launch
+                # already gated (a 2A-deep input-gradient GEMM launch less; the layer below reads one operand, not two)
+                hl = (pf_l[-1][0], tape_pf.outs[-2], self.act) if len(pf_l) >= 2 and len(tape_pf.outs) >= 2 else None
                 d_head = _C.sac_policy_grad(head, eps1, new_a, dys, ys, gate_act, w0, D, alpha, 1.0 / B,
-                                            algo.policy_std_reg_weight, algo.policy_mean_reg_weight, tanh_action)
+                                            algo.policy_std_reg_weight, algo.policy_mean_reg_weight, tanh_action,
+                                            head_layer=hl)
+                if hl is not None:
+                    d_head, pol_dz = d_head
             else:                                                         # shapes outside the streaming kernel: the layer GEMM
                 dx1, dx2 = _C.linear_bwd_input_group(dys, ys, gate_act, w0)
                 first = []
         if not first:
             d_head = _C.rsample_bwd_cols(head, eps1, new_a, dx1, dx2, D, alpha, 1.0 / B, algo.policy_std_reg_weight,
                                          algo.policy_mean_reg_weight, tanh_action)    # d_act = (dx1 + dx2)[:, D:]
-        ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], plan=plan)
+        ops.mlp_backward(tape_pf, d_head, grads=self.gviews[0], plan=plan, head_dx=pol_dz)
         # one process, soft target updates: the folds, the clip, the Adam steps, the Polyak step and the filing of the
         # statistics are ONE launch (FoldPlan.run_fused); otherwise fold here, (all-reduce,) clip + Adam (+ Polyak) below
         fused_tail = soft and self._fused_tail and dist.world_size() == 1 and plan.tiles(self.grads)

@@ -5,6 +5,7 @@
 // All kernels are memory-bound streaming passes over (B, <=32) fp32 rows; scalar results
 // (losses, means, Adam state of log_alpha) stay on the device.
 #include <algorithm>
+#include <cstdlib>
 #include "trl_common.h"
 #include "trl_mlp.h"
 #include "trl_philox.h"
@@ -297,6 +298,9 @@ extern "C" int trl_tanh_gauss_rsample_bwd_cols_f32(const float* head, const floa
 struct PolGrad {
   const float* dy[2]; const float* y[2]; const float* w[2];   // critic i: dY, Y (B, H); W (H, ldw); y[i] NULL: dy is dZ already
   int n, H, ldw, off, gate_act;
+  // optional: the policy's own head backward rides along -- dZ2 = (d_head W3) * act'(H2), the gradient at the policy's second
+  // hidden layer ALREADY gated for the layer below: hw3 (2A, H) the head's weight, hh2 (B, H) that layer's outputs, hdz (B, H)
+  const float* hw3; const float* hh2; float* hdz; int hact;
 };
 #ifdef TRL_EXP_CLK                                  // development aid (tools/bench_policy_grad.py): 100 MHz stamps of 2 workgroups
 __device__ long long g_pg_clk[2 * 8];
@@ -311,15 +315,23 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_policy_grad_kernel(PolGrad g,
                                                                       const float* __restrict__ d_logp_ptr, float d_logp_mul,
                                                                       float w_std, float w_mean, float* __restrict__ d_head,
                                                                       int B, int A, int tanh_action) {
-  extern __shared__ __attribute__((aligned(16))) float wt[];          // [critic][PG_MAX_A][H]
+  extern __shared__ __attribute__((aligned(16))) float wt[];          // [critic][PG_MAX_A][H] | head weight [2A][H] (g.hdz)
   const int H = g.H, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* const w3s = wt + g.n * PG_MAX_A * H;
   const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
   // a row's loads: 2 critics x {dY, Y} x 16 bytes per lane and chunk, and the sampler's inputs for lanes 0..A-1 -- requested
   // for the FIRST row before the weights are staged (nothing of a row depends on them), and for the next row before the
   // current one is reduced: one memory round trip per row instead of three
-  f32x4 zv[2][CH], yv[2][CH];
+  f32x4 zv[2][CH], yv[2][CH], hv[CH];
   float h_mean = 0.0f, h_raw = 0.0f, h_eps = 0.0f, h_act = 0.0f;
   auto fetch = [&](int b) {
+    if (g.hdz) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = c * 256 + lane * 4;
+        hv[c] = j < H ? *reinterpret_cast<const f32x4*>(g.hh2 + (size_t)b * H + j) : zero4;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -353,6 +365,8 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_policy_grad_kernel(PolGrad g,
       for (int r = A * H + threadIdx.x; r < PG_MAX_A * H; r += SAC_THREADS) wt[i * PG_MAX_A * H + r] = 0.0f;
     }
   }
+  if (g.hdz) for (int r = threadIdx.x; r < 2 * A * (H >> 2); r += SAC_THREADS)
+    reinterpret_cast<f32x4*>(w3s)[r] = reinterpret_cast<const f32x4*>(g.hw3)[r];
   __syncthreads();
   PCLK(2)
   const float d_logp = (d_logp_ptr ? *d_logp_ptr : 1.0f) * d_logp_mul;     // alpha / B, alpha a device scalar
@@ -395,13 +409,16 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_policy_grad_kernel(PolGrad g,
     }
     PCLK(3)
     const float mean = h_mean, raw = h_raw, ev = h_eps, a = h_act;
+    f32x4 hcur[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) hcur[c] = hv[c];
     if (b + stride < B) fetch(b + stride);
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
 #pragma unroll
       for (int o = 0; o < PG_MAX_A; ++o) part[o] += __shfl_xor(part[o], s, 64);
     }
-    float da = 0.0f;
+    float da = 0.0f, g_mean = 0.0f, g_ls = 0.0f;
 #pragma unroll
     for (int o = 0; o < PG_MAX_A; ++o) da = lane == o ? part[o] : da;
     if (lane < A) {
@@ -412,8 +429,41 @@ __global__ __launch_bounds__(SAC_THREADS) void sac_policy_grad_kernel(PolGrad g,
       float da_dz = 1.0f, t = 0.0f;
       if (tanh_action) { da_dz = fmaf(-a, a, 1.0f); t = 2.0f * a * da_dz / (da_dz + 1e-6f); }
       const float g_z = da * da_dz + d_logp * t;                         // through z
-      d_head[(size_t)b * 2 * A + o] = g_z + w_mean * reg * mean;
-      d_head[(size_t)b * 2 * A + A + o] = pass * (g_z * se - d_logp + w_std * reg * ls);
+      g_mean = g_z + w_mean * reg * mean;
+      g_ls = pass * (g_z * se - d_logp + w_std * reg * ls);
+      d_head[(size_t)b * 2 * A + o] = g_mean;
+      d_head[(size_t)b * 2 * A + A + o] = g_ls;
+    }
+    if (g.hdz) {
+      // dZ2[b][j] = (sum_k d_head[b][k] W3[k][j]) * act'(H2[b][j]), k ascending (means, then log_stds): lane owns 4 columns
+      // per chunk, the 2A head gradients are wave-uniform (read from the lanes that made them)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = c * 256 + lane * 4;
+        if (CH == 1 || j < H) {
+          const int j4 = (j < H ? j : 0) >> 2;
+          f32x4 acc = zero4;
+          for (int o = 0; o < A; ++o) {
+            const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g_mean), o));
+            const f32x4 wv = reinterpret_cast<const f32x4*>(w3s)[o * (H >> 2) + j4];
+            acc[0] = fmaf(m, wv[0], acc[0]); acc[1] = fmaf(m, wv[1], acc[1]); acc[2] = fmaf(m, wv[2], acc[2]); acc[3] = fmaf(m, wv[3], acc[3]);
+          }
+          for (int o = 0; o < A; ++o) {
+            const float l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g_ls), o));
+            const f32x4 wv = reinterpret_cast<const f32x4*>(w3s)[(A + o) * (H >> 2) + j4];
+            acc[0] = fmaf(l, wv[0], acc[0]); acc[1] = fmaf(l, wv[1], acc[1]); acc[2] = fmaf(l, wv[2], acc[2]); acc[3] = fmaf(l, wv[3], acc[3]);
+          }
+          const f32x4 h = hcur[c];
+          if (g.hact == TRL_ACT_RELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = h[q] > 0.0f ? acc[q] : 0.0f;
+          } else if (g.hact == TRL_ACT_TANH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] *= 1.0f - h[q] * h[q];
+          }
+          if (j < H) *reinterpret_cast<f32x4*>(g.hdz + (size_t)b * H + j) = acc;
+        }
+      }
     }
     PCLK(4)
   }
@@ -424,7 +474,8 @@ extern "C" int trl_sac_policy_grad_supported(int H, int A) {
 extern "C" int trl_sac_policy_grad_f32(int n, const float* const* dy, const float* const* y, int gate_act,
                                        const float* const* w, int H, int ldw, int off, const float* head, const float* eps,
                                        const float* act, const float* d_logp_ptr, float d_logp_mul, float w_std, float w_mean,
-                                       float* d_head, int B, int A, int tanh_action, void* stream) {
+                                       float* d_head, int B, int A, int tanh_action, const float* head_w, const float* head_h,
+                                       int head_act, float* head_dz, void* stream) {
   TRL_REQUIRE(B >= 0 && (n == 1 || n == 2) && trl_sac_policy_grad_supported(H, A), "policy_grad: 1-2 critics, H % 4 == 0, H <= 1024, A <= 8");
   TRL_REQUIRE(off >= 0 && off + A <= ldw, "policy_grad: action columns outside the weight");
   if (B == 0) return TRL_OK;
@@ -437,7 +488,14 @@ extern "C" int trl_sac_policy_grad_f32(int n, const float* const* dy, const floa
     g.dy[i] = dy[i]; g.y[i] = (y && gate_act != TRL_ACT_NONE) ? y[i] : nullptr; g.w[i] = w[i];
     TRL_REQUIRE(((reinterpret_cast<uintptr_t>(g.dy[i]) | reinterpret_cast<uintptr_t>(g.y[i])) & 15) == 0, "policy_grad: 16-byte aligned rows");
   }
-  const int lds = n * PG_MAX_A * H * (int)sizeof(float);
+  if (head_dz) {
+    TRL_REQUIRE(head_w && head_h, "policy_grad: head backward needs the head weight and the hidden outputs");
+    TRL_REQUIRE(head_act == TRL_ACT_TANH || head_act == TRL_ACT_RELU || head_act == TRL_ACT_NONE, "unknown activation");
+    TRL_REQUIRE(((reinterpret_cast<uintptr_t>(head_w) | reinterpret_cast<uintptr_t>(head_h) | reinterpret_cast<uintptr_t>(head_dz)) & 15) == 0,
+                "policy_grad: 16-byte aligned head operands");
+    g.hw3 = head_w; g.hh2 = head_h; g.hdz = head_dz; g.hact = head_act;
+  }
+  const int lds = (n * PG_MAX_A + (head_dz ? 2 * A : 0)) * H * (int)sizeof(float);
   // (a row is one memory round trip of its wave: as many waves as the chip holds, one or two rows each)
   const int grid = std::max(1, std::min(trl_ceil_div(B, SAC_THREADS / 64), 1024));
   if (H <= 256) {
@@ -559,6 +617,13 @@ __global__ __launch_bounds__(SAC_WIDE) void sac_losses_kernel(const float* __res
     }
   };
   request(threadIdx.x);
+  // the moment fold's first 64 partial rows (one per lane of the last wave) travel with the first group of loads
+  double mp[3][4] = {{0, 0, -INFINITY, -INFINITY}, {0, 0, -INFINITY, -INFINITY}, {0, 0, -INFINITY, -INFINITY}};
+  if (x.mom_part && (threadIdx.x >> 6) == (blockDim.x >> 6) - 1 && (int)(threadIdx.x & 63) < x.parts) {
+    const double* row = x.mom_part + (size_t)(threadIdx.x & 63) * 12;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { mp[j][0] = row[4 * j]; mp[j][1] = row[4 * j + 1]; mp[j][2] = row[4 * j + 2]; mp[j][3] = row[4 * j + 3]; }
+  }
   float alpha;
   if (x.alpha_state) {                                                 // (one workgroup: the launcher's contract)
     double s = 0.0;
@@ -590,11 +655,24 @@ __global__ __launch_bounds__(SAC_WIDE) void sac_losses_kernel(const float* __res
       s1 += (double)e1 * e1; s2 += (double)e2 * e2; sp += (double)(alpha * in[j][9] - fminf(a, c)); sr += (double)in[j][3];
     }
   }
-  if (x.mom_part && (threadIdx.x >> 6) == (blockDim.x >> 6) - 1) {     // the last wave: no barrier in here
-    const int lane = threadIdx.x & 63;
+  // the four loss sums: ONE exchange (wave sums side by side, one barrier, threads 0..3 add the waves in block_sum's order)
+  // instead of four block_sum calls with two barriers each
+  __shared__ double red4[SAC_WIDE / 64][4];
+  {
+    const double w1 = wave_sum(s1), w2 = wave_sum(s2), wp = wave_sum(sp), wr = wave_sum(sr);
+    if ((threadIdx.x & 63) == 0) { double* r = red4[threadIdx.x >> 6]; r[0] = w1; r[1] = w2; r[2] = wp; r[3] = wr; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {                                               // ONE workgroup (launcher)
+    double r = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += red4[w][threadIdx.x];
+    sums[threadIdx.x] = r;
+  }
+  if (x.mom_part && (threadIdx.x >> 6) == (blockDim.x >> 6) - 1) {     // the last wave folds the partial moments (values it
+    const int lane = threadIdx.x & 63;                                 // requested at kernel entry: mp[])
     for (int j = 0; j < 3; ++j) {
-      double a = 0, c = 0, mx = -INFINITY, nmn = -INFINITY;
-      for (int p = lane; p < x.parts; p += 64) {
+      double a = mp[j][0], c = mp[j][1], mx = mp[j][2], nmn = mp[j][3];
+      for (int p = lane + 64; p < x.parts; p += 64) {
         const double* row = x.mom_part + (size_t)p * 12 + 4 * j;
         a += row[0]; c += row[1]; mx = fmax(mx, row[2]); nmn = fmax(nmn, row[3]);
       }
@@ -608,8 +686,6 @@ __global__ __launch_bounds__(SAC_WIDE) void sac_losses_kernel(const float* __res
       }
     }
   }
-  s1 = block_sum(s1, smem); s2 = block_sum(s2, smem); sp = block_sum(sp, smem); sr = block_sum(sr, smem);
-  if (threadIdx.x == 0) { sums[0] = s1; sums[1] = s2; sums[2] = sp; sums[3] = sr; }     // ONE workgroup (launcher)
 }
 extern "C" int trl_sac_losses_f32(const float* q1, const float* q2, const float* tq1, const float* tq2,
                                        const float* logp_next, const float* rew, const float* term, const float* q1n,

@@ -52,12 +52,15 @@ def mlp_forward(layers, x, act, last_act=None):
     return h, t
 
 
-def mlp_backward(tape, d_out, grads=None, need_input=False, workspace=None, plan=None):
+def mlp_backward(tape, d_out, grads=None, need_input=False, workspace=None, plan=None, head_dx=None):
     """d_out: gradient w.r.t. the network output.  grads: [(dW_view, db_view), ...] to fill (or None
     to skip weight gradients).  Returns d(input) if need_input.  plan (_C.FoldPlan): the weight gradients are only
-    final after `plan.run()` (one fold launch for the whole pass)."""
+    final after `plan.run()` (one fold launch for the whole pass).  head_dx (with plan): the gradient at the last hidden
+    layer, ALREADY gated by that layer's act' (somebody computed it along the way): the last layer's input-gradient launch
+    is skipped."""
     if plan is not None:
-        out = mlp_backward_group([tape], [d_out], None if grads is None else [grads], need_input, plan=plan)
+        out = mlp_backward_group([tape], [d_out], None if grads is None else [grads], need_input, plan=plan,
+                                 head_dx=None if head_dx is None else [head_dx])
         return out[0] if need_input else None
     d = d_out
     n = len(tape.layers)
@@ -110,13 +113,16 @@ def mlp_forward_group(layers_list, xs, act, last_act=None, keep=None):
     return hs, tapes
 
 
-def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspace=None, plan=None, input_sink=None):
+def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspace=None, plan=None, input_sink=None,
+                       head_dx=None):
     """`mlp_backward` of G same-shaped tapes with grouped launches.  grads_list: [grads of tape g] or None; an entry may
     be None (no weight gradients for that tape).  need_input: one flag, or one per tape -- tapes that do not need
     d(input) drop out of the first layer's input-gradient launch (their slot of the result is None).
     input_sink(dys, ys, gate_act, ws): called INSTEAD of the first layer's input-gradient launch with the gradients at
     that layer's outputs, the outputs that gate them (or None) and the layer's weights, for the tapes that need d(input)
-    -- a caller that only needs some columns of it (SAC's policy gradient: the action columns) computes them itself."""
+    -- a caller that only needs some columns of it (SAC's policy gradient: the action columns) computes them itself.
+    head_dx: [gradient at the last hidden layer of tape g, already gated by its act'] -- replaces the last layer's
+    input-gradient launch."""
     ds = list(d_outs)
     n = len(tapes[0].layers)
     want_in = list(need_input) if isinstance(need_input, (list, tuple)) else [bool(need_input)] * len(tapes)
@@ -136,7 +142,9 @@ def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspa
                 _C.linear_bwd_weight_partials_group(*args, plan)
             else:
                 _C.linear_bwd_weight_group(*args, workspace=workspace)
-        if k > 0 and last and gate_act == _C.ACT_NONE and int(tapes[0].layers[k][0].shape[0]) == 1 and \
+        if k > 0 and last and head_dx is not None:
+            ds, pregated = list(head_dx), True
+        elif k > 0 and last and gate_act == _C.ACT_NONE and int(tapes[0].layers[k][0].shape[0]) == 1 and \
                 int(tapes[0].layers[k][0].shape[1]) % 4 == 0 and \
                 all(t.outs[k - 1].data_ptr() % 16 == 0 for t in tapes):
             # a head with ONE output: d(hidden) = dq w^T is rank 1 -- produced already gated for the layer below by one
