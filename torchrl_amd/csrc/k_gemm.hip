@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
                 "implicit operand orientation");
   static_assert(TMB == 1 || (TMB == 2 && WM == 2 && CONV == 0), "the 2 x 2-block wave tile is dense and square");
   constexpr bool CA = CONV == 1 || CONV == 3, CB = CONV == 2 || CONV == 4, U8 = CONV == 1 || CONV == 2;
-  static_assert(KPX == 0 || (KPX == 32 && CONV == 0), "panel override: 32, dense operands");
+  static_assert(KPX == 0 || (KPX == 32 && (CONV == 0 || CONV == 3)), "panel override: 32; dense operands or the fp32 channels-last forward");
   constexpr int KP = KPX ? KPX : gemm_panel<TMB>(), NQ = KP / 8;
   using PG = PanelGeom<KP>;
   constexpr int WN = 4 / WM, GM = 32 * WM * TMB, GN = 32 * WN * TMB;
@@ -649,26 +649,30 @@ static bool tile_128(const GemmDev& g, int splits) {
   return tiles >= 1024;
 }
 
-// Short reductions on many 64 x 64 tiles (>= 3 rounds of 256 workgroups, <= 8 panels of 64 each): the 32-wide panel,
-// four workgroups per CU.  TRL_GEMM_KP=64 / 32 pins either (development).
-static bool short_reduction(const GemmDev& g, int splits) {
+// Short reductions on many tiles (<= 8 panels of 64 each): the 32-wide panel -- half the LDS, twice the resident
+// workgroups (64 x 64 tile: four per CU instead of two; the 128 x 32 tile of narrow conv layers: three instead of ONE).
+// Dense products want >= 3 rounds of 256 workgroups before it pays, the implicit forward on the 128 x 32 tile >= 2.  TRL_GEMM_KP=64 / 32 pins either (development).
+static bool short_reduction(const GemmDev& g, int splits, int gm, int gn, int conv) {
   static const int pin = [] { const char* e = getenv("TRL_GEMM_KP"); return e ? atoi(e) : 0; }();
   if (g.hetero || pin == 64) return false;
-  const int64_t wgs = (int64_t)trl_ceil_div(g.M, 64) * trl_ceil_div(g.N, 64) * std::max(1, g.groups) * splits;
+  const int64_t wgs = (int64_t)trl_ceil_div(g.M, gm) * trl_ceil_div(g.N, gn) * std::max(1, g.groups) * splits;
   const int red = splits > 1 ? g.split_len : g.K;
   if (pin == 32) return true;
-  return wgs >= 768 && red <= 512;
+  return wgs >= (conv ? 512 : 768) && red <= 512;
 }
 
 template <bool TA, bool TB, int GATE, int CONV>
 static int launch_gemm_gate(const GemmDev& g, int splits, hipStream_t s) {
   switch (tile_wm(g.M, g.N)) {
-    case 4:  return launch_gemm_tile<TA, TB, GATE, CONV, 4>(g, splits, s);
+    case 4:
+      if constexpr (CONV == 3) { if (short_reduction(g, splits, 128, 32, CONV)) return launch_gemm_tile<TA, TB, GATE, CONV, 4, 1, 32>(g, splits, s); }
+      return launch_gemm_tile<TA, TB, GATE, CONV, 4>(g, splits, s);
     case 1:  return launch_gemm_tile<TA, TB, GATE, CONV, 1>(g, splits, s);
     default:
+      if constexpr (CONV == 0) { if (tile_128(g, splits)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 2>(g, splits, s); }
+      // (the implicit forward on 64 x 64 tiles decodes its taps once per panel: with twice the panels it lost, 56.6 vs 42 us)
       if constexpr (CONV == 0) {
-        if (tile_128(g, splits)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 2>(g, splits, s);
-        if (short_reduction(g, splits)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 1, 32>(g, splits, s);
+        if (short_reduction(g, splits, 64, 64, CONV)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 1, 32>(g, splits, s);
       }
       return launch_gemm_tile<TA, TB, GATE, CONV, 2>(g, splits, s);
   }
