@@ -476,6 +476,14 @@ int trl_linear_bwd_weight_partials_group_f32(int G, const float* const* dy, cons
                                              int N, void* stream);
 int trl_fold_partials_multi_f32(int count, const float* const* part, float* const* out, const int* n,
                                 const int* splits, void* stream);
+/* Fold scope: between begin and end (host state of the calling thread) every single-problem weight-gradient fold that
+ * trl_linear_bwd_weight_f32 / trl_conv_bwd_weight_{nhwc,u8}_f32 would launch is recorded instead, and `end` runs them as ONE
+ * launch -- same arithmetic and summation order (bit-identical gradients), one dependent launch instead of one per layer
+ * (the conv trunk of dqn_pong.json: three folds of ~5 us).  Up to 8 folds per scope (more are launched as they come); the
+ * caller gives each layer its own workspace region and reads no gradient before `end`.  Replaces nothing in the reference:
+ * it is the launch-count side of autograd's per-layer weight gradients (torchrl/networks/base.py:59-107 backward). */
+int trl_fold_scope_begin(void);
+int trl_fold_scope_end(void* stream);
 /* The weight gradients of up to 12 layers of DIFFERENT widths (K[i] inputs, N[i] outputs, the same batch M) as ONE
  * launch of split GEMMs: problem i leaves S_i = trl_linear_bwd_weight_multi_splits(M, K[i], N[i]) partials of dW_i at
  * workspace[i] ([S_i][N_i * K_i]) followed (want_db) by S_i partials of db_i ([S_i][N_i]); y_gate[i] may be NULL (no

@@ -487,3 +487,37 @@ def test_frame_env_rollout_as_a_replayed_graph_equals_the_step_by_step_rollout(Q
         for i in range(8, 12):
             assert np.array_equal(a[i], b[i]), (e, i)
     assert any(len(p[1]) for p in plain) == (horizon < max_frames)               # finished episodes were logged along the way
+
+
+@pytest.mark.parametrize("B", [5, 64])
+def test_conv_weight_gradient_folds_as_one_launch_equal_the_per_layer_folds(B):
+    """_C.FoldScope: the folds of the conv trunk's split weight-gradient partials recorded and run as ONE launch
+    (trl_fold_scope_*) against the per-layer launches -- same arithmetic, same order: bit-identical gradients.  The scope
+    closes on an error inside, and does not nest."""
+    from torchrl_amd import _C, ops
+    torch.manual_seed(2)
+    net = small_qnet(6, act=torch.nn.ReLU).to(DEV)
+    frames = torch.randint(0, 256, (B, 4, 84, 84), dtype=torch.uint8, device=DEV)
+    plist = ops.cnn_param_list(net)
+    out, tape = ops.cnn_forward(net, frames)
+    d_out = torch.randn(B, 6, device=DEV)
+    mk = lambda: [(torch.zeros_like(plist[k]), torch.zeros_like(plist[k + 1])) for k in range(0, len(plist), 2)]
+    one, per_layer = mk(), mk()
+    ops.cnn_backward(net, tape, d_out, one)                               # folds together at the end of the trunk
+    # the same trunk without the scope: every layer folds in its own launch
+    n_conv = len(tape.convs)
+    d_feat = ops.mlp_backward(tape.fc, d_out, grads=per_layer[n_conv:], need_input=True)
+    P, Cc = tape.feat_shape
+    d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P, y_gate=tape.convs[-1][2], gate_act=tape.act,
+                         gate_like_in=tape.feat_chw).view(tape.B * P, Cc)
+    needs = ops._conv_ws_needs(tape)
+    ops._cnn_trunk_backward(tape, d, per_layer, True, [torch.empty(n, device=DEV) for n in needs])
+    for (w1, b1), (w2, b2) in zip(one, per_layer):
+        assert torch.equal(w1, w2) and torch.equal(b1, b2)
+    assert any(w.abs().sum().item() > 0 for w, _ in one[:n_conv])
+    with pytest.raises(RuntimeError):
+        with _C.FoldScope(DEV):
+            raise RuntimeError("inside")
+    with _C.FoldScope(DEV):                                                # (closed by the failure above: opens again)
+        with pytest.raises(_C.TrlError):
+            _C.check(_C.lib().trl_fold_scope_begin(), "nested")

@@ -177,6 +177,8 @@ SIGNATURES = {
     "trl_fold_clip_adam_polyak_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p,
                                               C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                               C.c_void_p, C.c_void_p]),
+    "trl_fold_scope_begin": (C.c_int, []),
+    "trl_fold_scope_end": (C.c_int, [C.c_void_p]),
     "trl_sac_policy_grad_supported": (C.c_int, [C.c_int, C.c_int]),
     "trl_sac_policy_grad_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] +
                                 [C.c_void_p] * 4 + [C.c_float] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_int] +
@@ -792,6 +794,24 @@ def linear_bwd_weight_group(dys, y_gates, gate_act, xs, dws, dbs, workspace=None
                                                 _ptrs(xs, "x"), _ptrs(dws, "dw"), _ptrs(dbs, "db", True),
                                                 dev_ptr(workspace, name="workspace"), M, K, N,
                                                 stream_ptr(dys[0].device)), "trl_linear_bwd_weight_group_f32")
+
+
+class FoldScope:
+    """with FoldScope(device): the single-problem weight-gradient folds launched inside are recorded and run as ONE launch at
+    exit (include/trl_hip.h trl_fold_scope_*).  Every layer inside needs its own workspace region."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        check(lib().trl_fold_scope_begin(), "trl_fold_scope_begin")
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        rc = lib().trl_fold_scope_end(stream_ptr(self.device))       # always closes the scope, also on an error inside
+        if exc_type is None:
+            check(rc, "trl_fold_scope_end")
+        return False
 
 
 class FoldPlan:

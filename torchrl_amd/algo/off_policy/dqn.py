@@ -196,9 +196,7 @@ class _FusedDQN:
         if self.is_mlp:
             need = max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0])) for w, _ in self.layers)
         else:
-            need = max(_C.lib().trl_linear_bwd_weight_workspace(c[2].numel() // int(c[3].shape[0]), int(c[3].shape[1]),
-                                                                int(c[3].shape[0]))
-                       for c in tape.convs)                              # (output positions, C*kh*kw, Cout) per conv layer
+            need = ops.cnn_backward_workspace(tape)                          # every conv layer its own region (one fold launch)
             need = max(need, max(_C.lib().trl_linear_bwd_weight_workspace(B, int(w.shape[1]), int(w.shape[0]))
                                  for w, _ in ops.fc_layers(algo.qf)))
         if self.workspace is None or self.workspace.numel() < need:

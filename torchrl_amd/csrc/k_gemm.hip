@@ -550,10 +550,76 @@ __global__ __launch_bounds__(64 * FOLD_MAX_WAVES) void fold_partials_kernel(Fold
   }
 }
 
+// ---- fold scope: the weight-gradient folds of SEVERAL layers as one launch ----
+// Between trl_fold_scope_begin() and trl_fold_scope_end(stream) (host state of the calling thread) every single-problem
+// weight-gradient fold is RECORDED instead of launched -- the entry points that produce split partials (dense, implicit conv,
+// direct first conv layer) need no second form -- and `end` folds them all in one launch: same arithmetic, same summation
+// order, same wave count per fold as the launches it replaces (bit-identical), one dependent launch of ~5 us instead of one
+// per layer.  The caller keeps the partials of different layers in different workspace regions and reads no gradient in
+// between.
+#define FOLD_SCOPE_MAX 8
+struct FoldScopeEntry { int n, n2, splits, perm_c, perm_khw, waves, first_block; const float* part; float* out;
+                        const float* part2; float* out2; };
+struct FoldScopeDev { int count; FoldScopeEntry e[FOLD_SCOPE_MAX]; };
+static thread_local struct { bool on; int blocks; FoldScopeDev d; } g_fold_scope;
+__global__ __launch_bounds__(64 * FOLD_MAX_WAVES) void fold_scope_kernel(FoldScopeDev f) {
+  __shared__ float sl[FOLD_MAX_WAVES][FOLD_OUT];
+  int k = 0;
+  while (k + 1 < f.count && (int)blockIdx.x >= f.e[k + 1].first_block) ++k;
+  const FoldScopeEntry q = f.e[k];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6, waves = q.waves;
+  const int e = ((int)blockIdx.x - q.first_block) * FOLD_OUT + lane;
+  const bool second = e >= q.n;
+  const float* p = second ? q.part2 : q.part;
+  const int nn = second ? q.n2 : q.n, ee = second ? e - q.n : e;
+  float a = 0.0f;
+  if (slice < waves && ee < nn) {                  // (fold_partials_kernel's walk, with this fold's own wave count)
+    int s = slice;
+    for (; s + 3 * waves < q.splits; s += 4 * waves) {
+      const float x0 = p[(size_t)s * nn + ee], x1 = p[(size_t)(s + waves) * nn + ee];
+      const float x2 = p[(size_t)(s + 2 * waves) * nn + ee], x3 = p[(size_t)(s + 3 * waves) * nn + ee];
+      a += x0; a += x1; a += x2; a += x3;
+    }
+    for (; s < q.splits; s += waves) a += p[(size_t)s * nn + ee];
+  }
+  if (slice < waves) sl[slice][lane] = a;
+  __syncthreads();
+  if (slice == 0 && ee < nn) {
+    float v = (sl[0][lane] + sl[1][lane]) + (sl[2][lane] + sl[3][lane]);
+    for (int w = 4; w < waves; w += 4) v += (sl[w][lane] + sl[w + 1][lane]) + (sl[w + 2][lane] + sl[w + 3][lane]);
+    int eo = ee;
+    if (!second && q.perm_c > 0) {
+      const int K = q.perm_c * q.perm_khw, row = ee / K, kp = ee - row * K, ij = kp / q.perm_c, c = kp - ij * q.perm_c;
+      eo = row * K + c * q.perm_khw + ij;
+    }
+    (second ? q.out2 : q.out)[eo] = v;
+  }
+}
+extern "C" int trl_fold_scope_begin(void) {
+  TRL_REQUIRE(!g_fold_scope.on, "fold scope: already open on this thread");
+  g_fold_scope.on = true; g_fold_scope.blocks = 0; g_fold_scope.d.count = 0;
+  return TRL_OK;
+}
+extern "C" int trl_fold_scope_end(void* stream) {
+  TRL_REQUIRE(g_fold_scope.on, "fold scope: not open");
+  g_fold_scope.on = false;
+  if (g_fold_scope.d.count == 0) return TRL_OK;
+  hipLaunchKernelGGL(fold_scope_kernel, dim3(g_fold_scope.blocks), dim3(64 * FOLD_MAX_WAVES), 0, (hipStream_t)stream, g_fold_scope.d);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 static int launch_fold(FoldDev f, int groups, hipStream_t s) {
   const int blocks = trl_ceil_div((int64_t)f.n + f.n2, FOLD_OUT);
   // many splits behind few workgroups: 16 waves share them (latency-bound walk); otherwise 4
   const int waves = (f.splits >= 32 && (int64_t)blocks * groups < 2048) ? FOLD_MAX_WAVES : 4;
+  if (g_fold_scope.on && groups == 1 && f.n_cols == 0 && g_fold_scope.d.count < FOLD_SCOPE_MAX) {
+    const FoldGroup& q = f.grp[0];
+    g_fold_scope.d.e[g_fold_scope.d.count++] = FoldScopeEntry{f.n, f.n2, f.splits, f.perm_c, f.perm_khw, waves, g_fold_scope.blocks,
+                                                              q.part, q.out, q.part2, q.out2};
+    g_fold_scope.blocks += blocks;
+    return TRL_OK;
+  }
   hipLaunchKernelGGL(fold_partials_kernel, dim3(blocks, groups), dim3(64 * waves), 0, s, f);
   TRL_LAUNCH_CHECK();
   return TRL_OK;

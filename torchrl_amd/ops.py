@@ -328,11 +328,36 @@ def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=
     return (outs[0], tapes[0]), (outs[1], tapes[1])
 
 
+def _conv_ws_needs(tape):
+    """floats of split-partial workspace of every conv layer's weight gradient (each layer its own region: their folds
+    run together at the end of the trunk, _C.FoldScope)"""
+    needs = []
+    for kind, src, y, wmat, in_shape, (kh, kw, sh, sw) in tape.convs:
+        Cout = int(wmat.shape[0])
+        if kind == "nhwc":
+            B, H, W, Cc = (int(v) for v in src.shape)
+            n = _C.lib().trl_conv_bwd_weight_workspace(B, Cc, H, W, kh, kw, sh, sw, Cout)
+        elif kind == "u8":
+            B, Cc, H, W = (int(v) for v in src[0].shape)
+            n = _C.lib().trl_conv_bwd_weight_workspace(B, Cc, H, W, kh, kw, sh, sw, Cout)
+        else:
+            n = _C.lib().trl_linear_bwd_weight_workspace(y.numel() // Cout, int(wmat.shape[1]), Cout)
+        if n < 0:
+            raise _C.TrlError("cnn_backward: bad conv geometry")
+        needs.append((int(n) + 3) & ~3)                                    # regions stay 16-byte aligned
+    return needs
+
+
+def cnn_backward_workspace(tape):
+    return sum(_conv_ws_needs(tape))
+
+
 def cnn_backward(net, tape, d_out, grads, workspace=None):
     """grads: [(dW_view, db_view), ...] in cnn_param_list order (conv layers, then FC layers).
     The gradient flowing down the trunk is gated ONCE, where it is produced (dZ = dY * act'(Y): in the transpose that
     un-flattens d(features), and in the epilogue of each implicit input-gradient kernel), so the weight- and
-    input-gradient kernels of a layer read one tensor instead of two."""
+    input-gradient kernels of a layer read one tensor instead of two.  The conv layers' split weight-gradient partials are
+    folded by ONE launch at the end of the trunk (_C.FoldScope) instead of one per layer."""
     n_conv = len(tape.convs)
     d_feat = mlp_backward(tape.fc, d_out, grads=grads[n_conv:], need_input=True, workspace=workspace)
     P, Cc = tape.feat_shape
@@ -340,9 +365,20 @@ def cnn_backward(net, tape, d_out, grads, workspace=None):
     d = _C.transpose_bpc(d_feat.view(tape.B, Cc, P), tape.B, Cc, P, y_gate=top_y, gate_act=tape.act,
                          gate_like_in=tape.feat_chw).view(tape.B * P, Cc)   # back to (B, P, C)
     gated = True                                                         # d is dZ of layer k (else dY)
+    needs = _conv_ws_needs(tape)
+    if workspace is None or workspace.numel() < sum(needs) or workspace.data_ptr() % 16:
+        workspace = torch.empty(sum(needs), dtype=torch.float32, device=d.device)
+    offs = [sum(needs[:k]) for k in range(n_conv)]
+    with _C.FoldScope(d.device):
+        d = _cnn_trunk_backward(tape, d, grads, gated, [workspace[o:o + n] for o, n in zip(offs, needs)])
+
+
+def _cnn_trunk_backward(tape, d, grads, gated, regions):
+    n_conv = len(tape.convs)
     for k in range(n_conv - 1, -1, -1):
         kind, src, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]      # src: cols matrix / input activations / frames
         gw, gb = grads[k]
+        workspace = regions[k]
         yg, ga = (None, _C.ACT_NONE) if gated else (y, tape.act)
         if kind == "nhwc":                                                   # implicit GEMM on channels-last activations
             _C.conv_bwd_weight_nhwc(d, yg, ga, src, kh, kw, sh, sw, gw.view(wmat.shape), gb, workspace=workspace)
