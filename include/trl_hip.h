@@ -657,10 +657,14 @@ int trl_col2im_f32(const float* dcols, float* dx_nhwc, int B, int C, int H, int 
 int trl_conv_bwd_input_nhwc_ok(int Cin, int Cout, int kh, int kw, int sh, int sw);
 int trl_conv_bwd_input_nhwc_workspace(int Cin, int Cout, int kh, int kw);   /* floats: the weights re-ordered per call */
 /* x_gate (nullable, laid out like dx) with x_gate_act: the result is multiplied by act'(x_gate) on the way out, i.e. the
- * previous layer receives its dZ instead of its dY and gates nothing itself */
+ * previous layer receives its dZ instead of its dY and gates nothing itself.
+ * prepped != 0: `workspace` already holds this layer's re-ordered weights (trl_conv_bwd_input_nhwc_prep_f32 re-orders the
+ * weights of up to 8 layers in ONE launch -- a trunk's backward pass otherwise pays a ~5 us prep launch per layer) */
+int trl_conv_bwd_input_nhwc_prep_f32(int n, const float* const* w, float* const* workspace, const int* Cin, const int* Cout,
+                                     const int* kh, const int* kw, const int* sh, const int* sw, void* stream);
 int trl_conv_bwd_input_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
                                 const float* x_gate, int x_gate_act, float* workspace, int B, int Cin, int H, int W,
-                                int kh, int kw, int sh, int sw, int Cout, void* stream);
+                                int kh, int kw, int sh, int sw, int Cout, int prepped, void* stream);
 /* out[b][c][p] = in[b][p][c]  (NCHW flatten order in front of the first FC layer, and back) */
 int trl_transpose_bpc_f32(const float* in, float* out, int B, int P, int C, void* stream);
 /* the same with out[e] *= act'(y_gate[..]): d(features) -> the last conv layer's dZ.  gate_like_in == 0: y_gate is laid

@@ -144,6 +144,10 @@ def test_implicit_transposed_conv_input_gradient_vs_torch(B, C, H, W, kh, kw, sh
     assert (got.cpu() - want).abs().max().item() < 2e-5 * scale
     old = _C.col2im(_C.linear_bwd_input(rows(dy), gate, code, wd), B, C, H, W, kh, kw, sh, sw)
     assert (got - old).abs().max().item() < 2e-5 * scale
+    # the weights re-ordered ahead, together with another layer's, by ONE launch (trl_conv_bwd_input_nhwc_prep_f32)
+    other = torch.randn(32, 16 * 3 * 3, generator=torch.Generator().manual_seed(1)).to(DEV)   # (its own stream: `gen` goes on below)
+    preps = _C.conv_bwd_input_prep([(other, 16, 3, 3, 1, 1), (wd, C, kh, kw, sh, sw)], DEV)
+    assert torch.equal(_C.conv_bwd_input_nhwc(rows(dy), gate, code, wd, B, C, H, W, kh, kw, sh, sw, prep=preps[1]), got)
     # epilogue gate: the layer below receives dZ = dX * act'(its own output)
     below = torch.tanh(torch.randn(B, H, W, C, generator=gen)).to(DEV)
     gated = _C.conv_bwd_input_nhwc(rows(dy), gate, code, wd, B, C, H, W, kh, kw, sh, sw, x_gate=below.view(-1, C),

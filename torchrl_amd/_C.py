@@ -203,7 +203,8 @@ SIGNATURES = {
     "trl_conv_bwd_input_nhwc_ok": (C.c_int, [C.c_int] * 6),
     "trl_conv_bwd_input_nhwc_workspace": (C.c_int, [C.c_int] * 4),
     "trl_conv_bwd_input_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                             C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
+                                             C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
+    "trl_conv_bwd_input_nhwc_prep_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_void_p]),
     "trl_transpose_bpc_gate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 3
                                    + [C.c_void_p]),
     "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
@@ -1269,17 +1270,33 @@ def conv_bwd_input_ok(Cin, Cout, kh, kw, sh, sw):
     return bool(lib().trl_conv_bwd_input_nhwc_ok(int(Cin), int(Cout), kh, kw, sh, sw))
 
 
-def conv_bwd_input_nhwc(dy, y_gate, gate_act, weight, B, Cin, H, W, kh, kw, sh, sw, x_gate=None, x_gate_act=ACT_NONE):
+def conv_bwd_input_prep(layers, device):
+    """layers: [(weight (Cout, Cin*kh*kw), Cin, kh, kw, sh, sw)] -> [workspace holding the layer's re-ordered weights], ONE
+    launch for all of them (pass each as `prep=` to conv_bwd_input_nhwc)."""
+    n = len(layers)
+    wss = [torch.empty((lib().trl_conv_bwd_input_nhwc_workspace(cin, int(w.shape[0]), kh, kw),), dtype=torch.float32, device=device)
+           for w, cin, kh, kw, sh, sw in layers]
+    ints = lambda vals: (C.c_int * n)(*[int(v) for v in vals])
+    check(lib().trl_conv_bwd_input_nhwc_prep_f32(
+        n, _ptrs([w for w, *_ in layers], "weight"), _ptrs(wss, "workspace"), ints(l[1] for l in layers),
+        ints(int(l[0].shape[0]) for l in layers), ints(l[2] for l in layers), ints(l[3] for l in layers),
+        ints(l[4] for l in layers), ints(l[5] for l in layers), stream_ptr(device)), "trl_conv_bwd_input_nhwc_prep_f32")
+    return wss
+
+
+def conv_bwd_input_nhwc(dy, y_gate, gate_act, weight, B, Cin, H, W, kh, kw, sh, sw, x_gate=None, x_gate_act=ACT_NONE, prep=None):
     """dx (B, H, W, Cin) of a conv layer from dy (B*Ho*Wo, Cout), its activation output and the (Cout, Cin*kh*kw) weight;
-    with x_gate (the layer's INPUT activations) the result is already multiplied by act'(x_gate)."""
+    with x_gate (the layer's INPUT activations) the result is already multiplied by act'(x_gate).  prep: this layer's
+    workspace from conv_bwd_input_prep (its weights are re-ordered already)."""
     Cout = int(weight.shape[0])
     dx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
-    ws = torch.empty((lib().trl_conv_bwd_input_nhwc_workspace(Cin, Cout, kh, kw),), dtype=torch.float32, device=dy.device)
+    ws = prep if prep is not None else \
+        torch.empty((lib().trl_conv_bwd_input_nhwc_workspace(Cin, Cout, kh, kw),), dtype=torch.float32, device=dy.device)
     check(lib().trl_conv_bwd_input_nhwc_f32(dev_ptr(dy, name="dy"), dev_ptr(y_gate, name="y_gate", allow_none=True),
                                             gate_act, dev_ptr(weight, name="weight"), dev_ptr(dx, name="dx"),
                                             dev_ptr(x_gate, name="x_gate", allow_none=True), x_gate_act,
                                             dev_ptr(ws, name="workspace"), B, Cin, H, W, kh, kw, sh, sw, Cout,
-                                            stream_ptr(dy.device)), "trl_conv_bwd_input_nhwc_f32")
+                                            int(prep is not None), stream_ptr(dy.device)), "trl_conv_bwd_input_nhwc_f32")
     return dx
 
 

@@ -59,6 +59,26 @@ __global__ __launch_bounds__(256) void conv_dx_prep_kernel(const float* __restri
   }
 }
 
+// the re-ordered weights of SEVERAL layers in one launch (blockIdx.y = layer): a backward pass through a conv trunk needs
+// every layer's, and each prep launch of its own is ~5 us of dependent launch for a few KB
+#define DX_PREP_MAX 8
+struct DxPrepSet { const float* w[DX_PREP_MAX]; float* wprep[DX_PREP_MAX]; DxGeom g[DX_PREP_MAX]; };
+__global__ __launch_bounds__(256) void conv_dx_prep_multi_kernel(DxPrepSet p) {
+  const float* __restrict__ w = p.w[blockIdx.y];
+  float* __restrict__ wprep = p.wprep[blockIdx.y];
+  const DxGeom g = p.g[blockIdx.y];
+  const int total = g.Cout * g.Cin * g.kh * g.kw, CB = g.Cin >> 4, tap_floats = g.Cout * g.Cin;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {      // (conv_dx_prep_kernel's body)
+    const int jt = e % g.kw, it = (e / g.kw) % g.kh, c = (e / (g.kw * g.kh)) % g.Cin, co = e / (g.kw * g.kh * g.Cin);
+    const int py = it % g.sh, px = jt % g.sw, ti = it / g.sh, tj = jt / g.sw;
+    int off = 0;
+    for (int cls = 0; cls < py * g.sw + px; ++cls) off += dx_class_taps(g, cls / g.sw, cls % g.sw) * tap_floats;
+    const int ntj = (g.kw - px + g.sw - 1) / g.sw;
+    const int chunk = co >> 4, gq = (co >> 2) & 3, r = co & 3, cb = c >> 4, j = c & 15;
+    wprep[off + (ti * ntj + tj) * tap_floats + (((chunk * 4 + r) * CB + cb) * 4 + gq) * 16 + j] = w[e];
+  }
+}
+
 template <int CB, int NCH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void conv_dx_kernel(const float* __restrict__ dy, const float* __restrict__ yg,
                                                       const float* __restrict__ wprep, float* __restrict__ dx,
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_kernel(const float* __rest
 
 template <int CB, int NCH, int WAVES>
 static int launch_dx_waves(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
-                           DxGeom g, int lds, hipStream_t s) {
+                           DxGeom g, int lds, hipStream_t s, bool prepped) {
   static int attr_lds = 0;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_dx_kernel<CB, NCH, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -181,8 +201,10 @@ static int launch_dx_waves(const float* dy, const float* yg, const float* w, flo
     attr_lds = lds;
   }
   const int total = g.Cout * g.Cin * g.kh * g.kw;
-  hipLaunchKernelGGL(conv_dx_prep_kernel, dim3(std::min(64, trl_ceil_div(total, 256))), dim3(256), 0, s, w, wprep, g);
-  TRL_LAUNCH_CHECK();
+  if (!prepped) {
+    hipLaunchKernelGGL(conv_dx_prep_kernel, dim3(std::min(64, trl_ceil_div(total, 256))), dim3(256), 0, s, w, wprep, g);
+    TRL_LAUNCH_CHECK();
+  }
   const int64_t rows_max = (int64_t)g.B * trl_ceil_div(g.H, g.sh) * trl_ceil_div(g.W, g.sw);   // class (0, 0) is the largest
   const int tiles = trl_ceil_div(rows_max, 16 * WAVES), classes = g.sh * g.sw;
   // enough workgroups for ~8 per CU (what hides the loads is waves in flight); beyond that a workgroup walks several
@@ -199,22 +221,22 @@ static int launch_dx_waves(const float* dy, const float* yg, const float* w, flo
 }
 template <int CB, int NCH>
 static int launch_dx(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
-                     const DxGeom& g, hipStream_t s) {
+                     const DxGeom& g, hipStream_t s, bool prepped) {
   const int max_taps = trl_ceil_div(g.kh, g.sh) * trl_ceil_div(g.kw, g.sw);
   const int lds = max_taps * g.Cout * g.Cin * (int)sizeof(float);
   TRL_REQUIRE(lds <= 160 * 1024, "conv_bwd_input: one parity class of the weights exceeds the LDS");
   // a class's weights above ~40 KB leave room for two or three workgroups per CU: make them 8 waves each
-  if (lds > 40 * 1024) return launch_dx_waves<CB, NCH, 8>(dy, yg, w, wprep, dx, xg, g, lds, s);
-  return launch_dx_waves<CB, NCH, 4>(dy, yg, w, wprep, dx, xg, g, lds, s);
+  if (lds > 40 * 1024) return launch_dx_waves<CB, NCH, 8>(dy, yg, w, wprep, dx, xg, g, lds, s, prepped);
+  return launch_dx_waves<CB, NCH, 4>(dy, yg, w, wprep, dx, xg, g, lds, s, prepped);
 }
 
 template <int CB>
 static int launch_dx_cout(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
-                          const DxGeom& g, hipStream_t s) {
+                          const DxGeom& g, hipStream_t s, bool prepped) {
   switch (g.Cout >> 4) {
-    case 1: return launch_dx<CB, 1>(dy, yg, w, wprep, dx, xg, g, s);
-    case 2: return launch_dx<CB, 2>(dy, yg, w, wprep, dx, xg, g, s);
-    default: return launch_dx<CB, 4>(dy, yg, w, wprep, dx, xg, g, s);
+    case 1: return launch_dx<CB, 1>(dy, yg, w, wprep, dx, xg, g, s, prepped);
+    case 2: return launch_dx<CB, 2>(dy, yg, w, wprep, dx, xg, g, s, prepped);
+    default: return launch_dx<CB, 4>(dy, yg, w, wprep, dx, xg, g, s, prepped);
   }
 }
 
@@ -229,9 +251,28 @@ extern "C" int trl_conv_bwd_input_nhwc_workspace(int Cin, int Cout, int kh, int 
   return Cin * Cout * kh * kw;                       // floats: the re-ordered weights
 }
 
+extern "C" int trl_conv_bwd_input_nhwc_prep_f32(int n, const float* const* w, float* const* workspace, const int* Cin,
+                                                const int* Cout, const int* kh, const int* kw, const int* sh, const int* sw,
+                                                void* stream) {
+  TRL_REQUIRE(n >= 1 && n <= DX_PREP_MAX, "conv_bwd_input prep: 1..8 layers per launch");
+  TRL_REQUIRE(w && workspace && Cin && Cout && kh && kw && sh && sw, "null pointer array");
+  DxPrepSet p{};
+  int most = 0;
+  for (int i = 0; i < n; ++i) {
+    TRL_REQUIRE(w[i] && workspace[i] && trl_conv_bwd_input_nhwc_ok(Cin[i], Cout[i], kh[i], kw[i], sh[i], sw[i]),
+                "conv_bwd_input prep: null pointer / geometry outside trl_conv_bwd_input_nhwc_ok");
+    p.w[i] = w[i]; p.wprep[i] = workspace[i];
+    p.g[i] = DxGeom{0, Cin[i], 0, 0, kh[i], kw[i], sh[i], sw[i], 0, 0, Cout[i], TRL_ACT_NONE, TRL_ACT_NONE, 1};
+    most = std::max(most, Cout[i] * Cin[i] * kh[i] * kw[i]);
+  }
+  hipLaunchKernelGGL(conv_dx_prep_multi_kernel, dim3(std::min(64, trl_ceil_div(most, 256)), n), dim3(256), 0, (hipStream_t)stream, p);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 extern "C" int trl_conv_bwd_input_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
                                            const float* x_gate, int x_gate_act, float* workspace, int B, int Cin, int H,
-                                           int W, int kh, int kw, int sh, int sw, int Cout, void* stream) {
+                                           int W, int kh, int kw, int sh, int sw, int Cout, int prepped, void* stream) {
   TRL_REQUIRE(B >= 0 && H >= kh && W >= kw, "bad geometry");
   TRL_REQUIRE(trl_conv_bwd_input_nhwc_ok(Cin, Cout, kh, kw, sh, sw),
               "needs Cin a multiple of 16 (<= 64), Cout 16 / 32 / 64, stride <= kernel (else trl_linear_bwd_input_f32 + trl_col2im_f32)");
@@ -245,9 +286,9 @@ extern "C" int trl_conv_bwd_input_nhwc_f32(const float* dy, const float* y_gate,
   DxGeom g{B, Cin, H, W, kh, kw, sh, sw, (H - kh) / sh + 1, (W - kw) / sw + 1, Cout, gate_act, x_gate_act, 1};
   hipStream_t s = (hipStream_t)stream;
   switch (Cin >> 4) {
-    case 1: return launch_dx_cout<1>(dy, y_gate, w, workspace, dx, x_gate, g, s);
-    case 2: return launch_dx_cout<2>(dy, y_gate, w, workspace, dx, x_gate, g, s);
-    case 3: return launch_dx_cout<3>(dy, y_gate, w, workspace, dx, x_gate, g, s);
-    default: return launch_dx_cout<4>(dy, y_gate, w, workspace, dx, x_gate, g, s);
+    case 1: return launch_dx_cout<1>(dy, y_gate, w, workspace, dx, x_gate, g, s, prepped != 0);
+    case 2: return launch_dx_cout<2>(dy, y_gate, w, workspace, dx, x_gate, g, s, prepped != 0);
+    case 3: return launch_dx_cout<3>(dy, y_gate, w, workspace, dx, x_gate, g, s, prepped != 0);
+    default: return launch_dx_cout<4>(dy, y_gate, w, workspace, dx, x_gate, g, s, prepped != 0);
   }
 }

@@ -375,6 +375,13 @@ def cnn_backward(net, tape, d_out, grads, workspace=None):
 
 def _cnn_trunk_backward(tape, d, grads, gated, regions):
     n_conv = len(tape.convs)
+    # the implicit input-gradient kernels read the weights re-ordered: all layers' re-orderings in ONE launch up front
+    dx_layers = [k for k in range(1, n_conv)
+                 if _C.conv_bwd_input_ok(tape.convs[k][4][3], int(tape.convs[k][3].shape[0]), *tape.convs[k][5])]
+    preps = {}
+    if len(dx_layers) > 1:
+        wss = _C.conv_bwd_input_prep([(tape.convs[k][3], tape.convs[k][4][3]) + tuple(tape.convs[k][5]) for k in dx_layers], d.device)
+        preps = dict(zip(dx_layers, wss))
     for k in range(n_conv - 1, -1, -1):
         kind, src, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]      # src: cols matrix / input activations / frames
         gw, gb = grads[k]
@@ -395,7 +402,7 @@ def _cnn_trunk_backward(tape, d, grads, gated, regions):
                 # the NEXT layer down's act'
                 below = tape.convs[k - 1][2]
                 d = _C.conv_bwd_input_nhwc(d, yg, ga, wmat, B, Cin, H, W, kh, kw, sh, sw, x_gate=below,
-                                           x_gate_act=tape.act).view(B * H * W, Cin)
+                                           x_gate_act=tape.act, prep=preps.get(k)).view(B * H * W, Cin)
                 gated = True
             else:
                 dcols = _C.linear_bwd_input(d, yg, ga, wmat)
