@@ -745,8 +745,18 @@ int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const float* u, cons
 int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base,
                              int horizon, int A, uint8_t* next_obs, float* rewards, float* dones,
                              int N, int C, int HW, void* stream);
+/* the same step filing the WHOLE transition into row ring_row[0] of the replay ring itself (bases of the (rows, N, ...)
+ * tensors: uint8 obs / next_obs stacks, float acts / rewards / terminals / time_limits; base.py:22-28's keys) -- the
+ * pre-step stacks are stored while they are shifted -- plus this step's rewards / dones (N) for the collector's bookkeeping.
+ * The row lives on the device: a captured sequence of vector steps walks the ring, trl_synth_frames_reset_u8(ring_row)
+ * advances it at the end of a step */
+int trl_synth_frames_collect_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base, int horizon,
+                                int A, uint8_t* ring_obs, uint8_t* ring_next_obs, float* ring_acts, float* ring_rewards,
+                                float* ring_terminals, float* ring_time_limits, int64_t* ring_row, int n_rows,
+                                float* step_rewards, float* step_dones, int N, int C, int HW, void* stream);
+/* ring_row (nullable): ring_row[0] = (ring_row[0] + 1) % n_rows rides along */
 int trl_synth_frames_reset_u8(uint8_t* frames, int32_t* t_env, int64_t env_seed_base,
-                              const uint8_t* mask, int N, int C, int HW, void* stream);
+                              const uint8_t* mask, int64_t* ring_row, int n_rows, int N, int C, int HW, void* stream);
 
 /* --- K6b: frame-deduplicating replay (torchrl/replay_buffers/memory_efficient_replay_buffer.py:5-33,
  * LazyFrames / FrameStack, torchrl/env/atari_wrapper.py:142-227).  stream: (S, N, HW) uint8 ring of single

@@ -441,8 +441,9 @@ def test_one_launch_dqn_head_equals_the_layer_kernels_and_the_loss_launch(B, H, 
 @pytest.mark.parametrize("Q,horizon,max_frames", [(1, 3, 5), (8, 5, 4)])      # episodes end by `done` / by the frame cap
 def test_frame_env_rollout_as_a_replayed_graph_equals_the_step_by_step_rollout(Q, horizon, max_frames, monkeypatch):
     """collector/base.py _replayed_rollout_frames: host draws of all steps staged ahead, the steps of an epoch as ONE graph
-    into staging rows, then copied to the ring (wrapping).  Every epoch (eager first visit, captured, replayed ...) must
-    leave the ring, the epoch results, the env and the policy's epsilon exactly as the step-by-step path does."""
+    whose frame step files each transition into the ring row a device counter points at (trl_synth_frames_collect_u8; the
+    ring wraps inside an epoch here).  Every epoch (eager first visit, captured, replayed ...) must leave the ring, the
+    epoch results, the env and the policy's epsilon exactly as the step-by-step path does."""
     from torchrl.collector import VecCollector
     from torchrl.env import get_vec_env
     from torchrl.policies import EpsilonGreedyDQNDiscretePolicy, EpsilonGreedyQRDQNDiscretePolicy

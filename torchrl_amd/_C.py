@@ -225,7 +225,9 @@ SIGNATURES = {
                                [C.c_int, C.c_void_p, C.c_void_p]),
     "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
-    "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "trl_synth_frames_collect_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] +
+                                    [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_mt19937_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "trl_mt19937_states_at": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -1406,11 +1408,30 @@ def synth_frames_step(frames, acts, t_env, seed_base, horizon, A, next_obs, rewa
                                          stream_ptr(frames.device)), "trl_synth_frames_step_u8")
 
 
-def synth_frames_reset(frames, t_env, seed_base, mask):
+def synth_frames_reset(frames, t_env, seed_base, mask, ring_row=None, n_rows=0):
     N, Cc, HW = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2]) * int(frames.shape[3])
     check(lib().trl_synth_frames_reset_u8(dev_ptr(frames, torch.uint8, "frames"), dev_ptr(t_env, torch.int32, "t_env"),
-                                          int(seed_base), dev_ptr(mask, torch.uint8, "mask", allow_none=True), N, Cc, HW,
+                                          int(seed_base), dev_ptr(mask, torch.uint8, "mask", allow_none=True),
+                                          dev_ptr(ring_row, torch.int64, "ring_row", allow_none=True), int(n_rows), N, Cc, HW,
                                           stream_ptr(frames.device)), "trl_synth_frames_reset_u8")
+
+
+def synth_frames_collect(frames, acts, t_env, seed_base, horizon, A, ring, ring_row, step_rewards, step_dones):
+    """ring = (obs, next_obs, acts, rewards, terminals, time_limits) ring TENSORS (rows, N, ...): the step files its
+    transition into row ring_row[0] (device int64)."""
+    N, Cc, HW = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2]) * int(frames.shape[3])
+    r_obs, r_next, r_acts, r_rew, r_done, r_tl = ring
+    rows = int(r_obs.shape[0])
+    for t in ring:
+        if int(t.shape[0]) != rows or int(t.shape[1]) != N or not t.is_contiguous():
+            raise TrlError("synth_frames_collect: ring tensors must be contiguous (rows, N, ...)")
+    check(lib().trl_synth_frames_collect_u8(
+        dev_ptr(frames, torch.uint8, "frames"), dev_ptr(acts, torch.int64, "acts"), dev_ptr(t_env, torch.int32, "t_env"),
+        int(seed_base), int(horizon), int(A), dev_ptr(r_obs, torch.uint8, "ring obs"), dev_ptr(r_next, torch.uint8, "ring next_obs"),
+        dev_ptr(r_acts, name="ring acts"), dev_ptr(r_rew, name="ring rewards"), dev_ptr(r_done, name="ring terminals"),
+        dev_ptr(r_tl, name="ring time_limits"), dev_ptr(ring_row, torch.int64, "ring_row"), rows,
+        dev_ptr(step_rewards, name="step_rewards"), dev_ptr(step_dones, name="step_dones"), N, Cc, HW,
+        stream_ptr(frames.device)), "trl_synth_frames_collect_u8")
 
 
 def gauss_explore(mean, logstd, eps, tanh_action, act=None, logp=None):

@@ -450,10 +450,11 @@ class VecCollector(_CollectorBase):
         of all `n_steps` vector steps (conv forward, action, frame step, bookkeeping, masked reset) are ONE replayed HIP
         graph.  What the host decides per step goes in ahead of the replay -- the numpy draws of every step in the reference's
         order (discrete_policies.py:58-65: rand, then randint, per step) with the epsilon comparison already applied (the
-        kernel gets u in {0, 1} against a fixed 0.5), one upload each -- and what depends on the ring position comes out
-        after it: the steps write a block of `n_steps` staging rows with fixed addresses, copied to ring rows
-        [top, top + n_steps) by plain strided copies.  Same ring contents, header, episode log and env state as the
-        step-by-step path (tests/test_dqn_gpu.py).  Returns False when the configuration is outside that path."""
+        kernel gets u in {0, 1} against a fixed 0.5), one upload each -- and the ring position lives on the device: the frame
+        step files the whole transition into row `ring_row[0]` itself (trl_synth_frames_collect_u8: the pre-step stacks are
+        stored while they are shifted), the reset launch that ends a step advances the row, one 8-byte upload per epoch sets
+        it.  Same ring contents, header, episode log and env state as the step-by-step path (tests/test_dqn_gpu.py).
+        Returns False when the configuration is outside that path."""
         from .. import dist
         env, buf, pf = self.env, self.replay_buffer, self.pf
         if not (getattr(env, "kind", "vector") == "frames" and not self.continuous and hasattr(pf, "decay_frames")
@@ -462,22 +463,18 @@ class VecCollector(_CollectorBase):
                 and not getattr(env, "is_host_env", False)):
             return False
         n, shape, dev = env.env_nums, tuple(env.frame_shape), env.device
-        ring = {"obs": buf._ensure_key("obs", (n,) + shape, dtype=torch.uint8), "acts": buf._ensure_key("acts", (n, 1)),
-                "next_obs": buf._ensure_key("next_obs", (n,) + shape, dtype=torch.uint8),
-                "rewards": buf._ensure_key("rewards", (n, 1)), "terminals": buf._ensure_key("terminals", (n, 1)),
-                "time_limits": buf._ensure_key("time_limits", (n, 1))}
-        rows = int(ring["obs"].shape[0])
-        if n_steps > rows:
-            return False
+        ring = (buf._ensure_key("obs", (n,) + shape, dtype=torch.uint8), buf._ensure_key("next_obs", (n,) + shape, dtype=torch.uint8),
+                buf._ensure_key("acts", (n, 1)), buf._ensure_key("rewards", (n, 1)), buf._ensure_key("terminals", (n, 1)),
+                buf._ensure_key("time_limits", (n, 1)))
+        rows = int(ring[0].shape[0])
         A, Q = int(pf.action_shape), int(pf.quantile_num)
-        key = (env.cur_obs.data_ptr(), n, shape, A, Q, int(self.max_episode_frames), int(env.horizon), n_steps, id(pf.qf))
+        key = tuple(t.data_ptr() for t in ring) + (env.cur_obs.data_ptr(), n, shape, A, Q, int(self.max_episode_frames),
+                                                   int(env.horizon), n_steps, id(pf.qf), rows)
         st = getattr(self, "_fr", None)
         if st is None or st["key"] != key:
             st = self._fr = {"key": key, "graph": None, "seen": False,
-                             "obs": torch.empty((n_steps, n) + shape, dtype=torch.uint8, device=dev),
-                             "next_obs": torch.empty((n_steps, n) + shape, dtype=torch.uint8, device=dev),
-                             "acts": torch.empty(n_steps, n, 1, device=dev), "rewards": torch.empty(n_steps, n, 1, device=dev),
-                             "terminals": torch.empty(n_steps, n, 1, device=dev),
+                             "rew": torch.empty(n, 1, device=dev), "done": torch.empty(n, 1, device=dev),
+                             "row": torch.zeros(1, dtype=torch.int64, device=dev), "row_stager": _C.PinnedStager(1, torch.int64),
                              "u": torch.empty(n_steps, n, device=dev), "ra": torch.empty(n_steps, n, dtype=torch.int64, device=dev),
                              "u_stager": _C.PinnedStager(n_steps * n, torch.float32),
                              "ra_stager": _C.PinnedStager(n_steps * n, torch.int64)}
@@ -495,17 +492,17 @@ class VecCollector(_CollectorBase):
             u_host[t] = np.where(u < np.float32(pf.epsilon), np.float32(0.0), np.float32(1.0))
         st["u_stager"].upload(st["u"].view(-1))
         st["ra_stager"].upload(st["ra"].view(-1))
+        st["row_stager"].stage()[0] = buf._top                            # (the host may be epochs ahead of the device)
+        st["row_stager"].upload(st["row"])
 
         def one_step(t):
             q = pf._q(env.cur_obs)
             act = _C.eps_greedy(q.contiguous(), A, Q, st["u"][t], st["ra"][t], 0.5)
-            st["obs"][t].copy_(env.cur_obs)
-            st["acts"][t].copy_(act.unsqueeze(-1))
-            _C.synth_frames_step(env.cur_obs, act, env.t_env, env.seed_base, env.horizon, env.action_num, st["next_obs"][t],
-                                 st["rewards"][t], st["terminals"][t])
-            _C.collector_bookkeep(st["rewards"][t], st["terminals"][t], env.cur_step, env.ep_return, self.max_episode_frames,
+            _C.synth_frames_collect(env.cur_obs, act, env.t_env, env.seed_base, env.horizon, env.action_num, ring, st["row"],
+                                    st["rew"], st["done"])
+            _C.collector_bookkeep(st["rew"], st["done"], env.cur_step, env.ep_return, self.max_episode_frames,
                                   self._mask, self._epoch_reward, self._ep_count, self._ep_log, t)
-            _C.synth_frames_reset(env.cur_obs, env.t_env, env.seed_base, self._mask)
+            _C.synth_frames_reset(env.cur_obs, env.t_env, env.seed_base, self._mask, ring_row=st["row"], n_rows=rows)
 
         if self.global_step != self._log_step0:
             raise _C.TrlError("frame rollout replay: the episode log was not cleared for this rollout")
@@ -520,13 +517,6 @@ class VecCollector(_CollectorBase):
             st["graph"], _ = _C.capture_graph(lambda: [one_step(t) for t in range(n_steps)])
             st["hdr"] = hdr_key
             st["graph"].replay()
-        top = buf._top
-        first = min(n_steps, rows - top)
-        for name, src in (("obs", "obs"), ("acts", "acts"), ("next_obs", "next_obs"), ("rewards", "rewards"),
-                          ("terminals", "terminals"), ("time_limits", "terminals")):   # synthetic env: time_limit == done
-            ring[name][top:top + first].copy_(st[src][:first])
-            if first < n_steps:
-                ring[name][:n_steps - first].copy_(st[src][first:])
         buf._advance(n_steps)
         self.global_step += n_steps
         return True

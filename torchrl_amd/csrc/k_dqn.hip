@@ -524,27 +524,50 @@ __device__ __forceinline__ void synth_frame_fill(uint8_t* dst, int t, int64_t en
     *reinterpret_cast<uint4*>(dst + blk * 16) = make_uint4(x[0], x[1], x[2], x[3]);
   }
 }
+// FrameRing (optional, obs != NULL): the step files the WHOLE transition into row dyn[0] of the replay ring itself -- the
+// pre-step stacks (obs), the stacks it produces (next_obs), the actions as floats, rewards, terminals and time limits --
+// so a captured sequence of vector steps walks the ring on its own (the row lives on the device; the reset call that ends
+// a step advances it) and nothing is copied afterwards.
+struct FrameRing { uint8_t* obs; uint8_t* next; float* acts; float* rew; float* done; float* tl; int64_t* dyn; int n_rows; };
 __global__ __launch_bounds__(DQ_THREADS) void synth_frames_kernel(uint8_t* __restrict__ frames, const int64_t* __restrict__ act,
                                                                   int32_t* __restrict__ t_env, int64_t seed_base, int horizon,
                                                                   int A, uint8_t* __restrict__ next_out,
                                                                   float* __restrict__ rew, float* __restrict__ done,
                                                                   const uint8_t* __restrict__ reset_mask, int reset_all,
-                                                                  int N, int C, int HW) {
+                                                                  int N, int C, int HW, FrameRing r) {
   const int n = blockIdx.x;
   uint8_t* f = frames + (size_t)n * C * HW;
   const int64_t env_seed = seed_base + n;
   const bool is_reset_call = reset_all || reset_mask;
   if (is_reset_call) {
+    // (the last launch of a vector step: nobody of THIS launch reads the row)
+    if (r.dyn && blockIdx.x == 0 && threadIdx.x == 0) r.dyn[0] = (r.dyn[0] + 1) % r.n_rows;
     if (!reset_all && !reset_mask[n]) return;                  // block-uniform
     for (int c = 0; c < C; ++c) synth_frame_fill(f + (size_t)c * HW, c - (C - 1), env_seed, HW);
     if (threadIdx.x == 0) t_env[n] = 0;
     return;
   }
   const int t = t_env[n] + 1;
-  // shift frame c <- frame c + 1 (a thread moves the same 16-byte slots of every frame, in order)
-  for (int p = threadIdx.x * 16; p < HW; p += DQ_THREADS * 16)
-    for (int c = 0; c + 1 < C; ++c)
-      *reinterpret_cast<uint4*>(f + (size_t)c * HW + p) = *reinterpret_cast<const uint4*>(f + (size_t)(c + 1) * HW + p);
+  const size_t cell = r.obs ? (size_t)r.dyn[0] * N + n : 0;           // (ring row, env): uniform per block
+  if (r.obs) {
+    // the pre-step stack goes to the ring while it is shifted (every frame is read once)
+    uint8_t* o = r.obs + cell * C * HW;
+    for (int p = threadIdx.x * 16; p < HW; p += DQ_THREADS * 16) {
+      uint4 cur = *reinterpret_cast<const uint4*>(f + p);
+      *reinterpret_cast<uint4*>(o + p) = cur;
+      for (int c = 0; c + 1 < C; ++c) {
+        cur = *reinterpret_cast<const uint4*>(f + (size_t)(c + 1) * HW + p);
+        *reinterpret_cast<uint4*>(o + (size_t)(c + 1) * HW + p) = cur;
+        *reinterpret_cast<uint4*>(f + (size_t)c * HW + p) = cur;
+      }
+    }
+    next_out = r.next + (cell - n) * C * HW;                            // (indexed by n below)
+  } else {
+    // shift frame c <- frame c + 1 (a thread moves the same 16-byte slots of every frame, in order)
+    for (int p = threadIdx.x * 16; p < HW; p += DQ_THREADS * 16)
+      for (int c = 0; c + 1 < C; ++c)
+        *reinterpret_cast<uint4*>(f + (size_t)c * HW + p) = *reinterpret_cast<const uint4*>(f + (size_t)(c + 1) * HW + p);
+  }
   synth_frame_fill(f + (size_t)(C - 1) * HW, t, env_seed, HW);
   __syncthreads();
   if (next_out)
@@ -553,8 +576,10 @@ __global__ __launch_bounds__(DQ_THREADS) void synth_frames_kernel(uint8_t* __res
   if (threadIdx.x == 0) {
     t_env[n] = t;
     const int want = f[(size_t)(C - 1) * HW] % A;
-    rew[n] = ((int)act[n] == want) ? 1.0f : 0.0f;
-    done[n] = t >= horizon ? 1.0f : 0.0f;
+    const float rw = ((int)act[n] == want) ? 1.0f : 0.0f, dn = t >= horizon ? 1.0f : 0.0f;
+    rew[n] = rw;
+    done[n] = dn;
+    if (r.obs) { r.acts[cell] = (float)act[n]; r.rew[cell] = rw; r.done[cell] = dn; r.tl[cell] = dn; }   // synthetic env: time_limit == done
   }
 }
 extern "C" int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base,
@@ -564,18 +589,38 @@ extern "C" int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, in
   if (N == 0) return TRL_OK;
   TRL_REQUIRE(frames && t_env && acts && rewards && dones, "null pointer");
   hipLaunchKernelGGL(synth_frames_kernel, dim3(N), dim3(DQ_THREADS), 0, (hipStream_t)stream, frames, acts, t_env,
-                     env_seed_base, horizon, A, next_obs, rewards, dones, (const uint8_t*)nullptr, 0, N, C, HW);
+                     env_seed_base, horizon, A, next_obs, rewards, dones, (const uint8_t*)nullptr, 0, N, C, HW, FrameRing{});
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+extern "C" int trl_synth_frames_collect_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base,
+                                           int horizon, int A, uint8_t* ring_obs, uint8_t* ring_next_obs, float* ring_acts,
+                                           float* ring_rewards, float* ring_terminals, float* ring_time_limits,
+                                           int64_t* ring_row, int n_rows, float* step_rewards, float* step_dones, int N, int C,
+                                           int HW, void* stream) {
+  TRL_REQUIRE(N >= 0 && C > 0 && HW > 0 && HW % 16 == 0 && A > 0 && n_rows > 0, "bad sizes (HW must be a multiple of 16)");
+  if (N == 0) return TRL_OK;
+  TRL_REQUIRE(frames && t_env && acts && step_rewards && step_dones, "null pointer");
+  TRL_REQUIRE(ring_obs && ring_next_obs && ring_acts && ring_rewards && ring_terminals && ring_time_limits && ring_row,
+              "null ring pointer");
+  FrameRing r{ring_obs, ring_next_obs, ring_acts, ring_rewards, ring_terminals, ring_time_limits, ring_row, n_rows};
+  hipLaunchKernelGGL(synth_frames_kernel, dim3(N), dim3(DQ_THREADS), 0, (hipStream_t)stream, frames, acts, t_env,
+                     env_seed_base, horizon, A, (uint8_t*)nullptr, step_rewards, step_dones, (const uint8_t*)nullptr, 0, N, C,
+                     HW, r);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
 extern "C" int trl_synth_frames_reset_u8(uint8_t* frames, int32_t* t_env, int64_t env_seed_base, const uint8_t* mask,
-                                         int N, int C, int HW, void* stream) {
+                                         int64_t* ring_row, int n_rows, int N, int C, int HW, void* stream) {
   TRL_REQUIRE(N >= 0 && C > 0 && HW > 0 && HW % 16 == 0, "bad sizes (HW must be a multiple of 16)");
+  TRL_REQUIRE(!ring_row || n_rows > 0, "ring row without a row count");
   if (N == 0) return TRL_OK;
   TRL_REQUIRE(frames && t_env, "null pointer");
+  FrameRing r{};
+  r.dyn = ring_row; r.n_rows = n_rows;
   hipLaunchKernelGGL(synth_frames_kernel, dim3(N), dim3(DQ_THREADS), 0, (hipStream_t)stream, frames,
                      (const int64_t*)nullptr, t_env, env_seed_base, 1, 1, (uint8_t*)nullptr, (float*)nullptr,
-                     (float*)nullptr, mask, mask ? 0 : 1, N, C, HW);
+                     (float*)nullptr, mask, mask ? 0 : 1, N, C, HW, r);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
