@@ -31,6 +31,11 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_fwd_direct_kernel(ConvSrc cv
                                                                      int M, int K, int Cout, int act) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
+  // byte offset of every 4-tap group, once per workgroup (two run-time integer divisions apiece: sixteen of them per lane
+  // were ~600 of a wave's ~1500 vector instructions, next to 256 MFMAs)
+  __shared__ uint32_t tap_tab[4 * KU];
+  if (threadIdx.x < 4 * KU) tap_tab[threadIdx.x] = conv_tap_offset(cv, 4u * threadIdx.x);
+  __syncthreads();
   const int mw = (blockIdx.x * (C1_THREADS / 64) + wave) * 64;     // this wave's 64 output positions
   if (mw >= M) return;
   f32x4 wreg[KU];
@@ -40,15 +45,16 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_fwd_direct_kernel(ConvSrc cv
     const int kk = 16 * u + 4 * g;
     const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
     wreg[u] = j < Cout ? *reinterpret_cast<const f32x4*>(w + (size_t)j * K + kk) : z;
-    tap[u] = conv_tap_offset(cv, (uint32_t)kk);
+    tap[u] = tap_tab[4 * u + g];
   }
   f32x4 acc[4];
   uint32_t dw[2][KU];
   auto load_block = [&](int rb, uint32_t (&d)[KU]) {
     const int m = min(mw + 16 * rb + j, M - 1);     // rows past M are computed on a clamped address and never stored
-    const uint8_t* p = cv.frames + conv_row_offset(cv, (uint32_t)m);
+    const uint32_t ro = conv_row_offset(cv, (uint32_t)m);
+    // (uniform base + 32-bit lane offset: one add per load instead of a 64-bit address built per lane; the batch is < 4 GiB)
 #pragma unroll
-    for (int u = 0; u < KU; ++u) d[u] = *reinterpret_cast<const uint32_t*>(p + tap[u]);
+    for (int u = 0; u < KU; ++u) d[u] = *reinterpret_cast<const uint32_t*>(cv.frames + (size_t)(uint32_t)(ro + tap[u]));
   };
   load_block(0, dw[0]);
 #pragma unroll
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_bwdw_direct_kernel(ConvSrc c
   const int j = lane & 15, g = lane >> 4;
   uint32_t tapd[KQ];
 #pragma unroll
-  for (int q = 0; q < KQ; ++q) tapd[q] = conv_tap_offset(cv, (uint32_t)(64 * q + 4 * j));
+  for (int q = 0; q < KQ; ++q) tapd[q] = conv_tap_offset(cv, (uint32_t)(64 * q + 4 * j));   // (4 per lane, once per workgroup's long loop)
   f32x4 acc[KQ][4];
 #pragma unroll
   for (int q = 0; q < KQ; ++q)
