@@ -680,10 +680,15 @@ int trl_transpose_bpc_gate_f32(const float* in, const float* y_gate, int gate_ac
  * Requires kw, sw and W to be multiples of 4 (each 4 consecutive taps are one aligned dword); other geometries
  * return TRL_EINVAL and go through trl_im2col_u8_nchw + trl_linear_*.
  * trl_conv_bwd_weight_u8_f32: dw (Cout, C*kh*kw), db (Cout) (nullable) from dy (B*Ho*Wo, Cout), gated by
- * act'(y_gate) as in trl_linear_bwd_weight_f32; workspace: trl_conv_bwd_weight_workspace(...) floats. */
+ * act'(y_gate) as in trl_linear_bwd_weight_f32; workspace: trl_conv_bwd_weight_workspace(...) floats.
+ * n_perm (0..4) re-ordering jobs ride on the forward launch: weights perm_src[k] (perm_cout x perm_c x perm_khw, nn.Conv2d's
+ * layout) of LATER conv layers are copied to perm_dst[k] in the (i, j, c) reduction order of trl_conv_fwd_nhwc_f32, which then
+ * takes them with w_perm != 0 (dense 16-byte weight loads instead of strided 4-byte ones) -- re-made from the live weights by
+ * every forward pass, at no launch of their own. */
 int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias, float* y, int B, int C, int H,
                         int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
-                        void* stream);
+                        int n_perm, const float* const* perm_src, float* const* perm_dst, const int* perm_cout,
+                        const int* perm_c, const int* perm_khw, void* stream);
 int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout);
 /* The later conv layers, same idea on fp32 channels-last activations x (B, H, W, C), C % 4 == 0: the reduction
  * runs in (i, j, c) order so that a window row is one contiguous run of kw*C floats; w is still the nn.Conv2d
@@ -692,12 +697,12 @@ int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, in
  * layer's own epilogue instead of a transposing launch.
  * Workspace of the weight gradient: trl_conv_bwd_weight_workspace. */
 int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
-                          int kh, int kw, int sh, int sw, int Cout, int act, int out_chw, void* stream);
+                          int kh, int kw, int sh, int sw, int Cout, int act, int out_chw, int w_perm, void* stream);
 /* G conv layers of one geometry (different inputs / weights / outputs) in one launch: the online and the target
  * network of a DQN update (dqn.py:47-52) run the same trunk on obs and next_obs */
 int trl_conv_fwd_nhwc_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
                                 float* const* y, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout,
-                                int act, int out_chw, void* stream);
+                                int act, int out_chw, int w_perm, void* stream);
 int trl_conv_bwd_weight_nhwc_f32(const float* dy, const float* y_gate, int gate_act, const float* x, float* dw,
                                  float* db, float* workspace, int B, int C, int H, int W, int kh, int kw, int sh,
                                  int sw, int Cout, void* stream);

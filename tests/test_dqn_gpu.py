@@ -526,3 +526,37 @@ def test_conv_weight_gradient_folds_as_one_launch_equal_the_per_layer_folds(B):
     with _C.FoldScope(DEV):                                                # (closed by the failure above: opens again)
         with pytest.raises(_C.TrlError):
             _C.check(_C.lib().trl_fold_scope_begin(), "nested")
+
+
+@pytest.mark.parametrize("B", [3, 64])
+def test_forward_with_reordered_weight_shadows_equals_the_gathering_kernel(B, monkeypatch):
+    """ops.FWD_WEIGHT_SHADOWS: the later conv layers' weights re-ordered to the (i, j, c) reduction order by riders of the
+    first layer's launch (trl_conv_fwd_u8_f32 perm jobs, trl_conv_fwd_nhwc_f32 w_perm) -- same products in the same order as
+    the kernel that gathers nn.Conv2d's layout on the fly: bit-identical outputs and tapes, single and paired forward; the
+    shadows follow the live weights (changed in between)."""
+    from torchrl_amd import _C, ops
+    torch.manual_seed(B)
+    net, net_t = small_qnet(6, act=torch.nn.ReLU).to(DEV), small_qnet(6, act=torch.nn.ReLU).to(DEV)
+    fa = torch.randint(0, 256, (B, 4, 84, 84), dtype=torch.uint8, device=DEV)
+    fb = torch.randint(0, 256, (B, 4, 84, 84), dtype=torch.uint8, device=DEV)
+
+    def run():
+        out, tape = ops.cnn_forward(net, fa)
+        (oa, ta), (ob, tb) = ops.cnn_forward_pair(net, net_t, fa, fb)
+        return [out, oa, ob] + [c[2] for c in tape.convs] + [c[2] for c in ta.convs] + [c[2] for c in tb.convs]
+
+    for step in range(2):
+        monkeypatch.setattr(ops, "FWD_WEIGHT_SHADOWS", False)
+        want = run()
+        monkeypatch.setattr(ops, "FWD_WEIGHT_SHADOWS", True)
+        got = run()
+        assert len(want) == len(got) and all(torch.equal(w, g) for w, g in zip(want, got))
+        with torch.no_grad():                                               # new weights: the next pass re-makes its shadows
+            for p in list(net.parameters()) + list(net_t.parameters()):
+                p.add_(0.01 * torch.randn_like(p))
+    # the re-ordering itself, against torch
+    w = torch.randn(32, 16 * 3 * 3, device=DEV)
+    frames = torch.zeros(2, 4, 84, 84, dtype=torch.uint8, device=DEV)
+    w1 = torch.zeros(8, 4 * 8 * 8, device=DEV)
+    _, _, outs = _C.conv_fwd_u8(frames, w1, None, 8, 8, 4, 4, 1.0, 0.0, _C.ACT_NONE, perm=[(w, 16, 9)])
+    assert torch.equal(outs[0], w.view(32, 16, 9).permute(0, 2, 1).reshape(32, -1))

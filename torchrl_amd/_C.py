@@ -208,9 +208,10 @@ SIGNATURES = {
     "trl_transpose_bpc_gate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 3
                                    + [C.c_void_p]),
     "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
-    "trl_conv_fwd_u8_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "trl_conv_fwd_u8_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int] +
+                            [C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
     "trl_conv_bwd_weight_workspace": (C.c_int, [C.c_int] * 9),
-    "trl_conv_fwd_nhwc_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 11 + [C.c_void_p]),
+    "trl_conv_fwd_nhwc_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
     "trl_conv_bwd_weight_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 9
                                      + [C.c_void_p]),
     "trl_conv_bwd_weight_u8_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 8
@@ -255,7 +256,7 @@ SIGNATURES = {
     "trl_mlp3_forward_ok": (C.c_int, [C.c_int] * 4),
     "trl_mlp3_forward_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_void_p]),
     "trl_linear_fwd_splitk_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
-    "trl_conv_fwd_nhwc_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 11 + [C.c_void_p]),
+    "trl_conv_fwd_nhwc_group_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
     "trl_linear_fwd_splitk_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "trl_linear_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -1187,17 +1188,29 @@ def conv_u8_implicit_ok(frames, kh, kw, sh, sw):
     return kw % 4 == 0 and sw % 4 == 0 and int(frames.shape[3]) % 4 == 0
 
 
-def conv_fwd_u8(frames, w, bias, kh, kw, sh, sw, scale, shift, act):
-    """act(conv2d(frames * scale + shift, w) + bias) on (B, C, H, W) uint8 frames; returns ((B*Ho*Wo, Cout), (B, Ho, Wo))."""
+def conv_fwd_u8(frames, w, bias, kh, kw, sh, sw, scale, shift, act, perm=None):
+    """act(conv2d(frames * scale + shift, w) + bias) on (B, C, H, W) uint8 frames; returns ((B*Ho*Wo, Cout), (B, Ho, Wo)).
+    perm: [(weight (Cout, C*kh*kw) of a LATER conv layer, its C, its kh*kw)] (<= 4) -> also returns the list of those
+    weights re-ordered to the (i, j, c) reduction order `conv_fwd_nhwc(..., w_perm=True)` reads, made by riders of this
+    launch."""
     B, Cc, H, W = (int(v) for v in frames.shape)
     Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
     Cout = int(w.shape[0])
     y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=frames.device)
+    jobs = list(perm or [])
+    n = len(jobs)
+    outs = [torch.empty_like(wl, memory_format=torch.contiguous_format) for wl, _, _ in jobs]
+    ints = lambda vals: (C.c_int * max(n, 1))(*[int(v) for v in vals])
     check(lib().trl_conv_fwd_u8_f32(dev_ptr(frames, torch.uint8, "frames"), dev_ptr(w, name="w"),
                                     dev_ptr(bias, name="bias", allow_none=True), dev_ptr(y, name="y"), B, Cc, H, W,
-                                    kh, kw, sh, sw, float(scale), float(shift), Cout, act, stream_ptr(frames.device)),
+                                    kh, kw, sh, sw, float(scale), float(shift), Cout, act, n,
+                                    _ptrs([j[0] for j in jobs], "perm weight") if n else None, _ptrs(outs, "perm out") if n else None,
+                                    ints(int(j[0].shape[0]) for j in jobs), ints(j[1] for j in jobs), ints(j[2] for j in jobs),
+                                    stream_ptr(frames.device)),
           "trl_conv_fwd_u8_f32")
-    return y, (B, Ho, Wo)
+    if perm is None:
+        return y, (B, Ho, Wo)
+    return y, (B, Ho, Wo), outs
 
 
 def conv_bwd_weight_u8(dy, y_gate, gate_act, frames, kh, kw, sh, sw, scale, shift, dw, db, workspace=None):
@@ -1216,21 +1229,22 @@ def conv_bwd_weight_u8(dy, y_gate, gate_act, frames, kh, kw, sh, sw, scale, shif
     return dw, db
 
 
-def conv_fwd_nhwc(x, w, bias, kh, kw, sh, sw, act, out_chw=False):
+def conv_fwd_nhwc(x, w, bias, kh, kw, sh, sw, act, out_chw=False, w_perm=False):
     """act(conv2d(x) + bias) on (B, H, W, C) fp32 channels-last activations, C % 4 == 0; w (Cout, C*kh*kw) is the
     nn.Conv2d weight as stored.  Returns ((B*Ho*Wo, Cout), (B, Ho, Wo)); with `out_chw` the result is stored
-    (B, Cout, Ho*Wo) -- nn.Flatten's order -- and returned as (B, Cout*Ho*Wo)."""
+    (B, Cout, Ho*Wo) -- nn.Flatten's order -- and returned as (B, Cout*Ho*Wo).  w_perm: `w` is already in the (i, j, c)
+    reduction order (conv_fwd_u8(perm=))."""
     B, H, W, Cc = (int(v) for v in x.shape)
     Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
     Cout = int(w.shape[0])
     y = torch.empty((B, Cout * Ho * Wo) if out_chw else (B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
     check(lib().trl_conv_fwd_nhwc_f32(dev_ptr(x, name="x"), dev_ptr(w, name="w"), dev_ptr(bias, name="bias", allow_none=True),
                                       dev_ptr(y, name="y"), B, Cc, H, W, kh, kw, sh, sw, Cout, act, int(bool(out_chw)),
-                                      stream_ptr(x.device)), "trl_conv_fwd_nhwc_f32")
+                                      int(bool(w_perm)), stream_ptr(x.device)), "trl_conv_fwd_nhwc_f32")
     return y, (B, Ho, Wo)
 
 
-def conv_fwd_nhwc_group(xs, ws, biases, kh, kw, sh, sw, act, out_chw=False):
+def conv_fwd_nhwc_group(xs, ws, biases, kh, kw, sh, sw, act, out_chw=False, w_perm=False):
     """`conv_fwd_nhwc` of G same-geometry layers (different inputs / weights) in one launch; returns ([y_g], (B, Ho, Wo))."""
     B, H, W, Cc = (int(v) for v in xs[0].shape)
     if any(tuple(x.shape) != tuple(xs[0].shape) for x in xs) or any(tuple(w.shape) != tuple(ws[0].shape) for w in ws):
@@ -1241,7 +1255,7 @@ def conv_fwd_nhwc_group(xs, ws, biases, kh, kw, sh, sw, act, out_chw=False):
           for _ in xs]
     check(lib().trl_conv_fwd_nhwc_group_f32(len(xs), _ptrs(xs, "x"), _ptrs(ws, "w"), _ptrs(biases, "bias", True),
                                             _ptrs(ys, "y"), B, Cc, H, W, kh, kw, sh, sw, Cout, act, int(bool(out_chw)),
-                                            stream_ptr(xs[0].device)), "trl_conv_fwd_nhwc_group_f32")
+                                            int(bool(w_perm)), stream_ptr(xs[0].device)), "trl_conv_fwd_nhwc_group_f32")
     return ys, (B, Ho, Wo)
 
 

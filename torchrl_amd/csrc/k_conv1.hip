@@ -28,7 +28,11 @@ __device__ __forceinline__ float c1_byte(uint32_t x, int r, float scale, float s
 template <int KU>                                   // K / 16
 __global__ __launch_bounds__(C1_THREADS) void conv1_fwd_direct_kernel(ConvSrc cv, const float* __restrict__ w,
                                                                      const float* __restrict__ bias, float* __restrict__ y,
-                                                                     int M, int K, int Cout, int act) {
+                                                                     int M, int K, int Cout, int act, PermJobs pj, int n_main) {
+  if ((int)blockIdx.x >= n_main) {                   // riders: the later layers' weights into the reduction order of their kernels
+    conv_perm_jobs(pj, blockIdx.x - n_main, gridDim.x - n_main, threadIdx.x, C1_THREADS);
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   // byte offset of every 4-tap group, once per workgroup (two run-time integer divisions apiece: sixteen of them per lane
@@ -157,13 +161,14 @@ bool trl_conv1_direct_ok(int K, int Cout, const float* w) {     // w: the forwar
 }
 
 int trl_conv1_direct_fwd(const ConvSrc& cv, const float* w, const float* bias, float* y, int M, int K, int Cout, int act,
-                         hipStream_t stream) {
-  const dim3 grid(trl_ceil_div(M, 64 * (C1_THREADS / 64))), block(C1_THREADS);
+                         const PermJobs& pj, hipStream_t stream) {
+  const int n_main = trl_ceil_div(M, 64 * (C1_THREADS / 64));
+  const dim3 grid(n_main + (pj.n > 0 ? CONV_PERM_BLOCKS : 0)), block(C1_THREADS);
   switch (K / 16) {
-    case 4:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<4>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act); break;
-    case 8:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<8>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act); break;
-    case 12: hipLaunchKernelGGL(conv1_fwd_direct_kernel<12>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act); break;
-    default: hipLaunchKernelGGL(conv1_fwd_direct_kernel<16>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act); break;
+    case 4:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<4>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;
+    case 8:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<8>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;
+    case 12: hipLaunchKernelGGL(conv1_fwd_direct_kernel<12>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;
+    default: hipLaunchKernelGGL(conv1_fwd_direct_kernel<16>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;
   }
   TRL_LAUNCH_CHECK();
   return TRL_OK;

@@ -60,6 +60,7 @@ struct GemmDev {
   GemmGroup grp[GEMM_MAX_GROUPS];
   int prefer128;              // != 0: the caller sized its reduction split for 128 x 128 tiles (split-K forward of few-row layers)
   int hetero;                 // != 0: problem blockIdx.y also has its own shape (the grid is sized for the largest)
+  int b_perm;                 // CONV == 3: B is already stored in the (i, j, c) reduction order (dense rows of K floats)
   GemmShape shp[GEMM_MAX_GROUPS];
 };
 
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDev g) {
         const bool ok = ctap_ok && m < k_hi;
         rb[t] = ok ? *reinterpret_cast<const f32x4*>(g.cv.x + (ok ? nhwc_row_offset(g.cv, (uint32_t)m) + ctap : 0u)) : zero4;
       }
-    } else if (CONV == 3) {
+    } else if (CONV == 3 && !g.b_perm) {
       // B = conv weight (Cout, C, kh, kw) read in the reduction order k' = (i, j, c): 4 consecutive k' are 4
       // consecutive channels of one tap, kh * kw floats apart
       const int kk = k0 + 4 * (tid % PG::KT);
@@ -1180,17 +1181,33 @@ static int fill_conv(const char* who, const uint8_t* frames, int B, int C, int H
   return TRL_OK;
 }
 
+__global__ __launch_bounds__(256) void conv_perm_kernel(PermJobs pj) {
+  conv_perm_jobs(pj, blockIdx.x, gridDim.x, threadIdx.x, 256);
+}
 extern "C" int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias, float* y, int B, int C, int H,
                                    int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
-                                   void* stream) {
+                                   int n_perm, const float* const* perm_src, float* const* perm_dst, const int* perm_cout,
+                                   const int* perm_c, const int* perm_khw, void* stream) {
   TRL_REQUIRE(frames && w && y && Cout > 0, "null pointer / bad Cout");
   TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
+  TRL_REQUIRE(n_perm >= 0 && n_perm <= CONV_PERM_MAX && (n_perm == 0 || (perm_src && perm_dst && perm_cout && perm_c && perm_khw)),
+              "conv_fwd_u8: 0..4 weight re-ordering jobs");
+  PermJobs pj{};
+  pj.n = n_perm;
+  for (int k = 0; k < n_perm; ++k) {
+    TRL_REQUIRE(perm_src[k] && perm_dst[k] && perm_cout[k] > 0 && perm_c[k] > 0 && perm_khw[k] > 0, "conv_fwd_u8: bad re-ordering job");
+    pj.src[k] = perm_src[k]; pj.dst[k] = perm_dst[k]; pj.cout[k] = perm_cout[k]; pj.c[k] = perm_c[k]; pj.khw[k] = perm_khw[k];
+  }
   GemmDev g{};
   int M, K;
   int rc = fill_conv("conv_fwd_u8", frames, B, C, H, W, kh, kw, sh, sw, scale, shift, g.cv, M, K);
   if (rc) return rc;
   if (trl_conv1_direct_ok(K, Cout, w))               // narrow first layer: register-weights kernel, no LDS staging
-    return trl_conv1_direct_fwd(g.cv, w, bias, y, M, K, Cout, act, (hipStream_t)stream);
+    return trl_conv1_direct_fwd(g.cv, w, bias, y, M, K, Cout, act, pj, (hipStream_t)stream);
+  if (n_perm) {                                      // (the generic kernel carries no riders: a launch of their own)
+    hipLaunchKernelGGL(conv_perm_kernel, dim3(CONV_PERM_BLOCKS), dim3(256), 0, (hipStream_t)stream, pj);
+    TRL_LAUNCH_CHECK();
+  }
   g.A = nullptr; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
   g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
   return launch_gemm<false, true, 1>(g, 1, (hipStream_t)stream);
@@ -1218,7 +1235,7 @@ static int fill_conv_nhwc(const char* who, const float* x, int B, int C, int H, 
 }
 
 extern "C" int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
-                                     int kh, int kw, int sh, int sw, int Cout, int act, int out_chw, void* stream) {
+                                     int kh, int kw, int sh, int sw, int Cout, int act, int out_chw, int w_perm, void* stream) {
   TRL_REQUIRE(x && w && y && Cout > 0, "null pointer / bad Cout");
   TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
   GemmDev g{};
@@ -1228,6 +1245,7 @@ extern "C" int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float
   g.A = nullptr; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
   g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
   g.chw_p = out_chw ? g.cv.Ho * g.cv.Wo : 0;
+  g.b_perm = w_perm ? 1 : 0;
   return launch_gemm<false, true, 3>(g, 1, (hipStream_t)stream);
 }
 
@@ -1235,7 +1253,7 @@ extern "C" int trl_conv_fwd_nhwc_f32(const float* x, const float* w, const float
 // a DQN update run the same trunk on obs and next_obs
 extern "C" int trl_conv_fwd_nhwc_group_f32(int G, const float* const* x, const float* const* w, const float* const* bias,
                                            float* const* y, int B, int C, int H, int W, int kh, int kw, int sh, int sw,
-                                           int Cout, int act, int out_chw, void* stream) {
+                                           int Cout, int act, int out_chw, int w_perm, void* stream) {
   TRL_REQUIRE(G >= 1 && G <= GEMM_MAX_GROUPS, "1..12 problems per grouped launch");
   TRL_REQUIRE(x && w && y && Cout > 0, "null pointer array / bad Cout");
   TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
@@ -1252,6 +1270,7 @@ extern "C" int trl_conv_fwd_nhwc_group_f32(int G, const float* const* x, const f
   g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
   g.cv.x = x[0];
   g.chw_p = out_chw ? g.cv.Ho * g.cv.Wo : 0;
+  g.b_perm = w_perm ? 1 : 0;
   return launch_gemm<false, true, 3>(g, 1, (hipStream_t)stream);
 }
 

@@ -70,10 +70,26 @@ static inline void fastdiv_gen(uint32_t d, uint32_t& magic, uint32_t& shift) {
   magic = m + 1; shift = L;
 }
 
+// Re-ordering jobs that ride on a first-layer forward launch: the LATER conv layers' weights (Cout, C, kh * kw) copied
+// into the (i, j, c) reduction order of the channels-last implicit GEMM, dst[n][ij * C + c] = src[n][c * khw + ij], so that
+// its B operand is dense 16-byte loads instead of four strided 4-byte loads per slot.
+#define CONV_PERM_MAX 4
+struct PermJobs { int n; const float* src[CONV_PERM_MAX]; float* dst[CONV_PERM_MAX]; int cout[CONV_PERM_MAX], c[CONV_PERM_MAX], khw[CONV_PERM_MAX]; };
+__device__ __forceinline__ void conv_perm_jobs(const PermJobs& pj, int block, int n_blocks, int tid, int n_threads) {
+  for (int k = 0; k < pj.n; ++k) {
+    const int C = pj.c[k], khw = pj.khw[k], K = C * khw, total = pj.cout[k] * K;
+    for (int e = block * n_threads + tid; e < total; e += n_blocks * n_threads) {
+      const int row = e / K, kp = e - row * K, ij = kp / C, c = kp - ij * C;   // e = destination index
+      pj.dst[k][e] = pj.src[k][row * K + c * khw + ij];
+    }
+  }
+}
+#define CONV_PERM_BLOCKS 8
+
 // ---- direct kernels for a narrow first layer (k_conv1.hip); used by the trl_conv_*_u8 entry points when they apply ----
 bool trl_conv1_direct_ok(int K, int Cout, const float* w);
 int trl_conv1_direct_fwd(const ConvSrc& cv, const float* w, const float* bias, float* y, int M, int K, int Cout, int act,
-                         hipStream_t stream);
+                         const PermJobs& pj, hipStream_t stream);
 int trl_conv1_direct_bwdw_workspace(int M, int K, int Cout);          // floats
 int trl_conv1_direct_bwdw(const ConvSrc& cv, const float* dy, const float* y_gate, int gate_act, float* dw, float* db,
                           float* workspace, int M, int K, int Cout, hipStream_t stream);
