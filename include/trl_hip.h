@@ -681,14 +681,22 @@ int trl_transpose_bpc_gate_f32(const float* in, const float* y_gate, int gate_ac
  * return TRL_EINVAL and go through trl_im2col_u8_nchw + trl_linear_*.
  * trl_conv_bwd_weight_u8_f32: dw (Cout, C*kh*kw), db (Cout) (nullable) from dy (B*Ho*Wo, Cout), gated by
  * act'(y_gate) as in trl_linear_bwd_weight_f32; workspace: trl_conv_bwd_weight_workspace(...) floats.
- * n_perm (0..4) re-ordering jobs ride on the forward launch: weights perm_src[k] (perm_cout x perm_c x perm_khw, nn.Conv2d's
- * layout) of LATER conv layers are copied to perm_dst[k] in the (i, j, c) reduction order of trl_conv_fwd_nhwc_f32, which then
- * takes them with w_perm != 0 (dense 16-byte weight loads instead of strided 4-byte ones) -- re-made from the live weights by
- * every forward pass, at no launch of their own. */
+ * riders (nullable): small weight re-orderings that ride on the forward launch as extra workgroups -- re-made from the live
+ * weights by every forward pass, at no launch of their own:
+ *   perm jobs  the weight (perm_cout x perm_c x perm_khw, nn.Conv2d's layout) of a LATER conv layer copied to perm_dst in the
+ *              (i, j, c) reduction order of trl_conv_fwd_nhwc_f32, which then takes it with w_perm != 0 (dense 16-byte weight
+ *              loads instead of strided 4-byte ones);
+ *   dx jobs    what trl_conv_bwd_input_nhwc_prep_f32 makes for a later layer's input gradient (dx_ws:
+ *              trl_conv_bwd_input_nhwc_workspace floats), for a backward pass that follows with prepped != 0. */
+typedef struct trl_conv_riders_t {
+  int n_perm;                 /* <= 4 */
+  const float* perm_src[4]; float* perm_dst[4]; int perm_cout[4], perm_c[4], perm_khw[4];
+  int n_dx;                   /* <= 4 */
+  const float* dx_w[4]; float* dx_ws[4]; int dx_cin[4], dx_cout[4], dx_kh[4], dx_kw[4], dx_sh[4], dx_sw[4];
+} trl_conv_riders_t;
 int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias, float* y, int B, int C, int H,
                         int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
-                        int n_perm, const float* const* perm_src, float* const* perm_dst, const int* perm_cout,
-                        const int* perm_c, const int* perm_khw, void* stream);
+                        const trl_conv_riders_t* riders, void* stream);
 int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout);
 /* The later conv layers, same idea on fp32 channels-last activations x (B, H, W, C), C % 4 == 0: the reduction
  * runs in (i, j, c) order so that a window row is one contiguous run of kw*C floats; w is still the nn.Conv2d

@@ -558,5 +558,10 @@ def test_forward_with_reordered_weight_shadows_equals_the_gathering_kernel(B, mo
     w = torch.randn(32, 16 * 3 * 3, device=DEV)
     frames = torch.zeros(2, 4, 84, 84, dtype=torch.uint8, device=DEV)
     w1 = torch.zeros(8, 4 * 8 * 8, device=DEV)
-    _, _, outs = _C.conv_fwd_u8(frames, w1, None, 8, 8, 4, 4, 1.0, 0.0, _C.ACT_NONE, perm=[(w, 16, 9)])
+    w2 = torch.randn(32, 16 * 4 * 4, device=DEV)
+    _, _, (outs, wss) = _C.conv_fwd_u8(frames, w1, None, 8, 8, 4, 4, 1.0, 0.0, _C.ACT_NONE, perm=[(w, 16, 9)],
+                                       dx=[(w2, 16, 4, 4, 2, 2), (w, 16, 3, 3, 1, 1)])
     assert torch.equal(outs[0], w.view(32, 16, 9).permute(0, 2, 1).reshape(32, -1))
+    # ... and the input-gradient kernels' weight re-orderings as riders of the same launch, against the launch of their own
+    ref = _C.conv_bwd_input_prep([(w2, 16, 4, 4, 2, 2), (w, 16, 3, 3, 1, 1)], DEV)
+    assert torch.equal(wss[0], ref[0]) and torch.equal(wss[1], ref[1])

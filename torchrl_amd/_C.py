@@ -104,6 +104,13 @@ class AdamArgs(C.Structure):
     ]
 
 
+class ConvRiders(C.Structure):          # include/trl_hip.h trl_conv_riders_t
+    _fields_ = [("n_perm", C.c_int), ("perm_src", C.c_void_p * 4), ("perm_dst", C.c_void_p * 4), ("perm_cout", C.c_int * 4),
+                ("perm_c", C.c_int * 4), ("perm_khw", C.c_int * 4), ("n_dx", C.c_int), ("dx_w", C.c_void_p * 4),
+                ("dx_ws", C.c_void_p * 4), ("dx_cin", C.c_int * 4), ("dx_cout", C.c_int * 4), ("dx_kh", C.c_int * 4),
+                ("dx_kw", C.c_int * 4), ("dx_sh", C.c_int * 4), ("dx_sw", C.c_int * 4)]
+
+
 # name -> (restype, argtypes); the loader checks every one of these symbols exists
 SIGNATURES = {
     "trl_last_error": (C.c_char_p, []),
@@ -209,7 +216,7 @@ SIGNATURES = {
                                    + [C.c_void_p]),
     "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_conv_fwd_u8_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int] +
-                            [C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]),
+                            [C.POINTER(ConvRiders), C.c_void_p]),
     "trl_conv_bwd_weight_workspace": (C.c_int, [C.c_int] * 9),
     "trl_conv_fwd_nhwc_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
     "trl_conv_bwd_weight_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 9
@@ -1188,29 +1195,38 @@ def conv_u8_implicit_ok(frames, kh, kw, sh, sw):
     return kw % 4 == 0 and sw % 4 == 0 and int(frames.shape[3]) % 4 == 0
 
 
-def conv_fwd_u8(frames, w, bias, kh, kw, sh, sw, scale, shift, act, perm=None):
+def conv_fwd_u8(frames, w, bias, kh, kw, sh, sw, scale, shift, act, perm=None, dx=None):
     """act(conv2d(frames * scale + shift, w) + bias) on (B, C, H, W) uint8 frames; returns ((B*Ho*Wo, Cout), (B, Ho, Wo)).
-    perm: [(weight (Cout, C*kh*kw) of a LATER conv layer, its C, its kh*kw)] (<= 4) -> also returns the list of those
-    weights re-ordered to the (i, j, c) reduction order `conv_fwd_nhwc(..., w_perm=True)` reads, made by riders of this
-    launch."""
+    Riders of the launch (include/trl_hip.h trl_conv_riders_t; then a third return value (perm outs, dx workspaces)):
+    perm: [(weight (Cout, C*kh*kw) of a LATER conv layer, its C, its kh*kw)] (<= 4) -> those weights re-ordered to the
+    (i, j, c) reduction order `conv_fwd_nhwc(..., w_perm=True)` reads;  dx: [(weight, Cin, kh, kw, sh, sw)] (<= 4) -> the
+    workspaces `conv_bwd_input_nhwc(..., prep=)` takes."""
     B, Cc, H, W = (int(v) for v in frames.shape)
     Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
     Cout = int(w.shape[0])
     y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=frames.device)
-    jobs = list(perm or [])
-    n = len(jobs)
+    jobs, dxs = list(perm or []), list(dx or [])
     outs = [torch.empty_like(wl, memory_format=torch.contiguous_format) for wl, _, _ in jobs]
-    ints = lambda vals: (C.c_int * max(n, 1))(*[int(v) for v in vals])
+    wss = [torch.empty((lib().trl_conv_bwd_input_nhwc_workspace(cin, int(wl.shape[0]), a, b),), dtype=torch.float32, device=frames.device)
+           for wl, cin, a, b, _, _ in dxs]
+    r = None
+    if jobs or dxs:
+        r = ConvRiders()
+        r.n_perm, r.n_dx = len(jobs), len(dxs)
+        for k, ((wl, c, khw), o) in enumerate(zip(jobs, outs)):
+            r.perm_src[k], r.perm_dst[k] = dev_ptr(wl, name="perm weight"), dev_ptr(o, name="perm out")
+            r.perm_cout[k], r.perm_c[k], r.perm_khw[k] = int(wl.shape[0]), int(c), int(khw)
+        for k, ((wl, cin, a, b, c, d), ws) in enumerate(zip(dxs, wss)):
+            r.dx_w[k], r.dx_ws[k] = dev_ptr(wl, name="dx weight"), dev_ptr(ws, name="dx workspace")
+            r.dx_cin[k], r.dx_cout[k], r.dx_kh[k], r.dx_kw[k], r.dx_sh[k], r.dx_sw[k] = int(cin), int(wl.shape[0]), a, b, c, d
     check(lib().trl_conv_fwd_u8_f32(dev_ptr(frames, torch.uint8, "frames"), dev_ptr(w, name="w"),
                                     dev_ptr(bias, name="bias", allow_none=True), dev_ptr(y, name="y"), B, Cc, H, W,
-                                    kh, kw, sh, sw, float(scale), float(shift), Cout, act, n,
-                                    _ptrs([j[0] for j in jobs], "perm weight") if n else None, _ptrs(outs, "perm out") if n else None,
-                                    ints(int(j[0].shape[0]) for j in jobs), ints(j[1] for j in jobs), ints(j[2] for j in jobs),
-                                    stream_ptr(frames.device)),
+                                    kh, kw, sh, sw, float(scale), float(shift), Cout, act,
+                                    C.byref(r) if r is not None else None, stream_ptr(frames.device)),
           "trl_conv_fwd_u8_f32")
-    if perm is None:
+    if perm is None and dx is None:
         return y, (B, Ho, Wo)
-    return y, (B, Ho, Wo), outs
+    return y, (B, Ho, Wo), (outs, wss)
 
 
 def conv_bwd_weight_u8(dy, y_gate, gate_act, frames, kh, kw, sh, sw, scale, shift, dw, db, workspace=None):

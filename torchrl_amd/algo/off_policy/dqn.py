@@ -178,9 +178,9 @@ class _FusedDQN:
             (hw, hb), (tw, tb) = ops.fc_layers(algo.qf)[-1], ops.fc_layers(algo.target_qf)[-1]
             if Q == 1 and hb is not None and _C.dqn_head_supported(int(hw.shape[1]), A) and \
                     hw.data_ptr() % 16 == 0 and tw.data_ptr() % 16 == 0:
-                pair = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs, head=False)
+                pair = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs, head=False, dx_prep=True)
             if pair is None:
-                (q, tape), (qn, _) = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs)
+                (q, tape), (qn, _) = ops.cnn_forward_pair(algo.qf, algo.target_qf, obs, nobs, dx_prep=True)
         if pair is not None:
             # the A-wide head: both forward passes, the loss and its whole backward pass in one launch
             (h, tape), (hn, _) = pair

@@ -163,7 +163,7 @@ bool trl_conv1_direct_ok(int K, int Cout, const float* w) {     // w: the forwar
 int trl_conv1_direct_fwd(const ConvSrc& cv, const float* w, const float* bias, float* y, int M, int K, int Cout, int act,
                          const PermJobs& pj, hipStream_t stream) {
   const int n_main = trl_ceil_div(M, 64 * (C1_THREADS / 64));
-  const dim3 grid(n_main + (pj.n > 0 ? CONV_PERM_BLOCKS : 0)), block(C1_THREADS);
+  const dim3 grid(n_main + ((pj.n > 0 || pj.n_dx > 0) ? CONV_PERM_BLOCKS : 0)), block(C1_THREADS);
   switch (K / 16) {
     case 4:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<4>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;
     case 8:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<8>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;

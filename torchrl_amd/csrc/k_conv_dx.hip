@@ -20,11 +20,7 @@
 #include "trl_common.h"
 #include "trl_mlp.h"
 
-struct DxGeom {
-  int B, Cin, H, W, kh, kw, sh, sw, Ho, Wo, Cout;
-  int gate_act, x_gate_act, tiles_per_wg;
-  int dbg;                      // TRL_EXP_DX builds only (tools/bench_convdx.py): phases to skip
-};
+#include "trl_conv.h"
 
 __device__ __forceinline__ float dx_dact(int act, float y) {
   if (act == TRL_ACT_TANH) return 1.0f - y * y;
@@ -39,24 +35,10 @@ __device__ __forceinline__ int dx_div(int n, int d, float inv) {
   q += (r >= d) - (r < 0);
   return q;
 }
-__host__ __device__ inline int dx_class_taps(const DxGeom& g, int py, int px) {
-  const int nti = py < g.kh ? (g.kh - py + g.sh - 1) / g.sh : 0, ntj = px < g.kw ? (g.kw - px + g.sw - 1) / g.sw : 0;
-  return nti * ntj;
-}
-
 // wprep[class block][tap][co / 16][r][cb][gq][j] = W[co = 16 chunk + 4 gq + r][c = 16 cb + j][i][j_tap]: MFMA step
 // (chunk, r) of column block cb reads 64 consecutive floats.  Class blocks follow each other in class order.
 __global__ __launch_bounds__(256) void conv_dx_prep_kernel(const float* __restrict__ w, float* __restrict__ wprep, DxGeom g) {
-  const int total = g.Cout * g.Cin * g.kh * g.kw, CB = g.Cin >> 4, tap_floats = g.Cout * g.Cin;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    const int jt = e % g.kw, it = (e / g.kw) % g.kh, c = (e / (g.kw * g.kh)) % g.Cin, co = e / (g.kw * g.kh * g.Cin);
-    const int py = it % g.sh, px = jt % g.sw, ti = it / g.sh, tj = jt / g.sw;
-    int off = 0;
-    for (int cls = 0; cls < py * g.sw + px; ++cls) off += dx_class_taps(g, cls / g.sw, cls % g.sw) * tap_floats;
-    const int ntj = (g.kw - px + g.sw - 1) / g.sw;
-    const int chunk = co >> 4, gq = (co >> 2) & 3, r = co & 3, cb = c >> 4, j = c & 15;
-    wprep[off + (ti * ntj + tj) * tap_floats + (((chunk * 4 + r) * CB + cb) * 4 + gq) * 16 + j] = w[e];
-  }
+  dx_prep_range(w, wprep, g, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // the re-ordered weights of SEVERAL layers in one launch (blockIdx.y = layer): a backward pass through a conv trunk needs
@@ -64,19 +46,8 @@ __global__ __launch_bounds__(256) void conv_dx_prep_kernel(const float* __restri
 #define DX_PREP_MAX 8
 struct DxPrepSet { const float* w[DX_PREP_MAX]; float* wprep[DX_PREP_MAX]; DxGeom g[DX_PREP_MAX]; };
 __global__ __launch_bounds__(256) void conv_dx_prep_multi_kernel(DxPrepSet p) {
-  const float* __restrict__ w = p.w[blockIdx.y];
-  float* __restrict__ wprep = p.wprep[blockIdx.y];
   const DxGeom g = p.g[blockIdx.y];
-  const int total = g.Cout * g.Cin * g.kh * g.kw, CB = g.Cin >> 4, tap_floats = g.Cout * g.Cin;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {      // (conv_dx_prep_kernel's body)
-    const int jt = e % g.kw, it = (e / g.kw) % g.kh, c = (e / (g.kw * g.kh)) % g.Cin, co = e / (g.kw * g.kh * g.Cin);
-    const int py = it % g.sh, px = jt % g.sw, ti = it / g.sh, tj = jt / g.sw;
-    int off = 0;
-    for (int cls = 0; cls < py * g.sw + px; ++cls) off += dx_class_taps(g, cls / g.sw, cls % g.sw) * tap_floats;
-    const int ntj = (g.kw - px + g.sw - 1) / g.sw;
-    const int chunk = co >> 4, gq = (co >> 2) & 3, r = co & 3, cb = c >> 4, j = c & 15;
-    wprep[off + (ti * ntj + tj) * tap_floats + (((chunk * 4 + r) * CB + cb) * 4 + gq) * 16 + j] = w[e];
-  }
+  dx_prep_range(p.w[blockIdx.y], p.wprep[blockIdx.y], g, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 template <int CB, int NCH, int WAVES>

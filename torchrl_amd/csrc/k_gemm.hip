@@ -1186,17 +1186,28 @@ __global__ __launch_bounds__(256) void conv_perm_kernel(PermJobs pj) {
 }
 extern "C" int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias, float* y, int B, int C, int H,
                                    int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
-                                   int n_perm, const float* const* perm_src, float* const* perm_dst, const int* perm_cout,
-                                   const int* perm_c, const int* perm_khw, void* stream) {
+                                   const trl_conv_riders_t* riders, void* stream) {
   TRL_REQUIRE(frames && w && y && Cout > 0, "null pointer / bad Cout");
   TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
-  TRL_REQUIRE(n_perm >= 0 && n_perm <= CONV_PERM_MAX && (n_perm == 0 || (perm_src && perm_dst && perm_cout && perm_c && perm_khw)),
-              "conv_fwd_u8: 0..4 weight re-ordering jobs");
   PermJobs pj{};
-  pj.n = n_perm;
-  for (int k = 0; k < n_perm; ++k) {
-    TRL_REQUIRE(perm_src[k] && perm_dst[k] && perm_cout[k] > 0 && perm_c[k] > 0 && perm_khw[k] > 0, "conv_fwd_u8: bad re-ordering job");
-    pj.src[k] = perm_src[k]; pj.dst[k] = perm_dst[k]; pj.cout[k] = perm_cout[k]; pj.c[k] = perm_c[k]; pj.khw[k] = perm_khw[k];
+  if (riders) {
+    TRL_REQUIRE(riders->n_perm >= 0 && riders->n_perm <= CONV_PERM_MAX && riders->n_dx >= 0 && riders->n_dx <= CONV_PERM_MAX,
+                "conv_fwd_u8: 0..4 jobs of either kind");
+    pj.n = riders->n_perm; pj.n_dx = riders->n_dx;
+    for (int k = 0; k < pj.n; ++k) {
+      TRL_REQUIRE(riders->perm_src[k] && riders->perm_dst[k] && riders->perm_cout[k] > 0 && riders->perm_c[k] > 0 && riders->perm_khw[k] > 0,
+                  "conv_fwd_u8: bad re-ordering job");
+      pj.src[k] = riders->perm_src[k]; pj.dst[k] = riders->perm_dst[k]; pj.cout[k] = riders->perm_cout[k];
+      pj.c[k] = riders->perm_c[k]; pj.khw[k] = riders->perm_khw[k];
+    }
+    for (int k = 0; k < pj.n_dx; ++k) {
+      TRL_REQUIRE(riders->dx_w[k] && riders->dx_ws[k] &&
+                  trl_conv_bwd_input_nhwc_ok(riders->dx_cin[k], riders->dx_cout[k], riders->dx_kh[k], riders->dx_kw[k], riders->dx_sh[k], riders->dx_sw[k]),
+                  "conv_fwd_u8: dx job outside trl_conv_bwd_input_nhwc_ok");
+      pj.dx_w[k] = riders->dx_w[k]; pj.dx_ws[k] = riders->dx_ws[k];
+      pj.dx_g[k] = DxGeom{0, riders->dx_cin[k], 0, 0, riders->dx_kh[k], riders->dx_kw[k], riders->dx_sh[k], riders->dx_sw[k], 0, 0,
+                          riders->dx_cout[k], TRL_ACT_NONE, TRL_ACT_NONE, 1, 0};
+    }
   }
   GemmDev g{};
   int M, K;
@@ -1204,7 +1215,7 @@ extern "C" int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const 
   if (rc) return rc;
   if (trl_conv1_direct_ok(K, Cout, w))               // narrow first layer: register-weights kernel, no LDS staging
     return trl_conv1_direct_fwd(g.cv, w, bias, y, M, K, Cout, act, pj, (hipStream_t)stream);
-  if (n_perm) {                                      // (the generic kernel carries no riders: a launch of their own)
+  if (pj.n || pj.n_dx) {                             // (the generic kernel carries no riders: a launch of their own)
     hipLaunchKernelGGL(conv_perm_kernel, dim3(CONV_PERM_BLOCKS), dim3(256), 0, (hipStream_t)stream, pj);
     TRL_LAUNCH_CHECK();
   }

@@ -70,11 +70,40 @@ static inline void fastdiv_gen(uint32_t d, uint32_t& magic, uint32_t& shift) {
   magic = m + 1; shift = L;
 }
 
-// Re-ordering jobs that ride on a first-layer forward launch: the LATER conv layers' weights (Cout, C, kh * kw) copied
-// into the (i, j, c) reduction order of the channels-last implicit GEMM, dst[n][ij * C + c] = src[n][c * khw + ij], so that
-// its B operand is dense 16-byte loads instead of four strided 4-byte loads per slot.
+// geometry of an implicit transposed convolution (k_conv_dx.hip) and the re-ordering of its weights:
+// wprep[class block][tap][co / 16][r][cb][gq][j] = W[co = 16 chunk + 4 gq + r][c = 16 cb + j][i][j_tap]: MFMA step
+// (chunk, r) of column block cb reads 64 consecutive floats.  Class blocks follow each other in class order.
+struct DxGeom {
+  int B, Cin, H, W, kh, kw, sh, sw, Ho, Wo, Cout;
+  int gate_act, x_gate_act, tiles_per_wg;
+  int dbg;                      // TRL_EXP_DX builds only (tools/bench_convdx.py): phases to skip
+};
+__host__ __device__ inline int dx_class_taps(const DxGeom& g, int py, int px) {
+  const int nti = py < g.kh ? (g.kh - py + g.sh - 1) / g.sh : 0, ntj = px < g.kw ? (g.kw - px + g.sw - 1) / g.sw : 0;
+  return nti * ntj;
+}
+__device__ __forceinline__ void dx_prep_range(const float* __restrict__ w, float* __restrict__ wprep, const DxGeom& g, int first,
+                                              int stride) {
+  const int total = g.Cout * g.Cin * g.kh * g.kw, CB = g.Cin >> 4, tap_floats = g.Cout * g.Cin;
+  for (int e = first; e < total; e += stride) {
+    const int jt = e % g.kw, it = (e / g.kw) % g.kh, c = (e / (g.kw * g.kh)) % g.Cin, co = e / (g.kw * g.kh * g.Cin);
+    const int py = it % g.sh, px = jt % g.sw, ti = it / g.sh, tj = jt / g.sw;
+    int off = 0;
+    for (int cls = 0; cls < py * g.sw + px; ++cls) off += dx_class_taps(g, cls / g.sw, cls % g.sw) * tap_floats;
+    const int ntj = (g.kw - px + g.sw - 1) / g.sw;
+    const int chunk = co >> 4, gq = (co >> 2) & 3, r = co & 3, cb = c >> 4, j = c & 15;
+    wprep[off + (ti * ntj + tj) * tap_floats + (((chunk * 4 + r) * CB + cb) * 4 + gq) * 16 + j] = w[e];
+  }
+}
+// Jobs that ride on a first-layer forward launch (extra workgroups): the LATER conv layers' weights (Cout, C, kh * kw)
+// copied into the (i, j, c) reduction order of the channels-last implicit GEMM, dst[n][ij * C + c] = src[n][c * khw + ij]
+// (its B operand is then dense 16-byte loads instead of four strided 4-byte loads per slot), and the re-ordered weights
+// of the backward pass's implicit transposed convolutions.
 #define CONV_PERM_MAX 4
-struct PermJobs { int n; const float* src[CONV_PERM_MAX]; float* dst[CONV_PERM_MAX]; int cout[CONV_PERM_MAX], c[CONV_PERM_MAX], khw[CONV_PERM_MAX]; };
+struct PermJobs {
+  int n; const float* src[CONV_PERM_MAX]; float* dst[CONV_PERM_MAX]; int cout[CONV_PERM_MAX], c[CONV_PERM_MAX], khw[CONV_PERM_MAX];
+  int n_dx; const float* dx_w[CONV_PERM_MAX]; float* dx_ws[CONV_PERM_MAX]; DxGeom dx_g[CONV_PERM_MAX];
+};
 __device__ __forceinline__ void conv_perm_jobs(const PermJobs& pj, int block, int n_blocks, int tid, int n_threads) {
   for (int k = 0; k < pj.n; ++k) {
     const int C = pj.c[k], khw = pj.khw[k], K = C * khw, total = pj.cout[k] * K;
@@ -83,6 +112,7 @@ __device__ __forceinline__ void conv_perm_jobs(const PermJobs& pj, int block, in
       pj.dst[k][e] = pj.src[k][row * K + c * khw + ij];
     }
   }
+  for (int k = 0; k < pj.n_dx; ++k) dx_prep_range(pj.dx_w[k], pj.dx_ws[k], pj.dx_g[k], block * n_threads + tid, n_blocks * n_threads);
 }
 #define CONV_PERM_BLOCKS 8
 

@@ -176,7 +176,8 @@ def mlp_backward_group(tapes, d_outs, grads_list=None, need_input=False, workspa
 # in-kernel (x / 255 - 0.5, ScaledFloatFrame).
 class ConvTape:
     # feat_chw: the last conv layer's output (convs[-1][2]) is kept as (B, C, Ho*Wo) -- the flattened features themselves
-    __slots__ = ("convs", "fc", "B", "act", "feat_shape", "feat_chw")
+    # dx_preps: {layer index: re-ordered weights of its implicit input-gradient kernel}, made by riders of the forward
+    __slots__ = ("convs", "fc", "B", "act", "feat_shape", "feat_chw", "dx_preps")
 
 
 def conv_layers(net):
@@ -227,13 +228,26 @@ def _shadow_jobs(layers):
     return jobs
 
 
-def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
-    """frames_u8: (B, C, H, W) uint8.  Returns (out (B, O), tape)."""
+def _dx_jobs(layers):
+    """[(layer index, weight matrix, Cin, kh, kw, sh, sw)] of the conv layers whose input gradient is the implicit transposed
+    convolution: their weight re-orderings ride on the first layer's forward launch when a backward pass will follow."""
+    jobs = []
+    for k in range(1, len(layers)):
+        m = layers[k]
+        geo = (int(m.in_channels), int(m.kernel_size[0]), int(m.kernel_size[1]), int(m.stride[0]), int(m.stride[1]))
+        if _C.conv_bwd_input_ok(geo[0], int(m.weight.shape[0]), *geo[1:]) and len(jobs) < 4:
+            jobs.append((k, m.weight.view(m.weight.shape[0], -1)) + geo)
+    return jobs
+
+
+def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5, dx_prep=False):
+    """frames_u8: (B, C, H, W) uint8.  Returns (out (B, O), tape).  dx_prep: a backward pass will follow -- the weight
+    re-orderings of its input-gradient kernels ride on the first layer's launch (tape.dx_preps)."""
     if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
         raise _C.TrlError("cnn_forward expects (B, C, H, W) uint8 frame stacks")
     act = cnn_act_code(net)
     t = ConvTape()
-    t.convs, t.act, t.B, t.feat_chw = [], act, int(frames_u8.shape[0]), False
+    t.convs, t.act, t.B, t.feat_chw, t.dx_preps = [], act, int(frames_u8.shape[0]), False, None
     x, geom_in = frames_u8.contiguous(), None
     layers = conv_layers(net)
     shadows = {}                                                             # layer index -> weight in the (i, j, c) reduction order
@@ -243,9 +257,11 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
         if k == 0 and _C.conv_u8_implicit_ok(x, kh, kw, sh, sw):
             # implicit GEMM straight from the uint8 frames: the im2col matrix (210 MB at cfg 5) never exists
             wmat = m.weight.view(m.weight.shape[0], -1)
-            jobs = _shadow_jobs(layers)
-            y, (B, Ho, Wo), outs = _C.conv_fwd_u8(x, wmat, m.bias, kh, kw, sh, sw, scale, shift, act, perm=[j[1:] for j in jobs])
+            jobs, dxj = _shadow_jobs(layers), (_dx_jobs(layers) if dx_prep else [])
+            y, (B, Ho, Wo), (outs, wss) = _C.conv_fwd_u8(x, wmat, m.bias, kh, kw, sh, sw, scale, shift, act,
+                                                         perm=[j[1:] for j in jobs], dx=[j[1:] for j in dxj])
             shadows = {j[0]: o for j, o in zip(jobs, outs)}
+            t.dx_preps = {j[0]: ws for j, ws in zip(dxj, wss)}
             t.convs.append(("u8", (x, scale, shift), y, wmat, None, (kh, kw, sh, sw)))
             x = y.view(B, Ho, Wo, int(wmat.shape[0]))
             continue
@@ -281,7 +297,7 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5):
     return out, t
 
 
-def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=-0.5, head=True):
+def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=-0.5, head=True, dx_prep=False):
     """`cnn_forward` of two same-architecture networks on two frame batches -- DQN's online net on obs and target net on
     next_obs -- with every layer after the first as ONE grouped launch (conv 2 / 3 as grouped implicit GEMMs, the FC head
     as grouped (split-K) layers).  Returns ((out_a, tape_a), (out_b, tape_b)); falls back to two separate passes for
@@ -301,21 +317,23 @@ def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=
             any(int(m.in_channels) % 4 for m in convs_a[1:]):
         if not head:
             return None
-        return cnn_forward(net_a, frames_a, scale, shift), cnn_forward(net_b, frames_b, scale, shift)
+        return cnn_forward(net_a, frames_a, scale, shift, dx_prep=dx_prep), cnn_forward(net_b, frames_b, scale, shift)
     if not head and len(fc_layers(net_a)) < 2:
         return None
     tapes, xs, shadows = [], [], []
     for net, convs, frames in ((net_a, convs_a, frames_a), (net_b, convs_b, frames_b)):
         t = ConvTape()
-        t.convs, t.act, t.B, t.feat_chw = [], act, int(frames.shape[0]), False
+        t.convs, t.act, t.B, t.feat_chw, t.dx_preps = [], act, int(frames.shape[0]), False, None
         m = convs[0]
         kh, kw = m.kernel_size
         sh, sw = m.stride
         wmat = m.weight.view(m.weight.shape[0], -1)
         fr = frames.contiguous()
-        jobs = _shadow_jobs(convs)
-        y, (B, Ho, Wo), outs = _C.conv_fwd_u8(fr, wmat, m.bias, kh, kw, sh, sw, scale, shift, act, perm=[j[1:] for j in jobs])
+        jobs, dxj = _shadow_jobs(convs), (_dx_jobs(convs) if (dx_prep and net is net_a) else [])   # (net_a's backward follows)
+        y, (B, Ho, Wo), (outs, wss) = _C.conv_fwd_u8(fr, wmat, m.bias, kh, kw, sh, sw, scale, shift, act,
+                                                     perm=[j[1:] for j in jobs], dx=[j[1:] for j in dxj])
         shadows.append({j[0]: o for j, o in zip(jobs, outs)})
+        t.dx_preps = {j[0]: ws for j, ws in zip(dxj, wss)}
         t.convs.append(("u8", (fr, scale, shift), y, wmat, None, (kh, kw, sh, sw)))
         tapes.append(t)
         xs.append(y.view(B, Ho, Wo, int(wmat.shape[0])))
@@ -403,10 +421,11 @@ def _cnn_trunk_backward(tape, d, grads, gated, regions):
     # the implicit input-gradient kernels read the weights re-ordered: all layers' re-orderings in ONE launch up front
     dx_layers = [k for k in range(1, n_conv)
                  if _C.conv_bwd_input_ok(tape.convs[k][4][3], int(tape.convs[k][3].shape[0]), *tape.convs[k][5])]
-    preps = {}
-    if len(dx_layers) > 1:
-        wss = _C.conv_bwd_input_prep([(tape.convs[k][3], tape.convs[k][4][3]) + tuple(tape.convs[k][5]) for k in dx_layers], d.device)
-        preps = dict(zip(dx_layers, wss))
+    preps = dict(getattr(tape, "dx_preps", None) or {})                     # (made by riders of the forward's first launch)
+    todo = [k for k in dx_layers if k not in preps]
+    if len(todo) > 1:
+        wss = _C.conv_bwd_input_prep([(tape.convs[k][3], tape.convs[k][4][3]) + tuple(tape.convs[k][5]) for k in todo], d.device)
+        preps.update(zip(todo, wss))
     for k in range(n_conv - 1, -1, -1):
         kind, src, y, wmat, in_shape, (kh, kw, sh, sw) = tape.convs[k]      # src: cols matrix / input activations / frames
         gw, gb = grads[k]
