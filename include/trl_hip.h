@@ -448,6 +448,12 @@ int trl_linear_fwd_splitk_f32(const float* x, const float* w, const float* bias,
                               int M, int K, int N, int act, float* workspace, void* stream);
 int trl_linear_bwd_input_f32(const float* dy, const float* y_gate, int gate_act, const float* w,
                              float* dx, int M, int K, int N, void* stream);
+/* the same for few output tiles behind a long reduction (few rows, a wide layer: QR-DQN's 1200-wide head): the reduction over
+ * the N outputs is split over workgroup slices, partial dX in `workspace` (trl_linear_bwd_input_workspace floats; 0 = the
+ * shape does not split and the call is trl_linear_bwd_input_f32), fixed-order fold -- deterministic */
+int trl_linear_bwd_input_workspace(int M, int K, int N);
+int trl_linear_bwd_input_splitk_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
+                                    float* workspace, int M, int K, int N, void* stream);
 int trl_linear_bwd_weight_workspace(int M, int K, int N);
 int trl_linear_bwd_weight_f32(const float* dy, const float* y_gate, int gate_act, const float* x,
                               float* dw, float* db, float* workspace, int M, int K, int N,

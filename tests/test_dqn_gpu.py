@@ -565,3 +565,29 @@ def test_forward_with_reordered_weight_shadows_equals_the_gathering_kernel(B, mo
     # ... and the input-gradient kernels' weight re-orderings as riders of the same launch, against the launch of their own
     ref = _C.conv_bwd_input_prep([(w2, 16, 4, 4, 2, 2), (w, 16, 3, 3, 1, 1)], DEV)
     assert torch.equal(wss[0], ref[0]) and torch.equal(wss[1], ref[1])
+
+
+@pytest.mark.parametrize("M,K,N,act", [(512, 512, 1200, "relu"), (100, 70, 1030, "tanh"), (64, 64, 2048, "none")])
+def test_input_gradient_with_the_reduction_split_over_slices(M, K, N, act):
+    """trl_linear_bwd_input_splitk_f32 (few output tiles behind a long reduction: a wide head's input gradient) against
+    float64 and against the unsplit launch; deterministic."""
+    from torchrl_amd import _C
+    gen = torch.Generator().manual_seed(M + N)
+    dy, y, w = (torch.randn(M, N, generator=gen).to(DEV), torch.tanh(torch.randn(M, N, generator=gen)).to(DEV),
+                (torch.randn(N, K, generator=gen) / N ** 0.5).to(DEV))
+    if act == "relu":
+        y = y.clamp_min(0.0)
+    code = {"relu": _C.ACT_RELU, "tanh": _C.ACT_TANH, "none": _C.ACT_NONE}[act]
+    gate = None if act == "none" else y
+    assert _C.lib().trl_linear_bwd_input_workspace(M, K, N) > 0
+    got = _C.linear_bwd_input(dy, gate, code, w)                          # takes the split path
+    again = _C.linear_bwd_input(dy, gate, code, w)
+    assert torch.equal(got, again)
+    plain = torch.empty(M, K, device=DEV)
+    _C.check(_C.lib().trl_linear_bwd_input_f32(_C.dev_ptr(dy), _C.dev_ptr(gate, allow_none=True), code, _C.dev_ptr(w),
+                                               _C.dev_ptr(plain), M, K, N, _C.stream_ptr(DEV)), "plain")
+    d = {"relu": (y > 0).double(), "tanh": 1.0 - y.double() ** 2, "none": torch.ones_like(y).double()}[act]
+    want = (dy.double() * d) @ w.double()
+    sc = max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() < 2e-5 * sc and (plain.double() - want).abs().max().item() < 2e-5 * sc
+    assert _C.lib().trl_linear_bwd_input_workspace(4096, 256, 256) == 0    # ordinary layers do not split

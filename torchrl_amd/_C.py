@@ -267,6 +267,9 @@ SIGNATURES = {
     "trl_linear_fwd_splitk_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "trl_linear_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "trl_linear_bwd_input_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "trl_linear_bwd_input_splitk_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_linear_bwd_weight_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_linear_bwd_weight_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_linear_bwd_weight_partials_group_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -954,6 +957,14 @@ def linear_bwd_input(dy, y_gate, gate_act, w):
     M, N = int(dy.shape[0]), int(dy.shape[1])
     K = int(w.shape[1])
     dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    need = lib().trl_linear_bwd_input_workspace(M, K, N)
+    if need > 0:                                   # few output tiles behind a long reduction: split over slices + fold
+        ws = torch.empty((need,), dtype=torch.float32, device=dy.device)
+        check(lib().trl_linear_bwd_input_splitk_f32(dev_ptr(dy, name="dy"), dev_ptr(y_gate, name="y_gate", allow_none=True),
+                                                    gate_act, dev_ptr(w, name="w"), dev_ptr(dx, name="dx"),
+                                                    dev_ptr(ws, name="workspace"), M, K, N, stream_ptr(dy.device)),
+              "trl_linear_bwd_input_splitk_f32")
+        return dx
     check(lib().trl_linear_bwd_input_f32(dev_ptr(dy, name="dy"), dev_ptr(y_gate, name="y_gate", allow_none=True),
                                          gate_act, dev_ptr(w, name="w"), dev_ptr(dx, name="dx"), M, K, N,
                                          stream_ptr(dy.device)), "trl_linear_bwd_input_f32")

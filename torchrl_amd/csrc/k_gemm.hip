@@ -610,11 +610,11 @@ extern "C" int trl_fold_scope_end(void* stream) {
   return TRL_OK;
 }
 
-static int launch_fold(FoldDev f, int groups, hipStream_t s) {
+static int launch_fold(FoldDev f, int groups, hipStream_t s, bool immediate = false) {
   const int blocks = trl_ceil_div((int64_t)f.n + f.n2, FOLD_OUT);
   // many splits behind few workgroups: 16 waves share them (latency-bound walk); otherwise 4
   const int waves = (f.splits >= 32 && (int64_t)blocks * groups < 2048) ? FOLD_MAX_WAVES : 4;
-  if (g_fold_scope.on && groups == 1 && f.n_cols == 0 && g_fold_scope.d.count < FOLD_SCOPE_MAX) {
+  if (g_fold_scope.on && !immediate && groups == 1 && f.n_cols == 0 && g_fold_scope.d.count < FOLD_SCOPE_MAX) {
     const FoldGroup& q = f.grp[0];
     g_fold_scope.d.e[g_fold_scope.d.count++] = FoldScopeEntry{f.n, f.n2, f.splits, f.perm_c, f.perm_khw, waves, g_fold_scope.blocks,
                                                               q.part, q.out, q.part2, q.out2};
@@ -893,6 +893,39 @@ static int linear_bwd_input_impl(int G, const float* const* dy, const float* con
 extern "C" int trl_linear_bwd_input_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
                                         int M, int K, int N, void* stream) {
   return linear_bwd_input_impl(1, &dy, &y_gate, gate_act, &w, &dx, M, K, N, (hipStream_t)stream);
+}
+// Few output tiles behind a long reduction (a wide head's input gradient: QR-DQN's 512 x 1200 head on 512 rows is 64 tiles
+// walking 1200 outputs each -- 64 workgroups on 256 CUs, 31.8 us for 1.26 GFLOP): the reduction is split over slices like
+// the forward's (trl_linear_fwd_splitk_f32), partial dX in the workspace, fixed-order fold.
+static int bwdin_split_len(int M, int K, int N) {
+  const int tiles = trl_ceil_div(M, 64) * trl_ceil_div(K, 64);
+  if (tiles >= 128 || N < 8 * KC) return N;
+  const int target = std::min(8, trl_ceil_div(256, tiles));
+  return trl_ceil_div(trl_ceil_div(N, target), KC) * KC;
+}
+extern "C" int trl_linear_bwd_input_workspace(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  const int splits = trl_ceil_div(N, bwdin_split_len(M, K, N));
+  return splits > 1 ? splits * M * K : 0;
+}
+extern "C" int trl_linear_bwd_input_splitk_f32(const float* dy, const float* y_gate, int gate_act, const float* w, float* dx,
+                                               float* workspace, int M, int K, int N, void* stream) {
+  TRL_REQUIRE(M >= 0 && K > 0 && N > 0, "bad sizes");
+  if (M == 0) return TRL_OK;
+  const int split_len = bwdin_split_len(M, K, N), splits = trl_ceil_div(N, split_len);
+  if (splits <= 1) return linear_bwd_input_impl(1, &dy, &y_gate, gate_act, &w, &dx, M, K, N, (hipStream_t)stream);
+  TRL_REQUIRE(dy && w && dx && workspace, "null pointer");
+  GemmDev g{};
+  g.gate_act = gate_act; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldb = K; g.ldc = K; g.act = TRL_ACT_NONE; g.split_len = split_len;
+  g.groups = 1;
+  g.A = dy; g.B = w; g.C = workspace; g.a_gate = y_gate;
+  g.grp[0] = GemmGroup{dy, w, workspace, nullptr, y_gate, nullptr};
+  int rc = launch_gemm<false, false>(g, splits, (hipStream_t)stream);
+  if (rc) return rc;
+  FoldDev f{};
+  f.n = M * K; f.n2 = 0; f.splits = splits; f.n_cols = 0;
+  f.grp[0] = FoldGroup{workspace, dx, nullptr, nullptr};
+  return launch_fold(f, 1, (hipStream_t)stream, /*immediate=*/true);   // (its consumer follows: never deferred by a fold scope)
 }
 extern "C" int trl_linear_bwd_input_group_f32(int G, const float* const* dy, const float* const* y_gate, int gate_act,
                                               const float* const* w, float* const* dx, int M, int K, int N, void* stream) {
