@@ -760,7 +760,9 @@ static int bw_split_len(int M, int K, int N) {
   const int tiles = trl_ceil_div(N, 32 * wm) * trl_ceil_div(K, 32 * (4 / wm));
   // (>= 320 tiles already fill the chip: no split, and then no partials and no fold either -- the 512 x 3136 layer of the
   // conv nets wrote and folded 2 x 6.4 MB for nothing)
-  const int want = tiles >= 320 ? 1 : std::max(1, 1024 / tiles);
+  // (the 32 x 128 / 128 x 32 tiles hold 87 KB of panel buffers: ONE workgroup per CU, so the grid aims at one round of 256
+  // -- 324 workgroups were a full round plus a quarter-full one, 26 us for conv 2 of the Atari trunk)
+  const int want = tiles >= 320 ? 1 : std::max(1, (wm == 2 ? 1024 : 256) / tiles);
   const int len = trl_ceil_div(trl_ceil_div(M, want), KC) * KC;
   return std::max(256, len);
 }
