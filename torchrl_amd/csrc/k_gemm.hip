@@ -725,7 +725,14 @@ static bool short_reduction(const GemmDev& g, int splits, int gm, int gn, int co
   const int64_t wgs = (int64_t)trl_ceil_div(g.M, gm) * trl_ceil_div(g.N, gn) * std::max(1, g.groups) * splits;
   const int red = splits > 1 ? g.split_len : g.K;
   if (pin == 32) return true;
-  return wgs >= (conv ? 512 : 768) && red <= 512;
+  if (conv) {
+    // implicit forward: the 128 x 32 tile holds ONE workgroup per CU with 64-deep panels, three with 32-deep ones -- it pays
+    // as soon as the grid is more than one round of 256; the 64 x 64 tile (two per CU, four with 32-deep panels) only with
+    // pre-ordered weights (dense B loads) and more than one round of 512
+    if (gm == 128) return wgs > 256 && red <= 512;
+    return g.b_perm && wgs > 512 && wgs <= 1024 && red <= 512;
+  }
+  return wgs >= 768 && red <= 512;
 }
 
 template <bool TA, bool TB, int GATE, int CONV>
@@ -737,8 +744,9 @@ static int launch_gemm_gate(const GemmDev& g, int splits, hipStream_t s) {
     case 1:  return launch_gemm_tile<TA, TB, GATE, CONV, 1>(g, splits, s);
     default:
       if constexpr (CONV == 0) { if (tile_128(g, splits)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 2>(g, splits, s); }
-      // (the implicit forward on 64 x 64 tiles decodes its taps once per panel: with twice the panels it lost, 56.6 vs 42 us)
-      if constexpr (CONV == 0) {
+      // (the implicit forward on 64 x 64 tiles decodes its taps once per panel and, without pre-ordered weights, gathers B
+      // with strided 4-byte loads: with twice the panels that lost, 56.6 vs 42 us)
+      if constexpr (CONV == 0 || CONV == 3) {
         if (short_reduction(g, splits, 64, 64, CONV)) return launch_gemm_tile<TA, TB, GATE, CONV, 2, 1, 32>(g, splits, s);
       }
       return launch_gemm_tile<TA, TB, GATE, CONV, 2>(g, splits, s);
