@@ -114,7 +114,7 @@ __device__ __forceinline__ void conv_perm_jobs(const PermJobs& pj, int block, in
   }
   for (int k = 0; k < pj.n_dx; ++k) dx_prep_range(pj.dx_w[k], pj.dx_ws[k], pj.dx_g[k], block * n_threads + tid, n_blocks * n_threads);
 }
-#define CONV_PERM_BLOCKS 8
+#define CONV_PERM_BLOCKS 64
 
 // ---- direct kernels for a narrow first layer (k_conv1.hip); used by the trl_conv_*_u8 entry points when they apply ----
 bool trl_conv1_direct_ok(int K, int Cout, const float* w);
