@@ -760,6 +760,12 @@ int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* act
  * argmax_a of Q (Q == 1) or of the mean over Q quantiles; where u[n] < epsilon -> rand_act[n] */
 int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const float* u, const int64_t* rand_act,
                        float epsilon, int64_t* action, void* stream);
+/* the A <= 8 wide linear head of a Q network (nets.py:34-52's last nn.Linear) and the epsilon-greedy action in ONE launch:
+ * q[n][a] = h[n] . w[a] + bias[a] from the last hidden activations h (N, H), w (A, H); action as trl_eps_greedy_i64 (u /
+ * rand_act NULL: greedy); q_out (N, A) nullable.  H % 4 == 0, H <= 1024 (trl_dqn_act_supported), 16-byte aligned h, w */
+int trl_dqn_act_supported(int H, int A);
+int trl_dqn_act_f32(const float* h, const float* w, const float* bias, int N, int H, int A, const float* u,
+                    const int64_t* rand_act, float epsilon, float* q_out, int64_t* action, void* stream);
 /* synthetic Atari-shaped env: (N, C, HW) uint8 frame stacks, Philox frames (see k_dqn.hip) */
 int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base,
                              int horizon, int A, uint8_t* next_obs, float* rewards, float* dones,

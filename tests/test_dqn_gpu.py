@@ -591,3 +591,22 @@ def test_input_gradient_with_the_reduction_split_over_slices(M, K, N, act):
     sc = max(1.0, want.abs().max().item())
     assert (got.double() - want).abs().max().item() < 2e-5 * sc and (plain.double() - want).abs().max().item() < 2e-5 * sc
     assert _C.lib().trl_linear_bwd_input_workspace(4096, 256, 256) == 0    # ordinary layers do not split
+
+
+@pytest.mark.parametrize("N,H,A", [(512, 512, 6), (7, 32, 3), (130, 1024, 8), (3, 4, 1)])
+def test_head_and_action_in_one_launch_equal_the_layer_and_the_action_kernel(N, H, A):
+    """trl_dqn_act_f32: q = h W^T + b within round-off of the dense layer (another summation order), the action exactly what
+    trl_eps_greedy_i64 makes of THESE q values (greedy and mixed), deterministic."""
+    from torchrl_amd import _C
+    gen = torch.Generator().manual_seed(N + H)
+    h, w, b = torch.randn(N, H, generator=gen).to(DEV), (torch.randn(A, H, generator=gen) / H ** 0.5).to(DEV), torch.randn(A, generator=gen).to(DEV)
+    u, ra = torch.rand(N, generator=gen).to(DEV), torch.randint(0, A, (N,), generator=gen).to(DEV)
+    assert _C.dqn_act_ok(h, w)
+    q, act = _C.dqn_act(h, w, b, u, ra, 0.3)
+    q2, act2 = _C.dqn_act(h, w, b, u, ra, 0.3)
+    assert torch.equal(q, q2) and torch.equal(act, act2)
+    ref = _C.linear_fwd(h, w, b, _C.ACT_NONE)
+    assert (q - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(act, _C.eps_greedy(q, A, 1, u, ra, 0.3))
+    _, greedy = _C.dqn_act(h, w, b, None, None, 0.0, want_q=False)
+    assert torch.equal(greedy, q.max(dim=-1)[1])

@@ -231,6 +231,9 @@ SIGNATURES = {
                          [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_quantile_huber_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 +
                                [C.c_int, C.c_void_p, C.c_void_p]),
+    "trl_dqn_act_supported": (C.c_int, [C.c_int, C.c_int]),
+    "trl_dqn_act_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
@@ -1438,6 +1441,24 @@ def eps_greedy(q, A, Q, u, rand_act, epsilon):
                                    dev_ptr(rand_act, torch.int64, "rand_act", allow_none=True), float(epsilon),
                                    dev_ptr(action, torch.int64, "action"), stream_ptr(q.device)), "trl_eps_greedy_i64")
     return action
+
+
+def dqn_act_ok(h, w):
+    return (h.dim() == 2 and w.dim() == 2 and h.is_contiguous() and w.is_contiguous() and h.data_ptr() % 16 == 0
+            and w.data_ptr() % 16 == 0 and bool(lib().trl_dqn_act_supported(int(h.shape[1]), int(w.shape[0]))))
+
+
+def dqn_act(h, w, bias, u, rand_act, epsilon, want_q=True):
+    """(q (N, A) or None, action (N,) int64): the A <= 8 wide head on the last hidden activations + the epsilon-greedy
+    action, one launch (include/trl_hip.h trl_dqn_act_f32); u / rand_act None: greedy."""
+    N, H, A = int(h.shape[0]), int(h.shape[1]), int(w.shape[0])
+    q = torch.empty((N, A), dtype=torch.float32, device=h.device) if want_q else None
+    action = torch.empty(N, dtype=torch.int64, device=h.device)
+    check(lib().trl_dqn_act_f32(dev_ptr(h, name="h"), dev_ptr(w, name="w"), dev_ptr(bias, name="bias", allow_none=True), N, H, A,
+                                dev_ptr(u, name="u", allow_none=True), dev_ptr(rand_act, torch.int64, "rand_act", allow_none=True),
+                                float(epsilon), dev_ptr(q, name="q", allow_none=True), dev_ptr(action, torch.int64, "action"),
+                                stream_ptr(h.device)), "trl_dqn_act_f32")
+    return q, action
 
 
 def synth_frames_step(frames, acts, t_env, seed_base, horizon, A, next_obs, rewards, dones):

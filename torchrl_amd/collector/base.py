@@ -496,8 +496,7 @@ class VecCollector(_CollectorBase):
         st["row_stager"].upload(st["row"])
 
         def one_step(t):
-            q = pf._q(env.cur_obs)
-            act = _C.eps_greedy(q.contiguous(), A, Q, st["u"][t], st["ra"][t], 0.5)
+            act = pf.act_on(env.cur_obs, st["u"][t], st["ra"][t], 0.5, want_q=False)[1]
             _C.synth_frames_collect(env.cur_obs, act, env.t_env, env.seed_base, env.horizon, env.action_num, ring, st["row"],
                                     st["rew"], st["done"])
             _C.collector_bookkeep(st["rew"], st["done"], env.cur_step, env.ep_return, self.max_episode_frames,

@@ -508,6 +508,78 @@ extern "C" int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const flo
   return TRL_OK;
 }
 
+// K17b: the A <= 8 wide linear head of a Q network and the epsilon-greedy action in ONE launch (nets.py:34-52's last
+// nn.Linear + discrete_policies.py:40-67): q[n][a] = h[n] . w[a] + b[a], action = argmax_a q (first maximum, like torch.max),
+// replaced by rand_act[n] where u[n] < epsilon.  On 512 rows the head as a GEMM was 16 workgroups + a split-reduction fold
+// + the action launch: three dependent launches of 5-7 us for 6 dot products per row.  A wave owns a row; W sits in LDS.
+#define DQA_MAX_A 8
+__global__ __launch_bounds__(256) void dqn_act_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, int N, int H, int A,
+                                                      const float* __restrict__ u, const int64_t* __restrict__ ra, float epsilon,
+                                                      float* __restrict__ q_out, int64_t* __restrict__ action) {
+  extern __shared__ __attribute__((aligned(16))) float ws[];          // [A][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  const int H4 = H >> 2;
+  // this row's activations are requested before the weights are staged
+  f32x4 hv[4];                                                         // H <= 1024: four 16-byte pieces per lane
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k4 = lane + 64 * j;
+    hv[j] = (n < N && k4 < H4) ? reinterpret_cast<const f32x4*>(h + (size_t)n * H)[k4] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int e = threadIdx.x; e < A * H4; e += 256) reinterpret_cast<f32x4*>(ws)[e] = reinterpret_cast<const f32x4*>(w)[e];
+  __syncthreads();
+  if (n >= N) return;
+  float part[DQA_MAX_A];
+#pragma unroll
+  for (int a = 0; a < DQA_MAX_A; ++a) {
+    float s = 0.0f;
+    if (a < A) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k4 = lane + 64 * j;
+        if (k4 < H4) {
+          const f32x4 wv = reinterpret_cast<const f32x4*>(ws)[a * H4 + k4];
+          s = fmaf(hv[j][0], wv[0], s); s = fmaf(hv[j][1], wv[1], s); s = fmaf(hv[j][2], wv[2], s); s = fmaf(hv[j][3], wv[3], s);
+        }
+      }
+    }
+    part[a] = s;
+  }
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) {
+#pragma unroll
+    for (int a = 0; a < DQA_MAX_A; ++a) part[a] += __shfl_xor(part[a], sft, 64);
+  }
+  if (lane == 0) {
+    int best = 0;
+    float bv = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < DQA_MAX_A; ++a) {
+      if (a < A) {
+        const float qv = part[a] + (bias ? bias[a] : 0.0f);
+        if (q_out) q_out[(size_t)n * A + a] = qv;
+        if (qv > bv) { bv = qv; best = a; }
+      }
+    }
+    if (u && ra && u[n] < epsilon) best = (int)ra[n];
+    action[n] = best;
+  }
+}
+extern "C" int trl_dqn_act_supported(int H, int A) { return H >= 4 && (H & 3) == 0 && H <= 1024 && A >= 1 && A <= DQA_MAX_A; }
+extern "C" int trl_dqn_act_f32(const float* h, const float* w, const float* bias, int N, int H, int A, const float* u,
+                               const int64_t* rand_act, float epsilon, float* q_out, int64_t* action, void* stream) {
+  TRL_REQUIRE(N >= 0 && trl_dqn_act_supported(H, A), "dqn_act: H % 4 == 0, H <= 1024, A <= 8");
+  if (N == 0) return TRL_OK;
+  TRL_REQUIRE(h && w && action, "null pointer");
+  TRL_REQUIRE(((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(w)) & 15) == 0, "dqn_act: 16-byte aligned rows");
+  hipLaunchKernelGGL(dqn_act_kernel, dim3(trl_ceil_div(N, 4)), dim3(256), A * H * (int)sizeof(float), (hipStream_t)stream, h, w,
+                     bias, N, H, A, u, rand_act, epsilon, q_out, action);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 // ---------------------------------------------------------------- synthetic Atari-shaped env
 // Frame stacks (N, C=4, 84, 84) uint8.  A step shifts the stack by one frame and appends a new
 // pseudo-random frame: bytes [16 blk, 16 blk + 16) of the frame of env n at env-time t are the

@@ -240,9 +240,14 @@ def _dx_jobs(layers):
     return jobs
 
 
-def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5, dx_prep=False):
+def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5, dx_prep=False, head=True):
     """frames_u8: (B, C, H, W) uint8.  Returns (out (B, O), tape).  dx_prep: a backward pass will follow -- the weight
-    re-orderings of its input-gradient kernels ride on the first layer's launch (tape.dx_preps)."""
+    re-orderings of its input-gradient kernels ride on the first layer's launch (tape.dx_preps).  head=False: the pass
+    stops at the last HIDDEN activations (the caller runs the linear head itself, e.g. `_C.dqn_act`)."""
+    fcs = fc_layers(net)
+    run_fc = (lambda feat: mlp_forward(fcs, feat, act)) if head else (lambda feat: mlp_forward(fcs[:-1], feat, act, last_act=act))
+    if not head and len(fcs) < 2:
+        raise _C.TrlError("cnn_forward(head=False) needs a hidden FC layer in front of the head")
     if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
         raise _C.TrlError("cnn_forward expects (B, C, H, W) uint8 frame stacks")
     act = cnn_act_code(net)
@@ -276,7 +281,7 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5, dx_prep=False):
             t.convs.append(("nhwc", x, y, wmat, in_shape, (kh, kw, sh, sw)))
             if t.feat_chw:
                 t.feat_shape = (Ho * Wo, int(wmat.shape[0]))
-                out, t.fc = mlp_forward(fc_layers(net), y, act)
+                out, t.fc = run_fc(y)
                 return out, t
             x = y.view(B, Ho, Wo, int(wmat.shape[0]))
             continue
@@ -293,7 +298,7 @@ def cnn_forward(net, frames_u8, scale=1.0 / 255.0, shift=-0.5, dx_prep=False):
     B, Ho, Wo, Cc = (int(v) for v in x.shape)
     t.feat_shape = (Ho * Wo, Cc)
     feat = _C.transpose_bpc(x, B, Ho * Wo, Cc).view(B, Cc * Ho * Wo)       # PyTorch's NCHW flatten order
-    out, t.fc = mlp_forward(fc_layers(net), feat, act)
+    out, t.fc = run_fc(feat)
     return out, t
 
 

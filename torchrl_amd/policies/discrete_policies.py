@@ -35,6 +35,22 @@ class EpsilonGreedyDQNDiscretePolicy:
     def q_to_a(self, q):
         return _C.eps_greedy(q.contiguous(), self.action_shape, self.quantile_num, None, None, 0.0).unsqueeze(-1)
 
+    def act_on(self, x, u=None, rand_act=None, epsilon=0.0, want_q=True):
+        """(q or None, action (N,) int64) for a batch of observations: greedy (u None) or mixed with the given draws.  Conv
+        nets with a hidden FC layer and an A <= 8 wide head (Q = 1) run the head and the action as ONE launch on the last
+        hidden activations (trl_dqn_act_f32); everything else is Q network -> trl_eps_greedy_i64."""
+        A = int(self.action_shape)
+        if x.dtype == torch.uint8 and self.quantile_num == 1 and A <= 8:
+            fcs = ops.fc_layers(self.qf)
+            if len(fcs) >= 2 and fcs[-1][0].shape[0] == A:
+                with torch.no_grad():
+                    h, _ = ops.cnn_forward(self.qf, x, head=False)
+                w, b = fcs[-1]
+                if _C.dqn_act_ok(h, w):
+                    return _C.dqn_act(h, w, b, u, rand_act, epsilon, want_q=want_q)
+        q = self._q(x)
+        return q, _C.eps_greedy(q.contiguous(), A, self.quantile_num, u, rand_act, epsilon)
+
     def explore(self, x):
         self.count += 1
         if x.dim() in (3, 5) and x.shape[0] == 1:                    # the collector's unsqueeze(0) (base.py:185-186)
@@ -43,20 +59,18 @@ class EpsilonGreedyDQNDiscretePolicy:
             self.epsilon = self.start_epsilon - (self.start_epsilon - self.end_epsilon) * (self.count / self.decay_frames)
         else:
             self.epsilon = self.end_epsilon
-        output = self._q(x)
-        n = int(output.shape[0])
+        n = int(x.shape[0])
         from .. import dist
         w, r = dist.world_size(), dist.rank()                       # env shards on several ranks: this rank's rows of the
         u = np.random.rand(n * w, 1)[r * n:(r + 1) * n]             # host draws for ALL envs (identical numpy streams)
         ra = np.random.randint(low=0, high=self.action_shape, size=(n * w, 1))[r * n:(r + 1) * n]
-        u = torch.from_numpy(u.astype(np.float32)).to(output.device)
-        ra = torch.from_numpy(ra.astype(np.int64)).to(output.device)
-        action = _C.eps_greedy(output.contiguous(), self.action_shape, self.quantile_num, u.reshape(-1).contiguous(),
-                               ra.reshape(-1).contiguous(), self.epsilon).unsqueeze(-1)
-        return {"q_value": output, "action": action}
+        u = torch.from_numpy(u.astype(np.float32)).to(x.device)
+        ra = torch.from_numpy(ra.astype(np.int64)).to(x.device)
+        output, action = self.act_on(x, u.reshape(-1).contiguous(), ra.reshape(-1).contiguous(), self.epsilon)
+        return {"q_value": output, "action": action.unsqueeze(-1)}
 
     def eval_act(self, x):
-        return self.q_to_a(self._q(x)).cpu().numpy()
+        return self.act_on(x, want_q=False)[1].unsqueeze(-1).cpu().numpy()
 
     def to(self, device):
         self.qf.to(device)
