@@ -765,7 +765,9 @@ int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const float* u, cons
  * rand_act NULL: greedy); q_out (N, A) nullable.  H % 4 == 0, H <= 1024 (trl_dqn_act_supported), 16-byte aligned h, w */
 int trl_dqn_act_supported(int H, int A);
 int trl_dqn_act_f32(const float* h, const float* w, const float* bias, int N, int H, int A, const float* u,
-                    const int64_t* rand_act, float epsilon, float* q_out, int64_t* action, void* stream);
+                    const int64_t* rand_act, float epsilon, float* q_out, int64_t* action, int64_t* ring_row, int n_rows,
+                    void* stream);     /* ring_row (nullable): ring_row[0] = (ring_row[0] + 1) % n_rows rides along, see
+                                          trl_synth_frames_collect_u8 */
 /* synthetic Atari-shaped env: (N, C, HW) uint8 frame stacks, Philox frames (see k_dqn.hip) */
 int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base,
                              int horizon, int A, uint8_t* next_obs, float* rewards, float* dones,
@@ -778,7 +780,12 @@ int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, int32_t* t_en
 int trl_synth_frames_collect_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base, int horizon,
                                 int A, uint8_t* ring_obs, uint8_t* ring_next_obs, float* ring_acts, float* ring_rewards,
                                 float* ring_terminals, float* ring_time_limits, int64_t* ring_row, int n_rows,
-                                float* step_rewards, float* step_dones, int N, int C, int HW, void* stream);
+                                float* step_rewards, float* step_dones, int32_t* cur_step, float* ep_return, int max_frames,
+                                uint8_t* mask, double* epoch_reward, int32_t* ep_count, float* ep_log, int ep_cap, int step,
+                                int N, int C, int HW, void* stream);
+/* cur_step (nullable) .. step: trl_collector_bookkeep_f32's arguments -- the collector's bookkeeping of the step (collector/
+ * base.py:199-228) and the reset of the envs that ended (their own stacks, vecenv.py:47-51) happen in the same launch;
+ * the ring row is then advanced by the NEXT step's action launch (trl_dqn_act_f32) or by trl_synth_frames_reset_u8 */
 /* ring_row (nullable): ring_row[0] = (ring_row[0] + 1) % n_rows rides along */
 int trl_synth_frames_reset_u8(uint8_t* frames, int32_t* t_env, int64_t env_seed_base,
                               const uint8_t* mask, int64_t* ring_row, int n_rows, int N, int C, int HW, void* stream);

@@ -233,12 +233,13 @@ SIGNATURES = {
                                [C.c_int, C.c_void_p, C.c_void_p]),
     "trl_dqn_act_supported": (C.c_int, [C.c_int, C.c_int]),
     "trl_dqn_act_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
-                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "trl_synth_frames_collect_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] +
-                                    [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
+                                    [C.c_void_p] * 2 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.c_void_p, C.c_int, C.c_int] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_mt19937_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "trl_mt19937_states_at": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -1448,7 +1449,7 @@ def dqn_act_ok(h, w):
             and w.data_ptr() % 16 == 0 and bool(lib().trl_dqn_act_supported(int(h.shape[1]), int(w.shape[0]))))
 
 
-def dqn_act(h, w, bias, u, rand_act, epsilon, want_q=True):
+def dqn_act(h, w, bias, u, rand_act, epsilon, want_q=True, ring_row=None, n_rows=0):
     """(q (N, A) or None, action (N,) int64): the A <= 8 wide head on the last hidden activations + the epsilon-greedy
     action, one launch (include/trl_hip.h trl_dqn_act_f32); u / rand_act None: greedy."""
     N, H, A = int(h.shape[0]), int(h.shape[1]), int(w.shape[0])
@@ -1457,6 +1458,7 @@ def dqn_act(h, w, bias, u, rand_act, epsilon, want_q=True):
     check(lib().trl_dqn_act_f32(dev_ptr(h, name="h"), dev_ptr(w, name="w"), dev_ptr(bias, name="bias", allow_none=True), N, H, A,
                                 dev_ptr(u, name="u", allow_none=True), dev_ptr(rand_act, torch.int64, "rand_act", allow_none=True),
                                 float(epsilon), dev_ptr(q, name="q", allow_none=True), dev_ptr(action, torch.int64, "action"),
+                                dev_ptr(ring_row, torch.int64, "ring_row", allow_none=True), int(n_rows),
                                 stream_ptr(h.device)), "trl_dqn_act_f32")
     return q, action
 
@@ -1478,21 +1480,29 @@ def synth_frames_reset(frames, t_env, seed_base, mask, ring_row=None, n_rows=0):
                                           stream_ptr(frames.device)), "trl_synth_frames_reset_u8")
 
 
-def synth_frames_collect(frames, acts, t_env, seed_base, horizon, A, ring, ring_row, step_rewards, step_dones):
+def synth_frames_collect(frames, acts, t_env, seed_base, horizon, A, ring, ring_row, step_rewards, step_dones, book=None):
     """ring = (obs, next_obs, acts, rewards, terminals, time_limits) ring TENSORS (rows, N, ...): the step files its
-    transition into row ring_row[0] (device int64)."""
+    transition into row ring_row[0] (device int64).  book = (cur_step, ep_return, max_frames, mask, epoch_reward, ep_count,
+    ep_log, step): collector_bookkeep's arguments -- bookkeeping and the reset of the envs that ended in the same launch."""
     N, Cc, HW = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2]) * int(frames.shape[3])
     r_obs, r_next, r_acts, r_rew, r_done, r_tl = ring
     rows = int(r_obs.shape[0])
     for t in ring:
         if int(t.shape[0]) != rows or int(t.shape[1]) != N or not t.is_contiguous():
             raise TrlError("synth_frames_collect: ring tensors must be contiguous (rows, N, ...)")
+    if book is not None:
+        cur_step, ep_return, max_frames, mask, epoch_reward, ep_count, ep_log, step = book
+        bk = [dev_ptr(cur_step, torch.int32, "cur_step"), dev_ptr(ep_return, name="ep_return"), int(max_frames),
+              dev_ptr(mask, torch.uint8, "mask"), dev_ptr(epoch_reward, torch.float64, "epoch_reward", allow_none=True),
+              dev_ptr(ep_count, torch.int32, "ep_count"), dev_ptr(ep_log, name="ep_log"), int(ep_log.shape[0]), int(step)]
+    else:
+        bk = [None, None, 0, None, None, None, None, 0, 0]
     check(lib().trl_synth_frames_collect_u8(
         dev_ptr(frames, torch.uint8, "frames"), dev_ptr(acts, torch.int64, "acts"), dev_ptr(t_env, torch.int32, "t_env"),
         int(seed_base), int(horizon), int(A), dev_ptr(r_obs, torch.uint8, "ring obs"), dev_ptr(r_next, torch.uint8, "ring next_obs"),
         dev_ptr(r_acts, name="ring acts"), dev_ptr(r_rew, name="ring rewards"), dev_ptr(r_done, name="ring terminals"),
         dev_ptr(r_tl, name="ring time_limits"), dev_ptr(ring_row, torch.int64, "ring_row"), rows,
-        dev_ptr(step_rewards, name="step_rewards"), dev_ptr(step_dones, name="step_dones"), N, Cc, HW,
+        dev_ptr(step_rewards, name="step_rewards"), dev_ptr(step_dones, name="step_dones"), *bk, N, Cc, HW,
         stream_ptr(frames.device)), "trl_synth_frames_collect_u8")
 
 

@@ -516,8 +516,12 @@ extern "C" int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const flo
 __global__ __launch_bounds__(256) void dqn_act_kernel(const float* __restrict__ h, const float* __restrict__ w,
                                                       const float* __restrict__ bias, int N, int H, int A,
                                                       const float* __restrict__ u, const int64_t* __restrict__ ra, float epsilon,
-                                                      float* __restrict__ q_out, int64_t* __restrict__ action) {
+                                                      float* __restrict__ q_out, int64_t* __restrict__ action,
+                                                      int64_t* __restrict__ ring_row, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) float ws[];          // [A][H]
+  // (a captured sequence of vector steps: the replay ring's row advances here, between the frame step that filed row r
+  // -- finished, stream order -- and the one that will file row r + 1; nobody of this launch reads it)
+  if (ring_row && blockIdx.x == 0 && threadIdx.x == 0) ring_row[0] = (ring_row[0] + 1) % n_rows;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave;
   const int H4 = H >> 2;
@@ -569,13 +573,14 @@ __global__ __launch_bounds__(256) void dqn_act_kernel(const float* __restrict__ 
 }
 extern "C" int trl_dqn_act_supported(int H, int A) { return H >= 4 && (H & 3) == 0 && H <= 1024 && A >= 1 && A <= DQA_MAX_A; }
 extern "C" int trl_dqn_act_f32(const float* h, const float* w, const float* bias, int N, int H, int A, const float* u,
-                               const int64_t* rand_act, float epsilon, float* q_out, int64_t* action, void* stream) {
+                               const int64_t* rand_act, float epsilon, float* q_out, int64_t* action, int64_t* ring_row,
+                               int n_rows, void* stream) {
   TRL_REQUIRE(N >= 0 && trl_dqn_act_supported(H, A), "dqn_act: H % 4 == 0, H <= 1024, A <= 8");
   if (N == 0) return TRL_OK;
-  TRL_REQUIRE(h && w && action, "null pointer");
+  TRL_REQUIRE(h && w && action && (!ring_row || n_rows > 0), "null pointer / ring row without a row count");
   TRL_REQUIRE(((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(w)) & 15) == 0, "dqn_act: 16-byte aligned rows");
   hipLaunchKernelGGL(dqn_act_kernel, dim3(trl_ceil_div(N, 4)), dim3(256), A * H * (int)sizeof(float), (hipStream_t)stream, h, w,
-                     bias, N, H, A, u, rand_act, epsilon, q_out, action);
+                     bias, N, H, A, u, rand_act, epsilon, q_out, action, ring_row, n_rows);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -600,7 +605,11 @@ __device__ __forceinline__ void synth_frame_fill(uint8_t* dst, int t, int64_t en
 // pre-step stacks (obs), the stacks it produces (next_obs), the actions as floats, rewards, terminals and time limits --
 // so a captured sequence of vector steps walks the ring on its own (the row lives on the device; the reset call that ends
 // a step advances it) and nothing is copied afterwards.
-struct FrameRing { uint8_t* obs; uint8_t* next; float* acts; float* rew; float* done; float* tl; int64_t* dyn; int n_rows; };
+struct FrameRing { uint8_t* obs; uint8_t* next; float* acts; float* rew; float* done; float* tl; int64_t* dyn; int n_rows;
+                   // the collector's bookkeeping and the masked reset of the same vector step (cur_step != NULL): one launch
+                   // instead of three (trl_collector_bookkeep_f32's arithmetic per env; an env that ends resets its own stack)
+                   int32_t* cur_step; float* ep_return; int max_frames; uint8_t* mask; double* epoch_reward; int32_t* ep_count;
+                   float* ep_log; int ep_cap, step; };
 __global__ __launch_bounds__(DQ_THREADS) void synth_frames_kernel(uint8_t* __restrict__ frames, const int64_t* __restrict__ act,
                                                                   int32_t* __restrict__ t_env, int64_t seed_base, int horizon,
                                                                   int A, uint8_t* __restrict__ next_out,
@@ -653,6 +662,31 @@ __global__ __launch_bounds__(DQ_THREADS) void synth_frames_kernel(uint8_t* __res
     done[n] = dn;
     if (r.obs) { r.acts[cell] = (float)act[n]; r.rew[cell] = rw; r.done[cell] = dn; r.tl[cell] = dn; }   // synthetic env: time_limit == done
   }
+  if (r.cur_step) {
+    __shared__ int s_flag;
+    if (threadIdx.x == 0) {
+      const float rw = rew[n];
+      const bool d = done[n] != 0.0f;
+      const int cs = r.cur_step[n] + 1;
+      float er = r.ep_return[n] + rw;
+      if (d) {
+        const int slot = atomicAdd(r.ep_count, 1);
+        if (slot < r.ep_cap) { r.ep_log[slot * 3 + 0] = (float)r.step; r.ep_log[slot * 3 + 1] = (float)n; r.ep_log[slot * 3 + 2] = er; }
+        er = 0.0f;
+      }
+      const bool flag = d || cs >= r.max_frames;
+      r.cur_step[n] = flag ? 0 : cs;
+      r.ep_return[n] = er;
+      r.mask[n] = flag ? 1 : 0;
+      if (r.epoch_reward && rw != 0.0f) atomicAdd(r.epoch_reward, (double)rw);   // (a zero changes nothing; no return value awaited)
+      s_flag = flag ? 1 : 0;
+    }
+    __syncthreads();                               // (also: the ring copy of the post-step stack has been read from f)
+    if (s_flag) {
+      for (int c = 0; c < C; ++c) synth_frame_fill(f + (size_t)c * HW, c - (C - 1), env_seed, HW);
+      if (threadIdx.x == 0) t_env[n] = 0;
+    }
+  }
 }
 extern "C" int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base,
                                         int horizon, int A, uint8_t* next_obs, float* rewards, float* dones, int N, int C,
@@ -668,14 +702,18 @@ extern "C" int trl_synth_frames_step_u8(uint8_t* frames, const int64_t* acts, in
 extern "C" int trl_synth_frames_collect_u8(uint8_t* frames, const int64_t* acts, int32_t* t_env, int64_t env_seed_base,
                                            int horizon, int A, uint8_t* ring_obs, uint8_t* ring_next_obs, float* ring_acts,
                                            float* ring_rewards, float* ring_terminals, float* ring_time_limits,
-                                           int64_t* ring_row, int n_rows, float* step_rewards, float* step_dones, int N, int C,
-                                           int HW, void* stream) {
+                                           int64_t* ring_row, int n_rows, float* step_rewards, float* step_dones,
+                                           int32_t* cur_step, float* ep_return, int max_frames, uint8_t* mask,
+                                           double* epoch_reward, int32_t* ep_count, float* ep_log, int ep_cap, int step,
+                                           int N, int C, int HW, void* stream) {
   TRL_REQUIRE(N >= 0 && C > 0 && HW > 0 && HW % 16 == 0 && A > 0 && n_rows > 0, "bad sizes (HW must be a multiple of 16)");
   if (N == 0) return TRL_OK;
   TRL_REQUIRE(frames && t_env && acts && step_rewards && step_dones, "null pointer");
   TRL_REQUIRE(ring_obs && ring_next_obs && ring_acts && ring_rewards && ring_terminals && ring_time_limits && ring_row,
               "null ring pointer");
-  FrameRing r{ring_obs, ring_next_obs, ring_acts, ring_rewards, ring_terminals, ring_time_limits, ring_row, n_rows};
+  TRL_REQUIRE(!cur_step || (ep_return && mask && ep_count && ep_log && ep_cap > 0), "bookkeeping: null pointer");
+  FrameRing r{ring_obs, ring_next_obs, ring_acts, ring_rewards, ring_terminals, ring_time_limits, ring_row, n_rows,
+              cur_step, ep_return, max_frames, mask, epoch_reward, ep_count, ep_log, ep_cap, step};
   hipLaunchKernelGGL(synth_frames_kernel, dim3(N), dim3(DQ_THREADS), 0, (hipStream_t)stream, frames, acts, t_env,
                      env_seed_base, horizon, A, (uint8_t*)nullptr, step_rewards, step_dones, (const uint8_t*)nullptr, 0, N, C,
                      HW, r);

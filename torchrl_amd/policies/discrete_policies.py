@@ -35,19 +35,29 @@ class EpsilonGreedyDQNDiscretePolicy:
     def q_to_a(self, q):
         return _C.eps_greedy(q.contiguous(), self.action_shape, self.quantile_num, None, None, 0.0).unsqueeze(-1)
 
-    def act_on(self, x, u=None, rand_act=None, epsilon=0.0, want_q=True):
+    def one_launch_act(self):
+        """Conv nets with a hidden FC layer in front of an A <= 8 wide head (Q = 1): head and action are ONE launch."""
+        A = int(self.action_shape)
+        if self.quantile_num != 1 or A > 8 or not hasattr(self.qf, "base") or not hasattr(self.qf.base, "seq_convs"):
+            return False
+        fcs = ops.fc_layers(self.qf)
+        return len(fcs) >= 2 and int(fcs[-1][0].shape[0]) == A and \
+            bool(_C.lib().trl_dqn_act_supported(int(fcs[-1][0].shape[1]), A)) and fcs[-1][0].data_ptr() % 16 == 0
+
+    def act_on(self, x, u=None, rand_act=None, epsilon=0.0, want_q=True, ring_row=None, n_rows=0):
         """(q or None, action (N,) int64) for a batch of observations: greedy (u None) or mixed with the given draws.  Conv
         nets with a hidden FC layer and an A <= 8 wide head (Q = 1) run the head and the action as ONE launch on the last
-        hidden activations (trl_dqn_act_f32); everything else is Q network -> trl_eps_greedy_i64."""
+        hidden activations (trl_dqn_act_f32; `ring_row`: the collector's device-resident replay row advances in that launch,
+        only valid when `one_launch_act()`); everything else is Q network -> trl_eps_greedy_i64."""
         A = int(self.action_shape)
-        if x.dtype == torch.uint8 and self.quantile_num == 1 and A <= 8:
-            fcs = ops.fc_layers(self.qf)
-            if len(fcs) >= 2 and fcs[-1][0].shape[0] == A:
-                with torch.no_grad():
-                    h, _ = ops.cnn_forward(self.qf, x, head=False)
-                w, b = fcs[-1]
-                if _C.dqn_act_ok(h, w):
-                    return _C.dqn_act(h, w, b, u, rand_act, epsilon, want_q=want_q)
+        if x.dtype == torch.uint8 and self.one_launch_act():
+            with torch.no_grad():
+                h, _ = ops.cnn_forward(self.qf, x, head=False)
+            w, b = ops.fc_layers(self.qf)[-1]
+            if _C.dqn_act_ok(h, w):
+                return _C.dqn_act(h, w, b, u, rand_act, epsilon, want_q=want_q, ring_row=ring_row, n_rows=n_rows)
+        if ring_row is not None:
+            raise _C.TrlError("act_on: the ring row rides on the one-launch head only")
         q = self._q(x)
         return q, _C.eps_greedy(q.contiguous(), A, self.quantile_num, u, rand_act, epsilon)
 
