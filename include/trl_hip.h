@@ -759,7 +759,8 @@ int trl_quantile_huber_f32(const float* q, const int64_t* acts, const float* act
 /* --- K17: greedy / epsilon-greedy action (torchrl/policies/discrete_policies.py:40-67, 86-89):
  * argmax_a of Q (Q == 1) or of the mean over Q quantiles; where u[n] < epsilon -> rand_act[n] */
 int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const float* u, const int64_t* rand_act,
-                       float epsilon, int64_t* action, void* stream);
+                       float epsilon, int64_t* action, int64_t* ring_row, int n_rows, void* stream);
+/* (ring_row, nullable: ring_row[0] = (ring_row[0] + 1) % n_rows rides along -- trl_synth_frames_collect_u8) */
 /* the A <= 8 wide linear head of a Q network (nets.py:34-52's last nn.Linear) and the epsilon-greedy action in ONE launch:
  * q[n][a] = h[n] . w[a] + bias[a] from the last hidden activations h (N, H), w (A, H); action as trl_eps_greedy_i64 (u /
  * rand_act NULL: greedy); q_out (N, A) nullable.  H % 4 == 0, H <= 1024 (trl_dqn_act_supported), 16-byte aligned h, w */

@@ -234,7 +234,8 @@ SIGNATURES = {
     "trl_dqn_act_supported": (C.c_int, [C.c_int, C.c_int]),
     "trl_dqn_act_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "trl_eps_greedy_i64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_void_p]),
     "trl_synth_frames_step_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "trl_synth_frames_reset_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "trl_synth_frames_collect_u8": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] +
@@ -1435,12 +1436,14 @@ def quantile_huber(q, acts, q_next, rew, term, gamma, A, Q, sums, ring=None):
     return dq
 
 
-def eps_greedy(q, A, Q, u, rand_act, epsilon):
+def eps_greedy(q, A, Q, u, rand_act, epsilon, ring_row=None, n_rows=0):
     N = int(q.shape[0])
     action = torch.empty(N, dtype=torch.int64, device=q.device)
     check(lib().trl_eps_greedy_i64(dev_ptr(q, name="q"), N, A, Q, dev_ptr(u, name="u", allow_none=True),
                                    dev_ptr(rand_act, torch.int64, "rand_act", allow_none=True), float(epsilon),
-                                   dev_ptr(action, torch.int64, "action"), stream_ptr(q.device)), "trl_eps_greedy_i64")
+                                   dev_ptr(action, torch.int64, "action"),
+                                   dev_ptr(ring_row, torch.int64, "ring_row", allow_none=True), int(n_rows),
+                                   stream_ptr(q.device)), "trl_eps_greedy_i64")
     return action
 
 

@@ -495,25 +495,16 @@ class VecCollector(_CollectorBase):
         st["row_stager"].stage()[0] = buf._top                            # (the host may be epochs ahead of the device)
         st["row_stager"].upload(st["row"])
 
-        fused = pf.one_launch_act() and env.cur_obs.dtype == torch.uint8
-
         def one_step(t):
-            if fused:
-                # two launches behind the conv net: head + action (advancing the ring row from the second step on), then
-                # frame step + filing of the transition + the collector's bookkeeping + the reset of the envs that ended
-                act = pf.act_on(env.cur_obs, st["u"][t], st["ra"][t], 0.5, want_q=False,
-                                ring_row=st["row"] if t > 0 else None, n_rows=rows)[1]
-                _C.synth_frames_collect(env.cur_obs, act, env.t_env, env.seed_base, env.horizon, env.action_num, ring, st["row"],
-                                        st["rew"], st["done"],
-                                        book=(env.cur_step, env.ep_return, self.max_episode_frames, self._mask,
-                                              self._epoch_reward, self._ep_count, self._ep_log, t))
-                return
-            act = pf.act_on(env.cur_obs, st["u"][t], st["ra"][t], 0.5, want_q=False)[1]
+            # behind the Q network: the action launch (head + epsilon-greedy for narrow heads, trl_dqn_act_f32; it advances
+            # the ring row from the second step on), then ONE launch for the frame step, the filing of the transition, the
+            # collector's bookkeeping and the reset of the envs that ended
+            act = pf.act_on(env.cur_obs, st["u"][t], st["ra"][t], 0.5, want_q=False,
+                            ring_row=st["row"] if t > 0 else None, n_rows=rows)[1]
             _C.synth_frames_collect(env.cur_obs, act, env.t_env, env.seed_base, env.horizon, env.action_num, ring, st["row"],
-                                    st["rew"], st["done"])
-            _C.collector_bookkeep(st["rew"], st["done"], env.cur_step, env.ep_return, self.max_episode_frames,
-                                  self._mask, self._epoch_reward, self._ep_count, self._ep_log, t)
-            _C.synth_frames_reset(env.cur_obs, env.t_env, env.seed_base, self._mask, ring_row=st["row"], n_rows=rows)
+                                    st["rew"], st["done"],
+                                    book=(env.cur_step, env.ep_return, self.max_episode_frames, self._mask,
+                                          self._epoch_reward, self._ep_count, self._ep_log, t))
 
         if self.global_step != self._log_step0:
             raise _C.TrlError("frame rollout replay: the episode log was not cleared for this rollout")

@@ -468,7 +468,10 @@ extern "C" int trl_dqn_head_f32(const float* h, const float* h_next, const float
 // parity mode).  u / rand_act may be NULL (greedy).
 __global__ __launch_bounds__(DQ_THREADS) void eps_greedy_kernel(const float* __restrict__ q, int N, int A, int Q,
                                                                 const float* __restrict__ u, const int64_t* __restrict__ ra,
-                                                                float epsilon, int64_t* __restrict__ action) {
+                                                                float epsilon, int64_t* __restrict__ action,
+                                                                int64_t* __restrict__ ring_row, int n_rows) {
+  // (a captured sequence of vector steps: the replay ring's row advances here, see dqn_act_kernel)
+  if (ring_row && blockIdx.x == 0 && threadIdx.x == 0) ring_row[0] = (ring_row[0] + 1) % n_rows;
   // Q == 1: a thread per env.  Quantile nets: a wave per env, lanes stride over the quantiles of an action
   // (coalesced reads of the A * Q row; a thread per env walked it with a stride of A * Q floats).
   int best = 0;
@@ -498,12 +501,12 @@ __global__ __launch_bounds__(DQ_THREADS) void eps_greedy_kernel(const float* __r
   action[n] = best;
 }
 extern "C" int trl_eps_greedy_i64(const float* q, int N, int A, int Q, const float* u, const int64_t* rand_act,
-                                  float epsilon, int64_t* action, void* stream) {
-  TRL_REQUIRE(N >= 0 && A > 0 && Q > 0, "bad sizes");
+                                  float epsilon, int64_t* action, int64_t* ring_row, int n_rows, void* stream) {
+  TRL_REQUIRE(N >= 0 && A > 0 && Q > 0 && (!ring_row || n_rows > 0), "bad sizes");
   if (N == 0) return TRL_OK;
   TRL_REQUIRE(q && action, "null pointer");
   hipLaunchKernelGGL(eps_greedy_kernel, dim3(trl_ceil_div(N, Q == 1 ? DQ_THREADS : DQ_THREADS / 64)), dim3(DQ_THREADS), 0, (hipStream_t)stream, q,
-                     N, A, Q, u, rand_act, epsilon, action);
+                     N, A, Q, u, rand_act, epsilon, action, ring_row, n_rows);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }

@@ -47,8 +47,8 @@ class EpsilonGreedyDQNDiscretePolicy:
     def act_on(self, x, u=None, rand_act=None, epsilon=0.0, want_q=True, ring_row=None, n_rows=0):
         """(q or None, action (N,) int64) for a batch of observations: greedy (u None) or mixed with the given draws.  Conv
         nets with a hidden FC layer and an A <= 8 wide head (Q = 1) run the head and the action as ONE launch on the last
-        hidden activations (trl_dqn_act_f32; `ring_row`: the collector's device-resident replay row advances in that launch,
-        only valid when `one_launch_act()`); everything else is Q network -> trl_eps_greedy_i64."""
+        hidden activations (trl_dqn_act_f32); everything else is Q network -> trl_eps_greedy_i64.  `ring_row`: the collector's
+        device-resident replay row advances in the action launch."""
         A = int(self.action_shape)
         if x.dtype == torch.uint8 and self.one_launch_act():
             with torch.no_grad():
@@ -56,10 +56,8 @@ class EpsilonGreedyDQNDiscretePolicy:
             w, b = ops.fc_layers(self.qf)[-1]
             if _C.dqn_act_ok(h, w):
                 return _C.dqn_act(h, w, b, u, rand_act, epsilon, want_q=want_q, ring_row=ring_row, n_rows=n_rows)
-        if ring_row is not None:
-            raise _C.TrlError("act_on: the ring row rides on the one-launch head only")
         q = self._q(x)
-        return q, _C.eps_greedy(q.contiguous(), A, self.quantile_num, u, rand_act, epsilon)
+        return q, _C.eps_greedy(q.contiguous(), A, self.quantile_num, u, rand_act, epsilon, ring_row=ring_row, n_rows=n_rows)
 
     def explore(self, x):
         self.count += 1
