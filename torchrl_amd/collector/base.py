@@ -261,7 +261,7 @@ class VecCollector(_CollectorBase):
         if hasattr(pf, "norm_std_explore") or type(pf).__name__ == "DetContPolicy":
             # deterministic policies (continuous_policy.py:28-74): [tanh](mlp(obs)) (+ N(0, norm_std_explore))
             last = _C.ACT_TANH if pf.tanh_action else _C.ACT_NONE
-            act, _ = ops.mlp_forward(ops.linear_layers(pf), ob, ops.act_code(pf), last_act=last)
+            act, _ = ops.mlp_forward(ops.linear_layers(pf), ob, ops.act_code(pf), last_act=last, keep=False)
             sigma = float(getattr(pf, "norm_std_explore", 0.0))
             if deterministic or not sigma:
                 return act
@@ -270,7 +270,7 @@ class VecCollector(_CollectorBase):
             raise _C.TrlError("VecCollector's kernel path expects a GuassianContPolicy (mean | log_std head); "
                               "state-independent-std policies use VecOnPolicyCollector")
         n, a_dim = env.env_nums, env.act_dim
-        head, _ = ops.mlp_forward(ops.linear_layers(pf), ob, ops.act_code(pf))
+        head, _ = ops.mlp_forward(ops.linear_layers(pf), ob, ops.act_code(pf), keep=False)
         eps = torch.zeros(n, a_dim, device=env.device) if deterministic else self._explore_noise(env)
         act, _ = _C.rsample_fwd(head, eps, bool(pf.tanh_action))
         return act
@@ -331,7 +331,7 @@ class VecCollector(_CollectorBase):
         from .. import ops
         buf, pf = self.replay_buffer, self.pf
         n, d, a_dim = env.env_nums, env.obs_dim, env.act_dim
-        head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf))
+        head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf), keep=False)
         noise = None
         if deterministic:
             if getattr(self, "_zero_eps", None) is None or self._zero_eps.shape[0] != n:
@@ -426,7 +426,7 @@ class VecCollector(_CollectorBase):
                                                    bool(pf.tanh_action), int(env.horizon), n_steps)
 
         def one_step():
-            head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf))
+            head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf), keep=False)
             _C.synth_collect_step_dyn(env, head, env.cur_step, env.ep_return, self.max_episode_frames, ring, self._dyn,
                                       self._mask, self._epoch_reward, self._ep_count, self._ep_log, bool(pf.tanh_action),
                                       self._noise_seed, 0)

@@ -34,12 +34,13 @@ class Tape:
     __slots__ = ("x", "outs", "layers", "act", "last_act")
 
 
-def mlp_forward(layers, x, act, last_act=None):
+def mlp_forward(layers, x, act, last_act=None, keep=True):
     """layers: [(W, b), ...] (nn.Linear layout); returns (out, tape).  `last_act` (an ACT_* code) is applied to
-    the head output inside the last layer's epilogue (deterministic policies: tanh(mlp(x)))."""
+    the head output inside the last layer's epilogue (deterministic policies: tanh(mlp(x))).  keep=False: no backward pass
+    will follow (acting): the fused three-layer launch then leaves its hidden activations on chip."""
     if len(layers) == 3 and all(b is not None for _, b in layers[:2]) and \
             _C.mlp3_forward_ok(layers[0][0].shape[1], layers[0][0].shape[0], layers[1][0].shape[0], layers[2][0].shape[0]):
-        outs, tapes = mlp_forward_group([layers], [x], act, last_act=last_act)      # one fused launch
+        outs, tapes = mlp_forward_group([layers], [x], act, last_act=last_act, keep=[bool(keep)])      # one fused launch
         return outs[0], tapes[0]
     t = Tape()
     t.x, t.layers, t.act, t.outs = x, layers, act, []
