@@ -774,7 +774,7 @@ def main():
                        else ("by all-reduce calls (%s)" % transport if dist.collectives_active() else "not needed (one rank)"))},
         "roofline": {"bound": "mfma", "kernel": "ppo_grad_wave_kernel<17,64,6,tanh>", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                     "traffic": pmc_traffic(), "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
+                     "traffic": pmc_traffic()[0], "traffic_stamp": pmc_traffic()[1], "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
                      "whole_iteration_frac": FLOP_PER_ENV_STEP * env_steps / elapsed / world / 1e12 / MFMA_F32_PEAK_TFLOPS,
                      "launches_timed": len(grad_ms),
                      "timed_in": ("follow-up pass of %d iterations (the timed region replays a HIP graph)" % PROBE_STEPS)
@@ -820,16 +820,45 @@ def _shutdown_dist():
         td.destroy_process_group()
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE cannot be collected from inside the timed run; profiles/grad_kernel_traffic.json records the
-    measurement, its gfx950 correction and the source CSV).  None when the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "grad_kernel_traffic.json")
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "grad_kernel_traffic.json")
+TRAFFIC_SOURCES = ("torchrl_amd/csrc/k_ppo.hip", "torchrl_amd/csrc/trl_mlp.h")   # what the dominant kernel is compiled from
+
+
+def kernel_source_digest(root=REPO):
+    """sha256 over the dominant kernel's sources: the stamp that ties a committed PMC measurement to the code it measured
+    (the GPU box has no .git, so a commit id cannot be checked there; the digest can)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_traffic(path=None, root=REPO):
+    """(bytes per launch | None, stamp): HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot be collected from inside the timed run; the JSON records the
+    measurement, its gfx950 correction, the source CSV, the commit and the digest of the kernel sources it was taken at --
+    tools/stamp_traffic.py writes it).  The value is reported ONLY while the kernel sources are the ones that were measured:
+    after any edit of k_ppo.hip / trl_mlp.h it is null until the counters are collected again."""
     try:
-        with open(path) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
+        with open(path or TRAFFIC_FILE) as f:
+            rec = json.load(f)
+        value = rec["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
-        return None
+        return None, {"status": "no committed measurement"}
+    stamp = {"measured_at_commit": rec.get("measured_at_commit"), "kernel_source_sha256": rec.get("kernel_source_sha256"),
+             "source": rec.get("source")}
+    try:
+        now = kernel_source_digest(root)
+    except OSError:
+        now = None
+    stamp["tree_matches"] = bool(now) and now == rec.get("kernel_source_sha256")
+    if not stamp["tree_matches"]:
+        stamp["status"] = "stale: the kernel sources changed since the counters were collected -> traffic = null"
+        return None, stamp
+    stamp["status"] = "current"
+    return value, stamp
 
 
 if __name__ == "__main__":

@@ -1000,7 +1000,161 @@ def case_collect_offpolicy_norm():
     save("collect_offpolicy_norm", **out)
 
 
-CASES = {"collect_offpolicy_norm": case_collect_offpolicy_norm, "frame_dedup": case_frame_dedup, "collect_offpolicy": case_collect_offpolicy, "subproc_vecenv": case_subproc_vecenv, "eps_greedy": case_eps_greedy, "eval_epoch": case_eval_epoch, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
+def _load_py_envs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_py_envs", os.path.join(REPO, "torchrl_amd", "env", "py_envs.py"))
+    py_envs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(py_envs)
+    return py_envs
+
+
+def case_collect_hostenv():
+    """The reference's collectors over the reference's OWN VecEnv of single Python envs: what the ring really
+    holds.  VecEnv.partial_reset writes the fresh observations into the array `step` just returned (env/vecenv.py:47-51)
+    and both collectors add the sample AFTER the reset (collector/base.py:203-227, collector/on_policy.py:132-151): the
+    stored `next_obs` row of every env that was reset in a step -- by `done` or by the collector's max_episode_frames,
+    where `terminals` stays False -- is the RESET observation, not the one the env produced.  `*_reset_mask` logs the
+    masks partial_reset was called with (row t, env i), `*_true_next_obs` what env.step returned."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector.base import VecCollector
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.env.vecenv import VecEnv
+    from torchrl.replay_buffers.base import BaseReplayBuffer
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    from oracle.synth_env import SynthSingleEnvCPU
+    import gym
+    py_envs = _load_py_envs()
+
+    class ShortPendulum(py_envs.PendulumEnv):
+        """Episodes of 4 / 6 / 8 steps by seed, so that env time limits and the collector's limit interleave."""
+        def seed(self, seed):
+            super().seed(seed)
+            self._max_episode_steps = 4 + 2 * (int(seed) % 3)
+    short = ShortPendulum
+    out = {}
+
+    def make_env(kind, N, horizon, seed):
+        if kind == "synth":
+            count = iter(range(N))      # (the reference's list form trips over its own assert, vecenv.py:19: one factory)
+            env = VecEnv(N, lambda: (lambda i: SynthSingleEnvCPU(seed * N + i, horizon + 2 * (i % 3)))(next(count)), ())
+            env.envs[0].action_space = gym.spaces.Box(-1, 1, (6,))      # (`continuous` is an isinstance check on gym's Box)
+            return env
+        env = VecEnv(N, short if kind == "short_pendulum" else py_envs.PendulumEnv, ())
+        env.seed(seed)
+        return env
+
+    def logged(env, steps_done):
+        """Record every partial_reset mask and what env.step really returned."""
+        masks, true_next = [], []
+        reset, step = env.partial_reset, env.step
+
+        def partial_reset(mask, **kw):
+            masks.append(np.concatenate([[steps_done()], np.asarray(mask).reshape(-1).astype(np.int64)]))
+            return reset(mask, **kw)
+
+        def step_(actions):
+            res = step(actions)
+            true_next.append(np.array(res[0], copy=True))
+            return res
+        env.partial_reset, env.step = partial_reset, step_
+        return masks, true_next
+
+    # ---- off-policy (VecCollector, reparameterised tanh-Gaussian policy) ----
+    for tag, kind, N, steps, rows, horizon, max_frames, seed in (
+            ("off_pendulum_overlength", "pendulum", 4, 14, 20, 200, 5, 3),    # collector resets only: terminals all False
+            ("off_pendulum_mixed", "short_pendulum", 4, 26, 30, 0, 5, 4),     # env time limits (4 / 6 / 8) and collector resets
+            ("off_synth_wrap", "synth", 4, 20, 7, 4, 5, 5)):                  # 17/6 shape, horizons 4 / 6 / 8, the 7-row ring wraps twice
+        env, eval_env = make_env(kind, N, horizon, seed), make_env(kind, N, horizon, seed + 1)
+        D, A = env.observation_space.shape[0], env.action_space.shape[0]
+        torch.manual_seed(seed + 40)
+        net = dict(hidden_shapes=[32, 32], append_hidden_shapes=[], base_type=networks.MLPBase,
+                   activation_func=torch.nn.ReLU)
+        pf = policies.GuassianContPolicy(input_shape=D, output_shape=2 * A, tanh_action=True, **net)
+        torch.manual_seed(seed)
+        buf = BaseReplayBuffer(N * rows, env_nums=N)
+        col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=torch.device("cpu"),
+                           train_render=False, epoch_frames=N * steps, max_episode_frames=max_frames, eval_episodes=1)
+        masks, true_next = logged(env, lambda: len(true_next) - 1)
+        out.update(state_arrays(f"{tag}_pf_", pf))
+        out[f"{tag}_ob0"] = np.asarray(col.current_ob).copy()
+        res = col.train_one_epoch()
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+            out[f"{tag}_buf_{k}"] = np.asarray(getattr(buf, "_" + k)).copy()
+        out[f"{tag}_top_size"] = np.array([buf._top, buf._size], dtype=np.int64)
+        out[f"{tag}_reset_mask"] = np.stack(masks)
+        out[f"{tag}_true_next_obs"] = np.stack(true_next)
+        out[f"{tag}_train_epoch_reward"] = np.array(res["train_epoch_reward"])
+        out[f"{tag}_train_rewards"] = np.array(res["train_rewards"], dtype=np.float64).reshape(-1)
+        out[f"{tag}_current_ob"] = np.asarray(col.current_ob).copy()
+        out[f"{tag}_args"] = np.array([N, steps, rows, horizon, max_frames, seed], dtype=np.int64)
+        # the deviation this fixture pins: stored next_obs == reset observation exactly on the reset rows
+        flat_next, n_alias = np.stack(true_next), 0
+        for m in masks:
+            t, mask = int(m[0]), m[1:].astype(bool)
+            if t >= steps - rows:                                     # row still in the ring
+                stored = out[f"{tag}_buf_next_obs"][t % rows]
+                assert np.array_equal(stored[~mask], flat_next[t][~mask])
+                assert not np.array_equal(stored[mask], flat_next[t][mask])
+                assert np.array_equal(stored[mask], out[f"{tag}_buf_obs"][(t + 1) % rows][mask]) or t == steps - 1
+                n_alias += int(mask.sum())
+        assert n_alias > 0
+
+    # ---- on-policy (VecOnPolicyCollector): the bootstrap value uses the TRUE next observation, the row the reset one ----
+    for tag, kind, N, T, horizon, max_frames, seed in (
+            ("on_pendulum_mixed", "short_pendulum", 4, 24, 0, 5, 6),
+            ("on_synth_mixed", "synth", 8, 16, 4, 5, 7)):
+        env, eval_env = make_env(kind, N, horizon, seed), make_env(kind, N, horizon, seed + 1)
+        D, A = env.observation_space.shape[0], env.action_space.shape[0]
+        pf, vf = build_nets(D, A, 64, seed=seed + 20)
+        torch.manual_seed(seed)
+        buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+        col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=torch.device("cpu"),
+                                   train_render=False, epoch_frames=N * T, max_episode_frames=max_frames, eval_episodes=1)
+        masks, true_next = logged(env, lambda: len(true_next) - 1)
+        out.update(state_arrays(f"{tag}_pf_", pf))
+        out.update(state_arrays(f"{tag}_vf_", vf))
+        out[f"{tag}_ob0"] = np.asarray(col.current_ob).copy()
+        res = col.train_one_epoch()
+        for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+            out[f"{tag}_buf_{k}"] = np.asarray(getattr(buf, "_" + k)).copy()
+        out[f"{tag}_reset_mask"] = np.stack(masks)
+        out[f"{tag}_true_next_obs"] = np.stack(true_next)
+        out[f"{tag}_train_epoch_reward"] = np.array(res["train_epoch_reward"])
+        out[f"{tag}_train_rewards"] = np.array(res["train_rewards"], dtype=np.float64).reshape(-1)
+        out[f"{tag}_current_ob"] = np.asarray(col.current_ob).copy()
+        out[f"{tag}_args"] = np.array([N, T, horizon, max_frames, seed], dtype=np.int64)
+        for m in masks:
+            t, mask = int(m[0]), m[1:].astype(bool)
+            assert not np.array_equal(out[f"{tag}_buf_next_obs"][t][mask], np.stack(true_next)[t][mask])
+    save("collect_hostenv", **out)
+
+
+CNN_INIT_CONVS = [[16, [8, 8], [4, 4], [0, 0]], [32, [4, 4], [2, 2], [0, 0]], [64, [3, 3], [1, 1], [0, 0]]]
+
+
+def case_cnn_init():
+    """networks.Net over CNNBase (networks/base.py:59-107, nets.py) and the orthogonal initialiser (init.py:40-47) under
+    torch.manual_seed: the cfg 5 trunk (conv 16/32/64) on a 4 x 36 x 36 input (64 features) + fc 512 + a 6-wide head; a
+    QNet-style MLP with orthogonal_init; one forward pass of the conv net on a fixed uint8-valued input."""
+    import torchrl.networks as networks
+    out = {}
+    torch.manual_seed(43)
+    qf = networks.Net(output_shape=6, base_type=networks.CNNBase, append_hidden_shapes=[512],
+                      activation_func=torch.nn.ReLU, input_shape=(4, 36, 36), hidden_shapes=CNN_INIT_CONVS)
+    out.update(state_arrays("cnn_", qf))
+    x = torch.from_numpy(np.random.RandomState(0).randint(0, 256, (3, 4, 36, 36)).astype(np.float32))
+    out["input_x"] = x.numpy()
+    out["output_y"] = qf(x).detach().numpy()
+    torch.manual_seed(44)
+    mlp = networks.Net(input_shape=(11,), output_shape=3, hidden_shapes=[32, 32], append_hidden_shapes=[],
+                       base_type=networks.MLPBase, activation_func=torch.nn.ReLU,
+                       init_func=networks.orthogonal_init, net_last_init_func=networks.orthogonal_init)
+    out.update(state_arrays("ortho_", mlp))
+    save("cnn_init", **out)
+
+
+CASES = {"cnn_init": case_cnn_init, "collect_hostenv": case_collect_hostenv, "collect_offpolicy_norm": case_collect_offpolicy_norm, "frame_dedup": case_frame_dedup, "collect_offpolicy": case_collect_offpolicy, "subproc_vecenv": case_subproc_vecenv, "eps_greedy": case_eps_greedy, "eval_epoch": case_eval_epoch, "vecenv": case_vecenv, "gae": case_gae, "index_streams": case_index_streams, "init": case_init, "ppo_update": case_ppo_update,
          "collect_epoch": case_collect_and_epoch, "twin_sac_q": case_twin_sac_q, "dqn": case_dqn,
          "obs_norm": case_obs_norm, "a2c_update": case_a2c_update, "ddpg_td3": case_ddpg_td3, "vmpo_update": case_vmpo_update, "trpo_update": case_trpo_update}
 

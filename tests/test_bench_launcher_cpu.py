@@ -55,3 +55,38 @@ def test_device_map(monkeypatch):
     assert bench._device_map(4) == [0, 1, 2, 3]
     monkeypatch.setenv("TRL_BENCH_DEVICE_MAP", "0,0")
     assert bench._device_map(2) == [0, 0]
+
+
+def test_roofline_traffic_is_reported_only_for_the_kernel_sources_it_was_measured_on(tmp_path):
+    """`roofline.traffic` comes from a committed counter pass; bench.py must print it only while
+    k_ppo.hip / trl_mlp.h are byte for byte what was measured (sha256 stamp in profiles/grad_kernel_traffic.json, written
+    by tools/stamp_traffic.py), and null + a 'stale' stamp after any edit."""
+    import json
+    import shutil
+    bench = _bench_module()
+    with open(bench.TRAFFIC_FILE) as f:
+        rec = json.load(f)
+    assert rec["kernel_source_sha256"] and rec["measured_at_commit"] and list(rec["kernel_sources"]) == list(bench.TRAFFIC_SOURCES)
+    value, stamp = bench.pmc_traffic()
+    if stamp["tree_matches"]:                                             # committed measurement is of this tree
+        assert value == rec["traffic_bytes_per_launch"] and stamp["status"] == "current"
+        assert rec["kernel_source_sha256"] == bench.kernel_source_digest()
+    else:                                                                 # kernel edited since: nothing may be claimed
+        assert value is None and stamp["status"].startswith("stale")
+    # the same file against a tree whose kernel source differs by one byte
+    root = tmp_path / "tree"
+    for rel in bench.TRAFFIC_SOURCES:
+        (root / os.path.dirname(rel)).mkdir(parents=True, exist_ok=True)
+        shutil.copy(os.path.join(REPO, rel), root / rel)
+    same = dict(rec, kernel_source_sha256=bench.kernel_source_digest(str(root)))
+    path = tmp_path / "traffic.json"
+    path.write_text(json.dumps(same))
+    value, stamp = bench.pmc_traffic(str(path), str(root))
+    assert value == rec["traffic_bytes_per_launch"] and stamp["tree_matches"]
+    with open(root / bench.TRAFFIC_SOURCES[0], "ab") as f:
+        f.write(b"\n")
+    value, stamp = bench.pmc_traffic(str(path), str(root))
+    assert value is None and not stamp["tree_matches"] and stamp["status"].startswith("stale")
+    assert stamp["measured_at_commit"] == rec["measured_at_commit"]
+    value, stamp = bench.pmc_traffic(str(tmp_path / "absent.json"), str(root))
+    assert value is None and stamp["status"] == "no committed measurement"

@@ -144,20 +144,35 @@ def test_cfg3_update_on_a_sampled_full_size_batch_vs_oracle(errlog):
         worst = max(worst, abs(info[k] - w) / tol)
         assert abs(info[k] - w) < tol, (k, info[k], w)
     errlog("info scalars: max |got - want| / (1e-5 + 1e-4 |want|)", worst, 1.0)
-    # Post-step parameters.  These optimisers run Adam with eps = 1e-8 (torch default, twin_sac_q.py:52-67), whose
-    # FIRST step is lr * g / (|g| + eps): for the few elements whose gradient is itself ~1e-7 (dead ReLU columns) the
-    # step is ill-conditioned -- an fp32-round-off change of g moves it by a percent of lr = 3e-4.  So: all but 1e-4 of
-    # the elements within the contract's 1e-6, and every element within 2 % of one Adam step.
-    perr, n_out, n_all = 0.0, 0, 0
-    for mod, ref in ((pf, o.pf), (qf1, o.q1), (qf2, o.q2), (agent.target_qf1, o.tq1), (agent.target_qf2, o.tq2)):
-        for a, b in zip(lay(mod), ref):
-            d = (a - b.detach()).abs()
+    # Post-step parameters, bounded PER ELEMENT in units of one Adam step.  These optimisers run Adam
+    # with eps = 1e-8 (torch default, twin_sac_q.py:52-67), whose FIRST step is -lr * f(g), f(g) = g / (|g| + eps): the step
+    # of an element is as sensitive to its gradient as f'(g) = eps / (|g| + eps)^2.  With the oracle's own gradient g_e
+    # (10 x its first-moment estimate after one step) and DG = 1e-7 as the absolute fp32 round-off allowed on a gradient
+    # element (a sum over B = 4096 samples), element e may differ by
+    #     bound_e = max(1e-6, lr * min(0.02, DG * eps / (|g_e| + eps)^2))
+    # i.e. the contract's 1e-6 for every element with |g_e| >= 5.5e-7, and never more than 2 % of one step (dead ReLU
+    # columns, |g| ~ 1e-7, where f is ill-conditioned).  Targets move by tau x the step (floor: Polyak round-off).
+    lr, eps_adam, DG, tau = 3e-4, 1e-8, 1e-7, 0.005
+    perr, worst_ratio, n_out, n_all, n_loose = 0.0, 0.0, 0, 0, 0
+    groups = ((pf, o.pf, o.pf_opt, 1.0), (qf1, o.q1, o.q1_opt, 1.0), (qf2, o.q2, o.q2_opt, 1.0),
+              (agent.target_qf1, o.tq1, o.q1_opt, tau), (agent.target_qf2, o.tq2, o.q2_opt, tau))
+    for mod, ref, opt, scale in groups:
+        assert opt.t == 1
+        for a, b, m in zip(lay(mod), ref, opt.m):
+            g = (m / (1.0 - opt.b1)).abs().double()
+            bound = torch.clamp(lr * torch.clamp(DG * eps_adam / (g + eps_adam) ** 2, max=0.02), min=1e-6)
+            bound = bound if scale == 1.0 else torch.clamp(scale * bound, min=5e-7)
+            d = (a - b.detach()).abs().double()
+            worst_ratio = max(worst_ratio, (d / bound).max().item())
             perr = max(perr, d.max().item())
             n_out += int((d > 1e-6).sum())
+            n_loose += int((bound > 1e-6).sum())
             n_all += d.numel()
-    errlog("post-step params abs, max over %d elements (one update, B=4096, H=256, Adam eps 1e-8)" % n_all, perr, 6e-6)
+    errlog("post-step params: max over %d elements of |got - want| / bound_e (bound_e = 1e-6, up to 0.02 lr where "
+           "|g_e| < 5.5e-7: %d elements)" % (n_all, n_loose), worst_ratio, 1.0)
+    errlog("post-step params abs, max over %d elements (one update, B=4096, H=256, Adam eps 1e-8)" % n_all, perr, 0.02 * lr)
     errlog("post-step params: fraction of elements off by more than 1e-6", n_out / n_all, 1e-4)
-    assert perr < 6e-6 and n_out / n_all < 1e-4, (perr, n_out, n_all)
+    assert worst_ratio <= 1.0 and perr <= 0.02 * lr and n_out / n_all < 1e-4, (worst_ratio, perr, n_out, n_all)
     assert abs(float(agent.log_alpha.cpu()) - float(o.log_alpha.detach())) < 1e-6
 
 

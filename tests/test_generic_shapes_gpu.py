@@ -209,9 +209,18 @@ def test_fused_ppo_update_at_other_input_and_action_sizes_vs_oracle(D, A, act, t
         got = agent.update(batch)
         agent.engine().sync_target_pf()
         assert sorted(got) == sorted(want)
-        g, w = np.array([got[k] for k in sorted(want)]), np.array([want[k] for k in sorted(want)])
-        errlog("step %d info scalars: max |got - want| / (1e-5 + 1e-4 |want|)" % step, (np.abs(g - w) / (1e-5 + 1e-4 * np.abs(w))).max(), 1.0)
-        np.testing.assert_allclose(g, w, rtol=1e-4, atol=1e-5)
+        keys = sorted(want)
+        g, w = np.array([got[k] for k in keys]), np.array([want[k] for k in keys])
+        # One action dimension: the unbiased std over ONE element is NaN in the reference too (ppo.py:82-85: `.std()` of a
+        # 1-element tensor) -- exactly these keys, in both, and nothing else; every other scalar is compared by value.
+        nan_keys = {"log_std/std", "std/std"} & set(keys) if A == 1 else set()
+        assert {k for k, v in zip(keys, w) if np.isnan(v)} == nan_keys, "oracle NaNs"
+        assert {k for k, v in zip(keys, g) if np.isnan(v)} == nan_keys, "kernel NaNs"
+        fin = np.array([k not in nan_keys for k in keys])
+        assert fin.sum() >= len(keys) - 2 and np.isfinite(g[fin]).all()
+        errlog("step %d info scalars: max |got - want| / (1e-5 + 1e-4 |want|)" % step,
+               (np.abs(g[fin] - w[fin]) / (1e-5 + 1e-4 * np.abs(w[fin]))).max(), 1.0)
+        np.testing.assert_allclose(g[fin], w[fin], rtol=1e-4, atol=1e-5)
     perr = 0.0
     for mod, params in ((pf, ref.pf), (vf, ref.vf)):
         lin = [l for l in (list(mod.base.seq_fcs) + list(mod.seq_append_fcs)) if isinstance(l, torch.nn.Linear)]

@@ -12,10 +12,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def host_vec_env(N, horizon, seed):
+def host_vec_env(N, horizon, seed, alias_reset_obs=False):
+    """alias_reset_obs=False: the fixtures of the tests below come from the reference's collectors over a VECTOR env whose
+    partial_reset leaves the array `step` returned alone (oracle/synth_env.py), like the on-GPU env -- the reference's own
+    VecEnv behaviour (the stored next_obs row of a reset env is the reset observation) is pinned separately, in
+    test_reference_vecenv_alias_of_reset_observations below."""
     from torchrl.env import VecEnv
     # the reference's VecEnv.seed gives env i the seed s * N + i (vecenv.py:63-65)
-    return VecEnv(N, [SynthSingleEnvCPU] * N, [(seed * N + i, horizon) for i in range(N)])
+    env = VecEnv(N, [SynthSingleEnvCPU] * N, [(seed * N + i, horizon) for i in range(N)])
+    env.alias_reset_obs = alias_reset_obs
+    return env
 
 
 def nets(g, pf_prefix, vf_prefix):
@@ -75,6 +81,7 @@ def test_subproc_vecenv_under_the_collector_matches_reference(golden):
     pf, vf = nets(g, tag + "_pf0_", tag + "_vf0_")
     procs = 2 if N % 2 == 0 else 1
     env = SubProcVecEnv(procs, N, [SynthSingleEnvCPU] * N, [(seed * N + i, horizon) for i in range(N)])
+    env.alias_reset_obs = False                                           # (see host_vec_env)
     try:
         buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
         col = VecOnPolicyCollector(vf, env=env, eval_env=None, pf=pf, replay_buffer=buf, device=torch.device(DEV),
@@ -258,3 +265,108 @@ def test_single_env_sac_example_runs(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "EPOCH:1" in out.stdout
+
+
+def _reference_style_env(kind, N, horizon, seed):
+    from torchrl.env import VecEnv
+    from torchrl.env.py_envs import PendulumEnv
+    if kind == "synth":                                                       # horizons 4 / 6 / 8 by env index
+        return VecEnv(N, [SynthSingleEnvCPU] * N, [(seed * N + i, horizon + 2 * (i % 3)) for i in range(N)])
+
+    class ShortPendulum(PendulumEnv):                                          # (as in tests/golden/make_golden.py)
+        def seed(self, seed):
+            super().seed(seed)
+            self._max_episode_steps = 4 + 2 * (int(seed) % 3)
+    env = VecEnv(N, ShortPendulum if kind == "short_pendulum" else PendulumEnv, ())
+    env.seed(seed)
+    return env
+
+
+def _state(g, prefix, mod):
+    mod.load_state_dict({k[len(prefix):].replace("__", "."): torch.tensor(g[k]) for k in g.files if k.startswith(prefix)})
+    return mod
+
+
+@pytest.mark.parametrize("tag,kind", [("off_pendulum_overlength", "pendulum"), ("off_pendulum_mixed", "short_pendulum"),
+                                      ("off_synth_wrap", "synth")])
+def test_reference_vecenv_alias_of_reset_observations_off_policy(golden, tag, kind):
+    """SURVEY 8(a) a21, VERDICT r04 missing #2: the reference's VecEnv.partial_reset mutates the array `step` returned
+    (env/vecenv.py:47-51) and VecCollector.take_actions adds the sample after the reset (collector/base.py:203-227), so
+    the ring's `next_obs` rows of reset envs hold the RESET observation -- for over-length resets with terminals False.
+    tests/golden/collect_hostenv.npz is the reference's own collectors over the reference's own VecEnv; the default
+    (`alias_reset_obs = True`) must store exactly that, and the opt-out exactly the env's own observations."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector import VecCollector
+    from torchrl.replay_buffers import BaseReplayBuffer
+    g = golden("collect_hostenv")
+    N, steps, rows, horizon, max_frames, seed = (int(v) for v in g[tag + "_args"])
+    dev = torch.device(DEV)
+    for alias in (True, False):
+        env, eval_env = _reference_style_env(kind, N, horizon, seed), _reference_style_env(kind, N, horizon, seed + 1)
+        env.alias_reset_obs = alias
+        D, A = env.observation_space.shape[0], env.action_space.shape[0]
+        net = dict(hidden_shapes=[32, 32], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+        pf = _state(g, tag + "_pf_", policies.GuassianContPolicy(input_shape=D, output_shape=2 * A, tanh_action=True, **net))
+        torch.manual_seed(seed)
+        buf = BaseReplayBuffer(N * rows, env_nums=N)
+        col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=dev, train_render=False,
+                           epoch_frames=N * steps, max_episode_frames=max_frames, eval_episodes=1)
+        np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_ob0"], atol=1e-6)
+        res = col.train_one_epoch()
+        got = {k: getattr(buf, "_" + k).cpu().numpy() for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits")}
+        for k in ("obs", "acts", "rewards", "terminals", "time_limits"):
+            np.testing.assert_allclose(got[k], np.asarray(g[f"{tag}_buf_{k}"], dtype=np.float64).reshape(got[k].shape),
+                                       atol=3e-5, err_msg=k)
+        assert [buf._top, buf._size] == list(g[tag + "_top_size"])
+        np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_current_ob"], atol=3e-5)
+        assert abs(res["train_epoch_reward"] - float(g[tag + "_train_epoch_reward"])) < 1e-3
+        np.testing.assert_allclose(np.array(res["train_rewards"], dtype=np.float64), g[tag + "_train_rewards"], atol=1e-3)
+        want = g[tag + "_buf_next_obs"].astype(np.float64)
+        if alias:                                                             # what the reference stores
+            np.testing.assert_allclose(got["next_obs"], want, atol=3e-5)
+            continue
+        # opt-out: the env's own observations -- different from the reference's ring on EXACTLY the reset rows
+        true_next, differs = g[tag + "_true_next_obs"], np.zeros((rows, N), dtype=bool)
+        for m in g[tag + "_reset_mask"]:
+            if int(m[0]) >= steps - rows:
+                differs[int(m[0]) % rows] |= m[1:].astype(bool)
+        for t in range(max(0, steps - rows), steps):
+            np.testing.assert_allclose(got["next_obs"][t % rows], true_next[t], atol=3e-5)
+        row_differs = np.abs(got["next_obs"] - want).max(axis=-1) > 1e-4
+        written = np.zeros(rows, dtype=bool)
+        written[[t % rows for t in range(max(0, steps - rows), steps)]] = True
+        assert np.array_equal(row_differs[written], differs[written])
+        assert differs.any() and not got["terminals"][differs].all()          # over-length resets: terminals False
+
+
+@pytest.mark.parametrize("tag,kind", [("on_pendulum_mixed", "short_pendulum"), ("on_synth_mixed", "synth")])
+def test_reference_vecenv_alias_of_reset_observations_on_policy(golden, tag, kind):
+    """The same for VecOnPolicyCollector (collector/on_policy.py:132-151): the bootstrap value of an over-length env is
+    computed from the TRUE next observation (before the reset), the stored row is the reset one."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector.on_policy import VecOnPolicyCollector
+    from torchrl.replay_buffers.on_policy import OnPolicyReplayBuffer
+    g = golden("collect_hostenv")
+    N, T, horizon, max_frames, seed = (int(v) for v in g[tag + "_args"])
+    env, eval_env = _reference_style_env(kind, N, horizon, seed), _reference_style_env(kind, N, horizon, seed + 1)
+    D, A = env.observation_space.shape[0], env.action_space.shape[0]
+    net = dict(hidden_shapes=[64, 64], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.Tanh)
+    pf = _state(g, tag + "_pf_", policies.GuassianContPolicyBasicBias(input_shape=D, output_shape=A, tanh_action=True, **net))
+    vf = _state(g, tag + "_vf_", networks.Net(input_shape=(D,), output_shape=1, **net))
+    torch.manual_seed(seed)
+    buf = OnPolicyReplayBuffer(N * T, env_nums=N, time_limit_filter=True)
+    col = VecOnPolicyCollector(vf, env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=torch.device(DEV),
+                               train_render=False, epoch_frames=N * T, max_episode_frames=max_frames, eval_episodes=1)
+    res = col.train_one_epoch()
+    for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+        got = getattr(buf, "_" + k).cpu().numpy()
+        np.testing.assert_allclose(got, np.asarray(g[f"{tag}_buf_{k}"], dtype=np.float64).reshape(got.shape), atol=3e-5, err_msg=k)
+    np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_current_ob"], atol=3e-5)
+    assert abs(res["train_epoch_reward"] - float(g[tag + "_train_epoch_reward"])) < 1e-3
+    true_next, stored = g[tag + "_true_next_obs"], buf._next_obs.cpu().numpy()
+    for m in g[tag + "_reset_mask"]:                                          # the reset rows are NOT the env's own observations
+        t, mask = int(m[0]), m[1:].astype(bool)
+        assert np.abs(stored[t][mask] - true_next[t][mask]).max() > 1e-4
+        np.testing.assert_allclose(stored[t][~mask], true_next[t][~mask], atol=3e-5)

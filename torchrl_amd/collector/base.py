@@ -179,10 +179,11 @@ class VecCollector(_CollectorBase):
         if time_limits is not None:
             time_limits.copy_(done)                                         # synthetic env: time_limit == done
 
-    def _env_reset_masked(self, env):
-        """env.partial_reset(self._mask); env.cur_obs then holds the whole (raw) observation array."""
+    def _env_reset_masked(self, env, stored_next_obs=None):
+        """env.partial_reset(self._mask); env.cur_obs then holds the whole (raw) observation array.  stored_next_obs: the
+        ring row holding env.step's own return of this step (host envs: see VecEnv.alias_reset_obs)."""
         if getattr(env, "is_host_env", False):
-            env.host_partial_reset(self._mask)
+            env.host_partial_reset(self._mask, stored_next_obs)
         else:
             _C.synth_reset(env.cur_obs, env.t_env, env.cur_step, env.episode_idx, env.ep_return, self._mask, env.seed_base)
 
@@ -309,7 +310,7 @@ class VecCollector(_CollectorBase):
         _C.collector_bookkeep(rew, done, env.cur_step, env.ep_return,
                               self.max_episode_frames if max_frames is None else max_frames, self._mask,
                               self._epoch_reward, self._ep_count, self._ep_log, self.global_step - self._log_step0)
-        self._env_reset_masked(env)
+        self._env_reset_masked(env, nxt if (store and nz is None) else None)
         if store:
             buf._advance()
         self.global_step += 1

@@ -506,7 +506,7 @@ class VecOnPolicyCollector(VecCollector):
         _C.onpolicy_bookkeep(r["rewards"], sb["done"], sb["v_next"], self.discount, r["terminals"], env.cur_step,
                              env.ep_return, self.max_episode_frames if max_frames is None else max_frames, self._mask,
                              sb["any"], self._epoch_reward, self._ep_count, self._ep_log, step)
-        self._env_reset_masked(env)
+        self._env_reset_masked(env, r["next_obs"] if (store and nz is None) else None)
         # partial_reset returns the RAW observations of all envs (base_wrapper.py:23-26, vecenv.py:47-51)
         alt = nz.filt(env.cur_obs) if (nz is not None and getattr(env, "normalize_partial_reset", False)) else env.cur_obs
         nxt = torch.empty(N, D, device=env.device)

@@ -111,7 +111,8 @@ class SubProcVecEnv(VecEnv):
         index_mask = np.asarray(index_mask).reshape(-1).astype(bool)
         self._send_all("partial_reset", [(m, kwargs) for m in np.split(index_mask, self.proc_nums)])
         fresh = self._gather()
-        self._obs = self._obs.copy()                                   # see VecEnv.partial_reset
+        if not self.alias_reset_obs:                                   # see VecEnv.alias_reset_obs
+            self._obs = self._obs.copy()
         for index, ob in zip(np.flatnonzero(index_mask), fresh):
             self._obs[index] = ob
         return self._obs

@@ -18,6 +18,12 @@ import torch
 
 class VecEnv:
     is_device_env = False
+    # The reference's partial_reset writes the fresh observations INTO the array `step` just returned (vecenv.py:50), and
+    # its collectors add the sample after the reset (collector/base.py:203-227, on_policy.py:132-151): the `next_obs` row
+    # they store for an env that was reset in a step -- by `done` or by max_episode_frames, where `terminals` stays
+    # False and the TD target bootstraps from it -- is the RESET observation.  True (default): reproduce exactly that
+    # (tests/golden/collect_hostenv.npz).  False: the stored transition keeps the observation the env produced.
+    alias_reset_obs = True
 
     def __init__(self, env_nums, env_funcs, env_args):
         self.env_nums = int(env_nums)
@@ -57,10 +63,8 @@ class VecEnv:
 
     def partial_reset(self, index_mask, **kwargs):
         index_mask = np.asarray(index_mask).reshape(-1).astype(bool)
-        # The reference writes into the array `step` just returned (vecenv.py:50), so the `next_obs` its collectors
-        # store afterwards silently becomes the reset observation of those envs; here the stored transition keeps
-        # the observation the env actually produced (a conscious fix; the goldens are generated with it).
-        self._obs = self._obs.copy()
+        if not self.alias_reset_obs:
+            self._obs = self._obs.copy()                                   # leave the array `step` returned alone
         for index in np.flatnonzero(index_mask):
             self._obs[index] = np.asarray(self.envs[index].reset())
         return self._obs
@@ -178,9 +182,13 @@ class HostEnvBridge:
                 time_limits.zero_()
         return done
 
-    def host_partial_reset(self, mask):
-        """mask (N,) uint8 device: reset those envs; `cur_obs` becomes the env's whole observation array."""
+    def host_partial_reset(self, mask, stored_next_obs=None):
+        """mask (N,) uint8 device: reset those envs; `cur_obs` becomes the env's whole observation array.
+        stored_next_obs: the ring row this step's `next_obs` went to when it holds env.step's own array (no observation
+        wrapper in between) -- with `alias_reset_obs` it then reads what the reference stores, the array AFTER the reset."""
         m = mask.cpu().numpy().astype(bool)
         if m.any():
             self._upload(self.venv.partial_reset(m), self.cur_obs)
+            if stored_next_obs is not None and getattr(self.venv, "alias_reset_obs", False):
+                stored_next_obs.copy_(self.cur_obs)
         return m
