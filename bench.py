@@ -585,12 +585,34 @@ def main():
         # single-process one.  Otherwise: RCCL all-reduces, captured into the graph only after child processes have
         # shown that graph-captured collectives work on this node (TRL_GRAPH_COLLECTIVES overrides the probe).
         from torchrl_amd import dist as _dist
+        # Per-rank CPU slice before any thread pool exists (the reference-noise draw runs a pool of host threads per rank,
+        # one rollout ahead of the device; TRL_RANK_AFFINITY=0 leaves the scheduler alone).
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if os.environ.get("TRL_RANK_AFFINITY", "1") != "0":
+            mine = _dist.pin_rank_cpus(local, local_world)
+            comm_info["cpu_affinity"] = ("%d CPUs per rank (rank 0: %d-%d)" % (len(mine), mine[0], mine[-1])) if mine and rank == 0 \
+                else ("%d CPUs per rank" % len(mine) if mine else "not pinned")
+        # Pre-flight (rank 0 reports): can every pair of this job's GPUs reach each other, and over what
+        if not shared and torch.cuda.device_count() >= world:
+            try:
+                comm_info["link_preflight"] = _dist.link_preflight(devmap[:world])
+            except Exception as exc:                                      # noqa: BLE001 -- a diagnostic must not cost the run
+                comm_info["link_preflight"] = {"error": repr(exc)}
+        else:
+            comm_info["link_preflight"] = {"note": "%d ranks on %d device(s): nothing to probe" % (world, len(set(devmap[:world])))}
         if args.transport == "rccl":
             os.environ["TRL_NO_PEER"] = "1"
         peers = _dist.init_comm(torch.device("cuda", local_dev))
+        report = _dist.peer_report()
         comm_info["transport_requested"] = args.transport
         comm_info["peer_self_check"] = "passed on every rank" if peers else \
-            ("disabled (--transport rccl / TRL_NO_PEER=1)" if os.environ.get("TRL_NO_PEER") == "1" else "failed or unavailable")
+            ("disabled (--transport rccl / TRL_NO_PEER=1)" if os.environ.get("TRL_NO_PEER") == "1"
+             else report.get("self_check", "failed or unavailable"))
+        if report.get("not_used"):
+            comm_info["peer_transport_not_used"] = report["not_used"]
+        comm_info["ranks_per_device"] = report.get("ranks_per_device", 1 if not shared else None)
+        comm_info["transport_vote"] = "peer" if peers else ("all-reduce calls" + (" (peer self-check %s)" % report["self_check"]
+                                                                                   if report.get("self_check") else ""))
         if args.transport == "peer" and not peers:
             raise SystemExit("--transport peer: the peer-mapped transport did not pass its self-check on every rank")
         log("peer transport: %s" % ("up (self-check passed on every rank)" if peers else "unavailable -> all-reduce calls"))

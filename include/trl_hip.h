@@ -411,6 +411,9 @@ int trl_comm_error(trl_comm_t* comm);
 /* what the first timed-out peer wait was waiting for: out[4] = {region (1 gradient, 2 statistics; 0 none), slot = the rank
  * whose contribution was missing, epoch waited for, epoch tag found}; clears the record (diagnostics of a failed run). */
 int trl_comm_error_detail(trl_comm_t* comm, int32_t* out);
+/* pre-flight of a one-node multi-GPU run (host only, no communicator): out[3] = {peer access possible from dev_a to dev_b,
+ * link type (2 PCIe, 4 xGMI, -1 unknown), hops} -- what the peer transport's posted writes and RCCL's rings will run over. */
+int trl_comm_link_info(int dev_a, int dev_b, int32_t* out);
 int trl_comm_destroy(trl_comm_t* comm);
 /* buf <- SUM over ranks, in place, n floats (C1).  Peer transport up to 12 288 floats, RCCL beyond. */
 int trl_allreduce_sum_f32(float* buf, int64_t n, trl_comm_t* comm, void* stream);

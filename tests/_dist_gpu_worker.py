@@ -12,6 +12,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 N_TOTAL, T, ROWS_MB, EPOCHS, HORIZON, MAX_FRAMES = 64, 16, 4, 3, 12, 9
+if os.environ.get("TRL_TEST_SIZES"):            # "n_total,T,rows_per_minibatch,epochs": BASELINE cfg 4's real sizes in the 8-rank test
+    N_TOTAL, T, ROWS_MB, EPOCHS = (int(v) for v in os.environ["TRL_TEST_SIZES"].split(","))
 
 
 class Log:

@@ -22,7 +22,9 @@ def main():
     else:
         td.init_process_group("gloo", rank=rank, world_size=world)
     from torchrl_amd import _C, dist
-    assert dist.init_comm(dev, use_rccl=(backend == "nccl")), "peer transport did not come up"
+    # (world > 2 on the one GPU of the tests: only the small stand-alone all-reduces run here, all ranks' launches fit together)
+    assert dist.init_comm(dev, use_rccl=(backend == "nccl"), allow_shared_device=True), "peer transport did not come up"
+    assert dist.peer_report()["ranks_per_device"] == world
     lib = _C.lib()
     assert bool(lib.trl_comm_has_rccl(dist.comm_handle())) == (backend == "nccl")
     res = {}

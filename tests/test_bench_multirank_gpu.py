@@ -16,7 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _bench(extra_env, gpus=2, extra_args=()):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
-    env.update(TRL_BENCH_DEVICE_MAP="0,0", **extra_env)
+    env.update(TRL_BENCH_DEVICE_MAP=",".join(["0"] * gpus), **extra_env)
     res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "3",
                           "--no-cpu-baseline", "--no-secondary", *extra_args], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=600)
@@ -51,6 +51,24 @@ def test_plain_python_two_ranks_on_the_all_reduce_fallback():
     assert cfg["transport"] == "torch.distributed:gloo", (cfg, err[-2000:])
     assert cfg["peer_self_check"].startswith("disabled") and cfg["transport_requested"] == "rccl"
     assert all(v > 0 for v in cfg["collective_us"].values())
+
+
+def test_cfg4_layout_eight_ranks_on_one_gpu():
+    """BASELINE cfg 4 in its own shape as far as one GPU allows: `python bench.py --gpus 8`, 8 self-
+    spawned ranks x 2048 envs = 16 384 envs, every rank drawing its rows of the reference's (16384, 6) noise tensors.  All
+    eight hipIpc buffers are mapped and self-checked (8 slots each); the iterations then run on the all-reduce route,
+    because eight ranks sharing ONE device cannot wait for each other inside kernels (dist.MAX_PEER_RANKS_PER_DEVICE)."""
+    out, err = _bench({}, gpus=8)
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert abs(out["value"] - 8 * 2048 * 128 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert cfg["peer_self_check"].startswith("passed on every rank (8 slots"), (cfg, err[-2000:])
+    assert cfg["ranks_per_device"] == 8 and "8 ranks share one device" in cfg["peer_transport_not_used"]
+    assert cfg["transport"] == "torch.distributed:gloo" and cfg["launcher"].startswith("bench.py spawned")
+    assert all(v > 0 for v in cfg["collective_us"].values())
+    assert out["parity_mode_ms_per_step"] > 0 and out["device_noise_ms_per_step"] > 0      # world-8 reference noise was timed
+    assert "CPUs per rank" in cfg["cpu_affinity"]
+    assert cfg["exchanges_per_iteration"]["c1_gradient_sum_44KB"] == 40
 
 
 def test_a_rank_that_dies_takes_the_job_down_with_its_exit_code():

@@ -50,6 +50,54 @@ def test_two_ranks_reproduce_one_process(tmp_path):
     np.testing.assert_allclose(r0["infos"], single["infos"], rtol=2e-4, atol=2e-5)
 
 
+def test_eight_ranks_reproduce_one_process(tmp_path):
+    """BASELINE cfg 4's partition at test size: 8 ranks x 8 envs against one process x 64 envs, all on cuda:0 over gloo
+    (eight ranks on one device cannot wait for each other inside kernels: torchrl_amd.dist.MAX_PEER_RANKS_PER_DEVICE).
+    Device noise keyed by the global env index, then the reference's CPU noise stream with every rank drawing only its
+    rows of each step's (64, 6) tensor one rollout ahead (world-8 offsets through the real collector)."""
+    (single,) = _run(1, tmp_path)
+    ranks = _run(8, tmp_path)
+    np.testing.assert_allclose(np.concatenate([r["obs"] for r in ranks], axis=1), single["obs"], atol=1e-6)
+    np.testing.assert_allclose(np.concatenate([r["rewards"] for r in ranks], axis=1), single["rewards"], atol=1e-6)
+    for r in ranks[1:]:
+        assert np.array_equal(r["pf"], ranks[0]["pf"]) and np.array_equal(r["vf"], ranks[0]["vf"])
+        np.testing.assert_allclose(r["infos"], ranks[0]["infos"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(ranks[0]["pf"], single["pf"], atol=2e-6)
+    np.testing.assert_allclose(ranks[0]["vf"], single["vf"], atol=2e-6)
+    np.testing.assert_allclose(ranks[0]["infos"], single["infos"], rtol=2e-4, atol=2e-5)
+    # the reference's noise stream at world 8
+    (single_h,) = _run(1, tmp_path, extra=("plain", "host_perstep"))
+    ranks_h = _run(8, tmp_path, extra=("plain", "host_prefetch"))
+    acts = np.concatenate([r["acts"] for r in ranks_h], axis=2)             # (epoch, T, N_total, A)
+    assert np.array_equal(acts[0], single_h["acts"][0])                      # same parameters: the same actions, bit for bit
+    np.testing.assert_allclose(acts, single_h["acts"], atol=2e-5)
+    for r in ranks_h:
+        assert np.array_equal(r["tail"], single_h["tail"])                   # the CPU stream ends where the draws for ALL envs leave it
+        assert np.array_equal(r["pf"], ranks_h[0]["pf"]) and int(r["prefetched"]) >= 1
+    np.testing.assert_allclose(ranks_h[0]["pf"], single_h["pf"], atol=2e-6)
+
+
+def test_eight_ranks_at_cfg4_size_reproduce_one_process(tmp_path):
+    """The same at BASELINE cfg 4's real sizes: 16 384 envs x 128 steps, 8 ranks x 2048 envs with minibatches of 32 time rows
+    (65 536 samples per rank, 524 288 globally) against ONE process holding all 16 384 envs.  Every rank's rollout buffers
+    are the column blocks of the one-process buffers, parameters are bit-identical across the eight ranks after two
+    epochs of 8 updates and follow the one-process parameters up to the order of the gradient sum."""
+    sizes = {"TRL_TEST_SIZES": "16384,128,32,2"}
+    (single,) = _run(1, tmp_path, env=sizes)
+    ranks = _run(8, tmp_path, env=sizes)
+    assert single["obs"].shape == (128, 16384, 17) and ranks[0]["obs"].shape == (128, 2048, 17)
+    np.testing.assert_allclose(np.concatenate([r["obs"] for r in ranks], axis=1), single["obs"], atol=2e-6)
+    np.testing.assert_allclose(np.concatenate([r["rewards"] for r in ranks], axis=1), single["rewards"], atol=2e-6)
+    # the first epoch's actions come from identical parameters: the shards are the column blocks, bit for bit
+    assert np.array_equal(np.concatenate([r["acts"][0] for r in ranks], axis=1), single["acts"][0])
+    for r in ranks[1:]:
+        assert np.array_equal(r["pf"], ranks[0]["pf"]) and np.array_equal(r["vf"], ranks[0]["vf"])
+        np.testing.assert_allclose(r["infos"], ranks[0]["infos"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(ranks[0]["pf"], single["pf"], atol=2e-6)
+    np.testing.assert_allclose(ranks[0]["vf"], single["vf"], atol=2e-6)
+    np.testing.assert_allclose(ranks[0]["infos"], single["infos"], rtol=2e-4, atol=2e-5)
+
+
 def test_two_ranks_reproduce_one_process_a2c(tmp_path):
     """A2C logs value-prediction statistics (a2c.py:86-105): their sums / extrema are pooled over the ranks as well."""
     (single,) = _run(1, tmp_path, extra=("a2c",))
@@ -140,11 +188,13 @@ def test_one_rank_rccl_communicator_with_peer_transport(tmp_path):
     np.testing.assert_allclose(forced["infos"], single["infos"], rtol=2e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl"), (8, "gloo")])
 def test_abi_collectives_small_mid_large_and_graph_replay(tmp_path, world, backend):
     """trl_allreduce_sum_f32 / trl_allreduce_f64 through torchrl_amd.dist on their own: the statistics region (<= 4096 words),
     the gradient region (<= 12 288 floats), beyond it (RCCL on the nccl group, torch.distributed on the gloo one), the
-    mixed SUM / MAX statistics rows, and a captured all-reduce replayed three times."""
+    mixed SUM / MAX statistics rows, and a captured all-reduce replayed three times.  world = 8: BASELINE cfg 4's layout --
+    eight processes, eight hipIpc-mapped buffers of 8 slots x 2 halves each, every granule summed over the 8 slots in rank
+    order (all results exact: the test values are small integers)."""
     outs = _run(world, tmp_path, "_dist_gpu_worker_comm.py", (backend,))
     tot = sum(r + 1 for r in range(world))
     for r, o in enumerate(outs):

@@ -24,11 +24,31 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def noise_helper_tag():
+    """What a helper built now would be built for: this interpreter's torch version and C++ ABI flag."""
+    import torch
+    return "%s abi%d" % (torch.__version__, int(torch.compiled_with_cxx11_abi()))
+
+
+def noise_helper_built_for(path=None):
+    """The tag compiled into an existing libtrl_noise.so (read from the file, without loading it: a helper made for another
+    torch must not get the chance to pull its libtorch in), or None."""
+    import re
+    try:
+        with open(path or NOISE_LIB, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    m = re.search(rb"(\d+\.\d+[^\x00 ]* abi[01])\x00", blob)
+    return m.group(1).decode() if m else None
+
+
 def build_noise_helper(force=False, verbose=True):
     """libtrl_noise.so: csrc/trl_noise_ext.cpp against this interpreter's libtorch (g++, host only).  Optional -- returns
     None (and says why) when the torch headers or g++ are not there; collector/noise.py then draws from Python threads."""
     src = os.path.join(CSRC, NOISE_SRC)
-    if not force and os.path.exists(NOISE_LIB) and os.path.getmtime(NOISE_LIB) >= os.path.getmtime(src):
+    if not force and os.path.exists(NOISE_LIB) and os.path.getmtime(NOISE_LIB) >= os.path.getmtime(src) \
+            and noise_helper_built_for() == noise_helper_tag():
         return NOISE_LIB
     try:
         import torch
@@ -38,7 +58,8 @@ def build_noise_helper(force=False, verbose=True):
             raise RuntimeError("g++ not found")
         libp = ce.library_paths()
         cmd = [gxx, "-O2", "-std=c++17", "-shared", "-fPIC"] + ["-I" + i for i in ce.include_paths()] + \
-              ["-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch.compiled_with_cxx11_abi()), src, "-o", NOISE_LIB] + \
+              ["-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch.compiled_with_cxx11_abi()),
+               '-DTRL_NOISE_BUILT_FOR="%s"' % noise_helper_tag(), src, "-o", NOISE_LIB] + \
               ["-L" + p for p in libp] + ["-ltorch_cpu", "-lc10"] + ["-Wl,-rpath," + p for p in libp]
         os.makedirs(LIB_DIR, exist_ok=True)
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

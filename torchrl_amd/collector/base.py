@@ -402,6 +402,18 @@ class VecCollector(_CollectorBase):
             buf._advance()
         self.global_step += 1
 
+    def _capture_key_extras(self, env, net):
+        """Everything else a captured collection sequence bakes in besides the ring: the env's seed base, the bookkeeping
+        tensors (step / return counters, reset mask, header, episode log, env clock) and the parameter storages of the
+        network it runs -- a re-seed, a `.to()` or a checkpoint load that replaces tensors must force a fresh eager pass and
+        a re-capture instead of replaying stale values or freed pointers."""
+        ptr = lambda t: t.data_ptr() if isinstance(t, torch.Tensor) else None
+        params = [p for p in net.parameters()] if net is not None else []
+        return (int(getattr(env, "seed_base", 0)), int(getattr(env, "action_num", 0) or 0), ptr(getattr(env, "t_env", None)),
+                ptr(getattr(env, "cur_step", None)), ptr(getattr(env, "ep_return", None)), ptr(getattr(env, "episode_idx", None)),
+                ptr(self._mask), ptr(self._hdr), ptr(self._ep_log), id(net), len(params),
+                params[0].data_ptr() if params else None, params[-1].data_ptr() if params else None)
+
     def _replayed_rollout(self, n_steps):
         """Training collection on the synthetic vector env with device noise, one rank: a vector step = the policy pass +
         trl_synth_collect_step_f32 with its device-side state, whose step counter / ring row / epoch start live on the device -- captured into
@@ -424,7 +436,8 @@ class VecCollector(_CollectorBase):
         host[0], host[1], host[2], host[3] = self.global_step, buf._top, self._log_step0, 0
         self._dyn_stager.upload(self._dyn)                                 # one 32-byte upload per epoch
         key = tuple(t.data_ptr() for t in ring) + (env.cur_obs.data_ptr(), n, d, a_dim, int(self.max_episode_frames),
-                                                   bool(pf.tanh_action), int(env.horizon), n_steps)
+                                                   bool(pf.tanh_action), int(env.horizon), n_steps) \
+            + self._capture_key_extras(env, pf)
 
         def one_step():
             head, _ = ops.mlp_forward(ops.linear_layers(pf), env.cur_obs, ops.act_code(pf), keep=False)
@@ -470,7 +483,8 @@ class VecCollector(_CollectorBase):
         rows = int(ring[0].shape[0])
         A, Q = int(pf.action_shape), int(pf.quantile_num)
         key = tuple(t.data_ptr() for t in ring) + (env.cur_obs.data_ptr(), n, shape, A, Q, int(self.max_episode_frames),
-                                                   int(env.horizon), n_steps, id(pf.qf), rows)
+                                                   int(env.horizon), n_steps, id(pf.qf), rows) \
+            + self._capture_key_extras(env, pf.qf)
         st = getattr(self, "_fr", None)
         if st is None or st["key"] != key:
             st = self._fr = {"key": key, "graph": None, "seen": False,

@@ -102,15 +102,44 @@ def native_helper():
         path = os.path.join(os.path.dirname(_C.LIB_PATH), "libtrl_noise.so")
         if os.environ.get("TRL_NOISE_HELPER") != "0" and os.path.exists(path):
             try:
+                from .. import build as _build
+                made_for, now = _build.noise_helper_built_for(path), _build.noise_helper_tag()
+                if made_for != now:                  # built against another torch: loading it would map a second libtorch
+                    _log.warning("libtrl_noise.so was built for torch %s, this is %s: not loaded (python -c 'import "
+                                 "__graft_entry__ as g; g.build()' rebuilds it); the chunks are drawn from Python threads",
+                                 made_for, now)
+                    return None
                 lib = C.CDLL(path)
                 lib.trl_noise_draw_chunks.restype = C.c_int
                 lib.trl_noise_draw_chunks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
                 lib.trl_noise_last_error.restype = C.c_char_p
-                if lib.trl_noise_abi_version() == 1:
+                if lib.trl_noise_abi_version() == 1 and _native_check(lib):
                     _ext_lib = lib
             except (OSError, AttributeError):
                 _ext_lib = None
     return _ext_lib
+
+
+def _native_check(lib):
+    """One block through the helper against plain `torch.randn` on a private generator, before it is trusted."""
+    try:
+        g = torch.Generator()
+        g.manual_seed(977)
+        torch.randn(100, generator=g)
+        s0 = g.get_state()
+        if not _layout_known(s0):
+            return False
+        n, cut = 4096, [0, 1024, 2048 + 16, 4096]
+        want = torch.randn(n, generator=g)
+        recs = states_at(s0, cut)
+        got = torch.empty(n)
+        _draw_native(lib, recs, got, [(a, a, b) for a, b in zip(cut[:-1], cut[1:])], 3)
+        ok = bool(torch.equal(got, want))
+        if not ok:
+            _log.warning("libtrl_noise.so does not reproduce torch.randn on this build: not used")
+        return ok
+    except Exception:                                                   # noqa: BLE001
+        return False
 
 
 def _draw_native(lib, recs, flat, pieces, threads):

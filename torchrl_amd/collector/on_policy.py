@@ -309,8 +309,10 @@ class VecOnPolicyCollector(VecCollector):
             os.environ.get("TRL_GENERIC_PPO") != "1"
         mlp2 = pair and lib.trl_mlp2_forward_supported(ps[0], ps[1], ps[2]) and lib.trl_mlp2_forward_supported(ps[0], ps[1], 1)
         self._mlp2 = ps if mlp2 else None                                   # fused 2-layer forward kernel usable
+        # (TRL_NO_RT_ROLLOUT=1 switches the RUNTIME-dims instantiations off for A/B measurements; the compile-time benchmark
+        # shape -- the one the fused forward is instantiated for -- keeps its rollout kernel)
         roll = pair and bool(lib.trl_rollout_supported(ps[0], ps[1], ps[2], ps[3])) and \
-            os.environ.get("TRL_NO_RT_ROLLOUT") != "1"
+            (bool(mlp2) or os.environ.get("TRL_NO_RT_ROLLOUT") != "1")
         self._spec = ps if (roll and not getattr(self.env, "is_host_env", False)) else None   # ... and the rollout kernel
 
     def _forward(self, net, x, out_dim, out=None):
@@ -419,7 +421,13 @@ class VecOnPolicyCollector(VecCollector):
         n, w = env.env_nums, dist.world_size()
         if w == 1:
             return n, 0
-        return int(getattr(env, "total_env_nums", n * w)), int(getattr(env, "index_offset", dist.rank() * n))
+        n_total, e0 = int(getattr(env, "total_env_nums", n * w)), int(getattr(env, "index_offset", dist.rank() * n))
+        if n_total == n:
+            # envs built without total_env_nums / index_offset on a multi-rank run (the env's default is its own count): every
+            # rank would take the one-process path and draw the SAME block.  Same convention as the device-noise and
+            # epsilon-greedy paths (dist.shard_rows_of_global): rank r owns rows [r * n, (r + 1) * n) of an n * w draw.
+            n_total, e0 = n * w, dist.rank() * n
+        return n_total, e0
 
     def _host_noise(self, n_steps, env):
         """The reference's CPU stream, step by step; with env shards on several ranks, this rank's rows of each draw."""
@@ -609,8 +617,13 @@ class VecOnPolicyCollector(VecCollector):
         if getattr(self, "_noise_gated", False) and self.train_epoch_reward != self.train_epoch_reward:
             # the kernel poisons the epoch reward when its wait for the staged noise block times out (k_rollout.hip): that
             # rollout read a stale block -- an error, not data (the reference stops on NaN too, collector/on_policy.py:102-107)
-            raise _C.TrlError("rollout: NaN epoch reward -- the staged exploration-noise block never arrived (stamp wait "
-                              "timed out) or the policy produced NaN actions; the collected rollout must not be trained on")
+            import logging
+            msg = ("rollout: NaN epoch reward -- the staged exploration-noise block never arrived (stamp wait timed out) or "
+                   "the policy produced NaN actions.  The collected rollout is not valid data; an update that was launched "
+                   "on it before this result was read (RLAlgo.train launches the update first and reads the epoch result "
+                   "after) HAS changed the parameters: restore the last snapshot before continuing")
+            logging.getLogger("torchrl_amd").error(msg)
+            raise _C.TrlError(msg)
         if getattr(self, "_check_rendezvous", False):
             self._check_rendezvous = False
             if int(self._norm_ws[:2].view(torch.int32)[2].item()) != 0:

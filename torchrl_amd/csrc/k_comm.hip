@@ -178,6 +178,24 @@ extern "C" int trl_comm_error_detail(trl_comm_t* c, int32_t* out) {
   return TRL_OK;
 }
 
+// Pre-flight of a multi-GPU run (host, no communicator needed): out[3] = {peer access possible from dev_a to dev_b
+// (hipDeviceCanAccessPeer), link type (hsa_amd_link_info_type_t: 2 PCIe, 4 xGMI; -1 unknown), hops}.
+extern "C" int trl_comm_link_info(int dev_a, int dev_b, int32_t* out) {
+  TRL_REQUIRE(out, "null pointer");
+  out[0] = 0; out[1] = -1; out[2] = 0;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  TRL_REQUIRE(dev_a >= 0 && dev_b >= 0 && dev_a < n && dev_b < n, "device index out of range");
+  if (dev_a == dev_b) { out[0] = 1; return TRL_OK; }
+  int can = 0;
+  HIP_TRY(hipDeviceCanAccessPeer(&can, dev_a, dev_b));
+  out[0] = can;
+  uint32_t type = 0, hops = 0;
+  if (hipExtGetLinkTypeAndHopCount(dev_a, dev_b, &type, &hops) == hipSuccess) { out[1] = (int32_t)type; out[2] = (int32_t)hops; }
+  else (void)hipGetLastError();
+  return TRL_OK;
+}
+
 extern "C" int trl_comm_destroy(trl_comm_t* c) {
   if (!c) return TRL_OK;
   for (int r = 0; r < c->world; ++r)

@@ -23,6 +23,12 @@ static thread_local std::string g_noise_err;
 
 extern "C" const char* trl_noise_last_error(void) { return g_noise_err.c_str(); }
 extern "C" int trl_noise_abi_version(void) { return 1; }
+// the torch build this helper was compiled against ("<torch.__version__> abi<0|1>", from the build command): the loader
+// refuses a helper made for another torch -- its rpath would pull a second libtorch into the process
+#ifndef TRL_NOISE_BUILT_FOR
+#define TRL_NOISE_BUILT_FOR "unknown"
+#endif
+extern "C" const char* trl_noise_built_for(void) { return TRL_NOISE_BUILT_FOR; }
 
 // chunk k: generator state image states[k * state_bytes ..) -> out[out_off[k] .. out_off[k] + out_len[k]) standard normals
 extern "C" int trl_noise_draw_chunks(const uint8_t* states, int64_t state_bytes, int64_t n_chunks, float* out,

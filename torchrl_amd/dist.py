@@ -34,6 +34,12 @@ _FORCE = os.environ.get("TRL_FORCE_COLLECTIVES", "0") == "1"
 _comm = None            # ctypes handle of the trl_comm_t
 _peer_ok = False        # peers mapped AND the self-check passed on every rank
 _has_rccl = False
+_peer_report = {}       # what init_comm found: self-check result, ranks per device, why the peers are (not) used
+# The peer transport waits INSIDE kernels (a rank's fold launch polls until every rank's granules have arrived), so every
+# rank's launches must be able to run at the same time.  One rank per GPU: always.  Ranks SHARING a GPU (the one-GPU
+# tests): a waiting fold launch holds 180 blocks x 8 waves, two of them leave no SIMD with the 416 free registers another
+# rank's gradient kernel needs -- beyond 2 ranks per device the ranks would wait for each other until the time-out.
+MAX_PEER_RANKS_PER_DEVICE = 2
 _SMALL_CAP = 4096       # TRL_XR_CAP_SMALL: 32-bit words per message of the peer transport (statistics region)
 _GRAD_CAP = 12288       # TRL_XR_CAP_GRAD: floats per message of its gradient region
 
@@ -98,10 +104,12 @@ def _all_agree(flag):
     return all(votes)
 
 
-def init_comm(device=None, use_rccl=None, peers=True):
+def init_comm(device=None, use_rccl=None, peers=True, allow_shared_device=False):
     """Create the trl_comm_t of this process group (idempotent).  `use_rccl` defaults to "the process group is
     nccl" (several ranks per device, as in the single-GPU tests, cannot form an RCCL communicator).  Every step is
-    voted on by all ranks, so all of them end up on the same transport.  Returns peer_ready()."""
+    voted on by all ranks, so all of them end up on the same transport.  Returns peer_ready().
+    allow_shared_device: keep the peers although more than MAX_PEER_RANKS_PER_DEVICE ranks share a GPU -- only for callers
+    whose launches all stay small (the stand-alone all-reduces: tests of the 8-slot buffer layout on one GPU)."""
     global _comm, _peer_ok, _has_rccl
     if _comm is not None or not initialized():
         return peer_ready()
@@ -143,9 +151,79 @@ def init_comm(device=None, use_rccl=None, peers=True):
         if _all_agree(ok):
             _peer_ok = True
             _peer_ok = _all_agree(_self_check(dev))
+        _peer_report["self_check"] = "passed on every rank (%d slots per buffer)" % w if _peer_ok else "failed or unavailable"
+        # ranks per physical device (host name + PCI bus id): see MAX_PEER_RANKS_PER_DEVICE
+        try:
+            import socket
+            props = torch.cuda.get_device_properties(dev)
+            key = (socket.gethostname(), getattr(props, "pci_bus_id", dev.index), getattr(props, "pci_device_id", 0),
+                   getattr(props, "pci_domain_id", 0), str(getattr(props, "uuid", "")))
+        except Exception:                                                  # noqa: BLE001
+            key = ("?", dev.index)
+        keys = [None] * w
+        td.all_gather_object(keys, key)
+        sharing = max(keys.count(k) for k in keys)
+        _peer_report["ranks_per_device"] = sharing
+        if _peer_ok and sharing > MAX_PEER_RANKS_PER_DEVICE and not allow_shared_device:
+            _peer_ok = False
+            _peer_report["not_used"] = ("%d ranks share one device: the in-kernel waits of the peer transport need every "
+                                        "rank's launches co-resident (at most %d ranks per device)"
+                                        % (sharing, MAX_PEER_RANKS_PER_DEVICE))
         if not _peer_ok and ok:
             lib.trl_comm_peer_enable(handle, 0)
     return peer_ready()
+
+
+def peer_report():
+    """What init_comm established about the peer transport (for bench.py's `config`)."""
+    return dict(_peer_report)
+
+
+def link_preflight(devices):
+    """Pre-flight of a one-node multi-GPU run: for every ordered pair of the given device indices whether peer access is
+    possible (hipDeviceCanAccessPeer) and over what (hipExtGetLinkTypeAndHopCount: xGMI or PCIe, hops) -- the peer
+    transport pushes granules straight into the other GPUs' memory, RCCL rings run over the same links.  Returns
+    {"pairs": n, "peer_access_all": bool, "links": {"xgmi": k, "pcie": m, ...}, "max_hops": h, "no_access": [...]}."""
+    from . import _C
+    lib = _C.lib()
+    names = {0: "hypertransport", 1: "qpi", 2: "pcie", 3: "infiniband", 4: "xgmi"}       # hsa_amd_link_info_type_t
+    out = {"pairs": 0, "peer_access_all": True, "links": {}, "max_hops": 0, "no_access": []}
+    devs = sorted(set(int(d) for d in devices))
+    for a in devs:
+        for b in devs:
+            if a == b:
+                continue
+            info = (C.c_int32 * 3)()
+            rc = lib.trl_comm_link_info(a, b, info)
+            out["pairs"] += 1
+            if rc != 0 or not info[0]:
+                out["peer_access_all"] = False
+                out["no_access"].append([a, b])
+                continue
+            name = names.get(int(info[1]), "type%d" % info[1]) if info[1] >= 0 else "unknown"
+            out["links"][name] = out["links"].get(name, 0) + 1
+            out["max_hops"] = max(out["max_hops"], int(info[2]))
+    return out
+
+
+def pin_rank_cpus(local_rank, local_world, reserve=0):
+    """Give every local rank its own slice of the host's cores (this process and the threads it starts later: the
+    reference-noise draw runs `noise.default_threads()` host threads per rank, one rollout ahead of the device -- eight
+    ranks' pools must not migrate over each other).  Slices are contiguous blocks of the CPUs this process may run on,
+    so that a rank's threads share a cache complex.  Returns the CPU list, or None when the platform cannot pin."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    per = (len(cpus) - reserve) // max(1, int(local_world))
+    if per < 2 or local_world <= 1:
+        return None
+    mine = cpus[reserve + local_rank * per: reserve + (local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
 
 
 def _self_check(dev):
