@@ -858,6 +858,15 @@ int trl_mt19937_advance(uint32_t* state, int32_t* left, int64_t* next, int64_t c
  * makes the column blocks a partition of the reference's minibatch). */
 int trl_mt19937_states_at(const uint8_t* tmpl, int64_t state_bytes, int64_t off_left, int64_t off_next, int64_t off_mt,
                           const int64_t* pos, int64_t K, uint8_t* out);
+/* The same records (byte for byte) derived by `threads` host threads: the position list is cut into contiguous groups and
+ * every group but the first starts from the template JUMPED ahead -- F^J = (x^J mod phi)(F) for MT19937's GF(2)-linear
+ * transition F, ~0.2 ms per jump whatever J is, the polynomials cached per process (csrc/trl_mtjump.cpp).  At BASELINE
+ * cfg 4 (8 ranks, 16 384 envs: 12.6 M engine calls per rollout between a rank's first and last chunk) the pass drops from
+ * 2.4 ms of one thread to the time of one group.  trl_mt19937_jump_ready(): 1 once phi has been derived and checked
+ * (Berlekamp-Massey on the recurrence, ~30 ms, first call); 0 = the _mt entry falls back to the sequential pass. */
+int trl_mt19937_states_at_mt(const uint8_t* tmpl, int64_t state_bytes, int64_t off_left, int64_t off_next, int64_t off_mt,
+                             const int64_t* pos, int64_t K, uint8_t* out, int threads);
+int trl_mt19937_jump_ready(void);
 
 /* --- calibration of the two rooflines (nominal AND achievable peaks) -------------------
  * No reference counterpart (the reference publishes no measurement); run by bench.py after its timed

@@ -122,10 +122,14 @@ def test_implicit_gemm_channels_last_conv_vs_torch(B, C, H, W, kh, kw, sh, sw, C
     (2, 16, 5, 4, 5, 4, 1, 1, 16),         # Ho = Wo = 1
 ])
 @pytest.mark.parametrize("act", ["relu", "tanh", "none"])
-def test_implicit_transposed_conv_input_gradient_vs_torch(B, C, H, W, kh, kw, sh, sw, Cout, act):
+@pytest.mark.parametrize("form", ["image", "class"])
+def test_implicit_transposed_conv_input_gradient_vs_torch(B, C, H, W, kh, kw, sh, sw, Cout, act, form, monkeypatch):
     """trl_conv_bwd_input_nhwc_f32 (no cols matrix) against autograd's conv2d input gradient, and against the
-    cols-GEMM + col2im pair it replaces."""
+    cols-GEMM + col2im pair it replaces.  Both forms of the kernel: `image` (the gated dZ of whole images staged in LDS once;
+    what every geometry whose weights + one image fit in LDS runs) and `class` (dZ re-read per tap: the larger layers),
+    which must agree bit for bit -- the same MFMA sequence per output element."""
     from torchrl_amd import _C
+    monkeypatch.setenv("TRL_DX_CLASS_FORM", "1" if form == "class" else "0")
     gen = torch.Generator().manual_seed(B * 10 + C + Cout)
     x = torch.randn(B, C, H, W, generator=gen).requires_grad_(True)
     w = torch.randn(Cout, C, kh, kw, generator=gen) / (C * kh * kw) ** 0.5
@@ -144,6 +148,14 @@ def test_implicit_transposed_conv_input_gradient_vs_torch(B, C, H, W, kh, kw, sh
     assert (got.cpu() - want).abs().max().item() < 2e-5 * scale
     old = _C.col2im(_C.linear_bwd_input(rows(dy), gate, code, wd), B, C, H, W, kh, kw, sh, sw)
     assert (got - old).abs().max().item() < 2e-5 * scale
+    if form == "image":
+        monkeypatch.setenv("TRL_DX_CLASS_FORM", "1")
+        assert torch.equal(_C.conv_bwd_input_nhwc(rows(dy), gate, code, wd, B, C, H, W, kh, kw, sh, sw), got)
+        monkeypatch.setenv("TRL_DX_CLASS_FORM", "0")
+        for img in ("1", "3"):                                              # images per workgroup: ragged last group
+            monkeypatch.setenv("TRL_DX_IMG", img)
+            assert torch.equal(_C.conv_bwd_input_nhwc(rows(dy), gate, code, wd, B, C, H, W, kh, kw, sh, sw), got)
+        monkeypatch.delenv("TRL_DX_IMG")
     # the weights re-ordered ahead, together with another layer's, by ONE launch (trl_conv_bwd_input_nhwc_prep_f32)
     other = torch.randn(32, 16 * 3 * 3, generator=torch.Generator().manual_seed(1)).to(DEV)   # (its own stream: `gen` goes on below)
     preps = _C.conv_bwd_input_prep([(other, 16, 3, 3, 1, 1), (wd, C, kh, kw, sh, sw)], DEV)

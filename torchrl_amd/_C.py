@@ -245,6 +245,9 @@ SIGNATURES = {
     "trl_linear_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_mt19937_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "trl_mt19937_states_at": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "trl_mt19937_states_at_mt": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.c_int]),
+    "trl_mt19937_jump_ready": (C.c_int, []),
     "trl_peak_copy_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "trl_peak_mfma_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "trl_adv_normalize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

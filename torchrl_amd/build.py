@@ -10,7 +10,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libtrl_hip.so")
 NOISE_LIB = os.path.join(LIB_DIR, "libtrl_noise.so")     # host helper of the reference noise stream; links libtorch (optional)
 NOISE_SRC = "trl_noise_ext.cpp"
-SOURCES = ["trl_host.cpp", "k_gae.hip", "k_gather.hip", "k_ppo.hip", "k_ppo_generic.hip", "k_vmpo.hip", "k_trpo.hip", "k_rollout.hip", "k_gemm.hip", "k_mlp3.hip", "k_conv1.hip", "k_conv_dx.hip", "k_sac.hip", "k_conv.hip", "k_dqn.hip", "k_norm.hip", "k_frames.hip", "k_comm.hip", "k_peaks.hip"]
+SOURCES = ["trl_host.cpp", "trl_mtjump.cpp", "k_gae.hip", "k_gather.hip", "k_ppo.hip", "k_ppo_generic.hip", "k_vmpo.hip", "k_trpo.hip", "k_rollout.hip", "k_gemm.hip", "k_mlp3.hip", "k_conv1.hip", "k_conv_dx.hip", "k_sac.hip", "k_conv.hip", "k_dqn.hip", "k_norm.hip", "k_frames.hip", "k_comm.hip", "k_peaks.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable"]
 

@@ -48,7 +48,8 @@ _GROUP_CHUNKS = 16                           # chunk states are derived this man
 _pool, _pool_lock, _gens = None, threading.Lock(), threading.local()
 _checked = None                              # None: not yet; True / False: result of the self-check
 _log = logging.getLogger("torchrl_amd")
-STATS = {"blocks": 0, "parallel_blocks": 0, "pieces": 0, "native_blocks": 0}     # what draw_block did so far (tests assert the parallel path ran)
+JUMP_MIN_CALLS = 1 << 21                     # streams at least this long are walked by several threads (jump-ahead)
+STATS = {"blocks": 0, "parallel_blocks": 0, "pieces": 0, "native_blocks": 0, "jump_passes": 0}     # what draw_block did so far (tests assert the parallel path ran)
 
 
 def default_threads():
@@ -68,13 +69,21 @@ def _layout_known(state):
     return state.dtype == torch.uint8 and state.numel() == _STATE_BYTES
 
 
-def states_at(state, positions):
-    """uint8 tensor (K, state bytes): `state` moved forward to each of the ascending engine-call positions."""
+def states_at(state, positions, threads=1):
+    """uint8 tensor (K, state bytes): `state` moved forward to each of the ascending engine-call positions.  threads > 1:
+    the pass over a long stream is shared by that many host threads, all but the first starting from a JUMPED state
+    (trl_mt19937_states_at_mt: the same records, byte for byte)."""
     if not _layout_known(state):
         raise _C.TrlError("CPU generator state of %d bytes: layout unknown to torchrl_amd.collector.noise" % state.numel())
     pos = np.ascontiguousarray(positions, dtype=np.int64)
     tmpl = state.contiguous()
     out = torch.empty(len(pos), _STATE_BYTES, dtype=torch.uint8)
+    if threads > 1 and len(pos) > 1 and int(pos[-1]) >= JUMP_MIN_CALLS and os.environ.get("TRL_NOISE_JUMP") != "0":
+        STATS["jump_passes"] += 1
+        _C.check(_C.lib().trl_mt19937_states_at_mt(tmpl.data_ptr(), _STATE_BYTES, _OFF_LEFT, _OFF_NEXT, _OFF_MT,
+                                                   pos.ctypes.data_as(C.c_void_p), len(pos), out.data_ptr(), int(threads)),
+                 "trl_mt19937_states_at_mt")
+        return out
     _C.check(_C.lib().trl_mt19937_states_at(tmpl.data_ptr(), _STATE_BYTES, _OFF_LEFT, _OFF_NEXT, _OFF_MT,
                                             pos.ctypes.data_as(C.c_void_p), len(pos), out.data_ptr()),
              "trl_mt19937_states_at")
@@ -237,7 +246,7 @@ def draw_block(state0, out, n_chunks=1, stride=None, offset=0, threads=None):
     STATS["parallel_blocks"] += 1
     ext = native_helper()
     if ext is not None:                                                 # one pass over the stream, then every chunk natively
-        recs = states_at(state0, [p[0] for p in pieces] + [end_pos])
+        recs = states_at(state0, [p[0] for p in pieces] + [end_pos], threads=threads)
         _draw_native(ext, recs, flat, pieces, threads)
         STATS["native_blocks"] += 1
         return recs[-1].clone()

@@ -162,6 +162,165 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_kernel(const float* __rest
   }
 }
 
+
+// ---- image-tile form: the gated dZ of a few whole images is staged in LDS ONCE and every tap reads it from there ----
+// The class form above re-reads a tile's dZ (and its gate) through L1 once per tap: at cfg 5 that is ~64 B/clk/CU of
+// half-used cache lines -- the L1's whole bandwidth -- for 32 MFMAs per tap, and the activation derivative is recomputed
+// per tap (rocprofv3 round 4: 0.24 / 0.33 MFMA-busy, SQ_WAIT_INST_ANY 1.3x SQ_ACTIVE_INST_ANY).  Here a workgroup owns
+// `img` whole images: it stages ALL classes' re-ordered weights and dZ = dY * act'(Y) of its images (rows padded to
+// Cout + 4 floats: the 16 lanes of a ds_read_b128 group hit 16 different bank quads), then walks the parity classes;
+// a wave takes 16-position blocks of a class, its A operand is one 16-byte LDS read per (tap, 16 output channels).
+// Same MFMA sequence per output element as the class form (taps ascending, then channels): bit-identical results.
+template <int CB, int NCH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv_dx_img_kernel(const float* __restrict__ dy, const float* __restrict__ yg,
+                                                          const float* __restrict__ wprep, float* __restrict__ dx,
+                                                          const float* __restrict__ xg, DxGeom g, int img_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float Ws[];
+  constexpr int COUT = 16 * NCH, LDZ = COUT + 4, TAP = 16 * NCH * 16 * CB, THREADS = 64 * WAVES, Q = COUT / 4;
+  const int wfloats = COUT * 16 * CB * g.kh * g.kw;
+  float* Zs = Ws + wfloats;
+  const int img0 = blockIdx.x * img_per_wg;
+  const int nimg = min(img_per_wg, g.B - img0);
+  const int HW = g.Ho * g.Wo;
+  const bool gated = yg != nullptr && g.gate_act != TRL_ACT_NONE;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(wprep);
+    f32x4* dst = reinterpret_cast<f32x4*>(Ws);
+    const int n4 = wfloats / 4;
+    for (int e = threadIdx.x; e < n4; e += 8 * THREADS) {        // 8 loads in flight per thread
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (e + THREADS * k < n4) v[k] = src[e + THREADS * k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (e + THREADS * k < n4) dst[e + THREADS * k] = v[k];
+    }
+    const int nz = nimg * HW * Q;                                // 16-byte pieces of the images' dZ
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy) + (size_t)img0 * HW * Q;
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(yg) + (size_t)img0 * HW * Q;
+    for (int e = threadIdx.x; e < nz; e += 4 * THREADS) {
+      f32x4 v[4], y[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ee = e + THREADS * k;
+        if (ee < nz) { v[k] = d4[ee]; if (gated) y[k] = y4[ee]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ee = e + THREADS * k;
+        if (ee >= nz) break;
+        if (gated) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[k][r] *= dx_dact(g.gate_act, y[k][r]);
+        }
+        const int row = ee / Q, q = ee - row * Q;
+        *reinterpret_cast<f32x4*>(Zs + row * LDZ + 4 * q) = v[k];
+      }
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, gq = lane >> 4;
+  int woff = 0;
+  for (int cls = 0; cls < g.sh * g.sw; ++cls) {
+    const int py = cls / g.sw, px = cls - py * g.sw;
+    const int Hc = py < g.H ? (g.H - py + g.sh - 1) / g.sh : 0, Wc = px < g.W ? (g.W - px + g.sw - 1) / g.sw : 0;
+    const int nti = py < g.kh ? (g.kh - py + g.sh - 1) / g.sh : 0, ntj = px < g.kw ? (g.kw - px + g.sw - 1) / g.sw : 0;
+    const int ntap = nti * ntj, rows = nimg * Hc * Wc;
+    const float* Wc_lds = Ws + woff;
+    woff += ntap * TAP;
+    if (rows <= 0 || ntap <= 0) continue;
+    const float inv_wc = 1.0f / (float)Wc, inv_hc = 1.0f / (float)Hc, inv_ntj = 1.0f / (float)ntj;
+    for (int row0 = 16 * wave; row0 < rows; row0 += 16 * WAVES) {
+      const int row = row0 + j;                                  // A row of this lane
+      const bool row_ok = row < rows;
+      int b = 0, yq = 0, xq = 0;
+      if (row_ok) { const int t = dx_div(row, Wc, inv_wc); xq = row - t * Wc; b = dx_div(t, Hc, inv_hc); yq = t - b * Hc; }
+      f32x4 acc[CB];
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      constexpr int G = 8 / NCH;
+      f32x4 a[G][NCH];
+      for (int t0 = 0; t0 < ntap; t0 += G) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const int t = t0 + u;
+          if (t >= ntap) break;
+          const int ti = dx_div(t, ntj, inv_ntj), tj = t - ti * ntj;
+          const int oy = yq - ti, ox = xq - tj;
+          const bool ok = row_ok && oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo;
+          const float* zr = Zs + (ok ? ((b * g.Ho + oy) * g.Wo + ox) * LDZ + 4 * gq : 0);
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {
+            const f32x4 z = *reinterpret_cast<const f32x4*>(zr + 16 * ch);
+            a[u][ch] = ok ? z : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (t0 + u >= ntap) break;
+          const float* wt = Wc_lds + (t0 + u) * TAP + lane;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int cb = 0; cb < CB; ++cb)
+                acc[cb] = mfma16(a[u][ch][r], wt[((ch * 4 + r) * CB + cb) * 64], acc[cb]);
+        }
+      }
+      // C reg r of lane (j, gq): position 4 gq + r of the wave's block, input channel 16 cb + j
+      const int orow0 = row0 + 4 * gq;
+      const int t0o = dx_div(orow0, Wc, inv_wc);
+      int xo = orow0 - t0o * Wc, bo = dx_div(t0o, Hc, inv_hc), yo = t0o - bo * Hc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (orow0 + r >= rows) break;
+        if (r > 0 && ++xo == Wc) { xo = 0; if (++yo == Hc) { yo = 0; ++bo; } }   // the next position of the class
+        const size_t o = (((size_t)(img0 + bo) * g.H + (g.sh * yo + py)) * g.W + (g.sw * xo + px)) * g.Cin + j;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          float v = acc[cb][r];
+          if (xg) v *= dx_dact(g.x_gate_act, xg[o + 16 * cb]);   // hand the previous layer its dZ, not its dY
+          dx[o + 16 * cb] = v;
+        }
+      }
+    }
+  }
+}
+
+// images per workgroup of the image-tile form, 0 = the layer does not fit (use the class form): all classes' weights plus
+// the padded dZ of the images within 150 KB of LDS; as many images as keeps the grid at one workgroup per CU or more
+static int dx_img_per_wg(const DxGeom& g, int* lds_bytes) {
+  const int64_t wbytes = (int64_t)g.Cout * g.Cin * g.kh * g.kw * 4;
+  const int64_t zbytes = (int64_t)g.Ho * g.Wo * (g.Cout + 4) * 4;
+  if (getenv("TRL_DX_CLASS_FORM") && atoi(getenv("TRL_DX_CLASS_FORM"))) return 0;
+  if (wbytes + zbytes > 150 * 1024 || (int64_t)g.Ho * g.Wo > 4096) return 0;
+  int img = std::max(1, std::min(4, g.B / 256));
+  if (getenv("TRL_DX_IMG")) img = std::max(1, atoi(getenv("TRL_DX_IMG")));
+  while (img > 1 && wbytes + img * zbytes > 150 * 1024) --img;
+  img = std::min(img, std::max(1, g.B));
+  *lds_bytes = (int)(wbytes + img * zbytes);
+  return img;
+}
+template <int CB, int NCH, int WAVES>
+static int launch_dx_img(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
+                         const DxGeom& g, int img, int lds, hipStream_t s, bool prepped) {
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_dx_img_kernel<CB, NCH, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { trl_set_error("conv_bwd_input: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_lds = lds;
+  }
+  if (!prepped) {
+    const int total = g.Cout * g.Cin * g.kh * g.kw;
+    hipLaunchKernelGGL(conv_dx_prep_kernel, dim3(std::min(64, trl_ceil_div(total, 256))), dim3(256), 0, s, w, wprep, g);
+    TRL_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL((conv_dx_img_kernel<CB, NCH, WAVES>), dim3(trl_ceil_div(g.B, img)), dim3(64 * WAVES), lds, s, dy, yg, wprep,
+                     dx, xg, g, img);
+  TRL_LAUNCH_CHECK();
+  return TRL_OK;
+}
+
 template <int CB, int NCH, int WAVES>
 static int launch_dx_waves(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
                            DxGeom g, int lds, hipStream_t s, bool prepped) {
@@ -193,6 +352,20 @@ static int launch_dx_waves(const float* dy, const float* yg, const float* w, flo
 template <int CB, int NCH>
 static int launch_dx(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
                      const DxGeom& g, hipStream_t s, bool prepped) {
+  {
+    int lds_img = 0;
+    const int img = dx_img_per_wg(g, &lds_img);
+    if (img > 0) {
+      // blocks of 16 positions per workgroup: a handful -> 4 waves (one per SIMD), many -> 8
+      int blocks = 0;
+      for (int cls = 0; cls < g.sh * g.sw; ++cls)
+        blocks += trl_ceil_div(img * trl_ceil_div(g.H - cls / g.sw, g.sh) * trl_ceil_div(g.W - cls % g.sw, g.sw), 16);
+      bool eight = blocks > 16;
+      if (getenv("TRL_DX_WAVES")) eight = atoi(getenv("TRL_DX_WAVES")) >= 8;
+      return eight ? launch_dx_img<CB, NCH, 8>(dy, yg, w, wprep, dx, xg, g, img, lds_img, s, prepped)
+                   : launch_dx_img<CB, NCH, 4>(dy, yg, w, wprep, dx, xg, g, img, lds_img, s, prepped);
+    }
+  }
   const int max_taps = trl_ceil_div(g.kh, g.sh) * trl_ceil_div(g.kw, g.sw);
   const int lds = max_taps * g.Cout * g.Cin * (int)sizeof(float);
   TRL_REQUIRE(lds <= 160 * 1024, "conv_bwd_input: one parity class of the weights exceeds the LDS");
