@@ -110,6 +110,7 @@ _T0 = time.perf_counter()
 
 
 FLOP_PER_ENV_STEP = 671e3                         # whole iteration, SURVEY.md section 8(d) (log pi_old cached)
+BYTES_PER_ENV_STEP = 1240                         # algorithmic HBM bytes per env-step (collect 176 + GAE 24 + 10 x 104), BASELINE.md section 4
 PROBE_STEPS = 5                                   # iterations of the event-probed pass after a graph-replayed timed region
 
 
@@ -207,6 +208,63 @@ def cpu_baseline(budget_s=27.0):
                          "/".join("%.0f" % (N_PER_GPU / collect[p][0]) for p in sorted(collect)), t_gae, n_upd,
                          OPT_EPOCHS * n_mb, BATCH_PER_GPU, threads, t_upd,
                          "/".join("%.1f" % full[p] for p in sorted(collect)), best)}
+
+
+def cpu_baseline_full(warm=3, timed=20, procs=4):
+    """BASELINE.md section 3, literally: the reference-style CPU path (oracle/, a port) run as WHOLE iterations on this host --
+    3 warm-up + 20 timed iterations of {collect T=128 vector steps on N=2048 envs (SubProcVecEnv-like workers, proc_nums =
+    4 as the reference's example hard-codes), GAE, 10 epochs x 4 minibatch updates of B=65536} -- reported as median / min /
+    max env-steps/s for (a) env-only stepping, (b) collect (policy + env + buffer), (c) the full PPO iteration.  About two
+    minutes of host time per ~25 iterations; `python bench.py --cpu-baseline-full` prints one JSON line (kept under profiles/)."""
+    import functools
+    import torch
+    from oracle import nets, replay
+    from oracle.collector import VecOnPolicyCollectorOracle
+    from oracle.subproc_env import SubProcVecEnvCPU
+    from oracle.ppo import PPOOracle
+    from oracle.synth_env import SynthSingleEnvCPU
+    cores = os.cpu_count() or 1
+    threads = min(cores, 32)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    fns = [functools.partial(SynthSingleEnvCPU, i) for i in range(N_PER_GPU)]
+    gen = torch.Generator().manual_seed(0)
+    pf, vf = nets.init_mlp(D, [H, H], A, generator=gen), nets.init_mlp(D, [H, H], 1, generator=gen)
+    ls = torch.full((A,), float(np.log(0.125)))
+    env = SubProcVecEnvCPU(procs, N_PER_GPU, fns, SynthSingleEnvCPU(0))
+    steps = N_PER_GPU * T
+    stat = lambda xs: {"median": float(np.median(xs)), "min": float(np.min(xs)), "max": float(np.max(xs)), "n": len(xs)}
+    try:
+        ring = replay.RingOracle(steps, env_nums=N_PER_GPU, time_limit_filter=True)
+        col = VecOnPolicyCollectorOracle(env, ring, pf, ls, vf, epoch_frames=steps, max_episode_frames=1000)
+        ppo = PPOOracle(pf, ls, vf, entropy_coeff=0.005, opt_epochs=OPT_EPOCHS, batch_size=BATCH_PER_GPU, num_epochs=100000)
+        keys = ["obs", "acts", "advs", "estimate_returns", "values"]
+        t_env, t_col, t_all = [], [], []
+        acts = np.zeros((N_PER_GPU, A))
+        for it in range(warm + timed):
+            t0 = time.perf_counter()
+            for _ in range(T):                                              # (a) env-only stepping, zero actions
+                env.step(acts)
+            t1 = time.perf_counter()
+            col.train_one_epoch()                                           # (b) collect
+            t2 = time.perf_counter()
+            ppo.process_epoch_samples(ring)                                 # GAE
+            for _ in range(OPT_EPOCHS):
+                for _idx, batch in ring.epoch_minibatches(BATCH_PER_GPU, keys, True):
+                    ppo.update(batch)
+            t3 = time.perf_counter()
+            log("cpu baseline (full): iteration %d: env %.2f s, collect %.2f s, GAE + updates %.2f s" % (it, t1 - t0, t2 - t1, t3 - t2))
+            if it >= warm:
+                t_env.append(steps / (t1 - t0)); t_col.append(steps / (t2 - t1)); t_all.append(steps / (t3 - t1))
+    finally:
+        env.close()
+    return {"value": float(np.median(t_all)), "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "host_hw_threads": cores, "torch_threads": threads, "env_worker_procs": procs,
+            "protocol": "BASELINE.md section 3: %d warm-up + %d timed whole iterations; median / min / max" % (warm, timed),
+            "env_only_env_steps_per_s": stat(t_env), "collect_env_steps_per_s": stat(t_col), "full_iteration_env_steps_per_s": stat(t_all),
+            "sample": "%d whole iterations of N=%d x T=%d, %d x %d updates of B=%d, nothing scaled" % (timed, N_PER_GPU, T, OPT_EPOCHS,
+                                                                                                     steps // BATCH_PER_GPU, BATCH_PER_GPU)}
 
 
 def cpu_baseline_offpolicy(kind):
@@ -539,12 +597,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg 3 / cfg 5 epochs and the peak calibration")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="BASELINE.md section 3 literally: 3 warm-up + 20 timed whole CPU iterations (median / min / max); "
+                         "prints one JSON line and exits (about two minutes, no GPU work)")
     ap.add_argument("--workload", default="ppo", choices=["ppo", "sac", "dqn", "qrdqn"],
                     help="with --cpu-baseline-only: which workload's CPU baseline to time (tools/bench_{sac,dqn}.py)")
     ap.add_argument("--probe-graph-collectives", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.probe_graph_collectives:
         _probe_child()
+    if args.cpu_baseline_full:
+        print(json.dumps({"cpu_baseline_full": cpu_baseline_full()}), flush=True)
+        return
     if args.cpu_baseline_only:                      # child mode of the cpu_baseline leg
         res = cpu_baseline() if args.workload == "ppo" else cpu_baseline_offpolicy(args.workload)
         print("CPU_BASELINE " + json.dumps(res), flush=True)
@@ -748,6 +812,13 @@ def main():
         gc.freeze()                                                        # (as before the first timed region)
         parity_elapsed, pmarks, pread = timed_region()
         log("reference-noise mode: timed %d iterations in %.3f s" % (args.steps, parity_elapsed))
+        pre = getattr(col, "_prefetcher", None)
+        if pre is not None:                                                # how the blocks reached the device (all rollouts so far)
+            from torchrl_amd.collector import noise as _noise
+            comm_info["noise_blocks"] = dict(pre.transport_counts, dropped=pre.dropped_blocks,
+                                             host_threads=pre.draw_threads or _noise.default_threads(),
+                                             jump_ahead_passes=_noise.STATS["jump_passes"],
+                                             native_helper=_noise.native_helper() is not None)
         log("per-iteration ms: " + " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip(pmarks[:-1], pmarks[1:])))
         col.stop_noise_prefetch()
         col.noise_mode, col.prefetch_noise = "device", False
@@ -798,10 +869,17 @@ def main():
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": pmc_traffic()[0], "traffic_stamp": pmc_traffic()[1], "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
                      "whole_iteration_frac": FLOP_PER_ENV_STEP * env_steps / elapsed / world / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                     # the HBM side of the same iteration (north_star: fraction of the HBM roofline): SURVEY.md 8(d)'s 1 240
+                     # algorithmic bytes per env-step against the nominal 8 TB/s -- the path is MFMA-bound, this says by how much
+                     "hbm_whole_iteration_frac": BYTES_PER_ENV_STEP * env_steps / elapsed / world / 8e12,
+                     "hbm_whole_iteration_GBps": BYTES_PER_ENV_STEP * env_steps / elapsed / world / 1e9,
+                     "mfma_busy": pmc_traffic()[2],
                      "launches_timed": len(grad_ms),
                      "timed_in": ("follow-up pass of %d iterations (the timed region replays a HIP graph)" % PROBE_STEPS)
                      if graph_mode else "the timed region"},
     }
+    if backend is None and comm_info:
+        out["config"].update(comm_info)                                    # (one rank: how the noise blocks travelled)
     if backend is not None:
         out["config"]["process_group_backend"] = backend
         out["config"].update(comm_info)
@@ -858,7 +936,7 @@ def kernel_source_digest(root=REPO):
 
 
 def pmc_traffic(path=None, root=REPO):
-    """(bytes per launch | None, stamp): HBM bytes per launch of the dominant kernel from the committed PMC passes
+    """(bytes per launch | None, stamp, MFMA-busy record | None): HBM bytes per launch of the dominant kernel from the committed PMC passes
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot be collected from inside the timed run; the JSON records the
     measurement, its gfx950 correction, the source CSV, the commit and the digest of the kernel sources it was taken at --
     tools/stamp_traffic.py writes it).  The value is reported ONLY while the kernel sources are the ones that were measured:
@@ -868,7 +946,7 @@ def pmc_traffic(path=None, root=REPO):
             rec = json.load(f)
         value = rec["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
-        return None, {"status": "no committed measurement"}
+        return None, {"status": "no committed measurement"}, None
     stamp = {"measured_at_commit": rec.get("measured_at_commit"), "kernel_source_sha256": rec.get("kernel_source_sha256"),
              "source": rec.get("source")}
     try:
@@ -878,9 +956,11 @@ def pmc_traffic(path=None, root=REPO):
     stamp["tree_matches"] = bool(now) and now == rec.get("kernel_source_sha256")
     if not stamp["tree_matches"]:
         stamp["status"] = "stale: the kernel sources changed since the counters were collected -> traffic = null"
-        return None, stamp
+        return None, stamp, None
     stamp["status"] = "current"
-    return value, stamp
+    # matrix-pipe occupancy of the same kernel from the SQ counter pass of the same tree (rocprofv3 --pmc, a run of its own):
+    # SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32) = share of the launch's SIMD-cycles with an MFMA in the pipe
+    return value, stamp, rec.get("mfma_busy")
 
 
 if __name__ == "__main__":

@@ -67,7 +67,7 @@ def test_roofline_traffic_is_reported_only_for_the_kernel_sources_it_was_measure
     with open(bench.TRAFFIC_FILE) as f:
         rec = json.load(f)
     assert rec["kernel_source_sha256"] and rec["measured_at_commit"] and list(rec["kernel_sources"]) == list(bench.TRAFFIC_SOURCES)
-    value, stamp = bench.pmc_traffic()
+    value, stamp, busy = bench.pmc_traffic()
     if stamp["tree_matches"]:                                             # committed measurement is of this tree
         assert value == rec["traffic_bytes_per_launch"] and stamp["status"] == "current"
         assert rec["kernel_source_sha256"] == bench.kernel_source_digest()
@@ -81,12 +81,12 @@ def test_roofline_traffic_is_reported_only_for_the_kernel_sources_it_was_measure
     same = dict(rec, kernel_source_sha256=bench.kernel_source_digest(str(root)))
     path = tmp_path / "traffic.json"
     path.write_text(json.dumps(same))
-    value, stamp = bench.pmc_traffic(str(path), str(root))
-    assert value == rec["traffic_bytes_per_launch"] and stamp["tree_matches"]
+    value, stamp, busy = bench.pmc_traffic(str(path), str(root))
+    assert busy == rec.get("mfma_busy") and value == rec["traffic_bytes_per_launch"] and stamp["tree_matches"]
     with open(root / bench.TRAFFIC_SOURCES[0], "ab") as f:
         f.write(b"\n")
-    value, stamp = bench.pmc_traffic(str(path), str(root))
-    assert value is None and not stamp["tree_matches"] and stamp["status"].startswith("stale")
+    value, stamp, busy = bench.pmc_traffic(str(path), str(root))
+    assert busy is None and value is None and not stamp["tree_matches"] and stamp["status"].startswith("stale")
     assert stamp["measured_at_commit"] == rec["measured_at_commit"]
-    value, stamp = bench.pmc_traffic(str(tmp_path / "absent.json"), str(root))
+    value, stamp, busy = bench.pmc_traffic(str(tmp_path / "absent.json"), str(root))
     assert value is None and stamp["status"] == "no committed measurement"

@@ -725,3 +725,44 @@ def test_last_sample_is_the_last_row_of_the_ring():
                 assert not v.any()                                         # the ring's last row has not been written yet
         if buf._top == 0:                                                  # ring just filled: the row written last
             assert np.array_equal(got["next_obs"].cpu().numpy(), sample["next_obs"])
+
+
+def test_mt19937_jump_ahead_gives_the_states_of_the_sequential_walk():
+    """trl_mt19937_states_at_mt (csrc/trl_mtjump.cpp): the K engine states of a long stream derived by several host threads,
+    all but the first starting from the template JUMPED ahead -- F^J = (x^J mod phi)(F) on MT19937's GF(2)-linear window --
+    must be the records of the sequential pass BYTE FOR BYTE (all 5056 bytes of torch's generator state, the 31 dead bits of
+    the window included: every jump lands a block early and regenerates), for templates anywhere inside a 624-word block,
+    for BASELINE cfg 4's position list (rank 3 of 8: 128 chunks 98 304 calls apart) and for random ones; and the values drawn
+    from those states are the reference's: this rank's rows of 128 successive torch.randn(16384, 6) draws."""
+    import numpy as np
+    import torch
+    from torchrl_amd import _C
+    from torchrl_amd.collector import noise
+    assert _C.lib().trl_mt19937_jump_ready() == 1
+    g = torch.Generator()
+    rs = np.random.RandomState(5)
+    before = noise.STATS["jump_passes"]
+    for trial in range(5):
+        g.manual_seed(100 + trial)
+        if trial:                                                          # trial 0: the freshly seeded state (left = 1, next = 0)
+            torch.randn(16 * int(rs.randint(1, 3000)), generator=g)
+        s0 = g.get_state()
+        if trial < 2:
+            S, off, T = 16384 * 6, 3 * 2048 * 6, 128
+            pos = [t * S + off for t in range(T)] + [T * S]
+        else:
+            pos = np.sort(rs.randint(0, 9_000_000, size=50)).tolist()
+            pos[0] = 0 if trial == 2 else pos[0]
+        seq = noise.states_at(s0, pos)
+        for threads in (2, 5, 8):
+            assert torch.equal(noise.states_at(s0, pos, threads=threads), seq), (trial, threads)
+    assert noise.STATS["jump_passes"] - before == 15
+    # end to end at cfg 4's layout (fewer steps): rows [6144, 8192) of T successive (16384, 6) draws
+    T, n, n_total, e0, A = 24, 2048, 16384, 3 * 2048, 6
+    torch.manual_seed(77)
+    want = torch.stack([torch.randn(n_total, A)[e0:e0 + n] for _ in range(T)])
+    tail = torch.randn(4)
+    torch.manual_seed(77)
+    got = noise.randn_shard_into(torch.empty(T, n, A), T, n, n_total, e0, A, threads=4)
+    assert torch.equal(got, want) and torch.equal(torch.randn(4), tail)   # values and the generator's end state
+    assert noise.STATS["jump_passes"] - before >= 15                       # (16 when the native helper is loaded)

@@ -171,6 +171,15 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_kernel(const float* __rest
 // Cout + 4 floats: the 16 lanes of a ds_read_b128 group hit 16 different bank quads), then walks the parity classes;
 // a wave takes 16-position blocks of a class, its A operand is one 16-byte LDS read per (tap, 16 output channels).
 // Same MFMA sequence per output element as the class form (taps ascending, then channels): bit-identical results.
+struct DxPad { int pt, pl, Hp, Wp; };                  // zero border of an image's dZ in LDS: rows above / columns left, padded size
+__host__ __device__ inline DxPad dx_pad(const DxGeom& g) {
+  // tap (ti, tj) of the position (yq, xq) of a class reads dZ[yq - ti][xq - tj]: yq - ti runs from -(ceil(kh / sh) - 1) to
+  // ceil(H / sh) - 1, of which [0, Ho) exists -- the rest is the border
+  const int pt = (g.kh + g.sh - 1) / g.sh - 1, pl = (g.kw + g.sw - 1) / g.sw - 1;
+  const int pb = std::max(0, (g.H + g.sh - 1) / g.sh - g.Ho), pr = std::max(0, (g.W + g.sw - 1) / g.sw - g.Wo);
+  return DxPad{pt, pl, g.Ho + pt + pb, g.Wo + pl + pr};
+}
+
 template <int CB, int NCH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void conv_dx_img_kernel(const float* __restrict__ dy, const float* __restrict__ yg,
                                                           const float* __restrict__ wprep, float* __restrict__ dx,
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_img_kernel(const float* __
   float* Zs = Ws + wfloats;
   const int img0 = blockIdx.x * img_per_wg;
   const int nimg = min(img_per_wg, g.B - img0);
-  const int HW = g.Ho * g.Wo;
+  const DxPad pd = dx_pad(g);
   const bool gated = yg != nullptr && g.gate_act != TRL_ACT_NONE;
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(wprep);
@@ -194,15 +203,29 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_img_kernel(const float* __
 #pragma unroll
       for (int k = 0; k < 8; ++k) if (e + THREADS * k < n4) dst[e + THREADS * k] = v[k];
     }
-    const int nz = nimg * HW * Q;                                // 16-byte pieces of the images' dZ
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy) + (size_t)img0 * HW * Q;
-    const f32x4* y4 = reinterpret_cast<const f32x4*>(yg) + (size_t)img0 * HW * Q;
+    // the images' dZ = dY * act'(Y) with a ZERO BORDER (pd): a tap that falls outside the layer's output reads zeros, so
+    // the tap walk needs no range test and no select -- one scalar offset per tap on top of a per-block lane address
+    const int cells = nimg * pd.Hp * pd.Wp, nz = cells * Q;      // 16-byte pieces
+    const float inv_q = 1.0f / (float)Q, inv_wp = 1.0f / (float)pd.Wp, inv_hp = 1.0f / (float)pd.Hp;
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy) + (size_t)img0 * g.Ho * g.Wo * Q;
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(yg) + (size_t)img0 * g.Ho * g.Wo * Q;
     for (int e = threadIdx.x; e < nz; e += 4 * THREADS) {
       f32x4 v[4], y[4];
+      int cell[4], q[4];
+      bool in[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int ee = e + THREADS * k;
-        if (ee < nz) { v[k] = d4[ee]; if (gated) y[k] = y4[ee]; }
+        in[k] = false;
+        if (ee < nz) {
+          cell[k] = dx_div(ee, Q, inv_q); q[k] = ee - cell[k] * Q;
+          const int t = dx_div(cell[k], pd.Wp, inv_wp), xp = cell[k] - t * pd.Wp, b = dx_div(t, pd.Hp, inv_hp), yp = t - b * pd.Hp;
+          const int oy = yp - pd.pt, ox = xp - pd.pl;
+          in[k] = oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo;
+          const int srcp = in[k] ? ((b * g.Ho + oy) * g.Wo + ox) * Q + q[k] : 0;
+          v[k] = d4[srcp];
+          if (gated) y[k] = y4[srcp];
+        }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -212,8 +235,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_img_kernel(const float* __
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[k][r] *= dx_dact(g.gate_act, y[k][r]);
         }
-        const int row = ee / Q, q = ee - row * Q;
-        *reinterpret_cast<f32x4*>(Zs + row * LDZ + 4 * q) = v[k];
+        *reinterpret_cast<f32x4*>(Zs + cell[k] * LDZ + 4 * q[k]) = in[k] ? v[k] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
     }
   }
@@ -228,31 +250,45 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_img_kernel(const float* __
     const float* Wc_lds = Ws + woff;
     woff += ntap * TAP;
     if (rows <= 0 || ntap <= 0) continue;
-    const float inv_wc = 1.0f / (float)Wc, inv_hc = 1.0f / (float)Hc, inv_ntj = 1.0f / (float)ntj;
+    const float inv_wc = 1.0f / (float)Wc, inv_hc = 1.0f / (float)Hc;
     for (int row0 = 16 * wave; row0 < rows; row0 += 16 * WAVES) {
-      const int row = row0 + j;                                  // A row of this lane
-      const bool row_ok = row < rows;
-      int b = 0, yq = 0, xq = 0;
-      if (row_ok) { const int t = dx_div(row, Wc, inv_wc); xq = row - t * Wc; b = dx_div(t, Hc, inv_hc); yq = t - b * Hc; }
+      // A row of this lane; rows past the end read row 0's cells: an MFMA output row depends on its own A row only, and
+      // those output rows are never stored
+      const int row = row0 + j < rows ? row0 + j : 0;
+      const int t = dx_div(row, Wc, inv_wc), xq = row - t * Wc, b = dx_div(t, Hc, inv_hc), yq = t - b * Hc;
+      const float* zlane = Zs + (((b * pd.Hp + yq + pd.pt) * pd.Wp) + xq + pd.pl) * LDZ + 4 * gq;
+      // C reg r of lane (j, gq): position 4 gq + r of the wave's block, input channel 16 cb + j.  The output addresses are
+      // decoded and the gate of the layer below (x_gate) is requested BEFORE the tap walk: its global round trip runs
+      // under the MFMAs instead of behind them
+      const int orow0 = row0 + 4 * gq;
+      size_t oaddr[4];
+      float xgv[4][CB];
+      {
+        const int t0o = dx_div(orow0 < rows ? orow0 : 0, Wc, inv_wc);
+        int xo = (orow0 < rows ? orow0 : 0) - t0o * Wc, bo = dx_div(t0o, Hc, inv_hc), yo = t0o - bo * Hc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r > 0 && ++xo == Wc) { xo = 0; if (++yo == Hc) { yo = 0; ++bo; } }   // the next position of the class
+          const bool live = orow0 + r < rows;
+          oaddr[r] = live ? (((size_t)(img0 + bo) * g.H + (g.sh * yo + py)) * g.W + (g.sw * xo + px)) * g.Cin + j : 0;
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) xgv[r][cb] = xg ? xg[oaddr[r] + 16 * cb] : 0.0f;
+        }
+      }
       f32x4 acc[CB];
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       constexpr int G = 8 / NCH;
       f32x4 a[G][NCH];
+      int ti = 0, tj = 0;                                        // tap (ti, tj) of t0, advanced incrementally (uniform)
       for (int t0 = 0; t0 < ntap; t0 += G) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-          const int t = t0 + u;
-          if (t >= ntap) break;
-          const int ti = dx_div(t, ntj, inv_ntj), tj = t - ti * ntj;
-          const int oy = yq - ti, ox = xq - tj;
-          const bool ok = row_ok && oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo;
-          const float* zr = Zs + (ok ? ((b * g.Ho + oy) * g.Wo + ox) * LDZ + 4 * gq : 0);
+          if (t0 + u >= ntap) break;
+          const float* zr = zlane - (ti * pd.Wp + tj) * LDZ;     // dZ[yq - ti][xq - tj], zero outside the output
 #pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) {
-            const f32x4 z = *reinterpret_cast<const f32x4*>(zr + 16 * ch);
-            a[u][ch] = ok ? z : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-          }
+          for (int ch = 0; ch < NCH; ++ch) a[u][ch] = *reinterpret_cast<const f32x4*>(zr + 16 * ch);
+          if (++tj == ntj) { tj = 0; ++ti; }
         }
 #pragma unroll
         for (int u = 0; u < G; ++u) {
@@ -267,20 +303,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_img_kernel(const float* __
                 acc[cb] = mfma16(a[u][ch][r], wt[((ch * 4 + r) * CB + cb) * 64], acc[cb]);
         }
       }
-      // C reg r of lane (j, gq): position 4 gq + r of the wave's block, input channel 16 cb + j
-      const int orow0 = row0 + 4 * gq;
-      const int t0o = dx_div(orow0, Wc, inv_wc);
-      int xo = orow0 - t0o * Wc, bo = dx_div(t0o, Hc, inv_hc), yo = t0o - bo * Hc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (orow0 + r >= rows) break;
-        if (r > 0 && ++xo == Wc) { xo = 0; if (++yo == Hc) { yo = 0; ++bo; } }   // the next position of the class
-        const size_t o = (((size_t)(img0 + bo) * g.H + (g.sh * yo + py)) * g.W + (g.sw * xo + px)) * g.Cin + j;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
           float v = acc[cb][r];
-          if (xg) v *= dx_dact(g.x_gate_act, xg[o + 16 * cb]);   // hand the previous layer its dZ, not its dY
-          dx[o + 16 * cb] = v;
+          if (xg) v *= dx_dact(g.x_gate_act, xgv[r][cb]);       // hand the previous layer its dZ, not its dY
+          dx[oaddr[r] + 16 * cb] = v;
         }
       }
     }
@@ -291,12 +321,24 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_img_kernel(const float* __
 // the padded dZ of the images within 150 KB of LDS; as many images as keeps the grid at one workgroup per CU or more
 static int dx_img_per_wg(const DxGeom& g, int* lds_bytes) {
   const int64_t wbytes = (int64_t)g.Cout * g.Cin * g.kh * g.kw * 4;
-  const int64_t zbytes = (int64_t)g.Ho * g.Wo * (g.Cout + 4) * 4;
+  const DxPad pd = dx_pad(g);
+  const int64_t zbytes = (int64_t)pd.Hp * pd.Wp * (g.Cout + 4) * 4;    // an image's dZ with its zero border
+  const int64_t cap = 150 * 1024;
   if (getenv("TRL_DX_CLASS_FORM") && atoi(getenv("TRL_DX_CLASS_FORM"))) return 0;
-  if (wbytes + zbytes > 150 * 1024 || (int64_t)g.Ho * g.Wo > 4096) return 0;
-  int img = std::max(1, std::min(4, g.B / 256));
+  if (wbytes + zbytes > cap || (int64_t)pd.Hp * pd.Wp > 4096) return 0;
+  // The fewest images per workgroup for which the WHOLE grid is resident at once (160 KB of LDS per CU, 256 CUs): measured
+  // at cfg 5 (tools/ab_convdx.py, MI355X): conv 2 (45 KB per image-workgroup: 512 workgroups, two per CU) 29 us against
+  // 33 / 51 us with 2 / 4 images; conv 3 (87 KB: one per CU) 27 us with 2 images = 256 workgroups against 35 us with 1
+  // image = two rounds and 44 us with 4 = half the CUs idle.
+  int img = 1;
+  for (; img < 8; ++img) {
+    const int64_t lds = wbytes + img * zbytes;
+    if (lds + zbytes > cap) break;                                         // one more image would not fit
+    const int64_t resident = 256 * std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / lds));
+    if ((g.B + img - 1) / img <= resident) break;
+  }
   if (getenv("TRL_DX_IMG")) img = std::max(1, atoi(getenv("TRL_DX_IMG")));
-  while (img > 1 && wbytes + img * zbytes > 150 * 1024) --img;
+  while (img > 1 && wbytes + img * zbytes > cap) --img;
   img = std::min(img, std::max(1, g.B));
   *lds_bytes = (int)(wbytes + img * zbytes);
   return img;
@@ -356,11 +398,12 @@ static int launch_dx(const float* dy, const float* yg, const float* w, float* wp
     int lds_img = 0;
     const int img = dx_img_per_wg(g, &lds_img);
     if (img > 0) {
-      // blocks of 16 positions per workgroup: a handful -> 4 waves (one per SIMD), many -> 8
+      // eight waves (two per SIMD) hide the LDS round trips of the tap walk: faster than four at every measured
+      // geometry (29 vs 34 us, 27 vs 34 us); a workgroup with at most 4 blocks of 16 positions has nothing for them to do
       int blocks = 0;
       for (int cls = 0; cls < g.sh * g.sw; ++cls)
         blocks += trl_ceil_div(img * trl_ceil_div(g.H - cls / g.sw, g.sh) * trl_ceil_div(g.W - cls % g.sw, g.sw), 16);
-      bool eight = blocks > 16;
+      bool eight = blocks > 4;
       if (getenv("TRL_DX_WAVES")) eight = atoi(getenv("TRL_DX_WAVES")) >= 8;
       return eight ? launch_dx_img<CB, NCH, 8>(dy, yg, w, wprep, dx, xg, g, img, lds_img, s, prepped)
                    : launch_dx_img<CB, NCH, 4>(dy, yg, w, wprep, dx, xg, g, img, lds_img, s, prepped);
