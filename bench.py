@@ -657,12 +657,12 @@ def main():
             comm_info["cpu_affinity"] = ("%d CPUs per rank (rank 0: %d-%d)" % (len(mine), mine[0], mine[-1])) if mine and rank == 0 \
                 else ("%d CPUs per rank" % len(mine) if mine else "not pinned")
         # Pre-flight (rank 0 reports): can every pair of this job's GPUs reach each other, and over what
-        if not shared and torch.cuda.device_count() >= world:
+        if not shared and torch.cuda.device_count() >= world and rank == 0:   # (one process asks: queries only, no contexts on the other GPUs)
             try:
                 comm_info["link_preflight"] = _dist.link_preflight(devmap[:world])
             except Exception as exc:                                      # noqa: BLE001 -- a diagnostic must not cost the run
                 comm_info["link_preflight"] = {"error": repr(exc)}
-        else:
+        elif rank == 0:
             comm_info["link_preflight"] = {"note": "%d ranks on %d device(s): nothing to probe" % (world, len(set(devmap[:world])))}
         if args.transport == "rccl":
             os.environ["TRL_NO_PEER"] = "1"

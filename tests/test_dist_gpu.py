@@ -255,3 +255,23 @@ def test_two_ranks_reproduce_one_process_td3_dqn(tmp_path, algo):
     assert list(r0["keys"]) == list(single["keys"])
     np.testing.assert_allclose(r0["infos"], r1["infos"], rtol=1e-12, atol=0)
     np.testing.assert_allclose(r0["infos"], single["infos"], rtol=5e-4, atol=5e-5)
+
+
+def test_link_preflight_reports_every_pair_of_the_devices_present():
+    """bench.py's pre-flight for `--gpus N`: peer access and link type for every ordered pair through
+    trl_comm_link_info (hipDeviceCanAccessPeer + hipExtGetLinkTypeAndHopCount).  On the one-GPU test box: no pairs, the
+    diagonal answers, an index past the device count is rejected."""
+    import ctypes
+    import torch
+    from torchrl_amd import _C, dist
+    n = torch.cuda.device_count()
+    out = dist.link_preflight(range(n))
+    assert out["pairs"] == n * (n - 1) and isinstance(out["peer_access_all"], bool)
+    assert sum(out["links"].values()) + len(out["no_access"]) == out["pairs"]
+    info = (ctypes.c_int32 * 3)()
+    assert _C.lib().trl_comm_link_info(0, 0, info) == 0 and info[0] == 1
+    assert _C.lib().trl_comm_link_info(0, n, info) != 0
+    if n > 1:
+        assert out["max_hops"] >= 1 and set(out["links"]) <= {"xgmi", "pcie", "hypertransport", "qpi", "infiniband", "unknown"}
+    cpus = dist.pin_rank_cpus(0, 1)                                        # one rank per host: nothing to slice
+    assert cpus is None
