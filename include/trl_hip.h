@@ -706,6 +706,14 @@ typedef struct trl_conv_riders_t {
 int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias, float* y, int B, int C, int H,
                         int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
                         const trl_conv_riders_t* riders, void* stream);
+/* The same layer of TWO networks of one architecture on two frame batches of one shape -- DQN's online net on obs and its
+ * target net on next_obs (torchrl/algo/off_policy/dqn.py:38-52) -- as ONE launch (narrow first layers: one ragged last
+ * round of workgroups instead of two and one launch boundary less; wide ones: two launches).  `riders` may carry both
+ * networks' jobs (at most 4 of either kind together). */
+int trl_conv_fwd_u8_pair_f32(const uint8_t* frames_a, const float* w_a, const float* bias_a, float* y_a,
+                             const uint8_t* frames_b, const float* w_b, const float* bias_b, float* y_b, int B, int C, int H,
+                             int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
+                             const trl_conv_riders_t* riders, void* stream);
 int trl_conv_bwd_weight_workspace(int B, int C, int H, int W, int kh, int kw, int sh, int sw, int Cout);
 /* The later conv layers, same idea on fp32 channels-last activations x (B, H, W, C), C % 4 == 0: the reduction
  * runs in (i, j, c) order so that a window row is one contiguous run of kw*C floats; w is still the nn.Conv2d

@@ -182,12 +182,16 @@ def test_implicit_transposed_conv_coverage_and_errors():
                                2, 4, 4, 4, 3, 3, 1, 1)
 
 
-def test_paired_forward_of_online_and_target_net_equals_two_passes():
-    """ops.cnn_forward_pair (conv 2 / 3, the FC layer and the head of both networks as grouped launches) against two
-    ops.cnn_forward passes: outputs and every tape tensor bit for bit, at cfg 5's shapes."""
+@pytest.mark.parametrize("B,dx_prep,pair_first", [(96, False, True), (37, True, True), (96, True, False)])
+def test_paired_forward_of_online_and_target_net_equals_two_passes(B, dx_prep, pair_first, monkeypatch):
+    """ops.cnn_forward_pair (both first conv layers as ONE launch -- trl_conv_fwd_u8_pair_f32, with both networks' weight
+    re-orderings as its riders --, conv 2 / 3, the FC layer and the head of both networks as grouped launches) against two
+    ops.cnn_forward passes: outputs and every tape tensor bit for bit, at cfg 5's shapes; a ragged batch (37 x 400 positions:
+    the second problem's workgroups start mid-way through a round) and the two-launch first layer as well."""
     import copy
     import torchrl.networks as networks
     from torchrl_amd import ops
+    monkeypatch.setattr(ops, "PAIR_FIRST_CONV", pair_first)
     torch.manual_seed(2)
     convs = [[16, [8, 8], [4, 4], [0, 0]], [32, [4, 4], [2, 2], [0, 0]], [64, [3, 3], [1, 1], [0, 0]]]
     qf = networks.Net(output_shape=6, base_type=networks.CNNBase, append_hidden_shapes=[512], activation_func=torch.nn.Tanh,
@@ -196,12 +200,15 @@ def test_paired_forward_of_online_and_target_net_equals_two_passes():
     with torch.no_grad():
         for p in tq.parameters():
             p.add_(0.01 * torch.randn_like(p))
-    fa = torch.randint(0, 256, (96, 4, 84, 84), dtype=torch.uint8, device=DEV)
-    fb = torch.randint(0, 256, (96, 4, 84, 84), dtype=torch.uint8, device=DEV)
-    (qa, ta), (qb, tb) = ops.cnn_forward_pair(qf, tq, fa, fb)
-    wa, wta = ops.cnn_forward(qf, fa)
+    fa = torch.randint(0, 256, (B, 4, 84, 84), dtype=torch.uint8, device=DEV)
+    fb = torch.randint(0, 256, (B, 4, 84, 84), dtype=torch.uint8, device=DEV)
+    (qa, ta), (qb, tb) = ops.cnn_forward_pair(qf, tq, fa, fb, dx_prep=dx_prep)
+    wa, wta = ops.cnn_forward(qf, fa, dx_prep=dx_prep)
     wb, wtb = ops.cnn_forward(tq, fb)
     assert torch.equal(qa, wa) and torch.equal(qb, wb)
+    if dx_prep:                                                           # the backward pass's re-ordered weights rode along
+        assert sorted(ta.dx_preps) == sorted(wta.dx_preps) and all(torch.equal(ta.dx_preps[k], wta.dx_preps[k]) for k in ta.dx_preps)
+        assert not tb.dx_preps
     for got, want in ((ta, wta), (tb, wtb)):
         assert len(got.convs) == len(want.convs) == 3 and got.feat_shape == want.feat_shape
         for g, w in zip(got.convs, want.convs):

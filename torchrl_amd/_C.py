@@ -218,6 +218,8 @@ SIGNATURES = {
     "trl_transpose_bpc_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "trl_conv_fwd_u8_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int] +
                             [C.POINTER(ConvRiders), C.c_void_p]),
+    "trl_conv_fwd_u8_pair_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 8 + [C.c_float, C.c_float, C.c_int, C.c_int] +
+                                 [C.POINTER(ConvRiders), C.c_void_p]),
     "trl_conv_bwd_weight_workspace": (C.c_int, [C.c_int] * 9),
     "trl_conv_fwd_nhwc_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
     "trl_conv_bwd_weight_nhwc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 9
@@ -1247,6 +1249,43 @@ def conv_fwd_u8(frames, w, bias, kh, kw, sh, sw, scale, shift, act, perm=None, d
     if perm is None and dx is None:
         return y, (B, Ho, Wo)
     return y, (B, Ho, Wo), (outs, wss)
+
+
+def conv_fwd_u8_pair(frames_a, w_a, bias_a, frames_b, w_b, bias_b, kh, kw, sh, sw, scale, shift, act, perm=None, dx=None):
+    """`conv_fwd_u8` of two same-geometry problems (two networks of one architecture on two frame batches of one shape) as ONE
+    launch; the riders (`perm` / `dx`, together at most 4 of either kind) may come from both networks.  Returns
+    (y_a, y_b, (B, Ho, Wo), (perm outs, dx workspaces))."""
+    if tuple(frames_a.shape) != tuple(frames_b.shape) or tuple(w_a.shape) != tuple(w_b.shape):
+        raise TrlError("conv_fwd_u8_pair: the two problems must have one geometry")
+    B, Cc, H, W = (int(v) for v in frames_a.shape)
+    Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
+    Cout = int(w_a.shape[0])
+    ya = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=frames_a.device)
+    yb = torch.empty_like(ya)
+    jobs, dxs = list(perm or []), list(dx or [])
+    if len(jobs) > 4 or len(dxs) > 4:
+        raise TrlError("conv_fwd_u8_pair: at most 4 riders of either kind")
+    outs = [torch.empty_like(wl, memory_format=torch.contiguous_format) for wl, _, _ in jobs]
+    wss = [torch.empty((lib().trl_conv_bwd_input_nhwc_workspace(cin, int(wl.shape[0]), a, b),), dtype=torch.float32, device=ya.device)
+           for wl, cin, a, b, _, _ in dxs]
+    r = None
+    if jobs or dxs:
+        r = ConvRiders()
+        r.n_perm, r.n_dx = len(jobs), len(dxs)
+        for k, ((wl, c, khw), o) in enumerate(zip(jobs, outs)):
+            r.perm_src[k], r.perm_dst[k] = dev_ptr(wl, name="perm weight"), dev_ptr(o, name="perm out")
+            r.perm_cout[k], r.perm_c[k], r.perm_khw[k] = int(wl.shape[0]), int(c), int(khw)
+        for k, ((wl, cin, a, b, c, d), ws) in enumerate(zip(dxs, wss)):
+            r.dx_w[k], r.dx_ws[k] = dev_ptr(wl, name="dx weight"), dev_ptr(ws, name="dx workspace")
+            r.dx_cin[k], r.dx_cout[k], r.dx_kh[k], r.dx_kw[k], r.dx_sh[k], r.dx_sw[k] = int(cin), int(wl.shape[0]), a, b, c, d
+    check(lib().trl_conv_fwd_u8_pair_f32(dev_ptr(frames_a, torch.uint8, "frames_a"), dev_ptr(w_a, name="w_a"),
+                                         dev_ptr(bias_a, name="bias_a", allow_none=True), dev_ptr(ya, name="y_a"),
+                                         dev_ptr(frames_b, torch.uint8, "frames_b"), dev_ptr(w_b, name="w_b"),
+                                         dev_ptr(bias_b, name="bias_b", allow_none=True), dev_ptr(yb, name="y_b"), B, Cc, H, W,
+                                         kh, kw, sh, sw, float(scale), float(shift), Cout, act,
+                                         C.byref(r) if r is not None else None, stream_ptr(ya.device)),
+          "trl_conv_fwd_u8_pair_f32")
+    return ya, yb, (B, Ho, Wo), (outs, wss)
 
 
 def conv_bwd_weight_u8(dy, y_gate, gate_act, frames, kh, kw, sh, sw, scale, shift, dw, db, workspace=None):

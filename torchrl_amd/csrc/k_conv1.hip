@@ -25,14 +25,23 @@ __device__ __forceinline__ float c1_byte(uint32_t x, int r, float scale, float s
   return fmaf((float)((x >> (8 * r)) & 0xffu), scale, shift);
 }
 
+// A SECOND problem of the same geometry in the same launch (DQN's target net on next_obs beside the online net on obs,
+// dqn.py:38-52): workgroups [n_main, 2 n_main) run it -- one launch boundary less, and one ragged last round of
+// workgroups instead of two (864 workgroups are 3.4 rounds of 256 CUs, 1728 are 6.75).
+struct Conv1Second { const uint8_t* frames; const float* w; const float* bias; float* y; };
+
 template <int KU>                                   // K / 16
 __global__ __launch_bounds__(C1_THREADS) void conv1_fwd_direct_kernel(ConvSrc cv, const float* __restrict__ w,
                                                                      const float* __restrict__ bias, float* __restrict__ y,
-                                                                     int M, int K, int Cout, int act, PermJobs pj, int n_main) {
-  if ((int)blockIdx.x >= n_main) {                   // riders: the later layers' weights into the reduction order of their kernels
-    conv_perm_jobs(pj, blockIdx.x - n_main, gridDim.x - n_main, threadIdx.x, C1_THREADS);
+                                                                     int M, int K, int Cout, int act, PermJobs pj, int n_main,
+                                                                     Conv1Second second) {
+  const int n_work = second.frames ? 2 * n_main : n_main;
+  if ((int)blockIdx.x >= n_work) {                   // riders: the later layers' weights into the reduction order of their kernels
+    conv_perm_jobs(pj, blockIdx.x - n_work, gridDim.x - n_work, threadIdx.x, C1_THREADS);
     return;
   }
+  int block = blockIdx.x;
+  if (block >= n_main) { block -= n_main; cv.frames = second.frames; w = second.w; bias = second.bias; y = second.y; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   // byte offset of every 4-tap group, once per workgroup (two run-time integer divisions apiece: sixteen of them per lane
@@ -40,7 +49,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_fwd_direct_kernel(ConvSrc cv
   __shared__ uint32_t tap_tab[4 * KU];
   if (threadIdx.x < 4 * KU) tap_tab[threadIdx.x] = conv_tap_offset(cv, 4u * threadIdx.x);
   __syncthreads();
-  const int mw = (blockIdx.x * (C1_THREADS / 64) + wave) * 64;     // this wave's 64 output positions
+  const int mw = (block * (C1_THREADS / 64) + wave) * 64;          // this wave's 64 output positions
   if (mw >= M) return;
   f32x4 wreg[KU];
   uint32_t tap[KU];
@@ -161,14 +170,16 @@ bool trl_conv1_direct_ok(int K, int Cout, const float* w) {     // w: the forwar
 }
 
 int trl_conv1_direct_fwd(const ConvSrc& cv, const float* w, const float* bias, float* y, int M, int K, int Cout, int act,
-                         const PermJobs& pj, hipStream_t stream) {
+                         const PermJobs& pj, hipStream_t stream, const uint8_t* frames2, const float* w2, const float* bias2,
+                         float* y2) {
   const int n_main = trl_ceil_div(M, 64 * (C1_THREADS / 64));
-  const dim3 grid(n_main + ((pj.n > 0 || pj.n_dx > 0) ? CONV_PERM_BLOCKS : 0)), block(C1_THREADS);
+  const Conv1Second second{frames2, w2, bias2, y2};
+  const dim3 grid((frames2 ? 2 : 1) * n_main + ((pj.n > 0 || pj.n_dx > 0) ? CONV_PERM_BLOCKS : 0)), block(C1_THREADS);
   switch (K / 16) {
-    case 4:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<4>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;
-    case 8:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<8>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;
-    case 12: hipLaunchKernelGGL(conv1_fwd_direct_kernel<12>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;
-    default: hipLaunchKernelGGL(conv1_fwd_direct_kernel<16>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main); break;
+    case 4:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<4>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main, second); break;
+    case 8:  hipLaunchKernelGGL(conv1_fwd_direct_kernel<8>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main, second); break;
+    case 12: hipLaunchKernelGGL(conv1_fwd_direct_kernel<12>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main, second); break;
+    default: hipLaunchKernelGGL(conv1_fwd_direct_kernel<16>, grid, block, 0, stream, cv, w, bias, y, M, K, Cout, act, pj, n_main, second); break;
   }
   TRL_LAUNCH_CHECK();
   return TRL_OK;

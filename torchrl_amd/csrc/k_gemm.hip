@@ -1227,9 +1227,29 @@ static int fill_conv(const char* who, const uint8_t* frames, int B, int C, int H
 __global__ __launch_bounds__(256) void conv_perm_kernel(PermJobs pj) {
   conv_perm_jobs(pj, blockIdx.x, gridDim.x, threadIdx.x, 256);
 }
+static int conv_fwd_u8(const uint8_t* frames, const float* w, const float* bias, float* y, const uint8_t* frames2,
+                       const float* w2, const float* bias2, float* y2, int B, int C, int H, int W, int kh, int kw, int sh,
+                       int sw, float scale, float shift, int Cout, int act, const trl_conv_riders_t* riders, void* stream);
 extern "C" int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const float* bias, float* y, int B, int C, int H,
                                    int W, int kh, int kw, int sh, int sw, float scale, float shift, int Cout, int act,
                                    const trl_conv_riders_t* riders, void* stream) {
+  return conv_fwd_u8(frames, w, bias, y, nullptr, nullptr, nullptr, nullptr, B, C, H, W, kh, kw, sh, sw, scale, shift, Cout,
+                     act, riders, stream);
+}
+// The first conv layer of TWO networks of one architecture on two frame batches of one shape -- DQN's online net on obs and
+// target net on next_obs (torchrl/algo/off_policy/dqn.py:38-52) -- as ONE launch; the riders may carry both networks' jobs.
+extern "C" int trl_conv_fwd_u8_pair_f32(const uint8_t* frames_a, const float* w_a, const float* bias_a, float* y_a,
+                                        const uint8_t* frames_b, const float* w_b, const float* bias_b, float* y_b, int B,
+                                        int C, int H, int W, int kh, int kw, int sh, int sw, float scale, float shift,
+                                        int Cout, int act, const trl_conv_riders_t* riders, void* stream) {
+  TRL_REQUIRE(frames_b && w_b && y_b, "conv_fwd_u8_pair: null pointer of the second problem");
+  TRL_REQUIRE((bias_a == nullptr) == (bias_b == nullptr), "conv_fwd_u8_pair: both problems with or both without a bias");
+  return conv_fwd_u8(frames_a, w_a, bias_a, y_a, frames_b, w_b, bias_b, y_b, B, C, H, W, kh, kw, sh, sw, scale, shift, Cout,
+                     act, riders, stream);
+}
+static int conv_fwd_u8(const uint8_t* frames, const float* w, const float* bias, float* y, const uint8_t* frames2,
+                       const float* w2, const float* bias2, float* y2, int B, int C, int H, int W, int kh, int kw, int sh,
+                       int sw, float scale, float shift, int Cout, int act, const trl_conv_riders_t* riders, void* stream) {
   TRL_REQUIRE(frames && w && y && Cout > 0, "null pointer / bad Cout");
   TRL_REQUIRE(act == TRL_ACT_TANH || act == TRL_ACT_RELU || act == TRL_ACT_NONE, "unknown activation");
   PermJobs pj{};
@@ -1256,14 +1276,17 @@ extern "C" int trl_conv_fwd_u8_f32(const uint8_t* frames, const float* w, const 
   int M, K;
   int rc = fill_conv("conv_fwd_u8", frames, B, C, H, W, kh, kw, sh, sw, scale, shift, g.cv, M, K);
   if (rc) return rc;
-  if (trl_conv1_direct_ok(K, Cout, w))               // narrow first layer: register-weights kernel, no LDS staging
-    return trl_conv1_direct_fwd(g.cv, w, bias, y, M, K, Cout, act, pj, (hipStream_t)stream);
+  if (trl_conv1_direct_ok(K, Cout, w) && (!frames2 || trl_conv1_direct_ok(K, Cout, w2)))   // narrow first layer: register-weights
+    return trl_conv1_direct_fwd(g.cv, w, bias, y, M, K, Cout, act, pj, (hipStream_t)stream, frames2, w2, bias2, y2);   // kernel, no LDS staging
   if (pj.n || pj.n_dx) {                             // (the generic kernel carries no riders: a launch of their own)
     hipLaunchKernelGGL(conv_perm_kernel, dim3(CONV_PERM_BLOCKS), dim3(256), 0, (hipStream_t)stream, pj);
     TRL_LAUNCH_CHECK();
   }
   g.A = nullptr; g.B = w; g.C = y; g.bias = bias; g.a_gate = nullptr; g.M = M; g.N = Cout; g.K = K;
   g.lda = K; g.ldb = K; g.ldc = Cout; g.act = act; g.gate_act = TRL_ACT_NONE; g.split_len = K; g.colsum = nullptr;
+  rc = launch_gemm<false, true, 1>(g, 1, (hipStream_t)stream);
+  if (rc || !frames2) return rc;
+  g.cv.frames = frames2; g.B = w2; g.C = y2; g.bias = bias2;       // (wide first layers: the second problem as a launch of its own)
   return launch_gemm<false, true, 1>(g, 1, (hipStream_t)stream);
 }
 

@@ -118,8 +118,10 @@ __device__ __forceinline__ void conv_perm_jobs(const PermJobs& pj, int block, in
 
 // ---- direct kernels for a narrow first layer (k_conv1.hip); used by the trl_conv_*_u8 entry points when they apply ----
 bool trl_conv1_direct_ok(int K, int Cout, const float* w);
+// (frames2 .. y2: a second problem of the same geometry in the same launch, or nulls)
 int trl_conv1_direct_fwd(const ConvSrc& cv, const float* w, const float* bias, float* y, int M, int K, int Cout, int act,
-                         const PermJobs& pj, hipStream_t stream);
+                         const PermJobs& pj, hipStream_t stream, const uint8_t* frames2 = nullptr, const float* w2 = nullptr,
+                         const float* bias2 = nullptr, float* y2 = nullptr);
 int trl_conv1_direct_bwdw_workspace(int M, int K, int Cout);          // floats
 int trl_conv1_direct_bwdw(const ConvSrc& cv, const float* dy, const float* y_gate, int gate_act, float* dw, float* db,
                           float* workspace, int M, int K, int Cout, hipStream_t stream);

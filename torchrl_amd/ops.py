@@ -215,6 +215,9 @@ def cnn_param_list(net):
 FWD_WEIGHT_SHADOWS = True       # (tests switch it off to compare)
 
 
+PAIR_FIRST_CONV = True        # cnn_forward_pair: both networks' first conv layer as one launch (tests switch it off to compare)
+
+
 def _shadow_jobs(layers):
     """[(layer index, weight matrix, C, kh*kw)] of the later conv layers that take the channels-last implicit GEMM: their
     weights are re-ordered to its (i, j, c) reduction order by riders of the first layer's launch (always from the live
@@ -327,19 +330,34 @@ def cnn_forward_pair(net_a, net_b, frames_a, frames_b, scale=1.0 / 255.0, shift=
     if not head and len(fc_layers(net_a)) < 2:
         return None
     tapes, xs, shadows = [], [], []
-    for net, convs, frames in ((net_a, convs_a, frames_a), (net_b, convs_b, frames_b)):
+    m = convs_a[0]
+    kh, kw = m.kernel_size
+    sh, sw = m.stride
+    jobs_a, jobs_b = _shadow_jobs(convs_a), _shadow_jobs(convs_b)
+    dxj = _dx_jobs(convs_a) if dx_prep else []                            # (net_a's backward follows)
+    paired = PAIR_FIRST_CONV and len(jobs_a) + len(jobs_b) <= 4 and (convs_a[0].bias is None) == (convs_b[0].bias is None)
+    if paired:
+        # both first layers -- online net on obs, target net on next_obs -- as ONE launch that also carries both networks'
+        # weight re-orderings (trl_conv_fwd_u8_pair_f32)
+        wa, wb = (c[0].weight.view(c[0].weight.shape[0], -1) for c in (convs_a, convs_b))
+        fa, fb = frames_a.contiguous(), frames_b.contiguous()
+        ya, yb, (B, Ho, Wo), (outs, wss) = _C.conv_fwd_u8_pair(fa, wa, convs_a[0].bias, fb, wb, convs_b[0].bias, kh, kw, sh, sw,
+                                                               scale, shift, act, perm=[j[1:] for j in jobs_a + jobs_b],
+                                                               dx=[j[1:] for j in dxj])
+        first = ((fa, wa, ya, jobs_a, outs[:len(jobs_a)], dxj, wss), (fb, wb, yb, jobs_b, outs[len(jobs_a):], [], []))
+    for idx, (net, convs, frames) in enumerate(((net_a, convs_a, frames_a), (net_b, convs_b, frames_b))):
         t = ConvTape()
         t.convs, t.act, t.B, t.feat_chw, t.dx_preps = [], act, int(frames.shape[0]), False, None
-        m = convs[0]
-        kh, kw = m.kernel_size
-        sh, sw = m.stride
-        wmat = m.weight.view(m.weight.shape[0], -1)
-        fr = frames.contiguous()
-        jobs, dxj = _shadow_jobs(convs), (_dx_jobs(convs) if (dx_prep and net is net_a) else [])   # (net_a's backward follows)
-        y, (B, Ho, Wo), (outs, wss) = _C.conv_fwd_u8(fr, wmat, m.bias, kh, kw, sh, sw, scale, shift, act,
-                                                     perm=[j[1:] for j in jobs], dx=[j[1:] for j in dxj])
-        shadows.append({j[0]: o for j, o in zip(jobs, outs)})
-        t.dx_preps = {j[0]: ws for j, ws in zip(dxj, wss)}
+        if paired:
+            fr, wmat, y, jobs, outs_, dxj_, wss_ = first[idx]
+        else:
+            wmat = convs[0].weight.view(convs[0].weight.shape[0], -1)
+            fr = frames.contiguous()
+            jobs, dxj_ = (jobs_a, dxj) if net is net_a else (jobs_b, [])
+            y, (B, Ho, Wo), (outs_, wss_) = _C.conv_fwd_u8(fr, wmat, convs[0].bias, kh, kw, sh, sw, scale, shift, act,
+                                                           perm=[j[1:] for j in jobs], dx=[j[1:] for j in dxj_])
+        shadows.append({j[0]: o for j, o in zip(jobs, outs_)})
+        t.dx_preps = {j[0]: ws for j, ws in zip(dxj_, wss_)}
         t.convs.append(("u8", (fr, scale, shift), y, wmat, None, (kh, kw, sh, sw)))
         tapes.append(t)
         xs.append(y.view(B, Ho, Wo, int(wmat.shape[0])))
