@@ -93,7 +93,7 @@ __global__ __launch_bounds__(DQ_THREADS) void quantile_huber_kernel(const float*
                                                                     const float* __restrict__ term, float gamma, int B, int A,
                                                                     int Q, float* __restrict__ dq,
                                                                     double* __restrict__ part /* (B, 2): loss, q_s_a sums */) {
-  extern __shared__ float sm[];                     // T[Q] | theta[Q] | means[A]
+  extern __shared__ __attribute__((aligned(16))) float sm[];                     // T[Q] | theta[Q] | means[A]
   __shared__ double smem[DQ_THREADS / 64];
   __shared__ int s_astar;
   float* T = sm;
@@ -124,16 +124,25 @@ __global__ __launch_bounds__(DQ_THREADS) void quantile_huber_kernel(const float*
   const float norm = 1.0f / ((float)B * (float)Q * (float)Q);
   double loss = 0.0, qsum = 0.0;
   for (int j = threadIdx.x; j < Q; j += DQ_THREADS) {
-    const float tj = th[j], tau = (2.0f * j + 1.0f) / (2.0f * Q);
+    const float tj = th[j], tau = (2.0f * j + 1.0f) / (2.0f * Q), one_m_tau = 1.0f - tau;
     float l = 0.0f, g = 0.0f;
-    for (int i = 0; i < Q; ++i) {
-      const float d = T[i] - tj;
+    // Q^2 Huber terms per sample make this launch VALU-bound (40 000 per sample at Q = 200): nine vector instructions per
+    // term instead of fourteen -- with m = min(|d|, 1): huber(d) = m (|d| - m / 2) (= d^2 / 2 inside, |d| - 1/2 outside),
+    // huber'(d) = clamp(d, -1, 1) (one v_med3), weight = d < 0 ? 1 - tau : tau (one select)
+    auto term = [&](float Ti) {
+      const float d = Ti - tj;
       const float ad = fabsf(d);
-      const float w = fabsf(tau - (d < 0.0f ? 1.0f : 0.0f));
-      const bool quad = ad < 1.0f;
-      l = fmaf(quad ? 0.5f * d * d : ad - 0.5f, w, l);
-      g = fmaf(quad ? d : (d > 0.0f ? 1.0f : -1.0f), w, g);      // d huber / d diff  (d diff / d theta_j = -1)
+      const float w = d < 0.0f ? one_m_tau : tau;
+      const float m = fminf(ad, 1.0f);
+      l = fmaf(m * fmaf(-0.5f, m, ad), w, l);
+      g = fmaf(__builtin_amdgcn_fmed3f(d, -1.0f, 1.0f), w, g);  // d huber / d diff  (d diff / d theta_j = -1)
+    };
+    int i = 0;
+    for (; i + 4 <= Q; i += 4) {                                 // T is read four values at a time (16-byte LDS reads)
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(T + i);
+      term(t4[0]); term(t4[1]); term(t4[2]); term(t4[3]);
     }
+    for (; i < Q; ++i) term(T[i]);
     dq[(size_t)b * A * Q + at * Q + j] = -g * norm;
     loss += (double)l; qsum += (double)tj;
   }
