@@ -1100,6 +1100,44 @@ def case_collect_hostenv():
                 n_alias += int(mask.sum())
         assert n_alias > 0
 
+    # ---- off-policy, DISCRETE actions: epsilon-greedy Q policy (numpy global stream) on cart-poles that fall (`done` resets, terminals
+    # True) and hit the collector's limit (terminals False) ----
+    for tag, N, steps, rows, max_frames, seed in (("off_cartpole_dqn", 4, 40, 48, 12, 8),):
+        env = VecEnv(N, py_envs.CartPoleEnv, ())
+        eval_env = VecEnv(N, py_envs.CartPoleEnv, ())
+        env.seed(seed)
+        eval_env.seed(seed + 1)
+        torch.manual_seed(seed + 60)
+        qf = networks.Net(input_shape=4, output_shape=2, hidden_shapes=[32, 32], append_hidden_shapes=[],
+                          base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+        pf = policies.EpsilonGreedyDQNDiscretePolicy(qf, start_epsilon=0.8, end_epsilon=0.3, decay_frames=25, action_shape=2)
+        np.random.seed(seed)
+        buf = BaseReplayBuffer(N * rows, env_nums=N)
+        col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=torch.device("cpu"),
+                           train_render=False, epoch_frames=N * steps, max_episode_frames=max_frames, eval_episodes=1)
+        masks, true_next = logged(env, lambda: len(true_next) - 1)
+        out.update(state_arrays(f"{tag}_qf_", qf))
+        out[f"{tag}_ob0"] = np.asarray(col.current_ob).copy()
+        res = col.train_one_epoch()
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+            out[f"{tag}_buf_{k}"] = np.asarray(getattr(buf, "_" + k)).copy()
+        out[f"{tag}_top_size"] = np.array([buf._top, buf._size], dtype=np.int64)
+        out[f"{tag}_reset_mask"] = np.stack(masks)
+        out[f"{tag}_true_next_obs"] = np.stack(true_next)
+        out[f"{tag}_train_epoch_reward"] = np.array(res["train_epoch_reward"])
+        out[f"{tag}_train_rewards"] = np.array(res["train_rewards"], dtype=np.float64).reshape(-1)
+        out[f"{tag}_current_ob"] = np.asarray(col.current_ob).copy()
+        out[f"{tag}_epsilon_count"] = np.array([pf.epsilon, pf.count], dtype=np.float64)
+        out[f"{tag}_args"] = np.array([N, steps, rows, max_frames, seed], dtype=np.int64)
+        term = out[f"{tag}_buf_terminals"].reshape(rows, N)[:steps]
+        reset = np.zeros((steps, N), dtype=bool)
+        for m in masks:
+            reset[int(m[0])] |= m[1:].astype(bool)
+        assert term.any() and (reset & (term == 0)).any(), "want both fallen poles and over-length resets"
+        for m in masks:
+            t, mask = int(m[0]), m[1:].astype(bool)
+            assert not np.array_equal(out[f"{tag}_buf_next_obs"][t][mask], np.stack(true_next)[t][mask])
+
     # ---- on-policy (VecOnPolicyCollector): the bootstrap value uses the TRUE next observation, the row the reset one ----
     for tag, kind, N, T, horizon, max_frames, seed in (
             ("on_pendulum_mixed", "short_pendulum", 4, 24, 0, 5, 6),

@@ -370,3 +370,47 @@ def test_reference_vecenv_alias_of_reset_observations_on_policy(golden, tag, kin
         t, mask = int(m[0]), m[1:].astype(bool)
         assert np.abs(stored[t][mask] - true_next[t][mask]).max() > 1e-4
         np.testing.assert_allclose(stored[t][~mask], true_next[t][~mask], atol=3e-5)
+
+
+def test_reference_vecenv_alias_with_discrete_actions_and_fallen_poles(golden):
+    """The same pin for DISCRETE actions: the reference's VecCollector with an epsilon-greedy Q policy (numpy global stream,
+    discrete_policies.py:43-67) over its own VecEnv of cart-poles -- poles that fall (`done`: terminals True) and envs the
+    collector resets at max_episode_frames (terminals False, the TD target bootstraps from the stored row) in one ring."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector import VecCollector
+    from torchrl.env import VecEnv
+    from torchrl.env.py_envs import CartPoleEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    g = golden("collect_hostenv")
+    tag = "off_cartpole_dqn"
+    N, steps, rows, max_frames, seed = (int(v) for v in g[tag + "_args"])
+    env, eval_env = VecEnv(N, CartPoleEnv, ()), VecEnv(N, CartPoleEnv, ())
+    env.seed(seed)
+    eval_env.seed(seed + 1)
+    qf = _state(g, tag + "_qf_", networks.Net(input_shape=4, output_shape=2, hidden_shapes=[32, 32], append_hidden_shapes=[],
+                                               base_type=networks.MLPBase, activation_func=torch.nn.ReLU))
+    pf = policies.EpsilonGreedyDQNDiscretePolicy(qf, start_epsilon=0.8, end_epsilon=0.3, decay_frames=25, action_shape=2)
+    np.random.seed(seed)
+    buf = BaseReplayBuffer(N * rows, env_nums=N)
+    col = VecCollector(env=env, eval_env=eval_env, pf=pf, replay_buffer=buf, device=torch.device(DEV), train_render=False,
+                       epoch_frames=N * steps, max_episode_frames=max_frames, eval_episodes=1)
+    np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_ob0"], atol=1e-6)
+    res = col.train_one_epoch()
+    for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+        got = getattr(buf, "_" + k).cpu().numpy()[:steps]
+        want = np.asarray(g[f"{tag}_buf_{k}"], dtype=np.float64)[:steps].reshape(got.shape)
+        np.testing.assert_allclose(got, want, atol=3e-5, err_msg=k)
+    assert [buf._top, buf._size] == list(g[tag + "_top_size"])
+    assert [pf.epsilon, pf.count] == list(g[tag + "_epsilon_count"])
+    np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_current_ob"], atol=3e-5)
+    np.testing.assert_allclose(np.array(res["train_rewards"], dtype=np.float64), g[tag + "_train_rewards"], atol=1e-6)
+    assert abs(res["train_epoch_reward"] - float(g[tag + "_train_epoch_reward"])) < 1e-6
+    stored, true_next, term = buf._next_obs.cpu().numpy(), g[tag + "_true_next_obs"], buf._terminals.cpu().numpy().reshape(rows, N)
+    over_length = 0
+    for m in g[tag + "_reset_mask"]:
+        t, mask = int(m[0]), m[1:].astype(bool)
+        assert np.abs(stored[t][mask] - true_next[t][mask]).max() > 1e-4        # the reset observation, not the env's own
+        np.testing.assert_allclose(stored[t][~mask], true_next[t][~mask], atol=3e-5)
+        over_length += int((mask & (term[t] == 0)).sum())
+    assert over_length > 0 and term[:steps].sum() > 0
