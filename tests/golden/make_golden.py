@@ -1138,6 +1138,43 @@ def case_collect_hostenv():
             t, mask = int(m[0]), m[1:].astype(bool)
             assert not np.array_equal(out[f"{tag}_buf_next_obs"][t][mask], np.stack(true_next)[t][mask])
 
+    # ---- the reference's SubProcVecEnv (spawned workers; its partial_reset writes into the stacked array too,
+    # env/subproc_vecenv.py:108-121) under VecCollector: env `done` resets and collector resets ----
+    from torchrl.env.subproc_vecenv import SubProcVecEnv
+    os.environ["PYTHONPATH"] = os.pathsep.join(p for p in sys.path if p)     # for the spawned workers
+    for tag, N, procs, steps, rows, horizon, max_frames, seed in (("off_subproc_done", 6, 3, 11, 12, 3, 999, 9),
+                                                                  ("off_subproc_overlength", 6, 3, 11, 12, 1000, 4, 10)):
+        env = SubProcVecEnv(procs, N, SynthSingleEnvCPU, (0, horizon))      # (workers ignore `seed`, Q15: every env has seed 0)
+        eval_env = None
+        try:
+            env.example_env.action_space = gym.spaces.Box(-1, 1, (6,))
+            torch.manual_seed(seed + 40)
+            net = dict(hidden_shapes=[32, 32], append_hidden_shapes=[], base_type=networks.MLPBase,
+                       activation_func=torch.nn.ReLU)
+            pf = policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net)
+            torch.manual_seed(seed)
+            buf = BaseReplayBuffer(N * rows, env_nums=N)
+            col = VecCollector(env=env, eval_env=env, pf=pf, replay_buffer=buf, device=torch.device("cpu"),
+                               train_render=False, epoch_frames=N * steps, max_episode_frames=max_frames, eval_episodes=1)
+            masks, true_next = logged(env, lambda: len(true_next) - 1)
+            out.update(state_arrays(f"{tag}_pf_", pf))
+            out[f"{tag}_ob0"] = np.asarray(col.current_ob).copy()
+            res = col.train_one_epoch()
+        finally:
+            env.close()
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+            out[f"{tag}_buf_{k}"] = np.asarray(getattr(buf, "_" + k)).copy()
+        out[f"{tag}_top_size"] = np.array([buf._top, buf._size], dtype=np.int64)
+        out[f"{tag}_reset_mask"] = np.stack(masks)
+        out[f"{tag}_true_next_obs"] = np.stack(true_next)
+        out[f"{tag}_train_epoch_reward"] = np.array(res["train_epoch_reward"])
+        out[f"{tag}_train_rewards"] = np.array(res["train_rewards"], dtype=np.float64).reshape(-1)
+        out[f"{tag}_current_ob"] = np.asarray(col.current_ob).copy()
+        out[f"{tag}_args"] = np.array([N, procs, steps, rows, horizon, max_frames, seed], dtype=np.int64)
+        for m in masks:
+            t, mask = int(m[0]), m[1:].astype(bool)
+            assert not np.array_equal(out[f"{tag}_buf_next_obs"][t][mask], np.stack(true_next)[t][mask])
+
     # ---- on-policy (VecOnPolicyCollector): the bootstrap value uses the TRUE next observation, the row the reset one ----
     for tag, kind, N, T, horizon, max_frames, seed in (
             ("on_pendulum_mixed", "short_pendulum", 4, 24, 0, 5, 6),

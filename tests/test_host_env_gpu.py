@@ -414,3 +414,48 @@ def test_reference_vecenv_alias_with_discrete_actions_and_fallen_poles(golden):
         np.testing.assert_allclose(stored[t][~mask], true_next[t][~mask], atol=3e-5)
         over_length += int((mask & (term[t] == 0)).sum())
     assert over_length > 0 and term[:steps].sum() > 0
+
+
+@pytest.mark.parametrize("tag", ["off_subproc_done", "off_subproc_overlength"])
+def test_reference_subproc_vecenv_alias_of_reset_observations(golden, tag):
+    """The reference's SubProcVecEnv writes the fresh observations into the stacked array `step` returned as well
+    (env/subproc_vecenv.py:108-121); under its VecCollector the ring's `next_obs` rows of reset envs are the reset
+    observations -- after env `done` and after the collector's own limit.  The product's SubProcVecEnv (spawned workers)
+    under the device collector must store the same ring."""
+    import torchrl.networks as networks
+    import torchrl.policies as policies
+    from torchrl.collector import VecCollector
+    from torchrl.env import SubProcVecEnv
+    from torchrl.replay_buffers import BaseReplayBuffer
+    g = golden("collect_hostenv")
+    N, procs, steps, rows, horizon, max_frames, seed = (int(v) for v in g[tag + "_args"])
+    env = SubProcVecEnv(procs, N, [SynthSingleEnvCPU] * N, [(0, horizon)] * N)    # (the reference's workers ignore `seed`: all 0)
+    assert env.alias_reset_obs
+    col = None
+    try:
+        net = dict(hidden_shapes=[32, 32], append_hidden_shapes=[], base_type=networks.MLPBase, activation_func=torch.nn.ReLU)
+        pf = _state(g, tag + "_pf_", policies.GuassianContPolicy(input_shape=17, output_shape=12, tanh_action=True, **net))
+        torch.manual_seed(seed)
+        buf = BaseReplayBuffer(N * rows, env_nums=N)
+        col = VecCollector(env=env, eval_env=None, pf=pf, replay_buffer=buf, device=torch.device(DEV), train_render=False,
+                           epoch_frames=N * steps, max_episode_frames=max_frames, eval_episodes=1)
+        np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_ob0"], atol=1e-6)
+        res = col.train_one_epoch()
+        for k in ("obs", "next_obs", "acts", "rewards", "terminals", "time_limits"):
+            got = getattr(buf, "_" + k).cpu().numpy()[:steps]
+            np.testing.assert_allclose(got, np.asarray(g[f"{tag}_buf_{k}"], dtype=np.float64)[:steps].reshape(got.shape),
+                                       atol=3e-5, err_msg=k)
+        assert [buf._top, buf._size] == list(g[tag + "_top_size"])
+        np.testing.assert_allclose(col.current_ob.cpu().numpy(), g[tag + "_current_ob"], atol=3e-5)
+        assert abs(res["train_epoch_reward"] - float(g[tag + "_train_epoch_reward"])) < 1e-3
+        np.testing.assert_allclose(np.array(res["train_rewards"], dtype=np.float64), g[tag + "_train_rewards"], atol=1e-4)
+        stored, true_next = buf._next_obs.cpu().numpy(), g[tag + "_true_next_obs"]
+        assert len(g[tag + "_reset_mask"]) >= 2
+        for m in g[tag + "_reset_mask"]:
+            t, mask = int(m[0]), m[1:].astype(bool)
+            assert np.abs(stored[t][mask] - true_next[t][mask]).max() > 1e-4
+    finally:
+        if col is not None:
+            col.terminate()
+        else:
+            env.close()
