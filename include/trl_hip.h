@@ -381,6 +381,20 @@ int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, in
                             int D, int H, int A, float* grads, double* info,
                             const trl_adam_t* adam, float* workspace, void* stream);
 
+/* The whole minibatch step of ONE process as ONE launch: trl_ppo_minibatch_grad_f32 followed, inside the same launch, by
+ * what trl_ppo_reduce_adam_f32 does (PPO.update's backward, clip_grad_norm_ and optimizer.step of both networks,
+ * torchrl/algo/on_policy/ppo.py:67-75, 113-122) -- the workgroups of the gradient grid meet through device-scope flags,
+ * fold the partial rows in trl_ppo_reduce_f32's order and step their own 64 parameters; results are bit-identical to the
+ * two-launch sequence.  args->n_wg must not exceed trl_ppo_step_max_workgroups() (every workgroup has to be resident at
+ * once: TRL_EUNSUPPORTED otherwise -- use the two launches), adam->params / + P_pf must be args->pf_params / vf_params,
+ * adam->grads == grads.  workspace: trl_ppo_step_workspace(D, H, A) floats, zeroed once; it begins with
+ * trl_ppo_reduce_adam_f32's workspace (same Adam header), so both routes may be used on it in turn.  A rendezvous that does
+ * not complete within ~2 s sets workspace word 0 and info[23] and leaves the parameters untouched. */
+int trl_ppo_step_workspace(int D, int H, int A);
+int trl_ppo_step_max_workgroups(void);
+int trl_ppo_minibatch_step_f32(const trl_ppo_batch_t* args, float* grads, double* info, const trl_adam_t* adam,
+                               float* workspace, void* stream);
+
 typedef struct trl_comm trl_comm_t;   /* opaque communicator, see the collectives section below */
 /* --- C1 / C2 / C3: collectives of the multi-GPU path ---------------
  * The reference has no distributed backend; with envs sharded by index over one process per GPU

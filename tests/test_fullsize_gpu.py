@@ -191,3 +191,66 @@ def test_full_size_headline_configuration_prefetched_parallel_reference_noise():
     assert counts["carried"] >= 1, counts                              # the default transport of the headline
     assert noise.STATS["parallel_blocks"] - par0 >= 3                  # every block came from the multi-threaded draw
     assert col._prefetcher.dropped_blocks == 0
+
+
+def test_cfg2_iteration_vs_oracle(errlog):
+    """The headline configuration against the CPU oracle, directly: 2048 envs x 128 steps with the reference's noise stream
+    (torchrl/collector/on_policy.py:90-155), GAE (on_rl_algo.py:22-33, replay_buffers/on_policy.py:16-44) and one pass of
+    four B = 65 536 updates (ppo.py:124-152) -- the 128-workgroup rollout grid, the 256-workgroup gradient grid and the ring
+    offsets at N = 2048 tied to the oracle rather than to themselves.  Tolerances of SURVEY.md section 8 (a1 / a6 / a11):
+    buffers abs 1e-5, advantages abs 2e-5 / rel 1e-3, info scalars rel 1e-4 / abs 1e-5, parameters abs 1e-6."""
+    from oracle import replay as oreplay
+    from oracle.collector import VecOnPolicyCollectorOracle
+    from oracle.ppo import PPOOracle
+    from oracle.synth_env import SynthVecEnvCPU
+    seed = 5
+    pf, vf, env, buf, col, agent = make(N, seed=seed, noise="host")
+    agent.logger.infos.clear()
+    pf_p = [p.detach().cpu().clone() for p in pf._mlp2_param_list()]
+    vf_p = [p.detach().cpu().clone() for p in vf._mlp2_param_list()]
+    ls = pf.logstd.detach().cpu().clone()
+    torch.manual_seed(seed)
+    col.train_one_epoch()
+    agent.current_epoch = 1
+    np.random.seed(seed + 100)
+    agent.update_per_epoch()
+    torch.cuda.synchronize()
+    infos = list(agent.logger.infos)
+    assert len(infos) == N * T // B == 4
+
+    oenv = SynthVecEnvCPU(N, horizon=50)
+    oenv.seed(seed)
+    ring = oreplay.RingOracle(N * T, env_nums=N, time_limit_filter=True)
+    ocol = VecOnPolicyCollectorOracle(oenv, ring, pf_p, ls, vf_p, epoch_frames=N * T, max_episode_frames=40)
+    torch.manual_seed(seed)
+    ocol.train_one_epoch()
+    o = PPOOracle(pf_p, ls, vf_p, plr=3e-4, vlr=3e-4, entropy_coeff=0.005, clip_para=0.2, opt_epochs=1,
+                  num_epochs=10, batch_size=B, discount=0.99, tau=0.95)
+    np.random.seed(seed + 100)
+    want_infos = o.epoch(ring, 1)
+    assert float(ring.data["terminals"].sum()) > 0                                                  # episodes ended inside the rollout
+
+    for k in ("obs", "next_obs", "acts", "values", "rewards", "terminals", "time_limits"):
+        err = np.abs(getattr(buf, "_" + k).cpu().numpy().astype(np.float64) - ring.data[k]).max()
+        errlog("cfg 2 full size: buffer %s abs" % k, err, 1e-5)
+        assert err < 1e-5, (k, err)
+    for k, name in (("advs", "advs"), ("estimate_returns", "estimate_returns")):
+        got, want = getattr(buf, "_" + k).cpu().numpy().astype(np.float64), ring.data[name]
+        errlog("cfg 2 full size: %s, max of |got - want| / (2e-5 + 1e-3 |want|)" % k,
+               (np.abs(got - want) / (2e-5 + 1e-3 * np.abs(want))).max(), 1.0)
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-5)
+    keys = sorted(want_infos[0].keys())
+    assert sorted(infos[0].keys()) == keys and len(want_infos) == 4
+    got = np.array([[i[k] for k in keys] for i in infos])
+    want = np.array([[i[k] for k in keys] for i in want_infos])
+    rel = np.abs(got - want) / (1e-5 + 1e-4 * np.abs(want))
+    errlog("cfg 2 full size: info scalars, max of |got - want| / (1e-5 + 1e-4 |want|)", rel.max(), 1.0)
+    bad = np.argwhere(rel > 1.0)
+    assert len(bad) == 0, [(int(r), keys[c], float(got[r, c]), float(want[r, c])) for r, c in bad]
+    got_p = torch.cat([p.detach().reshape(-1) for p in pf._mlp2_param_list()] + [pf.logstd.detach().reshape(-1)] +
+                      [p.detach().reshape(-1) for p in vf._mlp2_param_list()]).cpu()
+    want_p = torch.cat([p.detach().reshape(-1) for p in o.pf] + [o.logstd.detach().reshape(-1)] +
+                       [p.detach().reshape(-1) for p in o.vf])
+    perr = (got_p - want_p).abs().max().item()
+    errlog("cfg 2 full size: post-epoch params abs (4 updates of 65 536)", perr, 1e-6)
+    assert perr < 1e-6, perr

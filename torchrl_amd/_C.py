@@ -174,6 +174,9 @@ SIGNATURES = {
     "trl_ppo_reduce_adam_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_reduce_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
+    "trl_ppo_step_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "trl_ppo_step_max_workgroups": (C.c_int, []),
+    "trl_ppo_minibatch_step_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
     "trl_synth_reset_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "trl_gauss_logp_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "trl_concat2_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),

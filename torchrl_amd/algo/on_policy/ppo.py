@@ -149,8 +149,16 @@ class _FusedPPO:
         self.max_wg = 2 * max(1, self.n_cu // 2)
         self.partial = torch.zeros(self.max_wg, self.p_stride, device=self.dev)
         self.scal = torch.zeros(self.max_wg, 8, dtype=torch.float64, device=self.dev)
-        n_ws = _C.lib().trl_ppo_reduce_adam_workspace(self.D, self.H, self.A)
-        self.red_ws = torch.zeros(n_ws, device=self.dev)              # header + norm slots of the fused reduce/Adam
+        n_ws = _C.lib().trl_ppo_step_workspace(self.D, self.H, self.A)   # (begins with trl_ppo_reduce_adam_f32's workspace)
+        self.red_ws = torch.zeros(n_ws, device=self.dev)              # Adam header + flags / norm granules of the fused step
+        # TRL_PPO_STEP=fused (opt-in): the whole minibatch step as ONE launch (trl_ppo_minibatch_step_f32 -- its workgroups
+        # meet inside the launch, so the grid must be resident at once; one process per device).  Same bits as the default
+        # two-launch sequence (gradient, then fold / clip / Adam), and on MI355X 4 us per step SLOWER: rows that cross XCDs
+        # inside a launch must be written through to the coherence point and every dependent hop costs 2.2-2.6 us, which is
+        # what a graph-captured launch boundary costs too (profiles/NOTES_r06.md).
+        self.one_launch = os.environ.get("TRL_PPO_STEP", "split") == "fused"
+        self.step_max_wg = _C.lib().trl_ppo_step_max_workgroups()
+        self.one_launch = os.environ.get("TRL_PPO_STEP", "fused") != "split"
         self.red_ws[4:8].view(torch.float64).fill_(1.0)               # beta1^0, beta2^0 (device-side Adam state)
 
     def _alias_optimizer_state(self, opt, plist, offset):
@@ -245,6 +253,7 @@ class _FusedPPO:
         loss_mode = int(getattr(algo, "loss_mode", _C.LOSS_PPO_CLIP))
         probe = getattr(self, "probe", None)                           # bench.py: HIP events around the grad kernel
         fused = not dist.collectives_active()
+        one_launch = fused and self.one_launch and n_wg <= self.step_max_wg
         # Env shards on several ranks with the peer transport up (dist.init_comm): the gradient SUM over ranks happens
         # INSIDE the fold / clip / Adam launch (trl_ppo_reduce_adam_xrank_f32) and the statistics go through the
         # one-kernel all-reduce -- plain launches, so the sequence is graph-replayed exactly like the single-process one.
@@ -272,7 +281,7 @@ class _FusedPPO:
         hyper = (float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
                  int(bool(getattr(algo, "clipped_value_loss", False))), int(bool(algo.pf.tanh_action)))
         use_graph = (fused or xrank or graph_coll) and probe is None and os.environ.get("TRL_NO_GRAPH") != "1"
-        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, xrank, in_place) + hyper + tuple(
+        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, xrank, in_place, one_launch) + hyper + tuple(
             0 if t.get(k) is None else t[k].data_ptr() for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
 
         def launch_all():
@@ -318,6 +327,14 @@ class _FusedPPO:
                 if probe is not None:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
+                if one_launch:                                         # gradient + fold + clip + Adam: one launch
+                    _C.check(lib.trl_ppo_minibatch_step_f32(C.byref(g), self.grads.data_ptr(), info_base + 192 * k,
+                                                            C.byref(a), self.red_ws.data_ptr(), stream),
+                             "trl_ppo_minibatch_step_f32")
+                    if probe is not None:
+                        ev[1].record()
+                        probe.append(ev)
+                    continue
                 _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "trl_ppo_minibatch_grad_f32")
                 if probe is not None:
                     ev[1].record()
@@ -367,6 +384,10 @@ class _FusedPPO:
         def build(host):
             if xrank:
                 dist.check_comm()                                      # a rank that never delivered: raise, do not hang
+            if one_launch and host[4 * K:28 * K].view(K, 24)[:, 23].any():
+                raise _C.TrlError("trl_ppo_minibatch_step_f32: the in-launch rendezvous of a minibatch step timed out (its "
+                                  "workgroups were not resident together -- is another process using this GPU?); the "
+                                  "parameters of that step were left untouched.  TRL_PPO_STEP=split uses two launches.")
             return make(host[:4 * K].view(K, 4).numpy(), host[4 * K:28 * K].view(K, 24).numpy(),
                         host[28 * K:].view(torch.float32).view(K, 2).numpy(), n_global)
         pending = _PendingInfos(K, landed, host, build)

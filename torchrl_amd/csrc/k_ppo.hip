@@ -97,7 +97,9 @@ __device__ __forceinline__ float row_sum16(float v) {
 // D = 32 (WIDE, RT only; a.D in [18, 32] -- Ant's 27 observations): input features 16..31 are a SECOND 16-wide k group of
 // the first layer (four more MFMA steps forward, a second accumulator tile per slice for dW1) instead of the single
 // 17th column that rides on the VALU.
-template <int D, int H, int A, int ACT, bool IS_PF, bool CONTIG, bool RT>
+// WT: the workgroup's partial row is folded by other workgroups of THIS launch (the one-launch step): it leaves as
+// device-scope write-through stores instead of plain ones
+template <int D, int H, int A, int ACT, bool IS_PF, bool CONTIG, bool RT, bool WT = false>
 __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_wg_net) {
   using S = WvShape<D, H, A>;
   constexpr bool WIDE = D > 17;                      // a second 16-feature group (features 16 .. 31) on the matrix pipe
@@ -666,7 +668,13 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
     f32x4 acc = lds4(lds + 4 * e4);
 #pragma unroll
     for (int w = 1; w < WV_WAVES; ++w) acc += lds4(lds + w * S::P_STRIDE + 4 * e4);          // same order per element
-    *reinterpret_cast<f32x4*>(a.partial + (size_t)wg * a.p_stride + 4 * e4) = acc;
+    if constexpr (WT) {      // read by other workgroups of THIS launch: written through to the device's coherence point
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.partial + (size_t)wg * a.p_stride + 4 * e4);
+      __hip_atomic_store(dst, ((unsigned long long)__float_as_uint(acc[1]) << 32) | __float_as_uint(acc[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, ((unsigned long long)__float_as_uint(acc[3]) << 32) | __float_as_uint(acc[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      *reinterpret_cast<f32x4*>(a.partial + (size_t)wg * a.p_stride + 4 * e4) = acc;
+    }
   }
   WCLK(8)
 #ifdef TRL_EXP_CLK
@@ -693,15 +701,12 @@ __device__ void ppo_wave_pass(const PpoDev& a, float* lds, int wg_in_net, int n_
       const double o = sred[w * 8 + tid];
       r = (tid >= 2 && tid <= 5) ? fmax(r, o) : r + o;
     }
-    a.scal_partial[(size_t)wg * 8 + tid] = r;
+    if constexpr (WT)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.scal_partial + (size_t)wg * 8 + tid),
+                         (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      a.scal_partial[(size_t)wg * 8 + tid] = r;
   }
-}
-
-template <int D, int H, int A, int ACT, bool CONTIG, bool RT>
-__global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x < a.n_pf) ppo_wave_pass<D, H, A, ACT, true, CONTIG, RT>(a, lds, blockIdx.x, a.n_pf);
-  else                          ppo_wave_pass<D, H, A, ACT, false, CONTIG, RT>(a, lds, blockIdx.x - a.n_pf, a.n_wg - a.n_pf);
 }
 
 // ---------------------------------------------------------------- partial reduce
@@ -719,6 +724,136 @@ __global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a) 
 #ifndef RED_DEPTH
 #define RED_DEPTH 16
 #endif
+// ---- pieces of the fold shared by the stand-alone launch (8 waves per 64 parameters) and by the tail of the fused
+// minibatch step (4 waves, each playing two of the 8): the association order is part of the contract -- both give the
+// same bits.  Rows of one network's partials are dealt to 8 "fold waves" (row r -> wave r % 8), each with RED_DEPTH
+// independent chains (chain k takes rows w + 8 k + 128 round, in round order), chains folded pairwise (k with
+// k + 8, 4, 2, 1), fold waves as ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)).
+__device__ __forceinline__ float fold_chain_tree(float (&acc)[RED_DEPTH]) {
+#pragma unroll
+  for (int st = RED_DEPTH / 2; st > 0; st >>= 1)
+#pragma unroll
+    for (int k = 0; k < st; ++k) acc[k] += acc[k + st];
+  return acc[0];
+}
+// one fold wave: src = first row of the network + this lane's parameter
+__device__ __forceinline__ float fold_rows_wave(const float* __restrict__ src, int nrow, int p_stride, int w, bool in_range) {
+  // 16 independent loads in flight per lane and round: the fold is latency-, not bandwidth-bound
+  float acc[RED_DEPTH];
+#pragma unroll
+  for (int k = 0; k < RED_DEPTH; ++k) acc[k] = 0.0f;
+  if (in_range) {
+    for (; w < nrow; w += RED_DEPTH * RED_WAVES) { // predicated: a ragged row count must not fall back to a serial tail
+      float v[RED_DEPTH];
+#pragma unroll
+      for (int k = 0; k < RED_DEPTH; ++k) v[k] = (w + RED_WAVES * k < nrow) ? src[(size_t)(w + RED_WAVES * k) * p_stride] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < RED_DEPTH; ++k) acc[k] += v[k];
+    }
+  }
+  return fold_chain_tree(acc);
+}
+// two fold waves (w and w + 4) by one real wave, all their loads of a round in flight together
+// COH: the rows were written by other workgroups of THIS launch -- device-coherent loads (not served from this XCD's L2)
+template <bool COH> __device__ __forceinline__ float row_load(const float* p) {
+  if constexpr (COH) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void fold_rows_wave_pair(const float* __restrict__ src, int nrow, int p_stride, int w, bool in_range,
+                                                    float& r0, float& r1) {
+  float a0[RED_DEPTH], a1[RED_DEPTH];
+#pragma unroll
+  for (int k = 0; k < RED_DEPTH; ++k) a0[k] = a1[k] = 0.0f;
+  if (in_range) {
+    for (; w < nrow; w += RED_DEPTH * RED_WAVES) {
+      float v0[RED_DEPTH], v1[RED_DEPTH];
+#pragma unroll
+      for (int k = 0; k < RED_DEPTH; ++k) {
+        v0[k] = (w + RED_WAVES * k < nrow) ? row_load<COH>(src + (size_t)(w + RED_WAVES * k) * p_stride) : 0.0f;
+        v1[k] = (w + 4 + RED_WAVES * k < nrow) ? row_load<COH>(src + (size_t)(w + 4 + RED_WAVES * k) * p_stride) : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < RED_DEPTH; ++k) { a0[k] += v0[k]; a1[k] += v1[k]; }
+    }
+  }
+  r0 = fold_chain_tree(a0);
+  r1 = fold_chain_tree(a1);
+}
+__device__ __forceinline__ float fold_waves_tree(const float (*s_acc)[RED_CHUNK], int lane) {
+  float t4[RED_WAVES / 4];
+#pragma unroll
+  for (int q = 0; q < RED_WAVES / 4; ++q)
+    t4[q] = (s_acc[4 * q][lane] + s_acc[4 * q + 1][lane]) + (s_acc[4 * q + 2][lane] + s_acc[4 * q + 3][lane]);
+  float gval = t4[0];
+#pragma unroll
+  for (int q = 1; q < RED_WAVES / 4; ++q) gval += t4[q];
+  return gval;
+}
+// one wave: a network's loss / log-prob / value statistics from the workgroups' scalar rows, every row requested at once
+// (4 x 7 loads in flight per lane: up to 256 workgroups per network in one round trip; the per-lane accumulation order is
+// the one of the strided loop)
+template <bool COH = false>
+__device__ __forceinline__ void fold_scalar_stats(const double* __restrict__ base, int nrow, int net, int lane,
+                                                  double* __restrict__ info) {
+  double v[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? -INFINITY : 0.0;
+  for (int w0 = 0; w0 < nrow; w0 += 256) {
+    double o[4][7];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int w = w0 + lane + 64 * q;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        double x = (k >= 2 && k <= 5) ? -INFINITY : 0.0;
+        if (w < nrow) {
+          if constexpr (COH) x = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(base + (size_t)w * 8 + k),
+                                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          else x = base[(size_t)w * 8 + k];
+        }
+        o[q][k] = x;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? fmax(v[k], o[q][k]) : v[k] + o[q][k];
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? wave_max(v[k]) : wave_sum(v[k]);
+  if (lane == 0) {
+    if (net == 0) {
+      info[0] = v[6]; info[1] = v[0]; info[2] = v[1]; info[3] = v[2]; info[4] = v[3]; info[5] = v[4]; info[6] = v[5];
+    } else {
+      info[7] = v[6];
+      info[12] = v[0]; info[13] = v[1]; info[14] = v[2]; info[15] = v[3];   // v_pred: sum, sum of squares, max, -min
+    }
+  }
+}
+// one wave: log_std/{mean,std,max,min} (ppo.py:82-85) and the same four for std = exp(clamped logstd) (a2c.py:95-100),
+// one action dimension per lane (raw = the lane's log_std as stored, lanes >= n_act: anything)
+__device__ __forceinline__ void fold_logstd_stats_raw(float raw, int n_act, int lane, double* __restrict__ info) {
+  const bool has = lane < n_act;
+  const double x = has ? fmin(fmax((double)raw, -20.0), 2.0) : 0.0;
+  const double e = has ? exp(x) : 0.0;
+  const double sm = wave_sum(x), sq = wave_sum(x * x), es = wave_sum(e), eq = wave_sum(e * e);
+  const double mx = wave_max(has ? x : -INFINITY), mn = -wave_max(has ? -x : -INFINITY);
+  const double emx = wave_max(has ? e : -INFINITY), emn = -wave_max(has ? -e : -INFINITY);
+  if (lane == 0) {
+    const double mean = sm / n_act, em = es / n_act;
+    info[8] = mean;
+    info[9] = n_act > 1 ? sqrt(fmax((sq - sm * mean) / (n_act - 1), 0.0)) : NAN;
+    info[10] = mx; info[11] = mn;
+    info[16] = em;
+    info[17] = n_act > 1 ? sqrt(fmax((eq - es * em) / (n_act - 1), 0.0)) : NAN;
+    info[18] = emx; info[19] = emn;
+  }
+}
+__device__ __forceinline__ void fold_logstd_stats(const float* __restrict__ logstd, int n_act, int lane, double* __restrict__ info) {
+  fold_logstd_stats_raw(logstd[lane < n_act ? lane : 0], n_act, lane, info);
+}
+
 // returns (wave 0 lanes) this block's reduced gradient value, 0 outside the parameter range
 __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ partial,
                                                   const double* __restrict__ scal, int n_wg, int n_pf,
@@ -733,93 +868,21 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * RED_CHUNK + lane;
   const int pn = net == 0 ? p_pf : p_vf;
-  // 16 independent loads in flight per lane and round: the fold is latency-, not bandwidth-bound
-  float acc[RED_DEPTH];
-#pragma unroll
-  for (int k = 0; k < RED_DEPTH; ++k) acc[k] = 0.0f;
-  if (p < pn) {
-    const float* src = partial + (size_t)row0 * p_stride + p;
-    int w = wave;
-    for (; w < nrow; w += RED_DEPTH * RED_WAVES) { // predicated: a ragged row count must not fall back to a serial tail
-      float v[RED_DEPTH];
-#pragma unroll
-      for (int k = 0; k < RED_DEPTH; ++k) v[k] = (w + RED_WAVES * k < nrow) ? src[(size_t)(w + RED_WAVES * k) * p_stride] : 0.0f;
-#pragma unroll
-      for (int k = 0; k < RED_DEPTH; ++k) acc[k] += v[k];
-    }
-  }
-#pragma unroll
-  for (int st = RED_DEPTH / 2; st > 0; st >>= 1)
-#pragma unroll
-    for (int k = 0; k < st; ++k) acc[k] += acc[k + st];
-  s_acc[wave][lane] = acc[0];
+  s_acc[wave][lane] = fold_rows_wave(partial + (size_t)row0 * p_stride + p, nrow, p_stride, wave, p < pn);
   __syncthreads();
   float gval = 0.0f;
   if (wave == 0 && p < pn) {
-    float t4[RED_WAVES / 4];
-#pragma unroll
-    for (int q = 0; q < RED_WAVES / 4; ++q)
-      t4[q] = (s_acc[4 * q][lane] + s_acc[4 * q + 1][lane]) + (s_acc[4 * q + 2][lane] + s_acc[4 * q + 3][lane]);
-    gval = t4[0];
-#pragma unroll
-    for (int q = 1; q < RED_WAVES / 4; ++q) gval += t4[q];
+    gval = fold_waves_tree(s_acc, lane);
     grads[(net == 0 ? 0 : p_pf) + p] = gval;
   }
   // Scalar statistics.  They used to sit in block (0, 0) -- three dependent rounds of loads over the workgroup partials and
   // then the log_std / std statistics as a serial double-precision loop (six exp() in ONE lane): ~5 us that the whole
   // launch waited for, twice the time of the fold itself.  Now the LAST block of each network's row takes them, off the
-  // path of the blocks whose 64 parameters matter: wave 2 its network's loss / log-prob / value statistics with every row
-  // requested at once (4 x 7 loads in flight per lane: up to 256 workgroups per network in one round trip; the per-lane
-  // accumulation order is the one of the strided loop), wave 3 of the policy's block log_std and std with one action
-  // dimension per lane.
+  // path of the blocks whose 64 parameters matter: wave 2 its network's statistics, wave 3 of the policy's block log_std
+  // and std.
   const bool stat_block = blockIdx.x == gridDim.x - 1;
-  if (stat_block && wave == 2) {
-    const double* base = scal + (size_t)row0 * 8;
-    double v[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? -INFINITY : 0.0;
-    for (int w0 = 0; w0 < nrow; w0 += 256) {
-      double o[4][7];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int w = w0 + lane + 64 * q;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) o[q][k] = (w < nrow) ? base[(size_t)w * 8 + k] : ((k >= 2 && k <= 5) ? -INFINITY : 0.0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? fmax(v[k], o[q][k]) : v[k] + o[q][k];
-    }
-#pragma unroll
-    for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? wave_max(v[k]) : wave_sum(v[k]);
-    if (lane == 0) {
-      if (net == 0) {
-        info[0] = v[6]; info[1] = v[0]; info[2] = v[1]; info[3] = v[2]; info[4] = v[3]; info[5] = v[4]; info[6] = v[5];
-      } else {
-        info[7] = v[6];
-        info[12] = v[0]; info[13] = v[1]; info[14] = v[2]; info[15] = v[3];   // v_pred: sum, sum of squares, max, -min
-      }
-    }
-  }
-  if (stat_block && net == 0 && wave == 3 && logstd) {
-    // log_std/{mean,std,max,min} (ppo.py:82-85) and the same four for std = exp(clamped logstd) (a2c.py:95-100)
-    const bool has = lane < n_act;
-    const double x = has ? fmin(fmax((double)logstd[has ? lane : 0], -20.0), 2.0) : 0.0;
-    const double e = has ? exp(x) : 0.0;
-    const double sm = wave_sum(x), sq = wave_sum(x * x), es = wave_sum(e), eq = wave_sum(e * e);
-    const double mx = wave_max(has ? x : -INFINITY), mn = -wave_max(has ? -x : -INFINITY);
-    const double emx = wave_max(has ? e : -INFINITY), emn = -wave_max(has ? -e : -INFINITY);
-    if (lane == 0) {
-      const double mean = sm / n_act, em = es / n_act;
-      info[8] = mean;
-      info[9] = n_act > 1 ? sqrt(fmax((sq - sm * mean) / (n_act - 1), 0.0)) : NAN;
-      info[10] = mx; info[11] = mn;
-      info[16] = em;
-      info[17] = n_act > 1 ? sqrt(fmax((eq - es * em) / (n_act - 1), 0.0)) : NAN;
-      info[18] = emx; info[19] = emn;
-    }
-  }
+  if (stat_block && wave == 2) fold_scalar_stats(scal + (size_t)row0 * 8, nrow, net, lane, info);
+  if (stat_block && net == 0 && wave == 3 && logstd) fold_logstd_stats(logstd, n_act, lane, info);
   return gval;
 }
 
@@ -1037,6 +1100,234 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   }
 }
 
+// ---------------------------------------------------------------- the whole minibatch step in ONE launch
+// trl_ppo_minibatch_step_f32: the gradient pass above, then -- inside the same launch -- what ppo_reduce_adam_kernel does
+// (fold of the workgroups' partial rows, clip_grad_norm_, Adam; ppo.py:72-74, 117-122).  Every workgroup of the gradient
+// grid is resident at once (one per CU: 416 registers per wave, 100 KB of LDS), so they can meet:
+//   1. a workgroup stores its partial row and scalar row, makes them visible (agent-scope release) and raises its arrival
+//      flag = this launch's sequence number;
+//   2. it polls all n_wg flags (one per thread), then (acquire) owns fold jobs c = wg, wg + n_wg, ...: job c < 2 nb is the
+//      64 parameters `c % nb` of network `c / nb` -- the fold of ppo_reduce_block, same association order, so the step is
+//      bit-identical to the two-launch sequence -- jobs 2 nb .. 2 nb + 2 are the scalar statistics;
+//   3. it publishes its chunk's sum of squares as a {value, sequence} granule, polls the 2 nb granules, derives both clip
+//      coefficients in the fixed order and steps its own 64 parameters.
+// No ticket, no reset: flags and granules are valid iff they carry this launch's sequence number, which the kernel keeps in
+// its workspace (read by every workgroup before it raises its flag, advanced by workgroup 0 after it has seen every granule).
+// A wait that does not complete within ~2 s (the grid was not co-resident: something else held CUs for that long) sets
+// workspace word 0 and info[23] and leaves the parameters untouched.
+// Saves the dependent launch (~6 us of latency floor, measured) of every one of the 40 updates of an iteration.
+struct StepDev {
+  float* grads; double* info; float* ws; unsigned epoch; int device_state;
+  const float* logstd; int n_act, p_pf, p_vf;
+  AdamDev adam;
+};
+#define STEP_FLAGS 256                              /* arrival flags = threads of a workgroup */
+__host__ __device__ inline int step_ws_off(int nb) { return 16 + 4 * nb; }          // behind ppo_reduce_adam_kernel's region
+__host__ __device__ inline int step_ws_words(int nb) { return step_ws_off(nb) + 4 + STEP_FLAGS + 4 * nb; }
+
+// STEP_CLK (tools/ab_step.py): phase stamps of every workgroup behind the workspace.  Transfers that were built and measured
+// on MI355X before this one (profiles/NOTES_r06.md): plain row stores + agent-scope release / acquire fences (every wave's
+// release walks its XCD's L2: +21 us per launch), {value, sequence} granules polled by the fold itself (shortest tail, but
+// twice the bytes through the coherence point: the pass ends 3.7 us later).
+#ifdef STEP_CLK
+#define SCLK(k) { if (tid == 0) clk[k] = wall_clock64(); }
+#else
+#define SCLK(k)
+#endif
+
+// all n_wg arrival flags carry `seq` (block-uniform result; false: timed out).  Wave 0 polls, four flags per lane.
+__device__ __forceinline__ bool step_wait_flags(const unsigned* flags, int n_wg, unsigned seq, int* s_fail) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    unsigned long long t0 = 0;
+    for (unsigned it = 1;; ++it) {
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < STEP_FLAGS / 64; ++q) {
+        const int w = lane + 64 * q;
+        const unsigned f = __hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (w >= n_wg || f == seq);
+      }
+      if (__all(ok)) break;
+      if ((it & 63u) == 0) {
+        const unsigned long long now = wall_clock64();          // 100 MHz
+        if (t0 == 0) t0 = now;
+        else if (now - t0 > 200000000ull) { if (lane == 0) *s_fail = 1; break; }
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  return *s_fail == 0;
+}
+
+__device__ __forceinline__ void ppo_step_tail(const PpoDev& a, const StepDev& t, float* lds, unsigned seq) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, n_wg = a.n_wg;
+  const int nb = (a.p_stride + RED_CHUNK - 1) / RED_CHUNK;
+  unsigned* wsu = reinterpret_cast<unsigned*>(t.ws);
+  unsigned* seqp = wsu + step_ws_off(nb);
+  unsigned* flags = seqp + 4;
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(flags + STEP_FLAGS);   // [2 nets][nb] {ss bits, seq}
+#ifdef STEP_CLK
+  unsigned long long* clk = reinterpret_cast<unsigned long long*>(wsu + step_ws_words(nb)) + (size_t)wg * 8;
+#endif
+  float (*s_acc)[RED_CHUNK] = reinterpret_cast<float (*)[RED_CHUNK]>(lds);
+  float* s_coef = lds + RED_WAVES * RED_CHUNK;                   // [2]
+  float* s_hyper = s_coef + 2;                                   // bc1, bc2_sqrt, lr_pf, lr_vf
+  int* s_fail = reinterpret_cast<int*>(s_hyper + 4);
+  SCLK(1)
+  // ---- header: read before the arrival flag goes up (workgroup 0 advances it after the last rendezvous) ----
+  unsigned epoch = t.epoch;
+  double* bpow = reinterpret_cast<double*>(t.ws + 4);
+  double b1p = 0.0, b2p = 0.0;
+  float lr0 = 0.0f, lr1 = 0.0f;
+  if (t.device_state) {
+    epoch = wsu[1] + 1u;
+    if (tid == WV_THREADS - 1) { b1p = bpow[0]; b2p = bpow[1]; lr0 = t.ws[2]; lr1 = t.ws[3]; }
+  }
+  // log_std as it is BEFORE this step (its statistics are the pre-step ones, ppo.py:82-85): workgroup 0 reads it here --
+  // the load has returned by the barriers below, i.e. before this workgroup publishes the norm granule of its chunk, and
+  // no workgroup steps a parameter before it has seen every granule
+  float ls_raw = 0.0f;
+  if (wg == 0 && wave == WV_WAVES - 1 && t.logstd && lane < t.n_act) ls_raw = t.logstd[lane];
+  // ---- 1. this workgroup's rows are out: arrive ----
+  // the rows went out as device-scope write-through stores: they are at the coherence point once the wave's store counter
+  // has drained -- no agent-scope release fence (an L2 write-back walk per wave)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  if (tid == 0) *s_fail = 0;
+  __syncthreads();                                               // (also: the pass's LDS is dead from here)
+  if (tid == 0) __hip_atomic_store(flags + wg, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  SCLK(2)
+  // ---- 2. every workgroup's rows ----
+  if (!step_wait_flags(flags, n_wg, seq, s_fail)) {
+    if (tid == 0) { __hip_atomic_store(wsu, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); t.info[23] = 1.0; }
+    return;
+  }
+  SCLK(3)
+  SCLK(4)
+  if (t.device_state && tid == WV_THREADS - 1) {
+    b1p *= (double)t.adam.beta1; b2p *= (double)t.adam.beta2;
+    s_hyper[0] = (float)(1.0 - b1p);
+    s_hyper[1] = (float)sqrt(1.0 - b2p);
+    s_hyper[2] = lr0; s_hyper[3] = lr1;
+  }
+  // ---- 3. fold jobs (rows: device-coherent loads, not served from this XCD's L2) ----
+  const int n_jobs = 2 * nb + 2;                                 // the chunks of both networks, then their scalar statistics
+  float gval0 = 0.0f;                                            // wave 0: the folded gradient of this workgroup's FIRST chunk
+  bool has_chunk = false;
+  for (int c = wg; c < n_jobs; c += n_wg) {
+    if (c < 2 * nb) {
+      const int net = c / nb, bx = c - net * nb;
+      const int row0 = net == 0 ? 0 : a.n_pf, nrow = net == 0 ? a.n_pf : n_wg - a.n_pf;
+      const int p = bx * RED_CHUNK + lane, pn = net == 0 ? t.p_pf : t.p_vf;
+      if (has_chunk) __syncthreads();                            // s_acc is read by wave 0 of the previous job
+      float r0, r1;
+      fold_rows_wave_pair<true>(a.partial + (size_t)row0 * a.p_stride + p, nrow, a.p_stride, wave, p < pn, r0, r1);
+      s_acc[wave][lane] = r0; s_acc[wave + 4][lane] = r1;
+      __syncthreads();
+      if (wave == 0) {
+        float gval = 0.0f;
+        if (p < pn) { gval = fold_waves_tree(s_acc, lane); t.grads[(net == 0 ? 0 : t.p_pf) + p] = gval; }
+        if (!has_chunk) gval0 = gval;
+        const float ss = wave_sum(gval * gval);
+        if (lane == 0)
+          __hip_atomic_store(slots + net * nb + bx, ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(ss),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      has_chunk = true;
+    } else if (wave == 1) {                                      // a network's loss / log-prob / value statistics
+      const int j = c - 2 * nb;
+      fold_scalar_stats<true>(a.scal_partial + (size_t)(j == 0 ? 0 : a.n_pf) * 8, j == 0 ? a.n_pf : n_wg - a.n_pf, j, lane, t.info);
+    }
+  }
+  if (wg == 0 && wave == WV_WAVES - 1 && t.logstd) fold_logstd_stats_raw(ls_raw, t.n_act, lane, t.info);
+  SCLK(5)
+  if (!has_chunk) { SCLK(6) SCLK(7) return; }                     // (workgroup 0 always has one)
+  // the optimiser state of the first chunk is requested now and arrives while the norm granules are polled
+  const int net0 = wg / nb, pe0 = (wg - net0 * nb) * RED_CHUNK + lane;
+  const bool own0 = wave == 0 && pe0 < (net0 == 0 ? t.p_pf : t.p_vf);
+  const int ge0 = (net0 == 0 ? 0 : t.p_pf) + pe0;
+  float m_old = 0.0f, v_old = 0.0f, p_old = 0.0f;
+  if (own0) { m_old = t.adam.m[ge0]; v_old = t.adam.v[ge0]; p_old = t.adam.params[ge0]; }
+  // ---- 4. group norms (pf, vf): wave w polls net w's granules, then sums them in fixed order ----
+  if (wave < 2) {
+    float acc = 0.0f;
+    bool fail = false;
+    for (int b = lane; b < nb; b += 64) {
+      unsigned long long v;
+      unsigned it = 0;
+      unsigned long long t0 = 0;
+      while ((unsigned)((v = __hip_atomic_load(slots + wave * nb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++it & 1023u) == 0) {
+          const unsigned long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          if (now - t0 > 200000000ull) { fail = true; break; }
+        }
+      }
+      acc += __uint_as_float((unsigned)v);
+    }
+    if (fail) *s_fail = 1;
+    acc = wave_sum(acc) * t.adam.grad_scale * t.adam.grad_scale;
+    if (lane == 0) {
+      const float norm = sqrtf(acc);
+      s_coef[wave] = (t.adam.max_norm > 0.0f) ? fminf(t.adam.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+      if (t.adam.norms_out && wg == 0) t.adam.norms_out[wave] = norm;
+    }
+  }
+  __syncthreads();
+  SCLK(6)
+  if (*s_fail) {
+    if (tid == 0) { __hip_atomic_store(wsu, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); t.info[23] = 1.0; }
+    return;
+  }
+  float bc1 = t.adam.bc1, bc2_sqrt = t.adam.bc2_sqrt, lr_pf = t.adam.lr[0], lr_vf = t.adam.lr[1];
+  if (t.device_state) { bc1 = s_hyper[0]; bc2_sqrt = s_hyper[1]; lr_pf = s_hyper[2]; lr_vf = s_hyper[3]; }
+  if (wg == 0) {                                                 // every workgroup has read the header by now (see above)
+    if (tid == 0) {
+      __hip_atomic_store(seqp, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t.device_state) __hip_atomic_store(wsu + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t.device_state && tid == WV_THREADS - 1) { bpow[0] = b1p; bpow[1] = b2p; }
+  }
+  // ---- 5. Adam on the own chunks ----
+  if (wave == 0) {
+    bool first = true;
+    for (int c = wg; c < 2 * nb; c += n_wg, first = false) {
+      const int net = c / nb, pe = (c - net * nb) * RED_CHUNK + lane;
+      if (pe >= (net == 0 ? t.p_pf : t.p_vf)) continue;
+      const int ge = (net == 0 ? 0 : t.p_pf) + pe;
+      const float g_ = first ? gval0 : t.grads[ge];                 // (later chunks: this lane's own store of step 3)
+      const float mo = first ? m_old : t.adam.m[ge], vo = first ? v_old : t.adam.v[ge], po = first ? p_old : t.adam.params[ge];
+      const float gr = g_ * t.adam.grad_scale * s_coef[net];
+      const float m = t.adam.beta1 * mo + (1.0f - t.adam.beta1) * gr;
+      const float v = t.adam.beta2 * vo + (1.0f - t.adam.beta2) * gr * gr;
+      t.adam.m[ge] = m; t.adam.v[ge] = v;
+      const float denom = sqrtf(v) / bc2_sqrt + t.adam.eps;
+      t.adam.params[ge] = po - ((net == 0 ? lr_pf : lr_vf) / bc1) * (m / denom);
+    }
+  }
+  SCLK(7)
+}
+
+template <int D, int H, int A, int ACT, bool CONTIG, bool RT, bool STEP>
+__global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a, StepDev t) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // this launch's sequence number (the step's workspace): read by every workgroup before anything of it is published
+  unsigned seq = 0u;
+  if constexpr (STEP)
+    seq = __hip_atomic_load(reinterpret_cast<unsigned*>(t.ws) + step_ws_off((a.p_stride + RED_CHUNK - 1) / RED_CHUNK),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+#ifdef STEP_CLK
+  if (STEP && threadIdx.x == 0)
+    (reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(t.ws) + step_ws_words((a.p_stride + RED_CHUNK - 1) / RED_CHUNK)) + (size_t)blockIdx.x * 8)[0] = wall_clock64();
+#endif
+  if ((int)blockIdx.x < a.n_pf) ppo_wave_pass<D, H, A, ACT, true, CONTIG, RT, STEP>(a, lds, blockIdx.x, a.n_pf);
+  else                          ppo_wave_pass<D, H, A, ACT, false, CONTIG, RT, STEP>(a, lds, blockIdx.x - a.n_pf, a.n_wg - a.n_pf);
+  if constexpr (STEP) ppo_step_tail(a, t, lds, seq);
+}
+
 // ---------------------------------------------------------------- MLP inference
 template <int D, int H, int O, int ACT>
 __global__ __launch_bounds__(256) void mlp2_forward_kernel(const float* __restrict__ params,
@@ -1091,25 +1382,28 @@ extern "C" int trl_ppo_partial_stride(int D, int H, int A) {
 // and a PAIR of waves per tile with two waves per SIMD (75 us) -- on gfx950 the fp32 MFMA and the VALU do not
 // overlap across the two waves of a SIMD (tools/ubench/mfma_valu.hip: an MFMA-only wave and a VALU-only wave
 // on one SIMD take the SUM of their times), so a second wave only adds its duplicated loss / fetch work.
-template <int D, int H, int A, int ACT, bool CONTIG, bool RT>
-static int launch_ppo_v(const PpoDev& d, hipStream_t s) {
+template <int D, int H, int A, int ACT, bool CONTIG, bool RT, bool STEP>
+static int launch_ppo_v(const PpoDev& d, const StepDev& t, hipStream_t s) {
   using S = WvShape<D, H, A>;
   const size_t lds = S::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wave_kernel<D, H, A, ACT, CONTIG, RT>,
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wave_kernel<D, H, A, ACT, CONTIG, RT, STEP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { trl_set_error("ppo_grad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_grad_wave_kernel<D, H, A, ACT, CONTIG, RT>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d);
+  hipLaunchKernelGGL((ppo_grad_wave_kernel<D, H, A, ACT, CONTIG, RT, STEP>), dim3(d.n_wg), dim3(WV_THREADS), lds, s, d, t);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
-// N % 16 == 0 (every tile = 16 consecutive envs of one time row): scalar tile addressing; any other N: per-lane cells
+// N % 16 == 0 (every tile = 16 consecutive envs of one time row): scalar tile addressing; any other N: per-lane cells.
+// `t` non-null: the whole step (fold, clip, Adam) in the same launch.
 template <int D, int H, int A, int ACT, bool RT>
-static int launch_ppo(const PpoDev& d, hipStream_t s) {
-  return (d.N % 16 == 0) ? launch_ppo_v<D, H, A, ACT, true, RT>(d, s) : launch_ppo_v<D, H, A, ACT, false, RT>(d, s);
+static int launch_ppo(const PpoDev& d, const StepDev* t, hipStream_t s) {
+  static const StepDev none{};
+  if (t) return (d.N % 16 == 0) ? launch_ppo_v<D, H, A, ACT, true, RT, true>(d, *t, s) : launch_ppo_v<D, H, A, ACT, false, RT, true>(d, *t, s);
+  return (d.N % 16 == 0) ? launch_ppo_v<D, H, A, ACT, true, RT, false>(d, none, s) : launch_ppo_v<D, H, A, ACT, false, RT, false>(d, none, s);
 }
 
 // Policy / value split of the grid.  A policy tile costs more than a value tile (head, log-prob loss,
@@ -1131,7 +1425,7 @@ extern "C" int trl_ppo_wg_split(int D, int H, int A, int n_tiles, int n_wg) {
 }
 static int resolve_pf_wgs(int n_wg, int n_wg_pf) { return n_wg_pf > 0 ? n_wg_pf : n_wg / 2; }
 
-extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream) {
+static int ppo_grad_launch(const trl_ppo_batch_t* p, const StepDev* step, void* stream) {
   if (!p) { trl_set_error("ppo_grad: null descriptor"); return TRL_EINVAL; }
   TRL_REQUIRE(p->obs && p->acts && p->advs && p->rets, "null rollout tensor");
   TRL_REQUIRE(p->loss_mode == TRL_LOSS_PPO_CLIP || p->loss_mode == TRL_LOSS_A2C, "unknown loss_mode");
@@ -1159,20 +1453,22 @@ extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream
   hipStream_t s = (hipStream_t)stream;
   if (SHAPE_IS(17, 64, 6)) {
     d.p_stride = PpoShape<17, 64, 6>::P_STRIDE;
-    if (p->act == TRL_ACT_TANH) return launch_ppo<17, 64, 6, TRL_ACT_TANH, false>(d, s);
-    if (p->act == TRL_ACT_RELU) return launch_ppo<17, 64, 6, TRL_ACT_RELU, false>(d, s);
+    if (p->act == TRL_ACT_TANH) return launch_ppo<17, 64, 6, TRL_ACT_TANH, false>(d, step, s);
+    if (p->act == TRL_ACT_RELU) return launch_ppo<17, 64, 6, TRL_ACT_RELU, false>(d, step, s);
   } else if (ppo_shape_rt(D, H, A) && D <= 17) {      // actual dims at run time inside the (17, 64, 8) tile
     d.p_stride = trl_ppo_partial_stride(D, H, A);
-    if (p->act == TRL_ACT_TANH) return launch_ppo<17, 64, 8, TRL_ACT_TANH, true>(d, s);
-    if (p->act == TRL_ACT_RELU) return launch_ppo<17, 64, 8, TRL_ACT_RELU, true>(d, s);
+    if (p->act == TRL_ACT_TANH) return launch_ppo<17, 64, 8, TRL_ACT_TANH, true>(d, step, s);
+    if (p->act == TRL_ACT_RELU) return launch_ppo<17, 64, 8, TRL_ACT_RELU, true>(d, step, s);
   } else if (ppo_shape_rt(D, H, A)) {                 // 18 .. 32 input features: the (32, 64, 8) tile
     d.p_stride = trl_ppo_partial_stride(D, H, A);
-    if (p->act == TRL_ACT_TANH) return launch_ppo<32, 64, 8, TRL_ACT_TANH, true>(d, s);
-    if (p->act == TRL_ACT_RELU) return launch_ppo<32, 64, 8, TRL_ACT_RELU, true>(d, s);
+    if (p->act == TRL_ACT_TANH) return launch_ppo<32, 64, 8, TRL_ACT_TANH, true>(d, step, s);
+    if (p->act == TRL_ACT_RELU) return launch_ppo<32, 64, 8, TRL_ACT_RELU, true>(d, step, s);
   }
   trl_set_error("ppo_grad: shape D=%d H=%d A=%d act=%d not instantiated", D, H, A, p->act);
   return TRL_EUNSUPPORTED;
 }
+
+extern "C" int trl_ppo_minibatch_grad_f32(const trl_ppo_batch_t* p, void* stream) { return ppo_grad_launch(p, nullptr, stream); }
 
 extern "C" int trl_ppo_reduce_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf, int D,
                                   int H, int A, const float* pf_params, float* grads, double* info, void* stream) {
@@ -1259,6 +1555,47 @@ extern "C" int trl_ppo_reduce_adam_xrank_f32(const float* partial, const double*
   const XrArgs* xr = trl_comm_xr(comm);
   if (!xr) { trl_set_error("trl_ppo_reduce_adam_xrank_f32: communicator without mapped peers"); return TRL_EINVAL; }
   return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, xr, stream);
+}
+
+// The whole minibatch step as ONE launch (single process): trl_ppo_minibatch_grad_f32 + trl_ppo_reduce_adam_f32, bit for bit.
+// The grid must be co-resident (n_wg <= CUs of the device, <= 256): its workgroups wait for each other inside the launch.
+extern "C" int trl_ppo_step_workspace(int D, int H, int A) {
+  const int ps = trl_ppo_partial_stride(D, H, A);
+  if (ps < 0) return ps;
+#ifdef STEP_CLK
+  return step_ws_words(trl_ceil_div(ps, RED_CHUNK)) + 2 * 8 * STEP_FLAGS;      // + 8 phase stamps per workgroup
+#endif
+  return step_ws_words(trl_ceil_div(ps, RED_CHUNK));   // trl_ppo_reduce_adam_workspace's region first: the two routes share the Adam header
+}
+extern "C" int trl_ppo_step_max_workgroups(void) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return cus < STEP_FLAGS ? cus : STEP_FLAGS;
+}
+extern "C" int trl_ppo_minibatch_step_f32(const trl_ppo_batch_t* p, float* grads, double* info, const trl_adam_t* adam,
+                                          float* workspace, void* stream) {
+  if (!p) { trl_set_error("ppo_step: null descriptor"); return TRL_EINVAL; }
+  TRL_REQUIRE(grads && info && workspace, "null pointer");
+  const int D = p->D, H = p->H, A = p->A;
+  const int ps = trl_ppo_partial_stride(D, H, A);
+  if (ps < 0) return ps;
+  StepDev t{};
+  int rc = fill_adam(adam, t.adam);
+  if (rc) return rc;
+  const int p_pf = H * D + H + H * H + H + A * H + A + A, p_vf = H * D + H + H * H + H + H + 1;
+  TRL_REQUIRE(adam->n_groups == 2 && adam->group_sizes[0] == p_pf && adam->group_sizes[1] == p_vf,
+              "optimiser groups must be [policy | value] of this shape");
+  TRL_REQUIRE(adam->grads == grads, "adam->grads must be the fold output");
+  TRL_REQUIRE(adam->params == p->pf_params && adam->params + p_pf == p->vf_params,
+              "the networks' parameter blocks must be the optimiser's [policy | value] block");
+  const int max_wg = trl_ppo_step_max_workgroups();
+  if (p->n_wg > max_wg) {
+    trl_set_error("ppo_step: %d workgroups cannot be co-resident on this device (%d): use the two-launch sequence", p->n_wg, max_wg);
+    return TRL_EUNSUPPORTED;
+  }
+  t.grads = grads; t.info = info; t.ws = workspace; t.epoch = (unsigned)adam->step_count; t.device_state = adam->device_state;
+  t.logstd = adam->params + (p_pf - A); t.n_act = A; t.p_pf = p_pf; t.p_vf = p_vf;
+  return ppo_grad_launch(p, &t, stream);
 }
 
 #define TICK_PENDING 0x70000001                    /* clip_adam_launch: the step state still has to be advanced */
