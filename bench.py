@@ -675,6 +675,9 @@ def main():
         if report.get("not_used"):
             comm_info["peer_transport_not_used"] = report["not_used"]
         comm_info["ranks_per_device"] = report.get("ranks_per_device", 1 if not shared else None)
+        for key in ("peer_buffer", "wait_footprint"):                      # which allocation the peer buffer got; resident
+            if report.get(key):                                            # footprint of a fold launch that waits for other ranks
+                comm_info[key] = report[key]
         comm_info["transport_vote"] = "peer" if peers else ("all-reduce calls" + (" (peer self-check %s)" % report["self_check"]
                                                                                    if report.get("self_check") else ""))
         if args.transport == "peer" and not peers:

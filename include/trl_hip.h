@@ -419,6 +419,14 @@ int trl_comm_init(trl_comm_t** comm, int rank, int world, const void* unique_id)
 int trl_comm_peer_export(trl_comm_t* comm, void* handle_out);
 int trl_comm_peer_open(trl_comm_t* comm, const void* handles);
 int trl_comm_peer_ready(const trl_comm_t* comm);
+/* Resident footprint of the launches that wait inside a kernel for other ranks' data (trl_ppo_reduce_adam_xrank_f32):
+ * at most `blocks` blocks of 8 waves stay on the device while a rank's gradient is outstanding; 0 (default) = the kernel's
+ * own grid (one block per 64 parameters).  Only ranks SHARING a device need it: the waiting launches of all of them must
+ * leave CUs for the gradient kernels they are waiting for (blocks <= CUs / (2 x ranks per device)); results do not depend
+ * on it.  trl_comm_peer_buffer_kind: 1 = the peer buffer is uncached device memory (hipDeviceMallocUncached), 0 = that
+ * allocation failed and plain hipMalloc memory is used (reported on stderr too), -1 = no peer buffer yet. */
+int trl_comm_set_wait_footprint(trl_comm_t* comm, int blocks);
+int trl_comm_peer_buffer_kind(const trl_comm_t* comm);
 int trl_comm_peer_enable(trl_comm_t* comm, int on);   /* 0 after a failed self-check: everything takes the RCCL route */
 int trl_comm_has_rccl(const trl_comm_t* comm);
 int trl_comm_error(trl_comm_t* comm);

@@ -62,6 +62,8 @@ def main():
         if mode != "nccl_graph":
             peer = trl_dist.init_comm(torch.device("cuda:0"), use_rccl=(mode == "nccl_peer"))
             assert peer, "peer transport did not come up"
+            if os.environ.get("TRL_TEST_WAIT_BLOCKS"):               # the fold launch's resident footprint, overridden
+                assert _lib().trl_comm_set_wait_footprint(trl_dist.comm_handle(), int(os.environ["TRL_TEST_WAIT_BLOCKS"])) == 0
             assert bool(_lib().trl_comm_has_rccl(trl_dist.comm_handle())) == (mode == "nccl_peer")
     import torchrl.networks as networks
     import torchrl.policies as policies

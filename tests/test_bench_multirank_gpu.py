@@ -54,17 +54,23 @@ def test_plain_python_two_ranks_on_the_all_reduce_fallback():
 
 
 def test_cfg4_layout_eight_ranks_on_one_gpu():
-    """BASELINE cfg 4 in its own shape as far as one GPU allows: `python bench.py --gpus 8`, 8 self-
-    spawned ranks x 2048 envs = 16 384 envs, every rank drawing its rows of the reference's (16384, 6) noise tensors.  All
-    eight hipIpc buffers are mapped and self-checked (8 slots each); the iterations then run on the all-reduce route,
-    because eight ranks sharing ONE device cannot wait for each other inside kernels (dist.MAX_PEER_RANKS_PER_DEVICE)."""
+    """BASELINE cfg 4 in its own shape as far as one GPU allows: `python bench.py --gpus 8`,
+    8 self-spawned ranks x 2048 envs = 16 384 envs, every rank drawing its rows of the reference's (16384, 6) noise tensors,
+    all eight hipIpc buffers mapped and self-checked (8 slots each) -- and since round 6 the iterations themselves on the
+    PEER transport: the gradient SUM over eight slots inside every rank's fold / clip / Adam launch, graph-replayed, at
+    cfg 4's real sizes.  Eight ranks share the device, so each waiting fold launch is bounded to 16 blocks
+    (`config.wait_footprint`; eight GPUs run the same kernel with one block per 64 parameters).  The figure itself is a
+    correctness artefact: eight processes time-slice one GPU."""
     out, err = _bench({}, gpus=8)
     cfg = out["config"]
     assert out["n_gpus"] == 8 and out["steps"] == 3 and out["scaling"] == "weak"
     assert abs(out["value"] - 8 * 2048 * 128 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
-    assert cfg["peer_self_check"].startswith("passed on every rank (8 slots"), (cfg, err[-2000:])
-    assert cfg["ranks_per_device"] == 8 and "8 ranks share one device" in cfg["peer_transport_not_used"]
-    assert cfg["transport"] == "torch.distributed:gloo" and cfg["launcher"].startswith("bench.py spawned")
+    assert cfg["peer_self_check"].startswith("passed on every rank"), (cfg, err[-2000:])
+    assert cfg["ranks_per_device"] == 8 and "peer_transport_not_used" not in cfg
+    assert cfg["transport"] == "peer" and cfg["transport_vote"] == "peer", (cfg, err[-2000:])
+    assert cfg["guarded_iterations"].startswith("3 completed") and cfg["wait_footprint"].startswith("16 blocks")
+    assert cfg["peer_buffer"].startswith("uncached") or cfg["peer_buffer"].startswith("plain")
+    assert cfg["launcher"].startswith("bench.py spawned")
     assert all(v > 0 for v in cfg["collective_us"].values())
     assert out["parity_mode_ms_per_step"] > 0 and out["device_noise_ms_per_step"] > 0      # world-8 reference noise was timed
     assert "CPUs per rank" in cfg["cpu_affinity"]

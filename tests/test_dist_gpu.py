@@ -177,6 +177,37 @@ def test_two_ranks_over_the_peer_transport_replay_a_graph(tmp_path):
     np.testing.assert_allclose(r0["infos"], single["infos"], rtol=2e-4, atol=2e-5)
 
 
+def test_eight_ranks_over_the_peer_transport_replay_a_graph(tmp_path):
+    """BASELINE cfg 4's exchange at test size, for real: 8 processes x 8 envs sharing cuda:0, eight
+    hipIpc-mapped buffers of 8 slots x 2 halves, the gradient SUM over the eight slots INSIDE the fold / clip / Adam launch
+    (trl_ppo_reduce_adam_xrank_f32: push granules to seven peers, poll eight slots, norm rendezvous, Adam), the statistics
+    through the one-kernel all-reduce, the sequence graph-replayed from the third epoch on (both epoch-parity halves of the
+    buffers are used).  The ranks share one device, so every rank's waiting fold launch is bounded to CUs / 16 blocks
+    (trl_comm_set_wait_footprint: a block then folds several 64-parameter jobs in turn) -- the same kernel that runs with
+    one block per job on eight GPUs.  Same bar as two ranks: parameters bit-identical across the eight ranks, the
+    single-process run up to the order of the gradient sum."""
+    (single,) = _run(1, tmp_path)
+    ranks = _run(8, tmp_path, extra=("peer",))
+    for r in ranks:
+        assert int(r["peer"]) == 1 and int(r["graph"]) == 1
+    np.testing.assert_allclose(np.concatenate([r["obs"] for r in ranks], axis=1), single["obs"], atol=1e-6)
+    for r in ranks[1:]:
+        assert np.array_equal(r["pf"], ranks[0]["pf"]) and np.array_equal(r["vf"], ranks[0]["vf"])
+        np.testing.assert_allclose(r["infos"], ranks[0]["infos"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(ranks[0]["pf"], single["pf"], atol=2e-6)
+    np.testing.assert_allclose(ranks[0]["vf"], single["vf"], atol=2e-6)
+    np.testing.assert_allclose(ranks[0]["infos"], single["infos"], rtol=2e-4, atol=2e-5)
+
+
+def test_fold_clip_adam_launch_does_not_depend_on_its_grid(tmp_path):
+    """trl_comm_set_wait_footprint only changes how the 2 x 90 fold jobs are dealt to blocks: two ranks over the peer
+    transport with the fold launch bounded to 3 blocks reproduce the run at the default footprint bit for bit."""
+    a0, a1 = _run(2, tmp_path, extra=("peer",))
+    b0, b1 = _run(2, tmp_path, extra=("peer",), env={"TRL_TEST_WAIT_BLOCKS": "3"})
+    for k in ("pf", "vf", "infos", "obs"):
+        assert np.array_equal(a0[k], b0[k]) and np.array_equal(a1[k], b1[k]), k
+
+
 def test_one_rank_rccl_communicator_with_peer_transport(tmp_path):
     """World size 1 on the nccl backend with the collectives forced on: ncclCommInitRank through the C ABI, the peer
     buffer mapped onto itself, the cross-rank launch sequence graph-replayed; it must reproduce the plain run."""

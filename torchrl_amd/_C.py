@@ -157,6 +157,8 @@ SIGNATURES = {
     "trl_comm_error": (C.c_int, [C.c_void_p]),
     "trl_comm_error_detail": (C.c_int, [C.c_void_p, C.c_void_p]),
     "trl_comm_link_info": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "trl_comm_set_wait_footprint": (C.c_int, [C.c_void_p, C.c_int]),
+    "trl_comm_peer_buffer_kind": (C.c_int, [C.c_void_p]),
     "trl_comm_destroy": (C.c_int, [C.c_void_p]),
     "trl_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "trl_allreduce_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),

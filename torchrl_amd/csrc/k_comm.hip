@@ -53,6 +53,8 @@ struct trl_comm {
   void* opened[TRL_MAX_RANKS];                     // hipIpcOpenMemHandle results (null for self / not opened)
   XrArgs xr;                                       // device-side view; xr.peer[] valid once peers are open
   int peers_ready;
+  int wait_blocks;                                 // resident footprint of a launch that waits for other ranks (0: the kernel's own grid)
+  int uncached;                                    // the peer buffer is hipDeviceMallocUncached memory (0: plain hipMalloc fallback)
 };
 
 #define HIP_TRY(expr)                                                                         \
@@ -111,7 +113,15 @@ extern "C" int trl_comm_peer_export(trl_comm_t* c, void* handle_out) {
     const size_t bytes = xr_buffer_granules(c->world) * sizeof(unsigned long long);
     void* p = nullptr;
     hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipMalloc(&p, bytes)); }
+    c->uncached = e == hipSuccess ? 1 : 0;
+    if (e != hipSuccess) {
+      // Said out loud: a CACHED buffer polled across physical devices is what the self-check exists to
+      // catch -- the operator learns which allocation this communicator got (trl_comm_peer_buffer_kind, bench.py config).
+      fprintf(stderr, "[trl_comm] rank %d: hipExtMallocWithFlags(hipDeviceMallocUncached) failed (%s): the peer buffer is plain "
+                      "hipMalloc memory; the self-check decides whether the peer transport is used\n", c->rank, hipGetErrorString(e));
+      (void)hipGetLastError();
+      HIP_TRY(hipMalloc(&p, bytes));
+    }
     HIP_TRY(hipMemset(p, 0, bytes));
     void* ctl = nullptr;
     HIP_TRY(hipMalloc(&ctl, 64));
@@ -209,6 +219,19 @@ extern "C" int trl_comm_destroy(trl_comm_t* c) {
 
 // the device-side view, for the fused kernels in other translation units (k_ppo.hip)
 const XrArgs* trl_comm_xr(const trl_comm_t* c) { return (c && c->peers_ready) ? &c->xr : nullptr; }
+int trl_comm_wait_blocks(const trl_comm_t* c) { return c ? c->wait_blocks : 0; }
+
+// Resident footprint of launches that wait INSIDE a kernel for other ranks (trl_ppo_reduce_adam_xrank_f32: blocks of 8
+// waves that stay on the device until every rank has delivered its gradient).  0 = the kernel's own grid (one block per 64
+// parameters: 180 for the benchmark shape) -- right for one rank per GPU.  Ranks SHARING a device must leave CUs for each
+// other's gradient kernels: the host sets blocks <= CUs / (2 x ranks per device).
+extern "C" int trl_comm_set_wait_footprint(trl_comm_t* c, int blocks) {
+  TRL_REQUIRE(c && blocks >= 0, "null communicator / negative block count");
+  c->wait_blocks = blocks;
+  return TRL_OK;
+}
+// 1: uncached device memory (hipDeviceMallocUncached), 0: plain hipMalloc (fallback), -1: no peer buffer yet
+extern "C" int trl_comm_peer_buffer_kind(const trl_comm_t* c) { return (c && c->local) ? c->uncached : -1; }
 
 // ---------------------------------------------------------------- small one-shot all-reduce
 // buf[i] <- reduce over ranks of buf[i]; element i is SUMmed, or MAXed when bit (i % period) of max_mask is set.

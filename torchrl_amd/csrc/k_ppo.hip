@@ -854,19 +854,20 @@ __device__ __forceinline__ void fold_logstd_stats(const float* __restrict__ logs
   fold_logstd_stats_raw(logstd[lane < n_act ? lane : 0], n_act, lane, info);
 }
 
-// returns (wave 0 lanes) this block's reduced gradient value, 0 outside the parameter range
+// returns (wave 0 lanes) the reduced gradient value of chunk `bx` (64 parameters) of network `net`, 0 outside the parameter
+// range; `stats`: this call also takes the network's scalar statistics (waves 2 / 3)
 __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ partial,
                                                   const double* __restrict__ scal, int n_wg, int n_pf,
                                                   int p_stride, int p_pf, int p_vf,
                                                   const float* __restrict__ logstd, int n_act,
-                                                  float* __restrict__ grads, double* __restrict__ info) {
+                                                  float* __restrict__ grads, double* __restrict__ info,
+                                                  int net, int bx, bool stats) {
   // block = 64 consecutive parameters x RED_WAVES waves; wave w folds partials w, w + RED_WAVES, ... with RED_DEPTH
   // independent accumulators (fixed order => deterministic), then the waves fold through LDS.
   __shared__ float s_acc[RED_WAVES][RED_CHUNK];
-  const int net = blockIdx.y;
   const int row0 = net == 0 ? 0 : n_pf, nrow = net == 0 ? n_pf : n_wg - n_pf;   // this network's partial rows
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int p = blockIdx.x * RED_CHUNK + lane;
+  const int p = bx * RED_CHUNK + lane;
   const int pn = net == 0 ? p_pf : p_vf;
   s_acc[wave][lane] = fold_rows_wave(partial + (size_t)row0 * p_stride + p, nrow, p_stride, wave, p < pn);
   __syncthreads();
@@ -877,12 +878,11 @@ __device__ __forceinline__ float ppo_reduce_block(const float* __restrict__ part
   }
   // Scalar statistics.  They used to sit in block (0, 0) -- three dependent rounds of loads over the workgroup partials and
   // then the log_std / std statistics as a serial double-precision loop (six exp() in ONE lane): ~5 us that the whole
-  // launch waited for, twice the time of the fold itself.  Now the LAST block of each network's row takes them, off the
+  // launch waited for, twice the time of the fold itself.  Now the LAST chunk of each network's row takes them, off the
   // path of the blocks whose 64 parameters matter: wave 2 its network's statistics, wave 3 of the policy's block log_std
   // and std.
-  const bool stat_block = blockIdx.x == gridDim.x - 1;
-  if (stat_block && wave == 2) fold_scalar_stats(scal + (size_t)row0 * 8, nrow, net, lane, info);
-  if (stat_block && net == 0 && wave == 3 && logstd) fold_logstd_stats(logstd, n_act, lane, info);
+  if (stats && wave == 2) fold_scalar_stats(scal + (size_t)row0 * 8, nrow, net, lane, info);
+  if (stats && net == 0 && wave == 3 && logstd) fold_logstd_stats(logstd, n_act, lane, info);
   return gval;
 }
 
@@ -891,7 +891,8 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_kernel(const float*
                                                          int p_stride, int p_pf, int p_vf,
                                                          const float* __restrict__ logstd, int n_act,
                                                          float* __restrict__ grads, double* __restrict__ info) {
-  ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
+  ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info, blockIdx.y, blockIdx.x,
+                   blockIdx.x == gridDim.x - 1);
 }
 
 // ---------------------------------------------------------------- K11 clip + Adam
@@ -980,13 +981,17 @@ __device__ __forceinline__ void adam_element(const AdamDev& a, int e, float gr) 
   a.params[e] -= (a.lr[g] / a.bc1) * (m / denom);
 }
 
-// Single-GPU path: partial reduce + clip_grad_norm_ + Adam in ONE launch.  Every block folds its 64
-// parameters and publishes their sum of squares as ONE 64-bit agent-scope store {ss, epoch}; every block
-// then polls the 2 x 90 slots until all carry the epoch of this launch (the blocks are always
-// co-resident: 180 small blocks on 256 CUs), derives the two group norms from them in the same fixed
-// order (deterministic, identical in all blocks) and takes the Adam step for its own 64 parameters straight
-// from registers.  No ticket, no reset: a slot is valid iff its epoch matches (epoch = Adam step count > 0;
+// Single-GPU path: partial reduce + clip_grad_norm_ + Adam in ONE launch.  The 2 x nb jobs (job j = the 64 parameters
+// `j % nb` of network `j / nb`) are dealt to the blocks of a 1-D grid (block b: jobs b, b + grid, ...; the default grid is
+// one block per job).  A block folds its jobs' parameters and publishes each one's sum of squares as ONE 64-bit
+// agent-scope store {ss, epoch}; every block then polls the 2 x nb slots until all carry the epoch of this launch (the
+// blocks are always co-resident: at most 180 small blocks on 256 CUs), derives the two group norms from them in the same
+// fixed order (deterministic, identical in all blocks) and takes the Adam step for its own parameters -- straight from
+// registers when it has one job.  No ticket, no reset: a slot is valid iff its epoch matches (epoch = Adam step count > 0;
 // the workspace starts zeroed).  The poll is capped: a scheduling accident trips ws[0] instead of hanging.
+// The GRID is the launch's resident footprint while it waits (for other ranks' gradients, with env shards on several
+// ranks): blocks x 8 waves that stay on the device until every rank has delivered.  One rank per GPU: irrelevant.  Ranks
+// sharing a device (tests): it must leave room for the other ranks' gradient kernels (trl_comm_set_wait_footprint).
 __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const float* __restrict__ partial,
                                                               const double* __restrict__ scal, int n_wg, int n_pf,
                                                               int p_stride, int p_pf, int p_vf,
@@ -997,9 +1002,10 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   __shared__ float s_coef[2];
   __shared__ float s_hyper[4];                                    // bc1, bc2_sqrt, lr_pf, lr_vf
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = (p_stride + RED_CHUNK - 1) / RED_CHUNK, n_jobs = 2 * nb, grid = gridDim.x, blk = blockIdx.x;
   // Graph-replayable form: the Adam step count and the learning rates live in the workspace header
   // (ws[1] = steps taken so far as uint32, ws[2..3] = lr), so no launch argument changes between replays.
-  // Every block reads the count BEFORE it publishes its slot; block (0, 0) bumps it only after it has seen
+  // Every block reads the count BEFORE it publishes its slots; block 0 bumps it only after it has seen
   // all slots, i.e. after every block has read it.
   // (the count was written by the previous launch, so a plain uniform load -- a scalar load that flies under the
   // reduction's vector loads -- is enough; the bias corrections are computed by an otherwise idle wave)
@@ -1011,19 +1017,30 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
     if (tid == 64 * (RED_WAVES - 1)) { b1p = bpow[0]; b2p = bpow[1]; lr0 = ws[2]; lr1 = ws[3]; }   // issued now, used after the fold
   }
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(ws + 16);    // [2 nets][nb] {ss bits, epoch}
-  const int nb = gridDim.x;
   // env shards on several ranks: the epoch of the cross-rank exchange is the communicator's own count of completed
-  // gradient exchanges (read by every block before it publishes anything, advanced by block (0, 0) at the end)
+  // gradient exchanges (read by every block before it publishes anything, advanced by block 0 at the end)
   const unsigned xepoch = xrank ? __hip_atomic_load(xr.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
-  float gval = ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info);
-  if (xrank && wave == 0) {
-    // C1 of SURVEY.md 8(e) inside the launch: every rank pushes its 64 folded values into its slot on all ranks and
-    // sums the slots in rank order (trl_comm.h) -- the gradient every rank clips and steps with is the same, bit for bit
-    const int pe = blockIdx.x * RED_CHUNK + lane;
-    const bool act = pe < (blockIdx.y == 0 ? p_pf : p_vf);
-    const int ge = (blockIdx.y == 0 ? 0 : p_pf) + pe;
-    gval = xr_allsum_f32(xr, xepoch, act ? ge : 0, gval, act);
-    if (act) grads[ge] = gval;
+  float gval0 = 0.0f;                                             // wave 0: the (summed) gradient of this block's FIRST job
+  for (int j = blk; j < n_jobs; j += grid) {
+    const int net = j / nb, bx = j - net * nb;
+    if (j != blk) __syncthreads();                                // the fold's LDS image is read by wave 0 of the previous job
+    float gval = ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info, net, bx, bx == nb - 1);
+    if (wave == 0) {
+      if (xrank) {
+        // C1 of SURVEY.md 8(e) inside the launch: every rank pushes its 64 folded values into its slot on all ranks and
+        // sums the slots in rank order (trl_comm.h) -- the gradient every rank clips and steps with is the same, bit for bit
+        const int pe = bx * RED_CHUNK + lane;
+        const bool act = pe < (net == 0 ? p_pf : p_vf);
+        const int ge = (net == 0 ? 0 : p_pf) + pe;
+        gval = xr_allsum_f32(xr, xepoch, act ? ge : 0, gval, act);
+        if (act) grads[ge] = gval;
+      }
+      if (j == blk) gval0 = gval;
+      const float ss = wave_sum(gval * gval);
+      if (lane == 0)
+        __hip_atomic_store(slots + net * nb + bx, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(ss),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (device_state && tid == 64 * (RED_WAVES - 1)) {
     b1p *= (double)a.beta1; b2p *= (double)a.beta2;
@@ -1031,17 +1048,11 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
     s_hyper[1] = (float)sqrt(1.0 - b2p);
     s_hyper[2] = lr0; s_hyper[3] = lr1;
   }
-  if (wave == 0) {
-    const float ss = wave_sum(gval * gval);
-    if (lane == 0)
-      __hip_atomic_store(slots + blockIdx.y * nb + blockIdx.x,
-                         ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(ss),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // the optimiser state of this block's parameters is requested now and arrives while the norm slots are polled
-  const int pe_ = blockIdx.x * RED_CHUNK + lane;
-  const bool own_ = wave == 0 && pe_ < (blockIdx.y == 0 ? p_pf : p_vf);
-  const int ge_ = (blockIdx.y == 0 ? 0 : p_pf) + pe_;
+  if (blk >= n_jobs) return;                                      // (a grid larger than the job list)
+  // the optimiser state of this block's first job is requested now and arrives while the norm slots are polled
+  const int net_ = blk / nb, pe_ = (blk - net_ * nb) * RED_CHUNK + lane;
+  const bool own_ = wave == 0 && pe_ < (net_ == 0 ? p_pf : p_vf);
+  const int ge_ = (net_ == 0 ? 0 : p_pf) + pe_;
   float m_old = 0.0f, v_old = 0.0f, p_old = 0.0f;
   if (own_) { m_old = a.m[ge_]; v_old = a.v[ge_]; p_old = a.params[ge_]; }
   // ---- group norms (pf, vf): wave w polls net w's slots, then sums them in fixed order ----
@@ -1068,7 +1079,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
     if (lane == 0) {
       const float norm = sqrtf(acc);
       s_coef[wave] = (a.max_norm > 0.0f) ? fminf(a.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
-      if (a.norms_out && blockIdx.x == 0 && blockIdx.y == 0) a.norms_out[wave] = norm;
+      if (a.norms_out && blk == 0) a.norms_out[wave] = norm;
     }
   }
   __syncthreads();
@@ -1077,26 +1088,33 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   float bc1 = a.bc1, bc2_sqrt = a.bc2_sqrt, lr_pf = a.lr[0], lr_vf = a.lr[1];
   if (device_state) {
     bc1 = s_hyper[0]; bc2_sqrt = s_hyper[1]; lr_pf = s_hyper[2]; lr_vf = s_hyper[3];
-    if (blockIdx.x == 0 && blockIdx.y == 0) {                    // every block has read the header by now (see above)
+    if (blk == 0) {                                              // every block has read the header by now (see above)
       if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tid == 64 * (RED_WAVES - 1)) { bpow[0] = b1p; bpow[1] = b2p; }
     }
   }
-  // (every block has passed its exchange by the time block (0, 0) has seen all norm slots)
-  if (xrank && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+  // (every block has passed its exchanges by the time block 0 has seen all norm slots)
+  if (xrank && blk == 0 && tid == 0)
     __hip_atomic_store(xr.ctl + 4, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // A cross-rank wait that timed out left a PARTIAL gradient sum: no parameter is written then (every block has finished
-  // its exchange before any block sees all norm slots, so the flag is final here and all blocks decide alike); the host
+  // its exchanges before any block sees all norm slots, so the flag is final here and all blocks decide alike); the host
   // raises through trl_comm_error at its next check.
   const bool xfail = xrank && __hip_atomic_load(xr.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-  if (own_ && !xfail) {                                            // adam_element on the prefetched state
-    const int net = blockIdx.y;
-    const float gr = gval * a.grad_scale * s_coef[net];
-    const float m = a.beta1 * m_old + (1.0f - a.beta1) * gr;
-    const float v = a.beta2 * v_old + (1.0f - a.beta2) * gr * gr;
-    a.m[ge_] = m; a.v[ge_] = v;
-    const float denom = sqrtf(v) / bc2_sqrt + a.eps;
-    a.params[ge_] = p_old - ((net == 0 ? lr_pf : lr_vf) / bc1) * (m / denom);
+  if (wave == 0 && !xfail) {                                       // adam_element, the first job on the prefetched state
+    for (int j = blk; j < n_jobs; j += grid) {
+      const int net = j / nb, pe = (j - net * nb) * RED_CHUNK + lane;
+      if (pe >= (net == 0 ? p_pf : p_vf)) continue;
+      const int ge = (net == 0 ? 0 : p_pf) + pe;
+      const bool first = j == blk;
+      const float g_ = first ? gval0 : grads[ge];                  // (later jobs: this lane's own store of the fold above)
+      const float mo = first ? m_old : a.m[ge], vo = first ? v_old : a.v[ge], po = first ? p_old : a.params[ge];
+      const float gr = g_ * a.grad_scale * s_coef[net];
+      const float m = a.beta1 * mo + (1.0f - a.beta1) * gr;
+      const float v = a.beta2 * vo + (1.0f - a.beta2) * gr * gr;
+      a.m[ge] = m; a.v[ge] = v;
+      const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+      a.params[ge] = po - ((net == 0 ? lr_pf : lr_vf) / bc1) * (m / denom);
+    }
   }
 }
 
@@ -1516,7 +1534,7 @@ extern "C" int trl_ppo_reduce_adam_workspace(int D, int H, int A) {
 
 static int launch_reduce_adam(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf, int D, int H, int A,
                               float* grads, double* info, const trl_adam_t* adam, float* workspace, const XrArgs* xr,
-                              void* stream) {
+                              int max_blocks, void* stream) {
   TRL_REQUIRE(partial && scal_partial && grads && info && workspace, "null pointer");
   TRL_REQUIRE(n_wg >= 2 && n_wg_pf >= 0 && n_wg_pf < n_wg, "need n_wg >= 2 and n_wg_pf in [0, n_wg)");
   const int ps = trl_ppo_partial_stride(D, H, A);
@@ -1532,7 +1550,9 @@ static int launch_reduce_adam(const float* partial, const double* scal_partial, 
   XrArgs none;
   none.rank = 0; none.world = 1; none.ctl = nullptr; none.wait_ticks = 0;
   for (int r = 0; r < TRL_MAX_RANKS; ++r) none.peer[r] = nullptr;
-  hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(trl_ceil_div(ps, RED_CHUNK), 2), dim3(64 * RED_WAVES), 0, (hipStream_t)stream,
+  int grid = 2 * trl_ceil_div(ps, RED_CHUNK);                     // one block per job, unless the caller bounds the footprint
+  if (max_blocks > 0 && max_blocks < grid) grid = max_blocks;
+  hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(grid), dim3(64 * RED_WAVES), 0, (hipStream_t)stream,
                      partial, scal_partial, n_wg, resolve_pf_wgs(n_wg, n_wg_pf), ps, p_pf, p_vf,
                      (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace, (unsigned)adam->step_count,
                      adam->device_state, xr ? 1 : 0, xr ? *xr : none);
@@ -1543,7 +1563,7 @@ static int launch_reduce_adam(const float* partial, const double* scal_partial, 
 extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
                                        int D, int H, int A, float* grads, double* info, const trl_adam_t* adam,
                                        float* workspace, void* stream) {
-  return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, nullptr, stream);
+  return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, nullptr, 0, stream);
 }
 
 // Env shards on several ranks: the same launch with the gradient SUM over ranks between the fold and the clip
@@ -1554,7 +1574,8 @@ extern "C" int trl_ppo_reduce_adam_xrank_f32(const float* partial, const double*
                                              float* workspace, trl_comm_t* comm, void* stream) {
   const XrArgs* xr = trl_comm_xr(comm);
   if (!xr) { trl_set_error("trl_ppo_reduce_adam_xrank_f32: communicator without mapped peers"); return TRL_EINVAL; }
-  return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, xr, stream);
+  return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, xr,
+                            trl_comm_wait_blocks(comm), stream);
 }
 
 // The whole minibatch step as ONE launch (single process): trl_ppo_minibatch_grad_f32 + trl_ppo_reduce_adam_f32, bit for bit.

@@ -27,6 +27,7 @@ struct XrArgs {                                    // passed by value to kernels
 
 struct trl_comm;
 const XrArgs* trl_comm_xr(const trl_comm* c);      // device-side view of a communicator whose peers are mapped, else null
+int trl_comm_wait_blocks(const trl_comm* c);       // trl_comm_set_wait_footprint's value (0: the kernel's own grid)
 
 // granule offsets inside a rank's buffer
 __host__ __device__ inline size_t xr_grad_off(int world, unsigned epoch, int slot, int i) {

@@ -37,9 +37,12 @@ _has_rccl = False
 _peer_report = {}       # what init_comm found: self-check result, ranks per device, why the peers are (not) used
 # The peer transport waits INSIDE kernels (a rank's fold launch polls until every rank's granules have arrived), so every
 # rank's launches must be able to run at the same time.  One rank per GPU: always.  Ranks SHARING a GPU (the one-GPU
-# tests): a waiting fold launch holds 180 blocks x 8 waves, two of them leave no SIMD with the 416 free registers another
-# rank's gradient kernel needs -- beyond 2 ranks per device the ranks would wait for each other until the time-out.
-MAX_PEER_RANKS_PER_DEVICE = 2
+# tests): the waiting fold launches of all of them together must leave CUs for the gradient kernels they are waiting for --
+# at the kernel's own grid (180 blocks x 8 waves) two ranks already leave no SIMD with the 416 free registers a gradient
+# wave needs on 104 of the 256 CUs, and a third rank starves (round 5).  So the fold launch's resident footprint is a
+# property of the communicator (trl_comm_set_wait_footprint): with r > 2 ranks per device every rank's fold launch is
+# CUs // (2 r) blocks, all ranks' waiting blocks together cover at most half of the device.
+MAX_PEER_RANKS_PER_DEVICE = 16                  # (= trl_comm_max_ranks(): no limit of its own any more)
 _SMALL_CAP = 4096       # TRL_XR_CAP_SMALL: 32-bit words per message of the peer transport (statistics region)
 _GRAD_CAP = 12288       # TRL_XR_CAP_GRAD: floats per message of its gradient region
 
@@ -164,6 +167,17 @@ def init_comm(device=None, use_rccl=None, peers=True, allow_shared_device=False)
         td.all_gather_object(keys, key)
         sharing = max(keys.count(k) for k in keys)
         _peer_report["ranks_per_device"] = sharing
+        _peer_report["peer_buffer"] = {1: "uncached device memory (hipDeviceMallocUncached)",
+                                       0: "plain hipMalloc memory (the uncached allocation failed: see stderr)"}.get(
+            int(lib.trl_comm_peer_buffer_kind(handle)), "none")
+        if _peer_ok and sharing > 2:                                       # (two ranks at the kernel's own grid leave 76 CUs: round 4)
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            blocks = max(1, cus // (2 * sharing))
+            lib.trl_comm_set_wait_footprint(handle, blocks)
+            _peer_report["wait_footprint"] = "%d blocks x 8 waves per rank while a gradient is outstanding (%d ranks on a %d-CU device)" \
+                % (blocks, sharing, cus)
+        elif _peer_ok:
+            _peer_report["wait_footprint"] = "the fold launch's own grid (one block per 64 parameters; %d rank(s) per device)" % sharing
         if _peer_ok and sharing > MAX_PEER_RANKS_PER_DEVICE and not allow_shared_device:
             _peer_ok = False
             _peer_report["not_used"] = ("%d ranks share one device: the in-kernel waits of the peer transport need every "
