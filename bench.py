@@ -870,7 +870,11 @@ def main():
                        else ("by all-reduce calls (%s)" % transport if dist.collectives_active() else "not needed (one rank)"))},
         "roofline": {"bound": "mfma", "kernel": "ppo_grad_wave_kernel<17,64,6,tanh>", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                     "traffic": pmc_traffic()[0], "traffic_stamp": pmc_traffic()[1], "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
+                     "traffic": pmc_traffic()[0], "traffic_stamp": pmc_traffic()[1],
+                     # traffic / mfma_busy are rocprofv3 --pmc figures of committed passes over THIS tree's kernel (the
+                     # digest stamp says so), not values of this process: counters cannot be collected inside the timed run
+                     "traffic_measured_in_this_run": False, "mfma_busy_measured_in_this_run": False,
+                     "flop_per_launch": flops, "avg_launch_us": avg_s * 1e6,
                      "whole_iteration_frac": FLOP_PER_ENV_STEP * env_steps / elapsed / world / 1e12 / MFMA_F32_PEAK_TFLOPS,
                      # the HBM side of the same iteration (north_star: fraction of the HBM roofline): SURVEY.md 8(d)'s 1 240
                      # algorithmic bytes per env-step against the nominal 8 TB/s -- the path is MFMA-bound, this says by how much
