@@ -860,6 +860,11 @@ def main():
                                          + ("" if world == 1 else "; every rank draws only its rows of each step's (N_total, A) "
                                             "tensor, from the engine state at their position in the stream")) if headline_parity
                    else "device Philox4x32-10 keyed by the global env index",
+                   "update_launch_sequences": ("two: the critic's and the actor's updates (ppo.py:93-122 / 41-91) as two concurrent "
+                                               "launch sequences on two streams (152 + 104 workgroups per gradient launch), the next "
+                                               "rollout behind the policy's, its value pass behind the value function's; the probe pass "
+                                               "times the pair as ONE 256-workgroup launch (roofline.avg_launch_us)")
+                   if getattr(eng, "two_chains", False) and not dist.collectives_active() else "joint (one sequence, both networks per gradient launch)",
                    "setup_iterations": setup,
                    "update_infos_read_in_timed_region": infos_read,
                    "host_pipeline": "the info dicts of iteration i's updates are read while iteration i+1's rollout runs "

@@ -190,6 +190,11 @@ typedef struct trl_rollout_t {
    * Not with a running observation normaliser. */
   const float* stage_src; float* stage_dst; int64_t stage_n;
   const uint32_t* stage_ready; uint32_t stage_job; uint32_t* stage_state; uint32_t* stage_ack;
+  /* hipEvent_t or NULL: the VALUE PASS of this call (not the rollout in front of it) waits for this event
+   * (hipStreamWaitEvent on `stream`).  The rollout reads only the policy; the value function's parameters may still be
+   * in the hands of an update sequence on another stream (the critic's half of PPO.update_per_epoch, ppo.py:93-122, runs
+   * beside the actor's and beside the NEXT rollout): the event is that sequence's end. */
+  void* value_wait_event;
 } trl_rollout_t;
 int trl_rollout_synth_f32(const trl_rollout_t* args, void* stream);
 /* 1 when trl_rollout_synth_f32 carries networks of this shape (without a running observation normaliser): the
@@ -247,7 +252,10 @@ typedef struct trl_ppo_batch_t {
   double* scal_partial;       /* (n_wg, 8) */
   int n_wg;                   /* workgroups launched (>= 2); rows of partial / scal_partial */
   int n_wg_pf;                /* workgroups [0, n_wg_pf) run the policy, the rest the value net;
-                                 0 = even split.  trl_ppo_wg_split() returns the balanced choice. */
+                                 0 = even split.  trl_ppo_wg_split() returns the balanced choice.
+                                 n_wg_pf = n_wg: ALL workgroups run the policy (vf_params may be NULL);
+                                 n_wg_pf = -1: all run the value net (pf_params may be NULL) -- one network
+                                 per launch, for trl_ppo_reduce_adam_net_f32 */
 } trl_ppo_batch_t;
 int trl_ppo_partial_stride(int D, int H, int A);
 /* balanced policy / value split of n_wg workgroups for n_tiles = ceil(samples / 16) tiles */
@@ -394,6 +402,16 @@ int trl_ppo_step_workspace(int D, int H, int A);
 int trl_ppo_step_max_workgroups(void);
 int trl_ppo_minibatch_step_f32(const trl_ppo_batch_t* args, float* grads, double* info, const trl_adam_t* adam,
                                float* workspace, void* stream);
+
+/* One network's half of trl_ppo_reduce_adam_f32: the n_wg rows of `partial` / `scal_partial` come from a single-network
+ * gradient launch (trl_ppo_batch_t.n_wg_pf = n_wg: net 0, the policy; n_wg_pf = -1: net 1, the value function); folds them,
+ * clips that group by its own norm and takes its Adam step (adam: the two-group descriptor; only group `net` is stepped,
+ * norms_out[net] written).  PPO.update_critic and update_actor (ppo.py:93-122, 41-91) touch disjoint networks, optimisers
+ * and statistics, so the two halves are independent launch sequences -- the next rollout needs only the policy's.
+ * workspace: trl_ppo_reduce_adam_workspace floats PER NETWORK (each keeps its own Adam header). */
+int trl_ppo_reduce_adam_net_f32(const float* partial, const double* scal_partial, int n_wg, int net,
+                                int D, int H, int A, float* grads, double* info,
+                                const trl_adam_t* adam, float* workspace, void* stream);
 
 typedef struct trl_comm trl_comm_t;   /* opaque communicator, see the collectives section below */
 /* --- C1 / C2 / C3: collectives of the multi-GPU path ---------------

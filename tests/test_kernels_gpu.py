@@ -646,3 +646,69 @@ def test_one_launch_step_refuses_grids_that_cannot_be_resident():
     assert rc == -2 and b"co-resident" in lib.trl_last_error()      # TRL_EUNSUPPORTED
     torch.cuda.synchronize()
     assert torch.equal(params, before)
+
+
+@pytest.mark.parametrize("D,A,N,n_wg,n_pf", [(17, 6, 64, 8, 3), (17, 6, 256, 256, 147), (11, 3, 21, 6, 2), (27, 8, 32, 16, 9)])
+def test_one_network_per_launch_is_the_joint_sequence_bit_for_bit(D, A, N, n_wg, n_pf):
+    """The critic's and the actor's halves of an update as separate launches (trl_ppo_batch_t.n_wg_pf = n_wg / -1,
+    trl_ppo_reduce_adam_net_f32, each with its own workspace) against the joint launches of the same split
+    (ppo.py:93-122 / 41-91 touch disjoint networks, optimisers and statistics): parameters, Adam moments, folded gradient,
+    statistics and norms bit for bit over three steps, whichever half is launched first."""
+    from torchrl_amd import _C
+    lib = _C.lib()
+    T, rows_mb = 8, 4
+    pf, ls, vf, buf = _step_fixture(D, A, T, N, seed=D * 7 + n_wg)
+    P_pf, P_vf = 64 * D + 64 + 64 * 64 + 64 + A * 64 + 2 * A, 64 * D + 64 + 64 * 64 + 64 + 64 + 1
+    ps = _C.ppo_partial_stride(D, 64, A)
+    idx = torch.as_tensor(np.random.RandomState(2).permutation(T)[:rows_mb].astype(np.int64)).to(DEV)
+    raw = torch.zeros(1, 4, dtype=torch.float64, device=DEV)
+    _C.adv_stats(buf["advs"].reshape(T, N), idx.reshape(1, -1), raw)
+    stream = _C.stream_ptr(torch.device(DEV))
+    results = []
+    for mode in ("joint", "pf_first", "vf_first"):
+        params = torch.cat([flat(pf, ls), flat(vf)]).contiguous()
+        m, v, grads = torch.zeros_like(params), torch.zeros_like(params), torch.zeros_like(params)
+        n_ws = lib.trl_ppo_reduce_adam_workspace(D, 64, A)
+        wss = [torch.zeros(n_ws, device=DEV) for _ in range(2)]
+        for ws in wss:
+            ws[4:8].view(torch.float64).fill_(1.0)
+            ws[2:4] = torch.tensor([3e-4, 1e-3])
+        infos, norms = torch.zeros(3, 24, dtype=torch.float64, device=DEV), torch.zeros(3, 2, device=DEV)
+        g = _C.PpoBatchArgs()
+        for k, name in (("obs", "obs"), ("acts", "acts"), ("advs", "advs"), ("rets", "estimate_returns"),
+                        ("old_values", "values"), ("old_logp", "old_logp")):
+            setattr(g, k, buf[name].data_ptr())
+        g.row_idx, g.rows_mb, g.N = idx.data_ptr(), rows_mb, N
+        g.adv_raw, g.n_global = raw.data_ptr(), float(rows_mb * N)
+        g.pf_params, g.vf_params = params.data_ptr(), params.data_ptr() + 4 * P_pf
+        g.D, g.H, g.A, g.act = D, 64, A, _C.ACT_TANH
+        g.clip_para, g.entropy_coeff, g.clipped_value_loss, g.tanh_action = 0.2, 0.005, 1, 1
+        a = _C.AdamArgs()
+        a.params, a.grads, a.exp_avg, a.exp_avg_sq = params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.n_groups = 2
+        a.group_sizes[0], a.group_sizes[1] = P_pf, P_vf
+        a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale, a.device_state = 0.5, 0.9, 0.999, 1e-5, 1.0, 1
+        parts = [torch.zeros(n_wg, ps, device=DEV) for _ in range(2)]
+        scals = [torch.zeros(n_wg, 8, dtype=torch.float64, device=DEV) for _ in range(2)]
+        for k in range(3):
+            a.norms_out = norms[k].data_ptr()
+            if mode == "joint":
+                g.partial, g.scal_partial, g.n_wg, g.n_wg_pf = parts[0].data_ptr(), scals[0].data_ptr(), n_wg, n_pf
+                _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "grad")
+                _C.check(lib.trl_ppo_reduce_adam_f32(parts[0].data_ptr(), scals[0].data_ptr(), n_wg, n_pf, D, 64, A, grads.data_ptr(),
+                                                     infos[k].data_ptr(), C.byref(a), wss[0].data_ptr(), stream), "reduce_adam")
+                continue
+            for net in ((0, 1) if mode == "pf_first" else (1, 0)):
+                g.partial, g.scal_partial = parts[net].data_ptr(), scals[net].data_ptr()
+                g.n_wg, g.n_wg_pf = (n_pf, n_pf) if net == 0 else (n_wg - n_pf, -1)
+                _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "grad (one network)")
+                _C.check(lib.trl_ppo_reduce_adam_net_f32(parts[net].data_ptr(), scals[net].data_ptr(), g.n_wg, net, D, 64, A,
+                                                         grads.data_ptr(), infos[k].data_ptr(), C.byref(a), wss[net].data_ptr(), stream),
+                         "reduce_adam_net")
+        torch.cuda.synchronize()
+        assert all(int(ws[:2].view(torch.int32)[0].item()) == 0 for ws in wss)
+        assert int(wss[0][:2].view(torch.int32)[1].item()) == 3 and (mode == "joint" or int(wss[1][:2].view(torch.int32)[1].item()) == 3)
+        results.append([x.cpu() for x in (params, m, v, grads, infos, norms)])
+    for other in results[1:]:
+        for name, x, y in zip(("params", "exp_avg", "exp_avg_sq", "grads", "info", "norms"), results[0], other):
+            assert torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0)), name

@@ -313,6 +313,46 @@ def test_single_env_example_cfg1(tmp_path):
     assert any(f.startswith("_obs_normalizer") or "normalizer" in f for f in os.listdir(model_dir)), os.listdir(model_dir)
 
 
+@pytest.mark.parametrize("noise_mode", ["device", "host"])
+def test_two_update_chains_match_the_joint_sequence(golden, monkeypatch, noise_mode):
+    """One process runs the critic's and the actor's updates of an epoch as two launch sequences on two streams, with the
+    next rollout behind the policy chain and its value pass behind the value chain's end event (`_FusedPPO._run_chains`);
+    TRL_PPO_CHAINS=joint is the single sequence.  Six epochs -- eager, captured, replayed -- of collect + update must
+    give the same rollout buffers every epoch, the same parameters, Adam state and info dicts: any missing dependency
+    between the streams (a rollout reading a policy that is still being stepped, a value pass reading a value function
+    that is, statistics read too early) shows up as a difference."""
+    g = golden("collect_epoch")
+    tag = "mixed"
+    N, T, horizon, max_frames, B, seed = (int(x) for x in g[f"{tag}_args"])
+    results = []
+    for chains in ("joint", "two"):
+        monkeypatch.setenv("TRL_PPO_CHAINS", chains)
+        torch.manual_seed(seed)
+        pf, vf, env, buf, col, agent, logger = build(g, tag, N, T, horizon, max_frames, B, seed, noise_mode=noise_mode)
+        snaps = []
+        for epoch in range(6):
+            col.train_one_epoch()
+            agent.current_epoch = epoch
+            np.random.seed(seed + epoch)
+            agent.update_per_epoch()
+            snaps.append({k: getattr(buf, "_" + k).clone() for k in ("obs", "acts", "values", "rewards", "advs", "estimate_returns")})
+        eng = agent.engine()
+        assert eng.two_chains == (chains == "two")
+        assert (getattr(eng, "_chain_graphs", None) is not None) == (chains == "two")
+        v_now = vf(torch.zeros(3, 17, device="cuda:0"))                  # a reader of the value function settles first
+        torch.cuda.synchronize()
+        assert int(eng.red_ws[:2].view(torch.int32)[1].item()) == eng.step_count == len(logger.infos)
+        if chains == "two":
+            assert int(eng.red_ws_v[:2].view(torch.int32)[1].item()) == eng.step_count
+        results.append((eng.flat.clone(), eng.m.clone(), eng.v.clone(), logger.infos, snaps, v_now.clone()))
+    (f0, m0, v0, i0, s0, y0), (f1, m1, v1, i1, s1, y1) = results
+    for e, (a, b) in enumerate(zip(s0, s1)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (e, k)
+    assert torch.equal(f0, f1) and torch.equal(m0, m1) and torch.equal(v0, v1) and torch.equal(y0, y1)
+    assert len(i0) == len(i1) and all(a == b for a, b in zip(i0, i1))
+
+
 def test_graph_replay_matches_eager_launches(golden, monkeypatch):
     """The captured-and-replayed minibatch loop (third and later epochs of a shape) must be bit-identical to
     launching the same kernels one by one: same parameters, same Adam state, same info dicts."""
@@ -329,7 +369,8 @@ def test_graph_replay_matches_eager_launches(golden, monkeypatch):
             np.random.seed(seed + epoch)
             agent.update_per_epoch()
         eng = agent.engine()
-        assert (eng._graph is not None) == (no_graph == "0")
+        replayed = getattr(eng, "_graph", None) is not None or getattr(eng, "_chain_graphs", None) is not None
+        assert replayed == (no_graph == "0")
         assert int(eng.red_ws[:2].view(torch.int32)[1].item()) == eng.step_count == len(logger.infos)
         results.append((eng.flat.clone(), eng.m.clone(), eng.v.clone(), logger.infos))
     (f0, m0, v0, i0), (f1, m1, v1, i1) = results

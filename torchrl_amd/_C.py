@@ -74,6 +74,7 @@ class RolloutArgs(C.Structure):
         ("noise_flag", C.c_void_p), ("noise_stamp", C.c_uint32),
         ("stage_src", C.c_void_p), ("stage_dst", C.c_void_p), ("stage_n", C.c_int64),
         ("stage_ready", C.c_void_p), ("stage_job", C.c_uint32), ("stage_state", C.c_void_p), ("stage_ack", C.c_void_p),
+        ("value_wait_event", C.c_void_p),
     ]
 
 
@@ -176,6 +177,8 @@ SIGNATURES = {
     "trl_ppo_reduce_adam_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_reduce_adam_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
+    "trl_ppo_reduce_adam_net_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
     "trl_ppo_step_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_step_max_workgroups": (C.c_int, []),
     "trl_ppo_minibatch_step_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),

@@ -158,7 +158,13 @@ class _FusedPPO:
         # what a graph-captured launch boundary costs too (profiles/NOTES_r06.md).
         self.one_launch = os.environ.get("TRL_PPO_STEP", "split") == "fused"
         self.step_max_wg = _C.lib().trl_ppo_step_max_workgroups()
-        self.one_launch = os.environ.get("TRL_PPO_STEP", "fused") != "split"
+        # One process: the critic's and the actor's updates of an epoch (ppo.py:93-122 / 41-91: separate networks, optimisers,
+        # clips and statistics) run as TWO launch sequences on two streams (`_run_chains`); TRL_PPO_CHAINS=joint keeps the
+        # single sequence in which every gradient launch carries both networks.  Same bits either way.
+        self.two_chains = os.environ.get("TRL_PPO_CHAINS", "two") != "joint"
+        self.red_ws_v = torch.zeros(n_ws, device=self.dev)            # the value chain's own Adam header + norm granules
+        self.red_ws_v[4:8].view(torch.float64).fill_(1.0)
+        self._side, self._value_done, self._hdr_owner = None, None, "joint"
         self.red_ws[4:8].view(torch.float64).fill_(1.0)               # beta1^0, beta2^0 (device-side Adam state)
 
     def _alias_optimizer_state(self, opt, plist, offset):
@@ -188,6 +194,17 @@ class _FusedPPO:
         n_pf = _C.lib().trl_ppo_wg_split(self.D, self.H, self.A, tiles, n_wg)
         if not 0 < n_pf < n_wg:
             raise _C.TrlError("trl_ppo_wg_split(%d tiles, %d workgroups) returned %d" % (tiles, n_wg, n_pf))
+        if n_wg >= self.n_cu and n_wg % 8 == 0 and n_wg >= 16:
+            # A full-chip grid: workgroup i runs on XCD i % 8, one workgroup per CU.  When the two networks' workgroups are
+            # launched as SEPARATE kernels (two chains), a split that is not a multiple of 8 puts 33 workgroups on some XCDs
+            # and 31 on others (147 + 109: 19 + 14 on XCDs 0-2) -- the 33rd waits a whole pass for a CU (round 6: 4.5-6 us
+            # per launch).  The neighbouring multiples of 8 are compared with the cost model of trl_ppo_wg_split (a tile of
+            # the policy costs 1.3 of the value net's; both counts of tiles per wave are what matters): 152 + 104 here.
+            waves = lambda x: -(-tiles // (4 * x))
+            cost = lambda x: max(waves(x) * 15.3, waves(n_wg - x) * 11.8)
+            cands = [x for x in (n_pf // 8 * 8, -(-n_pf // 8) * 8) if 0 < x < n_wg]
+            if cands:
+                n_pf = min(cands, key=lambda x: (cost(x), abs(x - n_pf)))
         return n_wg, n_pf
 
     def _buffers(self, K, rows_mb):
@@ -258,6 +275,10 @@ class _FusedPPO:
         # INSIDE the fold / clip / Adam launch (trl_ppo_reduce_adam_xrank_f32) and the statistics go through the
         # one-kernel all-reduce -- plain launches, so the sequence is graph-replayed exactly like the single-process one.
         xrank = not fused and dist.peer_ready()
+        if fused and not one_launch and probe is None and self.two_chains and n_wg_pf >= 1 and n_wg - n_wg_pf >= 1:
+            return self._run_chains(t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global)
+        self._settle_value_chain()                                     # (a joint launch sequence after a two-chain one)
+        self._hdr_owner = "joint"                                      # (its Adam header is red_ws, which the policy chain kept current)
         # TRL_GRAPH_COLLECTIVES=1 (opt-in, RCCL route): capture the multi-rank sequence -- RCCL all-reduces included -- into
         # the HIP graph as well; the Adam step count and learning rates then live on the device like in the fused launch.
         graph_coll = not fused and not xrank and os.environ.get("TRL_GRAPH_COLLECTIVES") == "1"
@@ -395,6 +416,168 @@ class _FusedPPO:
             self._pending = pending
             return pending
         return pending.resolve()                                       # the only host wait of the update
+
+    def _settle_value_chain(self):
+        """The current stream waits for the value chain of the last two-chain run (a no-op when it was waited for already,
+        e.g. by the value pass of a fused rollout)."""
+        if self._value_done is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._value_done)
+
+    def _sync_headers(self, owner):
+        """The joint sequence keeps its Adam header (step count, beta powers, learning rates) in `red_ws`; of the two chains
+        the policy's uses `red_ws` and the value's `red_ws_v`.  Both chains step once per update, so the headers agree
+        after every run -- a change of route just hands the current one over."""
+        if self._hdr_owner != owner:
+            if owner == "two":
+                self.red_ws_v[:8].copy_(self.red_ws[:8])
+            self._hdr_owner = owner
+
+    def _run_chains(self, t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global):
+        """K minibatch updates as TWO launch sequences (one process): after the epoch's prologue on the current stream
+        (`pre`, advantage statistics, target copy, uploads) the POLICY chain -- K x {gradient launch of the policy's
+        workgroups, its fold / clip / Adam} -- stays on the current stream and the VALUE chain -- the same for the value
+        function's workgroups -- goes to a side stream.  Critic and actor updates are independent given the epoch's
+        advantages (ppo.py:93-122 / 41-91), so the results are those of the joint sequence, bit for bit (same tiles per
+        workgroup, same fold order, same Adam arithmetic) -- but the NEXT ROLLOUT, which reads only the policy, starts as
+        soon as the policy chain is through, on the CUs that chain frees, while the value chain (whose ten-tile
+        workgroups make it the longer one) is still stepping: the rollout's 0.2 ms latency chain disappears under it.
+        The value pass behind that rollout waits for the value chain's end event (trl_rollout_t.value_wait_event); every
+        other reader of the value function's parameters settles through networks.nets.settle."""
+        import ctypes as C
+        algo, dev = self.algo, self.dev
+        K, rows_mb = row_idx.shape
+        main = torch.cuda.current_stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+        side = self._side
+        self._settle_value_chain()                                     # the previous run's value chain (normally long done)
+        self._sync_headers("two")
+        idx_dev, _ = self._buffers(K, rows_mb)
+        if getattr(self, "_stats2_key", None) != (K, rows_mb):
+            self._stats2_key = (K, rows_mb)
+            self._stats2 = torch.zeros(2, 29 * K, dtype=torch.float64, device=dev)        # [policy chain | value chain]
+            self._stats2_host = torch.zeros(2, 29 * K, dtype=torch.float64).pin_memory()
+            self._chain_graphs = None
+        stats2 = self._stats2
+        self._idx_host.numpy()[:] = row_idx.reshape(-1)
+        rows_total = t["advs"].shape[0]
+        raw = stats2[0, :4 * K].view(K, 4)
+        lr_pf, lr_vf = algo.pf_optimizer.param_groups[0]['lr'], algo.vf_optimizer.param_groups[0]['lr']
+        self._set_device_hyper(lr_pf, lr_vf, upload=False)
+        hyper = (float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
+                 int(bool(getattr(algo, "clipped_value_loss", False))), int(bool(algo.pf.tanh_action)))
+        n_wg_vf = n_wg - n_wg_pf
+        if getattr(self, "_chain_rows", None) is None:
+            self._chain_rows = (torch.zeros(self.max_wg, self.p_stride, device=dev), torch.zeros(self.max_wg, 8, dtype=torch.float64, device=dev))
+        partial_v, scal_v = self._chain_rows                           # (the policy chain uses self.partial / self.scal)
+        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None) + hyper + tuple(
+            0 if t.get(k) is None else t[k].data_ptr() for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
+
+        def head():
+            self._copy_in_prologue = False
+            if pre is not None:
+                pre()
+            if getattr(self, "_pro_ws", None) is None or self._pro_ws_k != (K, rows_mb):
+                self._pro_ws, self._pro_ws_k = _C.ppo_epoch_prologue_workspace(K, dev), (K, rows_mb)
+            copies = [(self.target_flat, self.flat[:self.P_pf])] if self._copy_in_prologue else []
+            copies += [(idx_dev, self._idx_host), (self.red_ws[2:4], self._hyper_host), (self.red_ws_v[2:4], self._hyper_host)]
+            _C.ppo_epoch_prologue(t["advs"].reshape(rows_total, N), self._idx_host.view(K, rows_mb), raw, self._pro_ws,
+                                  zero=stats2.view(-1)[4 * K:], copies=copies)
+
+        def chain(net):
+            lib = _C.lib()
+            stream = _C.stream_ptr(dev)
+            g = _C.PpoBatchArgs()
+            for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"):
+                setattr(g, k, _C.dev_ptr(t[k], name=k).value if t.get(k) is not None else None)
+            g.loss_mode = loss_mode
+            g.rows_mb, g.N, g.n_global = rows_mb, N, n_global
+            g.pf_params, g.vf_params = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.P_pf
+            g.D, g.H, g.A, g.act = self.D, self.H, self.A, self.act
+            g.clip_para, g.entropy_coeff, g.clipped_value_loss, g.tanh_action = hyper
+            part, scal, ws = (self.partial, self.scal, self.red_ws) if net == 0 else (partial_v, scal_v, self.red_ws_v)
+            g.partial, g.scal_partial = part.data_ptr(), scal.data_ptr()
+            g.n_wg, g.n_wg_pf = (n_wg_pf, n_wg_pf) if net == 0 else (n_wg_vf, -1)
+            a = _C.AdamArgs()
+            a.params, a.grads, a.exp_avg, a.exp_avg_sq = (self.flat.data_ptr(), self.grads.data_ptr(),
+                                                          self.m.data_ptr(), self.v.data_ptr())
+            a.n_groups = 2
+            a.group_sizes[0], a.group_sizes[1] = self.P_pf, self.P_vf
+            a.group_lr[0], a.group_lr[1] = lr_pf, lr_vf
+            a.max_norm, a.beta1, a.beta2, a.eps, a.grad_scale = 0.5, 0.9, 0.999, 1e-5, 1.0
+            a.device_state = 1
+            st = stats2[net]
+            info_base, norm_base = st[4 * K:].data_ptr(), st[28 * K:].data_ptr()
+            for k in range(K):
+                g.row_idx = idx_dev.data_ptr() + 8 * rows_mb * k
+                g.adv_raw = raw.data_ptr() + 32 * k
+                a.step_count, a.norms_out = self.step_count + k + 1, norm_base + 8 * k
+                _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "trl_ppo_minibatch_grad_f32")
+                _C.check(lib.trl_ppo_reduce_adam_net_f32(part.data_ptr(), scal.data_ptr(), g.n_wg, net, self.D, self.H, self.A,
+                                                         self.grads.data_ptr(), info_base + 192 * k, C.byref(a), ws.data_ptr(), stream),
+                         "trl_ppo_reduce_adam_net_f32")
+
+        use_graph = os.environ.get("TRL_NO_GRAPH") != "1"
+        graphs = self._chain_graphs if (use_graph and getattr(self, "_chain_key", None) == key) else None
+        if use_graph and graphs is None and getattr(self, "_chain_seen", None) == key:        # second visit: capture
+            g0, _ = _C.capture_graph(head)
+            gp, _ = _C.capture_graph(lambda: chain(0))
+            with torch.cuda.stream(side):
+                gv, _ = _C.capture_graph(lambda: chain(1))
+            graphs = self._chain_graphs = (g0, gp, gv)
+            self._chain_key = key
+        elif graphs is None:
+            self._chain_seen, self._chain_graphs = key, None             # first visit of a shape: eager (warm-up)
+        run_head, run_p, run_v = (head, lambda: chain(0), lambda: chain(1)) if graphs is None else \
+            (graphs[0].replay, graphs[1].replay, graphs[2].replay)
+        only = os.environ.get("TRL_CHAIN_ONLY")                        # development aid (tools/time_chains.py): one chain alone
+        if only == "v":
+            run_p = lambda: None
+        if only == "p":
+            run_v = lambda: None
+        run_head()
+        forked = torch.cuda.Event()
+        forked.record(main)
+        run_p()                                                        # policy chain: the current stream (the next rollout follows it)
+        self._stats2_host[0].copy_(stats2[0], non_blocking=True)
+        landed_p = torch.cuda.Event()
+        landed_p.record(main)
+        with torch.cuda.stream(side):                                  # value chain: beside it, and beside the next rollout
+            side.wait_event(forked)
+            run_v()
+            self._stats2_host[1].copy_(stats2[1], non_blocking=True)
+            done_v = torch.cuda.Event()
+            done_v.record(side)
+        self._value_done = done_v
+        from ...networks import nets as _nets
+        _nets.set_pending(algo.vf, done_v)
+        self.step_count += K
+        for s_ in self._opt_steps:                                      # host bookkeeping under the device's shadow
+            s_.fill_(float(self.step_count))
+        make = self._infos_a2c if loss_mode == _C.LOSS_A2C else self._infos
+
+        class _Both:
+            @staticmethod
+            def synchronize():
+                landed_p.synchronize()
+                done_v.synchronize()
+
+        def build(host):
+            hp, hv = host[0], host[1]
+            info = hp[4 * K:28 * K].view(K, 24).clone()
+            iv = hv[4 * K:28 * K].view(K, 24)
+            for col in (7, 12, 13, 14, 15):                             # the value chain's entries of the statistics row
+                info[:, col] = iv[:, col]
+            norms = hp[28 * K:].view(torch.float32).view(K, 2).clone()
+            norms[:, 1] = hv[28 * K:].view(torch.float32).view(K, 2)[:, 1]
+            return make(hp[:4 * K].view(K, 4).numpy(), info.numpy(), norms.numpy(), n_global)
+        pending = _PendingInfos(K, _Both, self._stats2_host, build)
+        if defer:
+            self._pending = pending
+            return pending
+        out = pending.resolve()
+        self._settle_value_chain()                                     # a caller that reads in place gets settled parameters too
+        return out
 
     def _infos_a2c(self, raw, info, norms, n):
         """The info dict of A2C.update (a2c.py:86-105); `std` is (B, A) there, each dim repeated B times."""

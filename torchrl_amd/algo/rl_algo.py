@@ -78,6 +78,9 @@ class RLAlgo:
         if prefix is None or dist.rank() != 0:                            # (rank of THIS package's process group: a process that
             return                                                     # merely inherited RANK != 0 still writes its files)
         dist.check_comm()                                              # never snapshot parameters stepped with a partial gradient sum
+        from ..networks import nets as _nets
+        for _name, network in self.snapshot_networks:                  # ... nor parameters another stream is still stepping
+            _nets.settle(network)
         normalizer = getattr(self.env, "_obs_normalizer", None)
         if normalizer is not None:
             with open(os.path.join(prefix, "_obs_normalizer_%s.pkl" % (epoch,)), "wb") as handle:

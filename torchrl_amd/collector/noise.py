@@ -53,7 +53,12 @@ STATS = {"blocks": 0, "parallel_blocks": 0, "pieces": 0, "native_blocks": 0, "ju
 
 
 def default_threads():
-    cores = os.cpu_count() or 1
+    """Host threads of one draw: half of the CPUs THIS process may run on (a rank pinned to its slice of the host by
+    dist.pin_rank_cpus must not size its pool -- or the jump-ahead threads of trl_mt19937_states_at_mt -- by the whole machine)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
     return max(1, min(8, cores // 2))
 
 

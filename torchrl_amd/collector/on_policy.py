@@ -318,6 +318,8 @@ class VecOnPolicyCollector(VecCollector):
     def _forward(self, net, x, out_dim, out=None):
         """mean / value of an MLP on the device: the fused 2-layer kernel when instantiated, the dense-layer family
         otherwise."""
+        from ..networks import nets as _nets
+        _nets.settle(net, x.device)                                     # (parameters still being stepped on another stream)
         if self._mlp2 is not None:
             D, H, A, act = self._mlp2
             return _C.mlp2_forward(net.flat_params(), x, D, H, out_dim, act, out=out)
@@ -361,6 +363,18 @@ class VecOnPolicyCollector(VecCollector):
             a.normalize_partial_reset = int(bool(getattr(env, "normalize_partial_reset", False)))
         a.pf_params = self.pf.flat_params().data_ptr()
         a.vf_params = self.vf.flat_params().data_ptr()
+        # The rollout reads the policy only; the value function may still be in the hands of the previous epoch's critic
+        # updates on another stream (algo/on_policy/ppo.py: two update chains): the value pass behind the rollout waits
+        # for their end, the rollout itself does not.
+        from ..networks import nets as _nets
+        _nets.settle(self.pf, env.device)
+        vf_ev = _nets.pending_event(self.vf)
+        if vf_ev is not None:
+            if store:
+                a.value_wait_event = vf_ev.cuda_event
+                self._vf_event_keepalive = vf_ev                        # (the handle must outlive the launch)
+            else:
+                pass                                                    # no value pass in this call
         a.D, a.H, a.A, a.act = D, H, A, act
         a.tanh_action = int(bool(self.pf.tanh_action))
         a.env_A, a.env_B = env.env_A.data_ptr(), env.env_B.data_ptr()

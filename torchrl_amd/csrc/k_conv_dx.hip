@@ -317,14 +317,39 @@ __global__ __launch_bounds__(64 * WAVES) void conv_dx_img_kernel(const float* __
   }
 }
 
+// What the launch heuristics need to know about the CURRENT device (asked once per device: a process may hold several),
+// and the development switches of this file (read once per process).
+struct DxDev { int cus, lds; };
+static int dx_device() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : 0; }
+static DxDev dx_dev() {
+  static DxDev caps[64];
+  static bool known[64];
+  const int d = dx_device();
+  if (!known[d]) {
+    int cus = 0, lds = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0) cus = 256;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, d) != hipSuccess || lds <= 0) lds = 160 * 1024;
+    (void)hipGetLastError();
+    caps[d] = DxDev{cus, lds};
+    known[d] = true;
+  }
+  return caps[d];
+}
+static int dx_env(const char* name) {                  // -1: not set
+  const char* v = getenv(name);
+  return v ? atoi(v) : -1;
+}
+static const int ENV_CLASS_FORM = dx_env("TRL_DX_CLASS_FORM"), ENV_IMG = dx_env("TRL_DX_IMG"), ENV_WAVES = dx_env("TRL_DX_WAVES");
+
 // images per workgroup of the image-tile form, 0 = the layer does not fit (use the class form): all classes' weights plus
 // the padded dZ of the images within 150 KB of LDS; as many images as keeps the grid at one workgroup per CU or more
 static int dx_img_per_wg(const DxGeom& g, int* lds_bytes) {
   const int64_t wbytes = (int64_t)g.Cout * g.Cin * g.kh * g.kw * 4;
   const DxPad pd = dx_pad(g);
   const int64_t zbytes = (int64_t)pd.Hp * pd.Wp * (g.Cout + 4) * 4;    // an image's dZ with its zero border
-  const int64_t cap = 150 * 1024;
-  if (getenv("TRL_DX_CLASS_FORM") && atoi(getenv("TRL_DX_CLASS_FORM"))) return 0;
+  const DxDev dev = dx_dev();
+  const int64_t cap = dev.lds - 10 * 1024;                                   // (150 KB of MI355X's 160)
+  if (ENV_CLASS_FORM > 0) return 0;
   if (wbytes + zbytes > cap || (int64_t)pd.Hp * pd.Wp > 4096) return 0;
   // The fewest images per workgroup for which the WHOLE grid is resident at once (160 KB of LDS per CU, 256 CUs): measured
   // at cfg 5 (tools/ab_convdx.py, MI355X): conv 2 (45 KB per image-workgroup: 512 workgroups, two per CU) 29 us against
@@ -334,10 +359,10 @@ static int dx_img_per_wg(const DxGeom& g, int* lds_bytes) {
   for (; img < 8; ++img) {
     const int64_t lds = wbytes + img * zbytes;
     if (lds + zbytes > cap) break;                                         // one more image would not fit
-    const int64_t resident = 256 * std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / lds));
+    const int64_t resident = dev.cus * std::max<int64_t>(1, std::min<int64_t>(8, dev.lds / lds));
     if ((g.B + img - 1) / img <= resident) break;
   }
-  if (getenv("TRL_DX_IMG")) img = std::max(1, atoi(getenv("TRL_DX_IMG")));
+  if (ENV_IMG >= 0) img = std::max(1, ENV_IMG);
   while (img > 1 && wbytes + img * zbytes > cap) --img;
   img = std::min(img, std::max(1, g.B));
   *lds_bytes = (int)(wbytes + img * zbytes);
@@ -346,11 +371,12 @@ static int dx_img_per_wg(const DxGeom& g, int* lds_bytes) {
 template <int CB, int NCH, int WAVES>
 static int launch_dx_img(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
                          const DxGeom& g, int img, int lds, hipStream_t s, bool prepped) {
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
+  static int attr_lds[64];                                                  // the raised dynamic-LDS limit is per device
+  const int d = dx_device();
+  if (lds > attr_lds[d]) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_dx_img_kernel<CB, NCH, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { trl_set_error("conv_bwd_input: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_lds = lds;
+    attr_lds[d] = lds;
   }
   if (!prepped) {
     const int total = g.Cout * g.Cin * g.kh * g.kw;
@@ -366,11 +392,12 @@ static int launch_dx_img(const float* dy, const float* yg, const float* w, float
 template <int CB, int NCH, int WAVES>
 static int launch_dx_waves(const float* dy, const float* yg, const float* w, float* wprep, float* dx, const float* xg,
                            DxGeom g, int lds, hipStream_t s, bool prepped) {
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
+  static int attr_lds[64];
+  const int d = dx_device();
+  if (lds > attr_lds[d]) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_dx_kernel<CB, NCH, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { trl_set_error("conv_bwd_input: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_lds = lds;
+    attr_lds[d] = lds;
   }
   const int total = g.Cout * g.Cin * g.kh * g.kw;
   if (!prepped) {
@@ -404,14 +431,14 @@ static int launch_dx(const float* dy, const float* yg, const float* w, float* wp
       for (int cls = 0; cls < g.sh * g.sw; ++cls)
         blocks += trl_ceil_div(img * trl_ceil_div(g.H - cls / g.sw, g.sh) * trl_ceil_div(g.W - cls % g.sw, g.sw), 16);
       bool eight = blocks > 4;
-      if (getenv("TRL_DX_WAVES")) eight = atoi(getenv("TRL_DX_WAVES")) >= 8;
+      if (ENV_WAVES >= 0) eight = ENV_WAVES >= 8;
       return eight ? launch_dx_img<CB, NCH, 8>(dy, yg, w, wprep, dx, xg, g, img, lds_img, s, prepped)
                    : launch_dx_img<CB, NCH, 4>(dy, yg, w, wprep, dx, xg, g, img, lds_img, s, prepped);
     }
   }
   const int max_taps = trl_ceil_div(g.kh, g.sh) * trl_ceil_div(g.kw, g.sw);
   const int lds = max_taps * g.Cout * g.Cin * (int)sizeof(float);
-  TRL_REQUIRE(lds <= 160 * 1024, "conv_bwd_input: one parity class of the weights exceeds the LDS");
+  TRL_REQUIRE(lds <= dx_dev().lds, "conv_bwd_input: one parity class of the weights exceeds the LDS");
   // a class's weights above ~40 KB leave room for two or three workgroups per CU: make them 8 waves each
   if (lds > 40 * 1024) return launch_dx_waves<CB, NCH, 8>(dy, yg, w, wprep, dx, xg, g, lds, s, prepped);
   return launch_dx_waves<CB, NCH, 4>(dy, yg, w, wprep, dx, xg, g, lds, s, prepped);

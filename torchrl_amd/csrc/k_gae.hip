@@ -17,6 +17,7 @@
 // chunk in flight at once (one memory round trip instead of one per 16 time steps), no second read of V in the write-back,
 // the wave's envs scanned in lockstep (their shuffle chains overlap), 8 envs per workgroup (256 workgroups at N = 2048
 // instead of 128 on 256 CUs).  What is left is launch + three dependent phases (load, LDS scan, store) of a 6 MB kernel.
+// Round 6: tiles are dealt to workgroups so that each XCD's L2 sees a contiguous run of envs (see below).
 #include "trl_common.h"
 
 #define ENV_TILE 8
@@ -34,7 +35,14 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_scan_kernel(
   __shared__ float s_carry[ENV_TILE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * ENV_TILE;
+  // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin (b -> XCD b % 8), and an env tile's row piece is
+  // 32 B of a 128-B line -- with tile = b the four tiles sharing a line sat in four different L2s and every line was
+  // fetched four times over the fabric (round 5: FETCH_SIZE 8.26 MB against 4.19 MB read).  Each XCD now takes a
+  // CONTIGUOUS run of tiles (XCD x: its (G - x + 7) / 8 workgroups, in order), so a line is fetched into one L2.
+  const int G = gridDim.x, xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  int first = 0;
+  for (int y = 0; y < xcd; ++y) first += (G - y + 7) >> 3;
+  const int n0 = (first + q) * ENV_TILE;
   const int e_ld = tid % ENV_TILE, t_ld = tid / ENV_TILE;       // staging role
   const int n_ld = n0 + e_ld;
 

@@ -998,11 +998,13 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
                                                               const float* __restrict__ logstd, int n_act,
                                                               float* __restrict__ grads, double* __restrict__ info,
                                                               AdamDev a, float* __restrict__ ws, unsigned epoch,
-                                                              int device_state, int xrank, XrArgs xr) {
+                                                              int device_state, int xrank, XrArgs xr, int only_net) {
   __shared__ float s_coef[2];
   __shared__ float s_hyper[4];                                    // bc1, bc2_sqrt, lr_pf, lr_vf
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nb = (p_stride + RED_CHUNK - 1) / RED_CHUNK, n_jobs = 2 * nb, grid = gridDim.x, blk = blockIdx.x;
+  // only_net >= 0: the rows are ONE network's (a single-network gradient launch); its nb jobs only, its norm, its group
+  const int nb = (p_stride + RED_CHUNK - 1) / RED_CHUNK, grid = gridDim.x, job0 = only_net == 1 ? nb : 0;
+  const int n_jobs = only_net >= 0 ? job0 + nb : 2 * nb, blk = job0 + (int)blockIdx.x;
   // Graph-replayable form: the Adam step count and the learning rates live in the workspace header
   // (ws[1] = steps taken so far as uint32, ws[2..3] = lr), so no launch argument changes between replays.
   // Every block reads the count BEFORE it publishes its slots; block 0 bumps it only after it has seen
@@ -1056,7 +1058,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   float m_old = 0.0f, v_old = 0.0f, p_old = 0.0f;
   if (own_) { m_old = a.m[ge_]; v_old = a.v[ge_]; p_old = a.params[ge_]; }
   // ---- group norms (pf, vf): wave w polls net w's slots, then sums them in fixed order ----
-  if (wave < 2) {
+  if (wave < 2 && (only_net < 0 || wave == only_net)) {
     float acc = 0.0f;
     for (int b = lane; b < nb; b += 64) {
       unsigned long long v;
@@ -1079,7 +1081,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
     if (lane == 0) {
       const float norm = sqrtf(acc);
       s_coef[wave] = (a.max_norm > 0.0f) ? fminf(a.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
-      if (a.norms_out && blk == 0) a.norms_out[wave] = norm;
+      if (a.norms_out && blk == job0) a.norms_out[wave] = norm;
     }
   }
   __syncthreads();
@@ -1088,13 +1090,13 @@ __global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const f
   float bc1 = a.bc1, bc2_sqrt = a.bc2_sqrt, lr_pf = a.lr[0], lr_vf = a.lr[1];
   if (device_state) {
     bc1 = s_hyper[0]; bc2_sqrt = s_hyper[1]; lr_pf = s_hyper[2]; lr_vf = s_hyper[3];
-    if (blk == 0) {                                              // every block has read the header by now (see above)
+    if (blk == job0) {                                           // every block has read the header by now (see above)
       if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(ws) + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tid == 64 * (RED_WAVES - 1)) { bpow[0] = b1p; bpow[1] = b2p; }
     }
   }
   // (every block has passed its exchanges by the time block 0 has seen all norm slots)
-  if (xrank && blk == 0 && tid == 0)
+  if (xrank && blk == job0 && tid == 0)
     __hip_atomic_store(xr.ctl + 4, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // A cross-rank wait that timed out left a PARTIAL gradient sum: no parameter is written then (every block has finished
   // its exchanges before any block sees all norm slots, so the flag is final here and all blocks decide alike); the host
@@ -1341,8 +1343,19 @@ __global__ __launch_bounds__(WV_THREADS, 1) void ppo_grad_wave_kernel(PpoDev a, 
   if (STEP && threadIdx.x == 0)
     (reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(t.ws) + step_ws_words((a.p_stride + RED_CHUNK - 1) / RED_CHUNK)) + (size_t)blockIdx.x * 8)[0] = wall_clock64();
 #endif
+#ifdef TRL_CHAIN_CLK                                  /* tools/time_chains.py: when did this workgroup start and end (100 MHz) */
+  const unsigned long long clk0 = wall_clock64();
+#endif
   if ((int)blockIdx.x < a.n_pf) ppo_wave_pass<D, H, A, ACT, true, CONTIG, RT, STEP>(a, lds, blockIdx.x, a.n_pf);
   else                          ppo_wave_pass<D, H, A, ACT, false, CONTIG, RT, STEP>(a, lds, blockIdx.x - a.n_pf, a.n_wg - a.n_pf);
+#ifdef TRL_CHAIN_CLK
+  __syncthreads();
+  if (threadIdx.x == 0) {                             // the row's unused 8th scalar and the last three padding floats of the partial row
+    a.scal_partial[(size_t)blockIdx.x * 8 + 7] = (double)wall_clock64();
+    float* pad = a.partial + (size_t)blockIdx.x * a.p_stride + a.p_stride - 3;
+    pad[0] = (float)(clk0 >> 40); pad[1] = (float)((clk0 >> 20) & 0xFFFFFull); pad[2] = (float)(clk0 & 0xFFFFFull);
+  }
+#endif
   if constexpr (STEP) ppo_step_tail(a, t, lds, seq);
 }
 
@@ -1441,7 +1454,10 @@ extern "C" int trl_ppo_wg_split(int D, int H, int A, int n_tiles, int n_wg) {
   (void)D; (void)H; (void)A;
   return best;
 }
-static int resolve_pf_wgs(int n_wg, int n_wg_pf) { return n_wg_pf > 0 ? n_wg_pf : n_wg / 2; }
+// n_wg_pf: 0 = even split, [1, n_wg) = that many policy workgroups, n_wg = ALL workgroups run the policy, -1 = all run the
+// value net (one network per launch: the two update chains of PPO are independent -- ppo.py:93-122 vs 41-91 -- and may run
+// as separate, concurrent launch sequences)
+static int resolve_pf_wgs(int n_wg, int n_wg_pf) { return n_wg_pf < 0 ? 0 : (n_wg_pf > 0 ? n_wg_pf : n_wg / 2); }
 
 static int ppo_grad_launch(const trl_ppo_batch_t* p, const StepDev* step, void* stream) {
   if (!p) { trl_set_error("ppo_grad: null descriptor"); return TRL_EINVAL; }
@@ -1449,10 +1465,12 @@ static int ppo_grad_launch(const trl_ppo_batch_t* p, const StepDev* step, void* 
   TRL_REQUIRE(p->loss_mode == TRL_LOSS_PPO_CLIP || p->loss_mode == TRL_LOSS_A2C, "unknown loss_mode");
   TRL_REQUIRE(p->loss_mode == TRL_LOSS_A2C || p->old_logp, "the clipped surrogate needs old_logp");
   TRL_REQUIRE(!p->clipped_value_loss || p->old_values, "the clipped value loss needs old_values");
-  TRL_REQUIRE(p->adv_raw && p->pf_params && p->vf_params && p->partial && p->scal_partial, "null pointer");
+  TRL_REQUIRE(p->adv_raw && (p->pf_params || p->vf_params) && p->partial && p->scal_partial, "null pointer");
   TRL_REQUIRE(p->rows_mb > 0 && p->N > 0, "empty minibatch");
-  TRL_REQUIRE(p->n_wg >= 2, "n_wg must be >= 2");
-  TRL_REQUIRE(p->n_wg_pf >= 0 && p->n_wg_pf < p->n_wg, "n_wg_pf must be 0 (even split) or in [1, n_wg)");
+  TRL_REQUIRE(p->n_wg >= 1 && (p->n_wg >= 2 || p->n_wg_pf == -1 || p->n_wg_pf == p->n_wg), "n_wg must be >= 2 (>= 1 for one network)");
+  TRL_REQUIRE(p->n_wg_pf >= -1 && p->n_wg_pf <= p->n_wg, "n_wg_pf must be 0 (even split), in [1, n_wg], or -1 (value net only)");
+  TRL_REQUIRE(p->n_wg_pf == p->n_wg || p->vf_params, "null value parameters");
+  TRL_REQUIRE(p->n_wg_pf == -1 || p->pf_params, "null policy parameters");
   TRL_REQUIRE(p->n_global > 1.0, "n_global must exceed 1 (unbiased std)");
   const int D = p->D, H = p->H, A = p->A;
   TRL_REQUIRE(((uintptr_t)p->partial & 15) == 0 && (((uintptr_t)p->pf_params | (uintptr_t)p->vf_params) & 3) == 0,
@@ -1534,9 +1552,9 @@ extern "C" int trl_ppo_reduce_adam_workspace(int D, int H, int A) {
 
 static int launch_reduce_adam(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf, int D, int H, int A,
                               float* grads, double* info, const trl_adam_t* adam, float* workspace, const XrArgs* xr,
-                              int max_blocks, void* stream) {
+                              int max_blocks, void* stream, int only_net = -1) {
   TRL_REQUIRE(partial && scal_partial && grads && info && workspace, "null pointer");
-  TRL_REQUIRE(n_wg >= 2 && n_wg_pf >= 0 && n_wg_pf < n_wg, "need n_wg >= 2 and n_wg_pf in [0, n_wg)");
+  TRL_REQUIRE(only_net >= 0 ? n_wg >= 1 : (n_wg >= 2 && n_wg_pf >= 0 && n_wg_pf < n_wg), "need n_wg >= 2 and n_wg_pf in [0, n_wg)");
   const int ps = trl_ppo_partial_stride(D, H, A);
   if (ps < 0) return ps;
   AdamDev d;
@@ -1550,12 +1568,13 @@ static int launch_reduce_adam(const float* partial, const double* scal_partial, 
   XrArgs none;
   none.rank = 0; none.world = 1; none.ctl = nullptr; none.wait_ticks = 0;
   for (int r = 0; r < TRL_MAX_RANKS; ++r) none.peer[r] = nullptr;
-  int grid = 2 * trl_ceil_div(ps, RED_CHUNK);                     // one block per job, unless the caller bounds the footprint
+  int grid = (only_net >= 0 ? 1 : 2) * trl_ceil_div(ps, RED_CHUNK);   // one block per job, unless the caller bounds the footprint
   if (max_blocks > 0 && max_blocks < grid) grid = max_blocks;
+  const int n_pf = only_net == 0 ? n_wg : (only_net == 1 ? 0 : resolve_pf_wgs(n_wg, n_wg_pf));
   hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(grid), dim3(64 * RED_WAVES), 0, (hipStream_t)stream,
-                     partial, scal_partial, n_wg, resolve_pf_wgs(n_wg, n_wg_pf), ps, p_pf, p_vf,
+                     partial, scal_partial, n_wg, n_pf, ps, p_pf, p_vf,
                      (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace, (unsigned)adam->step_count,
-                     adam->device_state, xr ? 1 : 0, xr ? *xr : none);
+                     adam->device_state, xr ? 1 : 0, xr ? *xr : none, only_net);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
@@ -1564,6 +1583,18 @@ extern "C" int trl_ppo_reduce_adam_f32(const float* partial, const double* scal_
                                        int D, int H, int A, float* grads, double* info, const trl_adam_t* adam,
                                        float* workspace, void* stream) {
   return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, nullptr, 0, stream);
+}
+
+// ONE network's half of the step: `partial` / `scal_partial` hold the n_wg rows of a single-network gradient launch
+// (trl_ppo_minibatch_grad_f32 with n_wg_pf = n_wg: net 0, the policy; n_wg_pf = -1: net 1, the value function); the fold,
+// that group's clip and its Adam step.  PPO's critic and actor updates are independent (separate networks, optimisers
+// and clips: ppo.py:93-122 / 41-91), so the two halves may run as separate launch sequences, concurrently, each with its
+// own workspace (own Adam header: both count the same steps).  Same arithmetic and order as the joint launch: bit-identical.
+extern "C" int trl_ppo_reduce_adam_net_f32(const float* partial, const double* scal_partial, int n_wg, int net,
+                                           int D, int H, int A, float* grads, double* info, const trl_adam_t* adam,
+                                           float* workspace, void* stream) {
+  TRL_REQUIRE(net == 0 || net == 1, "net: 0 = policy, 1 = value function");
+  return launch_reduce_adam(partial, scal_partial, n_wg, 0, D, H, A, grads, info, adam, workspace, nullptr, 0, stream, net);
 }
 
 // Env shards on several ranks: the same launch with the gradient SUM over ranks between the fold and the clip

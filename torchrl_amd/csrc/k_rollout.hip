@@ -751,7 +751,7 @@ static int rollout_norm_capacity() {
 }
 
 template <int D, int H, int A, int ACT, bool RT = false>
-static int launch_rollout(const RolloutDev& d, hipStream_t s) {
+static int launch_rollout(const RolloutDev& d, hipStream_t s, hipEvent_t value_wait = nullptr) {
   const int n_wg = trl_ceil_div(d.N, RO_ENVS);
   if constexpr (RT) {
     if (d.norm_state) { trl_set_error("rollout: the normalised rollout is instantiated for the benchmark shape only"); return TRL_EUNSUPPORTED; }
@@ -772,6 +772,10 @@ static int launch_rollout(const RolloutDev& d, hipStream_t s) {
   }
   TRL_LAUNCH_CHECK();
   if (d.store) {
+    if (value_wait) {                               // the value function's parameters are still being stepped on another stream
+      hipError_t e = hipStreamWaitEvent(s, value_wait, 0);
+      if (e != hipSuccess) { trl_set_error("rollout: hipStreamWaitEvent(value_wait_event): %s", hipGetErrorString(e)); return (int)e; }
+    }
     ValueDev v{d.vf_params, d.obs, d.next_obs, d.values, d.rewards, d.rows, d.top, d.N, d.n_steps, d.discount, d.boot,
                d.pub_dst, d.pub_src, d.pub_words, d.D};
     const int64_t n_tiles = ((int64_t)d.n_steps * d.N + 15) / 16;
@@ -854,18 +858,19 @@ extern "C" int trl_rollout_synth_f32(const trl_rollout_t* p, void* stream) {
               "clear_header must not be the header this launch accumulates into");
   TRL_REQUIRE(!p->norm_state || (p->policy_obs && p->norm_workspace), "normaliser needs policy_obs and its workspace");
   hipStream_t s = (hipStream_t)stream;
+  hipEvent_t vw = (hipEvent_t)p->value_wait_event;
   d.D = p->D; d.A = p->A;
   if (p->D == 17 && p->H == 64 && p->A == 6) {
-    if (p->act == TRL_ACT_TANH) return launch_rollout<17, 64, 6, TRL_ACT_TANH>(d, s);
-    if (p->act == TRL_ACT_RELU) return launch_rollout<17, 64, 6, TRL_ACT_RELU>(d, s);
+    if (p->act == TRL_ACT_TANH) return launch_rollout<17, 64, 6, TRL_ACT_TANH>(d, s, vw);
+    if (p->act == TRL_ACT_RELU) return launch_rollout<17, 64, 6, TRL_ACT_RELU>(d, s, vw);
   }
   if (trl_rollout_supported(p->D, p->H, p->A, p->act) && !p->norm_state) {        // runtime-dims instantiations
     if (p->D <= 17) {
-      if (p->act == TRL_ACT_TANH) return launch_rollout<17, 64, 8, TRL_ACT_TANH, true>(d, s);
-      return launch_rollout<17, 64, 8, TRL_ACT_RELU, true>(d, s);
+      if (p->act == TRL_ACT_TANH) return launch_rollout<17, 64, 8, TRL_ACT_TANH, true>(d, s, vw);
+      return launch_rollout<17, 64, 8, TRL_ACT_RELU, true>(d, s, vw);
     }
-    if (p->act == TRL_ACT_TANH) return launch_rollout<32, 64, 8, TRL_ACT_TANH, true>(d, s);
-    return launch_rollout<32, 64, 8, TRL_ACT_RELU, true>(d, s);
+    if (p->act == TRL_ACT_TANH) return launch_rollout<32, 64, 8, TRL_ACT_TANH, true>(d, s, vw);
+    return launch_rollout<32, 64, 8, TRL_ACT_RELU, true>(d, s, vw);
   }
   trl_set_error("rollout: shape D=%d H=%d A=%d act=%d not instantiated", p->D, p->H, p->A, p->act);
   return TRL_EUNSUPPORTED;

@@ -139,19 +139,27 @@ void pow_x(uint64_t J, Poly& out) {                                   // x^J mod
   out = r;
 }
 
-std::map<uint64_t, Poly> g_cache;
+struct CachedPoly { Poly p; uint64_t used; };
+std::map<uint64_t, CachedPoly> g_cache;
 std::mutex g_cache_mutex;
+uint64_t g_cache_clock = 0;
 Poly jump_poly(uint64_t J) {                                          // by value: the cache may drop entries under other threads
   {
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     auto it = g_cache.find(J);
-    if (it != g_cache.end()) return it->second;
+    if (it != g_cache.end()) { it->second.used = ++g_cache_clock; return it->second.p; }
   }
   Poly p;
   pow_x(J, p);                                                        // outside the lock: several threads may compute their own
   std::lock_guard<std::mutex> lock(g_cache_mutex);
-  if (g_cache.size() > 256) g_cache.clear();                          // (bounded: the position lists of a run are few)
-  g_cache.emplace(J, p);
+  // bounded at 256 polynomials (~2.5 KB each); the LEAST RECENTLY USED one goes, so that a run whose chunk layout changes
+  // now and then keeps the polynomials of the layouts it returns to (a wholesale clear() made every one of them ~0.1 s again)
+  while (g_cache.size() >= 256) {
+    auto victim = g_cache.begin();
+    for (auto it = g_cache.begin(); it != g_cache.end(); ++it) if (it->second.used < victim->second.used) victim = it;
+    g_cache.erase(victim);
+  }
+  g_cache[J] = CachedPoly{p, ++g_cache_clock};
   return p;
 }
 
@@ -269,9 +277,16 @@ extern "C" int trl_mt19937_states_at_mt(const uint8_t* tmpl, int64_t state_bytes
       for (int i = 0; i < MT_N; ++i) { const uint64_t w = st[i]; memcpy(rec + off_mt + 8 * i, &w, 8); }
     }
   };
+  // A thread that cannot be created (std::system_error: thread limit of the container, EAGAIN) must not escape through the
+  // C ABI -- it would end the process; the groups it would have taken run inline instead.
   std::vector<std::thread> pool;
-  for (int p = 1; p < P; ++p) pool.emplace_back(run, p);
+  int started = 1;
+  for (; started < P; ++started) {
+    try { pool.emplace_back(run, started); }
+    catch (const std::exception&) { break; }
+  }
   run(0);
+  for (int p = started; p < P; ++p) run(p);
   for (auto& t : pool) t.join();
   return TRL_OK;
 }

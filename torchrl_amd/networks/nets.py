@@ -21,6 +21,32 @@ from .. import _C
 _ACT_CODE = {nn.Tanh: _C.ACT_TANH, nn.ReLU: _C.ACT_RELU}
 
 
+# Parameters that a launch sequence on ANOTHER stream is still stepping (the critic's half of a PPO epoch runs beside the
+# next rollout, algo/on_policy/ppo.py): net -> the event that sequence ends with.  Whoever is about to read such a net's
+# parameters on the current stream waits for the event first (`settle`); weak keys: nothing is kept alive, nothing is
+# pickled or deep-copied with the module.
+import weakref
+_PENDING = weakref.WeakKeyDictionary()
+
+
+def set_pending(net, event):
+    if event is None:
+        _PENDING.pop(net, None)
+    else:
+        _PENDING[net] = event
+
+
+def pending_event(net):
+    return _PENDING.get(net)
+
+
+def settle(net, device=None):
+    """Make the current stream wait for whatever is still writing `net`'s parameters on another stream."""
+    ev = _PENDING.get(net)
+    if ev is not None:
+        torch.cuda.current_stream(device).wait_event(ev)
+
+
 class Net(nn.Module):
     def __init__(self, output_shape, base_type, append_hidden_shapes=[],
                  append_hidden_init_func=init.basic_init, net_last_init_func=init.uniform_init,
@@ -89,6 +115,8 @@ class Net(nn.Module):
     def forward(self, x):
         spec = self.mlp2_spec()
         needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if x.is_cuda and _PENDING:
+            settle(self, x.device)
         if x.is_cuda and not needs_graph:
             lead = x.shape[:-1]
             if spec is not None and _C.lib().trl_mlp2_forward_supported(spec[0], spec[1], spec[2]):
