@@ -604,6 +604,9 @@ def main():
                     help="with --cpu-baseline-only: which workload's CPU baseline to time (tools/bench_{sac,dqn}.py)")
     ap.add_argument("--probe-graph-collectives", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if os.environ.get("TRL_BENCH_DUMP_AFTER_S") and ("RANK" in os.environ or args.gpus == 1):   # diagnosing a wedged rank: every thread's stack, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["TRL_BENCH_DUMP_AFTER_S"]), exit=True)
     if args.probe_graph_collectives:
         _probe_child()
     if args.cpu_baseline_full:

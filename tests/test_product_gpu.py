@@ -329,6 +329,13 @@ def test_two_update_chains_match_the_joint_sequence(golden, monkeypatch, noise_m
         monkeypatch.setenv("TRL_PPO_CHAINS", chains)
         torch.manual_seed(seed)
         pf, vf, env, buf, col, agent, logger = build(g, tag, N, T, horizon, max_frames, B, seed, noise_mode=noise_mode)
+        # hold every value chain back by ~2 ms of device spin: the next rollout then runs (and finishes) while the chain is
+        # still reading the previous rollout's observations, and its value pass has to wait for the chain -- at test
+        # size the host would otherwise never be fast enough to make the two overlap (a rollout that overwrote the `obs`
+        # the chain reads, round 6, only showed at 16 384 envs)
+        agent.engine()._test_value_chain_delay = 5_000_000
+        later = []                                                       # the updates are launched, not awaited (utils.Logger's protocol)
+        logger.add_update_infos_later = later.append
         snaps = []
         for epoch in range(6):
             col.train_one_epoch()
@@ -336,9 +343,11 @@ def test_two_update_chains_match_the_joint_sequence(golden, monkeypatch, noise_m
             np.random.seed(seed + epoch)
             agent.update_per_epoch()
             snaps.append({k: getattr(buf, "_" + k).clone() for k in ("obs", "acts", "values", "rewards", "advs", "estimate_returns")})
+        for resolve in later:                                            # read in order, after everything was launched
+            logger.infos.extend(dict(d) for d in resolve())
         eng = agent.engine()
         assert eng.two_chains == (chains == "two")
-        assert (getattr(eng, "_chain_graphs", None) is not None) == (chains == "two")
+        assert bool(getattr(eng, "_chain_graphs", None)) == (chains == "two")       # (captured launch sequences were replayed)
         v_now = vf(torch.zeros(3, 17, device="cuda:0"))                  # a reader of the value function settles first
         torch.cuda.synchronize()
         assert int(eng.red_ws[:2].view(torch.int32)[1].item()) == eng.step_count == len(logger.infos)
@@ -369,7 +378,7 @@ def test_graph_replay_matches_eager_launches(golden, monkeypatch):
             np.random.seed(seed + epoch)
             agent.update_per_epoch()
         eng = agent.engine()
-        replayed = getattr(eng, "_graph", None) is not None or getattr(eng, "_chain_graphs", None) is not None
+        replayed = getattr(eng, "_graph", None) is not None or bool(getattr(eng, "_chain_graphs", None))
         assert replayed == (no_graph == "0")
         assert int(eng.red_ws[:2].view(torch.int32)[1].item()) == eng.step_count == len(logger.infos)
         results.append((eng.flat.clone(), eng.m.clone(), eng.v.clone(), logger.infos))

@@ -164,7 +164,7 @@ class _FusedPPO:
         self.two_chains = os.environ.get("TRL_PPO_CHAINS", "two") != "joint"
         self.red_ws_v = torch.zeros(n_ws, device=self.dev)            # the value chain's own Adam header + norm granules
         self.red_ws_v[4:8].view(torch.float64).fill_(1.0)
-        self._side, self._value_done, self._hdr_owner = None, None, "joint"
+        self._side, self._value_done, self._hdr_owner, self._chain_graphs = None, None, "joint", {}
         self.red_ws[4:8].view(torch.float64).fill_(1.0)               # beta1^0, beta2^0 (device-side Adam state)
 
     def _alias_optimizer_state(self, opt, plist, offset):
@@ -278,6 +278,10 @@ class _FusedPPO:
         if fused and not one_launch and probe is None and self.two_chains and n_wg_pf >= 1 and n_wg - n_wg_pf >= 1:
             return self._run_chains(t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global)
         self._settle_value_chain()                                     # (a joint launch sequence after a two-chain one)
+        if self._value_done is not None:
+            from ...networks import nets as _nets
+            _nets.set_pending(algo.vf, None)
+            self._value_done = None
         self._hdr_owner = "joint"                                      # (its Adam header is red_ws, which the policy chain kept current)
         # TRL_GRAPH_COLLECTIVES=1 (opt-in, RCCL route): capture the multi-rank sequence -- RCCL all-reduces included -- into
         # the HIP graph as well; the Adam step count and learning rates then live on the device like in the fused launch.
@@ -457,7 +461,7 @@ class _FusedPPO:
             self._stats2_key = (K, rows_mb)
             self._stats2 = torch.zeros(2, 29 * K, dtype=torch.float64, device=dev)        # [policy chain | value chain]
             self._stats2_host = torch.zeros(2, 29 * K, dtype=torch.float64).pin_memory()
-            self._chain_graphs = None
+            self._chain_graphs = {}
         stats2 = self._stats2
         self._idx_host.numpy()[:] = row_idx.reshape(-1)
         rows_total = t["advs"].shape[0]
@@ -517,17 +521,21 @@ class _FusedPPO:
                                                          self.grads.data_ptr(), info_base + 192 * k, C.byref(a), ws.data_ptr(), stream),
                          "trl_ppo_reduce_adam_net_f32")
 
+        # (graphs by key, a few of them: the stored observations alternate between the ring's tensor and its shadow, see
+        # collector/on_policy.py::_launch, so a steady run replays TWO captured sets in turn)
         use_graph = os.environ.get("TRL_NO_GRAPH") != "1"
-        graphs = self._chain_graphs if (use_graph and getattr(self, "_chain_key", None) == key) else None
-        if use_graph and graphs is None and getattr(self, "_chain_seen", None) == key:        # second visit: capture
+        cache = self._chain_graphs if isinstance(self._chain_graphs, dict) else {}
+        self._chain_graphs = cache
+        seen = self.__dict__.setdefault("_chain_seen", set())
+        graphs = cache.get(key) if use_graph else None
+        if use_graph and graphs is None and key in seen and len(cache) < 6:                    # second visit: capture
             g0, _ = _C.capture_graph(head)
             gp, _ = _C.capture_graph(lambda: chain(0))
             with torch.cuda.stream(side):
                 gv, _ = _C.capture_graph(lambda: chain(1))
-            graphs = self._chain_graphs = (g0, gp, gv)
-            self._chain_key = key
+            graphs = cache[key] = (g0, gp, gv)
         elif graphs is None:
-            self._chain_seen, self._chain_graphs = key, None             # first visit of a shape: eager (warm-up)
+            seen.add(key)                                              # first visit of a shape: eager (warm-up)
         run_head, run_p, run_v = (head, lambda: chain(0), lambda: chain(1)) if graphs is None else \
             (graphs[0].replay, graphs[1].replay, graphs[2].replay)
         only = os.environ.get("TRL_CHAIN_ONLY")                        # development aid (tools/time_chains.py): one chain alone
@@ -544,6 +552,8 @@ class _FusedPPO:
         landed_p.record(main)
         with torch.cuda.stream(side):                                  # value chain: beside it, and beside the next rollout
             side.wait_event(forked)
+            if getattr(self, "_test_value_chain_delay", 0):            # tests: hold the value chain back (device spin) so that the
+                torch.cuda._sleep(int(self._test_value_chain_delay))   # next rollout really runs beside / ahead of it
             run_v()
             self._stats2_host[1].copy_(stats2[1], non_blocking=True)
             done_v = torch.cuda.Event()

@@ -369,12 +369,16 @@ class VecOnPolicyCollector(VecCollector):
         from ..networks import nets as _nets
         _nets.settle(self.pf, env.device)
         vf_ev = _nets.pending_event(self.vf)
-        if vf_ev is not None:
-            if store:
+        if vf_ev is not None and store:
+            # ... and that chain still READS the stored observations: a rollout that rewrites the whole ring gets the
+            # shadow `obs` tensor (swapped in here, before the pointers are taken) and runs beside it; one that rewrites
+            # only part of the ring has to keep the other rows, so it waits for the chain like everybody else.
+            if n_steps == buf._max_replay_buffer_size and hasattr(buf, "_obs"):
+                buf._flip_key("obs")
                 a.value_wait_event = vf_ev.cuda_event
                 self._vf_event_keepalive = vf_ev                        # (the handle must outlive the launch)
             else:
-                pass                                                    # no value pass in this call
+                _nets.settle(self.vf, env.device)
         a.D, a.H, a.A, a.act = D, H, A, act
         a.tanh_action = int(bool(self.pf.tanh_action))
         a.env_A, a.env_B = env.env_A.data_ptr(), env.env_B.data_ptr()

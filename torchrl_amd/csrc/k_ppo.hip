@@ -791,18 +791,19 @@ __device__ __forceinline__ float fold_waves_tree(const float (*s_acc)[RED_CHUNK]
   return gval;
 }
 // one wave: a network's loss / log-prob / value statistics from the workgroups' scalar rows, every row requested at once
-// (4 x 7 loads in flight per lane: up to 256 workgroups per network in one round trip; the per-lane accumulation order is
-// the one of the strided loop)
+// (2 x 7 loads in flight per lane; the per-lane accumulation order is the one of the strided loop)
 template <bool COH = false>
-__device__ __forceinline__ void fold_scalar_stats(const double* __restrict__ base, int nrow, int net, int lane,
+__device__ __noinline__ void fold_scalar_stats(const double* __restrict__ base, int nrow, int net, int lane,
                                                   double* __restrict__ info) {
   double v[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? -INFINITY : 0.0;
-  for (int w0 = 0; w0 < nrow; w0 += 256) {
-    double o[4][7];
+  // (two rows per lane and round: 28 doubles in flight, not 56 -- the launch's register count is what lets two ranks' waiting
+  // launches share a CU; a lane still adds its rows lane, lane + 64, lane + 128, ... in that order)
+  for (int w0 = 0; w0 < nrow; w0 += 128) {
+    double o[2][7];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
       const int w = w0 + lane + 64 * q;
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
@@ -816,7 +817,7 @@ __device__ __forceinline__ void fold_scalar_stats(const double* __restrict__ bas
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? fmax(v[k], o[q][k]) : v[k] + o[q][k];
   }
@@ -833,7 +834,9 @@ __device__ __forceinline__ void fold_scalar_stats(const double* __restrict__ bas
 }
 // one wave: log_std/{mean,std,max,min} (ppo.py:82-85) and the same four for std = exp(clamped logstd) (a2c.py:95-100),
 // one action dimension per lane (raw = the lane's log_std as stored, lanes >= n_act: anything)
-__device__ __forceinline__ void fold_logstd_stats_raw(float raw, int n_act, int lane, double* __restrict__ info) {
+// (not inlined, like fold_scalar_stats: double-precision exp() and 14 doubles in flight would otherwise set the register
+// count of every launch that CAN reach them -- ppo_reduce_adam_kernel went from 85 to 156 registers that way, see there)
+__device__ __noinline__ void fold_logstd_stats_raw(float raw, int n_act, int lane, double* __restrict__ info) {
   const bool has = lane < n_act;
   const double x = has ? fmin(fmax((double)raw, -20.0), 2.0) : 0.0;
   const double e = has ? exp(x) : 0.0;
@@ -992,7 +995,11 @@ __device__ __forceinline__ void adam_element(const AdamDev& a, int e, float gr) 
 // The GRID is the launch's resident footprint while it waits (for other ranks' gradients, with env shards on several
 // ranks): blocks x 8 waves that stay on the device until every rank has delivered.  One rank per GPU: irrelevant.  Ranks
 // sharing a device (tests): it must leave room for the other ranks' gradient kernels (trl_comm_set_wait_footprint).
-__global__ __launch_bounds__(64 * RED_WAVES) void ppo_reduce_adam_kernel(const float* __restrict__ partial,
+// (at most 128 registers per wave: a block is 2 waves per SIMD, and two ranks sharing a device need TWO waiting launches'
+// blocks -- 4 waves per SIMD -- resident beside each other.  With the statistics inlined into the job loop the kernel took
+// 156 registers: the second rank's blocks found no room next to the first's, its norm rendezvous could not complete, and
+// both ranks sat out their time-outs -- round 6, caught by tests/test_bench_multirank_gpu.py)
+__global__ __launch_bounds__(64 * RED_WAVES, 4) void ppo_reduce_adam_kernel(const float* __restrict__ partial,
                                                               const double* __restrict__ scal, int n_wg, int n_pf,
                                                               int p_stride, int p_pf, int p_vf,
                                                               const float* __restrict__ logstd, int n_act,

@@ -40,6 +40,20 @@ class BaseReplayBuffer:
             self._keys.append(key)
         return getattr(self, name)
 
+    def _flip_key(self, key):
+        """Swap `_key` with its shadow tensor (allocated on the first flip): a writer that is about to rewrite EVERY row of
+        the key gets fresh storage while a reader on another stream still walks the old one (the value function's update
+        chain reads `obs` beside the next rollout, algo/on_policy/ppo.py).  Only for full-ring rewrites -- the shadow's
+        content is whatever it held two rollouts ago."""
+        name, alt = "_" + key, "_" + key + "_shadow"
+        cur = getattr(self, name)
+        other = getattr(self, alt, None)
+        if other is None or other.shape != cur.shape or other.device != cur.device:
+            other = torch.zeros_like(cur)
+        setattr(self, alt, cur)
+        setattr(self, name, other)
+        return other
+
     def _as_row(self, value):
         if isinstance(value, torch.Tensor):
             t = value
