@@ -266,7 +266,8 @@ def test_update_infos_taken_later_equal_the_ones_read_in_place(monkeypatch):
                 log.drain()                                                 # the logger asks first ...
         if deferred:                                                        # ... or the engine did, at its next run
             assert log.calls == 4 and len(log.infos) == 2 * 2 * 4 and agent.training_update_num == 4 * 2 * 4
-            assert agent.engine()._pending is not None
+            eng = agent.engine()                                            # (the last run's statistics are still pending)
+            assert getattr(eng, "_pending", None) is not None or len(getattr(eng, "_chain_pend", [])) > 0
         log.drain()
         return log.infos, pf.flat_params().cpu().clone()
     (want, pw), (got, pg) = run(False), run(True)

@@ -1,11 +1,11 @@
 #!/bin/bash
-# The end-of-round measurement set (profiles/r05z_*; r04z_* was the same script one round earlier): run on the MI355X box from the repo root, e.g.
+# The end-of-round measurement set (profiles/r06z_*; r05z_* / r04z_* were the same script one and two rounds earlier): run on the MI355X box from the repo root, e.g.
 #   gpurun --timeout 2400 -- 'bash tools/measure_round.sh'
 # Writes into gpurun_out/ (scratch); copy what is to be kept into profiles/.  Counter passes are runs of their own with no
 # tracing domain besides the kernel trace.  T = file prefix.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
-T=${T:-r05z}
+T=${T:-r06z}
 # 1. the default bench line (cpu baseline, secondary workloads, peaks)
 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.log; tail -1 $O/${T}_bench.json | cut -c1-400
 # 2. kernel trace of the same command (short: no cpu baseline / secondary)

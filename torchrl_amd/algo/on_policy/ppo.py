@@ -257,26 +257,26 @@ class _FusedPPO:
         world = dist.world_size()
         n_local = rows_mb * N
         n_global = float(n_local * world)
-        last = getattr(self, "_pending", None)
-        if last is not None:                                           # its statistics still sit in the host twin this
-            last.land()                                                # run is about to reuse: wait + snapshot (the dicts are
-            self._pending = None                                       # assembled when somebody reads them)
-        idx_dev, stats = self._buffers(K, rows_mb)
-        self._idx_host.numpy()[:] = row_idx.reshape(-1)
-        rows_total = t["advs"].shape[0]
-        raw, info = stats[:4 * K].view(K, 4), stats[4 * K:28 * K].view(K, 24)
-        norms = stats[28 * K:].view(torch.float32).view(K, 2)
         n_wg, n_wg_pf = self._n_wg(n_local)
         loss_mode = int(getattr(algo, "loss_mode", _C.LOSS_PPO_CLIP))
         probe = getattr(self, "probe", None)                           # bench.py: HIP events around the grad kernel
         fused = not dist.collectives_active()
         one_launch = fused and self.one_launch and n_wg <= self.step_max_wg
+        if fused and not one_launch and probe is None and self.two_chains and n_wg_pf >= 1 and n_wg - n_wg_pf >= 1:
+            return self._run_chains(t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global)
+        for last in [getattr(self, "_pending", None)] + list(getattr(self, "_chain_pend", [])):
+            if last is not None:                                       # its statistics still sit in the host twin this
+                last.land()                                            # run is about to reuse: wait + snapshot (the dicts are
+        self._pending, self._chain_pend = None, []                     # assembled when somebody reads them)
+        idx_dev, stats = self._buffers(K, rows_mb)
+        self._idx_host.numpy()[:] = row_idx.reshape(-1)
+        rows_total = t["advs"].shape[0]
+        raw, info = stats[:4 * K].view(K, 4), stats[4 * K:28 * K].view(K, 24)
+        norms = stats[28 * K:].view(torch.float32).view(K, 2)
         # Env shards on several ranks with the peer transport up (dist.init_comm): the gradient SUM over ranks happens
         # INSIDE the fold / clip / Adam launch (trl_ppo_reduce_adam_xrank_f32) and the statistics go through the
         # one-kernel all-reduce -- plain launches, so the sequence is graph-replayed exactly like the single-process one.
         xrank = not fused and dist.peer_ready()
-        if fused and not one_launch and probe is None and self.two_chains and n_wg_pf >= 1 and n_wg - n_wg_pf >= 1:
-            return self._run_chains(t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global)
         self._settle_value_chain()                                     # (a joint launch sequence after a two-chain one)
         if self._value_done is not None:
             from ...networks import nets as _nets
@@ -454,27 +454,47 @@ class _FusedPPO:
         if self._side is None:
             self._side = torch.cuda.Stream(dev)
         side = self._side
-        self._settle_value_chain()                                     # the previous run's value chain (normally long done)
+        # The host may be ONE run ahead of the device: this run's launches are issued while the previous run's value chain
+        # (which ends about when the rollout between the two does) may still be running -- waiting for it here would leave
+        # the device waiting for the host right after the value pass.  Everything the host writes per run therefore exists
+        # TWICE (page-locked index / learning-rate slab, which the prologue reads in place, and the statistics' host twin),
+        # used in turn; the run before the previous one has to have landed before its set is reused.
+        last = getattr(self, "_pending", None)                         # (a joint run before this one)
+        if last is not None:
+            last.land()
+            self._pending = None
+        pend = self.__dict__.setdefault("_chain_pend", [])
+        while len(pend) > (0 if os.environ.get("TRL_CHAIN_HOST_AHEAD") == "0" else 1):   # (=0: development A/B, wait for the previous run)
+            pend.pop(0).land()
+        self._settle_value_chain()                                     # device-side order (normally long satisfied: the value pass waited)
         self._sync_headers("two")
         idx_dev, _ = self._buffers(K, rows_mb)
         if getattr(self, "_stats2_key", None) != (K, rows_mb):
+            for q in pend:
+                q.land()
+            del pend[:]
             self._stats2_key = (K, rows_mb)
             self._stats2 = torch.zeros(2, 29 * K, dtype=torch.float64, device=dev)        # [policy chain | value chain]
-            self._stats2_host = torch.zeros(2, 29 * K, dtype=torch.float64).pin_memory()
-            self._chain_graphs = {}
+            self._chain_host = [(torch.zeros(K * rows_mb + 1, dtype=torch.int64).pin_memory(),
+                                 torch.zeros(2, 29 * K, dtype=torch.float64).pin_memory()) for _ in range(2)]
+            self._chain_graphs, self._chain_turn = {}, 0
         stats2 = self._stats2
-        self._idx_host.numpy()[:] = row_idx.reshape(-1)
+        turn = self._chain_turn = 1 - self._chain_turn
+        slab, stats_host = self._chain_host[turn]
+        idx_host, hyper_host = slab[:K * rows_mb], slab[K * rows_mb:].view(torch.float32)
+        idx_host.numpy()[:] = row_idx.reshape(-1)
         rows_total = t["advs"].shape[0]
         raw = stats2[0, :4 * K].view(K, 4)
         lr_pf, lr_vf = algo.pf_optimizer.param_groups[0]['lr'], algo.vf_optimizer.param_groups[0]['lr']
-        self._set_device_hyper(lr_pf, lr_vf, upload=False)
+        hyper_host[0], hyper_host[1] = float(lr_pf), float(lr_vf)
+        self._hyper = None                                             # (the joint route uploads its own copy when it runs next)
         hyper = (float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
                  int(bool(getattr(algo, "clipped_value_loss", False))), int(bool(algo.pf.tanh_action)))
         n_wg_vf = n_wg - n_wg_pf
         if getattr(self, "_chain_rows", None) is None:
             self._chain_rows = (torch.zeros(self.max_wg, self.p_stride, device=dev), torch.zeros(self.max_wg, 8, dtype=torch.float64, device=dev))
         partial_v, scal_v = self._chain_rows                           # (the policy chain uses self.partial / self.scal)
-        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None) + hyper + tuple(
+        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, turn) + hyper + tuple(
             0 if t.get(k) is None else t[k].data_ptr() for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
 
         def head():
@@ -484,8 +504,8 @@ class _FusedPPO:
             if getattr(self, "_pro_ws", None) is None or self._pro_ws_k != (K, rows_mb):
                 self._pro_ws, self._pro_ws_k = _C.ppo_epoch_prologue_workspace(K, dev), (K, rows_mb)
             copies = [(self.target_flat, self.flat[:self.P_pf])] if self._copy_in_prologue else []
-            copies += [(idx_dev, self._idx_host), (self.red_ws[2:4], self._hyper_host), (self.red_ws_v[2:4], self._hyper_host)]
-            _C.ppo_epoch_prologue(t["advs"].reshape(rows_total, N), self._idx_host.view(K, rows_mb), raw, self._pro_ws,
+            copies += [(idx_dev, idx_host), (self.red_ws[2:4], hyper_host), (self.red_ws_v[2:4], hyper_host)]
+            _C.ppo_epoch_prologue(t["advs"].reshape(rows_total, N), idx_host.view(K, rows_mb), raw, self._pro_ws,
                                   zero=stats2.view(-1)[4 * K:], copies=copies)
 
         def chain(net):
@@ -528,7 +548,7 @@ class _FusedPPO:
         self._chain_graphs = cache
         seen = self.__dict__.setdefault("_chain_seen", set())
         graphs = cache.get(key) if use_graph else None
-        if use_graph and graphs is None and key in seen and len(cache) < 6:                    # second visit: capture
+        if use_graph and graphs is None and key in seen and len(cache) < 8:                    # second visit: capture
             g0, _ = _C.capture_graph(head)
             gp, _ = _C.capture_graph(lambda: chain(0))
             with torch.cuda.stream(side):
@@ -547,7 +567,7 @@ class _FusedPPO:
         forked = torch.cuda.Event()
         forked.record(main)
         run_p()                                                        # policy chain: the current stream (the next rollout follows it)
-        self._stats2_host[0].copy_(stats2[0], non_blocking=True)
+        stats_host[0].copy_(stats2[0], non_blocking=True)
         landed_p = torch.cuda.Event()
         landed_p.record(main)
         with torch.cuda.stream(side):                                  # value chain: beside it, and beside the next rollout
@@ -555,7 +575,7 @@ class _FusedPPO:
             if getattr(self, "_test_value_chain_delay", 0):            # tests: hold the value chain back (device spin) so that the
                 torch.cuda._sleep(int(self._test_value_chain_delay))   # next rollout really runs beside / ahead of it
             run_v()
-            self._stats2_host[1].copy_(stats2[1], non_blocking=True)
+            stats_host[1].copy_(stats2[1], non_blocking=True)
             done_v = torch.cuda.Event()
             done_v.record(side)
         self._value_done = done_v
@@ -581,9 +601,9 @@ class _FusedPPO:
             norms = hp[28 * K:].view(torch.float32).view(K, 2).clone()
             norms[:, 1] = hv[28 * K:].view(torch.float32).view(K, 2)[:, 1]
             return make(hp[:4 * K].view(K, 4).numpy(), info.numpy(), norms.numpy(), n_global)
-        pending = _PendingInfos(K, _Both, self._stats2_host, build)
+        pending = _PendingInfos(K, _Both, stats_host, build)
         if defer:
-            self._pending = pending
+            pend.append(pending)
             return pending
         out = pending.resolve()
         self._settle_value_chain()                                     # a caller that reads in place gets settled parameters too
