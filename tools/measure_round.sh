@@ -13,7 +13,13 @@ B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary"
 rm -rf $O/prof_b; rocprofv3 --kernel-trace --stats -d $O/prof_b -- $B > $O/${T}_prof_bench.json 2>/dev/null
 python tools/kstats.py $(find $O/prof_b -name "*.db" | head -1) > $O/${T}_bench_kernel_stats.csv
 head -12 $O/${T}_bench_kernel_stats.csv | cut -c1-150
+# 2b. the same with the two networks in ONE launch per minibatch (TRL_PPO_CHAINS=joint): what the roofline entry times
+rm -rf $O/prof_b; TRL_PPO_CHAINS=joint rocprofv3 --kernel-trace --stats -d $O/prof_b -- $B > /dev/null 2>&1
+python tools/kstats.py $(find $O/prof_b -name "*.db" | head -1) > $O/${T}_bench_kernel_stats_joint.csv
+head -4 $O/${T}_bench_kernel_stats_joint.csv | cut -c1-150
 # 3. HBM traffic counters, separate passes; then the SQ counters of the same command (MFMA-busy of the headline kernel)
+#    -- joint launches: the counters of the 256-workgroup launch the roofline entry refers to
+export TRL_PPO_CHAINS=joint
 B3="python bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-secondary"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c; rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- $B3 > /dev/null 2>&1
@@ -24,6 +30,7 @@ CNT0="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
 rm -rf $O/pmc_ppo; rocprofv3 --pmc $CNT0 --output-format csv -d $O/pmc_ppo -- $B3 > /dev/null 2>&1
 python tools/summarize_pmc.py $(find $O/pmc_ppo -name "*counter_collection.csv") > $O/${T}_ppo_pmc_per_kernel_mean.csv
 grep -E "kernel,|ppo_grad|reduce_adam" $O/${T}_ppo_pmc_per_kernel_mean.csv | cut -c1-220
+unset TRL_PPO_CHAINS
 # 4. cfg 3 / cfg 5 tables and MFMA counters
 CNT="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS"
 for w in sac dqn qrdqn; do

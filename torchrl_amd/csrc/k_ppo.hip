@@ -791,19 +791,20 @@ __device__ __forceinline__ float fold_waves_tree(const float (*s_acc)[RED_CHUNK]
   return gval;
 }
 // one wave: a network's loss / log-prob / value statistics from the workgroups' scalar rows, every row requested at once
-// (2 x 7 loads in flight per lane; the per-lane accumulation order is the one of the strided loop)
+// (3 x 7 loads in flight per lane; the per-lane accumulation order is the one of the strided loop)
 template <bool COH = false>
 __device__ __noinline__ void fold_scalar_stats(const double* __restrict__ base, int nrow, int net, int lane,
                                                   double* __restrict__ info) {
   double v[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? -INFINITY : 0.0;
-  // (two rows per lane and round: 28 doubles in flight, not 56 -- the launch's register count is what lets two ranks' waiting
-  // launches share a CU; a lane still adds its rows lane, lane + 64, lane + 128, ... in that order)
-  for (int w0 = 0; w0 < nrow; w0 += 128) {
-    double o[2][7];
+  // (three rows per lane and round: up to 192 workgroups per network in ONE round trip with 42 doubles in flight -- the
+  // function is out of line and the launches that call it are bounded to 128 registers, see ppo_reduce_adam_kernel; a lane
+  // still adds its rows lane, lane + 64, lane + 128, ... in that order)
+  for (int w0 = 0; w0 < nrow; w0 += 192) {
+    double o[3][7];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 3; ++q) {
       const int w = w0 + lane + 64 * q;
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
@@ -817,7 +818,7 @@ __device__ __noinline__ void fold_scalar_stats(const double* __restrict__ base, 
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int k = 0; k < 7; ++k) v[k] = (k >= 2 && k <= 5) ? fmax(v[k], o[q][k]) : v[k] + o[q][k];
   }
@@ -999,6 +1000,7 @@ __device__ __forceinline__ void adam_element(const AdamDev& a, int e, float gr) 
 // blocks -- 4 waves per SIMD -- resident beside each other.  With the statistics inlined into the job loop the kernel took
 // 156 registers: the second rank's blocks found no room next to the first's, its norm rendezvous could not complete, and
 // both ranks sat out their time-outs -- round 6, caught by tests/test_bench_multirank_gpu.py)
+template <bool LOOP>                                  // false: the grid has one block per job (no job loop: the common launch)
 __global__ __launch_bounds__(64 * RED_WAVES, 4) void ppo_reduce_adam_kernel(const float* __restrict__ partial,
                                                               const double* __restrict__ scal, int n_wg, int n_pf,
                                                               int p_stride, int p_pf, int p_vf,
@@ -1030,7 +1032,7 @@ __global__ __launch_bounds__(64 * RED_WAVES, 4) void ppo_reduce_adam_kernel(cons
   // gradient exchanges (read by every block before it publishes anything, advanced by block 0 at the end)
   const unsigned xepoch = xrank ? __hip_atomic_load(xr.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
   float gval0 = 0.0f;                                             // wave 0: the (summed) gradient of this block's FIRST job
-  for (int j = blk; j < n_jobs; j += grid) {
+  for (int j = blk; j < (LOOP ? n_jobs : blk + 1); j += LOOP ? grid : 1) {
     const int net = j / nb, bx = j - net * nb;
     if (j != blk) __syncthreads();                                // the fold's LDS image is read by wave 0 of the previous job
     float gval = ppo_reduce_block(partial, scal, n_wg, n_pf, p_stride, p_pf, p_vf, logstd, n_act, grads, info, net, bx, bx == nb - 1);
@@ -1057,7 +1059,7 @@ __global__ __launch_bounds__(64 * RED_WAVES, 4) void ppo_reduce_adam_kernel(cons
     s_hyper[1] = (float)sqrt(1.0 - b2p);
     s_hyper[2] = lr0; s_hyper[3] = lr1;
   }
-  if (blk >= n_jobs) return;                                      // (a grid larger than the job list)
+  if (LOOP && blk >= n_jobs) return;                              // (a grid larger than the job list)
   // the optimiser state of this block's first job is requested now and arrives while the norm slots are polled
   const int net_ = blk / nb, pe_ = (blk - net_ * nb) * RED_CHUNK + lane;
   const bool own_ = wave == 0 && pe_ < (net_ == 0 ? p_pf : p_vf);
@@ -1110,7 +1112,7 @@ __global__ __launch_bounds__(64 * RED_WAVES, 4) void ppo_reduce_adam_kernel(cons
   // raises through trl_comm_error at its next check.
   const bool xfail = xrank && __hip_atomic_load(xr.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
   if (wave == 0 && !xfail) {                                       // adam_element, the first job on the prefetched state
-    for (int j = blk; j < n_jobs; j += grid) {
+    for (int j = blk; j < (LOOP ? n_jobs : blk + 1); j += LOOP ? grid : 1) {
       const int net = j / nb, pe = (j - net * nb) * RED_CHUNK + lane;
       if (pe >= (net == 0 ? p_pf : p_vf)) continue;
       const int ge = (net == 0 ? 0 : p_pf) + pe;
@@ -1578,10 +1580,17 @@ static int launch_reduce_adam(const float* partial, const double* scal_partial, 
   int grid = (only_net >= 0 ? 1 : 2) * trl_ceil_div(ps, RED_CHUNK);   // one block per job, unless the caller bounds the footprint
   if (max_blocks > 0 && max_blocks < grid) grid = max_blocks;
   const int n_pf = only_net == 0 ? n_wg : (only_net == 1 ? 0 : resolve_pf_wgs(n_wg, n_wg_pf));
-  hipLaunchKernelGGL(ppo_reduce_adam_kernel, dim3(grid), dim3(64 * RED_WAVES), 0, (hipStream_t)stream,
-                     partial, scal_partial, n_wg, n_pf, ps, p_pf, p_vf,
-                     (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace, (unsigned)adam->step_count,
-                     adam->device_state, xr ? 1 : 0, xr ? *xr : none, only_net);
+  const int jobs = (only_net >= 0 ? 1 : 2) * trl_ceil_div(ps, RED_CHUNK);
+  if (grid == jobs)
+    hipLaunchKernelGGL(ppo_reduce_adam_kernel<false>, dim3(grid), dim3(64 * RED_WAVES), 0, (hipStream_t)stream,
+                       partial, scal_partial, n_wg, n_pf, ps, p_pf, p_vf,
+                       (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace, (unsigned)adam->step_count,
+                       adam->device_state, xr ? 1 : 0, xr ? *xr : none, only_net);
+  else
+    hipLaunchKernelGGL(ppo_reduce_adam_kernel<true>, dim3(grid), dim3(64 * RED_WAVES), 0, (hipStream_t)stream,
+                       partial, scal_partial, n_wg, n_pf, ps, p_pf, p_vf,
+                       (const float*)(adam->params + (p_pf - A)), A, grads, info, d, workspace, (unsigned)adam->step_count,
+                       adam->device_state, xr ? 1 : 0, xr ? *xr : none, only_net);
   TRL_LAUNCH_CHECK();
   return TRL_OK;
 }
