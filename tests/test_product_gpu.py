@@ -108,6 +108,47 @@ def test_collect_gae_ppo_epoch_matches_reference(golden, tag, engine, monkeypatc
     assert type(agent.engine()).__name__ == ("_GenericPPO" if engine == "generic" else "_FusedPPO")
 
 
+def test_chain_error_growth_per_update(golden, errlog):
+    """The tightest margin of the suite is the parameter bound after the four chained updates of the `surpass` chain (0.92 of
+    1e-6).  This is the same chain taken one update at a time -- PPO.update on the batches of one_iteration, against the CPU
+    oracle stepping the same batches -- with the parameter error after EVERY update in the error log, so that a kernel
+    change which moves a summation order and trips the bound shows where the error enters."""
+    from oracle.ppo import PPOOracle
+    g = golden("collect_epoch")
+    tag = "surpass"
+    N, T, horizon, max_frames, B, seed = (int(x) for x in g[f"{tag}_args"])
+    pf, vf, env, buf, col, agent, logger = build(g, tag, N, T, horizon, max_frames, B, seed)
+    pf_p = [p.detach().cpu().clone() for p in pf._mlp2_param_list()]
+    vf_p = [p.detach().cpu().clone() for p in vf._mlp2_param_list()]
+    ls = pf.logstd.detach().cpu().clone()
+    torch.manual_seed(seed)
+    col.train_one_epoch()
+    agent.current_epoch = 1
+    agent.process_epoch_samples()
+    from torchrl.algo import utils as atu
+    atu.update_linear_schedule(agent.pf_optimizer, 1, 10, 3e-4)
+    atu.update_linear_schedule(agent.vf_optimizer, 1, 10, 3e-4)
+    atu.copy_model_params_from_to(agent.pf, agent.target_pf)
+    o = PPOOracle(pf_p, ls, vf_p, plr=3e-4, vlr=3e-4, entropy_coeff=0.005, clip_para=0.2, opt_epochs=2, num_epochs=10,
+                  batch_size=B)
+    o.pf_opt.lr = o.vf_opt.lr = 3e-4 - 3e-4 * (1 / 10.0)
+    np.random.seed(seed + 100)
+    k = 0
+    for _ in range(2):
+        for batch in buf.one_iteration(B, agent.sample_key, True):
+            agent.update(batch)
+            o.update({key: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for key, v in batch.items()})
+            k += 1
+            got = torch.cat([p.detach().reshape(-1) for p in pf._mlp2_param_list()] + [pf.logstd.detach().reshape(-1)] +
+                            [p.detach().reshape(-1) for p in vf._mlp2_param_list()]).cpu()
+            want = torch.cat([p.detach().reshape(-1) for p in o.pf] + [o.logstd.detach().reshape(-1)] +
+                             [p.detach().reshape(-1) for p in o.vf])
+            err = (got - want).abs().max().item()
+            errlog("params abs after update %d of the chain (vs the oracle stepping the same batches)" % k, err, 1e-6)
+            assert err < 1e-6, (k, err)
+    assert k == len(g[f"{tag}_infos"])
+
+
 def test_update_entry_point_and_one_iteration(golden):
     """PPO.update(batch) with batches from one_iteration (reference call pattern, on_rl_algo.py:37-40)."""
     g = golden("collect_epoch")
