@@ -385,6 +385,10 @@ def test_two_update_chains_match_the_joint_sequence(golden, monkeypatch, noise_m
             np.random.seed(seed + epoch)
             agent.update_per_epoch()
             snaps.append({k: getattr(buf, "_" + k).clone() for k in ("obs", "acts", "values", "rewards", "advs", "estimate_returns")})
+            if chains == "two" and epoch == 2:
+                # the stored observations alternate between two tensors, so a steady run replays two captured sets: the
+                # shape's first run is eager, the next two capture -- a default bench (3 warm-up iterations) times replays only
+                assert len(agent.engine()._chain_graphs) == 2
         for resolve in later:                                            # read in order, after everything was launched
             logger.infos.extend(dict(d) for d in resolve())
         eng = agent.engine()

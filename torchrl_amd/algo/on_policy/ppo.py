@@ -494,7 +494,8 @@ class _FusedPPO:
         if getattr(self, "_chain_rows", None) is None:
             self._chain_rows = (torch.zeros(self.max_wg, self.p_stride, device=dev), torch.zeros(self.max_wg, 8, dtype=torch.float64, device=dev))
         partial_v, scal_v = self._chain_rows                           # (the policy chain uses self.partial / self.scal)
-        key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, turn) + hyper + tuple(
+        shape_key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None) + hyper
+        key = shape_key + (turn,) + tuple(
             0 if t.get(k) is None else t[k].data_ptr() for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
 
         def head():
@@ -548,14 +549,16 @@ class _FusedPPO:
         self._chain_graphs = cache
         seen = self.__dict__.setdefault("_chain_seen", set())
         graphs = cache.get(key) if use_graph else None
-        if use_graph and graphs is None and key in seen and len(cache) < 8:                    # second visit: capture
+        if use_graph and graphs is None and shape_key in seen and len(cache) < 8:
+            # a shape's first run is eager (kernels load, attributes are set); every set of addresses after that is captured
+            # on its first visit -- the two sets of a steady run are both replaying from the fourth iteration on
             g0, _ = _C.capture_graph(head)
             gp, _ = _C.capture_graph(lambda: chain(0))
             with torch.cuda.stream(side):
                 gv, _ = _C.capture_graph(lambda: chain(1))
             graphs = cache[key] = (g0, gp, gv)
         elif graphs is None:
-            seen.add(key)                                              # first visit of a shape: eager (warm-up)
+            seen.add(shape_key)                                        # first visit of a shape: eager (warm-up)
         run_head, run_p, run_v = (head, lambda: chain(0), lambda: chain(1)) if graphs is None else \
             (graphs[0].replay, graphs[1].replay, graphs[2].replay)
         only = os.environ.get("TRL_CHAIN_ONLY")                        # development aid (tools/time_chains.py): one chain alone
