@@ -467,6 +467,14 @@ int trl_allreduce_f64(double* buf, int64_t n, int period, uint64_t max_mask, trl
 int trl_ppo_reduce_adam_xrank_f32(const float* partial, const double* scal_partial, int n_wg, int n_wg_pf,
                                   int D, int H, int A, float* grads, double* info,
                                   const trl_adam_t* adam, float* workspace, trl_comm_t* comm, void* stream);
+/* trl_ppo_reduce_adam_net_f32 with the gradient SUM over ranks inside: one network's half of the step for a rank that
+ * runs the critic's and the actor's updates as two launch sequences (ppo.py:93-122 / 41-91) while its env shards sit on
+ * several ranks.  Each sequence counts its own exchanges and owns its network's granules of the gradient region, so the
+ * two never meet; all ranks must run the same route (joint launches and single-network launches may alternate between
+ * runs, not within one).  A bounded wait footprint (trl_comm_set_wait_footprint) is split between the two sequences. */
+int trl_ppo_reduce_adam_xrank_net_f32(const float* partial, const double* scal_partial, int n_wg, int net,
+                                      int D, int H, int A, float* grads, double* info,
+                                      const trl_adam_t* adam, float* workspace, trl_comm_t* comm, void* stream);
 
 /* --- K10 (generic): dense layers of any shape on fp32 MFMA -----------------
  * replaces nn.Linear + activation forward/backward (torchrl/networks/base.py:30-44,

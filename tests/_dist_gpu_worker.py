@@ -122,7 +122,8 @@ def main():
              obs=buf._obs.cpu().numpy(), rewards=buf._rewards.cpu().numpy(), acts=np.stack(acts), tail=tail,
              prefetched=np.array(0 if pre is None else sum(pre.transport_counts.values()) - pre.dropped_blocks - 1),
              norm_state=env._obs_normalizer.state.cpu().numpy() if obs_norm else np.zeros(1),
-             peer=np.array(int(peer)), graph=np.array(int(getattr(agent.engine(), "_graph", None) is not None)))
+             peer=np.array(int(peer)), graph=np.array(int(getattr(agent.engine(), "_graph", None) is not None or bool(getattr(agent.engine(), "_chain_graphs", None)))),
+             chains=np.array(int(bool(getattr(agent.engine(), "_chain_graphs", None)))))
     if world > 1 or mode in ("nccl_graph", "nccl_peer"):
         import torch.distributed as td
         from torchrl_amd import dist as trl_dist

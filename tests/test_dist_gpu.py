@@ -31,7 +31,7 @@ def _run(world, tmp_path, worker="_dist_gpu_worker.py", extra=(), env=None):
     for p in procs:
         log, _ = p.communicate(timeout=600)
         assert p.returncode == 0, log[-3000:]
-    return [np.load(o) for o in outs]
+    return [dict(np.load(o)) for o in outs]                           # (materialised: a later run with the same arguments rewrites the files)
 
 
 def test_two_ranks_reproduce_one_process(tmp_path):
@@ -177,7 +177,21 @@ def test_two_ranks_over_the_peer_transport_replay_a_graph(tmp_path):
     np.testing.assert_allclose(r0["infos"], single["infos"], rtol=2e-4, atol=2e-5)
 
 
-def test_eight_ranks_over_the_peer_transport_replay_a_graph(tmp_path):
+def test_two_update_chains_across_ranks_equal_the_joint_exchange(tmp_path):
+    """Env shards on two ranks, peer transport: the critic's and the actor's updates as two launch sequences per rank --
+    each fold launch carrying its own network's gradient SUM over ranks (trl_ppo_reduce_adam_xrank_net_f32: the policy's
+    exchanges counted in ctl[4], the value function's in ctl[6], each network its own granules) -- against the joint
+    sequence (TRL_PPO_CHAINS_XRANK=0: one exchange for both networks per update).  Same folds, same rank order of the
+    sums, same Adam arithmetic: every buffer, parameter and logged statistic bit for bit, on both ranks."""
+    a0, a1 = _run(2, tmp_path, extra=("peer",), env={"TRL_PPO_CHAINS_XRANK": "1"})
+    b0, b1 = _run(2, tmp_path, extra=("peer",))                        # (ranks sharing a device: the joint exchange is the default)
+    assert int(a0["chains"]) == 1 and int(b0["chains"]) == 0 and int(b0["graph"]) == 1
+    for k in ("pf", "vf", "infos", "obs"):
+        assert np.array_equal(a0[k], b0[k]) and np.array_equal(a1[k], b1[k]), k
+
+
+@pytest.mark.parametrize("chains", ["joint", "two"])
+def test_eight_ranks_over_the_peer_transport_replay_a_graph(tmp_path, chains):
     """BASELINE cfg 4's exchange at test size, for real: 8 processes x 8 envs sharing cuda:0, eight
     hipIpc-mapped buffers of 8 slots x 2 halves, the gradient SUM over the eight slots INSIDE the fold / clip / Adam launch
     (trl_ppo_reduce_adam_xrank_f32: push granules to seven peers, poll eight slots, norm rendezvous, Adam), the statistics
@@ -187,9 +201,11 @@ def test_eight_ranks_over_the_peer_transport_replay_a_graph(tmp_path):
     one block per job on eight GPUs.  Same bar as two ranks: parameters bit-identical across the eight ranks, the
     single-process run up to the order of the gradient sum."""
     (single,) = _run(1, tmp_path)
-    ranks = _run(8, tmp_path, extra=("peer",))
+    # `two`: every rank runs the critic's and the actor's updates as two launch sequences, i.e. sixteen sequences of waiting
+    # fold launches on the one device, each network's exchange in its own granules (what one-rank-per-GPU runs do by default)
+    ranks = _run(8, tmp_path, extra=("peer",), env={"TRL_PPO_CHAINS_XRANK": "1" if chains == "two" else "0"})
     for r in ranks:
-        assert int(r["peer"]) == 1 and int(r["graph"]) == 1
+        assert int(r["peer"]) == 1 and int(r["graph"]) == 1 and int(r["chains"]) == (chains == "two")
     np.testing.assert_allclose(np.concatenate([r["obs"] for r in ranks], axis=1), single["obs"], atol=1e-6)
     for r in ranks[1:]:
         assert np.array_equal(r["pf"], ranks[0]["pf"]) and np.array_equal(r["vf"], ranks[0]["vf"])

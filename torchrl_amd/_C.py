@@ -179,6 +179,8 @@ SIGNATURES = {
                                           C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
     "trl_ppo_reduce_adam_net_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                               C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
+    "trl_ppo_reduce_adam_xrank_net_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                    C.c_void_p, C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "trl_ppo_step_workspace": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "trl_ppo_step_max_workgroups": (C.c_int, []),
     "trl_ppo_minibatch_step_f32": (C.c_int, [C.POINTER(PpoBatchArgs), C.c_void_p, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),

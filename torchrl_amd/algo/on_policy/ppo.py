@@ -262,8 +262,11 @@ class _FusedPPO:
         probe = getattr(self, "probe", None)                           # bench.py: HIP events around the grad kernel
         fused = not dist.collectives_active()
         one_launch = fused and self.one_launch and n_wg <= self.step_max_wg
-        if fused and not one_launch and probe is None and self.two_chains and n_wg_pf >= 1 and n_wg - n_wg_pf >= 1:
-            return self._run_chains(t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global)
+        # (env shards on several ranks: the two chains need the in-launch gradient exchange of the peer transport, whose
+        # granules and exchange counts are per network; over all-reduce CALLS the joint sequence stays)
+        xrank_chains = not fused and self.chains_across_ranks()
+        if (fused or xrank_chains) and not one_launch and probe is None and self.two_chains and n_wg_pf >= 1 and n_wg - n_wg_pf >= 1:
+            return self._run_chains(t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global, xrank=not fused)
         for last in [getattr(self, "_pending", None)] + list(getattr(self, "_chain_pend", [])):
             if last is not None:                                       # its statistics still sit in the host twin this
                 last.land()                                            # run is about to reuse: wait + snapshot (the dicts are
@@ -421,6 +424,17 @@ class _FusedPPO:
             return pending
         return pending.resolve()                                       # the only host wait of the update
 
+    def chains_across_ranks(self):
+        """Env shards on several ranks: do the updates run as two chains?  Needs the peer transport (the in-launch exchange
+        is per network).  Default: yes with one rank per GPU -- each device then runs what a single process runs, plus the
+        waits; no when ranks SHARE a device (tests, bench.py's device map): four or more chains and as many waiting fold
+        launches on one chip form convoys (two ranks on one MI355X: 5.9 ms per iteration against 5.5 joint, round 6).
+        TRL_PPO_CHAINS_XRANK=1 / 0 forces either."""
+        if not (self.two_chains and dist.collectives_active() and dist.peer_ready()):
+            return False
+        want = os.environ.get("TRL_PPO_CHAINS_XRANK")
+        return want == "1" if want in ("0", "1") else dist.ranks_per_device() == 1
+
     def _settle_value_chain(self):
         """The current stream waits for the value chain of the last two-chain run (a no-op when it was waited for already,
         e.g. by the value pass of a fused rollout)."""
@@ -436,7 +450,7 @@ class _FusedPPO:
                 self.red_ws_v[:8].copy_(self.red_ws[:8])
             self._hdr_owner = owner
 
-    def _run_chains(self, t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global):
+    def _run_chains(self, t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global, xrank=False):
         """K minibatch updates as TWO launch sequences (one process): after the epoch's prologue on the current stream
         (`pre`, advantage statistics, target copy, uploads) the POLICY chain -- K x {gradient launch of the policy's
         workgroups, its fold / clip / Adam} -- stays on the current stream and the VALUE chain -- the same for the value
@@ -446,7 +460,10 @@ class _FusedPPO:
         soon as the policy chain is through, on the CUs that chain frees, while the value chain (whose ten-tile
         workgroups make it the longer one) is still stepping: the rollout's 0.2 ms latency chain disappears under it.
         The value pass behind that rollout waits for the value chain's end event (trl_rollout_t.value_wait_event); every
-        other reader of the value function's parameters settles through networks.nets.settle."""
+        other reader of the value function's parameters settles through networks.nets.settle.
+        `xrank` (env shards on several ranks, peer transport): each chain's fold launch carries its network's gradient SUM
+        over ranks (trl_ppo_reduce_adam_xrank_net_f32: own exchange count, own granules); the advantage statistics are
+        reduced in the head, the logged statistics of both chains behind the value chain, on its stream."""
         import ctypes as C
         algo, dev = self.algo, self.dev
         K, rows_mb = row_idx.shape
@@ -494,7 +511,7 @@ class _FusedPPO:
         if getattr(self, "_chain_rows", None) is None:
             self._chain_rows = (torch.zeros(self.max_wg, self.p_stride, device=dev), torch.zeros(self.max_wg, 8, dtype=torch.float64, device=dev))
         partial_v, scal_v = self._chain_rows                           # (the policy chain uses self.partial / self.scal)
-        shape_key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None) + hyper
+        shape_key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, xrank) + hyper
         key = shape_key + (turn,) + tuple(
             0 if t.get(k) is None else t[k].data_ptr() for k in ("obs", "acts", "advs", "rets", "old_values", "old_logp"))
 
@@ -508,6 +525,7 @@ class _FusedPPO:
             copies += [(idx_dev, idx_host), (self.red_ws[2:4], hyper_host), (self.red_ws_v[2:4], hyper_host)]
             _C.ppo_epoch_prologue(t["advs"].reshape(rows_total, N), idx_host.view(K, rows_mb), raw, self._pro_ws,
                                   zero=stats2.view(-1)[4 * K:], copies=copies)
+            dist.reduce_adv_raw_(raw)                                  # C2 (identity in one process)
 
         def chain(net):
             lib = _C.lib()
@@ -538,6 +556,12 @@ class _FusedPPO:
                 g.adv_raw = raw.data_ptr() + 32 * k
                 a.step_count, a.norms_out = self.step_count + k + 1, norm_base + 8 * k
                 _C.check(lib.trl_ppo_minibatch_grad_f32(C.byref(g), stream), "trl_ppo_minibatch_grad_f32")
+                if xrank:                                              # the network's gradient SUM over ranks inside the launch
+                    _C.check(lib.trl_ppo_reduce_adam_xrank_net_f32(part.data_ptr(), scal.data_ptr(), g.n_wg, net, self.D, self.H,
+                                                                   self.A, self.grads.data_ptr(), info_base + 192 * k, C.byref(a),
+                                                                   ws.data_ptr(), dist.comm_handle(), stream),
+                             "trl_ppo_reduce_adam_xrank_net_f32")
+                    continue
                 _C.check(lib.trl_ppo_reduce_adam_net_f32(part.data_ptr(), scal.data_ptr(), g.n_wg, net, self.D, self.H, self.A,
                                                          self.grads.data_ptr(), info_base + 192 * k, C.byref(a), ws.data_ptr(), stream),
                          "trl_ppo_reduce_adam_net_f32")
@@ -570,7 +594,8 @@ class _FusedPPO:
         forked = torch.cuda.Event()
         forked.record(main)
         run_p()                                                        # policy chain: the current stream (the next rollout follows it)
-        stats_host[0].copy_(stats2[0], non_blocking=True)
+        if not xrank:
+            stats_host[0].copy_(stats2[0], non_blocking=True)
         landed_p = torch.cuda.Event()
         landed_p.record(main)
         with torch.cuda.stream(side):                                  # value chain: beside it, and beside the next rollout
@@ -578,6 +603,14 @@ class _FusedPPO:
             if getattr(self, "_test_value_chain_delay", 0):            # tests: hold the value chain back (device spin) so that the
                 torch.cuda._sleep(int(self._test_value_chain_delay))   # next rollout really runs beside / ahead of it
             run_v()
+            if xrank:
+                # C3 for both chains' statistics, here: the current stream goes on to the rollout without another
+                # collective, and the next one it issues (the next head's C2) comes after its value pass has waited for
+                # this stream -- every rank issues the small all-reduces in the same order
+                side.wait_event(landed_p)
+                for st_ in (stats2[0], stats2[1]):
+                    dist.reduce_info_(st_[4 * K:28 * K].view(K, 24))
+                stats_host[0].copy_(stats2[0], non_blocking=True)
             stats_host[1].copy_(stats2[1], non_blocking=True)
             done_v = torch.cuda.Event()
             done_v.record(side)
@@ -596,6 +629,8 @@ class _FusedPPO:
                 done_v.synchronize()
 
         def build(host):
+            if xrank:
+                dist.check_comm()                                      # a rank that never delivered: raise, do not hang
             hp, hv = host[0], host[1]
             info = hp[4 * K:28 * K].view(K, 24).clone()
             iv = hv[4 * K:28 * K].view(K, 24)

@@ -271,9 +271,13 @@ __global__ __launch_bounds__(256) void xr_allreduce_kernel(T* __restrict__ buf, 
 
 // Mid-size float vectors (up to TRL_XR_CAP_GRAD: the PPO gradient and anything like it) through the GRADIENT region, with
 // the same epoch counter (ctl[4]) and slot arithmetic as the exchange inside trl_ppo_reduce_adam_xrank_f32 -- which this
-// kernel therefore also exercises in the communicator's self-check.  ctl[5] is its block ticket.
+// kernel therefore also exercises in the communicator's self-check.  ctl[5] is its block ticket.  (ctl[6]: the count of
+// the value function's exchanges when a rank runs two update chains, k_ppo.hip; a launch that touches every granule, like
+// this one, takes the larger count and leaves both at its epoch)
 __global__ __launch_bounds__(256) void xr_allreduce_grad_kernel(float* __restrict__ buf, int n, XrArgs x) {
-  const unsigned epoch = __hip_atomic_load(x.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const unsigned e4 = __hip_atomic_load(x.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned e6 = __hip_atomic_load(x.ctl + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned epoch = (e4 > e6 ? e4 : e6) + 1u;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool act = i < n;
   const float v = xr_allsum_f32(x, epoch, act ? i : 0, act ? buf[i] : 0.0f, act);
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(256) void xr_allreduce_grad_kernel(float* __restric
     const unsigned before = __hip_atomic_fetch_add(x.ctl + 5, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (before == gridDim.x - 1) {
       __hip_atomic_store(x.ctl + 5, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(x.ctl + 6, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(x.ctl + 4, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

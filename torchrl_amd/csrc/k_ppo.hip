@@ -1030,7 +1030,16 @@ __global__ __launch_bounds__(64 * RED_WAVES, 4) void ppo_reduce_adam_kernel(cons
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(ws + 16);    // [2 nets][nb] {ss bits, epoch}
   // env shards on several ranks: the epoch of the cross-rank exchange is the communicator's own count of completed
   // gradient exchanges (read by every block before it publishes anything, advanced by block 0 at the end)
-  const unsigned xepoch = xrank ? __hip_atomic_load(xr.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
+  // (two counts, ctl[4] and ctl[6]: a single-network launch of the value function -- the second of two concurrent update
+  // chains -- counts its exchanges in ctl[6] and touches only the value function's granules, one of the policy in ctl[4];
+  // a joint launch, which touches all granules, takes the larger of the two and leaves both at its epoch: a granule's stamps
+  // only ever grow, whichever route wrote them last)
+  unsigned xepoch = 0u;
+  if (xrank) {
+    const unsigned e4 = __hip_atomic_load(xr.ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned e6 = __hip_atomic_load(xr.ctl + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xepoch = (only_net == 0 ? e4 : only_net == 1 ? e6 : (e4 > e6 ? e4 : e6)) + 1u;
+  }
   float gval0 = 0.0f;                                             // wave 0: the (summed) gradient of this block's FIRST job
   for (int j = blk; j < (LOOP ? n_jobs : blk + 1); j += LOOP ? grid : 1) {
     const int net = j / nb, bx = j - net * nb;
@@ -1105,8 +1114,10 @@ __global__ __launch_bounds__(64 * RED_WAVES, 4) void ppo_reduce_adam_kernel(cons
     }
   }
   // (every block has passed its exchanges by the time block 0 has seen all norm slots)
-  if (xrank && blk == job0 && tid == 0)
-    __hip_atomic_store(xr.ctl + 4, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (xrank && blk == job0 && tid == 0) {
+    if (only_net != 1) __hip_atomic_store(xr.ctl + 4, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (only_net != 0) __hip_atomic_store(xr.ctl + 6, xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // A cross-rank wait that timed out left a PARTIAL gradient sum: no parameter is written then (every block has finished
   // its exchanges before any block sees all norm slots, so the flag is final here and all blocks decide alike); the host
   // raises through trl_comm_error at its next check.
@@ -1623,6 +1634,20 @@ extern "C" int trl_ppo_reduce_adam_xrank_f32(const float* partial, const double*
   if (!xr) { trl_set_error("trl_ppo_reduce_adam_xrank_f32: communicator without mapped peers"); return TRL_EINVAL; }
   return launch_reduce_adam(partial, scal_partial, n_wg, n_wg_pf, D, H, A, grads, info, adam, workspace, xr,
                             trl_comm_wait_blocks(comm), stream);
+}
+
+// One network's half with the cross-rank SUM inside: the two update chains of a rank whose env shards sit on several
+// ranks.  Each chain counts its own exchanges (ctl[4] / ctl[6] of the communicator) and owns its network's granules of the
+// gradient region, so the two sequences of waiting launches never meet; a bounded wait footprint is shared between them.
+extern "C" int trl_ppo_reduce_adam_xrank_net_f32(const float* partial, const double* scal_partial, int n_wg, int net,
+                                                 int D, int H, int A, float* grads, double* info, const trl_adam_t* adam,
+                                                 float* workspace, trl_comm_t* comm, void* stream) {
+  TRL_REQUIRE(net == 0 || net == 1, "net: 0 = policy, 1 = value function");
+  const XrArgs* xr = trl_comm_xr(comm);
+  if (!xr) { trl_set_error("trl_ppo_reduce_adam_xrank_net_f32: communicator without mapped peers"); return TRL_EINVAL; }
+  const int wb = trl_comm_wait_blocks(comm);
+  return launch_reduce_adam(partial, scal_partial, n_wg, 0, D, H, A, grads, info, adam, workspace, xr,
+                            wb > 0 ? (wb + 1) / 2 : 0, stream, net);
 }
 
 // The whole minibatch step as ONE launch (single process): trl_ppo_minibatch_grad_f32 + trl_ppo_reduce_adam_f32, bit for bit.

@@ -188,6 +188,11 @@ def init_comm(device=None, use_rccl=None, peers=True, allow_shared_device=False)
     return peer_ready()
 
 
+def ranks_per_device():
+    """How many ranks share the most crowded physical device (1 on a one-process-per-GPU node; tests put several on one)."""
+    return int(_peer_report.get("ranks_per_device", 1))
+
+
 def peer_report():
     """What init_comm established about the peer transport (for bench.py's `config`)."""
     return dict(_peer_report)
