@@ -448,6 +448,9 @@ int trl_comm_peer_buffer_kind(const trl_comm_t* comm);
 int trl_comm_peer_enable(trl_comm_t* comm, int on);   /* 0 after a failed self-check: everything takes the RCCL route */
 int trl_comm_has_rccl(const trl_comm_t* comm);
 int trl_comm_error(trl_comm_t* comm);
+/* trl_comm_error without waiting for the device (a 4-byte read on a stream of the communicator's own): for a once-per-
+ * iteration check by a host that runs ahead of the device; a time-out raised by work still in flight is seen by the next call. */
+int trl_comm_error_peek(trl_comm_t* comm);
 /* what the first timed-out peer wait was waiting for: out[4] = {region (1 gradient, 2 statistics; 0 none), slot = the rank
  * whose contribution was missing, epoch waited for, epoch tag found}; clears the record (diagnostics of a failed run). */
 int trl_comm_error_detail(trl_comm_t* comm, int32_t* out);

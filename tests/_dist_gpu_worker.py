@@ -50,7 +50,7 @@ def main():
         else:
             td.init_process_group("gloo", rank=rank, world_size=world)
     peer = False
-    if mode in ("peer", "nccl_peer", "nccl_graph"):
+    if mode in ("peer", "nccl_peer", "nccl_graph", "peer_timeout"):
         # the library's own communicator (include/trl_hip.h: trl_comm_*): peer-mapped buffers between the two processes
         # sharing cuda:0 (no RCCL communicator: it refuses two ranks per device), or RCCL + peers on a one-rank group
         if mode == "nccl_peer":
@@ -65,6 +65,30 @@ def main():
             if os.environ.get("TRL_TEST_WAIT_BLOCKS"):               # the fold launch's resident footprint, overridden
                 assert _lib().trl_comm_set_wait_footprint(trl_dist.comm_handle(), int(os.environ["TRL_TEST_WAIT_BLOCKS"])) == 0
             assert bool(_lib().trl_comm_has_rccl(trl_dist.comm_handle())) == (mode == "nccl_peer")
+    if mode == "peer_timeout":
+        # rank 0 starts an exchange that rank 1 never joins (TRL_COMM_TIMEOUT_S = 1 from the test): the wait must give up, the
+        # flag must be readable WITHOUT idling the device (check_comm(peek=True), what the training loop calls once per
+        # iteration) and name the missing rank; the flag is cleared by the read
+        from torchrl_amd import _C as trl_C
+        import torch.distributed as td
+        raised, text, again = 0, "", 0
+        if rank == 0:
+            x = torch.ones(8, device="cuda:0")
+            trl_dist.all_reduce_sum_(x)
+            torch.cuda.synchronize()
+            try:
+                trl_dist.check_comm(peek=True)
+            except trl_C.TrlError as exc:
+                raised, text = 1, str(exc)
+            try:
+                trl_dist.check_comm()
+            except trl_C.TrlError:
+                again = 1
+        np.savez(out, raised=np.array(raised), text=np.array(text), again=np.array(again))
+        td.barrier()
+        trl_dist.destroy_comm()
+        td.destroy_process_group()
+        return
     import torchrl.networks as networks
     import torchrl.policies as policies
     from torchrl.algo import A2C, PPO, TRPO, VMPO

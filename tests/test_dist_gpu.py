@@ -190,6 +190,15 @@ def test_two_update_chains_across_ranks_equal_the_joint_exchange(tmp_path):
         assert np.array_equal(a0[k], b0[k]) and np.array_equal(a1[k], b1[k]), k
 
 
+def test_a_missing_rank_trips_the_flag_and_the_check_does_not_idle_the_device(tmp_path):
+    """A peer wait that nobody answers gives up after TRL_COMM_TIMEOUT_S instead of hanging the GPU, records whose granules
+    were missing, and `dist.check_comm(peek=True)` -- the once-per-iteration check of the update loop, a 4-byte read on a
+    stream of the communicator's own (trl_comm_error_peek) -- raises with that detail and clears the flag."""
+    r0, _ = _run(2, tmp_path, extra=("peer_timeout",), env={"TRL_COMM_TIMEOUT_S": "1"})
+    assert int(r0["raised"]) == 1 and int(r0["again"]) == 0, r0
+    assert "rank 0 waited for rank 1's" in str(r0["text"]) and "granules of exchange" in str(r0["text"]), str(r0["text"])
+
+
 @pytest.mark.parametrize("chains", ["joint", "two"])
 def test_eight_ranks_over_the_peer_transport_replay_a_graph(tmp_path, chains):
     """BASELINE cfg 4's exchange at test size, for real: 8 processes x 8 envs sharing cuda:0, eight

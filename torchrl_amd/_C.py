@@ -156,6 +156,7 @@ SIGNATURES = {
     "trl_comm_peer_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "trl_comm_has_rccl": (C.c_int, [C.c_void_p]),
     "trl_comm_error": (C.c_int, [C.c_void_p]),
+    "trl_comm_error_peek": (C.c_int, [C.c_void_p]),
     "trl_comm_error_detail": (C.c_int, [C.c_void_p, C.c_void_p]),
     "trl_comm_link_info": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "trl_comm_set_wait_footprint": (C.c_int, [C.c_void_p, C.c_int]),

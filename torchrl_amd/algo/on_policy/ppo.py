@@ -411,7 +411,7 @@ class _FusedPPO:
 
         def build(host):
             if xrank:
-                dist.check_comm()                                      # a rank that never delivered: raise, do not hang
+                dist.check_comm(peek=True)                             # a rank that never delivered: raise, do not hang
             if one_launch and host[4 * K:28 * K].view(K, 24)[:, 23].any():
                 raise _C.TrlError("trl_ppo_minibatch_step_f32: the in-launch rendezvous of a minibatch step timed out (its "
                                   "workgroups were not resident together -- is another process using this GPU?); the "
@@ -630,7 +630,7 @@ class _FusedPPO:
 
         def build(host):
             if xrank:
-                dist.check_comm()                                      # a rank that never delivered: raise, do not hang
+                dist.check_comm(peek=True)                             # a rank that never delivered: raise, do not hang
             hp, hv = host[0], host[1]
             info = hp[4 * K:28 * K].view(K, 24).clone()
             iv = hv[4 * K:28 * K].view(K, 24)

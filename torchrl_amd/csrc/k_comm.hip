@@ -55,6 +55,7 @@ struct trl_comm {
   int peers_ready;
   int wait_blocks;                                 // resident footprint of a launch that waits for other ranks (0: the kernel's own grid)
   int uncached;                                    // the peer buffer is hipDeviceMallocUncached memory (0: plain hipMalloc fallback)
+  hipStream_t peek;                                // trl_comm_error_peek: a non-blocking stream of its own (created on first use)
 };
 
 #define HIP_TRY(expr)                                                                         \
@@ -172,6 +173,22 @@ extern "C" int trl_comm_error(trl_comm_t* c) {
   return v ? 1 : 0;
 }
 
+// The same flag WITHOUT waiting for the device: a 4-byte read on a stream of the communicator's own that does not synchronise
+// with the caller's streams.  For the once-per-iteration check of a training loop whose host runs ahead of the device (the
+// kernels of the update being checked have completed -- the caller waited for their statistics -- while the next update's
+// are running): trl_comm_error there stalls the host until the device is idle, once per iteration, and the next rollout is
+// then launched onto an idle device (round 6: the reason multi-rank runs staged their exploration-noise blocks instead of
+// carrying them).  A time-out raised by work still in flight is seen by the next call.
+extern "C" int trl_comm_error_peek(trl_comm_t* c) {
+  if (!c || !c->xr.ctl) return 0;
+  if (!c->peek && hipStreamCreateWithFlags(&c->peek, hipStreamNonBlocking) != hipSuccess) { c->peek = nullptr; return trl_comm_error(c); }
+  unsigned v = 0;
+  if (hipMemcpyAsync(&v, c->xr.ctl + 2, sizeof(v), hipMemcpyDeviceToHost, c->peek) != hipSuccess) return 1;
+  if (hipStreamSynchronize(c->peek) != hipSuccess) return 1;
+  if (v) { (void)hipMemsetAsync(c->xr.ctl + 2, 0, sizeof(v), c->peek); (void)hipStreamSynchronize(c->peek); }
+  return v ? 1 : 0;
+}
+
 // What the first timed-out wait since the last call was waiting for: out[0] = region (1 gradient, 2 statistics; 0 = no
 // time-out recorded), out[1] = slot = the rank whose granules were missing, out[2] = epoch waited for, out[3] = epoch tag
 // found in the granule.  Clears the record; synchronises the device.
@@ -212,6 +229,7 @@ extern "C" int trl_comm_destroy(trl_comm_t* c) {
     if (c->opened[r]) (void)hipIpcCloseMemHandle(c->opened[r]);
   if (c->local) (void)hipFree(c->local);
   if (c->xr.ctl) (void)hipFree(c->xr.ctl);
+  if (c->peek) (void)hipStreamDestroy(c->peek);
   if (c->rccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->rccl);
   delete c;
   return TRL_OK;

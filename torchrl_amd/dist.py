@@ -285,11 +285,13 @@ def destroy_comm():
     _comm, _peer_ok, _has_rccl = None, False, False
 
 
-def check_comm():
-    """Raise if a peer wait timed out since the last check (a rank went missing); one small synchronous read."""
+def check_comm(peek=False):
+    """Raise if a peer wait timed out since the last check (a rank went missing); one small synchronous read -- which waits
+    for the device to go idle.  `peek=True` reads the flag on a stream of the communicator's own instead, without that wait
+    (the per-iteration check of an update whose statistics the caller has already waited for)."""
     if _comm is not None and _peer_ok:
         from . import _C
-        if _C.lib().trl_comm_error(_comm) != 0:
+        if (_C.lib().trl_comm_error_peek(_comm) if peek else _C.lib().trl_comm_error(_comm)) != 0:
             raise _C.TrlError("cross-rank exchange timed out: a rank did not deliver its contribution (%s)"
                               % (comm_error_detail() or "no detail recorded"))
 
