@@ -165,6 +165,8 @@ class _FusedPPO:
         self.red_ws_v = torch.zeros(n_ws, device=self.dev)            # the value chain's own Adam header + norm granules
         self.red_ws_v[4:8].view(torch.float64).fill_(1.0)
         self._side, self._value_done, self._hdr_owner, self._chain_graphs = None, None, "joint", {}
+        self._pending, self._chain_pend, self._chain_seen = None, [], set()         # deferred statistics; shapes already run eagerly
+        self._stats2_key = self._chain_rows = self._pro_ws = None                    # (allocated by the first run of a shape)
         self.red_ws[4:8].view(torch.float64).fill_(1.0)               # beta1^0, beta2^0 (device-side Adam state)
 
     def _alias_optimizer_state(self, opt, plist, offset):
@@ -267,7 +269,7 @@ class _FusedPPO:
         xrank_chains = not fused and self.chains_across_ranks()
         if (fused or xrank_chains) and not one_launch and probe is None and self.two_chains and n_wg_pf >= 1 and n_wg - n_wg_pf >= 1:
             return self._run_chains(t, row_idx, N, pre, pre_key, defer, n_wg, n_wg_pf, loss_mode, n_global, xrank=not fused)
-        for last in [getattr(self, "_pending", None)] + list(getattr(self, "_chain_pend", [])):
+        for last in [self._pending] + list(self._chain_pend):
             if last is not None:                                       # its statistics still sit in the host twin this
                 last.land()                                            # run is about to reuse: wait + snapshot (the dicts are
         self._pending, self._chain_pend = None, []                     # assembled when somebody reads them)
@@ -338,7 +340,7 @@ class _FusedPPO:
                 pre()
             stream = _C.stream_ptr(dev)
             # advantage statistics of all K minibatches; the statistics block cleared and target_pf <- pf in the same launch
-            if getattr(self, "_pro_ws", None) is None or self._pro_ws_k != (K, rows_mb):   # (its counters assume one slicing)
+            if self._pro_ws is None or self._pro_ws_k != (K, rows_mb):   # (its counters assume one slicing)
                 self._pro_ws, self._pro_ws_k = _C.ppo_epoch_prologue_workspace(K, dev), (K, rows_mb)
             copies = [(self.target_flat, self.flat[:self.P_pf])] if self._copy_in_prologue else []
             if in_place:
@@ -476,17 +478,17 @@ class _FusedPPO:
         # the device waiting for the host right after the value pass.  Everything the host writes per run therefore exists
         # TWICE (page-locked index / learning-rate slab, which the prologue reads in place, and the statistics' host twin),
         # used in turn; the run before the previous one has to have landed before its set is reused.
-        last = getattr(self, "_pending", None)                         # (a joint run before this one)
+        last = self._pending                                           # (a joint run before this one)
         if last is not None:
             last.land()
             self._pending = None
-        pend = self.__dict__.setdefault("_chain_pend", [])
+        pend = self._chain_pend
         while len(pend) > (0 if os.environ.get("TRL_CHAIN_HOST_AHEAD") == "0" else 1):   # (=0: development A/B, wait for the previous run)
             pend.pop(0).land()
         self._settle_value_chain()                                     # device-side order (normally long satisfied: the value pass waited)
         self._sync_headers("two")
         idx_dev, _ = self._buffers(K, rows_mb)
-        if getattr(self, "_stats2_key", None) != (K, rows_mb):
+        if self._stats2_key != (K, rows_mb):
             for q in pend:
                 q.land()
             del pend[:]
@@ -508,7 +510,7 @@ class _FusedPPO:
         hyper = (float(getattr(algo, "clip_para", 0.0)), float(algo.entropy_coeff),
                  int(bool(getattr(algo, "clipped_value_loss", False))), int(bool(algo.pf.tanh_action)))
         n_wg_vf = n_wg - n_wg_pf
-        if getattr(self, "_chain_rows", None) is None:
+        if self._chain_rows is None:
             self._chain_rows = (torch.zeros(self.max_wg, self.p_stride, device=dev), torch.zeros(self.max_wg, 8, dtype=torch.float64, device=dev))
         partial_v, scal_v = self._chain_rows                           # (the policy chain uses self.partial / self.scal)
         shape_key = (n_wg, n_wg_pf, loss_mode, n_global, rows_total, N, pre_key, pre is not None, xrank) + hyper
@@ -519,7 +521,7 @@ class _FusedPPO:
             self._copy_in_prologue = False
             if pre is not None:
                 pre()
-            if getattr(self, "_pro_ws", None) is None or self._pro_ws_k != (K, rows_mb):
+            if self._pro_ws is None or self._pro_ws_k != (K, rows_mb):
                 self._pro_ws, self._pro_ws_k = _C.ppo_epoch_prologue_workspace(K, dev), (K, rows_mb)
             copies = [(self.target_flat, self.flat[:self.P_pf])] if self._copy_in_prologue else []
             copies += [(idx_dev, idx_host), (self.red_ws[2:4], hyper_host), (self.red_ws_v[2:4], hyper_host)]
@@ -571,7 +573,7 @@ class _FusedPPO:
         use_graph = os.environ.get("TRL_NO_GRAPH") != "1"
         cache = self._chain_graphs if isinstance(self._chain_graphs, dict) else {}
         self._chain_graphs = cache
-        seen = self.__dict__.setdefault("_chain_seen", set())
+        seen = self._chain_seen
         graphs = cache.get(key) if use_graph else None
         if use_graph and graphs is None and shape_key in seen and len(cache) < 8:
             # a shape's first run is eager (kernels load, attributes are set); every set of addresses after that is captured
