@@ -129,6 +129,8 @@ def main():
         agent = TRPO(max_kl=0.01, cg_damping=1e-2, v_opt_times=2, cg_iters=10, residual_tol=1e-10, **common)
     else:
         agent = PPO(clip_para=0.2, opt_epochs=2, **common)
+    if os.environ.get("TRL_TEST_VALUE_CHAIN_DELAY"):                   # hold every value chain back (device spin): the next
+        agent.engine()._test_value_chain_delay = int(os.environ["TRL_TEST_VALUE_CHAIN_DELAY"])   # rollout runs beside / ahead of it
     torch.manual_seed(21)                  # the exploration-noise stream of the host modes (the CPU generator)
     acts = []
     for epoch in range(EPOCHS):

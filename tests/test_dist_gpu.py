@@ -190,6 +190,22 @@ def test_two_update_chains_across_ranks_equal_the_joint_exchange(tmp_path):
         assert np.array_equal(a0[k], b0[k]) and np.array_equal(a1[k], b1[k]), k
 
 
+def test_two_update_chains_across_ranks_at_full_size(tmp_path):
+    """The same at the headline's per-rank sizes -- two ranks x 2048 envs x 128 steps, minibatches of 65 536 samples per
+    rank, i.e. full-chip gradient grids split 152 + 104, four epochs (eager, two captures, a replay) -- where the next
+    rollout really runs beside the value chain: it writes the shadow `obs` tensor, its value pass waits for the value
+    chain's end event behind the cross-rank reduction of the statistics.  Rollout buffers of the last epoch (the rewards
+    carry the bootstrap values of the value function), parameters and statistics: bit for bit those of the joint exchange."""
+    sizes = {"TRL_TEST_SIZES": "4096,128,32,4"}
+    # (every value chain held back by ~2 ms of device spin, as in test_two_update_chains_match_the_joint_sequence: the rollout
+    # behind the policy chain is through before the value chain has read the previous rollout's observations)
+    a0, a1 = _run(2, tmp_path, extra=("peer",), env=dict(sizes, TRL_PPO_CHAINS_XRANK="1", TRL_TEST_VALUE_CHAIN_DELAY="5000000"))
+    b0, b1 = _run(2, tmp_path, extra=("peer",), env=dict(sizes, TRL_PPO_CHAINS_XRANK="0"))
+    assert a0["obs"].shape == (128, 2048, 17) and int(a0["chains"]) == 1 and int(b0["chains"]) == 0
+    for k in ("pf", "vf", "infos", "obs", "rewards", "acts"):
+        assert np.array_equal(a0[k], b0[k]) and np.array_equal(a1[k], b1[k]), k
+
+
 def test_a_missing_rank_trips_the_flag_and_the_check_does_not_idle_the_device(tmp_path):
     """A peer wait that nobody answers gives up after TRL_COMM_TIMEOUT_S instead of hanging the GPU, records whose granules
     were missing, and `dist.check_comm(peek=True)` -- the once-per-iteration check of the update loop, a 4-byte read on a
