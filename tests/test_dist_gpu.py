@@ -52,7 +52,8 @@ def test_two_ranks_reproduce_one_process(tmp_path):
 
 def test_eight_ranks_reproduce_one_process(tmp_path):
     """BASELINE cfg 4's partition at test size: 8 ranks x 8 envs against one process x 64 envs, all on cuda:0 over gloo
-    (eight ranks on one device cannot wait for each other inside kernels: torchrl_amd.dist.MAX_PEER_RANKS_PER_DEVICE).
+    (the host-staged all-reduce route; the same eight ranks over the peer transport:
+    test_eight_ranks_over_the_peer_transport_replay_a_graph).
     Device noise keyed by the global env index, then the reference's CPU noise stream with every rank drawing only its
     rows of each step's (64, 6) tensor one rollout ahead (world-8 offsets through the real collector)."""
     (single,) = _run(1, tmp_path)
