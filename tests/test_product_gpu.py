@@ -394,8 +394,10 @@ def test_two_update_chains_match_the_joint_sequence(golden, monkeypatch, noise_m
         eng = agent.engine()
         assert eng.two_chains == (chains == "two")
         assert bool(getattr(eng, "_chain_graphs", None)) == (chains == "two")       # (captured launch sequences were replayed)
+        saved = {k: v.cpu() for k, v in vf.state_dict().items()}         # so does whoever saves it (Net.state_dict)
         v_now = vf(torch.zeros(3, 17, device="cuda:0"))                  # a reader of the value function settles first
         torch.cuda.synchronize()
+        assert all(torch.equal(saved[k], v.cpu()) for k, v in vf.state_dict().items())
         assert int(eng.red_ws[:2].view(torch.int32)[1].item()) == eng.step_count == len(logger.infos)
         if chains == "two":
             assert int(eng.red_ws_v[:2].view(torch.int32)[1].item()) == eng.step_count

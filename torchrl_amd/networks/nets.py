@@ -112,6 +112,20 @@ class Net(nn.Module):
     def _extra_flat_params(self):
         return []
 
+    # (whoever saves or loads the parameters reads / writes them on the current stream: settle first, like `forward`)
+    def _settle_params(self):
+        if _PENDING and self in _PENDING:
+            p = next(self.parameters(), None)
+            settle(self, p.device if p is not None and p.is_cuda else None)
+
+    def state_dict(self, *args, **kwargs):
+        self._settle_params()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._settle_params()
+        return super().load_state_dict(*args, **kwargs)
+
     def forward(self, x):
         spec = self.mlp2_spec()
         needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
