@@ -22,14 +22,16 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run(world, tmp_path, worker="_dist_gpu_worker.py", extra=(), env=None):
+def _run(world, tmp_path, worker="_dist_gpu_worker.py", extra=(), env=None, _attempt=0):
     port = _free_port()
     outs = [str(tmp_path / ("%s_w%d_r%d%s.npz" % (worker[:-3], world, r, "_".join(extra)))) for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, worker), str(r), str(world), port, outs[r], *extra],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                               env=None if env is None else dict(os.environ, **env)) for r in range(world)]
-    for p in procs:
-        log, _ = p.communicate(timeout=600)
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    if _attempt == 0 and any(p.returncode != 0 for p in procs) and any("EADDRINUSE" in l or "address already in use" in l for l in logs):
+        return _run(world, tmp_path, worker, extra, env, _attempt=1)   # (the port was free when picked, not reserved: once more)
+    for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
     return [dict(np.load(o)) for o in outs]                           # (materialised: a later run with the same arguments rewrites the files)
 
